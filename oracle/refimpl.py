@@ -1,0 +1,584 @@
+"""CPU ORACLE -- test infrastructure, NOT the product.
+
+A numpy/C restatement of the reference scoring hot path (searcharray v0.0.73),
+used only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+searcharray_amd/ never imports this package.
+
+Layering mirrors the reference: the loops the reference wrote in Cython are in
+oracle/snp_ops.c (called through ctypes below); the parts the reference wrote
+in numpy (roaringish codec, bigram matcher, phrase planner, BM25 glue) are
+restated here in numpy.  Each function cites the reference file:line it
+follows (paths relative to the reference checkout).
+
+Parity status: PINNED.  tests/test_oracle_golden.py checks this module against
+(a) the known answers in the reference's own tests (test/test_similarity.py,
+test/test_search.py, test/test_phrase_matches.py, test/test_snp_ops.py,
+test/test_minmax_posns.py) and (b) outputs of the reference itself, captured by
+tests/golden/make_golden.py into tests/golden/*.npz.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+
+u64p = ctypes.POINTER(ctypes.c_uint64)
+f32p = ctypes.POINTER(ctypes.c_float)
+c_long = ctypes.c_long
+c_u64 = ctypes.c_uint64
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/*.c with gcc (make).  Returns the .so path."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.oracle_bm25_score.argtypes = [f32p, f32p, ctypes.c_float, ctypes.c_float,
+                                           ctypes.c_float, ctypes.c_float, c_long]
+        _lib.oracle_bm25_score.restype = None
+        _lib.oracle_as_dense.argtypes = [u64p, f32p, c_long, f32p, c_long]
+        _lib.oracle_as_dense.restype = None
+        _lib.oracle_popcount64_reduce.argtypes = [u64p, c_long, c_u64, c_u64, u64p, f32p]
+        _lib.oracle_popcount64_reduce.restype = c_long
+        _lib.oracle_unique.argtypes = [u64p, c_long, c_u64, u64p]
+        _lib.oracle_unique.restype = c_long
+        _lib.oracle_intersect_drop.argtypes = [u64p, c_long, u64p, c_long, c_u64, u64p, u64p]
+        _lib.oracle_intersect_drop.restype = c_long
+        _lib.oracle_intersect_keep.argtypes = [u64p, c_long, u64p, c_long, c_u64, u64p, u64p,
+                                               ctypes.POINTER(c_long), ctypes.POINTER(c_long)]
+        _lib.oracle_intersect_keep.restype = None
+        _lib.oracle_adjacent.argtypes = [u64p, c_long, u64p, c_long, c_u64, u64p, u64p]
+        _lib.oracle_adjacent.restype = c_long
+        _lib.oracle_intersect_with_adjacents.argtypes = [u64p, c_long, u64p, c_long, c_u64,
+                                                         u64p, u64p, u64p, u64p,
+                                                         ctypes.POINTER(c_long)]
+        _lib.oracle_intersect_with_adjacents.restype = c_long
+        _lib.oracle_merge.argtypes = [u64p, c_long, u64p, c_long, ctypes.c_int, u64p]
+        _lib.oracle_merge.restype = c_long
+        _lib.oracle_sort_merge_counts.argtypes = [u64p, f32p, c_long, u64p, f32p, c_long, u64p, f32p]
+        _lib.oracle_sort_merge_counts.restype = c_long
+        _lib.oracle_popcount64.argtypes = [u64p, c_long, u64p]
+        _lib.oracle_popcount64.restype = None
+        _lib.oracle_popcount_reduce_at.argtypes = [u64p, u64p, c_long, u64p, f32p]
+        _lib.oracle_popcount_reduce_at.restype = c_long
+        _lib.oracle_key_sum_over.argtypes = [u64p, u64p, c_long, u64p, f32p]
+        _lib.oracle_key_sum_over.restype = c_long
+        _lib.oracle_payload_slice.argtypes = [u64p, c_long, c_u64, c_u64, c_u64, u64p]
+        _lib.oracle_payload_slice.restype = c_long
+        _lib.oracle_topk.argtypes = [f32p, c_long, c_long, f32p, u64p]
+        _lib.oracle_topk.restype = c_long
+        if hasattr(_lib, "oracle_span_freqs"):
+            _lib.oracle_span_freqs.argtypes = [u64p, c_long, u64p, c_long, c_u64,
+                                               u64p, f32p, c_long]
+            _lib.oracle_span_freqs.restype = c_long
+    return _lib
+
+
+def _u64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p64(a: np.ndarray):
+    return a.ctypes.data_as(u64p)
+
+
+def _pf(a: np.ndarray):
+    return a.ctypes.data_as(f32p)
+
+
+ALL_BITS = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+# ---------------------------------------------------------------------------
+# Roaringish bit layout: searcharray/roaringish/roaringish.py:30-35,66-86
+# ---------------------------------------------------------------------------
+KEY_BITS = np.uint64(28)
+KEY_SHIFT = np.uint64(36)                       # 64 - key_bits
+KEY_MASK = np.uint64(0xFFFFFFF000000000)
+PAYLOAD_MSB_MASK = np.uint64(0x0000000FFFFC0000)
+PAYLOAD_MSB_BITS = np.uint64(18)
+PAYLOAD_LSB_MASK = np.uint64(0x000000000003FFFF)
+PAYLOAD_LSB_BITS = np.uint64(18)
+HEADER_MASK = np.uint64(0xFFFFFFFFFFFC0000)     # key | payload msb
+MAX_POSN = np.uint64(2 ** 18 - 1)               # roaringish.py:86, middle_out.py:41
+_1 = np.uint64(1)
+_UPPER_BIT = np.uint64(1 << 17)                 # bigram_freqs.py:31
+
+
+# ---------------------------------------------------------------------------
+# Native kernels (C restatement in snp_ops.c)
+# ---------------------------------------------------------------------------
+def bm25_score(term_freqs: np.ndarray, doc_lens: np.ndarray, avg_doc_lens, idf, k1, b) -> None:
+    """In-place BM25.  searcharray/bm25/bm25.pyx:28-41 (argument order of the .pyx)."""
+    assert term_freqs.dtype == np.float32 and term_freqs.flags.c_contiguous
+    dl = _f32(doc_lens)
+    lib().oracle_bm25_score(_pf(term_freqs), _pf(dl), np.float32(avg_doc_lens), np.float32(idf),
+                            np.float32(k1), np.float32(b), term_freqs.shape[0])
+
+
+def as_dense(indices, values, size: int) -> np.ndarray:
+    """roaringish_ops.pyx:84-98."""
+    indices = _u64(indices)
+    values = _f32(values)
+    if len(indices) != len(values):
+        raise ValueError("indices and values must have the same length")
+    out = np.empty(int(size), dtype=np.float32)
+    lib().oracle_as_dense(_p64(indices), _pf(values), len(indices), _pf(out), int(size))
+    return out
+
+
+def popcount64_reduce(arr, key_shift, value_mask) -> Tuple[np.ndarray, np.ndarray]:
+    """popcount.pyx:271-278."""
+    arr = _u64(arr)
+    n = len(arr)
+    keys = np.empty(n, dtype=np.uint64)
+    counts = np.empty(n, dtype=np.float32)
+    g = lib().oracle_popcount64_reduce(_p64(arr), n, int(key_shift), int(value_mask), _p64(keys), _pf(counts))
+    return keys[:g].copy(), counts[:g].copy()
+
+
+def unique(arr, rshift=0) -> np.ndarray:
+    """unique.pyx:139-145."""
+    arr = _u64(arr)
+    out = np.empty(len(arr), dtype=np.uint64)
+    g = lib().oracle_unique(_p64(arr), len(arr), int(rshift), _p64(out))
+    return out[:g].copy()
+
+
+def intersect(lhs, rhs, mask=ALL_BITS, drop_duplicates=True) -> Tuple[np.ndarray, np.ndarray]:
+    """intersect.pyx:278-320."""
+    lhs, rhs = _u64(lhs), _u64(rhs)
+    if mask is None:
+        mask = ALL_BITS
+    if int(mask) == 0:
+        raise ValueError("Mask cannot be zero")
+    if drop_duplicates:
+        n = min(len(lhs), len(rhs))
+        lo = np.empty(n, dtype=np.uint64)
+        ro = np.empty(n, dtype=np.uint64)
+        w = lib().oracle_intersect_drop(_p64(lhs), len(lhs), _p64(rhs), len(rhs), int(mask), _p64(lo), _p64(ro))
+        return lo[:w].copy(), ro[:w].copy()
+    n = max(len(lhs), len(rhs))
+    lo = np.empty(n, dtype=np.uint64)
+    ro = np.empty(n, dtype=np.uint64)
+    wl, wr = c_long(0), c_long(0)
+    lib().oracle_intersect_keep(_p64(lhs), len(lhs), _p64(rhs), len(rhs), int(mask), _p64(lo), _p64(ro),
+                                ctypes.byref(wl), ctypes.byref(wr))
+    return lo[:wl.value].copy(), ro[:wr.value].copy()
+
+
+def adjacent(lhs, rhs, mask=ALL_BITS) -> Tuple[np.ndarray, np.ndarray]:
+    """intersect.pyx:323-343."""
+    lhs, rhs = _u64(lhs), _u64(rhs)
+    if mask is None:
+        mask = ALL_BITS
+    if int(mask) == 0:
+        raise ValueError("Mask cannot be zero")
+    n = min(len(lhs), len(rhs))
+    lo = np.empty(n, dtype=np.uint64)
+    ro = np.empty(n, dtype=np.uint64)
+    w = lib().oracle_adjacent(_p64(lhs), len(lhs), _p64(rhs), len(rhs), int(mask), _p64(lo), _p64(ro))
+    return lo[:w].copy(), ro[:w].copy()
+
+
+def intersect_with_adjacents(lhs, rhs, mask=ALL_BITS):
+    """intersect.pyx:346-390."""
+    lhs, rhs = _u64(lhs), _u64(rhs)
+    if mask is None:
+        mask = ALL_BITS
+    if int(mask) == 0:
+        raise ValueError("Mask cannot be zero")
+    n = min(len(lhs), len(rhs))
+    lo = np.empty(n, dtype=np.uint64)
+    ro = np.empty(n, dtype=np.uint64)
+    la = np.empty(n, dtype=np.uint64)
+    ra = np.empty(n, dtype=np.uint64)
+    wa = c_long(0)
+    w = lib().oracle_intersect_with_adjacents(_p64(lhs), len(lhs), _p64(rhs), len(rhs), int(mask),
+                                              _p64(lo), _p64(ro), _p64(la), _p64(ra), ctypes.byref(wa))
+    return lo[:w].copy(), ro[:w].copy(), la[:wa.value].copy(), ra[:wa.value].copy()
+
+
+def merge(lhs, rhs, drop_duplicates=False) -> np.ndarray:
+    """merge.pyx:135-158."""
+    lhs, rhs = _u64(lhs), _u64(rhs)
+    out = np.empty(len(lhs) + len(rhs), dtype=np.uint64)
+    w = lib().oracle_merge(_p64(lhs), len(lhs), _p64(rhs), len(rhs), int(bool(drop_duplicates)), _p64(out))
+    return out[:w].copy()
+
+
+def sort_merge_counts(lhs_ids, lhs_counts, rhs_ids, rhs_counts):
+    """merge.pyx:221-232."""
+    lhs_ids, rhs_ids = _u64(lhs_ids), _u64(rhs_ids)
+    lhs_counts, rhs_counts = _f32(lhs_counts), _f32(rhs_counts)
+    n = len(lhs_ids) + len(rhs_ids)
+    oi = np.empty(n, dtype=np.uint64)
+    oc = np.empty(n, dtype=np.float32)
+    w = lib().oracle_sort_merge_counts(_p64(lhs_ids), _pf(lhs_counts), len(lhs_ids),
+                                       _p64(rhs_ids), _pf(rhs_counts), len(rhs_ids), _p64(oi), _pf(oc))
+    return oi[:w].copy(), oc[:w].copy()
+
+
+def popcount64(arr) -> np.ndarray:
+    """popcount.pyx:119-121."""
+    arr = _u64(arr)
+    out = np.empty(len(arr), dtype=np.uint64)
+    lib().oracle_popcount64(_p64(arr), len(arr), _p64(out))
+    return out
+
+
+def popcount_reduce_at(ids, payload):
+    """popcount.pyx:151-165."""
+    ids, payload = _u64(ids), _u64(payload)
+    if len(ids) != len(payload):
+        raise ValueError("ids and payload must have the same length")
+    oi = np.empty(len(ids), dtype=np.uint64)
+    oc = np.empty(len(ids), dtype=np.float32)
+    w = lib().oracle_popcount_reduce_at(_p64(ids), _p64(payload), len(ids), _p64(oi), _pf(oc))
+    return oi[:w].copy(), oc[:w].copy()
+
+
+def key_sum_over(ids, count):
+    """popcount.pyx:194-204."""
+    ids, count = _u64(ids), _u64(count)
+    if len(ids) != len(count):
+        raise ValueError("ids and count must have the same length")
+    oi = np.empty(len(ids), dtype=np.uint64)
+    oc = np.empty(len(ids), dtype=np.float32)
+    w = lib().oracle_key_sum_over(_p64(ids), _p64(count), len(ids), _p64(oi), _pf(oc))
+    return oi[:w].copy(), oc[:w].copy()
+
+
+def payload_slice(arr, payload_msb_mask, min_payload=0, max_payload=0xFFFFFFFFFFFFFFFF):
+    """roaringish_ops.pyx:63-68."""
+    arr = _u64(arr)
+    out = np.empty(len(arr), dtype=np.uint64)
+    w = lib().oracle_payload_slice(_p64(arr), len(arr), int(payload_msb_mask), int(min_payload),
+                                   int(max_payload) & 0xFFFFFFFFFFFFFFFF, _p64(out))
+    return out[:w].copy()
+
+
+def topk(scores, k: int):
+    """Caller idiom np.argpartition(scores, -k)[-k:] (utils/sort.py:24) with the deterministic
+    tie order of the GPU path: score descending, doc id ascending."""
+    scores = _f32(scores)
+    k = min(int(k), len(scores))
+    os_ = np.empty(k, dtype=np.float32)
+    od = np.empty(k, dtype=np.uint64)
+    m = lib().oracle_topk(_pf(scores), len(scores), k, _pf(os_), _p64(od))
+    return os_[:m], od[:m]
+
+
+# ---------------------------------------------------------------------------
+# Codec: RoaringishEncoder.encode, roaringish.py:93-142
+# ---------------------------------------------------------------------------
+def encode(term_ids: np.ndarray, doc_ids: np.ndarray, posns: np.ndarray):
+    """Encode (term, doc, posn) triples, sorted by (term, doc, posn), into roaringish words.
+
+    Returns (words u64[W], term_ids_present, term_offsets) where the words of
+    term_ids_present[i] are words[term_offsets[i]:term_offsets[i+1]].
+    One word per (term, doc, posn // 18): doc << 36 | (posn // 18) << 18 | OR(1 << posn % 18).
+    Term boundaries break OR-groups even when headers are equal (roaringish.py:119-130).
+    """
+    term_ids = np.asarray(term_ids).astype(np.uint64)
+    doc_ids = np.asarray(doc_ids).astype(np.uint64)
+    posns = np.asarray(posns).astype(np.uint64)
+    if len(posns) and posns.max() > MAX_POSN:
+        raise ValueError(f"Positions must be less than {2**18}")
+    if len(term_ids) == 0:
+        return (np.empty(0, np.uint64), np.empty(0, np.uint64), np.zeros(1, np.uint64))
+    header = (doc_ids << KEY_SHIFT) | ((posns // PAYLOAD_LSB_BITS) << PAYLOAD_MSB_BITS)
+    bits = _1 << (posns % PAYLOAD_LSB_BITS)
+    new_group = np.ones(len(header), dtype=bool)
+    new_group[1:] = (header[1:] != header[:-1]) | (term_ids[1:] != term_ids[:-1])
+    starts = np.flatnonzero(new_group)
+    words = np.bitwise_or.reduceat((header | bits).view(np.int64), starts).view(np.uint64)
+    word_terms = term_ids[starts]
+    tb = np.ones(len(word_terms), dtype=bool)
+    tb[1:] = word_terms[1:] != word_terms[:-1]
+    tstarts = np.flatnonzero(tb)
+    offsets = np.concatenate([tstarts, [len(words)]]).astype(np.uint64)
+    return words, word_terms[tstarts], offsets
+
+
+# ---------------------------------------------------------------------------
+# Bigram matcher: searcharray/phrase/bigram_freqs.py
+# ---------------------------------------------------------------------------
+CONT_LHS, CONT_RHS = 0, 1          # bigram_freqs.py:36-40 (BOTH is never used on the path)
+
+
+def _inner_bigram_same_term(lhs_int, rhs_int, lhs_doc_ids, cont):
+    """bigram_freqs.py:65-101 + _adj_to_phrase_freq :48-62."""
+    rhs_shift = rhs_int << _1
+    overlap = lhs_int & rhs_shift
+    adjacents = popcount64(overlap & PAYLOAD_LSB_MASK).view(np.int64)
+    consecutive = popcount64((overlap & (overlap << _1)) & PAYLOAD_LSB_MASK)
+    # adjacents -= ceil(consecutive / 2)      (:61, written as -floor_divide(x, -2))
+    adjacents = adjacents - (-np.floor_divide(consecutive, -2, dtype=np.int64))
+    adjusted = adjacents.astype(np.uint64)
+    ids, freqs = key_sum_over(lhs_doc_ids, adjusted)
+    msbs = lhs_int & ~PAYLOAD_LSB_MASK
+    rhs_cont = ((rhs_shift & rhs_int) & PAYLOAD_LSB_MASK) | msbs
+    lhs_cont = msbs | ((lhs_int & (lhs_int >> _1)) & PAYLOAD_LSB_MASK)
+    return (ids, freqs), (lhs_cont if cont == CONT_LHS else None, rhs_cont if cont == CONT_RHS else None)
+
+
+def _inner_bigram_freqs(lhs_int, rhs_int, cont):
+    """bigram_freqs.py:104-155."""
+    lhs_doc_ids = lhs_int >> KEY_SHIFT
+    if len(lhs_int) != len(rhs_int):
+        raise ValueError("Encoding error, MSBs apparently are duplicated among your encoded posn arrays.")
+    if len(lhs_int) == 0:
+        empty = (np.array([], dtype=np.uint64), np.array([], dtype=np.float32))
+        return empty, ((None, rhs_int) if cont == CONT_RHS else (lhs_int, None))
+    if np.all(lhs_int == rhs_int):
+        return _inner_bigram_same_term(lhs_int, rhs_int, lhs_doc_ids, cont)
+    overlap = (lhs_int & PAYLOAD_LSB_MASK) & ((rhs_int & PAYLOAD_LSB_MASK) >> _1)
+    rhs_next = lhs_next = None
+    if cont == CONT_RHS:
+        rhs_next = ((overlap << _1) & PAYLOAD_LSB_MASK) | (rhs_int & HEADER_MASK)
+    else:
+        lhs_next = overlap | (lhs_int & HEADER_MASK)
+    ids, counts = popcount_reduce_at(lhs_doc_ids, overlap)
+    return (ids, counts), (lhs_next, rhs_next)
+
+
+def _adjacent_bigram_freqs(lhs_adj, rhs_adj, cont):
+    """bigram_freqs.py:158-188."""
+    lhs_doc_ids = lhs_adj >> KEY_SHIFT
+    matches = ((lhs_adj & _UPPER_BIT) != 0) & ((rhs_adj & _1) != 0)
+    uniq, counts = np.unique(lhs_doc_ids[matches], return_counts=True)
+    rhs_next = None if cont == CONT_LHS else np.asarray([], dtype=np.uint64)
+    lhs_next = None if cont == CONT_RHS else np.asarray([], dtype=np.uint64)
+    if np.any(matches):
+        if cont == CONT_RHS:
+            rhs_next = (rhs_adj[matches] & HEADER_MASK) | _1
+        else:
+            lhs_next = (lhs_adj[matches] & HEADER_MASK) | _UPPER_BIT
+    return (uniq.astype(np.uint64), counts), (lhs_next, rhs_next)
+
+
+def _set_adjbit_at_header(next_inner, next_adj, cont):
+    """bigram_freqs.py:191-210."""
+    if len(next_inner) == 0:
+        return next_adj
+    if len(next_adj) == 0:
+        return next_inner
+    same_inner, same_adj = intersect(next_inner, next_adj, mask=HEADER_MASK)
+    keep = np.ones(len(next_adj), dtype=bool)
+    keep[same_adj.astype(np.int64)] = False
+    if len(same_inner) > 0:
+        next_inner = next_inner.copy()
+        next_inner[same_inner.astype(np.int64)] |= (_1 if cont == CONT_RHS else _UPPER_BIT)
+        next_adj = next_adj[keep]
+    return merge(next_inner, next_adj)
+
+
+def bigram_freqs(lhs, rhs, cont=CONT_RHS):
+    """bigram_freqs.py:213-307.  Returns ((ids, counts), (lhs_next, rhs_next))."""
+    lhs, rhs = _u64(lhs), _u64(rhs)
+    li, ri, la, ra = intersect_with_adjacents(lhs, rhs, mask=HEADER_MASK)      # roaringish.py:193-198
+    lhs_int, rhs_int = lhs[li.astype(np.int64)], rhs[ri.astype(np.int64)]
+    lhs_adj, rhs_adj = lhs[la.astype(np.int64)], rhs[ra.astype(np.int64)]
+    (ids, counts), (lni, rni) = _inner_bigram_freqs(lhs_int, rhs_int, cont)
+    (aids, acounts), (lna, rna) = _adjacent_bigram_freqs(lhs_adj, rhs_adj, cont)
+    ids1, counts1 = sort_merge_counts(ids, counts.astype(np.float32), aids, acounts.astype(np.float32))
+    lhs_next = rhs_next = None
+    if cont == CONT_RHS:
+        rhs_next = _set_adjbit_at_header(rni, rna, CONT_RHS)
+    else:
+        lhs_next = _set_adjbit_at_header(lni, lna, CONT_LHS)
+    return (ids1, counts1), (lhs_next, rhs_next)
+
+
+# ---------------------------------------------------------------------------
+# Phrase planner: searcharray/phrase/middle_out.py:73-168
+# ---------------------------------------------------------------------------
+def _intersect_bigram_matches(ids, counts, new_ids, new_counts):
+    """middle_out.py:73-93."""
+    if ids is None or counts is None:
+        return new_ids, new_counts
+    a, b = intersect(ids, new_ids)
+    a, b = a.astype(np.int64), b.astype(np.int64)
+    return ids[a], np.minimum(counts[a], new_counts[b])
+
+
+def _phrase_l2r(enc: Sequence[np.ndarray]):
+    """middle_out.py:96-122."""
+    if len(enc) < 2:
+        raise ValueError("phrase must have at least two terms")
+    ids = counts = None
+    lhs = enc[0]
+    for rhs in enc[1:]:
+        (nids, ncounts), conts = bigram_freqs(lhs, rhs, cont=CONT_RHS)
+        lhs = conts[1]
+        ids, counts = _intersect_bigram_matches(ids, counts, nids, ncounts)
+    return ids, counts
+
+
+def _phrase_r2l(enc: Sequence[np.ndarray]):
+    """middle_out.py:125-151."""
+    if len(enc) < 2:
+        raise ValueError("phrase must have at least two terms")
+    ids = counts = None
+    rhs = enc[-1]
+    for lhs in enc[-2::-1]:
+        (nids, ncounts), conts = bigram_freqs(lhs, rhs, cont=CONT_LHS)
+        rhs = conts[0]
+        ids, counts = _intersect_bigram_matches(ids, counts, nids, ncounts)
+    return ids, counts
+
+
+def compute_phrase_freqs(enc: Sequence[np.ndarray]):
+    """middle_out.py:154-168 (trim is always False on this path)."""
+    shortest = min(range(len(enc)), key=lambda i: len(enc[i]))     # first minimum on ties
+    if shortest <= 1:
+        return _phrase_l2r(enc)
+    if shortest >= len(enc) - 2:
+        return _phrase_r2l(enc)
+    lids, lcounts = _phrase_l2r(enc[:shortest])
+    rids, rcounts = _phrase_r2l(enc[shortest:])
+    return _intersect_bigram_matches(lids, lcounts, rids, rcounts)
+
+
+# ---------------------------------------------------------------------------
+# Similarity: searcharray/similarity.py:19-38
+# ---------------------------------------------------------------------------
+def compute_idf(num_docs, dfs):
+    """similarity.py:19-21 (float64 numpy math)."""
+    dfs = np.asarray(dfs)
+    return np.sum(np.log(1 + (num_docs - dfs + 0.5) / (dfs + 0.5)))
+
+
+def bm25(term_freqs: np.ndarray, doc_freqs, doc_lens, avg_doc_lens, num_docs, k1=1.2, b=0.75):
+    """similarity.py:24-38: mutates and returns term_freqs."""
+    if avg_doc_lens == 0:
+        return np.zeros_like(term_freqs)
+    idf = compute_idf(num_docs, doc_freqs)
+    bm25_score(term_freqs, doc_lens, avg_doc_lens, idf, k1, b)
+    return term_freqs
+
+
+# ---------------------------------------------------------------------------
+# Index object + search API: middle_out.py:320-553 (PosnBitArray), postings.py:607-708
+# ---------------------------------------------------------------------------
+class OracleIndex:
+    """Term-id keyed positional index with the reference's tf/df/phrase/score semantics.
+
+    Built from (term, doc, posn) triples sorted by term then doc then posn, exactly what
+    PosnBitArrayFromFlatBuilder consumes (middle_out.py:171-206), plus the fields
+    SearchArray.index assigns (postings.py:293-300).
+    """
+
+    def __init__(self, words: np.ndarray, term_ids: np.ndarray, offsets: np.ndarray,
+                 doc_lens: np.ndarray, num_docs: Optional[int] = None):
+        self.words = _u64(words)
+        self.offsets = np.asarray(offsets, dtype=np.int64)
+        self.term_slot = {int(t): i for i, t in enumerate(np.asarray(term_ids))}
+        self.doc_lens = _f32(doc_lens)
+        self.num_docs = int(num_docs if num_docs is not None else len(self.doc_lens))
+        self.max_doc_id = self.num_docs - 1
+        # postings.py:296 / indexing.py:282: np.mean of the float32 doc_lens
+        self.avg_doc_length = np.mean(self.doc_lens) if len(self.doc_lens) else 0.0
+        self.df_cache = {}
+        self.tf_cache = {}
+
+    @classmethod
+    def from_triples(cls, term_ids, doc_ids, posns, num_docs, doc_lens=None):
+        words, tids, offs = encode(term_ids, doc_ids, posns)
+        if doc_lens is None:
+            doc_lens = np.zeros(num_docs, dtype=np.float32)
+            if len(doc_ids):
+                # indexing.py:38-57 derives lengths from positions; with positions 0..L-1
+                # that is max posn + 1 per doc.
+                np.maximum.at(doc_lens, np.asarray(doc_ids, dtype=np.int64),
+                              (np.asarray(posns) + 1).astype(np.float32))
+        return cls(words, tids, offs, doc_lens, num_docs)
+
+    def has_term(self, term_id) -> bool:
+        return int(term_id) in self.term_slot
+
+    def enc(self, term_id) -> np.ndarray:
+        i = self.term_slot[int(term_id)]
+        return self.words[self.offsets[i]:self.offsets[i + 1]]
+
+    def clear_cache(self):
+        self.df_cache, self.tf_cache = {}, {}
+
+    # -- middle_out.py:521-528 / roaringish.py:176-179
+    def docfreq(self, term_id) -> int:
+        if not self.has_term(term_id):
+            return 0                                            # postings.py:646-647
+        t = int(term_id)
+        if t not in self.df_cache:
+            self.df_cache[t] = np.uint64(unique(self.enc(t), KEY_SHIFT).size)
+        return self.df_cache[t]
+
+    # -- middle_out.py:481-509 / roaringish.py:168-170
+    def termfreqs_sparse(self, term_id):
+        t = int(term_id)
+        if t not in self.tf_cache:
+            self.tf_cache[t] = popcount64_reduce(self.enc(t), KEY_SHIFT, PAYLOAD_LSB_MASK)
+        return self.tf_cache[t]
+
+    # -- postings.py:607-638 (non-subset branch)
+    def termfreqs(self, term) -> np.ndarray:
+        if isinstance(term, (list, tuple)):
+            if len(term) == 1:
+                term = term[0]
+            else:
+                return self.phrase_freqs(term)
+        if not self.has_term(term):
+            return np.zeros(self.num_docs, dtype=np.float32)
+        ids, tfs = self.termfreqs_sparse(term)
+        return as_dense(ids, tfs, self.num_docs)
+
+    # -- middle_out.py:418-441 (slop == 0), postings.py:689-708
+    def phrase_freqs(self, term_ids, slop: int = 0) -> np.ndarray:
+        out = np.zeros(self.max_doc_id + 1, dtype=np.float32)
+        if len(term_ids) < 2:
+            raise ValueError("Must have at least two terms")
+        if not all(self.has_term(t) for t in term_ids):
+            return out
+        enc = [self.enc(t) for t in term_ids]
+        if slop == 0:
+            ids, counts = compute_phrase_freqs(enc)
+        else:
+            from . import spans as _spans
+            ids, counts = _spans.span_search(enc, slop)
+        if ids is not None and len(ids):
+            out[ids.astype(np.int64)] = counts
+        return out
+
+    # -- postings.py:652-680
+    def score(self, term, k1=1.2, b=0.75, slop: int = 0) -> np.ndarray:
+        tokens = [term] if not isinstance(term, (list, tuple)) else list(term)
+        dfs = np.asarray([self.docfreq(t) for t in tokens])
+        if len(tokens) == 1:
+            tfs = self.termfreqs(tokens[0])
+        else:
+            tfs = self.phrase_freqs(tokens, slop=slop)
+        return bm25(tfs, dfs, self.doc_lens, self.avg_doc_length, self.num_docs, k1=k1, b=b)
+
+    # -- caller idiom test/test_msmarco.py:353-354 + utils/sort.py:24
+    def score_terms_sum(self, terms, k1=1.2, b=0.75) -> np.ndarray:
+        return np.sum([self.score(t, k1=k1, b=b) for t in terms], axis=0)

@@ -1,0 +1,147 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself (searcharray v0.0.73).
+
+Run in the build container only (the GPU box has no /root/reference):
+
+    cp -r /root/reference /tmp/ref && chmod -R u+w /tmp/ref
+    (cd /tmp/ref && python setup.py build_ext --inplace)
+    REF_BUILD=/tmp/ref python tests/golden/make_golden.py
+
+Nothing from the reference is copied into the repo: the fixtures hold seeded synthetic
+inputs (produced by searcharray_amd.synth) and the reference's OUTPUTS on them, plus the
+two of the reference's captured lhs/rhs/mask triples (data files, fixtures/*.npy) with
+the reference's outputs on them.
+"""
+import os
+import sys
+
+import numpy as np
+
+REF = os.environ.get("REF_BUILD", "/tmp/ref")
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)
+
+from searcharray.postings import SearchArray                      # noqa: E402
+from searcharray.similarity import bm25_similarity               # noqa: E402
+from searcharray.roaringish.intersect import intersect, adjacent, intersect_with_adjacents  # noqa: E402
+from searcharray.roaringish.merge import merge                   # noqa: E402
+from searcharray.roaringish.unique import unique                 # noqa: E402
+from searcharray.roaringish.popcount import popcount64_reduce    # noqa: E402
+from searcharray.phrase.bigram_freqs import bigram_freqs, Continuation  # noqa: E402
+from searcharray_amd import synth                                 # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+HEADER_MASK = np.uint64(0xFFFFFFFFFFFC0000)
+LSB_MASK = np.uint64(0x3FFFF)
+
+
+def snp_fixture_goldens():
+    """Reference set primitives on its own captured arrays (test/test_snp_ops.py:323-349)."""
+    out = {}
+    for tag in ("128", "24179"):
+        lhs = np.load(f"/root/reference/fixtures/lhs_{tag}.npy")
+        rhs = np.load(f"/root/reference/fixtures/rhs_{tag}.npy")
+        mask = np.load(f"/root/reference/fixtures/mask_{tag}.npy")
+        mask = np.uint64(mask) if mask.shape == () else np.uint64(mask.flatten()[0])
+        out[f"{tag}_lhs"], out[f"{tag}_rhs"], out[f"{tag}_mask"] = lhs, rhs, np.asarray(mask)
+        li, ri = intersect(lhs, rhs, mask=mask)
+        out[f"{tag}_int_drop_l"], out[f"{tag}_int_drop_r"] = li, ri
+        lk, rk = intersect(lhs, rhs, mask=mask, drop_duplicates=False)
+        out[f"{tag}_int_keep_l"], out[f"{tag}_int_keep_r"] = lk, rk
+        a, b, c, d = intersect_with_adjacents(lhs, rhs, mask=mask)
+        out[f"{tag}_iwa_l"], out[f"{tag}_iwa_r"], out[f"{tag}_iwa_al"], out[f"{tag}_iwa_ar"] = a, b, c, d
+        al, ar = adjacent(lhs, rhs, mask=mask)
+        out[f"{tag}_adj_l"], out[f"{tag}_adj_r"] = al, ar
+        out[f"{tag}_merge"] = merge(lhs, rhs)
+        out[f"{tag}_merge_drop"] = merge(lhs, rhs, drop_duplicates=True)
+        out[f"{tag}_unique36"] = unique(lhs, 36)
+        k, c = popcount64_reduce(lhs, np.uint64(36), LSB_MASK)
+        out[f"{tag}_pcr_keys"], out[f"{tag}_pcr_counts"] = k, c
+        (ids, cnt), (_, rn) = bigram_freqs(lhs, rhs, Continuation.RHS)
+        out[f"{tag}_bg_rhs_ids"], out[f"{tag}_bg_rhs_counts"], out[f"{tag}_bg_rhs_next"] = ids, cnt, rn
+        (ids, cnt), (ln, _) = bigram_freqs(lhs, rhs, Continuation.LHS)
+        out[f"{tag}_bg_lhs_ids"], out[f"{tag}_bg_lhs_counts"], out[f"{tag}_bg_lhs_next"] = ids, cnt, ln
+    np.savez_compressed(os.path.join(OUT, "snp_fixtures.npz"), **out)
+    print("snp_fixtures.npz", len(out), "arrays")
+
+
+def sparse(a):
+    idx = np.flatnonzero(a).astype(np.uint32)
+    return idx, a[idx]
+
+
+def corpus_goldens(name, num_docs, vocab, mean_len, seed, n_phr, slop_queries):
+    lens, terms = synth.zipf_batch_tokens(0, num_docs, vocab, mean_len, seed)
+    starts = np.zeros(num_docs + 1, dtype=np.int64)
+    np.cumsum(lens, out=starts[1:])
+    docs = [" ".join(f"t{t}" for t in terms[starts[i]:starts[i + 1]]) for i in range(num_docs)]
+    sa = SearchArray.index(docs, autowarm=False)
+    out = {"lens": lens, "terms": terms,
+           "meta": np.asarray([num_docs, vocab, mean_len, seed], dtype=np.int64),
+           "avg_doc_length": np.asarray(sa.avg_doc_length, dtype=np.float32),
+           "doc_lens": sa.doc_lens.astype(np.float32)}
+    # df for every term, tf (sparse) for a spread of terms
+    dfs = np.asarray([sa.docfreq(f"t{t}") for t in range(vocab)], dtype=np.uint64)
+    out["df"] = dfs
+    tf_terms = np.unique(np.concatenate([np.arange(0, 12), np.geomspace(12, vocab - 1, 24).astype(int)]))
+    out["tf_terms"] = tf_terms.astype(np.uint32)
+    for t in tf_terms:
+        i, v = sparse(sa.termfreqs(f"t{t}"))
+        out[f"tf_{t}_idx"], out[f"tf_{t}_val"] = i, v
+    # single-term BM25 (default + custom k1/b)
+    sc_terms = tf_terms[::3]
+    out["score_terms"] = sc_terms.astype(np.uint32)
+    custom = bm25_similarity(k1=1.7, b=0.3)
+    for t in sc_terms:
+        out[f"score_{t}"] = sa.score(f"t{t}")
+        out[f"score_custom_{t}"] = sa.score(f"t{t}", similarity=custom)
+    # 4-term disjunctions (caller idiom test/test_msmarco.py:353-354)
+    rng = np.random.default_rng(99)
+    queries = np.stack([rng.integers(0, min(10, vocab), 16), rng.integers(0, min(60, vocab), 16),
+                        rng.integers(0, vocab, 16), rng.integers(0, vocab, 16)], axis=1).astype(np.uint32)
+    queries[0] = [0, 1, 2, 3]
+    out["or_queries"] = queries
+    out["or_scores"] = np.stack([np.sum([sa.score(f"t{t}") for t in q], axis=0) for q in queries])
+    # phrases: real n-grams of length 2..7, random (mostly non-matching) ones, same-term ones
+    phrases = []
+    for length in (2, 3, 4, 5, 6, 7):
+        rngp = np.random.default_rng(1000 + length)
+        got = 0
+        while got < n_phr:
+            d = int(rngp.integers(0, num_docs))
+            if lens[d] < length:
+                continue
+            o = int(rngp.integers(0, lens[d] - length + 1))
+            phrases.append(terms[starts[d] + o: starts[d] + o + length].astype(np.int64))
+            got += 1
+        for _ in range(max(2, n_phr // 4)):
+            phrases.append(rngp.integers(0, min(vocab, 12), length))
+    phrases += [np.asarray(p) for p in ([0, 0], [0, 0, 0], [0, 0, 1], [1, 0, 0], [0, 1, 0], [1, 1], [0, 0, 0, 0],
+                                        [0, 1, 0, 1], [2, 0, 0, 3], [0, 1, 2, 0, 1], [3, 3, 3], [0, 0, 1, 1],
+                                        [5, 4, 0, 2, 1], [0, 1, 9, 2, 3], [1, 2, 0, 9, 3, 4, 0])]
+    out["n_phrases"] = np.asarray(len(phrases))
+    for i, p in enumerate(phrases):
+        toks = [f"t{t}" for t in p]
+        out[f"phr_{i}_terms"] = np.asarray(p, dtype=np.uint32)
+        idx, val = sparse(sa.termfreqs(toks))
+        out[f"phr_{i}_idx"], out[f"phr_{i}_val"] = idx, val
+        sidx, sval = sparse(sa.score(toks))
+        out[f"phr_{i}_sidx"], out[f"phr_{i}_sval"] = sidx, sval
+    # slop
+    out["n_slop"] = np.asarray(len(slop_queries))
+    for i, (p, slop) in enumerate(slop_queries):
+        toks = [f"t{t}" for t in p]
+        out[f"slop_{i}_terms"] = np.asarray(p, dtype=np.uint32)
+        out[f"slop_{i}_slop"] = np.asarray(slop)
+        idx, val = sparse(sa.termfreqs(toks, slop=slop))
+        out[f"slop_{i}_idx"], out[f"slop_{i}_val"] = idx, val
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(f"{name}.npz", len(out), "arrays,", num_docs, "docs")
+
+
+if __name__ == "__main__":
+    snp_fixture_goldens()
+    slopq = [([3, 7], 1), ([3, 7], 2), ([0, 1], 2), ([5, 2, 9], 2), ([10, 4], 3), ([1, 0], 1),
+             ([20, 30], 5), ([2, 2], 2), ([8, 1, 3], 4), ([40, 6], 2)]
+    corpus_goldens("zipf_small", 1500, 200, 40, 4321, 10, slopq)
+    corpus_goldens("zipf_sparse", 4000, 5000, 24, 77, 6, slopq[:4])

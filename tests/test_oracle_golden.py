@@ -1,0 +1,190 @@
+"""Pin the CPU oracle (oracle/) to the reference: (a) known answers quoted from the
+reference's own tests, (b) outputs of the reference itself captured in tests/golden/."""
+import numpy as np
+import pytest
+
+from oracle import refimpl as O
+from tests.helpers import load_golden, oracle_index, dense_from_sparse
+
+u64 = lambda x: np.asarray(x, dtype=np.uint64)  # noqa: E731
+
+
+# ---- BM25 known answers: reference test/test_similarity.py:16-61 (Lucene explain values)
+LUCENE = [
+    (2, 14, 4, 2.7322686, 8516, 3.52482),
+    (1, 5, 35, 50.580456, 8514, 3.8199246),
+    (2, 7, 44, 50.580456, 8514, 4.5636616),
+    (25, 7823, 152, 119.18542, 8516, 0.08028283),
+]
+
+
+@pytest.mark.parametrize("tf,df,dl,avgdl,n,expected", LUCENE)
+def test_bm25_matches_lucene(tf, df, dl, avgdl, n, expected):
+    got = O.bm25(np.asarray([tf], np.float32), np.asarray([df], np.float32),
+                 np.asarray([dl], np.float32), avgdl, n)
+    assert np.isclose(got, expected).all()
+
+
+def _index_strings(docs):
+    vocab = {}
+    t, d, p = [], [], []
+    for di, doc in enumerate(docs):
+        for pi, tok in enumerate(doc.split()):
+            t.append(vocab.setdefault(tok, len(vocab))); d.append(di); p.append(pi)
+    t, d, p = np.asarray(t, np.int64), np.asarray(d, np.int64), np.asarray(p, np.int64)
+    order = np.argsort(t, kind="stable")
+    lens = np.asarray([len(doc.split()) for doc in docs], np.float32)
+    return vocab, O.OracleIndex.from_triples(t[order], d[order], p[order], len(docs), doc_lens=lens)
+
+
+FIXTURE_100 = ["foo bar bar baz", "data2", "data3 bar", "bunny funny wunny"] * 25
+
+
+def test_search_fixture_known_answers():
+    """reference test/test_search.py:86-102,121-124."""
+    vocab, idx = _index_strings(FIXTURE_100)
+    assert (idx.termfreqs(vocab["bar"]) == [2, 0, 1, 0] * 25).all()
+    assert idx.docfreq(vocab["bar"]) == 50 and idx.docfreq(vocab["foo"]) == 25
+    assert idx.avg_doc_length == 2.5
+    assert np.isclose(idx.score(vocab["bar"]), [0.37066694, 0., 0.34314217, 0.] * 25).all()
+    assert idx.score(12345).sum() == 0
+
+
+# ---- phrase known answers: reference test/test_phrase_matches.py:17-194
+PHRASE_SCENARIOS = [
+    (["foo bar bar baz", "data2", "data3 bar", "bunny funny wunny"] * 25, "foo bar", [1, 0, 0, 0] * 25),
+    (["foo bear bar baz", "data2", "data3 bar", "bunny funny wunny"] * 25, "foo bar", [0, 0, 0, 0] * 25),
+    (["foo foo bar bar baz", "data2", "data3 bar", "bunny funny wunny"] * 25, "foo bar", [1, 0, 0, 0] * 25),
+    (["foo bar bar bar foo", "data2", "data3 bar", "bunny funny wunny"] * 25, "foo bar", [1, 0, 0, 0] * 25),
+    (["foo bar baz baz", "data2", "data3 bar", "bunny funny wunny"] * 25, "foo bar baz", [1, 0, 0, 0] * 25),
+    (["foo bar bar baz", "data2", "data3 bar", "bunny funny wunny"] * 25, "foo bar baz", [0, 0, 0, 0] * 25),
+    (["foo bar EEK foo URG bar baz", "data2", "data3 bar", "bunny funny wunny"] * 25, "foo bar baz", [0, 0, 0, 0] * 25),
+    (["foo foo foo", "data2", "data3 bar", "bunny funny wunny"] * 25, "foo foo", [1, 0, 0, 0] * 25),
+    (["foo foo bar", "data2", "data3 bar", "bunny funny wunny"] * 25, "foo foo bar", [1, 0, 0, 0] * 25),
+    (["foo bar bar", "data2", "data3 bar", "bunny funny wunny"] * 25, "foo bar bar", [1, 0, 0, 0] * 25),
+    (["foo bar bar foo bar bar", "data2", "data3 bar", "bunny funny wunny"] * 25, "foo bar bar", [2, 0, 0, 0] * 25),
+    (["foo foo foo", "data2", "data3 bar", "bunny funny wunny"] * 25, "foo foo foo", [1, 0, 0, 0] * 25),
+    (["foo foo foo foo", "data2", "data3 bar", "bunny funny wunny"] * 25, "foo foo foo foo", [1, 0, 0, 0] * 25),
+    (["foo foo foo foo", "data2", "data3 bar", "bunny funny wunny"] * 25, "foo foo", [2, 0, 0, 0] * 25),
+    (["foo foo foo foo baz foo foo", "data2", "data3 bar", "bunny funny wunny"] * 25, "foo foo", [3, 0, 0, 0] * 25),
+    (["foo foo bar bar", "data2", "data3 bar", "bunny funny wunny"] * 25, "foo foo bar bar", [1, 0, 0, 0] * 25),
+    (["foo bar foo bar", "data2", "data3 bar", "bunny funny wunny"] * 25, "foo bar", [2, 0, 0, 0] * 25),
+    (["foo bar baz foo bar baz", "data2", "data3 bar", "bunny funny wunny"] * 25, "foo bar baz", [2, 0, 0, 0] * 25),
+    (["foo bar baz foo bar buzz", "data2", "data3 bar", "bunny funny wunny"] * 25, "foo bar baz", [1, 0, 0, 0] * 25),
+    (["foo " + " ".join(["bar"] * 50), "data2", "data3 bar", "bunny funny wunny"] * 25, "foo bar", [1, 0, 0, 0] * 25),
+    (["data3 bar bar foo foo", "foo " + " ".join(["bar"] * 5), "foo " + " ".join(["bar"] * 50), "foo data2 bar",
+      "bunny funny wunny"] * 25, "foo bar", [0, 1, 1, 0, 0] * 25),
+    (["foo la ma bar bar baz", "data2 ma ta", "data3 bar ma", "bunny funny wunny",
+      "la ma ta wa ga ao a b c d e f g a be ae i la ma ta wa ga ao a foo bar foo bar"] * 25,
+     "la ma ta wa ga ao a", [0, 0, 0, 0, 2] * 25),
+    (["foo bar bar baz " + " ".join([" dummy foo bar baz"] * 100), "data2", "data3 bar",
+      "bunny funny wunny foo bar"] * 25, "foo bar", [101, 0, 0, 1] * 25),
+]
+
+
+@pytest.mark.parametrize("docs,phrase,expected", PHRASE_SCENARIOS)
+def test_phrase_known_answers(docs, phrase, expected):
+    vocab, idx = _index_strings(docs)
+    got = idx.phrase_freqs([vocab[t] for t in phrase.split()])
+    assert (got == np.asarray(expected, np.float32)).all()
+
+
+@pytest.mark.parametrize("phrase", ["foo bar baz", "foo bar", "foo foo foo", "foo foo bar", "foo bar bar",
+                                    "foo bar bar baz buz foo bar", "foo bar bar baz buz foo foo", "foo foo"])
+@pytest.mark.parametrize("offset", [0, 1, 15, 16, 17, 18, 19, 34, 35, 36, 53, 54, 71, 99])
+def test_phrase_offsets_cross_word_boundary(phrase, offset):
+    """reference test/test_phrase_matches.py:249-265 (offsets crossing the 18-bit word)."""
+    vocab, idx = _index_strings([" ".join(["dummy"] * offset) + " " + phrase, "not match"])
+    got = idx.phrase_freqs([vocab[t] for t in phrase.split()])
+    assert (got == [1, 0]).all()
+
+
+# ---- set primitives: scenario dicts from reference test/test_snp_ops.py:96-154,457-548
+def test_intersect_scenarios():
+    lhs, rhs = u64([1, 2, 3, 4, 5, 6, 7, 8, 9, 10]), u64([2, 4, 6, 8, 10])
+    li, ri = O.intersect(lhs, rhs)
+    assert (lhs[li.astype(int)] == rhs).all() and (rhs[ri.astype(int)] == rhs).all()
+    lhs, rhs = u64([1, 1, 2, 2, 3, 3, 4, 4, 5, 5]), u64([1, 2, 2, 10])
+    li, ri = O.intersect(lhs, rhs)
+    assert (lhs[li.astype(int)] == [1, 2]).all()
+    lhs = u64([0x1F, 0x2F, 0x3F, 0x4F, 0x5F, 0x6F, 0x7F, 0x8F, 0x9F, 0xAF])
+    rhs = u64([0x2F, 0x4F, 0x6F, 0x8F, 0xAF])
+    li, ri = O.intersect(lhs, rhs, mask=np.uint64(0xF0))
+    assert ((lhs[li.astype(int)] & np.uint64(0xF0)) == [0x20, 0x40, 0x60, 0x80, 0xA0]).all()
+    lhs, rhs = u64([9, 25, 28, 31, 31, 32, 38, 39, 42]), u64([0, 3, 11, 23, 32, 36, 41, 42])
+    li, ri = O.intersect(lhs, rhs)
+    assert (lhs[li.astype(int)] == [32, 42]).all()
+    lhs, rhs = u64([0, 0, 1]), u64([0, 0, 0, 0, 1])
+    li, ri = O.intersect(lhs, rhs)
+    assert (lhs[li.astype(int)] == [0, 1]).all()
+    with pytest.raises(ValueError):
+        O.intersect(lhs, rhs, mask=np.uint64(0))
+
+
+def test_merge_and_adjacent_scenarios():
+    assert (O.merge(u64([1, 3, 5]), u64([2, 4, 6])) == [1, 2, 3, 4, 5, 6]).all()
+    assert (O.merge(u64([1, 2, 5]), u64([2, 4])) == [1, 2, 2, 4, 5]).all()
+    assert (O.merge(u64([1, 2, 5]), u64([2, 4]), drop_duplicates=True) == [1, 2, 4, 5]).all()
+    lhs, rhs = u64([1, 5, 9]), u64([2, 5, 6, 7, 10])
+    li, ri = O.adjacent(lhs, rhs)
+    assert (lhs[li.astype(int)] == [1, 5, 9]).all() and (rhs[ri.astype(int)] == [2, 6, 10]).all()
+    a, b, c, d = O.intersect_with_adjacents(lhs, rhs)
+    assert (lhs[a.astype(int)] == [5]).all() and (lhs[c.astype(int)] == [1, 5, 9]).all()
+
+
+def test_popcount_known_answers():
+    """reference test/test_bitcount64.py:9-34."""
+    assert (O.popcount64(u64([0, 1, 3, 0xFFFFFFFFFFFFFFFF, 0x8000000000000000])) == [0, 1, 2, 64, 1]).all()
+
+
+# ---- reference outputs on its own captured arrays
+@pytest.mark.parametrize("tag", ["128", "24179"])
+def test_snp_fixtures_match_reference(tag):
+    g = load_golden("snp_fixtures")
+    lhs, rhs, mask = g[f"{tag}_lhs"], g[f"{tag}_rhs"], np.uint64(g[f"{tag}_mask"])
+    li, ri = O.intersect(lhs, rhs, mask=mask)
+    assert np.array_equal(li, g[f"{tag}_int_drop_l"]) and np.array_equal(ri, g[f"{tag}_int_drop_r"])
+    lk, rk = O.intersect(lhs, rhs, mask=mask, drop_duplicates=False)
+    assert np.array_equal(lk, g[f"{tag}_int_keep_l"]) and np.array_equal(rk, g[f"{tag}_int_keep_r"])
+    a, b, c, d = O.intersect_with_adjacents(lhs, rhs, mask=mask)
+    for got, key in ((a, "iwa_l"), (b, "iwa_r"), (c, "iwa_al"), (d, "iwa_ar")):
+        assert np.array_equal(got, g[f"{tag}_{key}"]), key
+    al, ar = O.adjacent(lhs, rhs, mask=mask)
+    assert np.array_equal(al, g[f"{tag}_adj_l"]) and np.array_equal(ar, g[f"{tag}_adj_r"])
+    assert np.array_equal(O.merge(lhs, rhs), g[f"{tag}_merge"])
+    assert np.array_equal(O.merge(lhs, rhs, drop_duplicates=True), g[f"{tag}_merge_drop"])
+    assert np.array_equal(O.unique(lhs, 36), g[f"{tag}_unique36"])
+    k, c = O.popcount64_reduce(lhs, 36, 0x3FFFF)
+    assert np.array_equal(k, g[f"{tag}_pcr_keys"]) and np.array_equal(c, g[f"{tag}_pcr_counts"])
+    (ids, cnt), (_, rn) = O.bigram_freqs(lhs, rhs, O.CONT_RHS)
+    assert np.array_equal(ids, g[f"{tag}_bg_rhs_ids"]) and np.array_equal(cnt, g[f"{tag}_bg_rhs_counts"])
+    assert np.array_equal(rn, g[f"{tag}_bg_rhs_next"])
+    (ids, cnt), (ln, _) = O.bigram_freqs(lhs, rhs, O.CONT_LHS)
+    assert np.array_equal(ids, g[f"{tag}_bg_lhs_ids"]) and np.array_equal(cnt, g[f"{tag}_bg_lhs_counts"])
+    assert np.array_equal(ln, g[f"{tag}_bg_lhs_next"])
+
+
+# ---- reference outputs on seeded synthetic corpora
+@pytest.mark.parametrize("name", ["zipf_small", "zipf_sparse"])
+def test_corpus_matches_reference(name):
+    g, idx = oracle_index(name)
+    n = idx.num_docs
+    assert np.float32(idx.avg_doc_length) == g["avg_doc_length"]
+    assert np.array_equal(idx.doc_lens, g["doc_lens"])
+    vocab = int(g["meta"][1])
+    dfs = np.asarray([idx.docfreq(t) for t in range(vocab)], dtype=np.uint64)
+    assert np.array_equal(dfs, g["df"])                                   # bit-exact df
+    for t in g["tf_terms"]:
+        want = dense_from_sparse(g[f"tf_{t}_idx"], g[f"tf_{t}_val"], n)
+        assert np.array_equal(idx.termfreqs(int(t)), want), f"tf t{t}"    # bit-exact tf
+    for t in g["score_terms"]:
+        assert np.array_equal(idx.score(int(t)), g[f"score_{t}"]), f"score t{t}"      # bit-exact fp32
+        assert np.array_equal(idx.score(int(t), k1=1.7, b=0.3), g[f"score_custom_{t}"])
+    for q, want in zip(g["or_queries"], g["or_scores"]):
+        assert np.array_equal(idx.score_terms_sum([int(t) for t in q]), want)
+    for i in range(int(g["n_phrases"])):
+        terms = [int(t) for t in g[f"phr_{i}_terms"]]
+        want = dense_from_sparse(g[f"phr_{i}_idx"], g[f"phr_{i}_val"], n)
+        assert np.array_equal(idx.phrase_freqs(terms), want), f"phrase {terms}"       # bit-exact counts
+        wants = dense_from_sparse(g[f"phr_{i}_sidx"], g[f"phr_{i}_sval"], n)
+        assert np.array_equal(idx.score(terms), wants), f"phrase score {terms}"
