@@ -1,0 +1,152 @@
+/*
+ * searcharray_hip.h -- C ABI of libsearcharray_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for searcharray's scoring hot path.  The reference has no FFI
+ * registry: its native boundary is the set of Cython `def` functions that take numpy
+ * buffers (searcharray/roaringish/__init__.py:1-7, searcharray/bm25/bm25.pyx:28).  Part 1
+ * mirrors those entry points one to one (host pointers in, host pointers out, caller-owned
+ * buffers with the reference's worst-case sizes), so a maintainer can rebind them with
+ * ctypes/cffi.  Part 2 is the HBM-resident index the Python classes
+ * (SearchArray / PosnBitArray) sit on: the index is uploaded once and every query runs on
+ * the device.  Part 3 is the doc-range-sharded multi-GPU top-k exchange over RCCL.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative SA_ERR_* code on failure; the message
+ *     is available from sa_last_error() (thread-local).  Nothing throws across the boundary.
+ *   - plain C types only; pointers are HOST pointers owned by the caller unless a parameter
+ *     is documented as a device pointer.
+ *   - calls on different index handles may run concurrently from different threads; calls
+ *     on one handle are serialised internally (the reference's callers score from thread
+ *     pools, test/test_tmdb.py:285-312).  ctypes releases the GIL around every call.
+ */
+#ifndef SEARCHARRAY_HIP_H
+#define SEARCHARRAY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SA_ABI_VERSION 1
+
+typedef struct sa_index sa_index_t;        /* opaque HBM-resident index (one doc-range shard) */
+typedef struct sa_batch sa_batch_t;        /* opaque device-resident query batch              */
+
+const char* sa_last_error(void);
+int sa_abi_version(void);
+int sa_device_count(int* out_count);
+int sa_device_name(int device, char* buf, int buf_len);
+
+/* ------------------------------------------------------------------------------------- */
+/* Part 1 -- kernel-level mirrors of the reference's native entry points                   */
+/* ------------------------------------------------------------------------------------- */
+
+/* bm25_score(term_freqs inout, doc_lens, avg_doc_lens, idf, k1, b)
+ * reference searcharray/bm25/bm25.pyx:28-41 (in-place, fp32, no FMA contraction). */
+int sa_bm25_score(float* term_freqs, const float* doc_lens, float avg_doc_lens, float idf,
+                  float k1, float b, int64_t n);
+
+/* as_dense(indices, values, size) -> float32[size]
+ * reference searcharray/roaringish/roaringish_ops.pyx:84-98, scatter_assign.h:6-29. */
+int sa_as_dense(const uint64_t* indices, const float* values, int64_t n, float* out, int64_t size);
+
+/* popcount64_reduce(arr, key_shift, value_mask) -> (keys u64[g], counts f32[g])
+ * reference searcharray/roaringish/popcount.pyx:212-237,271-278.  Outputs sized n. */
+int sa_popcount64_reduce(const uint64_t* arr, int64_t n, uint64_t key_shift, uint64_t value_mask,
+                         uint64_t* keys_out, float* counts_out, int64_t* n_out);
+
+/* unique(arr, rshift) -> distinct (arr >> rshift) of a sorted array
+ * reference searcharray/roaringish/unique.pyx:87-104,139-145.  Output sized n. */
+int sa_unique(const uint64_t* arr, int64_t n, uint64_t rshift, uint64_t* out, int64_t* n_out);
+
+/* popcount64(arr) -> u64[n]      reference searcharray/roaringish/popcount.pyx:71-81,119-121 */
+int sa_popcount64(const uint64_t* arr, int64_t n, uint64_t* out);
+
+/* ------------------------------------------------------------------------------------- */
+/* Part 2 -- HBM-resident index                                                            */
+/* ------------------------------------------------------------------------------------- */
+
+/* Upload one doc-range shard: roaringish words of all terms back to back (term-major, the
+ * reference's ArrayDict layout, searcharray/phrase/memmap_arrays.py:15-56), CSR offsets
+ * term_off[n_terms + 1], doc lengths of the shard's n_docs documents (doc ids inside `words`
+ * are shard-local), and the GLOBAL statistics avg_doc_len / corpus_size (BM25 must use
+ * global, not shard-local, statistics -- reference postings.py:293-299).
+ * Derives on the device what PosnBitArray.warm() caches on the host (reference
+ * middle_out.py:337-342): per-term TF postings and document frequencies.
+ * tile_docs: docs per scoring tile (0 = default 16384; allowed 1024, 8192, 16384, 32768). */
+int sa_index_create(int device, uint64_t n_docs, uint64_t doc_base, uint32_t n_terms,
+                    const uint64_t* words, const uint64_t* term_off, const float* doc_lens,
+                    float avg_doc_len, uint64_t corpus_size, uint32_t tile_docs,
+                    sa_index_t** out);
+int sa_index_destroy(sa_index_t* ix);
+
+/* shard-local document frequency of one term / of all terms (u64[n_terms])
+ * reference SearchArray.docfreq postings.py:640-647 -> PosnBitArray.docfreq middle_out.py:521 */
+int sa_index_docfreq(sa_index_t* ix, uint32_t term, uint64_t* out);
+int sa_index_docfreqs(sa_index_t* ix, uint64_t* out);
+
+/* dense term frequencies float32[n_docs] of one term (zeros for term >= n_terms)
+ * reference SearchArray.termfreqs single-term branch, postings.py:607-638 */
+int sa_index_termfreqs_dense(sa_index_t* ix, uint32_t term, float* out);
+
+/* sparse TF postings of one term: doc ids u64[df] (global = local + doc_base), tfs f32[df]
+ * reference PosnBitArray.termfreqs middle_out.py:481-509 */
+int sa_index_termfreqs_sparse(sa_index_t* ix, uint32_t term, uint64_t* doc_ids_out,
+                              float* tfs_out, int64_t* n_out);
+
+/* Term-at-a-time BM25 over n_query_terms terms, summed in query-term order in fp32 -- the
+ * caller idiom np.sum([arr.score(t) for t in q], axis=0) (reference test/test_msmarco.py:353)
+ * with similarity = bm25_similarity(k1, b) (similarity.py:24-38).  idf[i] is the float32 idf of
+ * term i computed by the host exactly as similarity.py:19-21 does.  terms[i] == 0xFFFFFFFF
+ * (unknown term) contributes nothing.  out = float32[n_docs]. */
+int sa_index_bm25_dense(sa_index_t* ix, const uint32_t* terms, const float* idf,
+                        int n_query_terms, float k1, float b, float* out);
+
+/* Device-resident batch of B queries x T terms with top-k selection (k <= 1024).
+ * terms/idf are [B][T] row-major.  Results per query: k (score, doc) pairs sorted by score
+ * descending then doc id ascending; slots beyond the number of matching docs hold
+ * score 0 and doc 0xFFFFFFFFFFFFFFFF.  Doc ids are global (local + doc_base). */
+int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const float* idf, int n_queries,
+                    int n_query_terms, int k, float k1, float b, sa_batch_t** out);
+/* one pass of the hot path over the batch; asynchronous on the index stream unless sync != 0.
+ * If the index has a communicator (Part 3) the per-shard top-k are exchanged and merged. */
+int sa_batch_run(sa_batch_t* batch, int sync);
+/* External-collective variant of sa_batch_run for callers that own the exchange (e.g.
+ * torch.distributed over RCCL): run this shard and copy its B*k ranking keys (u64, score bits
+ * << 32 | ~global_doc) to a DEVICE buffer; then merge `nranks` gathered key blocks
+ * [nranks][B][k] (DEVICE pointer) into the final top-k. */
+int sa_batch_run_local(sa_batch_t* batch, void* local_keys_out_device, int sync);
+int sa_batch_merge_gathered(sa_batch_t* batch, const void* gathered_keys_device, int nranks, int sync);
+/* wait for completion; copies results to host: scores f32[B][k], docs u64[B][k] */
+int sa_batch_fetch(sa_batch_t* batch, float* scores_out, uint64_t* docs_out);
+/* HIP-event time of the scoring kernel of the last sa_batch_run (ms) and its algorithmic
+ * bytes: sum over queries of (sum_t 8*df_t + 4*n_docs)  (SURVEY.md 8d). */
+int sa_batch_profile(sa_batch_t* batch, double* kernel_ms_out, uint64_t* alg_bytes_out,
+                     uint64_t* postings_bytes_out);
+int sa_batch_destroy(sa_batch_t* batch);
+
+typedef struct sa_index_info {
+    uint64_t n_docs, doc_base, corpus_size, n_words, n_postings;
+    uint32_t n_terms, tile_docs, n_tiles, n_dir_terms;
+    uint64_t hbm_bytes;          /* device memory held by the index */
+    int device;
+    int dl_packed;
+} sa_index_info_t;
+int sa_index_info(sa_index_t* ix, sa_index_info_t* out);
+
+/* ------------------------------------------------------------------------------------- */
+/* Part 3 -- doc-range sharding: per-shard top-k exchange over RCCL (xGMI)                 */
+/* ------------------------------------------------------------------------------------- */
+/* The reference is single-process; there is no counterpart to cite.  One process per GPU, each
+ * holding the shard [doc_base, doc_base + n_docs) built with GLOBAL avg_doc_len / corpus_size /
+ * idf.  The only collective is an all-gather of B*k 8-byte ranking keys per batch. */
+#define SA_COMM_ID_BYTES 128
+int sa_comm_unique_id(char* id_out, int len);                    /* rank 0: ncclGetUniqueId */
+int sa_index_comm_init(sa_index_t* ix, int rank, int nranks, const char* id_bytes, int len);
+int sa_index_comm_destroy(sa_index_t* ix);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEARCHARRAY_HIP_H */

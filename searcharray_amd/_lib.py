@@ -1,0 +1,151 @@
+"""ctypes binding of libsearcharray_hip.so (C ABI: include/searcharray_hip.h).
+
+The library is the ONLY compute path of this package: there is no CPU fallback.  If the
+gfx950 shared object is missing or cannot be loaded, importing a compute entry point raises
+``SearchArrayHipError`` with build instructions.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_uint32, c_uint64,
+                    c_void_p)
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libsearcharray_hip.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+
+u64p = POINTER(c_uint64)
+u32p = POINTER(c_uint32)
+f32p = POINTER(c_float)
+i64p = POINTER(c_int64)
+
+
+class SearchArrayHipError(RuntimeError):
+    """Raised for any failure reported by (or while loading) the HIP library."""
+
+
+class IndexInfo(ctypes.Structure):
+    _fields_ = [("n_docs", c_uint64), ("doc_base", c_uint64), ("corpus_size", c_uint64),
+                ("n_words", c_uint64), ("n_postings", c_uint64),
+                ("n_terms", c_uint32), ("tile_docs", c_uint32), ("n_tiles", c_uint32),
+                ("n_dir_terms", c_uint32), ("hbm_bytes", c_uint64), ("device", c_int),
+                ("dl_packed", c_int)]
+
+
+# name -> (restype, argtypes).  Every symbol declared in include/searcharray_hip.h.
+PROTOTYPES = {
+    "sa_last_error": (c_char_p, []),
+    "sa_abi_version": (c_int, []),
+    "sa_device_count": (c_int, [POINTER(c_int)]),
+    "sa_device_name": (c_int, [c_int, ctypes.c_char_p, c_int]),
+    # Part 1
+    "sa_bm25_score": (c_int, [f32p, f32p, c_float, c_float, c_float, c_float, c_int64]),
+    "sa_as_dense": (c_int, [u64p, f32p, c_int64, f32p, c_int64]),
+    "sa_popcount64_reduce": (c_int, [u64p, c_int64, c_uint64, c_uint64, u64p, f32p, i64p]),
+    "sa_unique": (c_int, [u64p, c_int64, c_uint64, u64p, i64p]),
+    "sa_popcount64": (c_int, [u64p, c_int64, u64p]),
+    # Part 2
+    "sa_index_create": (c_int, [c_int, c_uint64, c_uint64, c_uint32, u64p, u64p, f32p, c_float,
+                                c_uint64, c_uint32, POINTER(c_void_p)]),
+    "sa_index_destroy": (c_int, [c_void_p]),
+    "sa_index_docfreq": (c_int, [c_void_p, c_uint32, u64p]),
+    "sa_index_docfreqs": (c_int, [c_void_p, u64p]),
+    "sa_index_termfreqs_dense": (c_int, [c_void_p, c_uint32, f32p]),
+    "sa_index_termfreqs_sparse": (c_int, [c_void_p, c_uint32, u64p, f32p, i64p]),
+    "sa_index_bm25_dense": (c_int, [c_void_p, u32p, f32p, c_int, c_float, c_float, f32p]),
+    "sa_index_info": (c_int, [c_void_p, POINTER(IndexInfo)]),
+    "sa_batch_create": (c_int, [c_void_p, u32p, f32p, c_int, c_int, c_int, c_float, c_float,
+                                POINTER(c_void_p)]),
+    "sa_batch_run": (c_int, [c_void_p, c_int]),
+    "sa_batch_run_local": (c_int, [c_void_p, c_void_p, c_int]),
+    "sa_batch_merge_gathered": (c_int, [c_void_p, c_void_p, c_int, c_int]),
+    "sa_batch_fetch": (c_int, [c_void_p, f32p, u64p]),
+    "sa_batch_profile": (c_int, [c_void_p, POINTER(c_double), u64p, u64p]),
+    "sa_batch_destroy": (c_int, [c_void_p]),
+    # Part 3
+    "sa_comm_unique_id": (c_int, [ctypes.c_char_p, c_int]),
+    "sa_index_comm_init": (c_int, [c_void_p, c_int, c_int, ctypes.c_char_p, c_int]),
+    "sa_index_comm_destroy": (c_int, [c_void_p]),
+}
+
+
+class HipApi:
+    """Bound C ABI.  ``api.sa_xxx(...)`` returns the raw status; ``api.call('sa_xxx', ...)``
+    raises SearchArrayHipError on a non-zero status."""
+
+    def __init__(self, cdll: ctypes.CDLL, path: str):
+        self._cdll = cdll
+        self.path = path
+        missing = []
+        for name, (restype, argtypes) in PROTOTYPES.items():
+            try:
+                fn = getattr(cdll, name)
+            except AttributeError:
+                missing.append(name)
+                continue
+            fn.restype = restype
+            fn.argtypes = argtypes
+            setattr(self, name, fn)
+        if missing:
+            raise SearchArrayHipError(f"{path} does not export: {', '.join(missing)}")
+
+    def last_error(self) -> str:
+        msg = self.sa_last_error()
+        return msg.decode("utf-8", "replace") if msg else ""
+
+    def call(self, name: str, *args) -> None:
+        rc = getattr(self, name)(*args)
+        if rc != 0:
+            raise SearchArrayHipError(f"{name} failed ({rc}): {self.last_error()}")
+
+
+def bind(cdll: ctypes.CDLL, path: str = "<cdll>") -> HipApi:
+    return HipApi(cdll, path)
+
+
+_api = None
+
+
+def api() -> HipApi:
+    """The gfx950 library, loaded on first use.  Fails loudly -- there is no other backend."""
+    global _api
+    if _api is None:
+        if not os.path.exists(LIB_PATH):
+            raise SearchArrayHipError(
+                f"{LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C searcharray_amd/csrc` (needs hipcc, --offload-arch=gfx950). "
+                f"searcharray_amd has no CPU fallback.")
+        try:
+            cdll = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise SearchArrayHipError(f"cannot load {LIB_PATH}: {e}") from e
+        _api = bind(cdll, LIB_PATH)
+    return _api
+
+
+# ---- numpy <-> ctypes helpers --------------------------------------------------------------
+def as_u64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def as_u32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def as_f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def p_u64(a: np.ndarray):
+    return a.ctypes.data_as(u64p)
+
+
+def p_u32(a: np.ndarray):
+    return a.ctypes.data_as(u32p)
+
+
+def p_f32(a: np.ndarray):
+    return a.ctypes.data_as(f32p)

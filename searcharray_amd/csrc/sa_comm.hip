@@ -1,0 +1,75 @@
+// sa_comm.hip -- Part 3 of the C ABI: the one exchange step of the doc-range-sharded path.
+//
+// The reference is single-process (no NCCL/MPI anywhere); sharding is new work.  Documents are
+// independent, so GPU g scores its doc range with GLOBAL statistics and the only data-path
+// collective is one all-gather of the per-shard top-k keys (B * k * 8 bytes per rank -- 20 KiB for
+// B = 256, k = 10), followed by a local k-way merge on every rank.  Latency-bound on xGMI, so one
+// collective per query BATCH, enqueued on the index stream behind the scoring kernels.
+#include "sa_index.hpp"
+#include "../../include/searcharray_hip.h"
+#include <rccl/rccl.h>
+#include <new>
+
+struct sa_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+};
+
+#define SA_NCCL(expr)                                                                        \
+    do {                                                                                     \
+        ncclResult_t r_ = (expr);                                                            \
+        if (r_ != ncclSuccess) {                                                             \
+            sa_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, ncclGetErrorString(r_)); \
+            return SA_ERR_COMM;                                                              \
+        }                                                                                    \
+    } while (0)
+
+extern "C" int sa_comm_unique_id(char* id_out, int len) {
+    SA_ARG(id_out && len >= (int)sizeof(ncclUniqueId), "id buffer must hold 128 bytes");
+    ncclUniqueId id;
+    SA_NCCL(ncclGetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return SA_OK;
+}
+
+extern "C" int sa_index_comm_init(sa_index_t* ix, int rank, int nranks, const char* id_bytes, int len) {
+    SA_ARG(ix && id_bytes && len >= (int)sizeof(ncclUniqueId), "bad argument");
+    SA_ARG(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank");
+    std::lock_guard<std::mutex> g(ix->mu);
+    SA_ARG(!ix->comm, "communicator already initialised");
+    SA_HIP(hipSetDevice(ix->device));
+    sa_comm* c = new (std::nothrow) sa_comm();
+    if (!c) { sa_set_error("out of host memory"); return SA_ERR_NOMEM; }
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof(id));
+    ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
+    if (r != ncclSuccess) {
+        sa_set_error("ncclCommInitRank failed: %s", ncclGetErrorString(r));
+        delete c;
+        return SA_ERR_COMM;
+    }
+    c->rank = rank; c->nranks = nranks;
+    ix->comm = c;
+    return SA_OK;
+}
+
+extern "C" int sa_index_comm_destroy(sa_index_t* ix) {
+    SA_ARG(ix, "null index");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (!ix->comm) return SA_OK;
+    hipSetDevice(ix->device);
+    hipStreamSynchronize(ix->stream);
+    ncclCommDestroy(ix->comm->comm);
+    delete ix->comm;
+    ix->comm = nullptr;
+    return SA_OK;
+}
+
+// count == 0: only report nranks.
+int sa_comm_allgather_topk(sa_index* ix, const u64* d_local, u64* d_gather, size_t count, int* nranks_out) {
+    if (!ix->comm) { sa_set_error("index has no communicator"); return SA_ERR_STATE; }
+    *nranks_out = ix->comm->nranks;
+    if (count == 0) return SA_OK;
+    SA_NCCL(ncclAllGather(d_local, d_gather, count, ncclUint64, ix->comm->comm, ix->stream));
+    return SA_OK;
+}

@@ -1,0 +1,398 @@
+// sa_index.hip -- index upload and on-device derivation of TF postings / document frequencies.
+//
+// Replaces, on the device, what the reference computes lazily per term on the host:
+//   df  = len(unique(words >> 36))                  reference unique.pyx:87-104, middle_out.py:521-528
+//   tf  = popcount64_reduce(words, 36, 0x3FFFF)     reference popcount.pyx:212-237, middle_out.py:501-512
+// for ALL terms at once (= PosnBitArray.warm(), middle_out.py:337-342, without the >255 cut-off):
+// one segmented popcount-reduce over the whole term-major word array, segment = (term, doc).
+#include "sa_index.hpp"
+#include "sa_scan.hpp"
+#include "../../include/searcharray_hip.h"
+
+#include <math.h>
+#include <new>
+
+// ---------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------
+static thread_local std::string g_sa_error;
+
+void sa_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_sa_error = buf;
+}
+
+extern "C" const char* sa_last_error(void) { return g_sa_error.c_str(); }
+extern "C" int sa_abi_version(void) { return SA_ABI_VERSION; }
+
+extern "C" int sa_device_count(int* out_count) {
+    SA_ARG(out_count, "out_count is null");
+    int n = 0;
+    SA_HIP(hipGetDeviceCount(&n));
+    *out_count = n;
+    return SA_OK;
+}
+
+extern "C" int sa_device_name(int device, char* buf, int buf_len) {
+    SA_ARG(buf && buf_len > 0, "buf");
+    hipDeviceProp_t p;
+    SA_HIP(hipGetDeviceProperties(&p, device));
+    snprintf(buf, (size_t)buf_len, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return SA_OK;
+}
+
+__global__ void __launch_bounds__(1024)
+sa_k_scan_chunks(u32* __restrict__ counts, u32 nchunks, u32* __restrict__ total_out) {
+    __shared__ u32 red[16];
+    u32 carry = 0;
+    for (u32 base = 0; base < nchunks; base += 1024) {
+        const u32 i = base + threadIdx.x;
+        const u32 v = i < nchunks ? counts[i] : 0u;
+        u32 tot;
+        const u32 ex = sa_block_excl_scan<16>(v, red, &tot);
+        if (i < nchunks) counts[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+int sa_index_scratch(sa_index* ix, size_t bytes, void** out) {
+    if (bytes > ix->scratch_bytes) {
+        if (ix->d_scratch) SA_HIP(hipFree(ix->d_scratch));
+        ix->d_scratch = nullptr;
+        ix->scratch_bytes = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        SA_HIP(hipMalloc(&ix->d_scratch, want));
+        ix->scratch_bytes = want;
+    }
+    *out = ix->d_scratch;
+    return SA_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------
+
+// bit i of term_start is set iff a (non-empty) term's words begin at i
+__global__ void sa_k_mark_term_starts(const u64* __restrict__ term_off, u32 n_terms, u32* __restrict__ bits) {
+    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < n_terms; t += gridDim.x * blockDim.x) {
+        const u64 a = term_off[t], b = term_off[t + 1];
+        if (a < b) atomicOr(&bits[a >> 5], 1u << (a & 31));
+    }
+}
+
+// A word is a posting head when it opens a new (term, doc) group.
+struct PostingHeads {
+    const u64* words;
+    const u32* term_start_bits;
+    const u64* term_off;
+    u32 n_terms;
+    u32 n_words;
+    const float* doc_lens;
+    u64* tfp;          // out: fat postings
+    u64* tf_off;       // out: tf_off[t] for non-empty terms (others fixed up on the host)
+    u32* err;          // out: set to 1 when a word names a doc id >= n_docs
+    u64 n_docs;
+    int dl_packed;
+
+    __device__ __forceinline__ bool is_start(u32 i) const { return (term_start_bits[i >> 5] >> (i & 31)) & 1u; }
+    __device__ __forceinline__ bool flag(u32 i) const {
+        if (i == 0 || is_start(i)) return true;
+        return (words[i] >> SA_KEY_SHIFT) != (words[i - 1] >> SA_KEY_SHIFT);
+    }
+    __device__ __forceinline__ void emit(u32 i, u32 pos) const {
+        const u64 w = words[i];
+        const u64 doc = w >> SA_KEY_SHIFT;
+        u32 tf = (u32)__popcll(w & SA_LSB_MASK);
+        for (u32 j = i + 1; j < n_words && !flag(j); j++) tf += (u32)__popcll(words[j] & SA_LSB_MASK);
+        u64 dl = 0;
+        if (doc >= n_docs) { *err = 1u; }
+        else if (dl_packed) dl = (u64)(u32)doc_lens[doc];
+        tfp[pos] = (doc << SA_KEY_SHIFT) | (dl << SA_LSB_BITS) | (u64)tf;
+        if (is_start(i)) {
+            // last term t with term_off[t] <= i (empty terms share the offset and sort before it)
+            u32 lo = 0, hi = n_terms;            // invariant: term_off[lo] <= i < term_off[hi]
+            while (hi - lo > 1) {
+                const u32 mid = lo + ((hi - lo) >> 1);
+                if (term_off[mid] <= (u64)i) lo = mid; else hi = mid;
+            }
+            tf_off[lo] = pos;
+        }
+    }
+};
+
+// tile directory: row s = term dir_terms[s]; entry j = first posting with doc >= j * tile_docs
+__global__ void sa_k_build_tile_dir(const u64* __restrict__ tfp, const u64* __restrict__ tf_off,
+                                    const u32* __restrict__ dir_terms, u32 n_dir_terms, u32 n_tiles,
+                                    u32 tile_docs, u32* __restrict__ tile_dir) {
+    const u64 total = (u64)n_dir_terms * (n_tiles + 1);
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (u64)gridDim.x * blockDim.x) {
+        const u32 s = (u32)(e / (n_tiles + 1)), j = (u32)(e % (n_tiles + 1));
+        const u32 t = dir_terms[s];
+        const u64 base = tf_off[t];
+        const u32 cnt = (u32)(tf_off[t + 1] - base);
+        const u64 key = ((u64)j * tile_docs) << SA_KEY_SHIFT;
+        tile_dir[e] = sa_lower_bound(tfp + base, 0, cnt, key, SA_KEY_MASK);
+    }
+}
+
+// dense tf: zero-filled by a memset, then scatter (as_dense, reference roaringish_ops.pyx:84-98)
+__global__ void sa_k_scatter_tf(const u64* __restrict__ tfp, u64 lo, u64 hi, float* __restrict__ out) {
+    for (u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (u64)gridDim.x * blockDim.x) {
+        const u64 p = tfp[i];
+        out[p >> SA_KEY_SHIFT] = (float)(u32)(p & SA_LSB_MASK);
+    }
+}
+
+__global__ void sa_k_split_postings(const u64* __restrict__ tfp, u64 lo, u64 hi, u64 doc_base,
+                                    u64* __restrict__ ids, float* __restrict__ tfs) {
+    for (u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (u64)gridDim.x * blockDim.x) {
+        const u64 p = tfp[i];
+        ids[i - lo] = (p >> SA_KEY_SHIFT) + doc_base;
+        tfs[i - lo] = (float)(u32)(p & SA_LSB_MASK);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------
+static void sa_index_free(sa_index* ix) {
+    if (!ix) return;
+    hipSetDevice(ix->device);
+    if (ix->d_words) hipFree(ix->d_words);
+    if (ix->d_term_off) hipFree(ix->d_term_off);
+    if (ix->d_tfp) hipFree(ix->d_tfp);
+    if (ix->d_tf_off) hipFree(ix->d_tf_off);
+    if (ix->d_doc_lens) hipFree(ix->d_doc_lens);
+    if (ix->d_tile_dir) hipFree(ix->d_tile_dir);
+    if (ix->d_dir_slot) hipFree(ix->d_dir_slot);
+    if (ix->d_scratch) hipFree(ix->d_scratch);
+    if (ix->stream) hipStreamDestroy(ix->stream);
+    delete ix;
+}
+
+static int sa_index_build(sa_index* ix, const u64* words, const u64* term_off, const float* doc_lens) {
+    const u32 V = ix->n_terms;
+    const u64 W = ix->n_words;
+    SA_HIP(hipSetDevice(ix->device));
+    SA_HIP(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+    hipStream_t st = ix->stream;
+
+    SA_HIP(hipMalloc(&ix->d_words, (W ? W : 1) * sizeof(u64)));
+    SA_HIP(hipMalloc(&ix->d_term_off, ((size_t)V + 1) * sizeof(u64)));
+    SA_HIP(hipMalloc(&ix->d_tf_off, ((size_t)V + 1) * sizeof(u64)));
+    SA_HIP(hipMalloc(&ix->d_doc_lens, (ix->n_docs ? ix->n_docs : 1) * sizeof(float)));
+    SA_HIP(hipMalloc(&ix->d_dir_slot, ((size_t)V + 1) * sizeof(u32)));
+    SA_HIP(hipMemcpyAsync(ix->d_words, words, W * sizeof(u64), hipMemcpyHostToDevice, st));
+    SA_HIP(hipMemcpyAsync(ix->d_term_off, term_off, ((size_t)V + 1) * sizeof(u64), hipMemcpyHostToDevice, st));
+    SA_HIP(hipMemcpyAsync(ix->d_doc_lens, doc_lens, ix->n_docs * sizeof(float), hipMemcpyHostToDevice, st));
+
+    // ---- derive postings ----
+    const u32 nchunks = sa_compact_chunks((u32)W);
+    const size_t bits_words = (size_t)(W / 32 + 2);
+    u32 *d_bits = nullptr, *d_chunks = nullptr, *d_total = nullptr;
+    SA_HIP(hipMalloc(&d_bits, bits_words * sizeof(u32)));
+    SA_HIP(hipMalloc(&d_chunks, ((size_t)nchunks + 1) * sizeof(u32)));
+    SA_HIP(hipMalloc(&d_total, 2 * sizeof(u32)));
+    SA_HIP(hipMemsetAsync(d_total, 0, 2 * sizeof(u32), st));
+    SA_HIP(hipMemsetAsync(d_bits, 0, bits_words * sizeof(u32), st));
+    SA_HIP(hipMemsetAsync(ix->d_tf_off, 0xFF, ((size_t)V + 1) * sizeof(u64), st));
+    if (V) hipLaunchKernelGGL(sa_k_mark_term_starts, dim3(sa_div_up(V, 256) < 1024 ? sa_div_up(V, 256) : 1024),
+                              dim3(256), 0, st, ix->d_term_off, V, d_bits);
+
+    // worst case one posting per word; allocate exactly after counting
+    PostingHeads ph;
+    ph.words = ix->d_words; ph.term_start_bits = d_bits; ph.term_off = ix->d_term_off;
+    ph.n_terms = V; ph.n_words = (u32)W; ph.doc_lens = ix->d_doc_lens;
+    ph.tfp = nullptr; ph.tf_off = ix->d_tf_off; ph.dl_packed = ix->dl_packed ? 1 : 0;
+    ph.err = d_total + 1; ph.n_docs = ix->n_docs;
+    u32 P = 0;
+    if (W) {
+        const u32 grid = sa_compact_grid((u32)W);
+        hipLaunchKernelGGL((sa_k_compact_count<PostingHeads>), dim3(grid), dim3(SA_CT), 0, st, ph,
+                           (const u32*)nullptr, (u32)W, d_chunks);
+        hipLaunchKernelGGL(sa_k_scan_chunks, dim3(1), dim3(1024), 0, st, d_chunks, nchunks, d_total);
+        SA_HIP(hipMemcpyAsync(&P, d_total, sizeof(u32), hipMemcpyDeviceToHost, st));
+        SA_HIP(hipStreamSynchronize(st));
+        SA_HIP(hipMalloc(&ix->d_tfp, ((size_t)P + 1) * sizeof(u64)));
+        ph.tfp = ix->d_tfp;
+        hipLaunchKernelGGL((sa_k_compact_emit<PostingHeads>), dim3(grid), dim3(SA_CT), 0, st, ph,
+                           (const u32*)nullptr, (u32)W, d_chunks);
+    } else {
+        SA_HIP(hipMalloc(&ix->d_tfp, sizeof(u64)));
+    }
+    ix->n_postings = P;
+
+    // tf_off: non-empty terms were written by the kernel; empty terms take the next offset
+    ix->h_tf_off.resize((size_t)V + 1);
+    SA_HIP(hipMemcpyAsync(ix->h_tf_off.data(), ix->d_tf_off, ((size_t)V + 1) * sizeof(u64), hipMemcpyDeviceToHost, st));
+    u32 bad_doc = 0;
+    SA_HIP(hipMemcpyAsync(&bad_doc, d_total + 1, sizeof(u32), hipMemcpyDeviceToHost, st));
+    SA_HIP(hipStreamSynchronize(st));
+    SA_HIP(hipGetLastError());
+    if (bad_doc) {
+        sa_set_error("words reference a doc id >= n_docs (%llu)", (unsigned long long)ix->n_docs);
+        return SA_ERR_ARG;
+    }
+    ix->h_tf_off[V] = P;
+    for (i64 t = (i64)V - 1; t >= 0; t--)
+        if (ix->h_term_off[t] == ix->h_term_off[t + 1]) ix->h_tf_off[t] = ix->h_tf_off[t + 1];
+    for (u32 t = 0; t < V; t++) {
+        if (ix->h_tf_off[t] > ix->h_tf_off[t + 1]) {
+            sa_set_error("internal: tf offsets not monotone at term %u (words not sorted by doc within a term?)", t);
+            return SA_ERR_STATE;
+        }
+    }
+    SA_HIP(hipMemcpyAsync(ix->d_tf_off, ix->h_tf_off.data(), ((size_t)V + 1) * sizeof(u64), hipMemcpyHostToDevice, st));
+    SA_HIP(hipFree(d_bits));
+    SA_HIP(hipFree(d_chunks));
+    SA_HIP(hipFree(d_total));
+
+    // ---- tile directory for frequent terms ----
+    ix->n_tiles = ix->n_docs ? sa_div_up(ix->n_docs, ix->tile_docs) : 0;
+    ix->dir_min_df = 4 * (ix->n_tiles > 0 ? ix->n_tiles : 1);
+    std::vector<u32> slot((size_t)V + 1, 0xFFFFFFFFu), dir_terms;
+    for (u32 t = 0; t < V; t++) {
+        const u64 df = ix->h_tf_off[t + 1] - ix->h_tf_off[t];
+        if (df >= ix->dir_min_df) {
+            slot[t] = (u32)dir_terms.size();
+            dir_terms.push_back(t);
+        }
+    }
+    ix->n_dir_terms = (u32)dir_terms.size();
+    SA_HIP(hipMemcpyAsync(ix->d_dir_slot, slot.data(), ((size_t)V + 1) * sizeof(u32), hipMemcpyHostToDevice, st));
+    const u64 entries = (u64)ix->n_dir_terms * (ix->n_tiles + 1);
+    SA_HIP(hipMalloc(&ix->d_tile_dir, (entries ? entries : 1) * sizeof(u32)));
+    if (entries) {
+        u32* d_dir_terms = nullptr;
+        SA_HIP(hipMalloc(&d_dir_terms, dir_terms.size() * sizeof(u32)));
+        SA_HIP(hipMemcpyAsync(d_dir_terms, dir_terms.data(), dir_terms.size() * sizeof(u32), hipMemcpyHostToDevice, st));
+        const u32 grid = entries / 256 + 1 < 65536 ? (u32)(entries / 256 + 1) : 65536;
+        hipLaunchKernelGGL(sa_k_build_tile_dir, dim3(grid), dim3(256), 0, st, ix->d_tfp, ix->d_tf_off,
+                           d_dir_terms, ix->n_dir_terms, ix->n_tiles, ix->tile_docs, ix->d_tile_dir);
+        SA_HIP(hipStreamSynchronize(st));
+        SA_HIP(hipFree(d_dir_terms));
+    }
+    SA_HIP(hipStreamSynchronize(st));
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+
+extern "C" int sa_index_create(int device, uint64_t n_docs, uint64_t doc_base, uint32_t n_terms,
+                               const uint64_t* words, const uint64_t* term_off, const float* doc_lens,
+                               float avg_doc_len, uint64_t corpus_size, uint32_t tile_docs,
+                               sa_index_t** out) {
+    SA_ARG(out, "out is null");
+    SA_ARG(term_off, "term_off is null");
+    SA_ARG(n_docs == 0 || doc_lens, "doc_lens is null");
+    SA_ARG(n_docs <= (1ull << 28), "a shard holds at most 2^28 docs (28-bit roaringish key)");
+    if (tile_docs == 0) tile_docs = 16384;
+    SA_ARG(tile_docs == 1024 || tile_docs == 8192 || tile_docs == 16384 || tile_docs == 32768,
+           "tile_docs must be 1024, 8192, 16384 or 32768");
+    const u64 W = term_off[n_terms];
+    SA_ARG(term_off[0] == 0, "term_off[0] must be 0");
+    SA_ARG(W == 0 || words, "words is null");
+    SA_ARG(W < 0xFFFFF000ull, "more than 2^32 words per shard is not supported yet");
+    for (u32 t = 0; t < n_terms; t++) SA_ARG(term_off[t] <= term_off[t + 1], "term_off must be non-decreasing");
+
+    sa_index* ix = new (std::nothrow) sa_index();
+    if (!ix) { sa_set_error("out of host memory"); return SA_ERR_NOMEM; }
+    ix->device = device;
+    ix->n_docs = n_docs; ix->doc_base = doc_base; ix->corpus_size = corpus_size;
+    ix->n_terms = n_terms; ix->avg_doc_len = avg_doc_len; ix->n_words = W;
+    ix->tile_docs = tile_docs;
+    ix->h_term_off.assign(term_off, term_off + n_terms + 1);
+    // doc lengths ride in the postings when they are integers that fit 18 bits
+    // (always true for indexes built by SearchArray.index: reference indexing.py:141-142)
+    ix->dl_packed = true;
+    for (u64 d = 0; d < n_docs; d++) {
+        const float v = doc_lens[d];
+        if (!(v >= 0.f) || v > 262143.f || v != floorf(v)) { ix->dl_packed = false; break; }
+    }
+    int rc = sa_index_build(ix, words, term_off, doc_lens);
+    if (rc != SA_OK) { sa_index_free(ix); return rc; }
+    *out = ix;
+    return SA_OK;
+}
+
+extern "C" int sa_index_destroy(sa_index_t* ix) {
+    if (!ix) return SA_OK;
+    sa_index_free(ix);
+    return SA_OK;
+}
+
+extern "C" int sa_index_docfreq(sa_index_t* ix, uint32_t term, uint64_t* out) {
+    SA_ARG(ix && out, "null argument");
+    *out = term < ix->n_terms ? ix->h_tf_off[term + 1] - ix->h_tf_off[term] : 0;
+    return SA_OK;
+}
+
+extern "C" int sa_index_docfreqs(sa_index_t* ix, uint64_t* out) {
+    SA_ARG(ix && out, "null argument");
+    for (u32 t = 0; t < ix->n_terms; t++) out[t] = ix->h_tf_off[t + 1] - ix->h_tf_off[t];
+    return SA_OK;
+}
+
+extern "C" int sa_index_termfreqs_dense(sa_index_t* ix, uint32_t term, float* out) {
+    SA_ARG(ix && out, "null argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    SA_HIP(hipSetDevice(ix->device));
+    void* scratch;
+    SA_TRY(sa_index_scratch(ix, (ix->n_docs + 1) * sizeof(float), &scratch));
+    float* d_out = (float*)scratch;
+    SA_HIP(hipMemsetAsync(d_out, 0, ix->n_docs * sizeof(float), ix->stream));
+    if (term < ix->n_terms) {
+        const u64 lo = ix->h_tf_off[term], hi = ix->h_tf_off[term + 1];
+        if (hi > lo) {
+            const u32 grid = sa_div_up(hi - lo, 256) < 4096 ? sa_div_up(hi - lo, 256) : 4096;
+            hipLaunchKernelGGL(sa_k_scatter_tf, dim3(grid), dim3(256), 0, ix->stream, ix->d_tfp, lo, hi, d_out);
+        }
+    }
+    SA_HIP(hipMemcpyAsync(out, d_out, ix->n_docs * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    SA_HIP(hipStreamSynchronize(ix->stream));
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+
+extern "C" int sa_index_termfreqs_sparse(sa_index_t* ix, uint32_t term, uint64_t* doc_ids_out,
+                                         float* tfs_out, int64_t* n_out) {
+    SA_ARG(ix && n_out, "null argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    *n_out = 0;
+    if (term >= ix->n_terms) return SA_OK;
+    const u64 lo = ix->h_tf_off[term], hi = ix->h_tf_off[term + 1];
+    const u64 n = hi - lo;
+    if (n == 0) return SA_OK;
+    SA_ARG(doc_ids_out && tfs_out, "null output");
+    SA_HIP(hipSetDevice(ix->device));
+    void* scratch;
+    SA_TRY(sa_index_scratch(ix, n * (sizeof(u64) + sizeof(float)) + 64, &scratch));
+    u64* d_ids = (u64*)scratch;
+    float* d_tfs = (float*)(d_ids + n);
+    const u32 grid = sa_div_up(n, 256) < 4096 ? sa_div_up(n, 256) : 4096;
+    hipLaunchKernelGGL(sa_k_split_postings, dim3(grid), dim3(256), 0, ix->stream, ix->d_tfp, lo, hi,
+                       ix->doc_base, d_ids, d_tfs);
+    SA_HIP(hipMemcpyAsync(doc_ids_out, d_ids, n * sizeof(u64), hipMemcpyDeviceToHost, ix->stream));
+    SA_HIP(hipMemcpyAsync(tfs_out, d_tfs, n * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    SA_HIP(hipStreamSynchronize(ix->stream));
+    SA_HIP(hipGetLastError());
+    *n_out = (int64_t)n;
+    return SA_OK;
+}
+
+extern "C" int sa_index_info(sa_index_t* ix, sa_index_info_t* out) {
+    SA_ARG(ix && out, "null argument");
+    out->n_docs = ix->n_docs; out->doc_base = ix->doc_base; out->corpus_size = ix->corpus_size;
+    out->n_words = ix->n_words; out->n_postings = ix->n_postings;
+    out->n_terms = ix->n_terms; out->tile_docs = ix->tile_docs; out->n_tiles = ix->n_tiles;
+    out->n_dir_terms = ix->n_dir_terms;
+    out->device = ix->device;
+    out->dl_packed = ix->dl_packed ? 1 : 0;
+    out->hbm_bytes = ix->n_words * 8 + ix->n_postings * 8 + ((u64)ix->n_terms + 1) * 20 + ix->n_docs * 4 +
+                     (u64)ix->n_dir_terms * (ix->n_tiles + 1) * 4 + ix->scratch_bytes;
+    return SA_OK;
+}

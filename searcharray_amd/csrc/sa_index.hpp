@@ -1,0 +1,61 @@
+// sa_index.hpp -- the HBM-resident index object behind the C ABI (include/searcharray_hip.h).
+//
+// Resident arrays (one GPU = one doc-range shard [doc_base, doc_base + n_docs), doc ids in
+// the arrays are shard-local):
+//   words     u64[W]      roaringish positional words, term-major (reference ArrayDict layout,
+//                         reference searcharray/phrase/memmap_arrays.py:15-56)
+//   term_off  u64[V+1]    words of term t = words[term_off[t] : term_off[t+1]]
+//   tfp       u64[P]      derived "fat" TF postings, term-major, doc-sorted:
+//                         doc << 36 | doc_len << 18 | tf   (28 + 18 + 18 bits)
+//                         = what the reference caches per term as (doc_ids, term_freqs)
+//                         (reference middle_out.py:501-512) with the doc length riding along so
+//                         scoring is one coalesced 64-bit stream with no doc_lens gather.
+//   tf_off    u64[V+1]    postings of term t; df_t = tf_off[t+1] - tf_off[t]
+//   tile_dir  u32[S][n_tiles+1]  for the S terms with df >= dir_min_df: first posting (relative to
+//                         tf_off[t]) whose doc >= tile * tile_docs -- lets a workgroup find its
+//                         slice of a posting list with one load instead of a search.
+//   dir_slot  u32[V]      row of term t in tile_dir, or 0xFFFFFFFF
+//   doc_lens  f32[n_docs]
+#pragma once
+#include "sa_common.hpp"
+#include <mutex>
+#include <vector>
+
+struct sa_comm;   // RCCL communicator wrapper (sa_comm.hip)
+
+struct sa_index {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    u64 n_docs = 0, doc_base = 0, corpus_size = 0;
+    u32 n_terms = 0;
+    float avg_doc_len = 0.f;
+    u64 n_words = 0, n_postings = 0;
+    bool dl_packed = true;          // doc lengths are integers < 2^18 and ride in the postings
+
+    u64* d_words = nullptr;
+    u64* d_term_off = nullptr;
+    u64* d_tfp = nullptr;
+    u64* d_tf_off = nullptr;
+    float* d_doc_lens = nullptr;
+
+    u32 tile_docs = 0, n_tiles = 0, dir_min_df = 0, n_dir_terms = 0;
+    u32* d_tile_dir = nullptr;
+    u32* d_dir_slot = nullptr;
+
+    std::vector<u64> h_term_off, h_tf_off;
+
+    // reusable device scratch (grown on demand, guarded by mu)
+    void* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+
+    sa_comm* comm = nullptr;
+
+    // profile counters (sa_index_stats)
+    double last_kernel_ms = 0.0;
+    u64 last_alg_bytes = 0;
+
+    std::mutex mu;                  // one in-flight call per index handle (C ABI is re-entrant
+                                    // across handles and serialised per handle)
+};
+
+int sa_index_scratch(sa_index* ix, size_t bytes, void** out);

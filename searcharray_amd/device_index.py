@@ -1,0 +1,186 @@
+"""HBM-resident index and query batches (Part 2/3 of the C ABI) as Python objects.
+
+``DeviceIndex`` is the device-side counterpart of the reference's ``PosnBitArray``
+(searcharray/phrase/middle_out.py:320): it owns the roaringish words of one doc-range shard
+in HBM plus the derived TF postings, and answers docfreq / termfreqs / BM25 / phrase queries
+with GPU kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import IndexInfo, as_f32, as_u32, as_u64, p_f32, p_u32, p_u64
+
+NO_TERM = 0xFFFFFFFF
+NO_DOC = 0xFFFFFFFFFFFFFFFF
+
+
+def compute_idf(num_docs, dfs) -> np.float32:
+    """idf exactly as the reference computes it on the host: float64 numpy math, summed over
+    the tokens of the phrase, truncated to float32 at the native call
+    (searcharray/similarity.py:19-21, bm25.pyx:31)."""
+    dfs = np.asarray(dfs)
+    return np.float32(np.sum(np.log(1 + (num_docs - dfs + 0.5) / (dfs + 0.5))))
+
+
+class DeviceIndex:
+    def __init__(self, words: np.ndarray, term_off: np.ndarray, doc_lens: np.ndarray,
+                 avg_doc_len: Optional[float] = None, corpus_size: Optional[int] = None,
+                 doc_base: int = 0, device: int = 0, tile_docs: int = 0, api=None,
+                 global_df: Optional[np.ndarray] = None):
+        self.api = api if api is not None else _lib.api()
+        words = as_u64(words)
+        term_off = as_u64(term_off)
+        doc_lens = as_f32(doc_lens)
+        self.n_docs = len(doc_lens)
+        self.n_terms = len(term_off) - 1
+        self.doc_base = int(doc_base)
+        self.avg_doc_len = np.float32(np.mean(doc_lens) if avg_doc_len is None and self.n_docs
+                                      else (avg_doc_len or 0.0))
+        self.corpus_size = int(self.n_docs if corpus_size is None else corpus_size)
+        self._h = ctypes.c_void_p()
+        self.api.call("sa_index_create", int(device), self.n_docs, self.doc_base, self.n_terms,
+                      p_u64(words), p_u64(term_off), p_f32(doc_lens), self.avg_doc_len,
+                      self.corpus_size, int(tile_docs), ctypes.byref(self._h))
+        self._local_df = None
+        self._global_df = None if global_df is None else np.asarray(global_df, dtype=np.uint64)
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.api.sa_index_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self) -> IndexInfo:
+        out = IndexInfo()
+        self.api.call("sa_index_info", self._h, ctypes.byref(out))
+        return out
+
+    # -- statistics
+    def docfreqs(self) -> np.ndarray:
+        """Shard-local document frequency of every term (uint64[n_terms])."""
+        if self._local_df is None:
+            out = np.empty(self.n_terms, dtype=np.uint64)
+            if self.n_terms:
+                self.api.call("sa_index_docfreqs", self._h, p_u64(out))
+            self._local_df = out
+        return self._local_df
+
+    def set_global_docfreqs(self, df: np.ndarray):
+        """Sharded operation: BM25 idf must use corpus-wide df (sum over shards)."""
+        self._global_df = np.asarray(df, dtype=np.uint64)
+
+    def docfreq(self, term: int) -> np.uint64:
+        df = self._global_df if self._global_df is not None else self.docfreqs()
+        return df[term] if 0 <= term < self.n_terms else np.uint64(0)
+
+    # -- term frequencies
+    def termfreqs_dense(self, term: int) -> np.ndarray:
+        out = np.empty(self.n_docs, dtype=np.float32)
+        t = term if 0 <= term < self.n_terms else NO_TERM
+        self.api.call("sa_index_termfreqs_dense", self._h, t, p_f32(out))
+        return out
+
+    def termfreqs_sparse(self, term: int) -> Tuple[np.ndarray, np.ndarray]:
+        if not (0 <= term < self.n_terms):
+            return np.empty(0, np.uint64), np.empty(0, np.float32)
+        df = int(self.docfreqs()[term])
+        ids = np.empty(df, dtype=np.uint64)
+        tfs = np.empty(df, dtype=np.float32)
+        n = _lib.c_int64(0)
+        self.api.call("sa_index_termfreqs_sparse", self._h, term, p_u64(ids), p_f32(tfs), n)
+        return ids[:n.value], tfs[:n.value]
+
+    # -- scoring
+    def idfs(self, terms: Sequence[int]) -> np.ndarray:
+        return np.asarray([compute_idf(self.corpus_size, np.asarray([self.docfreq(int(t))]))
+                           if 0 <= int(t) < self.n_terms else np.float32(0) for t in terms],
+                          dtype=np.float32)
+
+    def bm25_dense(self, terms: Sequence[int], k1: float = 1.2, b: float = 0.75,
+                   idf: Optional[np.ndarray] = None) -> np.ndarray:
+        """sum_t BM25(t) in query-term order, float32[n_docs] (one kernel launch)."""
+        tarr = np.asarray([int(t) if 0 <= int(t) < self.n_terms else NO_TERM for t in terms],
+                          dtype=np.uint32)
+        idf = self.idfs(terms) if idf is None else as_f32(idf)
+        out = np.empty(self.n_docs, dtype=np.float32)
+        self.api.call("sa_index_bm25_dense", self._h, p_u32(tarr), p_f32(idf), len(tarr),
+                      np.float32(k1), np.float32(b), p_f32(out))
+        return out
+
+    def batch(self, queries: np.ndarray, k: int = 10, k1: float = 1.2, b: float = 0.75,
+              idf: Optional[np.ndarray] = None) -> "QueryBatch":
+        return QueryBatch(self, queries, k=k, k1=k1, b=b, idf=idf)
+
+    # -- multi-GPU
+    def comm_init(self, rank: int, nranks: int, unique_id: bytes):
+        self.api.call("sa_index_comm_init", self._h, rank, nranks, unique_id, len(unique_id))
+
+    def comm_destroy(self):
+        self.api.call("sa_index_comm_destroy", self._h)
+
+
+class QueryBatch:
+    """B queries x T terms resident on the device; ``run()`` is one pass of the hot path."""
+
+    def __init__(self, index: DeviceIndex, queries: np.ndarray, k: int = 10, k1: float = 1.2,
+                 b: float = 0.75, idf: Optional[np.ndarray] = None):
+        self.index = index
+        self.api = index.api
+        q = np.asarray(queries, dtype=np.int64)
+        if q.ndim != 2:
+            raise ValueError("queries must be [B][T] term ids")
+        self.B, self.T = q.shape
+        self.k = int(k)
+        terms = np.where((q >= 0) & (q < index.n_terms), q, NO_TERM).astype(np.uint32)
+        if idf is None:
+            flat = index.idfs(q.reshape(-1))
+            idf = flat.reshape(self.B, self.T)
+        idf = as_f32(idf)
+        self._h = ctypes.c_void_p()
+        self.api.call("sa_batch_create", index._h, p_u32(as_u32(terms)), p_f32(idf), self.B, self.T,
+                      self.k, np.float32(k1), np.float32(b), ctypes.byref(self._h))
+
+    def run(self, sync: bool = True):
+        self.api.call("sa_batch_run", self._h, 1 if sync else 0)
+
+    def run_local(self, local_keys_device_ptr: int = 0, sync: bool = True):
+        self.api.call("sa_batch_run_local", self._h, ctypes.c_void_p(local_keys_device_ptr), 1 if sync else 0)
+
+    def merge_gathered(self, gathered_device_ptr: int, nranks: int, sync: bool = True):
+        self.api.call("sa_batch_merge_gathered", self._h, ctypes.c_void_p(gathered_device_ptr), nranks,
+                      1 if sync else 0)
+
+    def fetch(self) -> Tuple[np.ndarray, np.ndarray]:
+        scores = np.empty((self.B, self.k), dtype=np.float32)
+        docs = np.empty((self.B, self.k), dtype=np.uint64)
+        self.api.call("sa_batch_fetch", self._h, p_f32(scores), p_u64(docs))
+        return scores, docs
+
+    def profile(self) -> Tuple[float, int, int]:
+        ms = _lib.c_double(0)
+        alg = _lib.c_uint64(0)
+        post = _lib.c_uint64(0)
+        self.api.call("sa_batch_profile", self._h, ctypes.byref(ms), ctypes.byref(alg), ctypes.byref(post))
+        return ms.value, alg.value, post.value
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.api.sa_batch_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

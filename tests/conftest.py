@@ -23,3 +23,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope="module", params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def api(request):
+    """C-ABI binding under test: host-emulated kernels (CPU suite) or the real gfx950 library."""
+    if request.param == "emu":
+        from tests.emu import emu_api
+        return emu_api()
+    from searcharray_amd import _lib
+    return _lib.api()

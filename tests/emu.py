@@ -1,0 +1,23 @@
+"""TEST INFRASTRUCTURE: builds and binds the host-emulated kernel library (tests/hipemu).
+
+The emulated library compiles the unmodified searcharray_amd/csrc/*.hip sources with g++ against
+a fiber-based HIP stand-in so kernel LOGIC is checked on machines without a GPU.  It is never
+used by the package itself (searcharray_amd._lib only loads the gfx950 build).
+"""
+import ctypes
+import os
+import subprocess
+
+from searcharray_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_SO = os.path.join(ROOT, "tests", "_emu", "libsearcharray_emu.so")
+_api = None
+
+
+def emu_api():
+    global _api
+    if _api is None:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "searcharray_amd", "csrc"), "emu"])
+        _api = _lib.bind(ctypes.CDLL(EMU_SO), EMU_SO)
+    return _api

@@ -1,0 +1,323 @@
+// tests/hipemu/hip/hip_runtime.h -- TEST INFRASTRUCTURE ONLY.
+//
+// A tiny host-side stand-in for the subset of the HIP runtime + device language that
+// searcharray_amd/csrc/*.hip uses, so the UNMODIFIED kernel sources can be compiled with
+// g++ (-I tests/hipemu -x c++) and their logic exercised on a machine without a GPU
+// (tests/test_emu_*.py).  The product never sees this header: the real build uses hipcc
+// and /opt/rocm's <hip/hip_runtime.h>, and searcharray_amd/_lib.py only ever loads the
+// gfx950 library.
+//
+// Execution model: blocks run one after another; the threads of a block are cooperative
+// fibers (ucontext) scheduled round-robin by one OS thread.  A fiber runs until it reaches
+// __syncthreads() or a wave-collective (__shfl*, __ballot, __any, __all, readfirstlane),
+// which makes the schedule deterministic and adversarial (thread 0 runs a whole phase
+// before thread 1 starts), so missing barriers show up as wrong results.  Wave width is 64.
+// A wave collective completes when every live lane of the wave is blocked; the lanes
+// blocked on the collective are its participants (models the exec mask under divergence).
+#pragma once
+#include <ucontext.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <chrono>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3_emu { unsigned x, y, z; };
+
+typedef int hipError_t;
+typedef struct hipemu_stream* hipStream_t;
+typedef struct hipemu_event* hipEvent_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost,
+                     hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum { hipStreamNonBlocking = 1, hipEventDefault = 0 };
+
+struct hipDeviceProp_t {
+    char name[256]; char gcnArchName[256]; int multiProcessorCount; size_t totalGlobalMem;
+};
+
+namespace hipemu {
+
+constexpr int WAVE = 64;
+enum State { RUNNABLE, WAIT_BLOCK, WAIT_WAVE, DONE };
+enum WaveOp { OP_NONE, OP_SHFL, OP_BALLOT, OP_FIRST };
+
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    State state = DONE;
+    uint3_emu tid{0, 0, 0};
+    int linear = 0;
+    // wave-collective mailbox
+    WaveOp op = OP_NONE;
+    uint64_t val = 0;      // posted value (shfl payload / predicate)
+    int src = 0;           // shfl source lane
+    uint64_t result = 0;
+};
+
+struct Machine {
+    std::vector<Fiber> fibers;
+    ucontext_t sched;
+    Fiber* cur = nullptr;
+    dim3 gridDim, blockDim, blockIdx;
+    std::function<void()> body;
+    size_t stack_size = 128 * 1024;
+};
+
+inline Machine& M() { static Machine m; return m; }
+
+inline void yield_to_sched() {
+    Machine& m = M();
+    swapcontext(&m.cur->ctx, &m.sched);
+}
+
+inline void fiber_entry() {
+    Machine& m = M();
+    m.body();
+    m.cur->state = DONE;
+    swapcontext(&m.cur->ctx, &m.sched);
+}
+
+inline void die(const char* msg) {
+    fprintf(stderr, "[hipemu] FATAL: %s\n", msg);
+    abort();
+}
+
+inline void run_block() {
+    Machine& m = M();
+    const int nthreads = (int)(m.blockDim.x * m.blockDim.y * m.blockDim.z);
+    if ((int)m.fibers.size() < nthreads) m.fibers.resize(nthreads);
+    for (int i = 0; i < nthreads; i++) {
+        Fiber& f = m.fibers[i];
+        if (!f.stack) f.stack = (char*)malloc(m.stack_size);
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = m.stack_size;
+        f.ctx.uc_link = &m.sched;
+        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+        f.state = RUNNABLE;
+        f.op = OP_NONE;
+        f.linear = i;
+        f.tid.x = i % m.blockDim.x;
+        f.tid.y = (i / m.blockDim.x) % m.blockDim.y;
+        f.tid.z = i / (m.blockDim.x * m.blockDim.y);
+    }
+    int alive = nthreads;
+    while (alive > 0) {
+        bool progressed = false;
+        for (int i = 0; i < nthreads; i++) {
+            Fiber& f = m.fibers[i];
+            if (f.state != RUNNABLE) continue;
+            m.cur = &f;
+            swapcontext(&m.sched, &f.ctx);
+            progressed = true;
+            if (f.state == DONE) alive--;
+        }
+        if (alive == 0) break;
+        // every live fiber is blocked now: resolve wave collectives
+        bool resolved = false;
+        const int nwaves = (nthreads + WAVE - 1) / WAVE;
+        for (int w = 0; w < nwaves; w++) {
+            int lo = w * WAVE, hi = lo + WAVE < nthreads ? lo + WAVE : nthreads;
+            WaveOp op = OP_NONE;
+            for (int i = lo; i < hi; i++) {
+                Fiber& f = m.fibers[i];
+                if (f.state == WAIT_WAVE) {
+                    if (op == OP_NONE) op = f.op;
+                    else if (op != f.op) die("lanes of one wave blocked on different collectives");
+                }
+            }
+            if (op == OP_NONE) continue;
+            uint64_t ballot = 0;
+            int first = -1;
+            for (int i = lo; i < hi; i++) {
+                Fiber& f = m.fibers[i];
+                if (f.state != WAIT_WAVE) continue;
+                if (first < 0) first = i;
+                if (f.val) ballot |= (1ull << (i - lo));
+            }
+            for (int i = lo; i < hi; i++) {
+                Fiber& f = m.fibers[i];
+                if (f.state != WAIT_WAVE) continue;
+                if (op == OP_BALLOT) f.result = ballot;
+                else if (op == OP_FIRST) f.result = m.fibers[first].val;
+                else {  // OP_SHFL
+                    int s = lo + (f.src & (WAVE - 1));
+                    if (s < hi && m.fibers[s].state == WAIT_WAVE) f.result = m.fibers[s].val;
+                    else f.result = f.val;   // reading an inactive lane: keep own value
+                }
+            }
+            for (int i = lo; i < hi; i++) {
+                Fiber& f = m.fibers[i];
+                if (f.state == WAIT_WAVE) { f.state = RUNNABLE; f.op = OP_NONE; }
+            }
+            resolved = true;
+        }
+        if (resolved) continue;
+        // no wave work: every live fiber must be at the block barrier
+        bool all_block = true;
+        for (int i = 0; i < nthreads; i++)
+            if (m.fibers[i].state != WAIT_BLOCK && m.fibers[i].state != DONE) all_block = false;
+        if (all_block) {
+            for (int i = 0; i < nthreads; i++)
+                if (m.fibers[i].state == WAIT_BLOCK) m.fibers[i].state = RUNNABLE;
+            continue;
+        }
+        if (!progressed) die("deadlock: no runnable fiber");
+    }
+}
+
+inline void launch(dim3 grid, dim3 block, std::function<void()> body) {
+    Machine& m = M();
+    m.gridDim = grid;
+    m.blockDim = block;
+    m.body = std::move(body);
+    for (unsigned z = 0; z < grid.z; z++)
+        for (unsigned y = 0; y < grid.y; y++)
+            for (unsigned x = 0; x < grid.x; x++) {
+                m.blockIdx = dim3(x, y, z);
+                run_block();
+            }
+}
+
+inline uint64_t wave_collective(WaveOp op, uint64_t val, int src) {
+    Machine& m = M();
+    Fiber* f = m.cur;
+    f->op = op; f->val = val; f->src = src; f->state = WAIT_WAVE;
+    yield_to_sched();
+    return f->result;
+}
+
+template <class T> inline uint64_t to_bits(T v) { uint64_t b = 0; memcpy(&b, &v, sizeof(T)); return b; }
+template <class T> inline T from_bits(uint64_t b) { T v; memcpy(&v, &b, sizeof(T)); return v; }
+
+}  // namespace hipemu
+
+#define threadIdx (hipemu::M().cur->tid)
+#define blockIdx (hipemu::M().blockIdx)
+#define blockDim (hipemu::M().blockDim)
+#define gridDim (hipemu::M().gridDim)
+#define warpSize 64
+
+inline void __syncthreads() {
+    hipemu::M().cur->state = hipemu::WAIT_BLOCK;
+    hipemu::yield_to_sched();
+}
+inline void __threadfence() {}
+inline void __threadfence_block() {}
+
+inline int __lane_id() { return hipemu::M().cur->linear & 63; }
+
+template <class T> inline T __shfl(T v, int src, int width = 64) {
+    int lane = __lane_id();
+    int base = lane & ~(width - 1);
+    return hipemu::from_bits<T>(hipemu::wave_collective(hipemu::OP_SHFL, hipemu::to_bits(v), base + (src & (width - 1))));
+}
+template <class T> inline T __shfl_xor(T v, int mask, int width = 64) {
+    int lane = __lane_id();
+    int s = lane ^ mask;
+    if ((s & ~(width - 1)) != (lane & ~(width - 1))) s = lane;
+    return hipemu::from_bits<T>(hipemu::wave_collective(hipemu::OP_SHFL, hipemu::to_bits(v), s));
+}
+template <class T> inline T __shfl_down(T v, unsigned d, int width = 64) {
+    int lane = __lane_id();
+    int s = lane + (int)d;
+    if ((s & ~(width - 1)) != (lane & ~(width - 1))) s = lane;
+    return hipemu::from_bits<T>(hipemu::wave_collective(hipemu::OP_SHFL, hipemu::to_bits(v), s));
+}
+template <class T> inline T __shfl_up(T v, unsigned d, int width = 64) {
+    int lane = __lane_id();
+    int s = lane - (int)d;
+    if (s < 0 || (s & ~(width - 1)) != (lane & ~(width - 1))) s = lane;
+    return hipemu::from_bits<T>(hipemu::wave_collective(hipemu::OP_SHFL, hipemu::to_bits(v), s));
+}
+inline unsigned long long __ballot(int pred) {
+    return hipemu::wave_collective(hipemu::OP_BALLOT, pred ? 1 : 0, 0);
+}
+inline int __any(int pred) { return __ballot(pred) != 0; }
+inline int __all(int pred) {
+    // all participating lanes true <=> no participating lane false
+    return __ballot(!pred) == 0;
+}
+inline int __builtin_amdgcn_readfirstlane(int v) {
+    return (int)hipemu::wave_collective(hipemu::OP_FIRST, (uint64_t)(uint32_t)v, 0);
+}
+
+inline int __popc(unsigned x) { return __builtin_popcount(x); }
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline int __ffs(int x) { return __builtin_ffs(x); }
+inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+inline float __fdiv_rn(float a, float b) { return a / b; }
+inline float __fmul_rn(float a, float b) { return a * b; }
+inline float __fadd_rn(float a, float b) { return a + b; }
+template <class T> inline T __ldg(const T* p) { return *p; }
+
+// atomics (single OS thread: plain read-modify-write)
+template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> inline T atomicSub(T* p, T v) { T o = *p; *p = o - v; return o; }
+template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
+template <class T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
+template <class T> inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hipemu::launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
+
+// ---- host runtime subset ----
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+    memset(p, 0, sizeof(*p)); strcpy(p->name, "hipemu"); strcpy(p->gcnArchName, "host");
+    p->multiProcessorCount = 4; p->totalGlobalMem = (size_t)8 << 30; return hipSuccess;
+}
+inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+template <class T> inline hipError_t hipHostMalloc(T** p, size_t n, unsigned = 0) { return hipMalloc((void**)p, n); }
+inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = 0) { if (n) memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = 0) { if (n) memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t) { return "hipemu error"; }
+struct hipemu_event { std::chrono::steady_clock::time_point t; };
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemu_event(); return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = 0) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess;
+}
+inline hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = (size_t)4 << 30; *t = (size_t)8 << 30; return hipSuccess; }

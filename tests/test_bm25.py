@@ -1,0 +1,143 @@
+"""Parity of the BM25 / tf / df / top-k path with the CPU oracle and the reference goldens.
+
+Every test runs twice: backend "emu" (kernel sources compiled for the host, tests/hipemu --
+checks kernel logic without a GPU) and backend "gpu" (the real gfx950 library through the C ABI;
+marked gpu).  tf / df / top-k doc ids are compared bit-exact; BM25 scores are compared bit-exact
+too (np.array_equal), which is stricter than the 1e-5 relative tolerance BASELINE.json allows."""
+import numpy as np
+import pytest
+
+from oracle import refimpl as O
+from searcharray_amd import ops, synth
+from searcharray_amd import roaringish as rz
+from searcharray_amd.device_index import DeviceIndex, NO_DOC
+from tests.helpers import golden_corpus, oracle_index
+
+
+def build_pair(name, tile_docs=1024, api=None):
+    g, (t, d, p), lens, num_docs, vocab = golden_corpus(name)
+    words, word_terms = rz.encode_sorted(t, d, p)
+    term_off = rz.term_offsets(word_terms, vocab)
+    dev = DeviceIndex(words, term_off, lens, tile_docs=tile_docs, api=api)
+    orc = O.OracleIndex.from_triples(t, d, p, num_docs, doc_lens=lens)
+    return g, dev, orc, vocab
+
+
+@pytest.fixture(scope="module")
+def small(api):
+    return build_pair("zipf_small", api=api)
+
+
+def test_ops_mirrors_match_oracle(api):
+    rng = np.random.default_rng(0)
+    tf = rng.integers(0, 6, 5000).astype(np.float32)
+    dl = rng.integers(1, 90, 5000).astype(np.float32)
+    want = tf.copy()
+    O.bm25_score(want, dl, 31.7, 2.345, 1.2, 0.75)
+    got = tf.copy()
+    ops.bm25_score(got, dl, 31.7, 2.345, 1.2, 0.75, api=api)
+    assert np.array_equal(got, want)
+    idx = np.sort(rng.choice(20000, 3000, replace=False)).astype(np.uint64)
+    val = rng.random(3000).astype(np.float32)
+    assert np.array_equal(ops.as_dense(idx, val, 20000, api=api), O.as_dense(idx, val, 20000))
+    docs = np.sort(rng.integers(0, 900, 7000)).astype(np.uint64)
+    arr = np.unique((docs << np.uint64(36)) | (rng.integers(0, 4, 7000).astype(np.uint64) << np.uint64(18))
+                    | rng.integers(1, 2 ** 18, 7000).astype(np.uint64))
+    k1, c1 = ops.popcount64_reduce(arr, 36, 0x3FFFF, api=api)
+    k2, c2 = O.popcount64_reduce(arr, 36, 0x3FFFF)
+    assert np.array_equal(k1, k2) and np.array_equal(c1, c2)
+    assert np.array_equal(ops.unique(arr, 36, api=api), O.unique(arr, 36))
+    assert np.array_equal(ops.unique(arr >> np.uint64(36), 0, api=api), O.unique(arr >> np.uint64(36), 0))
+    assert np.array_equal(ops.popcount64(arr, api=api), O.popcount64(arr))
+    assert len(ops.unique(np.empty(0, np.uint64), 36, api=api)) == 0
+
+
+def test_df_tf_bit_exact(small):
+    g, dev, orc, vocab = small
+    assert np.array_equal(dev.docfreqs(), g["df"])
+    for t in g["tf_terms"]:
+        assert np.array_equal(dev.termfreqs_dense(int(t)), orc.termfreqs(int(t))), f"tf t{t}"
+        ids, tfs = dev.termfreqs_sparse(int(t))
+        oi, ot = orc.termfreqs_sparse(int(t))
+        assert np.array_equal(ids, oi) and np.array_equal(tfs, ot)
+    assert dev.termfreqs_dense(vocab + 5).sum() == 0
+
+
+def test_bm25_dense_bit_exact(small):
+    g, dev, orc, vocab = small
+    for t in g["score_terms"]:
+        assert np.array_equal(dev.bm25_dense([int(t)]), g[f"score_{t}"]), f"score t{t}"
+        assert np.array_equal(dev.bm25_dense([int(t)], k1=1.7, b=0.3), g[f"score_custom_{t}"])
+    for q, want in zip(g["or_queries"], g["or_scores"]):
+        assert np.array_equal(dev.bm25_dense([int(t) for t in q]), want)
+    # unknown term contributes nothing
+    assert np.array_equal(dev.bm25_dense([3, vocab + 9]), orc.score(3))
+
+
+@pytest.mark.parametrize("k", [1, 10, 32, 40, 300])
+def test_topk_batch_matches_oracle(small, k):
+    g, dev, orc, vocab = small
+    queries = g["or_queries"][:6]
+    bt = dev.batch(queries, k=k)
+    bt.run()
+    scores, docs = bt.fetch()
+    for qi, q in enumerate(queries):
+        dense = orc.score_terms_sum([int(t) for t in q])
+        ws, wd = O.topk(dense, k)
+        nz = ws > 0
+        n = int(nz.sum())
+        assert np.array_equal(scores[qi, :n], ws[:n]), f"q{qi} scores"
+        assert np.array_equal(docs[qi, :n], wd[:n]), f"q{qi} docs"
+        assert (scores[qi, n:] == 0).all() and (docs[qi, n:] == NO_DOC).all()
+    ms, alg, post = bt.profile()
+    want_post = sum(8 * int(orc.docfreq(int(t))) for q in queries for t in q)
+    assert post == want_post and alg == want_post + 4 * orc.num_docs * len(queries)
+    bt.close()
+
+
+def test_topk_massive_ties_takes_fallback_path(api):
+    """All docs identical -> every score ties -> survivors exceed the candidate list."""
+    n = 1500
+    t = np.repeat(np.arange(3), n).astype(np.uint32)
+    d = np.tile(np.arange(n), 3).astype(np.uint64)
+    p = np.repeat(np.arange(3), n).astype(np.uint64)
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, 3), np.full(n, 3, np.float32), tile_docs=1024, api=api)
+    for k in (5, 40, 700):
+        bt = dev.batch(np.asarray([[0, 1, 2]]), k=k)
+        bt.run()
+        scores, docs = bt.fetch()
+        assert np.array_equal(docs[0], np.arange(k, dtype=np.uint64))         # ties -> smallest doc ids
+        assert (scores[0] == scores[0, 0]).all() and scores[0, 0] > 0
+        bt.close()
+
+
+def test_sparse_corpus_and_doc_base(api):
+    g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_sparse")
+    words, wt = rz.encode_sorted(t, d, p)
+    off = rz.term_offsets(wt, vocab)
+    orc = O.OracleIndex.from_triples(t, d, p, num_docs, doc_lens=lens)
+    dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api, doc_base=100000)
+    assert np.array_equal(dev.docfreqs(), g["df"])
+    q = g["or_queries"][:4]
+    for row, want in zip(q, g["or_scores"][:4]):
+        assert np.array_equal(dev.bm25_dense([int(x) for x in row]), want)
+    bt = dev.batch(q, k=10)
+    bt.run()
+    scores, docs = bt.fetch()
+    for qi, row in enumerate(q):
+        ws, wd = O.topk(g["or_scores"][qi], 10)
+        n = int((ws > 0).sum())
+        assert np.array_equal(scores[qi, :n], ws[:n]) and np.array_equal(docs[qi, :n], wd[:n] + 100000)
+    bt.close()
+
+
+def test_empty_and_degenerate_indexes(api):
+    dev = DeviceIndex(np.empty(0, np.uint64), np.zeros(4, np.uint64), np.zeros(10, np.float32), tile_docs=1024, api=api)
+    assert (dev.docfreqs() == 0).all()
+    assert dev.bm25_dense([0, 1]).sum() == 0            # avg_doc_len == 0 -> zeros (similarity.py:31-32)
+    assert dev.termfreqs_dense(1).sum() == 0
+    bt = dev.batch(np.asarray([[0, 1]]), k=3)
+    bt.run()
+    s, d_ = bt.fetch()
+    assert (s == 0).all() and (d_ == NO_DOC).all()
