@@ -1,0 +1,252 @@
+#!/usr/bin/env python
+"""bench.py -- the reference's headline workload on MI355X.
+
+Metric (BASELINE.json): queries/sec (+ GB/s of postings scanned) of 4-term disjunctive BM25 with
+top-k over a 10M-doc synthetic Zipf corpus, 1/2/4/8 GPUs.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one batch of 256 queries: BM25 tile kernel (postings
+stream -> LDS accumulators -> per-tile top-k) + per-shard merge (+ RCCL all-gather of the per-shard
+top-k keys and a final merge when N > 1).  The 10M-doc corpus is sharded by doc-id range
+(10M / N docs per GPU, global BM25 statistics), so scaling is STRONG.  Index and query batch are
+resident in HBM before the timed region; results stay on the device.
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
+
+
+def log(rank, *a):
+    if rank == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--docs", type=int, default=10_000_000)
+    ap.add_argument("--vocab", type=int, default=100_000)
+    ap.add_argument("--queries", type=int, default=256)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--tile", type=int, default=0, help="docs per scoring tile (0 = library default)")
+    ap.add_argument("--collective", choices=["rccl", "torch"], default="rccl",
+                    help="N>1 exchange: library-internal RCCL all-gather, or torch.distributed")
+    ap.add_argument("--corpus-cache", default="", help="directory to cache the encoded corpus shard (.npz)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(rank, f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from searcharray_amd import synth, _lib
+    from searcharray_amd.device_index import DeviceIndex, QueryBatch, compute_idf
+
+    api = _lib.api()                   # fails loudly if the gfx950 library is missing
+    D, V, B, K, W = args.docs, args.vocab, args.queries, args.steps, args.warmup
+
+    # ---- corpus shard (host) -------------------------------------------------------------
+    lo = (D * rank) // world
+    hi = (D * (rank + 1)) // world
+    t0 = time.time()
+    workers = max(1, min(8, (os.cpu_count() or 8) // world))
+    corpus = None
+    cpath = os.path.join(args.corpus_cache, f"zipf_{D}_{V}_{lo}_{hi}.npz") if args.corpus_cache else ""
+    if cpath and os.path.exists(cpath):
+        z = np.load(cpath)
+        corpus = synth.EncodedCorpus(z["words"], z["term_off"], z["doc_lens"], hi - lo, V, lo)
+    if corpus is None:
+        corpus = synth.zipf_corpus(hi - lo, vocab=V, doc_base=lo, total_docs=D, workers=workers)
+        if cpath:
+            os.makedirs(args.corpus_cache, exist_ok=True)
+            np.savez(cpath, words=corpus.words, term_off=corpus.term_off, doc_lens=corpus.doc_lens)
+    log(rank, f"shard docs [{lo},{hi}) words={len(corpus.words)} generated in {time.time()-t0:.1f}s "
+              f"({workers} host threads)")
+
+    # ---- global statistics (index-time constants, replicated) -----------------------------
+    sum_len = float(corpus.doc_lens.astype(np.float64).sum())
+    if world > 1:
+        tl = torch.tensor([sum_len], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tl)
+        sum_len = float(tl.item())
+    avgdl = np.float32(sum_len / D)
+
+    t0 = time.time()
+    index = DeviceIndex(corpus.words, corpus.term_off, corpus.doc_lens, avg_doc_len=avgdl,
+                        corpus_size=D, doc_base=lo, device=local_rank, tile_docs=args.tile, api=api)
+    info = index.info()
+    log(rank, f"index resident: {info.n_postings} postings, {info.hbm_bytes/1e9:.2f} GB HBM, "
+              f"tile_docs={info.tile_docs} n_tiles={info.n_tiles} dir_terms={info.n_dir_terms} "
+              f"({time.time()-t0:.1f}s incl. H2D + derive)")
+    df = index.docfreqs().astype(np.int64)
+    if world > 1:
+        tdf = torch.from_numpy(df).cuda()
+        dist.all_reduce(tdf)
+        df = tdf.cpu().numpy()
+    index.set_global_docfreqs(df.astype(np.uint64))
+
+    queries = synth.bm25_queries(B, vocab=V)
+    idf = np.asarray([[compute_idf(D, np.asarray([df[t]])) for t in q] for q in queries], dtype=np.float32)
+    batch = QueryBatch(index, queries, k=args.k, idf=idf)
+
+    collective = "none"
+    gathered = local_keys = None
+    if world > 1:
+        collective = args.collective
+        if collective == "rccl":
+            try:
+                ids = [None]
+                if rank == 0:
+                    buf = _lib.ctypes.create_string_buffer(128)
+                    api.call("sa_comm_unique_id", buf, 128)
+                    ids = [buf.raw]
+                dist.broadcast_object_list(ids, src=0)
+                index.comm_init(rank, world, ids[0])
+            except Exception as e:                      # noqa: BLE001
+                log(rank, f"library RCCL init failed ({e}); falling back to torch.distributed all_gather")
+                collective = "torch"
+            flag = torch.tensor([1 if collective == "torch" else 0], device="cuda")
+            dist.all_reduce(flag)
+            if flag.item() > 0 and collective == "rccl":
+                index.comm_destroy()
+                collective = "torch"
+        if collective == "torch":
+            local_keys = torch.zeros(B * args.k, dtype=torch.int64, device="cuda")
+            gathered = torch.zeros(world * B * args.k, dtype=torch.int64, device="cuda")
+
+    def step():
+        if world > 1 and collective == "torch":
+            batch.run_local(local_keys.data_ptr(), sync=True)
+            dist.all_gather_into_tensor(gathered, local_keys)
+            torch.cuda.synchronize()
+            batch.merge_gathered(gathered.data_ptr(), world, sync=False)
+        else:
+            batch.run(sync=False)
+
+    def sync_all():
+        index.synchronize()
+        if torch is not None:
+            torch.cuda.synchronize()
+
+    for _ in range(W):
+        step()
+    sync_all()
+    if W > 0:
+        batch.profile()                                  # reset the kernel-event ring
+    if world > 1:
+        dist.barrier()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    sync_all()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tdt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+        dt = float(tdt.item())
+
+    kernel_ms, alg_bytes, post_bytes = batch.profile()
+    post_total = float(post_bytes)
+    if world > 1:
+        tp = torch.tensor([post_total], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tp)
+        post_total = float(tp.item())
+    scores, docs = batch.fetch()
+
+    qps = B * K / dt
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("docs") == D and tj.get("queries") == B and tj.get("n_gpus") == world \
+                    and tj.get("tile_docs") == int(info.tile_docs):
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:                                 # noqa: BLE001
+            traffic = None
+
+    cpu_baseline = None
+    parity = "skipped"
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import refimpl as O                    # CPU port of the reference path (checker + baseline)
+        orc = O.OracleIndex(corpus.words, np.arange(V), corpus.term_off, corpus.doc_lens, D)
+        orc.avg_doc_length = avgdl
+        tq = time.perf_counter()
+        s0 = orc.score_terms_sum([int(t) for t in queries[0]])     # also warms this query's tf/df caches
+        first = time.perf_counter() - tq
+        nq = int(max(2, min(32, B, args.cpu_seconds / max(first, 1e-3) / 2)))
+        for q in queries[1:nq]:                                    # warm-up pass (reference test_msmarco.py:384-395)
+            orc.score_terms_sum([int(t) for t in q])
+        tq = time.perf_counter()
+        ok = True
+        for qi in range(nq):
+            dense = orc.score_terms_sum([int(t) for t in queries[qi]])
+            ws, wd = O.topk(dense, args.k)
+            ok &= bool(np.allclose(scores[qi], ws, rtol=1e-5, atol=0)) and \
+                bool(np.array_equal(docs[qi][ws > 0], wd[ws > 0]))
+        cpu_dt = time.perf_counter() - tq
+        parity = "ok" if ok else "MISMATCH"
+        cpu_baseline = {"value": round(nq / cpu_dt, 3), "unit": "queries/s", "cores": 1, "kind": "port",
+                        "sample": f"first {nq} of the {B} queries on the same {D}-doc corpus, tf/df caches warm, "
+                                  f"oracle/ C+numpy port of score()+np.sum+top-{args.k}, single thread, "
+                                  f"host has {os.cpu_count()} cores"}
+        del s0
+
+    if rank == 0:
+        out = {
+            "metric": "queries/sec, 4-term disjunctive BM25 + top-k over 10M synthetic Zipf docs",
+            "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"zipf-{D} (V={V}, Poisson(32) doc lengths, seed 1234) sharded by doc-id range, "
+                                   f"{B} x 4-term disjunctive BM25 queries (k1=1.2 b=0.75), top-{args.k}",
+                       "docs": D, "queries_per_step": B, "terms_per_query": 4, "k": args.k,
+                       "tile_docs": int(info.tile_docs), "parallelism": f"doc-range shards x{world}",
+                       "collective": collective},
+            "postings_scanned_GBps": round(post_total * K / dt / 1e9, 2),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "sa_k_bm25_tiles", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "note": "algorithmic bytes = sum_q(sum_t 8*df_t + 4*n_docs) per SURVEY 8d, rank 0's shard"},
+            "cpu_baseline": cpu_baseline,
+            "parity_check": parity,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        if collective == "rccl":
+            index.comm_destroy()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -63,6 +63,10 @@ int sa_unique(const uint64_t* arr, int64_t n, uint64_t rshift, uint64_t* out, in
 /* popcount64(arr) -> u64[n]      reference searcharray/roaringish/popcount.pyx:71-81,119-121 */
 int sa_popcount64(const uint64_t* arr, int64_t n, uint64_t* out);
 
+/* HBM read-bandwidth probe (roofline calibration): streams `bytes` of device memory `reps`
+ * times with 8-byte (mode 0) or 16-byte (mode 1) loads per lane; best GB/s. */
+int sa_stream_probe(uint64_t bytes, int mode, int reps, double* gbps_out);
+
 /* ------------------------------------------------------------------------------------- */
 /* Part 2 -- HBM-resident index                                                            */
 /* ------------------------------------------------------------------------------------- */
@@ -80,6 +84,8 @@ int sa_index_create(int device, uint64_t n_docs, uint64_t doc_base, uint32_t n_t
                     float avg_doc_len, uint64_t corpus_size, uint32_t tile_docs,
                     sa_index_t** out);
 int sa_index_destroy(sa_index_t* ix);
+/* block until everything enqueued on the index's stream has finished */
+int sa_index_synchronize(sa_index_t* ix);
 
 /* shard-local document frequency of one term / of all terms (u64[n_terms])
  * reference SearchArray.docfreq postings.py:640-647 -> PosnBitArray.docfreq middle_out.py:521 */
@@ -120,8 +126,9 @@ int sa_batch_run_local(sa_batch_t* batch, void* local_keys_out_device, int sync)
 int sa_batch_merge_gathered(sa_batch_t* batch, const void* gathered_keys_device, int nranks, int sync);
 /* wait for completion; copies results to host: scores f32[B][k], docs u64[B][k] */
 int sa_batch_fetch(sa_batch_t* batch, float* scores_out, uint64_t* docs_out);
-/* HIP-event time of the scoring kernel of the last sa_batch_run (ms) and its algorithmic
- * bytes: sum over queries of (sum_t 8*df_t + 4*n_docs)  (SURVEY.md 8d). */
+/* Mean HIP-event time (ms, events recorded on the index stream around the scoring kernel) over
+ * the runs since the previous call, and the algorithmic bytes of one run: sum over queries of
+ * (sum_t 8*df_t + 4*n_docs); postings_bytes is the sum_t 8*df_t part alone. */
 int sa_batch_profile(sa_batch_t* batch, double* kernel_ms_out, uint64_t* alg_bytes_out,
                      uint64_t* postings_bytes_out);
 int sa_batch_destroy(sa_batch_t* batch);

@@ -47,10 +47,12 @@ PROTOTYPES = {
     "sa_popcount64_reduce": (c_int, [u64p, c_int64, c_uint64, c_uint64, u64p, f32p, i64p]),
     "sa_unique": (c_int, [u64p, c_int64, c_uint64, u64p, i64p]),
     "sa_popcount64": (c_int, [u64p, c_int64, u64p]),
+    "sa_stream_probe": (c_int, [c_uint64, c_int, c_int, POINTER(c_double)]),
     # Part 2
     "sa_index_create": (c_int, [c_int, c_uint64, c_uint64, c_uint32, u64p, u64p, f32p, c_float,
                                 c_uint64, c_uint32, POINTER(c_void_p)]),
     "sa_index_destroy": (c_int, [c_void_p]),
+    "sa_index_synchronize": (c_int, [c_void_p]),
     "sa_index_docfreq": (c_int, [c_void_p, c_uint32, u64p]),
     "sa_index_docfreqs": (c_int, [c_void_p, u64p]),
     "sa_index_termfreqs_dense": (c_int, [c_void_p, c_uint32, f32p]),

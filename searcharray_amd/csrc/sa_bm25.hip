@@ -24,6 +24,7 @@
 
 #define SA_MAX_QTERMS 32
 #define SA_KMAX 1024
+#define SA_EVENT_RING 128
 
 struct Bm25Params {
     // index
@@ -393,7 +394,8 @@ struct sa_batch {
     u64* d_final = nullptr;         // [B][k]
     u64* d_xcand = nullptr;         // [B][nranks*k] regrouped gather
     int xcand_ranks = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> ev0, ev1;   // ring of (start, stop) events around the scoring kernel
+    u32 ev_n = 0;                       // runs recorded since the last sa_batch_profile
     u64 alg_bytes = 0, postings_bytes = 0;
     bool ran = false;
 };
@@ -482,8 +484,8 @@ static void sa_batch_free(sa_batch* bt) {
     if (bt->d_gather) hipFree(bt->d_gather);
     if (bt->d_final) hipFree(bt->d_final);
     if (bt->d_xcand) hipFree(bt->d_xcand);
-    if (bt->ev0) hipEventDestroy(bt->ev0);
-    if (bt->ev1) hipEventDestroy(bt->ev1);
+    for (hipEvent_t e : bt->ev0) hipEventDestroy(e);
+    for (hipEvent_t e : bt->ev1) hipEventDestroy(e);
     delete bt;
 }
 
@@ -542,8 +544,13 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
     SA_HIP_B(hipMemset(bt->d_local, 0, (size_t)B * bt->k * sizeof(u64)));
     SA_HIP_B(hipMemcpy(bt->d_terms, h_terms.data(), h_terms.size() * sizeof(u32), hipMemcpyHostToDevice));
     SA_HIP_B(hipMemcpy(bt->d_idf, h_idf.data(), h_idf.size() * sizeof(float), hipMemcpyHostToDevice));
-    SA_HIP_B(hipEventCreate(&bt->ev0));
-    SA_HIP_B(hipEventCreate(&bt->ev1));
+    for (int i = 0; i < SA_EVENT_RING; i++) {
+        hipEvent_t a = nullptr, c = nullptr;
+        SA_HIP_B(hipEventCreate(&a));
+        bt->ev0.push_back(a);
+        SA_HIP_B(hipEventCreate(&c));
+        bt->ev1.push_back(c);
+    }
 #undef SA_HIP_B
     (void)rc;
     *out = bt;
@@ -574,13 +581,15 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out) {
     p.q_per_xcd = (xcd_mode && bt->B >= 8) ? (bt->B + 7) / 8 : 0;
     p.small_k_argmax = (bt->k <= 32 && sa_env_int("SA_SMALLK_ARGMAX", 1)) ? 1 : 0;
     p.dense_out = nullptr; p.cand = bt->d_cand;
-    SA_HIP(hipEventRecord(bt->ev0, st));
+    const u32 slot = bt->ev_n % SA_EVENT_RING;
+    SA_HIP(hipEventRecord(bt->ev0[slot], st));
     if (ix->avg_doc_len != 0.f && ix->n_tiles > 0) {
         SA_TRY(sa_launch_bm25(ix, p, st));
     } else {
         SA_HIP(hipMemsetAsync(bt->d_cand, 0, (size_t)bt->B * (ix->n_tiles ? ix->n_tiles : 1) * bt->k * sizeof(u64), st));
     }
-    SA_HIP(hipEventRecord(bt->ev1, st));
+    SA_HIP(hipEventRecord(bt->ev1[slot], st));
+    bt->ev_n++;
     const u32 n_cand = (ix->n_tiles ? ix->n_tiles : 1) * bt->k;
     hipLaunchKernelGGL(sa_k_topk_merge, dim3(bt->B), dim3(1024), 0, st, bt->d_cand, n_cand, bt->k, shard_out,
                        (const u32*)bt->d_perm);
@@ -690,14 +699,21 @@ extern "C" int sa_batch_fetch(sa_batch_t* bt, float* scores_out, uint64_t* docs_
 extern "C" int sa_batch_profile(sa_batch_t* bt, double* kernel_ms_out, uint64_t* alg_bytes_out,
                                 uint64_t* postings_bytes_out) {
     SA_ARG(bt && bt->ix, "null batch");
-    SA_ARG(bt->ran, "batch has not been run");
+    SA_ARG(bt->ran && bt->ev_n > 0, "batch has not been run since the last profile call");
     sa_index* ix = bt->ix;
     std::lock_guard<std::mutex> g(ix->mu);
     SA_HIP(hipSetDevice(ix->device));
     SA_HIP(hipStreamSynchronize(ix->stream));
-    float ms = 0.f;
-    SA_HIP(hipEventElapsedTime(&ms, bt->ev0, bt->ev1));
-    if (kernel_ms_out) *kernel_ms_out = (double)ms;
+    // mean over the runs since the previous call (at most the last SA_EVENT_RING of them)
+    const u32 n = bt->ev_n < SA_EVENT_RING ? bt->ev_n : SA_EVENT_RING;
+    double sum = 0.0;
+    for (u32 i = 0; i < n; i++) {
+        float ms = 0.f;
+        SA_HIP(hipEventElapsedTime(&ms, bt->ev0[i], bt->ev1[i]));
+        sum += ms;
+    }
+    bt->ev_n = 0;
+    if (kernel_ms_out) *kernel_ms_out = n ? sum / n : 0.0;
     if (alg_bytes_out) *alg_bytes_out = bt->alg_bytes;
     if (postings_bytes_out) *postings_bytes_out = bt->postings_bytes;
     return SA_OK;

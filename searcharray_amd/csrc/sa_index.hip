@@ -384,6 +384,14 @@ extern "C" int sa_index_termfreqs_sparse(sa_index_t* ix, uint32_t term, uint64_t
     return SA_OK;
 }
 
+extern "C" int sa_index_synchronize(sa_index_t* ix) {
+    SA_ARG(ix, "null index");
+    SA_HIP(hipSetDevice(ix->device));
+    SA_HIP(hipStreamSynchronize(ix->stream));
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+
 extern "C" int sa_index_info(sa_index_t* ix, sa_index_info_t* out) {
     SA_ARG(ix && out, "null argument");
     out->n_docs = ix->n_docs; out->doc_base = ix->doc_base; out->corpus_size = ix->corpus_size;

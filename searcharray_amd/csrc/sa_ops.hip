@@ -168,3 +168,60 @@ extern "C" int sa_popcount64(const uint64_t* arr, int64_t n, uint64_t* out) {
     SA_HIP(hipMemcpy(out, d_o, (size_t)n * 8, hipMemcpyDeviceToHost));
     return SA_OK;
 }
+
+// ---- HBM read-bandwidth probe (calibration for the roofline figures, not a product path) ----
+// Streams `bytes` of device memory with the same access shapes the scoring kernel can use
+// (mode 0: one 8-byte load per lane, mode 1: one 16-byte load per lane) and reports GB/s.
+__global__ void __launch_bounds__(256) sa_k_stream8(const u64* __restrict__ a, u64 n, u64* __restrict__ sink) {
+    u64 acc = 0;
+    u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * 256;
+    for (; i + 3 * stride < n; i += 4 * stride) acc += a[i] ^ a[i + stride] ^ a[i + 2 * stride] ^ a[i + 3 * stride];
+    for (; i < n; i += stride) acc += a[i];
+    if (acc == 0x123456789ull) sink[0] = acc;
+}
+
+struct alignas(16) sa_u64x2 { u64 x, y; };
+
+__global__ void __launch_bounds__(256) sa_k_stream16(const sa_u64x2* __restrict__ a, u64 n, u64* __restrict__ sink) {
+    u64 acc = 0;
+    u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * 256;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const sa_u64x2 p = a[i], q = a[i + stride], r = a[i + 2 * stride], s = a[i + 3 * stride];
+        acc += (p.x ^ p.y) + (q.x ^ q.y) + (r.x ^ r.y) + (s.x ^ s.y);
+    }
+    for (; i < n; i += stride) acc += a[i].x ^ a[i].y;
+    if (acc == 0x123456789ull) sink[0] = acc;
+}
+
+extern "C" int sa_stream_probe(uint64_t bytes, int mode, int reps, double* gbps_out) {
+    SA_ARG(gbps_out && bytes >= 4096 && reps > 0, "bad argument");
+    DevBufs bufs;
+    u64 *d_a, *d_sink;
+    const u64 n8 = bytes / 8;
+    SA_TRY(bufs.alloc(&d_a, n8 + 2));
+    SA_TRY(bufs.alloc(&d_sink, 1));
+    SA_HIP(hipMemset(d_a, 0x5A, n8 * 8));
+    hipEvent_t e0, e1;
+    SA_HIP(hipEventCreate(&e0));
+    SA_HIP(hipEventCreate(&e1));
+    const u32 grid = 256 * 16;
+    double best = 0.0;
+    for (int r = 0; r < reps + 1; r++) {
+        SA_HIP(hipEventRecord(e0, 0));
+        if (mode == 0) hipLaunchKernelGGL(sa_k_stream8, dim3(grid), dim3(256), 0, 0, d_a, n8, d_sink);
+        else hipLaunchKernelGGL(sa_k_stream16, dim3(grid), dim3(256), 0, 0, (const sa_u64x2*)d_a, n8 / 2, d_sink);
+        SA_HIP(hipEventRecord(e1, 0));
+        SA_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        SA_HIP(hipEventElapsedTime(&ms, e0, e1));
+        const double g = (double)(n8 * 8) / (ms * 1e-3) / 1e9;
+        if (r > 0 && g > best) best = g;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    SA_HIP(hipGetLastError());
+    *gbps_out = best;
+    return SA_OK;
+}

@@ -61,6 +61,9 @@ class DeviceIndex:
         except Exception:
             pass
 
+    def synchronize(self):
+        self.api.call("sa_index_synchronize", self._h)
+
     def info(self) -> IndexInfo:
         out = IndexInfo()
         self.api.call("sa_index_info", self._h, ctypes.byref(out))

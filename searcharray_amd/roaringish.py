@@ -38,14 +38,16 @@ def encode_sorted(term_ids: np.ndarray, doc_ids: np.ndarray, posns: np.ndarray
     n = len(term_ids)
     if n == 0:
         return np.empty(0, np.uint64), np.empty(0, np.uint32)
-    posns = np.asarray(posns, dtype=np.uint64)
+    posns = np.asarray(posns)
     if int(posns.max()) > MAX_POSN:
         raise ValueError(f"Positions must be less than {1 << LSB_BITS}")
     doc_ids = np.asarray(doc_ids, dtype=np.uint64)
     if int(doc_ids.max()) > MAX_DOC_ID:
         raise ValueError(f"Doc ids must be less than {1 << KEY_BITS}")
-    blk, bit = np.divmod(posns, np.uint64(LSB_BITS))
-    word = (doc_ids << np.uint64(KEY_SHIFT)) | (blk << np.uint64(MSB_BITS))
+    p32 = posns.astype(np.uint32)
+    blk = p32 // np.uint32(LSB_BITS)                      # 32-bit division is ~3x the 64-bit rate
+    bit = (p32 - blk * np.uint32(LSB_BITS)).astype(np.uint64)
+    word = (doc_ids << np.uint64(KEY_SHIFT)) | (blk.astype(np.uint64) << np.uint64(MSB_BITS))
     first = np.empty(n, dtype=bool)
     first[0] = True
     np.not_equal(word[1:], word[:-1], out=first[1:])

@@ -41,13 +41,37 @@ def _zipf_cdf(vocab: int, s: float = 1.0) -> np.ndarray:
     return cdf
 
 
+_QUANTILE_BITS = 24
+_quantile_cache = {}
+
+
+def _zipf_quantile_table(vocab: int, s: float = 1.0) -> np.ndarray:
+    """Inverse-CDF lookup table with 2^24 equal-probability cells (term id per cell): sampling is
+    one random integer + one gather instead of a binary search per token."""
+    key = (vocab, s)
+    if key not in _quantile_cache:
+        cdf = _zipf_cdf(vocab, s)
+        u = (np.arange(1 << _QUANTILE_BITS, dtype=np.float64) + 0.5) / float(1 << _QUANTILE_BITS)
+        tab = np.searchsorted(cdf, u, side="right").astype(np.uint32)
+        np.minimum(tab, vocab - 1, out=tab)
+        _quantile_cache[key] = tab
+    return _quantile_cache[key]
+
+
 def zipf_batch_tokens(batch_index: int, n_docs: int, vocab: int = 100_000, mean_len: int = 32,
-                      seed: int = 1234, s: float = 1.0, cdf: Optional[np.ndarray] = None
-                      ) -> Tuple[np.ndarray, np.ndarray]:
-    """Tokens of one batch in document order: (doc_lens int64[n_docs], terms uint32[sum lens])."""
+                      seed: int = 1234, s: float = 1.0, cdf: Optional[np.ndarray] = None,
+                      fast: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    """Tokens of one batch in document order: (doc_lens int64[n_docs], terms uint32[sum lens]).
+
+    fast=False: exact inverse-CDF sampling (binary search per token; used by the golden
+    fixtures).  fast=True: the 2^24-cell quantile table (what the large bench corpora use)."""
     rng = np.random.default_rng([seed, batch_index])
     lens = np.maximum(1, rng.poisson(mean_len, n_docs)).astype(np.int64)
     total = int(lens.sum())
+    if fast:
+        tab = _zipf_quantile_table(vocab, s)
+        terms = tab[rng.integers(0, 1 << _QUANTILE_BITS, total, dtype=np.uint32)]
+        return lens, terms
     if cdf is None:
         cdf = _zipf_cdf(vocab, s)
     terms = np.searchsorted(cdf, rng.random(total), side="right").astype(np.uint32)
@@ -108,7 +132,7 @@ def concat_term_major(batches: Sequence[Tuple[np.ndarray, np.ndarray]], vocab: i
 
 def zipf_corpus(num_docs: int, vocab: int = 100_000, mean_len: int = 32, seed: int = 1234,
                 doc_base: int = 0, batch_docs: int = 1_000_000, total_docs: Optional[int] = None,
-                workers: int = 1) -> EncodedCorpus:
+                workers: int = 1, fast: bool = True) -> EncodedCorpus:
     """Encode docs [doc_base, doc_base + num_docs) of the ``zipf-N`` corpus (N = total_docs).
 
     doc_base must be a multiple of batch_docs-aligned shard boundaries only in the sense that
@@ -117,7 +141,9 @@ def zipf_corpus(num_docs: int, vocab: int = 100_000, mean_len: int = 32, seed: i
     """
     if total_docs is None:
         total_docs = doc_base + num_docs
-    cdf = _zipf_cdf(vocab)
+    cdf = None if fast else _zipf_cdf(vocab)
+    if fast:
+        _zipf_quantile_table(vocab)          # build once before the worker threads start
     first_b = doc_base // batch_docs
     last_b = (doc_base + num_docs - 1) // batch_docs if num_docs > 0 else first_b - 1
     jobs = []
@@ -128,7 +154,7 @@ def zipf_corpus(num_docs: int, vocab: int = 100_000, mean_len: int = 32, seed: i
 
     def run(job):
         b, b_lo, b_n = job
-        lens, terms = zipf_batch_tokens(b, b_n, vocab, mean_len, seed, cdf=cdf)
+        lens, terms = zipf_batch_tokens(b, b_n, vocab, mean_len, seed, cdf=cdf, fast=fast)
         lo = max(doc_base, b_lo) - b_lo
         hi = min(doc_base + num_docs, b_lo + b_n) - b_lo
         if lo > 0 or hi < b_n:
