@@ -21,8 +21,9 @@ def main():
     ap.add_argument("--vocab", type=int, default=100_000)
     ap.add_argument("--queries", type=int, default=256)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--tiles", default="8192,16384,32768")
-    ap.add_argument("--ks", default="10,1000")
+    ap.add_argument("--tiles", default="2048,4096,8192,16384")
+    ap.add_argument("--ks", default="10")
+    ap.add_argument("--dir-divs", default="8")
     ap.add_argument("--corpus-cache", default="")
     args = ap.parse_args()
     api = _lib.api()
@@ -43,16 +44,18 @@ def main():
             np.savez(cpath, words=corpus.words, term_off=corpus.term_off, doc_lens=corpus.doc_lens)
     print(json.dumps({"corpus_s": round(time.time() - t0, 1), "words": int(len(corpus.words))}), flush=True)
     queries = synth.bm25_queries(B, vocab=V)
-    for tile in [int(x) for x in args.tiles.split(",")]:
+    for tile, ddiv in [(int(x), y) for x in args.tiles.split(",") for y in args.dir_divs.split(",")]:
+        os.environ["SA_DIR_DIV"] = ddiv
         t0 = time.time()
         index = DeviceIndex(corpus.words, corpus.term_off, corpus.doc_lens, tile_docs=tile, api=api)
         build_s = time.time() - t0
         for k in [int(x) for x in args.ks.split(",")]:
             batch = QueryBatch(index, queries, k=k)
-            modes = [(1, 1), (0, 1), (1, 0)] if k <= 32 else [(1, 0), (0, 0)]
-            for xcd, argmax in modes:
+            modes = [(0, 1, 0), (1, 1, 0), (0, 0, 0), (0, 1, 1)] if k <= 32 else [(0, 0, 0), (0, 0, 1)]
+            for xcd, argmax, notopk in modes:
                 os.environ["SA_XCD_MODE"] = str(xcd)
                 os.environ["SA_SMALLK_ARGMAX"] = str(argmax)
+                os.environ["SA_NO_TOPK"] = str(notopk)
                 for _ in range(2):
                     batch.run(sync=False)
                 index.synchronize()
@@ -63,7 +66,8 @@ def main():
                 index.synchronize()
                 dt = time.perf_counter() - t0
                 ms, alg, post = batch.profile()
-                print(json.dumps({"tile": tile, "k": k, "xcd_mode": xcd, "argmax": argmax,
+                print(json.dumps({"tile": tile, "dir_div": ddiv, "dir_terms": int(index.info().n_dir_terms), "k": k,
+                                  "xcd_mode": xcd, "argmax": argmax, "no_topk": notopk,
                                   "qps": round(B * args.steps / dt, 1), "ms_per_step": round(dt / args.steps * 1e3, 3),
                                   "kernel_ms": round(ms, 3), "alg_GBps": round(alg / ms / 1e6, 1),
                                   "postings_GBps": round(post / ms / 1e6, 1), "index_build_s": round(build_s, 1)}),

@@ -26,6 +26,8 @@
 #define SA_KMAX 1024
 #define SA_EVENT_RING 128
 
+struct alignas(16) sa_u64x2 { u64 x, y; };
+
 struct Bm25Params {
     // index
     const u64* tfp;
@@ -43,6 +45,11 @@ struct Bm25Params {
     float k1, b, avgdl;
     u32 q_per_xcd;         // >0: XCD-grouped block mapping, 0: plain tile-major
     int small_k_argmax;    // k <= 32: iterative block arg-max instead of threshold selection
+    int no_topk;           // timing experiments only: skip the per-tile selection
+    u32 cand_per_tile;     // general mode: candidate slots per (query, tile) = k
+    u32 cand_cap;          // pruned mode: capacity of each query's append list
+    u32* cand_cnt;         // pruned mode: [B] append cursors
+    u32* slots;            // pruned mode: [B][32] pruning slots (score bits)
     // outputs
     float* dense_out;      // [B][n_docs] or null
     u64* cand;             // [B][n_tiles][k] composite keys (global doc ids) or null
@@ -86,6 +93,11 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
     const u32 tid = threadIdx.x;
     const u64 tile_base = (u64)tile * TILE;
     const u32 T = p.T;
+    // pruning slots of this query (see the top-k section); loaded first so the L2 latency hides
+    // behind the posting stream.  L1-bypassing load: a fresher bound prunes more.
+    u32 slot_val = 0xFFFFFFFFu;
+    if (p.small_k_argmax && (tid & (SA_WAVE - 1)) < 32u)
+        slot_val = __hip_atomic_load(&p.slots[q * 32u + (tid & 31u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // 1. clear accumulators, locate this tile's slice of every query term
 #pragma unroll
@@ -113,40 +125,42 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
     }
     __syncthreads();
 
-    // 2. term-at-a-time accumulation
+    // 2. term-at-a-time accumulation.  Postings are streamed as 16-byte pairs (one
+    // global_load_dwordx4 per lane, 4 in flight) from the 16-byte-aligned part of the slice;
+    // the unaligned head/tail posting is handled by lane 0.
     const float k1 = p.k1, bb = p.b, avgdl = p.avgdl;
     const float one_minus_b = 1.0f - bb;
+    auto score_into = [&](u64 x, float idf) {
+        const u32 d = (u32)((x >> SA_KEY_SHIFT) - tile_base);
+        const float tf = (float)(u32)(x & SA_LSB_MASK);
+        const float dl = p.dl_packed ? (float)(u32)((x >> SA_LSB_BITS) & SA_LSB_MASK)
+                                     : p.doc_lens[tile_base + d];
+        const float norm = __fmul_rn(k1, __fadd_rn(one_minus_b, __fmul_rn(bb, __fdiv_rn(dl, avgdl))));
+        const float s = __fmul_rn(__fdiv_rn(tf, __fadd_rn(tf, norm)), idf);
+        acc[d] = __fadd_rn(acc[d], s);
+    };
     for (u32 t = 0; t < T; t++) {
         const u64 lo = s_lo[t], hi = s_hi[t];
         const float idf = p.idf[q * T + t];
-        u64 i = lo + tid;
-        // 4 independent 64-bit loads in flight per lane
-        for (; i + 3ull * THREADS < hi; i += 4ull * THREADS) {
-            u64 pp[4];
+        u64 a = (lo + 1ull) & ~1ull;
+        if (a > hi) a = hi;
+        if (tid == 0 && lo < a) score_into(p.tfp[lo], idf);
+        const u64 npairs = (hi - a) >> 1;
+        const sa_u64x2* pairs = (const sa_u64x2*)(p.tfp + a);
+        u64 j = tid;
+        for (; j + 3ull * THREADS < npairs; j += 4ull * THREADS) {
+            sa_u64x2 pp[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) pp[u] = p.tfp[i + (u64)u * THREADS];
+            for (int u = 0; u < 4; u++) pp[u] = pairs[j + (u64)u * THREADS];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const u64 x = pp[u];
-                const u32 d = (u32)((x >> SA_KEY_SHIFT) - tile_base);
-                const float tf = (float)(u32)(x & SA_LSB_MASK);
-                const float dl = p.dl_packed ? (float)(u32)((x >> SA_LSB_BITS) & SA_LSB_MASK)
-                                             : p.doc_lens[tile_base + d];
-                const float norm = __fmul_rn(k1, __fadd_rn(one_minus_b, __fmul_rn(bb, __fdiv_rn(dl, avgdl))));
-                const float s = __fmul_rn(__fdiv_rn(tf, __fadd_rn(tf, norm)), idf);
-                acc[d] = __fadd_rn(acc[d], s);
-            }
+            for (int u = 0; u < 4; u++) { score_into(pp[u].x, idf); score_into(pp[u].y, idf); }
         }
-        for (; i < hi; i += THREADS) {
-            const u64 x = p.tfp[i];
-            const u32 d = (u32)((x >> SA_KEY_SHIFT) - tile_base);
-            const float tf = (float)(u32)(x & SA_LSB_MASK);
-            const float dl = p.dl_packed ? (float)(u32)((x >> SA_LSB_BITS) & SA_LSB_MASK)
-                                         : p.doc_lens[tile_base + d];
-            const float norm = __fmul_rn(k1, __fadd_rn(one_minus_b, __fmul_rn(bb, __fdiv_rn(dl, avgdl))));
-            const float s = __fmul_rn(__fdiv_rn(tf, __fadd_rn(tf, norm)), idf);
-            acc[d] = __fadd_rn(acc[d], s);
+        for (; j < npairs; j += THREADS) {
+            const sa_u64x2 pq = pairs[j];
+            score_into(pq.x, idf);
+            score_into(pq.y, idf);
         }
+        if (tid == 0 && ((hi - a) & 1ull)) score_into(p.tfp[hi - 1], idf);
         __syncthreads();
     }
 
@@ -162,47 +176,100 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
             if (e < tile_n) out[e] = acc[e];
         }
     }
-    if (!p.cand) return;
+    if (!p.cand || p.no_topk) return;
 
     // 4. per-tile top-k -> composite keys  score_bits<<32 | ~global_doc
     const u32 k = p.k;
-    u64* cand = p.cand + ((u64)q * p.n_tiles + tile) * k;
+    u64* cand = p.cand + (p.small_k_argmax ? 0ull : ((u64)q * p.n_tiles + tile) * p.cand_per_tile);
     u64* sel = smem + CAP;                    // selected keys (aliases acc once keys are in registers)
     u32 nsel = 0;
 
     if (p.small_k_argmax) {
-        // k rounds of block arg-max; scores stay in LDS, the winner's slot is cleared.
-        u64 best = 0;
+        // k <= 32: PRUNED selection.  Per query, 32 global slots hold the best score seen by 32
+        // disjoint families of waves (slot = wave index mod 32), so G = min(slots) is a score that
+        // at least 32 distinct docs reach: nothing below G can enter the top-k.  A wave whose
+        // maximum is below G (almost every wave once the first tiles have run) is done after one
+        // DPP reduction.  Otherwise it appends its elements >= G -- all of them when there are at
+        // most k, else its exact top-k by k rounds of a wave-wide arg-max -- to the query's
+        // candidate list.  Stale slot reads only weaken the pruning (slots grow monotonically);
+        // the final top-k is exact and deterministic.
+        const u32 lane = tid & (SA_WAVE - 1), wave = tid / SA_WAVE;
+        u32 lmax = 0;
 #pragma unroll
         for (int j = 0; j < E; j++) {
-            const u32 e = j * THREADS + tid;
-            const u64 c = ((u64)__float_as_uint(acc[e]) << 32) | (u64)(0xFFFFu - e);
-            if ((c >> 32) != 0 && c > best) best = c;
+            const u32 x = __float_as_uint(acc[j * THREADS + tid]);
+            lmax = x > lmax ? x : lmax;
         }
-        u64 mine_out = 0;
-        for (u32 r = 0; r < k; r++) {
-            const u64 bm = sa_block_max64<NW>(best, red64);
-            if (bm == 0) break;                                   // uniform
-            if (tid == r) mine_out = bm;
-            if (best == bm) {                                     // exactly one owner (keys unique)
-                const u32 e = 0xFFFFu - (u32)(bm & 0xFFFFu);
-                acc[e] = 0.f;
-                best = 0;
+        const u32 wmax = sa_wave_max_u32(lmax);
+        const u32 g = sa_wave_min_u32(slot_val);
+        const u32 thr = g > 1u ? g : 1u;
+        if (wmax < thr) return;                                   // wave-uniform
+        const u32 widx = tile * NW + wave;
+        if (lane == 0) atomicMax(&p.slots[q * 32u + (widx & 31u)], wmax);
+        u64* qcand = p.cand + (u64)q * p.cand_cap;
+        const u64 lt = (1ull << lane) - 1ull;
+        u32 c = 0;
 #pragma unroll
-                for (int j = 0; j < E; j++) {
-                    const u32 e2 = j * THREADS + tid;
-                    const u64 c = ((u64)__float_as_uint(acc[e2]) << 32) | (u64)(0xFFFFu - e2);
-                    if ((c >> 32) != 0 && c > best) best = c;
+        for (int j = 0; j < E; j++)
+            c += (u32)__popcll(__ballot(__float_as_uint(acc[j * THREADS + tid]) >= thr));
+        if (c <= k) {
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(&p.cand_cnt[q], c);
+            base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const u32 e = j * THREADS + tid;
+                const u32 x = __float_as_uint(acc[e]);
+                const bool keep = x >= thr;
+                const u64 b = __ballot(keep);
+                if (keep) {
+                    const u32 pos = base + (u32)__popcll(b & lt);
+                    const u64 doc = p.doc_base + tile_base + e;
+                    if (pos < p.cand_cap) qcand[pos] = ((u64)x << 32) | (u64)(u32)(~(u32)doc);
                 }
+                base += (u32)__popcll(b);
             }
+            return;
         }
-        if (tid < k) {
-            u64 o = 0;
-            if (mine_out) {
-                const u64 doc = p.doc_base + tile_base + (0xFFFFu - (u32)(mine_out & 0xFFFFu));
-                o = (mine_out & 0xFFFFFFFF00000000ull) | (u64)(u32)(~(u32)doc);
-            }
-            cand[tid] = o;
+        // more than k survivors (first tiles of a query, or heavy ties): exact top-k of this wave.
+        // Each lane tracks its best and second best element in registers (branch-free); the tile
+        // is rescanned only when one lane wins twice in a row of promotions.
+        u32 b1k, b1j, b2k, b2j;
+#define SA_RESCAN()                                                                   \
+        do {                                                                          \
+            b1k = 0; b1j = 0; b2k = 0; b2j = 0;                                       \
+            _Pragma("unroll") for (int j = 0; j < E; j++) {                           \
+                const u32 x = __float_as_uint(acc[j * THREADS + tid]);                \
+                const bool g1 = x > b1k, g2 = x > b2k;                                \
+                const u32 n2k = g1 ? b1k : (g2 ? x : b2k);                            \
+                const u32 n2j = g1 ? b1j : (g2 ? (u32)j : b2j);                       \
+                b1k = g1 ? x : b1k; b1j = g1 ? (u32)j : b1j; b2k = n2k; b2j = n2j;    \
+            }                                                                         \
+        } while (0)
+        SA_RESCAN();
+        bool stale = false;                         // true: b2 already promoted, next best unknown
+        u64 mine_out = 0;
+        u32 found = 0;
+        for (u32 r = 0; r < k; r++) {
+            const u32 m = sa_wave_max_u32(b1k);
+            if (m == 0) break;                       // wave-uniform
+            const u32 e1 = (b1k == m) ? (b1j * THREADS + tid) : 0xFFFFFFFFu;
+            const u32 emin = sa_wave_min_u32(e1);    // ties -> smallest doc id
+            if (lane == r) mine_out = ((u64)m << 32) | (u64)emin;
+            found = r + 1;
+            const bool owner = (e1 == emin);
+            if (owner) acc[emin] = 0.f;
+            const bool need = owner && stale;
+            if (owner && !stale) { b1k = b2k; b1j = b2j; b2k = 0; stale = true; }
+            if (__any(need)) { SA_RESCAN(); stale = false; }
+        }
+#undef SA_RESCAN
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(&p.cand_cnt[q], found);
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+        if (lane < found && base + lane < p.cand_cap) {
+            const u64 doc = p.doc_base + tile_base + (u32)(mine_out & 0xFFFFFFFFull);
+            qcand[base + lane] = (mine_out & 0xFFFFFFFF00000000ull) | (u64)(u32)(~(u32)doc);
         }
         return;
     }
@@ -307,7 +374,7 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
     }
     __syncthreads();
     nsel = s_cnt[1] < k ? s_cnt[1] : k;
-    for (u32 i = tid; i < k; i += THREADS) {
+    for (u32 i = tid; i < p.cand_per_tile; i += THREADS) {
         u64 o = 0;
         if (i < nsel) {
             const u64 c = sel[i];
@@ -319,35 +386,47 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
 }
 
 // Merge n_cand candidate keys per query into the k best, sorted descending.
-// One workgroup of 1024 threads per query; candidates are re-read from L2/HBM per bisection
-// step (n_cand is n_tiles * k, or n_ranks * k after the RCCL all-gather).
+// One workgroup of 1024 threads per query.
+//
+// rank_stride > 0: the candidates come in groups of rank_stride keys sorted by rank (a wave's
+// arg-max output, or a rank's sorted top-k), so the k-th largest GROUP LEADER is a lower bound G
+// of the k-th largest key overall (k distinct groups own a key >= G).  One pass then keeps only
+// keys >= G -- a few dozen -- in LDS and a bitonic sort finishes.  If the survivors overflow the
+// LDS list (pathological ties), or rank_stride == 0, the k-th largest is found by MSB-first
+// bisection over the whole candidate array instead.
+#define SA_MERGE_LIST 2048
+
 __global__ void __launch_bounds__(1024)
-sa_k_topk_merge(const u64* __restrict__ cand, u32 n_cand, u32 k, u64* __restrict__ out,
-                const u32* __restrict__ out_row) {
+sa_k_topk_merge(const u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__ out,
+                const u32* __restrict__ out_row, u32 rank_stride, const u32* __restrict__ cnt) {
     constexpr int NW = 1024 / SA_WAVE;
     __shared__ u64 red64[NW + 1];
-    __shared__ u64 sel[2 * SA_KMAX];
+    __shared__ u64 sel[SA_MERGE_LIST];
     __shared__ u32 s_n;
     const u32 q = blockIdx.x, tid = threadIdx.x;
-    const u64* c = cand + (u64)q * n_cand;
-    u32 kp2 = 1;
-    while (kp2 < k) kp2 <<= 1;
-    for (u32 i = tid; i < kp2; i += 1024) sel[i] = 0;
+    const u64* c = cand + (u64)q * n_cand_max;
+    // cnt != null: the row is an append list holding cnt[q] keys (pruned tile selection)
+    u32 n_cand = n_cand_max;
+    if (cnt) { const u32 have = cnt[q]; n_cand = have < n_cand_max ? have : n_cand_max; }
+    const u32 row = out_row ? out_row[q] : q;       // device row q holds caller query out_row[q]
+    for (u32 i = tid; i < SA_MERGE_LIST; i += 1024) sel[i] = 0;
     if (tid == 0) s_n = 0;
+    __syncthreads();
 
-    // k-th largest via MSB-first bisection over the candidate array (2 bits per step)
-    u64 m = 0;
-    for (u32 i = tid; i < n_cand; i += 1024) { const u64 x = c[i]; m = x > m ? x : m; }
-    m = sa_block_max64<NW>(m, red64);
-    u64 prefix = 0;
-    if (m != 0 && n_cand > k) {
+    // MSB-first bisection (2 bits per step) for the k-th largest of c[0 : n : stride]
+    auto kth_largest = [&](u32 n, u32 stride) -> u64 {
+        u64 m = 0;
+        for (u32 i = tid; i < n; i += 1024) { const u64 x = c[(u64)i * stride]; m = x > m ? x : m; }
+        m = sa_block_max64<NW>(m, red64);
+        if (m == 0 || n < k) return 0;
         int top = 63 - __clzll((long long)m);
         if ((top & 1) == 0) top++;
+        u64 prefix = 0;
         for (int bit = top; bit >= 1; bit -= 2) {
             const u64 c1 = prefix | (1ull << (bit - 1)), c2 = prefix | (2ull << (bit - 1)), c3 = prefix | (3ull << (bit - 1));
             u64 packed = 0;
-            for (u32 i = tid; i < n_cand; i += 1024) {
-                const u64 x = c[i];
+            for (u32 i = tid; i < n; i += 1024) {
+                const u64 x = c[(u64)i * stride];
                 packed += (x >= c1 ? 1ull : 0ull) + (x >= c2 ? (1ull << 21) : 0ull) + (x >= c3 ? (1ull << 42) : 0ull);
             }
 #pragma unroll
@@ -361,20 +440,44 @@ sa_k_topk_merge(const u64* __restrict__ cand, u32 n_cand, u32 k, u64* __restrict
             const u32 n1 = (u32)(tot & 0x1FFFFF), n2 = (u32)((tot >> 21) & 0x1FFFFF), n3 = (u32)((tot >> 42) & 0x1FFFFF);
             if (n3 >= k) prefix = c3; else if (n2 >= k) prefix = c2; else if (n1 >= k) prefix = c1;
         }
+        return prefix;
+    };
+
+    u64 thr = 1;
+    bool exact = false;                               // thr is the exact k-th largest key
+    if (rank_stride > 0 && n_cand / rank_stride >= k) {
+        const u64 g = kth_largest(n_cand / rank_stride, rank_stride);
+        thr = g > 1 ? g : 1;
+    } else if (n_cand > SA_MERGE_LIST) {
+        const u64 g = kth_largest(n_cand, 1);
+        thr = g > 1 ? g : 1;
+        exact = true;
     }
-    const u64 thr = prefix > 1 ? prefix : 1;
-    __syncthreads();
-    for (u32 i = tid; i < n_cand; i += 1024) {
-        const u64 x = c[i];
-        if (x >= thr) {
-            const u32 pos = atomicAdd(&s_n, 1u);
-            if (pos < kp2) sel[pos] = x;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        for (u32 i = tid; i < n_cand; i += 1024) {
+            const u64 x = c[i];
+            if (x >= thr) {
+                const u32 pos = atomicAdd(&s_n, 1u);
+                if (pos < SA_MERGE_LIST) sel[pos] = x;
+            }
         }
+        __syncthreads();
+        const u32 n_sel = s_n;
+        __syncthreads();
+        if (n_sel <= SA_MERGE_LIST || exact) break;   // uniform
+        // survivors overflowed the list: fall back to the exact threshold and gather again
+        for (u32 i = tid; i < SA_MERGE_LIST; i += 1024) sel[i] = 0;
+        if (tid == 0) s_n = 0;
+        const u64 g = kth_largest(n_cand, 1);
+        thr = g > 1 ? g : 1;
+        exact = true;
+        __syncthreads();
     }
-    __syncthreads();
-    sa_block_bitonic_desc(sel, kp2);
-    const u32 row = out_row ? out_row[q] : q;       // device row q holds caller query out_row[q]
-    for (u32 i = tid; i < k; i += 1024) out[(u64)row * k + i] = sel[i];
+    u32 n_sel = s_n < SA_MERGE_LIST ? s_n : SA_MERGE_LIST;
+    u32 np2 = 2;
+    while (np2 < n_sel) np2 <<= 1;
+    sa_block_bitonic_desc(sel, np2);
+    for (u32 i = tid; i < k; i += 1024) out[(u64)row * k + i] = (i < SA_MERGE_LIST) ? sel[i] : 0ull;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -388,7 +491,9 @@ struct sa_batch {
     u32* d_terms = nullptr;
     u32* d_perm = nullptr;
     float* d_idf = nullptr;
-    u64* d_cand = nullptr;          // [B][n_tiles][k]
+    u64* d_cand = nullptr;          // [B][n_tiles][waves*k]: per-tile blocks, or per-query append lists
+    u32* d_cand_cnt = nullptr;      // [B] append cursors (pruned selection)
+    u32* d_slots = nullptr;         // [B][32] pruning slots
     u64* d_local = nullptr;         // [B][k] per-shard result
     u64* d_gather = nullptr;        // [nranks][B][k] (multi-GPU)
     u64* d_final = nullptr;         // [B][k]
@@ -414,12 +519,23 @@ static void sa_fill_params(const sa_index* ix, Bm25Params& p) {
     p.avgdl = ix->avg_doc_len;
 }
 
+static u32 sa_tile_waves(u32 tile_docs) {
+    switch (tile_docs) {
+        case 1024: return 2; case 2048: return 1; case 4096: return 2; case 8192: return 4;
+        case 16384: return 8; case 32768: return 16; default: return 1;
+    }
+}
+
 static int sa_launch_bm25(sa_index* ix, const Bm25Params& p, hipStream_t st) {
     if (ix->n_tiles == 0 || p.B == 0) return SA_OK;
     const u32 grid = p.q_per_xcd ? 8u * p.q_per_xcd * ix->n_tiles : p.B * ix->n_tiles;
     switch (ix->tile_docs) {
         case 1024:
             hipLaunchKernelGGL((sa_k_bm25_tiles<1024, 128>), dim3(grid), dim3(128), 0, st, p); break;
+        case 2048:
+            hipLaunchKernelGGL((sa_k_bm25_tiles<2048, 64>), dim3(grid), dim3(64), 0, st, p); break;
+        case 4096:
+            hipLaunchKernelGGL((sa_k_bm25_tiles<4096, 128>), dim3(grid), dim3(128), 0, st, p); break;
         case 8192:
             hipLaunchKernelGGL((sa_k_bm25_tiles<8192, 256>), dim3(grid), dim3(256), 0, st, p); break;
         case 16384:
@@ -480,6 +596,8 @@ static void sa_batch_free(sa_batch* bt) {
     if (bt->d_perm) hipFree(bt->d_perm);
     if (bt->d_idf) hipFree(bt->d_idf);
     if (bt->d_cand) hipFree(bt->d_cand);
+    if (bt->d_cand_cnt) hipFree(bt->d_cand_cnt);
+    if (bt->d_slots) hipFree(bt->d_slots);
     if (bt->d_local) hipFree(bt->d_local);
     if (bt->d_gather) hipFree(bt->d_gather);
     if (bt->d_final) hipFree(bt->d_final);
@@ -536,8 +654,10 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
     SA_HIP_B(hipMalloc(&bt->d_idf, h_idf.size() * sizeof(float)));
     SA_HIP_B(hipMalloc(&bt->d_perm, (size_t)B * sizeof(u32)));
     SA_HIP_B(hipMemcpy(bt->d_perm, bt->perm.data(), (size_t)B * sizeof(u32), hipMemcpyHostToDevice));
-    const size_t ncand = (size_t)B * (ix->n_tiles ? ix->n_tiles : 1) * bt->k;
+    const size_t ncand = (size_t)B * (ix->n_tiles ? ix->n_tiles : 1) * bt->k * sa_tile_waves(ix->tile_docs);
     SA_HIP_B(hipMalloc(&bt->d_cand, ncand * sizeof(u64)));
+    SA_HIP_B(hipMalloc(&bt->d_cand_cnt, (size_t)B * sizeof(u32)));
+    SA_HIP_B(hipMalloc(&bt->d_slots, (size_t)B * 32 * sizeof(u32)));
     SA_HIP_B(hipMalloc(&bt->d_local, (size_t)B * bt->k * sizeof(u64)));
     SA_HIP_B(hipMalloc(&bt->d_final, (size_t)B * bt->k * sizeof(u64)));
     SA_HIP_B(hipMemset(bt->d_final, 0, (size_t)B * bt->k * sizeof(u64)));
@@ -577,22 +697,31 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out) {
     sa_fill_params(ix, p);
     p.terms = bt->d_terms; p.idf = bt->d_idf; p.B = bt->B; p.T = bt->T; p.k = bt->k;
     p.k1 = bt->k1; p.b = bt->b;
-    const int xcd_mode = sa_env_int("SA_XCD_MODE", 1);
+    const int xcd_mode = sa_env_int("SA_XCD_MODE", 0);
     p.q_per_xcd = (xcd_mode && bt->B >= 8) ? (bt->B + 7) / 8 : 0;
     p.small_k_argmax = (bt->k <= 32 && sa_env_int("SA_SMALLK_ARGMAX", 1)) ? 1 : 0;
     p.dense_out = nullptr; p.cand = bt->d_cand;
+    p.no_topk = sa_env_int("SA_NO_TOPK", 0);
+    p.cand_per_tile = bt->k;
+    p.cand_cap = (ix->n_tiles ? ix->n_tiles : 1) * bt->k * sa_tile_waves(ix->tile_docs);
+    p.cand_cnt = bt->d_cand_cnt;
+    p.slots = bt->d_slots;
+    if (p.small_k_argmax) {
+        SA_HIP(hipMemsetAsync(bt->d_cand_cnt, 0, (size_t)bt->B * sizeof(u32), st));
+        SA_HIP(hipMemsetAsync(bt->d_slots, 0, (size_t)bt->B * 32 * sizeof(u32), st));
+    }
     const u32 slot = bt->ev_n % SA_EVENT_RING;
     SA_HIP(hipEventRecord(bt->ev0[slot], st));
     if (ix->avg_doc_len != 0.f && ix->n_tiles > 0) {
         SA_TRY(sa_launch_bm25(ix, p, st));
     } else {
-        SA_HIP(hipMemsetAsync(bt->d_cand, 0, (size_t)bt->B * (ix->n_tiles ? ix->n_tiles : 1) * bt->k * sizeof(u64), st));
+        SA_HIP(hipMemsetAsync(bt->d_cand, 0, (size_t)bt->B * p.cand_cap * sizeof(u64), st));
     }
     SA_HIP(hipEventRecord(bt->ev1[slot], st));
     bt->ev_n++;
-    const u32 n_cand = (ix->n_tiles ? ix->n_tiles : 1) * bt->k;
+    const u32 n_cand = p.small_k_argmax ? p.cand_cap : (ix->n_tiles ? ix->n_tiles : 1) * p.cand_per_tile;
     hipLaunchKernelGGL(sa_k_topk_merge, dim3(bt->B), dim3(1024), 0, st, bt->d_cand, n_cand, bt->k, shard_out,
-                       (const u32*)bt->d_perm);
+                       (const u32*)bt->d_perm, 0u, (const u32*)(p.small_k_argmax ? bt->d_cand_cnt : nullptr));
     bt->ran = true;
     return SA_OK;
 }
@@ -611,8 +740,9 @@ static int sa_batch_merge_ranks(sa_batch* bt, const u64* d_gathered, int nranks)
     const u64 total = (u64)nranks * count;
     const u32 grid = total / 256 + 1 < 4096 ? (u32)(total / 256 + 1) : 4096;
     hipLaunchKernelGGL(sa_k_regroup, dim3(grid), dim3(256), 0, st, d_gathered, (u32)nranks, bt->B, bt->k, bt->d_xcand);
+    // every rank's block is its sorted top-k: group leaders = rank maxima
     hipLaunchKernelGGL(sa_k_topk_merge, dim3(bt->B), dim3(1024), 0, st, bt->d_xcand, (u32)nranks * bt->k, bt->k, bt->d_final,
-                       (const u32*)nullptr);
+                       (const u32*)nullptr, bt->k, (const u32*)nullptr);
     return SA_OK;
 }
 

@@ -83,6 +83,35 @@ __device__ __forceinline__ u64 sa_wave_max64(u64 v) {
     return v;
 }
 
+// Full-wave (64 lanes, all active) unsigned max / min through the DPP data path: a row scan by
+// row_shr 1/2/4/8, then row_bcast:15 and row_bcast:31 fold the four rows into lane 63.  Pure
+// VALU (no LDS crossbar round trips like ds_bpermute-based __shfl), result is wave-uniform.
+#define SA_DPP_ROW_SHR(n) (0x110 + (n))
+#define SA_DPP_ROW_BCAST15 0x142
+#define SA_DPP_ROW_BCAST31 0x143
+
+__device__ __forceinline__ u32 sa_wave_max_u32(u32 v) {
+    u32 t;
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, SA_DPP_ROW_SHR(1), 0xf, 0xf, false); v = t > v ? t : v;
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, SA_DPP_ROW_SHR(2), 0xf, 0xf, false); v = t > v ? t : v;
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, SA_DPP_ROW_SHR(4), 0xf, 0xf, false); v = t > v ? t : v;
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, SA_DPP_ROW_SHR(8), 0xf, 0xf, false); v = t > v ? t : v;
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, SA_DPP_ROW_BCAST15, 0xa, 0xf, false); v = t > v ? t : v;
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, SA_DPP_ROW_BCAST31, 0xc, 0xf, false); v = t > v ? t : v;
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ u32 sa_wave_min_u32(u32 v) {
+    u32 t;
+    t = (u32)__builtin_amdgcn_update_dpp(-1, (int)v, SA_DPP_ROW_SHR(1), 0xf, 0xf, false); v = t < v ? t : v;
+    t = (u32)__builtin_amdgcn_update_dpp(-1, (int)v, SA_DPP_ROW_SHR(2), 0xf, 0xf, false); v = t < v ? t : v;
+    t = (u32)__builtin_amdgcn_update_dpp(-1, (int)v, SA_DPP_ROW_SHR(4), 0xf, 0xf, false); v = t < v ? t : v;
+    t = (u32)__builtin_amdgcn_update_dpp(-1, (int)v, SA_DPP_ROW_SHR(8), 0xf, 0xf, false); v = t < v ? t : v;
+    t = (u32)__builtin_amdgcn_update_dpp(-1, (int)v, SA_DPP_ROW_BCAST15, 0xa, 0xf, false); v = t < v ? t : v;
+    t = (u32)__builtin_amdgcn_update_dpp(-1, (int)v, SA_DPP_ROW_BCAST31, 0xc, 0xf, false); v = t < v ? t : v;
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Block-wide sum of a u32 for blocks of NWAVES waves.  `red` is LDS scratch of >= NWAVES+1
 // words; the result is returned to every thread.  Contains two barriers; safe to call in a loop.
 template <int NWAVES>

@@ -10,6 +10,7 @@
 #include "../../include/searcharray_hip.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <new>
 
 // ---------------------------------------------------------------------------------------
@@ -254,7 +255,15 @@ static int sa_index_build(sa_index* ix, const u64* words, const u64* term_off, c
 
     // ---- tile directory for frequent terms ----
     ix->n_tiles = ix->n_docs ? sa_div_up(ix->n_docs, ix->tile_docs) : 0;
-    ix->dir_min_df = 4 * (ix->n_tiles > 0 ? ix->n_tiles : 1);
+    {
+        // terms with at least ~1/8 posting per tile get a directory row; rarer terms are short
+        // enough that a workgroup's lower-bound search stays inside a few cache lines
+        const char* dv = getenv("SA_DIR_DIV");
+        const int div = dv ? atoi(dv) : 8;
+        ix->dir_min_df = div > 0 ? ix->n_tiles / (u32)div : 4 * ix->n_tiles;
+        if (div < 0) ix->dir_min_df = (u32)(-div) * ix->n_tiles;
+        if (ix->dir_min_df < 64) ix->dir_min_df = 64;
+    }
     std::vector<u32> slot((size_t)V + 1, 0xFFFFFFFFu), dir_terms;
     for (u32 t = 0; t < V; t++) {
         const u64 df = ix->h_tf_off[t + 1] - ix->h_tf_off[t];
@@ -290,9 +299,10 @@ extern "C" int sa_index_create(int device, uint64_t n_docs, uint64_t doc_base, u
     SA_ARG(term_off, "term_off is null");
     SA_ARG(n_docs == 0 || doc_lens, "doc_lens is null");
     SA_ARG(n_docs <= (1ull << 28), "a shard holds at most 2^28 docs (28-bit roaringish key)");
-    if (tile_docs == 0) tile_docs = 16384;
-    SA_ARG(tile_docs == 1024 || tile_docs == 8192 || tile_docs == 16384 || tile_docs == 32768,
-           "tile_docs must be 1024, 8192, 16384 or 32768");
+    if (tile_docs == 0) tile_docs = 4096;
+    SA_ARG(tile_docs == 1024 || tile_docs == 2048 || tile_docs == 4096 || tile_docs == 8192 ||
+               tile_docs == 16384 || tile_docs == 32768,
+           "tile_docs must be 1024, 2048, 4096, 8192, 16384 or 32768");
     const u64 W = term_off[n_terms];
     SA_ARG(term_off[0] == 0, "term_off[0] must be 0");
     SA_ARG(W == 0 || words, "words is null");

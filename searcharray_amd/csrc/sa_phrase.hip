@@ -1,0 +1,460 @@
+// sa_phrase.hip -- exact-phrase (slop = 0) match counts over the roaringish positional words.
+//
+// Two device paths, both producing the dense float32 phrase-frequency vector the reference's
+// PosnBitArray.phrase_freqs returns (reference searcharray/phrase/middle_out.py:418-441):
+//
+//  * the GENERAL chain: a data-parallel restatement of the reference's bigram chain
+//      compute_phrase_freqs / l2r / r2l / middle-out      middle_out.py:96-168
+//      bigram_freqs and its helpers                       phrase/bigram_freqs.py:48-307
+//      intersect_with_adjacents / intersect / merge       roaringish/intersect.pyx:213-275, merge.pyx:54-92
+//    with identical observable semantics, including the same-term rule (bigram_freqs.py:48-101),
+//    zero-payload continuation words and the T>=5 middle-out quirk.
+//    The serial galloping two-pointer of the reference becomes: per lhs word, a lower-bound probe
+//    into rhs on the 46-bit header (headers are unique within a term, so the match set is the
+//    same), then stable stream compaction with device-resident lengths -- the whole chain is
+//    enqueued on one stream with no host round trip.
+//    Because only phrase_freqs[ids] = counts survives (ids-intersection + np.minimum over bigram
+//    steps, middle_out.py:73-93), per-step counts are scatter-added into a dense u32 vector and the
+//    running result is an elementwise min -- equal to the reference's sorted (ids, counts) algebra
+//    (absent doc == count 0), without sort_merge_counts / popcount_reduce_at round trips.
+//
+//  * the FUSED kernel for phrases of pairwise-distinct terms: anchored on the rarest term, each
+//    anchor word probes the other terms' words at headers h-1, h, h+1, aligns their 18-bit bitmaps
+//    by the phrase offsets and counts popcount(AND) -- one pass, every word of the anchor read once.
+//    For distinct terms the reference's chain equals the exact count of positions p with
+//    t0@p, t1@p+1, ... (and, for the middle-out plan, the min of the two sub-phrase counts).
+#include "sa_index.hpp"
+#include "sa_scan.hpp"
+#include "../../include/searcharray_hip.h"
+
+#include <stdlib.h>
+
+#define SA_NONE 0xFFFFFFFFu
+#define SA_MAX_PHRASE 32
+
+enum { CONT_LHS = 0, CONT_RHS = 1 };
+
+// ---------------------------------------------------------------------------------------
+// general chain kernels
+// ---------------------------------------------------------------------------------------
+
+// per lhs word: index of the rhs word with the same header / with header + 1, or SA_NONE
+// (intersect_with_adjacents, intersect.pyx:213-275); clears *same when an inner pair differs
+// (the same-term test `np.all(lhs_int == rhs_int)`, bigram_freqs.py:140).
+__global__ void __launch_bounds__(256)
+sa_k_probe(const u64* __restrict__ lhs, const u32* __restrict__ nl_dev, const u64* __restrict__ rhs,
+           const u32* __restrict__ nr_dev, u32* __restrict__ jin, u32* __restrict__ jadj, u32* __restrict__ same) {
+    const u32 nl = *nl_dev, nr = *nr_dev;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nl; i += gridDim.x * blockDim.x) {
+        const u64 l = lhs[i];
+        const u64 h = l & SA_HEADER_MASK;
+        const u32 j = sa_lower_bound(rhs, 0, nr, h, SA_HEADER_MASK);
+        u32 ji = SA_NONE, ja = SA_NONE;
+        if (j < nr && (rhs[j] & SA_HEADER_MASK) == h) {
+            ji = j;
+            if (rhs[j] != l) *same = 0u;
+        }
+        const u64 h2 = h + (1ull << SA_LSB_BITS);
+        const u32 j2 = sa_lower_bound(rhs, j, nr, h2, SA_HEADER_MASK);
+        if (j2 < nr && (rhs[j2] & SA_HEADER_MASK) == h2) ja = j2;
+        jin[i] = ji;
+        jadj[i] = ja;
+    }
+}
+
+// inner matches: bigram_freqs.py:104-155 (and the same-term branch :65-101)
+struct InnerBigram {
+    const u64* lhs; const u64* rhs; const u32* jin; const u32* same;
+    u64* next_inner; u32* step; int cont;
+    __device__ __forceinline__ bool flag(u32 i) const { return jin[i] != SA_NONE; }
+    __device__ __forceinline__ void emit(u32 i, u32 pos) const {
+        const u64 l = lhs[i], r = rhs[jin[i]];
+        u32 count;
+        u64 nxt;
+        if (*same) {
+            const u64 ov = l & (r << 1);
+            const int adj = __popcll(ov & SA_LSB_MASK);
+            const int cons = __popcll((ov & (ov << 1)) & SA_LSB_MASK);
+            count = (u32)(adj - ((cons + 1) >> 1));
+            const u64 msbs = l & ~SA_LSB_MASK;
+            nxt = (cont == CONT_RHS) ? ((((r << 1) & r) & SA_LSB_MASK) | msbs)
+                                     : (msbs | ((l & (l >> 1)) & SA_LSB_MASK));
+        } else {
+            const u64 ov = (l & SA_LSB_MASK) & ((r & SA_LSB_MASK) >> 1);
+            count = (u32)__popcll(ov);
+            nxt = (cont == CONT_RHS) ? (((ov << 1) & SA_LSB_MASK) | (r & SA_HEADER_MASK))
+                                     : (ov | (l & SA_HEADER_MASK));
+        }
+        next_inner[pos] = nxt;
+        if (count) atomicAdd(&step[l >> SA_KEY_SHIFT], count);
+    }
+};
+
+// cross-word matches: lhs bit 17 & rhs bit 0 at header + 1 (bigram_freqs.py:158-188)
+struct AdjBigram {
+    const u64* lhs; const u64* rhs; const u32* jadj;
+    u64* next_adj; u32* step; int cont;
+    __device__ __forceinline__ bool flag(u32 i) const {
+        const u32 j = jadj[i];
+        return j != SA_NONE && (lhs[i] & SA_UPPER_BIT) != 0 && (rhs[j] & 1ull) != 0;
+    }
+    __device__ __forceinline__ void emit(u32 i, u32 pos) const {
+        const u64 l = lhs[i], r = rhs[jadj[i]];
+        next_adj[pos] = (cont == CONT_RHS) ? ((r & SA_HEADER_MASK) | 1ull) : ((l & SA_HEADER_MASK) | SA_UPPER_BIT);
+        atomicAdd(&step[l >> SA_KEY_SHIFT], 1u);
+    }
+};
+
+// _set_adjbit_at_header (bigram_freqs.py:191-210), part 1: OR the adjacency bit into the inner
+// continuation word with the same header and mark that adjacent word as absorbed.
+__global__ void __launch_bounds__(256)
+sa_k_absorb_adj(u64* __restrict__ next_inner, const u32* __restrict__ ni_dev, const u64* __restrict__ next_adj,
+                const u32* __restrict__ na_dev, u32* __restrict__ absorbed, int cont) {
+    const u32 ni = *ni_dev, na = *na_dev;
+    const u64 bit = (cont == CONT_RHS) ? 1ull : SA_UPPER_BIT;
+    for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < na; j += gridDim.x * blockDim.x) {
+        const u64 h = next_adj[j] & SA_HEADER_MASK;
+        const u32 idx = sa_lower_bound(next_inner, 0, ni, h, SA_HEADER_MASK);
+        if (idx < ni && (next_inner[idx] & SA_HEADER_MASK) == h) {
+            atomicOr((unsigned long long*)&next_inner[idx], (unsigned long long)bit);
+            absorbed[j] = 1u;
+        } else {
+            absorbed[j] = 0u;
+        }
+    }
+}
+
+struct KeepUnabsorbed {
+    const u64* next_adj; const u32* absorbed; u64* out;
+    __device__ __forceinline__ bool flag(u32 j) const { return absorbed[j] == 0u; }
+    __device__ __forceinline__ void emit(u32 j, u32 pos) const { out[pos] = next_adj[j]; }
+};
+
+// part 2: merge(next_inner, unabsorbed adj) (merge.pyx:54-92; the two sets have disjoint headers,
+// so each element's output slot is its own rank plus its rank in the other array).
+__global__ void __launch_bounds__(256)
+sa_k_merge_by_rank(const u64* __restrict__ a, const u32* __restrict__ na_dev, const u64* __restrict__ b,
+                   const u32* __restrict__ nb_dev, u64* __restrict__ out, u32* __restrict__ nout_dev) {
+    const u32 na = *na_dev, nb = *nb_dev;
+    const u32 total = na + nb;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        if (i < na) {
+            const u64 x = a[i];
+            out[i + sa_lower_bound(b, 0, nb, x, ~0ull)] = x;
+        } else {
+            const u32 j = i - na;
+            const u64 x = b[j];
+            out[j + sa_lower_bound(a, 0, na, x, ~0ull)] = x;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *nout_dev = total;
+}
+
+// running = min(running, step) and clear step (the ids-intersect + np.minimum of
+// _intersect_bigram_matches, middle_out.py:73-93, in dense form)
+__global__ void __launch_bounds__(256)
+sa_k_min_step(float* __restrict__ running, u32* __restrict__ step, u64 n, int first) {
+    for (u64 d = (u64)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += (u64)gridDim.x * blockDim.x) {
+        const float c = (float)step[d];
+        step[d] = 0u;
+        running[d] = first ? c : (c < running[d] ? c : running[d]);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+sa_k_min2(float* __restrict__ a, const float* __restrict__ b, u64 n) {
+    for (u64 d = (u64)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += (u64)gridDim.x * blockDim.x)
+        a[d] = b[d] < a[d] ? b[d] : a[d];
+}
+
+// ---------------------------------------------------------------------------------------
+// fused kernel (pairwise-distinct terms)
+// ---------------------------------------------------------------------------------------
+struct FusedPhraseParams {
+    const u64* words;
+    u64 off[SA_MAX_PHRASE];      // start of each term's words
+    u32 len[SA_MAX_PHRASE];
+    int T, anchor;
+    u32* step;                   // dense per-doc match counts (u32, atomically accumulated)
+};
+
+// 18-bit payload of the word with header h in [base, base+n), 0 if absent.  `hint` carries the
+// previous probe's position so the three probes h-1, h, h+1 cost one search.
+__device__ __forceinline__ u64 sa_payload_at(const u64* __restrict__ a, u32 n, u64 h, u32& hint) {
+    const u32 j = sa_lower_bound(a, hint, n, h, SA_HEADER_MASK);
+    hint = j;
+    return (j < n && (a[j] & SA_HEADER_MASK) == h) ? (a[j] & SA_LSB_MASK) : 0ull;
+}
+
+__global__ void __launch_bounds__(256) sa_k_phrase_fused(const FusedPhraseParams p) {
+    const u64* anc = p.words + p.off[p.anchor];
+    const u32 na = p.len[p.anchor];
+    const u64 delta = 1ull << SA_LSB_BITS;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < na; i += gridDim.x * blockDim.x) {
+        const u64 w = anc[i];
+        const u64 h = w & SA_HEADER_MASK;
+        const u64 doc_key = w & SA_KEY_MASK;
+        u64 m = w & SA_LSB_MASK;                 // bit p: anchor term at position 18*blk + p
+        for (int t = 0; t < p.T && m; t++) {
+            if (t == p.anchor) continue;
+            const int d = t - p.anchor;          // term t must sit at anchor position + d, |d| < 18
+            const u64* a = p.words + p.off[t];
+            const u32 n = p.len[t];
+            // 54-bit window: payloads of headers h-1 | h | h+1 (same doc only)
+            u32 hint = 0;
+            u64 win = 0;
+            if (d < 0) {
+                const u64 hm = h - delta;
+                if ((h & ~SA_KEY_MASK & SA_HEADER_MASK) != 0 && (hm & SA_KEY_MASK) == doc_key)
+                    win |= sa_payload_at(a, n, hm, hint);
+            }
+            win |= sa_payload_at(a, n, h, hint) << 18;
+            if (d > 0) {
+                const u64 hp = h + delta;
+                if ((hp & SA_KEY_MASK) == doc_key) win |= sa_payload_at(a, n, hp, hint) << 36;
+            }
+            m &= (win >> (18 + d)) & SA_LSB_MASK;
+        }
+        if (m) atomicAdd(&p.step[w >> SA_KEY_SHIFT], (u32)__popcll(m));
+    }
+}
+
+// tf (phrase counts) -> BM25 in place; reference bm25.pyx:11-25 over the dense phrase_freqs
+__global__ void __launch_bounds__(256)
+sa_k_bm25_from_tf(float* __restrict__ tf, const float* __restrict__ dl, float avgdl, float idf, float k1, float b, u64 n) {
+    const float one_minus_b = 1.0f - b;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const float t = tf[i];
+        const float norm = __fmul_rn(k1, __fadd_rn(one_minus_b, __fmul_rn(b, __fdiv_rn(dl[i], avgdl))));
+        tf[i] = __fmul_rn(__fdiv_rn(t, __fadd_rn(t, norm)), idf);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, used = 0;
+    template <class T> T* take(size_t n) {
+        const size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+        if (used + bytes > cap) return nullptr;
+        T* p = (T*)(base + used);
+        used += bytes;
+        return p;
+    }
+};
+
+struct DArr {              // device array of roaringish words with a device-resident length
+    const u64* data;
+    const u32* n_dev;
+    u32 bound;             // host-known upper bound of the length
+};
+
+static inline u32 sa_grid_for(u64 n) {
+    const u64 g = (n + 255) / 256;
+    return (u32)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+struct StepScratch {
+    u32 *jin, *jadj, *absorbed, *chunks, *cnt;   // cnt: [0]=ni [1]=na [2]=nu [3]=same
+    u64 *next_inner, *next_adj, *ua;
+    u32 cap;
+};
+
+// One bigram step on the stream: updates `step` (dense counts) and writes the continuation
+// array into out (length -> out_n_dev).
+static int sa_bigram_step(hipStream_t st, const DArr& lhs, const DArr& rhs, int cont, StepScratch& s,
+                          u32* step, u64* out, u32* out_n_dev) {
+    if (lhs.bound > s.cap) { sa_set_error("internal: phrase scratch too small"); return SA_ERR_STATE; }
+    SA_HIP(hipMemsetAsync(s.cnt, 0, 3 * sizeof(u32), st));
+    const u32 one = 1u;
+    SA_HIP(hipMemcpyAsync(s.cnt + 3, &one, sizeof(u32), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(sa_k_probe, dim3(sa_grid_for(lhs.bound)), dim3(256), 0, st, lhs.data, lhs.n_dev, rhs.data,
+                       rhs.n_dev, s.jin, s.jadj, s.cnt + 3);
+    InnerBigram ib;
+    ib.lhs = lhs.data; ib.rhs = rhs.data; ib.jin = s.jin; ib.same = s.cnt + 3;
+    ib.next_inner = s.next_inner; ib.step = step; ib.cont = cont;
+    sa_compact(ib, lhs.n_dev, lhs.bound, s.chunks, s.cnt + 0, st);
+    AdjBigram ab;
+    ab.lhs = lhs.data; ab.rhs = rhs.data; ab.jadj = s.jadj; ab.next_adj = s.next_adj; ab.step = step; ab.cont = cont;
+    sa_compact(ab, lhs.n_dev, lhs.bound, s.chunks, s.cnt + 1, st);
+    hipLaunchKernelGGL(sa_k_absorb_adj, dim3(sa_grid_for(lhs.bound)), dim3(256), 0, st, s.next_inner, s.cnt + 0,
+                       s.next_adj, s.cnt + 1, s.absorbed, cont);
+    KeepUnabsorbed ku;
+    ku.next_adj = s.next_adj; ku.absorbed = s.absorbed; ku.out = s.ua;
+    sa_compact(ku, s.cnt + 1, lhs.bound, s.chunks, s.cnt + 2, st);
+    hipLaunchKernelGGL(sa_k_merge_by_rank, dim3(sa_grid_for(2ull * lhs.bound)), dim3(256), 0, st, s.next_inner,
+                       s.cnt + 0, s.ua, s.cnt + 2, out, out_n_dev);
+    return SA_OK;
+}
+
+struct PhrasePlan {
+    int T;
+    u32 terms[SA_MAX_PHRASE];
+};
+
+// dense phrase counts of terms[0..T) into d_running (float[n_docs]); uses the index scratch.
+// mode: 0 auto, 1 general chain, 2 fused.
+static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mode, float** d_running_out) {
+    hipStream_t st = ix->stream;
+    const u64 N = ix->n_docs;
+    u32 lens[SA_MAX_PHRASE];
+    u64 offs[SA_MAX_PHRASE];
+    u32 maxlen = 0;
+    bool known = true, distinct = true;
+    for (int t = 0; t < T; t++) {
+        if (terms[t] >= ix->n_terms) { known = false; lens[t] = 0; offs[t] = 0; continue; }
+        offs[t] = ix->h_term_off[terms[t]];
+        lens[t] = (u32)(ix->h_term_off[terms[t] + 1] - offs[t]);
+        maxlen = lens[t] > maxlen ? lens[t] : maxlen;
+        for (int u = 0; u < t; u++) if (terms[u] == terms[t]) distinct = false;
+    }
+    const size_t M = (size_t)maxlen + 64;
+    const size_t chunk_words = sa_compact_chunks((u32)(2 * M)) + 8;
+    const size_t need = (N + 64) * 12 + M * (3 * 4 + 3 * 8 + 2 * 8 * 2) + chunk_words * 4 + 16 * 1024;
+    void* scratch;
+    SA_TRY(sa_index_scratch(ix, need, &scratch));
+    Arena ar;
+    ar.base = (char*)scratch; ar.cap = need;
+    float* running = ar.take<float>(N + 1);
+    float* running2 = ar.take<float>(N + 1);
+    u32* step = ar.take<u32>(N + 1);
+    u32* lens_dev = ar.take<u32>(SA_MAX_PHRASE + 8);          // [t] term lengths, then ping-pong counters
+    StepScratch s;
+    s.cap = (u32)M;
+    s.jin = ar.take<u32>(M); s.jadj = ar.take<u32>(M); s.absorbed = ar.take<u32>(M);
+    s.chunks = ar.take<u32>(chunk_words); s.cnt = ar.take<u32>(8);
+    s.next_inner = ar.take<u64>(M); s.next_adj = ar.take<u64>(M); s.ua = ar.take<u64>(M);
+    u64* pp[2] = {ar.take<u64>(2 * M), ar.take<u64>(2 * M)};
+    if (!pp[1] || !s.ua || !running2) { sa_set_error("internal: phrase arena exhausted"); return SA_ERR_STATE; }
+    *d_running_out = running;
+    SA_HIP(hipMemsetAsync(running, 0, N * sizeof(float), st));
+    SA_HIP(hipMemsetAsync(step, 0, N * sizeof(u32), st));
+    if (!known || N == 0) return SA_OK;                         // TermMissingError -> zeros (postings.py:705-708)
+    SA_HIP(hipMemcpyAsync(lens_dev, lens, (size_t)T * sizeof(u32), hipMemcpyHostToDevice, st));
+    u32* ppn = lens_dev + SA_MAX_PHRASE;                        // two ping-pong length counters
+
+    // plan: reference compute_phrase_freqs, middle_out.py:154-168 (first shortest on ties)
+    int shortest = 0;
+    for (int t = 1; t < T; t++) if (lens[t] < lens[shortest]) shortest = t;
+    const bool l2r_only = shortest <= 1, r2l_only = !l2r_only && shortest >= T - 2;
+
+    const bool use_fused = (mode == 2) || (mode == 0 && distinct);
+    if (use_fused) {
+        if (!distinct) { sa_set_error("fused phrase kernel needs pairwise-distinct terms"); return SA_ERR_ARG; }
+        // sub-phrases the reference evaluates: the whole phrase (l2r / r2l plans) or the two halves
+        int parts[2][2] = {{0, T}, {0, 0}};
+        int nparts = 1;
+        if (!l2r_only && !r2l_only) { parts[0][1] = shortest; parts[1][0] = shortest; parts[1][1] = T; nparts = 2; }
+        for (int pi = 0; pi < nparts; pi++) {
+            const int a = parts[pi][0], b = parts[pi][1];
+            FusedPhraseParams fp;
+            memset(&fp, 0, sizeof(fp));
+            fp.words = ix->d_words; fp.T = b - a; fp.step = step;
+            int anchor = 0;
+            for (int t = a; t < b; t++) {
+                fp.off[t - a] = offs[t]; fp.len[t - a] = lens[t];
+                if (lens[t] < lens[a + anchor]) anchor = t - a;
+            }
+            fp.anchor = anchor;
+            if (fp.T > 18) { sa_set_error("phrases longer than 18 terms are not supported"); return SA_ERR_UNSUPPORTED; }
+            if (fp.len[anchor] > 0)
+                hipLaunchKernelGGL(sa_k_phrase_fused, dim3(sa_grid_for(fp.len[anchor])), dim3(256), 0, st, fp);
+            hipLaunchKernelGGL(sa_k_min_step, dim3(sa_grid_for(N)), dim3(256), 0, st, running, step, N, pi == 0 ? 1 : 0);
+        }
+        return SA_OK;
+    }
+
+    // general chain
+    auto term_arr = [&](int t) {
+        DArr a; a.data = ix->d_words + offs[t]; a.n_dev = lens_dev + t; a.bound = lens[t]; return a;
+    };
+    auto chain = [&](int a, int b, bool left_to_right, float* dst) -> int {
+        // enc = terms[a..b)
+        int first = 1, cur = 0;
+        if (left_to_right) {
+            DArr lhs = term_arr(a);
+            for (int t = a + 1; t < b; t++) {
+                DArr rhs = term_arr(t);
+                SA_TRY(sa_bigram_step(st, lhs, rhs, CONT_RHS, s, step, pp[cur], ppn + cur));
+                hipLaunchKernelGGL(sa_k_min_step, dim3(sa_grid_for(N)), dim3(256), 0, st, dst, step, N, first);
+                first = 0;
+                const u32 nb = lhs.bound < rhs.bound ? 2 * lhs.bound : rhs.bound;     // cont headers come from rhs
+                lhs.data = pp[cur]; lhs.n_dev = ppn + cur; lhs.bound = nb < rhs.bound ? nb : rhs.bound;
+                cur ^= 1;
+            }
+        } else {
+            DArr rhs = term_arr(b - 1);
+            for (int t = b - 2; t >= a; t--) {
+                DArr lhs = term_arr(t);
+                SA_TRY(sa_bigram_step(st, lhs, rhs, CONT_LHS, s, step, pp[cur], ppn + cur));
+                hipLaunchKernelGGL(sa_k_min_step, dim3(sa_grid_for(N)), dim3(256), 0, st, dst, step, N, first);
+                first = 0;
+                const u32 nb = rhs.bound < lhs.bound ? 2 * rhs.bound : lhs.bound;     // cont headers come from lhs
+                rhs.data = pp[cur]; rhs.n_dev = ppn + cur; rhs.bound = nb < lhs.bound ? nb : lhs.bound;
+                cur ^= 1;
+            }
+        }
+        return SA_OK;
+    };
+    if (l2r_only) {
+        SA_TRY(chain(0, T, true, running));
+    } else if (r2l_only) {
+        SA_TRY(chain(0, T, false, running));
+    } else {
+        SA_TRY(chain(0, shortest, true, running));
+        SA_TRY(chain(shortest, T, false, running2));
+        hipLaunchKernelGGL(sa_k_min2, dim3(sa_grid_for(N)), dim3(256), 0, st, running, running2, N);
+    }
+    return SA_OK;
+}
+
+static int sa_phrase_mode() {
+    const char* v = getenv("SA_PHRASE_MODE");
+    if (!v) return 0;
+    if (!strcmp(v, "general")) return 1;
+    if (!strcmp(v, "fused")) return 2;
+    return 0;
+}
+
+extern "C" int sa_index_phrase_freqs_dense(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop, float* out) {
+    SA_ARG(ix && out && terms, "null argument");
+    // reference middle_out.py:425-426
+    if (n_terms < 2) { sa_set_error("Must have at least two terms"); return SA_ERR_ARG; }
+    SA_ARG(n_terms <= SA_MAX_PHRASE, "phrase too long (max 32 terms)");
+    if (slop != 0) { sa_set_error("slop > 0 is not implemented on the device yet"); return SA_ERR_UNSUPPORTED; }
+    std::lock_guard<std::mutex> g(ix->mu);
+    SA_HIP(hipSetDevice(ix->device));
+    float* d_running = nullptr;
+    SA_TRY(sa_phrase_counts_device(ix, terms, n_terms, sa_phrase_mode(), &d_running));
+    SA_HIP(hipMemcpyAsync(out, d_running, ix->n_docs * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    SA_HIP(hipStreamSynchronize(ix->stream));
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+
+// SearchArray.score(phrase): phrase counts -> BM25 with the idf summed over the phrase's terms
+// (reference postings.py:652-680, similarity.py:19-38); idf is computed by the host.
+extern "C" int sa_index_bm25_phrase_dense(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop,
+                                          float idf, float k1, float b, float* out) {
+    SA_ARG(ix && out && terms, "null argument");
+    if (n_terms < 2) { sa_set_error("Must have at least two terms"); return SA_ERR_ARG; }
+    SA_ARG(n_terms <= SA_MAX_PHRASE, "phrase too long (max 32 terms)");
+    if (slop != 0) { sa_set_error("slop > 0 is not implemented on the device yet"); return SA_ERR_UNSUPPORTED; }
+    std::lock_guard<std::mutex> g(ix->mu);
+    SA_HIP(hipSetDevice(ix->device));
+    const u64 N = ix->n_docs;
+    if (ix->avg_doc_len == 0.f) {                      // similarity.py:31-32
+        memset(out, 0, N * sizeof(float));
+        return SA_OK;
+    }
+    float* d_running = nullptr;
+    SA_TRY(sa_phrase_counts_device(ix, terms, n_terms, sa_phrase_mode(), &d_running));
+    if (N) hipLaunchKernelGGL(sa_k_bm25_from_tf, dim3(sa_grid_for(N)), dim3(256), 0, ix->stream, d_running,
+                              ix->d_doc_lens, ix->avg_doc_len, idf, k1, b, N);
+    SA_HIP(hipMemcpyAsync(out, d_running, N * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    SA_HIP(hipStreamSynchronize(ix->stream));
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}

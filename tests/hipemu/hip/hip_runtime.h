@@ -55,7 +55,7 @@ namespace hipemu {
 
 constexpr int WAVE = 64;
 enum State { RUNNABLE, WAIT_BLOCK, WAIT_WAVE, DONE };
-enum WaveOp { OP_NONE, OP_SHFL, OP_BALLOT, OP_FIRST };
+enum WaveOp { OP_NONE, OP_SHFL, OP_BALLOT, OP_FIRST, OP_DPP };
 
 struct Fiber {
     ucontext_t ctx;
@@ -67,6 +67,8 @@ struct Fiber {
     WaveOp op = OP_NONE;
     uint64_t val = 0;      // posted value (shfl payload / predicate)
     int src = 0;           // shfl source lane
+    uint64_t old = 0;      // DPP: value kept when the lane is masked off / source invalid
+    int ctrl = 0, row_mask = 0xf, bank_mask = 0xf, bound_ctrl = 0;
     uint64_t result = 0;
 };
 
@@ -156,6 +158,20 @@ inline void run_block() {
                 if (f.state != WAIT_WAVE) continue;
                 if (op == OP_BALLOT) f.result = ballot;
                 else if (op == OP_FIRST) f.result = m.fibers[first].val;
+                else if (op == OP_DPP) {
+                    // gfx9 DPP semantics for the controls the kernels use
+                    const int l = i - lo, row = l >> 4, bank = (l & 15) >> 2;
+                    int s = -1;
+                    if (f.ctrl >= 0x111 && f.ctrl <= 0x11F) { const int n = f.ctrl - 0x110; if ((l & 15) >= n) s = l - n; }
+                    else if (f.ctrl == 0x142) { if (row >= 1) s = (row - 1) * 16 + 15; }
+                    else if (f.ctrl == 0x143) { if (row >= 2) s = 31; }
+                    else die("unsupported dpp_ctrl in emulator");
+                    const bool enabled = ((f.row_mask >> row) & 1) && ((f.bank_mask >> bank) & 1);
+                    const bool valid = s >= 0 && lo + s < hi && m.fibers[lo + s].state == WAIT_WAVE;
+                    if (!enabled) f.result = f.old;
+                    else if (valid) f.result = m.fibers[lo + s].val;
+                    else f.result = f.bound_ctrl ? 0 : f.old;
+                }
                 else {  // OP_SHFL
                     int s = lo + (f.src & (WAVE - 1));
                     if (s < hi && m.fibers[s].state == WAIT_WAVE) f.result = m.fibers[s].val;
@@ -254,6 +270,15 @@ inline int __all(int pred) {
     // all participating lanes true <=> no participating lane false
     return __ballot(!pred) == 0;
 }
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    hipemu::Fiber* f = hipemu::M().cur;
+    f->old = (uint64_t)(uint32_t)old; f->ctrl = ctrl; f->row_mask = row_mask; f->bank_mask = bank_mask;
+    f->bound_ctrl = bound_ctrl ? 1 : 0;
+    return (int)(uint32_t)hipemu::wave_collective(hipemu::OP_DPP, (uint64_t)(uint32_t)src, 0);
+}
+inline int __builtin_amdgcn_readlane(int v, int lane) {
+    return (int)(uint32_t)hipemu::wave_collective(hipemu::OP_SHFL, (uint64_t)(uint32_t)v, lane);
+}
 inline int __builtin_amdgcn_readfirstlane(int v) {
     return (int)hipemu::wave_collective(hipemu::OP_FIRST, (uint64_t)(uint32_t)v, 0);
 }
@@ -272,6 +297,8 @@ inline float __fdiv_rn(float a, float b) { return a / b; }
 inline float __fmul_rn(float a, float b) { return a * b; }
 inline float __fadd_rn(float a, float b) { return a + b; }
 template <class T> inline T __ldg(const T* p) { return *p; }
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(ptr, order, scope) (*(ptr))
 
 // atomics (single OS thread: plain read-modify-write)
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }

@@ -112,12 +112,13 @@ def test_topk_massive_ties_takes_fallback_path(api):
         bt.close()
 
 
-def test_sparse_corpus_and_doc_base(api):
+@pytest.mark.parametrize("tile_docs", [1024, 2048])
+def test_sparse_corpus_and_doc_base(api, tile_docs):
     g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_sparse")
     words, wt = rz.encode_sorted(t, d, p)
     off = rz.term_offsets(wt, vocab)
     orc = O.OracleIndex.from_triples(t, d, p, num_docs, doc_lens=lens)
-    dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api, doc_base=100000)
+    dev = DeviceIndex(words, off, lens, tile_docs=tile_docs, api=api, doc_base=100000)
     assert np.array_equal(dev.docfreqs(), g["df"])
     q = g["or_queries"][:4]
     for row, want in zip(q, g["or_scores"][:4]):
@@ -141,3 +142,26 @@ def test_empty_and_degenerate_indexes(api):
     bt.run()
     s, d_ = bt.fetch()
     assert (s == 0).all() and (d_ == NO_DOC).all()
+
+
+@pytest.mark.parametrize("tile_docs,k", [(1024, 10), (2048, 3), (1024, 32)])
+def test_topk_pruning_over_many_tiles(api, tile_docs, k):
+    """Enough tiles that the global pruning slots fill up (> 32 waves per query): most waves are
+    rejected by the bound, and the result must still be the exact top-k."""
+    n_docs, vocab = 40000, 400
+    t, d, p, lens = synth.corpus_triples(n_docs, vocab, 10, seed=11)
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=tile_docs, api=api)
+    orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
+    queries = np.asarray([[0, 5, 50, 300], [1, 2, 3, 4], [7, 90, 200, 399], [399, 398, 397, 396]])
+    bt = dev.batch(queries, k=k)
+    for _ in range(2):                      # a second run must reset the slots / cursors
+        bt.run()
+        scores, docs = bt.fetch()
+        for qi, q in enumerate(queries):
+            ws, wd = O.topk(orc.score_terms_sum([int(x) for x in q]), k)
+            n = int((ws > 0).sum())
+            assert np.array_equal(scores[qi, :n], ws[:n]), f"q{qi} scores"
+            assert np.array_equal(docs[qi, :n], wd[:n]), f"q{qi} docs"
+            assert (docs[qi, n:] == NO_DOC).all()
+    bt.close()
