@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--tiles", default="2048,4096,8192,16384")
     ap.add_argument("--ks", default="10")
     ap.add_argument("--dir-divs", default="8")
+    ap.add_argument("--kflags", default="0")
     ap.add_argument("--corpus-cache", default="")
     args = ap.parse_args()
     api = _lib.api()
@@ -51,8 +52,9 @@ def main():
         build_s = time.time() - t0
         for k in [int(x) for x in args.ks.split(",")]:
             batch = QueryBatch(index, queries, k=k)
-            modes = [(0, 1, 0), (1, 1, 0), (0, 0, 0), (0, 1, 1)] if k <= 32 else [(0, 0, 0), (0, 0, 1)]
-            for xcd, argmax, notopk in modes:
+            modes = [(0, 1, 0, "0"), (0, 1, 1, "0")] if k <= 32 else [(0, 0, 0, "1")]
+            for xcd, argmax, notopk, kf in modes:
+                os.environ["SA_PERSISTENT"] = kf
                 os.environ["SA_XCD_MODE"] = str(xcd)
                 os.environ["SA_SMALLK_ARGMAX"] = str(argmax)
                 os.environ["SA_NO_TOPK"] = str(notopk)
@@ -67,7 +69,7 @@ def main():
                 dt = time.perf_counter() - t0
                 ms, alg, post = batch.profile()
                 print(json.dumps({"tile": tile, "dir_div": ddiv, "dir_terms": int(index.info().n_dir_terms), "k": k,
-                                  "xcd_mode": xcd, "argmax": argmax, "no_topk": notopk,
+                                  "xcd_mode": xcd, "argmax": argmax, "no_topk": notopk, "grid_mult": kf,
                                   "qps": round(B * args.steps / dt, 1), "ms_per_step": round(dt / args.steps * 1e3, 3),
                                   "kernel_ms": round(ms, 3), "alg_GBps": round(alg / ms / 1e6, 1),
                                   "postings_GBps": round(post / ms / 1e6, 1), "index_build_s": round(build_s, 1)}),

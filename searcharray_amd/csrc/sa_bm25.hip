@@ -41,9 +41,12 @@ struct Bm25Params {
     // batch
     const u32* terms;      // [B][T]
     const float* idf;      // [B][T]
+    const float* sattab;   // [SA_SAT_NTF][tab_w] saturation table (sa_k_make_sattab)
+    u32 tab_w;             // 0: no table (doc lengths not packed in the postings); else 64/128
+    const u32* bounds;     // [B][T][n_tiles+1] slice table (sa_k_make_bounds)
+    const u64* qbase;      // [B][T] posting base of each query term
     u32 B, T, k;
     float k1, b, avgdl;
-    u32 q_per_xcd;         // >0: XCD-grouped block mapping, 0: plain tile-major
     int small_k_argmax;    // k <= 32: iterative block arg-max instead of threshold selection
     int no_topk;           // timing experiments only: skip the per-tile selection
     u32 cand_per_tile;     // general mode: candidate slots per (query, tile) = k
@@ -55,120 +58,187 @@ struct Bm25Params {
     u64* cand;             // [B][n_tiles][k] composite keys (global doc ids) or null
 };
 
-// block -> (tile, query).  Hardware places consecutive workgroups on consecutive XCDs
-// (block b -> XCD b % 8, each XCD with a private 4 MiB L2).  In grouped mode XCD x serves
-// queries [x*q_per_xcd, (x+1)*q_per_xcd) and walks the tiles in order, so the queries that
-// stream the same tile of the same frequent term hit that XCD's L2.  Speed only.
-__device__ __forceinline__ bool sa_map_block(const Bm25Params& p, u32& tile, u32& q) {
-    const u32 b = blockIdx.x;
-    if (p.q_per_xcd) {
-        const u32 xcd = b & 7u, j = b >> 3;
-        tile = j / p.q_per_xcd;
-        q = xcd * p.q_per_xcd + (j % p.q_per_xcd);
-        return q < p.B && tile < p.n_tiles;
+// Saturation table of a batch.  For integer doc lengths dl < tab_w and term frequencies
+// 1 <= tf <= SA_SAT_NTF the per-posting factor  tf / (tf + k1 * ((1 - b) + b * (dl / avgdl)))
+// depends only on (tf, dl) and the batch constants, so it is tabulated once per batch with the
+// reference's exact operation order (bm25.pyx:19-23: every op rounded to fp32, IEEE division) and
+// copied into LDS by each workgroup: scoring a posting becomes one LDS read and one multiply by
+// idf instead of two divisions.  Postings outside the table take the arithmetic path.
+#define SA_SAT_NTF 8
+#define SA_SAT_WMAX 128
+
+__global__ void sa_k_make_sattab(float* __restrict__ tab, u32 tab_w, float k1, float b, float avgdl) {
+    const float one_minus_b = 1.0f - b;
+    const u32 n = SA_SAT_NTF * tab_w;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float tf = (float)(i / tab_w + 1), dl = (float)(i % tab_w);
+        const float norm = __fmul_rn(k1, __fadd_rn(one_minus_b, __fmul_rn(b, __fdiv_rn(dl, avgdl))));
+        tab[i] = __fdiv_rn(tf, __fadd_rn(tf, norm));
     }
-    tile = b / p.B;
-    q = b % p.B;
-    return tile < p.n_tiles;
 }
 
-template <int TILE, int THREADS>
+// Per-batch slice table: for every (query, term, tile) the first posting of that term whose
+// doc id is >= tile * TILE, relative to the term's posting base (qbase).  Built once per batch
+// (the index is immutable) from the tile directory -- or by a lower-bound search for terms too
+// rare to have a directory row -- so the scoring kernel finds its slices with ONE dependent load.
+__global__ void __launch_bounds__(256)
+sa_k_make_bounds(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, const u32* __restrict__ dir_slot,
+                 const u32* __restrict__ tile_dir, u32 n_terms, u32 n_tiles, u32 tile_docs,
+                 const u32* __restrict__ terms, u32 BT, u32* __restrict__ bounds, u64* __restrict__ qbase) {
+    const u64 total = (u64)BT * (n_tiles + 1);
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (u64)gridDim.x * blockDim.x) {
+        const u32 qt = (u32)(e / (n_tiles + 1)), tile = (u32)(e % (n_tiles + 1));
+        const u32 term = terms[qt];
+        u32 rel = 0;
+        u64 base = 0;
+        if (term < n_terms) {
+            base = tf_off[term];
+            const u32 cnt = (u32)(tf_off[term + 1] - base);
+            const u32 slot = dir_slot[term];
+            if (slot != 0xFFFFFFFFu) rel = tile_dir[(u64)slot * (n_tiles + 1) + tile];
+            else rel = sa_lower_bound(tfp + base, 0, cnt, ((u64)tile * tile_docs) << SA_KEY_SHIFT, SA_KEY_MASK);
+        }
+        bounds[e] = rel;
+        if (tile == 0) qbase[qt] = base;
+    }
+}
+
+// MODE 0: dense output and/or block-level threshold top-k (any k <= 1024).
+// MODE 1: pruned wave-level top-k (k <= 32), the batch fast path.
+template <int TILE, int THREADS, int MODE>
 __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
     constexpr int NW = THREADS / SA_WAVE;
     constexpr int E = TILE / THREADS;
-    constexpr int CAP = (TILE >= 8192) ? 2048 : TILE / 4;      // candidate list capacity
+    constexpr int CAP = (TILE >= 8192) ? 2048 : TILE / 4;      // candidate list capacity (MODE 0)
     constexpr int LE = (CAP + THREADS - 1) / THREADS;
     constexpr size_t ACC_BYTES = (size_t)TILE * 4;
-    constexpr size_t SEL_BYTES = (size_t)(CAP + SA_KMAX) * 8;
+    constexpr size_t SEL_BYTES = MODE == 0 ? (size_t)(CAP + SA_KMAX) * 8 : 0;
     constexpr size_t SMEM_U64 = (ACC_BYTES > SEL_BYTES ? ACC_BYTES : SEL_BYTES) / 8;
+    constexpr int PF = 4;                                       // 16-byte loads in flight per lane
     __shared__ u64 smem[SMEM_U64];
     __shared__ u64 s_lo[SA_MAX_QTERMS], s_hi[SA_MAX_QTERMS];
     __shared__ u64 red64[NW + 1];
     __shared__ u32 red[NW + 1];
     __shared__ u32 s_cnt[2];
+    __shared__ float s_tab[SA_SAT_NTF * SA_SAT_WMAX];
     float* acc = (float*)smem;
 
-    u32 tile, q;
-    if (!sa_map_block(p, tile, q)) return;              // uniform per block
+    // Work items (tile, query) are numbered tile-major, one workgroup per item: the items in
+    // flight at any moment are the same few tiles across many queries, so posting slices shared
+    // by queries are served from L2.  (A resident grid walking the items with a static stride was
+    // measured slower on MI355X -- 3.3-3.7 ms vs 2.7 ms per 256-query batch at 10M docs: the
+    // hardware dispatcher is the better load balancer, and the loop inflates register use.)
     const u32 tid = threadIdx.x;
-    const u64 tile_base = (u64)tile * TILE;
     const u32 T = p.T;
+    const u32 tab_w = p.tab_w;
+    for (u32 i = tid; i < SA_SAT_NTF * tab_w; i += THREADS) s_tab[i] = p.sattab[i];
+    const u32 item = blockIdx.x;
+    const u32 tile = item / p.B, q = item % p.B;
+    const u64 tile_base = (u64)tile * TILE;
     // pruning slots of this query (see the top-k section); loaded first so the L2 latency hides
     // behind the posting stream.  L1-bypassing load: a fresher bound prunes more.
     u32 slot_val = 0xFFFFFFFFu;
-    if (p.small_k_argmax && (tid & (SA_WAVE - 1)) < 32u)
+    if (MODE == 1 && (tid & (SA_WAVE - 1)) < 32u)
         slot_val = __hip_atomic_load(&p.slots[q * 32u + (tid & 31u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-    // 1. clear accumulators, locate this tile's slice of every query term
+    // 1. this tile's slice [lo, hi) of every query term: one dependent load from the batch's
+    //    slice table; clear the accumulators meanwhile
+    if (tid < T) {
+        const u32 qt = q * T + tid;
+        const u32* row = p.bounds + (u64)qt * (p.n_tiles + 1) + tile;
+        const u64 base = p.qbase[qt];
+        s_lo[tid] = base + row[0];
+        s_hi[tid] = base + row[1];
+    }
 #pragma unroll
     for (int j = 0; j < E; j++) acc[j * THREADS + tid] = 0.f;
-    if (tid < T) {
-        const u32 term = p.terms[q * T + tid];
-        u64 lo = 0, hi = 0;
-        if (term < p.n_terms) {
-            const u64 base = p.tf_off[term];
-            const u32 cnt = (u32)(p.tf_off[term + 1] - base);
-            const u32 slot = p.dir_slot[term];
-            if (slot != 0xFFFFFFFFu) {
-                const u32* row = p.tile_dir + (u64)slot * (p.n_tiles + 1);
-                lo = base + row[tile];
-                hi = base + row[tile + 1];
-            } else {
-                const u32 a = sa_lower_bound(p.tfp + base, 0, cnt, tile_base << SA_KEY_SHIFT, SA_KEY_MASK);
-                const u32 z = sa_lower_bound(p.tfp + base, a, cnt, (tile_base + TILE) << SA_KEY_SHIFT, SA_KEY_MASK);
-                lo = base + a;
-                hi = base + z;
-            }
-        }
-        s_lo[tid] = lo;
-        s_hi[tid] = hi;
-    }
     __syncthreads();
 
-    // 2. term-at-a-time accumulation.  Postings are streamed as 16-byte pairs (one
-    // global_load_dwordx4 per lane, 4 in flight) from the 16-byte-aligned part of the slice;
-    // the unaligned head/tail posting is handled by lane 0.
+    // 2. term-at-a-time accumulation.  A slice is read as 16-byte pairs from its 16-byte-aligned
+    //    hull (one global_load_dwordx4 per lane, PF in flight); a pair element outside [lo, hi)
+    //    belongs to a neighbouring tile and is masked.  The first PF loads of term t+1 are issued
+    //    before term t is scored, so short slices cost no extra memory round trip.
     const float k1 = p.k1, bb = p.b, avgdl = p.avgdl;
     const float one_minus_b = 1.0f - bb;
-    auto score_into = [&](u64 x, float idf) {
+    // Per posting: unpack, saturation-table lookup (or the arithmetic path for out-of-table
+    // tf / dl), multiply by idf, and a read-modify-write of the doc's LDS accumulator.  One
+    // posting per (term, doc): no two lanes of a term phase touch the same slot.
+    auto score_into = [&](u64 x, bool valid, float idf) {
         const u32 d = (u32)((x >> SA_KEY_SHIFT) - tile_base);
-        const float tf = (float)(u32)(x & SA_LSB_MASK);
-        const float dl = p.dl_packed ? (float)(u32)((x >> SA_LSB_BITS) & SA_LSB_MASK)
-                                     : p.doc_lens[tile_base + d];
-        const float norm = __fmul_rn(k1, __fadd_rn(one_minus_b, __fmul_rn(bb, __fdiv_rn(dl, avgdl))));
-        const float s = __fmul_rn(__fdiv_rn(tf, __fadd_rn(tf, norm)), idf);
-        acc[d] = __fadd_rn(acc[d], s);
+        const u32 tfi = (u32)(x & SA_LSB_MASK);
+        const u32 dli = (u32)((x >> SA_LSB_BITS) & SA_LSB_MASK);
+        if (valid) {
+            float sat;
+            if (tfi - 1u < (u32)SA_SAT_NTF && dli < tab_w) {
+                sat = s_tab[(tfi - 1u) * tab_w + dli];
+            } else {
+                const float tf = (float)tfi;
+                const float dl = p.dl_packed ? (float)dli : p.doc_lens[tile_base + d];
+                const float norm = __fmul_rn(k1, __fadd_rn(one_minus_b, __fmul_rn(bb, __fdiv_rn(dl, avgdl))));
+                sat = __fdiv_rn(tf, __fadd_rn(tf, norm));
+            }
+            acc[d] = __fadd_rn(acc[d], __fmul_rn(sat, idf));
+        }
     };
+    struct Batch { sa_u64x2 v[PF]; };
+    // pairs [first, first + PF*THREADS) of the hull of [lo, hi)
+    auto load_batch = [&](u64 lo, u64 hi, u64 first) -> Batch {
+        Batch b;
+        const u64 a0 = lo & ~1ull;
+        const u64 npairs = (hi > a0) ? ((hi - a0 + 1) >> 1) : 0;
+        const sa_u64x2* pairs = (const sa_u64x2*)(p.tfp + a0);
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const u64 j = first + (u64)u * THREADS + tid;
+            if (j < npairs) b.v[u] = pairs[j];
+            else { b.v[u].x = 0; b.v[u].y = 0; }
+        }
+        return b;
+    };
+    auto score_batch = [&](const Batch& b, u64 lo, u64 hi, u64 first, float idf) {
+        const u64 a0 = lo & ~1ull;
+        const u64 npairs = (hi > a0) ? ((hi - a0 + 1) >> 1) : 0;
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            // wave-uniform skip: no lane of this wave has a pair at this step
+            const u64 jw = first + (u64)u * THREADS + (tid & ~(u32)(SA_WAVE - 1));
+            if (jw >= npairs) continue;
+            const u64 i0 = a0 + 2 * (first + (u64)u * THREADS + tid);
+            score_into(b.v[u].x, i0 >= lo && i0 < hi, idf);
+            score_into(b.v[u].y, i0 + 1 < hi, idf);          // i0 + 1 >= lo always holds
+        }
+    };
+    Batch cur = load_batch(s_lo[0], s_hi[0], 0);
     for (u32 t = 0; t < T; t++) {
         const u64 lo = s_lo[t], hi = s_hi[t];
         const float idf = p.idf[q * T + t];
-        u64 a = (lo + 1ull) & ~1ull;
-        if (a > hi) a = hi;
-        if (tid == 0 && lo < a) score_into(p.tfp[lo], idf);
-        const u64 npairs = (hi - a) >> 1;
-        const sa_u64x2* pairs = (const sa_u64x2*)(p.tfp + a);
-        u64 j = tid;
-        for (; j + 3ull * THREADS < npairs; j += 4ull * THREADS) {
-            sa_u64x2 pp[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) pp[u] = pairs[j + (u64)u * THREADS];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { score_into(pp[u].x, idf); score_into(pp[u].y, idf); }
+        Batch nxt;
+        const bool more = t + 1 < T;
+        if (more) nxt = load_batch(s_lo[t + 1], s_hi[t + 1], 0);
+        score_batch(cur, lo, hi, 0, idf);
+        const u64 a0 = lo & ~1ull;
+        const u64 npairs = (hi > a0) ? ((hi - a0 + 1) >> 1) : 0;
+        if (npairs > (u64)PF * THREADS) {                       // long slice (frequent term)
+            u64 first = (u64)PF * THREADS;
+            Batch b = load_batch(lo, hi, first);
+            while (first < npairs) {
+                const u64 nf = first + (u64)PF * THREADS;
+                Batch b2;
+                if (nf < npairs) b2 = load_batch(lo, hi, nf);
+                score_batch(b, lo, hi, first, idf);
+                if (nf < npairs) b = b2;
+                first = nf;
+            }
         }
-        for (; j < npairs; j += THREADS) {
-            const sa_u64x2 pq = pairs[j];
-            score_into(pq.x, idf);
-            score_into(pq.y, idf);
-        }
-        if (tid == 0 && ((hi - a) & 1ull)) score_into(p.tfp[hi - 1], idf);
         __syncthreads();
+        if (more) cur = nxt;
     }
 
     const u64 remain = p.n_docs - tile_base;
     const u32 tile_n = remain < (u64)TILE ? (u32)remain : (u32)TILE;
 
     // 3. dense drop-in output (SearchArray.score): coalesced tile store
-    if (p.dense_out) {
+    if (MODE == 0 && p.dense_out) {
         float* out = p.dense_out + (u64)q * p.n_docs + tile_base;
 #pragma unroll
         for (int j = 0; j < E; j++) {
@@ -176,15 +246,10 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
             if (e < tile_n) out[e] = acc[e];
         }
     }
-    if (!p.cand || p.no_topk) return;
-
-    // 4. per-tile top-k -> composite keys  score_bits<<32 | ~global_doc
     const u32 k = p.k;
-    u64* cand = p.cand + (p.small_k_argmax ? 0ull : ((u64)q * p.n_tiles + tile) * p.cand_per_tile);
-    u64* sel = smem + CAP;                    // selected keys (aliases acc once keys are in registers)
-    u32 nsel = 0;
-
-    if (p.small_k_argmax) {
+    if (p.cand && !p.no_topk) {
+    if constexpr (MODE == 1) {
+        do {
         // k <= 32: PRUNED selection.  Per query, 32 global slots hold the best score seen by 32
         // disjoint families of waves (slot = wave index mod 32), so G = min(slots) is a score that
         // at least 32 distinct docs reach: nothing below G can enter the top-k.  A wave whose
@@ -203,7 +268,8 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
         const u32 wmax = sa_wave_max_u32(lmax);
         const u32 g = sa_wave_min_u32(slot_val);
         const u32 thr = g > 1u ? g : 1u;
-        if (wmax < thr) return;                                   // wave-uniform
+        if (wmax < thr) break;                                    // wave-uniform
+#define SA_ELEM(j) ((u32)(j) * THREADS + tid)
         const u32 widx = tile * NW + wave;
         if (lane == 0) atomicMax(&p.slots[q * 32u + (widx & 31u)], wmax);
         u64* qcand = p.cand + (u64)q * p.cand_cap;
@@ -211,14 +277,14 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
         u32 c = 0;
 #pragma unroll
         for (int j = 0; j < E; j++)
-            c += (u32)__popcll(__ballot(__float_as_uint(acc[j * THREADS + tid]) >= thr));
+            c += (u32)__popcll(__ballot(__float_as_uint(acc[SA_ELEM(j)]) >= thr));
         if (c <= k) {
             u32 base = 0;
             if (lane == 0) base = atomicAdd(&p.cand_cnt[q], c);
             base = (u32)__builtin_amdgcn_readfirstlane((int)base);
 #pragma unroll
             for (int j = 0; j < E; j++) {
-                const u32 e = j * THREADS + tid;
+                const u32 e = SA_ELEM(j);
                 const u32 x = __float_as_uint(acc[e]);
                 const bool keep = x >= thr;
                 const u64 b = __ballot(keep);
@@ -229,7 +295,7 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
                 }
                 base += (u32)__popcll(b);
             }
-            return;
+            break;
         }
         // more than k survivors (first tiles of a query, or heavy ties): exact top-k of this wave.
         // Each lane tracks its best and second best element in registers (branch-free); the tile
@@ -239,7 +305,7 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
         do {                                                                          \
             b1k = 0; b1j = 0; b2k = 0; b2j = 0;                                       \
             _Pragma("unroll") for (int j = 0; j < E; j++) {                           \
-                const u32 x = __float_as_uint(acc[j * THREADS + tid]);                \
+                const u32 x = __float_as_uint(acc[SA_ELEM(j)]);                \
                 const bool g1 = x > b1k, g2 = x > b2k;                                \
                 const u32 n2k = g1 ? b1k : (g2 ? x : b2k);                            \
                 const u32 n2j = g1 ? b1j : (g2 ? (u32)j : b2j);                       \
@@ -253,7 +319,7 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
         for (u32 r = 0; r < k; r++) {
             const u32 m = sa_wave_max_u32(b1k);
             if (m == 0) break;                       // wave-uniform
-            const u32 e1 = (b1k == m) ? (b1j * THREADS + tid) : 0xFFFFFFFFu;
+            const u32 e1 = (b1k == m) ? SA_ELEM(b1j) : 0xFFFFFFFFu;
             const u32 emin = sa_wave_min_u32(e1);    // ties -> smallest doc id
             if (lane == r) mine_out = ((u64)m << 32) | (u64)emin;
             found = r + 1;
@@ -271,9 +337,13 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
             const u64 doc = p.doc_base + tile_base + (u32)(mine_out & 0xFFFFFFFFull);
             qcand[base + lane] = (mine_out & 0xFFFFFFFF00000000ull) | (u64)(u32)(~(u32)doc);
         }
-        return;
-    }
-
+#undef SA_ELEM
+        } while (0);
+    } else {
+    // 4. per-tile top-k -> composite keys  score_bits<<32 | ~global_doc
+    u64* cand = p.cand + ((u64)q * p.n_tiles + tile) * p.cand_per_tile;
+    u64* sel = smem + CAP;                    // selected keys (aliases acc once keys are in registers)
+    u32 nsel = 0;
     // general k: threshold selection.
     u32 key32[E];
     u32 lmax = 0, nnz_local = 0;
@@ -383,6 +453,8 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
         }
         cand[i] = o;
     }
+    }
+    }   // top-k
 }
 
 // Merge n_cand candidate keys per query into the k best, sorted descending.
@@ -492,6 +564,10 @@ struct sa_batch {
     u32* d_perm = nullptr;
     float* d_idf = nullptr;
     u64* d_cand = nullptr;          // [B][n_tiles][waves*k]: per-tile blocks, or per-query append lists
+    float* d_sattab = nullptr;      // saturation table of this batch's (k1, b, avgdl)
+    u32 tab_w = 0;
+    u32* d_bounds = nullptr;        // [B][T][n_tiles+1] slice table
+    u64* d_qbase = nullptr;         // [B][T]
     u32* d_cand_cnt = nullptr;      // [B] append cursors (pruned selection)
     u32* d_slots = nullptr;         // [B][32] pruning slots
     u64* d_local = nullptr;         // [B][k] per-shard result
@@ -507,10 +583,6 @@ struct sa_batch {
 
 int sa_comm_allgather_topk(sa_index* ix, const u64* d_local, u64* d_gather, size_t count, int* nranks_out);
 
-static int sa_env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
 
 static void sa_fill_params(const sa_index* ix, Bm25Params& p) {
     p.tfp = ix->d_tfp; p.tf_off = ix->d_tf_off; p.dir_slot = ix->d_dir_slot; p.tile_dir = ix->d_tile_dir;
@@ -526,27 +598,58 @@ static u32 sa_tile_waves(u32 tile_docs) {
     }
 }
 
-static int sa_launch_bm25(sa_index* ix, const Bm25Params& p, hipStream_t st) {
-    if (ix->n_tiles == 0 || p.B == 0) return SA_OK;
-    const u32 grid = p.q_per_xcd ? 8u * p.q_per_xcd * ix->n_tiles : p.B * ix->n_tiles;
+static int sa_launch_make_sattab(sa_index* ix, float* d_tab, u32* tab_w_out, float k1, float b, hipStream_t st) {
+    u32 w = 0;
+    if (ix->dl_packed) {
+        w = 64;
+        while (w < SA_SAT_WMAX && w <= ix->max_doc_len) w <<= 1;
+    }
+    *tab_w_out = w;
+    if (w) hipLaunchKernelGGL(sa_k_make_sattab, dim3(sa_div_up((u64)SA_SAT_NTF * w, 256)), dim3(256), 0, st, d_tab, w, k1, b,
+                              ix->avg_doc_len);
+    return SA_OK;
+}
+
+static int sa_launch_make_bounds(sa_index* ix, const u32* d_terms, u32 BT, u32* d_bounds, u64* d_qbase, hipStream_t st) {
+    const u64 total = (u64)BT * (ix->n_tiles + 1);
+    if (total == 0) return SA_OK;
+    const u32 grid = total / 256 + 1 < 8192 ? (u32)(total / 256 + 1) : 8192;
+    hipLaunchKernelGGL(sa_k_make_bounds, dim3(grid), dim3(256), 0, st, ix->d_tfp, ix->d_tf_off, ix->d_dir_slot,
+                       ix->d_tile_dir, ix->n_terms, ix->n_tiles, ix->tile_docs, d_terms, BT, d_bounds, d_qbase);
+    return SA_OK;
+}
+
+static int sa_env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+#define SA_LAUNCH_TILE(TILE, THREADS)                                                              \
+    {                                                                                              \
+        hipLaunchKernelGGL((sa_k_bm25_tiles<TILE, THREADS, MODE>), dim3((u32)n_items), dim3(THREADS), 0, st, p); \
+    }                                                                                              \
+    break
+
+template <int MODE>
+static int sa_launch_bm25_mode(sa_index* ix, const Bm25Params& p, hipStream_t st) {
+    const u64 n_items = (u64)p.B * ix->n_tiles;
     switch (ix->tile_docs) {
-        case 1024:
-            hipLaunchKernelGGL((sa_k_bm25_tiles<1024, 128>), dim3(grid), dim3(128), 0, st, p); break;
-        case 2048:
-            hipLaunchKernelGGL((sa_k_bm25_tiles<2048, 64>), dim3(grid), dim3(64), 0, st, p); break;
-        case 4096:
-            hipLaunchKernelGGL((sa_k_bm25_tiles<4096, 128>), dim3(grid), dim3(128), 0, st, p); break;
-        case 8192:
-            hipLaunchKernelGGL((sa_k_bm25_tiles<8192, 256>), dim3(grid), dim3(256), 0, st, p); break;
-        case 16384:
-            hipLaunchKernelGGL((sa_k_bm25_tiles<16384, 512>), dim3(grid), dim3(512), 0, st, p); break;
-        case 32768:
-            hipLaunchKernelGGL((sa_k_bm25_tiles<32768, 1024>), dim3(grid), dim3(1024), 0, st, p); break;
+        case 1024: SA_LAUNCH_TILE(1024, 128);
+        case 2048: SA_LAUNCH_TILE(2048, 64);
+        case 4096: SA_LAUNCH_TILE(4096, 128);
+        case 8192: SA_LAUNCH_TILE(8192, 256);
+        case 16384: SA_LAUNCH_TILE(16384, 512);
+        case 32768: SA_LAUNCH_TILE(32768, 1024);
         default:
             sa_set_error("unsupported tile_docs %u", ix->tile_docs);
             return SA_ERR_STATE;
     }
     return SA_OK;
+}
+
+static int sa_launch_bm25(sa_index* ix, const Bm25Params& p, hipStream_t st) {
+    if (ix->n_tiles == 0 || p.B == 0) return SA_OK;
+    return p.small_k_argmax ? sa_launch_bm25_mode<1>(ix, p, st) : sa_launch_bm25_mode<0>(ix, p, st);
 }
 
 extern "C" int sa_index_bm25_dense(sa_index_t* ix, const uint32_t* terms, const float* idf,
@@ -568,20 +671,26 @@ extern "C" int sa_index_bm25_dense(sa_index_t* ix, const uint32_t* terms, const 
     const int T = n_query_terms;
     SA_ARG(T <= SA_MAX_QTERMS, "more than 32 query terms per call is not supported");
     void* scratch;
-    SA_TRY(sa_index_scratch(ix, N * sizeof(float) * 2 + (size_t)T * 8 + 256, &scratch));
+    const size_t nb = (size_t)T * (ix->n_tiles + 1);
+    SA_TRY(sa_index_scratch(ix, N * sizeof(float) + (size_t)T * 16 + nb * 4 + SA_SAT_NTF * SA_SAT_WMAX * 4 + 1024, &scratch));
     float* d_out = (float*)scratch;
-    float* d_tmp = d_out + N;
-    u32* d_terms = (u32*)(d_tmp + N);
+    u64* d_qbase = (u64*)(d_out + ((N + 1) & ~(u64)1));
+    u32* d_terms = (u32*)(d_qbase + T);
     float* d_idf = (float*)(d_terms + T);
+    float* d_tab = d_idf + T;
+    u32* d_bounds = (u32*)(d_tab + SA_SAT_NTF * SA_SAT_WMAX);
     SA_HIP(hipMemcpyAsync(d_terms, terms, (size_t)T * sizeof(u32), hipMemcpyHostToDevice, st));
     SA_HIP(hipMemcpyAsync(d_idf, idf, (size_t)T * sizeof(float), hipMemcpyHostToDevice, st));
     Bm25Params p;
     memset(&p, 0, sizeof(p));
     sa_fill_params(ix, p);
     p.terms = d_terms; p.idf = d_idf; p.B = 1; p.T = (u32)T; p.k = 0;
-    p.k1 = k1; p.b = b; p.q_per_xcd = 0; p.small_k_argmax = 0;
+    p.k1 = k1; p.b = b; p.small_k_argmax = 0;
     p.dense_out = d_out; p.cand = nullptr;
-    (void)d_tmp;
+    p.bounds = d_bounds; p.qbase = d_qbase;
+    p.sattab = d_tab;
+    SA_TRY(sa_launch_make_sattab(ix, d_tab, &p.tab_w, k1, b, st));
+    SA_TRY(sa_launch_make_bounds(ix, d_terms, (u32)T, d_bounds, d_qbase, st));
     SA_TRY(sa_launch_bm25(ix, p, st));
     SA_HIP(hipMemcpyAsync(out, d_out, N * sizeof(float), hipMemcpyDeviceToHost, st));
     SA_HIP(hipStreamSynchronize(st));
@@ -597,6 +706,9 @@ static void sa_batch_free(sa_batch* bt) {
     if (bt->d_idf) hipFree(bt->d_idf);
     if (bt->d_cand) hipFree(bt->d_cand);
     if (bt->d_cand_cnt) hipFree(bt->d_cand_cnt);
+    if (bt->d_bounds) hipFree(bt->d_bounds);
+    if (bt->d_sattab) hipFree(bt->d_sattab);
+    if (bt->d_qbase) hipFree(bt->d_qbase);
     if (bt->d_slots) hipFree(bt->d_slots);
     if (bt->d_local) hipFree(bt->d_local);
     if (bt->d_gather) hipFree(bt->d_gather);
@@ -664,6 +776,12 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
     SA_HIP_B(hipMemset(bt->d_local, 0, (size_t)B * bt->k * sizeof(u64)));
     SA_HIP_B(hipMemcpy(bt->d_terms, h_terms.data(), h_terms.size() * sizeof(u32), hipMemcpyHostToDevice));
     SA_HIP_B(hipMemcpy(bt->d_idf, h_idf.data(), h_idf.size() * sizeof(float), hipMemcpyHostToDevice));
+    SA_HIP_B(hipMalloc(&bt->d_bounds, ((size_t)B * T * (ix->n_tiles + 1) + 1) * sizeof(u32)));
+    SA_HIP_B(hipMalloc(&bt->d_qbase, (size_t)B * T * sizeof(u64)));
+    SA_HIP_B(hipMalloc(&bt->d_sattab, SA_SAT_NTF * SA_SAT_WMAX * sizeof(float)));
+    if (sa_launch_make_sattab(ix, bt->d_sattab, &bt->tab_w, k1, b, ix->stream) != SA_OK) return fail(SA_ERR_HIP);
+    if (sa_launch_make_bounds(ix, bt->d_terms, B * T, bt->d_bounds, bt->d_qbase, ix->stream) != SA_OK) return fail(SA_ERR_HIP);
+    SA_HIP_B(hipStreamSynchronize(ix->stream));
     for (int i = 0; i < SA_EVENT_RING; i++) {
         hipEvent_t a = nullptr, c = nullptr;
         SA_HIP_B(hipEventCreate(&a));
@@ -697,8 +815,8 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out) {
     sa_fill_params(ix, p);
     p.terms = bt->d_terms; p.idf = bt->d_idf; p.B = bt->B; p.T = bt->T; p.k = bt->k;
     p.k1 = bt->k1; p.b = bt->b;
-    const int xcd_mode = sa_env_int("SA_XCD_MODE", 0);
-    p.q_per_xcd = (xcd_mode && bt->B >= 8) ? (bt->B + 7) / 8 : 0;
+    p.bounds = bt->d_bounds; p.qbase = bt->d_qbase;
+    p.sattab = bt->d_sattab; p.tab_w = bt->tab_w;
     p.small_k_argmax = (bt->k <= 32 && sa_env_int("SA_SMALLK_ARGMAX", 1)) ? 1 : 0;
     p.dense_out = nullptr; p.cand = bt->d_cand;
     p.no_topk = sa_env_int("SA_NO_TOPK", 0);

@@ -180,6 +180,11 @@ static int sa_index_build(sa_index* ix, const u64* words, const u64* term_off, c
     const u32 V = ix->n_terms;
     const u64 W = ix->n_words;
     SA_HIP(hipSetDevice(ix->device));
+    {
+        hipDeviceProp_t prop;
+        SA_HIP(hipGetDeviceProperties(&prop, ix->device));
+        ix->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+    }
     SA_HIP(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
     hipStream_t st = ix->stream;
 
@@ -299,7 +304,7 @@ extern "C" int sa_index_create(int device, uint64_t n_docs, uint64_t doc_base, u
     SA_ARG(term_off, "term_off is null");
     SA_ARG(n_docs == 0 || doc_lens, "doc_lens is null");
     SA_ARG(n_docs <= (1ull << 28), "a shard holds at most 2^28 docs (28-bit roaringish key)");
-    if (tile_docs == 0) tile_docs = 4096;
+    if (tile_docs == 0) tile_docs = 8192;
     SA_ARG(tile_docs == 1024 || tile_docs == 2048 || tile_docs == 4096 || tile_docs == 8192 ||
                tile_docs == 16384 || tile_docs == 32768,
            "tile_docs must be 1024, 2048, 4096, 8192, 16384 or 32768");
@@ -322,6 +327,7 @@ extern "C" int sa_index_create(int device, uint64_t n_docs, uint64_t doc_base, u
     for (u64 d = 0; d < n_docs; d++) {
         const float v = doc_lens[d];
         if (!(v >= 0.f) || v > 262143.f || v != floorf(v)) { ix->dl_packed = false; break; }
+        if ((u32)v > ix->max_doc_len) ix->max_doc_len = (u32)v;
     }
     int rc = sa_index_build(ix, words, term_off, doc_lens);
     if (rc != SA_OK) { sa_index_free(ix); return rc; }

@@ -25,12 +25,14 @@ struct sa_comm;   // RCCL communicator wrapper (sa_comm.hip)
 
 struct sa_index {
     int device = 0;
+    int n_cus = 1;                  // compute units of the device (persistent grid sizing)
     hipStream_t stream = nullptr;
     u64 n_docs = 0, doc_base = 0, corpus_size = 0;
     u32 n_terms = 0;
     float avg_doc_len = 0.f;
     u64 n_words = 0, n_postings = 0;
     bool dl_packed = true;          // doc lengths are integers < 2^18 and ride in the postings
+    u32 max_doc_len = 0;            // largest doc length (when dl_packed)
 
     u64* d_words = nullptr;
     u64* d_term_off = nullptr;

@@ -38,6 +38,8 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct uint3_emu { unsigned x, y, z; };
+struct alignas(16) float4 { float x, y, z, w; };
+inline float4 make_float4(float x, float y, float z, float w) { float4 v; v.x = x; v.y = y; v.z = z; v.w = w; return v; }
 
 typedef int hipError_t;
 typedef struct hipemu_stream* hipStream_t;
@@ -307,6 +309,7 @@ template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; 
 template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <class T> inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
+inline float unsafeAtomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 template <class T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <class T> inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 
@@ -347,4 +350,5 @@ inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess;
 }
+template <class K> inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 2; return hipSuccess; }
 inline hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = (size_t)4 << 30; *t = (size_t)8 << 30; return hipSuccess; }

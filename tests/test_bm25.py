@@ -165,3 +165,36 @@ def test_topk_pruning_over_many_tiles(api, tile_docs, k):
             assert np.array_equal(docs[qi, :n], wd[:n]), f"q{qi} docs"
             assert (docs[qi, n:] == NO_DOC).all()
     bt.close()
+
+
+def _long_doc_corpus():
+    """Docs up to 700 tokens with term frequencies up to ~60: exercises postings outside the
+    LDS saturation table (tf > 8, doc length >= 256)."""
+    rng = np.random.default_rng(21)
+    n_docs, vocab = 3000, 50
+    lens = rng.integers(1, 700, n_docs)
+    lens[::7] = rng.integers(1, 20, len(lens[::7]))
+    terms = np.concatenate([rng.choice(vocab, L, p=np.r_[0.3, np.full(vocab - 1, 0.7 / (vocab - 1))]) for L in lens])
+    t, d, p = synth.tokens_to_triples(lens.astype(np.int64), terms.astype(np.uint32))
+    return t, d, p, lens.astype(np.float32), n_docs, vocab
+
+
+def test_out_of_table_postings_and_unpacked_doc_lens(api):
+    t, d, p, lens, n_docs, vocab = _long_doc_corpus()
+    words, wt = rz.encode_sorted(t, d, p)
+    off = rz.term_offsets(wt, vocab)
+    for dl in (lens, lens + 0.5):                 # integer lengths ride in the postings; others are gathered
+        orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=dl)
+        dev = DeviceIndex(words, off, dl, tile_docs=1024, api=api)
+        assert dev.info().dl_packed == (1 if dl is lens else 0)
+        for q in ([0], [0, 1, 2, 3], [5, 0, 49]):
+            assert np.array_equal(dev.bm25_dense(q), orc.score_terms_sum(q)), q
+            assert np.array_equal(dev.bm25_dense(q, k1=0.9, b=0.4),
+                                  np.sum([orc.score(x, k1=0.9, b=0.4) for x in q], axis=0))
+        bt = dev.batch(np.asarray([[0, 1, 2, 3], [4, 0, 9, 30]]), k=10)
+        bt.run()
+        scores, docs = bt.fetch()
+        for qi, q in enumerate([[0, 1, 2, 3], [4, 0, 9, 30]]):
+            ws, wd = O.topk(orc.score_terms_sum(q), 10)
+            assert np.array_equal(scores[qi], ws) and np.array_equal(docs[qi], wd)
+        bt.close()
