@@ -109,6 +109,23 @@ int sa_index_termfreqs_sparse(sa_index_t* ix, uint32_t term, uint64_t* doc_ids_o
 int sa_index_bm25_dense(sa_index_t* ix, const uint32_t* terms, const float* idf,
                         int n_query_terms, float k1, float b, float* out);
 
+/* Exact-phrase match counts (slop == 0) as a dense float32[n_docs]: positions p with
+ * terms[0]@p, terms[1]@p+1, ... under the reference's bigram-chain semantics, including its
+ * same-term rule and plan selection (reference PosnBitArray.phrase_freqs middle_out.py:418-441,
+ * compute_phrase_freqs :154-168, phrase/bigram_freqs.py:213-307).  Unknown terms give zeros
+ * (postings.py:705-708); n_terms < 2 is an error (middle_out.py:425-426).
+ * slop > 0 is reported as SA_ERR_UNSUPPORTED in this version. */
+int sa_index_phrase_freqs_dense(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop, float* out);
+
+/* SearchArray.score(phrase): BM25 over the phrase counts, idf = float32 sum over the phrase's
+ * terms computed by the host (reference postings.py:652-680, similarity.py:19-38). */
+int sa_index_bm25_phrase_dense(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop,
+                               float idf, float k1, float b, float* out);
+
+/* HIP-event time (ms) of the device work of the last phrase call on this index (D2H copy
+ * excluded) and its algorithmic bytes: sum_t 8 * W_t, every word of every term once. */
+int sa_index_last_profile(sa_index_t* ix, double* kernel_ms_out, uint64_t* alg_bytes_out);
+
 /* Device-resident batch of B queries x T terms with top-k selection (k <= 1024).
  * terms/idf are [B][T] row-major.  Results per query: k (score, doc) pairs sorted by score
  * descending then doc id ascending; slots beyond the number of matching docs hold

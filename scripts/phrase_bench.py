@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Config 3 (BASELINE.json): 1M synthetic docs, 3-token exact phrases on one MI355X.
+Times the fused kernel and the general bigram chain per phrase (dense float32[N] result copied to
+the host, as SearchArray.termfreqs returns it) next to the CPU oracle, and checks counts bit-exact."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from searcharray_amd import synth, _lib                              # noqa: E402
+from searcharray_amd.device_index import DeviceIndex                 # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--docs", type=int, default=1_000_000)
+    ap.add_argument("--vocab", type=int, default=100_000)
+    ap.add_argument("--phrases", type=int, default=64)
+    ap.add_argument("--cpu-phrases", type=int, default=8)
+    args = ap.parse_args()
+    api = _lib.api()
+    D, V = args.docs, args.vocab
+    lens, terms = synth.zipf_batch_tokens(0, D, V, fast=True)
+    words, counts = synth.encode_batch(lens, terms, V)
+    out_words, term_off = synth.concat_term_major([(words, counts)], V)
+    doc_lens = lens.astype(np.float32)
+    index = DeviceIndex(out_words, term_off, doc_lens, api=api)
+    phrases = [np.asarray([0, 1, 2], dtype=np.uint32)] + list(synth.phrase_queries_from_tokens(lens, terms, args.phrases, 3))
+    from oracle import refimpl as O
+    orc = O.OracleIndex(out_words, np.arange(V), term_off, doc_lens, D)
+    res = {}
+    for mode in ("fused", "general"):
+        os.environ["SA_PHRASE_MODE"] = mode
+        index.phrase_freqs_dense(phrases[0])
+        t0 = time.perf_counter()
+        outs, kms, kbytes = [], 0.0, 0
+        for p in phrases:
+            outs.append(index.phrase_freqs_dense(p))
+            ms, ab = index.last_profile()
+            kms += ms
+            kbytes += ab
+        dt = time.perf_counter() - t0
+        index.phrase_freqs_dense(phrases[0])
+        ms0, ab0 = index.last_profile()
+        wbytes = sum(8 * int(term_off[t + 1] - term_off[t]) for p in phrases for t in p)
+        res[mode] = {"ms_per_phrase": round(dt / len(phrases) * 1e3, 3), "phrases_per_s": round(len(phrases) / dt, 1),
+                     "words_GBps_incl_D2H": round(wbytes / dt / 1e9, 2),
+                     "device_ms_per_phrase": round(kms / len(phrases), 4), "device_alg_GBps": round(kbytes / kms / 1e6, 1),
+                     "t0t1t2_device_ms": round(ms0, 4), "t0t1t2_alg_GBps": round(ab0 / ms0 / 1e6, 1)}
+        res[mode + "_outs"] = outs
+    t0 = time.perf_counter()
+    ok = True
+    ncpu = min(args.cpu_phrases, len(phrases))
+    for i in range(ncpu):
+        want = orc.phrase_freqs([int(t) for t in phrases[i]])
+        ok &= bool(np.array_equal(want, res["fused_outs"][i])) and bool(np.array_equal(want, res["general_outs"][i]))
+    cpu_dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    want0 = orc.phrase_freqs([0, 1, 2])
+    cpu0 = time.perf_counter() - t0
+    print(json.dumps({"config": f"zipf-{D} 3-token phrases x{len(phrases)}", "fused": res["fused"], "general": res["general"],
+                      "cpu_oracle_ms_per_phrase": round(cpu_dt / ncpu * 1e3, 2), "cpu_oracle_t0t1t2_ms": round(cpu0 * 1e3, 2),
+                      "t0t1t2_matches": int(want0.sum()), "counts_bit_exact": ok}))
+
+
+if __name__ == "__main__":
+    main()

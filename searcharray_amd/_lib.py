@@ -58,6 +58,9 @@ PROTOTYPES = {
     "sa_index_termfreqs_dense": (c_int, [c_void_p, c_uint32, f32p]),
     "sa_index_termfreqs_sparse": (c_int, [c_void_p, c_uint32, u64p, f32p, i64p]),
     "sa_index_bm25_dense": (c_int, [c_void_p, u32p, f32p, c_int, c_float, c_float, f32p]),
+    "sa_index_phrase_freqs_dense": (c_int, [c_void_p, u32p, c_int, c_int, f32p]),
+    "sa_index_bm25_phrase_dense": (c_int, [c_void_p, u32p, c_int, c_int, c_float, c_float, c_float, f32p]),
+    "sa_index_last_profile": (c_int, [c_void_p, POINTER(c_double), u64p]),
     "sa_index_info": (c_int, [c_void_p, POINTER(IndexInfo)]),
     "sa_batch_create": (c_int, [c_void_p, u32p, f32p, c_int, c_int, c_int, c_float, c_float,
                                 POINTER(c_void_p)]),
@@ -126,6 +129,14 @@ def api() -> HipApi:
             raise SearchArrayHipError(f"cannot load {LIB_PATH}: {e}") from e
         _api = bind(cdll, LIB_PATH)
     return _api
+
+
+def use_api(binding) -> None:
+    """Install an explicit binding as the process default (``None`` restores lazy loading of the
+    gfx950 library).  Exists for the test-suite, which binds the host-emulated kernel build to
+    check kernel logic on machines without a GPU; nothing in the package calls it."""
+    global _api
+    _api = binding
 
 
 # ---- numpy <-> ctypes helpers --------------------------------------------------------------

@@ -172,6 +172,8 @@ static void sa_index_free(sa_index* ix) {
     if (ix->d_tile_dir) hipFree(ix->d_tile_dir);
     if (ix->d_dir_slot) hipFree(ix->d_dir_slot);
     if (ix->d_scratch) hipFree(ix->d_scratch);
+    if (ix->ev0) hipEventDestroy(ix->ev0);
+    if (ix->ev1) hipEventDestroy(ix->ev1);
     if (ix->stream) hipStreamDestroy(ix->stream);
     delete ix;
 }

@@ -55,6 +55,8 @@ struct sa_index {
     // profile counters (sa_index_stats)
     double last_kernel_ms = 0.0;
     u64 last_alg_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool profile_pending = false;
 
     std::mutex mu;                  // one in-flight call per index handle (C ABI is re-entrant
                                     // across handles and serialised per handle)

@@ -410,6 +410,43 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
     return SA_OK;
 }
 
+// algorithmic bytes of a phrase: every word of every term read once
+static u64 sa_phrase_alg_bytes(const sa_index* ix, const u32* terms, int T) {
+    u64 b = 0;
+    for (int t = 0; t < T; t++)
+        if (terms[t] < ix->n_terms) b += 8 * (ix->h_term_off[terms[t] + 1] - ix->h_term_off[terms[t]]);
+    return b;
+}
+
+static int sa_profile_begin(sa_index* ix) {
+    if (!ix->ev0) { SA_HIP(hipEventCreate(&ix->ev0)); SA_HIP(hipEventCreate(&ix->ev1)); }
+    SA_HIP(hipEventRecord(ix->ev0, ix->stream));
+    return SA_OK;
+}
+
+static int sa_profile_end(sa_index* ix, u64 alg_bytes) {
+    SA_HIP(hipEventRecord(ix->ev1, ix->stream));
+    ix->last_alg_bytes = alg_bytes;
+    ix->profile_pending = true;
+    return SA_OK;
+}
+
+extern "C" int sa_index_last_profile(sa_index_t* ix, double* kernel_ms_out, uint64_t* alg_bytes_out) {
+    SA_ARG(ix, "null index");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (ix->profile_pending) {
+        SA_HIP(hipSetDevice(ix->device));
+        SA_HIP(hipEventSynchronize(ix->ev1));
+        float ms = 0.f;
+        SA_HIP(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
+        ix->last_kernel_ms = ms;
+        ix->profile_pending = false;
+    }
+    if (kernel_ms_out) *kernel_ms_out = ix->last_kernel_ms;
+    if (alg_bytes_out) *alg_bytes_out = ix->last_alg_bytes;
+    return SA_OK;
+}
+
 static int sa_phrase_mode() {
     const char* v = getenv("SA_PHRASE_MODE");
     if (!v) return 0;
@@ -427,7 +464,9 @@ extern "C" int sa_index_phrase_freqs_dense(sa_index_t* ix, const uint32_t* terms
     std::lock_guard<std::mutex> g(ix->mu);
     SA_HIP(hipSetDevice(ix->device));
     float* d_running = nullptr;
+    SA_TRY(sa_profile_begin(ix));
     SA_TRY(sa_phrase_counts_device(ix, terms, n_terms, sa_phrase_mode(), &d_running));
+    SA_TRY(sa_profile_end(ix, sa_phrase_alg_bytes(ix, terms, n_terms)));
     SA_HIP(hipMemcpyAsync(out, d_running, ix->n_docs * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
     SA_HIP(hipStreamSynchronize(ix->stream));
     SA_HIP(hipGetLastError());

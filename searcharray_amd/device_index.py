@@ -121,6 +121,36 @@ class DeviceIndex:
                       np.float32(k1), np.float32(b), p_f32(out))
         return out
 
+    def phrase_freqs_dense(self, terms: Sequence[int], slop: int = 0) -> np.ndarray:
+        """Exact phrase match counts, float32[n_docs] (reference PosnBitArray.phrase_freqs)."""
+        if len(terms) < 2:
+            raise ValueError("Must have at least two terms")        # reference middle_out.py:425-426
+        tarr = np.asarray([int(t) if 0 <= int(t) < self.n_terms else NO_TERM for t in terms], dtype=np.uint32)
+        out = np.empty(self.n_docs, dtype=np.float32)
+        self.api.call("sa_index_phrase_freqs_dense", self._h, p_u32(tarr), len(tarr), int(slop), p_f32(out))
+        return out
+
+    def bm25_phrase_dense(self, terms: Sequence[int], k1: float = 1.2, b: float = 0.75, slop: int = 0,
+                          idf: Optional[float] = None) -> np.ndarray:
+        """BM25 of a phrase: idf summed over the phrase's terms (reference postings.py:671-679)."""
+        if len(terms) < 2:
+            raise ValueError("Must have at least two terms")
+        tarr = np.asarray([int(t) if 0 <= int(t) < self.n_terms else NO_TERM for t in terms], dtype=np.uint32)
+        if idf is None:
+            dfs = np.asarray([self.docfreq(int(t)) if 0 <= int(t) < self.n_terms else 0 for t in terms])
+            idf = compute_idf(self.corpus_size, dfs)
+        out = np.empty(self.n_docs, dtype=np.float32)
+        self.api.call("sa_index_bm25_phrase_dense", self._h, p_u32(tarr), len(tarr), int(slop),
+                      np.float32(idf), np.float32(k1), np.float32(b), p_f32(out))
+        return out
+
+    def last_profile(self) -> Tuple[float, int]:
+        """(kernel ms, algorithmic bytes) of the last phrase call."""
+        ms = _lib.c_double(0)
+        ab = _lib.c_uint64(0)
+        self.api.call("sa_index_last_profile", self._h, ctypes.byref(ms), ctypes.byref(ab))
+        return ms.value, ab.value
+
     def batch(self, queries: np.ndarray, k: int = 10, k1: float = 1.2, b: float = 0.75,
               idf: Optional[np.ndarray] = None) -> "QueryBatch":
         return QueryBatch(self, queries, k=k, k1=k1, b=b, idf=idf)

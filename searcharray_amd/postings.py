@@ -1,0 +1,530 @@
+"""Tokenized, searchable text as a pandas dtype -- the reference's public surface
+(searcharray/postings.py) over the MI355X scoring path.
+
+``SearchArray.index(strings)`` builds the positional index on the host, uploads it to HBM on
+first use and answers ``termfreqs`` / ``docfreq`` / ``score`` / phrase queries with the HIP
+kernels behind the C ABI (include/searcharray_hip.h).  The ExtensionArray protocol (slicing,
+take, copy, setitem, concat, factorize, equality) is host bookkeeping over an immutable shared
+index core plus a row selection.
+
+Differences from the reference, by design:
+  * a sliced / filtered array scores with corpus-wide document frequencies (the reference's
+    filtered views use slice-local df with global corpus size -- SURVEY appendix A.6);
+  * ``min_posn`` / ``max_posn`` and ``slop > 0`` raise NotImplementedError instead of silently
+    taking a CPU path (there is no CPU fallback in this package).
+"""
+from __future__ import annotations
+
+import json
+import numbers
+import warnings
+from collections import Counter
+from typing import Iterable, List, Optional, Union
+
+import numpy as np
+import pandas as pd
+from pandas.api.extensions import ExtensionArray, ExtensionDtype, register_extension_dtype, take
+from pandas.api.types import is_list_like
+
+from . import _lib
+from . import roaringish as rz
+from .device_index import DeviceIndex, compute_idf
+from .indexing import HostIndex, build_index_from_terms_list, build_index_from_tokenizer
+from .similarity import default_bm25
+from .term_dict import TermMissingError
+
+
+class Terms:
+    """One indexed doc: term -> tf, optional term -> positions, and the doc length
+    (reference postings.py:57-165)."""
+
+    def __init__(self, postings, doc_len: int = 0, posns: Optional[dict] = None, encoded=False):
+        self.postings = postings
+        self.encoded = encoded
+        self.doc_len = doc_len
+        self.posns = posns
+
+    def termfreq(self, token):
+        return self.postings[token]
+
+    def terms(self):
+        return self.postings.items()
+
+    def positions(self, term=None):
+        if self.posns is None:
+            return {}
+        if term is None:
+            return self.posns.items()
+        return self.posns[term]
+
+    def __len__(self):
+        return len(self.postings)
+
+    def __repr__(self):
+        return f"Terms({set(self.postings.keys())})"
+
+    __str__ = __repr__
+
+    def __eq__(self, other):
+        if isinstance(other, SearchArray):
+            return other == self
+        return isinstance(other, Terms) and self.postings == other.postings and self.doc_len == other.doc_len
+
+    def __ne__(self, other):
+        res = self.__eq__(other)
+        return ~res if isinstance(res, np.ndarray) else not res
+
+    def __lt__(self, other):
+        # lexical comparison of the two sparse tf vectors
+        for key in sorted(set(self.postings) | set(other.postings)):
+            a, b = self.postings.get(key, 0), other.postings.get(key, 0)
+            if a != b:
+                return a < b
+        return False
+
+    def __le__(self, other):
+        return self < other or self == other
+
+    def __gt__(self, other):
+        return not (self < other) and self != other
+
+    def __hash__(self):
+        return hash(json.dumps(self.postings, sort_keys=True))
+
+
+class TermsDtype(ExtensionDtype):
+    """pandas dtype ``tokenized_text`` (reference postings.py:168-203)."""
+    name = 'tokenized_text'
+    type = Terms
+    kind = 'O'
+
+    @classmethod
+    def construct_from_string(cls, string):
+        if not isinstance(string, str):
+            raise TypeError(f"'construct_from_string' expects a string, got {type(string)}")
+        if string == cls.name:
+            return cls()
+        raise TypeError(f"Cannot construct a '{cls.__name__}' from '{string}'")
+
+    @classmethod
+    def construct_array_type(cls):
+        return SearchArray
+
+    def __repr__(self):
+        return 'TermsDtype()'
+
+    @property
+    def na_value(self):
+        return Terms({})
+
+    def valid_value(self, value):
+        return isinstance(value, dict) or pd.isna(value) or isinstance(value, Terms)
+
+
+register_extension_dtype(TermsDtype)
+
+
+def ws_tokenizer(string):
+    if pd.isna(string):
+        return []
+    if not isinstance(string, str):
+        raise ValueError("Expected a string")
+    return string.split()
+
+
+class _IndexCore:
+    """The index behind a SearchArray and all of its views: host arrays + the lazily created
+    HBM-resident DeviceIndex.  Views (slices) share one core object, so an assignment through a
+    view is visible to its base -- pandas' view semantics.  ``copy()`` gets its own core object
+    that references the same immutable host arrays (and device handle) until one side is
+    assigned to (copy-on-write at core granularity)."""
+
+    def __init__(self, host: HostIndex, device: Optional[DeviceIndex] = None):
+        self._device: Optional[DeviceIndex] = device
+        self.replace(host, device)
+
+    def replace(self, host: HostIndex, device: Optional[DeviceIndex] = None):
+        self.host = host
+        self.term_dict = host.term_dict
+        self.doc_lens = host.doc_lens
+        # reference indexing.py:282-284 / postings.py:296: np.mean over the float32 lengths
+        self.avg_doc_length = np.mean(host.doc_lens) if len(host.doc_lens) else 0.0
+        self.corpus_size = len(host.doc_lens)
+        self._device = device
+
+    def fork(self) -> "_IndexCore":
+        return _IndexCore(self.host, self._device)
+
+    def device(self) -> DeviceIndex:
+        if self._device is None:
+            h = self.host
+            self._device = DeviceIndex(h.words, h.term_off, h.doc_lens, avg_doc_len=self.avg_doc_length,
+                                       corpus_size=self.corpus_size, api=_lib.api())
+        return self._device
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_device"] = None                    # HBM handles do not pickle; re-uploaded on demand
+        return state
+
+    # -- host-side doc reconstruction (scalar __getitem__, equality, positions)
+    def term_words_of_doc(self, term_id: int, doc_id: int) -> np.ndarray:
+        h = self.host
+        w = h.words[int(h.term_off[term_id]):int(h.term_off[term_id + 1])]
+        lo = np.searchsorted(w, np.uint64(doc_id) << np.uint64(rz.KEY_SHIFT), side="left")
+        hi = np.searchsorted(w, np.uint64(doc_id + 1) << np.uint64(rz.KEY_SHIFT), side="left")
+        return w[lo:hi]
+
+    def doc_as_terms(self, doc_id: int) -> Terms:
+        h = self.host
+        a, b = int(h.doc_term_ptr[doc_id]), int(h.doc_term_ptr[doc_id + 1])
+        postings, posns = {}, {}
+        for k in range(a, b):
+            tid = int(h.doc_term_ids[k])
+            term = self.term_dict.get_term(tid)
+            _, p = rz.decode_positions(self.term_words_of_doc(tid, doc_id))
+            if len(p):
+                postings[term] = len(p)
+                posns[term] = p.astype(np.uint32)
+            elif h.doc_term_tfs is not None:
+                postings[term] = h.doc_term_tfs[k]
+            else:
+                postings[term] = 0
+        return Terms(postings, doc_len=h.doc_lens[doc_id], posns=posns if posns else None)
+
+
+class _PosnsAdapter:
+    """``arr.posns`` of the reference (PosnBitArray) as seen by callers: df / warm / cache hooks."""
+
+    def __init__(self, array: "SearchArray"):
+        self._array = array
+
+    def docfreq(self, term_id: int):
+        return self._array._core.device().docfreq(int(term_id))
+
+    def warm(self):
+        self._array._core.device()            # upload + derive every term's tf / df on the device
+
+    def clear_cache(self):
+        pass                                   # derived postings are device-resident, nothing to clear
+
+    @property
+    def nbytes(self):
+        return self._array._core.host.words.nbytes
+
+
+class SearchArray(ExtensionArray):
+    """An array of tokenized text (reference postings.py:228-708)."""
+
+    dtype = TermsDtype()
+
+    def __init__(self, postings, tokenizer=ws_tokenizer, avoid_copies=True):
+        if not is_list_like(postings):
+            raise TypeError(f"Expected list-like object, got {type(postings)}")
+        self.avoid_copies = avoid_copies
+        self.tokenizer = tokenizer
+        self._core = _IndexCore(build_index_from_terms_list(postings, Terms))
+        self._rows: Optional[np.ndarray] = None
+
+    @classmethod
+    def index(cls, array: Iterable, tokenizer=ws_tokenizer, truncate=False, batch_size=100000,
+              avoid_copies=True, workers=4, cache_gt_than=25, data_dir: Optional[str] = None,
+              autowarm=True) -> 'SearchArray':
+        """Index strings with ``tokenizer`` (reference postings.py:249-300).  ``workers``,
+        ``cache_gt_than`` and ``data_dir`` are accepted for signature compatibility: index build
+        is a single host pass and the derived tf/df live on the device."""
+        if not is_list_like(array):
+            raise TypeError(f"Expected list-like object, got {type(array)}")
+        host = build_index_from_tokenizer(array, tokenizer, truncate=truncate, batch_size=batch_size)
+        arr = cls.__new__(cls)
+        arr.avoid_copies = avoid_copies
+        arr.tokenizer = tokenizer
+        arr._core = _IndexCore(host)
+        arr._rows = None
+        return arr
+
+    @classmethod
+    def _view(cls, core, rows, tokenizer, avoid_copies=True):
+        arr = cls.__new__(cls)
+        arr.avoid_copies = avoid_copies
+        arr.tokenizer = tokenizer
+        arr._core = core
+        arr._rows = rows
+        return arr
+
+    def warm(self):
+        self.posns.warm()
+
+    # ---- attributes the reference exposes ------------------------------------------------
+    @property
+    def term_dict(self):
+        return self._core.term_dict
+
+    @property
+    def avg_doc_length(self):
+        return self._core.avg_doc_length
+
+    @property
+    def corpus_size(self):
+        return self._core.corpus_size
+
+    @property
+    def doc_lens(self) -> np.ndarray:
+        return self._core.doc_lens if self._rows is None else self._core.doc_lens[self._rows]
+
+    @property
+    def posns(self):
+        return _PosnsAdapter(self)
+
+    def _row_ids(self) -> np.ndarray:
+        return np.arange(self._core.corpus_size, dtype=np.int64) if self._rows is None else self._rows
+
+    def _gather(self, dense: np.ndarray) -> np.ndarray:
+        return dense if self._rows is None else dense[self._rows]
+
+    # ---- ExtensionArray protocol -----------------------------------------------------------
+    @classmethod
+    def _from_sequence(cls, scalars, dtype=None, copy=False):
+        if dtype is not None and not isinstance(dtype, TermsDtype):
+            return scalars
+        if isinstance(scalars, SearchArray):
+            return scalars.copy() if copy else scalars
+        if isinstance(scalars, np.ndarray) and scalars.dtype != object and scalars.dtype.kind not in 'US':
+            return scalars
+        return cls(scalars)
+
+    @classmethod
+    def _from_factorized(cls, values, original):
+        return cls(values)
+
+    def _values_for_factorize(self):
+        return np.asarray(self._as_terms_list(), dtype=object), Terms({})
+
+    @classmethod
+    def _concat_same_type(cls, to_concat):
+        items: List[Terms] = []
+        for arr in to_concat:
+            items.extend(arr._as_terms_list())
+        return SearchArray(items, tokenizer=to_concat[0].tokenizer)
+
+    def __len__(self):
+        return self._core.corpus_size if self._rows is None else len(self._rows)
+
+    @property
+    def nbytes(self):
+        h = self._core.host
+        return h.words.nbytes + h.term_off.nbytes + h.doc_lens.nbytes + h.doc_term_ids.nbytes + self.term_dict.nbytes
+
+    def memory_usage(self, deep=False):
+        return self.nbytes
+
+    def _as_terms_list(self) -> List[Terms]:
+        return [self._core.doc_as_terms(int(d)) for d in self._row_ids()]
+
+    def __getitem__(self, key):
+        key = pd.api.indexers.check_array_indexer(self, key)
+        if isinstance(key, numbers.Integral):
+            n = len(self)
+            if key < -n or key >= n:
+                raise IndexError("index out of bounds")
+            return self._core.doc_as_terms(int(self._row_ids()[key]))
+        rows = self._row_ids()[key]
+        return SearchArray._view(self._core, np.asarray(rows, dtype=np.int64), self.tokenizer, self.avoid_copies)
+
+    def __setitem__(self, key, value):
+        key = pd.api.indexers.check_array_indexer(self, key)
+        if isinstance(value, (pd.Series,)):
+            value = value.values
+        if isinstance(value, pd.DataFrame):
+            value = value.values.flatten()
+        if isinstance(value, SearchArray):
+            value = np.asarray(value._as_terms_list(), dtype=object)
+        if isinstance(value, list):
+            value = np.asarray(value, dtype=object)
+        if not isinstance(value, np.ndarray) and not self.dtype.valid_value(value):
+            raise ValueError(f"Cannot set non-object array to SearchArray -- you passed type:{type(value)} -- {value}")
+        if isinstance(key, numbers.Integral) and isinstance(value, np.ndarray):
+            raise ValueError("Cannot set a single value to an array")
+
+        def as_terms(v):
+            if isinstance(v, Terms):
+                return v
+            if isinstance(v, dict):
+                return Terms(v, doc_len=len(v))
+            if v is None or (isinstance(v, float) and np.isnan(v)):
+                return Terms({})
+            raise ValueError(f"Cannot store {type(v)} in a SearchArray")
+
+        # Assignment rewrites the shared core in place (slow path, like the reference's "this is
+        # slow" warning): the docs this array's rows select are replaced and the index is rebuilt.
+        core = self._core
+        targets = np.atleast_1d(self._row_ids()[key])
+        if isinstance(value, np.ndarray):
+            new_vals = [as_terms(v) for v in value]
+            if len(new_vals) != len(targets):
+                if len(new_vals) == 1:
+                    new_vals = new_vals * len(targets)
+                else:
+                    raise ValueError("cannot set using a list-like indexer with a different length than the value")
+        else:
+            new_vals = [as_terms(value)] * len(targets)
+        items = [core.doc_as_terms(d) for d in range(core.corpus_size)]
+        for d, v in zip(targets, new_vals):
+            items[int(d)] = v
+        core.replace(build_index_from_terms_list(items, Terms))
+
+    def __array__(self, dtype=None, copy=None):
+        # object array of Terms; always a fresh materialisation (nothing to share with numpy), so
+        # copy=False gets pandas' own NumPy-2 transition warning instead of a silent copy
+        if copy is False:
+            warnings.warn("Starting with NumPy 2.0, the behavior of the 'copy' keyword has changed and passing "
+                          "'copy=False' raises an error when returning a zero-copy NumPy array is not possible. "
+                          "SearchArray always materialises a new object array.", FutureWarning, stacklevel=2)
+        out = np.empty(len(self), dtype=object)
+        for i, t in enumerate(self._as_terms_list()):
+            out[i] = t
+        return out
+
+    def isna(self):
+        return self.doc_lens == 0
+
+    def take(self, indices, allow_fill=False, fill_value=None):
+        rows = self._row_ids()
+        picked = take(np.arange(len(rows)), indices, allow_fill=allow_fill, fill_value=-1)
+        picked = np.asarray(picked, dtype=np.int64)
+        if allow_fill and (picked == -1).any():
+            if fill_value is None or pd.isna(fill_value):
+                fill_value = Terms({}, encoded=True)
+            items = [self._core.doc_as_terms(int(rows[i])) if i >= 0 else fill_value for i in picked]
+            return SearchArray(items, tokenizer=self.tokenizer)
+        return SearchArray._view(self._core.fork(), rows[picked], self.tokenizer, self.avoid_copies)   # take copies
+
+    def copy(self):
+        rows = None if self._rows is None else self._rows.copy()
+        return SearchArray._view(self._core.fork(), rows, self.tokenizer, self.avoid_copies)
+
+    def unique(self):
+        return self[:]
+
+    def value_counts(self, dropna: bool = True):
+        counts = Counter(self._as_terms_list())
+        if dropna:
+            counts.pop(Terms({}), None)
+        return pd.Series(counts)
+
+    def __iter__(self):
+        if len(self) > 10000:
+            warnings.warn("Iterating over SearchArray is very slow and not recommended.")
+        return super().__iter__()
+
+    def __ne__(self, other):
+        if isinstance(other, (pd.DataFrame, pd.Series, pd.Index)):
+            return NotImplemented
+        return ~(self == other)
+
+    def __eq__(self, other):
+        if isinstance(other, (pd.DataFrame, pd.Series, pd.Index)):
+            return NotImplemented
+        if isinstance(other, SearchArray):
+            if len(self) != len(other):
+                return False
+            if len(other) == 0:
+                return np.array([], dtype=bool)
+            if other._core.host is self._core.host:
+                return self._row_ids() == other._row_ids()
+            a, b = self._as_terms_list(), other._as_terms_list()
+            return np.asarray([bool(x == y) for x, y in zip(a, b)], dtype=bool)
+        if isinstance(other, Terms):
+            return np.asarray([bool(x == other) for x in self._as_terms_list()], dtype=bool)
+        if is_list_like(other):
+            if len(self) != len(other):
+                return False
+            if len(other) == 0:
+                return np.array([], dtype=bool)
+            return self == SearchArray(other, tokenizer=self.tokenizer)
+        return np.full(len(self), False)
+
+    # ---- search API ---------------------------------------------------------------------------
+    def _check_token_arg(self, token):
+        if isinstance(token, str):
+            return token
+        if isinstance(token, list) and len(token) == 1:
+            return token[0]
+        if isinstance(token, list):
+            return token
+        raise TypeError("Expected a string or list of strings for phrases")
+
+    @staticmethod
+    def _check_posn_args(slop, min_posn, max_posn):
+        if min_posn is not None or max_posn is not None:
+            raise NotImplementedError("min_posn / max_posn are not implemented on the device path")
+        if slop != 0:
+            raise NotImplementedError("slop > 0 is not implemented on the device path yet")
+
+    def _term_id(self, token: str) -> int:
+        try:
+            return self.term_dict.get_term_id(token)
+        except TermMissingError:
+            return -1
+
+    def termfreqs(self, token: Union[List[str], str], slop: int = 0, min_posn: Optional[int] = None,
+                  max_posn: Optional[int] = None) -> np.ndarray:
+        """reference postings.py:607-638 (single term) / :689-708 (phrase)."""
+        token = self._check_token_arg(token)
+        self._check_posn_args(slop, min_posn, max_posn)
+        if len(self._core.doc_lens) == 0:
+            return np.zeros(len(self), dtype=np.float32)
+        dev = self._core.device()
+        if isinstance(token, list):
+            ids = [self._term_id(t) for t in token]
+            return self._gather(dev.phrase_freqs_dense(ids, slop=slop))
+        tid = self._term_id(token)
+        if tid < 0:
+            return np.zeros(len(self), dtype=np.float32)            # unknown term: zeros, never raises
+        return self._gather(dev.termfreqs_dense(tid))
+
+    def docfreq(self, token: str) -> int:
+        """reference postings.py:640-647."""
+        if not isinstance(token, str):
+            raise TypeError("Expected a string")
+        tid = self._term_id(token)
+        if tid < 0 or len(self._core.doc_lens) == 0:
+            return 0
+        return self._core.device().docfreq(tid)
+
+    def doclengths(self) -> np.ndarray:
+        return self.doc_lens
+
+    def score(self, token: Union[str, List[str]], similarity=default_bm25, slop: int = 0,
+              min_posn: Optional[int] = None, max_posn: Optional[int] = None) -> np.ndarray:
+        """BM25 (or any Similarity) of one term or one phrase for every doc (reference
+        postings.py:652-680).  Tagged BM25 closures run entirely on the GPU."""
+        token = self._check_token_arg(token)
+        self._check_posn_args(slop, min_posn, max_posn)
+        tokens = [token] if isinstance(token, str) else token
+        dfs = np.asarray([self.docfreq(t) for t in tokens])
+        if len(self._core.doc_lens) == 0:
+            return np.zeros(len(self), dtype=np.float32)
+        if getattr(similarity, "kind", None) == "bm25":
+            dev = self._core.device()
+            idf = np.float32(compute_idf(self.corpus_size, dfs))
+            ids = [self._term_id(t) for t in tokens]
+            if len(ids) == 1:
+                dense = dev.bm25_dense(ids, k1=similarity.k1, b=similarity.b, idf=np.asarray([idf], np.float32))
+            else:
+                dense = dev.bm25_phrase_dense(ids, k1=similarity.k1, b=similarity.b, slop=slop, idf=idf)
+            return self._gather(dense)
+        tfs = self.termfreqs(token, slop=slop)
+        return similarity(tfs, dfs, self.doc_lens, self.avg_doc_length, self.corpus_size)
+
+    def positions(self, token: str, key=None) -> List[np.ndarray]:
+        """positions of ``token`` per doc (reference postings.py:682-687)."""
+        tid = self.term_dict.get_term_id(token)
+        rows = self._row_ids()
+        if key is not None:
+            rows = np.atleast_1d(rows[key])
+        out = []
+        for d in rows:
+            _, p = rz.decode_positions(self._core.term_words_of_doc(tid, int(d)))
+            out.append(p.astype(np.uint32))
+        return out

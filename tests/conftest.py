@@ -33,3 +33,14 @@ def api(request):
         return emu_api()
     from searcharray_amd import _lib
     return _lib.api()
+
+
+@pytest.fixture(scope="module")
+def default_api(api):
+    """Make `api` the package default for code that does not take an explicit binding
+    (SearchArray); restored afterwards."""
+    from searcharray_amd import _lib
+    old = _lib._api
+    _lib.use_api(api)
+    yield api
+    _lib.use_api(old)

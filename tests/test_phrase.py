@@ -1,0 +1,102 @@
+"""Exact-phrase match counts: device paths (general bigram chain and fused kernel) against the
+CPU oracle and the reference goldens -- bit-exact counts.  Runs on the host emulator ("emu",
+CPU suite) and on the real gfx950 library ("gpu")."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import refimpl as O
+from searcharray_amd import synth
+from searcharray_amd import roaringish as rz
+from searcharray_amd.device_index import DeviceIndex
+from tests.helpers import golden_corpus, dense_from_sparse
+from tests.test_oracle_golden import PHRASE_SCENARIOS, _index_strings
+
+
+def _device_from_strings(docs, api):
+    vocab = {}
+    t, d, p = [], [], []
+    for di, doc in enumerate(docs):
+        for pi, tok in enumerate(doc.split()):
+            t.append(vocab.setdefault(tok, len(vocab))); d.append(di); p.append(pi)
+    t, d, p = np.asarray(t, np.int64), np.asarray(d, np.int64), np.asarray(p, np.int64)
+    order = np.argsort(t, kind="stable")
+    lens = np.asarray([len(doc.split()) for doc in docs], np.float32)
+    words, wt = rz.encode_sorted(t[order], d[order], p[order])
+    dev = DeviceIndex(words, rz.term_offsets(wt, len(vocab)), lens, tile_docs=1024, api=api)
+    return vocab, dev
+
+
+@pytest.fixture(params=["general", "auto"])
+def phrase_mode(request):
+    old = os.environ.get("SA_PHRASE_MODE")
+    if request.param == "general":
+        os.environ["SA_PHRASE_MODE"] = "general"
+    else:
+        os.environ.pop("SA_PHRASE_MODE", None)
+    yield request.param
+    if old is None:
+        os.environ.pop("SA_PHRASE_MODE", None)
+    else:
+        os.environ["SA_PHRASE_MODE"] = old
+
+
+@pytest.mark.parametrize("docs,phrase,expected", PHRASE_SCENARIOS[:23:2])
+def test_reference_phrase_scenarios(api, phrase_mode, docs, phrase, expected):
+    """known answers from the reference's test/test_phrase_matches.py:17-194"""
+    vocab, dev = _device_from_strings(docs, api)
+    got = dev.phrase_freqs_dense([vocab[t] for t in phrase.split()])
+    assert np.array_equal(got, np.asarray(expected, np.float32))
+
+
+@pytest.mark.parametrize("phrase", ["foo bar baz", "foo foo foo", "foo bar bar baz buz foo bar", "foo foo"])
+@pytest.mark.parametrize("offset", [0, 16, 17, 18, 35, 53])
+def test_offsets_cross_word_boundary(api, phrase_mode, phrase, offset):
+    vocab, dev = _device_from_strings([" ".join(["dummy"] * offset) + " " + phrase, "not match"], api)
+    got = dev.phrase_freqs_dense([vocab[t] for t in phrase.split()])
+    assert np.array_equal(got, [1, 0])
+
+
+@pytest.mark.parametrize("name", ["zipf_small", "zipf_sparse"])
+def test_corpus_phrases_match_reference(api, phrase_mode, name):
+    """reference outputs (counts and BM25 scores) on the seeded corpora, incl. same-term phrases,
+    2..7-term phrases and the T>=5 middle-out plan"""
+    g, (t, d, p), lens, num_docs, vocab = golden_corpus(name)
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    for i in range(int(g["n_phrases"])):
+        terms = [int(x) for x in g[f"phr_{i}_terms"]]
+        want = dense_from_sparse(g[f"phr_{i}_idx"], g[f"phr_{i}_val"], num_docs)
+        got = dev.phrase_freqs_dense(terms)
+        assert np.array_equal(got, want), f"phrase {terms}: {np.flatnonzero(got != want)[:5]}"
+    for i in range(0, int(g["n_phrases"]), 5):
+        terms = [int(x) for x in g[f"phr_{i}_terms"]]
+        wants = dense_from_sparse(g[f"phr_{i}_sidx"], g[f"phr_{i}_sval"], num_docs)
+        assert np.array_equal(dev.bm25_phrase_dense(terms), wants), f"phrase score {terms}"
+
+
+def test_fused_equals_general_on_random_distinct_phrases(api):
+    n_docs, vocab = 3000, 60
+    t, d, p, lens = synth.corpus_triples(n_docs, vocab, 45, seed=3)
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
+    rng = np.random.default_rng(5)
+    for length in (2, 3, 4, 5, 6, 8):
+        for _ in range(4):
+            terms = [int(x) for x in rng.choice(12, length, replace=False)]
+            want = orc.phrase_freqs(terms)
+            for mode in ("general", "fused"):
+                os.environ["SA_PHRASE_MODE"] = mode
+                got = dev.phrase_freqs_dense(terms)
+                assert np.array_equal(got, want), f"{mode} {terms}"
+    os.environ.pop("SA_PHRASE_MODE", None)
+
+
+def test_phrase_errors_and_unknown_terms(api):
+    vocab, dev = _device_from_strings(["foo bar", "bar foo"], api)
+    with pytest.raises(ValueError):
+        dev.phrase_freqs_dense([0])
+    assert dev.phrase_freqs_dense([0, 99]).sum() == 0
+    assert dev.bm25_phrase_dense([0, 99]).sum() == 0

@@ -1,0 +1,180 @@
+"""The drop-in surface: SearchArray.index / termfreqs / docfreq / score / phrases / pandas
+behaviour, written after the reference's own tests (test/test_search.py, test/test_phrase_matches.py,
+test/test_similarity.py) with their known answers.  Runs on "emu" (CPU suite) and "gpu"."""
+import pickle
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from searcharray_amd import SearchArray, Terms, bm25_similarity, bm25_impact, classic_similarity
+from searcharray_amd.similarity import compute_idf
+from tests.test_oracle_golden import PHRASE_SCENARIOS, LUCENE
+
+DOCS = ["foo bar bar baz", "data2", "data3 bar", "bunny funny wunny"] * 25
+
+
+@pytest.fixture(scope="module")
+def data(default_api):
+    return SearchArray.index(DOCS)
+
+
+def test_term_freqs_and_doc_freq(data):
+    """reference test_search.py:75-95"""
+    assert ((data.termfreqs("foo") > 0) == [True, False, False, False] * 25).all()
+    assert (data.termfreqs("not_present") == 0).all()
+    assert (data.termfreqs("bar") == [2, 0, 1, 0] * 25).all()
+    assert data.docfreq("bar") == 50 and data.docfreq("foo") == 25 and data.docfreq("nope") == 0
+    with pytest.raises(TypeError):
+        data.docfreq(["bar"])
+    with pytest.raises(TypeError):
+        data.termfreqs(5)
+
+
+def test_doc_lengths(data):
+    """reference test_search.py:98-102"""
+    assert data.doclengths().shape == (100,)
+    assert (data.doclengths() == [4, 1, 2, 3] * 25).all()
+    assert data.avg_doc_length == 2.5
+    assert len(data) == 100 and data.corpus_size == 100
+
+
+def test_default_score_matches_lucene(data):
+    """reference test_search.py:121-124"""
+    bm25 = data.score("bar")
+    assert bm25.shape == (100,) and bm25.dtype == np.float32
+    assert np.isclose(bm25, [0.37066694, 0., 0.34314217, 0.] * 25).all()
+    assert np.array_equal(data.score(["bar"]), bm25)                  # one-element list == the term
+
+
+def test_custom_similarities(data):
+    """reference test_search.py:105-118, test_similarity.py:64-86"""
+    bm25 = data.score("bar")
+    custom = bm25_similarity(k1=10, b=0.01)
+    c1, c2 = data.score("bar", similarity=custom), data.score("bar", similarity=custom)
+    assert np.array_equal(c1, c2)
+    assert not np.isclose(bm25[bm25 > 0], c1[c1 > 0]).any()
+    impact = data.score("bar", similarity=bm25_impact())
+    idf = compute_idf(100, np.asarray([50]))
+    assert np.isclose(impact * idf, bm25).all()
+    classic = data.score("bar", similarity=classic_similarity())
+    assert classic.shape == (100,) and (classic[1::4] == 0).all() and (classic[0::4] > 0).all()
+
+
+@pytest.mark.parametrize("tf,df,dl,avgdl,n,expected", LUCENE)
+def test_bm25_closure_matches_lucene(default_api, tf, df, dl, avgdl, n, expected):
+    """reference test_similarity.py:16-61: the Similarity protocol called directly"""
+    got = bm25_similarity(k1=1.2, b=0.75)(np.asarray([tf], np.float32), np.asarray([df], np.float32),
+                                          np.asarray([dl], np.float32), avgdl, n)
+    assert np.isclose(got, expected).all()
+
+
+def test_and_or_queries(data):
+    """reference test_search.py:127-226: boolean combinations are plain numpy on score()"""
+    foo, bar = data.score("foo") > 0, data.score("bar") > 0
+    assert ((foo & bar) == [True, False, False, False] * 25).all()
+    assert ((foo | bar) == [True, False, True, False] * 25).all()
+    summed = np.sum([data.score(t) for t in ("foo", "bar")], axis=0)
+    assert summed.argmax() % 4 == 0
+
+
+def test_empty_docs(default_api):
+    """reference test_search.py:42-59"""
+    arr = SearchArray.index(pd.DataFrame({"data": [""] * 100})["data"])
+    assert arr.score("foo").sum() == 0
+    assert arr.score(["foo", "bar"]).sum() == 0
+    assert arr.isna().all()
+
+
+def test_slices_copies_and_views(data):
+    sliced = data[1::2]
+    assert len(sliced) == 50
+    assert np.array_equal(sliced.termfreqs("bar"), data.termfreqs("bar")[1::2])
+    assert np.array_equal(sliced.score("bar"), data.score("bar")[1::2])
+    mask = np.asarray([True, False, True, False] * 25)
+    assert np.array_equal(data[mask].termfreqs("bar"), np.asarray([2, 1] * 25, dtype=np.float32))
+    cp = data.copy()
+    assert (cp == data).all() and np.array_equal(cp.score("foo"), data.score("foo"))
+    assert np.array_equal(data.take([0, 2, 2]).termfreqs("bar"), [2, 1, 1])
+    first = data[0]
+    assert isinstance(first, Terms) and first.postings == {"foo": 1, "bar": 2, "baz": 1} and first.doc_len == 4
+    assert (first.positions("bar") == [1, 2]).all()
+
+
+def test_positions(data):
+    """reference test_phrase_matches.py:400-425"""
+    posns = data.positions("bar")
+    assert len(posns) == 100 and (posns[0] == [1, 2]).all() and (posns[2] == [1]).all() and len(posns[1]) == 0
+    sub = data.positions("bar", np.asarray([True, False, False, False] * 25))
+    assert len(sub) == 25 and all((p == [1, 2]).all() for p in sub)
+
+
+@pytest.mark.parametrize("docs,phrase,expected", PHRASE_SCENARIOS[1::3])
+def test_phrase_api(default_api, docs, phrase, expected):
+    """reference test_phrase_matches.py:224-246 (full array and odd-doc slice)"""
+    arr = SearchArray.index(docs)
+    before = arr.copy()
+    tfs = arr.termfreqs(phrase.split())
+    assert (tfs == expected).all()
+    assert (arr == before).all()
+    assert (arr[1::2].termfreqs(phrase.split()) == np.asarray(expected)[1::2]).all()
+    scores = arr.score(phrase.split())
+    assert ((scores > 0) == (np.asarray(expected) > 0)).all()
+
+
+def test_phrase_too_many_posns(default_api):
+    """reference test_phrase_matches.py:382-397"""
+    big = "foo bar baz " + " ".join(["dummy"] * (2 ** 18 - 1)) + " blah blah blah"
+    with pytest.raises(ValueError):
+        SearchArray.index([big, "not match"])
+    arr = SearchArray.index([big, "not match"], truncate=True)
+    assert (arr.termfreqs(["foo", "bar", "baz"]) == [1, 0]).all()
+
+
+def test_unsupported_options_fail_loudly(data):
+    with pytest.raises(NotImplementedError):
+        data.termfreqs(["foo", "bar"], slop=2)
+    with pytest.raises(NotImplementedError):
+        data.score("foo", min_posn=0, max_posn=17)
+
+
+def test_threaded_scoring_is_deterministic(data):
+    """reference test_tmdb.py:285-312: concurrent score() calls must agree with serial ones"""
+    want = {t: data.score(t) for t in ("foo", "bar", "baz", "data2")}
+    phrase = data.score(["foo", "bar"])
+    with ThreadPoolExecutor(4) as ex:
+        futs = [(t, ex.submit(data.score, t)) for t in list(want) * 8]
+        pf = [ex.submit(data.score, ["foo", "bar"]) for _ in range(8)]
+        for t, f in futs:
+            assert np.array_equal(f.result(), want[t])
+        for f in pf:
+            assert np.array_equal(f.result(), phrase)
+
+
+def test_pickle_round_trip(data):
+    """reference test_search.py:62-73 (pickle of the array; the HBM copy is rebuilt on demand)"""
+    again = pickle.loads(pickle.dumps(data))
+    assert np.array_equal(again.score("bar"), data.score("bar"))
+    assert (again == data).all()
+
+
+def test_pandas_integration(data):
+    df = pd.DataFrame({"text": DOCS, "idx": np.arange(100)})
+    df["tokens"] = SearchArray.index(df["text"])
+    assert str(df["tokens"].dtype) == "tokenized_text"
+    top = df[df["tokens"].array.score("bar") > 0]
+    assert len(top) == 50
+    sub = df.iloc[::4]
+    assert (sub["tokens"].array.termfreqs("foo") == 1).all()
+    both = pd.concat([df.iloc[:4], df.iloc[4:8]])
+    assert (both["tokens"].array.termfreqs("bar") == [2, 0, 1, 0, 2, 0, 1, 0]).all()
+
+
+def test_setitem_and_from_dicts(default_api):
+    arr = SearchArray.index(["foo bar", "baz", "foo foo"])
+    arr[1] = arr[2]
+    assert (arr.termfreqs("foo") == [1, 2, 2]).all()
+    from_dicts = SearchArray([{"foo": 1, "bar": 2}, {}, {"baz": 1}])
+    assert len(from_dicts) == 3 and from_dicts.isna().tolist() == [False, True, False]
+    assert from_dicts[0] == Terms({"foo": 1, "bar": 2}, doc_len=2)
