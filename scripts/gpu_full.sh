@@ -1,0 +1,22 @@
+#!/bin/bash
+# Full GPU pass: smoke, all gpu tests, bench (N=1), phrase bench, rocprof stats + PMC passes.
+set -x
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+rm -rf $O/prof_stats $O/prof_pmc_fetch $O/prof_pmc_write
+mkdir -p $O
+export TMPDIR=/tmp
+cd $R
+( time timeout 600 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1
+( time timeout 1800 python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1
+( time timeout 900 python bench.py --corpus-cache /tmp/corpus ) > $O/bench.log 2>&1
+( time timeout 900 python bench.py --corpus-cache /tmp/corpus --k 1000 --no-cpu-baseline --steps 5 ) > $O/bench_k1000.log 2>&1
+( time timeout 900 python scripts/phrase_bench.py ) > $O/phrase_bench.log 2>&1
+cd /tmp
+( timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --corpus-cache /tmp/corpus ) > $O/prof_stats.log 2>&1
+( timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --corpus-cache /tmp/corpus ) > $O/prof_pmc_fetch.log 2>&1
+( timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_pmc_write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --corpus-cache /tmp/corpus ) > $O/prof_pmc_write.log 2>&1
+find $O -name "*.db" -delete 2>/dev/null
+find $O -type f -size +8M -delete 2>/dev/null
+grep -E "passed|failed" $O/pytest_gpu.log
+exit 0

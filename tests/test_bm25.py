@@ -198,3 +198,30 @@ def test_out_of_table_postings_and_unpacked_doc_lens(api):
             ws, wd = O.topk(orc.score_terms_sum(q), 10)
             assert np.array_equal(scores[qi], ws) and np.array_equal(docs[qi], wd)
         bt.close()
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_single_rank():
+    """The library-internal RCCL path (ncclCommInitRank + ncclAllGather on the index stream +
+    regroup + merge) with a one-rank communicator: results must equal the no-communicator run."""
+    import ctypes
+    from searcharray_amd import _lib
+    api = _lib.api()
+    g, dev, orc, vocab = build_pair("zipf_small", api=api)
+    queries = g["or_queries"][:8]
+    plain = dev.batch(queries, k=10)
+    plain.run()
+    want = plain.fetch()
+    buf = ctypes.create_string_buffer(128)
+    api.call("sa_comm_unique_id", buf, 128)
+    dev.comm_init(0, 1, buf.raw)
+    try:
+        bt = dev.batch(queries, k=10)
+        for _ in range(3):
+            bt.run()
+        got = bt.fetch()
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        bt.close()
+    finally:
+        dev.comm_destroy()
+    plain.close()

@@ -1,0 +1,78 @@
+"""Doc-range sharding across ranks (N > 1 path) on CPU: world_size-2 `gloo` processes, each
+holding one shard of a small corpus in the host-emulated kernel library, exchange their per-shard
+top-k keys with all_gather and merge -- the same entry points (sa_batch_run_local /
+sa_batch_merge_gathered) bench.py drives over RCCL on the GPUs.  The merged result must equal the
+single-index oracle top-k, and BM25 must use the GLOBAL statistics."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist          # noqa: E402
+import torch.multiprocessing as mp        # noqa: E402
+
+N_DOCS, VOCAB, K = 6000, 300, 10
+QUERIES = np.asarray([[0, 5, 50, 200], [1, 2, 3, 4], [7, 90, 150, 299], [10, 11, 12, 13]])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _corpus():
+    from searcharray_amd import synth
+    return synth.corpus_triples(N_DOCS, VOCAB, 14, seed=17)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from searcharray_amd import roaringish as rz
+    from searcharray_amd.device_index import DeviceIndex, QueryBatch, compute_idf
+    from tests.emu import emu_api
+    t, d, p, lens = _corpus()
+    lo, hi = N_DOCS * rank // world, N_DOCS * (rank + 1) // world
+    sel = (d >= lo) & (d < hi)
+    words, wt = rz.encode_sorted(t[sel], d[sel] - np.uint64(lo), p[sel])
+    # global statistics: total length and per-term df are summed over the shards
+    tot = torch.tensor([float(lens[lo:hi].sum())], dtype=torch.float64)
+    dist.all_reduce(tot)
+    avgdl = np.float32(tot.item() / N_DOCS)
+    index = DeviceIndex(words, rz.term_offsets(wt, VOCAB), lens[lo:hi], avg_doc_len=avgdl, corpus_size=N_DOCS,
+                        doc_base=lo, tile_docs=1024, api=emu_api())
+    df = torch.from_numpy(index.docfreqs().astype(np.int64))
+    dist.all_reduce(df)
+    index.set_global_docfreqs(df.numpy().astype(np.uint64))
+    idf = np.asarray([[compute_idf(N_DOCS, np.asarray([df[t_].item()])) for t_ in q] for q in QUERIES], dtype=np.float32)
+    batch = QueryBatch(index, QUERIES, k=K, idf=idf)
+    local = torch.zeros(len(QUERIES) * K, dtype=torch.int64)
+    gathered = torch.zeros(world * len(QUERIES) * K, dtype=torch.int64)
+    batch.run_local(local.data_ptr(), sync=True)
+    dist.all_gather_into_tensor(gathered, local)
+    batch.merge_gathered(gathered.data_ptr(), world, sync=True)
+    scores, docs = batch.fetch()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), scores=scores, docs=docs, avgdl=avgdl)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_topk_matches_single_index_oracle(tmp_path):
+    from oracle import refimpl as O
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    t, d, p, lens = _corpus()
+    orc = O.OracleIndex.from_triples(t, d, p, N_DOCS, doc_lens=lens)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["scores"], r1["scores"]) and np.array_equal(r0["docs"], r1["docs"])   # every rank merges
+    orc.avg_doc_length = r0["avgdl"]
+    for qi, q in enumerate(QUERIES):
+        ws, wd = O.topk(orc.score_terms_sum([int(x) for x in q]), K)
+        n = int((ws > 0).sum())
+        assert np.allclose(r0["scores"][qi, :n], ws[:n], rtol=1e-6), f"q{qi}"
+        assert np.array_equal(r0["docs"][qi, :n], wd[:n]), f"q{qi}"
