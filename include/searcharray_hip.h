@@ -63,6 +63,48 @@ int sa_unique(const uint64_t* arr, int64_t n, uint64_t rshift, uint64_t* out, in
 /* popcount64(arr) -> u64[n]      reference searcharray/roaringish/popcount.pyx:71-81,119-121 */
 int sa_popcount64(const uint64_t* arr, int64_t n, uint64_t* out);
 
+/* intersect(lhs, rhs, mask, drop_duplicates) -> index pairs into lhs / rhs of equal masked values
+ * reference searcharray/roaringish/intersect.pyx:278-320 (drop: first member of each equal run,
+ * outputs sized min(nl, nr); keep: every member of both runs, outputs sized max(nl, nr)).
+ * mask == 0 is an error ("Mask cannot be zero", intersect.pyx:290-291). */
+int sa_intersect(const uint64_t* lhs, int64_t nl, const uint64_t* rhs, int64_t nr, uint64_t mask,
+                 int drop_duplicates, uint64_t* lhs_idx, uint64_t* rhs_idx,
+                 int64_t* n_lhs_out, int64_t* n_rhs_out);
+
+/* adjacent(lhs, rhs, mask): pairs with lhs&mask + delta == rhs&mask, delta = lowest set bit of mask
+ * reference intersect.pyx:131-190,323-343.  Outputs sized min(nl, nr). */
+int sa_adjacent(const uint64_t* lhs, int64_t nl, const uint64_t* rhs, int64_t nr, uint64_t mask,
+                uint64_t* lhs_idx, uint64_t* rhs_idx, int64_t* n_out);
+
+/* intersect_with_adjacents(lhs, rhs, mask): equal pairs and adjacent pairs in one call
+ * reference intersect.pyx:213-275,346-390.  All four outputs sized min(nl, nr). */
+int sa_intersect_with_adjacents(const uint64_t* lhs, int64_t nl, const uint64_t* rhs, int64_t nr,
+                                uint64_t mask, uint64_t* lhs_idx, uint64_t* rhs_idx, int64_t* n_out,
+                                uint64_t* adj_lhs_idx, uint64_t* adj_rhs_idx, int64_t* n_adj_out);
+
+/* merge(lhs, rhs, drop_duplicates) of two sorted arrays; reference merge.pyx:54-158. Output sized nl+nr. */
+int sa_merge(const uint64_t* lhs, int64_t nl, const uint64_t* rhs, int64_t nr, int drop_duplicates,
+             uint64_t* out, int64_t* n_out);
+
+/* sort_merge_counts: union of two sorted id lists (ids unique within each list) with float counts
+ * added on equal ids; reference merge.pyx:161-232.  Outputs sized nl+nr. */
+int sa_sort_merge_counts(const uint64_t* lhs_ids, const float* lhs_counts, int64_t nl,
+                         const uint64_t* rhs_ids, const float* rhs_counts, int64_t nr,
+                         uint64_t* ids_out, float* counts_out, int64_t* n_out);
+
+/* popcount_reduce_at(ids, payload) / key_sum_over(ids, count): groups of consecutive equal ids,
+ * summing popcount(payload) / count; reference popcount.pyx:124-204.  Outputs sized n. */
+int sa_popcount_reduce_at(const uint64_t* ids, const uint64_t* payload, int64_t n, uint64_t* ids_out,
+                          float* counts_out, int64_t* n_out);
+int sa_key_sum_over(const uint64_t* ids, const uint64_t* count, int64_t n, uint64_t* ids_out,
+                    float* counts_out, int64_t* n_out);
+
+/* payload_slice(arr, payload_msb_mask, min_payload, max_payload): words whose UNSHIFTED
+ * (word & msb_mask) lies in [min, max] -- the reference's comparison, reference
+ * roaringish_ops.pyx:46-68.  Output sized n. */
+int sa_payload_slice(const uint64_t* arr, int64_t n, uint64_t payload_msb_mask, uint64_t min_payload,
+                     uint64_t max_payload, uint64_t* out, int64_t* n_out);
+
 /* HBM read-bandwidth probe (roofline calibration): streams `bytes` of device memory `reps`
  * times with 8-byte (mode 0) or 16-byte (mode 1) loads per lane; best GB/s. */
 int sa_stream_probe(uint64_t bytes, int mode, int reps, double* gbps_out);

@@ -47,6 +47,14 @@ PROTOTYPES = {
     "sa_popcount64_reduce": (c_int, [u64p, c_int64, c_uint64, c_uint64, u64p, f32p, i64p]),
     "sa_unique": (c_int, [u64p, c_int64, c_uint64, u64p, i64p]),
     "sa_popcount64": (c_int, [u64p, c_int64, u64p]),
+    "sa_intersect": (c_int, [u64p, c_int64, u64p, c_int64, c_uint64, c_int, u64p, u64p, i64p, i64p]),
+    "sa_adjacent": (c_int, [u64p, c_int64, u64p, c_int64, c_uint64, u64p, u64p, i64p]),
+    "sa_intersect_with_adjacents": (c_int, [u64p, c_int64, u64p, c_int64, c_uint64, u64p, u64p, i64p, u64p, u64p, i64p]),
+    "sa_merge": (c_int, [u64p, c_int64, u64p, c_int64, c_int, u64p, i64p]),
+    "sa_sort_merge_counts": (c_int, [u64p, f32p, c_int64, u64p, f32p, c_int64, u64p, f32p, i64p]),
+    "sa_popcount_reduce_at": (c_int, [u64p, u64p, c_int64, u64p, f32p, i64p]),
+    "sa_key_sum_over": (c_int, [u64p, u64p, c_int64, u64p, f32p, i64p]),
+    "sa_payload_slice": (c_int, [u64p, c_int64, c_uint64, c_uint64, c_uint64, u64p, i64p]),
     "sa_stream_probe": (c_int, [c_uint64, c_int, c_int, POINTER(c_double)]),
     # Part 2
     "sa_index_create": (c_int, [c_int, c_uint64, c_uint64, c_uint32, u64p, u64p, f32p, c_float,

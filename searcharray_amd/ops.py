@@ -70,3 +70,99 @@ def popcount64(arr, api=None) -> np.ndarray:
     out = np.empty(len(arr), dtype=np.uint64)
     _api(api).call("sa_popcount64", p_u64(arr), len(arr), p_u64(out))
     return out
+
+
+def _check_mask(mask):
+    if mask is None:
+        return int(ALL_BITS)
+    if int(mask) == 0:
+        raise ValueError("Mask cannot be zero")                     # reference intersect.pyx:290-291
+    return int(mask)
+
+
+def intersect(lhs, rhs, mask=ALL_BITS, drop_duplicates=True, api=None) -> Tuple[np.ndarray, np.ndarray]:
+    """reference searcharray/roaringish/intersect.pyx:278-320."""
+    lhs, rhs = as_u64(lhs), as_u64(rhs)
+    mask = _check_mask(mask)
+    n = min(len(lhs), len(rhs)) if drop_duplicates else max(len(lhs), len(rhs))
+    lo, ro = np.empty(n, dtype=np.uint64), np.empty(n, dtype=np.uint64)
+    nl, nr = _lib.c_int64(0), _lib.c_int64(0)
+    _api(api).call("sa_intersect", p_u64(lhs), len(lhs), p_u64(rhs), len(rhs), mask, 1 if drop_duplicates else 0,
+                   p_u64(lo), p_u64(ro), nl, nr)
+    return lo[:nl.value].copy(), ro[:nr.value].copy()
+
+
+def adjacent(lhs, rhs, mask=ALL_BITS, api=None) -> Tuple[np.ndarray, np.ndarray]:
+    """reference searcharray/roaringish/intersect.pyx:323-343."""
+    lhs, rhs = as_u64(lhs), as_u64(rhs)
+    mask = _check_mask(mask)
+    n = min(len(lhs), len(rhs))
+    lo, ro = np.empty(n, dtype=np.uint64), np.empty(n, dtype=np.uint64)
+    k = _lib.c_int64(0)
+    _api(api).call("sa_adjacent", p_u64(lhs), len(lhs), p_u64(rhs), len(rhs), mask, p_u64(lo), p_u64(ro), k)
+    return lo[:k.value].copy(), ro[:k.value].copy()
+
+
+def intersect_with_adjacents(lhs, rhs, mask=ALL_BITS, api=None):
+    """reference searcharray/roaringish/intersect.pyx:346-390."""
+    lhs, rhs = as_u64(lhs), as_u64(rhs)
+    mask = _check_mask(mask)
+    n = min(len(lhs), len(rhs))
+    lo, ro, la, ra = (np.empty(n, dtype=np.uint64) for _ in range(4))
+    k, ka = _lib.c_int64(0), _lib.c_int64(0)
+    _api(api).call("sa_intersect_with_adjacents", p_u64(lhs), len(lhs), p_u64(rhs), len(rhs), mask,
+                   p_u64(lo), p_u64(ro), k, p_u64(la), p_u64(ra), ka)
+    return lo[:k.value].copy(), ro[:k.value].copy(), la[:ka.value].copy(), ra[:ka.value].copy()
+
+
+def merge(lhs, rhs, drop_duplicates=False, api=None) -> np.ndarray:
+    """reference searcharray/roaringish/merge.pyx:135-158."""
+    lhs, rhs = as_u64(lhs), as_u64(rhs)
+    out = np.empty(len(lhs) + len(rhs), dtype=np.uint64)
+    k = _lib.c_int64(0)
+    _api(api).call("sa_merge", p_u64(lhs), len(lhs), p_u64(rhs), len(rhs), 1 if drop_duplicates else 0, p_u64(out), k)
+    return out[:k.value].copy()
+
+
+def sort_merge_counts(lhs_ids, lhs_counts, rhs_ids, rhs_counts, api=None):
+    """reference searcharray/roaringish/merge.pyx:221-232."""
+    lhs_ids, rhs_ids = as_u64(lhs_ids), as_u64(rhs_ids)
+    lhs_counts, rhs_counts = as_f32(lhs_counts), as_f32(rhs_counts)
+    n = len(lhs_ids) + len(rhs_ids)
+    oi, oc = np.empty(n, dtype=np.uint64), np.empty(n, dtype=np.float32)
+    k = _lib.c_int64(0)
+    _api(api).call("sa_sort_merge_counts", p_u64(lhs_ids), p_f32(lhs_counts), len(lhs_ids), p_u64(rhs_ids),
+                   p_f32(rhs_counts), len(rhs_ids), p_u64(oi), p_f32(oc), k)
+    return oi[:k.value].copy(), oc[:k.value].copy()
+
+
+def popcount_reduce_at(ids, payload, api=None):
+    """reference searcharray/roaringish/popcount.pyx:151-165."""
+    ids, payload = as_u64(ids), as_u64(payload)
+    if len(ids) != len(payload):
+        raise ValueError("ids and payload must have the same length")
+    oi, oc = np.empty(len(ids), dtype=np.uint64), np.empty(len(ids), dtype=np.float32)
+    k = _lib.c_int64(0)
+    _api(api).call("sa_popcount_reduce_at", p_u64(ids), p_u64(payload), len(ids), p_u64(oi), p_f32(oc), k)
+    return oi[:k.value].copy(), oc[:k.value].copy()
+
+
+def key_sum_over(ids, count, api=None):
+    """reference searcharray/roaringish/popcount.pyx:194-204."""
+    ids, count = as_u64(ids), as_u64(count)
+    if len(ids) != len(count):
+        raise ValueError("ids and count must have the same length")
+    oi, oc = np.empty(len(ids), dtype=np.uint64), np.empty(len(ids), dtype=np.float32)
+    k = _lib.c_int64(0)
+    _api(api).call("sa_key_sum_over", p_u64(ids), p_u64(count), len(ids), p_u64(oi), p_f32(oc), k)
+    return oi[:k.value].copy(), oc[:k.value].copy()
+
+
+def payload_slice(arr, payload_msb_mask, min_payload=0, max_payload=0xFFFFFFFFFFFFFFFF, api=None) -> np.ndarray:
+    """reference searcharray/roaringish/roaringish_ops.pyx:63-68."""
+    arr = as_u64(arr)
+    out = np.empty(len(arr), dtype=np.uint64)
+    k = _lib.c_int64(0)
+    _api(api).call("sa_payload_slice", p_u64(arr), len(arr), int(payload_msb_mask), int(min_payload),
+                   int(max_payload) & 0xFFFFFFFFFFFFFFFF, p_u64(out), k)
+    return out[:k.value].copy()
