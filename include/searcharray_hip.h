@@ -156,7 +156,9 @@ int sa_index_bm25_dense(sa_index_t* ix, const uint32_t* terms, const float* idf,
  * same-term rule and plan selection (reference PosnBitArray.phrase_freqs middle_out.py:418-441,
  * compute_phrase_freqs :154-168, phrase/bigram_freqs.py:213-307).  Unknown terms give zeros
  * (postings.py:705-708); n_terms < 2 is an error (middle_out.py:425-426).
- * slop > 0 is reported as SA_ERR_UNSUPPORTED in this version. */
+ * slop > 0 runs the reference's span search (phrase/spans.py:71-187, roaringish/spans.pyx:189-319):
+ * header-set candidate selection + one thread per document replaying the 512-span state machine,
+ * with the reference's observable quirks; at most 16 terms. */
 int sa_index_phrase_freqs_dense(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop, float* out);
 
 /* SearchArray.score(phrase): BM25 over the phrase counts, idf = float32 sum over the phrase's

@@ -83,10 +83,6 @@ def lib() -> ctypes.CDLL:
         _lib.oracle_payload_slice.restype = c_long
         _lib.oracle_topk.argtypes = [f32p, c_long, c_long, f32p, u64p]
         _lib.oracle_topk.restype = c_long
-        if hasattr(_lib, "oracle_span_freqs"):
-            _lib.oracle_span_freqs.argtypes = [u64p, c_long, u64p, c_long, c_u64,
-                                               u64p, f32p, c_long]
-            _lib.oracle_span_freqs.restype = c_long
     return _lib
 
 

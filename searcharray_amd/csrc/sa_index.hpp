@@ -63,3 +63,5 @@ struct sa_index {
 };
 
 int sa_index_scratch(sa_index* ix, size_t bytes, void** out);
+// slop > 0 phrase counts (sa_spans.hip): dense float[n_docs] inside the index scratch
+int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, float** d_out);

@@ -460,12 +460,13 @@ extern "C" int sa_index_phrase_freqs_dense(sa_index_t* ix, const uint32_t* terms
     // reference middle_out.py:425-426
     if (n_terms < 2) { sa_set_error("Must have at least two terms"); return SA_ERR_ARG; }
     SA_ARG(n_terms <= SA_MAX_PHRASE, "phrase too long (max 32 terms)");
-    if (slop != 0) { sa_set_error("slop > 0 is not implemented on the device yet"); return SA_ERR_UNSUPPORTED; }
+    SA_ARG(slop >= 0, "slop < 0");
     std::lock_guard<std::mutex> g(ix->mu);
     SA_HIP(hipSetDevice(ix->device));
     float* d_running = nullptr;
     SA_TRY(sa_profile_begin(ix));
-    SA_TRY(sa_phrase_counts_device(ix, terms, n_terms, sa_phrase_mode(), &d_running));
+    if (slop == 0) SA_TRY(sa_phrase_counts_device(ix, terms, n_terms, sa_phrase_mode(), &d_running));
+    else SA_TRY(sa_span_counts_device(ix, terms, n_terms, slop, &d_running));
     SA_TRY(sa_profile_end(ix, sa_phrase_alg_bytes(ix, terms, n_terms)));
     SA_HIP(hipMemcpyAsync(out, d_running, ix->n_docs * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
     SA_HIP(hipStreamSynchronize(ix->stream));
@@ -480,7 +481,7 @@ extern "C" int sa_index_bm25_phrase_dense(sa_index_t* ix, const uint32_t* terms,
     SA_ARG(ix && out && terms, "null argument");
     if (n_terms < 2) { sa_set_error("Must have at least two terms"); return SA_ERR_ARG; }
     SA_ARG(n_terms <= SA_MAX_PHRASE, "phrase too long (max 32 terms)");
-    if (slop != 0) { sa_set_error("slop > 0 is not implemented on the device yet"); return SA_ERR_UNSUPPORTED; }
+    SA_ARG(slop >= 0, "slop < 0");
     std::lock_guard<std::mutex> g(ix->mu);
     SA_HIP(hipSetDevice(ix->device));
     const u64 N = ix->n_docs;
@@ -489,7 +490,8 @@ extern "C" int sa_index_bm25_phrase_dense(sa_index_t* ix, const uint32_t* terms,
         return SA_OK;
     }
     float* d_running = nullptr;
-    SA_TRY(sa_phrase_counts_device(ix, terms, n_terms, sa_phrase_mode(), &d_running));
+    if (slop == 0) SA_TRY(sa_phrase_counts_device(ix, terms, n_terms, sa_phrase_mode(), &d_running));
+    else SA_TRY(sa_span_counts_device(ix, terms, n_terms, slop, &d_running));
     if (N) hipLaunchKernelGGL(sa_k_bm25_from_tf, dim3(sa_grid_for(N)), dim3(256), 0, ix->stream, d_running,
                               ix->d_doc_lens, ix->avg_doc_len, idf, k1, b, N);
     SA_HIP(hipMemcpyAsync(out, d_running, N * sizeof(float), hipMemcpyDeviceToHost, ix->stream));

@@ -10,8 +10,8 @@ index core plus a row selection.
 Differences from the reference, by design:
   * a sliced / filtered array scores with corpus-wide document frequencies (the reference's
     filtered views use slice-local df with global corpus size -- SURVEY appendix A.6);
-  * ``min_posn`` / ``max_posn`` and ``slop > 0`` raise NotImplementedError instead of silently
-    taking a CPU path (there is no CPU fallback in this package).
+  * ``min_posn`` / ``max_posn`` raise NotImplementedError instead of silently taking a CPU path
+    (there is no CPU fallback in this package).
 """
 from __future__ import annotations
 
@@ -458,8 +458,8 @@ class SearchArray(ExtensionArray):
     def _check_posn_args(slop, min_posn, max_posn):
         if min_posn is not None or max_posn is not None:
             raise NotImplementedError("min_posn / max_posn are not implemented on the device path")
-        if slop != 0:
-            raise NotImplementedError("slop > 0 is not implemented on the device path yet")
+        if slop < 0:
+            raise ValueError("slop must be >= 0")
 
     def _term_id(self, token: str) -> int:
         try:

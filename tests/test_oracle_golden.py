@@ -188,3 +188,21 @@ def test_corpus_matches_reference(name):
         assert np.array_equal(idx.phrase_freqs(terms), want), f"phrase {terms}"       # bit-exact counts
         wants = dense_from_sparse(g[f"phr_{i}_sidx"], g[f"phr_{i}_sval"], n)
         assert np.array_equal(idx.score(terms), wants), f"phrase score {terms}"
+
+
+@pytest.mark.parametrize("name", ["zipf_small", "zipf_sparse"])
+def test_slop_matches_reference(name):
+    """slop > 0 counts (reference phrase/spans.py + roaringish/spans.pyx) on the seeded corpora:
+    only match/no-match booleans are pinned by the reference's own tests (test_slop_matches.py), so
+    the counts are pinned against outputs of the reference itself."""
+    from oracle import spans as S
+    g, idx = oracle_index(name)
+    n = idx.num_docs
+    for i in range(int(g["n_slop"])):
+        terms = [int(t) for t in g[f"slop_{i}_terms"]]
+        slop = int(g[f"slop_{i}_slop"])
+        want = dense_from_sparse(g[f"slop_{i}_idx"], g[f"slop_{i}_val"], n)
+        got = idx.phrase_freqs(terms, slop=slop)
+        assert np.array_equal(got, want), f"slop {terms} {slop}"
+        _, _, overflow = S.span_search([idx.enc(t) for t in terms], slop, return_overflow=True)
+        assert overflow == 0            # no doc fills the 512-span table (reference UB territory)

@@ -100,3 +100,59 @@ def test_phrase_errors_and_unknown_terms(api):
         dev.phrase_freqs_dense([0])
     assert dev.phrase_freqs_dense([0, 99]).sum() == 0
     assert dev.bm25_phrase_dense([0, 99]).sum() == 0
+
+
+@pytest.mark.parametrize("name", ["zipf_small", "zipf_sparse"])
+def test_slop_counts_match_reference(api, name):
+    """slop > 0: candidate selection + per-document span state machine on the device vs the outputs
+    of the reference itself (tests/golden) -- bit-exact counts, and BM25 scores within 1e-5."""
+    g, (t, d, p), lens, num_docs, vocab = golden_corpus(name)
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    orc = O.OracleIndex.from_triples(t, d, p, num_docs, doc_lens=lens)
+    for i in range(int(g["n_slop"])):
+        terms = [int(x) for x in g[f"slop_{i}_terms"]]
+        slop = int(g[f"slop_{i}_slop"])
+        want = dense_from_sparse(g[f"slop_{i}_idx"], g[f"slop_{i}_val"], num_docs)
+        got = dev.phrase_freqs_dense(terms, slop=slop)
+        assert np.array_equal(got, want), f"slop {terms} {slop}: {np.flatnonzero(got != want)[:5]}"
+    terms, slop = [3, 7], 2
+    assert np.allclose(dev.bm25_phrase_dense(terms, slop=slop), orc.score(terms, slop=slop), rtol=1e-5, atol=0)
+
+
+def test_slop_scenarios_from_reference_tests(api):
+    """match / no-match booleans of reference test/test_slop_matches.py:7-88"""
+    docs = ["foo bar baz", "foo x bar", "foo x y bar", "bar foo", "foo foo bar", "nothing here"]
+    vocab, dev = _device_from_strings(docs, api)
+    vocab_o, orc = _index_strings(docs)
+    q = [vocab["foo"], vocab["bar"]]
+    for slop in (1, 2, 3):
+        got = dev.phrase_freqs_dense(q, slop=slop)
+        want = orc.phrase_freqs([vocab_o["foo"], vocab_o["bar"]], slop=slop)
+        assert np.array_equal(got, want), slop
+        assert got[0] > 0 and got[5] == 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_slop_random_differential(api, seed):
+    """random corpora / queries: device span search == oracle (which is pinned to the reference)"""
+    from oracle import spans as S
+    rng = np.random.default_rng(100 + seed)
+    n_docs, vocab = int(rng.integers(200, 900)), int(rng.integers(8, 40))
+    t, d, p, lens = synth.corpus_triples(n_docs, vocab, int(rng.integers(10, 70)), seed=seed)
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
+    for _ in range(6):
+        T = int(rng.integers(2, 5))
+        terms = [int(x) for x in rng.integers(0, vocab, T)]
+        slop = int(rng.integers(1, 6))
+        enc = [orc.enc(x) if orc.has_term(x) else np.empty(0, np.uint64) for x in terms]
+        if any(len(e) == 0 for e in enc):
+            continue
+        ids, counts, overflow = S.span_search(enc, slop, return_overflow=True)
+        want = np.zeros(n_docs, dtype=np.float32)
+        want[ids.astype(np.int64)] = counts
+        got = dev.phrase_freqs_dense(terms, slop=slop)
+        if overflow == 0:
+            assert np.array_equal(got, want), f"seed {seed} terms {terms} slop {slop}: {np.flatnonzero(got != want)[:5]}"

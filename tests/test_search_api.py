@@ -134,8 +134,6 @@ def test_phrase_too_many_posns(default_api):
 
 def test_unsupported_options_fail_loudly(data):
     with pytest.raises(NotImplementedError):
-        data.termfreqs(["foo", "bar"], slop=2)
-    with pytest.raises(NotImplementedError):
         data.score("foo", min_posn=0, max_posn=17)
 
 
