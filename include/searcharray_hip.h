@@ -161,6 +161,17 @@ int sa_index_bm25_dense(sa_index_t* ix, const uint32_t* terms, const float* idf,
  * with the reference's observable quirks; at most 16 terms. */
 int sa_index_phrase_freqs_dense(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop, float* out);
 
+/* The same with the reference's min_posn / max_posn restriction (-1 = None): every term's words are
+ * sliced with payload_slice first (reference middle_out.py:434-437, roaringish.py:266-282 -- the
+ * reference compares the UNSHIFTED (word & msb_mask) with posn // 18, kept as is).
+ * min_posn must be a multiple of 18 and max_posn a multiple of 18 minus 1, else SA_ERR_ARG. */
+int sa_index_phrase_freqs_dense_posn(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop,
+                                     int64_t min_posn, int64_t max_posn, float* out);
+int sa_index_bm25_phrase_dense_posn(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop,
+                                    int64_t min_posn, int64_t max_posn, float idf, float k1, float b, float* out);
+/* single-term dense tf restricted to the position range (reference middle_out.py:489-497) */
+int sa_index_termfreqs_dense_posn(sa_index_t* ix, uint32_t term, int64_t min_posn, int64_t max_posn, float* out);
+
 /* SearchArray.score(phrase): BM25 over the phrase counts, idf = float32 sum over the phrase's
  * terms computed by the host (reference postings.py:652-680, similarity.py:19-38). */
 int sa_index_bm25_phrase_dense(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop,

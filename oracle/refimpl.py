@@ -548,14 +548,27 @@ class OracleIndex:
         ids, tfs = self.termfreqs_sparse(term)
         return as_dense(ids, tfs, self.num_docs)
 
+    # -- roaringish.py:266-282: the min/max position slice (compares the unshifted msb field, A.6)
+    @staticmethod
+    def posn_slice(enc, min_posn, max_posn):
+        if min_posn is None and max_posn is None:
+            return enc
+        if min_posn is not None and min_posn % 18 != 0:
+            raise ValueError("min_payload must be a multiple of 18")
+        if max_posn is not None and max_posn % 18 != 17:
+            raise ValueError("max_payload must be a multiple of 18 - 1")
+        lo = 0 if min_posn is None else min_posn
+        hi = 0xFFFFFFFFFFFFFFFF if max_posn is None else max_posn
+        return payload_slice(enc, PAYLOAD_MSB_MASK, lo // 18, hi // 18)
+
     # -- middle_out.py:418-441 (slop == 0), postings.py:689-708
-    def phrase_freqs(self, term_ids, slop: int = 0) -> np.ndarray:
+    def phrase_freqs(self, term_ids, slop: int = 0, min_posn=None, max_posn=None) -> np.ndarray:
         out = np.zeros(self.max_doc_id + 1, dtype=np.float32)
         if len(term_ids) < 2:
             raise ValueError("Must have at least two terms")
         if not all(self.has_term(t) for t in term_ids):
             return out
-        enc = [self.enc(t) for t in term_ids]
+        enc = [self.posn_slice(self.enc(t), min_posn, max_posn) for t in term_ids]
         if slop == 0:
             ids, counts = compute_phrase_freqs(enc)
         else:

@@ -68,6 +68,9 @@ PROTOTYPES = {
     "sa_index_bm25_dense": (c_int, [c_void_p, u32p, f32p, c_int, c_float, c_float, f32p]),
     "sa_index_phrase_freqs_dense": (c_int, [c_void_p, u32p, c_int, c_int, f32p]),
     "sa_index_bm25_phrase_dense": (c_int, [c_void_p, u32p, c_int, c_int, c_float, c_float, c_float, f32p]),
+    "sa_index_phrase_freqs_dense_posn": (c_int, [c_void_p, u32p, c_int, c_int, c_int64, c_int64, f32p]),
+    "sa_index_bm25_phrase_dense_posn": (c_int, [c_void_p, u32p, c_int, c_int, c_int64, c_int64, c_float, c_float, c_float, f32p]),
+    "sa_index_termfreqs_dense_posn": (c_int, [c_void_p, c_uint32, c_int64, c_int64, f32p]),
     "sa_index_last_profile": (c_int, [c_void_p, POINTER(c_double), u64p]),
     "sa_index_info": (c_int, [c_void_p, POINTER(IndexInfo)]),
     "sa_batch_create": (c_int, [c_void_p, u32p, f32p, c_int, c_int, c_int, c_float, c_float,

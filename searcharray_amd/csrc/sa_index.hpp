@@ -63,5 +63,13 @@ struct sa_index {
 };
 
 int sa_index_scratch(sa_index* ix, size_t bytes, void** out);
+// min_posn / max_posn restriction of the positional words (reference roaringish.py:266-282)
+struct PosnFilter {
+    bool active = false;
+    u64 lo = 0, hi = 0xFFFFFFFFFFFFFFFFull;       // compared with the UNSHIFTED (word & msb_mask), as the reference does
+};
+int sa_posn_filter_bounds(int64_t min_posn, int64_t max_posn, PosnFilter* f);
+int sa_posn_filter_terms(sa_index* ix, const PosnFilter& f, int T, const u64** ptrs, u32* lens, u64** bufs,
+                         u32* d_counts, u32* d_chunks);
 // slop > 0 phrase counts (sa_spans.hip): dense float[n_docs] inside the index scratch
-int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, float** d_out);
+int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const PosnFilter& filt, float** d_out);

@@ -171,8 +171,7 @@ sa_k_min2(float* __restrict__ a, const float* __restrict__ b, u64 n) {
 // fused kernel (pairwise-distinct terms)
 // ---------------------------------------------------------------------------------------
 struct FusedPhraseParams {
-    const u64* words;
-    u64 off[SA_MAX_PHRASE];      // start of each term's words
+    const u64* ptr[SA_MAX_PHRASE];   // each term's (possibly position-filtered) words
     u32 len[SA_MAX_PHRASE];
     int T, anchor;
     u32* step;                   // dense per-doc match counts (u32, atomically accumulated)
@@ -187,7 +186,7 @@ __device__ __forceinline__ u64 sa_payload_at(const u64* __restrict__ a, u32 n, u
 }
 
 __global__ void __launch_bounds__(256) sa_k_phrase_fused(const FusedPhraseParams p) {
-    const u64* anc = p.words + p.off[p.anchor];
+    const u64* anc = p.ptr[p.anchor];
     const u32 na = p.len[p.anchor];
     const u64 delta = 1ull << SA_LSB_BITS;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < na; i += gridDim.x * blockDim.x) {
@@ -198,7 +197,7 @@ __global__ void __launch_bounds__(256) sa_k_phrase_fused(const FusedPhraseParams
         for (int t = 0; t < p.T && m; t++) {
             if (t == p.anchor) continue;
             const int d = t - p.anchor;          // term t must sit at anchor position + d, |d| < 18
-            const u64* a = p.words + p.off[t];
+            const u64* a = p.ptr[t];
             const u32 n = p.len[t];
             // 54-bit window: payloads of headers h-1 | h | h+1 (same doc only)
             u32 hint = 0;
@@ -294,25 +293,71 @@ struct PhrasePlan {
     u32 terms[SA_MAX_PHRASE];
 };
 
+// min_posn / max_posn filter: the reference slices every term's words with payload_slice before
+// matching (middle_out.py:434-437, roaringish.py:266-282), comparing the UNSHIFTED
+// (word & msb_mask) with min_posn // 18 and max_posn // 18 -- kept as is.
+struct PosnSlice {
+    const u64* arr; u64 lo, hi; u64* out;
+    __device__ __forceinline__ bool flag(u32 i) const { const u64 v = arr[i] & 0x0000000FFFFC0000ull; return v >= lo && v <= hi; }
+    __device__ __forceinline__ void emit(u32 i, u32 pos) const { out[pos] = arr[i]; }
+};
+
+int sa_posn_filter_bounds(int64_t min_posn, int64_t max_posn, PosnFilter* f) {
+    f->active = (min_posn >= 0 || max_posn >= 0);
+    if (min_posn >= 0 && min_posn % SA_LSB_BITS != 0) {
+        sa_set_error("min_payload must be a multiple of %d", SA_LSB_BITS);                 // roaringish.py:270-271
+        return SA_ERR_ARG;
+    }
+    if (max_posn >= 0 && max_posn % SA_LSB_BITS != SA_LSB_BITS - 1) {
+        sa_set_error("max_payload must be a multiple of %d - 1", SA_LSB_BITS);             // roaringish.py:272-273
+        return SA_ERR_ARG;
+    }
+    f->lo = min_posn >= 0 ? (u64)min_posn / SA_LSB_BITS : 0;
+    f->hi = max_posn >= 0 ? (u64)max_posn / SA_LSB_BITS : 0xFFFFFFFFFFFFFFFFull / SA_LSB_BITS;
+    return SA_OK;
+}
+
+// Apply the filter to every term: compacts into `bufs[t]` and reads the new lengths back.
+int sa_posn_filter_terms(sa_index* ix, const PosnFilter& f, int T, const u64** ptrs, u32* lens, u64** bufs,
+                         u32* d_counts, u32* d_chunks) {
+    hipStream_t st = ix->stream;
+    for (int t = 0; t < T; t++) {
+        if (lens[t] == 0) continue;
+        PosnSlice ps; ps.arr = ptrs[t]; ps.lo = f.lo; ps.hi = f.hi; ps.out = bufs[t];
+        sa_compact(ps, (const u32*)nullptr, lens[t], d_chunks, d_counts + t, st);
+        ptrs[t] = bufs[t];
+    }
+    u32 h[SA_MAX_PHRASE];
+    SA_HIP(hipMemcpyAsync(h, d_counts, (size_t)T * sizeof(u32), hipMemcpyDeviceToHost, st));
+    SA_HIP(hipStreamSynchronize(st));
+    for (int t = 0; t < T; t++) if (lens[t]) lens[t] = h[t];
+    return SA_OK;
+}
+
 // dense phrase counts of terms[0..T) into d_running (float[n_docs]); uses the index scratch.
 // mode: 0 auto, 1 general chain, 2 fused.
-static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mode, float** d_running_out) {
+static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mode, const PosnFilter& filt,
+                                   float** d_running_out) {
     hipStream_t st = ix->stream;
     const u64 N = ix->n_docs;
     u32 lens[SA_MAX_PHRASE];
-    u64 offs[SA_MAX_PHRASE];
+    const u64* ptrs[SA_MAX_PHRASE];
     u32 maxlen = 0;
+    size_t total_len = 0;
     bool known = true, distinct = true;
     for (int t = 0; t < T; t++) {
-        if (terms[t] >= ix->n_terms) { known = false; lens[t] = 0; offs[t] = 0; continue; }
-        offs[t] = ix->h_term_off[terms[t]];
-        lens[t] = (u32)(ix->h_term_off[terms[t] + 1] - offs[t]);
+        if (terms[t] >= ix->n_terms) { known = false; lens[t] = 0; ptrs[t] = ix->d_words; continue; }
+        const u64 off = ix->h_term_off[terms[t]];
+        ptrs[t] = ix->d_words + off;
+        lens[t] = (u32)(ix->h_term_off[terms[t] + 1] - off);
         maxlen = lens[t] > maxlen ? lens[t] : maxlen;
+        total_len += lens[t];
         for (int u = 0; u < t; u++) if (terms[u] == terms[t]) distinct = false;
     }
     const size_t M = (size_t)maxlen + 64;
     const size_t chunk_words = sa_compact_chunks((u32)(2 * M)) + 8;
-    const size_t need = (N + 64) * 12 + M * (3 * 4 + 3 * 8 + 2 * 8 * 2) + chunk_words * 4 + 16 * 1024;
+    const size_t filt_bytes = filt.active ? (total_len + 64 * (size_t)T) * 8 : 0;
+    const size_t need = (N + 64) * 12 + M * (3 * 4 + 3 * 8 + 2 * 8 * 2) + chunk_words * 4 + filt_bytes + 16 * 1024;
     void* scratch;
     SA_TRY(sa_index_scratch(ix, need, &scratch));
     Arena ar;
@@ -332,6 +377,14 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
     SA_HIP(hipMemsetAsync(running, 0, N * sizeof(float), st));
     SA_HIP(hipMemsetAsync(step, 0, N * sizeof(u32), st));
     if (!known || N == 0) return SA_OK;                         // TermMissingError -> zeros (postings.py:705-708)
+    if (filt.active) {
+        u64* bufs[SA_MAX_PHRASE];
+        for (int t = 0; t < T; t++) {
+            bufs[t] = ar.take<u64>((size_t)lens[t] + 1);
+            if (!bufs[t]) { sa_set_error("internal: phrase arena exhausted"); return SA_ERR_STATE; }
+        }
+        SA_TRY(sa_posn_filter_terms(ix, filt, T, ptrs, lens, bufs, lens_dev, s.chunks));
+    }
     SA_HIP(hipMemcpyAsync(lens_dev, lens, (size_t)T * sizeof(u32), hipMemcpyHostToDevice, st));
     u32* ppn = lens_dev + SA_MAX_PHRASE;                        // two ping-pong length counters
 
@@ -351,10 +404,10 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
             const int a = parts[pi][0], b = parts[pi][1];
             FusedPhraseParams fp;
             memset(&fp, 0, sizeof(fp));
-            fp.words = ix->d_words; fp.T = b - a; fp.step = step;
+            fp.T = b - a; fp.step = step;
             int anchor = 0;
             for (int t = a; t < b; t++) {
-                fp.off[t - a] = offs[t]; fp.len[t - a] = lens[t];
+                fp.ptr[t - a] = ptrs[t]; fp.len[t - a] = lens[t];
                 if (lens[t] < lens[a + anchor]) anchor = t - a;
             }
             fp.anchor = anchor;
@@ -368,7 +421,7 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
 
     // general chain
     auto term_arr = [&](int t) {
-        DArr a; a.data = ix->d_words + offs[t]; a.n_dev = lens_dev + t; a.bound = lens[t]; return a;
+        DArr a; a.data = ptrs[t]; a.n_dev = lens_dev + t; a.bound = lens[t]; return a;
     };
     auto chain = [&](int a, int b, bool left_to_right, float* dst) -> int {
         // enc = terms[a..b)
@@ -455,18 +508,25 @@ static int sa_phrase_mode() {
     return 0;
 }
 
-extern "C" int sa_index_phrase_freqs_dense(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop, float* out) {
+static int sa_phrase_or_span(sa_index* ix, const u32* terms, int n_terms, int slop, const PosnFilter& filt, float** d_out) {
+    if (slop == 0) return sa_phrase_counts_device(ix, terms, n_terms, sa_phrase_mode(), filt, d_out);
+    return sa_span_counts_device(ix, terms, n_terms, slop, filt, d_out);
+}
+
+extern "C" int sa_index_phrase_freqs_dense_posn(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop,
+                                                int64_t min_posn, int64_t max_posn, float* out) {
     SA_ARG(ix && out && terms, "null argument");
     // reference middle_out.py:425-426
     if (n_terms < 2) { sa_set_error("Must have at least two terms"); return SA_ERR_ARG; }
     SA_ARG(n_terms <= SA_MAX_PHRASE, "phrase too long (max 32 terms)");
     SA_ARG(slop >= 0, "slop < 0");
+    PosnFilter filt;
+    SA_TRY(sa_posn_filter_bounds(min_posn, max_posn, &filt));
     std::lock_guard<std::mutex> g(ix->mu);
     SA_HIP(hipSetDevice(ix->device));
     float* d_running = nullptr;
     SA_TRY(sa_profile_begin(ix));
-    if (slop == 0) SA_TRY(sa_phrase_counts_device(ix, terms, n_terms, sa_phrase_mode(), &d_running));
-    else SA_TRY(sa_span_counts_device(ix, terms, n_terms, slop, &d_running));
+    SA_TRY(sa_phrase_or_span(ix, terms, n_terms, slop, filt, &d_running));
     SA_TRY(sa_profile_end(ix, sa_phrase_alg_bytes(ix, terms, n_terms)));
     SA_HIP(hipMemcpyAsync(out, d_running, ix->n_docs * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
     SA_HIP(hipStreamSynchronize(ix->stream));
@@ -474,14 +534,21 @@ extern "C" int sa_index_phrase_freqs_dense(sa_index_t* ix, const uint32_t* terms
     return SA_OK;
 }
 
+extern "C" int sa_index_phrase_freqs_dense(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop, float* out) {
+    return sa_index_phrase_freqs_dense_posn(ix, terms, n_terms, slop, -1, -1, out);
+}
+
 // SearchArray.score(phrase): phrase counts -> BM25 with the idf summed over the phrase's terms
 // (reference postings.py:652-680, similarity.py:19-38); idf is computed by the host.
-extern "C" int sa_index_bm25_phrase_dense(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop,
-                                          float idf, float k1, float b, float* out) {
+extern "C" int sa_index_bm25_phrase_dense_posn(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop,
+                                               int64_t min_posn, int64_t max_posn, float idf, float k1, float b,
+                                               float* out) {
     SA_ARG(ix && out && terms, "null argument");
     if (n_terms < 2) { sa_set_error("Must have at least two terms"); return SA_ERR_ARG; }
     SA_ARG(n_terms <= SA_MAX_PHRASE, "phrase too long (max 32 terms)");
     SA_ARG(slop >= 0, "slop < 0");
+    PosnFilter filt;
+    SA_TRY(sa_posn_filter_bounds(min_posn, max_posn, &filt));
     std::lock_guard<std::mutex> g(ix->mu);
     SA_HIP(hipSetDevice(ix->device));
     const u64 N = ix->n_docs;
@@ -490,12 +557,67 @@ extern "C" int sa_index_bm25_phrase_dense(sa_index_t* ix, const uint32_t* terms,
         return SA_OK;
     }
     float* d_running = nullptr;
-    if (slop == 0) SA_TRY(sa_phrase_counts_device(ix, terms, n_terms, sa_phrase_mode(), &d_running));
-    else SA_TRY(sa_span_counts_device(ix, terms, n_terms, slop, &d_running));
+    SA_TRY(sa_phrase_or_span(ix, terms, n_terms, slop, filt, &d_running));
     if (N) hipLaunchKernelGGL(sa_k_bm25_from_tf, dim3(sa_grid_for(N)), dim3(256), 0, ix->stream, d_running,
                               ix->d_doc_lens, ix->avg_doc_len, idf, k1, b, N);
     SA_HIP(hipMemcpyAsync(out, d_running, N * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
     SA_HIP(hipStreamSynchronize(ix->stream));
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+
+extern "C" int sa_index_bm25_phrase_dense(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop,
+                                          float idf, float k1, float b, float* out) {
+    return sa_index_bm25_phrase_dense_posn(ix, terms, n_terms, slop, -1, -1, idf, k1, b, out);
+}
+
+// single-term tf restricted to a position range: popcount-reduce over the filtered words
+// (reference PosnBitArray.termfreqs with min/max posn, middle_out.py:489-497) scattered dense.
+struct TfHeads {
+    const u64* words; const u32* n_dev; float* out;
+    __device__ __forceinline__ bool flag(u32 i) const { return i == 0 || (words[i] >> SA_KEY_SHIFT) != (words[i - 1] >> SA_KEY_SHIFT); }
+    __device__ __forceinline__ void emit(u32 i, u32) const {
+        const u32 n = *n_dev;
+        const u64 doc = words[i] >> SA_KEY_SHIFT;
+        u32 tf = 0;
+        for (u32 j = i; j < n && (words[j] >> SA_KEY_SHIFT) == doc; j++) tf += (u32)__popcll(words[j] & SA_LSB_MASK);
+        out[doc] = (float)tf;
+    }
+};
+
+extern "C" int sa_index_termfreqs_dense_posn(sa_index_t* ix, uint32_t term, int64_t min_posn, int64_t max_posn, float* out) {
+    SA_ARG(ix && out, "null argument");
+    PosnFilter filt;
+    SA_TRY(sa_posn_filter_bounds(min_posn, max_posn, &filt));
+    if (!filt.active) return sa_index_termfreqs_dense(ix, term, out);
+    std::lock_guard<std::mutex> g(ix->mu);
+    SA_HIP(hipSetDevice(ix->device));
+    hipStream_t st = ix->stream;
+    const u64 N = ix->n_docs;
+    u32 len = 0;
+    const u64* ptr = ix->d_words;
+    if (term < ix->n_terms) {
+        ptr = ix->d_words + ix->h_term_off[term];
+        len = (u32)(ix->h_term_off[term + 1] - ix->h_term_off[term]);
+    }
+    const size_t chunk_words = sa_compact_chunks(len + 1) + 8;
+    void* scratch;
+    SA_TRY(sa_index_scratch(ix, (N + 64) * 4 + ((size_t)len + 64) * 8 + chunk_words * 4 + 4096, &scratch));
+    Arena ar; ar.base = (char*)scratch; ar.cap = ix->scratch_bytes;
+    float* d_out = ar.take<float>(N + 1);
+    u64* buf = ar.take<u64>((size_t)len + 1);
+    u32* chunks = ar.take<u32>(chunk_words);
+    u32* cnt = ar.take<u32>(4);
+    SA_HIP(hipMemsetAsync(d_out, 0, N * sizeof(float), st));
+    SA_HIP(hipMemsetAsync(cnt, 0, 16, st));
+    if (len) {
+        PosnSlice ps; ps.arr = ptr; ps.lo = filt.lo; ps.hi = filt.hi; ps.out = buf;
+        sa_compact(ps, (const u32*)nullptr, len, chunks, cnt, st);
+        TfHeads th; th.words = buf; th.n_dev = cnt; th.out = d_out;
+        sa_compact(th, cnt, len, chunks, cnt + 1, st);
+    }
+    SA_HIP(hipMemcpyAsync(out, d_out, N * sizeof(float), hipMemcpyDeviceToHost, st));
+    SA_HIP(hipStreamSynchronize(st));
     SA_HIP(hipGetLastError());
     return SA_OK;
 }

@@ -224,7 +224,7 @@ sa_k_counts_to_float(const u32* __restrict__ counts, float* __restrict__ out, u6
 }
 
 // dense slop > 0 phrase counts of terms[0..T) -> *d_out (float[n_docs], inside the index scratch)
-int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, float** d_out) {
+int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const PosnFilter& filt, float** d_out) {
     if (T > SA_SPAN_MAX_TERMS) { sa_set_error("slop phrases support at most %d terms", SA_SPAN_MAX_TERMS); return SA_ERR_UNSUPPORTED; }
     hipStream_t st = ix->stream;
     const u64 N = ix->n_docs;
@@ -243,7 +243,8 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, float
     }
     const size_t slab_words = (size_t)SA_SPAN_CHUNK_DOCS * 5 * SA_NSPANS;
     const size_t chunk_words = sa_compact_chunks((u32)(max_len + 1)) + 8;
-    const size_t need = (N + 64) * 8 + (total_len + 64 * T) * 12 + slab_words * 8 + chunk_words * 4 + 64 * 1024;
+    const size_t filt_bytes = filt.active ? (total_len + 64 * (size_t)T) * 8 : 0;
+    const size_t need = (N + 64) * 8 + (total_len + 64 * T) * 12 + slab_words * 8 + chunk_words * 4 + filt_bytes + 64 * 1024;
     void* scratch;
     SA_TRY(sa_index_scratch(ix, need, &scratch));
     char* base = (char*)scratch;
@@ -259,6 +260,19 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, float
     SA_HIP(hipMemsetAsync(counts, 0, N * sizeof(u32), st));
     SA_HIP(hipMemsetAsync(cnt, 0, 4 * SA_SPAN_MAX_TERMS * 4, st));
     if (!known || N == 0 || total_len == 0) return SA_OK;
+    if (filt.active) {
+        const u64* ptrs[SA_SPAN_MAX_TERMS];
+        u64* bufs[SA_SPAN_MAX_TERMS];
+        u32 lens[SA_SPAN_MAX_TERMS];
+        for (int t = 0; t < T; t++) {
+            ptrs[t] = terms_dev.words[t]; lens[t] = terms_dev.len[t];
+            bufs[t] = (u64*)take(((size_t)lens[t] + 1) * 8);
+        }
+        if (used > need) { sa_set_error("internal: span scratch exhausted"); return SA_ERR_STATE; }
+        SA_TRY(sa_posn_filter_terms(ix, filt, T, ptrs, lens, bufs, cnt + 3 * SA_SPAN_MAX_TERMS, chunks));
+        SA_HIP(hipMemsetAsync(cnt, 0, 3 * SA_SPAN_MAX_TERMS * 4, st));
+        for (int t = 0; t < T; t++) { terms_dev.words[t] = ptrs[t]; terms_dev.len[t] = lens[t]; }
+    }
 
     hipLaunchKernelGGL(sa_k_span_wrap_flag, dim3(1), dim3(64), 0, st, terms_dev, cnt + 2 * SA_SPAN_MAX_TERMS);
     SpanMachineParams mp;

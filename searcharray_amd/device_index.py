@@ -88,10 +88,20 @@ class DeviceIndex:
         return df[term] if 0 <= term < self.n_terms else np.uint64(0)
 
     # -- term frequencies
-    def termfreqs_dense(self, term: int) -> np.ndarray:
+    @staticmethod
+    def _check_posn_range(min_posn, max_posn):
+        # reference roaringish.py:270-273
+        if min_posn is not None and min_posn % 18 != 0:
+            raise ValueError("min_payload must be a multiple of 18")
+        if max_posn is not None and max_posn % 18 != 17:
+            raise ValueError("max_payload must be a multiple of 18 - 1")
+        return (-1 if min_posn is None else int(min_posn)), (-1 if max_posn is None else int(max_posn))
+
+    def termfreqs_dense(self, term: int, min_posn: Optional[int] = None, max_posn: Optional[int] = None) -> np.ndarray:
+        lo, hi = self._check_posn_range(min_posn, max_posn)
         out = np.empty(self.n_docs, dtype=np.float32)
         t = term if 0 <= term < self.n_terms else NO_TERM
-        self.api.call("sa_index_termfreqs_dense", self._h, t, p_f32(out))
+        self.api.call("sa_index_termfreqs_dense_posn", self._h, t, lo, hi, p_f32(out))
         return out
 
     def termfreqs_sparse(self, term: int) -> Tuple[np.ndarray, np.ndarray]:
@@ -121,17 +131,21 @@ class DeviceIndex:
                       np.float32(k1), np.float32(b), p_f32(out))
         return out
 
-    def phrase_freqs_dense(self, terms: Sequence[int], slop: int = 0) -> np.ndarray:
-        """Exact phrase match counts, float32[n_docs] (reference PosnBitArray.phrase_freqs)."""
+    def phrase_freqs_dense(self, terms: Sequence[int], slop: int = 0, min_posn: Optional[int] = None,
+                           max_posn: Optional[int] = None) -> np.ndarray:
+        """Phrase match counts, float32[n_docs] (reference PosnBitArray.phrase_freqs): exact for
+        slop == 0, the reference's span search for slop > 0."""
         if len(terms) < 2:
             raise ValueError("Must have at least two terms")        # reference middle_out.py:425-426
+        lo, hi = self._check_posn_range(min_posn, max_posn)
         tarr = np.asarray([int(t) if 0 <= int(t) < self.n_terms else NO_TERM for t in terms], dtype=np.uint32)
         out = np.empty(self.n_docs, dtype=np.float32)
-        self.api.call("sa_index_phrase_freqs_dense", self._h, p_u32(tarr), len(tarr), int(slop), p_f32(out))
+        self.api.call("sa_index_phrase_freqs_dense_posn", self._h, p_u32(tarr), len(tarr), int(slop), lo, hi, p_f32(out))
         return out
 
     def bm25_phrase_dense(self, terms: Sequence[int], k1: float = 1.2, b: float = 0.75, slop: int = 0,
-                          idf: Optional[float] = None) -> np.ndarray:
+                          idf: Optional[float] = None, min_posn: Optional[int] = None,
+                          max_posn: Optional[int] = None) -> np.ndarray:
         """BM25 of a phrase: idf summed over the phrase's terms (reference postings.py:671-679)."""
         if len(terms) < 2:
             raise ValueError("Must have at least two terms")
@@ -139,8 +153,9 @@ class DeviceIndex:
         if idf is None:
             dfs = np.asarray([self.docfreq(int(t)) if 0 <= int(t) < self.n_terms else 0 for t in terms])
             idf = compute_idf(self.corpus_size, dfs)
+        lo, hi = self._check_posn_range(min_posn, max_posn)
         out = np.empty(self.n_docs, dtype=np.float32)
-        self.api.call("sa_index_bm25_phrase_dense", self._h, p_u32(tarr), len(tarr), int(slop),
+        self.api.call("sa_index_bm25_phrase_dense_posn", self._h, p_u32(tarr), len(tarr), int(slop), lo, hi,
                       np.float32(idf), np.float32(k1), np.float32(b), p_f32(out))
         return out
 

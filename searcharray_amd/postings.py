@@ -10,8 +10,7 @@ index core plus a row selection.
 Differences from the reference, by design:
   * a sliced / filtered array scores with corpus-wide document frequencies (the reference's
     filtered views use slice-local df with global corpus size -- SURVEY appendix A.6);
-  * ``min_posn`` / ``max_posn`` raise NotImplementedError instead of silently taking a CPU path
-    (there is no CPU fallback in this package).
+  * there is no CPU fallback: every query-time computation goes through the C ABI.
 """
 from __future__ import annotations
 
@@ -456,8 +455,6 @@ class SearchArray(ExtensionArray):
 
     @staticmethod
     def _check_posn_args(slop, min_posn, max_posn):
-        if min_posn is not None or max_posn is not None:
-            raise NotImplementedError("min_posn / max_posn are not implemented on the device path")
         if slop < 0:
             raise ValueError("slop must be >= 0")
 
@@ -477,11 +474,11 @@ class SearchArray(ExtensionArray):
         dev = self._core.device()
         if isinstance(token, list):
             ids = [self._term_id(t) for t in token]
-            return self._gather(dev.phrase_freqs_dense(ids, slop=slop))
+            return self._gather(dev.phrase_freqs_dense(ids, slop=slop, min_posn=min_posn, max_posn=max_posn))
         tid = self._term_id(token)
         if tid < 0:
             return np.zeros(len(self), dtype=np.float32)            # unknown term: zeros, never raises
-        return self._gather(dev.termfreqs_dense(tid))
+        return self._gather(dev.termfreqs_dense(tid, min_posn=min_posn, max_posn=max_posn))
 
     def docfreq(self, token: str) -> int:
         """reference postings.py:640-647."""
@@ -505,16 +502,20 @@ class SearchArray(ExtensionArray):
         dfs = np.asarray([self.docfreq(t) for t in tokens])
         if len(self._core.doc_lens) == 0:
             return np.zeros(len(self), dtype=np.float32)
-        if getattr(similarity, "kind", None) == "bm25":
+        posn_filter = min_posn is not None or max_posn is not None
+        if getattr(similarity, "kind", None) == "bm25" and not (posn_filter and len(tokens) == 1):
             dev = self._core.device()
             idf = np.float32(compute_idf(self.corpus_size, dfs))
             ids = [self._term_id(t) for t in tokens]
             if len(ids) == 1:
                 dense = dev.bm25_dense(ids, k1=similarity.k1, b=similarity.b, idf=np.asarray([idf], np.float32))
             else:
-                dense = dev.bm25_phrase_dense(ids, k1=similarity.k1, b=similarity.b, slop=slop, idf=idf)
+                dense = dev.bm25_phrase_dense(ids, k1=similarity.k1, b=similarity.b, slop=slop, idf=idf,
+                                              min_posn=min_posn, max_posn=max_posn)
             return self._gather(dense)
-        tfs = self.termfreqs(token, slop=slop)
+        # any other Similarity (or a position-restricted single term): tf on the device, then the
+        # similarity callable (the stock BM25 closure applies the BM25 kernel through the C ABI)
+        tfs = self.termfreqs(token, slop=slop, min_posn=min_posn, max_posn=max_posn)
         return similarity(tfs, dfs, self.doc_lens, self.avg_doc_length, self.corpus_size)
 
     def positions(self, token: str, key=None) -> List[np.ndarray]:

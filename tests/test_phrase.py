@@ -156,3 +156,19 @@ def test_slop_random_differential(api, seed):
         got = dev.phrase_freqs_dense(terms, slop=slop)
         if overflow == 0:
             assert np.array_equal(got, want), f"seed {seed} terms {terms} slop {slop}: {np.flatnonzero(got != want)[:5]}"
+
+
+@pytest.mark.parametrize("min_posn,max_posn", [(0, 17), (18, None), (0, 35), (18, 53), (None, 17)])
+def test_posn_range_matches_oracle(api, min_posn, max_posn):
+    """min_posn / max_posn restriction (reference roaringish.py:266-282 incl. its unshifted-msb
+    comparison) on exact phrases, same-term phrases and slop, device vs oracle"""
+    g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_small")
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    orc = O.OracleIndex.from_triples(t, d, p, num_docs, doc_lens=lens)
+    for terms, slop in (([0, 1], 0), ([3, 0, 2], 0), ([0, 0], 0), ([1, 0, 0, 2], 0), ([5, 4, 0, 2, 1], 0), ([3, 7], 2)):
+        want = orc.phrase_freqs(terms, slop=slop, min_posn=min_posn, max_posn=max_posn)
+        got = dev.phrase_freqs_dense(terms, slop=slop, min_posn=min_posn, max_posn=max_posn)
+        assert np.array_equal(got, want), (terms, slop, min_posn, max_posn)
+    ids, tfs = O.popcount64_reduce(orc.posn_slice(orc.enc(0), min_posn, max_posn), 36, 0x3FFFF)
+    assert np.array_equal(dev.termfreqs_dense(0, min_posn=min_posn, max_posn=max_posn), O.as_dense(ids, tfs, num_docs))

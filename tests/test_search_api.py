@@ -132,9 +132,36 @@ def test_phrase_too_many_posns(default_api):
     assert (arr.termfreqs(["foo", "bar", "baz"]) == [1, 0]).all()
 
 
-def test_unsupported_options_fail_loudly(data):
-    with pytest.raises(NotImplementedError):
-        data.score("foo", min_posn=0, max_posn=17)
+MINMAX_DOCS = ["foo bar bar baz" + " ".join(["boz"] * 25) + " foo bar", "data2", "data3 bar", "bunny funny wunny"] * 25
+
+
+@pytest.mark.parametrize("phrase,min_posn,max_posn,expected", [
+    (["foo", "bar"], 0, 17, [1, 0, 0, 0] * 25),
+    (["foo", "bar"], 0, None, [2, 0, 0, 0] * 25),
+    (["foo", "bar"], 18, None, [1, 0, 0, 0] * 25),
+])
+def test_min_max_posn(default_api, phrase, min_posn, max_posn, expected):
+    """reference test/test_minmax_posns.py:5-52 (known answers)"""
+    arr = SearchArray.index(MINMAX_DOCS)
+    before = arr.copy()
+    assert (arr.termfreqs(phrase, min_posn=min_posn, max_posn=max_posn) == expected).all()
+    assert (arr == before).all()
+    scores = arr.score(phrase, min_posn=min_posn, max_posn=max_posn)
+    assert ((scores > 0) == (np.asarray(expected) > 0)).all()
+
+
+def test_min_max_posn_same_term_and_single_term(default_api):
+    docs = ["foo foo baz baz" + " ".join(["boz"] * 25) + " foo foo", "data2", "data3 bar", "bunny funny wunny"] * 25
+    arr = SearchArray.index(docs)
+    assert (arr.termfreqs(["foo", "foo"], min_posn=0, max_posn=17) == [1, 0, 0, 0] * 25).all()     # test_minmax_posns.py:35-43
+    assert (arr.termfreqs("foo", min_posn=0, max_posn=17) == [2, 0, 0, 0] * 25).all()
+    assert (arr.termfreqs("foo", min_posn=18) == [2, 0, 0, 0] * 25).all()
+    assert (arr.termfreqs("foo") == [4, 0, 0, 0] * 25).all()
+    assert ((arr.score("foo", min_posn=0, max_posn=17) > 0) == [True, False, False, False] * 25).all()
+    with pytest.raises(ValueError):
+        arr.termfreqs(["foo", "foo"], min_posn=5)
+    with pytest.raises(ValueError):
+        arr.termfreqs("foo", max_posn=18)
 
 
 def test_threaded_scoring_is_deterministic(data):
