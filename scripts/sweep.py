@@ -52,11 +52,11 @@ def main():
         build_s = time.time() - t0
         for k in [int(x) for x in args.ks.split(",")]:
             batch = QueryBatch(index, queries, k=k)
-            modes = [(0, 1, 0, "0"), (0, 1, 1, "0")] if k <= 32 else [(0, 0, 0, "1")]
+            modes = [(0, 1, 0, "0"), (0, 0, 0, "0")] if k > 32 else [(0, 1, 0, "0"), (0, 1, 1, "0")]
             for xcd, argmax, notopk, kf in modes:
                 os.environ["SA_PERSISTENT"] = kf
                 os.environ["SA_XCD_MODE"] = str(xcd)
-                os.environ["SA_SMALLK_ARGMAX"] = str(argmax)
+                os.environ["SA_PRUNED_TOPK"] = str(argmax)
                 os.environ["SA_NO_TOPK"] = str(notopk)
                 for _ in range(2):
                     batch.run(sync=False)

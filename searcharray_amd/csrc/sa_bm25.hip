@@ -250,14 +250,15 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
     if (p.cand && !p.no_topk) {
     if constexpr (MODE == 1) {
         do {
-        // k <= 32: PRUNED selection.  Per query, 32 global slots hold the best score seen by 32
-        // disjoint families of waves (slot = wave index mod 32), so G = min(slots) is a score that
-        // at least 32 distinct docs reach: nothing below G can enter the top-k.  A wave whose
-        // maximum is below G (almost every wave once the first tiles have run) is done after one
-        // DPP reduction.  Otherwise it appends its elements >= G -- all of them when there are at
-        // most k, else its exact top-k by k rounds of a wave-wide arg-max -- to the query's
-        // candidate list.  Stale slot reads only weaken the pruning (slots grow monotonically);
-        // the final top-k is exact and deterministic.
+        // PRUNED selection.  Per query, 32 global slots each hold a score that `rr = ceil(k/32)`
+        // distinct docs of ONE wave reach (the rr-th largest per-lane maximum of that wave), taken
+        // over 32 disjoint families of waves (slot = wave index mod 32).  So G = min(slots) is a
+        // score at least 32 * rr >= k distinct docs reach: nothing below G can enter the top-k.
+        // A wave whose maximum is below G (almost every wave once the first tiles have run) is
+        // done after one DPP reduction.  Otherwise it appends its elements >= G -- all of them when
+        // there are at most k, else its exact top-k by k rounds of a wave-wide arg-max -- to the
+        // query's candidate list.  Stale slot reads only weaken the pruning (slots grow
+        // monotonically); the final top-k is exact and deterministic.
         const u32 lane = tid & (SA_WAVE - 1), wave = tid / SA_WAVE;
         u32 lmax = 0;
 #pragma unroll
@@ -271,7 +272,22 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
         if (wmax < thr) break;                                    // wave-uniform
 #define SA_ELEM(j) ((u32)(j) * THREADS + tid)
         const u32 widx = tile * NW + wave;
-        if (lane == 0) atomicMax(&p.slots[q * 32u + (widx & 31u)], wmax);
+        {
+            // slot update: the rr-th largest lane maximum (lanes counted individually)
+            const u32 my_slot = (u32)__shfl((int)slot_val, (int)(widx & 31u), SA_WAVE);
+            if (wmax > my_slot) {                                 // wave-uniform
+                const u32 rr = (k + 31u) / 32u;
+                u32 v = lmax, cnt = 0, mr = 0;
+                for (u32 it = 0; it < rr; it++) {
+                    const u32 m = it == 0 ? wmax : sa_wave_max_u32(v);
+                    if (m == 0) break;
+                    cnt += (u32)__popcll(__ballot(v == m));
+                    if (cnt >= rr) { mr = m; break; }
+                    v = (v == m) ? 0u : v;
+                }
+                if (lane == 0 && mr > my_slot) atomicMax(&p.slots[q * 32u + (widx & 31u)], mr);
+            }
+        }
         u64* qcand = p.cand + (u64)q * p.cand_cap;
         const u64 lt = (1ull << lane) - 1ull;
         u32 c = 0;
@@ -300,6 +316,9 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
         // more than k survivors (first tiles of a query, or heavy ties): exact top-k of this wave.
         // Each lane tracks its best and second best element in registers (branch-free); the tile
         // is rescanned only when one lane wins twice in a row of promotions.
+        u32 cbase = 0;
+        if (lane == 0) cbase = atomicAdd(&p.cand_cnt[q], k);
+        cbase = (u32)__builtin_amdgcn_readfirstlane((int)cbase);
         u32 b1k, b1j, b2k, b2j;
 #define SA_RESCAN()                                                                   \
         do {                                                                          \
@@ -314,30 +333,27 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
         } while (0)
         SA_RESCAN();
         bool stale = false;                         // true: b2 already promoted, next best unknown
-        u64 mine_out = 0;
         u32 found = 0;
         for (u32 r = 0; r < k; r++) {
             const u32 m = sa_wave_max_u32(b1k);
             if (m == 0) break;                       // wave-uniform
             const u32 e1 = (b1k == m) ? SA_ELEM(b1j) : 0xFFFFFFFFu;
             const u32 emin = sa_wave_min_u32(e1);    // ties -> smallest doc id
-            if (lane == r) mine_out = ((u64)m << 32) | (u64)emin;
             found = r + 1;
             const bool owner = (e1 == emin);
-            if (owner) acc[emin] = 0.f;
+            if (owner) {
+                acc[emin] = 0.f;
+                const u64 doc = p.doc_base + tile_base + emin;
+                if (cbase + r < p.cand_cap) qcand[cbase + r] = ((u64)m << 32) | (u64)(u32)(~(u32)doc);
+            }
             const bool need = owner && stale;
             if (owner && !stale) { b1k = b2k; b1j = b2j; b2k = 0; stale = true; }
             if (__any(need)) { SA_RESCAN(); stale = false; }
         }
 #undef SA_RESCAN
-        u32 base = 0;
-        if (lane == 0) base = atomicAdd(&p.cand_cnt[q], found);
-        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-        if (lane < found && base + lane < p.cand_cap) {
-            const u64 doc = p.doc_base + tile_base + (u32)(mine_out & 0xFFFFFFFFull);
-            qcand[base + lane] = (mine_out & 0xFFFFFFFF00000000ull) | (u64)(u32)(~(u32)doc);
-        }
 #undef SA_ELEM
+        for (u32 r = found + lane; r < k; r += SA_WAVE)           // unused reserved slots
+            if (cbase + r < p.cand_cap) qcand[cbase + r] = 0ull;
         } while (0);
     } else {
     // 4. per-tile top-k -> composite keys  score_bits<<32 | ~global_doc
@@ -568,6 +584,8 @@ struct sa_batch {
     u32 tab_w = 0;
     u32* d_bounds = nullptr;        // [B][T][n_tiles+1] slice table
     u64* d_qbase = nullptr;         // [B][T]
+    u32 cand_cap = 0;               // keys per query in d_cand
+    bool cap_limited = false;       // cand_cap below the worst case: overflow must be checked
     u32* d_cand_cnt = nullptr;      // [B] append cursors (pruned selection)
     u32* d_slots = nullptr;         // [B][32] pruning slots
     u64* d_local = nullptr;         // [B][k] per-shard result
@@ -766,7 +784,16 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
     SA_HIP_B(hipMalloc(&bt->d_idf, h_idf.size() * sizeof(float)));
     SA_HIP_B(hipMalloc(&bt->d_perm, (size_t)B * sizeof(u32)));
     SA_HIP_B(hipMemcpy(bt->d_perm, bt->perm.data(), (size_t)B * sizeof(u32), hipMemcpyHostToDevice));
-    const size_t ncand = (size_t)B * (ix->n_tiles ? ix->n_tiles : 1) * bt->k * sa_tile_waves(ix->tile_docs);
+    // candidate storage per query: worst case every wave appends k keys; capped at 1 Mi keys per
+    // query (8 MiB) -- with the cap an overflow is theoretically possible and is detected at run
+    // time (sa_batch_run_shard re-runs the batch with the unpruned block-level selection).
+    const u64 worst = (u64)(ix->n_tiles ? ix->n_tiles : 1) * bt->k * sa_tile_waves(ix->tile_docs);
+    const u64 mode0 = (u64)(ix->n_tiles ? ix->n_tiles : 1) * bt->k;
+    u64 cap = worst < (1ull << 20) ? worst : (1ull << 20);
+    if (cap < mode0) cap = mode0;                      // the unpruned layout [n_tiles][k] must fit too
+    bt->cand_cap = (u32)cap;
+    bt->cap_limited = cap < worst;
+    const size_t ncand = (size_t)B * cap;
     SA_HIP_B(hipMalloc(&bt->d_cand, ncand * sizeof(u64)));
     SA_HIP_B(hipMalloc(&bt->d_cand_cnt, (size_t)B * sizeof(u32)));
     SA_HIP_B(hipMalloc(&bt->d_slots, (size_t)B * 32 * sizeof(u32)));
@@ -817,11 +844,11 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out) {
     p.k1 = bt->k1; p.b = bt->b;
     p.bounds = bt->d_bounds; p.qbase = bt->d_qbase;
     p.sattab = bt->d_sattab; p.tab_w = bt->tab_w;
-    p.small_k_argmax = (bt->k <= 32 && sa_env_int("SA_SMALLK_ARGMAX", 1)) ? 1 : 0;
+    p.small_k_argmax = sa_env_int("SA_PRUNED_TOPK", 1) ? 1 : 0;   // pruned wave-level selection (any k <= 1024)
     p.dense_out = nullptr; p.cand = bt->d_cand;
     p.no_topk = sa_env_int("SA_NO_TOPK", 0);
     p.cand_per_tile = bt->k;
-    p.cand_cap = (ix->n_tiles ? ix->n_tiles : 1) * bt->k * sa_tile_waves(ix->tile_docs);
+    p.cand_cap = bt->cand_cap;
     p.cand_cnt = bt->d_cand_cnt;
     p.slots = bt->d_slots;
     if (p.small_k_argmax) {
@@ -837,6 +864,19 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out) {
     }
     SA_HIP(hipEventRecord(bt->ev1[slot], st));
     bt->ev_n++;
+    if (p.small_k_argmax && bt->cap_limited && ix->n_tiles > 0) {
+        // the candidate lists are smaller than the worst case: make sure no query ran over
+        std::vector<u32> h_cnt(bt->B);
+        SA_HIP(hipMemcpyAsync(h_cnt.data(), bt->d_cand_cnt, (size_t)bt->B * sizeof(u32), hipMemcpyDeviceToHost, st));
+        SA_HIP(hipStreamSynchronize(st));
+        bool over = false;
+        for (u32 i = 0; i < bt->B; i++) over |= h_cnt[i] > bt->cand_cap;
+        if (over) {
+            p.small_k_argmax = 0;
+            p.cand_per_tile = bt->k;
+            SA_TRY(sa_launch_bm25(ix, p, st));
+        }
+    }
     const u32 n_cand = p.small_k_argmax ? p.cand_cap : (ix->n_tiles ? ix->n_tiles : 1) * p.cand_per_tile;
     hipLaunchKernelGGL(sa_k_topk_merge, dim3(bt->B), dim3(1024), 0, st, bt->d_cand, n_cand, bt->k, shard_out,
                        (const u32*)bt->d_perm, 0u, (const u32*)(p.small_k_argmax ? bt->d_cand_cnt : nullptr));

@@ -225,3 +225,20 @@ def test_rccl_exchange_single_rank():
     finally:
         dev.comm_destroy()
     plain.close()
+
+
+@pytest.mark.parametrize("k", [10, 100])
+def test_unpruned_block_selection_path(small, k, monkeypatch):
+    """SA_PRUNED_TOPK=0 forces the block-level threshold selection (the overflow fallback of the
+    pruned path): same exact results."""
+    monkeypatch.setenv("SA_PRUNED_TOPK", "0")
+    g, dev, orc, vocab = small
+    queries = g["or_queries"][:4]
+    bt = dev.batch(queries, k=k)
+    bt.run()
+    scores, docs = bt.fetch()
+    for qi, q in enumerate(queries):
+        ws, wd = O.topk(orc.score_terms_sum([int(t) for t in q]), k)
+        n = int((ws > 0).sum())
+        assert np.array_equal(scores[qi, :n], ws[:n]) and np.array_equal(docs[qi, :n], wd[:n])
+    bt.close()
