@@ -476,23 +476,27 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
 // Merge n_cand candidate keys per query into the k best, sorted descending.
 // One workgroup of 1024 threads per query.
 //
-// rank_stride > 0: the candidates come in groups of rank_stride keys sorted by rank (a wave's
-// arg-max output, or a rank's sorted top-k), so the k-th largest GROUP LEADER is a lower bound G
-// of the k-th largest key overall (k distinct groups own a key >= G).  One pass then keeps only
-// keys >= G -- a few dozen -- in LDS and a bitonic sort finishes.  If the survivors overflow the
-// LDS list (pathological ties), or rank_stride == 0, the k-th largest is found by MSB-first
-// bisection over the whole candidate array instead.
+// Small rows (<= SA_MERGE_LIST keys: a cross-rank merge, or a well-pruned append list) go straight
+// into LDS and a bitonic sort finishes.  Larger rows are first cut by a lower bound of the k-th
+// largest key that is already known:
+//   slots != null      the pruning slots the tile kernel left behind (>= k docs score >= min slot)
+//   rank_stride > 0    rows made of sorted groups of rank_stride keys: the k-th largest GROUP
+//                      LEADER bounds the k-th largest key (k distinct groups own a key >= it)
+// One pass keeps the keys above the bound in LDS.  If they overflow the LDS list (large k, ties)
+// the survivors are compacted in place at the front of the row and the exact k-th largest is
+// found by MSB-first bisection over the survivors only.
 #define SA_MERGE_LIST 2048
 
 __global__ void __launch_bounds__(1024)
-sa_k_topk_merge(const u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__ out,
-                const u32* __restrict__ out_row, u32 rank_stride, const u32* __restrict__ cnt) {
+sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__ out,
+                const u32* __restrict__ out_row, u32 rank_stride, const u32* __restrict__ cnt,
+                const u32* __restrict__ slots) {
     constexpr int NW = 1024 / SA_WAVE;
     __shared__ u64 red64[NW + 1];
     __shared__ u64 sel[SA_MERGE_LIST];
     __shared__ u32 s_n;
     const u32 q = blockIdx.x, tid = threadIdx.x;
-    const u64* c = cand + (u64)q * n_cand_max;
+    u64* c = cand + (u64)q * n_cand_max;
     // cnt != null: the row is an append list holding cnt[q] keys (pruned tile selection)
     u32 n_cand = n_cand_max;
     if (cnt) { const u32 have = cnt[q]; n_cand = have < n_cand_max ? have : n_cand_max; }
@@ -532,17 +536,52 @@ sa_k_topk_merge(const u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __rest
     };
 
     u64 thr = 1;
-    bool exact = false;                               // thr is the exact k-th largest key
-    if (rank_stride > 0 && n_cand / rank_stride >= k) {
-        const u64 g = kth_largest(n_cand / rank_stride, rank_stride);
-        thr = g > 1 ? g : 1;
-    } else if (n_cand > SA_MERGE_LIST) {
-        const u64 g = kth_largest(n_cand, 1);
-        thr = g > 1 ? g : 1;
-        exact = true;
+    if (n_cand > SA_MERGE_LIST) {
+        if (slots) {
+            u32 g = slots[(u64)q * 32 + (tid & 31)];
+            g = sa_wave_min_u32(g);                   // every wave computes the same minimum
+            thr = (u64)g << 32;
+        } else if (rank_stride > 0 && n_cand / rank_stride >= k) {
+            thr = kth_largest(n_cand / rank_stride, rank_stride);
+        }
+        if (thr < 1) thr = 1;
     }
-    for (int attempt = 0; attempt < 2; attempt++) {
-        for (u32 i = tid; i < n_cand; i += 1024) {
+    for (u32 i = tid; i < n_cand; i += 1024) {
+        const u64 x = c[i];
+        if (x >= thr) {
+            const u32 pos = atomicAdd(&s_n, 1u);
+            if (pos < SA_MERGE_LIST) sel[pos] = x;
+        }
+    }
+    __syncthreads();
+    u32 n_sel = s_n;
+    __syncthreads();
+    if (n_sel > SA_MERGE_LIST) {                      // uniform
+        // compact the survivors to the front of the row (a chunk's writes land below its own
+        // end: at most as many survivors as keys read so far), then bisect over them only
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        for (u32 base = 0; base < n_cand; base += 4096) {
+            u64 x[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32 i = base + j * 1024 + tid;
+                x[j] = i < n_cand ? c[i] : 0ull;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (x[j] >= thr) c[atomicAdd(&s_n, 1u)] = x[j];
+        }
+        __syncthreads();
+        const u32 n_surv = s_n;
+        __syncthreads();
+        const u64 g = kth_largest(n_surv, 1);         // exact: keys are distinct, so exactly k keys are >= g
+        thr = g > 1 ? g : 1;
+        for (u32 i = tid; i < SA_MERGE_LIST; i += 1024) sel[i] = 0;
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        for (u32 i = tid; i < n_surv; i += 1024) {
             const u64 x = c[i];
             if (x >= thr) {
                 const u32 pos = atomicAdd(&s_n, 1u);
@@ -550,18 +589,9 @@ sa_k_topk_merge(const u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __rest
             }
         }
         __syncthreads();
-        const u32 n_sel = s_n;
-        __syncthreads();
-        if (n_sel <= SA_MERGE_LIST || exact) break;   // uniform
-        // survivors overflowed the list: fall back to the exact threshold and gather again
-        for (u32 i = tid; i < SA_MERGE_LIST; i += 1024) sel[i] = 0;
-        if (tid == 0) s_n = 0;
-        const u64 g = kth_largest(n_cand, 1);
-        thr = g > 1 ? g : 1;
-        exact = true;
-        __syncthreads();
+        n_sel = s_n;
     }
-    u32 n_sel = s_n < SA_MERGE_LIST ? s_n : SA_MERGE_LIST;
+    n_sel = n_sel < SA_MERGE_LIST ? n_sel : SA_MERGE_LIST;
     u32 np2 = 2;
     while (np2 < n_sel) np2 <<= 1;
     sa_block_bitonic_desc(sel, np2);
@@ -589,7 +619,13 @@ struct sa_batch {
     u32* d_cand_cnt = nullptr;      // [B] append cursors (pruned selection)
     u32* d_slots = nullptr;         // [B][32] pruning slots
     u64* d_local = nullptr;         // [B][k] per-shard result
-    u64* d_gather = nullptr;        // [nranks][B][k] (multi-GPU)
+    u64* d_gather = nullptr;        // [2][nranks][B][k] (multi-GPU, double-buffered like d_xlocal)
+    u64* d_xlocal = nullptr;        // [2][B][k] per-shard results handed to the exchange stream
+    hipEvent_t ev_scored[2] = {nullptr, nullptr};     // d_xlocal[b] written (index stream)
+    hipEvent_t ev_exchanged[2] = {nullptr, nullptr};  // d_xlocal[b] / d_gather[b] consumed (exchange stream)
+    bool exchanged_valid[2] = {false, false};
+    u32 xstep = 0;
+    int gather_ranks = 0;
     u64* d_final = nullptr;         // [B][k]
     u64* d_xcand = nullptr;         // [B][nranks*k] regrouped gather
     int xcand_ranks = 0;
@@ -599,7 +635,8 @@ struct sa_batch {
     bool ran = false;
 };
 
-int sa_comm_allgather_topk(sa_index* ix, const u64* d_local, u64* d_gather, size_t count, int* nranks_out);
+int sa_comm_allgather_topk(sa_index* ix, const u64* d_local, u64* d_gather, size_t count, int* nranks_out,
+                           hipStream_t st);
 
 
 static void sa_fill_params(const sa_index* ix, Bm25Params& p) {
@@ -718,18 +755,26 @@ extern "C" int sa_index_bm25_dense(sa_index_t* ix, const uint32_t* terms, const 
 
 static void sa_batch_free(sa_batch* bt) {
     if (!bt) return;
-    if (bt->ix) hipSetDevice(bt->ix->device);
+    if (bt->ix) {
+        hipSetDevice(bt->ix->device);
+        hipStreamSynchronize(bt->ix->stream);
+        if (bt->ix->xstream) hipStreamSynchronize(bt->ix->xstream);
+    }
     if (bt->d_terms) hipFree(bt->d_terms);
     if (bt->d_perm) hipFree(bt->d_perm);
     if (bt->d_idf) hipFree(bt->d_idf);
     if (bt->d_cand) hipFree(bt->d_cand);
-    if (bt->d_cand_cnt) hipFree(bt->d_cand_cnt);
     if (bt->d_bounds) hipFree(bt->d_bounds);
     if (bt->d_sattab) hipFree(bt->d_sattab);
     if (bt->d_qbase) hipFree(bt->d_qbase);
     if (bt->d_slots) hipFree(bt->d_slots);
     if (bt->d_local) hipFree(bt->d_local);
     if (bt->d_gather) hipFree(bt->d_gather);
+    if (bt->d_xlocal) hipFree(bt->d_xlocal);
+    for (int i = 0; i < 2; i++) {
+        if (bt->ev_scored[i]) hipEventDestroy(bt->ev_scored[i]);
+        if (bt->ev_exchanged[i]) hipEventDestroy(bt->ev_exchanged[i]);
+    }
     if (bt->d_final) hipFree(bt->d_final);
     if (bt->d_xcand) hipFree(bt->d_xcand);
     for (hipEvent_t e : bt->ev0) hipEventDestroy(e);
@@ -795,8 +840,8 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
     bt->cap_limited = cap < worst;
     const size_t ncand = (size_t)B * cap;
     SA_HIP_B(hipMalloc(&bt->d_cand, ncand * sizeof(u64)));
-    SA_HIP_B(hipMalloc(&bt->d_cand_cnt, (size_t)B * sizeof(u32)));
-    SA_HIP_B(hipMalloc(&bt->d_slots, (size_t)B * 32 * sizeof(u32)));
+    SA_HIP_B(hipMalloc(&bt->d_slots, (size_t)B * 33 * sizeof(u32)));   // slots + cursors: one memset per run
+    bt->d_cand_cnt = bt->d_slots + (size_t)B * 32;
     SA_HIP_B(hipMalloc(&bt->d_local, (size_t)B * bt->k * sizeof(u64)));
     SA_HIP_B(hipMalloc(&bt->d_final, (size_t)B * bt->k * sizeof(u64)));
     SA_HIP_B(hipMemset(bt->d_final, 0, (size_t)B * bt->k * sizeof(u64)));
@@ -852,8 +897,7 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out) {
     p.cand_cnt = bt->d_cand_cnt;
     p.slots = bt->d_slots;
     if (p.small_k_argmax) {
-        SA_HIP(hipMemsetAsync(bt->d_cand_cnt, 0, (size_t)bt->B * sizeof(u32), st));
-        SA_HIP(hipMemsetAsync(bt->d_slots, 0, (size_t)bt->B * 32 * sizeof(u32), st));
+        SA_HIP(hipMemsetAsync(bt->d_slots, 0, (size_t)bt->B * 33 * sizeof(u32), st));   // slots + cursors
     }
     const u32 slot = bt->ev_n % SA_EVENT_RING;
     SA_HIP(hipEventRecord(bt->ev0[slot], st));
@@ -879,15 +923,14 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out) {
     }
     const u32 n_cand = p.small_k_argmax ? p.cand_cap : (ix->n_tiles ? ix->n_tiles : 1) * p.cand_per_tile;
     hipLaunchKernelGGL(sa_k_topk_merge, dim3(bt->B), dim3(1024), 0, st, bt->d_cand, n_cand, bt->k, shard_out,
-                       (const u32*)bt->d_perm, 0u, (const u32*)(p.small_k_argmax ? bt->d_cand_cnt : nullptr));
+                       (const u32*)bt->d_perm, 0u, (const u32*)(p.small_k_argmax ? bt->d_cand_cnt : nullptr),
+                       (const u32*)(p.small_k_argmax ? bt->d_slots : nullptr));
     bt->ran = true;
     return SA_OK;
 }
 
 // stage 3: merge the per-rank top-k lists [nranks][B][k] (device memory) into d_final
-static int sa_batch_merge_ranks(sa_batch* bt, const u64* d_gathered, int nranks) {
-    sa_index* ix = bt->ix;
-    hipStream_t st = ix->stream;
+static int sa_batch_merge_ranks(sa_batch* bt, const u64* d_gathered, int nranks, hipStream_t st) {
     const size_t count = (size_t)bt->B * bt->k;
     if (!bt->d_xcand || bt->xcand_ranks < nranks) {
         if (bt->d_xcand) SA_HIP(hipFree(bt->d_xcand));
@@ -900,7 +943,7 @@ static int sa_batch_merge_ranks(sa_batch* bt, const u64* d_gathered, int nranks)
     hipLaunchKernelGGL(sa_k_regroup, dim3(grid), dim3(256), 0, st, d_gathered, (u32)nranks, bt->B, bt->k, bt->d_xcand);
     // every rank's block is its sorted top-k: group leaders = rank maxima
     hipLaunchKernelGGL(sa_k_topk_merge, dim3(bt->B), dim3(1024), 0, st, bt->d_xcand, (u32)nranks * bt->k, bt->k, bt->d_final,
-                       (const u32*)nullptr, bt->k, (const u32*)nullptr);
+                       (const u32*)nullptr, bt->k, (const u32*)nullptr, (const u32*)nullptr);
     return SA_OK;
 }
 
@@ -911,13 +954,41 @@ extern "C" int sa_batch_run(sa_batch_t* bt, int sync) {
     SA_HIP(hipSetDevice(ix->device));
     hipStream_t st = ix->stream;
     if (ix->comm) {
-        SA_TRY(sa_batch_run_shard(bt, bt->d_local));
+        // Scoring runs on the index stream; the all-gather of the per-shard top-k and the
+        // cross-rank merge run on the exchange stream, double-buffered, so they overlap the next
+        // run's scoring kernels (the exchange is latency-bound: B*k*8 bytes per rank).
         int nranks = 1;
         const size_t count = (size_t)bt->B * bt->k;
-        SA_TRY(sa_comm_allgather_topk(ix, nullptr, nullptr, 0, &nranks));
-        if (!bt->d_gather) SA_HIP(hipMalloc(&bt->d_gather, (size_t)nranks * count * sizeof(u64)));
-        SA_TRY(sa_comm_allgather_topk(ix, bt->d_local, bt->d_gather, count, &nranks));
-        SA_TRY(sa_batch_merge_ranks(bt, bt->d_gather, nranks));
+        hipStream_t xs = ix->xstream;
+        SA_TRY(sa_comm_allgather_topk(ix, nullptr, nullptr, 0, &nranks, xs));
+        if (!bt->d_xlocal) {
+            SA_HIP(hipMalloc(&bt->d_xlocal, 2 * count * sizeof(u64)));
+            for (int i = 0; i < 2; i++) {
+                SA_HIP(hipEventCreateWithFlags(&bt->ev_scored[i], hipEventDisableTiming));
+                SA_HIP(hipEventCreateWithFlags(&bt->ev_exchanged[i], hipEventDisableTiming));
+            }
+        }
+        if (!bt->d_gather || bt->gather_ranks < nranks) {
+            SA_HIP(hipStreamSynchronize(xs));
+            if (bt->d_gather) SA_HIP(hipFree(bt->d_gather));
+            bt->d_gather = nullptr;
+            SA_HIP(hipMalloc(&bt->d_gather, 2 * (size_t)nranks * count * sizeof(u64)));
+            bt->gather_ranks = nranks;
+        }
+        if (!bt->d_xcand || bt->xcand_ranks < nranks) SA_HIP(hipStreamSynchronize(xs));   // merge_ranks reallocates
+        const u32 bsel = bt->xstep & 1;
+        bt->xstep++;
+        u64* xl = bt->d_xlocal + bsel * count;
+        u64* xg = bt->d_gather + bsel * (size_t)nranks * count;
+        if (bt->exchanged_valid[bsel]) SA_HIP(hipStreamWaitEvent(st, bt->ev_exchanged[bsel], 0));
+        SA_TRY(sa_batch_run_shard(bt, xl));
+        SA_HIP(hipEventRecord(bt->ev_scored[bsel], st));
+        SA_HIP(hipStreamWaitEvent(xs, bt->ev_scored[bsel], 0));
+        SA_TRY(sa_comm_allgather_topk(ix, xl, xg, count, &nranks, xs));
+        SA_TRY(sa_batch_merge_ranks(bt, xg, nranks, xs));
+        SA_HIP(hipEventRecord(bt->ev_exchanged[bsel], xs));
+        bt->exchanged_valid[bsel] = true;
+        if (sync) SA_HIP(hipStreamSynchronize(xs));
     } else {
         SA_TRY(sa_batch_run_shard(bt, bt->d_final));
     }
@@ -952,7 +1023,7 @@ extern "C" int sa_batch_merge_gathered(sa_batch_t* bt, const void* gathered_keys
     sa_index* ix = bt->ix;
     std::lock_guard<std::mutex> g(ix->mu);
     SA_HIP(hipSetDevice(ix->device));
-    SA_TRY(sa_batch_merge_ranks(bt, (const u64*)gathered_keys_device, nranks));
+    SA_TRY(sa_batch_merge_ranks(bt, (const u64*)gathered_keys_device, nranks, ix->stream));
     if (sync) {
         SA_HIP(hipStreamSynchronize(ix->stream));
         SA_HIP(hipGetLastError());
@@ -968,6 +1039,7 @@ extern "C" int sa_batch_fetch(sa_batch_t* bt, float* scores_out, uint64_t* docs_
     const size_t n = (size_t)bt->B * bt->k;
     std::vector<u64> keys(n);
     SA_HIP(hipStreamSynchronize(ix->stream));
+    if (ix->xstream) SA_HIP(hipStreamSynchronize(ix->xstream));
     SA_HIP(hipGetLastError());
     SA_HIP(hipMemcpy(keys.data(), bt->d_final, n * sizeof(u64), hipMemcpyDeviceToHost));
     for (u32 r = 0; r < bt->B; r++) {

@@ -4,7 +4,8 @@
 // independent, so GPU g scores its doc range with GLOBAL statistics and the only data-path
 // collective is one all-gather of the per-shard top-k keys (B * k * 8 bytes per rank -- 20 KiB for
 // B = 256, k = 10), followed by a local k-way merge on every rank.  Latency-bound on xGMI, so one
-// collective per query BATCH, enqueued on the index stream behind the scoring kernels.
+// collective per query BATCH, enqueued on the index's exchange stream so it (and the cross-rank
+// merge) overlaps the next batch's scoring kernels.
 #include "sa_index.hpp"
 #include "../../include/searcharray_hip.h"
 #include <rccl/rccl.h>
@@ -49,6 +50,12 @@ extern "C" int sa_index_comm_init(sa_index_t* ix, int rank, int nranks, const ch
         return SA_ERR_COMM;
     }
     c->rank = rank; c->nranks = nranks;
+    if (!ix->xstream && hipStreamCreateWithFlags(&ix->xstream, hipStreamNonBlocking) != hipSuccess) {
+        sa_set_error("hipStreamCreate (exchange stream) failed");
+        ncclCommDestroy(c->comm);
+        delete c;
+        return SA_ERR_HIP;
+    }
     ix->comm = c;
     return SA_OK;
 }
@@ -59,6 +66,7 @@ extern "C" int sa_index_comm_destroy(sa_index_t* ix) {
     if (!ix->comm) return SA_OK;
     hipSetDevice(ix->device);
     hipStreamSynchronize(ix->stream);
+    if (ix->xstream) hipStreamSynchronize(ix->xstream);
     ncclCommDestroy(ix->comm->comm);
     delete ix->comm;
     ix->comm = nullptr;
@@ -66,10 +74,11 @@ extern "C" int sa_index_comm_destroy(sa_index_t* ix) {
 }
 
 // count == 0: only report nranks.
-int sa_comm_allgather_topk(sa_index* ix, const u64* d_local, u64* d_gather, size_t count, int* nranks_out) {
+int sa_comm_allgather_topk(sa_index* ix, const u64* d_local, u64* d_gather, size_t count, int* nranks_out,
+                           hipStream_t st) {
     if (!ix->comm) { sa_set_error("index has no communicator"); return SA_ERR_STATE; }
     *nranks_out = ix->comm->nranks;
     if (count == 0) return SA_OK;
-    SA_NCCL(ncclAllGather(d_local, d_gather, count, ncclUint64, ix->comm->comm, ix->stream));
+    SA_NCCL(ncclAllGather(d_local, d_gather, count, ncclUint64, ix->comm->comm, st));
     return SA_OK;
 }

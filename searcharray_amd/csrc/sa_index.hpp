@@ -51,6 +51,7 @@ struct sa_index {
     size_t scratch_bytes = 0;
 
     sa_comm* comm = nullptr;
+    hipStream_t xstream = nullptr;   // exchange stream: all-gather + cross-rank merge overlap the next batch's scoring
 
     // profile counters (sa_index_stats)
     double last_kernel_ms = 0.0;

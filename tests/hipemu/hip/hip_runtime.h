@@ -344,9 +344,12 @@ inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "hipemu error"; }
 struct hipemu_event { std::chrono::steady_clock::time_point t; };
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemu_event(); return hipSuccess; }
+enum { hipEventDisableTiming = 2 };
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipemu_event(); return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = 0) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess;
 }

@@ -1,6 +1,6 @@
 // TEST INFRASTRUCTURE: the host-emulated build has no RCCL; Part 3 entry points report that.
 #include "sa_index.hpp"
-int sa_comm_allgather_topk(sa_index*, const u64*, u64*, size_t, int*) {
+int sa_comm_allgather_topk(sa_index*, const u64*, u64*, size_t, int*, hipStream_t) {
     sa_set_error("emulated build has no RCCL communicator");
     return SA_ERR_UNSUPPORTED;
 }

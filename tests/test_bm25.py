@@ -95,9 +95,10 @@ def test_topk_batch_matches_oracle(small, k):
     bt.close()
 
 
-def test_topk_massive_ties_takes_fallback_path(api):
-    """All docs identical -> every score ties -> survivors exceed the candidate list."""
-    n = 1500
+@pytest.mark.parametrize("n", [1500, 7000])
+def test_topk_massive_ties_takes_fallback_path(api, n):
+    """All docs identical -> every score ties -> the bound cuts nothing; with n = 7000 the survivors
+    overflow the merge kernel's LDS list (in-place compaction + bisection over the survivors)."""
     t = np.repeat(np.arange(3), n).astype(np.uint32)
     d = np.tile(np.arange(n), 3).astype(np.uint64)
     p = np.repeat(np.arange(3), n).astype(np.uint64)
@@ -144,7 +145,7 @@ def test_empty_and_degenerate_indexes(api):
     assert (s == 0).all() and (d_ == NO_DOC).all()
 
 
-@pytest.mark.parametrize("tile_docs,k", [(1024, 10), (2048, 3), (1024, 32)])
+@pytest.mark.parametrize("tile_docs,k", [(1024, 10), (2048, 3), (1024, 32), (1024, 1000)])
 def test_topk_pruning_over_many_tiles(api, tile_docs, k):
     """Enough tiles that the global pruning slots fill up (> 32 waves per query): most waves are
     rejected by the bound, and the result must still be the exact top-k."""
