@@ -187,6 +187,19 @@ int sa_index_last_profile(sa_index_t* ix, double* kernel_ms_out, uint64_t* alg_b
  * score 0 and doc 0xFFFFFFFFFFFFFFFF.  Doc ids are global (local + doc_base). */
 int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const float* idf, int n_queries,
                     int n_query_terms, int k, float k1, float b, sa_batch_t** out);
+/* Device-resident batch of B exact phrases (slop 0) with BM25 scoring and top-k selection: the
+ * caller loop `for phrase in phrases: top_k(arr.score(phrase))` around reference
+ * SearchArray.score (postings.py:652-680) -> PosnBitArray.phrase_freqs (middle_out.py:418-446) ->
+ * compute_phrase_freqs (middle_out.py:73-168) -> bm25 (similarity.py:24-38).  terms is
+ * [B][max_terms] row-major, phrase i uses its first n_terms[i] entries (2 <= n_terms[i] <= 18,
+ * pairwise distinct; fewer than two terms is SA_ERR_ARG like the reference's ValueError
+ * (middle_out.py:425-426), repeated terms / longer phrases are SA_ERR_UNSUPPORTED here -- use
+ * sa_index_bm25_phrase_dense).  idf[B] is the per-phrase idf the host sums over the phrase's
+ * terms (similarity.py:19-21).  An unknown term (id >= n_terms) makes the phrase match nothing.
+ * The result is a sa_batch_t: run / run_local / merge_gathered / fetch / profile / destroy below
+ * apply unchanged (profile: alg_bytes = postings_bytes = sum over phrases of 8 * words of its terms). */
+int sa_phrase_batch_create(sa_index_t* ix, const uint32_t* terms, const int32_t* n_terms, const float* idf,
+                           int n_phrases, int max_terms, int k, float k1, float b, sa_batch_t** out);
 /* one pass of the hot path over the batch; asynchronous on the index stream unless sync != 0.
  * If the index has a communicator (Part 3) the per-shard top-k are exchanged and merged. */
 int sa_batch_run(sa_batch_t* batch, int sync);

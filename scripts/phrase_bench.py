@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--vocab", type=int, default=100_000)
     ap.add_argument("--phrases", type=int, default=64)
     ap.add_argument("--cpu-phrases", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=256)
     args = ap.parse_args()
     api = _lib.api()
     D, V = args.docs, args.vocab
@@ -52,6 +53,35 @@ def main():
                      "device_ms_per_phrase": round(kms / len(phrases), 4), "device_alg_GBps": round(kbytes / kms / 1e6, 1),
                      "t0t1t2_device_ms": round(ms0, 4), "t0t1t2_alg_GBps": round(ab0 / ms0 / 1e6, 1)}
         res[mode + "_outs"] = outs
+    os.environ.pop("SA_PHRASE_MODE", None)
+    # phrase batches: B phrases -> BM25 -> top-10, resident on the device
+    import itertools
+    batches = {
+        "sampled": [[int(t) for t in p] for p in synth.phrase_queries_from_tokens(lens, terms, args.batch, 3, seed=77)],
+        "heavy": [list(c) for c in itertools.islice(itertools.permutations(range(8), 3), args.batch)],
+    }
+    bres = {}
+    for name, plist in batches.items():
+        plist = [p for p in plist if len(set(p)) == len(p)]
+        bt = index.phrase_batch(plist, k=10)
+        bt.run()
+        bt.profile()
+        steps = 20
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            bt.run(sync=False)
+        index.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        kms, alg, _ = bt.profile()
+        scores, docs = bt.fetch()
+        okb = True
+        for i in range(min(4, len(plist))):
+            ws, wd = O.topk(orc.score(plist[i]), 10)
+            n = int((ws > 0).sum())
+            okb &= bool(np.array_equal(scores[i, :n], ws[:n])) and bool(np.array_equal(docs[i, :n], wd[:n]))
+        bres[name] = {"phrases": len(plist), "ms_per_batch": round(dt * 1e3, 4), "phrases_per_s": round(len(plist) / dt, 1),
+                      "kernel_ms": round(kms, 4), "alg_GBps": round(alg / kms / 1e6, 1), "topk_bit_exact": okb}
+        bt.close()
     t0 = time.perf_counter()
     ok = True
     ncpu = min(args.cpu_phrases, len(phrases))
@@ -62,7 +92,7 @@ def main():
     t0 = time.perf_counter()
     want0 = orc.phrase_freqs([0, 1, 2])
     cpu0 = time.perf_counter() - t0
-    print(json.dumps({"config": f"zipf-{D} 3-token phrases x{len(phrases)}", "fused": res["fused"], "general": res["general"],
+    print(json.dumps({"config": f"zipf-{D} 3-token phrases x{len(phrases)}", "fused": res["fused"], "general": res["general"], "batch_top10": bres,
                       "cpu_oracle_ms_per_phrase": round(cpu_dt / ncpu * 1e3, 2), "cpu_oracle_t0t1t2_ms": round(cpu0 * 1e3, 2),
                       "t0t1t2_matches": int(want0.sum()), "counts_bit_exact": ok}))
 

@@ -1,0 +1,59 @@
+// sa_batch.hpp -- a resident batch of top-k queries (BM25 term disjunctions or exact phrases):
+// per-batch tables, candidate lists, the per-shard merge and the cross-rank exchange buffers.
+#pragma once
+#include "sa_index.hpp"
+#include <vector>
+
+#define SA_MAX_QTERMS 32
+#define SA_KMAX 1024
+#define SA_EVENT_RING 128
+
+struct sa_batch {
+    sa_index* ix = nullptr;
+    u32 B = 0, T = 0, k = 0;
+    float k1 = 1.2f, b = 0.75f;
+    std::vector<u32> perm;          // device row r holds caller query perm[r] (results: caller order)
+    u32* d_terms = nullptr;
+    u32* d_perm = nullptr;
+    float* d_idf = nullptr;
+    u64* d_cand = nullptr;          // [B][n_tiles][waves*k]: per-tile blocks, or per-query append lists
+    float* d_sattab = nullptr;      // saturation table of this batch's (k1, b, avgdl)
+    u32 tab_w = 0;
+    u32* d_bounds = nullptr;        // [B][T][n_tiles+1] slice table
+    u64* d_qbase = nullptr;         // [B][T]
+    u32 cand_cap = 0;               // keys per query in d_cand
+    bool cap_limited = false;       // cand_cap below the worst case: overflow must be checked
+    u32* d_cand_cnt = nullptr;      // [B] append cursors (pruned selection)
+    u32* d_slots = nullptr;         // [B][32] pruning slots
+    u64* d_local = nullptr;         // [B][k] per-shard result
+    u64* d_gather = nullptr;        // [2][nranks][B][k] (multi-GPU, double-buffered like d_xlocal)
+    u64* d_xlocal = nullptr;        // [2][B][k] per-shard results handed to the exchange stream
+    hipEvent_t ev_scored[2] = {nullptr, nullptr};     // d_xlocal[b] written (index stream)
+    hipEvent_t ev_exchanged[2] = {nullptr, nullptr};  // d_xlocal[b] / d_gather[b] consumed (exchange stream)
+    bool exchanged_valid[2] = {false, false};
+    u32 xstep = 0;
+    int gather_ranks = 0;
+    u64* d_final = nullptr;         // [B][k]
+    u64* d_xcand = nullptr;         // [B][nranks*k] regrouped gather
+    int xcand_ranks = 0;
+    std::vector<hipEvent_t> ev0, ev1;   // ring of (start, stop) events around the scoring kernel
+    u32 ev_n = 0;                       // runs recorded since the last sa_batch_profile
+    u64 alg_bytes = 0, postings_bytes = 0;
+    bool ran = false;
+    // phrase batches (sa_phrase_batch.hip): kind == 1
+    int kind = 0;                   // 0: disjunctive BM25 over terms, 1: exact phrases
+    u32 ptile = 0, pn_tiles = 0;    // docs per phrase tile and their number
+    u32* d_plan = nullptr;          // [B][4]: n_terms, split, anchor of part 0, anchor of part 1
+    u32* d_wbounds = nullptr;       // [B][T][pn_tiles+1] first word of the term in each tile (relative)
+    u64* d_wbase = nullptr;         // [B][T] word base of each phrase term
+};
+
+
+int sa_comm_allgather_topk(sa_index* ix, const u64* d_local, u64* d_gather, size_t count, int* nranks_out,
+                           hipStream_t st);
+
+// tile scoring + pruned selection of a phrase batch on stream st (sa_phrase_batch.hip)
+int sa_launch_phrase_tiles(sa_batch* bt, hipStream_t st);
+// shared by the two batch kinds (sa_bm25.hip)
+int sa_batch_alloc_topk(sa_batch* bt, u32 n_tiles, u32 waves);
+void sa_batch_free(sa_batch* bt);

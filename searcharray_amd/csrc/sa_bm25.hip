@@ -16,15 +16,13 @@
 // doc_len into the posting so the real traffic is lower).
 #include "sa_index.hpp"
 #include "sa_topk.hpp"
+#include "sa_batch.hpp"
 #include "../../include/searcharray_hip.h"
 
 #include <algorithm>
 #include <new>
 #include <stdlib.h>
 
-#define SA_MAX_QTERMS 32
-#define SA_KMAX 1024
-#define SA_EVENT_RING 128
 
 struct alignas(16) sa_u64x2 { u64 x, y; };
 
@@ -249,112 +247,8 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
     const u32 k = p.k;
     if (p.cand && !p.no_topk) {
     if constexpr (MODE == 1) {
-        do {
-        // PRUNED selection.  Per query, 32 global slots each hold a score that `rr = ceil(k/32)`
-        // distinct docs of ONE wave reach (the rr-th largest per-lane maximum of that wave), taken
-        // over 32 disjoint families of waves (slot = wave index mod 32).  So G = min(slots) is a
-        // score at least 32 * rr >= k distinct docs reach: nothing below G can enter the top-k.
-        // A wave whose maximum is below G (almost every wave once the first tiles have run) is
-        // done after one DPP reduction.  Otherwise it appends its elements >= G -- all of them when
-        // there are at most k, else its exact top-k by k rounds of a wave-wide arg-max -- to the
-        // query's candidate list.  Stale slot reads only weaken the pruning (slots grow
-        // monotonically); the final top-k is exact and deterministic.
-        const u32 lane = tid & (SA_WAVE - 1), wave = tid / SA_WAVE;
-        u32 lmax = 0;
-#pragma unroll
-        for (int j = 0; j < E; j++) {
-            const u32 x = __float_as_uint(acc[j * THREADS + tid]);
-            lmax = x > lmax ? x : lmax;
-        }
-        const u32 wmax = sa_wave_max_u32(lmax);
-        const u32 g = sa_wave_min_u32(slot_val);
-        const u32 thr = g > 1u ? g : 1u;
-        if (wmax < thr) break;                                    // wave-uniform
-#define SA_ELEM(j) ((u32)(j) * THREADS + tid)
-        const u32 widx = tile * NW + wave;
-        {
-            // slot update: the rr-th largest lane maximum (lanes counted individually)
-            const u32 my_slot = (u32)__shfl((int)slot_val, (int)(widx & 31u), SA_WAVE);
-            if (wmax > my_slot) {                                 // wave-uniform
-                const u32 rr = (k + 31u) / 32u;
-                u32 v = lmax, cnt = 0, mr = 0;
-                for (u32 it = 0; it < rr; it++) {
-                    const u32 m = it == 0 ? wmax : sa_wave_max_u32(v);
-                    if (m == 0) break;
-                    cnt += (u32)__popcll(__ballot(v == m));
-                    if (cnt >= rr) { mr = m; break; }
-                    v = (v == m) ? 0u : v;
-                }
-                if (lane == 0 && mr > my_slot) atomicMax(&p.slots[q * 32u + (widx & 31u)], mr);
-            }
-        }
-        u64* qcand = p.cand + (u64)q * p.cand_cap;
-        const u64 lt = (1ull << lane) - 1ull;
-        u32 c = 0;
-#pragma unroll
-        for (int j = 0; j < E; j++)
-            c += (u32)__popcll(__ballot(__float_as_uint(acc[SA_ELEM(j)]) >= thr));
-        if (c <= k) {
-            u32 base = 0;
-            if (lane == 0) base = atomicAdd(&p.cand_cnt[q], c);
-            base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-#pragma unroll
-            for (int j = 0; j < E; j++) {
-                const u32 e = SA_ELEM(j);
-                const u32 x = __float_as_uint(acc[e]);
-                const bool keep = x >= thr;
-                const u64 b = __ballot(keep);
-                if (keep) {
-                    const u32 pos = base + (u32)__popcll(b & lt);
-                    const u64 doc = p.doc_base + tile_base + e;
-                    if (pos < p.cand_cap) qcand[pos] = ((u64)x << 32) | (u64)(u32)(~(u32)doc);
-                }
-                base += (u32)__popcll(b);
-            }
-            break;
-        }
-        // more than k survivors (first tiles of a query, or heavy ties): exact top-k of this wave.
-        // Each lane tracks its best and second best element in registers (branch-free); the tile
-        // is rescanned only when one lane wins twice in a row of promotions.
-        u32 cbase = 0;
-        if (lane == 0) cbase = atomicAdd(&p.cand_cnt[q], k);
-        cbase = (u32)__builtin_amdgcn_readfirstlane((int)cbase);
-        u32 b1k, b1j, b2k, b2j;
-#define SA_RESCAN()                                                                   \
-        do {                                                                          \
-            b1k = 0; b1j = 0; b2k = 0; b2j = 0;                                       \
-            _Pragma("unroll") for (int j = 0; j < E; j++) {                           \
-                const u32 x = __float_as_uint(acc[SA_ELEM(j)]);                \
-                const bool g1 = x > b1k, g2 = x > b2k;                                \
-                const u32 n2k = g1 ? b1k : (g2 ? x : b2k);                            \
-                const u32 n2j = g1 ? b1j : (g2 ? (u32)j : b2j);                       \
-                b1k = g1 ? x : b1k; b1j = g1 ? (u32)j : b1j; b2k = n2k; b2j = n2j;    \
-            }                                                                         \
-        } while (0)
-        SA_RESCAN();
-        bool stale = false;                         // true: b2 already promoted, next best unknown
-        u32 found = 0;
-        for (u32 r = 0; r < k; r++) {
-            const u32 m = sa_wave_max_u32(b1k);
-            if (m == 0) break;                       // wave-uniform
-            const u32 e1 = (b1k == m) ? SA_ELEM(b1j) : 0xFFFFFFFFu;
-            const u32 emin = sa_wave_min_u32(e1);    // ties -> smallest doc id
-            found = r + 1;
-            const bool owner = (e1 == emin);
-            if (owner) {
-                acc[emin] = 0.f;
-                const u64 doc = p.doc_base + tile_base + emin;
-                if (cbase + r < p.cand_cap) qcand[cbase + r] = ((u64)m << 32) | (u64)(u32)(~(u32)doc);
-            }
-            const bool need = owner && stale;
-            if (owner && !stale) { b1k = b2k; b1j = b2j; b2k = 0; stale = true; }
-            if (__any(need)) { SA_RESCAN(); stale = false; }
-        }
-#undef SA_RESCAN
-#undef SA_ELEM
-        for (u32 r = found + lane; r < k; r += SA_WAVE)           // unused reserved slots
-            if (cbase + r < p.cand_cap) qcand[cbase + r] = 0ull;
-        } while (0);
+        sa_tile_topk_pruned<TILE, THREADS>(acc, slot_val, q, tile, p.doc_base + tile_base, k, p.slots, p.cand,
+                                           p.cand_cap, p.cand_cnt);
     } else {
     // 4. per-tile top-k -> composite keys  score_bits<<32 | ~global_doc
     u64* cand = p.cand + ((u64)q * p.n_tiles + tile) * p.cand_per_tile;
@@ -601,42 +495,7 @@ sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-struct sa_batch {
-    sa_index* ix = nullptr;
-    u32 B = 0, T = 0, k = 0;
-    float k1 = 1.2f, b = 0.75f;
-    std::vector<u32> perm;          // device row r holds caller query perm[r] (results: caller order)
-    u32* d_terms = nullptr;
-    u32* d_perm = nullptr;
-    float* d_idf = nullptr;
-    u64* d_cand = nullptr;          // [B][n_tiles][waves*k]: per-tile blocks, or per-query append lists
-    float* d_sattab = nullptr;      // saturation table of this batch's (k1, b, avgdl)
-    u32 tab_w = 0;
-    u32* d_bounds = nullptr;        // [B][T][n_tiles+1] slice table
-    u64* d_qbase = nullptr;         // [B][T]
-    u32 cand_cap = 0;               // keys per query in d_cand
-    bool cap_limited = false;       // cand_cap below the worst case: overflow must be checked
-    u32* d_cand_cnt = nullptr;      // [B] append cursors (pruned selection)
-    u32* d_slots = nullptr;         // [B][32] pruning slots
-    u64* d_local = nullptr;         // [B][k] per-shard result
-    u64* d_gather = nullptr;        // [2][nranks][B][k] (multi-GPU, double-buffered like d_xlocal)
-    u64* d_xlocal = nullptr;        // [2][B][k] per-shard results handed to the exchange stream
-    hipEvent_t ev_scored[2] = {nullptr, nullptr};     // d_xlocal[b] written (index stream)
-    hipEvent_t ev_exchanged[2] = {nullptr, nullptr};  // d_xlocal[b] / d_gather[b] consumed (exchange stream)
-    bool exchanged_valid[2] = {false, false};
-    u32 xstep = 0;
-    int gather_ranks = 0;
-    u64* d_final = nullptr;         // [B][k]
-    u64* d_xcand = nullptr;         // [B][nranks*k] regrouped gather
-    int xcand_ranks = 0;
-    std::vector<hipEvent_t> ev0, ev1;   // ring of (start, stop) events around the scoring kernel
-    u32 ev_n = 0;                       // runs recorded since the last sa_batch_profile
-    u64 alg_bytes = 0, postings_bytes = 0;
-    bool ran = false;
-};
 
-int sa_comm_allgather_topk(sa_index* ix, const u64* d_local, u64* d_gather, size_t count, int* nranks_out,
-                           hipStream_t st);
 
 
 static void sa_fill_params(const sa_index* ix, Bm25Params& p) {
@@ -753,7 +612,7 @@ extern "C" int sa_index_bm25_dense(sa_index_t* ix, const uint32_t* terms, const 
     return SA_OK;
 }
 
-static void sa_batch_free(sa_batch* bt) {
+void sa_batch_free(sa_batch* bt) {
     if (!bt) return;
     if (bt->ix) {
         hipSetDevice(bt->ix->device);
@@ -777,9 +636,43 @@ static void sa_batch_free(sa_batch* bt) {
     }
     if (bt->d_final) hipFree(bt->d_final);
     if (bt->d_xcand) hipFree(bt->d_xcand);
+    if (bt->d_plan) hipFree(bt->d_plan);
+    if (bt->d_wbounds) hipFree(bt->d_wbounds);
+    if (bt->d_wbase) hipFree(bt->d_wbase);
     for (hipEvent_t e : bt->ev0) hipEventDestroy(e);
     for (hipEvent_t e : bt->ev1) hipEventDestroy(e);
     delete bt;
+}
+
+// Candidate lists, pruning slots, result buffers and the timing-event ring of a batch whose tile
+// kernel runs n_tiles tiles of `waves` waves per query.
+int sa_batch_alloc_topk(sa_batch* bt, u32 n_tiles, u32 waves) {
+    const u32 B = bt->B;
+    // candidate storage per query: worst case every wave appends k keys; capped at 1 Mi keys per
+    // query (8 MiB) -- with the cap an overflow is theoretically possible and is detected at run
+    // time (sa_batch_run_shard re-runs a BM25 batch with the unpruned block-level selection).
+    const u64 worst = (u64)(n_tiles ? n_tiles : 1) * bt->k * waves;
+    const u64 mode0 = (u64)(n_tiles ? n_tiles : 1) * bt->k;
+    u64 cap = worst < (1ull << 20) ? worst : (1ull << 20);
+    if (cap < mode0) cap = mode0;                      // the unpruned layout [n_tiles][k] must fit too
+    bt->cand_cap = (u32)cap;
+    bt->cap_limited = cap < worst;
+    const size_t ncand = (size_t)B * cap;
+    SA_HIP(hipMalloc(&bt->d_cand, ncand * sizeof(u64)));
+    SA_HIP(hipMalloc(&bt->d_slots, (size_t)B * 33 * sizeof(u32)));   // slots + cursors: one memset per run
+    bt->d_cand_cnt = bt->d_slots + (size_t)B * 32;
+    SA_HIP(hipMalloc(&bt->d_local, (size_t)B * bt->k * sizeof(u64)));
+    SA_HIP(hipMalloc(&bt->d_final, (size_t)B * bt->k * sizeof(u64)));
+    SA_HIP(hipMemset(bt->d_final, 0, (size_t)B * bt->k * sizeof(u64)));
+    SA_HIP(hipMemset(bt->d_local, 0, (size_t)B * bt->k * sizeof(u64)));
+    for (int i = 0; i < SA_EVENT_RING; i++) {
+        hipEvent_t a = nullptr, c = nullptr;
+        SA_HIP(hipEventCreate(&a));
+        bt->ev0.push_back(a);
+        SA_HIP(hipEventCreate(&c));
+        bt->ev1.push_back(c);
+    }
+    return SA_OK;
 }
 
 extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const float* idf, int n_queries,
@@ -829,23 +722,7 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
     SA_HIP_B(hipMalloc(&bt->d_idf, h_idf.size() * sizeof(float)));
     SA_HIP_B(hipMalloc(&bt->d_perm, (size_t)B * sizeof(u32)));
     SA_HIP_B(hipMemcpy(bt->d_perm, bt->perm.data(), (size_t)B * sizeof(u32), hipMemcpyHostToDevice));
-    // candidate storage per query: worst case every wave appends k keys; capped at 1 Mi keys per
-    // query (8 MiB) -- with the cap an overflow is theoretically possible and is detected at run
-    // time (sa_batch_run_shard re-runs the batch with the unpruned block-level selection).
-    const u64 worst = (u64)(ix->n_tiles ? ix->n_tiles : 1) * bt->k * sa_tile_waves(ix->tile_docs);
-    const u64 mode0 = (u64)(ix->n_tiles ? ix->n_tiles : 1) * bt->k;
-    u64 cap = worst < (1ull << 20) ? worst : (1ull << 20);
-    if (cap < mode0) cap = mode0;                      // the unpruned layout [n_tiles][k] must fit too
-    bt->cand_cap = (u32)cap;
-    bt->cap_limited = cap < worst;
-    const size_t ncand = (size_t)B * cap;
-    SA_HIP_B(hipMalloc(&bt->d_cand, ncand * sizeof(u64)));
-    SA_HIP_B(hipMalloc(&bt->d_slots, (size_t)B * 33 * sizeof(u32)));   // slots + cursors: one memset per run
-    bt->d_cand_cnt = bt->d_slots + (size_t)B * 32;
-    SA_HIP_B(hipMalloc(&bt->d_local, (size_t)B * bt->k * sizeof(u64)));
-    SA_HIP_B(hipMalloc(&bt->d_final, (size_t)B * bt->k * sizeof(u64)));
-    SA_HIP_B(hipMemset(bt->d_final, 0, (size_t)B * bt->k * sizeof(u64)));
-    SA_HIP_B(hipMemset(bt->d_local, 0, (size_t)B * bt->k * sizeof(u64)));
+    if (sa_batch_alloc_topk(bt, ix->n_tiles, sa_tile_waves(ix->tile_docs)) != SA_OK) return fail(SA_ERR_HIP);
     SA_HIP_B(hipMemcpy(bt->d_terms, h_terms.data(), h_terms.size() * sizeof(u32), hipMemcpyHostToDevice));
     SA_HIP_B(hipMemcpy(bt->d_idf, h_idf.data(), h_idf.size() * sizeof(float), hipMemcpyHostToDevice));
     SA_HIP_B(hipMalloc(&bt->d_bounds, ((size_t)B * T * (ix->n_tiles + 1) + 1) * sizeof(u32)));
@@ -854,13 +731,6 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
     if (sa_launch_make_sattab(ix, bt->d_sattab, &bt->tab_w, k1, b, ix->stream) != SA_OK) return fail(SA_ERR_HIP);
     if (sa_launch_make_bounds(ix, bt->d_terms, B * T, bt->d_bounds, bt->d_qbase, ix->stream) != SA_OK) return fail(SA_ERR_HIP);
     SA_HIP_B(hipStreamSynchronize(ix->stream));
-    for (int i = 0; i < SA_EVENT_RING; i++) {
-        hipEvent_t a = nullptr, c = nullptr;
-        SA_HIP_B(hipEventCreate(&a));
-        bt->ev0.push_back(a);
-        SA_HIP_B(hipEventCreate(&c));
-        bt->ev1.push_back(c);
-    }
 #undef SA_HIP_B
     (void)rc;
     *out = bt;
@@ -896,32 +766,39 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out) {
     p.cand_cap = bt->cand_cap;
     p.cand_cnt = bt->d_cand_cnt;
     p.slots = bt->d_slots;
+    if (bt->kind == 1) p.small_k_argmax = 1;                      // phrase tiles: pruned selection only
     if (p.small_k_argmax) {
         SA_HIP(hipMemsetAsync(bt->d_slots, 0, (size_t)bt->B * 33 * sizeof(u32), st));   // slots + cursors
     }
     const u32 slot = bt->ev_n % SA_EVENT_RING;
     SA_HIP(hipEventRecord(bt->ev0[slot], st));
-    if (ix->avg_doc_len != 0.f && ix->n_tiles > 0) {
-        SA_TRY(sa_launch_bm25(ix, p, st));
+    const u32 n_tiles = bt->kind == 1 ? bt->pn_tiles : ix->n_tiles;
+    if (ix->avg_doc_len != 0.f && n_tiles > 0) {
+        if (bt->kind == 1) SA_TRY(sa_launch_phrase_tiles(bt, st));
+        else SA_TRY(sa_launch_bm25(ix, p, st));
     } else {
         SA_HIP(hipMemsetAsync(bt->d_cand, 0, (size_t)bt->B * p.cand_cap * sizeof(u64), st));
     }
     SA_HIP(hipEventRecord(bt->ev1[slot], st));
     bt->ev_n++;
-    if (p.small_k_argmax && bt->cap_limited && ix->n_tiles > 0) {
+    if (p.small_k_argmax && bt->cap_limited && n_tiles > 0) {
         // the candidate lists are smaller than the worst case: make sure no query ran over
         std::vector<u32> h_cnt(bt->B);
         SA_HIP(hipMemcpyAsync(h_cnt.data(), bt->d_cand_cnt, (size_t)bt->B * sizeof(u32), hipMemcpyDeviceToHost, st));
         SA_HIP(hipStreamSynchronize(st));
         bool over = false;
         for (u32 i = 0; i < bt->B; i++) over |= h_cnt[i] > bt->cand_cap;
+        if (over && bt->kind == 1) {
+            sa_set_error("phrase batch: candidate list overflow (k too large for this many matching tiles)");
+            return SA_ERR_UNSUPPORTED;
+        }
         if (over) {
             p.small_k_argmax = 0;
             p.cand_per_tile = bt->k;
             SA_TRY(sa_launch_bm25(ix, p, st));
         }
     }
-    const u32 n_cand = p.small_k_argmax ? p.cand_cap : (ix->n_tiles ? ix->n_tiles : 1) * p.cand_per_tile;
+    const u32 n_cand = p.small_k_argmax ? p.cand_cap : (n_tiles ? n_tiles : 1) * p.cand_per_tile;
     hipLaunchKernelGGL(sa_k_topk_merge, dim3(bt->B), dim3(1024), 0, st, bt->d_cand, n_cand, bt->k, shard_out,
                        (const u32*)bt->d_perm, 0u, (const u32*)(p.small_k_argmax ? bt->d_cand_cnt : nullptr),
                        (const u32*)(p.small_k_argmax ? bt->d_slots : nullptr));

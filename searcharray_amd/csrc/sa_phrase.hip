@@ -25,6 +25,7 @@
 //    t0@p, t1@p+1, ... (and, for the middle-out plan, the min of the two sub-phrase counts).
 #include "sa_index.hpp"
 #include "sa_scan.hpp"
+#include "sa_phrase_dev.hpp"
 #include "../../include/searcharray_hip.h"
 
 #include <stdlib.h>
@@ -177,43 +178,12 @@ struct FusedPhraseParams {
     u32* step;                   // dense per-doc match counts (u32, atomically accumulated)
 };
 
-// 18-bit payload of the word with header h in [base, base+n), 0 if absent.  `hint` carries the
-// previous probe's position so the three probes h-1, h, h+1 cost one search.
-__device__ __forceinline__ u64 sa_payload_at(const u64* __restrict__ a, u32 n, u64 h, u32& hint) {
-    const u32 j = sa_lower_bound(a, hint, n, h, SA_HEADER_MASK);
-    hint = j;
-    return (j < n && (a[j] & SA_HEADER_MASK) == h) ? (a[j] & SA_LSB_MASK) : 0ull;
-}
-
 __global__ void __launch_bounds__(256) sa_k_phrase_fused(const FusedPhraseParams p) {
     const u64* anc = p.ptr[p.anchor];
     const u32 na = p.len[p.anchor];
-    const u64 delta = 1ull << SA_LSB_BITS;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < na; i += gridDim.x * blockDim.x) {
         const u64 w = anc[i];
-        const u64 h = w & SA_HEADER_MASK;
-        const u64 doc_key = w & SA_KEY_MASK;
-        u64 m = w & SA_LSB_MASK;                 // bit p: anchor term at position 18*blk + p
-        for (int t = 0; t < p.T && m; t++) {
-            if (t == p.anchor) continue;
-            const int d = t - p.anchor;          // term t must sit at anchor position + d, |d| < 18
-            const u64* a = p.ptr[t];
-            const u32 n = p.len[t];
-            // 54-bit window: payloads of headers h-1 | h | h+1 (same doc only)
-            u32 hint = 0;
-            u64 win = 0;
-            if (d < 0) {
-                const u64 hm = h - delta;
-                if ((h & ~SA_KEY_MASK & SA_HEADER_MASK) != 0 && (hm & SA_KEY_MASK) == doc_key)
-                    win |= sa_payload_at(a, n, hm, hint);
-            }
-            win |= sa_payload_at(a, n, h, hint) << 18;
-            if (d > 0) {
-                const u64 hp = h + delta;
-                if ((hp & SA_KEY_MASK) == doc_key) win |= sa_payload_at(a, n, hp, hint) << 36;
-            }
-            m &= (win >> (18 + d)) & SA_LSB_MASK;
-        }
+        const u64 m = sa_phrase_anchor_mask(w, p.T, p.anchor, [&](int t, const u64*& a, u32& n) { a = p.ptr[t]; n = p.len[t]; });
         if (m) atomicAdd(&p.step[w >> SA_KEY_SHIFT], (u32)__popcll(m));
     }
 }

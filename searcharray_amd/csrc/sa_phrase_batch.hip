@@ -1,0 +1,252 @@
+// sa_phrase_batch.hip -- many exact phrases at once: phrase match counts -> BM25 -> top-k, all on
+// the device (Part 2 of the C ABI, phrase flavour of sa_batch_*).
+//
+// Replaces the caller loop  `for phrase in phrases: scores = arr.score(phrase); top = argpartition`
+// around reference SearchArray.score (postings.py:652-680) -> PosnBitArray.phrase_freqs
+// (middle_out.py:418-446) -> compute_phrase_freqs (middle_out.py:73-168) -> bm25 (similarity.py:24-38,
+// bm25.pyx:11-25).  sa_index_bm25_phrase_dense remains the one-phrase, dense-output drop-in; the batch
+// keeps everything resident and returns only B x k (score, doc) pairs.
+//
+// Layout: documents are cut into tiles of SA_PTILE docs; one workgroup scores one (tile, phrase).  A
+// doc's roaringish words are contiguous in every term's list, so a tile owns one contiguous slice of
+// each phrase term (slice table built once per batch by lower-bound searches).  The workgroup walks
+// the slice of the phrase's rarest term (the anchor), lines the other terms up against each anchor
+// word (sa_phrase_anchor_mask: 54-bit windows, shifts, AND, popcount -- integer work, no MFMA) and
+// adds the match counts into per-doc LDS counters; counts -> fp32 BM25 with the reference's operation
+// order; the pruned wave-level top-k (sa_tile_topk_pruned) appends the few docs that can still reach
+// the query's top-k.  Tiles in which some phrase term has no word leave after two loads.
+//
+// The reference's evaluation plan is kept: with the shortest term list at index s, phrases with
+// s <= 1 or s >= T-2 are counted whole; otherwise the count is min(count(terms[:s]),
+// count(terms[s:])) per doc (middle_out.py:154-168, "middle out").
+#include "sa_index.hpp"
+#include "sa_topk.hpp"
+#include "sa_batch.hpp"
+#include "sa_phrase_dev.hpp"
+#include "../../include/searcharray_hip.h"
+#include <new>
+#include <vector>
+
+#define SA_PTILE 4096
+#define SA_PTHREADS 256
+#define SA_PHRASE_BATCH_MAXT 18      // |t - anchor| must stay below the 18-position block width
+
+struct PhraseTileParams {
+    const u64* words;
+    const float* doc_lens;
+    u64 n_docs, doc_base;
+    u32 n_tiles;
+    const u32* plan;       // [B][4]: n_terms (0: unknown term -> no match), split, anchor0, anchor1
+    const u32* bounds;     // [B][T][n_tiles+1]
+    const u64* wbase;      // [B][T]
+    const float* idf;      // [B]
+    u32 B, T, k;
+    float k1, b, avgdl;
+    u32 cand_cap;
+    u32* cand_cnt;
+    u32* slots;
+    u64* cand;
+};
+
+// first word of each phrase term at or after every tile boundary, relative to the term's base
+__global__ void __launch_bounds__(256)
+sa_k_make_word_bounds(const u64* __restrict__ words, const u64* __restrict__ term_off, u32 n_terms, u32 n_tiles,
+                      u32 tile_docs, const u32* __restrict__ terms, u32 BT, u32* __restrict__ bounds,
+                      u64* __restrict__ wbase) {
+    const u64 total = (u64)BT * (n_tiles + 1);
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (u64)gridDim.x * blockDim.x) {
+        const u32 qt = (u32)(e / (n_tiles + 1)), tile = (u32)(e % (n_tiles + 1));
+        const u32 term = terms[qt];
+        u32 rel = 0;
+        u64 base = 0;
+        if (term < n_terms) {
+            base = term_off[term];
+            const u32 cnt = (u32)(term_off[term + 1] - base);
+            rel = sa_lower_bound(words + base, 0, cnt, ((u64)tile * tile_docs) << SA_KEY_SHIFT, SA_KEY_MASK);
+        }
+        bounds[e] = rel;
+        if (tile == 0) wbase[qt] = base;
+    }
+}
+
+template <int TILE, int THREADS>
+__global__ void __launch_bounds__(THREADS) sa_k_phrase_tiles(const PhraseTileParams p) {
+    constexpr int E = TILE / THREADS;
+    __shared__ u32 cnt_a[TILE];                      // match counts, later the fp32 scores
+    __shared__ u32 cnt_b[TILE];                      // second half of a middle-out plan
+    __shared__ u64 s_lo[SA_PHRASE_BATCH_MAXT], s_hi[SA_PHRASE_BATCH_MAXT];
+    const u32 tid = threadIdx.x;
+    const u32 item = blockIdx.x;
+    const u32 tile = item / p.B, q = item % p.B;     // tile-major like the BM25 tiles
+    const u64 tile_base = (u64)tile * TILE;
+    const u32* plan = p.plan + (u64)q * 4;
+    const u32 Tq = plan[0], split = plan[1];
+    if (Tq == 0) return;                             // a term is unknown: zeros (postings.py:705-708)
+    u32 slot_val = 0xFFFFFFFFu;
+    if ((tid & (SA_WAVE - 1)) < 32u)
+        slot_val = __hip_atomic_load(&p.slots[q * 32u + (tid & 31u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < Tq) {
+        const u32 qt = q * p.T + tid;
+        const u32* row = p.bounds + (u64)qt * (p.n_tiles + 1) + tile;
+        const u64 base = p.wbase[qt];
+        s_lo[tid] = base + row[0];
+        s_hi[tid] = base + row[1];
+    }
+#pragma unroll
+    for (int j = 0; j < E; j++) cnt_a[j * THREADS + tid] = 0;
+    if (split) {
+#pragma unroll
+        for (int j = 0; j < E; j++) cnt_b[j * THREADS + tid] = 0;
+    }
+    __syncthreads();
+    // every term is needed by some part: an empty slice means no doc of this tile matches
+    bool empty = false;
+    for (u32 t = 0; t < Tq; t++) empty |= (s_lo[t] == s_hi[t]);
+    if (empty) return;                               // uniform
+
+    const int nparts = split ? 2 : 1;
+    for (int part = 0; part < nparts; part++) {
+        const int t0 = part == 0 ? 0 : (int)split;
+        const int t1 = (split && part == 0) ? (int)split : (int)Tq;
+        const int anchor = (int)plan[2 + part];      // index within [t0, t1)
+        u32* cnt = part == 0 ? cnt_a : cnt_b;
+        const u64 alo = s_lo[t0 + anchor];
+        const u32 na = (u32)(s_hi[t0 + anchor] - alo);
+        for (u32 i = tid; i < na; i += THREADS) {
+            const u64 w = p.words[alo + i];
+            const u64 m = sa_phrase_anchor_mask(w, t1 - t0, anchor, [&](int t, const u64*& a, u32& n) {
+                a = p.words + s_lo[t0 + t];
+                n = (u32)(s_hi[t0 + t] - s_lo[t0 + t]);
+            });
+            if (m) atomicAdd(&cnt[(u32)((w >> SA_KEY_SHIFT) - tile_base)], (u32)__popcll(m));
+        }
+    }
+    __syncthreads();
+
+    // counts -> BM25 (bm25.pyx:19-23 operation order, every op rounded to fp32); a thread converts
+    // exactly the elements it owns in the selection below, so no barrier is needed in between
+    float* acc = (float*)cnt_a;
+    const float one_minus_b = 1.0f - p.b;
+    const float idf = p.idf[q];
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        const u32 e = j * THREADS + tid;
+        u32 c = cnt_a[e];
+        if (split) { const u32 c2 = cnt_b[e]; c = c2 < c ? c2 : c; }
+        float s = 0.f;
+        if (c) {
+            const float tf = (float)c;
+            const float dl = p.doc_lens[tile_base + e];
+            const float norm = __fmul_rn(p.k1, __fadd_rn(one_minus_b, __fmul_rn(p.b, __fdiv_rn(dl, p.avgdl))));
+            s = __fmul_rn(__fdiv_rn(tf, __fadd_rn(tf, norm)), idf);
+        }
+        acc[e] = s;
+    }
+    sa_tile_topk_pruned<TILE, THREADS>(acc, slot_val, q, tile, p.doc_base + tile_base, p.k, p.slots, p.cand,
+                                       p.cand_cap, p.cand_cnt);
+}
+
+int sa_launch_phrase_tiles(sa_batch* bt, hipStream_t st) {
+    sa_index* ix = bt->ix;
+    if (bt->pn_tiles == 0 || bt->B == 0) return SA_OK;
+    PhraseTileParams p;
+    memset(&p, 0, sizeof(p));
+    p.words = ix->d_words; p.doc_lens = ix->d_doc_lens;
+    p.n_docs = ix->n_docs; p.doc_base = ix->doc_base; p.n_tiles = bt->pn_tiles;
+    p.plan = bt->d_plan; p.bounds = bt->d_wbounds; p.wbase = bt->d_wbase; p.idf = bt->d_idf;
+    p.B = bt->B; p.T = bt->T; p.k = bt->k; p.k1 = bt->k1; p.b = bt->b; p.avgdl = ix->avg_doc_len;
+    p.cand_cap = bt->cand_cap; p.cand_cnt = bt->d_cand_cnt; p.slots = bt->d_slots; p.cand = bt->d_cand;
+    const u64 n_items = (u64)bt->B * bt->pn_tiles;
+    hipLaunchKernelGGL((sa_k_phrase_tiles<SA_PTILE, SA_PTHREADS>), dim3((u32)n_items), dim3(SA_PTHREADS), 0, st, p);
+    return SA_OK;
+}
+
+extern "C" int sa_phrase_batch_create(sa_index_t* ix, const uint32_t* terms, const int32_t* n_terms, const float* idf,
+                                      int n_phrases, int max_terms, int k, float k1, float b, sa_batch_t** out) {
+    SA_ARG(ix && out && terms && n_terms && idf, "null argument");
+    SA_ARG(n_phrases > 0 && max_terms >= 2, "empty batch");
+    SA_ARG(k > 0 && k <= SA_KMAX, "k must be in [1, 1024]");
+    SA_ARG(ix->doc_base + ix->n_docs <= 0xFFFFFFFFull, "global doc ids must fit 32 bits for top-k");
+    const u32 B = (u32)n_phrases, T = (u32)max_terms;
+    for (u32 i = 0; i < B; i++) {
+        // reference middle_out.py:425-426
+        if (n_terms[i] < 2) { sa_set_error("Must have at least two terms"); return SA_ERR_ARG; }
+        SA_ARG(n_terms[i] <= max_terms, "n_terms[i] > max_terms");
+        if (n_terms[i] > SA_PHRASE_BATCH_MAXT) {
+            sa_set_error("phrase batches support at most %d terms per phrase", SA_PHRASE_BATCH_MAXT);
+            return SA_ERR_UNSUPPORTED;
+        }
+        for (int t = 0; t < n_terms[i]; t++)
+            for (int u = 0; u < t; u++)
+                if (terms[(size_t)i * T + t] == terms[(size_t)i * T + u] && terms[(size_t)i * T + t] < ix->n_terms) {
+                    sa_set_error("phrase batches need pairwise-distinct terms per phrase (use sa_index_bm25_phrase_dense)");
+                    return SA_ERR_UNSUPPORTED;
+                }
+    }
+    std::lock_guard<std::mutex> g(ix->mu);
+    SA_HIP(hipSetDevice(ix->device));
+    sa_batch* bt = new (std::nothrow) sa_batch();
+    if (!bt) { sa_set_error("out of host memory"); return SA_ERR_NOMEM; }
+    bt->ix = ix; bt->B = B; bt->T = T; bt->k = (u32)k; bt->k1 = k1; bt->b = b;
+    bt->kind = 1;
+    bt->ptile = SA_PTILE;
+    bt->pn_tiles = (u32)((ix->n_docs + SA_PTILE - 1) / SA_PTILE);
+    bt->perm.resize(B);
+    for (u32 i = 0; i < B; i++) bt->perm[i] = i;
+    // plan per phrase (host): reference compute_phrase_freqs, middle_out.py:154-168
+    std::vector<u32> plan((size_t)B * 4, 0);
+    std::vector<u32> h_terms((size_t)B * T, SA_NO_TERM);
+    bt->alg_bytes = 0; bt->postings_bytes = 0;
+    for (u32 i = 0; i < B; i++) {
+        const int Tq = n_terms[i];
+        u64 lens[SA_PHRASE_BATCH_MAXT];
+        bool known = true;
+        for (int t = 0; t < Tq; t++) {
+            const u32 term = terms[(size_t)i * T + t];
+            h_terms[(size_t)i * T + t] = term;
+            if (term >= ix->n_terms) { known = false; lens[t] = 0; continue; }
+            lens[t] = ix->h_term_off[term + 1] - ix->h_term_off[term];
+            bt->postings_bytes += 8 * lens[t];
+        }
+        if (!known) continue;                          // plan[0] == 0: no match anywhere
+        int shortest = 0;
+        for (int t = 1; t < Tq; t++) if (lens[t] < lens[shortest]) shortest = t;   // first shortest on ties
+        const bool whole = shortest <= 1 || shortest >= Tq - 2;
+        const u32 split = whole ? 0u : (u32)shortest;
+        auto anchor_of = [&](int a, int e) {
+            int best = a;
+            for (int t = a + 1; t < e; t++) if (lens[t] < lens[best]) best = t;
+            return (u32)(best - a);
+        };
+        plan[(size_t)i * 4 + 0] = (u32)Tq;
+        plan[(size_t)i * 4 + 1] = split;
+        plan[(size_t)i * 4 + 2] = split ? anchor_of(0, (int)split) : anchor_of(0, Tq);
+        plan[(size_t)i * 4 + 3] = split ? anchor_of((int)split, Tq) : 0u;
+    }
+    bt->alg_bytes = bt->postings_bytes;
+    auto fail = [&](int code) { sa_batch_free(bt); return code; };
+#define SA_HIP_B(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { sa_set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return fail(SA_ERR_HIP); } } while (0)
+    SA_HIP_B(hipMalloc(&bt->d_terms, h_terms.size() * sizeof(u32)));
+    SA_HIP_B(hipMalloc(&bt->d_idf, (size_t)B * sizeof(float)));
+    SA_HIP_B(hipMalloc(&bt->d_perm, (size_t)B * sizeof(u32)));
+    SA_HIP_B(hipMalloc(&bt->d_plan, plan.size() * sizeof(u32)));
+    SA_HIP_B(hipMalloc(&bt->d_wbounds, ((size_t)B * T * (bt->pn_tiles + 1) + 1) * sizeof(u32)));
+    SA_HIP_B(hipMalloc(&bt->d_wbase, (size_t)B * T * sizeof(u64)));
+    SA_HIP_B(hipMemcpy(bt->d_perm, bt->perm.data(), (size_t)B * sizeof(u32), hipMemcpyHostToDevice));
+    SA_HIP_B(hipMemcpy(bt->d_terms, h_terms.data(), h_terms.size() * sizeof(u32), hipMemcpyHostToDevice));
+    SA_HIP_B(hipMemcpy(bt->d_idf, idf, (size_t)B * sizeof(float), hipMemcpyHostToDevice));
+    SA_HIP_B(hipMemcpy(bt->d_plan, plan.data(), plan.size() * sizeof(u32), hipMemcpyHostToDevice));
+    if (sa_batch_alloc_topk(bt, bt->pn_tiles, SA_PTHREADS / SA_WAVE) != SA_OK) return fail(SA_ERR_HIP);
+    {
+        const u64 total = (u64)B * T * (bt->pn_tiles + 1);
+        const u32 grid = total / 256 + 1 < 65535 ? (u32)(total / 256 + 1) : 65535u;
+        hipLaunchKernelGGL(sa_k_make_word_bounds, dim3(grid), dim3(256), 0, ix->stream, ix->d_words, ix->d_term_off,
+                           ix->n_terms, bt->pn_tiles, (u32)SA_PTILE, (const u32*)bt->d_terms, B * T, bt->d_wbounds,
+                           bt->d_wbase);
+    }
+    SA_HIP_B(hipStreamSynchronize(ix->stream));
+    SA_HIP_B(hipGetLastError());
+#undef SA_HIP_B
+    *out = bt;
+    return SA_OK;
+}

@@ -80,3 +80,122 @@ __device__ __forceinline__ void sa_block_bitonic_desc(u64* a, u32 n_pow2) {
     }
     __syncthreads();
 }
+
+// ---------------------------------------------------------------------------------------
+// Pruned wave-level top-k of one scored tile (shared by the BM25 and the phrase tile kernels).
+//
+// `acc` holds the TILE fp32 scores of this workgroup's tile in LDS (thread tid owns elements
+// j * THREADS + tid); `doc0` is the global doc id of element 0.  Per query, 32 global slots each
+// hold a score that `rr = ceil(k/32)` distinct docs of ONE wave reach (the rr-th largest per-lane
+// maximum of that wave), taken over 32 disjoint families of waves (slot = wave index mod 32).  So
+// G = min(slots) is a score at least 32 * rr >= k distinct docs reach: nothing below G can enter
+// the top-k.  A wave whose maximum is below G (almost every wave once the first tiles have run) is
+// done after one DPP reduction.  Otherwise it appends its elements >= G -- all of them when there
+// are at most k, else its exact top-k by k rounds of a wave-wide arg-max -- to the query's
+// candidate list (cand[q * cand_cap ...], cursor cand_cnt[q]).  Stale slot reads only weaken the
+// pruning (slots grow monotonically); the final top-k is exact and deterministic.
+// `slot_val`: lanes 0..31 of every wave hold slots[q*32 + lane] (loaded early by the caller to
+// hide the latency), the other lanes 0xFFFFFFFF.  No barriers inside: waves finish independently.
+template <int TILE, int THREADS>
+__device__ __forceinline__ void sa_tile_topk_pruned(float* acc, u32 slot_val, u32 q, u32 tile, u64 doc0, u32 k,
+                                                    u32* __restrict__ slots, u64* __restrict__ cand, u32 cand_cap,
+                                                    u32* __restrict__ cand_cnt) {
+    constexpr int NW = THREADS / SA_WAVE;
+    constexpr int E = TILE / THREADS;
+    const u32 tid = threadIdx.x;
+    const u32 lane = tid & (SA_WAVE - 1), wave = tid / SA_WAVE;
+    u32 lmax = 0;
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        const u32 x = __float_as_uint(acc[j * THREADS + tid]);
+        lmax = x > lmax ? x : lmax;
+    }
+    const u32 wmax = sa_wave_max_u32(lmax);
+    const u32 g = sa_wave_min_u32(slot_val);
+    const u32 thr = g > 1u ? g : 1u;
+    if (wmax < thr) return;                                    // wave-uniform
+#define SA_ELEM(j) ((u32)(j) * THREADS + tid)
+    const u32 widx = tile * NW + wave;
+    {
+        // slot update: the rr-th largest lane maximum (lanes counted individually)
+        const u32 my_slot = (u32)__shfl((int)slot_val, (int)(widx & 31u), SA_WAVE);
+        if (wmax > my_slot) {                                 // wave-uniform
+            const u32 rr = (k + 31u) / 32u;
+            u32 v = lmax, cnt = 0, mr = 0;
+            for (u32 it = 0; it < rr; it++) {
+                const u32 m = it == 0 ? wmax : sa_wave_max_u32(v);
+                if (m == 0) break;
+                cnt += (u32)__popcll(__ballot(v == m));
+                if (cnt >= rr) { mr = m; break; }
+                v = (v == m) ? 0u : v;
+            }
+            if (lane == 0 && mr > my_slot) atomicMax(&slots[q * 32u + (widx & 31u)], mr);
+        }
+    }
+    u64* qcand = cand + (u64)q * cand_cap;
+    const u64 lt = (1ull << lane) - 1ull;
+    u32 c = 0;
+#pragma unroll
+    for (int j = 0; j < E; j++)
+        c += (u32)__popcll(__ballot(__float_as_uint(acc[SA_ELEM(j)]) >= thr));
+    if (c <= k) {
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(&cand_cnt[q], c);
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const u32 e = SA_ELEM(j);
+            const u32 x = __float_as_uint(acc[e]);
+            const bool keep = x >= thr;
+            const u64 b = __ballot(keep);
+            if (keep) {
+                const u32 pos = base + (u32)__popcll(b & lt);
+                const u64 doc = doc0 + e;
+                if (pos < cand_cap) qcand[pos] = ((u64)x << 32) | (u64)(u32)(~(u32)doc);
+            }
+            base += (u32)__popcll(b);
+        }
+        return;
+    }
+    // more than k survivors (first tiles of a query, or heavy ties): exact top-k of this wave.
+    // Each lane tracks its best and second best element in registers (branch-free); the tile
+    // is rescanned only when one lane wins twice in a row of promotions.
+    u32 cbase = 0;
+    if (lane == 0) cbase = atomicAdd(&cand_cnt[q], k);
+    cbase = (u32)__builtin_amdgcn_readfirstlane((int)cbase);
+    u32 b1k, b1j, b2k, b2j;
+#define SA_RESCAN()                                                                   \
+    do {                                                                          \
+        b1k = 0; b1j = 0; b2k = 0; b2j = 0;                                       \
+        _Pragma("unroll") for (int j = 0; j < E; j++) {                           \
+            const u32 x = __float_as_uint(acc[SA_ELEM(j)]);                \
+            const bool g1 = x > b1k, g2 = x > b2k;                                \
+            const u32 n2k = g1 ? b1k : (g2 ? x : b2k);                            \
+            const u32 n2j = g1 ? b1j : (g2 ? (u32)j : b2j);                       \
+            b1k = g1 ? x : b1k; b1j = g1 ? (u32)j : b1j; b2k = n2k; b2j = n2j;    \
+        }                                                                         \
+    } while (0)
+    SA_RESCAN();
+    bool stale = false;                         // true: b2 already promoted, next best unknown
+    u32 found = 0;
+    for (u32 r = 0; r < k; r++) {
+        const u32 m = sa_wave_max_u32(b1k);
+        if (m == 0) break;                       // wave-uniform
+        const u32 e1 = (b1k == m) ? SA_ELEM(b1j) : 0xFFFFFFFFu;
+        const u32 emin = sa_wave_min_u32(e1);    // ties -> smallest doc id
+        found = r + 1;
+        const bool owner = (e1 == emin);
+        if (owner) {
+            acc[emin] = 0.f;
+            const u64 doc = doc0 + emin;
+            if (cbase + r < cand_cap) qcand[cbase + r] = ((u64)m << 32) | (u64)(u32)(~(u32)doc);
+        }
+        const bool need = owner && stale;
+        if (owner && !stale) { b1k = b2k; b1j = b2j; b2k = 0; stale = true; }
+        if (__any(need)) { SA_RESCAN(); stale = false; }
+    }
+#undef SA_RESCAN
+#undef SA_ELEM
+    for (u32 r = found + lane; r < k; r += SA_WAVE)           // unused reserved slots
+        if (cbase + r < cand_cap) qcand[cbase + r] = 0ull;
+}

@@ -170,6 +170,10 @@ class DeviceIndex:
               idf: Optional[np.ndarray] = None) -> "QueryBatch":
         return QueryBatch(self, queries, k=k, k1=k1, b=b, idf=idf)
 
+    def phrase_batch(self, phrases: Sequence[Sequence[int]], k: int = 10, k1: float = 1.2, b: float = 0.75,
+                     idf: Optional[np.ndarray] = None) -> "PhraseBatch":
+        return PhraseBatch(self, phrases, k=k, k1=k1, b=b, idf=idf)
+
     # -- multi-GPU
     def comm_init(self, rank: int, nranks: int, unique_id: bytes):
         self.api.call("sa_index_comm_init", self._h, rank, nranks, unique_id, len(unique_id))
@@ -196,6 +200,9 @@ class QueryBatch:
             idf = flat.reshape(self.B, self.T)
         idf = as_f32(idf)
         self._h = ctypes.c_void_p()
+        self._create(index, terms, idf, k1, b)
+
+    def _create(self, index, terms, idf, k1, b):
         self.api.call("sa_batch_create", index._h, p_u32(as_u32(terms)), p_f32(idf), self.B, self.T,
                       self.k, np.float32(k1), np.float32(b), ctypes.byref(self._h))
 
@@ -232,3 +239,36 @@ class QueryBatch:
             self.close()
         except Exception:
             pass
+
+
+class PhraseBatch(QueryBatch):
+    """B exact phrases (lists of term ids, 2..18 distinct terms each) resident on the device;
+    ``run()`` scores every phrase with BM25 over its match counts and keeps the top k docs.
+
+    Same result contract as :class:`QueryBatch`; the dense single-phrase drop-in is
+    :meth:`DeviceIndex.bm25_phrase_dense` (reference ``SearchArray.score([...])``)."""
+
+    def __init__(self, index: DeviceIndex, phrases: Sequence[Sequence[int]], k: int = 10, k1: float = 1.2,
+                 b: float = 0.75, idf: Optional[np.ndarray] = None):
+        self.index = index
+        self.api = index.api
+        self.B = len(phrases)
+        if self.B == 0:
+            raise ValueError("empty phrase batch")
+        n_terms = np.asarray([len(p) for p in phrases], dtype=np.int32)
+        self.T = int(max(2, n_terms.max()))
+        self.k = int(k)
+        terms = np.full((self.B, self.T), NO_TERM, dtype=np.uint32)
+        for i, ph in enumerate(phrases):
+            row = np.asarray(ph, dtype=np.int64)
+            terms[i, :len(row)] = np.where((row >= 0) & (row < index.n_terms), row, NO_TERM)
+        if idf is None:
+            # idf of a phrase: float64 sum over its terms, then float32 (reference similarity.py:19-21)
+            idf = np.asarray([compute_idf(index.corpus_size,
+                                          np.asarray([index.docfreq(int(t)) if 0 <= int(t) < index.n_terms else 0
+                                                      for t in ph])) for ph in phrases], dtype=np.float32)
+        self._n_terms = n_terms
+        self._h = ctypes.c_void_p()
+        self.api.call("sa_phrase_batch_create", index._h, p_u32(as_u32(terms)),
+                      n_terms.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), p_f32(as_f32(idf)), self.B, self.T,
+                      self.k, np.float32(k1), np.float32(b), ctypes.byref(self._h))

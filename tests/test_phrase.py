@@ -9,7 +9,7 @@ import pytest
 from oracle import refimpl as O
 from searcharray_amd import synth
 from searcharray_amd import roaringish as rz
-from searcharray_amd.device_index import DeviceIndex
+from searcharray_amd.device_index import DeviceIndex, NO_DOC
 from tests.helpers import golden_corpus, dense_from_sparse
 from tests.test_oracle_golden import PHRASE_SCENARIOS, _index_strings
 
@@ -172,3 +172,84 @@ def test_posn_range_matches_oracle(api, min_posn, max_posn):
         assert np.array_equal(got, want), (terms, slop, min_posn, max_posn)
     ids, tfs = O.popcount64_reduce(orc.posn_slice(orc.enc(0), min_posn, max_posn), 36, 0x3FFFF)
     assert np.array_equal(dev.termfreqs_dense(0, min_posn=min_posn, max_posn=max_posn), O.as_dense(ids, tfs, num_docs))
+
+
+# ---------------------------------------------------------------------------------------------
+# phrase batches: B phrases -> BM25 -> top-k on the device (sa_phrase_batch_create)
+# ---------------------------------------------------------------------------------------------
+def _check_phrase_batch(dev, orc, phrases, k, num_docs, doc_base=0):
+    bt = dev.phrase_batch(phrases, k=k)
+    for _ in range(2):                                   # a second run must reset slots / cursors
+        bt.run()
+        scores, docs = bt.fetch()
+        for i, ph in enumerate(phrases):
+            known = all(0 <= t < dev.n_terms for t in ph)
+            want = orc.score(list(ph)) if known else np.zeros(num_docs, np.float32)
+            ws, wd = O.topk(want, k)
+            n = int((ws > 0).sum())
+            assert np.array_equal(scores[i, :n], ws[:n]), f"phrase {ph}: scores"
+            assert np.array_equal(docs[i, :n], wd[:n] + doc_base), f"phrase {ph}: docs"
+            assert (docs[i, n:] == NO_DOC).all() and (scores[i, n:] == 0).all()
+    bt.close()
+
+
+@pytest.mark.parametrize("k", [1, 10, 100])
+def test_phrase_batch_matches_oracle(api, k):
+    """2..8-term distinct phrases incl. the middle-out plan (shortest list strictly inside), ragged
+    batch, an unknown term; scores bit-exact and ties broken by doc id"""
+    n_docs, vocab = 9000, 60                             # 3 phrase tiles of 4096 docs
+    t, d, p, lens = synth.corpus_triples(n_docs, vocab, 45, seed=3)
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
+    rng = np.random.default_rng(8)
+    phrases = [[0, 1], [1, 0], [3, 2, 1], [0, 5, 1, 2, 3], [4, 0, 30, 1, 2, 3], [7, 99], [2, 3]]
+    for length in (2, 3, 4, 5, 6, 8):
+        for _ in range(3):
+            phrases.append([int(x) for x in rng.choice(14, length, replace=False)])
+    # make sure at least one phrase takes the two-part plan
+    lens_w = np.diff(rz.term_offsets(wt, vocab).astype(np.int64))
+    assert any(1 < int(np.argmin(lens_w[ph])) < len(ph) - 2 for ph in phrases if max(ph) < vocab)
+    _check_phrase_batch(dev, orc, phrases, k, n_docs)
+
+
+def test_phrase_batch_golden_corpus_and_doc_base(api):
+    g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_small")
+    words, wt = rz.encode_sorted(t, d, p)
+    orc = O.OracleIndex.from_triples(t, d, p, num_docs, doc_lens=lens)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api, doc_base=50000)
+    phrases = []
+    for i in range(int(g["n_phrases"])):
+        terms = [int(x) for x in g[f"phr_{i}_terms"]]
+        if len(set(terms)) == len(terms):
+            phrases.append(terms)
+    assert len(phrases) >= 5
+    _check_phrase_batch(dev, orc, phrases, 10, num_docs, doc_base=50000)
+    # the reference's own scores for the phrases it scored (golden fixture)
+    bt = dev.phrase_batch(phrases, k=5)
+    bt.run()
+    scores, docs = bt.fetch()
+    for i in range(0, int(g["n_phrases"]), 5):
+        terms = [int(x) for x in g[f"phr_{i}_terms"]]
+        if terms not in phrases:
+            continue
+        wants = dense_from_sparse(g[f"phr_{i}_sidx"], g[f"phr_{i}_sval"], num_docs)
+        ws, wd = O.topk(wants, 5)
+        n = int((ws > 0).sum())
+        j = phrases.index(terms)
+        assert np.array_equal(scores[j, :n], ws[:n]) and np.array_equal(docs[j, :n], wd[:n] + 50000)
+    bt.close()
+
+
+def test_phrase_batch_errors(api):
+    vocab, dev = _device_from_strings(["foo bar baz", "bar baz foo"], api)
+    with pytest.raises(Exception, match="at least two terms"):
+        dev.phrase_batch([[0]], k=3)
+    with pytest.raises(Exception, match="distinct"):
+        dev.phrase_batch([[0, 1, 0]], k=3)
+    bt = dev.phrase_batch([[vocab["foo"], vocab["bar"]], [vocab["bar"], vocab["baz"]]], k=3)
+    bt.run()
+    scores, docs = bt.fetch()
+    assert list(docs[0, :1]) == [0] and docs[0, 1] == NO_DOC
+    assert list(docs[1]) == [0, 1, NO_DOC]
+    bt.close()
