@@ -21,10 +21,10 @@
 // header, and the final sorted slice never reaches it.  The goldens (outputs of the reference
 // itself) pin this: e.g. query [8, 1, 3] on tests/golden/zipf_small.
 //
-// Stage 2 runs one thread per document group (documents are independent).  The k-th thread takes
-// the k-th document group of EVERY term -- the reference walks the terms' cursors in lock step
+// Stage 2 runs one thread per document group (documents are independent), a resident grid of
+// threads striding over the groups.  A thread takes the k-th document group of EVERY term -- the reference walks the terms' cursors in lock step
 // (spans.pyx:223-304) and does not re-align them by key -- and replays the state machine with the
-// span table in a per-thread slab of global memory.  Two quirks of the reference are part of the
+// span table in a per-thread column of a global slab (16-byte entries, interleaved across threads).  Two quirks of the reference are part of the
 // observable behaviour and are reproduced: position bits are `1 << (p % 64)` evaluated as a 32-bit
 // shift (count mod 32, sign-extended), and a rejected extension leaves its position bit set.
 // A document that fills the 512-entry table is undefined behaviour in the reference (it indexes
@@ -33,63 +33,104 @@
 #include "sa_index.hpp"
 #include "sa_scan.hpp"
 #include "../../include/searcharray_hip.h"
+#include <stdlib.h>
 
 #define SA_SPAN_MAX_TERMS 16
 #define SA_NSPANS 512
-#define SA_SPAN_CHUNK_DOCS 8192          // documents per state-machine launch (20 KiB of span table each)
+#define SA_SPAN_THREADS 65536            // resident state-machine threads (12 KiB of span table each)
 
 struct SpanTerms {
     const u64* words[SA_SPAN_MAX_TERMS];
     u32 len[SA_SPAN_MAX_TERMS];
+    u32 off[SA_SPAN_MAX_TERMS + 1];      // prefix sums of len: position of each term in the flag array
     int T;
 };
 
-__device__ __forceinline__ bool sa_has_header(const u64* __restrict__ a, u32 n, u64 h) {
-    const u32 j = sa_lower_bound(a, 0, n, h, SA_HEADER_MASK);
-    return j < n && (a[j] & SA_HEADER_MASK) == h;
-}
-
-__device__ bool sa_span_Lset(const SpanTerms& st, u64 h) {
+// Membership of the three headers h-1, h, h+1 (in units of one 18-position block) in a sorted word
+// list: bit 0 / 1 / 2.  One lower-bound search; the three headers are neighbours in sorted order.
+// The reference's unsigned arithmetic wraps at both ends (h-1 of header 0, h+1 of the largest
+// header); the wrapped values are looked up like any other header, as numpy does.
+__device__ __forceinline__ u32 sa_header_triple(const u64* __restrict__ a, u32 n, u64 h) {
     const u64 unit = 1ull << SA_LSB_BITS;
-    const bool a0 = sa_has_header(st.words[0], st.len[0], h);
-    const bool a0m = sa_has_header(st.words[0], st.len[0], h - unit);
-    for (int i = 1; i < st.T; i++) {
-        const bool bi = sa_has_header(st.words[i], st.len[i], h);
-        const bool bim = sa_has_header(st.words[i], st.len[i], h - unit);
-        if (!((a0 && bi) || (bi && a0m) || (a0 && bim))) return false;
+    if (n == 0) return 0;
+    const u64 hm = h - unit, hp = h + unit;
+    u32 bits = 0;
+    if (h == 0) {                                    // h-1 wrapped to the largest header
+        if ((a[n - 1] & SA_HEADER_MASK) == hm) bits |= 1u;
     }
-    return true;
+    if (hp == 0) {                                   // h+1 wrapped to header 0
+        if ((a[0] & SA_HEADER_MASK) == 0) bits |= 4u;
+    }
+    u32 j = sa_lower_bound(a, 0, n, h == 0 ? h : hm, SA_HEADER_MASK);
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        if (j >= n) break;
+        const u64 x = a[j] & SA_HEADER_MASK;
+        if (h != 0 && x == hm) bits |= 1u;
+        else if (x == h) bits |= 2u;
+        else if (hp != 0 && x == hp) bits |= 4u;
+        else break;
+        j++;
+    }
+    return bits;
 }
 
-__device__ bool sa_span_Rset(const SpanTerms& st, u64 h) {
-    const u64 unit = 1ull << SA_LSB_BITS;
-    const bool a0 = sa_has_header(st.words[0], st.len[0], h);
-    const bool a0p = sa_has_header(st.words[0], st.len[0], h + unit);
-    for (int i = 1; i < st.T; i++) {
-        const bool bi = sa_has_header(st.words[i], st.len[i], h);
-        const bool bip = sa_has_header(st.words[i], st.len[i], h + unit);
-        if (!((a0 && bi) || (a0 && bip) || (bi && a0p))) return false;
+// candidate predicate of one header (see the top of the file); m[i] = sa_header_triple of term i
+__device__ __forceinline__ bool sa_span_keep(const u32* m, int T, bool wrap) {
+    const bool a0m = m[0] & 1u, a0 = m[0] & 2u, a0p = m[0] & 4u;
+    bool L = true, R = true, Rm = true, Lp = true;   // L(h), R(h), R(h-1), L(h+1)
+    for (int i = 1; i < T; i++) {
+        const bool bim = m[i] & 1u, bi = m[i] & 2u, bip = m[i] & 4u;
+        L &= (a0 && bi) || (bi && a0m) || (a0 && bim);
+        R &= (a0 && bi) || (a0 && bip) || (bi && a0p);
+        Rm &= (a0m && bim) || (a0m && bi) || (bim && a0);
+        Lp &= (a0p && bip) || (bip && a0) || (a0p && bi);
     }
-    return true;
+    return L || R || Rm || (!wrap && Lp);
 }
 
+// header 0 in L?  (the `L - 1` widening is lost then, see the top of the file)
 __global__ void sa_k_span_wrap_flag(const SpanTerms st, u32* __restrict__ wrap) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *wrap = sa_span_Lset(st, 0ull) ? 1u : 0u;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    bool L = true;
+    const u32 m0 = sa_header_triple(st.words[0], st.len[0], 0ull);
+    for (int i = 1; i < st.T; i++) {
+        const u32 mi = sa_header_triple(st.words[i], st.len[i], 0ull);
+        const bool a0m = m0 & 1u, a0 = m0 & 2u, bim = mi & 1u, bi = mi & 2u;
+        L &= (a0 && bi) || (bi && a0m) || (a0 && bim);
+    }
+    *wrap = L ? 1u : 0u;
 }
 
-// stage 1: candidate words of term t, compacted into out (stable)
-struct SpanCandidates {
-    SpanTerms st;
-    int t;
-    u64* out;
-    const u32* wrap;                // 1: header 0 is in L, the `L - 1` widening is lost (see top)
-    __device__ __forceinline__ bool flag(u32 i) const {
-        const u64 unit = 1ull << SA_LSB_BITS;
-        const u64 h = st.words[t][i] & SA_HEADER_MASK;
-        if (sa_span_Lset(st, h) || sa_span_Rset(st, h) || sa_span_Rset(st, h - unit)) return true;
-        return !*wrap && sa_span_Lset(st, h + unit);
+// stage 1a: keep-flag of every word of every term (one launch; the predicate costs one search
+// per phrase term and is evaluated once, the compactions below only read the flags)
+__global__ void __launch_bounds__(256)
+sa_k_span_flags(const SpanTerms st, const u32* __restrict__ wrap, unsigned char* __restrict__ flags) {
+    const u32 total = st.off[st.T];
+    const bool wr = *wrap != 0;
+    for (u32 g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
+        int t = 0;
+        while (t + 1 < st.T && g >= st.off[t + 1]) t++;
+        const u64 h = st.words[t][g - st.off[t]] & SA_HEADER_MASK;
+        u32 m[SA_SPAN_MAX_TERMS];
+        bool possible = true;
+        for (int i = 0; i < st.T; i++) m[i] = 0;
+        for (int i = 0; i < st.T && possible; i++) {
+            m[i] = sa_header_triple(st.words[i], st.len[i], h);
+            // every set needs term 0 and term i around h: nothing there -> no candidate
+            if (m[i] == 0) possible = false;
+        }
+        flags[g] = (possible && sa_span_keep(m, st.T, wr)) ? 1 : 0;
     }
-    __device__ __forceinline__ void emit(u32 i, u32 pos) const { out[pos] = st.words[t][i]; }
+}
+
+// stage 1b: candidate words of term t, compacted into out (stable)
+struct SpanCandidates {
+    const u64* words;
+    const unsigned char* flags;
+    u64* out;
+    __device__ __forceinline__ bool flag(u32 i) const { return flags[i] != 0; }
+    __device__ __forceinline__ void emit(u32 i, u32 pos) const { out[pos] = words[i]; }
 };
 
 // document-group heads of a compacted candidate array
@@ -99,6 +140,11 @@ struct DocHeads {
     __device__ __forceinline__ void emit(u32 i, u32 pos) const { out[pos] = i; }
 };
 
+// One active span: term set, position-bit set, first and last position.  The reference keeps four
+// uint64 / int64 arrays; 16 bytes hold the same information (<= 16 terms; the position mask is a
+// sign-extended int32, see sa_posn_mask32; positions are < 2^23), so a span is one 16-byte access.
+struct alignas(16) SpanEnt { u32 terms; int posns; int beg; int end; };
+
 struct SpanMachineParams {
     const u64* cand[SA_SPAN_MAX_TERMS];       // candidate words of each term
     const u32* n_cand[SA_SPAN_MAX_TERMS];     // device lengths
@@ -106,116 +152,123 @@ struct SpanMachineParams {
     const u32* n_heads[SA_SPAN_MAX_TERMS];
     int T;
     u32 slop;
-    u32 doc_begin;                            // first group handled by this launch
-    u64* slab;                                // [SA_SPAN_CHUNK_DOCS][5][SA_NSPANS]: terms, posns, beg, end, collected
+    u32 n_threads;                            // G: resident threads, thread g owns column g of the slabs
+    SpanEnt* ents;                            // [SA_NSPANS][G] span tables, interleaved for coalescing
+    u64* col;                                 // [SA_NSPANS][G] collected (beg, end) pairs
     u32* counts;                              // dense per-doc counts (atomically accumulated)
     u64 n_docs;
 };
 
-__device__ __forceinline__ u64 sa_posn_mask(i64 p) {
-    // reference spans.pyx:108-109 as compiled: 32-bit shift, count mod 32, sign-extended
-    const int m = (int)(1u << ((u32)(p % 64) & 31u));
-    return (u64)(i64)m;
-}
+// reference spans.pyx:108-109 as compiled: `1 << (p % 64)` is a 32-bit shift (count mod 32) whose
+// int result is sign-extended to 64 bits.  Kept as the int32; OR / AND-NOT commute with the sign
+// extension, and the 64-bit popcount is recovered by sa_popc_sext.
+__device__ __forceinline__ int sa_posn_mask32(int p) { return (int)(1u << ((u32)(p % 64) & 31u)); }
+__device__ __forceinline__ u32 sa_popc_sext(int v) { return (u32)__popc((u32)v) + (v < 0 ? 32u : 0u); }
+__device__ __forceinline__ int sa_iabs32(int v) { return v < 0 ? -v : v; }
 
-__device__ __forceinline__ i64 sa_iabs(i64 v) { return v < 0 ? -v : v; }
-
+// Stage 2: the k-th thread takes the k-th, (k+G)-th, ... document group of EVERY term.
 __global__ void __launch_bounds__(64) sa_k_span_machine(const SpanMachineParams p) {
-    const u32 local = blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 k = p.doc_begin + local;
-    if (local >= SA_SPAN_CHUNK_DOCS || k >= *p.n_heads[0]) return;
-    u64* s_terms = p.slab + (u64)local * 5 * SA_NSPANS;
-    u64* s_posns = s_terms + SA_NSPANS;
-    i64* s_beg = (i64*)(s_posns + SA_NSPANS);
-    i64* s_end = s_beg + SA_NSPANS;
-    const u64 num_terms = (u64)p.T;
-    const u64 max_span_width = num_terms + p.slop;
-    u32 cursor = 0;
-    bool full = false;
-    u64 last_key = 0;
-    u64 sum_pop[SA_SPAN_MAX_TERMS];
-
-    for (int t = 0; t < p.T; t++) {
-        sum_pop[t] = 0;
-        const u32 ng = *p.n_heads[t];
-        if (k >= ng) continue;                                   // this term has no k-th document group
-        const u32 lo = p.heads[t][k];
-        const u32 hi = (k + 1 < ng) ? p.heads[t][k + 1] : *p.n_cand[t];
-        const u64 curr_term_mask = 1ull << t;
-        bool gave_up = false;
-        for (u32 wi = lo; wi < hi && !gave_up; wi++) {
-            const u64 w = p.cand[t][wi];
-            last_key = w >> SA_KEY_SHIFT;
-            const u64 payload_base = ((w >> SA_LSB_BITS) & SA_LSB_MASK) * SA_LSB_BITS;
-            u64 bits = w & SA_LSB_MASK;
-            sum_pop[t] += (u64)__popcll(bits);
-            while (bits != 0) {
-                const i64 curr_posn = (i64)(payload_base + (u64)(__ffsll((long long)bits) - 1));
-                bits &= bits - 1;
-                const u64 posn_mask = sa_posn_mask(curr_posn);
-                if (cursor >= SA_NSPANS) { full = true; break; }
-                s_terms[cursor] = curr_term_mask; s_posns[cursor] = posn_mask;
-                s_beg[cursor] = curr_posn; s_end[cursor] = curr_posn;
-                const u32 end = cursor;
-                cursor++;
-                for (u32 si = 0; si < end; si++) {
-                    const u64 st = s_terms[si], sp = s_posns[si];
-                    const u64 nt = (u64)__popcll(st), np = (u64)__popcll(sp);
-                    if (nt < num_terms && np == num_terms) continue;
-                    if (st & curr_term_mask) continue;           // term already in the span: nothing changes
-                    const u64 sp2 = sp | posn_mask;
-                    s_posns[si] = sp2;                           // the position bit stays even if rejected
-                    const u64 new_unique = (u64)__popcll(sp2);
-                    const u64 proposed = (u64)sa_iabs(curr_posn - s_beg[si]);
-                    if (np == new_unique || proposed > max_span_width) continue;
-                    s_terms[si] = st | curr_term_mask;
-                    if (cursor < SA_NSPANS) {
-                        s_terms[cursor] = st | curr_term_mask; s_posns[cursor] = sp2 & ~posn_mask;
-                        s_beg[cursor] = s_beg[si]; s_end[cursor] = s_end[si];
-                        cursor++;
-                        full = false;
-                    } else {
-                        full = true;
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 G = p.n_threads;
+    if (g >= G) return;
+    const u32 n_groups = *p.n_heads[0];
+    SpanEnt* ents = p.ents + g;
+    u64* col = p.col + g;
+    const u32 num_terms = (u32)p.T;
+    const int max_span_width = (int)(num_terms + p.slop);
+    for (u32 k = g; k < n_groups; k += G) {
+        u32 cursor = 0;
+        bool full = false;
+        u64 last_key = 0;
+        u32 sum_pop[SA_SPAN_MAX_TERMS];
+        for (int t = 0; t < p.T; t++) {
+            sum_pop[t] = 0;
+            const u32 ng = *p.n_heads[t];
+            if (k >= ng) continue;                                   // this term has no k-th document group
+            const u32 lo = p.heads[t][k];
+            const u32 hi = (k + 1 < ng) ? p.heads[t][k + 1] : *p.n_cand[t];
+            const u32 curr_term_mask = 1u << t;
+            bool gave_up = false;
+            for (u32 wi = lo; wi < hi && !gave_up; wi++) {
+                const u64 w = p.cand[t][wi];
+                last_key = w >> SA_KEY_SHIFT;
+                const int payload_base = (int)(((w >> SA_LSB_BITS) & SA_LSB_MASK) * SA_LSB_BITS);
+                u32 bits = (u32)(w & SA_LSB_MASK);
+                sum_pop[t] += (u32)__popc(bits);
+                while (bits != 0) {
+                    const int curr_posn = payload_base + (__ffs((int)bits) - 1);
+                    bits &= bits - 1;
+                    const int posn_mask = sa_posn_mask32(curr_posn);
+                    if (cursor >= SA_NSPANS) { full = true; break; }
+                    SpanEnt fresh;
+                    fresh.terms = curr_term_mask; fresh.posns = posn_mask; fresh.beg = curr_posn; fresh.end = curr_posn;
+                    ents[(u64)cursor * G] = fresh;
+                    const u32 end = cursor;
+                    cursor++;
+                    for (u32 si = 0; si < end; si++) {
+                        SpanEnt e = ents[(u64)si * G];
+                        const u32 nt = (u32)__popc(e.terms), np = sa_popc_sext(e.posns);
+                        if (nt < num_terms && np == num_terms) continue;
+                        if (e.terms & curr_term_mask) continue;          // term already in the span: nothing changes
+                        const int sp2 = e.posns | posn_mask;
+                        const u32 new_unique = sa_popc_sext(sp2);
+                        const int proposed = sa_iabs32(curr_posn - e.beg);
+                        if (np == new_unique || proposed > max_span_width) {
+                            if (sp2 != e.posns) { e.posns = sp2; ents[(u64)si * G] = e; }   // the position bit stays even if rejected
+                            continue;
+                        }
+                        if (cursor < SA_NSPANS) {
+                            SpanEnt fork;
+                            fork.terms = e.terms | curr_term_mask; fork.posns = sp2 & ~posn_mask;
+                            fork.beg = e.beg; fork.end = e.end;
+                            ents[(u64)cursor * G] = fork;
+                            cursor++;
+                            full = false;
+                        } else {
+                            full = true;
+                        }
+                        e.terms |= curr_term_mask; e.posns = sp2; e.end = curr_posn;
+                        ents[(u64)si * G] = e;
                     }
-                    s_end[si] = curr_posn;
+                    if (cursor >= SA_NSPANS) break;
                 }
-                if (cursor >= SA_NSPANS) break;
+                // reference compaction (spans.pyx:140-154) never removes a span (widths are bounded by
+                // construction), so a full table stays full: skip the rest of this term's words
+                if (cursor >= SA_NSPANS) gave_up = true;
             }
-            // reference compaction (spans.pyx:140-154) never removes a span (widths are bounded by
-            // construction), so a full table stays full: skip the rest of this term's words
-            if (cursor >= SA_NSPANS) gave_up = true;
         }
-    }
-    u32 incr;
-    if (full) {
-        u64 mn = 0;
-        for (int t = 0; t < p.T; t++) if (mn == 0 || sum_pop[t] < mn) mn = sum_pop[t];
-        incr = (u32)mn;
-    } else {
-        // _collect_spans, spans.pyx:157-186: walk the spans in order; a complete span narrower than
-        // max_width either replaces the first collected span it overlaps AND is shorter than, or is
-        // appended.  Collected (beg, end) pairs are packed into the fifth 512-entry lane of the slab.
-        u64* col = (u64*)(s_end + SA_NSPANS);
-        u32 ncol = 0;
-        for (u32 si = 0; si < cursor; si++) {
-            const bool complete = ((u64)__popcll(s_terms[si]) == num_terms) || ((u64)__popcll(s_posns[si]) == num_terms);
-            const i64 b = s_beg[si], e = s_end[si];
-            const i64 width = sa_iabs(e - b);
-            if (!complete || (u64)width >= max_span_width) continue;
-            bool replaced = false;
-            for (u32 c = 0; c < ncol; c++) {
-                const i64 cb = (i64)(col[c] >> 32), ce = (i64)(col[c] & 0xFFFFFFFFull);
-                if (b <= ce && e >= cb && width < sa_iabs(ce - cb)) {
-                    col[c] = ((u64)b << 32) | (u64)e;
-                    replaced = true;
-                    break;
+        u32 incr;
+        if (full) {
+            u32 mn = 0;
+            for (int t = 0; t < p.T; t++) if (mn == 0 || sum_pop[t] < mn) mn = sum_pop[t];
+            incr = mn;
+        } else {
+            // _collect_spans, spans.pyx:157-186: walk the spans in order; a complete span narrower than
+            // max_width either replaces the first collected span it overlaps AND is shorter than, or is
+            // appended.
+            u32 ncol = 0;
+            for (u32 si = 0; si < cursor; si++) {
+                const SpanEnt e = ents[(u64)si * G];
+                const bool complete = ((u32)__popc(e.terms) == num_terms) || (sa_popc_sext(e.posns) == num_terms);
+                const int b = e.beg, en = e.end;
+                const int width = sa_iabs32(en - b);
+                if (!complete || width >= max_span_width) continue;
+                bool replaced = false;
+                for (u32 c = 0; c < ncol; c++) {
+                    const u64 cc = col[(u64)c * G];
+                    const int cb = (int)(cc >> 32), ce = (int)(cc & 0xFFFFFFFFull);
+                    if (b <= ce && en >= cb && width < sa_iabs32(ce - cb)) {
+                        col[(u64)c * G] = ((u64)(u32)b << 32) | (u64)(u32)en;
+                        replaced = true;
+                        break;
+                    }
                 }
+                if (!replaced) { col[(u64)ncol * G] = ((u64)(u32)b << 32) | (u64)(u32)en; ncol++; }
             }
-            if (!replaced) col[ncol++] = ((u64)b << 32) | (u64)e;
+            incr = ncol;
         }
-        incr = ncol;
+        if (incr && last_key < p.n_docs) atomicAdd(&p.counts[last_key], incr);
     }
-    if (incr && last_key < p.n_docs) atomicAdd(&p.counts[last_key], incr);
 }
 
 __global__ void __launch_bounds__(256)
@@ -241,10 +294,17 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
         total_len += terms_dev.len[t];
         if (terms_dev.len[t] > max_len) max_len = terms_dev.len[t];
     }
-    const size_t slab_words = (size_t)SA_SPAN_CHUNK_DOCS * 5 * SA_NSPANS;
+    if (total_len > 0xFFFFFFF0ull) { sa_set_error("slop phrase: more than 2^32 words in the phrase's terms"); return SA_ERR_UNSUPPORTED; }
+    // resident state-machine threads: no more than there can be document groups
+    u32 G = (u32)((terms_dev.len[0] + 63u) & ~63u);
+    u32 g_max = SA_SPAN_THREADS;
+    if (const char* v = getenv("SA_SPAN_THREADS")) { const int x = atoi(v); if (x >= 64) g_max = ((u32)x + 63u) & ~63u; }   // tests: force the stride loop
+    if (G > g_max) G = g_max;
+    if (G == 0) G = 64;
+    const size_t slab_bytes = (size_t)G * SA_NSPANS * (sizeof(SpanEnt) + sizeof(u64));
     const size_t chunk_words = sa_compact_chunks((u32)(max_len + 1)) + 8;
     const size_t filt_bytes = filt.active ? (total_len + 64 * (size_t)T) * 8 : 0;
-    const size_t need = (N + 64) * 8 + (total_len + 64 * T) * 12 + slab_words * 8 + chunk_words * 4 + filt_bytes + 64 * 1024;
+    const size_t need = (N + 64) * 8 + (total_len + 64 * T) * 13 + slab_bytes + chunk_words * 4 + filt_bytes + 64 * 1024;
     void* scratch;
     SA_TRY(sa_index_scratch(ix, need, &scratch));
     char* base = (char*)scratch;
@@ -254,7 +314,9 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
     u32* counts = (u32*)take((N + 1) * 4);
     u32* cnt = (u32*)take(4 * SA_SPAN_MAX_TERMS * 4);          // [t] n_cand, [16 + t] n_heads, [32] wrap flag
     u32* chunks = (u32*)take(chunk_words * 4);
-    u64* slab = (u64*)take(slab_words * 8);
+    SpanEnt* ents = (SpanEnt*)take((size_t)G * SA_NSPANS * sizeof(SpanEnt));
+    u64* col = (u64*)take((size_t)G * SA_NSPANS * sizeof(u64));
+    unsigned char* flags = (unsigned char*)take(total_len + 64);
     *d_out = running;
     SA_HIP(hipMemsetAsync(running, 0, N * sizeof(float), st));
     SA_HIP(hipMemsetAsync(counts, 0, N * sizeof(u32), st));
@@ -273,11 +335,17 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
         SA_HIP(hipMemsetAsync(cnt, 0, 3 * SA_SPAN_MAX_TERMS * 4, st));
         for (int t = 0; t < T; t++) { terms_dev.words[t] = ptrs[t]; terms_dev.len[t] = lens[t]; }
     }
-
+    terms_dev.off[0] = 0;
+    for (int t = 0; t < T; t++) terms_dev.off[t + 1] = terms_dev.off[t] + terms_dev.len[t];
     hipLaunchKernelGGL(sa_k_span_wrap_flag, dim3(1), dim3(64), 0, st, terms_dev, cnt + 2 * SA_SPAN_MAX_TERMS);
+    {
+        const u32 total = terms_dev.off[T];
+        const u32 grid = total / 256 + 1 < 16384 ? total / 256 + 1 : 16384;
+        hipLaunchKernelGGL(sa_k_span_flags, dim3(grid), dim3(256), 0, st, terms_dev, (const u32*)(cnt + 2 * SA_SPAN_MAX_TERMS), flags);
+    }
     SpanMachineParams mp;
     memset(&mp, 0, sizeof(mp));
-    mp.T = T; mp.slop = (u32)slop; mp.slab = slab; mp.counts = counts; mp.n_docs = N;
+    mp.T = T; mp.slop = (u32)slop; mp.ents = ents; mp.col = col; mp.counts = counts; mp.n_docs = N; mp.n_threads = G;
     for (int t = 0; t < T; t++) {
         u64* cand = (u64*)take(((size_t)terms_dev.len[t] + 1) * 8);
         u32* heads = (u32*)take(((size_t)terms_dev.len[t] + 1) * 4);
@@ -285,20 +353,13 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
         mp.cand[t] = cand; mp.n_cand[t] = cnt + t; mp.heads[t] = heads; mp.n_heads[t] = cnt + SA_SPAN_MAX_TERMS + t;
         if (terms_dev.len[t] == 0) continue;
         SpanCandidates sc;
-        sc.st = terms_dev; sc.t = t; sc.out = cand; sc.wrap = cnt + 2 * SA_SPAN_MAX_TERMS;
+        sc.words = terms_dev.words[t]; sc.flags = flags + terms_dev.off[t]; sc.out = cand;
         sa_compact(sc, (const u32*)nullptr, terms_dev.len[t], chunks, cnt + t, st);
         DocHeads dh;
         dh.words = cand; dh.out = heads;
         sa_compact(dh, cnt + t, terms_dev.len[t], chunks, cnt + SA_SPAN_MAX_TERMS + t, st);
     }
-    u32 n_groups = 0;
-    SA_HIP(hipMemcpyAsync(&n_groups, cnt + SA_SPAN_MAX_TERMS, sizeof(u32), hipMemcpyDeviceToHost, st));
-    SA_HIP(hipStreamSynchronize(st));
-    for (u32 begin = 0; begin < n_groups; begin += SA_SPAN_CHUNK_DOCS) {
-        mp.doc_begin = begin;
-        const u32 n = n_groups - begin < SA_SPAN_CHUNK_DOCS ? n_groups - begin : SA_SPAN_CHUNK_DOCS;
-        hipLaunchKernelGGL(sa_k_span_machine, dim3((n + 63) / 64), dim3(64), 0, st, mp);
-    }
+    hipLaunchKernelGGL(sa_k_span_machine, dim3(G / 64), dim3(64), 0, st, mp);
     const u64 g = (N + 255) / 256;
     hipLaunchKernelGGL(sa_k_counts_to_float, dim3((u32)(g < 8192 ? (g ? g : 1) : 8192)), dim3(256), 0, st, counts, running, N);
     return SA_OK;

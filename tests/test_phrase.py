@@ -120,6 +120,20 @@ def test_slop_counts_match_reference(api, name):
     assert np.allclose(dev.bm25_phrase_dense(terms, slop=slop), orc.score(terms, slop=slop), rtol=1e-5, atol=0)
 
 
+def test_slop_more_doc_groups_than_resident_threads(api, monkeypatch):
+    """the state-machine grid is resident (threads stride over the document groups): force a grid
+    of 64 threads over ~1500 groups"""
+    monkeypatch.setenv("SA_SPAN_THREADS", "64")
+    g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_small")
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    for i in range(0, int(g["n_slop"]), 3):
+        terms = [int(x) for x in g[f"slop_{i}_terms"]]
+        slop = int(g[f"slop_{i}_slop"])
+        want = dense_from_sparse(g[f"slop_{i}_idx"], g[f"slop_{i}_val"], num_docs)
+        assert np.array_equal(dev.phrase_freqs_dense(terms, slop=slop), want), f"slop {terms} {slop}"
+
+
 def test_slop_scenarios_from_reference_tests(api):
     """match / no-match booleans of reference test/test_slop_matches.py:7-88"""
     docs = ["foo bar baz", "foo x bar", "foo x y bar", "bar foo", "foo foo bar", "nothing here"]
