@@ -191,7 +191,7 @@ def main():
         try:
             tj = json.load(open(tpath))
             if tj.get("docs") == D and tj.get("queries") == B and tj.get("n_gpus") == world \
-                    and tj.get("tile_docs") == int(info.tile_docs):
+                    and tj.get("tile_docs") == int(info.tile_docs) and tj.get("k", args.k) == args.k:
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:                                 # noqa: BLE001
             traffic = None

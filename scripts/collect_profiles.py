@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""Copy the outputs of scripts/gpu_full.sh from gpurun_out/ into profiles/ (tracked), named per round:
+bench JSON lines, rocprofv3 kernel stats, and the per-kernel means of the FETCH_SIZE / WRITE_SIZE
+PMC passes with the gfx950 correction -> profiles/pmc_traffic.json (read by bench.py)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+PROF = os.path.join(ROOT, "profiles")
+RND = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def last_json_line(path):
+    if not os.path.exists(path):
+        return None
+    for line in reversed(open(path).read().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    return None
+
+
+def pmc_means(directory, counter):
+    rows = defaultdict(list)
+    for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") == counter:
+                rows[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: (len(v), sum(v) / len(v)) for k, v in rows.items()}
+
+
+def main():
+    os.makedirs(PROF, exist_ok=True)
+    for src, dst in [("bench.log", f"bench_{RND}.json"), ("bench_k100.log", f"bench_{RND}_k100.json"),
+                     ("bench_k1000.log", f"bench_{RND}_k1000.json"), ("phrase_bench.log", f"phrase_bench_{RND}.json"),
+                     ("slop_bench.log", f"slop_bench_{RND}.json"), ("dist1_rccl.log", f"bench_{RND}_dist1rank_1250k.json")]:
+        j = last_json_line(os.path.join(OUT, src))
+        if j is not None:
+            json.dump(j, open(os.path.join(PROF, dst), "w"), indent=1)
+            print("wrote", dst)
+    for sub, dst in [("prof_stats", f"{RND}_bench_kernel_stats.csv"), ("prof_phrase", f"{RND}_phrase_bench_kernel_stats.csv"),
+                     ("prof_slop", f"{RND}_slop_bench_kernel_stats.csv")]:
+        fs = glob.glob(os.path.join(OUT, sub, "**", "*kernel_stats.csv"), recursive=True)
+        if fs:
+            shutil.copy(fs[0], os.path.join(PROF, dst))
+            print("wrote", dst)
+    fetch = pmc_means(os.path.join(OUT, "prof_pmc_fetch"), "FETCH_SIZE")
+    write = pmc_means(os.path.join(OUT, "prof_pmc_write"), "WRITE_SIZE")
+    if fetch:
+        with open(os.path.join(PROF, f"{RND}_bench_pmc_summary.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "counter", "dispatches", "mean_counter_value_KiB_per_dispatch"])
+            for name, (n, mean) in fetch.items():
+                w.writerow([name, "FETCH_SIZE", n, round(mean, 3)])
+            for name, (n, mean) in write.items():
+                w.writerow([name, "WRITE_SIZE", n, round(mean, 3)])
+        tiles = [k for k in fetch if "sa_k_bm25_tiles" in k]
+        bench = last_json_line(os.path.join(OUT, "bench.log")) or {}
+        if tiles:
+            fk = fetch[tiles[0]][1]
+            wk = write.get(tiles[0], (0, 0.0))[1]
+            cfg = bench.get("config", {})
+            json.dump({"docs": cfg.get("docs"), "queries": cfg.get("queries_per_step"), "n_gpus": 1,
+                       "tile_docs": cfg.get("tile_docs"), "k": cfg.get("k"),
+                       "fetch_size_KiB_raw": fk, "write_size_KiB_raw": wk,
+                       "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section; "
+                                     "calibrated on sa_k_compact_count<PostingHeads>, a pure stream of the index words); "
+                                     "WRITE_SIZE taken as reported",
+                       "hbm_bytes_per_launch": int(2 * fk * 1024 + wk * 1024)},
+                      open(os.path.join(PROF, "pmc_traffic.json"), "w"), indent=1)
+            print("wrote pmc_traffic.json")
+
+
+if __name__ == "__main__":
+    main()
