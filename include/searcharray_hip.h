@@ -224,6 +224,8 @@ typedef struct sa_index_info {
     uint64_t hbm_bytes;          /* device memory held by the index */
     int device;
     int dl_packed;
+    uint32_t n_docdir_terms;     /* frequent terms with a doc directory (phrase probes) */
+    uint32_t reserved;
 } sa_index_info_t;
 int sa_index_info(sa_index_t* ix, sa_index_info_t* out);
 

@@ -61,7 +61,10 @@ def main():
         "heavy": [list(c) for c in itertools.islice(itertools.permutations(range(8), 3), args.batch)],
     }
     bres = {}
-    for name, plist in batches.items():
+    variants = [(name, plist, pt) for name, plist in batches.items() for pt in ("4096", "2048")]   # docs per phrase tile
+    for name, plist, pt in variants:
+        os.environ["SA_PTILE"] = pt
+        name = f"{name}_tile{pt}"
         plist = [p for p in plist if len(set(p)) == len(p)]
         bt = index.phrase_batch(plist, k=10)
         bt.run()

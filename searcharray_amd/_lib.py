@@ -32,7 +32,7 @@ class IndexInfo(ctypes.Structure):
                 ("n_words", c_uint64), ("n_postings", c_uint64),
                 ("n_terms", c_uint32), ("tile_docs", c_uint32), ("n_tiles", c_uint32),
                 ("n_dir_terms", c_uint32), ("hbm_bytes", c_uint64), ("device", c_int),
-                ("dl_packed", c_int)]
+                ("dl_packed", c_int), ("n_docdir_terms", c_uint32), ("reserved", c_uint32)]
 
 
 # name -> (restype, argtypes).  Every symbol declared in include/searcharray_hip.h.

@@ -46,6 +46,7 @@ struct sa_batch {
     u32* d_plan = nullptr;          // [B][4]: n_terms, split, anchor of part 0, anchor of part 1
     u32* d_wbounds = nullptr;       // [B][T][pn_tiles+1] first word of the term in each tile (relative)
     u64* d_wbase = nullptr;         // [B][T] word base of each phrase term
+    u32* d_wlen = nullptr;          // [B][T] words of each phrase term
 };
 
 

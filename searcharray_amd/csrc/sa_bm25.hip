@@ -639,6 +639,7 @@ void sa_batch_free(sa_batch* bt) {
     if (bt->d_plan) hipFree(bt->d_plan);
     if (bt->d_wbounds) hipFree(bt->d_wbounds);
     if (bt->d_wbase) hipFree(bt->d_wbase);
+    if (bt->d_wlen) hipFree(bt->d_wlen);
     for (hipEvent_t e : bt->ev0) hipEventDestroy(e);
     for (hipEvent_t e : bt->ev1) hipEventDestroy(e);
     delete bt;

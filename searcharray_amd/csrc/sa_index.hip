@@ -8,6 +8,7 @@
 #include "sa_index.hpp"
 #include "sa_scan.hpp"
 #include "../../include/searcharray_hip.h"
+#include <algorithm>
 
 #include <math.h>
 #include <stdlib.h>
@@ -127,6 +128,15 @@ struct PostingHeads {
 };
 
 // tile directory: row s = term dir_terms[s]; entry j = first posting with doc >= j * tile_docs
+// doc directory row of one term: the first word of every doc the term occurs in
+__global__ void __launch_bounds__(256)
+sa_k_build_docdir(const u64* __restrict__ words, u32 n, u32* __restrict__ row) {
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const u64 doc = words[i] >> SA_KEY_SHIFT;
+        if (i == 0 || (words[i - 1] >> SA_KEY_SHIFT) != doc) row[doc] = i;
+    }
+}
+
 __global__ void sa_k_build_tile_dir(const u64* __restrict__ tfp, const u64* __restrict__ tf_off,
                                     const u32* __restrict__ dir_terms, u32 n_dir_terms, u32 n_tiles,
                                     u32 tile_docs, u32* __restrict__ tile_dir) {
@@ -171,6 +181,8 @@ static void sa_index_free(sa_index* ix) {
     if (ix->d_doc_lens) hipFree(ix->d_doc_lens);
     if (ix->d_tile_dir) hipFree(ix->d_tile_dir);
     if (ix->d_dir_slot) hipFree(ix->d_dir_slot);
+    if (ix->d_docdir) hipFree(ix->d_docdir);
+    if (ix->d_dd_slot) hipFree(ix->d_dd_slot);
     if (ix->d_scratch) hipFree(ix->d_scratch);
     if (ix->ev0) hipEventDestroy(ix->ev0);
     if (ix->ev1) hipEventDestroy(ix->ev1);
@@ -293,6 +305,41 @@ static int sa_index_build(sa_index* ix, const u64* words, const u64* term_off, c
                            d_dir_terms, ix->n_dir_terms, ix->n_tiles, ix->tile_docs, ix->d_tile_dir);
         SA_HIP(hipStreamSynchronize(st));
         SA_HIP(hipFree(d_dir_terms));
+    }
+    // ---- doc directory for the terms phrase probes hit hardest ----
+    {
+        // terms with at least one word per SA_DOCDIR_DIV docs (default 32), most frequent first,
+        // within a memory budget of the size of the word array itself
+        const char* dv = getenv("SA_DOCDIR_DIV");
+        const int div = dv ? atoi(dv) : 32;
+        std::vector<std::pair<u64, u32>> cand;
+        if (div > 0 && ix->n_docs > 0)
+            for (u32 t = 0; t < V; t++) {
+                const u64 w = ix->h_term_off[t + 1] - ix->h_term_off[t];
+                if (w >= 64 && w * (u64)div >= ix->n_docs && w < 0xFFFFFFFFull) cand.push_back({w, t});
+            }
+        std::sort(cand.begin(), cand.end(), [](const std::pair<u64, u32>& a, const std::pair<u64, u32>& b) {
+            return a.first != b.first ? a.first > b.first : a.second < b.second;
+        });
+        const u64 budget_rows = ix->n_docs ? (ix->n_words * 8 + (64ull << 20)) / (ix->n_docs * 4) : 0;
+        if (cand.size() > budget_rows) cand.resize((size_t)budget_rows);
+        if (cand.size() > 4096) cand.resize(4096);
+        ix->n_dd_terms = (u32)cand.size();
+        std::vector<u32>& dd_slot = ix->h_dd_slot;
+        dd_slot.assign((size_t)V + 1, SA_DD_NONE);
+        for (u32 r = 0; r < ix->n_dd_terms; r++) dd_slot[cand[r].second] = r;
+        SA_HIP(hipMalloc(&ix->d_dd_slot, ((size_t)V + 1) * sizeof(u32)));
+        SA_HIP(hipMemcpyAsync(ix->d_dd_slot, dd_slot.data(), ((size_t)V + 1) * sizeof(u32), hipMemcpyHostToDevice, st));
+        const size_t dd_bytes = (size_t)ix->n_dd_terms * ix->n_docs * sizeof(u32);
+        SA_HIP(hipMalloc(&ix->d_docdir, dd_bytes ? dd_bytes : 4));
+        if (dd_bytes) SA_HIP(hipMemsetAsync(ix->d_docdir, 0xFF, dd_bytes, st));
+        for (u32 r = 0; r < ix->n_dd_terms; r++) {
+            const u32 t = cand[r].second;
+            const u32 n = (u32)cand[r].first;
+            const u32 grid = n / 256 + 1 < 16384 ? n / 256 + 1 : 16384;
+            hipLaunchKernelGGL(sa_k_build_docdir, dim3(grid), dim3(256), 0, st, ix->d_words + ix->h_term_off[t], n,
+                               ix->d_docdir + (size_t)r * ix->n_docs);
+        }
     }
     SA_HIP(hipStreamSynchronize(st));
     SA_HIP(hipGetLastError());
@@ -420,7 +467,9 @@ extern "C" int sa_index_info(sa_index_t* ix, sa_index_info_t* out) {
     out->n_dir_terms = ix->n_dir_terms;
     out->device = ix->device;
     out->dl_packed = ix->dl_packed ? 1 : 0;
+    out->n_docdir_terms = ix->n_dd_terms;
+    out->reserved = 0;
     out->hbm_bytes = ix->n_words * 8 + ix->n_postings * 8 + ((u64)ix->n_terms + 1) * 20 + ix->n_docs * 4 +
-                     (u64)ix->n_dir_terms * (ix->n_tiles + 1) * 4 + ix->scratch_bytes;
+                     (u64)ix->n_dir_terms * (ix->n_tiles + 1) * 4 + (u64)ix->n_dd_terms * ix->n_docs * 4 + ix->scratch_bytes;
     return SA_OK;
 }

@@ -23,6 +23,9 @@
 
 struct sa_comm;   // RCCL communicator wrapper (sa_comm.hip)
 
+#define SA_DD_ABSENT 0xFFFFFFFFu
+#define SA_DD_NONE 0xFFFFFFFFu
+
 struct sa_index {
     int device = 0;
     int n_cus = 1;                  // compute units of the device (persistent grid sizing)
@@ -44,7 +47,15 @@ struct sa_index {
     u32* d_tile_dir = nullptr;
     u32* d_dir_slot = nullptr;
 
+    // Doc directory of the frequent terms (phrase probes): docdir[slot][doc] = index, relative to the
+    // term's first word, of the first roaringish word of `doc` in that term, or SA_DD_ABSENT.  Finding a
+    // term's words of a given doc becomes one 4-byte load instead of a binary search of the term's list.
+    u32 n_dd_terms = 0;
+    u32* d_docdir = nullptr;         // [n_dd_terms][n_docs]
+    u32* d_dd_slot = nullptr;        // [n_terms] directory row of a term, or SA_DD_NONE
+
     std::vector<u64> h_term_off, h_tf_off;
+    std::vector<u32> h_dd_slot;      // host copy of d_dd_slot
 
     // reusable device scratch (grown on demand, guarded by mu)
     void* d_scratch = nullptr;

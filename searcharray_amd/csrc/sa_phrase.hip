@@ -174,6 +174,7 @@ sa_k_min2(float* __restrict__ a, const float* __restrict__ b, u64 n) {
 struct FusedPhraseParams {
     const u64* ptr[SA_MAX_PHRASE];   // each term's (possibly position-filtered) words
     u32 len[SA_MAX_PHRASE];
+    const u32* dd[SA_MAX_PHRASE];    // doc directory row of the term (whole, unfiltered list), or null
     int T, anchor;
     u32* step;                   // dense per-doc match counts (u32, atomically accumulated)
 };
@@ -183,7 +184,18 @@ __global__ void __launch_bounds__(256) sa_k_phrase_fused(const FusedPhraseParams
     const u32 na = p.len[p.anchor];
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < na; i += gridDim.x * blockDim.x) {
         const u64 w = anc[i];
-        const u64 m = sa_phrase_anchor_mask(w, p.T, p.anchor, [&](int t, const u64*& a, u32& n) { a = p.ptr[t]; n = p.len[t]; });
+        const u64 m = sa_phrase_anchor_mask_win(w, p.T, p.anchor, [&](int t, u64 h, bool want_prev, bool want_next) -> u64 {
+            const u64* a = p.ptr[t];
+            const u32 n = p.len[t];
+            if (p.dd[t]) return sa_window_docdir(a, n, p.dd[t], h, want_prev, want_next);   // uniform per term
+            const u64 delta = 1ull << SA_LSB_BITS;
+            u32 hint = 0;
+            u64 win = 0;
+            if (want_prev) win |= sa_payload_at(a, n, h - delta, hint);
+            win |= sa_payload_at(a, n, h, hint) << 18;
+            if (want_next) win |= sa_payload_at(a, n, h + delta, hint) << 36;
+            return win;
+        });
         if (m) atomicAdd(&p.step[w >> SA_KEY_SHIFT], (u32)__popcll(m));
     }
 }
@@ -363,6 +375,17 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
     for (int t = 1; t < T; t++) if (lens[t] < lens[shortest]) shortest = t;
     const bool l2r_only = shortest <= 1, r2l_only = !l2r_only && shortest >= T - 2;
 
+    // doc directory rows (valid for the unfiltered term lists only)
+    const u32* dd_rows[SA_MAX_PHRASE];
+    {
+        const char* v = getenv("SA_PHRASE_DOCDIR");
+        const bool use_dd = !filt.active && ix->n_dd_terms > 0 && !(v && atoi(v) == 0);
+        std::vector<u32>& slots = ix->h_dd_slot;
+        for (int t = 0; t < T; t++) {
+            const u32 sl = (use_dd && terms[t] < ix->n_terms) ? slots[terms[t]] : SA_DD_NONE;
+            dd_rows[t] = sl != SA_DD_NONE ? ix->d_docdir + (size_t)sl * ix->n_docs : nullptr;
+        }
+    }
     const bool use_fused = (mode == 2) || (mode == 0 && distinct);
     if (use_fused) {
         if (!distinct) { sa_set_error("fused phrase kernel needs pairwise-distinct terms"); return SA_ERR_ARG; }
@@ -378,6 +401,7 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
             int anchor = 0;
             for (int t = a; t < b; t++) {
                 fp.ptr[t - a] = ptrs[t]; fp.len[t - a] = lens[t];
+                fp.dd[t - a] = dd_rows[t];
                 if (lens[t] < lens[a + anchor]) anchor = t - a;
             }
             fp.anchor = anchor;

@@ -11,8 +11,10 @@
 // doc's roaringish words are contiguous in every term's list, so a tile owns one contiguous slice of
 // each phrase term (slice table built once per batch by lower-bound searches).  The workgroup walks
 // the slice of the phrase's rarest term (the anchor), lines the other terms up against each anchor
-// word (sa_phrase_anchor_mask: 54-bit windows, shifts, AND, popcount -- integer work, no MFMA) and
-// adds the match counts into per-doc LDS counters; counts -> fp32 BM25 with the reference's operation
+// word (sa_phrase_anchor_mask_win: 54-bit windows, shifts, AND, popcount -- integer work, no MFMA;
+// frequent terms are located through the index's doc directory, one 4-byte load per probe, rare
+// ones by a lower-bound search of their short tile slice) and adds the match counts into per-doc
+// LDS counters; counts -> fp32 BM25 with the reference's operation
 // order; the pruned wave-level top-k (sa_tile_topk_pruned) appends the few docs that can still reach
 // the query's top-k.  Tiles in which some phrase term has no word leave after two loads.
 //
@@ -25,9 +27,11 @@
 #include "sa_phrase_dev.hpp"
 #include "../../include/searcharray_hip.h"
 #include <new>
+#include <stdlib.h>
+#include <type_traits>
 #include <vector>
 
-#define SA_PTILE 4096
+#define SA_PTILE 2048
 #define SA_PTHREADS 256
 #define SA_PHRASE_BATCH_MAXT 18      // |t - anchor| must stay below the 18-position block width
 
@@ -46,26 +50,31 @@ struct PhraseTileParams {
     u32* cand_cnt;
     u32* slots;
     u64* cand;
+    const u32* terms;      // [B][T] term ids
+    const u32* wlen;       // [B][T] words of each phrase term (whole list)
+    const u32* docdir;     // index doc directory [n_dd_terms][n_docs]
+    const u32* dd_slot;    // [n_terms]
+    int use_docdir;        // 0: binary-search every probe (SA_PHRASE_DOCDIR=0, tests)
 };
 
 // first word of each phrase term at or after every tile boundary, relative to the term's base
 __global__ void __launch_bounds__(256)
 sa_k_make_word_bounds(const u64* __restrict__ words, const u64* __restrict__ term_off, u32 n_terms, u32 n_tiles,
                       u32 tile_docs, const u32* __restrict__ terms, u32 BT, u32* __restrict__ bounds,
-                      u64* __restrict__ wbase) {
+                      u64* __restrict__ wbase, u32* __restrict__ wlen) {
     const u64 total = (u64)BT * (n_tiles + 1);
     for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (u64)gridDim.x * blockDim.x) {
         const u32 qt = (u32)(e / (n_tiles + 1)), tile = (u32)(e % (n_tiles + 1));
         const u32 term = terms[qt];
-        u32 rel = 0;
+        u32 rel = 0, cnt = 0;
         u64 base = 0;
         if (term < n_terms) {
             base = term_off[term];
-            const u32 cnt = (u32)(term_off[term + 1] - base);
+            cnt = (u32)(term_off[term + 1] - base);
             rel = sa_lower_bound(words + base, 0, cnt, ((u64)tile * tile_docs) << SA_KEY_SHIFT, SA_KEY_MASK);
         }
         bounds[e] = rel;
-        if (tile == 0) wbase[qt] = base;
+        if (tile == 0) { wbase[qt] = base; wlen[qt] = cnt; }
     }
 }
 
@@ -75,6 +84,9 @@ __global__ void __launch_bounds__(THREADS) sa_k_phrase_tiles(const PhraseTilePar
     __shared__ u32 cnt_a[TILE];                      // match counts, later the fp32 scores
     __shared__ u32 cnt_b[TILE];                      // second half of a middle-out plan
     __shared__ u64 s_lo[SA_PHRASE_BATCH_MAXT], s_hi[SA_PHRASE_BATCH_MAXT];
+    __shared__ u64 s_tbase[SA_PHRASE_BATCH_MAXT];    // first word of the term (whole list)
+    __shared__ u32 s_tlen[SA_PHRASE_BATCH_MAXT];
+    __shared__ u32 s_dd[SA_PHRASE_BATCH_MAXT];       // doc directory row of the term, or SA_DD_NONE
     const u32 tid = threadIdx.x;
     const u32 item = blockIdx.x;
     const u32 tile = item / p.B, q = item % p.B;     // tile-major like the BM25 tiles
@@ -91,6 +103,9 @@ __global__ void __launch_bounds__(THREADS) sa_k_phrase_tiles(const PhraseTilePar
         const u64 base = p.wbase[qt];
         s_lo[tid] = base + row[0];
         s_hi[tid] = base + row[1];
+        s_tbase[tid] = base;
+        s_tlen[tid] = p.wlen[qt];
+        s_dd[tid] = p.use_docdir ? p.dd_slot[p.terms[qt]] : SA_DD_NONE;
     }
 #pragma unroll
     for (int j = 0; j < E; j++) cnt_a[j * THREADS + tid] = 0;
@@ -104,6 +119,9 @@ __global__ void __launch_bounds__(THREADS) sa_k_phrase_tiles(const PhraseTilePar
     for (u32 t = 0; t < Tq; t++) empty |= (s_lo[t] == s_hi[t]);
     if (empty) return;                               // uniform
 
+    // Probing term t for the anchor's doc: frequent terms have a doc directory (one 4-byte load
+    // finds the doc's words or rejects the doc); the others are searched inside their tile slice,
+    // which is short precisely because the term is rare.
     const int nparts = split ? 2 : 1;
     for (int part = 0; part < nparts; part++) {
         const int t0 = part == 0 ? 0 : (int)split;
@@ -114,9 +132,20 @@ __global__ void __launch_bounds__(THREADS) sa_k_phrase_tiles(const PhraseTilePar
         const u32 na = (u32)(s_hi[t0 + anchor] - alo);
         for (u32 i = tid; i < na; i += THREADS) {
             const u64 w = p.words[alo + i];
-            const u64 m = sa_phrase_anchor_mask(w, t1 - t0, anchor, [&](int t, const u64*& a, u32& n) {
-                a = p.words + s_lo[t0 + t];
-                n = (u32)(s_hi[t0 + t] - s_lo[t0 + t]);
+            const u64 m = sa_phrase_anchor_mask_win(w, t1 - t0, anchor, [&](int t, u64 h, bool want_prev, bool want_next) -> u64 {
+                const u32 dd = s_dd[t0 + t];
+                if (dd != SA_DD_NONE)                // uniform per term
+                    return sa_window_docdir(p.words + s_tbase[t0 + t], s_tlen[t0 + t], p.docdir + (u64)dd * p.n_docs,
+                                            h, want_prev, want_next);
+                const u64 delta = 1ull << SA_LSB_BITS;
+                const u64* a = p.words + s_lo[t0 + t];
+                const u32 n = (u32)(s_hi[t0 + t] - s_lo[t0 + t]);
+                u32 hint = 0;
+                u64 win = 0;
+                if (want_prev) win |= sa_payload_at(a, n, h - delta, hint);
+                win |= sa_payload_at(a, n, h, hint) << 18;
+                if (want_next) win |= sa_payload_at(a, n, h + delta, hint) << 36;
+                return win;
             });
             if (m) atomicAdd(&cnt[(u32)((w >> SA_KEY_SHIFT) - tile_base)], (u32)__popcll(m));
         }
@@ -156,8 +185,14 @@ int sa_launch_phrase_tiles(sa_batch* bt, hipStream_t st) {
     p.plan = bt->d_plan; p.bounds = bt->d_wbounds; p.wbase = bt->d_wbase; p.idf = bt->d_idf;
     p.B = bt->B; p.T = bt->T; p.k = bt->k; p.k1 = bt->k1; p.b = bt->b; p.avgdl = ix->avg_doc_len;
     p.cand_cap = bt->cand_cap; p.cand_cnt = bt->d_cand_cnt; p.slots = bt->d_slots; p.cand = bt->d_cand;
+    p.terms = bt->d_terms; p.wlen = bt->d_wlen; p.docdir = ix->d_docdir; p.dd_slot = ix->d_dd_slot;
+    p.use_docdir = ix->n_dd_terms > 0 ? 1 : 0;
+    if (const char* v = getenv("SA_PHRASE_DOCDIR")) { if (atoi(v) == 0) p.use_docdir = 0; }
     const u64 n_items = (u64)bt->B * bt->pn_tiles;
-    hipLaunchKernelGGL((sa_k_phrase_tiles<SA_PTILE, SA_PTHREADS>), dim3((u32)n_items), dim3(SA_PTHREADS), 0, st, p);
+    if (bt->ptile == 2048)
+        hipLaunchKernelGGL((sa_k_phrase_tiles<2048, SA_PTHREADS>), dim3((u32)n_items), dim3(SA_PTHREADS), 0, st, p);
+    else
+        hipLaunchKernelGGL((sa_k_phrase_tiles<4096, SA_PTHREADS>), dim3((u32)n_items), dim3(SA_PTHREADS), 0, st, p);
     return SA_OK;
 }
 
@@ -190,7 +225,8 @@ extern "C" int sa_phrase_batch_create(sa_index_t* ix, const uint32_t* terms, con
     bt->ix = ix; bt->B = B; bt->T = T; bt->k = (u32)k; bt->k1 = k1; bt->b = b;
     bt->kind = 1;
     bt->ptile = SA_PTILE;
-    bt->pn_tiles = (u32)((ix->n_docs + SA_PTILE - 1) / SA_PTILE);
+    if (const char* v = getenv("SA_PTILE")) { if (atoi(v) == 2048 || atoi(v) == 4096) bt->ptile = (u32)atoi(v); }
+    bt->pn_tiles = (u32)((ix->n_docs + bt->ptile - 1) / bt->ptile);
     bt->perm.resize(B);
     for (u32 i = 0; i < B; i++) bt->perm[i] = i;
     // plan per phrase (host): reference compute_phrase_freqs, middle_out.py:154-168
@@ -232,6 +268,7 @@ extern "C" int sa_phrase_batch_create(sa_index_t* ix, const uint32_t* terms, con
     SA_HIP_B(hipMalloc(&bt->d_plan, plan.size() * sizeof(u32)));
     SA_HIP_B(hipMalloc(&bt->d_wbounds, ((size_t)B * T * (bt->pn_tiles + 1) + 1) * sizeof(u32)));
     SA_HIP_B(hipMalloc(&bt->d_wbase, (size_t)B * T * sizeof(u64)));
+    SA_HIP_B(hipMalloc(&bt->d_wlen, (size_t)B * T * sizeof(u32)));
     SA_HIP_B(hipMemcpy(bt->d_perm, bt->perm.data(), (size_t)B * sizeof(u32), hipMemcpyHostToDevice));
     SA_HIP_B(hipMemcpy(bt->d_terms, h_terms.data(), h_terms.size() * sizeof(u32), hipMemcpyHostToDevice));
     SA_HIP_B(hipMemcpy(bt->d_idf, idf, (size_t)B * sizeof(float), hipMemcpyHostToDevice));
@@ -241,8 +278,8 @@ extern "C" int sa_phrase_batch_create(sa_index_t* ix, const uint32_t* terms, con
         const u64 total = (u64)B * T * (bt->pn_tiles + 1);
         const u32 grid = total / 256 + 1 < 65535 ? (u32)(total / 256 + 1) : 65535u;
         hipLaunchKernelGGL(sa_k_make_word_bounds, dim3(grid), dim3(256), 0, ix->stream, ix->d_words, ix->d_term_off,
-                           ix->n_terms, bt->pn_tiles, (u32)SA_PTILE, (const u32*)bt->d_terms, B * T, bt->d_wbounds,
-                           bt->d_wbase);
+                           ix->n_terms, bt->pn_tiles, bt->ptile, (const u32*)bt->d_terms, B * T, bt->d_wbounds,
+                           bt->d_wbase, bt->d_wlen);
     }
     SA_HIP_B(hipStreamSynchronize(ix->stream));
     SA_HIP_B(hipGetLastError());

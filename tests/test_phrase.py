@@ -227,6 +227,28 @@ def test_phrase_batch_matches_oracle(api, k):
     _check_phrase_batch(dev, orc, phrases, k, n_docs)
 
 
+@pytest.mark.parametrize("ptile,docdir,div", [("2048", "0", "32"), ("4096", "1", "32"), ("2048", "1", "1000000"),
+                                              ("4096", "1", "0")])
+def test_phrase_batch_tile_and_directory_variants(api, monkeypatch, ptile, docdir, div):
+    """both tile sizes; probes by binary search only, by the doc directory of the frequent terms, with
+    a directory for every term of >= 64 words, and with no directory in the index at all.  The
+    single-phrase fused kernel takes the same probes."""
+    monkeypatch.setenv("SA_PTILE", ptile)
+    monkeypatch.setenv("SA_PHRASE_DOCDIR", docdir)
+    monkeypatch.setenv("SA_DOCDIR_DIV", div)
+    n_docs, vocab = 9000, 60
+    t, d, p, lens = synth.corpus_triples(n_docs, vocab, 45, seed=3)
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    info = dev.info()
+    assert (info.n_docdir_terms > 0) == (div != "0")
+    orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
+    phrases = [[0, 1], [3, 2, 1], [0, 5, 1, 2, 3], [4, 0, 30, 1, 2, 3], [2, 3], [1, 0, 2], [40, 41], [1, 45, 2]]
+    _check_phrase_batch(dev, orc, phrases, 10, n_docs)
+    for ph in phrases[:5]:
+        assert np.array_equal(dev.phrase_freqs_dense(ph), orc.phrase_freqs(ph)), ph
+
+
 def test_phrase_batch_golden_corpus_and_doc_base(api):
     g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_small")
     words, wt = rz.encode_sorted(t, d, p)
