@@ -125,6 +125,18 @@ int sa_index_create(int device, uint64_t n_docs, uint64_t doc_base, uint32_t n_t
                     const uint64_t* words, const uint64_t* term_off, const float* doc_lens,
                     float avg_doc_len, uint64_t corpus_size, uint32_t tile_docs,
                     sa_index_t** out);
+/* The same index built from the TOKEN STREAM instead of pre-encoded words (index build on the
+ * device): tokens[doc_ptr[d] .. doc_ptr[d+1]) are the term ids of doc d in position order
+ * (position = index within the doc).  Replaces the host part of the reference indexer -- the stable
+ * sort by term (indexing.py:102-115) and RoaringishEncoder.encode (roaringish.py:93-142); the
+ * resulting words are byte-identical.  A term id >= n_terms or a doc longer than 18 * 2^18 tokens
+ * ("Document length exceeds maximum", indexing.py:141-142) is SA_ERR_ARG. */
+int sa_index_create_from_tokens(int device, uint64_t n_docs, uint64_t doc_base, uint32_t n_terms,
+                                const uint32_t* tokens, const uint64_t* doc_ptr, const float* doc_lens,
+                                float avg_doc_len, uint64_t corpus_size, uint32_t tile_docs, sa_index_t** out);
+/* copy the resident roaringish words (u64[n_words], see sa_index_info) and / or term offsets
+ * (u64[n_terms + 1]) back to the host; either pointer may be null */
+int sa_index_words(sa_index_t* ix, uint64_t* words_out, uint64_t* term_off_out);
 int sa_index_destroy(sa_index_t* ix);
 /* block until everything enqueued on the index's stream has finished */
 int sa_index_synchronize(sa_index_t* ix);

@@ -171,7 +171,7 @@ __global__ void sa_k_split_postings(const u64* __restrict__ tfp, u64 lo, u64 hi,
 // ---------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------
-static void sa_index_free(sa_index* ix) {
+void sa_index_free(sa_index* ix) {
     if (!ix) return;
     hipSetDevice(ix->device);
     if (ix->d_words) hipFree(ix->d_words);
@@ -191,9 +191,8 @@ static void sa_index_free(sa_index* ix) {
     delete ix;
 }
 
-static int sa_index_build(sa_index* ix, const u64* words, const u64* term_off, const float* doc_lens) {
-    const u32 V = ix->n_terms;
-    const u64 W = ix->n_words;
+// device, stream and the doc lengths (shared by both ways of creating an index)
+int sa_index_setup(sa_index* ix, const float* doc_lens) {
     SA_HIP(hipSetDevice(ix->device));
     {
         hipDeviceProp_t prop;
@@ -201,16 +200,40 @@ static int sa_index_build(sa_index* ix, const u64* words, const u64* term_off, c
         ix->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
     }
     SA_HIP(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
-    hipStream_t st = ix->stream;
+    // doc lengths ride in the postings when they are integers that fit 18 bits
+    // (always true for indexes built by SearchArray.index: reference indexing.py:141-142)
+    ix->dl_packed = true;
+    ix->max_doc_len = 0;
+    for (u64 d = 0; d < ix->n_docs; d++) {
+        const float v = doc_lens[d];
+        if (!(v >= 0.f) || v > 262143.f || v != floorf(v)) { ix->dl_packed = false; break; }
+        if ((u32)v > ix->max_doc_len) ix->max_doc_len = (u32)v;
+    }
+    SA_HIP(hipMalloc(&ix->d_doc_lens, (ix->n_docs ? ix->n_docs : 1) * sizeof(float)));
+    SA_HIP(hipMemcpyAsync(ix->d_doc_lens, doc_lens, ix->n_docs * sizeof(float), hipMemcpyHostToDevice, ix->stream));
+    return SA_OK;
+}
 
+static int sa_index_build(sa_index* ix, const u64* words, const u64* term_off, const float* doc_lens) {
+    const u32 V = ix->n_terms;
+    const u64 W = ix->n_words;
+    SA_TRY(sa_index_setup(ix, doc_lens));
+    hipStream_t st = ix->stream;
     SA_HIP(hipMalloc(&ix->d_words, (W ? W : 1) * sizeof(u64)));
     SA_HIP(hipMalloc(&ix->d_term_off, ((size_t)V + 1) * sizeof(u64)));
-    SA_HIP(hipMalloc(&ix->d_tf_off, ((size_t)V + 1) * sizeof(u64)));
-    SA_HIP(hipMalloc(&ix->d_doc_lens, (ix->n_docs ? ix->n_docs : 1) * sizeof(float)));
-    SA_HIP(hipMalloc(&ix->d_dir_slot, ((size_t)V + 1) * sizeof(u32)));
     SA_HIP(hipMemcpyAsync(ix->d_words, words, W * sizeof(u64), hipMemcpyHostToDevice, st));
     SA_HIP(hipMemcpyAsync(ix->d_term_off, term_off, ((size_t)V + 1) * sizeof(u64), hipMemcpyHostToDevice, st));
-    SA_HIP(hipMemcpyAsync(ix->d_doc_lens, doc_lens, ix->n_docs * sizeof(float), hipMemcpyHostToDevice, st));
+    return sa_index_derive(ix);
+}
+
+// Everything derived from the resident words: fat TF postings, tile directory, doc directory.
+// Needs d_words, d_term_off, d_doc_lens on the device and h_term_off on the host.
+int sa_index_derive(sa_index* ix) {
+    const u32 V = ix->n_terms;
+    const u64 W = ix->n_words;
+    hipStream_t st = ix->stream;
+    SA_HIP(hipMalloc(&ix->d_tf_off, ((size_t)V + 1) * sizeof(u64)));
+    SA_HIP(hipMalloc(&ix->d_dir_slot, ((size_t)V + 1) * sizeof(u32)));
 
     // ---- derive postings ----
     const u32 nchunks = sa_compact_chunks((u32)W);
@@ -371,17 +394,19 @@ extern "C" int sa_index_create(int device, uint64_t n_docs, uint64_t doc_base, u
     ix->n_terms = n_terms; ix->avg_doc_len = avg_doc_len; ix->n_words = W;
     ix->tile_docs = tile_docs;
     ix->h_term_off.assign(term_off, term_off + n_terms + 1);
-    // doc lengths ride in the postings when they are integers that fit 18 bits
-    // (always true for indexes built by SearchArray.index: reference indexing.py:141-142)
-    ix->dl_packed = true;
-    for (u64 d = 0; d < n_docs; d++) {
-        const float v = doc_lens[d];
-        if (!(v >= 0.f) || v > 262143.f || v != floorf(v)) { ix->dl_packed = false; break; }
-        if ((u32)v > ix->max_doc_len) ix->max_doc_len = (u32)v;
-    }
     int rc = sa_index_build(ix, words, term_off, doc_lens);
     if (rc != SA_OK) { sa_index_free(ix); return rc; }
     *out = ix;
+    return SA_OK;
+}
+
+extern "C" int sa_index_words(sa_index_t* ix, uint64_t* words_out, uint64_t* term_off_out) {
+    SA_ARG(ix, "null index");
+    std::lock_guard<std::mutex> g(ix->mu);
+    SA_HIP(hipSetDevice(ix->device));
+    SA_HIP(hipStreamSynchronize(ix->stream));
+    if (words_out && ix->n_words) SA_HIP(hipMemcpy(words_out, ix->d_words, ix->n_words * sizeof(u64), hipMemcpyDeviceToHost));
+    if (term_off_out) memcpy(term_off_out, ix->h_term_off.data(), ((size_t)ix->n_terms + 1) * sizeof(u64));
     return SA_OK;
 }
 

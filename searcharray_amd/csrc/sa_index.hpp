@@ -75,6 +75,10 @@ struct sa_index {
 };
 
 int sa_index_scratch(sa_index* ix, size_t bytes, void** out);
+// index construction pieces shared by sa_index_create (sa_index.hip) and sa_index_create_from_tokens (sa_build.hip)
+int sa_index_setup(sa_index* ix, const float* doc_lens);
+int sa_index_derive(sa_index* ix);
+void sa_index_free(sa_index* ix);
 // min_posn / max_posn restriction of the positional words (reference roaringish.py:266-282)
 struct PosnFilter {
     bool active = false;

@@ -49,6 +49,44 @@ class DeviceIndex:
         self._local_df = None
         self._global_df = None if global_df is None else np.asarray(global_df, dtype=np.uint64)
 
+    @classmethod
+    def from_tokens(cls, tokens: np.ndarray, doc_ptr: np.ndarray, n_terms: int,
+                    doc_lens: Optional[np.ndarray] = None, avg_doc_len: Optional[float] = None,
+                    corpus_size: Optional[int] = None, doc_base: int = 0, device: int = 0, tile_docs: int = 0,
+                    api=None, global_df: Optional[np.ndarray] = None) -> "DeviceIndex":
+        """Build the index on the device from the token stream: ``tokens[doc_ptr[d]:doc_ptr[d+1]]`` are
+        the term ids of doc ``d`` in position order (what a tokenizer + term dictionary produce).
+        Sort by term and roaringish encoding happen on the GPU (reference indexing.py:102-115,
+        roaringish.py:93-142); ``words()`` downloads the encoded index when the host needs it."""
+        self = cls.__new__(cls)
+        self.api = api if api is not None else _lib.api()
+        tokens = as_u32(tokens)
+        doc_ptr = as_u64(doc_ptr)
+        self.n_docs = len(doc_ptr) - 1
+        if doc_lens is None:
+            doc_lens = np.diff(doc_ptr.astype(np.int64)).astype(np.float32)
+        doc_lens = as_f32(doc_lens)
+        self.n_terms = int(n_terms)
+        self.doc_base = int(doc_base)
+        self.avg_doc_len = np.float32(np.mean(doc_lens) if avg_doc_len is None and self.n_docs
+                                      else (avg_doc_len or 0.0))
+        self.corpus_size = int(self.n_docs if corpus_size is None else corpus_size)
+        self._h = ctypes.c_void_p()
+        self.api.call("sa_index_create_from_tokens", int(device), self.n_docs, self.doc_base, self.n_terms,
+                      p_u32(tokens), p_u64(doc_ptr), p_f32(doc_lens), self.avg_doc_len,
+                      self.corpus_size, int(tile_docs), ctypes.byref(self._h))
+        self._local_df = None
+        self._global_df = None if global_df is None else np.asarray(global_df, dtype=np.uint64)
+        return self
+
+    def words(self) -> Tuple[np.ndarray, np.ndarray]:
+        """(roaringish words uint64[W] term-major, term offsets uint64[V+1]) copied from the device."""
+        info = self.info()
+        words = np.empty(int(info.n_words), dtype=np.uint64)
+        term_off = np.empty(self.n_terms + 1, dtype=np.uint64)
+        self.api.call("sa_index_words", self._h, p_u64(words), p_u64(term_off))
+        return words, term_off
+
     # -- lifetime
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -1,13 +1,15 @@
 """Host-side index build: tokenise -> (term, doc, posn) triples -> roaringish words.
 
-Index build stays on the host in this version (the tokenizer is arbitrary Python; SURVEY.md
-8f ranks device-side encode as the next step).  The output -- term-major roaringish words, CSR
-offsets, doc lengths -- is byte-compatible with what the reference's indexer produces
-(reference searcharray/indexing.py:118-160,235-296) and is what ``DeviceIndex`` uploads.
+The tokenizer is arbitrary Python and stays on the host together with the term dictionary; the
+token stream it produces is sorted by term and roaringish-encoded ON THE DEVICE
+(``DeviceIndex.from_tokens`` -> csrc/sa_build.hip).  The encoded index -- term-major roaringish
+words, CSR offsets, doc lengths -- is byte-compatible with what the reference's indexer produces
+(reference searcharray/indexing.py:118-160,235-296); ``HostIndex`` downloads it lazily when the host
+needs the words.  Already-tokenised input (``Terms`` / dicts with explicit positions) is encoded on
+the host and uploaded.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
 from typing import Callable, Iterable, List, Optional
 
 import numpy as np
@@ -16,19 +18,82 @@ from . import roaringish as rz
 from .term_dict import TermDict
 
 
-@dataclass
 class HostIndex:
-    term_dict: TermDict
-    words: np.ndarray           # uint64[W] term-major
-    term_off: np.ndarray        # uint64[V+1]
-    doc_lens: np.ndarray        # float32[N]
-    doc_term_ptr: np.ndarray    # int64[N+1]   CSR over docs -> distinct term ids (for __getitem__)
-    doc_term_ids: np.ndarray    # uint32[...]
-    doc_term_tfs: Optional[np.ndarray] = None     # only for docs given as {term: tf} without positions
+    """Host side of an index.  Always present: term dictionary and doc lengths.  The roaringish words
+    and the doc -> distinct-terms CSR are materialised on first use: an index built from a token
+    stream is encoded ON THE DEVICE (DeviceIndex.from_tokens) and only downloaded if the host asks for
+    the words (positions(), scalar __getitem__, pickling)."""
+
+    def __init__(self, term_dict: TermDict, doc_lens: np.ndarray, words: Optional[np.ndarray] = None,
+                 term_off: Optional[np.ndarray] = None, doc_term_ptr: Optional[np.ndarray] = None,
+                 doc_term_ids: Optional[np.ndarray] = None, doc_term_tfs: Optional[np.ndarray] = None,
+                 tokens: Optional[np.ndarray] = None, doc_ptr: Optional[np.ndarray] = None):
+        self.term_dict = term_dict
+        self.doc_lens = doc_lens            # float32[N]
+        self._words = words                 # uint64[W] term-major
+        self._term_off = term_off           # uint64[V+1]
+        self._doc_term_ptr = doc_term_ptr   # int64[N+1]  CSR over docs -> distinct term ids (for __getitem__)
+        self._doc_term_ids = doc_term_ids   # uint32[...]
+        self.doc_term_tfs = doc_term_tfs    # only for docs given as {term: tf} without positions
+        self.tokens = tokens                # uint32[n_tokens] term id per token, docs back to back (or None)
+        self.doc_ptr = doc_ptr              # uint64[N+1] token offsets
+        self.words_source: Optional[Callable] = None     # () -> (words, term_off), set by the device owner
 
     @property
     def num_docs(self) -> int:
         return len(self.doc_lens)
+
+    @property
+    def has_words(self) -> bool:
+        return self._words is not None
+
+    def _materialise_words(self):
+        if self._words is not None:
+            return
+        if self.words_source is not None:
+            self._words, self._term_off = self.words_source()
+            return
+        # no device copy yet: encode on the host (same bytes)
+        lens = np.diff(self.doc_ptr.astype(np.int64))
+        if len(self.tokens):
+            t, d, p = _triples(lens, self.tokens)
+            words, word_terms = rz.encode_sorted(t, d, p)
+        else:
+            words, word_terms = np.empty(0, np.uint64), np.empty(0, np.uint32)
+        self._words, self._term_off = words, rz.term_offsets(word_terms, len(self.term_dict))
+
+    @property
+    def words(self) -> np.ndarray:
+        self._materialise_words()
+        return self._words
+
+    @property
+    def term_off(self) -> np.ndarray:
+        self._materialise_words()
+        return self._term_off
+
+    def _materialise_doc_terms(self):
+        if self._doc_term_ptr is not None:
+            return
+        lens = np.diff(self.doc_ptr.astype(np.int64))
+        docs = np.repeat(np.arange(len(lens), dtype=np.uint64), lens)
+        self._doc_term_ptr, self._doc_term_ids = _csr_doc_terms(self.tokens, docs, len(lens))
+
+    @property
+    def doc_term_ptr(self) -> np.ndarray:
+        self._materialise_doc_terms()
+        return self._doc_term_ptr
+
+    @property
+    def doc_term_ids(self) -> np.ndarray:
+        self._materialise_doc_terms()
+        return self._doc_term_ids
+
+    def __getstate__(self):
+        self._materialise_words()                   # pickles are self-contained
+        state = dict(self.__dict__)
+        state["words_source"] = None
+        return state
 
 
 def _csr_doc_terms(terms: np.ndarray, docs: np.ndarray, n_docs: int):
@@ -44,22 +109,15 @@ def _csr_doc_terms(terms: np.ndarray, docs: np.ndarray, n_docs: int):
 
 
 def build_from_token_ids(term_dict: TermDict, doc_tokens: List[np.ndarray]) -> HostIndex:
-    """doc_tokens[d] = term ids of doc d in position order"""
+    """doc_tokens[d] = term ids of doc d in position order.  Only the token stream is assembled here;
+    sorting by term and the roaringish encoding run on the device when the index is first used."""
     n_docs = len(doc_tokens)
     lens = np.fromiter((len(t) for t in doc_tokens), dtype=np.int64, count=n_docs)
     total = int(lens.sum())
-    if total:
-        terms = np.concatenate(doc_tokens).astype(np.uint32)
-        t, d, p = _triples(lens, terms)
-        words, word_terms = rz.encode_sorted(t, d, p)
-    else:
-        terms = np.empty(0, np.uint32)
-        t = np.empty(0, np.uint32); d = np.empty(0, np.uint64)
-        words, word_terms = np.empty(0, np.uint64), np.empty(0, np.uint32)
-    V = len(term_dict)
-    term_off = rz.term_offsets(word_terms, V)
-    ptr, ids = _csr_doc_terms(t, d, n_docs)
-    return HostIndex(term_dict, words, term_off, lens.astype(np.float32), ptr, ids)
+    tokens = np.concatenate(doc_tokens).astype(np.uint32) if total else np.empty(0, np.uint32)
+    doc_ptr = np.zeros(n_docs + 1, dtype=np.uint64)
+    np.cumsum(lens, out=doc_ptr[1:])
+    return HostIndex(term_dict, lens.astype(np.float32), tokens=tokens, doc_ptr=doc_ptr)
 
 
 def _triples(lens: np.ndarray, terms: np.ndarray):
@@ -120,6 +178,6 @@ def build_index_from_terms_list(postings, Terms) -> HostIndex:
         words, word_terms = rz.encode_sorted(t[order].astype(np.uint32), d[order].astype(np.uint64), p[order].astype(np.uint64))
     else:
         words, word_terms = np.empty(0, np.uint64), np.empty(0, np.uint32)
-    return HostIndex(term_dict, words, rz.term_offsets(word_terms, V), np.asarray(doc_lens, dtype=np.float32),
-                     np.asarray(ptr, dtype=np.int64), np.asarray(ids, dtype=np.uint32),
-                     np.asarray(tfs, dtype=np.float64))
+    return HostIndex(term_dict, np.asarray(doc_lens, dtype=np.float32), words=words,
+                     term_off=rz.term_offsets(word_terms, V), doc_term_ptr=np.asarray(ptr, dtype=np.int64),
+                     doc_term_ids=np.asarray(ids, dtype=np.uint32), doc_term_tfs=np.asarray(tfs, dtype=np.float64))

@@ -157,8 +157,16 @@ class _IndexCore:
     def device(self) -> DeviceIndex:
         if self._device is None:
             h = self.host
-            self._device = DeviceIndex(h.words, h.term_off, h.doc_lens, avg_doc_len=self.avg_doc_length,
-                                       corpus_size=self.corpus_size, api=_lib.api())
+            if not h.has_words and h.tokens is not None:
+                # index build on the device: sort by term + roaringish encode in HBM
+                dev = DeviceIndex.from_tokens(h.tokens, h.doc_ptr, len(self.term_dict), doc_lens=h.doc_lens,
+                                              avg_doc_len=self.avg_doc_length, corpus_size=self.corpus_size,
+                                              api=_lib.api())
+                h.words_source = dev.words
+                self._device = dev
+            else:
+                self._device = DeviceIndex(h.words, h.term_off, h.doc_lens, avg_doc_len=self.avg_doc_length,
+                                           corpus_size=self.corpus_size, api=_lib.api())
         return self._device
 
     def __getstate__(self):

@@ -243,3 +243,54 @@ def test_unpruned_block_selection_path(small, k, monkeypatch):
         n = int((ws > 0).sum())
         assert np.array_equal(scores[qi, :n], ws[:n]) and np.array_equal(docs[qi, :n], wd[:n])
     bt.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# index build on the device (sa_index_create_from_tokens)
+# ---------------------------------------------------------------------------------------------
+def _tokens_of(t, d, p, n_docs):
+    """(term, doc, pos) triples -> flat token stream in (doc, pos) order + doc offsets"""
+    order = np.lexsort((p, d))
+    lens = np.bincount(d.astype(np.int64), minlength=n_docs)
+    ptr = np.zeros(n_docs + 1, dtype=np.uint64)
+    np.cumsum(lens, out=ptr[1:])
+    return t[order].astype(np.uint32), ptr
+
+
+@pytest.mark.parametrize("name", ["zipf_small", "zipf_sparse"])
+def test_device_index_build_is_byte_identical(api, name):
+    """token stream -> sort by term + roaringish encode on the device == the host encoder (which is
+    pinned to the reference's encoder on these corpora), and the derived statistics agree"""
+    g, (t, d, p), lens, num_docs, vocab = golden_corpus(name)
+    words, wt = rz.encode_sorted(t, d, p)
+    off = rz.term_offsets(wt, vocab)
+    tokens, ptr = _tokens_of(t, d, p, num_docs)
+    dev = DeviceIndex.from_tokens(tokens, ptr, vocab, doc_lens=lens, tile_docs=1024, api=api)
+    got_words, got_off = dev.words()
+    assert np.array_equal(got_off, off)
+    assert np.array_equal(got_words, words)
+    assert np.array_equal(dev.docfreqs(), g["df"])
+    row = [int(x) for x in g["or_queries"][0]]
+    assert np.array_equal(dev.bm25_dense(row), g["or_scores"][0])
+
+
+def test_device_index_build_edge_cases(api):
+    # empty docs, a term that never occurs, positions crossing the 18-bit block boundary
+    lens = np.asarray([0, 40, 0, 3, 0], dtype=np.int64)
+    ptr = np.zeros(6, dtype=np.uint64)
+    np.cumsum(lens, out=ptr[1:])
+    tokens = np.concatenate([np.tile([0, 2], 20), [2, 2, 4]]).astype(np.uint32)
+    dev = DeviceIndex.from_tokens(tokens, ptr, 6, api=api, tile_docs=1024)
+    words, off = dev.words()
+    d = np.repeat(np.arange(5), lens).astype(np.uint64)
+    p = np.concatenate([np.arange(n) for n in lens]).astype(np.uint64)
+    order = np.lexsort((p, d, tokens))
+    want_words, wt = rz.encode_sorted(tokens[order], d[order], p[order])
+    assert np.array_equal(words, want_words) and np.array_equal(off, rz.term_offsets(wt, 6))
+    assert list(dev.docfreqs()) == [1, 0, 2, 0, 1, 0]
+    assert dev.termfreqs_dense(2)[1] == 20 and dev.termfreqs_dense(2)[3] == 2
+    # no tokens at all
+    dev0 = DeviceIndex.from_tokens(np.empty(0, np.uint32), np.zeros(4, np.uint64), 3, api=api, tile_docs=1024)
+    assert dev0.words()[0].size == 0 and (dev0.docfreqs() == 0).all()
+    with pytest.raises(Exception, match="term id"):
+        DeviceIndex.from_tokens(np.asarray([7], np.uint32), np.asarray([0, 1], np.uint64), 3, api=api)
