@@ -127,19 +127,28 @@ def _triples(lens: np.ndarray, terms: np.ndarray):
 
 def build_index_from_tokenizer(array: Iterable, tokenizer: Callable, truncate: bool = False,
                                batch_size: int = 100000) -> HostIndex:
-    """reference indexing.py:235-296 (single pass; batch_size only bounds the token buffers)."""
+    """reference indexing.py:235-296 (single pass; batch_size is accepted for signature parity).
+    Host work is the tokenizer and the term dictionary only; the result carries the token stream."""
     term_dict = TermDict()
-    doc_tokens: List[np.ndarray] = []
+    add_terms = term_dict.add_terms
     max_posn = rz.MAX_POSN
+    flat: List[int] = []
+    lens: List[int] = []
     for doc in array:
-        toks = [term_dict.add_term(tok) for tok in tokenizer(doc)]
+        toks = add_terms(tokenizer(doc))
         if len(toks) > max_posn:
             if truncate:
                 toks = toks[:max_posn]                      # reference indexing.py:120-122,76-78
             else:
                 raise ValueError(f"Document length exceeds maximum of {max_posn}")    # indexing.py:141-142
-        doc_tokens.append(np.asarray(toks, dtype=np.uint32))
-    return build_from_token_ids(term_dict, doc_tokens)
+        flat.extend(toks)
+        lens.append(len(toks))
+    n_docs = len(lens)
+    lens_a = np.asarray(lens, dtype=np.int64) if n_docs else np.empty(0, np.int64)
+    tokens = np.asarray(flat, dtype=np.uint32) if flat else np.empty(0, np.uint32)
+    doc_ptr = np.zeros(n_docs + 1, dtype=np.uint64)
+    np.cumsum(lens_a, out=doc_ptr[1:])
+    return HostIndex(term_dict, lens_a.astype(np.float32), tokens=tokens, doc_ptr=doc_ptr)
 
 
 def build_index_from_terms_list(postings, Terms) -> HostIndex:
