@@ -2,6 +2,7 @@
 // per-batch tables, candidate lists, the per-shard merge and the cross-rank exchange buffers.
 #pragma once
 #include "sa_index.hpp"
+#include "sa_topk.hpp"
 #include <vector>
 
 #define SA_MAX_QTERMS 32
@@ -25,6 +26,8 @@ struct sa_batch {
     bool cap_limited = false;       // cand_cap below the worst case: overflow must be checked
     u32* d_cand_cnt = nullptr;      // [B] append cursors (pruned selection)
     u32* d_slots = nullptr;         // [B][32] pruning slots
+    u32* d_gthr = nullptr;          // [B] cached histogram bound (k > 32), inside the d_slots allocation
+    u32* d_hist = nullptr;          // [B][SA_HBINS] score histograms (k > 32), inside the d_slots allocation
     u64* d_local = nullptr;         // [B][k] per-shard result
     u64* d_gather = nullptr;        // [2][nranks][B][k] (multi-GPU, double-buffered like d_xlocal)
     u64* d_xlocal = nullptr;        // [2][B][k] per-shard results handed to the exchange stream

@@ -51,6 +51,8 @@ struct Bm25Params {
     u32 cand_cap;          // pruned mode: capacity of each query's append list
     u32* cand_cnt;         // pruned mode: [B] append cursors
     u32* slots;            // pruned mode: [B][32] pruning slots (score bits)
+    u32* hist;             // pruned mode, k > 32: [B][SA_HBINS] score histograms (null: use the slots)
+    u32* gthr;             // pruned mode, k > 32: [B] cached bound (score bits)
     // outputs
     float* dense_out;      // [B][n_docs] or null
     u64* cand;             // [B][n_tiles][k] composite keys (global doc ids) or null
@@ -135,9 +137,13 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
     const u64 tile_base = (u64)tile * TILE;
     // pruning slots of this query (see the top-k section); loaded first so the L2 latency hides
     // behind the posting stream.  L1-bypassing load: a fresher bound prunes more.
+    // (k > 32 on tiles of <= 4 waves: the cached histogram bound instead, see sa_tile_topk_hist)
+    constexpr bool HIST_OK = (size_t)NW * SA_HBINS * 4 <= sizeof(float) * SA_SAT_NTF * SA_SAT_WMAX;
+    const bool use_hist = MODE == 1 && HIST_OK && p.hist != nullptr;
     u32 slot_val = 0xFFFFFFFFu;
-    if (MODE == 1 && (tid & (SA_WAVE - 1)) < 32u)
+    if (MODE == 1 && !use_hist && (tid & (SA_WAVE - 1)) < 32u)
         slot_val = __hip_atomic_load(&p.slots[q * 32u + (tid & 31u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (use_hist) slot_val = __hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // 1. this tile's slice [lo, hi) of every query term: one dependent load from the batch's
     //    slice table; clear the accumulators meanwhile
@@ -247,6 +253,14 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
     const u32 k = p.k;
     if (p.cand && !p.no_topk) {
     if constexpr (MODE == 1) {
+        if constexpr (HIST_OK) {
+            if (use_hist) {
+                // the saturation table is dead (barrier after the last term): its LDS is the waves' scratch
+                sa_tile_topk_hist<TILE, THREADS>(acc, slot_val, q, tile, p.doc_base + tile_base, k, p.hist, p.gthr, p.cand,
+                                                 p.cand_cap, p.cand_cnt, (u32*)s_tab);
+                return;
+            }
+        }
         sa_tile_topk_pruned<TILE, THREADS>(acc, slot_val, q, tile, p.doc_base + tile_base, k, p.slots, p.cand,
                                            p.cand_cap, p.cand_cnt);
     } else {
@@ -373,7 +387,7 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
 // Small rows (<= SA_MERGE_LIST keys: a cross-rank merge, or a well-pruned append list) go straight
 // into LDS and a bitonic sort finishes.  Larger rows are first cut by a lower bound of the k-th
 // largest key that is already known:
-//   slots != null      the pruning slots the tile kernel left behind (>= k docs score >= min slot)
+//   gthr / slots       the bound the tile kernel left behind (>= k docs score at or above it)
 //   rank_stride > 0    rows made of sorted groups of rank_stride keys: the k-th largest GROUP
 //                      LEADER bounds the k-th largest key (k distinct groups own a key >= it)
 // One pass keeps the keys above the bound in LDS.  If they overflow the LDS list (large k, ties)
@@ -384,7 +398,7 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
 __global__ void __launch_bounds__(1024)
 sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__ out,
                 const u32* __restrict__ out_row, u32 rank_stride, const u32* __restrict__ cnt,
-                const u32* __restrict__ slots) {
+                const u32* __restrict__ slots, const u32* __restrict__ gthr) {
     constexpr int NW = 1024 / SA_WAVE;
     __shared__ u64 red64[NW + 1];
     __shared__ u64 sel[SA_MERGE_LIST];
@@ -431,7 +445,9 @@ sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__
 
     u64 thr = 1;
     if (n_cand > SA_MERGE_LIST) {
-        if (slots) {
+        if (gthr) {
+            thr = (u64)gthr[q] << 32;                 // histogram bound left behind by the tile kernel
+        } else if (slots) {
             u32 g = slots[(u64)q * 32 + (tid & 31)];
             g = sa_wave_min_u32(g);                   // every wave computes the same minimum
             thr = (u64)g << 32;
@@ -660,8 +676,11 @@ int sa_batch_alloc_topk(sa_batch* bt, u32 n_tiles, u32 waves) {
     bt->cap_limited = cap < worst;
     const size_t ncand = (size_t)B * cap;
     SA_HIP(hipMalloc(&bt->d_cand, ncand * sizeof(u64)));
-    SA_HIP(hipMalloc(&bt->d_slots, (size_t)B * 33 * sizeof(u32)));   // slots + cursors: one memset per run
+    // slots + cursors (+ cached bounds + score histograms for k > 32): one memset per run
+    SA_HIP(hipMalloc(&bt->d_slots, (size_t)B * (34 + SA_HBINS) * sizeof(u32)));
     bt->d_cand_cnt = bt->d_slots + (size_t)B * 32;
+    bt->d_gthr = bt->d_slots + (size_t)B * 33;
+    bt->d_hist = bt->d_slots + (size_t)B * 34;
     SA_HIP(hipMalloc(&bt->d_local, (size_t)B * bt->k * sizeof(u64)));
     SA_HIP(hipMalloc(&bt->d_final, (size_t)B * bt->k * sizeof(u64)));
     SA_HIP(hipMemset(bt->d_final, 0, (size_t)B * bt->k * sizeof(u64)));
@@ -768,8 +787,14 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out) {
     p.cand_cnt = bt->d_cand_cnt;
     p.slots = bt->d_slots;
     if (bt->kind == 1) p.small_k_argmax = 1;                      // phrase tiles: pruned selection only
+    // k > 32: histogram bound (BM25 tiles of <= 4 waves); SA_TOPK_HIST=0 keeps the slot bound
+    const bool use_hist = p.small_k_argmax && bt->kind == 0 && bt->k > 32 && sa_tile_waves(ix->tile_docs) <= 4 &&
+                          sa_env_int("SA_TOPK_HIST", 1) != 0;
+    p.hist = use_hist ? bt->d_hist : nullptr;
+    p.gthr = use_hist ? bt->d_gthr : nullptr;
     if (p.small_k_argmax) {
-        SA_HIP(hipMemsetAsync(bt->d_slots, 0, (size_t)bt->B * 33 * sizeof(u32), st));   // slots + cursors
+        const size_t words = use_hist ? (size_t)bt->B * (34 + SA_HBINS) : (size_t)bt->B * 33;
+        SA_HIP(hipMemsetAsync(bt->d_slots, 0, words * sizeof(u32), st));
     }
     const u32 slot = bt->ev_n % SA_EVENT_RING;
     SA_HIP(hipEventRecord(bt->ev0[slot], st));
@@ -782,7 +807,8 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out) {
     }
     SA_HIP(hipEventRecord(bt->ev1[slot], st));
     bt->ev_n++;
-    if (p.small_k_argmax && bt->cap_limited && n_tiles > 0) {
+    // (with the histogram bound a wave appends all its survivors, so the worst case is not bounded by k)
+    if (p.small_k_argmax && (bt->cap_limited || use_hist) && n_tiles > 0) {
         // the candidate lists are smaller than the worst case: make sure no query ran over
         std::vector<u32> h_cnt(bt->B);
         SA_HIP(hipMemcpyAsync(h_cnt.data(), bt->d_cand_cnt, (size_t)bt->B * sizeof(u32), hipMemcpyDeviceToHost, st));
@@ -796,13 +822,15 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out) {
         if (over) {
             p.small_k_argmax = 0;
             p.cand_per_tile = bt->k;
+            p.hist = nullptr; p.gthr = nullptr;
             SA_TRY(sa_launch_bm25(ix, p, st));
         }
     }
     const u32 n_cand = p.small_k_argmax ? p.cand_cap : (n_tiles ? n_tiles : 1) * p.cand_per_tile;
     hipLaunchKernelGGL(sa_k_topk_merge, dim3(bt->B), dim3(1024), 0, st, bt->d_cand, n_cand, bt->k, shard_out,
                        (const u32*)bt->d_perm, 0u, (const u32*)(p.small_k_argmax ? bt->d_cand_cnt : nullptr),
-                       (const u32*)(p.small_k_argmax ? bt->d_slots : nullptr));
+                       (const u32*)(p.small_k_argmax && !p.hist ? bt->d_slots : nullptr),
+                       (const u32*)(p.small_k_argmax && p.hist ? bt->d_gthr : nullptr));
     bt->ran = true;
     return SA_OK;
 }
@@ -821,7 +849,7 @@ static int sa_batch_merge_ranks(sa_batch* bt, const u64* d_gathered, int nranks,
     hipLaunchKernelGGL(sa_k_regroup, dim3(grid), dim3(256), 0, st, d_gathered, (u32)nranks, bt->B, bt->k, bt->d_xcand);
     // every rank's block is its sorted top-k: group leaders = rank maxima
     hipLaunchKernelGGL(sa_k_topk_merge, dim3(bt->B), dim3(1024), 0, st, bt->d_xcand, (u32)nranks * bt->k, bt->k, bt->d_final,
-                       (const u32*)nullptr, bt->k, (const u32*)nullptr, (const u32*)nullptr);
+                       (const u32*)nullptr, bt->k, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr);
     return SA_OK;
 }
 

@@ -199,3 +199,149 @@ __device__ __forceinline__ void sa_tile_topk_pruned(float* acc, u32 slot_val, u3
     for (u32 r = found + lane; r < k; r += SA_WAVE)           // unused reserved slots
         if (cbase + r < cand_cap) qcand[cbase + r] = 0ull;
 }
+
+// ---------------------------------------------------------------------------------------
+// Pruned top-k for large k (32 < k <= 1024): the bound comes from a per-query score HISTOGRAM.
+//
+// The slot bound above is loose for k >> 32 (a slot holds a score that only ceil(k/32) docs of one
+// wave reach).  Here every wave that survives the bound adds its surviving docs to a global
+// 256-bin histogram of the query (bins = the top bits of the fp32 pattern: 16 bins per octave,
+// 4.4 % wide, scores 2^-6 .. 2^10), and the bound is the lower edge of the highest bin above which
+// at least k docs have been counted -- the k-th best score seen so far, to bin resolution.  Every
+// doc is counted at most once (by the wave that owns it) and only docs that exist are counted, so
+// at least k docs reach the bound: nothing below it can enter the top-k.  Waves whose maximum is
+// below the cached bound gthr[q] are done after one reduction; the others count their survivors
+// (per-wave histogram in LDS, flushed with one global atomic per non-empty bin), refresh the bound
+// and append ALL their docs at or above it (no per-wave exact top-k: the bound is tight enough
+// that appending is cheaper).  Stale reads only weaken the bound.
+// lds_hist: 256 u32 per wave of scratch LDS.
+// ---------------------------------------------------------------------------------------
+#define SA_HBINS 256
+#define SA_HBIN_SHIFT 19
+#define SA_HBIN_BASE ((127u - 6u) << 4)
+
+__device__ __forceinline__ u32 sa_score_bin(u32 x) {
+    const u32 e = x >> SA_HBIN_SHIFT;
+    return e <= SA_HBIN_BASE ? 0u : (e - SA_HBIN_BASE > (u32)(SA_HBINS - 1) ? (u32)(SA_HBINS - 1) : e - SA_HBIN_BASE);
+}
+__device__ __forceinline__ u32 sa_bin_edge(u32 b) { return b == 0 ? 0u : (b + SA_HBIN_BASE) << SA_HBIN_SHIFT; }
+
+template <int TILE, int THREADS>
+__device__ __forceinline__ void sa_tile_topk_hist(float* acc, u32 gc, u32 q, u32 tile, u64 doc0, u32 k,
+                                                  u32* __restrict__ hist, u32* __restrict__ gthr,
+                                                  u64* __restrict__ cand, u32 cand_cap, u32* __restrict__ cand_cnt,
+                                                  u32* lds_hist) {
+    constexpr int E = TILE / THREADS;
+    const u32 tid = threadIdx.x;
+    const u32 lane = tid & (SA_WAVE - 1), wave = tid / SA_WAVE;
+    u32 lmax = 0;
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        const u32 x = __float_as_uint(acc[j * THREADS + tid]);
+        lmax = x > lmax ? x : lmax;
+    }
+    const u32 wmax = sa_wave_max_u32(lmax);
+    const u32 thr0 = gc > 1u ? gc : 1u;
+    if (wmax < thr0) return;                                   // wave-uniform
+    u32* qh = hist + (u64)q * SA_HBINS;
+    u64* qcand = cand + (u64)q * cand_cap;
+    const u64 lt = (1ull << lane) - 1ull;
+    u32 c0 = 0;
+#pragma unroll
+    for (int j = 0; j < E; j++)
+        c0 += (u32)__popcll(__ballot(__float_as_uint(acc[j * THREADS + tid]) >= thr0));
+    // Steady state: a handful of docs reach the cached bound.  Count them with one global atomic
+    // each and append them; the bound itself is refreshed by every 8th surviving wave (and by any
+    // wave with many survivors, i.e. while the bound is still far off) -- a stale bound is valid.
+    constexpr int NW = THREADS / SA_WAVE;
+    if (c0 <= 16u && ((tile * NW + wave) & 7u) != 0u) {
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(&cand_cnt[q], c0);
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const u32 e = (u32)j * THREADS + tid;
+            const u32 x = __float_as_uint(acc[e]);
+            const bool keep = x >= thr0;
+            const u64 b = __ballot(keep);
+            if (keep) {
+                atomicAdd(&qh[sa_score_bin(x)], 1u);
+                const u32 pos = base + (u32)__popcll(b & lt);
+                if (pos < cand_cap) qcand[pos] = ((u64)x << 32) | (u64)(u32)(~(u32)(doc0 + e));
+            }
+            base += (u32)__popcll(b);
+        }
+        return;
+    }
+    // 1. count this wave's docs >= the cached bound, per bin
+    u32* wh = lds_hist + wave * SA_HBINS;
+#pragma unroll
+    for (int i = 0; i < SA_HBINS / SA_WAVE; i++) wh[i * SA_WAVE + lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        const u32 x = __float_as_uint(acc[j * THREADS + tid]);
+        if (x >= thr0) atomicAdd(&wh[sa_score_bin(x)], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // lane L owns bins 4L .. 4L+3: flush, then read the query's totals back
+    u32 tot[SA_HBINS / SA_WAVE];
+#pragma unroll
+    for (int i = 0; i < SA_HBINS / SA_WAVE; i++) {
+        const u32 b = lane * (SA_HBINS / SA_WAVE) + i;
+        const u32 v = wh[b];
+        u32 old = 0;
+        if (v) old = atomicAdd(&qh[b], v);
+        else old = __hip_atomic_load(&qh[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tot[i] = old + v;
+    }
+    // 2. the bound: highest bin with at least k docs at or above it
+    u32 lane_sum = 0;
+#pragma unroll
+    for (int i = 0; i < SA_HBINS / SA_WAVE; i++) lane_sum += tot[i];
+    u32 suf = lane_sum;                                         // inclusive suffix sum over lanes
+#pragma unroll
+    for (int o = 1; o < SA_WAVE; o <<= 1) {
+        const u32 up = __shfl_down(suf, (unsigned)o, SA_WAVE);
+        if (lane + (u32)o < (u32)SA_WAVE) suf += up;
+    }
+    const u64 ok = __ballot(suf >= k);
+    u32 g = 0;
+    if (ok) {
+        const u32 ls = 63u - (u32)__clzll((long long)ok);       // highest lane whose suffix reaches k
+        u32 above = __shfl_down(suf, 1u, SA_WAVE);              // docs in the lanes above mine
+        if (lane == (u32)SA_WAVE - 1) above = 0;
+        u32 bsel = 0;
+#pragma unroll
+        for (int i = SA_HBINS / SA_WAVE - 1; i >= 0; i--) {
+            above += tot[i];
+            if (bsel == 0 && above >= k) bsel = lane * (SA_HBINS / SA_WAVE) + (u32)i + 1u;   // +1: 0 means none
+        }
+        const u32 b = (u32)__shfl((int)bsel, (int)ls, SA_WAVE);
+        g = b ? sa_bin_edge(b - 1u) : 0u;
+    }
+    if (lane == 0 && g > gc) atomicMax(&gthr[q], g);
+    const u32 thr = g > thr0 ? g : thr0;
+    // 3. append every doc of this wave at or above the bound
+    u32 c = 0;
+#pragma unroll
+    for (int j = 0; j < E; j++)
+        c += (u32)__popcll(__ballot(__float_as_uint(acc[j * THREADS + tid]) >= thr));
+    if (c == 0) return;
+    u32 base = 0;
+    if (lane == 0) base = atomicAdd(&cand_cnt[q], c);
+    base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        const u32 e = (u32)j * THREADS + tid;
+        const u32 x = __float_as_uint(acc[e]);
+        const bool keep = x >= thr;
+        const u64 b = __ballot(keep);
+        if (keep) {
+            const u32 pos = base + (u32)__popcll(b & lt);
+            if (pos < cand_cap) qcand[pos] = ((u64)x << 32) | (u64)(u32)(~(u32)(doc0 + e));
+        }
+        base += (u32)__popcll(b);
+    }
+}
+

@@ -278,6 +278,8 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
     f->bound_ctrl = bound_ctrl ? 1 : 0;
     return (int)(uint32_t)hipemu::wave_collective(hipemu::OP_DPP, (uint64_t)(uint32_t)src, 0);
 }
+// scheduling barrier on the GPU; here the lanes of a wave are fibers, so it must really line them up
+inline void __builtin_amdgcn_wave_barrier() { (void)__ballot(1); }
 inline int __builtin_amdgcn_readlane(int v, int lane) {
     return (int)(uint32_t)hipemu::wave_collective(hipemu::OP_SHFL, (uint64_t)(uint32_t)v, lane);
 }

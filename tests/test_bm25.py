@@ -294,3 +294,11 @@ def test_device_index_build_edge_cases(api):
     assert dev0.words()[0].size == 0 and (dev0.docfreqs() == 0).all()
     with pytest.raises(Exception, match="term id"):
         DeviceIndex.from_tokens(np.asarray([7], np.uint32), np.asarray([0, 1], np.uint64), 3, api=api)
+
+
+@pytest.mark.parametrize("k", [40, 300])
+def test_large_k_slot_bound_path(small, k, monkeypatch):
+    """k > 32 defaults to the histogram bound; SA_TOPK_HIST=0 keeps the slot bound (also what tiles of
+    more than 4 waves and phrase batches use)"""
+    monkeypatch.setenv("SA_TOPK_HIST", "0")
+    test_topk_batch_matches_oracle(small, k)
