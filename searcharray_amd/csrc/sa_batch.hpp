@@ -28,6 +28,7 @@ struct sa_batch {
     u32* d_slots = nullptr;         // [B][32] pruning slots
     u32* d_gthr = nullptr;          // [B] cached histogram bound (k > 32), inside the d_slots allocation
     u32* d_hist = nullptr;          // [B][SA_HBINS] score histograms (k > 32), inside the d_slots allocation
+    u32* d_overflow = nullptr;      // set by the merge kernel when a candidate list ran over (checked at fetch)
     u64* d_local = nullptr;         // [B][k] per-shard result
     u64* d_gather = nullptr;        // [2][nranks][B][k] (multi-GPU, double-buffered like d_xlocal)
     u64* d_xlocal = nullptr;        // [2][B][k] per-shard results handed to the exchange stream

@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
 __global__ void __launch_bounds__(1024)
 sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__ out,
                 const u32* __restrict__ out_row, u32 rank_stride, const u32* __restrict__ cnt,
-                const u32* __restrict__ slots, const u32* __restrict__ gthr) {
+                const u32* __restrict__ slots, const u32* __restrict__ gthr, u32* __restrict__ overflow) {
     constexpr int NW = 1024 / SA_WAVE;
     __shared__ u64 red64[NW + 1];
     __shared__ u64 sel[SA_MERGE_LIST];
@@ -407,7 +407,11 @@ sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__
     u64* c = cand + (u64)q * n_cand_max;
     // cnt != null: the row is an append list holding cnt[q] keys (pruned tile selection)
     u32 n_cand = n_cand_max;
-    if (cnt) { const u32 have = cnt[q]; n_cand = have < n_cand_max ? have : n_cand_max; }
+    if (cnt) {
+        const u32 have = cnt[q];
+        n_cand = have < n_cand_max ? have : n_cand_max;
+        if (have > n_cand_max && overflow && tid == 0) atomicMax(overflow, 1u);   // the list ran over: see sa_batch_fetch
+    }
     const u32 row = out_row ? out_row[q] : q;       // device row q holds caller query out_row[q]
     for (u32 i = tid; i < SA_MERGE_LIST; i += 1024) sel[i] = 0;
     if (tid == 0) s_n = 0;
@@ -677,10 +681,12 @@ int sa_batch_alloc_topk(sa_batch* bt, u32 n_tiles, u32 waves) {
     const size_t ncand = (size_t)B * cap;
     SA_HIP(hipMalloc(&bt->d_cand, ncand * sizeof(u64)));
     // slots + cursors (+ cached bounds + score histograms for k > 32): one memset per run
-    SA_HIP(hipMalloc(&bt->d_slots, (size_t)B * (34 + SA_HBINS) * sizeof(u32)));
+    SA_HIP(hipMalloc(&bt->d_slots, ((size_t)B * (34 + SA_HBINS) + 1) * sizeof(u32)));
     bt->d_cand_cnt = bt->d_slots + (size_t)B * 32;
     bt->d_gthr = bt->d_slots + (size_t)B * 33;
     bt->d_hist = bt->d_slots + (size_t)B * 34;
+    bt->d_overflow = bt->d_slots + (size_t)B * (34 + SA_HBINS);      // outside the per-run memset
+    SA_HIP(hipMemset(bt->d_overflow, 0, sizeof(u32)));
     SA_HIP(hipMalloc(&bt->d_local, (size_t)B * bt->k * sizeof(u64)));
     SA_HIP(hipMalloc(&bt->d_final, (size_t)B * bt->k * sizeof(u64)));
     SA_HIP(hipMemset(bt->d_final, 0, (size_t)B * bt->k * sizeof(u64)));
@@ -769,7 +775,9 @@ __global__ void sa_k_regroup(const u64* __restrict__ gathered, u32 nranks, u32 B
 }
 
 // stage 1 (tile scoring + per-tile top-k) and stage 2 (per-shard merge) on the index stream
-static int sa_batch_run_shard(sa_batch* bt, u64* shard_out) {
+// defer_check: an overflowing candidate list is only flagged on the device; sa_batch_fetch re-runs the
+// batch unpruned before handing out results (no host round trip between the tile kernel and the merge)
+static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bool force_unpruned = false) {
     sa_index* ix = bt->ix;
     hipStream_t st = ix->stream;
     Bm25Params p;
@@ -779,17 +787,17 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out) {
     p.k1 = bt->k1; p.b = bt->b;
     p.bounds = bt->d_bounds; p.qbase = bt->d_qbase;
     p.sattab = bt->d_sattab; p.tab_w = bt->tab_w;
-    p.small_k_argmax = sa_env_int("SA_PRUNED_TOPK", 1) ? 1 : 0;   // pruned wave-level selection (any k <= 1024)
+    p.small_k_argmax = (sa_env_int("SA_PRUNED_TOPK", 1) && !force_unpruned) ? 1 : 0;   // pruned wave-level selection (any k <= 1024)
     p.dense_out = nullptr; p.cand = bt->d_cand;
     p.no_topk = sa_env_int("SA_NO_TOPK", 0);
     p.cand_per_tile = bt->k;
     p.cand_cap = bt->cand_cap;
     p.cand_cnt = bt->d_cand_cnt;
     p.slots = bt->d_slots;
-    if (bt->kind == 1) p.small_k_argmax = 1;                      // phrase tiles: pruned selection only
+    if (bt->kind == 1) { p.small_k_argmax = 1; defer_check = false; }   // phrase tiles: pruned selection only
     // k > 32: histogram bound (BM25 tiles of <= 4 waves); SA_TOPK_HIST=0 keeps the slot bound
-    const bool use_hist = p.small_k_argmax && bt->kind == 0 && bt->k > 32 && sa_tile_waves(ix->tile_docs) <= 4 &&
-                          sa_env_int("SA_TOPK_HIST", 1) != 0;
+    const bool use_hist = p.small_k_argmax && bt->kind == 0 && bt->k >= (u32)sa_env_int("SA_TOPK_HIST_MINK", defer_check ? 1 : 33) &&
+                          sa_tile_waves(ix->tile_docs) <= 4 && sa_env_int("SA_TOPK_HIST", 1) != 0;
     p.hist = use_hist ? bt->d_hist : nullptr;
     p.gthr = use_hist ? bt->d_gthr : nullptr;
     if (p.small_k_argmax) {
@@ -808,7 +816,8 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out) {
     SA_HIP(hipEventRecord(bt->ev1[slot], st));
     bt->ev_n++;
     // (with the histogram bound a wave appends all its survivors, so the worst case is not bounded by k)
-    if (p.small_k_argmax && (bt->cap_limited || use_hist) && n_tiles > 0) {
+    const bool may_overflow = p.small_k_argmax && (bt->cap_limited || use_hist) && n_tiles > 0;
+    if (may_overflow && !defer_check) {
         // the candidate lists are smaller than the worst case: make sure no query ran over
         std::vector<u32> h_cnt(bt->B);
         SA_HIP(hipMemcpyAsync(h_cnt.data(), bt->d_cand_cnt, (size_t)bt->B * sizeof(u32), hipMemcpyDeviceToHost, st));
@@ -830,7 +839,8 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out) {
     hipLaunchKernelGGL(sa_k_topk_merge, dim3(bt->B), dim3(1024), 0, st, bt->d_cand, n_cand, bt->k, shard_out,
                        (const u32*)bt->d_perm, 0u, (const u32*)(p.small_k_argmax ? bt->d_cand_cnt : nullptr),
                        (const u32*)(p.small_k_argmax && !p.hist ? bt->d_slots : nullptr),
-                       (const u32*)(p.small_k_argmax && p.hist ? bt->d_gthr : nullptr));
+                       (const u32*)(p.small_k_argmax && p.hist ? bt->d_gthr : nullptr),
+                       (may_overflow && defer_check) ? bt->d_overflow : (u32*)nullptr);
     bt->ran = true;
     return SA_OK;
 }
@@ -849,7 +859,8 @@ static int sa_batch_merge_ranks(sa_batch* bt, const u64* d_gathered, int nranks,
     hipLaunchKernelGGL(sa_k_regroup, dim3(grid), dim3(256), 0, st, d_gathered, (u32)nranks, bt->B, bt->k, bt->d_xcand);
     // every rank's block is its sorted top-k: group leaders = rank maxima
     hipLaunchKernelGGL(sa_k_topk_merge, dim3(bt->B), dim3(1024), 0, st, bt->d_xcand, (u32)nranks * bt->k, bt->k, bt->d_final,
-                       (const u32*)nullptr, bt->k, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr);
+                       (const u32*)nullptr, bt->k, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr,
+                       (u32*)nullptr);
     return SA_OK;
 }
 
@@ -887,7 +898,7 @@ extern "C" int sa_batch_run(sa_batch_t* bt, int sync) {
         u64* xl = bt->d_xlocal + bsel * count;
         u64* xg = bt->d_gather + bsel * (size_t)nranks * count;
         if (bt->exchanged_valid[bsel]) SA_HIP(hipStreamWaitEvent(st, bt->ev_exchanged[bsel], 0));
-        SA_TRY(sa_batch_run_shard(bt, xl));
+        SA_TRY(sa_batch_run_shard(bt, xl, false));
         SA_HIP(hipEventRecord(bt->ev_scored[bsel], st));
         SA_HIP(hipStreamWaitEvent(xs, bt->ev_scored[bsel], 0));
         SA_TRY(sa_comm_allgather_topk(ix, xl, xg, count, &nranks, xs));
@@ -896,7 +907,7 @@ extern "C" int sa_batch_run(sa_batch_t* bt, int sync) {
         bt->exchanged_valid[bsel] = true;
         if (sync) SA_HIP(hipStreamSynchronize(xs));
     } else {
-        SA_TRY(sa_batch_run_shard(bt, bt->d_final));
+        SA_TRY(sa_batch_run_shard(bt, bt->d_final, true));
     }
     if (sync) {
         SA_HIP(hipStreamSynchronize(st));
@@ -912,7 +923,7 @@ extern "C" int sa_batch_run_local(sa_batch_t* bt, void* local_keys_out_device, i
     sa_index* ix = bt->ix;
     std::lock_guard<std::mutex> g(ix->mu);
     SA_HIP(hipSetDevice(ix->device));
-    SA_TRY(sa_batch_run_shard(bt, bt->d_local));
+    SA_TRY(sa_batch_run_shard(bt, bt->d_local, false));
     if (local_keys_out_device)
         SA_HIP(hipMemcpyAsync(local_keys_out_device, bt->d_local, (size_t)bt->B * bt->k * sizeof(u64),
                               hipMemcpyDeviceToDevice, ix->stream));
@@ -947,6 +958,18 @@ extern "C" int sa_batch_fetch(sa_batch_t* bt, float* scores_out, uint64_t* docs_
     SA_HIP(hipStreamSynchronize(ix->stream));
     if (ix->xstream) SA_HIP(hipStreamSynchronize(ix->xstream));
     SA_HIP(hipGetLastError());
+    if (bt->d_overflow && !ix->comm) {
+        // a run since the last fetch overflowed a candidate list (only possible when the bound could
+        // not rise: degenerate score distributions): redo the batch with the unpruned selection
+        u32 over = 0;
+        SA_HIP(hipMemcpy(&over, bt->d_overflow, sizeof(u32), hipMemcpyDeviceToHost));
+        if (over) {
+            SA_HIP(hipMemset(bt->d_overflow, 0, sizeof(u32)));
+            SA_TRY(sa_batch_run_shard(bt, bt->d_final, false, true));
+            SA_HIP(hipStreamSynchronize(ix->stream));
+            SA_HIP(hipGetLastError());
+        }
+    }
     SA_HIP(hipMemcpy(keys.data(), bt->d_final, n * sizeof(u64), hipMemcpyDeviceToHost));
     for (u32 r = 0; r < bt->B; r++) {
         const u32 qi = r;                        // results are stored in caller order
