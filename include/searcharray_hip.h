@@ -228,6 +228,10 @@ int sa_batch_fetch(sa_batch_t* batch, float* scores_out, uint64_t* docs_out);
  * (sum_t 8*df_t + 4*n_docs); postings_bytes is the sum_t 8*df_t part alone. */
 int sa_batch_profile(sa_batch_t* batch, double* kernel_ms_out, uint64_t* alg_bytes_out,
                      uint64_t* postings_bytes_out);
+/* Diagnostics of the dynamic pruning (BM25 batches): enable != 0 starts counting the candidate docs
+ * the sparse path scores (one extra atomic each: not for timed runs); returns the count accumulated
+ * since the previous call and how many queries of the last run were answered without a tile scan. */
+int sa_batch_stats(sa_batch_t* batch, int enable, uint64_t* sparse_candidates_out, uint64_t* sparse_queries_out);
 int sa_batch_destroy(sa_batch_t* batch);
 
 typedef struct sa_index_info {
@@ -237,7 +241,7 @@ typedef struct sa_index_info {
     int device;
     int dl_packed;
     uint32_t n_docdir_terms;     /* frequent terms with a doc directory (phrase probes) */
-    uint32_t reserved;
+    uint32_t n_tf8_terms;        /* frequent terms with a dense tf row (dynamic pruning) */
 } sa_index_info_t;
 int sa_index_info(sa_index_t* ix, sa_index_info_t* out);
 

@@ -32,7 +32,7 @@ class IndexInfo(ctypes.Structure):
                 ("n_words", c_uint64), ("n_postings", c_uint64),
                 ("n_terms", c_uint32), ("tile_docs", c_uint32), ("n_tiles", c_uint32),
                 ("n_dir_terms", c_uint32), ("hbm_bytes", c_uint64), ("device", c_int),
-                ("dl_packed", c_int), ("n_docdir_terms", c_uint32), ("reserved", c_uint32)]
+                ("dl_packed", c_int), ("n_docdir_terms", c_uint32), ("n_tf8_terms", c_uint32)]
 
 
 # name -> (restype, argtypes).  Every symbol declared in include/searcharray_hip.h.
@@ -85,6 +85,7 @@ PROTOTYPES = {
     "sa_batch_merge_gathered": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "sa_batch_fetch": (c_int, [c_void_p, f32p, u64p]),
     "sa_batch_profile": (c_int, [c_void_p, POINTER(c_double), u64p, u64p]),
+    "sa_batch_stats": (c_int, [c_void_p, c_int, u64p, u64p]),
     "sa_batch_destroy": (c_int, [c_void_p]),
     # Part 3
     "sa_comm_unique_id": (c_int, [ctypes.c_char_p, c_int]),

@@ -28,6 +28,23 @@ struct sa_batch {
     u32* d_slots = nullptr;         // [B][32] pruning slots
     u32* d_gthr = nullptr;          // [B] cached histogram bound (k > 32), inside the d_slots allocation
     u32* d_hist = nullptr;          // [B][SA_HBINS] score histograms (k > 32), inside the d_slots allocation
+    float* d_ub = nullptr;          // [B][T+1] dynamic pruning: score bound of the j smallest-idf terms
+    u32* d_ub_order = nullptr;      // [B][T] query-term index of the j-th smallest idf
+    u32* d_stats = nullptr;         // diagnostics (sa_batch_stats), null unless enabled
+    // sparse candidate path (sa_sparse.hip)
+    u32* d_lead = nullptr;          // [B] query-term index of the lead term, or 0xFFFFFFFF
+    u64* d_p1_off = nullptr;        // [B+1] prefix sums of the lead terms' df
+    u32* d_route = nullptr;         // [B] 0: answered by the sparse path, 1: tiles
+    u32* d_emask = nullptr;         // [B] essential query terms
+    u64* d_p2_off = nullptr;        // [B+1] prefix sums of the phase-2 candidates
+    u32* d_tile_q = nullptr;        // [B] queries left to the tile kernel, then [1] their number, [1] survivor count
+    u32* d_qdf = nullptr;           // [B][T] postings of each query term in this shard
+    u32* d_qrow8 = nullptr;         // [B][T] dense tf row of each query term
+    u64* d_surv = nullptr;          // phase-2 survivors
+    u32* d_bloom = nullptr;         // [B][2^17 bytes] Bloom filters of the lead terms' docs
+    u32 surv_cap = 0;
+    u64 sparse_p1_total = 0, sparse_limit2 = 0, sparse_p2_max = 0;
+    bool sparse_ok = false;         // tables built and the scoring formula admits the idf bound
     u32* d_overflow = nullptr;      // set by the merge kernel when a candidate list ran over (checked at fetch)
     u64* d_local = nullptr;         // [B][k] per-shard result
     u64* d_gather = nullptr;        // [2][nranks][B][k] (multi-GPU, double-buffered like d_xlocal)
@@ -62,3 +79,5 @@ int sa_launch_phrase_tiles(sa_batch* bt, hipStream_t st);
 // shared by the two batch kinds (sa_bm25.hip)
 int sa_batch_alloc_topk(sa_batch* bt, u32 n_tiles, u32 waves);
 void sa_batch_free(sa_batch* bt);
+// dynamic pruning: lead-term candidates, routing, remaining essential candidates (sa_sparse.hip)
+int sa_launch_sparse(sa_batch* bt, hipStream_t st);

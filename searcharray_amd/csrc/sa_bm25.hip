@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <new>
 #include <stdlib.h>
+#include <math.h>
 
 
 struct alignas(16) sa_u64x2 { u64 x, y; };
@@ -53,6 +54,15 @@ struct Bm25Params {
     u32* slots;            // pruned mode: [B][32] pruning slots (score bits)
     u32* hist;             // pruned mode, k > 32: [B][SA_HBINS] score histograms (null: use the slots)
     u32* gthr;             // pruned mode, k > 32: [B] cached bound (score bits)
+    // dynamic pruning (MaxScore): per query the terms in ascending idf order and the score a doc
+    // can reach at most from the j smallest-idf terms alone
+    const float* ub;       // [B][T+1] upper bounds (ub[0] = 0), or null: exhaustive scoring
+    const u32* ub_order;   // [B][T] query-term index of the j-th smallest idf
+    const unsigned char* tf8;   // index dense tf rows [n_tf8_terms][n_docs]
+    const u32* tf8_slot;   // [n_terms]
+    u32* stats;            // diagnostics (sa_batch_stats): [B] candidates scored by the sparse path, or null
+    const u32* qlist;      // queries to scan (after the sparse path took the others), or null: all B
+    u32 nq;                // number of queries to scan (= B without a list)
     // outputs
     float* dense_out;      // [B][n_docs] or null
     u64* cand;             // [B][n_tiles][k] composite keys (global doc ids) or null
@@ -133,7 +143,9 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
     const u32 tab_w = p.tab_w;
     for (u32 i = tid; i < SA_SAT_NTF * tab_w; i += THREADS) s_tab[i] = p.sattab[i];
     const u32 item = blockIdx.x;
-    const u32 tile = item / p.B, q = item % p.B;
+    // (queries answered by the sparse candidate path, sa_sparse.hip, are not in the list)
+    const u32 tile = item / p.nq;
+    const u32 q = p.qlist ? p.qlist[item % p.nq] : item % p.nq;
     const u64 tile_base = (u64)tile * TILE;
     // pruning slots of this query (see the top-k section); loaded first so the L2 latency hides
     // behind the posting stream.  L1-bypassing load: a fresher bound prunes more.
@@ -523,6 +535,7 @@ static void sa_fill_params(const sa_index* ix, Bm25Params& p) {
     p.doc_lens = ix->d_doc_lens; p.n_terms = ix->n_terms; p.n_tiles = ix->n_tiles;
     p.n_docs = ix->n_docs; p.doc_base = ix->doc_base; p.dl_packed = ix->dl_packed ? 1 : 0;
     p.avgdl = ix->avg_doc_len;
+    p.qlist = nullptr; p.nq = 0;                     // callers set nq (= B) after filling B
 }
 
 static u32 sa_tile_waves(u32 tile_docs) {
@@ -566,7 +579,7 @@ static int sa_env_int(const char* name, int dflt) {
 
 template <int MODE>
 static int sa_launch_bm25_mode(sa_index* ix, const Bm25Params& p, hipStream_t st) {
-    const u64 n_items = (u64)p.B * ix->n_tiles;
+    const u64 n_items = (u64)p.nq * ix->n_tiles;
     switch (ix->tile_docs) {
         case 1024: SA_LAUNCH_TILE(1024, 128);
         case 2048: SA_LAUNCH_TILE(2048, 64);
@@ -582,7 +595,7 @@ static int sa_launch_bm25_mode(sa_index* ix, const Bm25Params& p, hipStream_t st
 }
 
 static int sa_launch_bm25(sa_index* ix, const Bm25Params& p, hipStream_t st) {
-    if (ix->n_tiles == 0 || p.B == 0) return SA_OK;
+    if (ix->n_tiles == 0 || p.nq == 0) return SA_OK;
     return p.small_k_argmax ? sa_launch_bm25_mode<1>(ix, p, st) : sa_launch_bm25_mode<0>(ix, p, st);
 }
 
@@ -618,7 +631,7 @@ extern "C" int sa_index_bm25_dense(sa_index_t* ix, const uint32_t* terms, const 
     Bm25Params p;
     memset(&p, 0, sizeof(p));
     sa_fill_params(ix, p);
-    p.terms = d_terms; p.idf = d_idf; p.B = 1; p.T = (u32)T; p.k = 0;
+    p.terms = d_terms; p.idf = d_idf; p.B = 1; p.nq = 1; p.T = (u32)T; p.k = 0;
     p.k1 = k1; p.b = b; p.small_k_argmax = 0;
     p.dense_out = d_out; p.cand = nullptr;
     p.bounds = d_bounds; p.qbase = d_qbase;
@@ -660,6 +673,19 @@ void sa_batch_free(sa_batch* bt) {
     if (bt->d_wbounds) hipFree(bt->d_wbounds);
     if (bt->d_wbase) hipFree(bt->d_wbase);
     if (bt->d_wlen) hipFree(bt->d_wlen);
+    if (bt->d_ub) hipFree(bt->d_ub);
+    if (bt->d_ub_order) hipFree(bt->d_ub_order);
+    if (bt->d_stats) hipFree(bt->d_stats);
+    if (bt->d_lead) hipFree(bt->d_lead);
+    if (bt->d_p1_off) hipFree(bt->d_p1_off);
+    if (bt->d_route) hipFree(bt->d_route);
+    if (bt->d_emask) hipFree(bt->d_emask);
+    if (bt->d_p2_off) hipFree(bt->d_p2_off);
+    if (bt->d_tile_q) hipFree(bt->d_tile_q);
+    if (bt->d_qdf) hipFree(bt->d_qdf);
+    if (bt->d_qrow8) hipFree(bt->d_qrow8);
+    if (bt->d_surv) hipFree(bt->d_surv);
+    if (bt->d_bloom) hipFree(bt->d_bloom);
     for (hipEvent_t e : bt->ev0) hipEventDestroy(e);
     for (hipEvent_t e : bt->ev1) hipEventDestroy(e);
     delete bt;
@@ -676,8 +702,14 @@ int sa_batch_alloc_topk(sa_batch* bt, u32 n_tiles, u32 waves) {
     const u64 mode0 = (u64)(n_tiles ? n_tiles : 1) * bt->k;
     u64 cap = worst < (1ull << 20) ? worst : (1ull << 20);
     if (cap < mode0) cap = mode0;                      // the unpruned layout [n_tiles][k] must fit too
+    // the sparse candidate path appends every doc of a lead term that is scored before the bound exists
+    if (bt->kind == 0 && cap < (1ull << 17)) cap = 1ull << 17;
+    if (const char* v = getenv("SA_CAND_CAP")) {       // tests: force the overflow handling
+        const u64 forced = (u64)atoll(v);
+        cap = forced > mode0 ? forced : mode0;
+    }
     bt->cand_cap = (u32)cap;
-    bt->cap_limited = cap < worst;
+    bt->cap_limited = cap < worst;                     // (sa_tile_topk_pruned appends at most k keys per wave)
     const size_t ncand = (size_t)B * cap;
     SA_HIP(hipMalloc(&bt->d_cand, ncand * sizeof(u64)));
     // slots + cursors (+ cached bounds + score histograms for k > 32): one memset per run
@@ -754,6 +786,91 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
     SA_HIP_B(hipMalloc(&bt->d_bounds, ((size_t)B * T * (ix->n_tiles + 1) + 1) * sizeof(u32)));
     SA_HIP_B(hipMalloc(&bt->d_qbase, (size_t)B * T * sizeof(u64)));
     SA_HIP_B(hipMalloc(&bt->d_sattab, SA_SAT_NTF * SA_SAT_WMAX * sizeof(float)));
+    {
+        // Dynamic pruning tables (sa_sparse.hip).  Per query: the terms in ascending idf order with the
+        // prefix sums of their idf -- what the j cheapest terms can add to a score at most, since
+        // tf/(tf+norm) <= 1 (needs k1 >= 0 and 0 <= b <= 1; a negative or non-finite idf switches the
+        // pruning off) -- and the LEAD term: the highest-idf term with postings in this shard.
+        std::vector<float> h_ub((size_t)B * (T + 1), 0.f);
+        std::vector<u32> h_ord((size_t)B * T, 0), h_lead(B, 0xFFFFFFFFu);
+        std::vector<u64> h_p1((size_t)B + 1, 0);
+        const bool formula_ok = k1 >= 0.f && b >= 0.f && b <= 1.f;
+        // lead terms up to 1/64 of the shard's docs (phase 1 scores every one of them), and never more
+        // postings than fit the candidate list while the bound is still unknown
+        u64 limit1 = ix->n_docs / 64 > 4096 ? ix->n_docs / 64 : 4096;
+        if (limit1 > (u64)bt->cand_cap * 3 / 4) limit1 = (u64)bt->cand_cap * 3 / 4;
+        bt->sparse_limit2 = ix->n_docs / (u64)sa_env_int("SA_SPARSE_DIV", 8) > 4096 ? ix->n_docs / (u64)sa_env_int("SA_SPARSE_DIV", 8) : 4096;
+        bool all_ok = formula_ok;
+        for (u32 r = 0; r < B; r++) {
+            std::vector<std::pair<float, u32>> v;
+            bool ok = formula_ok;
+            for (u32 t = 0; t < T; t++) {
+                const bool known = h_terms[(size_t)r * T + t] < ix->n_terms;
+                const float w = known ? h_idf[(size_t)r * T + t] : 0.f;
+                if (!(w >= 0.f) || w > 3.0e38f) ok = false;
+                v.push_back({w, t});
+            }
+            std::stable_sort(v.begin(), v.end(), [](const std::pair<float, u32>& a, const std::pair<float, u32>& c) { return a.first < c.first; });
+            double acc = 0.0;
+            for (u32 j = 0; j < T; j++) {
+                h_ord[(size_t)r * T + j] = v[j].second;
+                acc += (double)v[j].first;
+                // rounded up: the fp32 sum the kernels form can exceed the exact sum by a few ulps
+                float ubf = (float)(acc * (1.0 + 1e-5));
+                ubf = nextafterf(ubf, INFINITY);
+                h_ub[(size_t)r * (T + 1) + j + 1] = ok ? ubf : INFINITY;
+            }
+            // lead: highest idf among the terms with postings here; too frequent -> scan the tiles
+            if (ok) {
+                for (int j = (int)T - 1; j >= 0; j--) {
+                    const u32 t = v[(size_t)j].second;
+                    const u32 term = h_terms[(size_t)r * T + t];
+                    if (term >= ix->n_terms) continue;
+                    const u64 df = ix->h_tf_off[term + 1] - ix->h_tf_off[term];
+                    if (df == 0) continue;
+                    if (df <= limit1) { h_lead[r] = t; h_p1[r + 1] = (df + 1023) / 1024; }   // items of SA_SP_CHUNK postings
+                    break;
+                }
+            }
+            all_ok = all_ok && ok;
+        }
+        for (u32 r = 0; r < B; r++) h_p1[r + 1] += h_p1[r];
+        bt->sparse_p1_total = h_p1[B];
+        bt->sparse_ok = true;
+        SA_HIP_B(hipMalloc(&bt->d_ub, h_ub.size() * sizeof(float)));
+        SA_HIP_B(hipMalloc(&bt->d_ub_order, h_ord.size() * sizeof(u32)));
+        SA_HIP_B(hipMalloc(&bt->d_lead, (size_t)B * sizeof(u32)));
+        SA_HIP_B(hipMalloc(&bt->d_p1_off, ((size_t)B + 1) * sizeof(u64)));
+        SA_HIP_B(hipMalloc(&bt->d_route, (size_t)B * sizeof(u32)));
+        SA_HIP_B(hipMalloc(&bt->d_emask, (size_t)B * sizeof(u32)));
+        SA_HIP_B(hipMalloc(&bt->d_p2_off, ((size_t)B + 1) * sizeof(u64)));
+        SA_HIP_B(hipMalloc(&bt->d_tile_q, ((size_t)B + 2) * sizeof(u32)));
+        {
+            std::vector<u32> h_qdf((size_t)B * T, 0), h_row8((size_t)B * T, SA_DD_NONE);
+            for (size_t i = 0; i < (size_t)B * T; i++) {
+                const u32 term = h_terms[i];
+                if (term >= ix->n_terms) continue;
+                h_qdf[i] = (u32)(ix->h_tf_off[term + 1] - ix->h_tf_off[term]);
+                bt->sparse_p2_max += ((u64)h_qdf[i] + 1023) / 1024;
+                if (!ix->h_tf8_slot.empty()) h_row8[i] = ix->h_tf8_slot[term];
+            }
+            SA_HIP_B(hipMalloc(&bt->d_qdf, h_qdf.size() * sizeof(u32)));
+            SA_HIP_B(hipMalloc(&bt->d_qrow8, h_row8.size() * sizeof(u32)));
+            SA_HIP_B(hipMemcpy(bt->d_qdf, h_qdf.data(), h_qdf.size() * sizeof(u32), hipMemcpyHostToDevice));
+            SA_HIP_B(hipMemcpy(bt->d_qrow8, h_row8.data(), h_row8.size() * sizeof(u32), hipMemcpyHostToDevice));
+            // survivors of the phase-2 bound check: a few percent of the candidates; capped, the rest is scored in place
+            u64 cap = (u64)B * 65536;
+            if (cap > (16u << 20)) cap = 16u << 20;
+            bt->surv_cap = (u32)cap;
+            SA_HIP_B(hipMalloc(&bt->d_surv, (size_t)cap * 2 * sizeof(u64)));
+            SA_HIP_B(hipMalloc(&bt->d_bloom, (size_t)B * (1u << 17)));             // SA_BLOOM_CELLS per query
+        }
+        SA_HIP_B(hipMemcpy(bt->d_ub, h_ub.data(), h_ub.size() * sizeof(float), hipMemcpyHostToDevice));
+        SA_HIP_B(hipMemcpy(bt->d_ub_order, h_ord.data(), h_ord.size() * sizeof(u32), hipMemcpyHostToDevice));
+        SA_HIP_B(hipMemcpy(bt->d_lead, h_lead.data(), (size_t)B * sizeof(u32), hipMemcpyHostToDevice));
+        SA_HIP_B(hipMemcpy(bt->d_p1_off, h_p1.data(), ((size_t)B + 1) * sizeof(u64), hipMemcpyHostToDevice));
+        SA_HIP_B(hipMemset(bt->d_route, 0xFF, (size_t)B * sizeof(u32)));
+    }
     if (sa_launch_make_sattab(ix, bt->d_sattab, &bt->tab_w, k1, b, ix->stream) != SA_OK) return fail(SA_ERR_HIP);
     if (sa_launch_make_bounds(ix, bt->d_terms, B * T, bt->d_bounds, bt->d_qbase, ix->stream) != SA_OK) return fail(SA_ERR_HIP);
     SA_HIP_B(hipStreamSynchronize(ix->stream));
@@ -796,10 +913,17 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     p.slots = bt->d_slots;
     if (bt->kind == 1) { p.small_k_argmax = 1; defer_check = false; }   // phrase tiles: pruned selection only
     // k > 32: histogram bound (BM25 tiles of <= 4 waves); SA_TOPK_HIST=0 keeps the slot bound
-    const bool use_hist = p.small_k_argmax && bt->kind == 0 && bt->k >= (u32)sa_env_int("SA_TOPK_HIST_MINK", defer_check ? 1 : 33) &&
-                          sa_tile_waves(ix->tile_docs) <= 4 && sa_env_int("SA_TOPK_HIST", 1) != 0;
+    // dynamic pruning (sa_sparse.hip; SA_SPARSE=0: score every posting, the exhaustive reference
+    // behaviour): needs the histogram bound for every k
+    const bool hist_possible = p.small_k_argmax && bt->kind == 0 && sa_tile_waves(ix->tile_docs) <= 4 &&
+                               sa_env_int("SA_TOPK_HIST", 1) != 0;
+    const bool sparse = hist_possible && bt->sparse_ok && ix->avg_doc_len != 0.f && ix->n_tiles > 0 &&
+                        sa_env_int("SA_SPARSE", 1) != 0;
+    const bool use_hist = hist_possible &&
+                          (sparse || bt->k >= (u32)sa_env_int("SA_TOPK_HIST_MINK", defer_check ? 1 : 33));
     p.hist = use_hist ? bt->d_hist : nullptr;
     p.gthr = use_hist ? bt->d_gthr : nullptr;
+    p.qlist = nullptr; p.nq = bt->B;
     if (p.small_k_argmax) {
         const size_t words = use_hist ? (size_t)bt->B * (34 + SA_HBINS) : (size_t)bt->B * 33;
         SA_HIP(hipMemsetAsync(bt->d_slots, 0, words * sizeof(u32), st));
@@ -809,7 +933,17 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     const u32 n_tiles = bt->kind == 1 ? bt->pn_tiles : ix->n_tiles;
     if (ix->avg_doc_len != 0.f && n_tiles > 0) {
         if (bt->kind == 1) SA_TRY(sa_launch_phrase_tiles(bt, st));
-        else SA_TRY(sa_launch_bm25(ix, p, st));
+        else {
+            if (sparse) {
+                // candidates first; the tile kernel then scans only the queries the sparse path gave back
+                SA_TRY(sa_launch_sparse(bt, st));
+                u32 n_scan = 0;
+                SA_HIP(hipMemcpyAsync(&n_scan, bt->d_tile_q + bt->B, sizeof(u32), hipMemcpyDeviceToHost, st));
+                SA_HIP(hipStreamSynchronize(st));
+                p.qlist = bt->d_tile_q; p.nq = n_scan;
+            }
+            SA_TRY(sa_launch_bm25(ix, p, st));
+        }
     } else {
         SA_HIP(hipMemsetAsync(bt->d_cand, 0, (size_t)bt->B * p.cand_cap * sizeof(u64), st));
     }
@@ -831,7 +965,7 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
         if (over) {
             p.small_k_argmax = 0;
             p.cand_per_tile = bt->k;
-            p.hist = nullptr; p.gthr = nullptr;
+            p.hist = nullptr; p.gthr = nullptr; p.qlist = nullptr; p.nq = bt->B;
             SA_TRY(sa_launch_bm25(ix, p, st));
         }
     }
@@ -982,6 +1116,38 @@ extern "C" int sa_batch_fetch(sa_batch_t* bt, float* scores_out, uint64_t* docs_
             docs_out[(size_t)qi * bt->k + j] = key ? (u64)(u32)(~(u32)(key & 0xFFFFFFFFull)) : SA_NO_DOC;
         }
     }
+    return SA_OK;
+}
+
+// Diagnostics: switch on per-query counting of the candidate docs the sparse path scores (an extra
+// atomic per candidate, so not for timed runs) and read the totals of the runs since the previous call.
+extern "C" int sa_batch_stats(sa_batch_t* bt, int enable, uint64_t* sparse_candidates_out, uint64_t* sparse_queries_out) {
+    SA_ARG(bt && bt->ix, "null batch");
+    sa_index* ix = bt->ix;
+    std::lock_guard<std::mutex> g(ix->mu);
+    SA_HIP(hipSetDevice(ix->device));
+    SA_HIP(hipStreamSynchronize(ix->stream));
+    u64 total = 0, nq = 0;
+    if (bt->d_stats) {
+        std::vector<u32> h(bt->B);
+        SA_HIP(hipMemcpy(h.data(), bt->d_stats, (size_t)bt->B * sizeof(u32), hipMemcpyDeviceToHost));
+        for (u32 v : h) total += v;
+        SA_HIP(hipMemset(bt->d_stats, 0, (size_t)bt->B * sizeof(u32)));
+    }
+    if (bt->d_route) {
+        std::vector<u32> h(bt->B);
+        SA_HIP(hipMemcpy(h.data(), bt->d_route, (size_t)bt->B * sizeof(u32), hipMemcpyDeviceToHost));
+        for (u32 v : h) nq += v == 0 ? 1 : 0;
+    }
+    if (enable && !bt->d_stats) {
+        SA_HIP(hipMalloc(&bt->d_stats, (size_t)bt->B * sizeof(u32)));
+        SA_HIP(hipMemset(bt->d_stats, 0, (size_t)bt->B * sizeof(u32)));
+    } else if (!enable && bt->d_stats) {
+        SA_HIP(hipFree(bt->d_stats));
+        bt->d_stats = nullptr;
+    }
+    if (sparse_candidates_out) *sparse_candidates_out = total;
+    if (sparse_queries_out) *sparse_queries_out = nq;
     return SA_OK;
 }
 

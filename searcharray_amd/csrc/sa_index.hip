@@ -137,6 +137,18 @@ sa_k_build_docdir(const u64* __restrict__ words, u32 n, u32* __restrict__ row) {
     }
 }
 
+// dense tf row of one term from its fat postings
+__global__ void __launch_bounds__(256)
+sa_k_build_tf8(const u64* __restrict__ tfp, u32 n, unsigned char* __restrict__ row, u32* __restrict__ bits) {
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const u64 x = tfp[i];
+        const u64 doc = x >> SA_KEY_SHIFT;
+        const u32 tf = (u32)(x & SA_LSB_MASK);
+        row[doc] = (unsigned char)(tf < 255u ? tf : 255u);
+        atomicOr(&bits[doc >> 5], 1u << (doc & 31u));
+    }
+}
+
 __global__ void sa_k_build_tile_dir(const u64* __restrict__ tfp, const u64* __restrict__ tf_off,
                                     const u32* __restrict__ dir_terms, u32 n_dir_terms, u32 n_tiles,
                                     u32 tile_docs, u32* __restrict__ tile_dir) {
@@ -183,6 +195,9 @@ void sa_index_free(sa_index* ix) {
     if (ix->d_dir_slot) hipFree(ix->d_dir_slot);
     if (ix->d_docdir) hipFree(ix->d_docdir);
     if (ix->d_dd_slot) hipFree(ix->d_dd_slot);
+    if (ix->d_tf8) hipFree(ix->d_tf8);
+    if (ix->d_tfbits) hipFree(ix->d_tfbits);
+    if (ix->d_tf8_slot) hipFree(ix->d_tf8_slot);
     if (ix->d_scratch) hipFree(ix->d_scratch);
     if (ix->ev0) hipEventDestroy(ix->ev0);
     if (ix->ev1) hipEventDestroy(ix->ev1);
@@ -328,6 +343,43 @@ int sa_index_derive(sa_index* ix) {
                            d_dir_terms, ix->n_dir_terms, ix->n_tiles, ix->tile_docs, ix->d_tile_dir);
         SA_HIP(hipStreamSynchronize(st));
         SA_HIP(hipFree(d_dir_terms));
+    }
+    // ---- dense tf rows of the frequent terms (dynamic pruning looks candidates up in them) ----
+    {
+        const char* dv = getenv("SA_TF8_DIV");
+        const int div = dv ? atoi(dv) : 128;
+        std::vector<std::pair<u64, u32>> cand;
+        if (div > 0 && ix->n_docs > 0)
+            for (u32 t = 0; t < V; t++) {
+                const u64 df = ix->h_tf_off[t + 1] - ix->h_tf_off[t];
+                if (df >= 64 && df * (u64)div >= ix->n_docs) cand.push_back({df, t});
+            }
+        std::sort(cand.begin(), cand.end(), [](const std::pair<u64, u32>& a, const std::pair<u64, u32>& b) {
+            return a.first != b.first ? a.first > b.first : a.second < b.second;
+        });
+        const u64 budget_rows = ix->n_docs ? (ix->n_postings * 8 + (64ull << 20)) / ix->n_docs : 0;
+        if (cand.size() > budget_rows) cand.resize((size_t)budget_rows);
+        if (cand.size() > 4096) cand.resize(4096);
+        ix->n_tf8_terms = (u32)cand.size();
+        std::vector<u32>& slot8 = ix->h_tf8_slot;
+        slot8.assign((size_t)V + 1, SA_DD_NONE);
+        for (u32 r = 0; r < ix->n_tf8_terms; r++) slot8[cand[r].second] = r;
+        SA_HIP(hipMalloc(&ix->d_tf8_slot, ((size_t)V + 1) * sizeof(u32)));
+        SA_HIP(hipMemcpyAsync(ix->d_tf8_slot, slot8.data(), ((size_t)V + 1) * sizeof(u32), hipMemcpyHostToDevice, st));
+        const size_t bytes = (size_t)ix->n_tf8_terms * ix->n_docs;
+        SA_HIP(hipMalloc(&ix->d_tf8, bytes ? bytes : 4));
+        if (bytes) SA_HIP(hipMemsetAsync(ix->d_tf8, 0, bytes, st));
+        ix->tfbits_words = (ix->n_docs + 31) / 32;
+        const size_t bbytes = (size_t)ix->n_tf8_terms * ix->tfbits_words * sizeof(u32);
+        SA_HIP(hipMalloc(&ix->d_tfbits, bbytes ? bbytes : 4));
+        if (bbytes) SA_HIP(hipMemsetAsync(ix->d_tfbits, 0, bbytes, st));
+        for (u32 r = 0; r < ix->n_tf8_terms; r++) {
+            const u32 t = cand[r].second;
+            const u32 n = (u32)cand[r].first;
+            const u32 grid = n / 256 + 1 < 16384 ? n / 256 + 1 : 16384;
+            hipLaunchKernelGGL(sa_k_build_tf8, dim3(grid), dim3(256), 0, st, ix->d_tfp + ix->h_tf_off[t], n,
+                               ix->d_tf8 + (size_t)r * ix->n_docs, ix->d_tfbits + (size_t)r * ix->tfbits_words);
+        }
     }
     // ---- doc directory for the terms phrase probes hit hardest ----
     {
@@ -493,8 +545,8 @@ extern "C" int sa_index_info(sa_index_t* ix, sa_index_info_t* out) {
     out->device = ix->device;
     out->dl_packed = ix->dl_packed ? 1 : 0;
     out->n_docdir_terms = ix->n_dd_terms;
-    out->reserved = 0;
+    out->n_tf8_terms = ix->n_tf8_terms;
     out->hbm_bytes = ix->n_words * 8 + ix->n_postings * 8 + ((u64)ix->n_terms + 1) * 20 + ix->n_docs * 4 +
-                     (u64)ix->n_dir_terms * (ix->n_tiles + 1) * 4 + (u64)ix->n_dd_terms * ix->n_docs * 4 + ix->scratch_bytes;
+                     (u64)ix->n_dir_terms * (ix->n_tiles + 1) * 4 + (u64)ix->n_dd_terms * ix->n_docs * 4 + (u64)ix->n_tf8_terms * (ix->n_docs + ix->tfbits_words * 4) + ix->scratch_bytes;
     return SA_OK;
 }

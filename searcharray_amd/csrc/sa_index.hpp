@@ -54,8 +54,18 @@ struct sa_index {
     u32* d_docdir = nullptr;         // [n_dd_terms][n_docs]
     u32* d_dd_slot = nullptr;        // [n_terms] directory row of a term, or SA_DD_NONE
 
+    // Dense term-frequency rows of the frequent terms (dynamic pruning, sa_bm25.hip): tf8[slot][doc] =
+    // min(tf, 255), 0 when the doc lacks the term.  Scoring a handful of candidate docs against a
+    // frequent term is then one byte load per doc instead of streaming the term's postings.
+    u32 n_tf8_terms = 0;
+    unsigned char* d_tf8 = nullptr;  // [n_tf8_terms][n_docs]
+    u32* d_tfbits = nullptr;         // [n_tf8_terms][tfbits_words] presence bitmap of the same terms (cache-resident probes)
+    u64 tfbits_words = 0;            // u32 words per bitmap row = ceil(n_docs / 32)
+    u32* d_tf8_slot = nullptr;       // [n_terms] row of a term, or SA_DD_NONE
+
     std::vector<u64> h_term_off, h_tf_off;
     std::vector<u32> h_dd_slot;      // host copy of d_dd_slot
+    std::vector<u32> h_tf8_slot;     // host copy of d_tf8_slot
 
     // reusable device scratch (grown on demand, guarded by mu)
     void* d_scratch = nullptr;

@@ -226,6 +226,48 @@ __device__ __forceinline__ u32 sa_score_bin(u32 x) {
 }
 __device__ __forceinline__ u32 sa_bin_edge(u32 b) { return b == 0 ? 0u : (b + SA_HBIN_BASE) << SA_HBIN_SHIFT; }
 
+// The bound of a query's histogram: lower edge of the highest bin with at least k docs at or above
+// it (0 if fewer than k docs are counted).  Wave-cooperative: lane L passes the totals of bins
+// 4L .. 4L+3; every lane returns the same value.
+__device__ __forceinline__ u32 sa_hist_bound(const u32 (&tot)[SA_HBINS / SA_WAVE], u32 k, u32 lane) {
+    u32 lane_sum = 0;
+#pragma unroll
+    for (int i = 0; i < SA_HBINS / SA_WAVE; i++) lane_sum += tot[i];
+    u32 suf = lane_sum;                                         // inclusive suffix sum over lanes
+#pragma unroll
+    for (int o = 1; o < SA_WAVE; o <<= 1) {
+        const u32 up = __shfl_down(suf, (unsigned)o, SA_WAVE);
+        if (lane + (u32)o < (u32)SA_WAVE) suf += up;
+    }
+    const u64 ok = __ballot(suf >= k);
+    u32 g = 0;
+    if (ok) {
+        const u32 ls = 63u - (u32)__clzll((long long)ok);       // highest lane whose suffix reaches k
+        u32 above = __shfl_down(suf, 1u, SA_WAVE);              // docs in the lanes above mine
+        if (lane == (u32)SA_WAVE - 1) above = 0;
+        u32 bsel = 0;
+#pragma unroll
+        for (int i = SA_HBINS / SA_WAVE - 1; i >= 0; i--) {
+            above += tot[i];
+            if (bsel == 0 && above >= k) bsel = lane * (SA_HBINS / SA_WAVE) + (u32)i + 1u;   // +1: 0 means none
+        }
+        const u32 b = (u32)__shfl((int)bsel, (int)ls, SA_WAVE);
+        g = b ? sa_bin_edge(b - 1u) : 0u;
+    }
+    return g;
+}
+
+// read a query's histogram and raise its cached bound (one wave; every lane must call)
+__device__ __forceinline__ u32 sa_hist_refresh(u32* __restrict__ qh, u32* __restrict__ gthr_q, u32 k, u32 lane) {
+    u32 tot[SA_HBINS / SA_WAVE];
+#pragma unroll
+    for (int i = 0; i < SA_HBINS / SA_WAVE; i++)
+        tot[i] = __hip_atomic_load(&qh[lane * (SA_HBINS / SA_WAVE) + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32 g = sa_hist_bound(tot, k, lane);
+    if (lane == 0 && g) atomicMax(gthr_q, g);
+    return g;
+}
+
 template <int TILE, int THREADS>
 __device__ __forceinline__ void sa_tile_topk_hist(float* acc, u32 gc, u32 q, u32 tile, u64 doc0, u32 k,
                                                   u32* __restrict__ hist, u32* __restrict__ gthr,
@@ -296,30 +338,7 @@ __device__ __forceinline__ void sa_tile_topk_hist(float* acc, u32 gc, u32 q, u32
         tot[i] = old + v;
     }
     // 2. the bound: highest bin with at least k docs at or above it
-    u32 lane_sum = 0;
-#pragma unroll
-    for (int i = 0; i < SA_HBINS / SA_WAVE; i++) lane_sum += tot[i];
-    u32 suf = lane_sum;                                         // inclusive suffix sum over lanes
-#pragma unroll
-    for (int o = 1; o < SA_WAVE; o <<= 1) {
-        const u32 up = __shfl_down(suf, (unsigned)o, SA_WAVE);
-        if (lane + (u32)o < (u32)SA_WAVE) suf += up;
-    }
-    const u64 ok = __ballot(suf >= k);
-    u32 g = 0;
-    if (ok) {
-        const u32 ls = 63u - (u32)__clzll((long long)ok);       // highest lane whose suffix reaches k
-        u32 above = __shfl_down(suf, 1u, SA_WAVE);              // docs in the lanes above mine
-        if (lane == (u32)SA_WAVE - 1) above = 0;
-        u32 bsel = 0;
-#pragma unroll
-        for (int i = SA_HBINS / SA_WAVE - 1; i >= 0; i--) {
-            above += tot[i];
-            if (bsel == 0 && above >= k) bsel = lane * (SA_HBINS / SA_WAVE) + (u32)i + 1u;   // +1: 0 means none
-        }
-        const u32 b = (u32)__shfl((int)bsel, (int)ls, SA_WAVE);
-        g = b ? sa_bin_edge(b - 1u) : 0u;
-    }
+    const u32 g = sa_hist_bound(tot, k, lane);
     if (lane == 0 && g > gc) atomicMax(&gthr[q], g);
     const u32 thr = g > thr0 ? g : thr0;
     // 3. append every doc of this wave at or above the bound

@@ -267,6 +267,14 @@ class QueryBatch:
         self.api.call("sa_batch_profile", self._h, ctypes.byref(ms), ctypes.byref(alg), ctypes.byref(post))
         return ms.value, alg.value, post.value
 
+    def stats(self, enable: bool = True) -> Tuple[int, int]:
+        """(candidate docs scored by the sparse path since the last call, queries of the last run that
+        were answered without a tile scan); diagnostics, switches the counting on / off."""
+        cands = _lib.c_uint64(0)
+        nq = _lib.c_uint64(0)
+        self.api.call("sa_batch_stats", self._h, 1 if enable else 0, ctypes.byref(cands), ctypes.byref(nq))
+        return cands.value, nq.value
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self.api.sa_batch_destroy(self._h)

@@ -95,10 +95,13 @@ def test_topk_batch_matches_oracle(small, k):
     bt.close()
 
 
-@pytest.mark.parametrize("n", [1500, 7000])
-def test_topk_massive_ties_takes_fallback_path(api, n):
+@pytest.mark.parametrize("n,cap", [(1500, ""), (7000, ""), (7000, "100")])
+def test_topk_massive_ties_takes_fallback_path(api, n, cap, monkeypatch):
     """All docs identical -> every score ties -> the bound cuts nothing; with n = 7000 the survivors
-    overflow the merge kernel's LDS list (in-place compaction + bisection over the survivors)."""
+    overflow the merge kernel's LDS list (in-place compaction + bisection over the survivors), and with
+    a candidate list of 100 keys the list itself runs over: the batch is redone unpruned at fetch."""
+    if cap:
+        monkeypatch.setenv("SA_CAND_CAP", cap)
     t = np.repeat(np.arange(3), n).astype(np.uint32)
     d = np.tile(np.arange(n), 3).astype(np.uint64)
     p = np.repeat(np.arange(3), n).astype(np.uint64)
@@ -302,3 +305,42 @@ def test_large_k_slot_bound_path(small, k, monkeypatch):
     more than 4 waves and phrase batches use)"""
     monkeypatch.setenv("SA_TOPK_HIST", "0")
     test_topk_batch_matches_oracle(small, k)
+
+
+# ---------------------------------------------------------------------------------------------
+# dynamic pruning (sa_sparse.hip): only docs that can still reach the top-k are scored
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sparse,tf8_div", [("1", "128"), ("1", "0"), ("0", "128")])
+@pytest.mark.parametrize("k", [5, 40])
+def test_dynamic_pruning_is_exact(api, monkeypatch, sparse, tf8_div, k):
+    """rare + frequent terms: queries with a rare term are answered by scoring candidates only (checked
+    through the diagnostics counters), with and without dense tf rows in the index; all-frequent
+    queries fall back to the tile scan; the top-k equals the exhaustive oracle bit for bit"""
+    monkeypatch.setenv("SA_SPARSE", sparse)
+    monkeypatch.setenv("SA_TF8_DIV", tf8_div)
+    n_docs, vocab = 60000, 3000
+    t, d, p, lens = synth.corpus_triples(n_docs, vocab, 12, seed=5)
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    assert (dev.info().n_tf8_terms > 0) == (tf8_div != "0")
+    orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
+    queries = np.asarray([[0, 40, 700, 2500], [2900, 1, 3, 1500], [5, 6, 7, 8], [2999, 2998, 0, 1], [0, 2000, 2000, 9],
+                          [1, 0, 2, 3], [3100, 2, 1, 0], [2950, 2951, 2952, 2953]])
+    bt = dev.batch(queries, k=k)
+    bt.stats(True)
+    for _ in range(2):
+        bt.run()
+        scores, docs = bt.fetch()
+        for qi, q in enumerate(queries):
+            ws, wd = O.topk(orc.score_terms_sum([int(x) for x in q]), k)
+            n = int((ws > 0).sum())
+            assert np.array_equal(scores[qi, :n], ws[:n]), f"q{qi} scores"
+            assert np.array_equal(docs[qi, :n], wd[:n]), f"q{qi} docs"
+            assert (docs[qi, n:] == NO_DOC).all()
+    cands, sparse_queries = bt.stats(False)
+    if sparse == "1":
+        assert 2 <= sparse_queries < len(queries), sparse_queries     # rare-term queries sparse, all-frequent ones scanned
+        assert 0 < cands < 2 * len(queries) * n_docs // 8
+    else:
+        assert cands == 0
+    bt.close()
