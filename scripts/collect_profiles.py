@@ -59,21 +59,29 @@ def main():
                 w.writerow([name, "FETCH_SIZE", n, round(mean, 3)])
             for name, (n, mean) in write.items():
                 w.writerow([name, "WRITE_SIZE", n, round(mean, 3)])
-        tiles = [k for k in fetch if "sa_k_bm25_tiles" in k]
+        def corrected(name):
+            fk = fetch.get(name, (0, 0.0))[1]
+            wk = write.get(name, (0, 0.0))[1]
+            return 2 * fk * 1024 + wk * 1024, fk, wk
+        exh = [k for k in fetch if "sa_k_bm25_tiles<" in k and "list" not in k]
+        pruned = [k for k in fetch if "sa_k_sparse_" in k or "sa_k_bm25_tiles_list" in k]
         bench = last_json_line(os.path.join(OUT, "bench.log")) or {}
-        if tiles:
-            fk = fetch[tiles[0]][1]
-            wk = write.get(tiles[0], (0, 0.0))[1]
-            cfg = bench.get("config", {})
-            json.dump({"docs": cfg.get("docs"), "queries": cfg.get("queries_per_step"), "n_gpus": 1,
-                       "tile_docs": cfg.get("tile_docs"), "k": cfg.get("k"),
-                       "fetch_size_KiB_raw": fk, "write_size_KiB_raw": wk,
-                       "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section; "
-                                     "calibrated on sa_k_compact_count<PostingHeads>, a pure stream of the index words); "
-                                     "WRITE_SIZE taken as reported",
-                       "hbm_bytes_per_launch": int(2 * fk * 1024 + wk * 1024)},
-                      open(os.path.join(PROF, "pmc_traffic.json"), "w"), indent=1)
-            print("wrote pmc_traffic.json")
+        cfg = bench.get("config", {})
+        out = {"docs": cfg.get("docs"), "queries": cfg.get("queries_per_step"), "n_gpus": 1,
+               "tile_docs": cfg.get("tile_docs"), "k": cfg.get("k"),
+               "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section; "
+                             "calibrated on sa_k_compact_count<PostingHeads>, a pure stream of the index words); "
+                             "WRITE_SIZE taken as reported; per kernel = mean over its dispatches"}
+        if exh:
+            tot, fk, wk = corrected(exh[0])
+            out["exhaustive_hbm_bytes_per_launch"] = int(tot)
+            out["exhaustive_fetch_size_KiB_raw"] = fk
+            out["exhaustive_write_size_KiB_raw"] = wk
+        if pruned:
+            out["pruned_hbm_bytes_per_step"] = int(sum(corrected(k)[0] for k in pruned))
+            out["pruned_kernels"] = {k.split("(")[0]: int(corrected(k)[0]) for k in pruned}
+        json.dump(out, open(os.path.join(PROF, "pmc_traffic.json"), "w"), indent=1)
+        print("wrote pmc_traffic.json")
 
 
 if __name__ == "__main__":

@@ -74,6 +74,8 @@ struct sa_batch {
 int sa_comm_allgather_topk(sa_index* ix, const u64* d_local, u64* d_gather, size_t count, int* nranks_out,
                            hipStream_t st);
 
+int sa_comm_allreduce_max_u32(sa_index* ix, u32* d_val, hipStream_t st);
+
 // tile scoring + pruned selection of a phrase batch on stream st (sa_phrase_batch.hip)
 int sa_launch_phrase_tiles(sa_batch* bt, hipStream_t st);
 // shared by the two batch kinds (sa_bm25.hip)

@@ -63,6 +63,7 @@ struct Bm25Params {
     u32* stats;            // diagnostics (sa_batch_stats): [B] candidates scored by the sparse path, or null
     const u32* qlist;      // queries to scan (after the sparse path took the others), or null: all B
     u32 nq;                // number of queries to scan (= B without a list)
+    const u32* nq_dev;     // the same on the device (sa_k_bm25_tiles_list)
     // outputs
     float* dense_out;      // [B][n_docs] or null
     u64* cand;             // [B][n_tiles][k] composite keys (global doc ids) or null
@@ -115,8 +116,9 @@ sa_k_make_bounds(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, co
 
 // MODE 0: dense output and/or block-level threshold top-k (any k <= 1024).
 // MODE 1: pruned wave-level top-k (k <= 32), the batch fast path.
+// One work item = one (tile, query) pair; `nq` queries are in play (p.qlist maps them, if set).
 template <int TILE, int THREADS, int MODE>
-__global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
+__device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32 item, const u32 nq) {
     constexpr int NW = THREADS / SA_WAVE;
     constexpr int E = TILE / THREADS;
     constexpr int CAP = (TILE >= 8192) ? 2048 : TILE / 4;      // candidate list capacity (MODE 0)
@@ -142,10 +144,9 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
     const u32 T = p.T;
     const u32 tab_w = p.tab_w;
     for (u32 i = tid; i < SA_SAT_NTF * tab_w; i += THREADS) s_tab[i] = p.sattab[i];
-    const u32 item = blockIdx.x;
     // (queries answered by the sparse candidate path, sa_sparse.hip, are not in the list)
-    const u32 tile = item / p.nq;
-    const u32 q = p.qlist ? p.qlist[item % p.nq] : item % p.nq;
+    const u32 tile = item / nq;
+    const u32 q = p.qlist ? p.qlist[item % nq] : item % nq;
     const u64 tile_base = (u64)tile * TILE;
     // pruning slots of this query (see the top-k section); loaded first so the L2 latency hides
     // behind the posting stream.  L1-bypassing load: a fresher bound prunes more.
@@ -393,6 +394,24 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
     }   // top-k
 }
 
+template <int TILE, int THREADS, int MODE>
+__global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
+    sa_bm25_tile_item<TILE, THREADS, MODE>(p, blockIdx.x, p.nq);
+}
+
+// The queries the sparse candidate path handed back (usually none): their number is only known on the
+// device, so a resident grid walks the (tile, query) items of the list -- no host round trip to size a
+// launch.  Slower per item than one workgroup per item, which does not matter for a rare fallback.
+template <int TILE, int THREADS>
+__global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles_list(const Bm25Params p) {
+    const u32 nq = *p.nq_dev;
+    const u64 n_items = (u64)nq * p.n_tiles;
+    for (u64 item = blockIdx.x; item < n_items; item += gridDim.x) {
+        sa_bm25_tile_item<TILE, THREADS, 1>(p, (u32)item, nq);
+        __syncthreads();                              // LDS is reused by the next item
+    }
+}
+
 // Merge n_cand candidate keys per query into the k best, sorted descending.
 // One workgroup of 1024 threads per query.
 //
@@ -589,6 +608,28 @@ static int sa_launch_bm25_mode(sa_index* ix, const Bm25Params& p, hipStream_t st
         case 32768: SA_LAUNCH_TILE(32768, 1024);
         default:
             sa_set_error("unsupported tile_docs %u", ix->tile_docs);
+            return SA_ERR_STATE;
+    }
+    return SA_OK;
+}
+
+#define SA_LAUNCH_LIST(TILE, THREADS)                                                              \
+    {                                                                                              \
+        hipLaunchKernelGGL((sa_k_bm25_tiles_list<TILE, THREADS>), dim3(grid), dim3(THREADS), 0, st, p); \
+    }                                                                                              \
+    break
+
+static int sa_launch_bm25_list(sa_index* ix, const Bm25Params& p, hipStream_t st) {
+    if (ix->n_tiles == 0 || p.B == 0) return SA_OK;
+    const u64 worst = (u64)p.B * ix->n_tiles;
+    const u32 grid = worst < 4096 ? (u32)worst : 4096u;
+    switch (ix->tile_docs) {
+        case 1024: SA_LAUNCH_LIST(1024, 128);
+        case 2048: SA_LAUNCH_LIST(2048, 64);
+        case 4096: SA_LAUNCH_LIST(4096, 128);
+        case 8192: SA_LAUNCH_LIST(8192, 256);
+        default:
+            sa_set_error("unsupported tile_docs %u for the query-list scan", ix->tile_docs);
             return SA_ERR_STATE;
     }
     return SA_OK;
@@ -935,14 +976,13 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
         if (bt->kind == 1) SA_TRY(sa_launch_phrase_tiles(bt, st));
         else {
             if (sparse) {
-                // candidates first; the tile kernel then scans only the queries the sparse path gave back
+                // candidates first; a resident grid then scans the queries the sparse path gave back
                 SA_TRY(sa_launch_sparse(bt, st));
-                u32 n_scan = 0;
-                SA_HIP(hipMemcpyAsync(&n_scan, bt->d_tile_q + bt->B, sizeof(u32), hipMemcpyDeviceToHost, st));
-                SA_HIP(hipStreamSynchronize(st));
-                p.qlist = bt->d_tile_q; p.nq = n_scan;
+                p.qlist = bt->d_tile_q; p.nq_dev = bt->d_tile_q + bt->B;
+                SA_TRY(sa_launch_bm25_list(ix, p, st));
+            } else {
+                SA_TRY(sa_launch_bm25(ix, p, st));
             }
-            SA_TRY(sa_launch_bm25(ix, p, st));
         }
     } else {
         SA_HIP(hipMemsetAsync(bt->d_cand, 0, (size_t)bt->B * p.cand_cap * sizeof(u64), st));
@@ -1032,7 +1072,7 @@ extern "C" int sa_batch_run(sa_batch_t* bt, int sync) {
         u64* xl = bt->d_xlocal + bsel * count;
         u64* xg = bt->d_gather + bsel * (size_t)nranks * count;
         if (bt->exchanged_valid[bsel]) SA_HIP(hipStreamWaitEvent(st, bt->ev_exchanged[bsel], 0));
-        SA_TRY(sa_batch_run_shard(bt, xl, false));
+        SA_TRY(sa_batch_run_shard(bt, xl, true));
         SA_HIP(hipEventRecord(bt->ev_scored[bsel], st));
         SA_HIP(hipStreamWaitEvent(xs, bt->ev_scored[bsel], 0));
         SA_TRY(sa_comm_allgather_topk(ix, xl, xg, count, &nranks, xs));
@@ -1092,15 +1132,31 @@ extern "C" int sa_batch_fetch(sa_batch_t* bt, float* scores_out, uint64_t* docs_
     SA_HIP(hipStreamSynchronize(ix->stream));
     if (ix->xstream) SA_HIP(hipStreamSynchronize(ix->xstream));
     SA_HIP(hipGetLastError());
-    if (bt->d_overflow && !ix->comm) {
-        // a run since the last fetch overflowed a candidate list (only possible when the bound could
-        // not rise: degenerate score distributions): redo the batch with the unpruned selection
+    if (bt->d_overflow) {
+        // A run since the last fetch overflowed a candidate list (only possible when the bound could
+        // not rise: degenerate score distributions): redo the batch with the unpruned selection.
+        // Sharded: the ranks agree first (every rank calls fetch), then all of them redo the exchange.
+        if (ix->comm) {
+            SA_TRY(sa_comm_allreduce_max_u32(ix, bt->d_overflow, ix->xstream));
+            SA_HIP(hipStreamSynchronize(ix->xstream));
+        }
         u32 over = 0;
         SA_HIP(hipMemcpy(&over, bt->d_overflow, sizeof(u32), hipMemcpyDeviceToHost));
         if (over) {
             SA_HIP(hipMemset(bt->d_overflow, 0, sizeof(u32)));
-            SA_TRY(sa_batch_run_shard(bt, bt->d_final, false, true));
-            SA_HIP(hipStreamSynchronize(ix->stream));
+            if (ix->comm) {
+                const size_t count = (size_t)bt->B * bt->k;
+                int nranks = 1;
+                SA_TRY(sa_comm_allgather_topk(ix, nullptr, nullptr, 0, &nranks, ix->xstream));
+                SA_TRY(sa_batch_run_shard(bt, bt->d_xlocal, false, true));
+                SA_HIP(hipStreamSynchronize(ix->stream));
+                SA_TRY(sa_comm_allgather_topk(ix, bt->d_xlocal, bt->d_gather, count, &nranks, ix->xstream));
+                SA_TRY(sa_batch_merge_ranks(bt, bt->d_gather, nranks, ix->xstream));
+                SA_HIP(hipStreamSynchronize(ix->xstream));
+            } else {
+                SA_TRY(sa_batch_run_shard(bt, bt->d_final, false, true));
+                SA_HIP(hipStreamSynchronize(ix->stream));
+            }
             SA_HIP(hipGetLastError());
         }
     }

@@ -82,3 +82,10 @@ int sa_comm_allgather_topk(sa_index* ix, const u64* d_local, u64* d_gather, size
     SA_NCCL(ncclAllGather(d_local, d_gather, count, ncclUint64, ix->comm->comm, st));
     return SA_OK;
 }
+
+// max over the ranks of one device-resident u32 (in place)
+int sa_comm_allreduce_max_u32(sa_index* ix, u32* d_val, hipStream_t st) {
+    if (!ix->comm) { sa_set_error("index has no communicator"); return SA_ERR_STATE; }
+    SA_NCCL(ncclAllReduce(d_val, d_val, 1, ncclUint32, ncclMax, ix->comm->comm, st));
+    return SA_OK;
+}
