@@ -47,8 +47,9 @@ def main():
                     help="N>1 exchange: library-internal RCCL all-gather, or torch.distributed")
     ap.add_argument("--corpus-cache", default="", help="directory to cache the encoded corpus shard (.npz)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exhaustive", action="store_true",
-                    help="time the exhaustive streaming kernel in the main region (dynamic pruning is reported beside it)")
+    ap.add_argument("--pruned", action="store_true",
+                    help="time dynamic pruning in the main region (default: the exhaustive streaming kernel, which "
+                         "scores every posting like the reference; the other mode is always reported beside it)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -178,10 +179,12 @@ def main():
             dt_ = float(tdt.item())
         return dt_
 
-    # The library answers a top-k batch with dynamic pruning (csrc/sa_sparse.hip: only docs that can
-    # still reach the top-k are scored; results identical).  --exhaustive (SA_SPARSE=0) times the
-    # streaming kernel that scores every posting like the reference; the other mode is timed after
-    # the main region and reported next to it.
+    # The main region times the EXHAUSTIVE streaming kernel: every posting of every query term is
+    # scored, as the reference does -- the workload BASELINE.json's metric and roofline are defined on.
+    # The library's default for top-k batches is dynamic pruning (csrc/sa_sparse.hip: only docs that
+    # can still reach the top-k are scored; identical results); it is timed right after and reported
+    # as "dynamic_pruning".  --pruned swaps the two.
+    args.exhaustive = not args.pruned
     os.environ["SA_SPARSE"] = "0" if args.exhaustive else "1"
     dt = timed(max(W, 1), K)
     kernel_ms, alg_bytes, post_bytes = batch.profile()
