@@ -24,7 +24,6 @@ def main():
     ap.add_argument("--tiles", default="2048,4096,8192,16384")
     ap.add_argument("--ks", default="10")
     ap.add_argument("--dir-divs", default="8")
-    ap.add_argument("--kflags", default="0")
     ap.add_argument("--corpus-cache", default="")
     args = ap.parse_args()
     api = _lib.api()
@@ -52,12 +51,13 @@ def main():
         build_s = time.time() - t0
         for k in [int(x) for x in args.ks.split(",")]:
             batch = QueryBatch(index, queries, k=k)
-            modes = [(0, 1, 0, "0"), (0, 0, 0, "0")] if k > 32 else [(0, 1, 0, "0"), (0, 1, 1, "0")]
-            for xcd, argmax, notopk, kf in modes:
-                os.environ["SA_PERSISTENT"] = kf
-                os.environ["SA_XCD_MODE"] = str(xcd)
-                os.environ["SA_PRUNED_TOPK"] = str(argmax)
-                os.environ["SA_NO_TOPK"] = str(notopk)
+            # (sparse, pruned selection, skip selection): dynamic pruning; exhaustive with the pruned
+            # wave-level top-k; exhaustive with the block-level selection; exhaustive without any selection
+            modes = [("1", "1", "0"), ("0", "1", "0"), ("0", "0", "0"), ("0", "1", "1")]
+            for sparse, pruned, notopk in modes:
+                os.environ["SA_SPARSE"] = sparse
+                os.environ["SA_PRUNED_TOPK"] = pruned
+                os.environ["SA_NO_TOPK"] = notopk
                 for _ in range(2):
                     batch.run(sync=False)
                 index.synchronize()
@@ -69,7 +69,7 @@ def main():
                 dt = time.perf_counter() - t0
                 ms, alg, post = batch.profile()
                 print(json.dumps({"tile": tile, "dir_div": ddiv, "dir_terms": int(index.info().n_dir_terms), "k": k,
-                                  "xcd_mode": xcd, "argmax": argmax, "no_topk": notopk, "grid_mult": kf,
+                                  "sparse": sparse, "pruned_topk": pruned, "no_topk": notopk,
                                   "qps": round(B * args.steps / dt, 1), "ms_per_step": round(dt / args.steps * 1e3, 3),
                                   "kernel_ms": round(ms, 3), "alg_GBps": round(alg / ms / 1e6, 1),
                                   "postings_GBps": round(post / ms / 1e6, 1), "index_build_s": round(build_s, 1)}),

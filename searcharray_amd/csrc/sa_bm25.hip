@@ -46,7 +46,7 @@ struct Bm25Params {
     const u64* qbase;      // [B][T] posting base of each query term
     u32 B, T, k;
     float k1, b, avgdl;
-    int small_k_argmax;    // k <= 32: iterative block arg-max instead of threshold selection
+    int pruned;            // 1: wave-level selection against a global bound (MODE 1); 0: block-level selection (MODE 0)
     int no_topk;           // timing experiments only: skip the per-tile selection
     u32 cand_per_tile;     // general mode: candidate slots per (query, tile) = k
     u32 cand_cap;          // pruned mode: capacity of each query's append list
@@ -115,7 +115,7 @@ sa_k_make_bounds(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, co
 }
 
 // MODE 0: dense output and/or block-level threshold top-k (any k <= 1024).
-// MODE 1: pruned wave-level top-k (k <= 32), the batch fast path.
+// MODE 1: pruned wave-level top-k against the query's global bound (any k <= 1024), the batch fast path.
 // One work item = one (tile, query) pair; `nq` queries are in play (p.qlist maps them, if set).
 template <int TILE, int THREADS, int MODE>
 __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32 item, const u32 nq) {
@@ -637,7 +637,7 @@ static int sa_launch_bm25_list(sa_index* ix, const Bm25Params& p, hipStream_t st
 
 static int sa_launch_bm25(sa_index* ix, const Bm25Params& p, hipStream_t st) {
     if (ix->n_tiles == 0 || p.nq == 0) return SA_OK;
-    return p.small_k_argmax ? sa_launch_bm25_mode<1>(ix, p, st) : sa_launch_bm25_mode<0>(ix, p, st);
+    return p.pruned ? sa_launch_bm25_mode<1>(ix, p, st) : sa_launch_bm25_mode<0>(ix, p, st);
 }
 
 extern "C" int sa_index_bm25_dense(sa_index_t* ix, const uint32_t* terms, const float* idf,
@@ -673,7 +673,7 @@ extern "C" int sa_index_bm25_dense(sa_index_t* ix, const uint32_t* terms, const 
     memset(&p, 0, sizeof(p));
     sa_fill_params(ix, p);
     p.terms = d_terms; p.idf = d_idf; p.B = 1; p.nq = 1; p.T = (u32)T; p.k = 0;
-    p.k1 = k1; p.b = b; p.small_k_argmax = 0;
+    p.k1 = k1; p.b = b; p.pruned = 0;
     p.dense_out = d_out; p.cand = nullptr;
     p.bounds = d_bounds; p.qbase = d_qbase;
     p.sattab = d_tab;
@@ -945,18 +945,18 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     p.k1 = bt->k1; p.b = bt->b;
     p.bounds = bt->d_bounds; p.qbase = bt->d_qbase;
     p.sattab = bt->d_sattab; p.tab_w = bt->tab_w;
-    p.small_k_argmax = (sa_env_int("SA_PRUNED_TOPK", 1) && !force_unpruned) ? 1 : 0;   // pruned wave-level selection (any k <= 1024)
+    p.pruned = (sa_env_int("SA_PRUNED_TOPK", 1) && !force_unpruned) ? 1 : 0;   // pruned wave-level selection (any k <= 1024)
     p.dense_out = nullptr; p.cand = bt->d_cand;
     p.no_topk = sa_env_int("SA_NO_TOPK", 0);
     p.cand_per_tile = bt->k;
     p.cand_cap = bt->cand_cap;
     p.cand_cnt = bt->d_cand_cnt;
     p.slots = bt->d_slots;
-    if (bt->kind == 1) { p.small_k_argmax = 1; defer_check = false; }   // phrase tiles: pruned selection only
+    if (bt->kind == 1) { p.pruned = 1; defer_check = false; }   // phrase tiles: pruned selection only
     // k > 32: histogram bound (BM25 tiles of <= 4 waves); SA_TOPK_HIST=0 keeps the slot bound
     // dynamic pruning (sa_sparse.hip; SA_SPARSE=0: score every posting, the exhaustive reference
     // behaviour): needs the histogram bound for every k
-    const bool hist_possible = p.small_k_argmax && bt->kind == 0 && sa_tile_waves(ix->tile_docs) <= 4 &&
+    const bool hist_possible = p.pruned && bt->kind == 0 && sa_tile_waves(ix->tile_docs) <= 4 &&
                                sa_env_int("SA_TOPK_HIST", 1) != 0;
     const bool sparse = hist_possible && bt->sparse_ok && ix->avg_doc_len != 0.f && ix->n_tiles > 0 &&
                         sa_env_int("SA_SPARSE", 1) != 0;
@@ -965,7 +965,7 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     p.hist = use_hist ? bt->d_hist : nullptr;
     p.gthr = use_hist ? bt->d_gthr : nullptr;
     p.qlist = nullptr; p.nq = bt->B;
-    if (p.small_k_argmax) {
+    if (p.pruned) {
         const size_t words = use_hist ? (size_t)bt->B * (34 + SA_HBINS) : (size_t)bt->B * 33;
         SA_HIP(hipMemsetAsync(bt->d_slots, 0, words * sizeof(u32), st));
     }
@@ -990,7 +990,7 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     SA_HIP(hipEventRecord(bt->ev1[slot], st));
     bt->ev_n++;
     // (with the histogram bound a wave appends all its survivors, so the worst case is not bounded by k)
-    const bool may_overflow = p.small_k_argmax && (bt->cap_limited || use_hist) && n_tiles > 0;
+    const bool may_overflow = p.pruned && (bt->cap_limited || use_hist) && n_tiles > 0;
     if (may_overflow && !defer_check) {
         // the candidate lists are smaller than the worst case: make sure no query ran over
         std::vector<u32> h_cnt(bt->B);
@@ -1003,17 +1003,17 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
             return SA_ERR_UNSUPPORTED;
         }
         if (over) {
-            p.small_k_argmax = 0;
+            p.pruned = 0;
             p.cand_per_tile = bt->k;
             p.hist = nullptr; p.gthr = nullptr; p.qlist = nullptr; p.nq = bt->B;
             SA_TRY(sa_launch_bm25(ix, p, st));
         }
     }
-    const u32 n_cand = p.small_k_argmax ? p.cand_cap : (n_tiles ? n_tiles : 1) * p.cand_per_tile;
+    const u32 n_cand = p.pruned ? p.cand_cap : (n_tiles ? n_tiles : 1) * p.cand_per_tile;
     hipLaunchKernelGGL(sa_k_topk_merge, dim3(bt->B), dim3(1024), 0, st, bt->d_cand, n_cand, bt->k, shard_out,
-                       (const u32*)bt->d_perm, 0u, (const u32*)(p.small_k_argmax ? bt->d_cand_cnt : nullptr),
-                       (const u32*)(p.small_k_argmax && !p.hist ? bt->d_slots : nullptr),
-                       (const u32*)(p.small_k_argmax && p.hist ? bt->d_gthr : nullptr),
+                       (const u32*)bt->d_perm, 0u, (const u32*)(p.pruned ? bt->d_cand_cnt : nullptr),
+                       (const u32*)(p.pruned && !p.hist ? bt->d_slots : nullptr),
+                       (const u32*)(p.pruned && p.hist ? bt->d_gthr : nullptr),
                        (may_overflow && defer_check) ? bt->d_overflow : (u32*)nullptr);
     bt->ran = true;
     return SA_OK;

@@ -69,7 +69,6 @@ struct SparseParams {
     u32* cand_cnt;
     unsigned char* bloom;  // [B][SA_BLOOM_CELLS] lead docs of each query (filled by phase 1)
     u32 tile_shift;        // log2(tile_docs)
-    u32 debug;
     u32* stats;
     // phase-2 survivors of the bound check, scored by their own kernel (no divergence with the filter)
     u64* surv;             // [surv_cap][2]: doc << 32 | q,  tc << 40 | tf << 20 | dl  (fits: 18-bit tf / dl)
@@ -333,12 +332,9 @@ __global__ void __launch_bounds__(256) sa_k_sparse_rest(const SparseParams p) {
                 float have = sa_sparse_term_score(p, ktf, kdl, doc, idf_c);
                 float rest = rest0;
                 // probe the other terms from the most valuable down (ub_order is ascending in idf)
-                if (p.debug == 1) alive = false;
-                int probes = 0;
                 for (int j = (int)p.T - 1; j >= 0 && alive; j--) {
                     const u32 t = p.ub_order[q * p.T + (u32)j];
                     if (t == tc) continue;
-                    if (p.debug >= 2 && probes++ >= (int)p.debug - 1) { alive = false; break; }
                     const u32 qt2 = q * p.T + t;
                     const u32 term = p.terms[qt2];
                     if (term >= p.n_terms) continue;
@@ -438,8 +434,6 @@ int sa_launch_sparse(sa_batch* bt, hipStream_t st) {
     p.stats = bt->d_stats;
     p.bloom = (unsigned char*)bt->d_bloom;
     p.tile_shift = 0;
-    p.debug = 0;
-    if (const char* v = getenv("SA_SPDBG")) p.debug = (u32)atoi(v);
     while ((1u << p.tile_shift) < ix->tile_docs) p.tile_shift++;
     hipMemsetAsync(bt->d_bloom, 0, (size_t)bt->B * SA_BLOOM_CELLS, st);
     p.qdf = bt->d_qdf; p.qrow8 = bt->d_qrow8;
