@@ -15,6 +15,7 @@ import torch.multiprocessing as mp        # noqa: E402
 
 N_DOCS, VOCAB, K = 6000, 300, 10
 QUERIES = np.asarray([[0, 5, 50, 200], [1, 2, 3, 4], [7, 90, 150, 299], [10, 11, 12, 13]])
+PHRASES = [[0, 1], [2, 1, 0], [5, 3], [1, 0, 4, 2]]
 
 
 def _free_port():
@@ -57,7 +58,16 @@ def _worker(rank, world, port, out_dir):
     dist.all_gather_into_tensor(gathered, local)
     batch.merge_gathered(gathered.data_ptr(), world, sync=True)
     scores, docs = batch.fetch()
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), scores=scores, docs=docs, avgdl=avgdl)
+    # exact phrases through the same exchange: phrase idf from the GLOBAL document frequencies
+    pidf = np.asarray([compute_idf(N_DOCS, np.asarray([df[t_].item() for t_ in ph])) for ph in PHRASES], dtype=np.float32)
+    pbatch = index.phrase_batch(PHRASES, k=K, idf=pidf)
+    plocal = torch.zeros(len(PHRASES) * K, dtype=torch.int64)
+    pgathered = torch.zeros(world * len(PHRASES) * K, dtype=torch.int64)
+    pbatch.run_local(plocal.data_ptr(), sync=True)
+    dist.all_gather_into_tensor(pgathered, plocal)
+    pbatch.merge_gathered(pgathered.data_ptr(), world, sync=True)
+    pscores, pdocs = pbatch.fetch()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), scores=scores, docs=docs, avgdl=avgdl, pscores=pscores, pdocs=pdocs)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -76,3 +86,9 @@ def test_two_rank_sharded_topk_matches_single_index_oracle(tmp_path):
         n = int((ws > 0).sum())
         assert np.allclose(r0["scores"][qi, :n], ws[:n], rtol=1e-6), f"q{qi}"
         assert np.array_equal(r0["docs"][qi, :n], wd[:n]), f"q{qi}"
+    assert np.array_equal(r0["pscores"], r1["pscores"]) and np.array_equal(r0["pdocs"], r1["pdocs"])
+    for pi, ph in enumerate(PHRASES):
+        ws, wd = O.topk(orc.score(list(ph)), K)
+        n = int((ws > 0).sum())
+        assert np.allclose(r0["pscores"][pi, :n], ws[:n], rtol=1e-6), f"phrase {ph}"
+        assert np.array_equal(r0["pdocs"][pi, :n], wd[:n]), f"phrase {ph}"
