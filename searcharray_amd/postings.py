@@ -495,7 +495,13 @@ class SearchArray(ExtensionArray):
         tid = self._term_id(token)
         if tid < 0 or len(self._core.doc_lens) == 0:
             return 0
-        return self._core.device().docfreq(tid)
+        if self._rows is None:
+            return self._core.device().docfreq(tid)
+        # A sliced array counts the docs of the SLICE that contain the term (the reference's slices
+        # carry FilteredPosns, middle_out.py:291-317, so docfreq -- and with it the idf of every score
+        # on a slice -- is subset-local while corpus_size and avg_doc_length stay global).
+        tf = self._core.device().termfreqs_dense(tid)
+        return np.uint64(np.count_nonzero(tf[np.unique(self._rows)]))
 
     def doclengths(self) -> np.ndarray:
         return self.doc_lens

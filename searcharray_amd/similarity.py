@@ -10,9 +10,16 @@ device-computed term frequencies.
 """
 from __future__ import annotations
 
+from typing import Callable
+
 import numpy as np
 
 from . import ops
+
+
+# the reference's Similarity protocol (similarity.py:8-16): any
+# callable(term_freqs, doc_freqs, doc_lens, avg_doc_lens, num_docs) -> ndarray
+Similarity = Callable[..., np.ndarray]
 
 
 def compute_idf(num_docs, dfs):

@@ -139,9 +139,58 @@ def corpus_goldens(name, num_docs, vocab, mean_len, seed, n_phr, slop_queries):
     print(f"{name}.npz", len(out), "arrays,", num_docs, "docs")
 
 
+def edismax_goldens():
+    """Reference solr.edismax outputs on seeded multi-field frames (scores and explain strings)."""
+    import json
+    import pandas as pd
+    from searcharray.solr import edismax
+    rng = np.random.default_rng(99)
+    vocab = [f"w{i}" for i in range(40)]
+    probs = 1.0 / np.arange(1, 41)
+    probs /= probs.sum()
+
+    def docs(n, mean_len):
+        return [" ".join(rng.choice(vocab, size=max(1, rng.poisson(mean_len)), p=probs)) for _ in range(n)]
+
+    n = 300
+    fields = {"title": docs(n, 6), "body": docs(n, 30), "tags": docs(n, 3)}
+
+    def lower_whole(text):              # a tokenizer that yields ONE token: forces the field-centric path
+        return [text.lower()]
+
+    frame = pd.DataFrame({"title": SearchArray.index(fields["title"]), "body": SearchArray.index(fields["body"]),
+                          "tags": SearchArray.index(fields["tags"], tokenizer=lower_whole)})
+    cases = [
+        {"q": "w0 w3", "qf": ["title", "body"]},
+        {"q": "w1 w2 w5", "qf": ["title^3", "body"], "tie": 0.2},
+        {"q": "w0 w1 w2 w7", "qf": ["title", "body^0.5"], "mm": "3"},
+        {"q": "w0 w1 w2 w7", "qf": ["title", "body"], "mm": "2<75%", "tie": 0.1},
+        {"q": "w2 w1", "qf": ["title", "body"], "pf": ["body^2"]},
+        {"q": "w0 w1 w3", "qf": ["title", "body"], "pf": ["title", "body"], "pf2": ["body"], "pf3": ["body^1.5"]},
+        {"q": "w0 w1 w3", "qf": ["body", "title"], "pf2": ["body", "title^4"], "q_op": "AND"},
+        {"q": "w4 w0", "qf": ["title", "tags"]},                              # field-centric
+        {"q": "w4 w0", "qf": ["tags^2", "title", "body"], "mm": "2", "tie": 0.3},
+        {"q": "w39 w38", "qf": ["title", "body"], "mm": -1},
+        {"q": "w1", "qf": ["title", "body"], "pf": ["title"], "pf2": ["title"], "pf3": ["title"]},
+        {"q": "zzz w1", "qf": ["title", "body"]},                              # unknown term
+    ]
+    out = {"n_cases": np.asarray(len(cases)), "cases": np.asarray(json.dumps(cases))}
+    for k, v in fields.items():
+        out[f"field_{k}"] = np.asarray(v)
+    for i, c in enumerate(cases):
+        scores, explain = edismax(frame, **c)
+        out[f"scores_{i}"] = np.asarray(scores)              # native dtype: float64 term-centric, float32 field-centric
+        out[f"explain_{i}"] = np.asarray(explain)
+    np.savez_compressed(os.path.join(OUT, "edismax.npz"), **out)
+
+
 if __name__ == "__main__":
-    snp_fixture_goldens()
-    slopq = [([3, 7], 1), ([3, 7], 2), ([0, 1], 2), ([5, 2, 9], 2), ([10, 4], 3), ([1, 0], 1),
-             ([20, 30], 5), ([2, 2], 2), ([8, 1, 3], 4), ([40, 6], 2)]
-    corpus_goldens("zipf_small", 1500, 200, 40, 4321, 10, slopq)
-    corpus_goldens("zipf_sparse", 4000, 5000, 24, 77, 6, slopq[:4])
+    only = os.environ.get("ONLY", "")          # "" = everything, or one of: core, edismax
+    if only in ("", "core"):
+        snp_fixture_goldens()
+        slopq = [([3, 7], 1), ([3, 7], 2), ([0, 1], 2), ([5, 2, 9], 2), ([10, 4], 3), ([1, 0], 1),
+                 ([20, 30], 5), ([2, 2], 2), ([8, 1, 3], 4), ([40, 6], 2)]
+        corpus_goldens("zipf_small", 1500, 200, 40, 4321, 10, slopq)
+        corpus_goldens("zipf_sparse", 4000, 5000, 24, 77, 6, slopq[:4])
+    if only in ("", "edismax"):
+        edismax_goldens()

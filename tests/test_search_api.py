@@ -203,3 +203,23 @@ def test_setitem_and_from_dicts(default_api):
     from_dicts = SearchArray([{"foo": 1, "bar": 2}, {}, {"baz": 1}])
     assert len(from_dicts) == 3 and from_dicts.isna().tolist() == [False, True, False]
     assert from_dicts[0] == Terms({"foo": 1, "bar": 2}, doc_len=2)
+
+
+def test_slices_use_subset_local_docfreq(default_api):
+    """Known answers produced by the reference itself (v0.0.73, `arr[mask].score(...)`): a slice keeps
+    the global corpus_size / avg_doc_length but its docfreq -- hence the idf of every score on it --
+    counts only the slice's docs (FilteredPosns, reference middle_out.py:291-317, postings.py:345-358)."""
+    docs = ["foo bar bar baz", "data2", "data3 bar", "bunny funny wunny", "bar foo", "bar bar"] * 3
+    arr = SearchArray.index(docs)
+    mask = np.zeros(len(docs), dtype=bool)
+    mask[[0, 2, 4, 5, 9]] = True
+    sl = arr[mask]
+    assert arr.docfreq("bar") == 12 and sl.docfreq("bar") == 4
+    assert sl.corpus_size == 18 and np.isclose(sl.avg_doc_length, 2.3333333)
+    assert np.allclose(arr.score("bar")[mask], [0.21791613, 0.202136, 0.202136, 0.27264857, 0.0], rtol=1e-6)
+    assert np.allclose(sl.score("bar"), [0.7496305, 0.69534695, 0.69534695, 0.93790984, 0.0], rtol=1e-6)
+    assert np.allclose(sl.score(["foo", "bar"]), [1.2200788, 0, 0, 0, 0], rtol=1e-6)
+    assert np.array_equal(sl.termfreqs("bar"), [2, 1, 1, 2, 0]) and np.array_equal(sl.termfreqs(["bar", "bar"]), [1, 0, 0, 1, 0])
+    sl2 = arr[2:8]
+    assert sl2.docfreq("bar") == 4
+    assert np.allclose(sl2.score("bar"), [0.69534695, 0.0, 0.69534695, 0.93790984, 0.7496305, 0.0], rtol=1e-6)
