@@ -41,7 +41,10 @@ struct sa_batch {
     u32* d_qdf = nullptr;           // [B][T] postings of each query term in this shard
     u32* d_qrow8 = nullptr;         // [B][T] dense tf row of each query term
     u64* d_surv = nullptr;          // phase-2 survivors
-    u32* d_bloom = nullptr;         // [B][2^17 bytes] Bloom filters of the lead terms' docs
+    u32* d_bloom = nullptr;         // Bloom filters of the lead terms' docs (bytes), query q at d_bloom_off[q]
+    u64* d_bloom_off = nullptr;     // [B]
+    u32* d_bloom_shift = nullptr;   // [B] hash >> shift = cell
+    size_t bloom_bytes = 0;
     u32 surv_cap = 0;
     u64 sparse_p1_total = 0, sparse_limit2 = 0, sparse_p2_max = 0;
     bool sparse_ok = false;         // tables built and the scoring formula admits the idf bound

@@ -727,6 +727,8 @@ void sa_batch_free(sa_batch* bt) {
     if (bt->d_qrow8) hipFree(bt->d_qrow8);
     if (bt->d_surv) hipFree(bt->d_surv);
     if (bt->d_bloom) hipFree(bt->d_bloom);
+    if (bt->d_bloom_off) hipFree(bt->d_bloom_off);
+    if (bt->d_bloom_shift) hipFree(bt->d_bloom_shift);
     for (hipEvent_t e : bt->ev0) hipEventDestroy(e);
     for (hipEvent_t e : bt->ev1) hipEventDestroy(e);
     delete bt;
@@ -904,7 +906,24 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
             if (cap > (16u << 20)) cap = 16u << 20;
             bt->surv_cap = (u32)cap;
             SA_HIP_B(hipMalloc(&bt->d_surv, (size_t)cap * 2 * sizeof(u64)));
-            SA_HIP_B(hipMalloc(&bt->d_bloom, (size_t)B * (1u << 17)));             // SA_BLOOM_CELLS per query
+            // Bloom filter of every lead term: the power of two in [8, 16) x df cells, at least 1024
+            std::vector<u64> h_boff(B, 0);
+            std::vector<u32> h_bshift(B, 22);
+            size_t bytes = 0;
+            for (u32 r = 0; r < B; r++) {
+                const u64 df = h_lead[r] == 0xFFFFFFFFu ? 0 : h_qdf[(size_t)r * T + h_lead[r]];
+                u32 bits = 10;
+                while ((1ull << bits) < 8 * df && bits < 30) bits++;
+                h_boff[r] = bytes;
+                h_bshift[r] = 32 - bits;
+                bytes += (size_t)1 << bits;
+            }
+            bt->bloom_bytes = bytes;
+            SA_HIP_B(hipMalloc(&bt->d_bloom, bytes));
+            SA_HIP_B(hipMalloc(&bt->d_bloom_off, (size_t)B * sizeof(u64)));
+            SA_HIP_B(hipMalloc(&bt->d_bloom_shift, (size_t)B * sizeof(u32)));
+            SA_HIP_B(hipMemcpy(bt->d_bloom_off, h_boff.data(), (size_t)B * sizeof(u64), hipMemcpyHostToDevice));
+            SA_HIP_B(hipMemcpy(bt->d_bloom_shift, h_bshift.data(), (size_t)B * sizeof(u32), hipMemcpyHostToDevice));
         }
         SA_HIP_B(hipMemcpy(bt->d_ub, h_ub.data(), h_ub.size() * sizeof(float), hipMemcpyHostToDevice));
         SA_HIP_B(hipMemcpy(bt->d_ub_order, h_ord.data(), h_ord.size() * sizeof(u32), hipMemcpyHostToDevice));

@@ -29,10 +29,9 @@
 #include <stdlib.h>
 
 #define SA_NO_LEAD 0xFFFFFFFFu
-// per-query Bloom filter (one hash) of the lead term's docs: 2^17 one-byte cells, so phase 1 fills it
-// with plain stores (setting a bit would take an atomic per doc)
-#define SA_BLOOM_BITS 17
-#define SA_BLOOM_CELLS (1u << SA_BLOOM_BITS)
+// Per-query Bloom filter (one hash) of the lead term's docs: one-byte cells, so phase 1 fills it with
+// plain stores (setting a bit would take an atomic per doc); 8..16 cells per lead doc (sized at
+// batch creation), i.e. 6..12 % false positives.
 
 struct SparseParams {
     const u64* tfp;
@@ -67,7 +66,9 @@ struct SparseParams {
     u64* cand;
     u32 cand_cap;
     u32* cand_cnt;
-    unsigned char* bloom;  // [B][SA_BLOOM_CELLS] lead docs of each query (filled by phase 1)
+    unsigned char* bloom;  // Bloom filters of the lead docs, query q at bloom_off[q], 2^(32 - bloom_shift[q]) cells
+    const u64* bloom_off;  // [B]
+    const u32* bloom_shift;// [B]
     u32 tile_shift;        // log2(tile_docs)
     u32* stats;
     // phase-2 survivors of the bound check, scored by their own kernel (no divergence with the filter)
@@ -78,7 +79,7 @@ struct SparseParams {
 
 __device__ __forceinline__ u64 sa_sp_df(const SparseParams& p, u32 q, u32 t) { return p.qdf[q * p.T + t]; }
 
-__device__ __forceinline__ u32 sa_bloom_bit(u64 doc) { return ((u32)doc * 2654435761u) >> (32 - SA_BLOOM_BITS); }
+__device__ __forceinline__ u32 sa_bloom_cell(u64 doc, u32 shift) { return ((u32)doc * 2654435761u) >> shift; }
 
 // tf (and the posting's doc-length field) of query term t in `doc`; 0 when the doc lacks the term.
 // Frequent terms: one byte of their dense tf row.  Others: a lower-bound search of the doc's tile slice.
@@ -205,6 +206,8 @@ __global__ void __launch_bounds__(256) sa_k_sparse_lead(const SparseParams p) {
         const u64* post = p.tfp + p.qbase[qt] + start;
         const u32 gq = __hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const u32 thr = gq > 1u ? gq : 1u;
+        unsigned char* bloom = p.bloom + p.bloom_off[q];
+        const u32 bshift = p.bloom_shift[q];
         for (u32 i0 = 0; i0 < n; i0 += 256) {                       // uniform trip count
             const u32 i = i0 + threadIdx.x;
             const bool active = i < n;
@@ -213,7 +216,7 @@ __global__ void __launch_bounds__(256) sa_k_sparse_lead(const SparseParams p) {
             if (active) {
                 const u64 x = post[i];
                 doc = x >> SA_KEY_SHIFT;
-                p.bloom[(u64)q * SA_BLOOM_CELLS + sa_bloom_bit(doc)] = 1;
+                bloom[sa_bloom_cell(doc, bshift)] = 1;
                 s = sa_sparse_score(p, q, doc, lt, (u32)(x & SA_LSB_MASK), (u32)((x >> SA_LSB_BITS) & SA_LSB_MASK));
             }
             sa_sparse_keep(p, q, doc, s, thr, active);
@@ -315,6 +318,8 @@ __global__ void __launch_bounds__(256) sa_k_sparse_rest(const SparseParams p) {
         const u32 gq = p.gthr[q];
         const u32 thr = gq > 1u ? gq : 1u;
         const float gf = __uint_as_float(thr);
+        const unsigned char* bloom = p.bloom + p.bloom_off[q];
+        const u32 bshift = p.bloom_shift[q];
         const float idf_c = p.idf[qt];
         const float rest0 = p.ub[(u64)q * (p.T + 1) + p.T] - idf_c;
         // ---- per posting
@@ -343,8 +348,7 @@ __global__ void __launch_bounds__(256) sa_k_sparse_rest(const SparseParams p) {
                     if (t == lt) {
                         // the lead's docs are in the query's Bloom filter: most candidates are cleared by one
                         // load, the rest by the exact search
-                        const u32 hb = sa_bloom_bit(doc);
-                        has = p.bloom[(u64)q * SA_BLOOM_CELLS + hb] != 0 && sa_sparse_has(p, qt2, term, doc, tile);
+                        has = bloom[sa_bloom_cell(doc, bshift)] != 0 && sa_sparse_has(p, qt2, term, doc, tile);
                     } else {
                         has = sa_sparse_has(p, qt2, term, doc, tile);
                     }
@@ -432,10 +436,10 @@ int sa_launch_sparse(sa_batch* bt, hipStream_t st) {
     p.tile_q = bt->d_tile_q; p.tile_cnt = bt->d_tile_q + bt->B;
     p.hist = bt->d_hist; p.gthr = bt->d_gthr; p.cand = bt->d_cand; p.cand_cap = bt->cand_cap; p.cand_cnt = bt->d_cand_cnt;
     p.stats = bt->d_stats;
-    p.bloom = (unsigned char*)bt->d_bloom;
+    p.bloom = (unsigned char*)bt->d_bloom; p.bloom_off = bt->d_bloom_off; p.bloom_shift = bt->d_bloom_shift;
     p.tile_shift = 0;
     while ((1u << p.tile_shift) < ix->tile_docs) p.tile_shift++;
-    hipMemsetAsync(bt->d_bloom, 0, (size_t)bt->B * SA_BLOOM_CELLS, st);
+    hipMemsetAsync(bt->d_bloom, 0, bt->bloom_bytes, st);
     p.qdf = bt->d_qdf; p.qrow8 = bt->d_qrow8;
     p.surv = bt->d_surv; p.surv_cap = bt->surv_cap; p.surv_cnt = bt->d_tile_q + bt->B + 1;
     const u64 n1 = bt->sparse_p1_total;                            // work items of phase 1
