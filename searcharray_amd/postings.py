@@ -18,7 +18,7 @@ import json
 import numbers
 import warnings
 from collections import Counter
-from typing import Iterable, List, Optional, Union
+from typing import Iterable, List, Optional, Tuple, Union
 
 import numpy as np
 import pandas as pd
@@ -27,7 +27,7 @@ from pandas.api.types import is_list_like
 
 from . import _lib
 from . import roaringish as rz
-from .device_index import DeviceIndex, compute_idf
+from .device_index import DeviceIndex, NO_DOC, compute_idf
 from .indexing import HostIndex, build_index_from_terms_list, build_index_from_tokenizer
 from .similarity import default_bm25
 from .term_dict import TermMissingError
@@ -531,6 +531,47 @@ class SearchArray(ExtensionArray):
         # similarity callable (the stock BM25 closure applies the BM25 kernel through the C ABI)
         tfs = self.termfreqs(token, slop=slop, min_posn=min_posn, max_posn=max_posn)
         return similarity(tfs, dfs, self.doc_lens, self.avg_doc_length, self.corpus_size)
+
+    # -- batched top-k (no counterpart in the reference: its callers loop over score() + argpartition)
+    def search(self, queries, k: int = 10, similarity=default_bm25) -> Tuple[np.ndarray, np.ndarray]:
+        """Top-``k`` docs for many queries at once, without materialising dense score vectors:
+        ``queries`` is a list of token lists (each scored as a disjunction: the sum of its terms' BM25,
+        ``np.sum([arr.score(t) for t in q], axis=0)`` in reference terms) or a list of strings (each run
+        through this array's tokenizer first).  Returns ``(scores float32[B][k], doc_ids uint64[B][k])``
+        sorted by score descending then doc id ascending; unused slots hold score 0 and doc id 2**64-1.
+        Needs a stock BM25 similarity (``bm25_similarity(k1, b)``) and the whole array (not a slice)."""
+        return self._topk(queries, k, similarity, phrases=False)
+
+    def search_phrases(self, phrases, k: int = 10, similarity=default_bm25) -> Tuple[np.ndarray, np.ndarray]:
+        """Like :meth:`search`, each query an exact phrase (2..18 pairwise-distinct tokens):
+        the top-``k`` of ``arr.score(phrase)``."""
+        return self._topk(phrases, k, similarity, phrases=True)
+
+    def _topk(self, queries, k, similarity, phrases):
+        if getattr(similarity, "kind", None) != "bm25":
+            raise ValueError("batched search needs a stock BM25 similarity (bm25_similarity(k1, b))")
+        if self._rows is not None:
+            raise ValueError("batched search runs on the whole indexed array, not on a slice")
+        toks = [list(self.tokenizer(q)) if isinstance(q, str) else [self._check_token_arg(t) for t in q] for q in queries]
+        B = len(toks)
+        if B == 0 or len(self._core.doc_lens) == 0:
+            return np.zeros((B, k), np.float32), np.full((B, k), NO_DOC, np.uint64)
+        dev = self._core.device()
+        unknown = dev.n_terms                                   # any id >= n_terms matches nothing
+        ids = [[t if (t := self._term_id(tok)) >= 0 else unknown for tok in q] for q in toks]
+        if phrases:
+            batch = dev.phrase_batch(ids, k=k, k1=similarity.k1, b=similarity.b)
+        else:
+            T = max(1, max(len(q) for q in ids))
+            mat = np.full((B, T), unknown, dtype=np.int64)
+            for i, q in enumerate(ids):
+                mat[i, :len(q)] = q
+            batch = dev.batch(mat, k=k, k1=similarity.k1, b=similarity.b)
+        try:
+            batch.run()
+            return batch.fetch()
+        finally:
+            batch.close()
 
     def positions(self, token: str, key=None) -> List[np.ndarray]:
         """positions of ``token`` per doc (reference postings.py:682-687)."""

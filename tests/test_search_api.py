@@ -223,3 +223,33 @@ def test_slices_use_subset_local_docfreq(default_api):
     sl2 = arr[2:8]
     assert sl2.docfreq("bar") == 4
     assert np.allclose(sl2.score("bar"), [0.69534695, 0.0, 0.69534695, 0.93790984, 0.7496305, 0.0], rtol=1e-6)
+
+
+def test_batched_search_matches_score_loops(default_api):
+    """SearchArray.search / search_phrases == top-k of the dense score() the reference's callers build"""
+    rng = np.random.default_rng(3)
+    vocab = [f"w{i}" for i in range(30)]
+    p = 1.0 / np.arange(1, 31)
+    p /= p.sum()
+    docs = [" ".join(rng.choice(vocab, size=max(1, rng.poisson(12)), p=p)) for _ in range(700)]
+    arr = SearchArray.index(docs)
+    queries = [["w0", "w7", "w20"], "w3 w29", ["w1"], ["nope", "w2"], ["w5", "w5"]]
+    scores, ids = arr.search(queries, k=7)
+    for i, q in enumerate(queries):
+        toks = q.split() if isinstance(q, str) else q
+        dense = np.sum([arr.score(t) for t in toks], axis=0)
+        order = np.lexsort((np.arange(len(dense)), -dense))[:7]
+        n = int((dense[order] > 0).sum())
+        assert np.array_equal(ids[i, :n], order[:n].astype(np.uint64)) and np.allclose(scores[i, :n], dense[order][:n], rtol=1e-6)
+    phrases = [["w0", "w1"], ["w2", "w0", "w1"], "w1 w0"]
+    pscores, pids = arr.search_phrases(phrases, k=5)
+    for i, ph in enumerate(phrases):
+        toks = ph.split() if isinstance(ph, str) else ph
+        dense = arr.score(toks)
+        order = np.lexsort((np.arange(len(dense)), -dense))[:5]
+        n = int((dense[order] > 0).sum())
+        assert np.array_equal(pids[i, :n], order[:n].astype(np.uint64)) and np.allclose(pscores[i, :n], dense[order][:n], rtol=1e-6)
+    with pytest.raises(ValueError, match="slice"):
+        arr[:10].search(queries)
+    with pytest.raises(ValueError, match="BM25"):
+        arr.search(queries, similarity=lambda *a: a[0])
