@@ -198,31 +198,34 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
         }
     };
     struct Batch { sa_u64x2 v[PF]; };
+    // All indices below are relative to a0, the 16-byte-aligned start of the slice's hull: a slice is
+    // far shorter than 2^32 postings, so the per-posting bookkeeping is 32-bit.
     // pairs [first, first + PF*THREADS) of the hull of [lo, hi)
-    auto load_batch = [&](u64 lo, u64 hi, u64 first) -> Batch {
+    auto load_batch = [&](u64 lo, u64 hi, u32 first) -> Batch {
         Batch b;
         const u64 a0 = lo & ~1ull;
-        const u64 npairs = (hi > a0) ? ((hi - a0 + 1) >> 1) : 0;
+        const u32 npairs = (hi > a0) ? (u32)((hi - a0 + 1) >> 1) : 0u;
         const sa_u64x2* pairs = (const sa_u64x2*)(p.tfp + a0);
 #pragma unroll
         for (int u = 0; u < PF; u++) {
-            const u64 j = first + (u64)u * THREADS + tid;
+            const u32 j = first + (u32)u * THREADS + tid;
             if (j < npairs) b.v[u] = pairs[j];
             else { b.v[u].x = 0; b.v[u].y = 0; }
         }
         return b;
     };
-    auto score_batch = [&](const Batch& b, u64 lo, u64 hi, u64 first, float idf) {
+    auto score_batch = [&](const Batch& b, u64 lo, u64 hi, u32 first, float idf) {
         const u64 a0 = lo & ~1ull;
-        const u64 npairs = (hi > a0) ? ((hi - a0 + 1) >> 1) : 0;
+        const u32 npairs = (hi > a0) ? (u32)((hi - a0 + 1) >> 1) : 0u;
+        const u32 r_lo = (u32)(lo - a0), r_hi = (u32)(hi - a0);     // the slice inside its hull
 #pragma unroll
         for (int u = 0; u < PF; u++) {
             // wave-uniform skip: no lane of this wave has a pair at this step
-            const u64 jw = first + (u64)u * THREADS + (tid & ~(u32)(SA_WAVE - 1));
+            const u32 jw = first + (u32)u * THREADS + (tid & ~(u32)(SA_WAVE - 1));
             if (jw >= npairs) continue;
-            const u64 i0 = a0 + 2 * (first + (u64)u * THREADS + tid);
-            score_into(b.v[u].x, i0 >= lo && i0 < hi, idf);
-            score_into(b.v[u].y, i0 + 1 < hi, idf);          // i0 + 1 >= lo always holds
+            const u32 r0 = 2u * (first + (u32)u * THREADS + tid);
+            score_into(b.v[u].x, r0 >= r_lo && r0 < r_hi, idf);
+            score_into(b.v[u].y, r0 + 1u < r_hi, idf);           // r0 + 1 >= r_lo always holds
         }
     };
     Batch cur = load_batch(s_lo[0], s_hi[0], 0);
@@ -234,12 +237,12 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
         if (more) nxt = load_batch(s_lo[t + 1], s_hi[t + 1], 0);
         score_batch(cur, lo, hi, 0, idf);
         const u64 a0 = lo & ~1ull;
-        const u64 npairs = (hi > a0) ? ((hi - a0 + 1) >> 1) : 0;
-        if (npairs > (u64)PF * THREADS) {                       // long slice (frequent term)
-            u64 first = (u64)PF * THREADS;
+        const u32 npairs = (hi > a0) ? (u32)((hi - a0 + 1) >> 1) : 0u;
+        if (npairs > (u32)PF * THREADS) {                       // long slice (frequent term)
+            u32 first = (u32)PF * THREADS;
             Batch b = load_batch(lo, hi, first);
             while (first < npairs) {
-                const u64 nf = first + (u64)PF * THREADS;
+                const u32 nf = first + (u32)PF * THREADS;
                 Batch b2;
                 if (nf < npairs) b2 = load_batch(lo, hi, nf);
                 score_batch(b, lo, hi, first, idf);
