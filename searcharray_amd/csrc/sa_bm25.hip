@@ -69,7 +69,7 @@ struct Bm25Params {
     u64* cand;             // [B][n_tiles][k] composite keys (global doc ids) or null
 };
 
-// Saturation table of a batch.  For integer doc lengths dl < tab_w and term frequencies
+// Saturation table of a batch, laid out [dl][tf - 1].  For integer doc lengths dl < tab_w and term frequencies
 // 1 <= tf <= SA_SAT_NTF the per-posting factor  tf / (tf + k1 * ((1 - b) + b * (dl / avgdl)))
 // depends only on (tf, dl) and the batch constants, so it is tabulated once per batch with the
 // reference's exact operation order (bm25.pyx:19-23: every op rounded to fp32, IEEE division) and
@@ -82,7 +82,7 @@ __global__ void sa_k_make_sattab(float* __restrict__ tab, u32 tab_w, float k1, f
     const float one_minus_b = 1.0f - b;
     const u32 n = SA_SAT_NTF * tab_w;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float tf = (float)(i / tab_w + 1), dl = (float)(i % tab_w);
+        const float tf = (float)(i % SA_SAT_NTF + 1), dl = (float)(i / SA_SAT_NTF);   // [dl][tf - 1]: index = dl << 3 | tf - 1
         const float norm = __fmul_rn(k1, __fadd_rn(one_minus_b, __fmul_rn(b, __fdiv_rn(dl, avgdl))));
         tab[i] = __fdiv_rn(tf, __fadd_rn(tf, norm));
     }
@@ -187,7 +187,7 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
         if (valid) {
             float sat;
             if (tfi - 1u < (u32)SA_SAT_NTF && dli < tab_w) {
-                sat = s_tab[(tfi - 1u) * tab_w + dli];
+                sat = s_tab[(dli << 3) + tfi - 1u];              // [dl][tf - 1] (SA_SAT_NTF == 8): shift + add, no multiply
             } else {
                 const float tf = (float)tfi;
                 const float dl = p.dl_packed ? (float)dli : p.doc_lens[tile_base + d];
