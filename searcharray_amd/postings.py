@@ -517,7 +517,10 @@ class SearchArray(ExtensionArray):
         if len(self._core.doc_lens) == 0:
             return np.zeros(len(self), dtype=np.float32)
         posn_filter = min_posn is not None or max_posn is not None
-        if getattr(similarity, "kind", None) == "bm25" and not (posn_filter and len(tokens) == 1):
+        # (k1 == 0 or b == 1 can make the BM25 denominator 0 for docs without the term: the reference
+        # then returns 0/0 = NaN there, which only the dense tf -> bm25_score route reproduces)
+        degenerate = getattr(similarity, "k1", 1.0) == 0 or getattr(similarity, "b", 0.0) == 1
+        if getattr(similarity, "kind", None) == "bm25" and not (posn_filter and len(tokens) == 1) and not degenerate:
             dev = self._core.device()
             idf = np.float32(compute_idf(self.corpus_size, dfs))
             ids = [self._term_id(t) for t in tokens]

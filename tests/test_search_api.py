@@ -253,3 +253,14 @@ def test_batched_search_matches_score_loops(default_api):
         arr[:10].search(queries)
     with pytest.raises(ValueError, match="BM25"):
         arr.search(queries, similarity=lambda *a: a[0])
+
+
+def test_degenerate_bm25_parameters_keep_the_reference_nan(default_api):
+    """k1 = 0 makes the BM25 denominator 0 for docs without the term; the reference returns 0/0 = NaN
+    there (known answers produced by the reference itself)"""
+    from searcharray_amd.similarity import bm25_similarity
+    arr = SearchArray.index(["foo bar bar baz", "data2", "data3 bar", "bunny funny wunny"])
+    got = arr.score("bar", similarity=bm25_similarity(k1=0.0))
+    assert np.allclose(got[[0, 2]], 0.6931472) and np.isnan(got[[1, 3]]).all()
+    got = arr.score(["foo", "bar"], similarity=bm25_similarity(k1=0.0))
+    assert np.isclose(got[0], 1.89712) and np.isnan(got[1:]).all()
