@@ -1,0 +1,70 @@
+"""Randomised differential tests: small random corpora and queries, every result against the oracle.
+A few iterations per seed keep the suite fast; scripts in the development history ran hundreds."""
+import numpy as np
+import pytest
+
+from oracle import refimpl as O
+from searcharray_amd import roaringish as rz
+from searcharray_amd import synth
+from searcharray_amd.device_index import DeviceIndex, NO_DOC
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_bm25_batches_pruned_and_exhaustive(api, seed, monkeypatch):
+    rng = np.random.default_rng(seed)
+    for _ in range(4):
+        n_docs, vocab, mean = int(rng.integers(50, 6000)), int(rng.integers(5, 600)), int(rng.integers(2, 30))
+        t, d, p, lens = synth.corpus_triples(n_docs, vocab, mean, seed=int(rng.integers(1 << 30)))
+        words, wt = rz.encode_sorted(t, d, p)
+        monkeypatch.setenv("SA_TF8_DIV", str(rng.choice([0, 8, 128, 100000])))
+        dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=int(rng.choice([1024, 2048, 4096])), api=api)
+        orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
+        T, B, k = int(rng.integers(1, 7)), int(rng.integers(1, 7)), int(rng.choice([1, 3, 10, 33, 100]))
+        queries = rng.integers(0, vocab + 3, size=(B, T))                       # includes unknown ids
+        queries[rng.random((B, T)) < 0.3] = vocab - 1 - rng.integers(0, max(1, vocab // 4))
+        k1, b = float(rng.choice([1.2, 0.4, 2.0])), float(rng.choice([0.75, 0.0, 1.0]))
+        got = {}
+        for sparse in ("1", "0"):
+            monkeypatch.setenv("SA_SPARSE", sparse)
+            bt = dev.batch(queries, k=k, k1=k1, b=b)
+            bt.run()
+            got[sparse] = bt.fetch()
+            bt.close()
+        assert np.array_equal(got["1"][0], got["0"][0]) and np.array_equal(got["1"][1], got["0"][1])
+        for qi, q in enumerate(queries):
+            known = [int(x) for x in q if x < vocab]
+            dense = orc.score_terms_sum(known, k1=k1, b=b) if known else np.zeros(n_docs, np.float32)
+            ws, wd = O.topk(dense, k)
+            n = int((ws > 0).sum())
+            assert np.array_equal(got["1"][0][qi, :n], ws[:n]) and np.array_equal(got["1"][1][qi, :n], wd[:n])
+            assert (got["1"][1][qi, n:] == NO_DOC).all()
+        dev.close()
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_random_phrases_batches_and_slop(api, seed, monkeypatch):
+    rng = np.random.default_rng(seed)
+    for _ in range(3):
+        n_docs, vocab, mean = int(rng.integers(50, 5000)), int(rng.integers(4, 60)), int(rng.integers(3, 60))
+        t, d, p, lens = synth.corpus_triples(n_docs, vocab, mean, seed=int(rng.integers(1 << 30)))
+        words, wt = rz.encode_sorted(t, d, p)
+        monkeypatch.setenv("SA_DOCDIR_DIV", str(rng.choice([0, 4, 32, 100000])))
+        monkeypatch.setenv("SA_PTILE", str(rng.choice([2048, 4096])))
+        dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+        orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
+        phrases = [[int(x) for x in rng.choice(vocab, int(rng.integers(2, min(8, vocab))), replace=False)]
+                   for _ in range(int(rng.integers(1, 6)))]
+        k = int(rng.choice([1, 5, 40]))
+        bt = dev.phrase_batch(phrases, k=k)
+        bt.run()
+        s, dd = bt.fetch()
+        bt.close()
+        for i, ph in enumerate(phrases):
+            ws, wd = O.topk(orc.score(list(ph)), k)
+            n = int((ws > 0).sum())
+            assert np.array_equal(s[i, :n], ws[:n]) and np.array_equal(dd[i, :n], wd[:n]) and (dd[i, n:] == NO_DOC).all()
+            assert np.array_equal(dev.phrase_freqs_dense(ph), orc.phrase_freqs(ph))
+            if len(ph) <= 4:
+                slop = int(rng.integers(1, 4))
+                assert np.array_equal(dev.phrase_freqs_dense(ph, slop=slop), orc.phrase_freqs(ph, slop=slop))
+        dev.close()
