@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Randomised differential run (development tool): the tests/test_fuzz.py loops with many iterations,
+on the GPU library (default) or the host stand-in (--emu)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+class _Env:
+    def setenv(self, k, v):
+        os.environ[k] = v
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--emu", action="store_true")
+    ap.add_argument("--seeds", type=int, default=20)
+    args = ap.parse_args()
+    if args.emu:
+        from tests.emu import emu_api
+        api = emu_api()
+    else:
+        from searcharray_amd import _lib
+        api = _lib.api()
+    from tests import test_fuzz
+    fails = 0
+    for seed in range(100, 100 + args.seeds):
+        for fn in (test_fuzz.test_random_bm25_batches_pruned_and_exhaustive, test_fuzz.test_random_phrases_batches_and_slop):
+            try:
+                fn(api, seed, _Env())
+            except AssertionError as e:
+                fails += 1
+                print("FAIL", fn.__name__, seed, str(e)[:200], flush=True)
+    print(f"fuzz done: {2 * args.seeds} runs, {fails} failures")
+
+
+if __name__ == "__main__":
+    main()
