@@ -9,3 +9,4 @@ __version__ = "0.1.0"
 from .postings import SearchArray, Terms, TermsDtype, ws_tokenizer      # noqa: E402,F401
 from .similarity import (bm25_similarity, bm25_impact, bm25_legacy_similarity, classic_similarity,  # noqa: E402,F401
                          default_bm25)
+from .results import SetOfResults                                         # noqa: E402,F401

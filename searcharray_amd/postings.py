@@ -56,6 +56,20 @@ class Terms:
             return self.posns.items()
         return self.posns[term]
 
+    def raw_positions(self, term_dict, term=None):
+        """(term id, positions) pairs, ids from ``term_dict`` (reference postings.py:94-101)."""
+        if self.posns is None:
+            return {}
+        wanted = self.posns.items() if term is None else [(term, self.posns[term])]
+        return [(term_dict.get_term_id(tok), plist) for tok, plist in wanted]
+
+    def tf_to_dense(self, term_dict):
+        """term frequencies as a vector over the dictionary (reference postings.py:103-108)."""
+        dense = np.zeros(len(term_dict))
+        for tok, tf in self.terms():
+            dense[term_dict.get_term_id(tok)] = tf
+        return dense
+
     def __len__(self):
         return len(self.postings)
 
@@ -534,6 +548,31 @@ class SearchArray(ExtensionArray):
         # similarity callable (the stock BM25 closure applies the BM25 kernel through the C ABI)
         tfs = self.termfreqs(token, slop=slop, min_posn=min_posn, max_posn=max_posn)
         return similarity(tfs, dfs, self.doc_lens, self.avg_doc_length, self.corpus_size)
+
+    def memory_report(self, N=1000):
+        """Where the bytes are (reference postings.py:570-602): host structures, what the index holds in
+        HBM, and the ``N`` largest terms by positional words."""
+        def human(n):
+            for unit in ("bytes", "KB", "MB", "GB"):
+                if n < 1024 or unit == "GB":
+                    return f"{n:.2f} {unit}" if unit != "bytes" else f"{int(n)} bytes"
+                n /= 1024.0
+        h = self._core.host
+        sizes = np.diff(h.term_off.astype(np.int64)) * 8
+        order = np.argsort(-sizes, kind="stable")[:min(N, len(sizes))]
+        lines = ["", "SearchArray Memory Report", "-------------------------",
+                 f"Number of Terms: {len(self.term_dict)}", "-------------------------",
+                 f"Doc -> terms CSR: {human(h.doc_term_ids.nbytes + h.doc_term_ptr.nbytes)}",
+                 f"Positions:        {human(h.words.nbytes)}",
+                 f"Term Dictionary:  {human(self.term_dict.nbytes)}"]
+        if self._core._device is not None:
+            lines.append(f"On the device:    {human(self._core._device.info().hbm_bytes)}")
+        lines.append("")
+        running = 0
+        for rank, tid in enumerate(order):
+            running += int(sizes[tid])
+            lines.append(f"Term {rank}: {self.term_dict.get_term(int(tid))} - {human(int(sizes[tid]))} - Cumulative: {human(running)}")
+        return "\n".join("        " + ln for ln in lines) + "\n"
 
     # -- batched top-k (no counterpart in the reference: its callers loop over score() + argpartition)
     def search(self, queries, k: int = 10, similarity=default_bm25) -> Tuple[np.ndarray, np.ndarray]:

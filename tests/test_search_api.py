@@ -264,3 +264,26 @@ def test_degenerate_bm25_parameters_keep_the_reference_nan(default_api):
     assert np.allclose(got[[0, 2]], 0.6931472) and np.isnan(got[[1, 3]]).all()
     got = arr.score(["foo", "bar"], similarity=bm25_similarity(k1=0.0))
     assert np.isclose(got[0], 1.89712) and np.isnan(got[1:]).all()
+
+
+def test_terms_helpers_memory_report_and_set_of_results(default_api):
+    import pandas as pd
+    from searcharray_amd import SetOfResults
+    arr = SearchArray.index(["foo bar bar baz", "data2", "data3 bar", "bunny funny wunny"])
+    doc = arr[0]
+    dense = doc.tf_to_dense(arr.term_dict)
+    assert dense[arr.term_dict.get_term_id("bar")] == 2 and dense.sum() == 4
+    raw = dict(doc.raw_positions(arr.term_dict))
+    assert list(raw[arr.term_dict.get_term_id("bar")]) == [1, 2]
+    assert list(dict(doc.raw_positions(arr.term_dict, "foo"))[arr.term_dict.get_term_id("foo")]) == [0]
+    report = arr.memory_report(N=3)
+    assert "Number of Terms: 8" in report and "Term 0: bar" in report and "Cumulative" in report
+    df = pd.DataFrame({"title": arr, "id": [10, 11, 12, 13]})
+    res = SetOfResults(df)
+    res.ins_top_n(arr.score("bar"), N=2, query="bar", metadata={"run": "a"})
+    res.ins_top_n(arr.score("bunny"), N=1, query="bunny", metadata={"run": ["b"]})
+    out = res.get_all()
+    assert list(out.columns) == ["id", "score", "query", "run", "rank"]
+    assert list(out["id"]) == [10, 12, 13] and list(out["rank"]) == [1, 2, 1]
+    with pytest.raises(ValueError):
+        res.ins_top_n(arr.score("bar"), N=2, query="x", metadata={"run": ["only one"]})
