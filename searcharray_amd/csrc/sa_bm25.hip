@@ -151,7 +151,7 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     // pruning slots of this query (see the top-k section); loaded first so the L2 latency hides
     // behind the posting stream.  L1-bypassing load: a fresher bound prunes more.
     // (k > 32 on tiles of <= 4 waves: the cached histogram bound instead, see sa_tile_topk_hist)
-    constexpr bool HIST_OK = (size_t)NW * SA_HBINS * 4 <= sizeof(float) * SA_SAT_NTF * SA_SAT_WMAX;
+    constexpr bool HIST_OK = (size_t)NW * SA_HBINS * 2 <= sizeof(float) * SA_SAT_NTF * SA_SAT_WMAX;   // 16-bit bins
     const bool use_hist = MODE == 1 && HIST_OK && p.hist != nullptr;
     u32 slot_val = 0xFFFFFFFFu;
     if (MODE == 1 && !use_hist && (tid & (SA_WAVE - 1)) < 32u)
@@ -978,9 +978,9 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     // k > 32: histogram bound (BM25 tiles of <= 4 waves); SA_TOPK_HIST=0 keeps the slot bound
     // dynamic pruning (sa_sparse.hip; SA_SPARSE=0: score every posting, the exhaustive reference
     // behaviour): needs the histogram bound for every k
-    const bool hist_possible = p.pruned && bt->kind == 0 && sa_tile_waves(ix->tile_docs) <= 4 &&
+    const bool hist_possible = p.pruned && bt->kind == 0 && sa_tile_waves(ix->tile_docs) <= 8 &&
                                sa_env_int("SA_TOPK_HIST", 1) != 0;
-    const bool sparse = hist_possible && bt->sparse_ok && ix->avg_doc_len != 0.f && ix->n_tiles > 0 &&
+    const bool sparse = hist_possible && ix->tile_docs <= 8192 && bt->sparse_ok && ix->avg_doc_len != 0.f && ix->n_tiles > 0 &&
                         sa_env_int("SA_SPARSE", 1) != 0;
     const bool use_hist = hist_possible &&
                           (sparse || bt->k >= (u32)sa_env_int("SA_TOPK_HIST_MINK", defer_check ? 1 : 33));

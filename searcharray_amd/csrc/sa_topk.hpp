@@ -214,7 +214,7 @@ __device__ __forceinline__ void sa_tile_topk_pruned(float* acc, u32 slot_val, u3
 // (per-wave histogram in LDS, flushed with one global atomic per non-empty bin), refresh the bound
 // and append ALL their docs at or above it (no per-wave exact top-k: the bound is tight enough
 // that appending is cheaper).  Stale reads only weaken the bound.
-// lds_hist: 256 u32 per wave of scratch LDS.
+// lds_hist: 128 u32 per wave of scratch LDS (two 16-bit bins per word: a wave owns < 2^16 docs).
 // ---------------------------------------------------------------------------------------
 #define SA_HBINS 256
 #define SA_HBIN_SHIFT 19
@@ -315,15 +315,16 @@ __device__ __forceinline__ void sa_tile_topk_hist(float* acc, u32 gc, u32 q, u32
         }
         return;
     }
-    // 1. count this wave's docs >= the cached bound, per bin
-    u32* wh = lds_hist + wave * SA_HBINS;
+    // 1. count this wave's docs >= the cached bound, per bin (bin b = half b & 1 of word b >> 1)
+    static_assert(E * SA_WAVE < 65536, "16-bit bins");
+    u32* wh = lds_hist + wave * (SA_HBINS / 2);
 #pragma unroll
-    for (int i = 0; i < SA_HBINS / SA_WAVE; i++) wh[i * SA_WAVE + lane] = 0;
+    for (int i = 0; i < SA_HBINS / 2 / SA_WAVE; i++) wh[i * SA_WAVE + lane] = 0;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < E; j++) {
         const u32 x = __float_as_uint(acc[j * THREADS + tid]);
-        if (x >= thr0) atomicAdd(&wh[sa_score_bin(x)], 1u);
+        if (x >= thr0) { const u32 b = sa_score_bin(x); atomicAdd(&wh[b >> 1], 1u << (16u * (b & 1u))); }
     }
     __builtin_amdgcn_wave_barrier();
     // lane L owns bins 4L .. 4L+3: flush, then read the query's totals back
@@ -331,7 +332,7 @@ __device__ __forceinline__ void sa_tile_topk_hist(float* acc, u32 gc, u32 q, u32
 #pragma unroll
     for (int i = 0; i < SA_HBINS / SA_WAVE; i++) {
         const u32 b = lane * (SA_HBINS / SA_WAVE) + i;
-        const u32 v = wh[b];
+        const u32 v = (wh[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu;
         u32 old = 0;
         if (v) old = atomicAdd(&qh[b], v);
         else old = __hip_atomic_load(&qh[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
