@@ -8,6 +8,9 @@
 #define SA_MAX_QTERMS 32
 #define SA_KMAX 1024
 #define SA_EVENT_RING 128
+// postings per work item of the sparse candidate path (the lead phase of a small shard takes the small size)
+#define SA_SP_CHUNK_LEAD 256
+#define SA_SP_CHUNK 1024
 
 struct sa_batch {
     sa_index* ix = nullptr;
@@ -47,6 +50,7 @@ struct sa_batch {
     size_t bloom_bytes = 0;
     u32 surv_cap = 0;
     u64 sparse_p1_total = 0, sparse_limit2 = 0, sparse_p2_max = 0;
+    u32 sparse_chunk1 = SA_SP_CHUNK_LEAD;
     bool sparse_ok = false;         // tables built and the scoring formula admits the idf bound
     u32* d_overflow = nullptr;      // set by the merge kernel when a candidate list ran over (checked at fetch)
     u64* d_local = nullptr;         // [B][k] per-shard result

@@ -54,7 +54,8 @@ struct SparseParams {
     const u32* qdf;        // [B][T] postings of each query term in this shard
     const u32* qrow8;      // [B][T] dense tf row of each query term, or SA_DD_NONE
     const u32* lead;       // [B] query-term index of the lead term, or SA_NO_LEAD (scan the tiles)
-    const u64* p1_off;     // [B+1] prefix sums of the lead terms' work items (chunks of SA_SP_CHUNK postings)
+    u32 chunk1;            // postings per lead-phase work item
+    const u64* p1_off;     // [B+1] prefix sums of the lead terms' work items (chunks of SA_SP_CHUNK_LEAD postings)
     u32* route;            // [B] 0: sparse, 1: tiles
     u32* emask;            // [B] essential query terms (bit t)
     u64* p2_off;           // [B+1] prefix sums of the phase-2 work items
@@ -179,7 +180,6 @@ __device__ __forceinline__ void sa_sparse_keep(const SparseParams& p, u32 q, u64
     if (keep && pos < p.cand_cap) p.cand[(u64)q * p.cand_cap + pos] = ((u64)x << 32) | (u64)(u32)(~(u32)(p.doc_base + doc));
 }
 
-#define SA_SP_CHUNK 1024            // postings per work item (one workgroup, 4 per thread)
 
 // largest q with off[q] <= g
 __device__ __forceinline__ u32 sa_sp_find(const u64* __restrict__ off, u32 n, u64 g) {
@@ -200,9 +200,9 @@ __global__ void __launch_bounds__(256) sa_k_sparse_lead(const SparseParams p) {
         const u32 q = sa_sp_find(p.p1_off, p.B, item);
         const u32 lt = p.lead[q];
         const u32 qt = q * p.T + lt;
-        const u64 start = (item - p.p1_off[q]) * SA_SP_CHUNK;
+        const u64 start = (item - p.p1_off[q]) * p.chunk1;
         const u64 df = p.qdf[qt];
-        const u32 n = df - start < (u64)SA_SP_CHUNK ? (u32)(df - start) : (u32)SA_SP_CHUNK;
+        const u32 n = df - start < (u64)p.chunk1 ? (u32)(df - start) : p.chunk1;
         const u64* post = p.tfp + p.qbase[qt] + start;
         const u32 gq = __hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const u32 thr = gq > 1u ? gq : 1u;
@@ -436,6 +436,7 @@ int sa_launch_sparse(sa_batch* bt, hipStream_t st) {
     p.tile_q = bt->d_tile_q; p.tile_cnt = bt->d_tile_q + bt->B;
     p.hist = bt->d_hist; p.gthr = bt->d_gthr; p.cand = bt->d_cand; p.cand_cap = bt->cand_cap; p.cand_cnt = bt->d_cand_cnt;
     p.stats = bt->d_stats;
+    p.chunk1 = bt->sparse_chunk1;
     p.bloom = (unsigned char*)bt->d_bloom; p.bloom_off = bt->d_bloom_off; p.bloom_shift = bt->d_bloom_shift;
     p.tile_shift = 0;
     while ((1u << p.tile_shift) < ix->tile_docs) p.tile_shift++;
