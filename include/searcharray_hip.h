@@ -245,6 +245,12 @@ typedef struct sa_index_info {
 } sa_index_info_t;
 int sa_index_info(sa_index_t* ix, sa_index_info_t* out);
 
+/* Page-locked host buffers for dense results (optional): any host pointer works as `out` of the
+ * dense calls above; a buffer from sa_host_alloc is filled at full PCIe rate and can be recycled by
+ * the binding without first-touch page faults (searcharray_amd/device_index.py keeps a small pool). */
+int sa_host_alloc(uint64_t bytes, void** out);
+int sa_host_free(void* p);
+
 /* ------------------------------------------------------------------------------------- */
 /* Part 3 -- doc-range sharding: per-shard top-k exchange over RCCL (xGMI)                 */
 /* ------------------------------------------------------------------------------------- */

@@ -87,6 +87,8 @@ PROTOTYPES = {
     "sa_batch_profile": (c_int, [c_void_p, POINTER(c_double), u64p, u64p]),
     "sa_batch_stats": (c_int, [c_void_p, c_int, u64p, u64p]),
     "sa_batch_destroy": (c_int, [c_void_p]),
+    "sa_host_alloc": (c_int, [c_uint64, POINTER(c_void_p)]),
+    "sa_host_free": (c_int, [c_void_p]),
     # Part 3
     "sa_comm_unique_id": (c_int, [ctypes.c_char_p, c_int]),
     "sa_index_comm_init": (c_int, [c_void_p, c_int, c_int, ctypes.c_char_p, c_int]),

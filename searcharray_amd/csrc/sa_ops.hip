@@ -225,3 +225,19 @@ extern "C" int sa_stream_probe(uint64_t bytes, int mode, int reps, double* gbps_
     *gbps_out = best;
     return SA_OK;
 }
+
+// Page-locked host memory for the dense float32[N] results of the drop-in calls: the device copies
+// into it at full PCIe rate, and a recycled buffer costs no page faults (a fresh 40 MB numpy array
+// costs ~3 ms of first-touch faults, more than the copy itself).
+extern "C" int sa_host_alloc(uint64_t bytes, void** out) {
+    SA_ARG(out, "out is null");
+    *out = nullptr;
+    SA_HIP(hipHostMalloc(out, bytes ? (size_t)bytes : 1));
+    return SA_OK;
+}
+
+extern "C" int sa_host_free(void* p) {
+    if (p) SA_HIP(hipHostFree(p));
+    return SA_OK;
+}
+

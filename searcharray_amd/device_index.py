@@ -8,6 +8,7 @@ with GPU kernels.
 from __future__ import annotations
 
 import ctypes
+import weakref
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -25,6 +26,60 @@ def compute_idf(num_docs, dfs) -> np.float32:
     (searcharray/similarity.py:19-21, bm25.pyx:31)."""
     dfs = np.asarray(dfs)
     return np.float32(np.sum(np.log(1 + (num_docs - dfs + 0.5) / (dfs + 0.5))))
+
+
+class _PinnedPool:
+    """float32 result arrays backed by page-locked host memory, recycled when the array dies.
+
+    The dense drop-in calls return a fresh ``float32[n_docs]`` every time.  Allocating that with numpy
+    costs first-touch page faults (≈3 ms for 40 MB -- more than the device work plus the copy), and a
+    pageable destination halves the PCIe rate.  Buffers here come from ``sa_host_alloc``; when the numpy
+    array (and every view of it) has been garbage-collected its buffer goes back to the pool, so a caller
+    that consumes results as they come keeps reusing the same few buffers.  A caller that keeps every
+    result simply keeps every buffer: the arrays stay valid and caller-owned."""
+
+    MAX_IDLE_BYTES = 1 << 30
+
+    def __init__(self, api):
+        self.api = api
+        self.idle = {}                # nbytes -> [address, ...]
+        self.idle_bytes = 0
+
+    def _release(self, addr: int, nbytes: int):
+        try:
+            if self.idle_bytes + nbytes <= self.MAX_IDLE_BYTES:
+                self.idle.setdefault(nbytes, []).append(addr)
+                self.idle_bytes += nbytes
+            else:
+                self.api.sa_host_free(ctypes.c_void_p(addr))
+        except Exception:             # interpreter shutdown
+            pass
+
+    def empty_f32(self, n: int) -> np.ndarray:
+        if n == 0:
+            return np.empty(0, dtype=np.float32)
+        nbytes = 4 * n
+        stack = self.idle.get(nbytes)
+        if stack:
+            addr = stack.pop()
+            self.idle_bytes -= nbytes
+        else:
+            ptr = ctypes.c_void_p()
+            self.api.call("sa_host_alloc", nbytes, ctypes.byref(ptr))
+            addr = ptr.value
+        buf = (ctypes.c_float * n).from_address(addr)
+        weakref.finalize(buf, self._release, addr, nbytes)     # runs when the last array / view is gone
+        return np.frombuffer(buf, dtype=np.float32)
+
+
+_pools = {}
+
+
+def _pool(api) -> _PinnedPool:
+    pool = _pools.get(id(api))
+    if pool is None:
+        pool = _pools[id(api)] = _PinnedPool(api)
+    return pool
 
 
 class DeviceIndex:
@@ -137,7 +192,7 @@ class DeviceIndex:
 
     def termfreqs_dense(self, term: int, min_posn: Optional[int] = None, max_posn: Optional[int] = None) -> np.ndarray:
         lo, hi = self._check_posn_range(min_posn, max_posn)
-        out = np.empty(self.n_docs, dtype=np.float32)
+        out = _pool(self.api).empty_f32(self.n_docs)
         t = term if 0 <= term < self.n_terms else NO_TERM
         self.api.call("sa_index_termfreqs_dense_posn", self._h, t, lo, hi, p_f32(out))
         return out
@@ -164,7 +219,7 @@ class DeviceIndex:
         tarr = np.asarray([int(t) if 0 <= int(t) < self.n_terms else NO_TERM for t in terms],
                           dtype=np.uint32)
         idf = self.idfs(terms) if idf is None else as_f32(idf)
-        out = np.empty(self.n_docs, dtype=np.float32)
+        out = _pool(self.api).empty_f32(self.n_docs)
         self.api.call("sa_index_bm25_dense", self._h, p_u32(tarr), p_f32(idf), len(tarr),
                       np.float32(k1), np.float32(b), p_f32(out))
         return out
@@ -177,7 +232,7 @@ class DeviceIndex:
             raise ValueError("Must have at least two terms")        # reference middle_out.py:425-426
         lo, hi = self._check_posn_range(min_posn, max_posn)
         tarr = np.asarray([int(t) if 0 <= int(t) < self.n_terms else NO_TERM for t in terms], dtype=np.uint32)
-        out = np.empty(self.n_docs, dtype=np.float32)
+        out = _pool(self.api).empty_f32(self.n_docs)
         self.api.call("sa_index_phrase_freqs_dense_posn", self._h, p_u32(tarr), len(tarr), int(slop), lo, hi, p_f32(out))
         return out
 
@@ -192,7 +247,7 @@ class DeviceIndex:
             dfs = np.asarray([self.docfreq(int(t)) if 0 <= int(t) < self.n_terms else 0 for t in terms])
             idf = compute_idf(self.corpus_size, dfs)
         lo, hi = self._check_posn_range(min_posn, max_posn)
-        out = np.empty(self.n_docs, dtype=np.float32)
+        out = _pool(self.api).empty_f32(self.n_docs)
         self.api.call("sa_index_bm25_phrase_dense_posn", self._h, p_u32(tarr), len(tarr), int(slop), lo, hi,
                       np.float32(idf), np.float32(k1), np.float32(b), p_f32(out))
         return out
