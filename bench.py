@@ -251,6 +251,22 @@ def main():
                                   f"oracle/ C+numpy port of score()+np.sum+top-{args.k}, single thread, "
                                   f"host has {os.cpu_count()} cores"}
         del s0
+        # the same port on many host threads (the reference's own throughput test runs score() from a
+        # ThreadPoolExecutor, test_msmarco.py:483-507): ctypes and numpy release the GIL in the heavy parts
+        from concurrent.futures import ThreadPoolExecutor
+        n_thr = int(max(2, min(32, (os.cpu_count() or 2))))
+        mt_q = [queries[i % B] for i in range(int(min(4 * n_thr, max(n_thr, 2 * nq))))]
+
+        def one(qrow):
+            dense = orc.score_terms_sum([int(t) for t in qrow])
+            return O.topk(dense, args.k)[1][0]
+        with ThreadPoolExecutor(n_thr) as ex:
+            list(ex.map(one, mt_q[:n_thr]))                        # warm the remaining caches
+            tq = time.perf_counter()
+            list(ex.map(one, mt_q))
+            mt_dt = time.perf_counter() - tq
+        cpu_baseline["threaded"] = {"value": round(len(mt_q) / mt_dt, 3), "unit": "queries/s", "cores": n_thr,
+                                    "sample": f"{len(mt_q)} queries through ThreadPoolExecutor({n_thr}) over the same port"}
 
     def roof(kms, traf, exhaustive):
         ach = alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
