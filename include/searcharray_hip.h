@@ -245,6 +245,13 @@ typedef struct sa_index_info {
 } sa_index_info_t;
 int sa_index_info(sa_index_t* ix, sa_index_info_t* out);
 
+/* Subset output for the dense calls above (sliced arrays, rerank-top-N: reference arr[mask].score(...),
+ * postings.py:619-627,702-703): after sa_index_select_rows the NEXT dense call on `ix` made by the same
+ * thread writes out[i] = dense[rows[i]] for i < n_rows (n_rows floats; rows >= n_docs give 0) instead of
+ * the whole vector -- the rows are gathered on the device.  The selection is consumed by that call;
+ * rows must stay valid until it returns.  rows == NULL clears a pending selection. */
+int sa_index_select_rows(sa_index_t* ix, const uint64_t* rows, uint64_t n_rows);
+
 /* Page-locked host buffers for dense results (optional): any host pointer works as `out` of the
  * dense calls above; a buffer from sa_host_alloc is filled at full PCIe rate and can be recycled by
  * the binding without first-touch page faults (searcharray_amd/device_index.py keeps a small pool). */

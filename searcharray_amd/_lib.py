@@ -87,6 +87,7 @@ PROTOTYPES = {
     "sa_batch_profile": (c_int, [c_void_p, POINTER(c_double), u64p, u64p]),
     "sa_batch_stats": (c_int, [c_void_p, c_int, u64p, u64p]),
     "sa_batch_destroy": (c_int, [c_void_p]),
+    "sa_index_select_rows": (c_int, [c_void_p, u64p, c_uint64]),
     "sa_host_alloc": (c_int, [c_uint64, POINTER(c_void_p)]),
     "sa_host_free": (c_int, [c_void_p]),
     # Part 3

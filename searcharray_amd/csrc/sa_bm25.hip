@@ -653,9 +653,8 @@ extern "C" int sa_index_bm25_dense(sa_index_t* ix, const uint32_t* terms, const 
     hipStream_t st = ix->stream;
     const u64 N = ix->n_docs;
     // reference similarity.py:31-32: avg_doc_lens == 0 -> zeros
-    if (N == 0) return SA_OK;
-    if (n_query_terms == 0 || ix->avg_doc_len == 0.f) {
-        memset(out, 0, N * sizeof(float));
+    if (N == 0 || n_query_terms == 0 || ix->avg_doc_len == 0.f) {
+        sa_emit_zeros(ix, out);
         return SA_OK;
     }
     // scratch: [out chunk accumulators N floats][terms][idf]
@@ -683,7 +682,7 @@ extern "C" int sa_index_bm25_dense(sa_index_t* ix, const uint32_t* terms, const 
     SA_TRY(sa_launch_make_sattab(ix, d_tab, &p.tab_w, k1, b, st));
     SA_TRY(sa_launch_make_bounds(ix, d_terms, (u32)T, d_bounds, d_qbase, st));
     SA_TRY(sa_launch_bm25(ix, p, st));
-    SA_HIP(hipMemcpyAsync(out, d_out, N * sizeof(float), hipMemcpyDeviceToHost, st));
+    SA_TRY(sa_emit_dense(ix, d_out, out));
     SA_HIP(hipStreamSynchronize(st));
     SA_HIP(hipGetLastError());
     return SA_OK;

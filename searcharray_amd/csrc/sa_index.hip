@@ -199,6 +199,7 @@ void sa_index_free(sa_index* ix) {
     if (ix->d_tfbits) hipFree(ix->d_tfbits);
     if (ix->d_tf8_slot) hipFree(ix->d_tf8_slot);
     if (ix->d_scratch) hipFree(ix->d_scratch);
+    if (ix->d_rows_scratch) hipFree(ix->d_rows_scratch);
     if (ix->ev0) hipEventDestroy(ix->ev0);
     if (ix->ev1) hipEventDestroy(ix->ev1);
     if (ix->xstream) hipStreamDestroy(ix->xstream);
@@ -480,6 +481,58 @@ extern "C" int sa_index_docfreqs(sa_index_t* ix, uint64_t* out) {
     return SA_OK;
 }
 
+// ---- subset output: the rerank / sliced-array use case (reference arr[mask].score(...), postings.py:
+// 619-627, 702-703) wants a few rows of a dense vector; gathering them on the device keeps the PCIe
+// copy proportional to the slice instead of to the index.
+struct RowSelection { const sa_index* ix = nullptr; const uint64_t* rows = nullptr; uint64_t n = 0; };
+static thread_local RowSelection tl_rows;
+
+extern "C" int sa_index_select_rows(sa_index_t* ix, const uint64_t* rows, uint64_t n_rows) {
+    SA_ARG(ix, "null index");
+    SA_ARG(n_rows == 0 || rows, "rows is null");
+    tl_rows.ix = rows ? ix : nullptr;
+    tl_rows.rows = rows;
+    tl_rows.n = n_rows;
+    return SA_OK;
+}
+
+__global__ void __launch_bounds__(256)
+sa_k_gather_rows(const float* __restrict__ vec, const u64* __restrict__ rows, u64 n, u64 n_docs, float* __restrict__ out) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
+        out[i] = rows[i] < n_docs ? vec[rows[i]] : 0.f;
+}
+
+void sa_emit_zeros(sa_index* ix, float* out) {
+    u64 n = ix->n_docs;
+    if (tl_rows.ix == ix) { n = tl_rows.n; tl_rows = RowSelection(); }
+    if (n) memset(out, 0, n * sizeof(float));
+}
+
+int sa_emit_dense(sa_index* ix, const float* d_vec, float* out) {
+    hipStream_t st = ix->stream;
+    if (tl_rows.ix != ix) {
+        SA_HIP(hipMemcpyAsync(out, d_vec, ix->n_docs * sizeof(float), hipMemcpyDeviceToHost, st));
+        return SA_OK;
+    }
+    const RowSelection sel = tl_rows;
+    tl_rows = RowSelection();                        // consumed by this call
+    if (sel.n == 0) return SA_OK;
+    const size_t need = sel.n * (sizeof(u64) + sizeof(float)) + 256;
+    if (ix->rows_scratch_bytes < need) {
+        if (ix->d_rows_scratch) SA_HIP(hipFree(ix->d_rows_scratch));
+        ix->d_rows_scratch = nullptr; ix->rows_scratch_bytes = 0;
+        SA_HIP(hipMalloc(&ix->d_rows_scratch, need));
+        ix->rows_scratch_bytes = need;
+    }
+    u64* d_rows = (u64*)ix->d_rows_scratch;
+    float* d_sel = (float*)(d_rows + sel.n);
+    SA_HIP(hipMemcpyAsync(d_rows, sel.rows, sel.n * sizeof(u64), hipMemcpyHostToDevice, st));
+    const u32 grid = sel.n / 256 + 1 < 4096 ? (u32)(sel.n / 256 + 1) : 4096u;
+    hipLaunchKernelGGL(sa_k_gather_rows, dim3(grid), dim3(256), 0, st, d_vec, (const u64*)d_rows, sel.n, ix->n_docs, d_sel);
+    SA_HIP(hipMemcpyAsync(out, d_sel, sel.n * sizeof(float), hipMemcpyDeviceToHost, st));
+    return SA_OK;
+}
+
 extern "C" int sa_index_termfreqs_dense(sa_index_t* ix, uint32_t term, float* out) {
     SA_ARG(ix && out, "null argument");
     std::lock_guard<std::mutex> g(ix->mu);
@@ -495,7 +548,7 @@ extern "C" int sa_index_termfreqs_dense(sa_index_t* ix, uint32_t term, float* ou
             hipLaunchKernelGGL(sa_k_scatter_tf, dim3(grid), dim3(256), 0, ix->stream, ix->d_tfp, lo, hi, d_out);
         }
     }
-    SA_HIP(hipMemcpyAsync(out, d_out, ix->n_docs * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    SA_TRY(sa_emit_dense(ix, d_out, out));
     SA_HIP(hipStreamSynchronize(ix->stream));
     SA_HIP(hipGetLastError());
     return SA_OK;

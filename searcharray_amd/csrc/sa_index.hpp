@@ -71,6 +71,10 @@ struct sa_index {
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
 
+    // row selection scratch (sa_index_select_rows): device copy of the selected doc ids + gathered values
+    void* d_rows_scratch = nullptr;
+    size_t rows_scratch_bytes = 0;
+
     sa_comm* comm = nullptr;
     hipStream_t xstream = nullptr;   // exchange stream: all-gather + cross-rank merge overlap the next batch's scoring
 
@@ -85,6 +89,12 @@ struct sa_index {
 };
 
 int sa_index_scratch(sa_index* ix, size_t bytes, void** out);
+// Copy a dense float[n_docs] device vector to the host `out` -- or, if this thread selected rows for
+// this index (sa_index_select_rows), only those rows: out[i] = d_vec[rows[i]].  Enqueued on the index
+// stream; the caller synchronises.  Call with the index lock held.
+int sa_emit_dense(sa_index* ix, const float* d_vec, float* out);
+// the same for an all-zero result (no device work)
+void sa_emit_zeros(sa_index* ix, float* out);
 // index construction pieces shared by sa_index_create (sa_index.hip) and sa_index_create_from_tokens (sa_build.hip)
 int sa_index_setup(sa_index* ix, const float* doc_lens);
 int sa_index_derive(sa_index* ix);

@@ -522,7 +522,7 @@ extern "C" int sa_index_phrase_freqs_dense_posn(sa_index_t* ix, const uint32_t* 
     SA_TRY(sa_profile_begin(ix));
     SA_TRY(sa_phrase_or_span(ix, terms, n_terms, slop, filt, &d_running));
     SA_TRY(sa_profile_end(ix, sa_phrase_alg_bytes(ix, terms, n_terms)));
-    SA_HIP(hipMemcpyAsync(out, d_running, ix->n_docs * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    SA_TRY(sa_emit_dense(ix, d_running, out));
     SA_HIP(hipStreamSynchronize(ix->stream));
     SA_HIP(hipGetLastError());
     return SA_OK;
@@ -547,14 +547,14 @@ extern "C" int sa_index_bm25_phrase_dense_posn(sa_index_t* ix, const uint32_t* t
     SA_HIP(hipSetDevice(ix->device));
     const u64 N = ix->n_docs;
     if (ix->avg_doc_len == 0.f) {                      // similarity.py:31-32
-        memset(out, 0, N * sizeof(float));
+        sa_emit_zeros(ix, out);
         return SA_OK;
     }
     float* d_running = nullptr;
     SA_TRY(sa_phrase_or_span(ix, terms, n_terms, slop, filt, &d_running));
     if (N) hipLaunchKernelGGL(sa_k_bm25_from_tf, dim3(sa_grid_for(N)), dim3(256), 0, ix->stream, d_running,
                               ix->d_doc_lens, ix->avg_doc_len, idf, k1, b, N);
-    SA_HIP(hipMemcpyAsync(out, d_running, N * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    SA_TRY(sa_emit_dense(ix, d_running, out));
     SA_HIP(hipStreamSynchronize(ix->stream));
     SA_HIP(hipGetLastError());
     return SA_OK;
@@ -610,7 +610,7 @@ extern "C" int sa_index_termfreqs_dense_posn(sa_index_t* ix, uint32_t term, int6
         TfHeads th; th.words = buf; th.n_dev = cnt; th.out = d_out;
         sa_compact(th, cnt, len, chunks, cnt + 1, st);
     }
-    SA_HIP(hipMemcpyAsync(out, d_out, N * sizeof(float), hipMemcpyDeviceToHost, st));
+    SA_TRY(sa_emit_dense(ix, d_out, out));
     SA_HIP(hipStreamSynchronize(st));
     SA_HIP(hipGetLastError());
     return SA_OK;

@@ -180,6 +180,24 @@ class DeviceIndex:
         df = self._global_df if self._global_df is not None else self.docfreqs()
         return df[term] if 0 <= term < self.n_terms else np.uint64(0)
 
+    # -- dense results, whole or a row subset
+    def _dense(self, fn: str, rows: Optional[np.ndarray], *args) -> np.ndarray:
+        """Run a dense C-ABI call (its last argument is the float32 output).  rows given: only those doc
+        ids come back (gathered on the device: the copy is proportional to the subset)."""
+        if rows is None:
+            out = _pool(self.api).empty_f32(self.n_docs)
+            self.api.call(fn, self._h, *args, p_f32(out))
+            return out
+        rows = as_u64(rows)
+        out = np.empty(len(rows), dtype=np.float32)
+        self.api.call("sa_index_select_rows", self._h, p_u64(rows), len(rows))
+        try:
+            self.api.call(fn, self._h, *args, p_f32(out))
+        except Exception:
+            self.api.call("sa_index_select_rows", self._h, None, 0)      # an argument error leaves it pending
+            raise
+        return out
+
     # -- term frequencies
     @staticmethod
     def _check_posn_range(min_posn, max_posn):
@@ -190,12 +208,11 @@ class DeviceIndex:
             raise ValueError("max_payload must be a multiple of 18 - 1")
         return (-1 if min_posn is None else int(min_posn)), (-1 if max_posn is None else int(max_posn))
 
-    def termfreqs_dense(self, term: int, min_posn: Optional[int] = None, max_posn: Optional[int] = None) -> np.ndarray:
+    def termfreqs_dense(self, term: int, min_posn: Optional[int] = None, max_posn: Optional[int] = None,
+                        rows: Optional[np.ndarray] = None) -> np.ndarray:
         lo, hi = self._check_posn_range(min_posn, max_posn)
-        out = _pool(self.api).empty_f32(self.n_docs)
         t = term if 0 <= term < self.n_terms else NO_TERM
-        self.api.call("sa_index_termfreqs_dense_posn", self._h, t, lo, hi, p_f32(out))
-        return out
+        return self._dense("sa_index_termfreqs_dense_posn", rows, t, lo, hi)
 
     def termfreqs_sparse(self, term: int) -> Tuple[np.ndarray, np.ndarray]:
         if not (0 <= term < self.n_terms):
@@ -214,31 +231,26 @@ class DeviceIndex:
                           dtype=np.float32)
 
     def bm25_dense(self, terms: Sequence[int], k1: float = 1.2, b: float = 0.75,
-                   idf: Optional[np.ndarray] = None) -> np.ndarray:
+                   idf: Optional[np.ndarray] = None, rows: Optional[np.ndarray] = None) -> np.ndarray:
         """sum_t BM25(t) in query-term order, float32[n_docs] (one kernel launch)."""
         tarr = np.asarray([int(t) if 0 <= int(t) < self.n_terms else NO_TERM for t in terms],
                           dtype=np.uint32)
         idf = self.idfs(terms) if idf is None else as_f32(idf)
-        out = _pool(self.api).empty_f32(self.n_docs)
-        self.api.call("sa_index_bm25_dense", self._h, p_u32(tarr), p_f32(idf), len(tarr),
-                      np.float32(k1), np.float32(b), p_f32(out))
-        return out
+        return self._dense("sa_index_bm25_dense", rows, p_u32(tarr), p_f32(idf), len(tarr), np.float32(k1), np.float32(b))
 
     def phrase_freqs_dense(self, terms: Sequence[int], slop: int = 0, min_posn: Optional[int] = None,
-                           max_posn: Optional[int] = None) -> np.ndarray:
+                           max_posn: Optional[int] = None, rows: Optional[np.ndarray] = None) -> np.ndarray:
         """Phrase match counts, float32[n_docs] (reference PosnBitArray.phrase_freqs): exact for
         slop == 0, the reference's span search for slop > 0."""
         if len(terms) < 2:
             raise ValueError("Must have at least two terms")        # reference middle_out.py:425-426
         lo, hi = self._check_posn_range(min_posn, max_posn)
         tarr = np.asarray([int(t) if 0 <= int(t) < self.n_terms else NO_TERM for t in terms], dtype=np.uint32)
-        out = _pool(self.api).empty_f32(self.n_docs)
-        self.api.call("sa_index_phrase_freqs_dense_posn", self._h, p_u32(tarr), len(tarr), int(slop), lo, hi, p_f32(out))
-        return out
+        return self._dense("sa_index_phrase_freqs_dense_posn", rows, p_u32(tarr), len(tarr), int(slop), lo, hi)
 
     def bm25_phrase_dense(self, terms: Sequence[int], k1: float = 1.2, b: float = 0.75, slop: int = 0,
                           idf: Optional[float] = None, min_posn: Optional[int] = None,
-                          max_posn: Optional[int] = None) -> np.ndarray:
+                          max_posn: Optional[int] = None, rows: Optional[np.ndarray] = None) -> np.ndarray:
         """BM25 of a phrase: idf summed over the phrase's terms (reference postings.py:671-679)."""
         if len(terms) < 2:
             raise ValueError("Must have at least two terms")
@@ -247,10 +259,8 @@ class DeviceIndex:
             dfs = np.asarray([self.docfreq(int(t)) if 0 <= int(t) < self.n_terms else 0 for t in terms])
             idf = compute_idf(self.corpus_size, dfs)
         lo, hi = self._check_posn_range(min_posn, max_posn)
-        out = _pool(self.api).empty_f32(self.n_docs)
-        self.api.call("sa_index_bm25_phrase_dense_posn", self._h, p_u32(tarr), len(tarr), int(slop), lo, hi,
-                      np.float32(idf), np.float32(k1), np.float32(b), p_f32(out))
-        return out
+        return self._dense("sa_index_bm25_phrase_dense_posn", rows, p_u32(tarr), len(tarr), int(slop), lo, hi,
+                           np.float32(idf), np.float32(k1), np.float32(b))
 
     def last_profile(self) -> Tuple[float, int]:
         """(kernel ms, algorithmic bytes) of the last phrase call."""

@@ -300,8 +300,6 @@ class SearchArray(ExtensionArray):
     def _row_ids(self) -> np.ndarray:
         return np.arange(self._core.corpus_size, dtype=np.int64) if self._rows is None else self._rows
 
-    def _gather(self, dense: np.ndarray) -> np.ndarray:
-        return dense if self._rows is None else dense[self._rows]
 
     # ---- ExtensionArray protocol -----------------------------------------------------------
     @classmethod
@@ -494,13 +492,14 @@ class SearchArray(ExtensionArray):
         if len(self._core.doc_lens) == 0:
             return np.zeros(len(self), dtype=np.float32)
         dev = self._core.device()
+        # a slice asks the device for its rows only (gathered in HBM: the copy is len(self) floats)
         if isinstance(token, list):
             ids = [self._term_id(t) for t in token]
-            return self._gather(dev.phrase_freqs_dense(ids, slop=slop, min_posn=min_posn, max_posn=max_posn))
+            return dev.phrase_freqs_dense(ids, slop=slop, min_posn=min_posn, max_posn=max_posn, rows=self._rows)
         tid = self._term_id(token)
         if tid < 0:
             return np.zeros(len(self), dtype=np.float32)            # unknown term: zeros, never raises
-        return self._gather(dev.termfreqs_dense(tid, min_posn=min_posn, max_posn=max_posn))
+        return dev.termfreqs_dense(tid, min_posn=min_posn, max_posn=max_posn, rows=self._rows)
 
     def docfreq(self, token: str) -> int:
         """reference postings.py:640-647."""
@@ -514,8 +513,8 @@ class SearchArray(ExtensionArray):
         # A sliced array counts the docs of the SLICE that contain the term (the reference's slices
         # carry FilteredPosns, middle_out.py:291-317, so docfreq -- and with it the idf of every score
         # on a slice -- is subset-local while corpus_size and avg_doc_length stay global).
-        tf = self._core.device().termfreqs_dense(tid)
-        return np.uint64(np.count_nonzero(tf[np.unique(self._rows)]))
+        tf = self._core.device().termfreqs_dense(tid, rows=np.unique(self._rows))
+        return np.uint64(np.count_nonzero(tf))
 
     def doclengths(self) -> np.ndarray:
         return self.doc_lens
@@ -539,11 +538,10 @@ class SearchArray(ExtensionArray):
             idf = np.float32(compute_idf(self.corpus_size, dfs))
             ids = [self._term_id(t) for t in tokens]
             if len(ids) == 1:
-                dense = dev.bm25_dense(ids, k1=similarity.k1, b=similarity.b, idf=np.asarray([idf], np.float32))
-            else:
-                dense = dev.bm25_phrase_dense(ids, k1=similarity.k1, b=similarity.b, slop=slop, idf=idf,
-                                              min_posn=min_posn, max_posn=max_posn)
-            return self._gather(dense)
+                return dev.bm25_dense(ids, k1=similarity.k1, b=similarity.b, idf=np.asarray([idf], np.float32),
+                                      rows=self._rows)
+            return dev.bm25_phrase_dense(ids, k1=similarity.k1, b=similarity.b, slop=slop, idf=idf,
+                                         min_posn=min_posn, max_posn=max_posn, rows=self._rows)
         # any other Similarity (or a position-restricted single term): tf on the device, then the
         # similarity callable (the stock BM25 closure applies the BM25 kernel through the C ABI)
         tfs = self.termfreqs(token, slop=slop, min_posn=min_posn, max_posn=max_posn)

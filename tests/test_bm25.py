@@ -344,3 +344,25 @@ def test_dynamic_pruning_is_exact(api, monkeypatch, sparse, tf8_div, k):
     else:
         assert cands == 0
     bt.close()
+
+
+def test_dense_calls_with_a_row_selection(api):
+    """sa_index_select_rows: the next dense call returns only the selected rows (gathered on the device);
+    a failed call must not leave the selection pending"""
+    g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_small")
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    rows = np.asarray([5, 0, 1499, 700, 5, 3], dtype=np.uint64)
+    full_tf, full_bm = dev.termfreqs_dense(3), dev.bm25_dense([3, 7, 1])
+    assert np.array_equal(dev.termfreqs_dense(3, rows=rows), full_tf[rows.astype(np.int64)])
+    assert np.array_equal(dev.bm25_dense([3, 7, 1], rows=rows), full_bm[rows.astype(np.int64)])
+    assert np.array_equal(dev.phrase_freqs_dense([3, 7], rows=rows), dev.phrase_freqs_dense([3, 7])[rows.astype(np.int64)])
+    assert np.array_equal(dev.phrase_freqs_dense([3, 7], slop=2, rows=rows), dev.phrase_freqs_dense([3, 7], slop=2)[rows.astype(np.int64)])
+    assert np.array_equal(dev.bm25_phrase_dense([3, 7], rows=rows), dev.bm25_phrase_dense([3, 7])[rows.astype(np.int64)])
+    assert np.array_equal(dev.termfreqs_dense(3, min_posn=0, max_posn=17, rows=rows),
+                          dev.termfreqs_dense(3, min_posn=0, max_posn=17)[rows.astype(np.int64)])
+    assert dev.termfreqs_dense(3, rows=np.empty(0, np.uint64)).size == 0
+    assert dev.bm25_dense([3], rows=np.asarray([num_docs + 5], np.uint64))[0] == 0          # beyond the index: 0
+    with pytest.raises(Exception):
+        dev.phrase_freqs_dense(list(range(40)), rows=rows)                                  # too long a phrase
+    assert np.array_equal(dev.termfreqs_dense(3), full_tf)                                  # selection was cleared
