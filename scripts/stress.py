@@ -38,4 +38,23 @@ for it in range(args.batches):
             bad = np.flatnonzero((got[name][1] != ref[1]).any(axis=1))
             print("MISMATCH", it, name, dict(B=B, T=T, k=k), "queries", bad[:5].tolist(), flush=True)
     batch.close()
-print(f"stress done: {args.batches} batches, {fails} mismatches")
+# phrase batches against the single-phrase dense path (both phrase kernels) + host-side top-k
+pf = 0
+for it in range(max(2, args.batches // 8)):
+    n, L, k = int(rng.integers(1, 100)), int(rng.integers(2, 5)), int(rng.choice([1, 10, 50]))
+    phrases = [[int(x) for x in rng.choice(300, L, replace=False)] for _ in range(n)]
+    pb = index.phrase_batch(phrases, k=k)
+    pb.run()
+    s, d = pb.fetch()
+    pb.close()
+    for i in range(0, n, max(1, n // 6)):
+        for mode in ("fused", "general"):
+            os.environ["SA_PHRASE_MODE"] = mode
+            dense = index.bm25_phrase_dense(phrases[i])
+            order = np.lexsort((np.arange(len(dense)), -dense))[:k]
+            m = int((dense[order] > 0).sum())
+            if not (np.array_equal(d[i, :m], order[:m].astype(np.uint64)) and np.array_equal(s[i, :m], dense[order][:m])):
+                pf += 1
+                print("PHRASE MISMATCH", it, mode, phrases[i], flush=True)
+    os.environ.pop("SA_PHRASE_MODE", None)
+print(f"stress done: {args.batches} batches, {fails} mismatches; phrase mismatches {pf}")
