@@ -31,7 +31,8 @@ extern "C" {
 #define SA_ABI_VERSION 1
 
 typedef struct sa_index sa_index_t;        /* opaque HBM-resident index (one doc-range shard) */
-typedef struct sa_batch sa_batch_t;        /* opaque device-resident query batch              */
+typedef struct sa_batch sa_batch_t;
+typedef struct sa_vec sa_vec_t;        /* opaque device-resident query batch              */
 
 const char* sa_last_error(void);
 int sa_abi_version(void);
@@ -268,6 +269,40 @@ int sa_host_free(void* p);
 int sa_comm_unique_id(char* id_out, int len);                    /* rank 0: ncclGetUniqueId */
 int sa_index_comm_init(sa_index_t* ix, int rank, int nranks, const char* id_bytes, int len);
 int sa_index_comm_destroy(sa_index_t* ix);
+
+/* ------------------------------------------------------------------------------------- */
+/* Part 4 -- dense vectors on the device: the combine step of Solr-style multi-field queries */
+/* ------------------------------------------------------------------------------------- */
+/* reference searcharray/solr.py:112-355 combines the per-field, per-term score() vectors with numpy on
+ * the host.  Here the vectors stay in HBM: a score is computed straight into a float32 vector
+ * (sa_index_select_vec + any dense call of Part 2) and combined by the calls below, which reproduce
+ * numpy's arithmetic (float64 accumulators fed by float32 scores on the term-centric path, float32 on
+ * the field-centric path, one rounding per operation).  All calls are synchronous.
+ * Vector kinds: f64 (is_f64 != 0) or 32-bit (float32 values, or uint32 counters). */
+int sa_vec_create(int device, uint64_t n, int is_f64, sa_vec_t** out);        /* zero-initialised */
+int sa_vec_destroy(sa_vec_t* v);
+int sa_vec_zero(sa_vec_t* v);
+int sa_vec_copy(sa_vec_t* dst, const sa_vec_t* src);                          /* same kind and length */
+int sa_vec_fetch(sa_vec_t* v, void* host_out);                               /* n * 8 or n * 4 bytes */
+/* the next dense call on `ix` from this thread writes (result * boost if has_boost) into out32 on the
+ * device instead of to its host `out`; out32 == NULL clears a pending selection */
+int sa_index_select_vec(sa_index_t* ix, sa_vec_t* out32, float boost, int has_boost);
+/* term-centric (solr.py:124-143): sum += s; max = maximum(max, s)  |  clause = max + (sum - max) * tie;
+ * total += clause; cnt += clause > 0  |  total[cnt < need] = 0 */
+int sa_vec_dismax_acc(sa_vec_t* sum64, sa_vec_t* max64, const sa_vec_t* s32);
+int sa_vec_clause(const sa_vec_t* sum64, const sa_vec_t* max64, double tie, sa_vec_t* total64, sa_vec_t* cnt32);
+int sa_vec_mask_min_count(sa_vec_t* v64, const sa_vec_t* cnt32, uint32_t need);
+/* field-centric (solr.py:156-176): sum += s; cnt += s > 0  |  row = (cnt >= need ? sum : 0) * boost;
+ * fsum (+)= row; fmax = max(fmax, row)  |  out = fmax + (fsum - fmax) * tie */
+int sa_vec_sum_count32(sa_vec_t* sum32, sa_vec_t* cnt32, const sa_vec_t* s32);
+int sa_vec_field_row(const sa_vec_t* sum32, const sa_vec_t* cnt32, uint32_t need, float boost, int has_boost, int first,
+                     sa_vec_t* fsum32, sa_vec_t* fmax32);
+int sa_vec_field_finish(const sa_vec_t* fsum32, const sa_vec_t* fmax32, float tie, sa_vec_t* out32);
+/* phrase boosts (solr.py:320-353): dst32 (+)= src32  |  dst[i] += extra32[i] where mask[i] != 0  |
+ * docs with tf32 > 0 and mask > 0 (the subset-local docfreq of the matched docs) */
+int sa_vec_add32(sa_vec_t* dst32, const sa_vec_t* src32, int first);
+int sa_vec_add_where(sa_vec_t* dst, const sa_vec_t* extra32, const sa_vec_t* mask);
+int sa_vec_count_where(const sa_vec_t* tf32, const sa_vec_t* mask, uint64_t* out);
 
 #ifdef __cplusplus
 }

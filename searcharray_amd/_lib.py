@@ -90,6 +90,22 @@ PROTOTYPES = {
     "sa_index_select_rows": (c_int, [c_void_p, u64p, c_uint64]),
     "sa_host_alloc": (c_int, [c_uint64, POINTER(c_void_p)]),
     "sa_host_free": (c_int, [c_void_p]),
+    # Part 4
+    "sa_vec_create": (c_int, [c_int, c_uint64, c_int, POINTER(c_void_p)]),
+    "sa_vec_destroy": (c_int, [c_void_p]),
+    "sa_vec_zero": (c_int, [c_void_p]),
+    "sa_vec_copy": (c_int, [c_void_p, c_void_p]),
+    "sa_vec_fetch": (c_int, [c_void_p, c_void_p]),
+    "sa_index_select_vec": (c_int, [c_void_p, c_void_p, c_float, c_int]),
+    "sa_vec_dismax_acc": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "sa_vec_clause": (c_int, [c_void_p, c_void_p, c_double, c_void_p, c_void_p]),
+    "sa_vec_mask_min_count": (c_int, [c_void_p, c_void_p, c_uint32]),
+    "sa_vec_sum_count32": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "sa_vec_field_row": (c_int, [c_void_p, c_void_p, c_uint32, c_float, c_int, c_int, c_void_p, c_void_p]),
+    "sa_vec_field_finish": (c_int, [c_void_p, c_void_p, c_float, c_void_p]),
+    "sa_vec_add32": (c_int, [c_void_p, c_void_p, c_int]),
+    "sa_vec_add_where": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "sa_vec_count_where": (c_int, [c_void_p, c_void_p, u64p]),
     # Part 3
     "sa_comm_unique_id": (c_int, [ctypes.c_char_p, c_int]),
     "sa_index_comm_init": (c_int, [c_void_p, c_int, c_int, ctypes.c_char_p, c_int]),

@@ -503,6 +503,7 @@ sa_k_gather_rows(const float* __restrict__ vec, const u64* __restrict__ rows, u6
 }
 
 void sa_emit_zeros(sa_index* ix, float* out) {
+    if (sa_emit_to_vec(ix, nullptr)) { hipStreamSynchronize(ix->stream); return; }
     u64 n = ix->n_docs;
     if (tl_rows.ix == ix) { n = tl_rows.n; tl_rows = RowSelection(); }
     if (n) memset(out, 0, n * sizeof(float));
@@ -510,6 +511,7 @@ void sa_emit_zeros(sa_index* ix, float* out) {
 
 int sa_emit_dense(sa_index* ix, const float* d_vec, float* out) {
     hipStream_t st = ix->stream;
+    if (sa_emit_to_vec(ix, d_vec)) return SA_OK;
     if (tl_rows.ix != ix) {
         SA_HIP(hipMemcpyAsync(out, d_vec, ix->n_docs * sizeof(float), hipMemcpyDeviceToHost, st));
         return SA_OK;

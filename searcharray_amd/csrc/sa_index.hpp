@@ -95,6 +95,8 @@ int sa_index_scratch(sa_index* ix, size_t bytes, void** out);
 int sa_emit_dense(sa_index* ix, const float* d_vec, float* out);
 // the same for an all-zero result (no device work)
 void sa_emit_zeros(sa_index* ix, float* out);
+// sa_vec.hip: divert the result into a device vector if this thread asked for it (sa_index_select_vec)
+bool sa_emit_to_vec(sa_index* ix, const float* d_vec);
 // index construction pieces shared by sa_index_create (sa_index.hip) and sa_index_create_from_tokens (sa_build.hip)
 int sa_index_setup(sa_index* ix, const float* doc_lens);
 int sa_index_derive(sa_index* ix);

@@ -198,6 +198,18 @@ class DeviceIndex:
             raise
         return out
 
+    def into_vec(self, vec: "DeviceVec", boost: Optional[float], fn: str, *args) -> None:
+        """Run a dense C-ABI call with its result diverted into ``vec`` (float32[n_docs] on the device),
+        multiplied by ``boost`` if given."""
+        dummy = np.zeros(1, dtype=np.float32)
+        self.api.call("sa_index_select_vec", self._h, vec._h, np.float32(1.0 if boost is None else boost),
+                      0 if boost is None else 1)
+        try:
+            self.api.call(fn, self._h, *args, p_f32(dummy))
+        except Exception:
+            self.api.call("sa_index_select_vec", self._h, None, np.float32(1.0), 0)
+            raise
+
     # -- term frequencies
     @staticmethod
     def _check_posn_range(min_posn, max_posn):
@@ -383,3 +395,36 @@ class PhraseBatch(QueryBatch):
         self.api.call("sa_phrase_batch_create", index._h, p_u32(as_u32(terms)),
                       n_terms.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), p_f32(as_f32(idf)), self.B, self.T,
                       self.k, np.float32(k1), np.float32(b), ctypes.byref(self._h))
+
+
+class DeviceVec:
+    """A dense per-doc vector in HBM (float64, or 32-bit: float32 values / uint32 counters); Part 4 of
+    the C ABI.  Used by ``searcharray_amd.solr`` to combine multi-field scores without leaving the device."""
+
+    def __init__(self, api, n: int, f64: bool, device: int = 0):
+        self.api, self.n, self.f64 = api, int(n), bool(f64)
+        self._h = ctypes.c_void_p()
+        api.call("sa_vec_create", int(device), self.n, 1 if f64 else 0, ctypes.byref(self._h))
+
+    def zero(self):
+        self.api.call("sa_vec_zero", self._h)
+
+    def copy_from(self, other: "DeviceVec"):
+        self.api.call("sa_vec_copy", self._h, other._h)
+
+    def fetch(self, dtype=None) -> np.ndarray:
+        out = np.empty(self.n, dtype=dtype if dtype is not None else (np.float64 if self.f64 else np.float32))
+        self.api.call("sa_vec_fetch", self._h, out.ctypes.data_as(ctypes.c_void_p))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.api.sa_vec_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+

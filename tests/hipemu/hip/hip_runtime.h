@@ -300,6 +300,10 @@ inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
 inline float __fdiv_rn(float a, float b) { return a / b; }
 inline float __fmul_rn(float a, float b) { return a * b; }
 inline float __fadd_rn(float a, float b) { return a + b; }
+inline float __fsub_rn(float a, float b) { return a - b; }
+inline double __dadd_rn(double a, double b) { return a + b; }
+inline double __dsub_rn(double a, double b) { return a - b; }
+inline double __dmul_rn(double a, double b) { return a * b; }
 template <class T> inline T __ldg(const T* p) { return *p; }
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(ptr, order, scope) (*(ptr))

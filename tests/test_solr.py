@@ -138,9 +138,19 @@ def test_edismax_matches_reference_outputs():
                           "tags": SearchArray.index(list(g["field_tags"]), tokenizer=_lower_whole)})
     cases = json.loads(str(g["cases"]))
     assert len(cases) == int(g["n_cases"]) >= 10
+    from searcharray_amd.solr import _DeviceCombiner, _Field
+    from searcharray_amd.similarity import default_bm25
+    probe = [_Field(c, None, frame[c].array, [], default_bm25) for c in frame.columns]
+    assert _DeviceCombiner.usable(probe, len(frame))          # stock BM25 on whole arrays: the GPU combination applies
     for i, params in enumerate(cases):
-        scores, explain = edismax(frame, **params)
         want = g[f"scores_{i}"]
-        assert scores.dtype == want.dtype
-        assert np.allclose(scores, want, rtol=1e-6, atol=0), f"case {i}: {params}"
-        assert explain == str(g[f"explain_{i}"]), f"case {i}: {params}"
+        got = {}
+        for route in (True, False):                            # combination on the device / with numpy on the host
+            scores, explain = edismax(frame, use_device=route, **params)
+            assert scores.dtype == want.dtype, f"case {i} route {route}"
+            assert np.allclose(scores, want, rtol=1e-6, atol=0), f"case {i}: {params} route {route}"
+            assert explain == str(g[f"explain_{i}"]), f"case {i}: {params} route {route}"
+            got[route] = scores
+        assert np.array_equal(got[True], got[False]), f"case {i}: the two routes differ"
+        default, _ = edismax(frame, **params)
+        assert np.array_equal(default, got[True])
