@@ -8,7 +8,10 @@
  * buffers with the reference's worst-case sizes), so a maintainer can rebind them with
  * ctypes/cffi.  Part 2 is the HBM-resident index the Python classes
  * (SearchArray / PosnBitArray) sit on: the index is uploaded once and every query runs on
- * the device.  Part 3 is the doc-range-sharded multi-GPU top-k exchange over RCCL.
+ * the device (index build from a token stream, dense drop-in results, resident top-k batches
+ * of BM25 term disjunctions and of exact phrases).  Part 3 is the doc-range-sharded multi-GPU
+ * top-k exchange over RCCL.  Part 4 keeps dense per-doc vectors on the device for the
+ * combination step of multi-field (Solr edismax style) queries.
  *
  * Conventions
  *   - every function returns 0 on success, a negative SA_ERR_* code on failure; the message
@@ -31,8 +34,8 @@ extern "C" {
 #define SA_ABI_VERSION 1
 
 typedef struct sa_index sa_index_t;        /* opaque HBM-resident index (one doc-range shard) */
-typedef struct sa_batch sa_batch_t;
-typedef struct sa_vec sa_vec_t;        /* opaque device-resident query batch              */
+typedef struct sa_batch sa_batch_t;        /* opaque device-resident query batch              */
+typedef struct sa_vec sa_vec_t;            /* opaque dense per-doc vector in HBM (Part 4)     */
 
 const char* sa_last_error(void);
 int sa_abi_version(void);
