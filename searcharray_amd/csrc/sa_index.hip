@@ -87,23 +87,27 @@ __global__ void sa_k_mark_term_starts(const u64* __restrict__ term_off, u32 n_te
     }
 }
 
-// A word is a posting head when it opens a new (term, doc) group.
+// A word is a posting head when it opens a new (term, doc) group.  The compaction runs over one
+// SEGMENT of the index at a time -- a run of whole terms with fewer than 2^31 words -- so its 32-bit
+// element indices are segment-relative; i_base / p_base place the segment in the index.
 struct PostingHeads {
-    const u64* words;
-    const u32* term_start_bits;
+    const u64* words;          // first word of the segment
+    const u32* term_start_bits;// bit (i_base + i) set iff a term starts at word i_base + i
     const u64* term_off;
     u32 n_terms;
-    u32 n_words;
+    u32 n_words;               // words in the segment
+    u64 i_base;                // index of the segment's first word
+    u64 p_base;                // index of the segment's first posting
     const float* doc_lens;
-    u64* tfp;          // out: fat postings
+    u64* tfp;          // out: fat postings (whole index)
     u64* tf_off;       // out: tf_off[t] for non-empty terms (others fixed up on the host)
     u32* err;          // out: set to 1 when a word names a doc id >= n_docs
     u64 n_docs;
     int dl_packed;
 
-    __device__ __forceinline__ bool is_start(u32 i) const { return (term_start_bits[i >> 5] >> (i & 31)) & 1u; }
+    __device__ __forceinline__ bool is_start(u32 i) const { const u64 g = i_base + i; return (term_start_bits[g >> 5] >> (g & 31)) & 1u; }
     __device__ __forceinline__ bool flag(u32 i) const {
-        if (i == 0 || is_start(i)) return true;
+        if (i == 0 || is_start(i)) return true;          // a segment starts with a term
         return (words[i] >> SA_KEY_SHIFT) != (words[i - 1] >> SA_KEY_SHIFT);
     }
     __device__ __forceinline__ void emit(u32 i, u32 pos) const {
@@ -114,15 +118,16 @@ struct PostingHeads {
         u64 dl = 0;
         if (doc >= n_docs) { *err = 1u; }
         else if (dl_packed) dl = (u64)(u32)doc_lens[doc];
-        tfp[pos] = (doc << SA_KEY_SHIFT) | (dl << SA_LSB_BITS) | (u64)tf;
+        tfp[p_base + pos] = (doc << SA_KEY_SHIFT) | (dl << SA_LSB_BITS) | (u64)tf;
         if (is_start(i)) {
             // last term t with term_off[t] <= i (empty terms share the offset and sort before it)
-            u32 lo = 0, hi = n_terms;            // invariant: term_off[lo] <= i < term_off[hi]
+            const u64 g = i_base + i;
+            u32 lo = 0, hi = n_terms;            // invariant: term_off[lo] <= g < term_off[hi]
             while (hi - lo > 1) {
                 const u32 mid = lo + ((hi - lo) >> 1);
-                if (term_off[mid] <= (u64)i) lo = mid; else hi = mid;
+                if (term_off[mid] <= g) lo = mid; else hi = mid;
             }
-            tf_off[lo] = pos;
+            tf_off[lo] = p_base + pos;
         }
     }
 };
@@ -252,11 +257,39 @@ int sa_index_derive(sa_index* ix) {
     SA_HIP(hipMalloc(&ix->d_dir_slot, ((size_t)V + 1) * sizeof(u32)));
 
     // ---- derive postings ----
-    const u32 nchunks = sa_compact_chunks((u32)W);
+    // Segments: runs of whole terms with < 2^31 words each (a posting group never straddles a term
+    // boundary), so the 32-bit stream compaction can serve shards far beyond 2^32 words.
+    struct Seg { u64 w0, w1, p0; u32 cnt; };
+    std::vector<Seg> segs;
+    {
+        u64 SEG_MAX = 1ull << 31;
+        if (const char* sv = getenv("SA_SEG_WORDS")) {           // test hook: force small segments
+            const u64 v = strtoull(sv, nullptr, 10);
+            if (v > 0 && v < SEG_MAX) SEG_MAX = v;
+        }
+        u32 t = 0;
+        while (t < V) {
+            const u64 w0 = ix->h_term_off[t];
+            u32 e = t;
+            while (e < V && ix->h_term_off[e + 1] - w0 <= SEG_MAX) e++;
+            if (e == t) {                                        // one term alone exceeds the segment size
+                if (ix->h_term_off[t + 1] - w0 > (1ull << 31)) {
+                    sa_set_error("term %u has more than 2^31 roaringish words", t);
+                    return SA_ERR_UNSUPPORTED;
+                }
+                e = t + 1;
+            }
+            if (ix->h_term_off[e] > w0) segs.push_back({w0, ix->h_term_off[e], 0, 0});
+            t = e;
+        }
+    }
+    u64 max_seg = 0;
+    for (const Seg& sg : segs) max_seg = sg.w1 - sg.w0 > max_seg ? sg.w1 - sg.w0 : max_seg;
+    const u32 max_chunks = sa_compact_chunks((u32)max_seg);
     const size_t bits_words = (size_t)(W / 32 + 2);
     u32 *d_bits = nullptr, *d_chunks = nullptr, *d_total = nullptr;
     SA_HIP(hipMalloc(&d_bits, bits_words * sizeof(u32)));
-    SA_HIP(hipMalloc(&d_chunks, ((size_t)nchunks + 1) * sizeof(u32)));
+    SA_HIP(hipMalloc(&d_chunks, ((size_t)max_chunks * (segs.size() ? segs.size() : 1) + 1) * sizeof(u32)));
     SA_HIP(hipMalloc(&d_total, 2 * sizeof(u32)));
     SA_HIP(hipMemsetAsync(d_total, 0, 2 * sizeof(u32), st));
     SA_HIP(hipMemsetAsync(d_bits, 0, bits_words * sizeof(u32), st));
@@ -264,26 +297,36 @@ int sa_index_derive(sa_index* ix) {
     if (V) hipLaunchKernelGGL(sa_k_mark_term_starts, dim3(sa_div_up(V, 256) < 1024 ? sa_div_up(V, 256) : 1024),
                               dim3(256), 0, st, ix->d_term_off, V, d_bits);
 
-    // worst case one posting per word; allocate exactly after counting
     PostingHeads ph;
-    ph.words = ix->d_words; ph.term_start_bits = d_bits; ph.term_off = ix->d_term_off;
-    ph.n_terms = V; ph.n_words = (u32)W; ph.doc_lens = ix->d_doc_lens;
+    ph.term_start_bits = d_bits; ph.term_off = ix->d_term_off;
+    ph.n_terms = V; ph.doc_lens = ix->d_doc_lens;
     ph.tfp = nullptr; ph.tf_off = ix->d_tf_off; ph.dl_packed = ix->dl_packed ? 1 : 0;
     ph.err = d_total + 1; ph.n_docs = ix->n_docs;
-    u32 P = 0;
-    if (W) {
-        const u32 grid = sa_compact_grid((u32)W);
-        hipLaunchKernelGGL((sa_k_compact_count<PostingHeads>), dim3(grid), dim3(SA_CT), 0, st, ph,
-                           (const u32*)nullptr, (u32)W, d_chunks);
-        hipLaunchKernelGGL(sa_k_scan_chunks, dim3(1), dim3(1024), 0, st, d_chunks, nchunks, d_total);
-        SA_HIP(hipMemcpyAsync(&P, d_total, sizeof(u32), hipMemcpyDeviceToHost, st));
+    // pass 1: count the postings of every segment (chunk counts are kept for the emit pass)
+    u64 P = 0;
+    for (size_t k = 0; k < segs.size(); k++) {
+        Seg& sg = segs[k];
+        const u32 n = (u32)(sg.w1 - sg.w0);
+        u32* chunks = d_chunks + k * max_chunks;
+        ph.words = ix->d_words + sg.w0; ph.n_words = n; ph.i_base = sg.w0; ph.p_base = 0;
+        hipLaunchKernelGGL((sa_k_compact_count<PostingHeads>), dim3(sa_compact_grid(n)), dim3(SA_CT), 0, st, ph,
+                           (const u32*)nullptr, n, chunks);
+        hipLaunchKernelGGL(sa_k_scan_chunks, dim3(1), dim3(1024), 0, st, chunks, sa_compact_chunks(n), d_total);
+        SA_HIP(hipMemcpyAsync(&sg.cnt, d_total, sizeof(u32), hipMemcpyDeviceToHost, st));
         SA_HIP(hipStreamSynchronize(st));
-        SA_HIP(hipMalloc(&ix->d_tfp, ((size_t)P + 1) * sizeof(u64)));
-        ph.tfp = ix->d_tfp;
-        hipLaunchKernelGGL((sa_k_compact_emit<PostingHeads>), dim3(grid), dim3(SA_CT), 0, st, ph,
-                           (const u32*)nullptr, (u32)W, d_chunks);
-    } else {
-        SA_HIP(hipMalloc(&ix->d_tfp, sizeof(u64)));
+        sg.p0 = P;
+        P += sg.cnt;
+    }
+    // worst case one posting per word; allocated exactly after counting
+    SA_HIP(hipMalloc(&ix->d_tfp, ((size_t)P + 1) * sizeof(u64)));
+    ph.tfp = ix->d_tfp;
+    // pass 2: emit
+    for (size_t k = 0; k < segs.size(); k++) {
+        const Seg& sg = segs[k];
+        const u32 n = (u32)(sg.w1 - sg.w0);
+        ph.words = ix->d_words + sg.w0; ph.n_words = n; ph.i_base = sg.w0; ph.p_base = sg.p0;
+        hipLaunchKernelGGL((sa_k_compact_emit<PostingHeads>), dim3(sa_compact_grid(n)), dim3(SA_CT), 0, st, ph,
+                           (const u32*)nullptr, n, (const u32*)(d_chunks + k * max_chunks));
     }
     ix->n_postings = P;
 
@@ -437,7 +480,6 @@ extern "C" int sa_index_create(int device, uint64_t n_docs, uint64_t doc_base, u
     const u64 W = term_off[n_terms];
     SA_ARG(term_off[0] == 0, "term_off[0] must be 0");
     SA_ARG(W == 0 || words, "words is null");
-    SA_ARG(W < 0xFFFFF000ull, "more than 2^32 words per shard is not supported yet");
     for (u32 t = 0; t < n_terms; t++) SA_ARG(term_off[t] <= term_off[t + 1], "term_off must be non-decreasing");
 
     sa_index* ix = new (std::nothrow) sa_index();

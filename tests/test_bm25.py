@@ -116,6 +116,30 @@ def test_topk_massive_ties_takes_fallback_path(api, n, cap, monkeypatch):
         bt.close()
 
 
+@pytest.mark.parametrize("seg_words", ["1", "37", "700"])
+def test_segmented_posting_derivation(api, seg_words, monkeypatch):
+    """Shards beyond 2^32 words derive their TF postings in segments of whole terms (< 2^31 words
+    each); SA_SEG_WORDS forces tiny segments so the same code runs here -- down to one term per
+    segment -- and must give the postings of the one-segment build."""
+    g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_sparse")
+    words, wt = rz.encode_sorted(t, d, p)
+    off = rz.term_offsets(wt, vocab)
+    monkeypatch.setenv("SA_SEG_WORDS", seg_words)
+    dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api)
+    assert np.array_equal(dev.docfreqs(), g["df"])
+    assert dev.info().n_postings == int(np.sum(g["df"]))
+    for row, want in zip(g["or_queries"][:6], g["or_scores"][:6]):
+        assert np.array_equal(dev.bm25_dense([int(x) for x in row]), want)
+    bt = dev.batch(np.asarray(g["or_queries"][:6]), k=10)
+    bt.run()
+    scores, docs = bt.fetch()
+    for i, want in enumerate(g["or_scores"][:6]):
+        order = np.lexsort((np.arange(num_docs), -want))[:10]
+        keep = want[order] > 0
+        assert np.array_equal(docs[i][keep], order[keep].astype(np.uint64))
+    bt.close()
+
+
 @pytest.mark.parametrize("tile_docs", [1024, 2048])
 def test_sparse_corpus_and_doc_base(api, tile_docs):
     g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_sparse")
