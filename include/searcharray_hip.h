@@ -129,6 +129,23 @@ int sa_index_create(int device, uint64_t n_docs, uint64_t doc_base, uint32_t n_t
                     const uint64_t* words, const uint64_t* term_off, const float* doc_lens,
                     float avg_doc_len, uint64_t corpus_size, uint32_t tile_docs,
                     sa_index_t** out);
+/* The same index read from the reference's ON-DISK format: one raw file of uint64 roaringish words
+ * (ArrayDict.data.tofile, searcharray/phrase/memmap_arrays.py:158-161) whose per-term
+ * {offset, length} metadata (element units, memmap_arrays.py:28-54; it travels in the reference's
+ * pickle, memmap_arrays.py:196-208) is passed as term_src_off[n_terms] / term_len[n_terms]; a term
+ * without an entry has length 0.  Terms may lie in any order in the file; the device keeps them
+ * back to back in id order.  The file is streamed file -> page-locked ring -> HBM (reads and H2D
+ * copies overlapped); no pageable host copy is made -- this replaces the np.memmap the reference
+ * faults in page by page (memmap_arrays.py:163-165).  I/O failures are SA_ERR_IO, a term outside
+ * the file is SA_ERR_ARG. */
+int sa_index_create_from_file(int device, uint64_t n_docs, uint64_t doc_base, uint32_t n_terms,
+                              const char* path, const uint64_t* term_src_off, const uint64_t* term_len,
+                              const float* doc_lens, float avg_doc_len, uint64_t corpus_size,
+                              uint32_t tile_docs, sa_index_t** out);
+/* Write the resident words to `path` in that same format (terms back to back in id order, i.e.
+ * offset = term_off[t], length = term_off[t+1] - term_off[t] as returned by sa_index_words):
+ * what PosnBitArray.memmap(data_dir) does for the host arrays (middle_out.py:333-335). */
+int sa_index_save(sa_index_t* ix, const char* path);
 /* The same index built from the TOKEN STREAM instead of pre-encoded words (index build on the
  * device): tokens[doc_ptr[d] .. doc_ptr[d+1]) are the term ids of doc d in position order
  * (position = index within the doc).  Replaces the host part of the reference indexer -- the stable

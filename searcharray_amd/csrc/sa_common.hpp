@@ -27,7 +27,7 @@ typedef int64_t i64;
 
 // ---- error reporting (thread-local message, negative status codes) ----
 enum { SA_OK = 0, SA_ERR_HIP = -1, SA_ERR_ARG = -2, SA_ERR_NOMEM = -3, SA_ERR_STATE = -4,
-       SA_ERR_UNSUPPORTED = -5, SA_ERR_COMM = -6 };
+       SA_ERR_UNSUPPORTED = -5, SA_ERR_COMM = -6, SA_ERR_IO = -7 };
 
 void sa_set_error(const char* fmt, ...);
 

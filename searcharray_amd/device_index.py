@@ -8,6 +8,7 @@ with GPU kernels.
 from __future__ import annotations
 
 import ctypes
+import os
 import weakref
 from typing import Optional, Sequence, Tuple
 
@@ -133,6 +134,58 @@ class DeviceIndex:
         self._local_df = None
         self._global_df = None if global_df is None else np.asarray(global_df, dtype=np.uint64)
         return self
+
+    @classmethod
+    def from_file(cls, path: str, metadata, doc_lens: np.ndarray, n_terms: Optional[int] = None,
+                  avg_doc_len: Optional[float] = None, corpus_size: Optional[int] = None, doc_base: int = 0,
+                  device: int = 0, tile_docs: int = 0, api=None,
+                  global_df: Optional[np.ndarray] = None) -> "DeviceIndex":
+        """Stream an index from the reference's on-disk format straight into HBM: ``path`` is the raw
+        uint64 ``.dat`` file MemoryMappedArrays writes (reference phrase/memmap_arrays.py:158-161) and
+        ``metadata`` its ArrayDict metadata ``{term_id: {'offset': o, 'length': n}}`` (element units,
+        memmap_arrays.py:28-54) -- or, equivalently, the CSR offsets ``uint64[V+1]`` of a file that
+        holds the terms back to back in id order (what ``save`` writes)."""
+        self = cls.__new__(cls)
+        self.api = api if api is not None else _lib.api()
+        if isinstance(metadata, dict):
+            V = int(n_terms) if n_terms is not None else (max(int(k) for k in metadata) + 1 if metadata else 0)
+            src = np.zeros(V, dtype=np.uint64)
+            length = np.zeros(V, dtype=np.uint64)
+            for k, v in metadata.items():
+                if int(k) >= V:
+                    raise ValueError(f"metadata names term {k} but the index has {V} terms")
+                src[int(k)] = int(v["offset"])
+                length[int(k)] = int(v["length"])
+        else:
+            off = as_u64(np.asarray(metadata))
+            V = len(off) - 1 if n_terms is None else int(n_terms)
+            if len(off) != V + 1:
+                raise ValueError("term offsets must hold n_terms + 1 entries")
+            src = np.ascontiguousarray(off[:-1])
+            length = np.ascontiguousarray(np.diff(off))
+        doc_lens = as_f32(doc_lens)
+        self.n_docs = len(doc_lens)
+        self.n_terms = V
+        self.doc_base = int(doc_base)
+        self.avg_doc_len = np.float32(np.mean(doc_lens) if avg_doc_len is None and self.n_docs
+                                      else (avg_doc_len or 0.0))
+        self.corpus_size = int(self.n_docs if corpus_size is None else corpus_size)
+        self._h = ctypes.c_void_p()
+        self.api.call("sa_index_create_from_file", int(device), self.n_docs, self.doc_base, self.n_terms,
+                      os.fsencode(path), p_u64(src), p_u64(length), p_f32(doc_lens), self.avg_doc_len,
+                      self.corpus_size, int(tile_docs), ctypes.byref(self._h))
+        self._local_df = None
+        self._global_df = None if global_df is None else np.asarray(global_df, dtype=np.uint64)
+        return self
+
+    def save(self, path: str) -> np.ndarray:
+        """Write the resident words to ``path`` as one raw uint64 file (the reference's ``.dat``,
+        phrase/memmap_arrays.py:158-161), device -> page-locked ring -> file.  Returns the term
+        offsets ``uint64[V+1]`` that index it (term t = elements [off[t], off[t+1]))."""
+        self.api.call("sa_index_save", self._h, os.fsencode(path))
+        term_off = np.empty(self.n_terms + 1, dtype=np.uint64)
+        self.api.call("sa_index_words", self._h, None, p_u64(term_off))
+        return term_off
 
     def words(self) -> Tuple[np.ndarray, np.ndarray]:
         """(roaringish words uint64[W] term-major, term offsets uint64[V+1]) copied from the device."""

@@ -10,6 +10,7 @@ the host and uploaded.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Iterable, List, Optional
 
 import numpy as np
@@ -38,6 +39,9 @@ class HostIndex:
         self.tokens = tokens                # uint32[n_tokens] term id per token, docs back to back (or None)
         self.doc_ptr = doc_ptr              # uint64[N+1] token offsets
         self.words_source: Optional[Callable] = None     # () -> (words, term_off), set by the device owner
+        # (path, term_src_off uint64[V], term_len uint64[V]) when the words live in a raw uint64 file --
+        # the reference's MemoryMappedArrays .dat (phrase/memmap_arrays.py:145-165)
+        self.words_file: Optional[tuple] = None
 
     @property
     def num_docs(self) -> int:
@@ -52,6 +56,19 @@ class HostIndex:
             return
         if self.words_source is not None:
             self._words, self._term_off = self.words_source()
+            return
+        if self.words_file is not None:
+            path, src, length = self.words_file
+            off = np.zeros(len(length) + 1, dtype=np.uint64)
+            np.cumsum(length, out=off[1:])
+            mm = np.memmap(path, dtype=np.uint64, mode="r") if os.path.getsize(path) else np.empty(0, np.uint64)
+            if np.array_equal(src, off[:-1]):
+                words = mm                                  # terms back to back in id order: map, do not copy
+            else:
+                words = np.empty(int(off[-1]), dtype=np.uint64)
+                for t in np.flatnonzero(length):
+                    words[int(off[t]):int(off[t + 1])] = mm[int(src[t]):int(src[t]) + int(length[t])]
+            self._words, self._term_off = words, off
             return
         # no device copy yet: encode on the host (same bytes)
         lens = np.diff(self.doc_ptr.astype(np.int64))
@@ -75,6 +92,12 @@ class HostIndex:
     def _materialise_doc_terms(self):
         if self._doc_term_ptr is not None:
             return
+        if self.tokens is None:                             # only the words exist (index read from a file)
+            words, off = self.words, self.term_off
+            terms = np.repeat(np.arange(len(off) - 1, dtype=np.uint64), np.diff(off.astype(np.int64)))
+            docs = np.asarray(words) >> np.uint64(rz.KEY_SHIFT)
+            self._doc_term_ptr, self._doc_term_ids = _csr_doc_terms(terms, docs, len(self.doc_lens))
+            return
         lens = np.diff(self.doc_ptr.astype(np.int64))
         docs = np.repeat(np.arange(len(lens), dtype=np.uint64), lens)
         self._doc_term_ptr, self._doc_term_ids = _csr_doc_terms(self.tokens, docs, len(lens))
@@ -90,9 +113,16 @@ class HostIndex:
         return self._doc_term_ids
 
     def __getstate__(self):
-        self._materialise_words()                   # pickles are self-contained
         state = dict(self.__dict__)
         state["words_source"] = None
+        if self.words_file is not None:
+            # like the reference's MemoryMappedArrays (memmap_arrays.py:196-208): the pickle carries the
+            # filename and the per-term metadata, never the words
+            state["_words"] = None
+            state["_term_off"] = None
+        else:
+            self._materialise_words()               # pickles are self-contained
+            state["_words"], state["_term_off"] = self._words, self._term_off
         return state
 
 

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import json
 import numbers
+import os
 import warnings
 from collections import Counter
 from typing import Iterable, List, Optional, Tuple, Union
@@ -30,7 +31,7 @@ from . import roaringish as rz
 from .device_index import DeviceIndex, NO_DOC, compute_idf
 from .indexing import HostIndex, build_index_from_terms_list, build_index_from_tokenizer
 from .similarity import default_bm25
-from .term_dict import TermMissingError
+from .term_dict import TermDict, TermMissingError
 
 
 class Terms:
@@ -171,7 +172,14 @@ class _IndexCore:
     def device(self) -> DeviceIndex:
         if self._device is None:
             h = self.host
-            if not h.has_words and h.tokens is not None:
+            if not h.has_words and h.words_file is not None:
+                # file -> page-locked ring -> HBM, no host copy of the words
+                path, src, length = h.words_file
+                meta = {int(t): {"offset": int(src[t]), "length": int(length[t])} for t in np.flatnonzero(length)}
+                self._device = DeviceIndex.from_file(path, meta, h.doc_lens, n_terms=len(self.term_dict),
+                                                     avg_doc_len=self.avg_doc_length,
+                                                     corpus_size=self.corpus_size, api=_lib.api())
+            elif not h.has_words and h.tokens is not None:
                 # index build on the device: sort by term + roaringish encode in HBM
                 dev = DeviceIndex.from_tokens(h.tokens, h.doc_ptr, len(self.term_dict), doc_lens=h.doc_lens,
                                               avg_doc_len=self.avg_doc_length, corpus_size=self.corpus_size,
@@ -251,12 +259,54 @@ class SearchArray(ExtensionArray):
     def index(cls, array: Iterable, tokenizer=ws_tokenizer, truncate=False, batch_size=100000,
               avoid_copies=True, workers=4, cache_gt_than=25, data_dir: Optional[str] = None,
               autowarm=True) -> 'SearchArray':
-        """Index strings with ``tokenizer`` (reference postings.py:249-300).  ``workers``,
-        ``cache_gt_than`` and ``data_dir`` are accepted for signature compatibility: index build
-        is a single host pass and the derived tf/df live on the device."""
+        """Index strings with ``tokenizer`` (reference postings.py:249-300).  ``workers`` and
+        ``cache_gt_than`` are accepted for signature compatibility: index build is a single host pass
+        and the derived tf/df live on the device.  ``data_dir``: as in the reference
+        (indexing.py:291-293 -> PosnBitArray.memmap, middle_out.py:333-335) the encoded positions are
+        written to ``<data_dir>/<number of files in it>.dat`` as raw uint64 and pickles of the array
+        then carry the filename instead of the words; here the file is written from, and read back
+        into, HBM directly (csrc/sa_io.hip)."""
         if not is_list_like(array):
             raise TypeError(f"Expected list-like object, got {type(array)}")
         host = build_index_from_tokenizer(array, tokenizer, truncate=truncate, batch_size=batch_size)
+        arr = cls.__new__(cls)
+        arr.avoid_copies = avoid_copies
+        arr.tokenizer = tokenizer
+        arr._core = _IndexCore(host)
+        arr._rows = None
+        if data_dir is not None and len(host.term_dict):
+            arr.memmap(data_dir)
+        return arr
+
+    def memmap(self, data_dir: str) -> str:
+        """Persist the encoded positions under ``data_dir`` (reference PosnBitArray.memmap,
+        middle_out.py:333-335; file naming of memmap_arrays.py:7-12).  Returns the file name."""
+        core = self._core
+        filename = os.path.join(data_dir, f"{len(os.listdir(data_dir))}") + ".dat"
+        term_off = core.device().save(filename)
+        core.host.words_file = (filename, np.ascontiguousarray(term_off[:-1]),
+                                np.ascontiguousarray(np.diff(term_off)))
+        return filename
+
+    @classmethod
+    def from_memmap(cls, filename: str, metadata, terms: Iterable[str], doc_lens, tokenizer=ws_tokenizer,
+                    avoid_copies=True) -> 'SearchArray':
+        """Open an index persisted in the reference's on-disk format without re-indexing: ``filename``
+        is the raw uint64 ``.dat`` (phrase/memmap_arrays.py:158-161), ``metadata`` the ArrayDict
+        metadata ``{term_id: {'offset', 'length'}}`` (memmap_arrays.py:28-54), ``terms`` the term
+        strings in id order (TermDict, reference term_dict.py) and ``doc_lens`` the doc lengths.
+        The words go from the file straight to HBM on first use."""
+        term_dict = TermDict()
+        term_dict.add_terms(list(terms))
+        V = len(term_dict)
+        src = np.zeros(V, dtype=np.uint64)
+        length = np.zeros(V, dtype=np.uint64)
+        for k, v in metadata.items():
+            if not 0 <= int(k) < V:
+                raise ValueError(f"metadata names term id {k}; the dictionary has {V} terms")
+            src[int(k)], length[int(k)] = int(v["offset"]), int(v["length"])
+        host = HostIndex(term_dict, np.ascontiguousarray(doc_lens, dtype=np.float32))
+        host.words_file = (filename, src, length)
         arr = cls.__new__(cls)
         arr.avoid_copies = avoid_copies
         arr.tokenizer = tokenizer

@@ -184,8 +184,41 @@ def edismax_goldens():
     np.savez_compressed(os.path.join(OUT, "edismax.npz"), **out)
 
 
+def memmap_goldens():
+    """The reference's on-disk index: SearchArray.index(..., data_dir=...) writes one raw uint64 .dat
+    (phrase/memmap_arrays.py:158-161) and keeps {term_id: {offset, length}} metadata.  The fixture holds
+    the file's content, the metadata, the term dictionary, doc lengths and reference scores."""
+    import tempfile
+    rng = np.random.default_rng(2024)
+    vocab = [f"w{i}" for i in range(60)]
+    probs = 1.0 / np.arange(1, 61)
+    probs /= probs.sum()
+    docs = [" ".join(rng.choice(vocab, size=max(1, rng.poisson(12)), p=probs)) for _ in range(400)]
+    with tempfile.TemporaryDirectory() as d:
+        arr = SearchArray.index(docs, data_dir=d)
+        files = sorted(os.listdir(d))
+        assert len(files) == 1 and files[0].endswith(".dat"), files
+        dat = np.fromfile(os.path.join(d, files[0]), dtype=np.uint64)
+        md = arr.posns.encoded_term_posns.arrays.metadata
+        ids = np.asarray(sorted(md), dtype=np.int64)
+        out = {"dat": dat, "ids": ids,
+               "offsets": np.asarray([md[int(i)]["offset"] for i in ids], dtype=np.uint64),
+               "lengths": np.asarray([md[int(i)]["length"] for i in ids], dtype=np.uint64),
+               "terms": np.asarray([arr.term_dict.get_term(int(i)) for i in range(len(arr.term_dict))]),
+               "doc_lens": np.asarray(arr.doc_lens, dtype=np.float32), "docs": np.asarray(docs)}
+        queries = ["w0", "w3", "w17", "w59"]
+        phrases = [["w0", "w1"], ["w1", "w0", "w2"], ["w2", "w2"], ["w5", "w0"]]
+        for i, q in enumerate(queries):
+            out[f"score_{i}"] = arr.score(q)
+        for i, q in enumerate(phrases):
+            out[f"phrase_{i}"] = arr.score(q)
+        out["queries"] = np.asarray(queries)
+        out["phrases"] = np.asarray(["|".join(p) for p in phrases])
+    np.savez_compressed(os.path.join(OUT, "memmap.npz"), **out)
+
+
 if __name__ == "__main__":
-    only = os.environ.get("ONLY", "")          # "" = everything, or one of: core, edismax
+    only = os.environ.get("ONLY", "")          # "" = everything, or one of: core, edismax, memmap
     if only in ("", "core"):
         snp_fixture_goldens()
         slopq = [([3, 7], 1), ([3, 7], 2), ([0, 1], 2), ([5, 2, 9], 2), ([10, 4], 3), ([1, 0], 1),
@@ -194,3 +227,5 @@ if __name__ == "__main__":
         corpus_goldens("zipf_sparse", 4000, 5000, 24, 77, 6, slopq[:4])
     if only in ("", "edismax"):
         edismax_goldens()
+    if only in ("", "memmap"):
+        memmap_goldens()
