@@ -205,6 +205,22 @@ int sa_index_bm25_phrase_dense_posn(sa_index_t* ix, const uint32_t* terms, int n
 /* single-term dense tf restricted to the position range (reference middle_out.py:489-497) */
 int sa_index_termfreqs_dense_posn(sa_index_t* ix, uint32_t term, int64_t min_posn, int64_t max_posn, float* out);
 
+/* The reference's other stock similarities (searcharray/similarity.py:41-89) of one term (n_terms == 1)
+ * or one phrase (n_terms >= 2, slop as above), positions restricted like the _posn calls (-1 = open):
+ * what SearchArray.score(token, similarity=bm25_impact() | bm25_legacy_similarity() | classic_similarity())
+ * returns (postings.py:652-680).  Evaluated on the device with numpy's operation order and rounding, so
+ * the result is bit-identical to the reference's: float32[n_docs] for SA_SIM_BM25_IMPACT, float64[n_docs]
+ * for SA_SIM_BM25_LEGACY and SA_SIM_CLASSIC (their np.float64 idf promotes the product).  idf is what the
+ * similarity computes from the doc frequencies (compute_idf, or log((N + 1) / (df + 1)) + 1 for classic);
+ * it is ignored by SA_SIM_BM25_IMPACT, k1 / b are ignored by SA_SIM_CLASSIC.  Honours
+ * sa_index_select_rows.  The caller handles avg_doc_len == 0 (the reference returns zeros). */
+#define SA_SIM_BM25_IMPACT 1
+#define SA_SIM_BM25_LEGACY 2
+#define SA_SIM_CLASSIC 3
+int sa_index_similarity_dense(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop,
+                              int64_t min_posn, int64_t max_posn, int kind, double idf, double k1, double b,
+                              void* out);
+
 /* SearchArray.score(phrase): BM25 over the phrase counts, idf = float32 sum over the phrase's
  * terms computed by the host (reference postings.py:652-680, similarity.py:19-38). */
 int sa_index_bm25_phrase_dense(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop,

@@ -64,6 +64,8 @@ PROTOTYPES = {
     "sa_index_create_from_file": (c_int, [c_int, c_uint64, c_uint64, c_uint32, c_char_p, u64p, u64p, f32p, c_float,
                                           c_uint64, c_uint32, POINTER(c_void_p)]),
     "sa_index_save": (c_int, [c_void_p, c_char_p]),
+    "sa_index_similarity_dense": (c_int, [c_void_p, u32p, c_int, c_int, c_int64, c_int64, c_int, c_double, c_double,
+                                          c_double, c_void_p]),
     "sa_index_words": (c_int, [c_void_p, u64p, u64p]),
     "sa_index_destroy": (c_int, [c_void_p]),
     "sa_index_synchronize": (c_int, [c_void_p]),

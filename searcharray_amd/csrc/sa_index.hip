@@ -205,6 +205,7 @@ void sa_index_free(sa_index* ix) {
     if (ix->d_tf8_slot) hipFree(ix->d_tf8_slot);
     if (ix->d_scratch) hipFree(ix->d_scratch);
     if (ix->d_rows_scratch) hipFree(ix->d_rows_scratch);
+    if (ix->d_sim_scratch) hipFree(ix->d_sim_scratch);
     if (ix->ev0) hipEventDestroy(ix->ev0);
     if (ix->ev1) hipEventDestroy(ix->ev1);
     if (ix->xstream) hipStreamDestroy(ix->xstream);
@@ -538,10 +539,11 @@ extern "C" int sa_index_select_rows(sa_index_t* ix, const uint64_t* rows, uint64
     return SA_OK;
 }
 
+template <class T>
 __global__ void __launch_bounds__(256)
-sa_k_gather_rows(const float* __restrict__ vec, const u64* __restrict__ rows, u64 n, u64 n_docs, float* __restrict__ out) {
+sa_k_gather_rows(const T* __restrict__ vec, const u64* __restrict__ rows, u64 n, u64 n_docs, T* __restrict__ out) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
-        out[i] = rows[i] < n_docs ? vec[rows[i]] : 0.f;
+        out[i] = rows[i] < n_docs ? vec[rows[i]] : (T)0;
 }
 
 void sa_emit_zeros(sa_index* ix, float* out) {
@@ -551,17 +553,46 @@ void sa_emit_zeros(sa_index* ix, float* out) {
     if (n) memset(out, 0, n * sizeof(float));
 }
 
-int sa_emit_dense(sa_index* ix, const float* d_vec, float* out) {
+// ---- the other stock similarities (reference similarity.py:41-89) applied to a tf vector on the
+// device.  Each follows numpy's evaluation of the reference's expression operation by operation
+// (float32 arrays, Python-float constants rounded to float32 when they meet an array, np.float64 idf
+// promoting the last product to float64), so results are bit-identical to the reference's.
+struct SimSelection { const sa_index* ix = nullptr; int kind = 0; double idf = 0, k1 = 0, b = 0; };
+static thread_local SimSelection tl_sim;
+
+struct SimParams { float k1, kb, one_minus_b, k1_plus_1, avg; double idf; };
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+sa_k_similarity(const float* __restrict__ tf, const float* __restrict__ doc_lens, SimParams p, u64 n,
+                float* __restrict__ out32, double* __restrict__ out64) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const float f = tf[i], dl = doc_lens[i];
+        if (KIND == SA_SIM_CLASSIC) {
+            // idf * np.sqrt(term_freqs) * (1.0 / np.sqrt(doc_lens))   similarity.py:83-88
+            const float length_norm = __fdiv_rn(1.0f, __fsqrt_rn(dl));
+            out64[i] = __dmul_rn(__dmul_rn(p.idf, (double)__fsqrt_rn(f)), (double)length_norm);
+        } else {
+            // k1 * (1 - b + b * doc_lens / avg_doc_lens)               similarity.py:50,63-64
+            const float norm = __fmul_rn(p.k1, __fadd_rn(p.one_minus_b, __fdiv_rn(__fmul_rn(p.kb, dl), p.avg)));
+            const float den = __fadd_rn(f, norm);
+            if (KIND == SA_SIM_BM25_IMPACT) out32[i] = __fdiv_rn(f, den);
+            else out64[i] = __dmul_rn(p.idf, (double)__fdiv_rn(__fmul_rn(f, p.k1_plus_1), den));
+        }
+    }
+}
+
+template <class T>
+static int sa_emit_typed(sa_index* ix, const T* d_vec, T* out) {
     hipStream_t st = ix->stream;
-    if (sa_emit_to_vec(ix, d_vec)) return SA_OK;
     if (tl_rows.ix != ix) {
-        SA_HIP(hipMemcpyAsync(out, d_vec, ix->n_docs * sizeof(float), hipMemcpyDeviceToHost, st));
+        SA_HIP(hipMemcpyAsync(out, d_vec, ix->n_docs * sizeof(T), hipMemcpyDeviceToHost, st));
         return SA_OK;
     }
     const RowSelection sel = tl_rows;
     tl_rows = RowSelection();                        // consumed by this call
     if (sel.n == 0) return SA_OK;
-    const size_t need = sel.n * (sizeof(u64) + sizeof(float)) + 256;
+    const size_t need = sel.n * (sizeof(u64) + sizeof(T)) + 256;
     if (ix->rows_scratch_bytes < need) {
         if (ix->d_rows_scratch) SA_HIP(hipFree(ix->d_rows_scratch));
         ix->d_rows_scratch = nullptr; ix->rows_scratch_bytes = 0;
@@ -569,12 +600,63 @@ int sa_emit_dense(sa_index* ix, const float* d_vec, float* out) {
         ix->rows_scratch_bytes = need;
     }
     u64* d_rows = (u64*)ix->d_rows_scratch;
-    float* d_sel = (float*)(d_rows + sel.n);
+    T* d_sel = (T*)(d_rows + sel.n);
     SA_HIP(hipMemcpyAsync(d_rows, sel.rows, sel.n * sizeof(u64), hipMemcpyHostToDevice, st));
     const u32 grid = sel.n / 256 + 1 < 4096 ? (u32)(sel.n / 256 + 1) : 4096u;
-    hipLaunchKernelGGL(sa_k_gather_rows, dim3(grid), dim3(256), 0, st, d_vec, (const u64*)d_rows, sel.n, ix->n_docs, d_sel);
-    SA_HIP(hipMemcpyAsync(out, d_sel, sel.n * sizeof(float), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL((sa_k_gather_rows<T>), dim3(grid), dim3(256), 0, st, d_vec, (const u64*)d_rows, sel.n, ix->n_docs, d_sel);
+    SA_HIP(hipMemcpyAsync(out, d_sel, sel.n * sizeof(T), hipMemcpyDeviceToHost, st));
     return SA_OK;
+}
+
+// the tf vector of a dense call turned into the selected similarity's scores, then emitted
+static int sa_emit_similarity(sa_index* ix, const float* d_tf, void* out) {
+    const SimSelection sim = tl_sim;
+    tl_sim = SimSelection();                         // consumed by this call
+    const u64 N = ix->n_docs;
+    hipStream_t st = ix->stream;
+    SimParams p;
+    p.k1 = (float)sim.k1; p.kb = (float)sim.b; p.one_minus_b = (float)(1.0 - sim.b);
+    p.k1_plus_1 = (float)(sim.k1 + 1.0); p.avg = ix->avg_doc_len; p.idf = sim.idf;
+    const u32 grid = sa_div_up(N ? N : 1, 256) < 8192 ? sa_div_up(N ? N : 1, 256) : 8192;
+    if (sim.kind == SA_SIM_BM25_IMPACT) {
+        float* d = const_cast<float*>(d_tf);         // in place: the tf vector is this call's scratch
+        hipLaunchKernelGGL((sa_k_similarity<SA_SIM_BM25_IMPACT>), dim3(grid), dim3(256), 0, st, d_tf, ix->d_doc_lens, p, N, d, (double*)nullptr);
+        return sa_emit_typed<float>(ix, d, (float*)out);
+    }
+    const size_t need = (N + 1) * sizeof(double);
+    if (ix->sim_scratch_bytes < need) {
+        if (ix->d_sim_scratch) SA_HIP(hipFree(ix->d_sim_scratch));
+        ix->d_sim_scratch = nullptr; ix->sim_scratch_bytes = 0;
+        SA_HIP(hipMalloc(&ix->d_sim_scratch, need));
+        ix->sim_scratch_bytes = need;
+    }
+    double* d64 = (double*)ix->d_sim_scratch;
+    if (sim.kind == SA_SIM_BM25_LEGACY)
+        hipLaunchKernelGGL((sa_k_similarity<SA_SIM_BM25_LEGACY>), dim3(grid), dim3(256), 0, st, d_tf, ix->d_doc_lens, p, N, (float*)nullptr, d64);
+    else
+        hipLaunchKernelGGL((sa_k_similarity<SA_SIM_CLASSIC>), dim3(grid), dim3(256), 0, st, d_tf, ix->d_doc_lens, p, N, (float*)nullptr, d64);
+    return sa_emit_typed<double>(ix, d64, (double*)out);
+}
+
+int sa_emit_dense(sa_index* ix, const float* d_vec, float* out) {
+    if (tl_sim.ix == ix) return sa_emit_similarity(ix, d_vec, out);
+    if (sa_emit_to_vec(ix, d_vec)) return SA_OK;
+    return sa_emit_typed<float>(ix, d_vec, out);
+}
+
+extern "C" int sa_index_similarity_dense(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop,
+                                         int64_t min_posn, int64_t max_posn, int kind, double idf, double k1,
+                                         double b, void* out) {
+    SA_ARG(ix && out && terms, "null argument");
+    SA_ARG(kind == SA_SIM_BM25_IMPACT || kind == SA_SIM_BM25_LEGACY || kind == SA_SIM_CLASSIC,
+           "kind must be SA_SIM_BM25_IMPACT, SA_SIM_BM25_LEGACY or SA_SIM_CLASSIC");
+    SA_ARG(n_terms >= 1, "no terms");
+    tl_sim.ix = ix; tl_sim.kind = kind; tl_sim.idf = idf; tl_sim.k1 = k1; tl_sim.b = b;
+    const int rc = n_terms == 1
+        ? sa_index_termfreqs_dense_posn(ix, terms[0], min_posn, max_posn, (float*)out)
+        : sa_index_phrase_freqs_dense_posn(ix, terms, n_terms, slop, min_posn, max_posn, (float*)out);
+    tl_sim = SimSelection();                         // an argument error leaves nothing pending
+    return rc;
 }
 
 extern "C" int sa_index_termfreqs_dense(sa_index_t* ix, uint32_t term, float* out) {

@@ -74,6 +74,8 @@ struct sa_index {
     // row selection scratch (sa_index_select_rows): device copy of the selected doc ids + gathered values
     void* d_rows_scratch = nullptr;
     size_t rows_scratch_bytes = 0;
+    void* d_sim_scratch = nullptr;              // float64[n_docs] results of the f64 similarities
+    size_t sim_scratch_bytes = 0;
 
     sa_comm* comm = nullptr;
     hipStream_t xstream = nullptr;   // exchange stream: all-gather + cross-rank merge overlap the next batch's scoring

@@ -57,9 +57,13 @@ class _PinnedPool:
             pass
 
     def empty_f32(self, n: int) -> np.ndarray:
+        return self.empty(n, np.float32)
+
+    def empty(self, n: int, dtype) -> np.ndarray:
+        dtype = np.dtype(dtype)
         if n == 0:
-            return np.empty(0, dtype=np.float32)
-        nbytes = 4 * n
+            return np.empty(0, dtype=dtype)
+        nbytes = dtype.itemsize * n
         stack = self.idle.get(nbytes)
         if stack:
             addr = stack.pop()
@@ -68,9 +72,9 @@ class _PinnedPool:
             ptr = ctypes.c_void_p()
             self.api.call("sa_host_alloc", nbytes, ctypes.byref(ptr))
             addr = ptr.value
-        buf = (ctypes.c_float * n).from_address(addr)
+        buf = (ctypes.c_char * nbytes).from_address(addr)
         weakref.finalize(buf, self._release, addr, nbytes)     # runs when the last array / view is gone
-        return np.frombuffer(buf, dtype=np.float32)
+        return np.frombuffer(buf, dtype=dtype)
 
 
 _pools = {}
@@ -234,18 +238,20 @@ class DeviceIndex:
         return df[term] if 0 <= term < self.n_terms else np.uint64(0)
 
     # -- dense results, whole or a row subset
-    def _dense(self, fn: str, rows: Optional[np.ndarray], *args) -> np.ndarray:
-        """Run a dense C-ABI call (its last argument is the float32 output).  rows given: only those doc
-        ids come back (gathered on the device: the copy is proportional to the subset)."""
+    def _dense(self, fn: str, rows: Optional[np.ndarray], *args, dtype=np.float32) -> np.ndarray:
+        """Run a dense C-ABI call (its last argument is the float32 -- or ``dtype`` -- output).  rows
+        given: only those doc ids come back (gathered on the device: the copy is proportional to the
+        subset)."""
+        ptr = p_f32 if dtype == np.float32 else (lambda a: a.ctypes.data_as(ctypes.c_void_p))
         if rows is None:
-            out = _pool(self.api).empty_f32(self.n_docs)
-            self.api.call(fn, self._h, *args, p_f32(out))
+            out = _pool(self.api).empty(self.n_docs, dtype)
+            self.api.call(fn, self._h, *args, ptr(out))
             return out
         rows = as_u64(rows)
-        out = np.empty(len(rows), dtype=np.float32)
+        out = np.empty(len(rows), dtype=dtype)
         self.api.call("sa_index_select_rows", self._h, p_u64(rows), len(rows))
         try:
-            self.api.call(fn, self._h, *args, p_f32(out))
+            self.api.call(fn, self._h, *args, ptr(out))
         except Exception:
             self.api.call("sa_index_select_rows", self._h, None, 0)      # an argument error leaves it pending
             raise
@@ -326,6 +332,20 @@ class DeviceIndex:
         lo, hi = self._check_posn_range(min_posn, max_posn)
         return self._dense("sa_index_bm25_phrase_dense_posn", rows, p_u32(tarr), len(tarr), int(slop), lo, hi,
                            np.float32(idf), np.float32(k1), np.float32(b))
+
+    SIMILARITY_KINDS = {"bm25_impact": (1, np.float32), "bm25_legacy": (2, np.float64), "classic": (3, np.float64)}
+
+    def similarity_dense(self, kind: str, terms: Sequence[int], idf: float = 0.0, k1: float = 1.2, b: float = 0.75,
+                         slop: int = 0, min_posn: Optional[int] = None, max_posn: Optional[int] = None,
+                         rows: Optional[np.ndarray] = None) -> np.ndarray:
+        """One of the reference's other stock similarities (similarity.py:41-89) of a term (one id) or a
+        phrase, computed on the device with numpy's rounding: float32 for ``bm25_impact``, float64 for
+        ``bm25_legacy`` / ``classic``."""
+        code, dtype = self.SIMILARITY_KINDS[kind]
+        tarr = np.asarray([int(t) if 0 <= int(t) < self.n_terms else NO_TERM for t in terms], dtype=np.uint32)
+        lo, hi = self._check_posn_range(min_posn, max_posn)
+        return self._dense("sa_index_similarity_dense", rows, p_u32(tarr), len(tarr), int(slop), lo, hi, code,
+                           float(idf), float(k1), float(b), dtype=dtype)
 
     def last_profile(self) -> Tuple[float, int]:
         """(kernel ms, algorithmic bytes) of the last phrase call."""

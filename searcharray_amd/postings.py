@@ -30,7 +30,7 @@ from . import _lib
 from . import roaringish as rz
 from .device_index import DeviceIndex, NO_DOC, compute_idf
 from .indexing import HostIndex, build_index_from_terms_list, build_index_from_tokenizer
-from .similarity import default_bm25
+from .similarity import compute_idf as similarity_idf, default_bm25
 from .term_dict import TermDict, TermMissingError
 
 
@@ -592,6 +592,19 @@ class SearchArray(ExtensionArray):
                                       rows=self._rows)
             return dev.bm25_phrase_dense(ids, k1=similarity.k1, b=similarity.b, slop=slop, idf=idf,
                                          min_posn=min_posn, max_posn=max_posn, rows=self._rows)
+        kind = getattr(similarity, "kind", None)
+        if (kind in DeviceIndex.SIMILARITY_KINDS and self.avg_doc_length != 0
+                and (isinstance(token, str) or len(tokens) >= 2)):
+            # the reference's other stock similarities (similarity.py:41-89) as device kernels
+            if kind == "classic":
+                idf = np.log((self.corpus_size + 1) / (np.sum(dfs, axis=0) + 1)) + 1
+                k1 = b = 0.0
+            else:
+                idf, k1, b = similarity_idf(self.corpus_size, dfs), similarity.k1, similarity.b   # float64
+
+            return self._core.device().similarity_dense(kind, [self._term_id(t) for t in tokens], idf=idf, k1=k1, b=b,
+                                                        slop=slop, min_posn=min_posn, max_posn=max_posn,
+                                                        rows=self._rows)
         # any other Similarity (or a position-restricted single term): tf on the device, then the
         # similarity callable (the stock BM25 closure applies the BM25 kernel through the C ABI)
         tfs = self.termfreqs(token, slop=slop, min_posn=min_posn, max_posn=max_posn)

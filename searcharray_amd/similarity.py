@@ -5,8 +5,9 @@
 ``bm25_similarity`` closures are tagged (``.kind == "bm25"``, ``.k1``, ``.b``) so
 ``SearchArray.score`` can run them entirely on the GPU.  Called directly (protocol use, e.g. by a
 caller that already holds term frequencies) they apply the BM25 kernel to the given arrays through
-the C ABI.  The other stock similarities are the reference's numpy one-liners over
-device-computed term frequencies.
+the C ABI.  The other stock similarities are tagged the same way (``bm25_impact``, ``bm25_legacy``,
+``classic``) and run on the device from ``SearchArray.score``; called directly they are the
+reference's numpy expressions, which is also what the device kernels reproduce bit for bit.
 """
 from __future__ import annotations
 
@@ -48,6 +49,9 @@ def bm25_impact(k1: float = 1.2, b: float = 0.75):
         if avg_doc_lens == 0:
             return np.zeros_like(term_freqs)
         return term_freqs / (term_freqs + k1 * (1 - b + b * doc_lens / avg_doc_lens))
+    bm25.kind = "bm25_impact"
+    bm25.k1 = float(k1)
+    bm25.b = float(b)
     return bm25
 
 
@@ -59,6 +63,9 @@ def bm25_legacy_similarity(k1: float = 1.2, b: float = 0.75):
         idf = compute_idf(num_docs, doc_freqs)
         tf = (term_freqs * (k1 + 1)) / (term_freqs + k1 * (1 - b + b * doc_lens / avg_doc_lens))
         return idf * tf
+    bm25.kind = "bm25_legacy"
+    bm25.k1 = float(k1)
+    bm25.b = float(b)
     return bm25
 
 
@@ -69,6 +76,7 @@ def classic_similarity():
         idf = np.log((num_docs + 1) / (sum_dfs + 1)) + 1
         length_norm = 1.0 / np.sqrt(doc_lens)
         return idf * np.sqrt(term_freqs) * length_norm
+    classic.kind = "classic"
     return classic
 
 

@@ -184,6 +184,34 @@ def edismax_goldens():
     np.savez_compressed(os.path.join(OUT, "edismax.npz"), **out)
 
 
+def similarity_goldens():
+    """Reference scores under its other stock similarities (similarity.py:41-89): single terms, phrases,
+    slop, position ranges and a slice, native dtypes (float32 for bm25_impact, float64 for the others)."""
+    from searcharray.similarity import bm25_impact, bm25_legacy_similarity, classic_similarity
+    rng = np.random.default_rng(31337)
+    vocab = [f"w{i}" for i in range(50)]
+    probs = 1.0 / np.arange(1, 51)
+    probs /= probs.sum()
+    docs = [" ".join(rng.choice(vocab, size=max(1, rng.poisson(25)), p=probs)) for _ in range(600)]
+    arr = SearchArray.index(docs)
+    sims = {"impact": bm25_impact(), "impact_b": bm25_impact(k1=0.9, b=0.3), "legacy": bm25_legacy_similarity(),
+            "legacy_b": bm25_legacy_similarity(k1=1.7, b=0.3), "classic": classic_similarity()}
+    cases = [("w0", {}), ("w7", {}), ("w49", {}), ("nope", {}), (["w0", "w1"], {}), (["w1", "w0", "w2"], {}),
+             (["w0", "w0"], {}), (["w0", "nope"], {}), (["w3", "w1"], {"slop": 2}),
+             ("w0", {"min_posn": 0, "max_posn": 17}), (["w0", "w1"], {"min_posn": 0, "max_posn": 35})]
+    # (a single term with min_posn > 0 raises inside the reference's as_dense -- float64 counts -- so
+    #  only ranges starting at 0 can be pinned for single terms)
+    out = {"docs": np.asarray(docs), "n_cases": np.asarray(len(cases)), "sims": np.asarray(list(sims))}
+    rows = np.asarray([5, 17, 300, 420, 599])
+    for name, sim in sims.items():
+        for i, (tok, kw) in enumerate(cases):
+            out[f"{name}_{i}"] = arr.score(tok, similarity=sim, **kw)
+        out[f"{name}_slice"] = arr[rows].score("w0", similarity=sim)
+        out[f"{name}_slice_phrase"] = arr[rows].score(["w0", "w1"], similarity=sim)
+    out["rows"] = rows
+    np.savez_compressed(os.path.join(OUT, "similarities.npz"), **out)
+
+
 def memmap_goldens():
     """The reference's on-disk index: SearchArray.index(..., data_dir=...) writes one raw uint64 .dat
     (phrase/memmap_arrays.py:158-161) and keeps {term_id: {offset, length}} metadata.  The fixture holds
@@ -218,7 +246,7 @@ def memmap_goldens():
 
 
 if __name__ == "__main__":
-    only = os.environ.get("ONLY", "")          # "" = everything, or one of: core, edismax, memmap
+    only = os.environ.get("ONLY", "")          # "" = everything, or one of: core, edismax, memmap, similarity
     if only in ("", "core"):
         snp_fixture_goldens()
         slopq = [([3, 7], 1), ([3, 7], 2), ([0, 1], 2), ([5, 2, 9], 2), ([10, 4], 3), ([1, 0], 1),
@@ -229,3 +257,5 @@ if __name__ == "__main__":
         edismax_goldens()
     if only in ("", "memmap"):
         memmap_goldens()
+    if only in ("", "similarity"):
+        similarity_goldens()

@@ -298,6 +298,7 @@ inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f;
 inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
 inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
 inline float __fdiv_rn(float a, float b) { return a / b; }
+inline float __fsqrt_rn(float a) { return sqrtf(a); }
 inline float __fmul_rn(float a, float b) { return a * b; }
 inline float __fadd_rn(float a, float b) { return a + b; }
 inline float __fsub_rn(float a, float b) { return a - b; }

@@ -11,6 +11,7 @@ import pytest
 from searcharray_amd import SearchArray, Terms, bm25_similarity, bm25_impact, classic_similarity
 from searcharray_amd.similarity import compute_idf
 from tests.test_oracle_golden import PHRASE_SCENARIOS, LUCENE
+from tests.helpers import load_golden
 
 DOCS = ["foo bar bar baz", "data2", "data3 bar", "bunny funny wunny"] * 25
 
@@ -287,3 +288,46 @@ def test_terms_helpers_memory_report_and_set_of_results(default_api):
     assert list(out["id"]) == [10, 12, 13] and list(out["rank"]) == [1, 2, 1]
     with pytest.raises(ValueError):
         res.ins_top_n(arr.score("bar"), N=2, query="x", metadata={"run": ["only one"]})
+
+
+# ---- the reference's other stock similarities as device kernels ----------------------
+def _sim(name):
+    from searcharray_amd.similarity import bm25_impact, bm25_legacy_similarity, classic_similarity
+    return {"impact": bm25_impact(), "impact_b": bm25_impact(k1=0.9, b=0.3), "legacy": bm25_legacy_similarity(),
+            "legacy_b": bm25_legacy_similarity(k1=1.7, b=0.3), "classic": classic_similarity()}[name]
+
+
+SIM_CASES = [("w0", {}), ("w7", {}), ("w49", {}), ("nope", {}), (["w0", "w1"], {}), (["w1", "w0", "w2"], {}),
+             (["w0", "w0"], {}), (["w0", "nope"], {}), (["w3", "w1"], {"slop": 2}),
+             ("w0", {"min_posn": 0, "max_posn": 17}), (["w0", "w1"], {"min_posn": 0, "max_posn": 35})]
+
+
+@pytest.mark.parametrize("name", ["impact", "impact_b", "legacy", "legacy_b", "classic"])
+def test_other_similarities_bit_identical_to_reference(default_api, name):
+    """bm25_impact / bm25_legacy_similarity / classic_similarity (reference similarity.py:41-89) run on the
+    device with numpy's rounding: same dtype and the same bits as the reference's host expressions
+    (goldens: tests/golden/make_golden.py ONLY=similarity)."""
+    g = load_golden("similarities")
+    assert int(g["n_cases"]) == len(SIM_CASES)
+    arr = SearchArray.index([str(d) for d in g["docs"]])
+    sim = _sim(name)
+    calls = []
+    dev = arr._core.device()
+    orig = dev.similarity_dense
+    dev.similarity_dense = lambda *a, **k: (calls.append(a[0]), orig(*a, **k))[1]
+    try:
+        for i, (tok, kw) in enumerate(SIM_CASES):
+            got, want = arr.score(tok, similarity=sim, **kw), g[f"{name}_{i}"]
+            assert got.dtype == want.dtype, (tok, kw)
+            assert np.array_equal(got, want, equal_nan=True), (tok, kw, np.abs(got - want).max())
+        rows = g["rows"]
+        for key, tok in (("slice", "w0"), ("slice_phrase", ["w0", "w1"])):
+            got, want = arr[rows].score(tok, similarity=sim), g[f"{name}_{key}"]
+            assert got.dtype == want.dtype and np.array_equal(got, want, equal_nan=True)
+    finally:
+        dev.similarity_dense = orig
+    assert len(calls) == len(SIM_CASES) + 2            # every score came from the device kernel
+    # the closures keep working as plain Similarity callables (protocol use) and agree with the kernel
+    tf = arr.termfreqs("w7")
+    direct = sim(tf.copy(), np.asarray([arr.docfreq("w7")]), arr.doc_lens, arr.avg_doc_length, arr.corpus_size)
+    assert np.array_equal(direct, g[f"{name}_1"], equal_nan=True)
