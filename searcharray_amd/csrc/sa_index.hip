@@ -570,8 +570,9 @@ sa_k_similarity(const float* __restrict__ tf, const float* __restrict__ doc_lens
         const float f = tf[i], dl = doc_lens[i];
         if (KIND == SA_SIM_CLASSIC) {
             // idf * np.sqrt(term_freqs) * (1.0 / np.sqrt(doc_lens))   similarity.py:83-88
-            const float length_norm = __fdiv_rn(1.0f, __fsqrt_rn(dl));
-            out64[i] = __dmul_rn(__dmul_rn(p.idf, (double)__fsqrt_rn(f)), (double)length_norm);
+            // (sqrtf / '/' are correctly rounded under hipcc's defaults; __fsqrt_rn is the NATIVE approximation)
+            const float length_norm = __fdiv_rn(1.0f, sqrtf(dl));
+            out64[i] = __dmul_rn(__dmul_rn(p.idf, (double)sqrtf(f)), (double)length_norm);
         } else {
             // k1 * (1 - b + b * doc_lens / avg_doc_lens)               similarity.py:50,63-64
             const float norm = __fmul_rn(p.k1, __fadd_rn(p.one_minus_b, __fdiv_rn(__fmul_rn(p.kb, dl), p.avg)));

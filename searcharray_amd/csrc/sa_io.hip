@@ -5,7 +5,7 @@
 // in element units (memmap_arrays.py:28-54) that travels in the pickle; reading it back is a numpy
 // memmap whose pages fault in term by term as queries touch them (memmap_arrays.py:163-165).
 //
-// Here the file is streamed straight into HBM: a reader thread preads 32 MiB pieces into a ring of
+// Here the file is streamed straight into HBM: file threads pread 16 MiB pieces into a ring of
 // page-locked buffers while the copy engine drains the previous pieces, so disk / page-cache reads and
 // H2D copies overlap and no pageable host copy of the index ever exists.  Saving runs the same ring
 // the other way (D2H -> pwrite), so an index encoded on the device reaches the disk without a host
@@ -24,24 +24,38 @@
 
 namespace {
 
-constexpr size_t SA_IO_PIECE = 32u << 20;   // bytes per staged piece
-constexpr int SA_IO_SLOTS = 3;              // ring depth: one being read, one in flight, one spare
+// bytes per staged piece (SA_IO_PIECE_BYTES: test hook, lets small files exercise the ring's wrap-around)
+static size_t sa_io_piece() {
+    size_t v = 16u << 20;
+    if (const char* e = getenv("SA_IO_PIECE_BYTES")) {
+        const size_t x = (size_t)strtoull(e, nullptr, 10);
+        if (x >= 64 && x <= (256u << 20)) v = x & ~(size_t)7;
+    }
+    return v;
+}
+constexpr int SA_IO_WORKERS = 4;            // file threads: a single pread / pwrite stream tops out near 10 GB/s
+constexpr int SA_IO_SLOTS = 3 * SA_IO_WORKERS;
 
 struct Piece { u64 file_byte; u64 dev_word; u64 bytes; };
 
-// Single-producer / single-consumer ring of pinned staging buffers.
+// Ring of pinned staging buffers shared by the file threads (piece k belongs to thread k % WORKERS and
+// lives in slot k % SLOTS) and the thread that drives the copy engine.
 struct Ring {
     void* buf[SA_IO_SLOTS] = {};
     hipEvent_t done[SA_IO_SLOTS] = {};      // device finished with the slot
     std::mutex mu;
     std::condition_variable cv;
-    u64 produced = 0, consumed = 0;         // pieces filled by the io thread / released by the device side
+    u64 staged[SA_IO_SLOTS] = {};           // piece index + 1 whose bytes the slot holds (file side done / copy done)
+    u64 released = 0;                       // pieces whose slot may be reused
     int io_errno = 0;
     bool abort = false;
 
+    size_t piece = 0;
+
     int init() {
+        piece = sa_io_piece();
         for (int i = 0; i < SA_IO_SLOTS; i++) {
-            SA_HIP(hipHostMalloc(&buf[i], SA_IO_PIECE));
+            SA_HIP(hipHostMalloc(&buf[i], piece));
             SA_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
         }
         return SA_OK;
@@ -51,6 +65,14 @@ struct Ring {
             if (done[i]) hipEventDestroy(done[i]);
             if (buf[i]) hipHostFree(buf[i]);
         }
+    }
+    void stop(std::vector<std::thread>& workers) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            abort = true;
+            cv.notify_all();
+        }
+        for (std::thread& t : workers) t.join();
     }
 };
 
@@ -75,59 +97,57 @@ bool full_pwrite(int fd, const void* src, u64 bytes, u64 off) {
     return true;
 }
 
-// file -> device: the io thread fills slots, this thread issues the copies
+// file -> device: the file threads fill slots, this thread issues the copies in piece order
 int stream_in(int fd, const std::vector<Piece>& pieces, u64* d_words, hipStream_t st) {
     Ring ring;
     SA_TRY(ring.init());
-    std::thread io([&] {
-        for (u64 k = 0; k < pieces.size(); k++) {
-            {
-                std::unique_lock<std::mutex> lk(ring.mu);
-                ring.cv.wait(lk, [&] { return ring.abort || k - ring.consumed < (u64)SA_IO_SLOTS; });
-                if (ring.abort) return;
+    const u64 n = pieces.size();
+    std::vector<std::thread> workers;
+    for (int w = 0; w < SA_IO_WORKERS; w++) {
+        workers.emplace_back([&, w] {
+            for (u64 k = (u64)w; k < n; k += SA_IO_WORKERS) {
+                {
+                    std::unique_lock<std::mutex> lk(ring.mu);
+                    ring.cv.wait(lk, [&] { return ring.abort || ring.io_errno || k < ring.released + SA_IO_SLOTS; });
+                    if (ring.abort || ring.io_errno) return;
+                }
+                const bool ok = full_pread(fd, ring.buf[k % SA_IO_SLOTS], pieces[k].bytes, pieces[k].file_byte);
+                std::lock_guard<std::mutex> lk(ring.mu);
+                if (!ok) { if (!ring.io_errno) ring.io_errno = errno ? errno : EIO; }
+                else ring.staged[k % SA_IO_SLOTS] = k + 1;
+                ring.cv.notify_all();
+                if (!ok) return;
             }
-            const bool ok = full_pread(fd, ring.buf[k % SA_IO_SLOTS], pieces[k].bytes, pieces[k].file_byte);
-            std::lock_guard<std::mutex> lk(ring.mu);
-            if (!ok) { ring.io_errno = errno ? errno : EIO; ring.cv.notify_all(); return; }
-            ring.produced = k + 1;
-            ring.cv.notify_all();
-        }
-    });
+        });
+    }
     int rc = SA_OK;
     hipError_t he = hipSuccess;
-    u64 issued = 0;
-    for (u64 k = 0; k < pieces.size() && rc == SA_OK; k++) {
+    const u64 lag = SA_IO_SLOTS / 2;                          // copies kept in flight before a slot is released
+    for (u64 k = 0; k < n; k++) {
+        const int s = (int)(k % SA_IO_SLOTS);
         {
             std::unique_lock<std::mutex> lk(ring.mu);
-            ring.cv.wait(lk, [&] { return ring.io_errno || ring.produced > k; });
-            if (ring.produced <= k) {
+            ring.cv.wait(lk, [&] { return ring.io_errno || ring.staged[s] == k + 1; });
+            if (ring.staged[s] != k + 1) {
                 sa_set_error("reading the index file failed: %s", strerror(ring.io_errno));
                 rc = SA_ERR_IO;
                 break;
             }
         }
-        const int s = (int)(k % SA_IO_SLOTS);
         he = hipMemcpyAsync(d_words + pieces[k].dev_word, ring.buf[s], pieces[k].bytes, hipMemcpyHostToDevice, st);
         if (he == hipSuccess) he = hipEventRecord(ring.done[s], st);
         if (he != hipSuccess) break;
-        issued = k + 1;
-        // release the oldest slot once the device is done with it, so the reader can refill it
-        if (issued >= (u64)SA_IO_SLOTS - 1) {
-            const u64 r = issued - ((u64)SA_IO_SLOTS - 1);
+        if (k + 1 >= lag) {                                   // hand the oldest in-flight slot back to the file threads
+            const u64 r = k + 1 - lag;
             he = hipEventSynchronize(ring.done[r % SA_IO_SLOTS]);
             if (he != hipSuccess) break;
             std::lock_guard<std::mutex> lk(ring.mu);
-            ring.consumed = r + 1;
+            ring.released = r + 1;
             ring.cv.notify_all();
         }
     }
-    {
-        std::lock_guard<std::mutex> lk(ring.mu);
-        ring.abort = true;
-        ring.cv.notify_all();
-    }
-    io.join();
-    const hipError_t hs = hipStreamSynchronize(st);      // slots must be idle before the ring is freed
+    ring.stop(workers);
+    const hipError_t hs = hipStreamSynchronize(st);           // slots must be idle before the ring is freed
     if (he == hipSuccess) he = hs;
     if (rc == SA_OK && he != hipSuccess) {
         sa_set_error("%s: copy to the device failed: %s", __FILE__, hipGetErrorString(he));
@@ -136,64 +156,81 @@ int stream_in(int fd, const std::vector<Piece>& pieces, u64* d_words, hipStream_
     return rc;
 }
 
-// device -> file: this thread issues D2H copies, the io thread writes finished slots
+// device -> file: this thread issues D2H copies in piece order, the file threads write finished slots
 int stream_out(int fd, u64 n_words, const u64* d_words, hipStream_t st) {
     Ring ring;
     SA_TRY(ring.init());
     const u64 total = n_words * sizeof(u64);
-    const u64 n_pieces = (total + SA_IO_PIECE - 1) / SA_IO_PIECE;
-    // produced = pieces whose D2H copy completed (written by this thread), consumed = pieces on disk
-    std::thread io([&] {
-        for (u64 k = 0; k < n_pieces; k++) {
-            {
-                std::unique_lock<std::mutex> lk(ring.mu);
-                ring.cv.wait(lk, [&] { return ring.abort || ring.produced > k; });
-                if (ring.produced <= k) return;
+    const u64 SA_IO_PIECE = ring.piece;
+    const u64 n = (total + SA_IO_PIECE - 1) / SA_IO_PIECE;
+    u64 written = 0;                                          // pieces on disk (any order), guarded by ring.mu
+    u64 on_disk[SA_IO_SLOTS] = {};                            // piece index + 1 last written from the slot
+    std::vector<std::thread> workers;
+    for (int w = 0; w < SA_IO_WORKERS; w++) {
+        workers.emplace_back([&, w] {
+            for (u64 k = (u64)w; k < n; k += SA_IO_WORKERS) {
+                const int s = (int)(k % SA_IO_SLOTS);
+                {
+                    std::unique_lock<std::mutex> lk(ring.mu);
+                    ring.cv.wait(lk, [&] { return ring.abort || ring.io_errno || ring.staged[s] == k + 1; });
+                    if (ring.staged[s] != k + 1) return;
+                }
+                const u64 off = k * SA_IO_PIECE;
+                const u64 bytes = total - off < SA_IO_PIECE ? total - off : SA_IO_PIECE;
+                const bool ok = full_pwrite(fd, ring.buf[s], bytes, off);
+                std::lock_guard<std::mutex> lk(ring.mu);
+                if (!ok) { if (!ring.io_errno) ring.io_errno = errno ? errno : EIO; }
+                else { on_disk[s] = k + 1; written++; }
+                ring.cv.notify_all();
+                if (!ok) return;
             }
-            const u64 off = k * SA_IO_PIECE;
-            const u64 bytes = total - off < SA_IO_PIECE ? total - off : SA_IO_PIECE;
-            const bool ok = full_pwrite(fd, ring.buf[k % SA_IO_SLOTS], bytes, off);
-            std::lock_guard<std::mutex> lk(ring.mu);
-            if (!ok) { ring.io_errno = errno ? errno : EIO; ring.cv.notify_all(); return; }
-            ring.consumed = k + 1;
-            ring.cv.notify_all();
-        }
-    });
-    int rc = SA_OK;
+        });
+    }
     hipError_t he = hipSuccess;
-    for (u64 k = 0; k < n_pieces; k++) {
-        {
+    auto publish = [&](u64 k) -> hipError_t {                 // piece k's copy has landed: hand it to its writer
+        const hipError_t e = hipEventSynchronize(ring.done[k % SA_IO_SLOTS]);
+        if (e != hipSuccess) return e;
+        std::lock_guard<std::mutex> lk(ring.mu);
+        ring.staged[k % SA_IO_SLOTS] = k + 1;
+        ring.cv.notify_all();
+        return hipSuccess;
+    };
+    u64 issued = 0, published = 0;
+    for (u64 k = 0; k < n && he == hipSuccess; k++) {
+        const int s = (int)(k % SA_IO_SLOTS);
+        // the slot's previous piece (k - SLOTS) must be on disk; publish copies that landed while we wait
+        while (k >= SA_IO_SLOTS && he == hipSuccess) {
+            {
+                std::lock_guard<std::mutex> lk(ring.mu);
+                if (ring.io_errno || on_disk[s] == k - SA_IO_SLOTS + 1) break;
+            }
+            if (published < issued) { he = publish(published); published++; continue; }
             std::unique_lock<std::mutex> lk(ring.mu);
-            ring.cv.wait(lk, [&] { return ring.io_errno || k - ring.consumed < (u64)SA_IO_SLOTS; });
+            ring.cv.wait(lk, [&] { return ring.io_errno || on_disk[s] == k - SA_IO_SLOTS + 1; });
+        }
+        {
+            std::lock_guard<std::mutex> lk(ring.mu);
             if (ring.io_errno) break;
         }
+        if (he != hipSuccess) break;
         const u64 off = k * SA_IO_PIECE;
         const u64 bytes = total - off < SA_IO_PIECE ? total - off : SA_IO_PIECE;
-        const int s = (int)(k % SA_IO_SLOTS);
         he = hipMemcpyAsync(ring.buf[s], (const char*)d_words + off, bytes, hipMemcpyDeviceToHost, st);
         if (he == hipSuccess) he = hipEventRecord(ring.done[s], st);
         if (he != hipSuccess) break;
-        // hand the previous piece to the writer while this one is in flight
-        if (k > 0) {
-            he = hipEventSynchronize(ring.done[(k - 1) % SA_IO_SLOTS]);
-            if (he != hipSuccess) break;
-            std::lock_guard<std::mutex> lk(ring.mu);
-            ring.produced = k;
-            ring.cv.notify_all();
-        }
+        issued = k + 1;
+        while (he == hipSuccess && issued - published > 2) { he = publish(published); published++; }
     }
-    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    while (he == hipSuccess && published < issued) { he = publish(published); published++; }
     {
         std::unique_lock<std::mutex> lk(ring.mu);
-        if (he == hipSuccess && !ring.io_errno) {
-            ring.produced = n_pieces;
-            ring.cv.notify_all();
-            ring.cv.wait(lk, [&] { return ring.io_errno || ring.consumed == n_pieces; });
-        }
-        ring.abort = true;
-        ring.cv.notify_all();
+        if (he == hipSuccess && issued == n)
+            ring.cv.wait(lk, [&] { return ring.io_errno || written == n; });
     }
-    io.join();
+    ring.stop(workers);
+    const hipError_t hs = hipStreamSynchronize(st);
+    if (he == hipSuccess) he = hs;
+    int rc = SA_OK;
     if (ring.io_errno) {
         sa_set_error("writing the index file failed: %s", strerror(ring.io_errno));
         rc = SA_ERR_IO;
@@ -227,6 +264,7 @@ extern "C" int sa_index_create_from_file(int device, uint64_t n_docs, uint64_t d
     if (fstat(fd, &sb) != 0) { sa_set_error("cannot stat %s: %s", path, strerror(errno)); return SA_ERR_IO; }
     const u64 file_words = (u64)sb.st_size / sizeof(u64);
 
+    const u64 SA_IO_PIECE = sa_io_piece();
     // device layout: terms back to back in id order, whatever their order in the file
     std::vector<u64> term_off((size_t)n_terms + 1, 0);
     std::vector<Piece> pieces;

@@ -70,6 +70,34 @@ def test_file_in_any_term_order_and_with_gaps(api, tmp_path):
     dev.close()
 
 
+@pytest.mark.parametrize("piece", ["64", "4096", "100000"])
+def test_ring_wraps_with_many_pieces(api, tmp_path, monkeypatch, piece):
+    """Tiny staging pieces (SA_IO_PIECE_BYTES) push hundreds of pieces through the 12-slot ring and its
+    4 file threads, both directions."""
+    monkeypatch.setenv("SA_IO_PIECE_BYTES", piece)
+    g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_small")
+    words, wt = rz.encode_sorted(t, d, p)
+    off = rz.term_offsets(wt, vocab)
+    if piece == "64":                                            # keep the piece count reasonable
+        words, off = words[:int(off[3])], np.concatenate([off[:4], np.full(vocab - 3, off[3], np.uint64)])
+    dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api)
+    path = str(tmp_path / "ring.dat")
+    dev.save(path)
+    assert np.array_equal(np.fromfile(path, dtype=np.uint64), words)
+    dev2 = DeviceIndex.from_file(path, off, lens, tile_docs=1024, api=api)
+    back, back_off = dev2.words()
+    assert np.array_equal(back, words) and np.array_equal(back_off, off)
+    # terms in reverse file order: every term is its own run of pieces
+    rev = np.concatenate([words[int(off[k]):int(off[k + 1])] for k in range(vocab - 1, -1, -1)])
+    rpath = str(tmp_path / "rev.dat")
+    rev.tofile(rpath)
+    lens_t = np.diff(off.astype(np.int64))
+    starts = np.concatenate([[0], np.cumsum(lens_t[::-1])])[:-1][::-1]
+    md = {k: {"offset": int(starts[k]), "length": int(lens_t[k])} for k in range(vocab)}
+    dev3 = DeviceIndex.from_file(rpath, md, lens, n_terms=vocab, tile_docs=1024, api=api)
+    assert np.array_equal(dev3.words()[0], words)
+
+
 def test_save_round_trip_and_empty_index(api, tmp_path):
     g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_small")
     words, wt = rz.encode_sorted(t, d, p)
