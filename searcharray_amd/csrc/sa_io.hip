@@ -26,15 +26,20 @@ namespace {
 
 // bytes per staged piece (SA_IO_PIECE_BYTES: test hook, lets small files exercise the ring's wrap-around)
 static size_t sa_io_piece() {
-    size_t v = 16u << 20;
+    size_t v = 4u << 20;      // larger pieces only add page-locking time (~0.5 ms per MiB of ring), measured
     if (const char* e = getenv("SA_IO_PIECE_BYTES")) {
         const size_t x = (size_t)strtoull(e, nullptr, 10);
         if (x >= 64 && x <= (256u << 20)) v = x & ~(size_t)7;
     }
     return v;
 }
-constexpr int SA_IO_WORKERS = 4;            // file threads: a single pread / pwrite stream tops out near 10 GB/s
-constexpr int SA_IO_SLOTS = 3 * SA_IO_WORKERS;
+constexpr int SA_IO_SLOTS = 12;
+// file threads: a single pread / pwrite stream tops out near 10 GB/s (SA_IO_THREADS: 1..SA_IO_SLOTS / 2)
+static int sa_io_workers() {
+    int v = 4;
+    if (const char* e = getenv("SA_IO_THREADS")) v = atoi(e);
+    return v < 1 ? 1 : (v > SA_IO_SLOTS / 2 ? SA_IO_SLOTS / 2 : v);
+}
 
 struct Piece { u64 file_byte; u64 dev_word; u64 bytes; };
 
@@ -52,19 +57,47 @@ struct Ring {
 
     size_t piece = 0;
 
+    // Page-locking the ring costs more than streaming a small index through it, so one set of buffers is
+    // parked here between calls (per process; a second concurrent stream allocates its own).
+    struct Parked { std::mutex mu; void* buf[SA_IO_SLOTS] = {}; size_t piece = 0; bool full = false; };
+    static Parked& parked() { static Parked p; return p; }
+
     int init() {
         piece = sa_io_piece();
+        {
+            Parked& pk = parked();
+            std::lock_guard<std::mutex> lk(pk.mu);
+            if (pk.full && pk.piece == piece) {
+                for (int i = 0; i < SA_IO_SLOTS; i++) { buf[i] = pk.buf[i]; pk.buf[i] = nullptr; }
+                pk.full = false;
+            }
+        }
         for (int i = 0; i < SA_IO_SLOTS; i++) {
-            SA_HIP(hipHostMalloc(&buf[i], piece));
+            if (!buf[i]) SA_HIP(hipHostMalloc(&buf[i], piece));
             SA_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
         }
         return SA_OK;
     }
     ~Ring() {
-        for (int i = 0; i < SA_IO_SLOTS; i++) {
+        for (int i = 0; i < SA_IO_SLOTS; i++)
             if (done[i]) hipEventDestroy(done[i]);
-            if (buf[i]) hipHostFree(buf[i]);
+        bool complete = true;
+        for (int i = 0; i < SA_IO_SLOTS; i++) complete = complete && buf[i];
+        if (complete) {
+            Parked& pk = parked();
+            std::lock_guard<std::mutex> lk(pk.mu);
+            if (pk.full && pk.piece != piece) {                  // a ring of another piece size: replace it
+                for (int i = 0; i < SA_IO_SLOTS; i++) { hipHostFree(pk.buf[i]); pk.buf[i] = nullptr; }
+                pk.full = false;
+            }
+            if (!pk.full) {
+                for (int i = 0; i < SA_IO_SLOTS; i++) { pk.buf[i] = buf[i]; buf[i] = nullptr; }
+                pk.piece = piece;
+                pk.full = true;
+            }
         }
+        for (int i = 0; i < SA_IO_SLOTS; i++)
+            if (buf[i]) hipHostFree(buf[i]);
     }
     void stop(std::vector<std::thread>& workers) {
         {
@@ -102,6 +135,7 @@ int stream_in(int fd, const std::vector<Piece>& pieces, u64* d_words, hipStream_
     Ring ring;
     SA_TRY(ring.init());
     const u64 n = pieces.size();
+    const int SA_IO_WORKERS = sa_io_workers();
     std::vector<std::thread> workers;
     for (int w = 0; w < SA_IO_WORKERS; w++) {
         workers.emplace_back([&, w] {
@@ -163,6 +197,7 @@ int stream_out(int fd, u64 n_words, const u64* d_words, hipStream_t st) {
     const u64 total = n_words * sizeof(u64);
     const u64 SA_IO_PIECE = ring.piece;
     const u64 n = (total + SA_IO_PIECE - 1) / SA_IO_PIECE;
+    const int SA_IO_WORKERS = sa_io_workers();
     u64 written = 0;                                          // pieces on disk (any order), guarded by ring.mu
     u64 on_disk[SA_IO_SLOTS] = {};                            // piece index + 1 last written from the slot
     std::vector<std::thread> workers;
