@@ -212,6 +212,66 @@ def similarity_goldens():
     np.savez_compressed(os.path.join(OUT, "similarities.npz"), **out)
 
 
+def encoder_goldens():
+    """The reference's RoaringishEncoder (roaringish/roaringish.py:54-282) on seeded inputs, for key widths
+    28 (default), 32 and 20: encode with and without boundaries, decode, per-key counts, header / key
+    intersections, key partitions and slices."""
+    from searcharray.roaringish.roaringish import RoaringishEncoder, convert_keys
+    out = {}
+    rng = np.random.default_rng(808)
+    for kb in (28, 32, 20):
+        enc = RoaringishEncoder(np.uint64(kb))
+        L = int(enc.payload_lsb_bits)
+
+        def make(n_keys, max_key, mean):
+            keys = np.sort(rng.choice(max_key, size=n_keys, replace=False)).astype(np.uint64)
+            ks, ps = [], []
+            for k in keys:
+                m = max(1, rng.poisson(mean))
+                p = np.sort(rng.choice(6 * L, size=min(m, 6 * L), replace=False))
+                ks.append(np.full(len(p), k, dtype=np.uint64))
+                ps.append(p.astype(np.uint64))
+            return np.concatenate(ks), np.concatenate(ps)
+
+        tag = f"k{kb}_"
+        # three "terms" back to back with boundaries
+        parts = [make(40, 200, 5), make(25, 200, 9), make(60, 200, 2)]
+        keys = np.concatenate([p[0] for p in parts])
+        posns = np.concatenate([p[1] for p in parts])
+        bounds = np.cumsum([0] + [len(p[0]) for p in parts])[:-1].astype(np.uint64)
+        out[tag + "keys"], out[tag + "posns"], out[tag + "bounds"] = keys, posns, bounds
+        words, nb = enc.encode(keys=keys, payload=posns, boundaries=bounds)
+        out[tag + "enc_b"], out[tag + "enc_b_bounds"] = words, nb
+        a = words[int(nb[0]):int(nb[1])]
+        b = words[int(nb[1]):int(nb[2])]
+        single, none = enc.encode(keys=parts[0][0], payload=parts[0][1])
+        assert none is None and np.array_equal(single, a)
+        out[tag + "enc_nokeys"] = enc.encode(payload=parts[1][1][:12])[0]
+        dec = enc.decode(a)
+        out[tag + "dec_keys"] = np.asarray([k for k, _ in dec], dtype=np.uint64)
+        out[tag + "dec_lens"] = np.asarray([len(v) for _, v in dec], dtype=np.int64)
+        out[tag + "dec_vals"] = np.concatenate([v for _, v in dec]).astype(np.uint64)
+        out[tag + "dec_nokeys_n"] = np.asarray(len(enc.decode(a, get_keys=False)))
+        k, c = enc.num_values_per_key(a)
+        out[tag + "nvpk_k"], out[tag + "nvpk_c"] = k, c
+        out[tag + "keys_of"], out[tag + "keys_unique"] = enc.keys(a), enc.keys_unique(a)
+        out[tag + "msb"], out[tag + "lsb"], out[tag + "hdr"] = enc.payload_msb(a), enc.payload_lsb(a), enc.header(a)
+        for name, res in (("cand", enc.intersect_candidates(a, b)), ("rshift", enc.intersect_rshift(a, b)),
+                          ("isect", enc.intersect(a, b))):
+            for j, r in enumerate(res):
+                out[f"{tag}{name}_{j}"] = r
+        out[tag + "part2"] = enc.key_partition(a, np.uint64(200), 2)
+        out[tag + "part8"] = enc.key_partition(a, np.uint64(200), 8)
+        some = convert_keys([int(x) for x in np.unique(parts[0][0])[::3]] + [9999])
+        out[tag + "slice_keys_in"] = some
+        out[tag + "slice_keys"] = enc.slice(a, keys=some)
+        out[tag + "slice_hdr"] = enc.slice(a, header=enc.header(b))
+        out[tag + "slice_posn"] = enc.slice(a, min_payload=L, max_payload=3 * L - 1)
+        out[tag + "slice_keys_posn"] = enc.slice(a, keys=some, max_payload=2 * L - 1)
+    out["convert"] = np.concatenate([convert_keys(5), convert_keys([3, 1]), convert_keys(range(2, 6)), convert_keys(range(0))])
+    np.savez_compressed(os.path.join(OUT, "encoder.npz"), **out)
+
+
 def memmap_goldens():
     """The reference's on-disk index: SearchArray.index(..., data_dir=...) writes one raw uint64 .dat
     (phrase/memmap_arrays.py:158-161) and keeps {term_id: {offset, length}} metadata.  The fixture holds
@@ -246,7 +306,7 @@ def memmap_goldens():
 
 
 if __name__ == "__main__":
-    only = os.environ.get("ONLY", "")          # "" = everything, or one of: core, edismax, memmap, similarity
+    only = os.environ.get("ONLY", "")          # "" = everything, or one of: core, edismax, memmap, similarity, encoder
     if only in ("", "core"):
         snp_fixture_goldens()
         slopq = [([3, 7], 1), ([3, 7], 2), ([0, 1], 2), ([5, 2, 9], 2), ([10, 4], 3), ([1, 0], 1),
@@ -259,3 +319,5 @@ if __name__ == "__main__":
         memmap_goldens()
     if only in ("", "similarity"):
         similarity_goldens()
+    if only in ("", "encoder"):
+        encoder_goldens()
