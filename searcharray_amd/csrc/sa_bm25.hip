@@ -429,6 +429,15 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles_list(const Bm25Params
 // found by MSB-first bisection over the survivors only.
 #define SA_MERGE_LIST 2048
 
+// clears `words` u32 at `slots` and `n8` 8-byte cells at `bloom`
+__global__ void __launch_bounds__(256)
+sa_k_run_reset(u32* __restrict__ slots, u64 words, u64* __restrict__ bloom, u64 n8) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (u64 i = t; i < words; i += stride) slots[i] = 0u;
+    for (u64 i = t; i < n8; i += stride) bloom[i] = 0ull;
+}
+
 __global__ void __launch_bounds__(1024)
 sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__ out,
                 const u32* __restrict__ out_row, u32 rank_stride, const u32* __restrict__ cnt,
@@ -482,10 +491,13 @@ sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__
     };
 
     u64 thr = 1;
-    if (n_cand > SA_MERGE_LIST) {
-        if (gthr) {
-            thr = (u64)gthr[q] << 32;                 // histogram bound left behind by the tile kernel
-        } else if (slots) {
+    if (gthr) {
+        // histogram bound left behind by the scoring kernels: at least k docs score >= it, so only
+        // keys at or above it matter -- usually a few dozen, sorted by one wave below
+        thr = (u64)gthr[q] << 32;
+        if (thr < 1) thr = 1;
+    } else if (n_cand > SA_MERGE_LIST) {
+        if (slots) {
             u32 g = slots[(u64)q * 32 + (tid & 31)];
             g = sa_wave_min_u32(g);                   // every wave computes the same minimum
             thr = (u64)g << 32;
@@ -540,9 +552,29 @@ sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__
         n_sel = s_n;
     }
     n_sel = n_sel < SA_MERGE_LIST ? n_sel : SA_MERGE_LIST;
-    u32 np2 = 2;
-    while (np2 < n_sel) np2 <<= 1;
-    sa_block_bitonic_desc(sel, np2);
+    if (n_sel <= SA_WAVE) {                           // uniform
+        // short list: one wave sorts it in registers (bitonic over lanes, no barriers)
+        if (tid < SA_WAVE) {
+            u64 x = sel[tid];                         // slots past n_sel are 0
+#pragma unroll
+            for (u32 size = 2; size <= SA_WAVE; size <<= 1) {
+#pragma unroll
+                for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
+                    const u64 y = __shfl_xor(x, (int)stride, SA_WAVE);
+                    const bool lower = (tid & stride) == 0;           // this lane holds the pair's lower index
+                    const bool desc = (tid & size) == 0;
+                    const bool take_max = lower == desc;
+                    x = take_max ? (x > y ? x : y) : (x < y ? x : y);
+                }
+            }
+            sel[tid] = x;
+        }
+        __syncthreads();
+    } else {
+        u32 np2 = 2;
+        while (np2 < n_sel) np2 <<= 1;
+        sa_block_bitonic_desc(sel, np2);
+    }
     for (u32 i = tid; i < k; i += 1024) out[(u64)row * k + i] = (i < SA_MERGE_LIST) ? sel[i] : 0ull;
 }
 
@@ -997,8 +1029,14 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     p.gthr = use_hist ? bt->d_gthr : nullptr;
     p.qlist = nullptr; p.nq = bt->B;
     if (p.pruned) {
+        // one launch clears the per-run state: bound slots / cursors / histograms and, for dynamic
+        // pruning, the lead terms' Bloom filters (two memsets cost two launches and a gap)
         const size_t words = use_hist ? (size_t)bt->B * (34 + SA_HBINS) : (size_t)bt->B * 33;
-        SA_HIP(hipMemsetAsync(bt->d_slots, 0, words * sizeof(u32), st));
+        const size_t bloom8 = sparse ? bt->bloom_bytes / 8 : 0;            // bloom_bytes is a multiple of 1024
+        const size_t work = words + bloom8 + 1;
+        const u32 grid = work / 256 + 1 < 2048 ? (u32)(work / 256 + 1) : 2048u;
+        hipLaunchKernelGGL(sa_k_run_reset, dim3(grid), dim3(256), 0, st, bt->d_slots, (u64)words,
+                           (u64*)(sparse ? bt->d_bloom : nullptr), (u64)bloom8);
     }
     const u32 slot = bt->ev_n % SA_EVENT_RING;
     SA_HIP(hipEventRecord(bt->ev0[slot], st));

@@ -440,7 +440,7 @@ int sa_launch_sparse(sa_batch* bt, hipStream_t st) {
     p.bloom = (unsigned char*)bt->d_bloom; p.bloom_off = bt->d_bloom_off; p.bloom_shift = bt->d_bloom_shift;
     p.tile_shift = 0;
     while ((1u << p.tile_shift) < ix->tile_docs) p.tile_shift++;
-    hipMemsetAsync(bt->d_bloom, 0, bt->bloom_bytes, st);
+    // (the Bloom filters were cleared by sa_k_run_reset together with the bound state)
     p.qdf = bt->d_qdf; p.qrow8 = bt->d_qrow8;
     p.surv = bt->d_surv; p.surv_cap = bt->surv_cap; p.surv_cnt = bt->d_tile_q + bt->B + 1;
     const u64 n1 = bt->sparse_p1_total;                            // work items of phase 1
