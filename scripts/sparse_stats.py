@@ -22,8 +22,6 @@ cands, nq = batch.stats(True)
 tot_post = int(sum(df[t] for q in queries for t in q))
 print(json.dumps({"sparse_queries": nq, "of": B, "candidates": cands, "all_postings": tot_post,
                   "cand_per_sparse_query": cands / max(nq, 1)}))
-for lim in ("64", "256", "1024"):
-    pass
 batch.stats(False)
 for _ in range(3):
     batch.run()
