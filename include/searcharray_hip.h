@@ -109,6 +109,15 @@ int sa_key_sum_over(const uint64_t* ids, const uint64_t* count, int64_t n, uint6
 int sa_payload_slice(const uint64_t* arr, int64_t n, uint64_t payload_msb_mask, uint64_t min_payload,
                      uint64_t max_payload, uint64_t* out, int64_t* n_out);
 
+/* span_search(posns, lengths, phrase_freqs, slop, key_mask, header_mask, key_bits, lsb_bits)
+ * reference searcharray/roaringish/spans.pyx:189-330: the slop > 0 span state machine over the
+ * terms' candidate words, term t = posns[lengths[t] : lengths[t + 1]] (what phrase/spans.py:171-187
+ * passes after _intersect_all; default 28 / 18 / 18 layout, at most 16 terms).  Returns the documents
+ * whose count the walk raised, ascending, and the increments -- the values the reference adds into its
+ * Counter.  Outputs sized by the number of distinct doc ids in the input (<= lengths[n_terms] - lengths[0]). */
+int sa_span_search(const uint64_t* posns, const uint64_t* lengths, int n_terms, uint64_t slop,
+                   uint64_t* docs_out, uint64_t* counts_out, int64_t* n_out);
+
 /* HBM read-bandwidth probe (roofline calibration): streams `bytes` of device memory `reps`
  * times with 8-byte (mode 0) or 16-byte (mode 1) loads per lane; best GB/s. */
 int sa_stream_probe(uint64_t bytes, int mode, int reps, double* gbps_out);

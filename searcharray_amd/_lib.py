@@ -55,6 +55,7 @@ PROTOTYPES = {
     "sa_popcount_reduce_at": (c_int, [u64p, u64p, c_int64, u64p, f32p, i64p]),
     "sa_key_sum_over": (c_int, [u64p, u64p, c_int64, u64p, f32p, i64p]),
     "sa_payload_slice": (c_int, [u64p, c_int64, c_uint64, c_uint64, c_uint64, u64p, i64p]),
+    "sa_span_search": (c_int, [u64p, u64p, c_int, c_uint64, u64p, u64p, POINTER(c_int64)]),
     "sa_stream_probe": (c_int, [c_uint64, c_int, c_int, POINTER(c_double)]),
     # Part 2
     "sa_index_create": (c_int, [c_int, c_uint64, c_uint64, c_uint32, u64p, u64p, f32p, c_float,

@@ -364,3 +364,95 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
     hipLaunchKernelGGL(sa_k_counts_to_float, dim3((u32)(g < 8192 ? (g ? g : 1) : 8192)), dim3(256), 0, st, counts, running, N);
     return SA_OK;
 }
+
+// ---- kernel-level mirror of span_search(posns, lengths, phrase_freqs, slop, ...) -------------------
+// (reference roaringish/spans.pyx:322-330): the terms' candidate words back to back in `posns`,
+// term t = posns[lengths[t] : lengths[t + 1]], as phrase/spans.py:171-187 hands them over after
+// _intersect_all.  Runs stage 2 (the span machine above) on them and returns the documents whose
+// count it raised, ascending, with the increment -- what the reference adds into its Counter.
+struct NonZeroCounts {
+    const u32* counts; u64* docs; u64* incr;
+    __device__ __forceinline__ bool flag(u32 i) const { return counts[i] != 0; }
+    __device__ __forceinline__ void emit(u32 i, u32 pos) const { docs[pos] = i; incr[pos] = counts[i]; }
+};
+
+extern "C" int sa_span_search(const uint64_t* posns, const uint64_t* lengths, int n_terms, uint64_t slop,
+                              uint64_t* docs_out, uint64_t* counts_out, int64_t* n_out) {
+    SA_ARG(lengths && n_out, "null argument");
+    *n_out = 0;
+    SA_ARG(n_terms >= 1, "no terms");
+    if (n_terms > SA_SPAN_MAX_TERMS) { sa_set_error("slop phrases support at most %d terms", SA_SPAN_MAX_TERMS); return SA_ERR_UNSUPPORTED; }
+    const int T = n_terms;
+    for (int t = 0; t < T; t++) SA_ARG(lengths[t] <= lengths[t + 1], "lengths must be non-decreasing");
+    const u64 total = lengths[T] - lengths[0];
+    SA_ARG(total < 0xFFFFF000ull, "array too long");
+    if (lengths[1] == lengths[0]) return SA_OK;                       // term 0 drives the walk (spans.pyx:224)
+    SA_ARG(posns && docs_out && counts_out, "null argument");
+    // doc ids are bounded by the largest key of any term (each term's words are sorted)
+    u64 n_docs = 0;
+    for (int t = 0; t < T; t++)
+        if (lengths[t + 1] > lengths[t]) {
+            const u64 key = posns[lengths[t + 1] - 1] >> SA_KEY_SHIFT;
+            if (key + 1 > n_docs) n_docs = key + 1;
+        }
+    struct Bufs {
+        std::vector<void*> p;
+        ~Bufs() { for (void* x : p) hipFree(x); }
+        int take(void** out, size_t bytes) {
+            SA_HIP(hipMalloc(out, bytes ? bytes : 8));
+            p.push_back(*out);
+            return SA_OK;
+        }
+    } bufs;
+    hipStream_t st = 0;
+    u64* d_words; u32 *d_counts, *d_cnt, *d_chunks, *d_heads;
+    SA_TRY(bufs.take((void**)&d_words, (size_t)total * 8));
+    SA_TRY(bufs.take((void**)&d_counts, ((size_t)n_docs + 1) * 4));
+    SA_TRY(bufs.take((void**)&d_cnt, 4 * SA_SPAN_MAX_TERMS * 4));
+    SA_TRY(bufs.take((void**)&d_heads, ((size_t)total + T) * 4));
+    const size_t max_n = (size_t)(total > n_docs ? total : n_docs);
+    SA_TRY(bufs.take((void**)&d_chunks, ((size_t)sa_compact_chunks((u32)max_n + 1) + 8) * 4));
+    SA_HIP(hipMemcpyAsync(d_words, posns + lengths[0], (size_t)total * 8, hipMemcpyHostToDevice, st));
+    SA_HIP(hipMemsetAsync(d_counts, 0, ((size_t)n_docs + 1) * 4, st));
+    u32 h_cnt[4 * SA_SPAN_MAX_TERMS];
+    memset(h_cnt, 0, sizeof(h_cnt));
+    for (int t = 0; t < T; t++) h_cnt[t] = (u32)(lengths[t + 1] - lengths[t]);
+    SA_HIP(hipMemcpyAsync(d_cnt, h_cnt, sizeof(h_cnt), hipMemcpyHostToDevice, st));
+    u32 G = (h_cnt[0] + 63u) & ~63u;
+    u32 g_max = SA_SPAN_THREADS;
+    if (const char* v = getenv("SA_SPAN_THREADS")) { const int x = atoi(v); if (x >= 64) g_max = ((u32)x + 63u) & ~63u; }
+    if (G > g_max) G = g_max;
+    SpanEnt* ents; u64* col;
+    SA_TRY(bufs.take((void**)&ents, (size_t)G * SA_NSPANS * sizeof(SpanEnt)));
+    SA_TRY(bufs.take((void**)&col, (size_t)G * SA_NSPANS * sizeof(u64)));
+    SpanMachineParams mp;
+    memset(&mp, 0, sizeof(mp));
+    mp.T = T; mp.slop = (u32)(slop > 0xFFFFFFFFull ? 0xFFFFFFFFull : slop); mp.ents = ents; mp.col = col;
+    mp.counts = d_counts; mp.n_docs = n_docs; mp.n_threads = G;
+    for (int t = 0; t < T; t++) {
+        const u64 off = lengths[t] - lengths[0];
+        mp.cand[t] = d_words + off; mp.n_cand[t] = d_cnt + t;
+        mp.heads[t] = d_heads + off + t; mp.n_heads[t] = d_cnt + SA_SPAN_MAX_TERMS + t;
+        if (h_cnt[t] == 0) continue;
+        DocHeads dh;
+        dh.words = d_words + off; dh.out = d_heads + off + t;
+        sa_compact(dh, (const u32*)nullptr, h_cnt[t], d_chunks, d_cnt + SA_SPAN_MAX_TERMS + t, st);
+    }
+    hipLaunchKernelGGL(sa_k_span_machine, dim3(G / 64), dim3(64), 0, st, mp);
+    u64 *d_docs, *d_incr;
+    const size_t n_hit_max = (size_t)(n_docs < total ? n_docs : total) + 1;   // one hit per document group at most
+    SA_TRY(bufs.take((void**)&d_docs, n_hit_max * 8));
+    SA_TRY(bufs.take((void**)&d_incr, n_hit_max * 8));
+    NonZeroCounts nz; nz.counts = d_counts; nz.docs = d_docs; nz.incr = d_incr;
+    sa_compact(nz, (const u32*)nullptr, (u32)n_docs, d_chunks, d_cnt + 3 * SA_SPAN_MAX_TERMS, st);
+    SA_HIP(hipGetLastError());
+    u32 n = 0;
+    SA_HIP(hipMemcpyAsync(&n, d_cnt + 3 * SA_SPAN_MAX_TERMS, 4, hipMemcpyDeviceToHost, st));
+    SA_HIP(hipStreamSynchronize(st));
+    if (n) {
+        SA_HIP(hipMemcpy(docs_out, d_docs, (size_t)n * 8, hipMemcpyDeviceToHost));
+        SA_HIP(hipMemcpy(counts_out, d_incr, (size_t)n * 8, hipMemcpyDeviceToHost));
+    }
+    *n_out = n;
+    return SA_OK;
+}

@@ -8,6 +8,7 @@ include/searcharray_hip.h).  They exist for drop-in rebinding of the reference's
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Optional, Tuple
 
 import numpy as np
@@ -166,3 +167,25 @@ def payload_slice(arr, payload_msb_mask, min_payload=0, max_payload=0xFFFFFFFFFF
     _api(api).call("sa_payload_slice", p_u64(arr), len(arr), int(payload_msb_mask), int(min_payload),
                    int(max_payload) & 0xFFFFFFFFFFFFFFFF, p_u64(out), k)
     return out[:k.value].copy()
+
+
+def span_search(posns, lengths, phrase_freqs, slop, key_mask=None, header_mask=None, key_bits=None, lsb_bits=None,
+                api=None) -> None:
+    """``span_search`` of the reference (roaringish/spans.pyx:322-330): walk the terms' candidate words --
+    term t = ``posns[lengths[t]:lengths[t + 1]]`` -- with the slop span machine and add each document's
+    count into ``phrase_freqs`` (a Counter / dict-like).  Only the default 28 / 18 / 18 layout is
+    implemented on the device."""
+    if key_bits is not None and int(key_bits) != 28 or lsb_bits is not None and int(lsb_bits) != 18:
+        raise NotImplementedError("span_search on the device supports the default 28/18/18 layout only")
+    if key_mask is not None and int(key_mask) != 0xFFFFFFF000000000 or \
+            header_mask is not None and int(header_mask) != 0xFFFFFFFFFFFC0000:
+        raise NotImplementedError("span_search on the device supports the default 28/18/18 layout only")
+    posns, lengths = as_u64(posns), as_u64(lengths)
+    n_max = max(1, int(lengths[-1] - lengths[0]))
+    docs = np.empty(n_max, dtype=np.uint64)
+    counts = np.empty(n_max, dtype=np.uint64)
+    n = ctypes.c_int64(0)
+    _api(api).call("sa_span_search", p_u64(posns), p_u64(lengths), len(lengths) - 1, int(slop), p_u64(docs),
+                   p_u64(counts), ctypes.byref(n))
+    for d, c in zip(docs[:n.value].tolist(), counts[:n.value].tolist()):
+        phrase_freqs[d] += c

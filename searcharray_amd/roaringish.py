@@ -268,4 +268,4 @@ class RoaringishEncoder:
 
 # the rest of the reference package's surface (searcharray/roaringish/__init__.py:1-7), GPU-backed
 from .ops import (adjacent, intersect, key_sum_over, merge, popcount64, popcount_reduce_at,   # noqa: E402,F401
-                  sort_merge_counts, unique)
+                  sort_merge_counts, span_search, unique)

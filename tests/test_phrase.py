@@ -289,3 +289,37 @@ def test_phrase_batch_errors(api):
     assert list(docs[0, :1]) == [0] and docs[0, 1] == NO_DOC
     assert list(docs[1]) == [0, 1, NO_DOC]
     bt.close()
+
+
+def test_span_search_mirror_matches_oracle(api):
+    """ops.span_search -- the kernel-level mirror of the reference's span_search(posns, lengths, Counter, slop,
+    masks...) (roaringish/spans.pyx:322-330) -- fed with the candidate words _intersect_all selects, against the
+    oracle's restatement of the same state machine (pinned to the reference by the slop goldens)."""
+    from collections import Counter
+    from oracle import spans as S
+    from searcharray_amd import ops
+    g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_small")
+    words, wt = rz.encode_sorted(t, d, p)
+    off = rz.term_offsets(wt, vocab).astype(np.int64)
+    rng = np.random.default_rng(3)
+    checked = 0
+    for trial in range(25):
+        T = int(rng.integers(2, 5))
+        terms = [int(x) for x in rng.choice(30, size=T, replace=False)]
+        slop = int(rng.integers(1, 5))
+        enc = [words[off[x]:off[x + 1]] for x in terms]
+        posns, lengths = S.intersect_all(enc)
+        want_ids, want_counts = S.span_search(enc, slop)
+        want = {int(k): int(v) for k, v in zip(want_ids, want_counts) if v != 0}
+        got = Counter()
+        ops.span_search(posns, lengths, got, np.uint64(slop), np.uint64(0xFFFFFFF000000000), np.uint64(0xFFFFFFFFFFFC0000),
+                        np.uint64(28), np.uint64(18), api=api)
+        assert {k: v for k, v in got.items() if v} == want, (terms, slop)
+        checked += len(want)
+    assert checked > 50
+    # empty first term: nothing to walk; other layouts are refused
+    got = Counter()
+    ops.span_search(np.asarray([5 << 36 | 1], dtype=np.uint64), np.asarray([0, 0, 1], dtype=np.uint64), got, 2, api=api)
+    assert not got
+    with pytest.raises(NotImplementedError):
+        ops.span_search(np.empty(0, np.uint64), np.zeros(3, np.uint64), got, 1, key_bits=32, api=api)
