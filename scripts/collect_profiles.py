@@ -38,7 +38,8 @@ def main():
     os.makedirs(PROF, exist_ok=True)
     for src, dst in [("bench.log", f"bench_{RND}.json"), ("bench_k100.log", f"bench_{RND}_k100.json"),
                      ("bench_k1000.log", f"bench_{RND}_k1000.json"), ("phrase_bench.log", f"phrase_bench_{RND}.json"),
-                     ("slop_bench.log", f"slop_bench_{RND}.json"), ("dist1_rccl.log", f"bench_{RND}_dist1rank_1250k.json")]:
+                     ("slop_bench.log", f"slop_bench_{RND}.json"), ("dist1_rccl.log", f"bench_{RND}_dist1rank_1250k.json"),
+                     ("io_bench.log", f"io_bench_{RND}.json"), ("sim_bench.log", f"sim_bench_{RND}.json")]:
         j = last_json_line(os.path.join(OUT, src))
         if j is not None:
             json.dump(j, open(os.path.join(PROF, dst), "w"), indent=1)

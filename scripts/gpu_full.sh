@@ -14,6 +14,8 @@ cd $R
 ( time timeout 900 python bench.py --corpus-cache /tmp/corpus --k 100 --no-cpu-baseline --steps 10 ) > $O/bench_k100.log 2>&1
 ( time timeout 900 python scripts/phrase_bench.py ) > $O/phrase_bench.log 2>&1
 ( time timeout 900 python scripts/slop_bench.py ) > $O/slop_bench.log 2>&1
+( time timeout 600 python scripts/io_bench.py ) > $O/io_bench.log 2>&1
+( time timeout 600 python scripts/sim_bench.py ) > $O/sim_bench.log 2>&1
 DOCS=1250000 bash scripts/gpu_dist1.sh
 cd /tmp
 ( timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --corpus-cache /tmp/corpus ) > $O/prof_stats.log 2>&1
