@@ -402,7 +402,8 @@ int sa_index_derive(sa_index* ix) {
         std::sort(cand.begin(), cand.end(), [](const std::pair<u64, u32>& a, const std::pair<u64, u32>& b) {
             return a.first != b.first ? a.first > b.first : a.second < b.second;
         });
-        const u64 budget_rows = ix->n_docs ? (ix->n_postings * 8 + (64ull << 20)) / ix->n_docs : 0;
+        u64 budget_rows = ix->n_docs ? (ix->n_postings * 8 + (64ull << 20)) / ix->n_docs : 0;
+        if (const char* mr = getenv("SA_TF8_MAXROWS")) budget_rows = strtoull(mr, nullptr, 10);
         if (cand.size() > budget_rows) cand.resize((size_t)budget_rows);
         if (cand.size() > 4096) cand.resize(4096);
         ix->n_tf8_terms = (u32)cand.size();
