@@ -132,6 +132,38 @@ __device__ __forceinline__ float sa_sparse_score(const SparseParams& p, u32 q, u
                                                  u32 known_dl) {
     const u32 tile = (u32)(doc >> p.tile_shift);
     float s = 0.f;
+    if (p.T <= 4 && p.dl_packed) {
+        // Up to four terms (the common query shape): fetch every term's tf FIRST -- the probes are
+        // independent random accesses (dense tf rows, tile slices), mostly L2 misses, and issued back to
+        // back they overlap instead of paying one memory round trip per term.  The doc length is the
+        // doc's, not the term's: the known posting carries it, no doc_lens load.
+        u32 tfv[4];
+        bool look[4];                                               // term present in the query and not the known one
+#pragma unroll
+        for (u32 t = 0; t < 4; t++) {                               // pass 1: the dense-row bytes, no dependent branches
+            tfv[t] = 0; look[t] = false;
+            if (t >= p.T) continue;
+            const u32 qt = q * p.T + t;
+            if (p.terms[qt] >= p.n_terms) continue;
+            if (t == known_t) { tfv[t] = known_tf; continue; }
+            look[t] = true;
+            const u32 row8 = p.qrow8[qt];
+            tfv[t] = row8 != SA_DD_NONE ? (u32)p.tf8[(u64)row8 * p.n_docs + doc] : 255u;
+        }
+#pragma unroll
+        for (u32 t = 0; t < 4; t++) {                               // pass 2: terms without a row / saturated bytes
+            if (look[t] && tfv[t] == 255u) {
+                u32 dl_unused;
+                tfv[t] = sa_sparse_tf(p, q * p.T + t, p.terms[q * p.T + t], doc, tile, dl_unused);
+            }
+        }
+#pragma unroll
+        for (u32 t = 0; t < 4; t++) {
+            if (t >= p.T || tfv[t] == 0) continue;
+            s = __fadd_rn(s, sa_sparse_term_score(p, tfv[t], known_dl, doc, p.idf[q * p.T + t]));
+        }
+        return s;
+    }
     for (u32 t = 0; t < p.T; t++) {
         const u32 qt = q * p.T + t;
         const u32 term = p.terms[qt];
