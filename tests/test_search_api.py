@@ -226,6 +226,24 @@ def test_slices_use_subset_local_docfreq(default_api):
     assert np.allclose(sl2.score("bar"), [0.69534695, 0.0, 0.69534695, 0.93790984, 0.7496305, 0.0], rtol=1e-6)
 
 
+def test_permuted_and_repeated_views_score_row_by_row(default_api):
+    """A view in arbitrary row order or with repeated rows (a sorted DataFrame, `take`): every row gets the
+    value of its own document, with the docfreq of the view's distinct docs.  (Deliberate difference: the
+    reference's subset path assumes sorted unique rows and returns misaligned values here -- DESIGN 4.)"""
+    docs = ["foo bar bar baz", "data2", "data3 bar", "bunny funny wunny"] * 25
+    arr = SearchArray.index(docs)
+    sorted_rows = np.asarray([0, 2, 4, 6])
+    base = arr[sorted_rows]
+    want = dict(zip(sorted_rows.tolist(), base.score("bar").tolist()))
+    want_ph = dict(zip(sorted_rows.tolist(), base.score(["bar", "baz"]).tolist()))
+    for rows in ([6, 4, 2, 0], [2, 0, 2, 6, 4, 4]):
+        view = arr.take(rows)
+        assert view.docfreq("bar") == base.docfreq("bar")
+        assert view.score("bar").tolist() == [want[r] for r in rows]
+        assert view.score(["bar", "baz"]).tolist() == [want_ph[r] for r in rows]
+        assert view.termfreqs("bar").tolist() == [2.0 if r % 4 == 0 else 1.0 for r in rows]
+
+
 def test_batched_search_matches_score_loops(default_api):
     """SearchArray.search / search_phrases == top-k of the dense score() the reference's callers build"""
     rng = np.random.default_rng(3)
