@@ -653,6 +653,10 @@ extern "C" int sa_index_similarity_dense(sa_index_t* ix, const uint32_t* terms, 
     SA_ARG(kind == SA_SIM_BM25_IMPACT || kind == SA_SIM_BM25_LEGACY || kind == SA_SIM_CLASSIC,
            "kind must be SA_SIM_BM25_IMPACT, SA_SIM_BM25_LEGACY or SA_SIM_CLASSIC");
     SA_ARG(n_terms >= 1, "no terms");
+    if (sa_vec_target_pending(ix, true)) {
+        sa_set_error("sa_index_select_vec cannot be combined with sa_index_similarity_dense (float32 BM25 / tf results only)");
+        return SA_ERR_STATE;
+    }
     tl_sim.ix = ix; tl_sim.kind = kind; tl_sim.idf = idf; tl_sim.k1 = k1; tl_sim.b = b;
     const int rc = n_terms == 1
         ? sa_index_termfreqs_dense_posn(ix, terms[0], min_posn, max_posn, (float*)out)

@@ -234,6 +234,13 @@ extern "C" int sa_index_select_vec(sa_index_t* ix, sa_vec_t* out32, float boost,
     return SA_OK;
 }
 
+// a diversion is pending for this thread's next dense call on `ix`; clear = drop it
+bool sa_vec_target_pending(const sa_index* ix, bool clear) {
+    const bool pending = tl_vec.ix == ix;
+    if (pending && clear) { tl_vec.ix = nullptr; tl_vec.v = nullptr; }
+    return pending;
+}
+
 // called by sa_emit_dense / sa_emit_zeros (sa_index.hip): true if the result was diverted into a vector
 bool sa_emit_to_vec(sa_index* ix, const float* d_vec) {
     if (tl_vec.ix != ix) return false;
