@@ -25,6 +25,8 @@ struct sa_batch {
     u32 tab_w = 0;
     u32* d_bounds = nullptr;        // [B][T][n_tiles+1] slice table
     u64* d_qbase = nullptr;         // [B][T]
+    std::shared_ptr<sa_impacts> impacts;   // impact stream of this batch's (k1, b), or null (tile kernel reads the TF postings)
+    u64* d_qbase_imp = nullptr;     // [B][T] base of each query term in the impact stream
     u32 cand_cap = 0;               // keys per query in d_cand
     bool cap_limited = false;       // cand_cap below the worst case: overflow must be checked
     u32* d_cand_cnt = nullptr;      // [B] append cursors (pruned selection)

@@ -44,6 +44,9 @@ struct Bm25Params {
     u32 tab_w;             // 0: no table (doc lengths not packed in the postings); else 64/128
     const u32* bounds;     // [B][T][n_tiles+1] slice table (sa_k_make_bounds)
     const u64* qbase;      // [B][T] posting base of each query term
+    const u64* imp;        // impact stream (sa_impacts, sa_index.hpp) or null: score the TF postings
+    const u64* qbase_imp;  // [B][T] base of each query term in the impact stream
+    int imp_route;         // 1 / 2: see sa_bm25_tile_item
     u32 B, T, k;
     float k1, b, avgdl;
     int pruned;            // 1: wave-level selection against a global bound (MODE 1); 0: block-level selection (MODE 0)
@@ -68,6 +71,94 @@ struct Bm25Params {
     float* dense_out;      // [B][n_docs] or null
     u64* cand;             // [B][n_tiles][k] composite keys (global doc ids) or null
 };
+
+// ---- impact stream ---------------------------------------------------------------------------------
+// The exhaustive tile kernel is bound by instruction issue per posting, not by posting bytes.
+// Everything of a posting's score except the final `* idf` depends only on (tf, doc_len) and the batch
+// constants k1, b, avgdl, so it is evaluated ONCE per (k1, b) for the whole shard -- with the reference's
+// operation order (bm25.pyx:19-23), so the bits are the ones the per-posting arithmetic would give -- and
+// kept beside the TF postings in the layout the tile kernel wants (sa_impacts in sa_index.hpp): per
+// posting the kernel is left with a subtract, a compare, a multiply and the LDS read-modify-write.
+sa_impacts::~sa_impacts() {
+    if (d_imp) {
+        hipSetDevice(device);
+        hipFree(d_imp);
+    }
+}
+
+__host__ __device__ __forceinline__ u64 sa_imp_base(u64 tf_base, u32 term) { return (tf_base + term + 1ull) & ~1ull; }
+
+__global__ void __launch_bounds__(256)
+sa_k_make_impacts(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, const float* __restrict__ doc_lens,
+                  u32 n_terms, u64 n_postings, int dl_packed, float k1, float b, float avgdl, u64* __restrict__ imp) {
+    constexpr u32 CHUNK = 2048;
+    __shared__ u32 s_t[2];
+    const float one_minus_b = 1.0f - b;
+    const u64 n_chunks = (n_postings + CHUNK - 1) / CHUNK;
+    for (u64 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const u64 first = c * CHUNK;
+        const u64 last = first + CHUNK <= n_postings ? first + CHUNK - 1 : n_postings - 1;
+        // terms of the chunk's first and last posting: largest t with tf_off[t] <= i
+        if (threadIdx.x < 2) {
+            const u64 i = threadIdx.x == 0 ? first : last;
+            u32 lo = 0, hi = n_terms;                  // answer in [lo, hi)
+            while (hi - lo > 1) {
+                const u32 mid = lo + (hi - lo) / 2;
+                if (tf_off[mid] <= i) lo = mid; else hi = mid;
+            }
+            s_t[threadIdx.x] = lo;
+        }
+        __syncthreads();
+        const u32 t_first = s_t[0], t_last = s_t[1];
+        for (u64 i = first + threadIdx.x; i <= last; i += blockDim.x) {
+            u32 lo = t_first, hi = t_last + 1;
+            while (hi - lo > 1) {
+                const u32 mid = lo + (hi - lo) / 2;
+                if (tf_off[mid] <= i) lo = mid; else hi = mid;
+            }
+            const u64 tbase = tf_off[lo];
+            const u64 x = tfp[i];
+            const u32 doc = (u32)(x >> SA_KEY_SHIFT);
+            const float tf = (float)(u32)(x & SA_LSB_MASK);
+            const float dl = dl_packed ? (float)(u32)((x >> SA_LSB_BITS) & SA_LSB_MASK) : doc_lens[doc];
+            const float norm = __fmul_rn(k1, __fadd_rn(one_minus_b, __fmul_rn(b, __fdiv_rn(dl, avgdl))));
+            const float sat = __fdiv_rn(tf, __fadd_rn(tf, norm));
+            imp[sa_imp_base(tbase, lo) + (i - tbase)] = ((u64)doc << 32) | (u64)__float_as_uint(sat);
+        }
+        __syncthreads();
+    }
+}
+
+// The impact stream of (k1, b) for this index: the cached one, or a new one (the cache keeps the most
+// recent; batches built earlier keep theirs alive).  Null when switched off (SA_IMPACT=0), for an empty
+// shard, or when HBM is short -- the tile kernel then scores the TF postings.  Call with the index lock held.
+static std::shared_ptr<sa_impacts> sa_impacts_get(sa_index* ix, float k1, float b) {
+    const char* env = getenv("SA_IMPACT");
+    if (env && atoi(env) == 0) return nullptr;
+    if (ix->n_postings == 0 || ix->n_terms == 0 || ix->avg_doc_len == 0.f) return nullptr;
+    // (bit patterns: a NaN parameter must still find its own stream)
+    auto same = [](float x, float y) { return memcmp(&x, &y, sizeof(float)) == 0; };
+    if (ix->impacts && same(ix->impacts->k1, k1) && same(ix->impacts->b, b) && same(ix->impacts->avgdl, ix->avg_doc_len))
+        return ix->impacts;
+    std::shared_ptr<sa_impacts> im(new (std::nothrow) sa_impacts());
+    if (!im) return nullptr;
+    im->device = ix->device; im->k1 = k1; im->b = b; im->avgdl = ix->avg_doc_len;
+    im->n = sa_imp_base(ix->n_postings, ix->n_terms) + 2;
+    if (hipMalloc(&im->d_imp, im->n * sizeof(u64)) != hipSuccess) {
+        (void)hipGetLastError();
+        im->d_imp = nullptr;
+        return nullptr;
+    }
+    hipStream_t st = ix->stream;
+    if (hipMemsetAsync(im->d_imp, 0xFF, im->n * sizeof(u64), st) != hipSuccess) return nullptr;
+    const u64 n_chunks = (ix->n_postings + 2047) / 2048;
+    const u32 grid = n_chunks < 16384 ? (u32)n_chunks : 16384u;
+    hipLaunchKernelGGL(sa_k_make_impacts, dim3(grid), dim3(256), 0, st, ix->d_tfp, ix->d_tf_off, ix->d_doc_lens,
+                       ix->n_terms, ix->n_postings, ix->dl_packed ? 1 : 0, k1, b, ix->avg_doc_len, im->d_imp);
+    if (hipGetLastError() != hipSuccess) return nullptr;
+    ix->impacts = im;
+    return im;
+}
 
 // Saturation table of a batch, laid out [dl][tf - 1].  For integer doc lengths dl < tab_w and term frequencies
 // 1 <= tf <= SA_SAT_NTF the per-posting factor  tf / (tf + k1 * ((1 - b) + b * (dl / avgdl)))
@@ -95,29 +186,39 @@ __global__ void sa_k_make_sattab(float* __restrict__ tab, u32 tab_w, float k1, f
 __global__ void __launch_bounds__(256)
 sa_k_make_bounds(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, const u32* __restrict__ dir_slot,
                  const u32* __restrict__ tile_dir, u32 n_terms, u32 n_tiles, u32 tile_docs,
-                 const u32* __restrict__ terms, u32 BT, u32* __restrict__ bounds, u64* __restrict__ qbase) {
+                 const u32* __restrict__ terms, u32 BT, u32* __restrict__ bounds, u64* __restrict__ qbase,
+                 u64* __restrict__ qbase_imp) {
     const u64 total = (u64)BT * (n_tiles + 1);
     for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (u64)gridDim.x * blockDim.x) {
         const u32 qt = (u32)(e / (n_tiles + 1)), tile = (u32)(e % (n_tiles + 1));
         const u32 term = terms[qt];
         u32 rel = 0;
-        u64 base = 0;
+        u64 base = 0, ibase = 0;
         if (term < n_terms) {
             base = tf_off[term];
+            ibase = sa_imp_base(base, term);
             const u32 cnt = (u32)(tf_off[term + 1] - base);
             const u32 slot = dir_slot[term];
             if (slot != 0xFFFFFFFFu) rel = tile_dir[(u64)slot * (n_tiles + 1) + tile];
             else rel = sa_lower_bound(tfp + base, 0, cnt, ((u64)tile * tile_docs) << SA_KEY_SHIFT, SA_KEY_MASK);
         }
         bounds[e] = rel;
-        if (tile == 0) qbase[qt] = base;
+        if (tile == 0) {
+            qbase[qt] = base;
+            if (qbase_imp) qbase_imp[qt] = ibase;
+        }
     }
 }
 
 // MODE 0: dense output and/or block-level threshold top-k (any k <= 1024).
 // MODE 1: pruned wave-level top-k against the query's global bound (any k <= 1024), the batch fast path.
 // One work item = one (tile, query) pair; `nq` queries are in play (p.qlist maps them, if set).
-template <int TILE, int THREADS, int MODE>
+// IMP != 0: read the impact stream (p.imp / p.qbase_imp) instead of the TF postings.
+//   1: one posting at a time (LDS read -> add -> write, masked lanes skipped by branches)
+//   2: full 8-posting batches update their accumulators together -- 8 LDS reads in flight, then the adds,
+//      then 8 writes; a posting outside the tile is steered to a spare slot behind the tile instead of
+//      being branched around.  Partial batches (short slices, the tail of a long one) take route 1.
+template <int TILE, int THREADS, int MODE, int IMP>
 __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32 item, const u32 nq) {
     constexpr int NW = THREADS / SA_WAVE;
     constexpr int E = TILE / THREADS;
@@ -125,9 +226,9 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     constexpr int LE = (CAP + THREADS - 1) / THREADS;
     constexpr size_t ACC_BYTES = (size_t)TILE * 4;
     constexpr size_t SEL_BYTES = MODE == 0 ? (size_t)(CAP + SA_KMAX) * 8 : 0;
-    constexpr size_t SMEM_U64 = (ACC_BYTES > SEL_BYTES ? ACC_BYTES : SEL_BYTES) / 8;
+    constexpr size_t SMEM_U64 = (ACC_BYTES > SEL_BYTES ? ACC_BYTES : SEL_BYTES) / 8 + 2;   // + the spare slot acc[TILE]
     constexpr int PF = 4;                                       // 16-byte loads in flight per lane
-    __shared__ u64 smem[SMEM_U64];
+    __shared__ alignas(16) u64 smem[SMEM_U64];
     __shared__ u64 s_lo[SA_MAX_QTERMS], s_hi[SA_MAX_QTERMS];
     __shared__ u64 red64[NW + 1];
     __shared__ u32 red[NW + 1];
@@ -143,7 +244,9 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     const u32 tid = threadIdx.x;
     const u32 T = p.T;
     const u32 tab_w = p.tab_w;
-    for (u32 i = tid; i < SA_SAT_NTF * tab_w; i += THREADS) s_tab[i] = p.sattab[i];
+    if constexpr (IMP == 0) {
+        for (u32 i = tid; i < SA_SAT_NTF * tab_w; i += THREADS) s_tab[i] = p.sattab[i];
+    }
     // (queries answered by the sparse candidate path, sa_sparse.hip, are not in the list)
     const u32 tile = item / nq;
     const u32 q = p.qlist ? p.qlist[item % nq] : item % nq;
@@ -163,7 +266,7 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     if (tid < T) {
         const u32 qt = q * T + tid;
         const u32* row = p.bounds + (u64)qt * (p.n_tiles + 1) + tile;
-        const u64 base = p.qbase[qt];
+        const u64 base = IMP != 0 ? p.qbase_imp[qt] : p.qbase[qt];
         s_lo[tid] = base + row[0];
         s_hi[tid] = base + row[1];
     }
@@ -197,6 +300,15 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
             acc[d] = __fadd_rn(acc[d], __fmul_rn(sat, idf));
         }
     };
+    // Impact stream: the factor is in the posting and a posting is valid iff its doc lies in this tile
+    // (terms start on even indices and gaps hold an all-ones sentinel, so whatever else a pair load of
+    // the hull brings along -- the previous / next tile's posting, padding -- fails the same test).
+    const u32 tile_base32 = (u32)tile_base;
+    auto score_imp = [&](u64 x, float idf) {
+        const u32 d = (u32)(x >> 32) - tile_base32;
+        if (d < (u32)TILE) acc[d] = __fadd_rn(acc[d], __fmul_rn(__uint_as_float((u32)x), idf));
+    };
+    const u64* const stream = IMP != 0 ? p.imp : p.tfp;
     struct Batch { sa_u64x2 v[PF]; };
     // All indices below are relative to a0, the 16-byte-aligned start of the slice's hull: a slice is
     // far shorter than 2^32 postings, so the per-posting bookkeeping is 32-bit.
@@ -205,27 +317,56 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
         Batch b;
         const u64 a0 = lo & ~1ull;
         const u32 npairs = (hi > a0) ? (u32)((hi - a0 + 1) >> 1) : 0u;
-        const sa_u64x2* pairs = (const sa_u64x2*)(p.tfp + a0);
+        const sa_u64x2* pairs = (const sa_u64x2*)(stream + a0);
+        const u64 fill = IMP != 0 ? ~0ull : 0ull;
 #pragma unroll
         for (int u = 0; u < PF; u++) {
             const u32 j = first + (u32)u * THREADS + tid;
             if (j < npairs) b.v[u] = pairs[j];
-            else { b.v[u].x = 0; b.v[u].y = 0; }
+            else { b.v[u].x = fill; b.v[u].y = fill; }
         }
         return b;
     };
     auto score_batch = [&](const Batch& b, u64 lo, u64 hi, u32 first, float idf) {
         const u64 a0 = lo & ~1ull;
         const u32 npairs = (hi > a0) ? (u32)((hi - a0 + 1) >> 1) : 0u;
+        if constexpr (IMP == 2) {
+            // wave-uniform: this wave has pairs at every step of the batch (lanes past the end hold sentinels)
+            if (first + (u32)(PF - 1) * THREADS + (tid & ~(u32)(SA_WAVE - 1)) < npairs) {
+                u32 slot[2 * PF];
+                float val[2 * PF];
+#pragma unroll
+                for (int u = 0; u < PF; u++) {
+                    const u32 d0 = (u32)(b.v[u].x >> 32) - tile_base32, d1 = (u32)(b.v[u].y >> 32) - tile_base32;
+                    slot[2 * u] = d0 < (u32)TILE ? d0 : (u32)TILE;
+                    slot[2 * u + 1] = d1 < (u32)TILE ? d1 : (u32)TILE;
+                }
+#pragma unroll
+                for (int i = 0; i < 2 * PF; i++) val[i] = acc[slot[i]];
+#pragma unroll
+                for (int u = 0; u < PF; u++) {
+                    val[2 * u] = __fadd_rn(val[2 * u], __fmul_rn(__uint_as_float((u32)b.v[u].x), idf));
+                    val[2 * u + 1] = __fadd_rn(val[2 * u + 1], __fmul_rn(__uint_as_float((u32)b.v[u].y), idf));
+                }
+#pragma unroll
+                for (int i = 0; i < 2 * PF; i++) acc[slot[i]] = val[i];
+                return;
+            }
+        }
         const u32 r_lo = (u32)(lo - a0), r_hi = (u32)(hi - a0);     // the slice inside its hull
 #pragma unroll
         for (int u = 0; u < PF; u++) {
             // wave-uniform skip: no lane of this wave has a pair at this step
             const u32 jw = first + (u32)u * THREADS + (tid & ~(u32)(SA_WAVE - 1));
             if (jw >= npairs) continue;
-            const u32 r0 = 2u * (first + (u32)u * THREADS + tid);
-            score_into(b.v[u].x, r0 >= r_lo && r0 < r_hi, idf);
-            score_into(b.v[u].y, r0 + 1u < r_hi, idf);           // r0 + 1 >= r_lo always holds
+            if constexpr (IMP != 0) {
+                score_imp(b.v[u].x, idf);
+                score_imp(b.v[u].y, idf);
+            } else {
+                const u32 r0 = 2u * (first + (u32)u * THREADS + tid);
+                score_into(b.v[u].x, r0 >= r_lo && r0 < r_hi, idf);
+                score_into(b.v[u].y, r0 + 1u < r_hi, idf);       // r0 + 1 >= r_lo always holds
+            }
         }
     };
     Batch cur = load_batch(s_lo[0], s_hi[0], 0);
@@ -397,20 +538,20 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     }   // top-k
 }
 
-template <int TILE, int THREADS, int MODE>
+template <int TILE, int THREADS, int MODE, int IMP>
 __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
-    sa_bm25_tile_item<TILE, THREADS, MODE>(p, blockIdx.x, p.nq);
+    sa_bm25_tile_item<TILE, THREADS, MODE, IMP>(p, blockIdx.x, p.nq);
 }
 
 // The queries the sparse candidate path handed back (usually none): their number is only known on the
 // device, so a resident grid walks the (tile, query) items of the list -- no host round trip to size a
 // launch.  Slower per item than one workgroup per item, which does not matter for a rare fallback.
-template <int TILE, int THREADS>
+template <int TILE, int THREADS, int IMP>
 __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles_list(const Bm25Params p) {
     const u32 nq = *p.nq_dev;
     const u64 n_items = (u64)nq * p.n_tiles;
     for (u64 item = blockIdx.x; item < n_items; item += gridDim.x) {
-        sa_bm25_tile_item<TILE, THREADS, 1>(p, (u32)item, nq);
+        sa_bm25_tile_item<TILE, THREADS, 1, IMP>(p, (u32)item, nq);
         __syncthreads();                              // LDS is reused by the next item
     }
 }
@@ -611,12 +752,13 @@ static int sa_launch_make_sattab(sa_index* ix, float* d_tab, u32* tab_w_out, flo
     return SA_OK;
 }
 
-static int sa_launch_make_bounds(sa_index* ix, const u32* d_terms, u32 BT, u32* d_bounds, u64* d_qbase, hipStream_t st) {
+static int sa_launch_make_bounds(sa_index* ix, const u32* d_terms, u32 BT, u32* d_bounds, u64* d_qbase, hipStream_t st,
+                                 u64* d_qbase_imp = nullptr) {
     const u64 total = (u64)BT * (ix->n_tiles + 1);
     if (total == 0) return SA_OK;
     const u32 grid = total / 256 + 1 < 8192 ? (u32)(total / 256 + 1) : 8192;
     hipLaunchKernelGGL(sa_k_make_bounds, dim3(grid), dim3(256), 0, st, ix->d_tfp, ix->d_tf_off, ix->d_dir_slot,
-                       ix->d_tile_dir, ix->n_terms, ix->n_tiles, ix->tile_docs, d_terms, BT, d_bounds, d_qbase);
+                       ix->d_tile_dir, ix->n_terms, ix->n_tiles, ix->tile_docs, d_terms, BT, d_bounds, d_qbase, d_qbase_imp);
     return SA_OK;
 }
 
@@ -627,7 +769,12 @@ static int sa_env_int(const char* name, int dflt) {
 
 #define SA_LAUNCH_TILE(TILE, THREADS)                                                              \
     {                                                                                              \
-        hipLaunchKernelGGL((sa_k_bm25_tiles<TILE, THREADS, MODE>), dim3((u32)n_items), dim3(THREADS), 0, st, p); \
+        if (MODE == 1 && p.imp && p.imp_route == 2)                                                \
+            hipLaunchKernelGGL((sa_k_bm25_tiles<TILE, THREADS, MODE, MODE == 1 ? 2 : 0>), dim3((u32)n_items), dim3(THREADS), 0, st, p); \
+        else if (MODE == 1 && p.imp)                                                               \
+            hipLaunchKernelGGL((sa_k_bm25_tiles<TILE, THREADS, MODE, MODE == 1 ? 1 : 0>), dim3((u32)n_items), dim3(THREADS), 0, st, p); \
+        else                                                                                       \
+            hipLaunchKernelGGL((sa_k_bm25_tiles<TILE, THREADS, MODE, 0>), dim3((u32)n_items), dim3(THREADS), 0, st, p); \
     }                                                                                              \
     break
 
@@ -650,7 +797,10 @@ static int sa_launch_bm25_mode(sa_index* ix, const Bm25Params& p, hipStream_t st
 
 #define SA_LAUNCH_LIST(TILE, THREADS)                                                              \
     {                                                                                              \
-        hipLaunchKernelGGL((sa_k_bm25_tiles_list<TILE, THREADS>), dim3(grid), dim3(THREADS), 0, st, p); \
+        if (p.imp)                                                                                 \
+            hipLaunchKernelGGL((sa_k_bm25_tiles_list<TILE, THREADS, 1>), dim3(grid), dim3(THREADS), 0, st, p); \
+        else                                                                                       \
+            hipLaunchKernelGGL((sa_k_bm25_tiles_list<TILE, THREADS, 0>), dim3(grid), dim3(THREADS), 0, st, p); \
     }                                                                                              \
     break
 
@@ -734,6 +884,8 @@ void sa_batch_free(sa_batch* bt) {
     if (bt->d_bounds) hipFree(bt->d_bounds);
     if (bt->d_sattab) hipFree(bt->d_sattab);
     if (bt->d_qbase) hipFree(bt->d_qbase);
+    if (bt->d_qbase_imp) hipFree(bt->d_qbase_imp);
+    bt->impacts.reset();
     if (bt->d_slots) hipFree(bt->d_slots);
     if (bt->d_local) hipFree(bt->d_local);
     if (bt->d_gather) hipFree(bt->d_gather);
@@ -976,7 +1128,10 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
         SA_HIP_B(hipMemset(bt->d_route, 0xFF, (size_t)B * sizeof(u32)));
     }
     if (sa_launch_make_sattab(ix, bt->d_sattab, &bt->tab_w, k1, b, ix->stream) != SA_OK) return fail(SA_ERR_HIP);
-    if (sa_launch_make_bounds(ix, bt->d_terms, B * T, bt->d_bounds, bt->d_qbase, ix->stream) != SA_OK) return fail(SA_ERR_HIP);
+    // the impact stream of this (k1, b): shared through the index, built on first use
+    bt->impacts = sa_impacts_get(ix, k1, b);
+    if (bt->impacts) SA_HIP_B(hipMalloc(&bt->d_qbase_imp, (size_t)B * T * sizeof(u64)));
+    if (sa_launch_make_bounds(ix, bt->d_terms, B * T, bt->d_bounds, bt->d_qbase, ix->stream, bt->d_qbase_imp) != SA_OK) return fail(SA_ERR_HIP);
     SA_HIP_B(hipStreamSynchronize(ix->stream));
 #undef SA_HIP_B
     (void)rc;
@@ -1007,6 +1162,10 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     p.terms = bt->d_terms; p.idf = bt->d_idf; p.B = bt->B; p.T = bt->T; p.k = bt->k;
     p.k1 = bt->k1; p.b = bt->b;
     p.bounds = bt->d_bounds; p.qbase = bt->d_qbase;
+    if (bt->impacts && bt->kind == 0 && sa_env_int("SA_IMPACT", 2) != 0) {
+        p.imp = bt->impacts->d_imp; p.qbase_imp = bt->d_qbase_imp;
+        p.imp_route = sa_env_int("SA_IMPACT", 2) == 1 ? 1 : 2;
+    }
     p.sattab = bt->d_sattab; p.tab_w = bt->tab_w;
     p.pruned = (sa_env_int("SA_PRUNED_TOPK", 1) && !force_unpruned) ? 1 : 0;   // pruned wave-level selection (any k <= 1024)
     p.dense_out = nullptr; p.cand = bt->d_cand;

@@ -203,6 +203,7 @@ void sa_index_free(sa_index* ix) {
     if (ix->d_tf8) hipFree(ix->d_tf8);
     if (ix->d_tfbits) hipFree(ix->d_tfbits);
     if (ix->d_tf8_slot) hipFree(ix->d_tf8_slot);
+    ix->impacts.reset();
     if (ix->d_scratch) hipFree(ix->d_scratch);
     if (ix->d_rows_scratch) hipFree(ix->d_rows_scratch);
     if (ix->d_sim_scratch) hipFree(ix->d_sim_scratch);
@@ -732,6 +733,7 @@ extern "C" int sa_index_info(sa_index_t* ix, sa_index_info_t* out) {
     out->n_docdir_terms = ix->n_dd_terms;
     out->n_tf8_terms = ix->n_tf8_terms;
     out->hbm_bytes = ix->n_words * 8 + ix->n_postings * 8 + ((u64)ix->n_terms + 1) * 20 + ix->n_docs * 4 +
-                     (u64)ix->n_dir_terms * (ix->n_tiles + 1) * 4 + (u64)ix->n_dd_terms * ix->n_docs * 4 + (u64)ix->n_tf8_terms * (ix->n_docs + ix->tfbits_words * 4) + ix->scratch_bytes;
+                     (u64)ix->n_dir_terms * (ix->n_tiles + 1) * 4 + (u64)ix->n_dd_terms * ix->n_docs * 4 + (u64)ix->n_tf8_terms * (ix->n_docs + ix->tfbits_words * 4) + ix->scratch_bytes +
+                     (ix->impacts ? ix->impacts->n * 8 : 0);
     return SA_OK;
 }

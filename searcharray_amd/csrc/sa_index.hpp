@@ -18,6 +18,7 @@
 //   doc_lens  f32[n_docs]
 #pragma once
 #include "sa_common.hpp"
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -25,6 +26,21 @@ struct sa_comm;   // RCCL communicator wrapper (sa_comm.hip)
 
 #define SA_DD_ABSENT 0xFFFFFFFFu
 #define SA_DD_NONE 0xFFFFFFFFu
+
+// Impact stream of one (k1, b, avgdl) instantiation of BM25 (sa_bm25.hip, sa_k_make_impacts): the TF
+// postings with the per-posting factor  tf / (tf + k1 * ((1 - b) + b * dl / avgdl))  already evaluated
+// (reference bm25.pyx:19-23, op for op), laid out for the exhaustive tile kernel:
+//   imp[i] = doc << 32 | float bits of the factor
+// Term t starts at the EVEN index  (tf_off[t] + t + 1) & ~1  and every gap holds the sentinel
+// 0xFFFF'FFFF'FFFF'FFFF (doc id no tile contains), so a 16-byte pair load never sees another term's
+// posting and "doc inside this tile" is the only validity test a posting needs.
+struct sa_impacts {
+    int device = 0;
+    float k1 = 0.f, b = 0.f, avgdl = 0.f;
+    u64* d_imp = nullptr;
+    u64 n = 0;                      // u64 cells incl. padding
+    ~sa_impacts();
+};
 
 struct sa_index {
     int device = 0;
@@ -76,6 +92,9 @@ struct sa_index {
     size_t rows_scratch_bytes = 0;
     void* d_sim_scratch = nullptr;              // float64[n_docs] results of the f64 similarities
     size_t sim_scratch_bytes = 0;
+
+    // most recent impact stream (shared with the batches built for the same k1 / b)
+    std::shared_ptr<sa_impacts> impacts;
 
     sa_comm* comm = nullptr;
     hipStream_t xstream = nullptr;   // exchange stream: all-gather + cross-rank merge overlap the next batch's scoring

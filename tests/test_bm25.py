@@ -390,3 +390,51 @@ def test_dense_calls_with_a_row_selection(api):
     with pytest.raises(Exception):
         dev.phrase_freqs_dense(list(range(40)), rows=rows)                                  # too long a phrase
     assert np.array_equal(dev.termfreqs_dense(3), full_tf)                                  # selection was cleared
+
+
+# ---------------------------------------------------------------------------------------------
+# impact stream (sa_k_make_impacts): the per-posting factor evaluated once per (k1, b)
+# ---------------------------------------------------------------------------------------------
+def _check_batch(bt, orc, queries, k, k1=1.2, b=0.75):
+    bt.run()
+    scores, docs = bt.fetch()
+    for qi, q in enumerate(queries):
+        ws, wd = O.topk(orc.score_terms_sum([int(x) for x in q], k1=k1, b=b), k)
+        n = int((ws > 0).sum())
+        assert np.array_equal(scores[qi, :n], ws[:n]), f"q{qi} scores"
+        assert np.array_equal(docs[qi, :n], wd[:n]), f"q{qi} docs"
+        assert (docs[qi, n:] == NO_DOC).all()
+    return scores, docs
+
+
+@pytest.mark.parametrize("integer_lens", [True, False])
+def test_impact_stream_exhaustive_scan(api, monkeypatch, integer_lens):
+    """SA_SPARSE=0: every posting is scored by the tile kernel.  With the impact stream (default) and
+    with the TF postings (SA_IMPACT=0) the top-k must equal the oracle bit for bit: long docs and high
+    term frequencies (outside the saturation table), odd and even posting counts (padding), unknown and
+    repeated terms, fractional doc lengths (doc_lens gathered at build time), two batches with different
+    (k1, b) alive at once, and a batch that outlives the index's cached stream."""
+    monkeypatch.setenv("SA_SPARSE", "0")
+    n_docs, vocab = 9000, 400
+    t, d, p, lens = synth.corpus_triples(n_docs, vocab, 150, seed=11)        # mean length 150: dl >= 128, tf > 8
+    if not integer_lens:
+        lens = (lens + np.float32(0.5)).astype(np.float32)
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    assert bool(dev.info().dl_packed) == integer_lens
+    orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
+    queries = np.asarray([[0, 1, 2, 3], [399, 398, 0, 200], [5, 5, 450, 7], [100, 101, 102, 103], [17, 390, 391, 2]])
+    a = dev.batch(queries, k=20)
+    c = dev.batch(queries, k=20, k1=1.7, b=0.3)                               # replaces the index's cached stream
+    s_a, d_a = _check_batch(a, orc, queries, 20)
+    _check_batch(c, orc, queries, 20, k1=1.7, b=0.3)
+    s_a2, d_a2 = _check_batch(a, orc, queries, 20)                            # `a` still owns its stream
+    assert np.array_equal(s_a, s_a2) and np.array_equal(d_a, d_a2)
+    for route in ("1", "0"):                                                  # same batch: one posting at a time / TF postings
+        monkeypatch.setenv("SA_IMPACT", route)
+        s_b, d_b = _check_batch(a, orc, queries, 20)
+        assert np.array_equal(s_a, s_b) and np.array_equal(d_a, d_b)
+    e = dev.batch(queries, k=20, k1=0.9, b=0.0)                               # built without a stream at all
+    _check_batch(e, orc, queries, 20, k1=0.9, b=0.0)
+    for bt in (a, c, e):
+        bt.close()
