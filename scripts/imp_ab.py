@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--ks", default="10,1000")
     ap.add_argument("--routes", default="0,1,2,0,2")
     ap.add_argument("--corpus-cache", default="")
+    ap.add_argument("--slots", default="", help="keep only these query-term columns, e.g. 0,1 (cost of a subset of the terms)")
+    ap.add_argument("--empty", action="store_true",
+                    help="queries of unknown terms only: the fixed cost of a launch (zero, slice lookup, barriers, selection)")
     args = ap.parse_args()
     api = _lib.api()
     V, B = args.vocab, args.queries
@@ -37,6 +40,10 @@ def main():
         else:
             corpus = synth.zipf_corpus(D, vocab=V, workers=min(8, os.cpu_count() or 8))
         queries = synth.bm25_queries(B, vocab=V)
+        if args.slots:
+            queries = np.asarray(queries)[:, [int(x) for x in args.slots.split(",")]]
+        if args.empty:
+            queries = np.full_like(np.asarray(queries), V + 5)
         index = DeviceIndex(corpus.words, corpus.term_off, corpus.doc_lens, api=api)
         for k in [int(x) for x in args.ks.split(",")]:
             os.environ["SA_IMPACT"] = "2"
@@ -62,7 +69,7 @@ def main():
                     if ref is None:
                         ref = res
                     same = bool(np.array_equal(ref[0], res[0]) and np.array_equal(ref[1], res[1]))
-                    print(json.dumps({"docs": D, "k": k, "sparse": sparse, "impact_route": route,
+                    print(json.dumps({"docs": D, "k": k, "sparse": sparse, "impact_route": route, "no_topk": os.environ.get("SA_NO_TOPK", "0"), "slots": args.slots,
                                       "qps": round(B * args.steps / dt, 1), "ms_per_step": round(dt / args.steps * 1e3, 4),
                                       "kernel_ms": round(ms, 4), "alg_GBps": round(alg / ms / 1e6, 1),
                                       "postings_GBps": round(post / ms / 1e6, 1), "same_results": same,

@@ -226,10 +226,12 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     constexpr int LE = (CAP + THREADS - 1) / THREADS;
     constexpr size_t ACC_BYTES = (size_t)TILE * 4;
     constexpr size_t SEL_BYTES = MODE == 0 ? (size_t)(CAP + SA_KMAX) * 8 : 0;
-    constexpr size_t SMEM_U64 = (ACC_BYTES > SEL_BYTES ? ACC_BYTES : SEL_BYTES) / 8 + 2;   // + the spare slot acc[TILE]
+    constexpr size_t SMEM_U64 = (ACC_BYTES > SEL_BYTES ? ACC_BYTES : SEL_BYTES) / 8 + SA_WAVE / 2;   // + one spare slot per lane: acc[TILE + lane]
     constexpr int PF = 4;                                       // 16-byte loads in flight per lane
     __shared__ alignas(16) u64 smem[SMEM_U64];
     __shared__ u64 s_lo[SA_MAX_QTERMS], s_hi[SA_MAX_QTERMS];
+    __shared__ float s_idf[SA_MAX_QTERMS];
+    __shared__ u32 s_mask;
     __shared__ u64 red64[NW + 1];
     __shared__ u32 red[NW + 1];
     __shared__ u32 s_cnt[2];
@@ -244,6 +246,7 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     const u32 tid = threadIdx.x;
     const u32 T = p.T;
     const u32 tab_w = p.tab_w;
+    if (p.no_topk == 2) return;                                 // timing experiments: dispatch cost only
     if constexpr (IMP == 0) {
         for (u32 i = tid; i < SA_SAT_NTF * tab_w; i += THREADS) s_tab[i] = p.sattab[i];
     }
@@ -263,16 +266,26 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
 
     // 1. this tile's slice [lo, hi) of every query term: one dependent load from the batch's
     //    slice table; clear the accumulators meanwhile
+    bool nonempty = false;
     if (tid < T) {
         const u32 qt = q * T + tid;
         const u32* row = p.bounds + (u64)qt * (p.n_tiles + 1) + tile;
         const u64 base = IMP != 0 ? p.qbase_imp[qt] : p.qbase[qt];
-        s_lo[tid] = base + row[0];
-        s_hi[tid] = base + row[1];
+        const u32 r0 = row[0], r1 = row[1];
+        s_lo[tid] = base + r0;
+        s_hi[tid] = base + r1;
+        s_idf[tid] = p.idf[qt];
+        nonempty = r1 > r0;
+    }
+    // the query terms with postings in this tile: phases of the others are skipped altogether
+    if (tid < SA_WAVE) {
+        const u64 bal = __ballot(nonempty);
+        if (tid == 0) s_mask = (u32)bal;
     }
 #pragma unroll
     for (int j = 0; j < E; j++) acc[j * THREADS + tid] = 0.f;
     __syncthreads();
+    if (p.no_topk == 3) return;                                 // timing experiments: + slice lookup and clear
 
     // 2. term-at-a-time accumulation.  A slice is read as 16-byte pairs from its 16-byte-aligned
     //    hull (one global_load_dwordx4 per lane, PF in flight); a pair element outside [lo, hi)
@@ -330,16 +343,34 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     auto score_batch = [&](const Batch& b, u64 lo, u64 hi, u32 first, float idf) {
         const u64 a0 = lo & ~1ull;
         const u32 npairs = (hi > a0) ? (u32)((hi - a0 + 1) >> 1) : 0u;
-        if constexpr (IMP == 2) {
-            // wave-uniform: this wave has pairs at every step of the batch (lanes past the end hold sentinels)
-            if (first + (u32)(PF - 1) * THREADS + (tid & ~(u32)(SA_WAVE - 1)) < npairs) {
+        if constexpr (IMP == 3) {
+            // the last step of a slice (a short slice's only one): one pair per lane, no branches
+            if (npairs - first <= (u32)THREADS) {               // (npairs > first: callers never pass an empty batch ... or nothing happens)
+                if (first + (tid & ~(u32)(SA_WAVE - 1)) < npairs) {
+                    const u32 spare = (u32)TILE + (tid & (u32)(SA_WAVE - 1));
+                    const u32 d0 = (u32)(b.v[0].x >> 32) - tile_base32, d1 = (u32)(b.v[0].y >> 32) - tile_base32;
+                    const u32 s0 = d0 < (u32)TILE ? d0 : spare, s1 = d1 < (u32)TILE ? d1 : spare;
+                    const float v0 = acc[s0], v1 = acc[s1];
+                    const float w0 = __fadd_rn(v0, __fmul_rn(__uint_as_float((u32)b.v[0].x), idf));
+                    const float w1 = __fadd_rn(v1, __fmul_rn(__uint_as_float((u32)b.v[0].y), idf));
+                    acc[s0] = w0;
+                    acc[s1] = w1;
+                }
+                return;
+            }
+        }
+        if constexpr (IMP >= 2) {
+            // wave-uniform: this wave has pairs at every step of the batch (IMP == 3: at its first step);
+            // lanes / steps past the end hold sentinels
+            if (first + (u32)(IMP == 2 ? PF - 1 : 0) * THREADS + (tid & ~(u32)(SA_WAVE - 1)) < npairs) {
                 u32 slot[2 * PF];
                 float val[2 * PF];
+                const u32 spare = (u32)TILE + (tid & (u32)(SA_WAVE - 1));
 #pragma unroll
                 for (int u = 0; u < PF; u++) {
                     const u32 d0 = (u32)(b.v[u].x >> 32) - tile_base32, d1 = (u32)(b.v[u].y >> 32) - tile_base32;
-                    slot[2 * u] = d0 < (u32)TILE ? d0 : (u32)TILE;
-                    slot[2 * u + 1] = d1 < (u32)TILE ? d1 : (u32)TILE;
+                    slot[2 * u] = d0 < (u32)TILE ? d0 : spare;
+                    slot[2 * u + 1] = d1 < (u32)TILE ? d1 : spare;
                 }
 #pragma unroll
                 for (int i = 0; i < 2 * PF; i++) val[i] = acc[slot[i]];
@@ -369,30 +400,97 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
             }
         }
     };
-    Batch cur = load_batch(s_lo[0], s_hi[0], 0);
-    for (u32 t = 0; t < T; t++) {
-        const u64 lo = s_lo[t], hi = s_hi[t];
-        const float idf = p.idf[q * T + t];
-        Batch nxt;
-        const bool more = t + 1 < T;
-        if (more) nxt = load_batch(s_lo[t + 1], s_hi[t + 1], 0);
-        score_batch(cur, lo, hi, 0, idf);
+    // Only terms with postings in this tile get a phase (and its barrier): an empty phase still costs
+    // an LDS round trip for its slice, address arithmetic and a barrier -- measured 0.15 ms per term
+    // and launch at 10 M docs x 256 queries, more than the postings of the rare terms themselves.
+    u32 todo = (u32)__builtin_amdgcn_readfirstlane((int)s_mask);
+    if (MODE == 1 && todo == 0u) return;                        // nothing scored: no doc can enter the top-k
+    auto uni64 = [](u64 x) -> u64 {                             // wave-uniform value -> scalar registers
+        const u32 l = (u32)__builtin_amdgcn_readfirstlane((int)(u32)x), h = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(x >> 32));
+        return ((u64)h << 32) | l;
+    };
+    // Phases are taken in groups of four.  A group's prologue fetches the slices (lo, hi, idf) of its
+    // terms from LDS in one go and requests the first 16 bytes per lane of ALL its phases (P[0..3]);
+    // the rest of a phase's first batch -- only slices longer than one step have one -- is requested
+    // one phase ahead (nxt).  Inside the group a phase starts from registers: a phase with few
+    // postings (the rare terms of a query) otherwise spends far longer on LDS round trips, address
+    // arithmetic and its own memory round trip than on its postings (measured: 0.2 ms per term and
+    // launch at 10 M docs x 256 queries, whatever the number of postings).
+    auto load_step = [&](u64 lo, u64 hi, u32 step) -> sa_u64x2 {         // step `step` of the first batch
         const u64 a0 = lo & ~1ull;
         const u32 npairs = (hi > a0) ? (u32)((hi - a0 + 1) >> 1) : 0u;
-        if (npairs > (u32)PF * THREADS) {                       // long slice (frequent term)
-            u32 first = (u32)PF * THREADS;
-            Batch b = load_batch(lo, hi, first);
-            while (first < npairs) {
-                const u32 nf = first + (u32)PF * THREADS;
-                Batch b2;
-                if (nf < npairs) b2 = load_batch(lo, hi, nf);
-                score_batch(b, lo, hi, first, idf);
-                if (nf < npairs) b = b2;
-                first = nf;
-            }
+        const sa_u64x2* pairs = (const sa_u64x2*)(stream + a0);
+        const u64 fill = IMP != 0 ? ~0ull : 0ull;
+        const u32 j = step * THREADS + tid;
+        sa_u64x2 v;
+        if (j < npairs) v = pairs[j];
+        else { v.x = fill; v.y = fill; }
+        return v;
+    };
+    auto pairs_of = [](u64 lo, u64 hi) -> u32 {
+        const u64 a0 = lo & ~1ull;
+        return (hi > a0) ? (u32)((hi - a0 + 1) >> 1) : 0u;
+    };
+    // steps 1 .. PF-1 of a slice's first batch (nothing to fetch for a slice of one step)
+    auto load_rest = [&](Batch& b, u64 lo, u64 hi) {
+        if (pairs_of(lo, hi) > (u32)THREADS) {
+#pragma unroll
+            for (int u = 1; u < PF; u++) b.v[u] = load_step(lo, hi, (u32)u);
+        } else {
+            const u64 fill = IMP != 0 ? ~0ull : 0ull;
+#pragma unroll
+            for (int u = 1; u < PF; u++) { b.v[u].x = fill; b.v[u].y = fill; }
         }
-        __syncthreads();
-        if (more) cur = nxt;
+    };
+    while (todo) {
+        u64 L[4], H[4];
+        float W[4];
+        sa_u64x2 P[4];
+        {
+            u32 g = todo;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const bool have = g != 0u;
+                const u32 ti = have ? (u32)__builtin_ctz(g) : 0u;
+                g &= g - 1u;                                     // (0 stays 0)
+                L[i] = s_lo[ti]; H[i] = s_hi[ti]; W[i] = s_idf[ti];
+                if (!have) { L[i] = 0; H[i] = 0; }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) { L[i] = uni64(L[i]); H[i] = uni64(H[i]); }
+#pragma unroll
+            for (int i = 0; i < 4; i++) P[i] = load_step(L[i], H[i], 0);
+        }
+        Batch nxt;
+        load_rest(nxt, L[0], H[0]);
+#pragma unroll 1
+        for (int k = 0; k < 4 && todo; k++) {
+            todo &= todo - 1u;
+            const u64 lo = L[0], hi = H[0];
+            const float idf = W[0];
+            Batch cur = nxt;
+            cur.v[0] = P[0];
+            load_rest(nxt, L[1], H[1]);                         // (the next group's first phase: nothing, L[1] = H[1] = 0)
+            score_batch(cur, lo, hi, 0, idf);
+            const u32 npairs = pairs_of(lo, hi);
+            if (npairs > (u32)PF * THREADS) {                   // long slice (frequent term)
+                u32 first = (u32)PF * THREADS;
+                Batch b = load_batch(lo, hi, first);
+                while (first < npairs) {
+                    const u32 nf = first + (u32)PF * THREADS;
+                    Batch b2;
+                    if (nf < npairs) b2 = load_batch(lo, hi, nf);
+                    score_batch(b, lo, hi, first, idf);
+                    if (nf < npairs) b = b2;
+                    first = nf;
+                }
+            }
+            __syncthreads();
+            L[0] = L[1]; L[1] = L[2]; L[2] = L[3]; L[3] = 0;
+            H[0] = H[1]; H[1] = H[2]; H[2] = H[3]; H[3] = 0;
+            W[0] = W[1]; W[1] = W[2]; W[2] = W[3];
+            P[0] = P[1]; P[1] = P[2]; P[2] = P[3];
+        }
     }
 
     const u64 remain = p.n_docs - tile_base;
@@ -769,7 +867,9 @@ static int sa_env_int(const char* name, int dflt) {
 
 #define SA_LAUNCH_TILE(TILE, THREADS)                                                              \
     {                                                                                              \
-        if (MODE == 1 && p.imp && p.imp_route == 2)                                                \
+        if (MODE == 1 && p.imp && p.imp_route == 3)                                                \
+            hipLaunchKernelGGL((sa_k_bm25_tiles<TILE, THREADS, MODE, MODE == 1 ? 3 : 0>), dim3((u32)n_items), dim3(THREADS), 0, st, p); \
+        else if (MODE == 1 && p.imp && p.imp_route == 2)                                           \
             hipLaunchKernelGGL((sa_k_bm25_tiles<TILE, THREADS, MODE, MODE == 1 ? 2 : 0>), dim3((u32)n_items), dim3(THREADS), 0, st, p); \
         else if (MODE == 1 && p.imp)                                                               \
             hipLaunchKernelGGL((sa_k_bm25_tiles<TILE, THREADS, MODE, MODE == 1 ? 1 : 0>), dim3((u32)n_items), dim3(THREADS), 0, st, p); \
@@ -1162,9 +1262,10 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     p.terms = bt->d_terms; p.idf = bt->d_idf; p.B = bt->B; p.T = bt->T; p.k = bt->k;
     p.k1 = bt->k1; p.b = bt->b;
     p.bounds = bt->d_bounds; p.qbase = bt->d_qbase;
-    if (bt->impacts && bt->kind == 0 && sa_env_int("SA_IMPACT", 2) != 0) {
+    if (bt->impacts && bt->kind == 0 && sa_env_int("SA_IMPACT", 3) != 0) {
         p.imp = bt->impacts->d_imp; p.qbase_imp = bt->d_qbase_imp;
-        p.imp_route = sa_env_int("SA_IMPACT", 2) == 1 ? 1 : 2;
+        p.imp_route = sa_env_int("SA_IMPACT", 3);
+        if (p.imp_route < 1 || p.imp_route > 3) p.imp_route = 3;
     }
     p.sattab = bt->d_sattab; p.tab_w = bt->tab_w;
     p.pruned = (sa_env_int("SA_PRUNED_TOPK", 1) && !force_unpruned) ? 1 : 0;   // pruned wave-level selection (any k <= 1024)
