@@ -6,10 +6,9 @@ mkdir -p $O
 cd $R
 ( time timeout 300 python bench.py --corpus-cache /tmp/corpus --no-cpu-baseline --steps 5 ) > $O/bench_quick.log 2>&1
 grep '^{"metric' $O/bench_quick.log | cut -c1-120
-( timeout 300 python scripts/imp_ab.py --corpus-cache /tmp/corpus --docs 10000000,1250000 --ks 10,1000 --routes 0,2,3,0,3 ) 2>&1 | grep '^{' | grep '"sparse": "0"' | cut -c1-200
+( timeout 120 python -m pytest tests/test_bm25.py tests/test_fuzz.py -m gpu -q -x ) 2>&1 | tail -n 7 | head -n 3
+( timeout 300 python scripts/imp_ab.py --corpus-cache /tmp/corpus --docs 10000000,1250000 --ks 10,1000 --routes 0,3,0,3 ) 2>&1 | grep '^{' | grep '"sparse": "0"' | cut -c1-200
 for sl in 3 2,3 0; do
   ( SA_NO_TOPK=1 timeout 300 python scripts/imp_ab.py --corpus-cache /tmp/corpus --docs 10000000 --ks 10 --routes 3 --slots $sl ) 2>&1 | grep '^{' | grep '"sparse": "0"' | cut -c50-200
 done
-( timeout 300 python -m pytest tests/test_bm25.py tests/test_fuzz.py tests/test_search_api.py -m gpu -q -x ) 2>&1 | tail -n 7 | head -n 3
-( SA_IMPACT=0 timeout 300 python -m pytest tests/test_bm25.py tests/test_fuzz.py -m gpu -q -x ) 2>&1 | tail -n 7 | head -n 3
 exit 0

@@ -46,7 +46,7 @@ struct Bm25Params {
     const u64* qbase;      // [B][T] posting base of each query term
     const u64* imp;        // impact stream (sa_impacts, sa_index.hpp) or null: score the TF postings
     const u64* qbase_imp;  // [B][T] base of each query term in the impact stream
-    int imp_route;         // 1 / 2: see sa_bm25_tile_item
+    int imp_route;         // 1 / 2 / 3: see sa_bm25_tile_item
     u32 B, T, k;
     float k1, b, avgdl;
     int pruned;            // 1: wave-level selection against a global bound (MODE 1); 0: block-level selection (MODE 0)
@@ -471,11 +471,13 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
             Batch cur = nxt;
             cur.v[0] = P[0];
             load_rest(nxt, L[1], H[1]);                         // (the next group's first phase: nothing, L[1] = H[1] = 0)
-            score_batch(cur, lo, hi, 0, idf);
             const u32 npairs = pairs_of(lo, hi);
-            if (npairs > (u32)PF * THREADS) {                   // long slice (frequent term)
+            const bool long_slice = npairs > (u32)PF * THREADS;  // (frequent term)
+            Batch b;
+            if (long_slice) b = load_batch(lo, hi, (u32)PF * THREADS);   // requested before the first batch is scored
+            score_batch(cur, lo, hi, 0, idf);
+            if (long_slice) {
                 u32 first = (u32)PF * THREADS;
-                Batch b = load_batch(lo, hi, first);
                 while (first < npairs) {
                     const u32 nf = first + (u32)PF * THREADS;
                     Batch b2;
