@@ -44,6 +44,12 @@ def main():
         if j is not None:
             json.dump(j, open(os.path.join(PROF, dst), "w"), indent=1)
             print("wrote", dst)
+    ab = os.path.join(OUT, "imp_ab.log")
+    if os.path.exists(ab):
+        lines = [ln for ln in open(ab).read().splitlines() if ln.startswith("{")]
+        if lines:
+            open(os.path.join(PROF, f"imp_ab_{RND}.jsonl"), "w").write("\n".join(lines) + "\n")
+            print("wrote", f"imp_ab_{RND}.jsonl")
     for sub, dst in [("prof_stats", f"{RND}_bench_kernel_stats.csv"), ("prof_phrase", f"{RND}_phrase_bench_kernel_stats.csv"),
                      ("prof_slop", f"{RND}_slop_bench_kernel_stats.csv")]:
         fs = glob.glob(os.path.join(OUT, sub, "**", "*kernel_stats.csv"), recursive=True)

@@ -12,6 +12,7 @@ cd $R
 ( time timeout 900 python bench.py --corpus-cache /tmp/corpus ) > $O/bench.log 2>&1
 ( time timeout 900 python bench.py --corpus-cache /tmp/corpus --k 1000 --no-cpu-baseline --steps 5 ) > $O/bench_k1000.log 2>&1
 ( time timeout 900 python bench.py --corpus-cache /tmp/corpus --k 100 --no-cpu-baseline --steps 10 ) > $O/bench_k100.log 2>&1
+( time timeout 400 python scripts/imp_ab.py --corpus-cache /tmp/corpus ) > $O/imp_ab.log 2>&1
 ( time timeout 900 python scripts/phrase_bench.py ) > $O/phrase_bench.log 2>&1
 ( time timeout 900 python scripts/slop_bench.py ) > $O/slop_bench.log 2>&1
 ( time timeout 600 python scripts/io_bench.py ) > $O/io_bench.log 2>&1

@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Same-box A/B of the exhaustive tile kernel's posting routes (development tool).
 
-SA_IMPACT=0: TF postings + saturation table; 1: impact stream, one posting at a time; 2: impact stream,
-8-posting batches.  One index per corpus size, one batch, every route timed on the same box; results of all
-routes must be identical.  Prints one JSON line per (docs, k, route)."""
+SA_IMPACT=0: TF postings + saturation table; 1: impact stream (the default).  One index per corpus size,
+one batch, every route timed on the same box; results of all routes must be identical.  --slots / --empty
+time subsets of the query terms (what a phase costs).  Prints one JSON line per (docs, k, route)."""
 import argparse
 import json
 import os
@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--queries", type=int, default=256)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--ks", default="10,1000")
-    ap.add_argument("--routes", default="0,1,2,0,2")
+    ap.add_argument("--routes", default="0,1,0,1")
     ap.add_argument("--corpus-cache", default="")
     ap.add_argument("--slots", default="", help="keep only these query-term columns, e.g. 0,1 (cost of a subset of the terms)")
     ap.add_argument("--empty", action="store_true",
@@ -46,7 +46,7 @@ def main():
             queries = np.full_like(np.asarray(queries), V + 5)
         index = DeviceIndex(corpus.words, corpus.term_off, corpus.doc_lens, api=api)
         for k in [int(x) for x in args.ks.split(",")]:
-            os.environ["SA_IMPACT"] = "2"
+            os.environ["SA_IMPACT"] = "1"
             t0 = time.perf_counter()
             batch = QueryBatch(index, queries, k=k)
             create_ms = (time.perf_counter() - t0) * 1e3

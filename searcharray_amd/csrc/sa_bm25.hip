@@ -46,7 +46,6 @@ struct Bm25Params {
     const u64* qbase;      // [B][T] posting base of each query term
     const u64* imp;        // impact stream (sa_impacts, sa_index.hpp) or null: score the TF postings
     const u64* qbase_imp;  // [B][T] base of each query term in the impact stream
-    int imp_route;         // 1 / 2 / 3: see sa_bm25_tile_item
     u32 B, T, k;
     float k1, b, avgdl;
     int pruned;            // 1: wave-level selection against a global bound (MODE 1); 0: block-level selection (MODE 0)
@@ -213,12 +212,10 @@ sa_k_make_bounds(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, co
 // MODE 0: dense output and/or block-level threshold top-k (any k <= 1024).
 // MODE 1: pruned wave-level top-k against the query's global bound (any k <= 1024), the batch fast path.
 // One work item = one (tile, query) pair; `nq` queries are in play (p.qlist maps them, if set).
-// IMP != 0: read the impact stream (p.imp / p.qbase_imp) instead of the TF postings.
-//   1: one posting at a time (LDS read -> add -> write, masked lanes skipped by branches)
-//   2: full 8-posting batches update their accumulators together -- 8 LDS reads in flight, then the adds,
-//      then 8 writes; a posting outside the tile is steered to a spare slot behind the tile instead of
-//      being branched around.  Partial batches (short slices, the tail of a long one) take route 1.
-template <int TILE, int THREADS, int MODE, int IMP>
+// IMP: read the impact stream (p.imp / p.qbase_imp) instead of the TF postings.  A batch of 8 postings per
+// lane then updates its accumulators together -- 8 LDS reads in flight, the adds, 8 writes -- and a posting
+// outside the tile is steered to a spare slot behind the tile instead of being branched around.
+template <int TILE, int THREADS, int MODE, bool IMP>
 __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32 item, const u32 nq) {
     constexpr int NW = THREADS / SA_WAVE;
     constexpr int E = TILE / THREADS;
@@ -229,9 +226,6 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     constexpr size_t SMEM_U64 = (ACC_BYTES > SEL_BYTES ? ACC_BYTES : SEL_BYTES) / 8 + SA_WAVE / 2;   // + one spare slot per lane: acc[TILE + lane]
     constexpr int PF = 4;                                       // 16-byte loads in flight per lane
     __shared__ alignas(16) u64 smem[SMEM_U64];
-    __shared__ u64 s_lo[SA_MAX_QTERMS], s_hi[SA_MAX_QTERMS];
-    __shared__ float s_idf[SA_MAX_QTERMS];
-    __shared__ u32 s_mask;
     __shared__ u64 red64[NW + 1];
     __shared__ u32 red[NW + 1];
     __shared__ u32 s_cnt[2];
@@ -247,7 +241,7 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     const u32 T = p.T;
     const u32 tab_w = p.tab_w;
     if (p.no_topk == 2) return;                                 // timing experiments: dispatch cost only
-    if constexpr (IMP == 0) {
+    if constexpr (!IMP) {
         for (u32 i = tid; i < SA_SAT_NTF * tab_w; i += THREADS) s_tab[i] = p.sattab[i];
     }
     // (queries answered by the sparse candidate path, sa_sparse.hip, are not in the list)
@@ -264,28 +258,28 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
         slot_val = __hip_atomic_load(&p.slots[q * 32u + (tid & 31u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (use_hist) slot_val = __hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-    // 1. this tile's slice [lo, hi) of every query term: one dependent load from the batch's
-    //    slice table; clear the accumulators meanwhile
-    bool nonempty = false;
-    if (tid < T) {
-        const u32 qt = q * T + tid;
+    // 1. this tile's slice [lo, hi) of every query term: one dependent load from the batch's slice
+    //    table.  Lane t of EVERY wave requests term t's entries (the same few cache lines), so the
+    //    slices reach the scalar registers by readlane -- no LDS staging, no barrier between the lookup
+    //    and the first posting loads; the accumulators are cleared while those are in flight.
+    const u32 lane = tid & (u32)(SA_WAVE - 1);
+    u64 r_lo = 0, r_hi = 0;
+    float r_idf = 0.f;
+    if (lane < T) {
+        const u32 qt = q * T + lane;
         const u32* row = p.bounds + (u64)qt * (p.n_tiles + 1) + tile;
-        const u64 base = IMP != 0 ? p.qbase_imp[qt] : p.qbase[qt];
+        const u64 base = IMP ? p.qbase_imp[qt] : p.qbase[qt];
         const u32 r0 = row[0], r1 = row[1];
-        s_lo[tid] = base + r0;
-        s_hi[tid] = base + r1;
-        s_idf[tid] = p.idf[qt];
-        nonempty = r1 > r0;
+        r_lo = base + r0;
+        r_hi = base + r1;
+        r_idf = p.idf[qt];
     }
     // the query terms with postings in this tile: phases of the others are skipped altogether
-    if (tid < SA_WAVE) {
-        const u64 bal = __ballot(nonempty);
-        if (tid == 0) s_mask = (u32)bal;
-    }
-#pragma unroll
-    for (int j = 0; j < E; j++) acc[j * THREADS + tid] = 0.f;
-    __syncthreads();
-    if (p.no_topk == 3) return;                                 // timing experiments: + slice lookup and clear
+    u32 todo = (u32)__ballot(r_hi > r_lo);
+    auto lane64 = [](u64 x, u32 l) -> u64 {                      // value of lane l (wave-uniform l) in scalar registers
+        const u32 a = (u32)__builtin_amdgcn_readlane((int)(u32)x, (int)l), b = (u32)__builtin_amdgcn_readlane((int)(u32)(x >> 32), (int)l);
+        return ((u64)b << 32) | a;
+    };
 
     // 2. term-at-a-time accumulation.  A slice is read as 16-byte pairs from its 16-byte-aligned
     //    hull (one global_load_dwordx4 per lane, PF in flight); a pair element outside [lo, hi)
@@ -317,11 +311,7 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     // (terms start on even indices and gaps hold an all-ones sentinel, so whatever else a pair load of
     // the hull brings along -- the previous / next tile's posting, padding -- fails the same test).
     const u32 tile_base32 = (u32)tile_base;
-    auto score_imp = [&](u64 x, float idf) {
-        const u32 d = (u32)(x >> 32) - tile_base32;
-        if (d < (u32)TILE) acc[d] = __fadd_rn(acc[d], __fmul_rn(__uint_as_float((u32)x), idf));
-    };
-    const u64* const stream = IMP != 0 ? p.imp : p.tfp;
+    const u64* const stream = IMP ? p.imp : p.tfp;
     struct Batch { sa_u64x2 v[PF]; };
     // All indices below are relative to a0, the 16-byte-aligned start of the slice's hull: a slice is
     // far shorter than 2^32 postings, so the per-posting bookkeeping is 32-bit.
@@ -331,7 +321,7 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
         const u64 a0 = lo & ~1ull;
         const u32 npairs = (hi > a0) ? (u32)((hi - a0 + 1) >> 1) : 0u;
         const sa_u64x2* pairs = (const sa_u64x2*)(stream + a0);
-        const u64 fill = IMP != 0 ? ~0ull : 0ull;
+        const u64 fill = IMP ? ~0ull : 0ull;
 #pragma unroll
         for (int u = 0; u < PF; u++) {
             const u32 j = first + (u32)u * THREADS + tid;
@@ -343,46 +333,39 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     auto score_batch = [&](const Batch& b, u64 lo, u64 hi, u32 first, float idf) {
         const u64 a0 = lo & ~1ull;
         const u32 npairs = (hi > a0) ? (u32)((hi - a0 + 1) >> 1) : 0u;
-        if constexpr (IMP == 3) {
-            // the last step of a slice (a short slice's only one): one pair per lane, no branches
-            if (npairs - first <= (u32)THREADS) {               // (npairs > first: callers never pass an empty batch ... or nothing happens)
-                if (first + (tid & ~(u32)(SA_WAVE - 1)) < npairs) {
-                    const u32 spare = (u32)TILE + (tid & (u32)(SA_WAVE - 1));
-                    const u32 d0 = (u32)(b.v[0].x >> 32) - tile_base32, d1 = (u32)(b.v[0].y >> 32) - tile_base32;
-                    const u32 s0 = d0 < (u32)TILE ? d0 : spare, s1 = d1 < (u32)TILE ? d1 : spare;
-                    const float v0 = acc[s0], v1 = acc[s1];
-                    const float w0 = __fadd_rn(v0, __fmul_rn(__uint_as_float((u32)b.v[0].x), idf));
-                    const float w1 = __fadd_rn(v1, __fmul_rn(__uint_as_float((u32)b.v[0].y), idf));
-                    acc[s0] = w0;
-                    acc[s1] = w1;
-                }
+        if constexpr (IMP) {
+            const u32 spare = (u32)TILE + (tid & (u32)(SA_WAVE - 1));
+            if (first + (tid & ~(u32)(SA_WAVE - 1)) >= npairs) return;     // wave-uniform: no pair of this batch is this wave's
+            if (npairs - first <= (u32)THREADS) {
+                // the last step of a slice (a short slice's only one): one pair per lane
+                const u32 d0 = (u32)(b.v[0].x >> 32) - tile_base32, d1 = (u32)(b.v[0].y >> 32) - tile_base32;
+                const u32 s0 = d0 < (u32)TILE ? d0 : spare, s1 = d1 < (u32)TILE ? d1 : spare;
+                const float v0 = acc[s0], v1 = acc[s1];
+                const float w0 = __fadd_rn(v0, __fmul_rn(__uint_as_float((u32)b.v[0].x), idf));
+                const float w1 = __fadd_rn(v1, __fmul_rn(__uint_as_float((u32)b.v[0].y), idf));
+                acc[s0] = w0;
+                acc[s1] = w1;
                 return;
             }
-        }
-        if constexpr (IMP >= 2) {
-            // wave-uniform: this wave has pairs at every step of the batch (IMP == 3: at its first step);
-            // lanes / steps past the end hold sentinels
-            if (first + (u32)(IMP == 2 ? PF - 1 : 0) * THREADS + (tid & ~(u32)(SA_WAVE - 1)) < npairs) {
-                u32 slot[2 * PF];
-                float val[2 * PF];
-                const u32 spare = (u32)TILE + (tid & (u32)(SA_WAVE - 1));
+            // lanes / steps past the end of the slice hold sentinels
+            u32 slot[2 * PF];
+            float val[2 * PF];
 #pragma unroll
-                for (int u = 0; u < PF; u++) {
-                    const u32 d0 = (u32)(b.v[u].x >> 32) - tile_base32, d1 = (u32)(b.v[u].y >> 32) - tile_base32;
-                    slot[2 * u] = d0 < (u32)TILE ? d0 : spare;
-                    slot[2 * u + 1] = d1 < (u32)TILE ? d1 : spare;
-                }
-#pragma unroll
-                for (int i = 0; i < 2 * PF; i++) val[i] = acc[slot[i]];
-#pragma unroll
-                for (int u = 0; u < PF; u++) {
-                    val[2 * u] = __fadd_rn(val[2 * u], __fmul_rn(__uint_as_float((u32)b.v[u].x), idf));
-                    val[2 * u + 1] = __fadd_rn(val[2 * u + 1], __fmul_rn(__uint_as_float((u32)b.v[u].y), idf));
-                }
-#pragma unroll
-                for (int i = 0; i < 2 * PF; i++) acc[slot[i]] = val[i];
-                return;
+            for (int u = 0; u < PF; u++) {
+                const u32 d0 = (u32)(b.v[u].x >> 32) - tile_base32, d1 = (u32)(b.v[u].y >> 32) - tile_base32;
+                slot[2 * u] = d0 < (u32)TILE ? d0 : spare;
+                slot[2 * u + 1] = d1 < (u32)TILE ? d1 : spare;
             }
+#pragma unroll
+            for (int i = 0; i < 2 * PF; i++) val[i] = acc[slot[i]];
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                val[2 * u] = __fadd_rn(val[2 * u], __fmul_rn(__uint_as_float((u32)b.v[u].x), idf));
+                val[2 * u + 1] = __fadd_rn(val[2 * u + 1], __fmul_rn(__uint_as_float((u32)b.v[u].y), idf));
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * PF; i++) acc[slot[i]] = val[i];
+            return;
         }
         const u32 r_lo = (u32)(lo - a0), r_hi = (u32)(hi - a0);     // the slice inside its hull
 #pragma unroll
@@ -390,37 +373,27 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
             // wave-uniform skip: no lane of this wave has a pair at this step
             const u32 jw = first + (u32)u * THREADS + (tid & ~(u32)(SA_WAVE - 1));
             if (jw >= npairs) continue;
-            if constexpr (IMP != 0) {
-                score_imp(b.v[u].x, idf);
-                score_imp(b.v[u].y, idf);
-            } else {
-                const u32 r0 = 2u * (first + (u32)u * THREADS + tid);
-                score_into(b.v[u].x, r0 >= r_lo && r0 < r_hi, idf);
-                score_into(b.v[u].y, r0 + 1u < r_hi, idf);       // r0 + 1 >= r_lo always holds
-            }
+            const u32 r0 = 2u * (first + (u32)u * THREADS + tid);
+            score_into(b.v[u].x, r0 >= r_lo && r0 < r_hi, idf);
+            score_into(b.v[u].y, r0 + 1u < r_hi, idf);           // r0 + 1 >= r_lo always holds
         }
     };
     // Only terms with postings in this tile get a phase (and its barrier): an empty phase still costs
-    // an LDS round trip for its slice, address arithmetic and a barrier -- measured 0.15 ms per term
-    // and launch at 10 M docs x 256 queries, more than the postings of the rare terms themselves.
-    u32 todo = (u32)__builtin_amdgcn_readfirstlane((int)s_mask);
+    // address arithmetic and a barrier -- measured 0.15 ms per term and launch at 10 M docs x 256
+    // queries, more than the postings of the rare terms themselves.
     if (MODE == 1 && todo == 0u) return;                        // nothing scored: no doc can enter the top-k
-    auto uni64 = [](u64 x) -> u64 {                             // wave-uniform value -> scalar registers
-        const u32 l = (u32)__builtin_amdgcn_readfirstlane((int)(u32)x), h = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(x >> 32));
-        return ((u64)h << 32) | l;
-    };
-    // Phases are taken in groups of four.  A group's prologue fetches the slices (lo, hi, idf) of its
-    // terms from LDS in one go and requests the first 16 bytes per lane of ALL its phases (P[0..3]);
+    // Phases are taken in groups of four.  A group's prologue moves the slices (lo, hi, idf) of its
+    // terms into scalar registers and requests the first 16 bytes per lane of ALL its phases (P[0..3]);
     // the rest of a phase's first batch -- only slices longer than one step have one -- is requested
     // one phase ahead (nxt).  Inside the group a phase starts from registers: a phase with few
-    // postings (the rare terms of a query) otherwise spends far longer on LDS round trips, address
-    // arithmetic and its own memory round trip than on its postings (measured: 0.2 ms per term and
+    // postings (the rare terms of a query) otherwise spends far longer on address arithmetic and its
+    // own memory round trip than on its postings (measured: 0.2 ms per term and
     // launch at 10 M docs x 256 queries, whatever the number of postings).
     auto load_step = [&](u64 lo, u64 hi, u32 step) -> sa_u64x2 {         // step `step` of the first batch
         const u64 a0 = lo & ~1ull;
         const u32 npairs = (hi > a0) ? (u32)((hi - a0 + 1) >> 1) : 0u;
         const sa_u64x2* pairs = (const sa_u64x2*)(stream + a0);
-        const u64 fill = IMP != 0 ? ~0ull : 0ull;
+        const u64 fill = IMP ? ~0ull : 0ull;
         const u32 j = step * THREADS + tid;
         sa_u64x2 v;
         if (j < npairs) v = pairs[j];
@@ -437,11 +410,12 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
 #pragma unroll
             for (int u = 1; u < PF; u++) b.v[u] = load_step(lo, hi, (u32)u);
         } else {
-            const u64 fill = IMP != 0 ? ~0ull : 0ull;
+            const u64 fill = IMP ? ~0ull : 0ull;
 #pragma unroll
             for (int u = 1; u < PF; u++) { b.v[u].x = fill; b.v[u].y = fill; }
         }
     };
+    bool cleared = false;
     while (todo) {
         u64 L[4], H[4];
         float W[4];
@@ -453,16 +427,21 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
                 const bool have = g != 0u;
                 const u32 ti = have ? (u32)__builtin_ctz(g) : 0u;
                 g &= g - 1u;                                     // (0 stays 0)
-                L[i] = s_lo[ti]; H[i] = s_hi[ti]; W[i] = s_idf[ti];
-                if (!have) { L[i] = 0; H[i] = 0; }
+                L[i] = have ? lane64(r_lo, ti) : 0ull;
+                H[i] = have ? lane64(r_hi, ti) : 0ull;
+                W[i] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(r_idf), (int)ti));
             }
-#pragma unroll
-            for (int i = 0; i < 4; i++) { L[i] = uni64(L[i]); H[i] = uni64(H[i]); }
 #pragma unroll
             for (int i = 0; i < 4; i++) P[i] = load_step(L[i], H[i], 0);
         }
         Batch nxt;
         load_rest(nxt, L[0], H[0]);
+        if (!cleared) {                                         // first group: clear the accumulators behind the loads
+#pragma unroll
+            for (int j = 0; j < E; j++) acc[j * THREADS + tid] = 0.f;
+            __syncthreads();
+            cleared = true;
+        }
 #pragma unroll 1
         for (int k = 0; k < 4 && todo; k++) {
             todo &= todo - 1u;
@@ -493,6 +472,11 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
             W[0] = W[1]; W[1] = W[2]; W[2] = W[3];
             P[0] = P[1]; P[1] = P[2]; P[2] = P[3];
         }
+    }
+    if (!cleared) {                                             // MODE 0 without any posting in the tile: all zero
+#pragma unroll
+        for (int j = 0; j < E; j++) acc[j * THREADS + tid] = 0.f;
+        __syncthreads();
     }
 
     const u64 remain = p.n_docs - tile_base;
@@ -638,7 +622,7 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     }   // top-k
 }
 
-template <int TILE, int THREADS, int MODE, int IMP>
+template <int TILE, int THREADS, int MODE, bool IMP>
 __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
     sa_bm25_tile_item<TILE, THREADS, MODE, IMP>(p, blockIdx.x, p.nq);
 }
@@ -646,7 +630,7 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
 // The queries the sparse candidate path handed back (usually none): their number is only known on the
 // device, so a resident grid walks the (tile, query) items of the list -- no host round trip to size a
 // launch.  Slower per item than one workgroup per item, which does not matter for a rare fallback.
-template <int TILE, int THREADS, int IMP>
+template <int TILE, int THREADS, bool IMP>
 __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles_list(const Bm25Params p) {
     const u32 nq = *p.nq_dev;
     const u64 n_items = (u64)nq * p.n_tiles;
@@ -869,14 +853,10 @@ static int sa_env_int(const char* name, int dflt) {
 
 #define SA_LAUNCH_TILE(TILE, THREADS)                                                              \
     {                                                                                              \
-        if (MODE == 1 && p.imp && p.imp_route == 3)                                                \
-            hipLaunchKernelGGL((sa_k_bm25_tiles<TILE, THREADS, MODE, MODE == 1 ? 3 : 0>), dim3((u32)n_items), dim3(THREADS), 0, st, p); \
-        else if (MODE == 1 && p.imp && p.imp_route == 2)                                           \
-            hipLaunchKernelGGL((sa_k_bm25_tiles<TILE, THREADS, MODE, MODE == 1 ? 2 : 0>), dim3((u32)n_items), dim3(THREADS), 0, st, p); \
-        else if (MODE == 1 && p.imp)                                                               \
-            hipLaunchKernelGGL((sa_k_bm25_tiles<TILE, THREADS, MODE, MODE == 1 ? 1 : 0>), dim3((u32)n_items), dim3(THREADS), 0, st, p); \
+        if (MODE == 1 && p.imp)                                                                    \
+            hipLaunchKernelGGL((sa_k_bm25_tiles<TILE, THREADS, MODE, MODE == 1>), dim3((u32)n_items), dim3(THREADS), 0, st, p); \
         else                                                                                       \
-            hipLaunchKernelGGL((sa_k_bm25_tiles<TILE, THREADS, MODE, 0>), dim3((u32)n_items), dim3(THREADS), 0, st, p); \
+            hipLaunchKernelGGL((sa_k_bm25_tiles<TILE, THREADS, MODE, false>), dim3((u32)n_items), dim3(THREADS), 0, st, p); \
     }                                                                                              \
     break
 
@@ -900,9 +880,9 @@ static int sa_launch_bm25_mode(sa_index* ix, const Bm25Params& p, hipStream_t st
 #define SA_LAUNCH_LIST(TILE, THREADS)                                                              \
     {                                                                                              \
         if (p.imp)                                                                                 \
-            hipLaunchKernelGGL((sa_k_bm25_tiles_list<TILE, THREADS, 1>), dim3(grid), dim3(THREADS), 0, st, p); \
+            hipLaunchKernelGGL((sa_k_bm25_tiles_list<TILE, THREADS, true>), dim3(grid), dim3(THREADS), 0, st, p); \
         else                                                                                       \
-            hipLaunchKernelGGL((sa_k_bm25_tiles_list<TILE, THREADS, 0>), dim3(grid), dim3(THREADS), 0, st, p); \
+            hipLaunchKernelGGL((sa_k_bm25_tiles_list<TILE, THREADS, false>), dim3(grid), dim3(THREADS), 0, st, p); \
     }                                                                                              \
     break
 
@@ -1264,10 +1244,8 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     p.terms = bt->d_terms; p.idf = bt->d_idf; p.B = bt->B; p.T = bt->T; p.k = bt->k;
     p.k1 = bt->k1; p.b = bt->b;
     p.bounds = bt->d_bounds; p.qbase = bt->d_qbase;
-    if (bt->impacts && bt->kind == 0 && sa_env_int("SA_IMPACT", 3) != 0) {
+    if (bt->impacts && bt->kind == 0 && sa_env_int("SA_IMPACT", 1) != 0) {
         p.imp = bt->impacts->d_imp; p.qbase_imp = bt->d_qbase_imp;
-        p.imp_route = sa_env_int("SA_IMPACT", 3);
-        if (p.imp_route < 1 || p.imp_route > 3) p.imp_route = 3;
     }
     p.sattab = bt->d_sattab; p.tab_w = bt->tab_w;
     p.pruned = (sa_env_int("SA_PRUNED_TOPK", 1) && !force_unpruned) ? 1 : 0;   // pruned wave-level selection (any k <= 1024)

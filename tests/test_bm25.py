@@ -430,10 +430,9 @@ def test_impact_stream_exhaustive_scan(api, monkeypatch, integer_lens):
     _check_batch(c, orc, queries, 20, k1=1.7, b=0.3)
     s_a2, d_a2 = _check_batch(a, orc, queries, 20)                            # `a` still owns its stream
     assert np.array_equal(s_a, s_a2) and np.array_equal(d_a, d_a2)
-    for route in ("1", "0"):                                                  # same batch: one posting at a time / TF postings
-        monkeypatch.setenv("SA_IMPACT", route)
-        s_b, d_b = _check_batch(a, orc, queries, 20)
-        assert np.array_equal(s_a, s_b) and np.array_equal(d_a, d_b)
+    monkeypatch.setenv("SA_IMPACT", "0")                                      # same batch, TF-posting route
+    s_b, d_b = _check_batch(a, orc, queries, 20)
+    assert np.array_equal(s_a, s_b) and np.array_equal(d_a, d_b)
     e = dev.batch(queries, k=20, k1=0.9, b=0.0)                               # built without a stream at all
     _check_batch(e, orc, queries, 20, k1=0.9, b=0.0)
     for bt in (a, c, e):
