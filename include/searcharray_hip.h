@@ -242,7 +242,11 @@ int sa_index_last_profile(sa_index_t* ix, double* kernel_ms_out, uint64_t* alg_b
 /* Device-resident batch of B queries x T terms with top-k selection (k <= 1024).
  * terms/idf are [B][T] row-major.  Results per query: k (score, doc) pairs sorted by score
  * descending then doc id ascending; slots beyond the number of matching docs hold
- * score 0 and doc 0xFFFFFFFFFFFFFFFF.  Doc ids are global (local + doc_base). */
+ * score 0 and doc 0xFFFFFFFFFFFFFFFF.  Doc ids are global (local + doc_base).
+ * The first batch created with a given (k1, b) also derives the index's impact stream for those
+ * parameters (8 bytes per posting of HBM, shared by later batches with the same parameters and
+ * released with the last of them; SA_IMPACT=0 or a failed allocation: batches score the TF
+ * postings instead, same results). */
 int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const float* idf, int n_queries,
                     int n_query_terms, int k, float k1, float b, sa_batch_t** out);
 /* Device-resident batch of B exact phrases (slop 0) with BM25 scoring and top-k selection: the
