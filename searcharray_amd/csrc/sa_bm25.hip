@@ -415,6 +415,40 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
             for (int u = 1; u < PF; u++) { b.v[u].x = fill; b.v[u].y = fill; }
         }
     };
+    // The first loads of a group are UNCONDITIONAL (lanes past the end of a slice re-read its last pair and
+    // are invalidated when the pair is consumed) and issued in the order  first batch of phase 0, second
+    // batch of phase 0 if its slice is long, first step of phases 1..3 : the compiler can then count them,
+    // and phase 0 -- peeled out of the loop below -- waits with vmcnt(3) for its own data only.  The slices of
+    // the rare terms (never shared between queries, so they come from HBM, not L2) arrive while the
+    // frequent first term is being scored instead of holding the workgroup up before it starts.
+    auto load_step_u = [&](u64 lo, u64 hi, u32 step) -> sa_u64x2 {
+        const u64 a0 = lo & ~1ull;
+        const u32 npairs = pairs_of(lo, hi);
+        const sa_u64x2* pairs = (const sa_u64x2*)(stream + a0);
+        const u32 j = step * THREADS + tid;
+        const u32 last = npairs ? npairs - 1u : 0u;
+        return pairs[j < last ? j : last];
+    };
+    auto invalidate = [&](sa_u64x2& v, u32 j, u32 npairs) {
+        const u64 fill = IMP ? ~0ull : 0ull;
+        if (j >= npairs) { v.x = fill; v.y = fill; }
+    };
+    // one term phase: the first batch `cur`, then -- long slices -- the rest, `b` being the second batch (already requested)
+    auto run_phase = [&](const Batch& cur, Batch& b, u64 lo, u64 hi, float idf) {
+        const u32 npairs = pairs_of(lo, hi);
+        score_batch(cur, lo, hi, 0, idf);
+        if (npairs > (u32)PF * THREADS) {
+            u32 first = (u32)PF * THREADS;
+            while (first < npairs) {
+                const u32 nf = first + (u32)PF * THREADS;
+                Batch b2;
+                if (nf < npairs) b2 = load_batch(lo, hi, nf);
+                score_batch(b, lo, hi, first, idf);
+                if (nf < npairs) b = b2;
+                first = nf;
+            }
+        }
+    };
     bool cleared = false;
     while (todo) {
         u64 L[4], H[4];
@@ -431,46 +465,48 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
                 H[i] = have ? lane64(r_hi, ti) : 0ull;
                 W[i] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(r_idf), (int)ti));
             }
-#pragma unroll
-            for (int i = 0; i < 4; i++) P[i] = load_step(L[i], H[i], 0);
         }
-        Batch nxt;
-        load_rest(nxt, L[0], H[0]);
-        if (!cleared) {                                         // first group: clear the accumulators behind the loads
-#pragma unroll
-            for (int j = 0; j < E; j++) acc[j * THREADS + tid] = 0.f;
-            __syncthreads();
-            cleared = true;
-        }
-#pragma unroll 1
-        for (int k = 0; k < 4 && todo; k++) {
-            todo &= todo - 1u;
+        // ---- phase 0 of the group
+        {
             const u64 lo = L[0], hi = H[0];
-            const float idf = W[0];
-            Batch cur = nxt;
-            cur.v[0] = P[0];
-            load_rest(nxt, L[1], H[1]);                         // (the next group's first phase: nothing, L[1] = H[1] = 0)
             const u32 npairs = pairs_of(lo, hi);
-            const bool long_slice = npairs > (u32)PF * THREADS;  // (frequent term)
-            Batch b;
-            if (long_slice) b = load_batch(lo, hi, (u32)PF * THREADS);   // requested before the first batch is scored
-            score_batch(cur, lo, hi, 0, idf);
-            if (long_slice) {
-                u32 first = (u32)PF * THREADS;
-                while (first < npairs) {
-                    const u32 nf = first + (u32)PF * THREADS;
-                    Batch b2;
-                    if (nf < npairs) b2 = load_batch(lo, hi, nf);
-                    score_batch(b, lo, hi, first, idf);
-                    if (nf < npairs) b = b2;
-                    first = nf;
-                }
+            Batch cur, b;
+#pragma unroll
+            for (int u = 0; u < PF; u++) cur.v[u] = load_step_u(lo, hi, (u32)u);
+            if (npairs > (u32)PF * THREADS) b = load_batch(lo, hi, (u32)PF * THREADS);
+#pragma unroll
+            for (int i = 1; i < 4; i++) P[i] = load_step_u(L[i], H[i], 0);
+            if (!cleared) {                                     // first group: clear the accumulators behind the loads
+#pragma unroll
+                for (int j = 0; j < E; j++) acc[j * THREADS + tid] = 0.f;
+                __syncthreads();
+                cleared = true;
             }
+            todo &= todo - 1u;
+#pragma unroll
+            for (int u = 0; u < PF; u++) invalidate(cur.v[u], (u32)u * THREADS + tid, npairs);
+            run_phase(cur, b, lo, hi, W[0]);
             __syncthreads();
+        }
+        // ---- phases 1..3
+        Batch nxt;
+        load_rest(nxt, L[1], H[1]);
+#pragma unroll 1
+        for (int k = 1; k < 4 && todo; k++) {
+            todo &= todo - 1u;
             L[0] = L[1]; L[1] = L[2]; L[2] = L[3]; L[3] = 0;
             H[0] = H[1]; H[1] = H[2]; H[2] = H[3]; H[3] = 0;
             W[0] = W[1]; W[1] = W[2]; W[2] = W[3];
             P[0] = P[1]; P[1] = P[2]; P[2] = P[3];
+            const u64 lo = L[0], hi = H[0];
+            const u32 npairs = pairs_of(lo, hi);
+            Batch cur = nxt, b;
+            cur.v[0] = P[0];
+            invalidate(cur.v[0], tid, npairs);
+            load_rest(nxt, L[1], H[1]);                         // (the next group's first phase: nothing, L[1] = H[1] = 0)
+            if (npairs > (u32)PF * THREADS) b = load_batch(lo, hi, (u32)PF * THREADS);   // requested before the first batch is scored
+            run_phase(cur, b, lo, hi, W[0]);
+            __syncthreads();
         }
     }
     if (!cleared) {                                             // MODE 0 without any posting in the tile: all zero
