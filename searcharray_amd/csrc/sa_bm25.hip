@@ -167,6 +167,7 @@ static std::shared_ptr<sa_impacts> sa_impacts_get(sa_index* ix, float k1, float 
 // idf instead of two divisions.  Postings outside the table take the arithmetic path.
 #define SA_SAT_NTF 8
 #define SA_SAT_WMAX 128
+#define SA_GRID_Y 32768u      // tiles per grid.y slab of the tile kernel's (queries, tiles) grid
 
 __global__ void sa_k_make_sattab(float* __restrict__ tab, u32 tab_w, float k1, float b, float avgdl) {
     const float one_minus_b = 1.0f - b;
@@ -216,7 +217,7 @@ sa_k_make_bounds(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, co
 // lane then updates its accumulators together -- 8 LDS reads in flight, the adds, 8 writes -- and a posting
 // outside the tile is steered to a spare slot behind the tile instead of being branched around.
 template <int TILE, int THREADS, int MODE, bool IMP>
-__device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32 item, const u32 nq) {
+__device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32 tile, const u32 qi) {
     constexpr int NW = THREADS / SA_WAVE;
     constexpr int E = TILE / THREADS;
     constexpr int CAP = (TILE >= 8192) ? 2048 : TILE / 4;      // candidate list capacity (MODE 0)
@@ -240,13 +241,11 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     const u32 tid = threadIdx.x;
     const u32 T = p.T;
     const u32 tab_w = p.tab_w;
-    if (p.no_topk == 2) return;                                 // timing experiments: dispatch cost only
     if constexpr (!IMP) {
         for (u32 i = tid; i < SA_SAT_NTF * tab_w; i += THREADS) s_tab[i] = p.sattab[i];
     }
     // (queries answered by the sparse candidate path, sa_sparse.hip, are not in the list)
-    const u32 tile = item / nq;
-    const u32 q = p.qlist ? p.qlist[item % nq] : item % nq;
+    const u32 q = p.qlist ? p.qlist[qi] : qi;
     const u64 tile_base = (u64)tile * TILE;
     // pruning slots of this query (see the top-k section); loaded first so the L2 latency hides
     // behind the posting stream.  L1-bypassing load: a fresher bound prunes more.
@@ -660,7 +659,10 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
 
 template <int TILE, int THREADS, int MODE, bool IMP>
 __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
-    sa_bm25_tile_item<TILE, THREADS, MODE, IMP>(p, blockIdx.x, p.nq);
+    // grid (queries, tiles): x runs fastest, so the dispatch order is tile-major without a division
+    const u32 tile = blockIdx.z * SA_GRID_Y + blockIdx.y;
+    if (tile >= p.n_tiles) return;
+    sa_bm25_tile_item<TILE, THREADS, MODE, IMP>(p, tile, blockIdx.x);
 }
 
 // The queries the sparse candidate path handed back (usually none): their number is only known on the
@@ -671,7 +673,7 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles_list(const Bm25Params
     const u32 nq = *p.nq_dev;
     const u64 n_items = (u64)nq * p.n_tiles;
     for (u64 item = blockIdx.x; item < n_items; item += gridDim.x) {
-        sa_bm25_tile_item<TILE, THREADS, 1, IMP>(p, (u32)item, nq);
+        sa_bm25_tile_item<TILE, THREADS, 1, IMP>(p, (u32)(item / nq), (u32)(item % nq));
         __syncthreads();                              // LDS is reused by the next item
     }
 }
@@ -890,15 +892,16 @@ static int sa_env_int(const char* name, int dflt) {
 #define SA_LAUNCH_TILE(TILE, THREADS)                                                              \
     {                                                                                              \
         if (MODE == 1 && p.imp)                                                                    \
-            hipLaunchKernelGGL((sa_k_bm25_tiles<TILE, THREADS, MODE, MODE == 1>), dim3((u32)n_items), dim3(THREADS), 0, st, p); \
+            hipLaunchKernelGGL((sa_k_bm25_tiles<TILE, THREADS, MODE, MODE == 1>), grid, dim3(THREADS), 0, st, p); \
         else                                                                                       \
-            hipLaunchKernelGGL((sa_k_bm25_tiles<TILE, THREADS, MODE, false>), dim3((u32)n_items), dim3(THREADS), 0, st, p); \
+            hipLaunchKernelGGL((sa_k_bm25_tiles<TILE, THREADS, MODE, false>), grid, dim3(THREADS), 0, st, p); \
     }                                                                                              \
     break
 
 template <int MODE>
 static int sa_launch_bm25_mode(sa_index* ix, const Bm25Params& p, hipStream_t st) {
-    const u64 n_items = (u64)p.nq * ix->n_tiles;
+    const u32 gy = ix->n_tiles < SA_GRID_Y ? ix->n_tiles : SA_GRID_Y;
+    const dim3 grid(p.nq, gy, (ix->n_tiles + SA_GRID_Y - 1) / SA_GRID_Y);
     switch (ix->tile_docs) {
         case 1024: SA_LAUNCH_TILE(1024, 128);
         case 2048: SA_LAUNCH_TILE(2048, 64);
