@@ -122,7 +122,7 @@ sa_k_make_impacts(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, c
             const float dl = dl_packed ? (float)(u32)((x >> SA_LSB_BITS) & SA_LSB_MASK) : doc_lens[doc];
             const float norm = __fmul_rn(k1, __fadd_rn(one_minus_b, __fmul_rn(b, __fdiv_rn(dl, avgdl))));
             const float sat = __fdiv_rn(tf, __fadd_rn(tf, norm));
-            imp[sa_imp_base(tbase, lo) + (i - tbase)] = ((u64)doc << 32) | (u64)__float_as_uint(sat);
+            imp[sa_imp_base(tbase, lo) + (i - tbase)] = ((u64)(doc << 2) << 32) | (u64)__float_as_uint(sat);   // doc * 4: the accumulator's byte offset
         }
         __syncthreads();
     }
@@ -309,7 +309,8 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     // Impact stream: the factor is in the posting and a posting is valid iff its doc lies in this tile
     // (terms start on even indices and gaps hold an all-ones sentinel, so whatever else a pair load of
     // the hull brings along -- the previous / next tile's posting, padding -- fails the same test).
-    const u32 tile_base32 = (u32)tile_base;
+    const u32 tile_base_b = (u32)tile_base * 4u;                // the stream holds doc * 4: byte offsets into the accumulators
+    auto acc_at = [&](u32 byte_off) -> float& { return *(float*)((char*)acc + byte_off); };
     const u64* const stream = IMP ? p.imp : p.tfp;
     struct Batch { sa_u64x2 v[PF]; };
     // All indices below are relative to a0, the 16-byte-aligned start of the slice's hull: a slice is
@@ -331,20 +332,20 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     };
     // impact stream: one pair per lane
     auto score_pair = [&](const sa_u64x2& v, float idf) {
-        const u32 spare = (u32)TILE + (tid & (u32)(SA_WAVE - 1));
-        const u32 d0 = (u32)(v.x >> 32) - tile_base32, d1 = (u32)(v.y >> 32) - tile_base32;
-        const u32 s0 = d0 < (u32)TILE ? d0 : spare, s1 = d1 < (u32)TILE ? d1 : spare;
-        const float v0 = acc[s0], v1 = acc[s1];
+        const u32 spare = ((u32)TILE + (tid & (u32)(SA_WAVE - 1))) * 4u;
+        const u32 d0 = (u32)(v.x >> 32) - tile_base_b, d1 = (u32)(v.y >> 32) - tile_base_b;
+        const u32 s0 = d0 < (u32)TILE * 4u ? d0 : spare, s1 = d1 < (u32)TILE * 4u ? d1 : spare;
+        const float v0 = acc_at(s0), v1 = acc_at(s1);
         const float w0 = __fadd_rn(v0, __fmul_rn(__uint_as_float((u32)v.x), idf));
         const float w1 = __fadd_rn(v1, __fmul_rn(__uint_as_float((u32)v.y), idf));
-        acc[s0] = w0;
-        acc[s1] = w1;
+        acc_at(s0) = w0;
+        acc_at(s1) = w1;
     };
     auto score_batch = [&](const Batch& b, u64 lo, u64 hi, u32 first, float idf) {
         const u64 a0 = lo & ~1ull;
         const u32 npairs = (hi > a0) ? (u32)((hi - a0 + 1) >> 1) : 0u;
         if constexpr (IMP) {
-            const u32 spare = (u32)TILE + (tid & (u32)(SA_WAVE - 1));
+            const u32 spare = ((u32)TILE + (tid & (u32)(SA_WAVE - 1))) * 4u;
             if (first + (tid & ~(u32)(SA_WAVE - 1)) >= npairs) return;     // wave-uniform: no pair of this batch is this wave's
             if (npairs - first <= (u32)THREADS) {               // the last step of a slice (a short slice's only one)
                 score_pair(b.v[0], idf);
@@ -355,19 +356,19 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
             float val[2 * PF];
 #pragma unroll
             for (int u = 0; u < PF; u++) {
-                const u32 d0 = (u32)(b.v[u].x >> 32) - tile_base32, d1 = (u32)(b.v[u].y >> 32) - tile_base32;
-                slot[2 * u] = d0 < (u32)TILE ? d0 : spare;
-                slot[2 * u + 1] = d1 < (u32)TILE ? d1 : spare;
+                const u32 d0 = (u32)(b.v[u].x >> 32) - tile_base_b, d1 = (u32)(b.v[u].y >> 32) - tile_base_b;
+                slot[2 * u] = d0 < (u32)TILE * 4u ? d0 : spare;
+                slot[2 * u + 1] = d1 < (u32)TILE * 4u ? d1 : spare;
             }
 #pragma unroll
-            for (int i = 0; i < 2 * PF; i++) val[i] = acc[slot[i]];
+            for (int i = 0; i < 2 * PF; i++) val[i] = acc_at(slot[i]);
 #pragma unroll
             for (int u = 0; u < PF; u++) {
                 val[2 * u] = __fadd_rn(val[2 * u], __fmul_rn(__uint_as_float((u32)b.v[u].x), idf));
                 val[2 * u + 1] = __fadd_rn(val[2 * u + 1], __fmul_rn(__uint_as_float((u32)b.v[u].y), idf));
             }
 #pragma unroll
-            for (int i = 0; i < 2 * PF; i++) acc[slot[i]] = val[i];
+            for (int i = 0; i < 2 * PF; i++) acc_at(slot[i]) = val[i];
             return;
         }
         const u32 r_lo = (u32)(lo - a0), r_hi = (u32)(hi - a0);     // the slice inside its hull
@@ -433,8 +434,10 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
         return pairs[j < last ? j : last];
     };
     auto invalidate = [&](sa_u64x2& v, u32 j, u32 npairs) {
-        const u64 fill = IMP ? ~0ull : 0ull;
-        if (j >= npairs) { v.x = fill; v.y = fill; }
+        if (j >= npairs) {
+            if constexpr (IMP) { v.x |= 0xFFFFFFFF00000000ull; v.y |= 0xFFFFFFFF00000000ull; }   // the doc word decides
+            else { v.x = 0; v.y = 0; }
+        }
     };
     // one term phase: the first batch `cur`, then -- long slices -- the rest, `b` being the second batch (already requested)
     auto run_phase = [&](const Batch& cur, Batch& b, u64 lo, u64 hi, float idf) {

@@ -30,7 +30,8 @@ struct sa_comm;   // RCCL communicator wrapper (sa_comm.hip)
 // Impact stream of one (k1, b, avgdl) instantiation of BM25 (sa_bm25.hip, sa_k_make_impacts): the TF
 // postings with the per-posting factor  tf / (tf + k1 * ((1 - b) + b * dl / avgdl))  already evaluated
 // (reference bm25.pyx:19-23, op for op), laid out for the exhaustive tile kernel:
-//   imp[i] = doc << 32 | float bits of the factor
+//   imp[i] = (doc * 4) << 32 | float bits of the factor      (doc * 4: the byte offset of the doc's
+//            fp32 accumulator once the tile base is subtracted)
 // Term t starts at the EVEN index  (tf_off[t] + t + 1) & ~1  and every gap holds the sentinel
 // 0xFFFF'FFFF'FFFF'FFFF (doc id no tile contains), so a 16-byte pair load never sees another term's
 // posting and "doc inside this tile" is the only validity test a posting needs.
