@@ -437,3 +437,13 @@ def test_impact_stream_exhaustive_scan(api, monkeypatch, integer_lens):
     _check_batch(e, orc, queries, 20, k1=0.9, b=0.0)
     for bt in (a, c, e):
         bt.close()
+    # nine terms per query: three groups of term phases (4 + 4 + 1), long slices in every position of a group,
+    # rare / unknown / repeated terms in between
+    monkeypatch.delenv("SA_IMPACT")
+    wide = np.asarray([[0, 399, 1, 398, 2, 397, 3, 396, 4], [399, 398, 397, 396, 395, 0, 1, 2, 3],
+                       [7, 7, 450, 8, 300, 0, 451, 9, 7], [390, 391, 392, 393, 394, 395, 396, 397, 398]])
+    for env in ("1", "0"):
+        monkeypatch.setenv("SA_IMPACT", env)
+        w = dev.batch(wide, k=15)
+        _check_batch(w, orc, wide, 15)
+        w.close()
