@@ -5,8 +5,9 @@
 //     as_dense (scatter, roaringish_ops.pyx:84-98)  ->  _bm25_score (bm25.pyx:11-25, O(N) per term)
 //     ->  np.sum(axis=0) (test/test_msmarco.py:353-354)  ->  np.argpartition (utils/sort.py:24)
 // with one sparse pass: a workgroup owns (query, doc tile); the tile's fp32 score accumulators
-// live in LDS; each query term's slice of the fat posting stream (doc|doc_len|tf in one u64) is
-// read once with coalesced 64-bit loads, scored, and added into LDS in QUERY-TERM ORDER (a barrier
+// live in LDS; each query term's slice of the posting stream -- the fat TF postings (doc|doc_len|tf
+// in one u64) or, for top-k batches, the impact stream derived from them (doc*4 | fp32 factor) -- is
+// read once with coalesced 16-byte loads, scored, and added into LDS in QUERY-TERM ORDER (a barrier
 // separates terms) so the fp32 sum is bit-identical to the reference's ((s0+s1)+s2)+s3.
 // Per-posting arithmetic is the reference's, op for op, each rounded to fp32 (no FMA contraction,
 // IEEE division):  tf / (tf + k1 * ((1 - b) + b * (dl / avgdl))) * idf.
@@ -212,7 +213,7 @@ sa_k_make_bounds(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, co
 
 // MODE 0: dense output and/or block-level threshold top-k (any k <= 1024).
 // MODE 1: pruned wave-level top-k against the query's global bound (any k <= 1024), the batch fast path.
-// One work item = one (tile, query) pair; `nq` queries are in play (p.qlist maps them, if set).
+// One work item = one (tile, query) pair; `qi` indexes the queries in play (p.qlist maps it, if set).
 // IMP: read the impact stream (p.imp / p.qbase_imp) instead of the TF postings.  A batch of 8 postings per
 // lane then updates its accumulators together -- 8 LDS reads in flight, the adds, 8 writes -- and a posting
 // outside the tile is steered to a spare slot behind the tile instead of being branched around.
@@ -233,11 +234,12 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     __shared__ float s_tab[SA_SAT_NTF * SA_SAT_WMAX];
     float* acc = (float*)smem;
 
-    // Work items (tile, query) are numbered tile-major, one workgroup per item: the items in
+    // Work items (tile, query) are dispatched tile-major, one workgroup per item: the items in
     // flight at any moment are the same few tiles across many queries, so posting slices shared
-    // by queries are served from L2.  (A resident grid walking the items with a static stride was
-    // measured slower on MI355X -- 3.3-3.7 ms vs 2.7 ms per 256-query batch at 10M docs: the
-    // hardware dispatcher is the better load balancer, and the loop inflates register use.)
+    // by queries are served from L2.  (Resident grids were measured slower on MI355X, twice: walking
+    // the items with a static stride -- 3.3-3.7 ms vs 2.7 ms per 256-query batch at 10M docs -- and
+    // pulling them from an atomic work queue with the next item's loads requested ahead -- 3.1 ms vs
+    // 1.6 ms: DESIGN 3.1.)
     const u32 tid = threadIdx.x;
     const u32 T = p.T;
     const u32 tab_w = p.tab_w;
