@@ -46,7 +46,7 @@ struct Bm25Params {
     const u32* bounds;     // [B][T][n_tiles+1] slice table (sa_k_make_bounds)
     const u64* qbase;      // [B][T] posting base of each query term
     const u64* imp;        // impact stream (sa_impacts, sa_index.hpp) or null: score the TF postings
-    const u64* qbase_imp;  // [B][T] base of each query term in the impact stream
+    const u64* qbase_imp;  // [B][T][2] impact stream: first cell of each query term, first cell of the sentinel pair behind it
     u32 B, T, k;
     float k1, b, avgdl;
     int pruned;            // 1: wave-level selection against a global bound (MODE 1); 0: block-level selection (MODE 0)
@@ -86,7 +86,11 @@ sa_impacts::~sa_impacts() {
     }
 }
 
-__host__ __device__ __forceinline__ u64 sa_imp_base(u64 tf_base, u32 term) { return (tf_base + term + 1ull) & ~1ull; }
+// (4 cells of slack per term: a term's last posting is followed by at least one whole, 16-byte-aligned pair
+//  of sentinels before the next term starts -- the pair every load past a slice's term is clamped to)
+__host__ __device__ __forceinline__ u64 sa_imp_base(u64 tf_base, u32 term) { return (tf_base + 4ull * term + 1ull) & ~1ull; }
+// first cell of that sentinel pair, for a term of df postings starting at `ibase`
+__host__ __device__ __forceinline__ u64 sa_imp_sentinel(u64 ibase, u64 df) { return ibase + ((df + 1ull) & ~1ull); }
 
 __global__ void __launch_bounds__(256)
 sa_k_make_impacts(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, const float* __restrict__ doc_lens,
@@ -143,7 +147,7 @@ static std::shared_ptr<sa_impacts> sa_impacts_get(sa_index* ix, float k1, float 
     std::shared_ptr<sa_impacts> im(new (std::nothrow) sa_impacts());
     if (!im) return nullptr;
     im->device = ix->device; im->k1 = k1; im->b = b; im->avgdl = ix->avg_doc_len;
-    im->n = sa_imp_base(ix->n_postings, ix->n_terms) + 2;
+    im->n = sa_imp_base(ix->n_postings, ix->n_terms) + 4;
     if (hipMalloc(&im->d_imp, im->n * sizeof(u64)) != hipSuccess) {
         (void)hipGetLastError();
         im->d_imp = nullptr;
@@ -194,10 +198,11 @@ sa_k_make_bounds(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, co
         const u32 qt = (u32)(e / (n_tiles + 1)), tile = (u32)(e % (n_tiles + 1));
         const u32 term = terms[qt];
         u32 rel = 0;
-        u64 base = 0, ibase = 0;
+        u64 base = 0, ibase = 0, isent = 0;
         if (term < n_terms) {
             base = tf_off[term];
             ibase = sa_imp_base(base, term);
+            isent = sa_imp_sentinel(ibase, tf_off[term + 1] - base);
             const u32 cnt = (u32)(tf_off[term + 1] - base);
             const u32 slot = dir_slot[term];
             if (slot != 0xFFFFFFFFu) rel = tile_dir[(u64)slot * (n_tiles + 1) + tile];
@@ -206,7 +211,7 @@ sa_k_make_bounds(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, co
         bounds[e] = rel;
         if (tile == 0) {
             qbase[qt] = base;
-            if (qbase_imp) qbase_imp[qt] = ibase;
+            if (qbase_imp) { qbase_imp[2 * (u64)qt] = ibase; qbase_imp[2 * (u64)qt + 1] = isent; }
         }
     }
 }
@@ -264,12 +269,19 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     //    slices reach the scalar registers by readlane -- no LDS staging, no barrier between the lookup
     //    and the first posting loads; the accumulators are cleared while those are in flight.
     const u32 lane = tid & (u32)(SA_WAVE - 1);
-    u64 r_lo = 0, r_hi = 0;
+    u64 r_lo = 0, r_hi = 0, r_send = 0;                         // r_send: the sentinel pair behind the term (impact stream)
     float r_idf = 0.f;
     if (lane < T) {
         const u32 qt = q * T + lane;
         const u32* row = p.bounds + (u64)qt * (p.n_tiles + 1) + tile;
-        const u64 base = IMP ? p.qbase_imp[qt] : p.qbase[qt];
+        u64 base;
+        if constexpr (IMP) {
+            const sa_u64x2 bs = ((const sa_u64x2*)p.qbase_imp)[qt];
+            base = bs.x;
+            r_send = bs.y;
+        } else {
+            base = p.qbase[qt];
+        }
         const u32 r0 = row[0], r1 = row[1];
         r_lo = base + r0;
         r_hi = base + r1;
@@ -318,17 +330,29 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     // All indices below are relative to a0, the 16-byte-aligned start of the slice's hull: a slice is
     // far shorter than 2^32 postings, so the per-posting bookkeeping is 32-bit.
     // pairs [first, first + PF*THREADS) of the hull of [lo, hi)
-    auto load_batch = [&](u64 lo, u64 hi, u32 first) -> Batch {
+    // `send` (impact stream): first cell of the sentinel pair behind the slice's term.  Every load of the
+    // impact stream is unconditional and clamped to that pair: what lies between the end of the slice and
+    // it are the term's postings of later tiles, which fail the doc test like the sentinels themselves --
+    // no per-lane bounds test, no fill value, nothing to invalidate.
+    auto load_batch = [&](u64 lo, u64 hi, u64 send, u32 first) -> Batch {
         Batch b;
         const u64 a0 = lo & ~1ull;
-        const u32 npairs = (hi > a0) ? (u32)((hi - a0 + 1) >> 1) : 0u;
         const sa_u64x2* pairs = (const sa_u64x2*)(stream + a0);
-        const u64 fill = IMP ? ~0ull : 0ull;
+        if constexpr (IMP) {
+            const u32 jc = (u32)((send - a0) >> 1);
 #pragma unroll
-        for (int u = 0; u < PF; u++) {
-            const u32 j = first + (u32)u * THREADS + tid;
-            if (j < npairs) b.v[u] = pairs[j];
-            else { b.v[u].x = fill; b.v[u].y = fill; }
+            for (int u = 0; u < PF; u++) {
+                const u32 j = first + (u32)u * THREADS + tid;
+                b.v[u] = pairs[j < jc ? j : jc];
+            }
+        } else {
+            const u32 npairs = (hi > a0) ? (u32)((hi - a0 + 1) >> 1) : 0u;
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const u32 j = first + (u32)u * THREADS + tid;
+                if (j < npairs) b.v[u] = pairs[j];
+                else { b.v[u].x = 0; b.v[u].y = 0; }
+            }
         }
         return b;
     };
@@ -395,54 +419,61 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     // postings (the rare terms of a query) otherwise spends far longer on address arithmetic and its
     // own memory round trip than on its postings (measured: 0.2 ms per term and
     // launch at 10 M docs x 256 queries, whatever the number of postings).
-    auto load_step = [&](u64 lo, u64 hi, u32 step) -> sa_u64x2 {         // step `step` of the first batch
+    auto load_step = [&](u64 lo, u64 hi, u64 send, u32 step) -> sa_u64x2 {     // step `step` of the first batch
         const u64 a0 = lo & ~1ull;
-        const u32 npairs = (hi > a0) ? (u32)((hi - a0 + 1) >> 1) : 0u;
         const sa_u64x2* pairs = (const sa_u64x2*)(stream + a0);
-        const u64 fill = IMP ? ~0ull : 0ull;
         const u32 j = step * THREADS + tid;
-        sa_u64x2 v;
-        if (j < npairs) v = pairs[j];
-        else { v.x = fill; v.y = fill; }
-        return v;
+        if constexpr (IMP) {
+            const u32 jc = (u32)((send - a0) >> 1);
+            return pairs[j < jc ? j : jc];
+        } else {
+            const u32 npairs = (hi > a0) ? (u32)((hi - a0 + 1) >> 1) : 0u;
+            sa_u64x2 v;
+            if (j < npairs) v = pairs[j];
+            else { v.x = 0; v.y = 0; }
+            return v;
+        }
     };
     auto pairs_of = [](u64 lo, u64 hi) -> u32 {
         const u64 a0 = lo & ~1ull;
         return (hi > a0) ? (u32)((hi - a0 + 1) >> 1) : 0u;
     };
     // steps 1 .. PF-1 of a slice's first batch (nothing to fetch for a slice of one step)
-    auto load_rest = [&](Batch& b, u64 lo, u64 hi) {
+    auto load_rest = [&](Batch& b, u64 lo, u64 hi, u64 send) {
         if (pairs_of(lo, hi) > (u32)THREADS) {
 #pragma unroll
-            for (int u = 1; u < PF; u++) b.v[u] = load_step(lo, hi, (u32)u);
+            for (int u = 1; u < PF; u++) b.v[u] = load_step(lo, hi, send, (u32)u);
         } else {
             const u64 fill = IMP ? ~0ull : 0ull;
 #pragma unroll
             for (int u = 1; u < PF; u++) { b.v[u].x = fill; b.v[u].y = fill; }
         }
     };
-    // The first loads of a group are UNCONDITIONAL (lanes past the end of a slice re-read its last pair and
-    // are invalidated when the pair is consumed) and issued in the order  first batch of phase 0, second
+    // The first loads of a group are UNCONDITIONAL (TF postings: lanes past the end of a slice re-read its last
+    // pair and are zeroed when the pair is consumed) and issued in the order  first batch of phase 0, second
     // batch of phase 0 if its slice is long, first step of phases 1..3 : the compiler can then count them,
     // and phase 0 -- peeled out of the loop below -- waits with vmcnt(3) for its own data only.  The slices of
     // the rare terms (never shared between queries, so they come from HBM, not L2) arrive while the
     // frequent first term is being scored instead of holding the workgroup up before it starts.
-    auto load_step_u = [&](u64 lo, u64 hi, u32 step) -> sa_u64x2 {
-        const u64 a0 = lo & ~1ull;
-        const u32 npairs = pairs_of(lo, hi);
-        const sa_u64x2* pairs = (const sa_u64x2*)(stream + a0);
-        const u32 j = step * THREADS + tid;
-        const u32 last = npairs ? npairs - 1u : 0u;
-        return pairs[j < last ? j : last];
+    auto load_step_u = [&](u64 lo, u64 hi, u64 send, u32 step) -> sa_u64x2 {
+        if constexpr (IMP) {
+            return load_step(lo, hi, send, step);
+        } else {
+            const u64 a0 = lo & ~1ull;
+            const u32 npairs = pairs_of(lo, hi);
+            const sa_u64x2* pairs = (const sa_u64x2*)(stream + a0);
+            const u32 j = step * THREADS + tid;
+            const u32 last = npairs ? npairs - 1u : 0u;
+            return pairs[j < last ? j : last];
+        }
     };
     auto invalidate = [&](sa_u64x2& v, u32 j, u32 npairs) {
-        if (j >= npairs) {
-            if constexpr (IMP) { v.x |= 0xFFFFFFFF00000000ull; v.y |= 0xFFFFFFFF00000000ull; }   // the doc word decides
-            else { v.x = 0; v.y = 0; }
+        if constexpr (!IMP) {
+            if (j >= npairs) { v.x = 0; v.y = 0; }
         }
     };
     // one term phase: the first batch `cur`, then -- long slices -- the rest, `b` being the second batch (already requested)
-    auto run_phase = [&](const Batch& cur, Batch& b, u64 lo, u64 hi, float idf) {
+    auto run_phase = [&](const Batch& cur, Batch& b, u64 lo, u64 hi, u64 send, float idf) {
         const u32 npairs = pairs_of(lo, hi);
         score_batch(cur, lo, hi, 0, idf);
         if (npairs > (u32)PF * THREADS) {
@@ -450,7 +481,7 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
             while (first < npairs) {
                 const u32 nf = first + (u32)PF * THREADS;
                 Batch b2;
-                if (nf < npairs) b2 = load_batch(lo, hi, nf);
+                if (nf < npairs) b2 = load_batch(lo, hi, send, nf);
                 score_batch(b, lo, hi, first, idf);
                 if (nf < npairs) b = b2;
                 first = nf;
@@ -459,7 +490,7 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     };
     bool cleared = false;
     while (todo) {
-        u64 L[4], H[4];
+        u64 L[4], H[4], S[4];
         float W[4];
         sa_u64x2 P[4];
         {
@@ -471,6 +502,7 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
                 g &= g - 1u;                                     // (0 stays 0)
                 L[i] = have ? lane64(r_lo, ti) : 0ull;
                 H[i] = have ? lane64(r_hi, ti) : 0ull;
+                S[i] = (IMP && have) ? lane64(r_send, ti) : 0ull;
                 W[i] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(r_idf), (int)ti));
             }
         }
@@ -480,10 +512,10 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
             const u32 npairs = pairs_of(lo, hi);
             Batch cur, b;
 #pragma unroll
-            for (int u = 0; u < PF; u++) cur.v[u] = load_step_u(lo, hi, (u32)u);
-            if (npairs > (u32)PF * THREADS) b = load_batch(lo, hi, (u32)PF * THREADS);
+            for (int u = 0; u < PF; u++) cur.v[u] = load_step_u(lo, hi, S[0], (u32)u);
+            if (npairs > (u32)PF * THREADS) b = load_batch(lo, hi, S[0], (u32)PF * THREADS);
 #pragma unroll
-            for (int i = 1; i < 4; i++) P[i] = load_step_u(L[i], H[i], 0);
+            for (int i = 1; i < 4; i++) P[i] = load_step_u(L[i], H[i], S[i], 0);
             if (!cleared) {                                     // first group: clear the accumulators behind the loads
 #pragma unroll
                 for (int j = 0; j < E; j++) acc[j * THREADS + tid] = 0.f;
@@ -493,7 +525,7 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
             todo &= todo - 1u;
 #pragma unroll
             for (int u = 0; u < PF; u++) invalidate(cur.v[u], (u32)u * THREADS + tid, npairs);
-            run_phase(cur, b, lo, hi, W[0]);
+            run_phase(cur, b, lo, hi, S[0], W[0]);
             __syncthreads();
         }
         // ---- phases 1..3
@@ -520,12 +552,13 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
             }
         }
         Batch nxt;
-        load_rest(nxt, L[1], H[1]);
+        load_rest(nxt, L[1], H[1], S[1]);
 #pragma unroll 1
         for (int k = 1; k < 4 && todo; k++) {
             todo &= todo - 1u;
             L[0] = L[1]; L[1] = L[2]; L[2] = L[3]; L[3] = 0;
             H[0] = H[1]; H[1] = H[2]; H[2] = H[3]; H[3] = 0;
+            S[0] = S[1]; S[1] = S[2]; S[2] = S[3]; S[3] = 0;
             W[0] = W[1]; W[1] = W[2]; W[2] = W[3];
             P[0] = P[1]; P[1] = P[2]; P[2] = P[3];
             const u64 lo = L[0], hi = H[0];
@@ -533,9 +566,9 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
             Batch cur = nxt, b;
             cur.v[0] = P[0];
             invalidate(cur.v[0], tid, npairs);
-            load_rest(nxt, L[1], H[1]);                         // (the next group's first phase: nothing, L[1] = H[1] = 0)
-            if (npairs > (u32)PF * THREADS) b = load_batch(lo, hi, (u32)PF * THREADS);   // requested before the first batch is scored
-            run_phase(cur, b, lo, hi, W[0]);
+            load_rest(nxt, L[1], H[1], S[1]);                   // (the next group's first phase: nothing, L[1] = H[1] = 0)
+            if (npairs > (u32)PF * THREADS) b = load_batch(lo, hi, S[0], (u32)PF * THREADS);   // requested before the first batch is scored
+            run_phase(cur, b, lo, hi, S[0], W[0]);
             __syncthreads();
         }
     }
@@ -1282,7 +1315,7 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
     if (sa_launch_make_sattab(ix, bt->d_sattab, &bt->tab_w, k1, b, ix->stream) != SA_OK) return fail(SA_ERR_HIP);
     // the impact stream of this (k1, b): shared through the index, built on first use
     bt->impacts = sa_impacts_get(ix, k1, b);
-    if (bt->impacts) SA_HIP_B(hipMalloc(&bt->d_qbase_imp, (size_t)B * T * sizeof(u64)));
+    if (bt->impacts) SA_HIP_B(hipMalloc(&bt->d_qbase_imp, (size_t)B * T * 2 * sizeof(u64)));
     if (sa_launch_make_bounds(ix, bt->d_terms, B * T, bt->d_bounds, bt->d_qbase, ix->stream, bt->d_qbase_imp) != SA_OK) return fail(SA_ERR_HIP);
     SA_HIP_B(hipStreamSynchronize(ix->stream));
 #undef SA_HIP_B

@@ -32,9 +32,11 @@ struct sa_comm;   // RCCL communicator wrapper (sa_comm.hip)
 // (reference bm25.pyx:19-23, op for op), laid out for the exhaustive tile kernel:
 //   imp[i] = (doc * 4) << 32 | float bits of the factor      (doc * 4: the byte offset of the doc's
 //            fp32 accumulator once the tile base is subtracted)
-// Term t starts at the EVEN index  (tf_off[t] + t + 1) & ~1  and every gap holds the sentinel
-// 0xFFFF'FFFF'FFFF'FFFF (doc id no tile contains), so a 16-byte pair load never sees another term's
-// posting and "doc inside this tile" is the only validity test a posting needs.
+// Term t starts at the EVEN index  (tf_off[t] + 4 t + 1) & ~1 ; every gap holds the sentinel
+// 0xFFFF'FFFF'FFFF'FFFF (doc id no tile contains) and every term is followed by at least one whole
+// 16-byte-aligned pair of sentinels, so a 16-byte pair load never sees another term's posting, loads
+// can be clamped to that pair instead of bounds-tested per lane, and "doc inside this tile" is the
+// only validity test a posting needs.
 struct sa_impacts {
     int device = 0;
     float k1 = 0.f, b = 0.f, avgdl = 0.f;
