@@ -27,7 +27,8 @@ def last_json_line(path):
 
 def pmc_means(directory, counter):
     rows = defaultdict(list)
-    for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+    files = sorted(glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:                                      # gpurun_out/ accumulates: the latest run only
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") == counter:
                 rows[r["Kernel_Name"]].append(float(r["Counter_Value"]))
@@ -52,9 +53,9 @@ def main():
             print("wrote", f"imp_ab_{RND}.jsonl")
     for sub, dst in [("prof_stats", f"{RND}_bench_kernel_stats.csv"), ("prof_phrase", f"{RND}_phrase_bench_kernel_stats.csv"),
                      ("prof_slop", f"{RND}_slop_bench_kernel_stats.csv")]:
-        fs = glob.glob(os.path.join(OUT, sub, "**", "*kernel_stats.csv"), recursive=True)
+        fs = sorted(glob.glob(os.path.join(OUT, sub, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
         if fs:
-            shutil.copy(fs[0], os.path.join(PROF, dst))
+            shutil.copy(fs[-1], os.path.join(PROF, dst))           # gpurun_out/ accumulates: the latest run
             print("wrote", dst)
     fetch = pmc_means(os.path.join(OUT, "prof_pmc_fetch"), "FETCH_SIZE")
     write = pmc_means(os.path.join(OUT, "prof_pmc_write"), "WRITE_SIZE")
