@@ -447,3 +447,22 @@ def test_impact_stream_exhaustive_scan(api, monkeypatch, integer_lens):
         w = dev.batch(wide, k=15)
         _check_batch(w, orc, wide, 15)
         w.close()
+
+
+def test_dynamic_pruning_default_policy(api, monkeypatch):
+    """SA_SPARSE unset: dynamic pruning only while the shard holds at least 4096 docs per requested result
+    (below that the exhaustive kernel is the faster one); either way the top-k equals the oracle."""
+    monkeypatch.delenv("SA_SPARSE", raising=False)
+    n_docs, vocab = 60000, 3000
+    t, d, p, lens = synth.corpus_triples(n_docs, vocab, 12, seed=5)
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
+    queries = np.asarray([[0, 40, 700, 2500], [2900, 1, 3, 1500], [2999, 2998, 0, 1]])
+    for k, pruned in ((5, True), (40, False)):                    # 60000 / 4096 = 14.6 results
+        bt = dev.batch(queries, k=k)
+        bt.stats(True)
+        _check_batch(bt, orc, queries, k)
+        cands, sparse_queries = bt.stats(False)
+        assert (sparse_queries > 0) == pruned and (cands > 0) == pruned
+        bt.close()
