@@ -133,7 +133,7 @@ int sa_stream_probe(uint64_t bytes, int mode, int reps, double* gbps_out);
  * global, not shard-local, statistics -- reference postings.py:293-299).
  * Derives on the device what PosnBitArray.warm() caches on the host (reference
  * middle_out.py:337-342): per-term TF postings and document frequencies.
- * tile_docs: docs per scoring tile (0 = default 8192; allowed 1024, 2048, 4096, 8192, 16384, 32768). */
+ * tile_docs: docs per scoring tile (0 = default 4096; allowed 1024, 2048, 4096, 8192, 16384, 32768). */
 int sa_index_create(int device, uint64_t n_docs, uint64_t doc_base, uint32_t n_terms,
                     const uint64_t* words, const uint64_t* term_off, const float* doc_lens,
                     float avg_doc_len, uint64_t corpus_size, uint32_t tile_docs,

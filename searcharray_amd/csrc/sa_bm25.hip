@@ -236,7 +236,9 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     __shared__ u64 red64[NW + 1];
     __shared__ u32 red[NW + 1];
     __shared__ u32 s_cnt[2];
-    __shared__ float s_tab[SA_SAT_NTF * SA_SAT_WMAX];
+    // TF route: the saturation table; impact route: only the selection's per-wave histogram scratch lives here
+    constexpr int TAB_FLOATS = IMP ? (NW * SA_HBINS / 2 > 64 ? NW * SA_HBINS / 2 : 64) : SA_SAT_NTF * SA_SAT_WMAX;
+    __shared__ float s_tab[TAB_FLOATS];
     float* acc = (float*)smem;
 
     // Work items (tile, query) are dispatched tile-major, one workgroup per item: the items in
@@ -257,7 +259,7 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     // pruning slots of this query (see the top-k section); loaded first so the L2 latency hides
     // behind the posting stream.  L1-bypassing load: a fresher bound prunes more.
     // (k > 32 on tiles of <= 4 waves: the cached histogram bound instead, see sa_tile_topk_hist)
-    constexpr bool HIST_OK = (size_t)NW * SA_HBINS * 2 <= sizeof(float) * SA_SAT_NTF * SA_SAT_WMAX;   // 16-bit bins
+    constexpr bool HIST_OK = (size_t)NW * SA_HBINS * 2 <= sizeof(float) * SA_SAT_NTF * SA_SAT_WMAX;   // 16-bit bins (<= 8 waves)
     const bool use_hist = MODE == 1 && HIST_OK && p.hist != nullptr;
     u32 slot_val = 0xFFFFFFFFu;
     if (MODE == 1 && !use_hist && (tid & (SA_WAVE - 1)) < 32u)

@@ -116,7 +116,7 @@ extern "C" int sa_index_create_from_tokens(int device, uint64_t n_docs, uint64_t
     SA_ARG(out && doc_ptr, "null argument");
     SA_ARG(n_docs == 0 || doc_lens, "doc_lens is null");
     SA_ARG(n_docs <= (1ull << 28), "a shard holds at most 2^28 docs (28-bit roaringish key)");
-    if (tile_docs == 0) tile_docs = 8192;
+    if (tile_docs == 0) tile_docs = SA_DEFAULT_TILE_DOCS;
     SA_ARG(tile_docs == 1024 || tile_docs == 2048 || tile_docs == 4096 || tile_docs == 8192 ||
                tile_docs == 16384 || tile_docs == 32768,
            "tile_docs must be 1024, 2048, 4096, 8192, 16384 or 32768");

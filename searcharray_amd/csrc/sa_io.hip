@@ -287,7 +287,7 @@ extern "C" int sa_index_create_from_file(int device, uint64_t n_docs, uint64_t d
     SA_ARG(n_terms == 0 || (term_src_off && term_len), "term_src_off / term_len is null");
     SA_ARG(n_docs == 0 || doc_lens, "doc_lens is null");
     SA_ARG(n_docs <= (1ull << 28), "a shard holds at most 2^28 docs (28-bit roaringish key)");
-    if (tile_docs == 0) tile_docs = 8192;
+    if (tile_docs == 0) tile_docs = SA_DEFAULT_TILE_DOCS;
     SA_ARG(tile_docs == 1024 || tile_docs == 2048 || tile_docs == 4096 || tile_docs == 8192 ||
                tile_docs == 16384 || tile_docs == 32768,
            "tile_docs must be 1024, 2048, 4096, 8192, 16384 or 32768");
