@@ -1367,10 +1367,10 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     const bool hist_possible = p.pruned && bt->kind == 0 && sa_tile_waves(ix->tile_docs) <= 8 &&
                                sa_env_int("SA_TOPK_HIST", 1) != 0;
     // Unset, SA_SPARSE follows the measurements: pruning pays while the shard holds many docs per requested
-    // result (10 M docs: 2.4x at k = 10, par at k = 1000; 1.25 M docs, k = 1000: the exhaustive kernel is 1.8x
-    // faster) -- on from 4096 docs per result.  SA_SPARSE=1 / 0 force it on / off.
+    // result (10 M docs: 2.2x at k = 10, 1.9x at k = 100, but the exhaustive kernel is 1.2x faster at k = 1000;
+    // 1.25 M docs, k = 1000: exhaustive 1.8x faster) -- on from 32768 docs per result.  SA_SPARSE=1 / 0 force it.
     const int sparse_env = sa_env_int("SA_SPARSE", -1);
-    const bool sparse_wanted = sparse_env >= 0 ? sparse_env != 0 : ix->n_docs >= (u64)bt->k * 4096ull;
+    const bool sparse_wanted = sparse_env >= 0 ? sparse_env != 0 : ix->n_docs >= (u64)bt->k * 32768ull;
     const bool sparse = hist_possible && ix->tile_docs <= 8192 && bt->sparse_ok && ix->avg_doc_len != 0.f && ix->n_tiles > 0 &&
                         sparse_wanted;
     const bool use_hist = hist_possible &&

@@ -450,7 +450,7 @@ def test_impact_stream_exhaustive_scan(api, monkeypatch, integer_lens):
 
 
 def test_dynamic_pruning_default_policy(api, monkeypatch):
-    """SA_SPARSE unset: dynamic pruning only while the shard holds at least 4096 docs per requested result
+    """SA_SPARSE unset: dynamic pruning only while the shard holds at least 32768 docs per requested result
     (below that the exhaustive kernel is the faster one); either way the top-k equals the oracle."""
     monkeypatch.delenv("SA_SPARSE", raising=False)
     n_docs, vocab = 60000, 3000
@@ -459,7 +459,7 @@ def test_dynamic_pruning_default_policy(api, monkeypatch):
     dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
     orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
     queries = np.asarray([[0, 40, 700, 2500], [2900, 1, 3, 1500], [2999, 2998, 0, 1]])
-    for k, pruned in ((5, True), (40, False)):                    # 60000 / 4096 = 14.6 results
+    for k, pruned in ((1, True), (5, False)):                     # 60000 / 32768 = 1.8 results
         bt = dev.batch(queries, k=k)
         bt.stats(True)
         _check_batch(bt, orc, queries, k)
