@@ -466,3 +466,37 @@ def test_dynamic_pruning_default_policy(api, monkeypatch):
         cands, sparse_queries = bt.stats(False)
         assert (sparse_queries > 0) == pruned and (cands > 0) == pruned
         bt.close()
+
+
+def test_threaded_batches_share_impact_streams(api, monkeypatch):
+    """Batches with different (k1, b) created, run and closed from several threads on one index (the C ABI
+    serialises calls per index handle; an impact stream lives as long as a batch uses it, the index caches only
+    the most recent one): every result equals the oracle's."""
+    from concurrent.futures import ThreadPoolExecutor
+    monkeypatch.setenv("SA_SPARSE", "0")
+    n_docs, vocab = 6000, 300
+    t, d, p, lens = synth.corpus_triples(n_docs, vocab, 40, seed=3)
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
+    queries = np.asarray([[0, 1, 250, 299], [5, 120, 7, 2], [299, 298, 297, 0]])
+    params = [(1.2, 0.75), (1.7, 0.3), (0.9, 0.0), (2.0, 1.0)]
+    want = {kb: [O.topk(orc.score_terms_sum([int(x) for x in q], k1=kb[0], b=kb[1]), 10) for q in queries] for kb in params}
+
+    def work(i):
+        kb = params[i % len(params)]
+        bt = dev.batch(queries, k=10, k1=kb[0], b=kb[1])
+        try:
+            for _ in range(2):
+                bt.run()
+                scores, docs = bt.fetch()
+                for qi, (ws, wd) in enumerate(want[kb]):
+                    n = int((ws > 0).sum())
+                    if not (np.array_equal(scores[qi, :n], ws[:n]) and np.array_equal(docs[qi, :n], wd[:n])):
+                        return False
+            return True
+        finally:
+            bt.close()
+
+    with ThreadPoolExecutor(4) as ex:
+        assert all(ex.map(work, range(16)))
