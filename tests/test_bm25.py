@@ -172,7 +172,7 @@ def test_empty_and_degenerate_indexes(api):
     assert (s == 0).all() and (d_ == NO_DOC).all()
 
 
-@pytest.mark.parametrize("tile_docs,k", [(1024, 10), (2048, 3), (1024, 32), (1024, 1000)])
+@pytest.mark.parametrize("tile_docs,k", [(1024, 10), (2048, 3), (1024, 32), (1024, 1000), (2048, 100), (4096, 10), (8192, 40)])
 def test_topk_pruning_over_many_tiles(api, tile_docs, k):
     """Enough tiles that the global pruning slots fill up (> 32 waves per query): most waves are
     rejected by the bound, and the result must still be the exact top-k."""
