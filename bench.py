@@ -1,23 +1,40 @@
 #!/usr/bin/env python
-"""bench.py -- the reference's headline workload on MI355X.
+"""bench.py -- the reference's headline workload on MI355X (no PyTorch anywhere: numpy + the C ABI).
 
 Metric (BASELINE.json): queries/sec (+ GB/s of postings scanned) of 4-term disjunctive BM25 with
 top-k over a 10M-doc synthetic Zipf corpus, 1/2/4/8 GPUs.
 
-  python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W          # N > 1: spawns one rank per GPU itself
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # or is launched as ranks
 
-A "step" = one pass of the hot path over one batch of 256 queries: BM25 tile kernel (postings
-stream -> LDS accumulators -> per-tile top-k) + per-shard merge (+ RCCL all-gather of the per-shard
-top-k keys and a final merge when N > 1).  The 10M-doc corpus is sharded by doc-id range
-(10M / N docs per GPU, global BM25 statistics), so scaling is STRONG.  Index and query batch are
-resident in HBM before the timed region; results stay on the device.
-Rank 0 prints one JSON line.
+Either way every rank is one process on one GPU that reads RANK / LOCAL_RANK / WORLD_SIZE from the
+environment; the ranks find each other through a 128-byte id file and everything collective -- global df,
+max-over-ranks timing, barriers, the per-batch exchange of the per-shard top-k -- goes through
+libsearcharray_hip.so's own RCCL communicator (include/searcharray_hip.h Part 3).
+
+A "step" = one pass of the hot path over one batch of 256 queries: scoring kernel(s) (postings stream ->
+LDS accumulators -> pruned per-tile selection) + per-shard merge (+ RCCL all-gather of the per-shard top-k
+keys and a final merge when N > 1).  The 10M-doc corpus is sharded by doc-id range (10M / N docs per GPU,
+global BM25 statistics), so scaling is STRONG.  Index and query batch are resident in HBM before the
+timed region; results stay on the device.  Rank 0 prints one JSON line.
+
+Legs (all on the same resident index; only the first is `value`):
+  main              the BASELINE query set (256 x 4 terms, one rank from each of 1-10 / 11-100 / 101-1000 /
+                    1001-10000), EXHAUSTIVE: every posting of every query term is scored, like the reference
+  dynamic_pruning   the same queries through the library's default top-k path (MaxScore-style pruning)
+  distinct_terms    256 x 4 pairwise-distinct terms (ranks 1..1024), exhaustive: no posting list is shared
+                    between queries, so cache reuse cannot flatter the bandwidth figure
+Roofline blocks are per leg; see roofline_block().
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -26,6 +43,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
+MARKER = "sa_k_stream8"    # PMC child: two dispatches of this kernel separate the legs
+CALIB = "sa_k_stream16"    # PMC child: a known byte count read with 16-byte loads (FETCH_SIZE calibration)
+CALIB_BYTES = 1 << 30
 
 
 def log(rank, *a):
@@ -33,7 +53,7 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -43,273 +63,554 @@ def main():
     ap.add_argument("--queries", type=int, default=256)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--tile", type=int, default=0, help="docs per scoring tile (0 = library default)")
-    ap.add_argument("--collective", choices=["rccl", "torch"], default="rccl",
-                    help="N>1 exchange: library-internal RCCL all-gather, or torch.distributed")
     ap.add_argument("--corpus-cache", default="", help="directory to cache the encoded corpus shard (.npz)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs (traffic / L2 hit rate)")
     ap.add_argument("--pruned", action="store_true",
-                    help="time dynamic pruning in the main region (default: the exhaustive streaming kernel, which "
-                         "scores every posting like the reference; the other mode is always reported beside it)")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    args = ap.parse_args()
+                    help="time dynamic pruning in the main region (default: the exhaustive kernel, which scores every "
+                         "posting like the reference; the other mode is always reported beside it)")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of each CPU baseline leg")
+    ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)      # internal: run under rocprofv3, print nothing
+    return ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        log(rank, f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
-    dist = torch = None
-    # under torch.distributed.run (RANK set) the distributed path is taken even for one rank, so the
-    # whole N > 1 machinery can be exercised on a single GPU
-    use_dist = world > 1 or os.environ.get("SA_BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from searcharray_amd import synth, _lib
-    from searcharray_amd.device_index import DeviceIndex, QueryBatch, compute_idf
+# ------------------------------------------------------------------------------------------------
+# launching: plain `python bench.py --gpus N` spawns the ranks itself
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(n):
+    idfile = os.path.join(tempfile.gettempdir(), f"sa_bench_id_{os.getpid()}_{int(time.time())}")
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), SA_BENCH_ID_FILE=idfile,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    if os.path.exists(idfile):
+        os.unlink(idfile)
+    sys.exit(rc)
 
-    api = _lib.api()                   # fails loudly if the gfx950 library is missing
-    D, V, B, K, W = args.docs, args.vocab, args.queries, args.steps, args.warmup
 
-    # ---- corpus shard (host) -------------------------------------------------------------
-    lo = (D * rank) // world
-    hi = (D * (rank + 1)) // world
+def id_file_path():
+    if os.environ.get("SA_BENCH_ID_FILE"):
+        return os.environ["SA_BENCH_ID_FILE"]
+    # launched by torch.distributed.run (or anything else that sets RANK): all ranks share the launcher
+    # as parent and the rendezvous port, which names a file no other job on this node uses
+    return os.path.join(tempfile.gettempdir(),
+                        f"sa_bench_id_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}")
+
+
+def exchange_unique_id(rank, make_id):
+    path = id_file_path()
+    if rank == 0:
+        uid = make_id()
+        tmp = path + f".tmp{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)                 # atomic: a reader sees nothing or all 128 bytes
+        return uid, path
     t0 = time.time()
-    workers = max(1, min(8, (os.cpu_count() or 8) // world))
-    corpus = None
-    cpath = os.path.join(args.corpus_cache, f"zipf_{D}_{V}_{lo}_{hi}.npz") if args.corpus_cache else ""
-    if cpath and os.path.exists(cpath):
-        z = np.load(cpath)
-        corpus = synth.EncodedCorpus(z["words"], z["term_off"], z["doc_lens"], hi - lo, V, lo)
-    if corpus is None:
-        corpus = synth.zipf_corpus(hi - lo, vocab=V, doc_base=lo, total_docs=D, workers=workers)
-        if cpath:
-            os.makedirs(args.corpus_cache, exist_ok=True)
-            np.savez(cpath, words=corpus.words, term_off=corpus.term_off, doc_lens=corpus.doc_lens)
-    log(rank, f"shard docs [{lo},{hi}) words={len(corpus.words)} generated in {time.time()-t0:.1f}s "
-              f"({workers} host threads)")
+    while time.time() - t0 < 600:
+        try:
+            if os.path.getmtime(path) > START_TIME - 600:      # (a leftover of a crashed earlier job is ignored)
+                with open(path, "rb") as f:
+                    uid = f.read()
+                if len(uid) == 128:
+                    return uid, path
+        except OSError:
+            pass
+        time.sleep(0.05)
+    raise RuntimeError(f"rank {rank}: no communicator id at {path} after 600 s")
 
-    # ---- global statistics (index-time constants, replicated) -----------------------------
-    sum_len = float(corpus.doc_lens.astype(np.float64).sum())
-    if use_dist:
-        tl = torch.tensor([sum_len], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tl)
-        sum_len = float(tl.item())
-    avgdl = np.float32(sum_len / D)
 
-    t0 = time.time()
-    index = DeviceIndex(corpus.words, corpus.term_off, corpus.doc_lens, avg_doc_len=avgdl,
-                        corpus_size=D, doc_base=lo, device=local_rank, tile_docs=args.tile, api=api)
-    info = index.info()
-    log(rank, f"index resident: {info.n_postings} postings, {info.hbm_bytes/1e9:.2f} GB HBM, "
-              f"tile_docs={info.tile_docs} n_tiles={info.n_tiles} dir_terms={info.n_dir_terms} "
-              f"({time.time()-t0:.1f}s incl. H2D + derive)")
-    df = index.docfreqs().astype(np.int64)
-    if use_dist:
-        tdf = torch.from_numpy(df).cuda()
-        dist.all_reduce(tdf)
-        df = tdf.cpu().numpy()
-    index.set_global_docfreqs(df.astype(np.uint64))
+START_TIME = time.time()
 
-    queries = synth.bm25_queries(B, vocab=V)
-    idf = np.asarray([[compute_idf(D, np.asarray([df[t]])) for t in q] for q in queries], dtype=np.float32)
-    batch = QueryBatch(index, queries, k=args.k, idf=idf)
 
-    collective = "none"
-    gathered = local_keys = None
-    if use_dist:
-        collective = args.collective
-        if collective == "rccl":
-            try:
-                ids = [None]
-                if rank == 0:
-                    buf = _lib.ctypes.create_string_buffer(128)
-                    api.call("sa_comm_unique_id", buf, 128)
-                    ids = [buf.raw]
-                dist.broadcast_object_list(ids, src=0)
-                index.comm_init(rank, world, ids[0])
-            except Exception as e:                      # noqa: BLE001
-                log(rank, f"library RCCL init failed ({e}); falling back to torch.distributed all_gather")
-                collective = "torch"
-            flag = torch.tensor([1 if collective == "torch" else 0], device="cuda")
-            dist.all_reduce(flag)
-            if flag.item() > 0 and collective == "rccl":
-                index.comm_destroy()
-                collective = "torch"
-        if collective == "torch":
-            local_keys = torch.zeros(B * args.k, dtype=torch.int64, device="cuda")
-            gathered = torch.zeros(world * B * args.k, dtype=torch.int64, device="cuda")
+# ------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------
+class Rank:
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
+        if self.world != args.gpus:
+            log(self.rank, f"warning: --gpus {args.gpus} but WORLD_SIZE {self.world}; using WORLD_SIZE")
+        from searcharray_amd import _lib
+        self.api = _lib.api()                 # fails loudly if the gfx950 library is missing
+        self.index = None
+        self.collective = "none"
+        # SA_BENCH_FORCE_COMM=1: take the communicator path with a single rank too (exercises the RCCL
+        # bootstrap, all-reduce, barrier and exchange on a one-GPU box)
+        self.use_comm = self.world > 1 or os.environ.get("SA_BENCH_FORCE_COMM") == "1"
 
-    def step():
-        if use_dist and collective == "torch":
-            batch.run_local(local_keys.data_ptr(), sync=True)
-            dist.all_gather_into_tensor(gathered, local_keys)
-            torch.cuda.synchronize()
-            batch.merge_gathered(gathered.data_ptr(), world, sync=False)
-        else:
-            batch.run(sync=False)
+    # -- corpus + index -------------------------------------------------------------------------
+    def build(self):
+        from searcharray_amd import synth
+        from searcharray_amd.device_index import DeviceIndex
+        a = self.args
+        D, V = a.docs, a.vocab
+        self.lo = (D * self.rank) // self.world
+        self.hi = (D * (self.rank + 1)) // self.world
+        t0 = time.time()
+        workers = max(1, min(8, (os.cpu_count() or 8) // self.world))
+        corpus = None
+        cpath = os.path.join(a.corpus_cache, f"zipf_{D}_{V}_{self.lo}_{self.hi}.npz") if a.corpus_cache else ""
+        if cpath and os.path.exists(cpath):
+            z = np.load(cpath)
+            corpus = synth.EncodedCorpus(z["words"], z["term_off"], z["doc_lens"], self.hi - self.lo, V, self.lo)
+        if corpus is None:
+            corpus = synth.zipf_corpus(self.hi - self.lo, vocab=V, doc_base=self.lo, total_docs=D, workers=workers)
+            if cpath:
+                os.makedirs(a.corpus_cache, exist_ok=True)
+                np.savez(cpath, words=corpus.words, term_off=corpus.term_off, doc_lens=corpus.doc_lens)
+        self.corpus = corpus
+        log(self.rank, f"shard docs [{self.lo},{self.hi}) words={len(corpus.words)} generated in {time.time()-t0:.1f}s "
+                       f"({workers} host threads)")
+        # global statistics (index-time constants, replicated).  avgdl exactly as the reference forms it,
+        # np.mean over the float32 lengths of the WHOLE corpus (indexing.py:282-284): the lengths are the
+        # first draw of every seeded batch, so every rank can produce all of them without the tokens
+        all_lens = corpus.doc_lens if self.world == 1 else synth.zipf_doc_lens(D)
+        self.avgdl = np.float32(np.mean(all_lens))
+        t0 = time.time()
+        self.index = DeviceIndex(corpus.words, corpus.term_off, corpus.doc_lens, avg_doc_len=self.avgdl,
+                                 corpus_size=D, doc_base=self.lo, device=self.local_rank, tile_docs=a.tile, api=self.api)
+        self.info = self.index.info()
+        log(self.rank, f"index resident: {self.info.n_postings} postings, {self.info.hbm_bytes/1e9:.2f} GB HBM, "
+                       f"tile_docs={self.info.tile_docs} n_tiles={self.info.n_tiles} "
+                       f"({time.time()-t0:.1f}s incl. H2D + derive)")
+        df = self.index.docfreqs().astype(np.uint64)
+        if self.use_comm:
+            uid, path = exchange_unique_id(self.rank, lambda: DeviceIndex.comm_unique_id(self.api))
+            self.index.comm_init(self.rank, self.world, uid)
+            self.collective = "rccl"
+            df = self.index.comm_allreduce(np.ascontiguousarray(df), "sum")      # global df = sum over the shards
+            self.index.comm_barrier()
+            if self.rank == 0 and os.path.exists(path):
+                os.unlink(path)
+        self.df = df
+        self.index.set_global_docfreqs(df)
 
-    def sync_all():
-        index.synchronize()
-        if torch is not None:
-            torch.cuda.synchronize()
+    def make_batch(self, queries):
+        from searcharray_amd.device_index import QueryBatch, compute_idf
+        D = self.args.docs
+        idf = np.asarray([[compute_idf(D, np.asarray([self.df[t]])) for t in q] for q in queries], dtype=np.float32)
+        return QueryBatch(self.index, queries, k=self.args.k, idf=idf)
 
-    def timed(n_warm, n_steps):
+    # -- collectives over the library's communicator -----------------------------------------------
+    def barrier(self):
+        self.index.synchronize()
+        if self.use_comm:
+            self.index.comm_barrier()
+
+    def allmax(self, x):
+        if not self.use_comm:
+            return x
+        return float(self.index.comm_allreduce(np.asarray([x], dtype=np.float64), "max")[0])
+
+    def allsum(self, x):
+        if not self.use_comm:
+            return x
+        return float(self.index.comm_allreduce(np.asarray([x], dtype=np.float64), "sum")[0])
+
+    def timed(self, batch, n_warm, n_steps):
         """n_warm untimed steps, then n_steps bracketed by barrier + synchronize; max over ranks"""
         for _ in range(n_warm):
-            step()
-        sync_all()
+            batch.run(sync=False)
+        self.barrier()
         batch.profile()                                  # reset the kernel-event ring
-        if use_dist:
-            dist.barrier()
-        sync_all()
+        self.barrier()
         t0 = time.perf_counter()
         for _ in range(n_steps):
-            step()
-        sync_all()
-        if use_dist:
-            dist.barrier()
-        dt_ = time.perf_counter() - t0
-        if use_dist:
-            tdt = torch.tensor([dt_], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-            dt_ = float(tdt.item())
-        return dt_
+            batch.run(sync=False)
+        self.barrier()
+        return self.allmax(time.perf_counter() - t0)
 
-    # The main region times the EXHAUSTIVE streaming kernel: every posting of every query term is
-    # scored, as the reference does -- the workload BASELINE.json's metric and roofline are defined on.
-    # The library's default for top-k batches is dynamic pruning (csrc/sa_sparse.hip: only docs that
-    # can still reach the top-k are scored; identical results); it is timed right after and reported
-    # as "dynamic_pruning".  --pruned swaps the two.
-    args.exhaustive = not args.pruned
-    os.environ["SA_SPARSE"] = "0" if args.exhaustive else "1"
-    dt = timed(max(W, 1), K)
+    def close(self):
+        if self.index is not None:
+            if self.use_comm:
+                self.index.comm_barrier()
+                self.index.comm_destroy()
+            self.index.close()
+
+
+def compulsory_bytes(df, queries, B, k):
+    """What one launch cannot avoid moving: the posting stream (8 bytes per posting) of every DISTINCT term
+    of the batch once, plus the result keys."""
+    terms = np.unique(np.asarray(queries).reshape(-1))
+    return int(8 * int(df[terms].astype(np.int64).sum()) + 8 * B * k)
+
+
+def roofline_block(kernel, kernel_ms, alg_bytes, compulsory, pmc, note):
+    """bound / achieved / peak / unit / frac / traffic per the bench contract, built so that `frac` is a
+    fraction of the HBM peak that cannot exceed 1:
+      traffic      HBM bytes per launch from the PMC counters (FETCH_SIZE x calibration + WRITE_SIZE), or null
+      achieved     traffic / kernel time when the counters were collected, else compulsory bytes / kernel time
+      compulsory_bytes   distinct posting lists once + outputs; wasted = traffic / compulsory_bytes
+      algorithmic_GBps   SURVEY 8d's per-query bytes (sum_t 8 df_t + 4 n_docs, every query counted in full)
+                         over the kernel time: a THROUGHPUT (it counts bytes that caches serve), not a fraction
+    """
+    sec = kernel_ms * 1e-3
+    r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": kernel, "kernel_ms": round(kernel_ms, 4),
+         "compulsory_bytes": int(compulsory),
+         "compulsory_GBps": round(compulsory / sec / 1e9, 1) if sec > 0 else 0.0,
+         "compulsory_frac": round(compulsory / sec / 1e9 / HBM_PEAK_GBS, 4) if sec > 0 else 0.0,
+         "algorithmic_bytes_per_launch": int(alg_bytes),
+         "algorithmic_GBps": round(alg_bytes / sec / 1e9, 1) if sec > 0 else 0.0}
+    if pmc and pmc.get("hbm_bytes"):
+        hb = pmc["hbm_bytes"]
+        r.update({"traffic": int(hb), "traffic_source": pmc["source"], "achieved": round(hb / sec / 1e9, 1),
+                  "frac": round(hb / sec / 1e9 / HBM_PEAK_GBS, 4), "frac_basis": "traffic",
+                  "wasted": round(hb / compulsory, 3) if compulsory else None,
+                  "l2_hit_rate": pmc.get("l2_hit_rate"), "fetch_calibration": pmc.get("fetch_calibration"),
+                  "pmc_kernel_ms": pmc.get("kernel_ms")})
+    else:
+        r.update({"traffic": None, "traffic_source": None, "achieved": r["compulsory_GBps"], "frac": r["compulsory_frac"],
+                  "frac_basis": "compulsory_bytes"})
+    r["note"] = note
+    return r
+
+
+# ------------------------------------------------------------------------------------------------
+# PMC child runs: bench.py re-invokes itself under rocprofv3, twice (FETCH_SIZE costs 3 of the 4 TCC
+# slots: MI355X_MICROARCH.md "rocprofv3 PMC slots"), kernel trace only
+# ------------------------------------------------------------------------------------------------
+PMC_PASSES = [("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"])]
+PMC_STEPS = 3
+
+
+def pmc_child(r, legs):
+    """legs: list of (name, batch, sparse_env).  Dispatch order written for the parent's parser:
+    calibration stream, then per leg: marker, PMC_STEPS runs."""
+    import ctypes
+    g = ctypes.c_double(0)
+    r.api.call("sa_stream_probe", CALIB_BYTES, 1, 1, ctypes.byref(g))
+    for name, batch, sparse in legs:
+        os.environ["SA_SPARSE"] = sparse
+        batch.run(sync=True)                                   # warm (impact stream etc. already built)
+        r.api.call("sa_stream_probe", 1 << 20, 0, 1, ctypes.byref(g))
+        for _ in range(PMC_STEPS):
+            batch.run(sync=True)
+    r.api.call("sa_stream_probe", 1 << 20, 0, 1, ctypes.byref(g))
+
+
+def run_pmc_children(args, leg_names):
+    """-> {leg: {"hbm_bytes", "l2_hit_rate", "kernels": {...}, ...}} or {} (no rocprofv3 / failure)."""
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return {}, "rocprofv3 not found"
+    out_root = tempfile.mkdtemp(prefix="sa_pmc_")
+    per_pass = {}
+    try:
+        for pname, counters in PMC_PASSES:
+            d = os.path.join(out_root, pname)
+            cmd = [exe, "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", pname, "--docs", str(args.docs),
+                   "--vocab", str(args.vocab), "--queries", str(args.queries), "--k", str(args.k), "--tile", str(args.tile),
+                   "--no-cpu-baseline", "--no-pmc"]
+            if args.corpus_cache:
+                cmd += ["--corpus-cache", args.corpus_cache]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(v, None)
+            try:
+                p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=420)
+            except subprocess.TimeoutExpired:
+                return {}, f"rocprofv3 pass '{pname}' timed out"
+            if p.returncode != 0:
+                return {}, f"rocprofv3 pass '{pname}' failed rc={p.returncode}: {p.stderr.decode(errors='replace')[-300:]}"
+            files = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getsize)
+            if not files:
+                return {}, f"rocprofv3 pass '{pname}' wrote no counter_collection.csv"
+            per_pass[pname] = parse_pmc_csv(files[-1], leg_names)
+    finally:
+        shutil.rmtree(out_root, ignore_errors=True)
+    return merge_pmc(per_pass, leg_names), None
+
+
+def parse_pmc_csv(path, leg_names):
+    """-> {"calib": {counter: mean}, leg: {kernel: {counter: [values]}, "_dur": {kernel: [ns]}}}"""
+    rows = {}
+    for r in csv.DictReader(open(path)):
+        key = int(r["Dispatch_Id"])
+        e = rows.setdefault(key, {"kernel": r["Kernel_Name"], "c": {}, "dur": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
+        e["c"][r["Counter_Name"]] = e["c"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    seq = [rows[k] for k in sorted(rows)]
+    out = {"calib": {}}
+    seg, in_marker = -1, False
+    calib = [e for e in seq if e["kernel"].startswith(CALIB)]
+    if calib:
+        for cname in calib[-1]["c"]:
+            out["calib"][cname] = calib[-1]["c"][cname]           # the second (warm) dispatch
+    started = False
+    for e in seq:
+        name = e["kernel"]
+        if name.startswith(MARKER):
+            if not in_marker:
+                seg += 1
+            in_marker, started = True, True
+            continue
+        in_marker = False
+        if not started or seg < 0 or seg >= len(leg_names):
+            continue
+        leg = out.setdefault(leg_names[seg], {"_dur": {}})
+        short = name.split("(")[0].replace("void ", "")
+        for cname, v in e["c"].items():
+            leg.setdefault(short, {}).setdefault(cname, []).append(v)
+        leg["_dur"].setdefault(short, []).append(e["dur"])
+    return out
+
+
+def merge_pmc(per_pass, leg_names):
+    fetch, write = per_pass.get("fetch", {}), per_pass.get("write", {})
+    # FETCH_SIZE is in KiB and under-reports wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM
+    # section: exactly 1/2 for 16 B per lane): calibrated here on a known 1 GiB read with 16-byte loads
+    raw = fetch.get("calib", {}).get("FETCH_SIZE")
+    factor = (CALIB_BYTES / (raw * 1024.0)) if raw else 2.0
+    if not (1.0 <= factor <= 4.0):
+        factor = 2.0
+    res = {}
+    for leg in leg_names:
+        f, w = fetch.get(leg, {}), write.get(leg, {})
+        kernels = {}
+        for kname in sorted(set(list(f) + list(w)) - {"_dur"}):
+            fv = f.get(kname, {}).get("FETCH_SIZE", [])
+            wv = w.get(kname, {}).get("WRITE_SIZE", [])
+            hit, miss = sum(w.get(kname, {}).get("TCC_HIT_sum", [])), sum(w.get(kname, {}).get("TCC_MISS_sum", []))
+            n = max(len(fv), len(wv), 1)
+            per_step = n / PMC_STEPS                               # dispatches of this kernel per step
+            fb = (sum(fv) / len(fv) * 1024.0 * factor) if fv else 0.0
+            wb = (sum(wv) / len(wv) * 1024.0) if wv else 0.0
+            durs = f.get("_dur", {}).get(kname, [])
+            kernels[kname] = {"hbm_bytes_per_dispatch": int(fb + wb), "dispatches_per_step": round(per_step, 2),
+                              "fetch_KiB_raw": round(sum(fv) / len(fv), 1) if fv else None,
+                              "write_KiB_raw": round(sum(wv) / len(wv), 1) if wv else None,
+                              "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss > 0 else None,
+                              "ms_under_pmc": round(sum(durs) / len(durs) / 1e6, 4) if durs else None}
+        res[leg] = {"kernels": kernels, "fetch_calibration": round(factor, 3),
+                    "source": "rocprofv3 --pmc child runs of this bench.py invocation (FETCH_SIZE | WRITE_SIZE TCC_HIT_sum "
+                              "TCC_MISS_sum, kernel trace only); FETCH_SIZE x calibration measured on a 1 GiB 16-byte-load stream"}
+    return res
+
+
+def dominant(pmc_leg, prefixes):
+    """sum over the kernels whose name starts with one of `prefixes` (per step), and the hit rate / time of the largest"""
+    if not pmc_leg:
+        return None
+    tot, best, best_b = 0.0, None, -1
+    for kname, kv in pmc_leg["kernels"].items():
+        if any(kname.startswith(p) for p in prefixes):
+            b = kv["hbm_bytes_per_dispatch"] * kv["dispatches_per_step"]
+            tot += b
+            if b > best_b:
+                best, best_b = kv, b
+    if best is None:
+        return None
+    return {"hbm_bytes": int(tot), "l2_hit_rate": best["l2_hit_rate"], "kernel_ms": best["ms_under_pmc"],
+            "source": pmc_leg["source"], "fetch_calibration": pmc_leg["fetch_calibration"]}
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline: the REFERENCE itself (oracle/_ref) when built, else the oracle port
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(r, queries, scores, docs):
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import refimpl as O                    # CPU restatement: the checker (and the fallback baseline)
+    from oracle import ref_loader
+    a = r.args
+    D, V, B, k = a.docs, a.vocab, len(queries), a.k
+    corpus = r.corpus
+    budget = a.cpu_seconds
+    n_cores = os.cpu_count() or 1
+    kind = "reference" if ref_loader.available() else "port"
+    if kind == "reference":
+        sa = ref_loader.reference_array(corpus.words, corpus.term_off, corpus.doc_lens, avg_doc_length=r.avgdl)
+        names = [[f"t{int(t)}" for t in q] for q in queries]
+
+        def dense(qi):                                  # the caller idiom of test/test_msmarco.py:353-354
+            return np.sum([sa.score(tok) for tok in names[qi]], axis=0)
+
+        def clear():
+            sa.posns.clear_cache()
+        what = "the reference itself (oracle/_ref: its Python + Cython built by its own setup.py), SearchArray.score per term + np.sum"
+    else:
+        orc = O.OracleIndex(corpus.words, np.arange(V), corpus.term_off, corpus.doc_lens, D)
+        orc.avg_doc_length = r.avgdl
+
+        def dense(qi):
+            return orc.score_terms_sum([int(t) for t in queries[qi]])
+
+        def clear():
+            orc.clear_cache() if hasattr(orc, "clear_cache") else None
+        what = "oracle/ C+numpy port of score()+np.sum (oracle/_ref not built)"
+
+    def topk_ref(s):                                     # reference utils/sort.py:24
+        return np.argpartition(s, -k)[-k:]
+
+    # -- cold: caches cleared before every query (test_msmarco.py:362-379), bounded sample
+    t0 = time.perf_counter()
+    n_cold = 0
+    for qi in range(B):
+        clear()
+        topk_ref(dense(qi))
+        n_cold += 1
+        if time.perf_counter() - t0 > budget * 0.4 and n_cold >= 4:
+            break
+    cold_dt = time.perf_counter() - t0
+    # -- warm, one thread: one pass to fill the tf/df caches (test_msmarco.py:384-395), then timed
+    n_warm = B
+    tw = time.perf_counter()
+    for qi in range(B):
+        dense(qi)
+        if time.perf_counter() - tw > budget and qi + 1 >= 8:
+            n_warm = qi + 1
+            break
+    ok = True
+    t0 = time.perf_counter()
+    for qi in range(n_warm):
+        s = dense(qi)
+        topk_ref(s)
+        ws, wd = O.topk(s, k)                            # parity of the GPU result against the CPU result
+        ok &= bool(np.allclose(scores[qi], ws, rtol=1e-5, atol=0)) and bool(np.array_equal(docs[qi][ws > 0], wd[ws > 0]))
+    warm_dt = time.perf_counter() - t0
+    # (the deterministic top-k used for the parity check is timed too; it is a few % of a query)
+    out = {"value": round(n_warm / warm_dt, 3), "unit": "queries/s", "cores": 1, "kind": kind,
+           "sample": f"queries 0..{n_warm - 1} of the {B} on the same {D}-doc corpus, tf/df caches warm (one untimed pass first), "
+                     f"single thread: {what} + np.argpartition top-{k}; host has {n_cores} hardware threads",
+           "cold": {"value": round(n_cold / cold_dt, 3), "unit": "queries/s", "cores": 1,
+                    "sample": f"first {n_cold} queries, posns.clear_cache() before each (tf/df recomputed from the roaringish words)"}}
+    # -- warm, thread pool (test_msmarco.py:483-507 runs its queries through a ThreadPoolExecutor)
+    n_thr = int(max(2, min(n_cores, 64)))                # each in-flight query holds ~5 dense float32[D] vectors
+    qs = [i % n_warm for i in range(max(n_warm, 2 * n_thr))]
+
+    def one(qi):
+        return int(topk_ref(dense(qi))[0])
+    with ThreadPoolExecutor(n_thr) as ex:
+        t0 = time.perf_counter()
+        list(ex.map(one, qs))
+        mt_dt = time.perf_counter() - t0
+    out["threaded"] = {"value": round(len(qs) / mt_dt, 3), "unit": "queries/s", "cores": n_thr,
+                       "sample": f"{len(qs)} warm queries through ThreadPoolExecutor({n_thr}) "
+                                 f"(capped at 64 of the {n_cores} hardware threads: every in-flight query holds several float32[{D}] vectors)"}
+    return out, ("ok" if ok else "MISMATCH"), n_warm
+
+
+# ------------------------------------------------------------------------------------------------
+def main():
+    args = parse_args()
+    if "RANK" not in os.environ and args.gpus > 1 and not args.pmc_child:
+        spawn_ranks(args.gpus)
+    r = Rank(args)
+    rank, world = r.rank, r.world
+    from searcharray_amd import synth
+    D, V, B, K, W = args.docs, args.vocab, args.queries, args.steps, args.warmup
+    r.build()
+    queries = synth.bm25_queries(B, vocab=V)
+    batch = r.make_batch(queries)
+    q_distinct = synth.bm25_queries_distinct(B, vocab=V) if 4 * B <= V else None
+    batch_d = r.make_batch(q_distinct) if q_distinct is not None else None
+    leg_names = ["main", "dynamic_pruning"] + (["distinct_terms"] if batch_d is not None else [])
+
+    if args.pmc_child:
+        legs = [("main", batch, "0"), ("dynamic_pruning", batch, "1")]
+        if batch_d is not None:
+            legs.append(("distinct_terms", batch_d, "0"))
+        pmc_child(r, legs)
+        r.close()
+        return
+
+    # The main region times the EXHAUSTIVE kernel: every posting of every query term is scored, as the
+    # reference does -- the workload BASELINE.json's metric and roofline are defined on.  The library's
+    # default for top-k batches is dynamic pruning (csrc/sa_sparse.hip: only docs that can still reach
+    # the top-k are scored; identical results); it is timed right after.  --pruned swaps the two.
+    exhaustive = not args.pruned
+    os.environ["SA_SPARSE"] = "0" if exhaustive else "1"
+    dt = r.timed(batch, max(W, 1), K)
     kernel_ms, alg_bytes, post_bytes = batch.profile()
-    post_total = float(post_bytes)
-    if use_dist:
-        tp = torch.tensor([post_total], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tp)
-        post_total = float(tp.item())
+    post_total = r.allsum(float(post_bytes))
     scores, docs = batch.fetch()
 
-    # second leg: the other mode, a few steps
-    os.environ["SA_SPARSE"] = "1" if args.exhaustive else "0"
+    os.environ["SA_SPARSE"] = "1" if exhaustive else "0"
     K2 = max(3, min(K, 10))
-    dt2 = timed(2, K2)
+    dt2 = r.timed(batch, 2, K2)
     kernel_ms2, _, _ = batch.profile()
     scores2, docs2 = batch.fetch()
     same = bool(np.array_equal(scores, scores2) and np.array_equal(docs, docs2))
-    cands = None
-    if rank == 0 and not use_dist:
-        os.environ["SA_SPARSE"] = "1"
-        batch.stats(True)
-        batch.run()
-        cands, _nq = batch.stats(False)
-    os.environ["SA_SPARSE"] = "0" if args.exhaustive else "1"
+
+    dt3 = kernel_ms3 = alg3 = None
+    if batch_d is not None:
+        os.environ["SA_SPARSE"] = "0"
+        dt3 = r.timed(batch_d, 2, K2)
+        kernel_ms3, alg3, post3 = batch_d.profile()
+        batch_d.fetch()
+    os.environ["SA_SPARSE"] = "0" if exhaustive else "1"
 
     qps = B * K / dt
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    pmc, pmc_err = {}, "skipped"
+    if rank == 0 and world == 1 and not args.no_pmc:
+        t0 = time.time()
+        r.index.synchronize()
+        pmc, pmc_err = run_pmc_children(args, leg_names)
+        log(rank, f"PMC child runs: {'ok' if pmc else pmc_err} ({time.time()-t0:.0f}s)")
 
-    traffic = traffic2 = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            if tj.get("docs") == D and tj.get("queries") == B and tj.get("n_gpus") == world \
-                    and tj.get("tile_docs") == int(info.tile_docs) and tj.get("k", args.k) == args.k:
-                t_pruned, t_exh = tj.get("pruned_hbm_bytes_per_step"), tj.get("exhaustive_hbm_bytes_per_launch")
-                traffic, traffic2 = (t_exh, t_pruned) if args.exhaustive else (t_pruned, t_exh)
-        except Exception:                                 # noqa: BLE001
-            traffic = traffic2 = None
-
-    cpu_baseline = None
-    parity = "skipped"
+    cpu, parity = None, "skipped"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import refimpl as O                    # CPU port of the reference path (checker + baseline)
-        orc = O.OracleIndex(corpus.words, np.arange(V), corpus.term_off, corpus.doc_lens, D)
-        orc.avg_doc_length = avgdl
-        tq = time.perf_counter()
-        s0 = orc.score_terms_sum([int(t) for t in queries[0]])     # also warms this query's tf/df caches
-        first = time.perf_counter() - tq
-        nq = int(max(2, min(32, B, args.cpu_seconds / max(first, 1e-3) / 2)))
-        for q in queries[1:nq]:                                    # warm-up pass (reference test_msmarco.py:384-395)
-            orc.score_terms_sum([int(t) for t in q])
-        tq = time.perf_counter()
-        ok = True
-        for qi in range(nq):
-            dense = orc.score_terms_sum([int(t) for t in queries[qi]])
-            ws, wd = O.topk(dense, args.k)
-            ok &= bool(np.allclose(scores[qi], ws, rtol=1e-5, atol=0)) and \
-                bool(np.array_equal(docs[qi][ws > 0], wd[ws > 0]))
-        cpu_dt = time.perf_counter() - tq
-        parity = "ok" if ok else "MISMATCH"
-        cpu_baseline = {"value": round(nq / cpu_dt, 3), "unit": "queries/s", "cores": 1, "kind": "port",
-                        "sample": f"first {nq} of the {B} queries on the same {D}-doc corpus, tf/df caches warm, "
-                                  f"oracle/ C+numpy port of score()+np.sum+top-{args.k}, single thread, "
-                                  f"host has {os.cpu_count()} cores"}
-        del s0
-        # the same port on many host threads (the reference's own throughput test runs score() from a
-        # ThreadPoolExecutor, test_msmarco.py:483-507): ctypes and numpy release the GIL in the heavy parts
-        from concurrent.futures import ThreadPoolExecutor
-        n_thr = int(max(2, min(32, (os.cpu_count() or 2))))
-        mt_q = [queries[i % B] for i in range(int(min(4 * n_thr, max(n_thr, 2 * nq))))]
-
-        def one(qrow):
-            dense = orc.score_terms_sum([int(t) for t in qrow])
-            return O.topk(dense, args.k)[1][0]
-        with ThreadPoolExecutor(n_thr) as ex:
-            list(ex.map(one, mt_q[:n_thr]))                        # warm the remaining caches
-            tq = time.perf_counter()
-            list(ex.map(one, mt_q))
-            mt_dt = time.perf_counter() - tq
-        cpu_baseline["threaded"] = {"value": round(len(mt_q) / mt_dt, 3), "unit": "queries/s", "cores": n_thr,
-                                    "sample": f"{len(mt_q)} queries through ThreadPoolExecutor({n_thr}) over the same port"}
-
-    def roof(kms, traf, exhaustive):
-        ach = alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-        r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traf, "kernel_ms": round(kms, 4),
-             "algorithmic_bytes_per_launch": int(alg_bytes)}
-        if exhaustive:
-            r["kernel"] = "sa_k_bm25_tiles"
-            r["note"] = ("every posting scored (reference behaviour); algorithmic bytes = sum_q(sum_t 8*df_t + 4*n_docs) "
-                         "per SURVEY 8d, rank 0's shard")
-        else:
-            r["kernel"] = "sa_k_sparse_lead + route + scan + rest + score (+ sa_k_bm25_tiles_list for queries without a rare term)"
-            r["note"] = ("dynamic pruning: postings of non-essential terms are never read, so the same algorithmic bytes "
-                         "(SURVEY 8d) over the scoring time exceed the HBM peak; kernel_ms = HIP events around all scoring "
-                         "kernels of a step; results identical to the exhaustive path (same_results / parity_check)")
-        return r
+        cpu, parity, _ = cpu_baseline(r, queries, scores, docs)
 
     if rank == 0:
+        n_tiles, waves = int(r.info.n_tiles), None
+        exh_ms, prn_ms = (kernel_ms, kernel_ms2) if exhaustive else (kernel_ms2, kernel_ms)
+        comp = compulsory_bytes(r.df if world == 1 else r.index.docfreqs(), queries, B, args.k)
+        exh_note = ("every posting of every query term scored (reference behaviour); kernel_ms = HIP events on the index "
+                    "stream around the scoring kernel(s) of a step, mean over the timed steps; rank 0's shard")
+        prn_note = ("dynamic pruning: postings of non-essential terms are never read (by design traffic < compulsory_bytes of the "
+                    "exhaustive leg is possible); byte model = the posting lists the routing keeps ESSENTIAL plus probes, so the "
+                    "bound is gather latency / sector traffic, reported as traffic-based GB/s; results identical (same_results)")
+        exh_block = roofline_block("sa_k_bm25_* (exhaustive scoring kernels of one step)", exh_ms, alg_bytes, comp,
+                                   dominant(pmc.get("main"), ("sa_k_bm25",)), exh_note)
+        prn_block = roofline_block("sa_k_sparse_lead + route + scan + rest + score (+ sa_k_bm25_tiles_list)", prn_ms, alg_bytes, comp,
+                                   dominant(pmc.get("dynamic_pruning"), ("sa_k_sparse", "sa_k_bm25")), prn_note)
+        exh_block["workgroups_per_launch"] = B * n_tiles
+        other = {"value": round(B * K2 / dt2, 2), "unit": "queries/s", "steps": K2, "ms_per_step": round(dt2 / K2 * 1e3, 4),
+                 "roofline": prn_block if exhaustive else exh_block, "same_results": same}
         out = {
             "metric": "queries/sec, 4-term disjunctive BM25 + top-k over 10M synthetic Zipf docs",
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"zipf-{D} (V={V}, Poisson(32) doc lengths, seed 1234) sharded by doc-id range, "
-                                   f"{B} x 4-term disjunctive BM25 queries (k1=1.2 b=0.75), top-{args.k}",
+                                   f"{B} x 4-term disjunctive BM25 queries (k1=1.2 b=0.75), top-{args.k}, "
+                                   f"{'exhaustive' if exhaustive else 'dynamic pruning'}",
                        "docs": D, "queries_per_step": B, "terms_per_query": 4, "k": args.k,
-                       "tile_docs": int(info.tile_docs), "parallelism": f"doc-range shards x{world}",
-                       "collective": collective},
+                       "distinct_terms_in_batch": int(len(np.unique(queries))),
+                       "tile_docs": int(r.info.tile_docs), "parallelism": f"doc-range shards x{world}",
+                       "collective": r.collective, "launcher": "torch-free: ranks rendezvous through an id file, "
+                                                               "collectives = libsearcharray_hip.so's RCCL communicator"},
             "postings_scanned_GBps": round(post_total * K / dt / 1e9, 2),
-            "roofline": roof(kernel_ms, traffic, args.exhaustive),
-            ("dynamic_pruning" if args.exhaustive else "exhaustive"): {
-                "value": round(B * K2 / dt2, 2), "unit": "queries/s", "steps": K2, "ms_per_step": round(dt2 / K2 * 1e3, 4),
-                "roofline": roof(kernel_ms2, traffic2, not args.exhaustive), "same_results": same},
-            "candidates_scored_per_step": cands,
-            "cpu_baseline": cpu_baseline,
+            "roofline": exh_block if exhaustive else prn_block,
+            ("dynamic_pruning" if exhaustive else "exhaustive"): other,
+            "cpu_baseline": cpu,
             "parity_check": parity,
         }
+        if batch_d is not None:
+            comp_d = compulsory_bytes(r.df if world == 1 else r.index.docfreqs(), q_distinct, B, args.k)
+            out["distinct_terms"] = {
+                "value": round(B * K2 / dt3, 2), "unit": "queries/s", "steps": K2, "ms_per_step": round(dt3 / K2 * 1e3, 4),
+                "workload": f"{B} x 4 pairwise-distinct terms (ranks 1..{4 * B}, one per quarter per query), exhaustive, top-{args.k}",
+                "roofline": roofline_block("sa_k_bm25_* (exhaustive)", kernel_ms3, alg3, comp_d,
+                                           dominant(pmc.get("distinct_terms"), ("sa_k_bm25",)),
+                                           "no posting list is shared between queries: compulsory_bytes = all posting bytes of the batch")}
+        if pmc:
+            out["pmc_kernels"] = {leg: pmc[leg]["kernels"] for leg in pmc}
+        elif not args.no_pmc:
+            out["pmc_error"] = pmc_err
         print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.barrier()
-        if collective == "rccl":
-            index.comm_destroy()
-        dist.destroy_process_group()
+    batch.close()
+    if batch_d is not None:
+        batch_d.close()
+    r.close()
 
 
 if __name__ == "__main__":

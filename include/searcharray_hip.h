@@ -133,7 +133,7 @@ int sa_stream_probe(uint64_t bytes, int mode, int reps, double* gbps_out);
  * global, not shard-local, statistics -- reference postings.py:293-299).
  * Derives on the device what PosnBitArray.warm() caches on the host (reference
  * middle_out.py:337-342): per-term TF postings and document frequencies.
- * tile_docs: docs per scoring tile (0 = default 4096; allowed 1024, 2048, 4096, 8192, 16384, 32768). */
+ * tile_docs: docs per scoring tile (0 = default 2048; allowed 1024, 2048, 4096, 8192, 16384, 32768). */
 int sa_index_create(int device, uint64_t n_docs, uint64_t doc_base, uint32_t n_terms,
                     const uint64_t* words, const uint64_t* term_off, const float* doc_lens,
                     float avg_doc_len, uint64_t corpus_size, uint32_t tile_docs,
@@ -318,6 +318,20 @@ int sa_host_free(void* p);
 int sa_comm_unique_id(char* id_out, int len);                    /* rank 0: ncclGetUniqueId */
 int sa_index_comm_init(sa_index_t* ix, int rank, int nranks, const char* id_bytes, int len);
 int sa_index_comm_destroy(sa_index_t* ix);
+/* rank / number of ranks of the index's communicator (0 / 1 without one) */
+int sa_index_comm_info(sa_index_t* ix, int* rank_out, int* nranks_out);
+/* Host-side reductions over the communicator, in place and blocking: the index-time statistics of a
+ * doc-range-sharded corpus -- df per term and the sum of the doc lengths (-> avgdl) are summed over the
+ * shards once, BM25 then uses the global values on every shard (the reference computes them over the
+ * whole corpus, indexing.py:282-284, middle_out.py:521-528) -- and max-over-ranks timings.  With these
+ * a one-process-per-GPU caller needs no other collective library (bench.py uses nothing else). */
+#define SA_DT_U64 0
+#define SA_DT_F64 1
+#define SA_OP_SUM 0
+#define SA_OP_MAX 1
+int sa_index_comm_allreduce(sa_index_t* ix, void* host_inout, uint64_t n, int dtype, int op);
+/* all ranks arrived and everything enqueued on this index's streams has finished */
+int sa_index_comm_barrier(sa_index_t* ix);
 
 /* ------------------------------------------------------------------------------------- */
 /* Part 4 -- dense vectors on the device: the combine step of Solr-style multi-field queries */

@@ -116,6 +116,9 @@ PROTOTYPES = {
     "sa_comm_unique_id": (c_int, [ctypes.c_char_p, c_int]),
     "sa_index_comm_init": (c_int, [c_void_p, c_int, c_int, ctypes.c_char_p, c_int]),
     "sa_index_comm_destroy": (c_int, [c_void_p]),
+    "sa_index_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "sa_index_comm_allreduce": (c_int, [c_void_p, c_void_p, c_uint64, c_int, c_int]),
+    "sa_index_comm_barrier": (c_int, [c_void_p]),
 }
 
 

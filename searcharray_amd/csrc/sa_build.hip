@@ -21,9 +21,6 @@
 #include <new>
 #include <numeric>
 #include <vector>
-#ifndef SA_EMU
-#include <rocprim/rocprim.hpp>
-#endif
 
 #define SA_POS_BITS 24
 
@@ -82,32 +79,8 @@ sa_k_term_offsets(const u32* __restrict__ wterm, u32 n_words, u32 n_terms, u64* 
     }
 }
 
-static int sa_sort_pairs_by_key(u32* keys_in, u32* keys_out, u64* vals_in, u64* vals_out, u32 n, int bits, hipStream_t st) {
-#ifdef SA_EMU
-    // host stand-in build: "device" memory is host memory
-    std::vector<u32> order(n);
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return keys_in[a] < keys_in[b]; });
-    for (u32 i = 0; i < n; i++) { keys_out[i] = keys_in[order[i]]; vals_out[i] = vals_in[order[i]]; }
-    (void)bits; (void)st;
-    return SA_OK;
-#else
-    size_t temp_bytes = 0;
-    SA_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
-                                     (unsigned int)bits, st));
-    void* temp = nullptr;
-    SA_HIP(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
-    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
-                                             (unsigned int)bits, st);
-    hipError_t e2 = hipStreamSynchronize(st);
-    hipFree(temp);
-    if (e != hipSuccess || e2 != hipSuccess) {
-        sa_set_error("radix sort failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
-        return SA_ERR_HIP;
-    }
-    return SA_OK;
-#endif
-}
+// stable sort of (key, value) pairs by the low `bits` bits of the key (sa_sort.hip)
+int sa_sort_pairs_by_key(u32* keys_in, u32* keys_out, u64* vals_in, u64* vals_out, u32 n, int bits, hipStream_t st);
 
 extern "C" int sa_index_create_from_tokens(int device, uint64_t n_docs, uint64_t doc_base, uint32_t n_terms,
                                            const uint32_t* tokens, const uint64_t* doc_ptr, const float* doc_lens,

@@ -89,3 +89,52 @@ int sa_comm_allreduce_max_u32(sa_index* ix, u32* d_val, hipStream_t st) {
     SA_NCCL(ncclAllReduce(d_val, d_val, 1, ncclUint32, ncclMax, ix->comm->comm, st));
     return SA_OK;
 }
+
+// Host-side reductions over the communicator: the index-time statistics of a sharded corpus (df per term,
+// sum of doc lengths -> avgdl) and the driver's "max over ranks" timing, so a multi-process caller needs no
+// other collective library.  dtype: SA_DT_U64 / SA_DT_F64, op: SA_OP_SUM / SA_OP_MAX; in place, blocking.
+extern "C" int sa_index_comm_allreduce(sa_index_t* ix, void* host_inout, uint64_t n, int dtype, int op) {
+    SA_ARG(ix && (host_inout || n == 0), "null argument");
+    SA_ARG(dtype == SA_DT_U64 || dtype == SA_DT_F64, "dtype must be SA_DT_U64 or SA_DT_F64");
+    SA_ARG(op == SA_OP_SUM || op == SA_OP_MAX, "op must be SA_OP_SUM or SA_OP_MAX");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (!ix->comm) { sa_set_error("index has no communicator"); return SA_ERR_STATE; }
+    if (n == 0) return SA_OK;
+    SA_HIP(hipSetDevice(ix->device));
+    void* d = nullptr;
+    SA_HIP(hipMalloc(&d, n * 8));
+    hipStream_t xs = ix->xstream;
+    int rc = SA_OK;
+    if (hipMemcpyAsync(d, host_inout, n * 8, hipMemcpyHostToDevice, xs) != hipSuccess) rc = SA_ERR_HIP;
+    if (rc == SA_OK) {
+        ncclResult_t r = ncclAllReduce(d, d, n, dtype == SA_DT_U64 ? ncclUint64 : ncclDouble, op == SA_OP_SUM ? ncclSum : ncclMax,
+                                       ix->comm->comm, xs);
+        if (r != ncclSuccess) { sa_set_error("ncclAllReduce failed: %s", ncclGetErrorString(r)); rc = SA_ERR_COMM; }
+    }
+    if (rc == SA_OK && hipMemcpyAsync(host_inout, d, n * 8, hipMemcpyDeviceToHost, xs) != hipSuccess) rc = SA_ERR_HIP;
+    if (hipStreamSynchronize(xs) != hipSuccess && rc == SA_OK) rc = SA_ERR_HIP;
+    hipFree(d);
+    if (rc == SA_ERR_HIP) sa_set_error("sa_index_comm_allreduce: HIP copy / synchronize failed");
+    return rc;
+}
+
+// every rank has reached this call and the work enqueued before it on both of the index's streams is done
+extern "C" int sa_index_comm_barrier(sa_index_t* ix) {
+    SA_ARG(ix, "null index");
+    {
+        std::lock_guard<std::mutex> g(ix->mu);
+        if (!ix->comm) { sa_set_error("index has no communicator"); return SA_ERR_STATE; }
+        SA_HIP(hipSetDevice(ix->device));
+        SA_HIP(hipStreamSynchronize(ix->stream));
+    }
+    uint64_t one = 1;
+    return sa_index_comm_allreduce(ix, &one, 1, SA_DT_U64, SA_OP_SUM);
+}
+
+extern "C" int sa_index_comm_info(sa_index_t* ix, int* rank_out, int* nranks_out) {
+    SA_ARG(ix, "null index");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (rank_out) *rank_out = ix->comm ? ix->comm->rank : 0;
+    if (nranks_out) *nranks_out = ix->comm ? ix->comm->nranks : 1;
+    return SA_OK;
+}

@@ -24,11 +24,10 @@
 
 struct sa_comm;   // RCCL communicator wrapper (sa_comm.hip)
 
-// Docs per scoring tile when the caller does not choose: 16 KiB of fp32 accumulators per workgroup of two
-// waves -- eight workgroups (the 16 waves the tile kernel's registers allow) fit a CU's LDS with room to
-// spare; measured best for the BM25 tile kernel (4096 / 8192 docs: 1.34 / 1.44 ms per 256-query launch at
-// 10 M docs, k = 1000: 1.92 / 2.25 ms), on a par for dynamic pruning.
-#define SA_DEFAULT_TILE_DOCS 4096u
+// Docs per scoring tile when the caller does not choose: 8 KiB of fp32 accumulators per ONE-wave workgroup (no
+// cross-wave barrier at all); measured best for the per-query BM25 tile kernel (2048 / 4096 / 8192 docs: 1.27 /
+// 1.33 / 1.44 ms per 256-query launch at 10 M docs, k = 1000: 1.83 / 1.93 / 2.25 ms), on a par for dynamic pruning.
+#define SA_DEFAULT_TILE_DOCS 2048u
 #define SA_DD_ABSENT 0xFFFFFFFFu
 #define SA_DD_NONE 0xFFFFFFFFu
 

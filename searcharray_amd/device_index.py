@@ -148,10 +148,17 @@ class DeviceIndex:
         uint64 ``.dat`` file MemoryMappedArrays writes (reference phrase/memmap_arrays.py:158-161) and
         ``metadata`` its ArrayDict metadata ``{term_id: {'offset': o, 'length': n}}`` (element units,
         memmap_arrays.py:28-54) -- or, equivalently, the CSR offsets ``uint64[V+1]`` of a file that
-        holds the terms back to back in id order (what ``save`` writes)."""
+        holds the terms back to back in id order (what ``save`` writes), or the pair of arrays
+        ``(term_src_off uint64[V], term_len uint64[V])``."""
         self = cls.__new__(cls)
         self.api = api if api is not None else _lib.api()
-        if isinstance(metadata, dict):
+        if isinstance(metadata, tuple) and len(metadata) == 2:
+            # (term_src_off uint64[V], term_len uint64[V]) as the C ABI takes them: no per-term Python work
+            src, length = as_u64(metadata[0]), as_u64(metadata[1])
+            V = len(length) if n_terms is None else int(n_terms)
+            if len(src) != V or len(length) != V:
+                raise ValueError("term_src_off / term_len must hold n_terms entries")
+        elif isinstance(metadata, dict):
             V = int(n_terms) if n_terms is not None else (max(int(k) for k in metadata) + 1 if metadata else 0)
             src = np.zeros(V, dtype=np.uint64)
             length = np.zeros(V, dtype=np.uint64)
@@ -368,6 +375,32 @@ class DeviceIndex:
 
     def comm_destroy(self):
         self.api.call("sa_index_comm_destroy", self._h)
+
+    @staticmethod
+    def comm_unique_id(api=None) -> bytes:
+        """128 opaque bytes one rank creates and hands to all ranks of a communicator."""
+        api = api if api is not None else _lib.api()
+        buf = ctypes.create_string_buffer(128)
+        api.call("sa_comm_unique_id", buf, 128)
+        return buf.raw
+
+    def comm_allreduce(self, arr: np.ndarray, op: str = "sum") -> np.ndarray:
+        """Sum / max of a uint64 or float64 host array over the ranks (in place, blocking): global df,
+        the sum of the doc lengths, max-over-ranks timings."""
+        if arr.dtype == np.uint64:
+            dt = 0
+        elif arr.dtype == np.float64:
+            dt = 1
+        else:
+            raise TypeError("comm_allreduce takes uint64 or float64 arrays")
+        if not arr.flags.c_contiguous or not arr.flags.writeable:
+            raise ValueError("comm_allreduce works in place on a contiguous writable array")
+        self.api.call("sa_index_comm_allreduce", self._h, arr.ctypes.data_as(ctypes.c_void_p), arr.size, dt,
+                      {"sum": 0, "max": 1}[op])
+        return arr
+
+    def comm_barrier(self):
+        self.api.call("sa_index_comm_barrier", self._h)
 
 
 class QueryBatch:

@@ -7,10 +7,11 @@ kernels behind the C ABI (include/searcharray_hip.h).  The ExtensionArray protoc
 take, copy, setitem, concat, factorize, equality) is host bookkeeping over an immutable shared
 index core plus a row selection.
 
-Differences from the reference, by design:
-  * a sliced / filtered array scores with corpus-wide document frequencies (the reference's
-    filtered views use slice-local df with global corpus size -- SURVEY appendix A.6);
-  * there is no CPU fallback: every query-time computation goes through the C ABI.
+Slices behave like the reference's filtered views (``FilteredPosns``, middle_out.py:291-317):
+``docfreq`` -- and with it the idf of every score taken on a slice -- counts the docs of the SLICE that
+contain the term, while ``corpus_size`` and ``avg_doc_length`` stay those of the whole index
+(known answers from the reference in tests/test_search_api.py).
+There is no CPU fallback: every query-time computation goes through the C ABI.
 """
 from __future__ import annotations
 
@@ -169,14 +170,38 @@ class _IndexCore:
     def fork(self) -> "_IndexCore":
         return _IndexCore(self.host, self._device)
 
+    def words_nbytes(self) -> int:
+        """bytes of the roaringish words, wherever they live (host array, .dat file, HBM)"""
+        h = self.host
+        if h.has_words:
+            return int(h._words.nbytes)
+        if h.words_file is not None:
+            return int(8 * np.sum(h.words_file[2], dtype=np.uint64))
+        if self._device is not None:
+            return int(8 * self._device.info().n_words)
+        return int(h.words.nbytes)                       # nothing resident yet: host encode
+
+    def sharded(self, devices) -> "ShardedIndex":
+        """The same index as doc-range shards over several GPUs (searcharray_amd/sharded.py), kept for
+        the next batched search on the same device list."""
+        from .sharded import ShardedIndex
+        key = tuple(int(d) for d in devices)
+        cached = getattr(self, "_sharded", None)
+        if cached is None or cached[0] != key or cached[1] is not self.host:
+            if cached is not None:
+                cached[2].close()
+            h = self.host
+            self._sharded = (key, h, ShardedIndex(h.words, h.term_off, h.doc_lens, key, avg_doc_len=self.avg_doc_length,
+                                                   api=_lib.api()))
+        return self._sharded[2]
+
     def device(self) -> DeviceIndex:
         if self._device is None:
             h = self.host
             if not h.has_words and h.words_file is not None:
                 # file -> page-locked ring -> HBM, no host copy of the words
                 path, src, length = h.words_file
-                meta = {int(t): {"offset": int(src[t]), "length": int(length[t])} for t in np.flatnonzero(length)}
-                self._device = DeviceIndex.from_file(path, meta, h.doc_lens, n_terms=len(self.term_dict),
+                self._device = DeviceIndex.from_file(path, (src, length), h.doc_lens, n_terms=len(self.term_dict),
                                                      avg_doc_len=self.avg_doc_length,
                                                      corpus_size=self.corpus_size, api=_lib.api())
             elif not h.has_words and h.tokens is not None:
@@ -194,6 +219,7 @@ class _IndexCore:
     def __getstate__(self):
         state = dict(self.__dict__)
         state["_device"] = None                    # HBM handles do not pickle; re-uploaded on demand
+        state.pop("_sharded", None)
         return state
 
     # -- host-side doc reconstruction (scalar __getitem__, equality, positions)
@@ -239,7 +265,7 @@ class _PosnsAdapter:
 
     @property
     def nbytes(self):
-        return self._array._core.host.words.nbytes
+        return self._array._core.words_nbytes()
 
 
 class SearchArray(ExtensionArray):
@@ -381,8 +407,12 @@ class SearchArray(ExtensionArray):
 
     @property
     def nbytes(self):
+        # from SIZES, never from the data: pandas calls this from DataFrame.info() / memory_usage(), and an
+        # index built on the device or opened from a .dat file must not be copied to host RAM for that
         h = self._core.host
-        return h.words.nbytes + h.term_off.nbytes + h.doc_lens.nbytes + h.doc_term_ids.nbytes + self.term_dict.nbytes
+        n_terms = len(self.term_dict)
+        doc_terms = h._doc_term_ids.nbytes if h._doc_term_ids is not None else 0
+        return self._core.words_nbytes() + 8 * (n_terms + 1) + h.doc_lens.nbytes + doc_terms + self.term_dict.nbytes
 
     def memory_usage(self, deep=False):
         return self.nbytes
@@ -500,7 +530,13 @@ class SearchArray(ExtensionArray):
             if len(other) == 0:
                 return np.array([], dtype=bool)
             if other._core.host is self._core.host:
-                return self._row_ids() == other._row_ids()
+                # same index: equal row ids are equal docs; different rows may still hold equal CONTENT
+                # (the reference compares term_mat rows and doc_lens, postings.py:463-464)
+                ra, rb = self._row_ids(), other._row_ids()
+                out = ra == rb
+                for i in np.flatnonzero(~out):
+                    out[i] = bool(self._core.doc_as_terms(int(ra[i])) == self._core.doc_as_terms(int(rb[i])))
+                return out
             a, b = self._as_terms_list(), other._as_terms_list()
             return np.asarray([bool(x == y) for x, y in zip(a, b)], dtype=bool)
         if isinstance(other, Terms):
@@ -636,21 +672,23 @@ class SearchArray(ExtensionArray):
         return "\n".join("        " + ln for ln in lines) + "\n"
 
     # -- batched top-k (no counterpart in the reference: its callers loop over score() + argpartition)
-    def search(self, queries, k: int = 10, similarity=default_bm25) -> Tuple[np.ndarray, np.ndarray]:
+    def search(self, queries, k: int = 10, similarity=default_bm25, devices=None) -> Tuple[np.ndarray, np.ndarray]:
         """Top-``k`` docs for many queries at once, without materialising dense score vectors:
         ``queries`` is a list of token lists (each scored as a disjunction: the sum of its terms' BM25,
         ``np.sum([arr.score(t) for t in q], axis=0)`` in reference terms) or a list of strings (each run
         through this array's tokenizer first).  Returns ``(scores float32[B][k], doc_ids uint64[B][k])``
         sorted by score descending then doc id ascending; unused slots hold score 0 and doc id 2**64-1.
-        Needs a stock BM25 similarity (``bm25_similarity(k1, b)``) and the whole array (not a slice)."""
-        return self._topk(queries, k, similarity, phrases=False)
+        Needs a stock BM25 similarity (``bm25_similarity(k1, b)``) and the whole array (not a slice).
+        ``devices=[0, 1, ...]``: the index is cut into doc-id ranges, one per listed GPU, every shard is
+        scored concurrently with the global statistics and the per-shard top-k are merged over RCCL
+        (searcharray_amd/sharded.py) -- same results as on one device."""
+        return self._topk(queries, k, similarity, phrases=False, devices=devices)
 
-    def search_phrases(self, phrases, k: int = 10, similarity=default_bm25) -> Tuple[np.ndarray, np.ndarray]:
-        """Like :meth:`search`, each query an exact phrase (2..18 pairwise-distinct tokens):
-        the top-``k`` of ``arr.score(phrase)``."""
-        return self._topk(phrases, k, similarity, phrases=True)
+    def search_phrases(self, phrases, k: int = 10, similarity=default_bm25, devices=None) -> Tuple[np.ndarray, np.ndarray]:
+        """Like :meth:`search`, each query an exact phrase: the top-``k`` of ``arr.score(phrase)``."""
+        return self._topk(phrases, k, similarity, phrases=True, devices=devices)
 
-    def _topk(self, queries, k, similarity, phrases):
+    def _topk(self, queries, k, similarity, phrases, devices=None):
         if getattr(similarity, "kind", None) != "bm25":
             raise ValueError("batched search needs a stock BM25 similarity (bm25_similarity(k1, b))")
         if self._rows is not None:
@@ -659,7 +697,7 @@ class SearchArray(ExtensionArray):
         B = len(toks)
         if B == 0 or len(self._core.doc_lens) == 0:
             return np.zeros((B, k), np.float32), np.full((B, k), NO_DOC, np.uint64)
-        dev = self._core.device()
+        dev = self._core.sharded(devices) if devices is not None and len(devices) > 1 else self._core.device()
         unknown = dev.n_terms                                   # any id >= n_terms matches nothing
         ids = [[t if (t := self._term_id(tok)) >= 0 else unknown for tok in q] for q in toks]
         if phrases:

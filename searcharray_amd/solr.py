@@ -212,6 +212,11 @@ class _DeviceCombiner:
             sim = f.similarity
             if getattr(sim, "kind", None) != "bm25" or sim.k1 == 0 or sim.b == 1:
                 return False
+            # a negative boost makes the main-query scores mixed-sign; the reference then slices with
+            # `scores > 0` but adds at `np.where(scores)` and raises a broadcast ValueError
+            # (solr.py:320-353): only the host route reproduces that
+            if f.boost is not None and f.boost < 0:
+                return False
             if f.array._rows is not None or len(f.array) != n_docs or len(f.array._core.doc_lens) == 0:
                 return False
         return True

@@ -177,6 +177,18 @@ def zipf_corpus(num_docs: int, vocab: int = 100_000, mean_len: int = 32, seed: i
     return EncodedCorpus(words, term_off, doc_lens, num_docs, vocab, doc_base)
 
 
+def zipf_doc_lens(total_docs: int, mean_len: int = 32, seed: int = 1234, batch_docs: int = 1_000_000) -> np.ndarray:
+    """float32 doc lengths of the WHOLE ``zipf-N`` corpus without generating a single token (the lengths
+    are the first draw of every seeded batch): what a rank of a sharded run needs to form the reference's
+    ``avg_doc_length = np.mean(doc_lens)`` (reference indexing.py:282-284) bit for bit."""
+    out = []
+    for b in range((total_docs + batch_docs - 1) // batch_docs):
+        n = min(batch_docs, total_docs - b * batch_docs)
+        rng = np.random.default_rng([seed, b])
+        out.append(np.maximum(1, rng.poisson(mean_len, n)).astype(np.float32))
+    return np.concatenate(out) if out else np.empty(0, np.float32)
+
+
 def corpus_triples(num_docs: int, vocab: int, mean_len: int, seed: int = 1234,
                    batch_docs: int = 1_000_000):
     """Small-corpus helper for tests: the raw sorted (term, doc, posn) triples + doc lens."""
@@ -207,6 +219,17 @@ def bm25_queries(n_queries: int = 256, vocab: int = 100_000, seed: int = 42) -> 
     q = np.stack(cols, axis=1).astype(np.uint32)
     q[0] = [min(t, vocab - 1) for t in PROBE_QUERY]
     return q
+
+
+def bm25_queries_distinct(n_queries: int = 256, n_terms: int = 4, vocab: int = 100_000, seed: int = 43) -> np.ndarray:
+    """n_queries x n_terms term ids that are pairwise DISTINCT over the whole batch: slot j draws, without
+    replacement, from ranks j*n_queries+1 .. (j+1)*n_queries (ids = rank - 1), so no posting list is
+    shared between two queries and cache reuse across queries cannot flatter a bandwidth figure."""
+    if n_queries * n_terms > vocab:
+        raise ValueError("not enough terms for a pairwise-distinct batch")
+    rng = np.random.default_rng(seed)
+    cols = [rng.permutation(n_queries) + j * n_queries for j in range(n_terms)]
+    return np.stack(cols, axis=1).astype(np.uint32)
 
 
 def phrase_queries_from_tokens(lens: np.ndarray, terms: np.ndarray, n_queries: int = 64,

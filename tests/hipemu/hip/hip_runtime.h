@@ -16,6 +16,7 @@
 // blocked on the collective are its participants (models the exec mask under divergence).
 #pragma once
 #include <ucontext.h>
+#include <mutex>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -200,7 +201,12 @@ inline void run_block() {
     }
 }
 
+// one kernel at a time: the machine (fibers, __shared__ statics) is process-global, and the in-process
+// communicator of the test build drives one shard per host thread
+inline std::mutex& launch_mutex() { static std::mutex mu; return mu; }
+
 inline void launch(dim3 grid, dim3 block, std::function<void()> body) {
+    std::lock_guard<std::mutex> launch_guard(launch_mutex());
     Machine& m = M();
     m.gridDim = grid;
     m.blockDim = block;

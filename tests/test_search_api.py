@@ -349,3 +349,26 @@ def test_other_similarities_bit_identical_to_reference(default_api, name):
     tf = arr.termfreqs("w7")
     direct = sim(tf.copy(), np.asarray([arr.docfreq("w7")]), arr.doc_lens, arr.avg_doc_length, arr.corpus_size)
     assert np.array_equal(direct, g[f"{name}_1"], equal_nan=True)
+
+
+def test_eq_compares_content_when_rows_differ(default_api):
+    """Duplicate docs at different rows of one index are equal (reference postings.py:463-464 compares
+    term_mat rows and doc_lens, not row numbers)."""
+    from searcharray_amd import SearchArray
+    arr = SearchArray.index(["foo bar bar baz", "data2", "data3 bar", "bunny funny wunny"] * 3)
+    assert (arr[0:4] == arr[4:8]).all()
+    assert np.array_equal(arr.take([0, 4]) == arr.take([4, 0]), [True, True])
+    assert np.array_equal(arr[0:4] == arr[1:5], [False, False, False, False])
+    assert np.array_equal(arr[[0, 1, 2]] == arr[[4, 2, 6]], [True, False, True])
+
+
+def test_nbytes_does_not_materialise_device_built_words(default_api):
+    from searcharray_amd import SearchArray
+    arr = SearchArray.index(["foo bar bar baz", "data2", "data3 bar", "bunny funny wunny"] * 25)
+    arr.score("bar")                                        # index built on the device from the token stream
+    host = arr._core.host
+    had = host.has_words
+    n = arr.nbytes
+    assert n > 0 and arr.posns.nbytes > 0
+    assert host.has_words == had                            # asking for sizes downloaded nothing
+    assert arr.posns.nbytes == host.words.nbytes            # and the size was right

@@ -154,3 +154,18 @@ def test_edismax_matches_reference_outputs():
         assert np.array_equal(got[True], got[False]), f"case {i}: the two routes differ"
         default, _ = edismax(frame, **params)
         assert np.array_equal(default, got[True])
+
+
+def test_negative_boost_takes_the_host_route(default_api):
+    """A negative qf boost makes the main-query scores mixed-sign; the reference's phrase-boost step then
+    fails on a shape mismatch (solr.py:320-353), which only the host combination reproduces -- the device
+    combiner must decline such queries instead of returning a different answer."""
+    from searcharray_amd import solr
+    from searcharray_amd.similarity import default_bm25
+    import pandas as pd
+    from searcharray_amd import SearchArray
+    arr = SearchArray.index(["foo bar", "bar baz", "foo foo"])
+    f = solr._Field("title", -1.0, arr, ["foo"], default_bm25)
+    g = solr._Field("title", 1.0, arr, ["foo"], default_bm25)
+    assert solr._DeviceCombiner.usable([g], 3)
+    assert not solr._DeviceCombiner.usable([f], 3)
