@@ -138,18 +138,16 @@ class Rank:
         self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
         if self.world != args.gpus:
             log(self.rank, f"warning: --gpus {args.gpus} but WORLD_SIZE {self.world}; using WORLD_SIZE")
-        from searcharray_amd import _lib
-        self.api = _lib.api()                 # fails loudly if the gfx950 library is missing
+        self.api = None
         self.index = None
         self.collective = "none"
         # SA_BENCH_FORCE_COMM=1: take the communicator path with a single rank too (exercises the RCCL
         # bootstrap, all-reduce, barrier and exchange on a one-GPU box)
         self.use_comm = self.world > 1 or os.environ.get("SA_BENCH_FORCE_COMM") == "1"
 
-    # -- corpus + index -------------------------------------------------------------------------
-    def build(self):
+    # -- corpus (host only: nothing here touches the GPU) -----------------------------------------
+    def generate(self):
         from searcharray_amd import synth
-        from searcharray_amd.device_index import DeviceIndex
         a = self.args
         D, V = a.docs, a.vocab
         self.lo = (D * self.rank) // self.world
@@ -174,6 +172,13 @@ class Rank:
         # first draw of every seeded batch, so every rank can produce all of them without the tokens
         all_lens = corpus.doc_lens if self.world == 1 else synth.zipf_doc_lens(D)
         self.avgdl = np.float32(np.mean(all_lens))
+
+    # -- index --------------------------------------------------------------------------------------
+    def build(self):
+        from searcharray_amd import _lib
+        from searcharray_amd.device_index import DeviceIndex
+        self.api = _lib.api()                 # fails loudly if the gfx950 library is missing
+        a, corpus, D = self.args, self.corpus, self.args.docs
         t0 = time.time()
         self.index = DeviceIndex(corpus.words, corpus.term_off, corpus.doc_lens, avg_doc_len=self.avgdl,
                                  corpus_size=D, doc_base=self.lo, device=self.local_rank, tile_docs=a.tile, api=self.api)
@@ -296,22 +301,28 @@ def pmc_child(r, legs):
     r.api.call("sa_stream_probe", 1 << 20, 0, 1, ctypes.byref(g))
 
 
-def run_pmc_children(args, leg_names):
+def run_pmc_children(args, leg_names, corpus):
     """-> {leg: {"hbm_bytes", "l2_hit_rate", "kernels": {...}, ...}} or {} (no rocprofv3 / failure)."""
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return {}, "rocprofv3 not found"
+    if not os.path.exists("/dev/kfd"):
+        return {}, "no GPU"
     out_root = tempfile.mkdtemp(prefix="sa_pmc_")
     per_pass = {}
+    cache = args.corpus_cache
+    if not cache:                                             # hand the generated corpus to the children
+        cache = os.path.join(out_root, "corpus")
+        os.makedirs(cache)
+        np.savez(os.path.join(cache, f"zipf_{args.docs}_{args.vocab}_0_{args.docs}.npz"), words=corpus.words,
+                 term_off=corpus.term_off, doc_lens=corpus.doc_lens)
     try:
         for pname, counters in PMC_PASSES:
             d = os.path.join(out_root, pname)
             cmd = [exe, "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", pname, "--docs", str(args.docs),
                    "--vocab", str(args.vocab), "--queries", str(args.queries), "--k", str(args.k), "--tile", str(args.tile),
-                   "--no-cpu-baseline", "--no-pmc"]
-            if args.corpus_cache:
-                cmd += ["--corpus-cache", args.corpus_cache]
+                   "--no-cpu-baseline", "--no-pmc", "--corpus-cache", cache]
             env = dict(os.environ, TMPDIR="/tmp")
             for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
                 env.pop(v, None)
@@ -320,7 +331,12 @@ def run_pmc_children(args, leg_names):
             except subprocess.TimeoutExpired:
                 return {}, f"rocprofv3 pass '{pname}' timed out"
             if p.returncode != 0:
-                return {}, f"rocprofv3 pass '{pname}' failed rc={p.returncode}: {p.stderr.decode(errors='replace')[-300:]}"
+                err = p.stderr.decode(errors="replace")
+                keep = os.path.join(ROOT, "gpurun_out")
+                if os.path.isdir(keep):                       # (scratch dir of the GPU box: keep the evidence)
+                    open(os.path.join(keep, f"pmc_child_{pname}.stderr"), "w").write(err)
+                lines = [ln for ln in err.splitlines() if ln.strip() and not ln.lstrip().startswith("@")]
+                return {}, f"rocprofv3 pass '{pname}' failed rc={p.returncode}: {' | '.join(lines[-6:])[-600:]}"
             files = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getsize)
             if not files:
                 return {}, f"rocprofv3 pass '{pname}' wrote no counter_collection.csv"
@@ -506,12 +522,21 @@ def main():
     rank, world = r.rank, r.world
     from searcharray_amd import synth
     D, V, B, K, W = args.docs, args.vocab, args.queries, args.steps, args.warmup
+    r.generate()
+    leg_names = ["main", "dynamic_pruning"] + (["distinct_terms"] if 4 * B <= V else [])
+    # HBM traffic / L2 hit rate: bench.py profiles ITSELF under rocprofv3 --pmc, in child processes that run
+    # BEFORE this process touches the GPU (one process on the device at a time, as in a stand-alone rocprofv3
+    # run); the children read the corpus this process just generated instead of generating it again.
+    pmc, pmc_err = {}, "skipped"
+    if rank == 0 and world == 1 and not args.no_pmc and not args.pmc_child:
+        t0 = time.time()
+        pmc, pmc_err = run_pmc_children(args, leg_names, r.corpus)
+        log(rank, f"PMC child runs: {'ok' if pmc else pmc_err} ({time.time()-t0:.0f}s)")
     r.build()
     queries = synth.bm25_queries(B, vocab=V)
     batch = r.make_batch(queries)
     q_distinct = synth.bm25_queries_distinct(B, vocab=V) if 4 * B <= V else None
     batch_d = r.make_batch(q_distinct) if q_distinct is not None else None
-    leg_names = ["main", "dynamic_pruning"] + (["distinct_terms"] if batch_d is not None else [])
 
     if args.pmc_child:
         legs = [("main", batch, "0"), ("dynamic_pruning", batch, "1")]
@@ -548,12 +573,6 @@ def main():
     os.environ["SA_SPARSE"] = "0" if exhaustive else "1"
 
     qps = B * K / dt
-    pmc, pmc_err = {}, "skipped"
-    if rank == 0 and world == 1 and not args.no_pmc:
-        t0 = time.time()
-        r.index.synchronize()
-        pmc, pmc_err = run_pmc_children(args, leg_names)
-        log(rank, f"PMC child runs: {'ok' if pmc else pmc_err} ({time.time()-t0:.0f}s)")
 
     cpu, parity = None, "skipped"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
