@@ -543,6 +543,9 @@ def main():
         if batch_d is not None:
             legs.append(("distinct_terms", batch_d, "0"))
         pmc_child(r, legs)
+        batch.close()
+        if batch_d is not None:
+            batch_d.close()
         r.close()
         return
 

@@ -70,6 +70,13 @@ struct sa_batch {
     u32 ev_n = 0;                       // runs recorded since the last sa_batch_profile
     u64 alg_bytes = 0, postings_bytes = 0;
     bool ran = false;
+    // grouped exhaustive scoring (sa_k_bm25_group_tiles): device rows [0, n_grouped_rows) belong to groups of
+    // queries that share their first term, the others follow
+    u32* d_grp = nullptr;           // [n_groups][2] first row, rows
+    u64* d_wl = nullptr;            // (tile, row) items the grouped kernel leaves to the per-query kernel
+    u32* d_wl_cnt = nullptr;
+    u32* d_iota = nullptr;          // [B] 0 .. B-1 (query lists of the per-query kernel: rows [a, b) = d_iota + a)
+    u32 n_groups = 0, n_grouped_rows = 0, grp_tt = 1, grp_tt_shift = 0;
     // phrase batches (sa_phrase_batch.hip): kind == 1
     int kind = 0;                   // 0: disjunctive BM25 over terms, 1: exact phrases
     u32 ptile = 0, pn_tiles = 0;    // docs per phrase tile and their number

@@ -21,6 +21,7 @@
 #include "../../include/searcharray_hip.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <new>
 #include <stdlib.h>
 #include <math.h>
@@ -48,6 +49,7 @@ struct Bm25Params {
     const u64* imp;        // impact stream (sa_impacts, sa_index.hpp) or null: score the TF postings
     const u64* qbase_imp;  // [B][T][2] impact stream: first cell of each query term, first cell of the sentinel pair behind it
     u32 B, T, k;
+    u32 tile0, tile_end;   // tiles [tile0, tile_end) of this launch (sa_k_bm25_tiles)
     float k1, b, avgdl;
     int pruned;            // 1: wave-level selection against a global bound (MODE 1); 0: block-level selection (MODE 0)
     int no_topk;           // timing experiments only: skip the per-tile selection
@@ -222,23 +224,33 @@ sa_k_make_bounds(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, co
 // IMP: read the impact stream (p.imp / p.qbase_imp) instead of the TF postings.  A batch of 8 postings per
 // lane then updates its accumulators together -- 8 LDS reads in flight, the adds, 8 writes -- and a posting
 // outside the tile is steered to a spare slot behind the tile instead of being branched around.
+// LDS of one tile item: the accumulators (+ one spare slot per lane: acc[TILE + lane]) aliased with the
+// MODE 0 selection lists, and the saturation table (TF route) / the selection's per-wave histogram scratch
+// (impact route).  Declared by the kernels and handed to the item, so that a kernel which does other work
+// on the same tile (sa_k_bm25_group_tiles) can lend the item its own accumulators.
+template <int TILE, int MODE>
+__host__ __device__ constexpr size_t sa_tile_smem_u64() {
+    constexpr int CAP = (TILE >= 8192) ? 2048 : TILE / 4;
+    constexpr size_t ACC_BYTES = (size_t)TILE * 4;
+    constexpr size_t SEL_BYTES = MODE == 0 ? (size_t)(CAP + SA_KMAX) * 8 : 0;
+    return (ACC_BYTES > SEL_BYTES ? ACC_BYTES : SEL_BYTES) / 8 + SA_WAVE / 2;
+}
+template <int THREADS, bool IMP>
+__host__ __device__ constexpr int sa_tile_tab_floats() {
+    constexpr int NW = THREADS / SA_WAVE;
+    return IMP ? (NW * SA_HBINS / 2 > 64 ? NW * SA_HBINS / 2 : 64) : SA_SAT_NTF * SA_SAT_WMAX;
+}
+
 template <int TILE, int THREADS, int MODE, bool IMP>
-__device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32 tile, const u32 qi) {
+__device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32 tile, const u32 qi, u64* smem, float* s_tab) {
     constexpr int NW = THREADS / SA_WAVE;
     constexpr int E = TILE / THREADS;
     constexpr int CAP = (TILE >= 8192) ? 2048 : TILE / 4;      // candidate list capacity (MODE 0)
     constexpr int LE = (CAP + THREADS - 1) / THREADS;
-    constexpr size_t ACC_BYTES = (size_t)TILE * 4;
-    constexpr size_t SEL_BYTES = MODE == 0 ? (size_t)(CAP + SA_KMAX) * 8 : 0;
-    constexpr size_t SMEM_U64 = (ACC_BYTES > SEL_BYTES ? ACC_BYTES : SEL_BYTES) / 8 + SA_WAVE / 2;   // + one spare slot per lane: acc[TILE + lane]
     constexpr int PF = 4;                                       // 16-byte loads in flight per lane
-    __shared__ alignas(16) u64 smem[SMEM_U64];
     __shared__ u64 red64[NW + 1];
     __shared__ u32 red[NW + 1];
     __shared__ u32 s_cnt[2];
-    // TF route: the saturation table; impact route: only the selection's per-wave histogram scratch lives here
-    constexpr int TAB_FLOATS = IMP ? (NW * SA_HBINS / 2 > 64 ? NW * SA_HBINS / 2 : 64) : SA_SAT_NTF * SA_SAT_WMAX;
-    __shared__ float s_tab[TAB_FLOATS];
     float* acc = (float*)smem;
 
     // Work items (tile, query) are dispatched tile-major, one workgroup per item: the items in
@@ -726,9 +738,11 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
 template <int TILE, int THREADS, int MODE, bool IMP>
 __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
     // grid (queries, tiles): x runs fastest, so the dispatch order is tile-major without a division
-    const u32 tile = blockIdx.z * SA_GRID_Y + blockIdx.y;
-    if (tile >= p.n_tiles) return;
-    sa_bm25_tile_item<TILE, THREADS, MODE, IMP>(p, tile, blockIdx.x);
+    __shared__ alignas(16) u64 smem[sa_tile_smem_u64<TILE, MODE>()];
+    __shared__ float s_tab[sa_tile_tab_floats<THREADS, IMP>()];
+    const u32 tile = p.tile0 + blockIdx.z * SA_GRID_Y + blockIdx.y;
+    if (tile >= p.tile_end) return;
+    sa_bm25_tile_item<TILE, THREADS, MODE, IMP>(p, tile, blockIdx.x, smem, s_tab);
 }
 
 // The queries the sparse candidate path handed back (usually none): their number is only known on the
@@ -736,10 +750,346 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles(const Bm25Params p) {
 // launch.  Slower per item than one workgroup per item, which does not matter for a rare fallback.
 template <int TILE, int THREADS, bool IMP>
 __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles_list(const Bm25Params p) {
+    __shared__ alignas(16) u64 smem[sa_tile_smem_u64<TILE, 1>()];
+    __shared__ float s_tab[sa_tile_tab_floats<THREADS, IMP>()];
     const u32 nq = *p.nq_dev;
     const u64 n_items = (u64)nq * p.n_tiles;
     for (u64 item = blockIdx.x; item < n_items; item += gridDim.x) {
-        sa_bm25_tile_item<TILE, THREADS, 1, IMP>(p, (u32)(item / nq), (u32)(item % nq));
+        sa_bm25_tile_item<TILE, THREADS, 1, IMP>(p, (u32)(item / nq), (u32)(item % nq), smem, s_tab);
+        __syncthreads();                              // LDS is reused by the next item
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grouped exhaustive scoring: queries of a batch that share their FIRST term.
+//
+// Real batches repeat their frequent terms (the BASELINE query set draws its first term from ten terms),
+// and the frequent term is where the postings are: per (tile, query) item of sa_k_bm25_tiles ~87 % of the
+// posting loads and LDS updates belong to a term that 25 other queries of the batch score identically --
+// same impact stream, same idf, and, the term being FIRST in query order, the same partial sum
+// 0 + s0 = s0.  Here ONE wave owns a (tile, group) item:
+//   base      the shared first term is scored once into the tile's accumulators ("base");
+//   overlay   the queries of the group are taken one after the other: the postings of a query's further
+//             terms are added IN PLACE in query-term order (so a doc's sum is ((s0 + s1) + s2) + s3 bit for
+//             bit), the written value carrying its sign bit as a "touched by this query" mark; the lane that
+//             touched a doc first evaluates the doc's final score against the query's bound, appends it
+//             if it survives, and puts the base value back.  Docs a query does not touch score exactly the
+//             base value: they need no per-query work at all as long as the tile's largest base value is
+//             below the query's bound (else the general path below runs);
+//   general   a query whose further terms have more postings in the tile than the overlay holds in registers,
+//             or whose bound is not above the base values yet, is left to the per-query item: the (tile, query)
+//             pair goes on a work list that sa_k_bm25_tiles_wl walks right after this kernel.
+// Every posting of every query term is still read and scored -- nothing is skipped on a score bound; the
+// shared term is read once per group instead of once per query.  Results are bit-identical to the per-query
+// kernel (same candidates above the same bounds, same merge).  The next query's postings and bound are
+// requested before the current one is processed (fixed number of loads per query, so the compiler can
+// count them and wait for the current query's data only).
+// ---------------------------------------------------------------------------------------------
+#define SA_GRP_NH 12        // 64-posting halves of a query's further terms held in registers (768 postings per tile and query)
+#define SA_GRP_MAXQ 16      // queries per group item (bigger groups are cut into balanced pieces)
+
+struct GroupParams {
+    const u32* grp;         // [n_groups][2]: first device row, number of rows (rows of a group are contiguous)
+    u32 n_groups;
+    u32 tile0, n_tiles_run; // tiles [tile0, tile0 + n_tiles_run)
+    u32 tt, tt_shift;       // lanes per query while the step tables are built: power of two >= max(T - 1, 1)
+    u64* wl;                // work list of (tile << 32 | device row) items left to the per-query kernel
+    u32* wl_cnt;
+};
+
+// One HALF = up to 64 postings of ONE term of one query in this tile, one per lane (8-byte loads): every LDS
+// instruction of the overlay touches the postings of a single term, i.e. pairwise distinct docs.
+struct alignas(16) SaGrpHalf { u64 addr; float idf; u32 cnt; };
+
+// f(0), f(STEP), f(2 STEP), ... while the index is below n (< NH): nested tests, so the chain is left at the first
+// index that is not, and every index is a compile-time constant (arrays indexed by it stay in registers)
+template <int H, int NH, int STEP, class F>
+__device__ __forceinline__ void sa_static_while_below(u32 n, F&& f) {
+    if constexpr (H < NH) {
+        if ((u32)H < n) {
+            f(std::integral_constant<int, H>{});
+            sa_static_while_below<H + STEP, NH, STEP>(n, f);
+        }
+    }
+}
+
+// s_waitcnt with vmcnt = 0 and the other counters open (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14])
+#define SA_WAIT_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)
+
+template <int TILE>
+__global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, const GroupParams gp) {
+    constexpr int NH = SA_GRP_NH;
+    __shared__ alignas(16) u64 smem[sa_tile_smem_u64<TILE, 1>()];
+    __shared__ alignas(16) SaGrpHalf s_half[SA_GRP_MAXQ][NH];
+    __shared__ u32 s_nh[SA_GRP_MAXQ];
+    u32* const accu = (u32*)smem;
+    const u32 lane = threadIdx.x;
+    // XCD-aware item order: consecutive blocks go to consecutive XCDs (block b runs on XCD b % 8), so the
+    // eight tiles of a chunk sit on eight XCDs and ALL groups of a tile follow each other on the same XCD:
+    // the slices of the further terms that queries of different groups share are fetched into one L2 only.
+    const u32 per = 8u * gp.n_groups;
+    const u32 chunk = blockIdx.x / per, r = blockIdx.x % per;
+    const u32 g = r >> 3;
+    const u32 trel = chunk * 8u + (r & 7u);
+    if (trel >= gp.n_tiles_run) return;
+    const u32 tile = gp.tile0 + trel;
+    const u32 row0 = gp.grp[2 * g], n = gp.grp[2 * g + 1];
+    const u32 T = p.T;
+    const u64 tile_base = (u64)tile * TILE;
+    const u32 tile_base_b = (u32)tile_base * 4u;
+    const u32 spare = ((u32)TILE + lane) * 4u;                  // byte offset of this lane's spare slot
+    const u64* const stream = p.imp;
+    auto at = [&](u32 byte_off) -> u32& { return *(u32*)((char*)accu + byte_off); };
+
+    // ---- the shared first term
+    const u32 qt0 = row0 * T;
+    const u32* hrow = p.bounds + (u64)qt0 * (p.n_tiles + 1) + tile;
+    const u32 h0 = hrow[0], h1 = hrow[1];
+    const sa_u64x2 hbs = ((const sa_u64x2*)p.qbase_imp)[qt0];
+    const float hidf = p.idf[qt0];
+
+    // ---- half tables of the queries' further terms: lane (qi, t) looks up term t's slice of query qi in this
+    //      tile and writes one entry per 64 postings, in query-term order
+    const u32 TT = gp.tt, tsh = gp.tt_shift, QPP = 64u >> tsh;
+    struct Pre { u32 r0, r1; u64 base; float idf; };
+    auto pre_load = [&](u32 ps) -> Pre {
+        Pre x; x.r0 = 0; x.r1 = 0; x.base = 0; x.idf = 0.f;
+        const u32 qi = ps * QPP + (lane >> tsh), t = 1u + (lane & (TT - 1u));
+        if (qi < n && t < T) {
+            const u32 qt = (row0 + qi) * T + t;
+            const u32* row = p.bounds + (u64)qt * (p.n_tiles + 1) + tile;
+            x.base = p.qbase_imp[2 * (u64)qt];
+            x.r0 = row[0]; x.r1 = row[1]; x.idf = p.idf[qt];
+        }
+        return x;
+    };
+    auto pre_store = [&](u32 ps, const Pre& x) {
+        const u32 qi = ps * QPP + (lane >> tsh), tl = lane & (TT - 1u);
+        const u32 np = x.r1 - x.r0;                             // postings of this term in this tile
+        const u32 halves = (np + 63u) >> 6;
+        u32 incl = halves;                                      // inclusive scan over the TT lanes of a query
+        for (u32 o = 1; o < TT; o <<= 1) {
+            const u32 up = __shfl_up(incl, o, SA_WAVE);
+            if (tl >= o) incl += up;
+        }
+        const u32 excl = incl - halves;
+        const u32 total = (u32)__shfl((int)incl, (int)(lane | (TT - 1u)), SA_WAVE);
+        if (qi < n) {
+            const u64 first = (u64)(stream + x.base + x.r0);
+            for (u32 j = 0; j < halves && excl + j < (u32)NH; j++) {
+                SaGrpHalf d;
+                d.addr = first + (u64)j * 512ull;
+                d.idf = x.idf;
+                d.cnt = (np - j * 64u < 64u ? np - j * 64u : 64u) | (excl + j == 0u ? total << 8 : 0u);
+                s_half[qi][excl + j] = d;
+            }
+            if (tl == 0u) {
+                s_nh[qi] = total;
+                if (total == 0u || ((total & 1u) && total < (u32)NH)) {   // halves are taken two at a time: an odd count gets an empty partner
+                    SaGrpHalf d;
+                    d.addr = (u64)stream; d.idf = 0.f; d.cnt = 0u;          // (entry 0 of a query without postings: 0 halves)
+                    s_half[qi][total] = d;
+                }
+            }
+        }
+    };
+    const u32 NP = (n + QPP - 1u) / QPP;                        // 1 or 2 passes (host: n * TT <= 128)
+    {
+        const Pre x0 = pre_load(0);
+        Pre x1 = x0;
+        if (NP > 1u) x1 = pre_load(1);
+        pre_store(0, x0);
+        if (NP > 1u) pre_store(1, x1);
+    }
+    // One wave per workgroup: its LDS instructions execute in program order for all lanes, so lanes hand data
+    // to each other through LDS without s_barrier; the wave barriers below only pin the order of the accesses
+    // for the compiler (they emit no instruction).
+    __builtin_amdgcn_wave_barrier();
+    {
+        // nothing to score in this tile at all?
+        const u32 mine = lane < n ? s_nh[lane] : 0u;
+        if (h1 == h0 && __ballot(mine != 0u) == 0ull) return;
+    }
+
+    // The half descriptors of a query reach the scalar registers with ONE LDS instruction: lane h reads entry h
+    // (16 bytes) and v_readlane hands the fields out -- no LDS round trip per half.  Entry 0 carries the
+    // query's number of halves in bits 8.. of its count field.
+    struct Q { u64 v[NH]; u32 dlo, dhi, dcnt; float didf; };
+    typedef const __attribute__((address_space(1))) u64* gptr_u64;
+    // request the postings of query qi's halves (dynamic number of loads: the caller has made sure that no
+    // older load is outstanding, so "everything landed" is an exact wait for them later) and its bound
+    auto prefetch = [&](u32 qi, Q& X) {
+        const SaGrpHalf d = s_half[qi][lane < (u32)NH ? lane : 0u];
+        X.dlo = (u32)d.addr; X.dhi = (u32)(d.addr >> 32); X.dcnt = d.cnt; X.didf = d.idf;
+        const u32 nh_raw = (u32)__builtin_amdgcn_readfirstlane((int)d.cnt) >> 8;
+        const u32 nh = nh_raw <= (u32)NH ? nh_raw : 0u;         // (too many: the pair goes to the per-query kernel)
+        sa_static_while_below<0, NH, 1>(nh, [&](auto hc) {       // (a query has ~4 halves on average)
+            constexpr int h = decltype(hc)::value;
+            const u64 a = (u64)(u32)__builtin_amdgcn_readlane((int)X.dlo, h) | ((u64)(u32)__builtin_amdgcn_readlane((int)X.dhi, h) << 32);
+            const u32 cnt = (u32)__builtin_amdgcn_readlane((int)X.dcnt, h) & 0xFFu;
+            const u32 j = lane < cnt ? lane : cnt - 1u;         // lanes past the end re-read the last posting (masked when scored)
+            X.v[h] = ((gptr_u64)a)[j];
+        });
+    };
+    // the queries' bounds, one per lane, read once per item (a bound only ever rises: a stale one is valid)
+    const u32 thr_all = lane < n ? __hip_atomic_load(&p.gthr[row0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    Q A, B;
+    prefetch(0, A);                                             // in flight while the base is built
+
+    // ---- base: clear, then the first term's slice scored once (write-only: 0 + s0 = s0)
+    u32 base_max;
+    {
+        float4* a4 = (float4*)accu;
+#pragma unroll
+        for (int j = 0; j < TILE / 256; j++) a4[j * 64 + (int)lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __builtin_amdgcn_wave_barrier();
+        const u64 lo = hbs.x + h0, hi = hbs.x + h1, a0 = lo & ~1ull;
+        const u32 npairs = hi > lo ? (u32)((hi - a0 + 1) >> 1) : 0u;
+        const u32 jc = (u32)((hbs.y - a0) >> 1);
+        const sa_u64x2* pairs = (const sa_u64x2*)(stream + a0);
+        u32 lmax = 0;
+        constexpr int PF = 4;
+        sa_u64x2 cur[PF], nxt[PF];
+        if (npairs) {
+#pragma unroll
+            for (int u = 0; u < PF; u++) { const u32 j = (u32)u * 64u + lane; cur[u] = pairs[j < jc ? j : jc]; }
+        }
+        for (u32 first = 0; first < npairs; first += (u32)PF * 64u) {
+            const bool more = first + (u32)PF * 64u < npairs;
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < PF; u++) { const u32 j = first + (u32)(PF + u) * 64u + lane; nxt[u] = pairs[j < jc ? j : jc]; }
+            }
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const u32 d0 = (u32)(cur[u].x >> 32) - tile_base_b, d1 = (u32)(cur[u].y >> 32) - tile_base_b;
+                const bool in0 = d0 < (u32)TILE * 4u, in1 = d1 < (u32)TILE * 4u;
+                const u32 w0 = __float_as_uint(__fmul_rn(__uint_as_float((u32)cur[u].x), hidf));
+                const u32 w1 = __float_as_uint(__fmul_rn(__uint_as_float((u32)cur[u].y), hidf));
+                at(in0 ? d0 : spare) = w0;
+                at(in1 ? d1 : spare) = w1;
+                const u32 m0 = in0 ? w0 : 0u, m1 = in1 ? w1 : 0u;
+                lmax = m0 > lmax ? m0 : lmax;
+                lmax = m1 > lmax ? m1 : lmax;
+            }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < PF; u++) cur[u] = nxt[u];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        base_max = sa_wave_max_u32(lmax);
+    }
+
+    // queries left to the per-query kernel (work list at the end)
+    u64 deferred = 0ull;
+    auto process = [&](u32 qi, const Q& X) {
+        const u32 q = row0 + qi;
+        const u32 nh = (u32)__builtin_amdgcn_readfirstlane((int)X.dcnt) >> 8;
+        const u32 thr_q = (u32)__builtin_amdgcn_readlane((int)thr_all, (int)qi);
+        const u32 thr = thr_q > 1u ? thr_q : 1u;
+        if (nh > (u32)NH || base_max >= thr) { deferred |= 1ull << qi; return; }
+        if (nh == 0u) return;                                   // the query scores exactly the base here: all below its bound
+        u32 rs[NH], ro[NH];
+        // overlay: the query's further postings, in query-term order, in place
+        sa_static_while_below<0, NH, 2>(nh, [&](auto hc) {
+            constexpr int h2 = decltype(hc)::value;
+            {
+#pragma unroll
+                for (int h = h2; h < h2 + 2; h++) {
+                    __builtin_amdgcn_wave_barrier();            // a half sees the previous half's (other lanes') writes
+                    const u32 cnt = (u32)__builtin_amdgcn_readlane((int)X.dcnt, h) & 0xFFu;
+                    const float w = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(X.didf), h));
+                    const bool valid = lane < cnt;
+                    const u64 v = X.v[h];
+                    const u32 sl = valid ? (u32)(v >> 32) - tile_base_b : spare;
+                    const u32 o = at(sl);
+                    at(sl) = __float_as_uint(__fadd_rn(__uint_as_float(o & 0x7FFFFFFFu), __fmul_rn(__uint_as_float((u32)v), w))) | 0x80000000u;
+                    // the lane that found the doc untouched owns its evaluation and puts the base value back
+                    rs[h] = (valid && !(o >> 31)) ? sl : spare;
+                    ro[h] = o;
+                }
+            }
+        });
+        // final scores of the touched docs; base values back
+        __builtin_amdgcn_wave_barrier();
+        u64 anyk = 0ull;
+        sa_static_while_below<0, NH, 2>(nh, [&](auto hc) {
+            constexpr int h2 = decltype(hc)::value;
+#pragma unroll
+            for (int h = h2; h < h2 + 2; h++) {
+                const u32 sl = rs[h];
+                const u32 fin = at(sl) & 0x7FFFFFFFu;
+                at(sl) = ro[h];
+                ro[h] = fin;
+                anyk |= __ballot(sl != spare && fin >= thr);
+            }
+        });
+        __builtin_amdgcn_wave_barrier();
+        if (anyk == 0ull) return;                               // the usual case once the bound stands
+        u32 c = 0;
+#pragma unroll
+        for (int i = 0; i < NH; i++)
+            if ((u32)(i & ~1) < nh) c += (u32)__popcll(__ballot(rs[i] != spare && ro[i] >= thr));
+        if (c > 16u) { deferred |= 1ull << qi; return; }        // bound still far off: the per-query item's histogram path refines it first
+        u32* qh = p.hist + (u64)q * SA_HBINS;
+        u64* qcand = p.cand + (u64)q * p.cand_cap;
+        const u64 lt = (1ull << lane) - 1ull;
+        u32 cbase = 0;
+        if (lane == 0) cbase = atomicAdd(&p.cand_cnt[q], c);
+        cbase = (u32)__builtin_amdgcn_readfirstlane((int)cbase);
+#pragma unroll
+        for (int i = 0; i < NH; i++) {
+            if ((u32)(i & ~1) < nh) {
+                const bool keep = rs[i] != spare && ro[i] >= thr;
+                const u64 bl = __ballot(keep);
+                if (keep) {
+                    atomicAdd(&qh[sa_score_bin(ro[i])], 1u);
+                    const u32 pos = cbase + (u32)__popcll(bl & lt);
+                    const u64 doc = p.doc_base + tile_base + (u64)(rs[i] >> 2);
+                    if (pos < p.cand_cap) qcand[pos] = ((u64)ro[i] << 32) | (u64)(u32)(~(u32)doc);
+                }
+                cbase += (u32)__popcll(bl);
+            }
+        }
+        if (((tile + q) & 7u) == 0u) sa_hist_refresh(qh, &p.gthr[q], p.k, lane);
+    };
+
+    // ---- the queries of the group, two per round so that the prefetch buffers swap without copies.  Before the
+    //      next query's loads are issued everything older has landed (an exact wait: only the current query's
+    //      loads are outstanding), so the current query is processed while exactly the next one's loads fly.
+    for (u32 qi = 0; qi < n; qi += 2) {
+        SA_WAIT_VMCNT0();
+        if (qi + 1u < n) prefetch(qi + 1u, B);
+        process(qi, A);
+        if (qi + 1u < n) {
+            SA_WAIT_VMCNT0();
+            if (qi + 2u < n) prefetch(qi + 2u, A);
+            process(qi + 1u, B);
+        }
+    }
+    // ---- general path: hand the (tile, query) pairs to the per-query kernel that follows (sa_k_bm25_tiles_wl)
+    if (deferred) {
+        const u32 c = (u32)__popcll(deferred);
+        u32 wbase = 0;
+        if (lane == 0) wbase = atomicAdd(gp.wl_cnt, c);
+        wbase = (u32)__builtin_amdgcn_readfirstlane((int)wbase);
+        if ((deferred >> lane) & 1ull)
+            gp.wl[wbase + (u32)__popcll(deferred & ((1ull << lane) - 1ull))] = ((u64)tile << 32) | (u64)(row0 + lane);
+    }
+}
+
+// The (tile, query) items the grouped kernel left to the per-query path (usually none once the bounds stand):
+// their number is only known on the device, so a resident grid walks the work list.
+template <int TILE, int THREADS>
+__global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles_wl(const Bm25Params p, const u64* __restrict__ wl,
+                                                               const u32* __restrict__ wl_cnt) {
+    __shared__ alignas(16) u64 smem[sa_tile_smem_u64<TILE, 1>()];
+    __shared__ float s_tab[sa_tile_tab_floats<THREADS, true>()];
+    const u32 nitems = *wl_cnt;
+    for (u32 i = blockIdx.x; i < nitems; i += gridDim.x) {
+        const u64 it = wl[i];
+        sa_bm25_tile_item<TILE, THREADS, 1, true>(p, (u32)(it >> 32), (u32)it, smem, s_tab);
         __syncthreads();                              // LDS is reused by the next item
     }
 }
@@ -760,9 +1110,10 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles_list(const Bm25Params
 
 // clears `words` u32 at `slots` and `n8` 8-byte cells at `bloom`
 __global__ void __launch_bounds__(256)
-sa_k_run_reset(u32* __restrict__ slots, u64 words, u64* __restrict__ bloom, u64 n8) {
+sa_k_run_reset(u32* __restrict__ slots, u64 words, u64* __restrict__ bloom, u64 n8, u32* __restrict__ one_more) {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && one_more) *one_more = 0u;
     for (u64 i = t; i < words; i += stride) slots[i] = 0u;
     for (u64 i = t; i < n8; i += stride) bloom[i] = 0ull;
 }
@@ -919,6 +1270,7 @@ static void sa_fill_params(const sa_index* ix, Bm25Params& p) {
     p.n_docs = ix->n_docs; p.doc_base = ix->doc_base; p.dl_packed = ix->dl_packed ? 1 : 0;
     p.avgdl = ix->avg_doc_len;
     p.qlist = nullptr; p.nq = 0;                     // callers set nq (= B) after filling B
+    p.tile0 = 0; p.tile_end = ix->n_tiles;
 }
 
 static u32 sa_tile_waves(u32 tile_docs) {
@@ -966,8 +1318,9 @@ static int sa_env_int(const char* name, int dflt) {
 
 template <int MODE>
 static int sa_launch_bm25_mode(sa_index* ix, const Bm25Params& p, hipStream_t st) {
-    const u32 gy = ix->n_tiles < SA_GRID_Y ? ix->n_tiles : SA_GRID_Y;
-    const dim3 grid(p.nq, gy, (ix->n_tiles + SA_GRID_Y - 1) / SA_GRID_Y);
+    const u32 nt = p.tile_end - p.tile0;
+    const u32 gy = nt < SA_GRID_Y ? nt : SA_GRID_Y;
+    const dim3 grid(p.nq, gy, (nt + SA_GRID_Y - 1) / SA_GRID_Y);
     switch (ix->tile_docs) {
         case 1024: SA_LAUNCH_TILE(1024, 128);
         case 2048: SA_LAUNCH_TILE(2048, 64);
@@ -1007,8 +1360,38 @@ static int sa_launch_bm25_list(sa_index* ix, const Bm25Params& p, hipStream_t st
     return SA_OK;
 }
 
+static int sa_launch_bm25_groups(sa_index* ix, const sa_batch* bt, const Bm25Params& p, u32 tile0, hipStream_t st) {
+    GroupParams gp;
+    gp.grp = bt->d_grp; gp.n_groups = bt->n_groups;
+    gp.tile0 = tile0; gp.n_tiles_run = ix->n_tiles - tile0;
+    gp.tt = bt->grp_tt; gp.tt_shift = bt->grp_tt_shift;
+    const u64 blocks = (u64)((gp.n_tiles_run + 7u) / 8u) * 8u * gp.n_groups;
+    if (blocks == 0 || blocks > 0x7FFFFFFFull) { sa_set_error("grouped launch: bad grid"); return SA_ERR_STATE; }
+    gp.wl = bt->d_wl; gp.wl_cnt = bt->d_wl_cnt;
+    const u64 worst = (u64)gp.n_tiles_run * bt->n_grouped_rows;
+    const u32 wgrid = worst < 2048 ? (u32)worst : 2048u;
+    switch (ix->tile_docs) {
+        case 1024:
+            hipLaunchKernelGGL((sa_k_bm25_group_tiles<1024>), dim3((u32)blocks), dim3(64), 0, st, p, gp);
+            hipLaunchKernelGGL((sa_k_bm25_tiles_wl<1024, 128>), dim3(wgrid), dim3(128), 0, st, p, (const u64*)gp.wl, (const u32*)gp.wl_cnt);
+            break;
+        case 2048:
+            hipLaunchKernelGGL((sa_k_bm25_group_tiles<2048>), dim3((u32)blocks), dim3(64), 0, st, p, gp);
+            hipLaunchKernelGGL((sa_k_bm25_tiles_wl<2048, 64>), dim3(wgrid), dim3(64), 0, st, p, (const u64*)gp.wl, (const u32*)gp.wl_cnt);
+            break;
+        case 4096:
+            hipLaunchKernelGGL((sa_k_bm25_group_tiles<4096>), dim3((u32)blocks), dim3(64), 0, st, p, gp);
+            hipLaunchKernelGGL((sa_k_bm25_tiles_wl<4096, 128>), dim3(wgrid), dim3(128), 0, st, p, (const u64*)gp.wl, (const u32*)gp.wl_cnt);
+            break;
+        default:
+            sa_set_error("unsupported tile_docs %u for the grouped kernel", ix->tile_docs);
+            return SA_ERR_STATE;
+    }
+    return SA_OK;
+}
+
 static int sa_launch_bm25(sa_index* ix, const Bm25Params& p, hipStream_t st) {
-    if (ix->n_tiles == 0 || p.nq == 0) return SA_OK;
+    if (ix->n_tiles == 0 || p.nq == 0 || p.tile_end <= p.tile0) return SA_OK;
     return p.pruned ? sa_launch_bm25_mode<1>(ix, p, st) : sa_launch_bm25_mode<0>(ix, p, st);
 }
 
@@ -1090,6 +1473,10 @@ void sa_batch_free(sa_batch* bt) {
     if (bt->d_ub) hipFree(bt->d_ub);
     if (bt->d_ub_order) hipFree(bt->d_ub_order);
     if (bt->d_stats) hipFree(bt->d_stats);
+    if (bt->d_grp) hipFree(bt->d_grp);
+    if (bt->d_wl) hipFree(bt->d_wl);
+    if (bt->d_wl_cnt) hipFree(bt->d_wl_cnt);
+    if (bt->d_iota) hipFree(bt->d_iota);
     if (bt->d_lead) hipFree(bt->d_lead);
     if (bt->d_p1_off) hipFree(bt->d_p1_off);
     if (bt->d_route) hipFree(bt->d_route);
@@ -1183,6 +1570,52 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
         if (heavy[a] != heavy[c]) return heavy[a] > heavy[c];
         return heavy_term[a] < heavy_term[c];
     });
+    // Groups of queries that share their FIRST term (same term, same idf bits): sa_k_bm25_group_tiles scores the
+    // shared term once per (tile, group).  Grouped queries take the first device rows, group by group (big
+    // groups are cut into balanced pieces of at most `maxq` queries), the others keep their order behind them.
+    std::vector<u32> h_grp;
+    {
+        u32 tt = 1, tsh = 0;
+        while (tt + 1u < T) { tt <<= 1; tsh++; }               // power of two >= max(T - 1, 1)
+        bt->grp_tt = tt; bt->grp_tt_shift = tsh;
+        const u32 maxq = std::min<u32>(SA_GRP_MAXQ, 128u / tt);
+        const u32 gmin = (u32)std::max(1, sa_env_int("SA_GROUP_MIN", 2));
+        bool idf_ok = k1 >= 0.f && b >= 0.f && b <= 1.f;       // scores must be non-negative (the sign bit is a mark)
+        for (size_t i = 0; i < (size_t)B * T && idf_ok; i++) idf_ok = idf[i] >= 0.f && idf[i] <= 3.0e38f;
+        const bool on = sa_env_int("SA_GROUP", 1) != 0 && idf_ok && maxq >= 1 &&
+                        (ix->tile_docs == 1024 || ix->tile_docs == 2048 || ix->tile_docs == 4096);
+        if (on) {
+            std::vector<std::vector<u32>> members;              // in order of first appearance
+            std::vector<std::pair<u32, u32>> keys;
+            std::vector<u32> rest;
+            for (u32 r = 0; r < B; r++) {
+                const u32 q = bt->perm[r];
+                const u32 t0 = terms[(size_t)q * T];
+                u32 ib; memcpy(&ib, &idf[(size_t)q * T], 4);
+                if (t0 >= ix->n_terms) { rest.push_back(q); continue; }
+                size_t gi = 0;
+                for (; gi < keys.size(); gi++) if (keys[gi].first == t0 && keys[gi].second == ib) break;
+                if (gi == keys.size()) { keys.push_back({t0, ib}); members.emplace_back(); }
+                members[gi].push_back(q);
+            }
+            std::vector<u32> order;
+            for (auto& m : members) {
+                if (m.size() < gmin) { rest.insert(rest.end(), m.begin(), m.end()); continue; }
+                const u32 pieces = ((u32)m.size() + maxq - 1) / maxq;
+                u32 done = 0;
+                for (u32 pc = 0; pc < pieces; pc++) {
+                    const u32 sz = ((u32)m.size() - done + (pieces - pc) - 1) / (pieces - pc);
+                    h_grp.push_back((u32)order.size()); h_grp.push_back(sz);
+                    for (u32 i = 0; i < sz; i++) order.push_back(m[done + i]);
+                    done += sz;
+                }
+            }
+            bt->n_grouped_rows = (u32)order.size();
+            bt->n_groups = (u32)(h_grp.size() / 2);
+            order.insert(order.end(), rest.begin(), rest.end());
+            bt->perm = order;
+        }
+    }
     std::vector<u32> h_terms((size_t)B * T);
     std::vector<float> h_idf((size_t)B * T);
     for (u32 r = 0; r < B; r++) {
@@ -1196,6 +1629,19 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
     SA_HIP_B(hipMalloc(&bt->d_idf, h_idf.size() * sizeof(float)));
     SA_HIP_B(hipMalloc(&bt->d_perm, (size_t)B * sizeof(u32)));
     SA_HIP_B(hipMemcpy(bt->d_perm, bt->perm.data(), (size_t)B * sizeof(u32), hipMemcpyHostToDevice));
+    {
+        std::vector<u32> iota(B);
+        for (u32 i = 0; i < B; i++) iota[i] = i;
+        SA_HIP_B(hipMalloc(&bt->d_iota, (size_t)B * sizeof(u32)));
+        SA_HIP_B(hipMemcpy(bt->d_iota, iota.data(), (size_t)B * sizeof(u32), hipMemcpyHostToDevice));
+        if (bt->n_groups) {
+            SA_HIP_B(hipMalloc(&bt->d_wl, std::max<size_t>(1, (size_t)ix->n_tiles * bt->n_grouped_rows) * sizeof(u64)));
+            SA_HIP_B(hipMalloc(&bt->d_wl_cnt, sizeof(u32)));
+            SA_HIP_B(hipMemset(bt->d_wl_cnt, 0, sizeof(u32)));
+            SA_HIP_B(hipMalloc(&bt->d_grp, h_grp.size() * sizeof(u32)));
+            SA_HIP_B(hipMemcpy(bt->d_grp, h_grp.data(), h_grp.size() * sizeof(u32), hipMemcpyHostToDevice));
+        }
+    }
     if (sa_batch_alloc_topk(bt, ix->n_tiles, sa_tile_waves(ix->tile_docs)) != SA_OK) return fail(SA_ERR_HIP);
     SA_HIP_B(hipMemcpy(bt->d_terms, h_terms.data(), h_terms.size() * sizeof(u32), hipMemcpyHostToDevice));
     SA_HIP_B(hipMemcpy(bt->d_idf, h_idf.data(), h_idf.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1386,7 +1832,7 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
         const size_t work = words + bloom8 + 1;
         const u32 grid = work / 256 + 1 < 2048 ? (u32)(work / 256 + 1) : 2048u;
         hipLaunchKernelGGL(sa_k_run_reset, dim3(grid), dim3(256), 0, st, bt->d_slots, (u64)words,
-                           (u64*)(sparse ? bt->d_bloom : nullptr), (u64)bloom8);
+                           (u64*)(sparse ? bt->d_bloom : nullptr), (u64)bloom8, bt->d_wl_cnt);
     }
     const u32 slot = bt->ev_n % SA_EVENT_RING;
     SA_HIP(hipEventRecord(bt->ev0[slot], st));
@@ -1399,6 +1845,22 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
                 SA_TRY(sa_launch_sparse(bt, st));
                 p.qlist = bt->d_tile_q; p.nq_dev = bt->d_tile_q + bt->B;
                 SA_TRY(sa_launch_bm25_list(ix, p, st));
+            } else if (bt->n_groups && p.pruned && p.hist && p.imp && !p.no_topk && sa_env_int("SA_GROUP", 1) != 0) {
+                // Queries that share their first term: the first tiles through the per-query kernel, which
+                // establishes every query's bound (k-th best score so far), then one wave per (tile, group).
+                // Queries without a group go through the per-query kernel over all tiles.
+                u32 warm = std::max<u32>(16u, bt->k / 4u);
+                if (const char* v = getenv("SA_GROUP_WARM")) warm = (u32)atoi(v);
+                warm = std::min(warm, ix->n_tiles);
+                Bm25Params pa = p;
+                pa.qlist = bt->d_iota; pa.nq = bt->n_grouped_rows; pa.tile0 = 0; pa.tile_end = warm;
+                SA_TRY(sa_launch_bm25(ix, pa, st));
+                if (bt->n_grouped_rows < bt->B) {
+                    Bm25Params pu = p;
+                    pu.qlist = bt->d_iota + bt->n_grouped_rows; pu.nq = bt->B - bt->n_grouped_rows;
+                    SA_TRY(sa_launch_bm25(ix, pu, st));
+                }
+                if (ix->n_tiles > warm) SA_TRY(sa_launch_bm25_groups(ix, bt, p, warm, st));
             } else {
                 SA_TRY(sa_launch_bm25(ix, p, st));
             }

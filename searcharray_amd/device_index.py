@@ -207,7 +207,15 @@ class DeviceIndex:
         return words, term_off
 
     # -- lifetime
+    def _track(self, batch):
+        """batches hold device memory tied to this handle: they are closed before the index goes"""
+        if not hasattr(self, "_batches"):
+            self._batches = weakref.WeakSet()
+        self._batches.add(batch)
+
     def close(self):
+        for b in list(getattr(self, "_batches", ())):
+            b.close()
         if getattr(self, "_h", None) is not None and self._h.value:
             self.api.sa_index_destroy(self._h)
             self._h = ctypes.c_void_p()
@@ -422,6 +430,7 @@ class QueryBatch:
         idf = as_f32(idf)
         self._h = ctypes.c_void_p()
         self._create(index, terms, idf, k1, b)
+        index._track(self)
 
     def _create(self, index, terms, idf, k1, b):
         self.api.call("sa_batch_create", index._h, p_u32(as_u32(terms)), p_f32(idf), self.B, self.T,
@@ -501,6 +510,7 @@ class PhraseBatch(QueryBatch):
         self.api.call("sa_phrase_batch_create", index._h, p_u32(as_u32(terms)),
                       n_terms.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), p_f32(as_f32(idf)), self.B, self.T,
                       self.k, np.float32(k1), np.float32(b), ctypes.byref(self._h))
+        index._track(self)
 
 
 class DeviceVec:

@@ -286,6 +286,7 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
 }
 // scheduling barrier on the GPU; here the lanes of a wave are fibers, so it must really line them up
 inline void __builtin_amdgcn_wave_barrier() { (void)__ballot(1); }
+inline void __builtin_amdgcn_s_waitcnt(int) {}          // memory is synchronous here
 inline int __builtin_amdgcn_readlane(int v, int lane) {
     return (int)(uint32_t)hipemu::wave_collective(hipemu::OP_SHFL, (uint64_t)(uint32_t)v, lane);
 }

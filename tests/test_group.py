@@ -1,0 +1,112 @@
+"""Grouped exhaustive scoring (csrc/sa_bm25.hip, sa_k_bm25_group_tiles): queries of a batch that share their
+FIRST term are scored one wave per (tile, group) -- the shared term once, every query's further terms as an
+in-place overlay.  Results must equal the oracle's dense score + deterministic top-k bit for bit, whatever the
+group shapes, and equal the per-query kernel's (SA_GROUP=0)."""
+import numpy as np
+import pytest
+
+from oracle import refimpl as O
+from searcharray_amd import roaringish as rz, synth
+from searcharray_amd.device_index import DeviceIndex
+
+N_DOCS, VOCAB = 9000, 400
+
+
+@pytest.fixture(scope="module")
+def corpus():
+    t, d, p, lens = synth.corpus_triples(N_DOCS, VOCAB, 14, seed=31)
+    words, wt = rz.encode_sorted(t, d, p)
+    return words, rz.term_offsets(wt, VOCAB), lens, O.OracleIndex.from_triples(t, d, p, N_DOCS, doc_lens=lens)
+
+
+def check(api, corpus, queries, k, tile_docs=1024, doc_base=0, idf=None):
+    words, off, lens, orc = corpus
+    dev = DeviceIndex(words, off, lens, tile_docs=tile_docs, doc_base=doc_base, api=api)
+    bt = dev.batch(np.asarray(queries), k=k, idf=idf)
+    for _ in range(2):
+        bt.run()
+    scores, docs = bt.fetch()
+    for qi, q in enumerate(queries):
+        dense = orc.score_terms_sum([int(x) for x in q if 0 <= int(x) < VOCAB]) if idf is None else None
+        if dense is None:
+            continue
+        ws, wd = O.topk(dense, k)
+        n = int((ws > 0).sum())
+        assert np.array_equal(scores[qi, :n], ws[:n]), f"q{qi} {q} scores"
+        assert np.array_equal(docs[qi, :n], wd[:n] + np.uint64(doc_base)), f"q{qi} {q} docs"
+    bt.close()
+    dev.close()
+    return scores, docs
+
+
+def band_queries(rng, n, T, heads):
+    """n queries of T terms: term 0 from `heads` (few distinct -> groups), the others spread over the vocabulary"""
+    q = np.empty((n, T), dtype=np.int64)
+    q[:, 0] = rng.choice(heads, n)
+    for t in range(1, T):
+        lo = [3, 20, 100, 250][min(t - 1, 3)]
+        q[:, t] = rng.integers(lo, VOCAB, n)
+    return q
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 4, 6, 10])
+@pytest.mark.parametrize("k", [3, 50])
+def test_grouped_equals_oracle(api, corpus, monkeypatch, T, k):
+    monkeypatch.setenv("SA_SPARSE", "0")
+    rng = np.random.default_rng(100 + T + k)
+    queries = band_queries(rng, 40, T, heads=[0, 1, 2, 7, 350])
+    check(api, corpus, queries, k)
+
+
+@pytest.mark.parametrize("warm", ["0", "2"])
+@pytest.mark.parametrize("tile_docs", [1024, 2048, 4096])
+def test_grouped_without_warm_tiles_and_other_tile_sizes(api, corpus, monkeypatch, warm, tile_docs):
+    """SA_GROUP_WARM=0: no tile goes through the per-query kernel first, so every query starts below its base
+    values (bound 0) and takes the general path until the bound stands"""
+    monkeypatch.setenv("SA_SPARSE", "0")
+    monkeypatch.setenv("SA_GROUP_WARM", warm)
+    rng = np.random.default_rng(7)
+    queries = band_queries(rng, 24, 4, heads=[0, 3])
+    check(api, corpus, queries, 10, tile_docs=tile_docs, doc_base=50_000)
+
+
+def test_grouped_dense_further_terms_duplicates_unknowns(api, corpus, monkeypatch):
+    """further terms with more postings per tile than the overlay holds (general path), the shared term again
+    among the further terms, repeated further terms, unknown terms, a group of one (SA_GROUP_MIN=1), more
+    queries than one group item takes (split), and a batch where nothing is grouped"""
+    monkeypatch.setenv("SA_SPARSE", "0")
+    monkeypatch.setenv("SA_GROUP_WARM", "1")
+    queries = [[0, 1, 2, 3], [0, 0, 0, 5], [0, 2, 1, 1], [0, 390, 390, 9], [0, 4000, 17, 4001], [0, 4000, 4000, 4000],
+               [5, 1, 0, 2], [5, 300, 301, 302], [4000, 0, 1, 2], [9, 8, 7, 6]]
+    queries += [[0, 10 + i, 200 + i, 399 - i] for i in range(70)]
+    check(api, corpus, queries, 7)
+    monkeypatch.setenv("SA_GROUP_MIN", "1")
+    check(api, corpus, queries[:12], 7)
+    check(api, corpus, [[i, i + 1, i + 2, i + 3] for i in range(0, 40, 4)], 5)
+
+
+def test_grouped_and_per_query_kernels_agree(api, corpus, monkeypatch):
+    """same results with explicit (non-reference) idf weights, incl. two idf values for one first term (two
+    groups) -- compared with the per-query kernel, SA_GROUP=0"""
+    monkeypatch.setenv("SA_SPARSE", "0")
+    rng = np.random.default_rng(11)
+    queries = band_queries(rng, 30, 4, heads=[0, 1])
+    idf = rng.uniform(0.1, 9.0, size=queries.shape).astype(np.float32)
+    idf[:, 0] = np.where(rng.random(len(queries)) < 0.5, np.float32(0.25), np.float32(1.5))
+    idf[3] = 0.0                                                     # a query that scores nothing
+    got = check(api, corpus, queries, 20, idf=idf)
+    monkeypatch.setenv("SA_GROUP", "0")
+    want = check(api, corpus, queries, 20, idf=idf)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+def test_negative_idf_disables_grouping(api, corpus, monkeypatch):
+    """the overlay marks touched docs with the sign bit: batches with a negative weight use the per-query kernel"""
+    monkeypatch.setenv("SA_SPARSE", "0")
+    queries = np.asarray([[0, 5, 9, 100]] * 3 + [[0, 6, 8, 101]])
+    idf = np.full(queries.shape, 2.0, dtype=np.float32)
+    idf[1, 2] = -1.0
+    got = check(api, corpus, queries, 5, idf=idf)
+    monkeypatch.setenv("SA_GROUP", "0")
+    want = check(api, corpus, queries, 5, idf=idf)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
