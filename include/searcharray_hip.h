@@ -253,15 +253,22 @@ int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const float* idf, int
  * caller loop `for phrase in phrases: top_k(arr.score(phrase))` around reference
  * SearchArray.score (postings.py:652-680) -> PosnBitArray.phrase_freqs (middle_out.py:418-446) ->
  * compute_phrase_freqs (middle_out.py:73-168) -> bm25 (similarity.py:24-38).  terms is
- * [B][max_terms] row-major, phrase i uses its first n_terms[i] entries (2 <= n_terms[i] <= 18,
- * pairwise distinct; fewer than two terms is SA_ERR_ARG like the reference's ValueError
- * (middle_out.py:425-426), repeated terms / longer phrases are SA_ERR_UNSUPPORTED here -- use
- * sa_index_bm25_phrase_dense).  idf[B] is the per-phrase idf the host sums over the phrase's
+ * [B][max_terms] row-major, phrase i uses its first n_terms[i] entries (2 <= n_terms[i] <= 128; fewer
+ * than two terms is SA_ERR_ARG like the reference's ValueError, middle_out.py:425-426).  Exact phrases of
+ * up to 18 pairwise-distinct terms are scored tile by tile; the others take the dense route described at
+ * sa_phrase_batch_create_ex.  idf[B] is the per-phrase idf the host sums over the phrase's
  * terms (similarity.py:19-21).  An unknown term (id >= n_terms) makes the phrase match nothing.
  * The result is a sa_batch_t: run / run_local / merge_gathered / fetch / profile / destroy below
  * apply unchanged (profile: alg_bytes = postings_bytes = sum over phrases of 8 * words of its terms). */
 int sa_phrase_batch_create(sa_index_t* ix, const uint32_t* terms, const int32_t* n_terms, const float* idf,
                            int n_phrases, int max_terms, int k, float k1, float b, sa_batch_t** out);
+/* The same with a slop per phrase (slop == NULL: all exact): slop[i] > 0 scores phrase i with the reference's span
+ * search (phrase/spans.py:71-187, roaringish/spans.pyx:189-319; at most 16 terms), as SearchArray.score(phrase,
+ * slop=...) does.  Any phrase score() accepts is accepted: phrases with repeated terms, with more than 18 terms
+ * (up to 128) or with slop > 0 are counted over the whole shard by the single-phrase kernels and ranked on the
+ * device; only the B x k results leave it. */
+int sa_phrase_batch_create_ex(sa_index_t* ix, const uint32_t* terms, const int32_t* n_terms, const int32_t* slop,
+                              const float* idf, int n_phrases, int max_terms, int k, float k1, float b, sa_batch_t** out);
 /* one pass of the hot path over the batch; asynchronous on the index stream unless sync != 0.
  * If the index has a communicator (Part 3) the per-shard top-k are exchanged and merged. */
 int sa_batch_run(sa_batch_t* batch, int sync);

@@ -84,6 +84,12 @@ struct sa_batch {
     u32* d_wbounds = nullptr;       // [B][T][pn_tiles+1] first word of the term in each tile (relative)
     u64* d_wbase = nullptr;         // [B][T] word base of each phrase term
     u32* d_wlen = nullptr;          // [B][T] words of each phrase term
+    // phrases the tile kernel does not take (repeated terms, more than 18 terms, slop > 0): scored one after the
+    // other through the dense single-phrase path, ranked on the device
+    std::vector<u32> dense_rows;    // batch rows on the dense route
+    std::vector<u32> h_pterms;      // [B][T] host copy of the terms
+    std::vector<int> h_pn, h_pslop; // [B] terms / slop per phrase
+    std::vector<float> h_pidf;      // [B]
 };
 
 

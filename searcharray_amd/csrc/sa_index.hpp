@@ -139,4 +139,7 @@ int sa_posn_filter_bounds(int64_t min_posn, int64_t max_posn, PosnFilter* f);
 int sa_posn_filter_terms(sa_index* ix, const PosnFilter& f, int T, const u64** ptrs, u32* lens, u64** bufs,
                          u32* d_counts, u32* d_chunks);
 // slop > 0 phrase counts (sa_spans.hip): dense float[n_docs] inside the index scratch
+// dense phrase counts (any number of terms up to 128, repeated terms, slop) and counts -> BM25 (sa_phrase.hip)
+int sa_phrase_dense_counts_device(sa_index* ix, const u32* terms, int n_terms, int slop, float** d_out);
+void sa_launch_bm25_from_tf(sa_index* ix, float* d_tf, float idf, float k1, float b);
 int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const PosnFilter& filt, float** d_out);

@@ -31,7 +31,8 @@
 #include <stdlib.h>
 
 #define SA_NONE 0xFFFFFFFFu
-#define SA_MAX_PHRASE 32
+#define SA_MAX_PHRASE 128     // terms per phrase (general chain); the fused kernel takes sub-phrases of up to SA_MAX_FUSED
+#define SA_MAX_FUSED 18
 
 enum { CONT_LHS = 0, CONT_RHS = 1 };
 
@@ -172,9 +173,9 @@ sa_k_min2(float* __restrict__ a, const float* __restrict__ b, u64 n) {
 // fused kernel (pairwise-distinct terms)
 // ---------------------------------------------------------------------------------------
 struct FusedPhraseParams {
-    const u64* ptr[SA_MAX_PHRASE];   // each term's (possibly position-filtered) words
-    u32 len[SA_MAX_PHRASE];
-    const u32* dd[SA_MAX_PHRASE];    // doc directory row of the term (whole, unfiltered list), or null
+    const u64* ptr[SA_MAX_FUSED];    // each term's (possibly position-filtered) words
+    u32 len[SA_MAX_FUSED];
+    const u32* dd[SA_MAX_FUSED];     // doc directory row of the term (whole, unfiltered list), or null
     int T, anchor;
     u32* step;                   // dense per-doc match counts (u32, atomically accumulated)
 };
@@ -386,7 +387,10 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
             dd_rows[t] = sl != SA_DD_NONE ? ix->d_docdir + (size_t)sl * ix->n_docs : nullptr;
         }
     }
-    const bool use_fused = (mode == 2) || (mode == 0 && distinct);
+    // (a sub-phrase the fused kernel would have to take whole must fit its 18-position window: longer ones go
+    //  through the general chain, which has no such limit)
+    const int longest_part = (l2r_only || r2l_only) ? T : (shortest > T - shortest ? shortest : T - shortest);
+    const bool use_fused = (mode == 2) || (mode == 0 && distinct && longest_part <= SA_MAX_FUSED);
     if (use_fused) {
         if (!distinct) { sa_set_error("fused phrase kernel needs pairwise-distinct terms"); return SA_ERR_ARG; }
         // sub-phrases the reference evaluates: the whole phrase (l2r / r2l plans) or the two halves
@@ -405,7 +409,7 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
                 if (lens[t] < lens[a + anchor]) anchor = t - a;
             }
             fp.anchor = anchor;
-            if (fp.T > 18) { sa_set_error("phrases longer than 18 terms are not supported"); return SA_ERR_UNSUPPORTED; }
+            if (fp.T > SA_MAX_FUSED) { sa_set_error("fused phrase kernel: sub-phrase longer than 18 terms"); return SA_ERR_UNSUPPORTED; }
             if (fp.len[anchor] > 0)
                 hipLaunchKernelGGL(sa_k_phrase_fused, dim3(sa_grid_for(fp.len[anchor])), dim3(256), 0, st, fp);
             hipLaunchKernelGGL(sa_k_min_step, dim3(sa_grid_for(N)), dim3(256), 0, st, running, step, N, pi == 0 ? 1 : 0);
@@ -507,12 +511,24 @@ static int sa_phrase_or_span(sa_index* ix, const u32* terms, int n_terms, int sl
     return sa_span_counts_device(ix, terms, n_terms, slop, filt, d_out);
 }
 
+// for the phrase batches (sa_phrase_batch.hip): dense counts of any phrase / slop in the index scratch, and
+// counts -> BM25 in place; the caller holds the index lock and enqueues on ix->stream
+int sa_phrase_dense_counts_device(sa_index* ix, const u32* terms, int n_terms, int slop, float** d_out) {
+    if (n_terms > SA_MAX_PHRASE) { sa_set_error("phrase too long (max 128 terms)"); return SA_ERR_UNSUPPORTED; }
+    PosnFilter filt;
+    return sa_phrase_or_span(ix, terms, n_terms, slop, filt, d_out);
+}
+void sa_launch_bm25_from_tf(sa_index* ix, float* d_tf, float idf, float k1, float b) {
+    if (ix->n_docs) hipLaunchKernelGGL(sa_k_bm25_from_tf, dim3(sa_grid_for(ix->n_docs)), dim3(256), 0, ix->stream, d_tf,
+                                       ix->d_doc_lens, ix->avg_doc_len, idf, k1, b, ix->n_docs);
+}
+
 extern "C" int sa_index_phrase_freqs_dense_posn(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop,
                                                 int64_t min_posn, int64_t max_posn, float* out) {
     SA_ARG(ix && out && terms, "null argument");
     // reference middle_out.py:425-426
     if (n_terms < 2) { sa_set_error("Must have at least two terms"); return SA_ERR_ARG; }
-    SA_ARG(n_terms <= SA_MAX_PHRASE, "phrase too long (max 32 terms)");
+    SA_ARG(n_terms <= SA_MAX_PHRASE, "phrase too long (max 128 terms)");
     SA_ARG(slop >= 0, "slop < 0");
     PosnFilter filt;
     SA_TRY(sa_posn_filter_bounds(min_posn, max_posn, &filt));
@@ -539,7 +555,7 @@ extern "C" int sa_index_bm25_phrase_dense_posn(sa_index_t* ix, const uint32_t* t
                                                float* out) {
     SA_ARG(ix && out && terms, "null argument");
     if (n_terms < 2) { sa_set_error("Must have at least two terms"); return SA_ERR_ARG; }
-    SA_ARG(n_terms <= SA_MAX_PHRASE, "phrase too long (max 32 terms)");
+    SA_ARG(n_terms <= SA_MAX_PHRASE, "phrase too long (max 128 terms)");
     SA_ARG(slop >= 0, "slop < 0");
     PosnFilter filt;
     SA_TRY(sa_posn_filter_bounds(min_posn, max_posn, &filt));

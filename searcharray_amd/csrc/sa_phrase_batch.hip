@@ -175,6 +175,27 @@ __global__ void __launch_bounds__(THREADS) sa_k_phrase_tiles(const PhraseTilePar
                                        p.cand_cap, p.cand_cnt);
 }
 
+// Ranking of a dense score vector (one phrase of the dense route): a workgroup loads a tile of scores and runs the
+// same pruned selection as the phrase tiles
+template <int TILE, int THREADS>
+__global__ void __launch_bounds__(THREADS)
+sa_k_dense_topk_tiles(const float* __restrict__ scores, u64 n_docs, u64 doc_base, u32 q, u32 k, u32* __restrict__ slots,
+                      u64* __restrict__ cand, u32 cand_cap, u32* __restrict__ cand_cnt) {
+    constexpr int E = TILE / THREADS;
+    __shared__ float acc[TILE];
+    const u32 tid = threadIdx.x, tile = blockIdx.x;
+    const u64 tile_base = (u64)tile * TILE;
+    u32 slot_val = 0xFFFFFFFFu;
+    if ((tid & (SA_WAVE - 1)) < 32u)
+        slot_val = __hip_atomic_load(&slots[q * 32u + (tid & 31u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int j = 0; j < E; j++) {                    // (a thread loads exactly the elements it owns in the selection)
+        const u64 d = tile_base + (u64)(j * THREADS) + tid;
+        acc[j * THREADS + tid] = d < n_docs ? scores[d] : 0.f;
+    }
+    sa_tile_topk_pruned<TILE, THREADS>(acc, slot_val, q, tile, doc_base + tile_base, k, slots, cand, cand_cap, cand_cnt);
+}
+
 int sa_launch_phrase_tiles(sa_batch* bt, hipStream_t st) {
     sa_index* ix = bt->ix;
     if (bt->pn_tiles == 0 || bt->B == 0) return SA_OK;
@@ -189,34 +210,57 @@ int sa_launch_phrase_tiles(sa_batch* bt, hipStream_t st) {
     p.use_docdir = ix->n_dd_terms > 0 ? 1 : 0;
     if (const char* v = getenv("SA_PHRASE_DOCDIR")) { if (atoi(v) == 0) p.use_docdir = 0; }
     const u64 n_items = (u64)bt->B * bt->pn_tiles;
-    if (bt->ptile == 2048)
-        hipLaunchKernelGGL((sa_k_phrase_tiles<2048, SA_PTHREADS>), dim3((u32)n_items), dim3(SA_PTHREADS), 0, st, p);
-    else
-        hipLaunchKernelGGL((sa_k_phrase_tiles<4096, SA_PTHREADS>), dim3((u32)n_items), dim3(SA_PTHREADS), 0, st, p);
+    if (bt->dense_rows.size() < bt->B) {             // (rows on the dense route have plan[0] == 0: their items leave at once)
+        if (bt->ptile == 2048)
+            hipLaunchKernelGGL((sa_k_phrase_tiles<2048, SA_PTHREADS>), dim3((u32)n_items), dim3(SA_PTHREADS), 0, st, p);
+        else
+            hipLaunchKernelGGL((sa_k_phrase_tiles<4096, SA_PTHREADS>), dim3((u32)n_items), dim3(SA_PTHREADS), 0, st, p);
+    }
+    // the dense route: counts of the whole shard by the single-phrase kernels (general bigram chain with the
+    // same-term rule / span machine for slop > 0), BM25 in place, then the ranking kernel above
+    for (u32 row : bt->dense_rows) {
+        float* d_scores = nullptr;
+        SA_TRY(sa_phrase_dense_counts_device(ix, &bt->h_pterms[(size_t)row * bt->T], bt->h_pn[row], bt->h_pslop[row], &d_scores));
+        sa_launch_bm25_from_tf(ix, d_scores, bt->h_pidf[row], bt->k1, bt->b);
+        if (bt->ptile == 2048)
+            hipLaunchKernelGGL((sa_k_dense_topk_tiles<2048, SA_PTHREADS>), dim3(bt->pn_tiles), dim3(SA_PTHREADS), 0, st, (const float*)d_scores,
+                               ix->n_docs, ix->doc_base, row, bt->k, bt->d_slots, bt->d_cand, bt->cand_cap, bt->d_cand_cnt);
+        else
+            hipLaunchKernelGGL((sa_k_dense_topk_tiles<4096, SA_PTHREADS>), dim3(bt->pn_tiles), dim3(SA_PTHREADS), 0, st, (const float*)d_scores,
+                               ix->n_docs, ix->doc_base, row, bt->k, bt->d_slots, bt->d_cand, bt->cand_cap, bt->d_cand_cnt);
+    }
     return SA_OK;
 }
 
 extern "C" int sa_phrase_batch_create(sa_index_t* ix, const uint32_t* terms, const int32_t* n_terms, const float* idf,
                                       int n_phrases, int max_terms, int k, float k1, float b, sa_batch_t** out) {
+    return sa_phrase_batch_create_ex(ix, terms, n_terms, nullptr, idf, n_phrases, max_terms, k, k1, b, out);
+}
+
+extern "C" int sa_phrase_batch_create_ex(sa_index_t* ix, const uint32_t* terms, const int32_t* n_terms, const int32_t* slop,
+                                         const float* idf, int n_phrases, int max_terms, int k, float k1, float b,
+                                         sa_batch_t** out) {
     SA_ARG(ix && out && terms && n_terms && idf, "null argument");
     SA_ARG(n_phrases > 0 && max_terms >= 2, "empty batch");
     SA_ARG(k > 0 && k <= SA_KMAX, "k must be in [1, 1024]");
     SA_ARG(ix->doc_base + ix->n_docs <= 0xFFFFFFFFull, "global doc ids must fit 32 bits for top-k");
     const u32 B = (u32)n_phrases, T = (u32)max_terms;
+    std::vector<u32> dense_rows;
     for (u32 i = 0; i < B; i++) {
         // reference middle_out.py:425-426
         if (n_terms[i] < 2) { sa_set_error("Must have at least two terms"); return SA_ERR_ARG; }
         SA_ARG(n_terms[i] <= max_terms, "n_terms[i] > max_terms");
-        if (n_terms[i] > SA_PHRASE_BATCH_MAXT) {
-            sa_set_error("phrase batches support at most %d terms per phrase", SA_PHRASE_BATCH_MAXT);
-            return SA_ERR_UNSUPPORTED;
-        }
-        for (int t = 0; t < n_terms[i]; t++)
+        SA_ARG(!slop || slop[i] >= 0, "slop < 0");
+        if (n_terms[i] > 128) { sa_set_error("phrase too long (max 128 terms)"); return SA_ERR_UNSUPPORTED; }
+        if (slop && slop[i] > 0 && n_terms[i] > 16) { sa_set_error("slop phrases support at most 16 terms"); return SA_ERR_UNSUPPORTED; }
+        // the tile kernel takes exact phrases of up to 18 pairwise-distinct terms; everything else the reference's
+        // score() accepts -- repeated terms (same-term rule, bigram_freqs.py:48-101), longer phrases, slop > 0
+        // (spans.py:71-187) -- is scored through the dense single-phrase path and ranked on the device
+        bool dense = n_terms[i] > SA_PHRASE_BATCH_MAXT || (slop && slop[i] > 0);
+        for (int t = 0; t < n_terms[i] && !dense; t++)
             for (int u = 0; u < t; u++)
-                if (terms[(size_t)i * T + t] == terms[(size_t)i * T + u] && terms[(size_t)i * T + t] < ix->n_terms) {
-                    sa_set_error("phrase batches need pairwise-distinct terms per phrase (use sa_index_bm25_phrase_dense)");
-                    return SA_ERR_UNSUPPORTED;
-                }
+                if (terms[(size_t)i * T + t] == terms[(size_t)i * T + u] && terms[(size_t)i * T + t] < ix->n_terms) dense = true;
+        if (dense) dense_rows.push_back(i);
     }
     std::lock_guard<std::mutex> g(ix->mu);
     SA_HIP(hipSetDevice(ix->device));
@@ -233,8 +277,23 @@ extern "C" int sa_phrase_batch_create(sa_index_t* ix, const uint32_t* terms, con
     std::vector<u32> plan((size_t)B * 4, 0);
     std::vector<u32> h_terms((size_t)B * T, SA_NO_TERM);
     bt->alg_bytes = 0; bt->postings_bytes = 0;
+    bt->dense_rows = dense_rows;
+    bt->h_pterms.assign(terms, terms + (size_t)B * T);
+    bt->h_pn.assign(n_terms, n_terms + B);
+    bt->h_pslop.assign(B, 0);
+    if (slop) bt->h_pslop.assign(slop, slop + B);
+    bt->h_pidf.assign(idf, idf + B);
+    std::vector<char> is_dense(B, 0);
+    for (u32 r : dense_rows) is_dense[r] = 1;
     for (u32 i = 0; i < B; i++) {
         const int Tq = n_terms[i];
+        if (is_dense[i]) {                             // plan[0] stays 0: the tile kernel skips the row
+            for (int t = 0; t < Tq; t++) {
+                const u32 term = terms[(size_t)i * T + t];
+                if (term < ix->n_terms) bt->postings_bytes += 8 * (ix->h_term_off[term + 1] - ix->h_term_off[term]);
+            }
+            continue;
+        }
         u64 lens[SA_PHRASE_BATCH_MAXT];
         bool known = true;
         for (int t = 0; t < Tq; t++) {

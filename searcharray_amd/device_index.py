@@ -374,8 +374,8 @@ class DeviceIndex:
         return QueryBatch(self, queries, k=k, k1=k1, b=b, idf=idf)
 
     def phrase_batch(self, phrases: Sequence[Sequence[int]], k: int = 10, k1: float = 1.2, b: float = 0.75,
-                     idf: Optional[np.ndarray] = None) -> "PhraseBatch":
-        return PhraseBatch(self, phrases, k=k, k1=k1, b=b, idf=idf)
+                     idf: Optional[np.ndarray] = None, slop=0) -> "PhraseBatch":
+        return PhraseBatch(self, phrases, k=k, k1=k1, b=b, idf=idf, slop=slop)
 
     # -- multi-GPU
     def comm_init(self, rank: int, nranks: int, unique_id: bytes):
@@ -480,14 +480,15 @@ class QueryBatch:
 
 
 class PhraseBatch(QueryBatch):
-    """B exact phrases (lists of term ids, 2..18 distinct terms each) resident on the device;
-    ``run()`` scores every phrase with BM25 over its match counts and keeps the top k docs.
+    """B phrases (lists of term ids; any phrase ``score()`` takes: repeated terms, up to 128 terms, ``slop`` --
+    one value or one per phrase) resident on the device; ``run()`` scores every phrase with BM25 over its match
+    counts and keeps the top k docs.
 
     Same result contract as :class:`QueryBatch`; the dense single-phrase drop-in is
     :meth:`DeviceIndex.bm25_phrase_dense` (reference ``SearchArray.score([...])``)."""
 
     def __init__(self, index: DeviceIndex, phrases: Sequence[Sequence[int]], k: int = 10, k1: float = 1.2,
-                 b: float = 0.75, idf: Optional[np.ndarray] = None):
+                 b: float = 0.75, idf: Optional[np.ndarray] = None, slop=0):
         self.index = index
         self.api = index.api
         self.B = len(phrases)
@@ -507,8 +508,12 @@ class PhraseBatch(QueryBatch):
                                                       for t in ph])) for ph in phrases], dtype=np.float32)
         self._n_terms = n_terms
         self._h = ctypes.c_void_p()
-        self.api.call("sa_phrase_batch_create", index._h, p_u32(as_u32(terms)),
-                      n_terms.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), p_f32(as_f32(idf)), self.B, self.T,
+        slops = np.ascontiguousarray(np.broadcast_to(np.asarray(slop, dtype=np.int32), (self.B,)))   # one slop, or one per phrase
+        if (slops < 0).any():
+            raise ValueError("slop must be >= 0")
+        self.api.call("sa_phrase_batch_create_ex", index._h, p_u32(as_u32(terms)),
+                      n_terms.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                      slops.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), p_f32(as_f32(idf)), self.B, self.T,
                       self.k, np.float32(k1), np.float32(b), ctypes.byref(self._h))
         index._track(self)
 

@@ -684,11 +684,12 @@ class SearchArray(ExtensionArray):
         (searcharray_amd/sharded.py) -- same results as on one device."""
         return self._topk(queries, k, similarity, phrases=False, devices=devices)
 
-    def search_phrases(self, phrases, k: int = 10, similarity=default_bm25, devices=None) -> Tuple[np.ndarray, np.ndarray]:
-        """Like :meth:`search`, each query an exact phrase: the top-``k`` of ``arr.score(phrase)``."""
-        return self._topk(phrases, k, similarity, phrases=True, devices=devices)
+    def search_phrases(self, phrases, k: int = 10, similarity=default_bm25, devices=None, slop=0) -> Tuple[np.ndarray, np.ndarray]:
+        """Like :meth:`search`, each query a phrase: the top-``k`` of ``arr.score(phrase, slop=slop)`` (``slop``: one
+        value or one per phrase).  Any phrase ``score`` takes is fine -- repeated tokens, long phrases, slop."""
+        return self._topk(phrases, k, similarity, phrases=True, devices=devices, slop=slop)
 
-    def _topk(self, queries, k, similarity, phrases, devices=None):
+    def _topk(self, queries, k, similarity, phrases, devices=None, slop=0):
         if getattr(similarity, "kind", None) != "bm25":
             raise ValueError("batched search needs a stock BM25 similarity (bm25_similarity(k1, b))")
         if self._rows is not None:
@@ -701,7 +702,7 @@ class SearchArray(ExtensionArray):
         unknown = dev.n_terms                                   # any id >= n_terms matches nothing
         ids = [[t if (t := self._term_id(tok)) >= 0 else unknown for tok in q] for q in toks]
         if phrases:
-            batch = dev.phrase_batch(ids, k=k, k1=similarity.k1, b=similarity.b)
+            batch = dev.phrase_batch(ids, k=k, k1=similarity.k1, b=similarity.b, slop=slop)
         else:
             T = max(1, max(len(q) for q in ids))
             mat = np.full((B, T), unknown, dtype=np.int64)

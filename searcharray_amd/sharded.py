@@ -119,10 +119,10 @@ class ShardedIndex:
         idf = self.idfs(q.reshape(-1)).reshape(q.shape)
         return ShardedBatch(self, lambda g, s: QueryBatch(s, q, k=k, k1=k1, b=b, idf=idf))
 
-    def phrase_batch(self, phrases, k: int = 10, k1: float = 1.2, b: float = 0.75) -> "ShardedBatch":
+    def phrase_batch(self, phrases, k: int = 10, k1: float = 1.2, b: float = 0.75, slop=0) -> "ShardedBatch":
         idf = np.asarray([compute_idf(self.corpus_size, np.asarray([self.docfreq(int(t)) if 0 <= int(t) < self.n_terms else 0
                                                                     for t in ph])) for ph in phrases], dtype=np.float32)
-        return ShardedBatch(self, lambda g, s: PhraseBatch(s, phrases, k=k, k1=k1, b=b, idf=idf))
+        return ShardedBatch(self, lambda g, s: PhraseBatch(s, phrases, k=k, k1=k1, b=b, idf=idf, slop=slop))
 
     def close(self):
         if self._comm:

@@ -1,0 +1,110 @@
+"""Parity at the scale of BASELINE.json's configurations (GPU only; the CPU suite covers the same paths on small
+corpora).  One seeded zipf-1M corpus (V = 100k, Poisson(32) lengths, seed 1234), then
+
+  config 2  256 x 4-term disjunctive BM25, top-10 and top-1000: grouped exhaustive kernel, per-query exhaustive
+            kernel and dynamic pruning agree on every query; 16 queries equal the oracle's dense scores + top-k
+            (reference shapes: test/test_msmarco.py:345-395, utils/sort.py:24)
+  config 3  the 64 sampled consecutive trigrams + `t0 t1 t2` + the same-term set: match counts np.array_equal
+            the oracle's (reference shapes: test/test_msmarco.py:227-295, test_phrase_matches.py:73-117)
+  config 5  32 two-term slop-2 queries on mid-frequency terms (ranks 50-5000): counts exact, BM25 within 1e-5
+            relative of the oracle (reference shapes: test/test_msmarco.py:247-254)
+The oracle (oracle/refimpl.py + the C restatements) is pinned to the reference's outputs by tests/golden."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import refimpl as O
+from searcharray_amd import synth
+from searcharray_amd.device_index import DeviceIndex
+
+pytestmark = pytest.mark.gpu
+
+D, V = 1_000_000, 100_000
+
+
+@pytest.fixture(scope="module")
+def zipf1m():
+    from searcharray_amd import _lib
+    api = _lib.api()
+    lens, terms = synth.zipf_batch_tokens(0, D, V, fast=True)
+    words, counts = synth.encode_batch(lens, terms, V)
+    words, term_off = synth.concat_term_major([(words, counts)], V)
+    doc_lens = lens.astype(np.float32)
+    dev = DeviceIndex(words, term_off, doc_lens, api=api)
+    orc = O.OracleIndex(words, np.arange(V), term_off, doc_lens, D)
+    yield dev, orc, lens, terms
+    dev.close()
+
+
+def run_batch(dev, queries, k, env):
+    old = {key: os.environ.get(key) for key in ("SA_SPARSE", "SA_GROUP")}
+    os.environ.update(env)
+    try:
+        bt = dev.batch(queries, k=k)
+        bt.run()
+        res = bt.fetch()
+        bt.close()
+        return res
+    finally:
+        for key, v in old.items():
+            if v is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = v
+
+
+@pytest.mark.parametrize("k", [10, 1000])
+def test_config2_bm25_topk_at_1m_docs(zipf1m, k):
+    dev, orc, _, _ = zipf1m
+    queries = synth.bm25_queries(256, vocab=V)
+    grouped = run_batch(dev, queries, k, {"SA_SPARSE": "0", "SA_GROUP": "1"})
+    per_query = run_batch(dev, queries, k, {"SA_SPARSE": "0", "SA_GROUP": "0"})
+    pruned = run_batch(dev, queries, k, {"SA_SPARSE": "1"})
+    for name, got in (("per-query", per_query), ("pruned", pruned)):
+        assert np.array_equal(grouped[0], got[0]), f"scores: grouped vs {name}"
+        assert np.array_equal(grouped[1], got[1]), f"docs: grouped vs {name}"
+    for qi in list(range(8)) + list(range(100, 108)):
+        ws, wd = O.topk(orc.score_terms_sum([int(t) for t in queries[qi]]), k)
+        n = int((ws > 0).sum())
+        assert np.array_equal(grouped[0][qi, :n], ws[:n]), f"q{qi} scores vs oracle"
+        assert np.array_equal(grouped[1][qi, :n], wd[:n]), f"q{qi} docs vs oracle"
+
+
+def test_config3_trigram_counts_at_1m_docs(zipf1m):
+    dev, orc, lens, terms = zipf1m
+    phrases = [[0, 1, 2]] + [[int(t) for t in p] for p in synth.phrase_queries_from_tokens(lens, terms, 64, 3, seed=7)]
+    phrases += [[0, 0], [0, 0, 1], [1, 1, 1]]                       # the same-term rule (bigram_freqs.py:48-101)
+    for ph in phrases:
+        got = dev.phrase_freqs_dense(ph)
+        assert np.array_equal(got, orc.phrase_freqs(ph)), f"phrase {ph}"
+    assert dev.phrase_freqs_dense(phrases[1]).sum() >= 1            # sampled from a real doc: at least one match
+    # ... and ranked on the device: the phrase batch's top-10 of the 64 sampled trigrams
+    pb = dev.phrase_batch(phrases[:65], k=10)
+    pb.run()
+    ps, pd_ = pb.fetch()
+    pb.close()
+    for i in (0, 1, 17, 40, 64):
+        ws, wd = O.topk(orc.score(phrases[i]), 10)
+        n = int((ws > 0).sum())
+        assert np.array_equal(ps[i, :n], ws[:n]) and np.array_equal(pd_[i, :n], wd[:n]), f"phrase batch {phrases[i]}"
+
+
+def test_config5_slop2_at_1m_docs(zipf1m):
+    dev, orc, _, _ = zipf1m
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for _ in range(32):
+        a, b = (int(x) for x in rng.integers(49, 5000, 2))
+        if a == b:
+            b += 1
+        got = dev.phrase_freqs_dense([a, b], slop=2)
+        want = orc.phrase_freqs([a, b], slop=2)
+        assert np.array_equal(got, want), f"slop-2 counts [{a}, {b}]"
+        s_dev = dev.bm25_phrase_dense([a, b], slop=2)
+        s_cpu = orc.score([a, b], slop=2)
+        nz = s_cpu != 0
+        assert np.array_equal(s_dev != 0, nz)
+        if nz.any():
+            worst = max(worst, float(np.max(np.abs(s_dev[nz] - s_cpu[nz]) / np.abs(s_cpu[nz]))))
+    assert worst <= 1e-5, worst

@@ -50,6 +50,31 @@ def test_reference_phrase_scenarios(api, phrase_mode, docs, phrase, expected):
     assert np.array_equal(got, np.asarray(expected, np.float32))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["general", "auto"])
+def test_all_reference_phrase_scenarios_and_offsets_on_the_device(mode, monkeypatch):
+    """The reference runs every scenario of test/test_phrase_matches.py:17-194 and all 100 word-boundary offsets
+    (:249-379); so does the device (the host-emulated runs above take every other scenario and six offsets to keep
+    the CPU suite short)."""
+    from searcharray_amd import _lib
+    api = _lib.api()
+    if mode == "general":
+        monkeypatch.setenv("SA_PHRASE_MODE", "general")
+    else:
+        monkeypatch.delenv("SA_PHRASE_MODE", raising=False)
+    for docs, phrase, expected in PHRASE_SCENARIOS:
+        vocab, dev = _device_from_strings(docs, api)
+        got = dev.phrase_freqs_dense([vocab[t] for t in phrase.split()])
+        assert np.array_equal(got, np.asarray(expected, np.float32)), (docs, phrase)
+        dev.close()
+    for phrase in ["foo bar baz", "foo foo foo", "foo bar bar baz buz foo bar", "foo foo"]:
+        for offset in range(100):
+            vocab, dev = _device_from_strings([" ".join(["dummy"] * offset) + " " + phrase, "not match"], api)
+            got = dev.phrase_freqs_dense([vocab[t] for t in phrase.split()])
+            assert np.array_equal(got, [1, 0]), (phrase, offset)
+            dev.close()
+
+
 @pytest.mark.parametrize("phrase", ["foo bar baz", "foo foo foo", "foo bar bar baz buz foo bar", "foo foo"])
 @pytest.mark.parametrize("offset", [0, 16, 17, 18, 35, 53])
 def test_offsets_cross_word_boundary(api, phrase_mode, phrase, offset):
@@ -281,8 +306,8 @@ def test_phrase_batch_errors(api):
     vocab, dev = _device_from_strings(["foo bar baz", "bar baz foo"], api)
     with pytest.raises(Exception, match="at least two terms"):
         dev.phrase_batch([[0]], k=3)
-    with pytest.raises(Exception, match="distinct"):
-        dev.phrase_batch([[0, 1, 0]], k=3)
+    with pytest.raises(ValueError, match="slop"):
+        dev.phrase_batch([[0, 1]], k=3, slop=-1)
     bt = dev.phrase_batch([[vocab["foo"], vocab["bar"]], [vocab["bar"], vocab["baz"]]], k=3)
     bt.run()
     scores, docs = bt.fetch()
@@ -323,3 +348,59 @@ def test_span_search_mirror_matches_oracle(api):
     assert not got
     with pytest.raises(NotImplementedError):
         ops.span_search(np.empty(0, np.uint64), np.zeros(3, np.uint64), got, 1, key_bits=32, api=api)
+
+
+def test_phrase_batch_takes_every_phrase_score_takes(api):
+    """Phrases the tile kernel does not take -- repeated terms (the reference's same-term rule,
+    bigram_freqs.py:48-101), more than 18 terms, slop > 0 (span search, spans.py:71-187) -- mixed with ordinary
+    ones in ONE batch: counted by the single-phrase kernels, ranked on the device, top-k equal to the oracle's
+    score() + deterministic top-k.  Plus the reference's own outputs for its phrase and slop goldens."""
+    g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_small")
+    words, wt = rz.encode_sorted(t, d, p)
+    orc = O.OracleIndex.from_triples(t, d, p, num_docs, doc_lens=lens)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api, doc_base=7000)
+    phrases, slops = [], []
+    for i in range(int(g["n_phrases"])):                           # incl. the same-term phrases of the fixture
+        phrases.append([int(x) for x in g[f"phr_{i}_terms"]]); slops.append(0)
+    for i in range(int(g["n_slop"])):
+        phrases.append([int(x) for x in g[f"slop_{i}_terms"]]); slops.append(int(g[f"slop_{i}_slop"]))
+    phrases += [[0, 0], [0, 0, 1], [1, 0, 1, 0], [0, 1] * 10, list(range(19)), [0, vocab + 5, 0], [2, 1]]
+    slops += [0, 0, 0, 0, 0, 0, 3]
+    k = 6
+    bt = dev.phrase_batch(phrases, k=k, slop=slops)
+    for _ in range(2):
+        bt.run()
+        scores, docs = bt.fetch()
+    bt.close()
+    for i, (ph, sl) in enumerate(zip(phrases, slops)):
+        known = all(0 <= x < vocab for x in ph)
+        want = orc.score(list(ph), slop=sl) if known else np.zeros(num_docs, np.float32)
+        ws, wd = O.topk(want, k)
+        n = int((ws > 0).sum())
+        assert np.array_equal(scores[i, :n], ws[:n]), f"phrase {ph} slop {sl}: scores"
+        assert np.array_equal(docs[i, :n], wd[:n] + 7000), f"phrase {ph} slop {sl}: docs"
+        assert (docs[i, n:] == NO_DOC).all()
+    # the reference's own scores (golden fixture): exact phrases ...
+    for i in range(int(g["n_phrases"])):
+        ws, wd = O.topk(dense_from_sparse(g[f"phr_{i}_sidx"], g[f"phr_{i}_sval"], num_docs), k)
+        n = int((ws > 0).sum())
+        assert np.array_equal(scores[i, :n], ws[:n]) and np.array_equal(docs[i, :n], wd[:n] + 7000), f"golden phrase {i}"
+    dev.close()
+
+
+def test_search_phrases_with_repeated_tokens_and_slop(default_api):
+    """SearchArray.search_phrases == top-k of SearchArray.score for phrases with repeated tokens and for slop"""
+    from searcharray_amd import SearchArray
+    docs = ["foo foo foo foo bar", "foo bar foo bar", "bar foo foo", "baz foo x y bar", "nothing here"] * 7
+    arr = SearchArray.index(docs)
+    phrases = [["foo", "foo"], ["foo", "bar", "foo", "bar"], ["foo", "bar"], ["foo", "missing"]]
+    s, dd = arr.search_phrases(phrases, k=4)
+    for i, ph in enumerate(phrases):
+        ws, wd = O.topk(arr.score(ph), 4)
+        n = int((ws > 0).sum())
+        assert np.array_equal(s[i, :n], ws[:n]) and np.array_equal(dd[i, :n], wd[:n]), ph
+    s, dd = arr.search_phrases([["foo", "bar"], ["baz", "bar"]], k=4, slop=3)
+    for i, ph in enumerate([["foo", "bar"], ["baz", "bar"]]):
+        ws, wd = O.topk(arr.score(ph, slop=3), 4)
+        n = int((ws > 0).sum())
+        assert np.array_equal(s[i, :n], ws[:n]) and np.array_equal(dd[i, :n], wd[:n]), ph

@@ -87,6 +87,6 @@ def test_search_array_search_over_devices(default_api):
     many = arr.search([["bar"], ["foo", "baz"], ["nope"]], k=5, devices=list(range(G)))
     assert np.array_equal(one[0], many[0]) and np.array_equal(one[1], many[1])
     assert np.isclose(one[0][0][0], 0.37066694)                  # reference test_search.py:121-124
-    p1 = arr.search_phrases([["bar", "baz"], ["foo", "bar"]], k=3)
-    p2 = arr.search_phrases([["bar", "baz"], ["foo", "bar"]], k=3, devices=list(range(G)))
+    p1 = arr.search_phrases([["bar", "bar"], ["foo", "bar"]], k=3)
+    p2 = arr.search_phrases([["bar", "bar"], ["foo", "bar"]], k=3, devices=list(range(G)))
     assert np.array_equal(p1[0], p2[0]) and np.array_equal(p1[1], p2[1])
