@@ -288,14 +288,15 @@ PMC_STEPS = 3
 
 def pmc_child(r, legs):
     """legs: list of (name, batch, sparse_env).  Dispatch order written for the parent's parser:
-    calibration stream, then per leg: marker, PMC_STEPS runs."""
+    calibration stream, then per leg: marker, warm-up run, marker, PMC_STEPS counted runs; a last marker."""
     import ctypes
     g = ctypes.c_double(0)
     r.api.call("sa_stream_probe", CALIB_BYTES, 1, 1, ctypes.byref(g))
     for name, batch, sparse in legs:
         os.environ["SA_SPARSE"] = sparse
-        batch.run(sync=True)                                   # warm (impact stream etc. already built)
-        r.api.call("sa_stream_probe", 1 << 20, 0, 1, ctypes.byref(g))
+        r.api.call("sa_stream_probe", 1 << 20, 0, 1, ctypes.byref(g))     # marker: the leg's untimed warm-up run follows
+        batch.run(sync=True)
+        r.api.call("sa_stream_probe", 1 << 20, 0, 1, ctypes.byref(g))     # marker: the leg's PMC_STEPS counted runs follow
         for _ in range(PMC_STEPS):
             batch.run(sync=True)
     r.api.call("sa_stream_probe", 1 << 20, 0, 1, ctypes.byref(g))
@@ -369,9 +370,10 @@ def parse_pmc_csv(path, leg_names):
             in_marker, started = True, True
             continue
         in_marker = False
-        if not started or seg < 0 or seg >= len(leg_names):
+        # segments alternate: warm-up run of leg i (even), counted runs of leg i (odd)
+        if not started or seg < 0 or seg % 2 == 0 or seg // 2 >= len(leg_names):
             continue
-        leg = out.setdefault(leg_names[seg], {"_dur": {}})
+        leg = out.setdefault(leg_names[seg // 2], {"_dur": {}})
         short = name.split("(")[0].replace("void ", "")
         for cname, v in e["c"].items():
             leg.setdefault(short, {}).setdefault(cname, []).append(v)
