@@ -135,10 +135,13 @@ struct PostingHeads {
 // tile directory: row s = term dir_terms[s]; entry j = first posting with doc >= j * tile_docs
 // doc directory row of one term: the first word of every doc the term occurs in
 __global__ void __launch_bounds__(256)
-sa_k_build_docdir(const u64* __restrict__ words, u32 n, u32* __restrict__ row) {
+sa_k_build_docdir(const u64* __restrict__ words, u32 n, u32* __restrict__ row, u32* __restrict__ top_block) {
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const u64 doc = words[i] >> SA_KEY_SHIFT;
         if (i == 0 || (words[i - 1] >> SA_KEY_SHIFT) != doc) row[doc] = i;
+        // a word in the LAST 18-position block (positions >= 18 * (2^18 - 1)): only then can a header be the
+        // "h - 1" / "h + 1" neighbour of a header of ANOTHER doc (sa_spans.hip probes through this directory)
+        if (((words[i] >> SA_LSB_BITS) & SA_LSB_MASK) == SA_LSB_MASK) *top_block = 1u;
     }
 }
 
@@ -455,13 +458,21 @@ int sa_index_derive(sa_index* ix) {
         const size_t dd_bytes = (size_t)ix->n_dd_terms * ix->n_docs * sizeof(u32);
         SA_HIP(hipMalloc(&ix->d_docdir, dd_bytes ? dd_bytes : 4));
         if (dd_bytes) SA_HIP(hipMemsetAsync(ix->d_docdir, 0xFF, dd_bytes, st));
+        u32* d_top = nullptr;
+        SA_HIP(hipMalloc(&d_top, ((size_t)ix->n_dd_terms + 1) * sizeof(u32)));
+        SA_HIP(hipMemsetAsync(d_top, 0, ((size_t)ix->n_dd_terms + 1) * sizeof(u32), st));
         for (u32 r = 0; r < ix->n_dd_terms; r++) {
             const u32 t = cand[r].second;
             const u32 n = (u32)cand[r].first;
             const u32 grid = n / 256 + 1 < 16384 ? n / 256 + 1 : 16384;
             hipLaunchKernelGGL(sa_k_build_docdir, dim3(grid), dim3(256), 0, st, ix->d_words + ix->h_term_off[t], n,
-                               ix->d_docdir + (size_t)r * ix->n_docs);
+                               ix->d_docdir + (size_t)r * ix->n_docs, d_top + r);
         }
+        ix->h_dd_top.assign((size_t)ix->n_dd_terms + 1, 0);
+        hipError_t e1 = hipMemcpyAsync(ix->h_dd_top.data(), d_top, ((size_t)ix->n_dd_terms + 1) * sizeof(u32), hipMemcpyDeviceToHost, st);
+        hipError_t e2 = hipStreamSynchronize(st);
+        hipFree(d_top);
+        if (e1 != hipSuccess || e2 != hipSuccess) { sa_set_error("doc directory build failed"); return SA_ERR_HIP; }
     }
     SA_HIP(hipStreamSynchronize(st));
     SA_HIP(hipGetLastError());

@@ -88,6 +88,7 @@ struct sa_index {
 
     std::vector<u64> h_term_off, h_tf_off;
     std::vector<u32> h_dd_slot;      // host copy of d_dd_slot
+    std::vector<u32> h_dd_top;       // [n_dd_terms] 1: the term has a word in the last 18-position block (sa_spans.hip)
     std::vector<u32> h_tf8_slot;     // host copy of d_tf8_slot
 
     // reusable device scratch (grown on demand, guarded by mu)

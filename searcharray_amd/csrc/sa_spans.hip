@@ -41,8 +41,10 @@
 
 struct SpanTerms {
     const u64* words[SA_SPAN_MAX_TERMS];
+    const u32* dd[SA_SPAN_MAX_TERMS];    // doc directory row of the term (index of each doc's first word), or null
     u32 len[SA_SPAN_MAX_TERMS];
     u32 off[SA_SPAN_MAX_TERMS + 1];      // prefix sums of len: position of each term in the flag array
+    u64 n_docs;
     int T;
 };
 
@@ -71,6 +73,32 @@ __device__ __forceinline__ u32 sa_header_triple(const u64* __restrict__ a, u32 n
         else if (hp != 0 && x == hp) bits |= 4u;
         else break;
         j++;
+    }
+    return bits;
+}
+
+// The same through the term's doc directory: one 4-byte load finds the doc's first word (or rejects the doc),
+// and the doc's few words are scanned for the three headers -- instead of a binary search of the whole list
+// (20 dependent loads for a term with a million words).  Valid for a term without a word in the last
+// 18-position block (sa_k_build_docdir checks): then h - 1 and h + 1 can only match words of h's own doc,
+// because a neighbour in ANOTHER doc would have to be that doc's block 2^18 - 1 (and the wrapped neighbours
+// of header 0 / of the largest header do not exist either).
+__device__ __forceinline__ u32 sa_header_triple_dd(const u64* __restrict__ a, u32 n, const u32* __restrict__ dd, u64 n_docs, u64 h) {
+    const u64 unit = 1ull << SA_LSB_BITS;
+    const u64 doc = h >> SA_KEY_SHIFT;
+    if (((h >> SA_LSB_BITS) & SA_LSB_MASK) == SA_LSB_MASK) return sa_header_triple(a, n, h);   // the probe itself sits in a last block
+    if (doc >= n_docs) return 0;
+    u32 j = dd[doc];
+    if (j == SA_DD_ABSENT) return 0;
+    const u64 hm = h - unit, hp = h + unit;
+    const bool has_prev = (h & ~SA_KEY_MASK) != 0;                      // block > 0: h - 1 is in the same doc
+    u32 bits = 0;
+    for (; j < n; j++) {
+        const u64 x = a[j] & SA_HEADER_MASK;
+        if ((x >> SA_KEY_SHIFT) != doc || x > hp) break;
+        if (x == h) bits |= 2u;
+        else if (has_prev && x == hm) bits |= 1u;
+        else if (x == hp) bits |= 4u;
     }
     return bits;
 }
@@ -116,7 +144,8 @@ sa_k_span_flags(const SpanTerms st, const u32* __restrict__ wrap, unsigned char*
         bool possible = true;
         for (int i = 0; i < st.T; i++) m[i] = 0;
         for (int i = 0; i < st.T && possible; i++) {
-            m[i] = sa_header_triple(st.words[i], st.len[i], h);
+            m[i] = st.dd[i] ? sa_header_triple_dd(st.words[i], st.len[i], st.dd[i], st.n_docs, h)
+                            : sa_header_triple(st.words[i], st.len[i], h);
             // every set needs term 0 and term i around h: nothing there -> no candidate
             if (m[i] == 0) possible = false;
         }
@@ -167,13 +196,40 @@ __device__ __forceinline__ u32 sa_popc_sext(int v) { return (u32)__popc((u32)v) 
 __device__ __forceinline__ int sa_iabs32(int v) { return v < 0 ? -v : v; }
 
 // Stage 2: the k-th thread takes the k-th, (k+G)-th, ... document group of EVERY term.
+// The first SA_SPAN_LDS spans of a thread's table (and the first SA_COL_LDS collected spans) live in LDS -- a
+// column per lane, 16-byte entries: lane L's entry i sits at (i * 64 + L) * 16, so whatever rows the lanes of a
+// wave are at, they hit different banks -- and only a document whose table grows beyond that (many positions of
+// every term within the window) continues in the thread's column of the global slab.  A typical document needs a
+// handful of spans: its whole state machine runs at LDS latency instead of one HBM round trip per table access.
+#define SA_SPAN_LDS 24
+#define SA_COL_LDS 8
 __global__ void __launch_bounds__(64) sa_k_span_machine(const SpanMachineParams p) {
+    __shared__ alignas(16) SpanEnt s_ents[SA_SPAN_LDS * 64];
+    __shared__ u64 s_col[SA_COL_LDS * 64];
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 G = p.n_threads;
     if (g >= G) return;
     const u32 n_groups = *p.n_heads[0];
-    SpanEnt* ents = p.ents + g;
-    u64* col = p.col + g;
+    const u32 lane = threadIdx.x;
+    struct EntTable {
+        SpanEnt* lds; SpanEnt* glob; u64 G; u32 lane;
+        struct Ref {
+            SpanEnt* p;
+            __device__ __forceinline__ operator SpanEnt() const { return *p; }
+            __device__ __forceinline__ void operator=(const SpanEnt& e) const { *p = e; }
+        };
+        __device__ __forceinline__ Ref operator[](u32 i) const {
+            return Ref{i < (u32)SA_SPAN_LDS ? lds + (i * 64u + lane) : glob + (u64)(i - SA_SPAN_LDS) * G};
+        }
+    };
+    struct ColTable {
+        u64* lds; u64* glob; u64 G; u32 lane;
+        __device__ __forceinline__ u64& operator[](u32 i) const {
+            return i < (u32)SA_COL_LDS ? lds[i * 64u + lane] : glob[(u64)(i - SA_COL_LDS) * G];
+        }
+    };
+    const EntTable ents{s_ents, p.ents + g, (u64)G, lane};
+    const ColTable col{s_col, p.col + g, (u64)G, lane};
     const u32 num_terms = (u32)p.T;
     const int max_span_width = (int)(num_terms + p.slop);
     for (u32 k = g; k < n_groups; k += G) {
@@ -202,11 +258,11 @@ __global__ void __launch_bounds__(64) sa_k_span_machine(const SpanMachineParams 
                     if (cursor >= SA_NSPANS) { full = true; break; }
                     SpanEnt fresh;
                     fresh.terms = curr_term_mask; fresh.posns = posn_mask; fresh.beg = curr_posn; fresh.end = curr_posn;
-                    ents[(u64)cursor * G] = fresh;
+                    ents[cursor] = fresh;
                     const u32 end = cursor;
                     cursor++;
                     for (u32 si = 0; si < end; si++) {
-                        SpanEnt e = ents[(u64)si * G];
+                        SpanEnt e = ents[si];
                         const u32 nt = (u32)__popc(e.terms), np = sa_popc_sext(e.posns);
                         if (nt < num_terms && np == num_terms) continue;
                         if (e.terms & curr_term_mask) continue;          // term already in the span: nothing changes
@@ -214,21 +270,21 @@ __global__ void __launch_bounds__(64) sa_k_span_machine(const SpanMachineParams 
                         const u32 new_unique = sa_popc_sext(sp2);
                         const int proposed = sa_iabs32(curr_posn - e.beg);
                         if (np == new_unique || proposed > max_span_width) {
-                            if (sp2 != e.posns) { e.posns = sp2; ents[(u64)si * G] = e; }   // the position bit stays even if rejected
+                            if (sp2 != e.posns) { e.posns = sp2; ents[si] = e; }   // the position bit stays even if rejected
                             continue;
                         }
                         if (cursor < SA_NSPANS) {
                             SpanEnt fork;
                             fork.terms = e.terms | curr_term_mask; fork.posns = sp2 & ~posn_mask;
                             fork.beg = e.beg; fork.end = e.end;
-                            ents[(u64)cursor * G] = fork;
+                            ents[cursor] = fork;
                             cursor++;
                             full = false;
                         } else {
                             full = true;
                         }
                         e.terms |= curr_term_mask; e.posns = sp2; e.end = curr_posn;
-                        ents[(u64)si * G] = e;
+                        ents[si] = e;
                     }
                     if (cursor >= SA_NSPANS) break;
                 }
@@ -248,22 +304,22 @@ __global__ void __launch_bounds__(64) sa_k_span_machine(const SpanMachineParams 
             // appended.
             u32 ncol = 0;
             for (u32 si = 0; si < cursor; si++) {
-                const SpanEnt e = ents[(u64)si * G];
+                const SpanEnt e = ents[si];
                 const bool complete = ((u32)__popc(e.terms) == num_terms) || (sa_popc_sext(e.posns) == num_terms);
                 const int b = e.beg, en = e.end;
                 const int width = sa_iabs32(en - b);
                 if (!complete || width >= max_span_width) continue;
                 bool replaced = false;
                 for (u32 c = 0; c < ncol; c++) {
-                    const u64 cc = col[(u64)c * G];
+                    const u64 cc = col[c];
                     const int cb = (int)(cc >> 32), ce = (int)(cc & 0xFFFFFFFFull);
                     if (b <= ce && en >= cb && width < sa_iabs32(ce - cb)) {
-                        col[(u64)c * G] = ((u64)(u32)b << 32) | (u64)(u32)en;
+                        col[c] = ((u64)(u32)b << 32) | (u64)(u32)en;
                         replaced = true;
                         break;
                     }
                 }
-                if (!replaced) { col[(u64)ncol * G] = ((u64)(u32)b << 32) | (u64)(u32)en; ncol++; }
+                if (!replaced) { col[ncol] = ((u64)(u32)b << 32) | (u64)(u32)en; ncol++; }
             }
             incr = ncol;
         }
@@ -284,6 +340,7 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
     SpanTerms terms_dev;
     memset(&terms_dev, 0, sizeof(terms_dev));
     terms_dev.T = T;
+    terms_dev.n_docs = ix->n_docs;
     bool known = true;
     size_t total_len = 0, max_len = 0;
     for (int t = 0; t < T; t++) {
@@ -291,6 +348,13 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
         const u64 off = ix->h_term_off[terms[t]];
         terms_dev.words[t] = ix->d_words + off;
         terms_dev.len[t] = (u32)(ix->h_term_off[terms[t] + 1] - off);
+        // probes through the doc directory (whole, unfiltered lists of frequent terms without a top-block word)
+        const char* ddenv = getenv("SA_SPAN_DOCDIR");
+        if (!filt.active && ix->n_dd_terms > 0 && !(ddenv && atoi(ddenv) == 0)) {
+            const u32 sl = ix->h_dd_slot[terms[t]];
+            if (sl != SA_DD_NONE && sl < ix->h_dd_top.size() && ix->h_dd_top[sl] == 0)
+                terms_dev.dd[t] = ix->d_docdir + (size_t)sl * ix->n_docs;
+        }
         total_len += terms_dev.len[t];
         if (terms_dev.len[t] > max_len) max_len = terms_dev.len[t];
     }
