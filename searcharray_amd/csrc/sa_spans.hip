@@ -186,6 +186,8 @@ struct SpanMachineParams {
     u64* col;                                 // [SA_NSPANS][G] collected (beg, end) pairs
     u32* counts;                              // dense per-doc counts (atomically accumulated)
     u64 n_docs;
+    u32* over_list;                           // fast pass: document groups whose table outgrew the LDS column (or null)
+    u32* over_cnt;
 };
 
 // reference spans.pyx:108-109 as compiled: `1 << (p % 64)` is a 32-bit shift (count mod 32) whose
@@ -195,135 +197,184 @@ __device__ __forceinline__ int sa_posn_mask32(int p) { return (int)(1u << ((u32)
 __device__ __forceinline__ u32 sa_popc_sext(int v) { return (u32)__popc((u32)v) + (v < 0 ? 32u : 0u); }
 __device__ __forceinline__ int sa_iabs32(int v) { return v < 0 ? -v : v; }
 
-// Stage 2: the k-th thread takes the k-th, (k+G)-th, ... document group of EVERY term.
-// The first SA_SPAN_LDS spans of a thread's table (and the first SA_COL_LDS collected spans) live in LDS -- a
-// column per lane, 16-byte entries: lane L's entry i sits at (i * 64 + L) * 16, so whatever rows the lanes of a
-// wave are at, they hit different banks -- and only a document whose table grows beyond that (many positions of
-// every term within the window) continues in the thread's column of the global slab.  A typical document needs a
-// handful of spans: its whole state machine runs at LDS latency instead of one HBM round trip per table access.
-#define SA_SPAN_LDS 24
-#define SA_COL_LDS 8
-__global__ void __launch_bounds__(64) sa_k_span_machine(const SpanMachineParams p) {
+// Stage 2: one thread per document group (documents are independent).  Thread k takes the k-th document group of
+// EVERY term -- the reference walks the terms' cursors in lock step (spans.pyx:223-304) and does not re-align them
+// by key -- and replays the state machine.
+//
+// Two passes over two table placements:
+//   fast   one thread per document group, the whole span table in LDS -- a column per lane, 16-byte entries, lane
+//          L's entry i at (i * 64 + L) * 16: whatever rows the lanes of a wave are at, they hit different banks.
+//          SA_SPAN_LDS spans and SA_COL_LDS collected spans per lane keep a wave at 14 KiB of LDS, i.e. 11 waves per
+//          CU to hide the latency of the per-lane word loads.  A typical document needs a handful of spans; a
+//          document whose table would outgrow the column is ABANDONED here (nothing counted) and put on a list;
+//   slow   the listed documents again, one thread each, with the full 512-span table of the reference in the
+//          thread's column of a global slab (interleaved across threads so a wave's accesses coalesce).
+// Returns false when the table capacity CAP_E / CAP_C is exceeded before the reference's own limit (fast pass only).
+#define SA_SPAN_LDS 12
+#define SA_COL_LDS 4
+
+template <int CAP_E, int CAP_C, class Ents, class Col>
+__device__ __forceinline__ bool sa_span_doc(const SpanMachineParams& p, const u32 k, const Ents& ents, const Col& col,
+                                            u32* incr_out, u64* key_out) {
+    const u32 num_terms = (u32)p.T;
+    const int max_span_width = (int)(num_terms + p.slop);
+    u32 cursor = 0;
+    bool full = false;
+    u64 last_key = 0;
+    u32 sum_pop[SA_SPAN_MAX_TERMS];
+    for (int t = 0; t < p.T; t++) {
+        sum_pop[t] = 0;
+        const u32 ng = *p.n_heads[t];
+        if (k >= ng) continue;                                   // this term has no k-th document group
+        const u32 lo = p.heads[t][k];
+        const u32 hi = (k + 1 < ng) ? p.heads[t][k + 1] : *p.n_cand[t];
+        const u32 curr_term_mask = 1u << t;
+        bool gave_up = false;
+        for (u32 wi = lo; wi < hi && !gave_up; wi++) {
+            const u64 w = p.cand[t][wi];
+            last_key = w >> SA_KEY_SHIFT;
+            const int payload_base = (int)(((w >> SA_LSB_BITS) & SA_LSB_MASK) * SA_LSB_BITS);
+            u32 bits = (u32)(w & SA_LSB_MASK);
+            sum_pop[t] += (u32)__popc(bits);
+            while (bits != 0) {
+                const int curr_posn = payload_base + (__ffs((int)bits) - 1);
+                bits &= bits - 1;
+                const int posn_mask = sa_posn_mask32(curr_posn);
+                if (cursor >= SA_NSPANS) { full = true; break; }
+                if (CAP_E < SA_NSPANS && cursor >= (u32)CAP_E) return false;
+                SpanEnt fresh;
+                fresh.terms = curr_term_mask; fresh.posns = posn_mask; fresh.beg = curr_posn; fresh.end = curr_posn;
+                ents[cursor] = fresh;
+                const u32 end = cursor;
+                cursor++;
+                for (u32 si = 0; si < end; si++) {
+                    SpanEnt e = ents[si];
+                    const u32 nt = (u32)__popc(e.terms), np = sa_popc_sext(e.posns);
+                    if (nt < num_terms && np == num_terms) continue;
+                    if (e.terms & curr_term_mask) continue;          // term already in the span: nothing changes
+                    const int sp2 = e.posns | posn_mask;
+                    const u32 new_unique = sa_popc_sext(sp2);
+                    const int proposed = sa_iabs32(curr_posn - e.beg);
+                    if (np == new_unique || proposed > max_span_width) {
+                        if (sp2 != e.posns) { e.posns = sp2; ents[si] = e; }   // the position bit stays even if rejected
+                        continue;
+                    }
+                    if (cursor < SA_NSPANS) {
+                        if (CAP_E < SA_NSPANS && cursor >= (u32)CAP_E) return false;
+                        SpanEnt fork;
+                        fork.terms = e.terms | curr_term_mask; fork.posns = sp2 & ~posn_mask;
+                        fork.beg = e.beg; fork.end = e.end;
+                        ents[cursor] = fork;
+                        cursor++;
+                        full = false;
+                    } else {
+                        full = true;
+                    }
+                    e.terms |= curr_term_mask; e.posns = sp2; e.end = curr_posn;
+                    ents[si] = e;
+                }
+                if (cursor >= SA_NSPANS) break;
+            }
+            // reference compaction (spans.pyx:140-154) never removes a span (widths are bounded by
+            // construction), so a full table stays full: skip the rest of this term's words
+            if (cursor >= SA_NSPANS) gave_up = true;
+        }
+    }
+    u32 incr;
+    if (full) {
+        u32 mn = 0;
+        for (int t = 0; t < p.T; t++) if (mn == 0 || sum_pop[t] < mn) mn = sum_pop[t];
+        incr = mn;
+    } else {
+        // _collect_spans, spans.pyx:157-186: walk the spans in order; a complete span narrower than
+        // max_width either replaces the first collected span it overlaps AND is shorter than, or is
+        // appended.
+        u32 ncol = 0;
+        for (u32 si = 0; si < cursor; si++) {
+            const SpanEnt e = ents[si];
+            const bool complete = ((u32)__popc(e.terms) == num_terms) || (sa_popc_sext(e.posns) == num_terms);
+            const int b = e.beg, en = e.end;
+            const int width = sa_iabs32(en - b);
+            if (!complete || width >= max_span_width) continue;
+            bool replaced = false;
+            for (u32 c = 0; c < ncol; c++) {
+                const u64 cc = col[c];
+                const int cb = (int)(cc >> 32), ce = (int)(cc & 0xFFFFFFFFull);
+                if (b <= ce && en >= cb && width < sa_iabs32(ce - cb)) {
+                    col[c] = ((u64)(u32)b << 32) | (u64)(u32)en;
+                    replaced = true;
+                    break;
+                }
+            }
+            if (!replaced) {
+                if (CAP_C < SA_NSPANS && ncol >= (u32)CAP_C) return false;
+                col[ncol] = ((u64)(u32)b << 32) | (u64)(u32)en;
+                ncol++;
+            }
+        }
+        incr = ncol;
+    }
+    *incr_out = incr;
+    *key_out = last_key;
+    return true;
+}
+
+// fast pass: thread k = document group k, tables in LDS; overflowing groups go to p.over_list
+__global__ void __launch_bounds__(64) sa_k_span_machine_lds(const SpanMachineParams p) {
     __shared__ alignas(16) SpanEnt s_ents[SA_SPAN_LDS * 64];
     __shared__ u64 s_col[SA_COL_LDS * 64];
+    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= *p.n_heads[0]) return;
+    struct EntCol {
+        SpanEnt* base;
+        struct Ref {
+            SpanEnt* q;
+            __device__ __forceinline__ operator SpanEnt() const { return *q; }
+            __device__ __forceinline__ void operator=(const SpanEnt& e) const { *q = e; }
+        };
+        __device__ __forceinline__ Ref operator[](u32 i) const { return Ref{base + i * 64u}; }
+    };
+    struct ColCol {
+        u64* base;
+        __device__ __forceinline__ u64& operator[](u32 i) const { return base[i * 64u]; }
+    };
+    u32 incr = 0;
+    u64 key = 0;
+    if (sa_span_doc<SA_SPAN_LDS, SA_COL_LDS>(p, k, EntCol{s_ents + threadIdx.x}, ColCol{s_col + threadIdx.x}, &incr, &key)) {
+        if (incr && key < p.n_docs) atomicAdd(&p.counts[key], incr);
+    } else {
+        p.over_list[atomicAdd(p.over_cnt, 1u)] = k;
+    }
+}
+
+// slow pass: a resident grid strides over the listed document groups (all of them when over_list is null:
+// the kernel-level mirror sa_span_search), full tables in the thread's column of the global slab
+__global__ void __launch_bounds__(64) sa_k_span_machine(const SpanMachineParams p) {
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 G = p.n_threads;
     if (g >= G) return;
-    const u32 n_groups = *p.n_heads[0];
-    const u32 lane = threadIdx.x;
-    struct EntTable {
-        SpanEnt* lds; SpanEnt* glob; u64 G; u32 lane;
+    const u32 n_items = p.over_list ? *p.over_cnt : *p.n_heads[0];
+    struct EntSlab {
+        SpanEnt* base; u64 G;
         struct Ref {
-            SpanEnt* p;
-            __device__ __forceinline__ operator SpanEnt() const { return *p; }
-            __device__ __forceinline__ void operator=(const SpanEnt& e) const { *p = e; }
+            SpanEnt* q;
+            __device__ __forceinline__ operator SpanEnt() const { return *q; }
+            __device__ __forceinline__ void operator=(const SpanEnt& e) const { *q = e; }
         };
-        __device__ __forceinline__ Ref operator[](u32 i) const {
-            return Ref{i < (u32)SA_SPAN_LDS ? lds + (i * 64u + lane) : glob + (u64)(i - SA_SPAN_LDS) * G};
-        }
+        __device__ __forceinline__ Ref operator[](u32 i) const { return Ref{base + (u64)i * G}; }
     };
-    struct ColTable {
-        u64* lds; u64* glob; u64 G; u32 lane;
-        __device__ __forceinline__ u64& operator[](u32 i) const {
-            return i < (u32)SA_COL_LDS ? lds[i * 64u + lane] : glob[(u64)(i - SA_COL_LDS) * G];
-        }
+    struct ColSlab {
+        u64* base; u64 G;
+        __device__ __forceinline__ u64& operator[](u32 i) const { return base[(u64)i * G]; }
     };
-    const EntTable ents{s_ents, p.ents + g, (u64)G, lane};
-    const ColTable col{s_col, p.col + g, (u64)G, lane};
-    const u32 num_terms = (u32)p.T;
-    const int max_span_width = (int)(num_terms + p.slop);
-    for (u32 k = g; k < n_groups; k += G) {
-        u32 cursor = 0;
-        bool full = false;
-        u64 last_key = 0;
-        u32 sum_pop[SA_SPAN_MAX_TERMS];
-        for (int t = 0; t < p.T; t++) {
-            sum_pop[t] = 0;
-            const u32 ng = *p.n_heads[t];
-            if (k >= ng) continue;                                   // this term has no k-th document group
-            const u32 lo = p.heads[t][k];
-            const u32 hi = (k + 1 < ng) ? p.heads[t][k + 1] : *p.n_cand[t];
-            const u32 curr_term_mask = 1u << t;
-            bool gave_up = false;
-            for (u32 wi = lo; wi < hi && !gave_up; wi++) {
-                const u64 w = p.cand[t][wi];
-                last_key = w >> SA_KEY_SHIFT;
-                const int payload_base = (int)(((w >> SA_LSB_BITS) & SA_LSB_MASK) * SA_LSB_BITS);
-                u32 bits = (u32)(w & SA_LSB_MASK);
-                sum_pop[t] += (u32)__popc(bits);
-                while (bits != 0) {
-                    const int curr_posn = payload_base + (__ffs((int)bits) - 1);
-                    bits &= bits - 1;
-                    const int posn_mask = sa_posn_mask32(curr_posn);
-                    if (cursor >= SA_NSPANS) { full = true; break; }
-                    SpanEnt fresh;
-                    fresh.terms = curr_term_mask; fresh.posns = posn_mask; fresh.beg = curr_posn; fresh.end = curr_posn;
-                    ents[cursor] = fresh;
-                    const u32 end = cursor;
-                    cursor++;
-                    for (u32 si = 0; si < end; si++) {
-                        SpanEnt e = ents[si];
-                        const u32 nt = (u32)__popc(e.terms), np = sa_popc_sext(e.posns);
-                        if (nt < num_terms && np == num_terms) continue;
-                        if (e.terms & curr_term_mask) continue;          // term already in the span: nothing changes
-                        const int sp2 = e.posns | posn_mask;
-                        const u32 new_unique = sa_popc_sext(sp2);
-                        const int proposed = sa_iabs32(curr_posn - e.beg);
-                        if (np == new_unique || proposed > max_span_width) {
-                            if (sp2 != e.posns) { e.posns = sp2; ents[si] = e; }   // the position bit stays even if rejected
-                            continue;
-                        }
-                        if (cursor < SA_NSPANS) {
-                            SpanEnt fork;
-                            fork.terms = e.terms | curr_term_mask; fork.posns = sp2 & ~posn_mask;
-                            fork.beg = e.beg; fork.end = e.end;
-                            ents[cursor] = fork;
-                            cursor++;
-                            full = false;
-                        } else {
-                            full = true;
-                        }
-                        e.terms |= curr_term_mask; e.posns = sp2; e.end = curr_posn;
-                        ents[si] = e;
-                    }
-                    if (cursor >= SA_NSPANS) break;
-                }
-                // reference compaction (spans.pyx:140-154) never removes a span (widths are bounded by
-                // construction), so a full table stays full: skip the rest of this term's words
-                if (cursor >= SA_NSPANS) gave_up = true;
-            }
-        }
-        u32 incr;
-        if (full) {
-            u32 mn = 0;
-            for (int t = 0; t < p.T; t++) if (mn == 0 || sum_pop[t] < mn) mn = sum_pop[t];
-            incr = mn;
-        } else {
-            // _collect_spans, spans.pyx:157-186: walk the spans in order; a complete span narrower than
-            // max_width either replaces the first collected span it overlaps AND is shorter than, or is
-            // appended.
-            u32 ncol = 0;
-            for (u32 si = 0; si < cursor; si++) {
-                const SpanEnt e = ents[si];
-                const bool complete = ((u32)__popc(e.terms) == num_terms) || (sa_popc_sext(e.posns) == num_terms);
-                const int b = e.beg, en = e.end;
-                const int width = sa_iabs32(en - b);
-                if (!complete || width >= max_span_width) continue;
-                bool replaced = false;
-                for (u32 c = 0; c < ncol; c++) {
-                    const u64 cc = col[c];
-                    const int cb = (int)(cc >> 32), ce = (int)(cc & 0xFFFFFFFFull);
-                    if (b <= ce && en >= cb && width < sa_iabs32(ce - cb)) {
-                        col[c] = ((u64)(u32)b << 32) | (u64)(u32)en;
-                        replaced = true;
-                        break;
-                    }
-                }
-                if (!replaced) { col[ncol] = ((u64)(u32)b << 32) | (u64)(u32)en; ncol++; }
-            }
-            incr = ncol;
-        }
-        if (incr && last_key < p.n_docs) atomicAdd(&p.counts[last_key], incr);
+    const EntSlab ents{p.ents + g, (u64)G};
+    const ColSlab col{p.col + g, (u64)G};
+    for (u32 i = g; i < n_items; i += G) {
+        const u32 k = p.over_list ? p.over_list[i] : i;
+        u32 incr = 0;
+        u64 key = 0;
+        sa_span_doc<SA_NSPANS, SA_NSPANS>(p, k, ents, col, &incr, &key);
+        if (incr && key < p.n_docs) atomicAdd(&p.counts[key], incr);
     }
 }
 
@@ -368,7 +419,8 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
     const size_t slab_bytes = (size_t)G * SA_NSPANS * (sizeof(SpanEnt) + sizeof(u64));
     const size_t chunk_words = sa_compact_chunks((u32)(max_len + 1)) + 8;
     const size_t filt_bytes = filt.active ? (total_len + 64 * (size_t)T) * 8 : 0;
-    const size_t need = (N + 64) * 8 + (total_len + 64 * T) * 13 + slab_bytes + chunk_words * 4 + filt_bytes + 64 * 1024;
+    const size_t need = (N + 64) * 8 + (total_len + 64 * T) * 13 + slab_bytes + chunk_words * 4 + filt_bytes + 64 * 1024 +
+                        ((size_t)terms_dev.len[0] + 64) * 4;
     void* scratch;
     SA_TRY(sa_index_scratch(ix, need, &scratch));
     char* base = (char*)scratch;
@@ -376,15 +428,16 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
     auto take = [&](size_t bytes) { char* p = base + used; used += (bytes + 255) & ~(size_t)255; return p; };
     float* running = (float*)take((N + 1) * 4);
     u32* counts = (u32*)take((N + 1) * 4);
-    u32* cnt = (u32*)take(4 * SA_SPAN_MAX_TERMS * 4);          // [t] n_cand, [16 + t] n_heads, [32] wrap flag
+    u32* cnt = (u32*)take(5 * SA_SPAN_MAX_TERMS * 4);          // [t] n_cand, [16 + t] n_heads, [32] wrap flag, [48 + t] filter scratch, [64] abandoned groups
     u32* chunks = (u32*)take(chunk_words * 4);
     SpanEnt* ents = (SpanEnt*)take((size_t)G * SA_NSPANS * sizeof(SpanEnt));
     u64* col = (u64*)take((size_t)G * SA_NSPANS * sizeof(u64));
     unsigned char* flags = (unsigned char*)take(total_len + 64);
+    u32* over_list = (u32*)take(((size_t)terms_dev.len[0] + 64) * 4);
     *d_out = running;
     SA_HIP(hipMemsetAsync(running, 0, N * sizeof(float), st));
     SA_HIP(hipMemsetAsync(counts, 0, N * sizeof(u32), st));
-    SA_HIP(hipMemsetAsync(cnt, 0, 4 * SA_SPAN_MAX_TERMS * 4, st));
+    SA_HIP(hipMemsetAsync(cnt, 0, 5 * SA_SPAN_MAX_TERMS * 4, st));
     if (!known || N == 0 || total_len == 0) return SA_OK;
     if (filt.active) {
         const u64* ptrs[SA_SPAN_MAX_TERMS];
@@ -422,6 +475,12 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
         DocHeads dh;
         dh.words = cand; dh.out = heads;
         sa_compact(dh, cnt + t, terms_dev.len[t], chunks, cnt + SA_SPAN_MAX_TERMS + t, st);
+    }
+    // fast pass (tables in LDS, one thread per document group), then the groups it abandoned with full tables
+    const char* fast_env = getenv("SA_SPAN_FAST");
+    if (!(fast_env && atoi(fast_env) == 0) && terms_dev.len[0] > 0) {
+        mp.over_list = over_list; mp.over_cnt = cnt + 4 * SA_SPAN_MAX_TERMS;
+        hipLaunchKernelGGL(sa_k_span_machine_lds, dim3((terms_dev.len[0] + 63u) / 64u), dim3(64), 0, st, mp);
     }
     hipLaunchKernelGGL(sa_k_span_machine, dim3(G / 64), dim3(64), 0, st, mp);
     const u64 g = (N + 255) / 256;

@@ -159,6 +159,28 @@ def test_slop_more_doc_groups_than_resident_threads(api, monkeypatch):
         assert np.array_equal(dev.phrase_freqs_dense(terms, slop=slop), want), f"slop {terms} {slop}"
 
 
+@pytest.mark.parametrize("fast,docdir", [("1", "1"), ("0", "1"), ("1", "0")])
+def test_slop_table_placements_and_probe_routes_agree(api, monkeypatch, fast, docdir):
+    """the fast pass (span tables in LDS, abandoned documents redone with full tables) vs the full-table pass alone
+    (SA_SPAN_FAST=0), and header probes through the doc directory vs binary searches (SA_SPAN_DOCDIR=0): docs
+    with few positions and docs whose table outgrows the LDS column (> 12 spans), against the oracle (a table
+    beyond the reference's 512 spans is undefined behaviour there -- see the fuzz test)"""
+    monkeypatch.setenv("SA_SPAN_FAST", fast)
+    monkeypatch.setenv("SA_SPAN_DOCDIR", docdir)
+    monkeypatch.setenv("SA_DOCDIR_DIV", "1000000")          # a doc directory for every term of >= 64 words
+    rng = np.random.default_rng(3)
+    docs = []
+    for i in range(400):
+        n = int(rng.integers(2, 12)) if i % 7 else int(rng.integers(60, 140))
+        docs.append(" ".join(rng.choice(["a", "b", "c", "x", "y"], n, p=[0.3, 0.3, 0.1, 0.15, 0.15])))
+    vocab, dev = _device_from_strings(docs, api)
+    vocab_o, orc = _index_strings(docs)
+    for q, slop in ((["a", "b"], 2), (["b", "a"], 1), (["a", "b", "c"], 3), (["a", "a"], 2)):
+        got = dev.phrase_freqs_dense([vocab[x] for x in q], slop=slop)
+        want = orc.phrase_freqs([vocab_o[x] for x in q], slop=slop)
+        assert np.array_equal(got, want), (q, slop, np.flatnonzero(got != want)[:5])
+
+
 def test_slop_scenarios_from_reference_tests(api):
     """match / no-match booleans of reference test/test_slop_matches.py:7-88"""
     docs = ["foo bar baz", "foo x bar", "foo x y bar", "bar foo", "foo foo bar", "nothing here"]
