@@ -34,6 +34,7 @@
 #include "sa_scan.hpp"
 #include "../../include/searcharray_hip.h"
 #include <stdlib.h>
+#include <algorithm>
 
 #define SA_SPAN_MAX_TERMS 16
 #define SA_NSPANS 512
@@ -186,8 +187,10 @@ struct SpanMachineParams {
     u64* col;                                 // [SA_NSPANS][G] collected (beg, end) pairs
     u32* counts;                              // dense per-doc counts (atomically accumulated)
     u64 n_docs;
-    u32* over_list;                           // fast pass: document groups whose table outgrew the LDS column (or null)
-    u32* over_cnt;
+    u32* over_list;                           // LDS passes: document groups whose table outgrew the column; full-table
+    u32* over_cnt;                            //   pass: the groups to take (null: all of them)
+    const u32* in_list;                       // second LDS pass: the groups the first one abandoned
+    const u32* in_cnt;
 };
 
 // reference spans.pyx:108-109 as compiled: `1 << (p % 64)` is a 32-bit shift (count mod 32) whose
@@ -204,26 +207,27 @@ __device__ __forceinline__ int sa_iabs32(int v) { return v < 0 ? -v : v; }
 // Two passes over two table placements:
 //   fast   one thread per document group, the whole span table in LDS -- a column per lane, 16-byte entries, lane
 //          L's entry i at (i * 64 + L) * 16: whatever rows the lanes of a wave are at, they hit different banks.
-//          SA_SPAN_LDS spans and SA_COL_LDS collected spans per lane keep a wave at 14 KiB of LDS, i.e. 11 waves per
-//          CU to hide the latency of the per-lane word loads.  A typical document needs a handful of spans; a
+//          SA_SPAN_LDS spans per lane (the collected spans reuse the slots of the spans already visited) keep a
+//          wave at 12 KiB of LDS, i.e. 13 waves per CU to hide the latency of the per-lane word loads.  A typical document needs a handful of spans; a
 //          document whose table would outgrow the column is ABANDONED here (nothing counted) and put on a list;
-//   slow   the listed documents again, one thread each, with the full 512-span table of the reference in the
-//          thread's column of a global slab (interleaved across threads so a wave's accesses coalesce).
+//   heavy  the listed documents again, one WAVE each (sa_k_span_machine_wave below).
+// (sa_k_span_machine -- one thread per document with the full 512-span table in the thread's column of a global
+//  slab -- remains as the kernel-level mirror's machine and as the SA_SPAN_FAST=0 route the tests compare with.)
 // Returns false when the table capacity CAP_E / CAP_C is exceeded before the reference's own limit (fast pass only).
 #define SA_SPAN_LDS 12
-#define SA_COL_LDS 4
 
 template <int CAP_E, int CAP_C, class Ents, class Col>
 __device__ __forceinline__ bool sa_span_doc(const SpanMachineParams& p, const u32 k, const Ents& ents, const Col& col,
                                             u32* incr_out, u64* key_out) {
     const u32 num_terms = (u32)p.T;
     const int max_span_width = (int)(num_terms + p.slop);
+    constexpr bool CAN_FILL = CAP_E >= SA_NSPANS;                // only the full-table pass can reach the reference's limit
     u32 cursor = 0;
     bool full = false;
     u64 last_key = 0;
-    u32 sum_pop[SA_SPAN_MAX_TERMS];
+    u32 sum_pop[CAN_FILL ? SA_SPAN_MAX_TERMS : 1];               // (indexed by a run-time term: private memory)
     for (int t = 0; t < p.T; t++) {
-        sum_pop[t] = 0;
+        if (CAN_FILL) sum_pop[t] = 0;
         const u32 ng = *p.n_heads[t];
         if (k >= ng) continue;                                   // this term has no k-th document group
         const u32 lo = p.heads[t][k];
@@ -235,7 +239,7 @@ __device__ __forceinline__ bool sa_span_doc(const SpanMachineParams& p, const u3
             last_key = w >> SA_KEY_SHIFT;
             const int payload_base = (int)(((w >> SA_LSB_BITS) & SA_LSB_MASK) * SA_LSB_BITS);
             u32 bits = (u32)(w & SA_LSB_MASK);
-            sum_pop[t] += (u32)__popc(bits);
+            if (CAN_FILL) sum_pop[t] += (u32)__popc(bits);
             while (bits != 0) {
                 const int curr_posn = payload_base + (__ffs((int)bits) - 1);
                 bits &= bits - 1;
@@ -281,7 +285,7 @@ __device__ __forceinline__ bool sa_span_doc(const SpanMachineParams& p, const u3
         }
     }
     u32 incr;
-    if (full) {
+    if (CAN_FILL && full) {
         u32 mn = 0;
         for (int t = 0; t < p.T; t++) if (mn == 0 || sum_pop[t] < mn) mn = sum_pop[t];
         incr = mn;
@@ -319,12 +323,12 @@ __device__ __forceinline__ bool sa_span_doc(const SpanMachineParams& p, const u3
     return true;
 }
 
-// fast pass: thread k = document group k, tables in LDS; overflowing groups go to p.over_list
+// LDS passes: tables of CE spans / CC collected spans per lane.  LISTED = false: thread k = document group k (the
+// first pass); LISTED = true: a resident grid strides over the groups the previous pass abandoned (p.in_list).
+// Groups whose table outgrows this pass's column go to p.over_list.
+template <int CE, bool LISTED>
 __global__ void __launch_bounds__(64) sa_k_span_machine_lds(const SpanMachineParams p) {
-    __shared__ alignas(16) SpanEnt s_ents[SA_SPAN_LDS * 64];
-    __shared__ u64 s_col[SA_COL_LDS * 64];
-    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= *p.n_heads[0]) return;
+    __shared__ alignas(16) SpanEnt s_ents[CE * 64];
     struct EntCol {
         SpanEnt* base;
         struct Ref {
@@ -334,16 +338,164 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_lds(const SpanMachinePar
         };
         __device__ __forceinline__ Ref operator[](u32 i) const { return Ref{base + i * 64u}; }
     };
+    // The collected spans reuse the table's own storage: collecting walks the spans in order and has at most as
+    // many collected spans as spans already visited, so collected span c lives in the (dead) slot of span c.
     struct ColCol {
         u64* base;
-        __device__ __forceinline__ u64& operator[](u32 i) const { return base[i * 64u]; }
+        __device__ __forceinline__ u64& operator[](u32 i) const { return base[i * 128u]; }
     };
-    u32 incr = 0;
-    u64 key = 0;
-    if (sa_span_doc<SA_SPAN_LDS, SA_COL_LDS>(p, k, EntCol{s_ents + threadIdx.x}, ColCol{s_col + threadIdx.x}, &incr, &key)) {
-        if (incr && key < p.n_docs) atomicAdd(&p.counts[key], incr);
-    } else {
-        p.over_list[atomicAdd(p.over_cnt, 1u)] = k;
+    const u32 n_items = LISTED ? *p.in_cnt : *p.n_heads[0];
+    const u32 stride = LISTED ? gridDim.x * blockDim.x : 0xFFFFFFFFu;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += stride) {
+        const u32 k = LISTED ? p.in_list[i] : i;
+        u32 incr = 0;
+        u64 key = 0;
+        if (sa_span_doc<CE, CE>(p, k, EntCol{s_ents + threadIdx.x}, ColCol{(u64*)(s_ents + threadIdx.x)}, &incr, &key)) {
+            if (incr && key < p.n_docs) atomicAdd(&p.counts[key], incr);
+        } else {
+            p.over_list[atomicAdd(p.over_cnt, 1u)] = k;
+        }
+        if (!LISTED) break;
+    }
+}
+
+// Heavy documents: ONE WAVE per document group.  The span table (the reference's full 512 entries) is in LDS; the
+// positions are still taken one after the other, but what the reference does for one position -- visit every
+// span that existed before it, extend / fork -- is done for 64 spans at a time, one per lane: the visits are
+// independent of each other (a visit reads and writes its own span; forks are appended behind the spans that
+// existed, in span order -- a ballot prefix gives each fork its slot -- and are not visited for the same
+// position).  The cost of a document drops from positions x spans dependent steps of one lane to
+// positions x ceil(spans / 64) steps of a wave, and heavy documents no longer form the kernel's tail.
+__global__ void __launch_bounds__(64) sa_k_span_machine_wave(const SpanMachineParams p) {
+    __shared__ alignas(16) SpanEnt s_ents[SA_NSPANS];
+    u64* const s_col2 = (u64*)s_ents;                            // collected span c in the (dead) slot of span c: s_col2[2 c]
+    const u32 lane = threadIdx.x;
+    const u64 lt = (1ull << lane) - 1ull;
+    const u32 n_items = *p.in_cnt;
+    const u32 num_terms = (u32)p.T;
+    const int max_span_width = (int)(num_terms + p.slop);
+    for (u32 item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const u32 k = p.in_list[item];
+        u32 cursor = 0;
+        bool full = false;
+        u64 last_key = 0;
+        u32 my_sum = 0;                                          // lane t: summed popcounts of term t
+        __builtin_amdgcn_wave_barrier();
+        for (int t = 0; t < p.T; t++) {
+            const u32 ng = *p.n_heads[t];
+            if (k >= ng) continue;
+            const u32 lo = p.heads[t][k];
+            const u32 hi = (k + 1 < ng) ? p.heads[t][k + 1] : *p.n_cand[t];
+            const u32 curr_term_mask = 1u << t;
+            bool gave_up = false;
+            for (u32 wi = lo; wi < hi && !gave_up; wi++) {
+                const u64 w = p.cand[t][wi];
+                last_key = w >> SA_KEY_SHIFT;
+                const int payload_base = (int)(((w >> SA_LSB_BITS) & SA_LSB_MASK) * SA_LSB_BITS);
+                u32 bits = (u32)(w & SA_LSB_MASK);
+                if (lane == (u32)t) my_sum += (u32)__popc(bits);
+                while (bits != 0) {
+                    const int curr_posn = payload_base + (__ffs((int)bits) - 1);
+                    bits &= bits - 1;
+                    const int posn_mask = sa_posn_mask32(curr_posn);
+                    if (cursor >= SA_NSPANS) { full = true; break; }
+                    if (lane == 0) {
+                        SpanEnt fresh;
+                        fresh.terms = curr_term_mask; fresh.posns = posn_mask; fresh.beg = curr_posn; fresh.end = curr_posn;
+                        s_ents[cursor] = fresh;
+                    }
+                    const u32 end = cursor;
+                    cursor++;
+                    for (u32 base = 0; base < end; base += 64u) {
+                        const u32 si = base + lane;
+                        bool fork_it = false;
+                        SpanEnt e;
+                        e.terms = 0; e.posns = 0; e.beg = 0; e.end = 0;
+                        if (si < end) {
+                            e = s_ents[si];
+                            const u32 nt = (u32)__popc(e.terms), np = sa_popc_sext(e.posns);
+                            const bool skip = (nt < num_terms && np == num_terms) || (e.terms & curr_term_mask);
+                            if (!skip) {
+                                const int sp2 = e.posns | posn_mask;
+                                const u32 new_unique = sa_popc_sext(sp2);
+                                const int proposed = sa_iabs32(curr_posn - e.beg);
+                                if (np == new_unique || proposed > max_span_width) {
+                                    if (sp2 != e.posns) { e.posns = sp2; s_ents[si] = e; }   // the position bit stays even if rejected
+                                } else {
+                                    fork_it = true;
+                                }
+                            }
+                        }
+                        // forks of this chunk, in span order, behind what is already there
+                        const u64 fb = __ballot(fork_it);
+                        if (fb) {
+                            const u32 rank = (u32)__popcll(fb & lt), total = (u32)__popcll(fb);
+                            const u32 room = SA_NSPANS - cursor;                   // (cursor <= 512 here)
+                            if (fork_it) {
+                                const int sp2 = e.posns | posn_mask;
+                                if (rank < room) {
+                                    SpanEnt fork;
+                                    fork.terms = e.terms | curr_term_mask; fork.posns = sp2 & ~posn_mask;
+                                    fork.beg = e.beg; fork.end = e.end;
+                                    s_ents[cursor + rank] = fork;
+                                }
+                                e.terms |= curr_term_mask; e.posns = sp2; e.end = curr_posn;
+                                s_ents[si] = e;
+                            }
+                            // the reference takes the forks one by one: successes while there is room, then failures
+                            full = total > room;
+                            cursor += total < room ? total : room;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (cursor >= SA_NSPANS) break;
+                }
+                if (cursor >= SA_NSPANS) gave_up = true;
+            }
+        }
+        u32 incr;
+        if (full) {
+            u32 mn = 0;
+            for (int t = 0; t < p.T; t++) {
+                const u32 sp = (u32)__builtin_amdgcn_readlane((int)my_sum, t);
+                if (mn == 0 || sp < mn) mn = sp;
+            }
+            incr = mn;
+        } else {
+            // _collect_spans (spans.pyx:157-186), spans in order; the search for the first collected span a new one
+            // overlaps and undercuts runs over 64 collected spans at a time
+            u32 ncol = 0;
+            for (u32 si = 0; si < cursor; si++) {
+                const SpanEnt e = s_ents[si];
+                __builtin_amdgcn_wave_barrier();                 // every lane has the span before its slot is reused below
+                const bool complete = ((u32)__popc(e.terms) == num_terms) || (sa_popc_sext(e.posns) == num_terms);
+                const int b = e.beg, en = e.end;
+                const int width = sa_iabs32(en - b);
+                if (!complete || width >= max_span_width) continue;
+                bool replaced = false;
+                for (u32 cb0 = 0; cb0 < ncol && !replaced; cb0 += 64u) {
+                    const u32 c = cb0 + lane;
+                    bool hit = false;
+                    if (c < ncol) {
+                        const u64 cc = s_col2[2u * c];
+                        const int cb = (int)(cc >> 32), ce = (int)(cc & 0xFFFFFFFFull);
+                        hit = b <= ce && en >= cb && width < sa_iabs32(ce - cb);
+                    }
+                    const u64 hb = __ballot(hit);
+                    if (hb) {
+                        if (lane == (u32)__builtin_ctzll(hb)) s_col2[2u * c] = ((u64)(u32)b << 32) | (u64)(u32)en;
+                        replaced = true;
+                    }
+                }
+                if (!replaced) {
+                    if (lane == 0) s_col2[2u * ncol] = ((u64)(u32)b << 32) | (u64)(u32)en;
+                    ncol++;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            incr = ncol;
+        }
+        if (lane == 0 && incr && last_key < p.n_docs) atomicAdd(&p.counts[last_key], incr);
     }
 }
 
@@ -420,7 +572,7 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
     const size_t chunk_words = sa_compact_chunks((u32)(max_len + 1)) + 8;
     const size_t filt_bytes = filt.active ? (total_len + 64 * (size_t)T) * 8 : 0;
     const size_t need = (N + 64) * 8 + (total_len + 64 * T) * 13 + slab_bytes + chunk_words * 4 + filt_bytes + 64 * 1024 +
-                        ((size_t)terms_dev.len[0] + 64) * 4;
+                        ((size_t)terms_dev.len[0] + 64) * 8;
     void* scratch;
     SA_TRY(sa_index_scratch(ix, need, &scratch));
     char* base = (char*)scratch;
@@ -434,6 +586,7 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
     u64* col = (u64*)take((size_t)G * SA_NSPANS * sizeof(u64));
     unsigned char* flags = (unsigned char*)take(total_len + 64);
     u32* over_list = (u32*)take(((size_t)terms_dev.len[0] + 64) * 4);
+    u32* over_list2 = (u32*)take(((size_t)terms_dev.len[0] + 64) * 4);
     *d_out = running;
     SA_HIP(hipMemsetAsync(running, 0, N * sizeof(float), st));
     SA_HIP(hipMemsetAsync(counts, 0, N * sizeof(u32), st));
@@ -480,9 +633,13 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
     const char* fast_env = getenv("SA_SPAN_FAST");
     if (!(fast_env && atoi(fast_env) == 0) && terms_dev.len[0] > 0) {
         mp.over_list = over_list; mp.over_cnt = cnt + 4 * SA_SPAN_MAX_TERMS;
-        hipLaunchKernelGGL(sa_k_span_machine_lds, dim3((terms_dev.len[0] + 63u) / 64u), dim3(64), 0, st, mp);
+        hipLaunchKernelGGL((sa_k_span_machine_lds<SA_SPAN_LDS, false>), dim3((terms_dev.len[0] + 63u) / 64u), dim3(64), 0, st, mp);
+        mp.in_list = over_list; mp.in_cnt = cnt + 4 * SA_SPAN_MAX_TERMS;
+        const u32 g2 = std::min<u32>(8192u, terms_dev.len[0]);
+        hipLaunchKernelGGL(sa_k_span_machine_wave, dim3(g2), dim3(64), 0, st, mp);
+    } else {
+        hipLaunchKernelGGL(sa_k_span_machine, dim3(G / 64), dim3(64), 0, st, mp);       // every group, full tables in the global slab
     }
-    hipLaunchKernelGGL(sa_k_span_machine, dim3(G / 64), dim3(64), 0, st, mp);
     const u64 g = (N + 255) / 256;
     hipLaunchKernelGGL(sa_k_counts_to_float, dim3((u32)(g < 8192 ? (g ? g : 1) : 8192)), dim3(256), 0, st, counts, running, N);
     return SA_OK;
