@@ -63,7 +63,21 @@ def main():
         # BM25 scores against the oracle (tolerance of BASELINE.json's north_star: 1e-5 relative)
         s_dev = index.bm25_phrase_dense(phrases[1], slop=args.slop)
         s_cpu = orc.score(phrases[1], slop=args.slop)
+        # device-resident throughput: the same phrases as ONE slop batch -> BM25 -> top-10 (nothing but B x k results leaves HBM)
+        pb = index.phrase_batch(phrases, k=10, slop=args.slop)
+        pb.run()
+        tb = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            pb.run(sync=False)
+        index.synchronize()
+        batch_dt = (time.perf_counter() - tb) / reps
+        bs, bd = pb.fetch()
+        ws, wd = O.topk(orc.score(phrases[1], slop=args.slop), 10)
+        batch_ok = bool(np.array_equal(bs[1], ws) and np.array_equal(bd[1][ws > 0], wd[ws > 0]))
+        pb.close()
         res[f"{length}_terms"] = {
+            "slop_batch_phrases_per_s": round(len(phrases) / batch_dt, 1), "slop_batch_top10_matches_oracle": batch_ok,
             "phrases": len(phrases), "ms_per_phrase": round(dt / len(phrases) * 1e3, 3),
             "phrases_per_s": round(len(phrases) / dt, 1), "device_ms_per_phrase": round(kms / len(phrases), 4),
             "device_alg_GBps": round(kbytes / max(kms, 1e-9) / 1e6, 1),
