@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""Copy the outputs of scripts/gpu_full.sh from gpurun_out/ into profiles/ (tracked), named per round:
-bench JSON lines, rocprofv3 kernel stats, and the per-kernel means of the FETCH_SIZE / WRITE_SIZE
-PMC passes with the gfx950 correction -> profiles/pmc_traffic.json (read by bench.py)."""
+"""Copy the outputs of scripts/gpu_full_r2.sh from gpurun_out/ into profiles/ (tracked), named per round:
+bench JSON lines (which carry their own PMC traffic / L2 hit rates: bench.py profiles itself under rocprofv3),
+rocprofv3 kernel stats, and the SQ counters of the scoring kernels."""
 import csv
 import glob
 import json
@@ -13,7 +13,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 PROF = os.path.join(ROOT, "profiles")
-RND = sys.argv[1] if len(sys.argv) > 1 else "r01"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def last_json_line(path):
@@ -25,82 +25,55 @@ def last_json_line(path):
     return None
 
 
-def pmc_means(directory, counter):
-    rows = defaultdict(list)
-    files = sorted(glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
-    for f in files[-1:]:                                      # gpurun_out/ accumulates: the latest run only
-        for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name") == counter:
-                rows[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return {k: (len(v), sum(v) / len(v)) for k, v in rows.items()}
+def newest(pattern):
+    fs = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    return fs[-1] if fs else None
 
 
 def main():
     os.makedirs(PROF, exist_ok=True)
     for src, dst in [("bench.log", f"bench_{RND}.json"), ("bench_k100.log", f"bench_{RND}_k100.json"),
-                     ("bench_k1000.log", f"bench_{RND}_k1000.json"), ("phrase_bench.log", f"phrase_bench_{RND}.json"),
-                     ("slop_bench.log", f"slop_bench_{RND}.json"), ("dist1_rccl.log", f"bench_{RND}_dist1rank_1250k.json"),
+                     ("bench_k1000.log", f"bench_{RND}_k1000.json"), ("bench_nogroup.log", f"bench_{RND}_per_query_kernel.json"),
+                     ("bench_comm1.log", f"bench_{RND}_comm_1rank.json"), ("dist1_rccl.log", f"bench_{RND}_dist1rank_1250k.json"),
+                     ("phrase_bench.log", f"phrase_bench_{RND}.json"), ("slop_bench.log", f"slop_bench_{RND}.json"),
                      ("io_bench.log", f"io_bench_{RND}.json"), ("sim_bench.log", f"sim_bench_{RND}.json")]:
         j = last_json_line(os.path.join(OUT, src))
         if j is not None:
             json.dump(j, open(os.path.join(PROF, dst), "w"), indent=1)
             print("wrote", dst)
-    ab = os.path.join(OUT, "imp_ab.log")
+    ab = os.path.join(OUT, "group_ab.log")
     if os.path.exists(ab):
         lines = [ln for ln in open(ab).read().splitlines() if ln.startswith("{")]
         if lines:
-            open(os.path.join(PROF, f"imp_ab_{RND}.jsonl"), "w").write("\n".join(lines) + "\n")
-            print("wrote", f"imp_ab_{RND}.jsonl")
+            open(os.path.join(PROF, f"group_ab_{RND}.jsonl"), "w").write("\n".join(lines) + "\n")
+            print("wrote", f"group_ab_{RND}.jsonl")
     for sub, dst in [("prof_stats", f"{RND}_bench_kernel_stats.csv"), ("prof_phrase", f"{RND}_phrase_bench_kernel_stats.csv"),
                      ("prof_slop", f"{RND}_slop_bench_kernel_stats.csv")]:
-        fs = sorted(glob.glob(os.path.join(OUT, sub, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
-        if fs:
-            shutil.copy(fs[-1], os.path.join(PROF, dst))           # gpurun_out/ accumulates: the latest run
+        f = newest(os.path.join(OUT, sub, "**", "*kernel_stats.csv"))
+        if f:
+            shutil.copy(f, os.path.join(PROF, dst))
             print("wrote", dst)
-    fetch = pmc_means(os.path.join(OUT, "prof_pmc_fetch"), "FETCH_SIZE")
-    write = pmc_means(os.path.join(OUT, "prof_pmc_write"), "WRITE_SIZE")
-    if fetch:
-        with open(os.path.join(PROF, f"{RND}_bench_pmc_summary.csv"), "w", newline="") as f:
-            w = csv.writer(f)
-            w.writerow(["kernel", "counter", "dispatches", "mean_counter_value_KiB_per_dispatch"])
-            for name, (n, mean) in fetch.items():
-                w.writerow([name, "FETCH_SIZE", n, round(mean, 3)])
-            for name, (n, mean) in write.items():
-                w.writerow([name, "WRITE_SIZE", n, round(mean, 3)])
-        def corrected(name):
-            fk = fetch.get(name, (0, 0.0))[1]
-            wk = write.get(name, (0, 0.0))[1]
-            return 2 * fk * 1024 + wk * 1024, fk, wk
-        exh = [k for k in fetch if "sa_k_bm25_tiles<" in k and "list" not in k]
-        pruned = [k for k in fetch if "sa_k_sparse_" in k or "sa_k_bm25_tiles_list" in k]
-        bench = last_json_line(os.path.join(OUT, "bench.log")) or {}
-        cfg = bench.get("config", {})
-        out = {"docs": cfg.get("docs"), "queries": cfg.get("queries_per_step"), "n_gpus": 1,
-               "tile_docs": cfg.get("tile_docs"), "k": cfg.get("k"),
-               "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section; "
-                             "calibrated on sa_k_compact_count<PostingHeads>, a pure stream of the index words); "
-                             "WRITE_SIZE taken as reported; per kernel = mean over its dispatches"}
-        if exh:
-            tot, fk, wk = corrected(exh[0])
-            out["exhaustive_hbm_bytes_per_launch"] = int(tot)
-            out["exhaustive_fetch_size_KiB_raw"] = fk
-            out["exhaustive_write_size_KiB_raw"] = wk
-        if pruned:
-            out["pruned_hbm_bytes_per_step"] = int(sum(corrected(k)[0] for k in pruned))
-            out["pruned_kernels"] = {k.split("(")[0]: int(corrected(k)[0]) for k in pruned}
-        json.dump(out, open(os.path.join(PROF, "pmc_traffic.json"), "w"), indent=1)
-        print("wrote pmc_traffic.json")
-        # bench.py reads profiles/pmc_traffic.json at run time, i.e. the PREVIOUS pass's counters (none at all
-        # when the configuration changed): put this pass's counters into this pass's bench record
-        bpath = os.path.join(PROF, f"bench_{RND}.json")
-        if os.path.exists(bpath) and cfg.get("docs") == out["docs"]:
-            b = json.load(open(bpath))
-            if "exhaustive_hbm_bytes_per_launch" in out:
-                b["roofline"]["traffic"] = out["exhaustive_hbm_bytes_per_launch"]
-            if "pruned_hbm_bytes_per_step" in out and "dynamic_pruning" in b:
-                b["dynamic_pruning"]["roofline"]["traffic"] = out["pruned_hbm_bytes_per_step"]
-            json.dump(b, open(bpath, "w"), indent=1)
-            print("updated traffic in", os.path.basename(bpath))
+    # SQ counters of the scoring kernels (two passes of 8 counters), mean per dispatch
+    sq = {}
+    for sub in ("prof_grp_sq", "prof_grp_sq2"):
+        f = newest(os.path.join(OUT, sub, "**", "*counter_collection.csv"))
+        if not f:
+            continue
+        acc = defaultdict(lambda: defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            if "bm25" in k or "topk_merge" in k:
+                acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            sq.setdefault(k, {}).update({c: round(sum(x) / len(x)) for c, x in v.items()})
+            sq[k]["dispatches"] = len(next(iter(v.values())))
+    if sq:
+        out = {"command": "rocprofv3 --pmc <8 SQ counters> --kernel-trace -- python scripts/group_ab.py --ks 10 --only 1 --qsets baseline --steps 2 "
+                          "(two passes); 10M docs, 256 x 4-term BASELINE queries, top-10, grouped exhaustive path; mean per dispatch; "
+                          "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)",
+               "kernels": sq}
+        json.dump(out, open(os.path.join(PROF, f"{RND}_scoring_kernels_sq_counters.json"), "w"), indent=1)
+        print("wrote", f"{RND}_scoring_kernels_sq_counters.json")
 
 
 if __name__ == "__main__":
