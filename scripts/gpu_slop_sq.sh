@@ -1,0 +1,12 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+mkdir -p $O; rm -rf $O/prof_slop_sq $O/prof_slop_sq2
+export TMPDIR=/tmp
+cd /tmp
+T=${TERMS:-2}
+( timeout 150 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/prof_slop_sq -- python $R/scripts/slop_heavy.py --terms $T --reps 2 ) > $O/prof_slop_sq.log 2>&1
+( timeout 150 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/prof_slop_sq2 -- python $R/scripts/slop_heavy.py --terms $T --reps 2 ) > $O/prof_slop_sq2.log 2>&1
+find $O -name "*.db" -delete 2>/dev/null
+tail -2 $O/prof_slop_sq.log
+exit 0

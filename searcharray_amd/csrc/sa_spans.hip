@@ -105,10 +105,13 @@ __device__ __forceinline__ u32 sa_header_triple_dd(const u64* __restrict__ a, u3
 }
 
 // candidate predicate of one header (see the top of the file); m[i] = sa_header_triple of term i
+template <int TT>
 __device__ __forceinline__ bool sa_span_keep(const u32* m, int T, bool wrap) {
     const bool a0m = m[0] & 1u, a0 = m[0] & 2u, a0p = m[0] & 4u;
     bool L = true, R = true, Rm = true, Lp = true;   // L(h), R(h), R(h-1), L(h+1)
-    for (int i = 1; i < T; i++) {
+#pragma unroll
+    for (int i = 1; i < (TT ? TT : SA_SPAN_MAX_TERMS); i++) {
+        if (i >= T) break;
         const bool bim = m[i] & 1u, bi = m[i] & 2u, bip = m[i] & 4u;
         L &= (a0 && bi) || (bi && a0m) || (a0 && bim);
         R &= (a0 && bi) || (a0 && bip) || (bi && a0p);
@@ -118,9 +121,17 @@ __device__ __forceinline__ bool sa_span_keep(const u32* m, int T, bool wrap) {
     return L || R || Rm || (!wrap && Lp);
 }
 
-// header 0 in L?  (the `L - 1` widening is lost then, see the top of the file)
-__global__ void sa_k_span_wrap_flag(const SpanTerms st, u32* __restrict__ wrap) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// header 0 in L?  (the `L - 1` widening is lost then, see the top of the file).  Also clears the query's device
+// counters (cnt layout: sa_span_counts_device), so no separate fill is enqueued for them.
+#define SA_SPAN_NBINS 32                 // work bins of the fast pass (positions of a document group, saturated)
+#define SA_SPAN_CNT_BINS (5 * SA_SPAN_MAX_TERMS)                     // [.. + NBINS) bin sizes, [.. + 2 NBINS) bin cursors
+#define SA_SPAN_CNT_WORDS (5 * SA_SPAN_MAX_TERMS + 2 * SA_SPAN_NBINS)
+#define SA_SPAN_CNT_WRAP (2 * SA_SPAN_MAX_TERMS)
+__global__ void __launch_bounds__(256) sa_k_span_wrap_flag(const SpanTerms st, u32* __restrict__ cnt) {
+    if (blockIdx.x != 0) return;
+    if (cnt && threadIdx.x < SA_SPAN_CNT_WORDS && threadIdx.x != SA_SPAN_CNT_WRAP) cnt[threadIdx.x] = 0u;
+    if (threadIdx.x != 0) return;
+    u32* wrap = cnt + SA_SPAN_CNT_WRAP;
     bool L = true;
     const u32 m0 = sa_header_triple(st.words[0], st.len[0], 0ull);
     for (int i = 1; i < st.T; i++) {
@@ -132,36 +143,203 @@ __global__ void sa_k_span_wrap_flag(const SpanTerms st, u32* __restrict__ wrap) 
 }
 
 // stage 1a: keep-flag of every word of every term (one launch; the predicate costs one search
-// per phrase term and is evaluated once, the compactions below only read the flags)
+// per phrase term and is evaluated once, the compaction below only reads the flags).  The same launch clears the
+// dense per-doc counts the state machines accumulate into.  TT: the number of terms when it is 2, 3 or 4 (the loops
+// over the terms unroll and the per-term results stay in registers -- the generic code spends most of its
+// instructions on indexing them), 0: any number.
+template <int TT>
 __global__ void __launch_bounds__(256)
-sa_k_span_flags(const SpanTerms st, const u32* __restrict__ wrap, unsigned char* __restrict__ flags) {
-    const u32 total = st.off[st.T];
+sa_k_span_flags(const SpanTerms st, const u32* __restrict__ wrap, unsigned char* __restrict__ flags, float* __restrict__ counts) {
+    const int T = TT ? TT : st.T;
+    const u32 total = st.off[T];
     const bool wr = *wrap != 0;
+    for (u64 d = (u64)blockIdx.x * blockDim.x + threadIdx.x; d < st.n_docs; d += (u64)gridDim.x * blockDim.x) counts[d] = 0.f;
     for (u32 g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
         int t = 0;
-        while (t + 1 < st.T && g >= st.off[t + 1]) t++;
+#pragma unroll
+        for (int i = 1; i < (TT ? TT : SA_SPAN_MAX_TERMS); i++) t += (i < T && g >= st.off[i]) ? 1 : 0;
         const u64 h = st.words[t][g - st.off[t]] & SA_HEADER_MASK;
-        u32 m[SA_SPAN_MAX_TERMS];
+        u32 m[TT ? TT : SA_SPAN_MAX_TERMS];
         bool possible = true;
-        for (int i = 0; i < st.T; i++) m[i] = 0;
-        for (int i = 0; i < st.T && possible; i++) {
+#pragma unroll
+        for (int i = 0; i < (TT ? TT : SA_SPAN_MAX_TERMS); i++) m[i] = 0;
+        // The probes are chains of dependent loads (directory entry -> the doc's first words), and the kernel is bound
+        // by their latency: those of the first four terms are issued together -- all directory entries, then the
+        // first two words of the doc in every term -- instead of term after term.
+        constexpr int TU = 4;
+        const u64 unit = 1ull << SA_LSB_BITS;
+        const u64 doc = h >> SA_KEY_SHIFT, hm = h - unit, hp = h + unit;
+        const bool has_prev = (h & ~SA_KEY_MASK) != 0;
+        const bool plain = ((h >> SA_LSB_BITS) & SA_LSB_MASK) != SA_LSB_MASK && doc < st.n_docs;   // (else: sa_header_triple_dd's own handling)
+        u32 jj[TU];
+        u64 x0[TU], x1[TU];
+        bool via[TU];
+#pragma unroll
+        for (int i = 0; i < TU; i++) {
+            via[i] = i < T && st.dd[i] != nullptr && plain;
+            jj[i] = via[i] ? st.dd[i][doc] : SA_DD_ABSENT;
+        }
+#pragma unroll
+        for (int i = 0; i < TU; i++) {
+            const bool have = via[i] && jj[i] != SA_DD_ABSENT;
+            x0[i] = (have && jj[i] < st.len[i]) ? st.words[i][jj[i]] : ~0ull;
+            x1[i] = (have && jj[i] + 1u < st.len[i]) ? st.words[i][jj[i] + 1u] : ~0ull;
+        }
+#pragma unroll
+        for (int i = 0; i < (TT && TT < TU ? TT : TU); i++) {
+            if (i < T && possible) {
+                if (via[i]) {
+                    u32 bits = 0;
+                    auto step = [&](const u64 xw) -> bool {
+                        const u64 x = xw & SA_HEADER_MASK;
+                        if ((x >> SA_KEY_SHIFT) != doc || x > hp) return false;
+                        if (x == h) bits |= 2u;
+                        else if (has_prev && x == hm) bits |= 1u;
+                        else if (x == hp) bits |= 4u;
+                        return true;
+                    };
+                    if (step(x0[i]) && step(x1[i]))
+                        for (u32 j = jj[i] + 2u; j < st.len[i]; j++)
+                            if (!step(st.words[i][j])) break;
+                    m[i] = bits;
+                } else {
+                    m[i] = st.dd[i] ? sa_header_triple_dd(st.words[i], st.len[i], st.dd[i], st.n_docs, h)
+                                    : sa_header_triple(st.words[i], st.len[i], h);
+                }
+                // every set needs term 0 and term i around h: nothing there -> no candidate
+                if (m[i] == 0) possible = false;
+            }
+        }
+        for (int i = TU; i < T && possible; i++) {
             m[i] = st.dd[i] ? sa_header_triple_dd(st.words[i], st.len[i], st.dd[i], st.n_docs, h)
                             : sa_header_triple(st.words[i], st.len[i], h);
-            // every set needs term 0 and term i around h: nothing there -> no candidate
             if (m[i] == 0) possible = false;
         }
-        flags[g] = (possible && sa_span_keep(m, st.T, wr)) ? 1 : 0;
+        flags[g] = (possible && sa_span_keep<TT>(m, T, wr)) ? 1 : 0;
     }
 }
 
-// stage 1b: candidate words of term t, compacted into out (stable)
-struct SpanCandidates {
-    const u64* words;
-    const unsigned char* flags;
-    u64* out;
-    __device__ __forceinline__ bool flag(u32 i) const { return flags[i] != 0; }
-    __device__ __forceinline__ void emit(u32 i, u32 pos) const { out[pos] = words[i]; }
-};
+// stage 1b: ONE stable compaction for all terms and both outputs -- the candidate words of each term, and the index
+// (in the compacted array) of the first candidate word of each document: count per chunk, a scan per (term, output),
+// emit.  A candidate word opens a document group iff no earlier word of the same doc (they are neighbours in the
+// term's list, a handful at most) is a candidate.
+struct SpanChunkTab { u32 coff[SA_SPAN_MAX_TERMS + 1]; };      // chunks of term t: [coff[t], coff[t + 1])
+struct SpanCompactOut { u64* cand[SA_SPAN_MAX_TERMS]; u32* heads[SA_SPAN_MAX_TERMS]; unsigned char* gpos[SA_SPAN_MAX_TERMS]; };   // gpos: positions per document group (saturated)
+
+__device__ __forceinline__ bool sa_span_opens_doc(const u64* __restrict__ w, const unsigned char* __restrict__ f, u32 i) {
+    const u64 doc = w[i] >> SA_KEY_SHIFT;
+    for (u32 j = i; j > 0;) {
+        j--;
+        if ((w[j] >> SA_KEY_SHIFT) != doc) break;
+        if (f[j]) return false;
+    }
+    return true;
+}
+
+__global__ void __launch_bounds__(SA_CT)
+sa_k_span_compact_count(const SpanTerms st, const SpanChunkTab ck, const unsigned char* __restrict__ flags,
+                        u32* __restrict__ chunk_counts, u32 n_chunks) {
+    __shared__ u32 red[SA_CW + 1];
+    for (u32 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        int t = 0;
+        while (c >= ck.coff[t + 1]) t++;
+        const u32 base = (c - ck.coff[t]) * SA_CHUNK, n = st.len[t];
+        const u64* w = st.words[t];
+        const unsigned char* f = flags + st.off[t];
+        u32 nc = 0, nh = 0;
+#pragma unroll
+        for (int j = 0; j < SA_CI; j++) {
+            const u32 i = base + j * SA_CT + threadIdx.x;
+            if (i < n && f[i]) {
+                nc++;
+                if (sa_span_opens_doc(w, f, i)) nh++;
+            }
+        }
+        const u32 tot = sa_block_sum<SA_CW>(nc | (nh << 16), red);          // (a chunk has 2048 elements)
+        if (threadIdx.x == 0) { chunk_counts[c] = tot & 0xFFFFu; chunk_counts[n_chunks + c] = tot >> 16; }
+    }
+}
+
+// block b: exclusive scan of the chunk counts of term b % T, output b / T; totals -> cnt[t] / cnt[16 + t]
+__global__ void __launch_bounds__(1024)
+sa_k_span_compact_scan(const SpanChunkTab ck, int T, u32* __restrict__ chunk_counts, u32 n_chunks, u32* __restrict__ cnt) {
+    __shared__ u32 red[16];
+    const int t = (int)blockIdx.x % T, kind = (int)blockIdx.x / T;
+    u32* counts = chunk_counts + (u32)kind * n_chunks + ck.coff[t];
+    const u32 nck = ck.coff[t + 1] - ck.coff[t];
+    u32 carry = 0;
+    for (u32 base = 0; base < nck; base += 1024) {
+        const u32 i = base + threadIdx.x;
+        const u32 v = i < nck ? counts[i] : 0u;
+        u32 tot;
+        const u32 ex = sa_block_excl_scan<16>(v, red, &tot);
+        if (i < nck) counts[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) cnt[kind * SA_SPAN_MAX_TERMS + t] = carry;
+}
+
+__global__ void __launch_bounds__(SA_CT)
+sa_k_span_compact_emit(const SpanTerms st, const SpanChunkTab ck, const unsigned char* __restrict__ flags,
+                       const u32* __restrict__ chunk_off, u32 n_chunks, const SpanCompactOut out) {
+    __shared__ u32 wc[SA_CI][SA_CW];
+    const int lane = sa_lane(), wave = sa_wave_id();
+    const u64 lt = (1ull << lane) - 1ull;
+    for (u32 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        int t = 0;
+        while (c >= ck.coff[t + 1]) t++;
+        const u32 base = (c - ck.coff[t]) * SA_CHUNK, n = st.len[t];
+        const u64* w = st.words[t];
+        const unsigned char* f = flags + st.off[t];
+        u32 rank[SA_CI];                                           // candidate rank | head rank << 16, within the wave's round
+        u32 mine = 0;                                              // bit j: candidate; bit 8 + j: opens a document
+#pragma unroll
+        for (int j = 0; j < SA_CI; j++) {
+            const u32 i = base + j * SA_CT + threadIdx.x;
+            const bool fl = i < n && f[i];
+            const bool hd = fl && sa_span_opens_doc(w, f, i);
+            const u64 bc = __ballot(fl), bh = __ballot(hd);
+            rank[j] = (u32)__popcll(bc & lt) | ((u32)__popcll(bh & lt) << 16);
+            if (lane == 0) wc[j][wave] = (u32)__popcll(bc) | ((u32)__popcll(bh) << 16);
+            mine |= ((fl ? 1u : 0u) << j) | ((hd ? 1u : 0u) << (8 + j));
+        }
+        __syncthreads();
+        u32 off_c = chunk_off[c], off_h = chunk_off[n_chunks + c];
+        u64* cand = out.cand[t];
+        u32* heads = out.heads[t];
+#pragma unroll
+        for (int j = 0; j < SA_CI; j++) {
+#pragma unroll
+            for (int wv = 0; wv < SA_CW; wv++) {
+                if (wv == wave && ((mine >> j) & 1u)) {
+                    const u32 pos = off_c + (rank[j] & 0xFFFFu);
+                    cand[pos] = w[base + j * SA_CT + threadIdx.x];
+                    if ((mine >> (8 + j)) & 1u) {
+                        // opens a document group: its index in the compacted array, and how many positions the group holds
+                        const u32 i = base + j * SA_CT + threadIdx.x;
+                        const u64 doc = w[i] >> SA_KEY_SHIFT;
+                        // (a group rarely has more than three words: the next two are requested together)
+                        const u32 i1 = i + 1u < n ? i + 1u : i, i2 = i + 2u < n ? i + 2u : i;
+                        const u64 wa = w[i], wb = w[i1], wc = w[i2];
+                        const bool fb = f[i1] != 0, fc = f[i2] != 0;
+                        u32 np = (u32)__popc((u32)(wa & SA_LSB_MASK));
+                        const bool sb = i1 != i && (wb >> SA_KEY_SHIFT) == doc, sc = sb && i2 != i1 && (wc >> SA_KEY_SHIFT) == doc;
+                        if (sb && fb) np += (u32)__popc((u32)(wb & SA_LSB_MASK));
+                        if (sc && fc) np += (u32)__popc((u32)(wc & SA_LSB_MASK));
+                        if (sc)
+                            for (u32 x = i + 3u; x < n && (w[x] >> SA_KEY_SHIFT) == doc; x++)
+                                if (f[x]) np += (u32)__popc((u32)(w[x] & SA_LSB_MASK));
+                        heads[off_h + (rank[j] >> 16)] = pos;
+                        out.gpos[t][off_h + (rank[j] >> 16)] = (unsigned char)(np < 255u ? np : 255u);
+                    }
+                }
+                off_c += wc[j][wv] & 0xFFFFu;
+                off_h += wc[j][wv] >> 16;
+            }
+        }
+        __syncthreads();
+    }
+}
 
 // document-group heads of a compacted candidate array
 struct DocHeads {
@@ -185,13 +363,21 @@ struct SpanMachineParams {
     u32 n_threads;                            // G: resident threads, thread g owns column g of the slabs
     SpanEnt* ents;                            // [SA_NSPANS][G] span tables, interleaved for coalescing
     u64* col;                                 // [SA_NSPANS][G] collected (beg, end) pairs
-    u32* counts;                              // dense per-doc counts (atomically accumulated)
+    u32* counts;                              // dense per-doc counts (atomically accumulated) -- the kernel-level mirror; or
+    float* fcounts;                           //   the same as floats (the dense result itself: small integers, exact in any order)
     u64 n_docs;
     u32* over_list;                           // LDS passes: document groups whose table outgrew the column; full-table
     u32* over_cnt;                            //   pass: the groups to take (null: all of them)
-    const u32* in_list;                       // second LDS pass: the groups the first one abandoned
+    const u32* in_list;                       // heavy pass: the groups the fast pass abandoned
     const u32* in_cnt;
+    const u32* order;                         // fast pass: the document groups sorted by work (sa_k_span_bin_*), or null
 };
+
+__device__ __forceinline__ void sa_span_add(const SpanMachineParams& p, u64 key, u32 incr) {
+    if (incr == 0 || key >= p.n_docs) return;
+    if (p.fcounts) unsafeAtomicAdd(&p.fcounts[key], (float)incr);
+    else atomicAdd(&p.counts[key], incr);
+}
 
 // reference spans.pyx:108-109 as compiled: `1 << (p % 64)` is a 32-bit shift (count mod 32) whose
 // int result is sign-extended to 64 bits.  Kept as the int32; OR / AND-NOT commute with the sign
@@ -215,6 +401,40 @@ __device__ __forceinline__ int sa_iabs32(int v) { return v < 0 ? -v : v; }
 //  slab -- remains as the kernel-level mirror's machine and as the SA_SPAN_FAST=0 route the tests compare with.)
 // Returns false when the table capacity CAP_E / CAP_C is exceeded before the reference's own limit (fast pass only).
 #define SA_SPAN_LDS 12
+#define SA_SPAN_PMAX 16
+
+// _collect_spans, spans.pyx:157-186: walk the spans in order; a complete span narrower than max_width either
+// replaces the first collected span it overlaps AND is shorter than, or is appended.  Returns false when more than
+// CAP_C spans would be collected (fast pass only).
+template <int CAP_C, class Ents, class Col>
+__device__ __forceinline__ bool sa_span_collect(const Ents& ents, const Col& col, const u32 cursor, const u32 num_terms,
+                                                const int max_span_width, u32* n_out) {
+    u32 ncol = 0;
+    for (u32 si = 0; si < cursor; si++) {
+        const SpanEnt e = ents[si];
+        const bool complete = ((u32)__popc(e.terms) == num_terms) || (sa_popc_sext(e.posns) == num_terms);
+        const int b = e.beg, en = e.end;
+        const int width = sa_iabs32(en - b);
+        if (!complete || width >= max_span_width) continue;
+        bool replaced = false;
+        for (u32 c = 0; c < ncol; c++) {
+            const u64 cc = col[c];
+            const int cb = (int)(cc >> 32), ce = (int)(cc & 0xFFFFFFFFull);
+            if (b <= ce && en >= cb && width < sa_iabs32(ce - cb)) {
+                col[c] = ((u64)(u32)b << 32) | (u64)(u32)en;
+                replaced = true;
+                break;
+            }
+        }
+        if (!replaced) {
+            if (CAP_C < SA_NSPANS && ncol >= (u32)CAP_C) return false;
+            col[ncol] = ((u64)(u32)b << 32) | (u64)(u32)en;
+            ncol++;
+        }
+    }
+    *n_out = ncol;
+    return true;
+}
 
 template <int CAP_E, int CAP_C, class Ents, class Col>
 __device__ __forceinline__ bool sa_span_doc(const SpanMachineParams& p, const u32 k, const Ents& ents, const Col& col,
@@ -290,45 +510,78 @@ __device__ __forceinline__ bool sa_span_doc(const SpanMachineParams& p, const u3
         for (int t = 0; t < p.T; t++) if (mn == 0 || sum_pop[t] < mn) mn = sum_pop[t];
         incr = mn;
     } else {
-        // _collect_spans, spans.pyx:157-186: walk the spans in order; a complete span narrower than
-        // max_width either replaces the first collected span it overlaps AND is shorter than, or is
-        // appended.
-        u32 ncol = 0;
-        for (u32 si = 0; si < cursor; si++) {
-            const SpanEnt e = ents[si];
-            const bool complete = ((u32)__popc(e.terms) == num_terms) || (sa_popc_sext(e.posns) == num_terms);
-            const int b = e.beg, en = e.end;
-            const int width = sa_iabs32(en - b);
-            if (!complete || width >= max_span_width) continue;
-            bool replaced = false;
-            for (u32 c = 0; c < ncol; c++) {
-                const u64 cc = col[c];
-                const int cb = (int)(cc >> 32), ce = (int)(cc & 0xFFFFFFFFull);
-                if (b <= ce && en >= cb && width < sa_iabs32(ce - cb)) {
-                    col[c] = ((u64)(u32)b << 32) | (u64)(u32)en;
-                    replaced = true;
-                    break;
-                }
-            }
-            if (!replaced) {
-                if (CAP_C < SA_NSPANS && ncol >= (u32)CAP_C) return false;
-                col[ncol] = ((u64)(u32)b << 32) | (u64)(u32)en;
-                ncol++;
-            }
-        }
-        incr = ncol;
+        if (!sa_span_collect<CAP_C>(ents, col, cursor, num_terms, max_span_width, &incr)) return false;
     }
     *incr_out = incr;
     *key_out = last_key;
     return true;
 }
 
-// LDS passes: tables of CE spans / CC collected spans per lane.  LISTED = false: thread k = document group k (the
-// first pass); LISTED = true: a resident grid strides over the groups the previous pass abandoned (p.in_list).
-// Groups whose table outgrows this pass's column go to p.over_list.
-template <int CE, bool LISTED>
-__global__ void __launch_bounds__(64) sa_k_span_machine_lds(const SpanMachineParams p) {
-    __shared__ alignas(16) SpanEnt s_ents[CE * 64];
+// Work bins for the fast pass.  With one document per lane a wave runs as long as its busiest document, and the
+// machine's work grows with the square of a document's positions: taken in index order, a wave's busiest document
+// has ~4 x the average work.  So the document groups are sorted by their number of positions (a counting sort over
+// SA_SPAN_NBINS bins: sizes, then a scatter through per-bin cursors; busiest bins first) and a wave takes 64
+// neighbours of that order.
+struct SpanBinParams {
+    const unsigned char* gpos[SA_SPAN_MAX_TERMS];
+    const u32* n_heads[SA_SPAN_MAX_TERMS];
+    int T;
+    unsigned char* bin;                       // [n_heads[0]] bin of each document group
+    u32* sizes;                               // [NBINS] (zeroed by sa_k_span_wrap_flag)
+    u32* cursors;                             // [NBINS]
+    u32* order;                               // [n_heads[0]] out: document groups, busiest bin first
+};
+
+__global__ void __launch_bounds__(1024) sa_k_span_bin_count(const SpanBinParams bp) {
+    __shared__ u32 h[SA_SPAN_NBINS];
+    if (threadIdx.x < SA_SPAN_NBINS) h[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 n = *bp.n_heads[0];
+    const u32 per = (n + gridDim.x - 1) / gridDim.x;
+    const u32 lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (u32 k = lo + threadIdx.x; k < hi; k += blockDim.x) {
+        u32 np = 0;
+        for (int t = 0; t < bp.T; t++) if (k < *bp.n_heads[t]) np += bp.gpos[t][k];
+        const u32 b = np < (u32)SA_SPAN_NBINS - 1u ? np : (u32)SA_SPAN_NBINS - 1u;
+        bp.bin[k] = (unsigned char)b;
+        atomicAdd(&h[b], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < SA_SPAN_NBINS && h[threadIdx.x]) atomicAdd(&bp.sizes[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(1024) sa_k_span_bin_scatter(const SpanBinParams bp) {
+    __shared__ u32 h[SA_SPAN_NBINS], at[SA_SPAN_NBINS];
+    if (threadIdx.x < SA_SPAN_NBINS) h[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 n = *bp.n_heads[0];
+    const u32 per = (n + gridDim.x - 1) / gridDim.x;
+    const u32 lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (u32 k = lo + threadIdx.x; k < hi; k += blockDim.x) atomicAdd(&h[bp.bin[k]], 1u);
+    __syncthreads();
+    if (threadIdx.x < SA_SPAN_NBINS) {
+        u32 start = 0;                                           // bins in descending order
+        for (u32 b = threadIdx.x + 1u; b < (u32)SA_SPAN_NBINS; b++) start += bp.sizes[b];
+        at[threadIdx.x] = h[threadIdx.x] ? start + atomicAdd(&bp.cursors[threadIdx.x], h[threadIdx.x]) : 0u;
+    }
+    __syncthreads();
+    for (u32 k = lo + threadIdx.x; k < hi; k += blockDim.x) bp.order[atomicAdd(&at[bp.bin[k]], 1u)] = k;
+}
+
+// Fast pass: thread k = document group k, span table of CE entries per lane in LDS.
+//
+// The reference's machine is four nested loops (terms, words, position bits, spans); with one document per lane a
+// wave would pay, at every level, for the lane with the most iterations at THAT level -- the product of the maxima,
+// ~10 x what its busiest document needs.  So the document is first unrolled into its position list (term, position;
+// in the machine's order: term by term, word by word, bit by bit; PMAX entries per lane in LDS), and the machine then
+// runs as ONE flat loop per lane whose iteration is "take the next position if the current one has visited all its
+// spans, then visit one span": a wave runs as long as its busiest document, and the loop holds no global load.
+// Documents with more than PMAX positions or more than CE spans are ABANDONED (nothing counted) to p.over_list for
+// the heavy pass -- one counter update per wave, the abandoned lanes take consecutive slots.
+template <int CE, int PMAX>
+__global__ void __launch_bounds__(64) sa_k_span_machine_flat(const SpanMachineParams p) {
+    __shared__ alignas(16) SpanEnt s_ents[(CE + 1) * 64];        // lane L's entry i at (i * 64 + L): conflict-free whatever i each lane is at; row CE: scratch
+    __shared__ u32 s_pos[PMAX * 64];                             // term << 24 | position
     struct EntCol {
         SpanEnt* base;
         struct Ref {
@@ -344,18 +597,132 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_lds(const SpanMachinePar
         u64* base;
         __device__ __forceinline__ u64& operator[](u32 i) const { return base[i * 128u]; }
     };
-    const u32 n_items = LISTED ? *p.in_cnt : *p.n_heads[0];
-    const u32 stride = LISTED ? gridDim.x * blockDim.x : 0xFFFFFFFFu;
-    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += stride) {
-        const u32 k = LISTED ? p.in_list[i] : i;
-        u32 incr = 0;
-        u64 key = 0;
-        if (sa_span_doc<CE, CE>(p, k, EntCol{s_ents + threadIdx.x}, ColCol{(u64*)(s_ents + threadIdx.x)}, &incr, &key)) {
-            if (incr && key < p.n_docs) atomicAdd(&p.counts[key], incr);
-        } else {
-            p.over_list[atomicAdd(p.over_cnt, 1u)] = k;
+    const u32 lane = threadIdx.x;
+    const u32 n_items = *p.n_heads[0];
+    const u32 item = blockIdx.x * 64u + lane;
+    const u32 k = (item < n_items && p.order) ? p.order[item] : item;
+    const u32 num_terms = (u32)p.T;
+    const int max_span_width = (int)(num_terms + p.slop);
+    const EntCol ents{s_ents + lane};
+    bool abandoned = false;
+    if (item < n_items) {
+        // ---- the document's positions, in the machine's order.  The loads are what this kernel waits for (group
+        //      bounds -> words, per term), so those of the first four terms are issued together: all the bounds, then
+        //      the first two words of every term; further words and further terms (rare) take the plain loop.
+        u32 npos = 0;
+        u64 last_key = 0;
+        auto push_word = [&](const int t, const u64 w) {
+            last_key = w >> SA_KEY_SHIFT;
+            const u32 payload_base = (u32)((w >> SA_LSB_BITS) & SA_LSB_MASK) * (u32)SA_LSB_BITS;
+            u32 bits = (u32)(w & SA_LSB_MASK);
+            const u32 nb = (u32)__popc(bits);
+            if (npos + nb <= (u32)PMAX) {
+                u32 q = npos;
+                while (bits != 0) {
+                    s_pos[q * 64u + lane] = ((u32)t << 24) | (payload_base + (u32)(__ffs((int)bits) - 1));
+                    bits &= bits - 1;
+                    q++;
+                }
+            }
+            npos += nb;
+        };
+        constexpr int TU = 4;
+        u32 lo[TU], hi[TU];
+        u64 w0[TU], w1[TU];
+#pragma unroll
+        for (int t = 0; t < TU; t++) {
+            lo[t] = 0; hi[t] = 0;
+            if (t < p.T) {
+                const u32 ng = *p.n_heads[t];
+                if (k < ng) {                                    // (else: this term has no k-th document group)
+                    lo[t] = p.heads[t][k];
+                    hi[t] = (k + 1 < ng) ? p.heads[t][k + 1] : *p.n_cand[t];
+                }
+            }
         }
-        if (!LISTED) break;
+#pragma unroll
+        for (int t = 0; t < TU; t++) {
+            w0[t] = 0; w1[t] = 0;
+            if (hi[t] > lo[t]) w0[t] = p.cand[t][lo[t]];
+            if (hi[t] > lo[t] + 1u) w1[t] = p.cand[t][lo[t] + 1u];
+        }
+#pragma unroll
+        for (int t = 0; t < TU; t++) {
+            if (hi[t] > lo[t]) push_word(t, w0[t]);
+            if (hi[t] > lo[t] + 1u) push_word(t, w1[t]);
+            for (u32 wi = lo[t] + 2u; wi < hi[t]; wi++) push_word(t, p.cand[t][wi]);
+        }
+        for (int t = TU; t < p.T; t++) {
+            const u32 ng = *p.n_heads[t];
+            if (k >= ng) continue;
+            const u32 l = p.heads[t][k];
+            const u32 h = (k + 1 < ng) ? p.heads[t][k + 1] : *p.n_cand[t];
+            for (u32 wi = l; wi < h; wi++) push_word(t, p.cand[t][wi]);
+        }
+        abandoned = npos > (u32)PMAX;
+        // ---- the machine (sa_span_doc's loops, flattened).  The iteration is branch-free -- the kernel is bound by
+        //      instruction issue, and on divergent branches most of what is issued is exec-mask bookkeeping: every
+        //      lane computes both outcomes and writes through selected addresses, row CE of the table being a
+        //      scratch row for the writes that do not happen.
+        u32 cursor = 0, pi = 0, si = 0, end = 0, curr_term_mask = 0;
+        int curr_posn = 0, posn_mask = 0;
+        bool alive = !abandoned;
+        while (alive) {
+            // the current position has visited every span that existed before it: take the next one
+            const bool need = si >= end;
+            const bool done = need && pi >= npos;
+            const bool fresh_it = need && !done;
+            const u32 pv = s_pos[(pi < (u32)PMAX ? pi : (u32)PMAX - 1u) * 64u + lane];
+            curr_posn = fresh_it ? (int)(pv & 0xFFFFFFu) : curr_posn;
+            curr_term_mask = fresh_it ? 1u << (pv >> 24) : curr_term_mask;
+            posn_mask = sa_posn_mask32(curr_posn);
+            const bool over_f = fresh_it && cursor >= (u32)CE;
+            {
+                SpanEnt fresh;
+                fresh.terms = curr_term_mask; fresh.posns = posn_mask; fresh.beg = curr_posn; fresh.end = curr_posn;
+                ents[(fresh_it && !over_f) ? cursor : (u32)CE] = fresh;
+            }
+            end = fresh_it ? cursor : end;
+            si = fresh_it ? 0u : si;
+            cursor += fresh_it ? 1u : 0u;
+            pi += fresh_it ? 1u : 0u;
+            // visit span si
+            const bool vis = !done && !over_f && si < end;
+            const u32 slot = vis ? si : (u32)CE;
+            const SpanEnt e = ents[slot];
+            const u32 nt = (u32)__popc(e.terms), np = sa_popc_sext(e.posns);
+            const bool act = vis && !((nt < num_terms && np == num_terms) || (e.terms & curr_term_mask));
+            const int sp2 = e.posns | posn_mask;
+            const u32 new_unique = sa_popc_sext(sp2);
+            const int proposed = sa_iabs32(curr_posn - e.beg);
+            const bool rej = np == new_unique || proposed > max_span_width;    // (the position bit stays even if rejected)
+            const bool fork_it = act && !rej;
+            const bool over_k = fork_it && cursor >= (u32)CE;
+            SpanEnt upd, fork;
+            upd.terms = fork_it ? (e.terms | curr_term_mask) : e.terms;
+            upd.posns = act ? sp2 : e.posns;
+            upd.beg = e.beg;
+            upd.end = fork_it ? curr_posn : e.end;
+            ents[slot] = upd;
+            fork.terms = e.terms | curr_term_mask; fork.posns = sp2 & ~posn_mask; fork.beg = e.beg; fork.end = e.end;
+            ents[(fork_it && !over_k) ? cursor : (u32)CE] = fork;
+            cursor += (fork_it && !over_k) ? 1u : 0u;
+            si += vis ? 1u : 0u;
+            abandoned = over_f || over_k;
+            alive = !done && !abandoned;
+        }
+        if (!abandoned) {
+            u32 incr = 0;
+            sa_span_collect<SA_NSPANS>(ents, ColCol{(u64*)(s_ents + lane)}, cursor, num_terms, max_span_width, &incr);
+            sa_span_add(p, last_key, incr);
+        }
+    }
+    const u64 ab = __ballot(abandoned);
+    if (ab) {
+        u32 slot = 0;
+        if (lane == (u32)__builtin_ctzll(ab)) slot = atomicAdd(p.over_cnt, (u32)__popcll(ab));
+        slot = (u32)__shfl((int)slot, __builtin_ctzll(ab), SA_WAVE);
+        if (abandoned) p.over_list[slot + (u32)__popcll(ab & ((1ull << lane) - 1ull))] = k;
     }
 }
 
@@ -495,7 +862,7 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_wave(const SpanMachinePa
             }
             incr = ncol;
         }
-        if (lane == 0 && incr && last_key < p.n_docs) atomicAdd(&p.counts[last_key], incr);
+        if (lane == 0) sa_span_add(p, last_key, incr);
     }
 }
 
@@ -526,13 +893,8 @@ __global__ void __launch_bounds__(64) sa_k_span_machine(const SpanMachineParams 
         u32 incr = 0;
         u64 key = 0;
         sa_span_doc<SA_NSPANS, SA_NSPANS>(p, k, ents, col, &incr, &key);
-        if (incr && key < p.n_docs) atomicAdd(&p.counts[key], incr);
+        sa_span_add(p, key, incr);
     }
-}
-
-__global__ void __launch_bounds__(256)
-sa_k_counts_to_float(const u32* __restrict__ counts, float* __restrict__ out, u64 n) {
-    for (u64 d = (u64)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += (u64)gridDim.x * blockDim.x) out[d] = (float)counts[d];
 }
 
 // dense slop > 0 phrase counts of terms[0..T) -> *d_out (float[n_docs], inside the index scratch)
@@ -569,29 +931,32 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
     if (G > g_max) G = g_max;
     if (G == 0) G = 64;
     const size_t slab_bytes = (size_t)G * SA_NSPANS * (sizeof(SpanEnt) + sizeof(u64));
-    const size_t chunk_words = sa_compact_chunks((u32)(max_len + 1)) + 8;
+    // chunk counters: two rows (candidates, document heads) over the chunks of all terms; the position filter's
+    // compactions (one list at a time) use the same words
+    const size_t chunk_words = std::max<size_t>(2 * (total_len / SA_CHUNK + (size_t)T + 1), sa_compact_chunks((u32)(max_len + 1))) + 8;
     const size_t filt_bytes = filt.active ? (total_len + 64 * (size_t)T) * 8 : 0;
-    const size_t need = (N + 64) * 8 + (total_len + 64 * T) * 13 + slab_bytes + chunk_words * 4 + filt_bytes + 64 * 1024 +
-                        ((size_t)terms_dev.len[0] + 64) * 8;
+    const size_t need = (N + 64) * 8 + (total_len + 64 * T) * 14 + slab_bytes + chunk_words * 4 + filt_bytes + 64 * 1024 +
+                        ((size_t)terms_dev.len[0] + 64) * 13 + 256 * (size_t)T;
     void* scratch;
     SA_TRY(sa_index_scratch(ix, need, &scratch));
     char* base = (char*)scratch;
     size_t used = 0;
     auto take = [&](size_t bytes) { char* p = base + used; used += (bytes + 255) & ~(size_t)255; return p; };
     float* running = (float*)take((N + 1) * 4);
-    u32* counts = (u32*)take((N + 1) * 4);
-    u32* cnt = (u32*)take(5 * SA_SPAN_MAX_TERMS * 4);          // [t] n_cand, [16 + t] n_heads, [32] wrap flag, [48 + t] filter scratch, [64] abandoned groups
+    u32* cnt = (u32*)take(SA_SPAN_CNT_WORDS * 4);          // [t] n_cand, [16 + t] n_heads, [32] wrap flag, [48 + t] filter scratch, [64] abandoned groups
     u32* chunks = (u32*)take(chunk_words * 4);
     SpanEnt* ents = (SpanEnt*)take((size_t)G * SA_NSPANS * sizeof(SpanEnt));
     u64* col = (u64*)take((size_t)G * SA_NSPANS * sizeof(u64));
     unsigned char* flags = (unsigned char*)take(total_len + 64);
     u32* over_list = (u32*)take(((size_t)terms_dev.len[0] + 64) * 4);
-    u32* over_list2 = (u32*)take(((size_t)terms_dev.len[0] + 64) * 4);
+    u32* order = (u32*)take(((size_t)terms_dev.len[0] + 64) * 4);
+    unsigned char* bins = (unsigned char*)take((size_t)terms_dev.len[0] + 64);
     *d_out = running;
-    SA_HIP(hipMemsetAsync(running, 0, N * sizeof(float), st));
-    SA_HIP(hipMemsetAsync(counts, 0, N * sizeof(u32), st));
-    SA_HIP(hipMemsetAsync(cnt, 0, 5 * SA_SPAN_MAX_TERMS * 4, st));
-    if (!known || N == 0 || total_len == 0) return SA_OK;
+    if (!known || N == 0 || total_len == 0) {
+        SA_HIP(hipMemsetAsync(running, 0, N * sizeof(float), st));
+        return SA_OK;
+    }
+    // (no fills: sa_k_span_wrap_flag clears the counters, sa_k_span_flags the dense result the machines add into)
     if (filt.active) {
         const u64* ptrs[SA_SPAN_MAX_TERMS];
         u64* bufs[SA_SPAN_MAX_TERMS];
@@ -602,46 +967,77 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
         }
         if (used > need) { sa_set_error("internal: span scratch exhausted"); return SA_ERR_STATE; }
         SA_TRY(sa_posn_filter_terms(ix, filt, T, ptrs, lens, bufs, cnt + 3 * SA_SPAN_MAX_TERMS, chunks));
-        SA_HIP(hipMemsetAsync(cnt, 0, 3 * SA_SPAN_MAX_TERMS * 4, st));
         for (int t = 0; t < T; t++) { terms_dev.words[t] = ptrs[t]; terms_dev.len[t] = lens[t]; }
     }
     terms_dev.off[0] = 0;
     for (int t = 0; t < T; t++) terms_dev.off[t + 1] = terms_dev.off[t] + terms_dev.len[t];
-    hipLaunchKernelGGL(sa_k_span_wrap_flag, dim3(1), dim3(64), 0, st, terms_dev, cnt + 2 * SA_SPAN_MAX_TERMS);
+    hipLaunchKernelGGL(sa_k_span_wrap_flag, dim3(1), dim3(256), 0, st, terms_dev, cnt);
     {
         const u32 total = terms_dev.off[T];
         const u32 grid = total / 256 + 1 < 16384 ? total / 256 + 1 : 16384;
-        hipLaunchKernelGGL(sa_k_span_flags, dim3(grid), dim3(256), 0, st, terms_dev, (const u32*)(cnt + 2 * SA_SPAN_MAX_TERMS), flags);
+        const u32* wrap = cnt + SA_SPAN_CNT_WRAP;
+        switch (T) {
+        case 2: hipLaunchKernelGGL(sa_k_span_flags<2>, dim3(grid), dim3(256), 0, st, terms_dev, wrap, flags, running); break;
+        case 3: hipLaunchKernelGGL(sa_k_span_flags<3>, dim3(grid), dim3(256), 0, st, terms_dev, wrap, flags, running); break;
+        case 4: hipLaunchKernelGGL(sa_k_span_flags<4>, dim3(grid), dim3(256), 0, st, terms_dev, wrap, flags, running); break;
+        default: hipLaunchKernelGGL(sa_k_span_flags<0>, dim3(grid), dim3(256), 0, st, terms_dev, wrap, flags, running); break;
+        }
     }
     SpanMachineParams mp;
     memset(&mp, 0, sizeof(mp));
-    mp.T = T; mp.slop = (u32)slop; mp.ents = ents; mp.col = col; mp.counts = counts; mp.n_docs = N; mp.n_threads = G;
+    mp.T = T; mp.slop = (u32)slop; mp.ents = ents; mp.col = col; mp.fcounts = running; mp.n_docs = N; mp.n_threads = G;
+    SpanChunkTab ck;
+    SpanCompactOut co;
+    memset(&ck, 0, sizeof(ck));
+    memset(&co, 0, sizeof(co));
     for (int t = 0; t < T; t++) {
         u64* cand = (u64*)take(((size_t)terms_dev.len[t] + 1) * 8);
         u32* heads = (u32*)take(((size_t)terms_dev.len[t] + 1) * 4);
         if (used > need) { sa_set_error("internal: span scratch exhausted"); return SA_ERR_STATE; }
         mp.cand[t] = cand; mp.n_cand[t] = cnt + t; mp.heads[t] = heads; mp.n_heads[t] = cnt + SA_SPAN_MAX_TERMS + t;
-        if (terms_dev.len[t] == 0) continue;
-        SpanCandidates sc;
-        sc.words = terms_dev.words[t]; sc.flags = flags + terms_dev.off[t]; sc.out = cand;
-        sa_compact(sc, (const u32*)nullptr, terms_dev.len[t], chunks, cnt + t, st);
-        DocHeads dh;
-        dh.words = cand; dh.out = heads;
-        sa_compact(dh, cnt + t, terms_dev.len[t], chunks, cnt + SA_SPAN_MAX_TERMS + t, st);
+        co.cand[t] = cand; co.heads[t] = heads;
+        co.gpos[t] = (unsigned char*)take((size_t)terms_dev.len[t] + 1);
+        if (used > need) { sa_set_error("internal: span scratch exhausted"); return SA_ERR_STATE; }
+        ck.coff[t + 1] = ck.coff[t] + sa_compact_chunks(terms_dev.len[t]);
+    }
+    for (int t = T; t < SA_SPAN_MAX_TERMS; t++) ck.coff[t + 1] = ck.coff[t];
+    {
+        const u32 n_chunks = ck.coff[T];                       // (> 0: total_len > 0)
+        const u32 grid = n_chunks < 16384u ? n_chunks : 16384u;
+        hipLaunchKernelGGL(sa_k_span_compact_count, dim3(grid), dim3(SA_CT), 0, st, terms_dev, ck, (const unsigned char*)flags, chunks, n_chunks);
+        hipLaunchKernelGGL(sa_k_span_compact_scan, dim3(2 * T), dim3(1024), 0, st, ck, T, chunks, n_chunks, cnt);
+        hipLaunchKernelGGL(sa_k_span_compact_emit, dim3(grid), dim3(SA_CT), 0, st, terms_dev, ck, (const unsigned char*)flags, (const u32*)chunks, n_chunks, co);
     }
     // fast pass (tables in LDS, one thread per document group), then the groups it abandoned with full tables
     const char* fast_env = getenv("SA_SPAN_FAST");
     if (!(fast_env && atoi(fast_env) == 0) && terms_dev.len[0] > 0) {
         mp.over_list = over_list; mp.over_cnt = cnt + 4 * SA_SPAN_MAX_TERMS;
-        hipLaunchKernelGGL((sa_k_span_machine_lds<SA_SPAN_LDS, false>), dim3((terms_dev.len[0] + 63u) / 64u), dim3(64), 0, st, mp);
+        if (!(getenv("SA_SPAN_SORT") && atoi(getenv("SA_SPAN_SORT")) == 0)) {
+            SpanBinParams bp;
+            memset(&bp, 0, sizeof(bp));
+            for (int t = 0; t < T; t++) { bp.gpos[t] = co.gpos[t]; bp.n_heads[t] = mp.n_heads[t]; }
+            bp.T = T; bp.bin = bins; bp.sizes = cnt + SA_SPAN_CNT_BINS; bp.cursors = cnt + SA_SPAN_CNT_BINS + SA_SPAN_NBINS; bp.order = order;
+            const u32 bg = std::max<u32>(1u, std::min<u32>(256u, (terms_dev.len[0] + 2047u) / 2048u));
+            hipLaunchKernelGGL(sa_k_span_bin_count, dim3(bg), dim3(1024), 0, st, bp);
+            hipLaunchKernelGGL(sa_k_span_bin_scatter, dim3(bg), dim3(1024), 0, st, bp);
+            mp.order = order;
+        }
+        const dim3 fg((terms_dev.len[0] + 63u) / 64u);
+        // table size: two-term documents rarely need more than 12 spans; with three terms and more 15 % of them do,
+        // and the heavy pass (a wave per document) costs more than the lower residency of a larger table
+        switch ((getenv("SA_SPAN_CE") ? atoi(getenv("SA_SPAN_CE")) : (T <= 2 ? SA_SPAN_LDS : 16))) {      // (SA_SPAN_CE: measurement knob)
+        case 8: hipLaunchKernelGGL((sa_k_span_machine_flat<8, 12>), fg, dim3(64), 0, st, mp); break;
+        case 16: hipLaunchKernelGGL((sa_k_span_machine_flat<16, 16>), fg, dim3(64), 0, st, mp); break;
+        case 20: hipLaunchKernelGGL((sa_k_span_machine_flat<20, 20>), fg, dim3(64), 0, st, mp); break;
+        case 24: hipLaunchKernelGGL((sa_k_span_machine_flat<24, 24>), fg, dim3(64), 0, st, mp); break;
+        default: hipLaunchKernelGGL((sa_k_span_machine_flat<SA_SPAN_LDS, SA_SPAN_PMAX>), fg, dim3(64), 0, st, mp); break;
+        }
         mp.in_list = over_list; mp.in_cnt = cnt + 4 * SA_SPAN_MAX_TERMS;
         const u32 g2 = std::min<u32>(8192u, terms_dev.len[0]);
         hipLaunchKernelGGL(sa_k_span_machine_wave, dim3(g2), dim3(64), 0, st, mp);
     } else {
         hipLaunchKernelGGL(sa_k_span_machine, dim3(G / 64), dim3(64), 0, st, mp);       // every group, full tables in the global slab
     }
-    const u64 g = (N + 255) / 256;
-    hipLaunchKernelGGL(sa_k_counts_to_float, dim3((u32)(g < 8192 ? (g ? g : 1) : 8192)), dim3(256), 0, st, counts, running, N);
     return SA_OK;
 }
 

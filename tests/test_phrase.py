@@ -219,6 +219,36 @@ def test_slop_random_differential(api, seed):
             assert np.array_equal(got, want), f"seed {seed} terms {terms} slop {slop}: {np.flatnonzero(got != want)[:5]}"
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_slop_five_to_eight_terms(api, seed, monkeypatch):
+    """phrases of more terms than the span kernels are specialised for (flags: 2-4 terms; the fast pass requests the
+    first four terms' loads together): the generic paths, with and without the doc directory, vs the oracle"""
+    from oracle import spans as S
+    monkeypatch.setenv("SA_DOCDIR_DIV", "1000000" if seed % 2 else "0")
+    rng = np.random.default_rng(300 + seed)
+    n_docs, vocab = int(rng.integers(300, 700)), int(rng.integers(6, 12))
+    t, d, p, lens = synth.corpus_triples(n_docs, vocab, int(rng.integers(20, 50)), seed=40 + seed)
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
+    checked = 0
+    for T in (5, 6, 7, 8, 5, 6):
+        terms = [int(x) for x in rng.integers(0, vocab, T)]
+        slop = int(rng.integers(1, 4))
+        enc = [orc.enc(x) if orc.has_term(x) else np.empty(0, np.uint64) for x in terms]
+        if any(len(e) == 0 for e in enc):
+            continue
+        ids, counts, overflow = S.span_search(enc, slop, return_overflow=True)
+        want = np.zeros(n_docs, dtype=np.float32)
+        want[ids.astype(np.int64)] = counts
+        got = dev.phrase_freqs_dense(terms, slop=slop)
+        if overflow == 0:
+            assert np.array_equal(got, want), f"seed {seed} terms {terms} slop {slop}: {np.flatnonzero(got != want)[:5]}"
+            checked += 1
+    dev.close()
+    assert checked > 0
+
+
 @pytest.mark.parametrize("min_posn,max_posn", [(0, 17), (18, None), (0, 35), (18, 53), (None, 17)])
 def test_posn_range_matches_oracle(api, min_posn, max_posn):
     """min_posn / max_posn restriction (reference roaringish.py:266-282 incl. its unshifted-msb
