@@ -45,7 +45,7 @@ inline float4 make_float4(float x, float y, float z, float w) { float4 v; v.x = 
 typedef int hipError_t;
 typedef struct hipemu_stream* hipStream_t;
 typedef struct hipemu_event* hipEvent_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorInvalidConfiguration = 9 };
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost,
                      hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum { hipStreamNonBlocking = 1, hipEventDefault = 0 };
@@ -205,7 +205,13 @@ inline void run_block() {
 // communicator of the test build drives one shard per host thread
 inline std::mutex& launch_mutex() { static std::mutex mu; return mu; }
 
+// like the runtime: a launch with an empty grid or block does not run and leaves an error for hipGetLastError()
+inline int& last_launch_error() { static thread_local int e = 0; return e; }
 inline void launch(dim3 grid, dim3 block, std::function<void()> body) {
+    if (grid.x == 0 || grid.y == 0 || grid.z == 0 || block.x * block.y * block.z == 0 || block.x * block.y * block.z > 1024) {
+        last_launch_error() = 9;
+        return;
+    }
     std::lock_guard<std::mutex> launch_guard(launch_mutex());
     Machine& m = M();
     m.gridDim = grid;
@@ -353,9 +359,9 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = null
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
-inline hipError_t hipGetLastError() { return hipSuccess; }
-inline hipError_t hipPeekAtLastError() { return hipSuccess; }
-inline const char* hipGetErrorString(hipError_t) { return "hipemu error"; }
+inline hipError_t hipGetLastError() { const int e = hipemu::last_launch_error(); hipemu::last_launch_error() = 0; return (hipError_t)e; }
+inline hipError_t hipPeekAtLastError() { return (hipError_t)hipemu::last_launch_error(); }
+inline const char* hipGetErrorString(hipError_t e) { return (int)e == 9 ? "invalid configuration argument" : "hipemu error"; }
 struct hipemu_event { std::chrono::steady_clock::time_point t; };
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemu_event(); return hipSuccess; }
 enum { hipEventDisableTiming = 2 };
