@@ -121,8 +121,26 @@ __device__ __forceinline__ bool sa_span_keep(const u32* m, int T, bool wrap) {
     return L || R || Rm || (!wrap && Lp);
 }
 
+// header 0 in L?  (the `L - 1` widening is lost then, see the top of the file).  Also clears the query's device
+// counters (cnt layout: sa_span_counts_device), so no separate fill is enqueued for them.
 #define SA_SPAN_NBINS 32                 // work bins of the fast pass (positions of a document group, saturated)
-#define SA_SPAN_CNT_WORDS (5 * SA_SPAN_MAX_TERMS)               // the query's device counters (layout: sa_span_counts_device)
+#define SA_SPAN_CNT_BINS (5 * SA_SPAN_MAX_TERMS)                     // [.. + NBINS) bin sizes, [.. + 2 NBINS) bin cursors
+#define SA_SPAN_CNT_WORDS (5 * SA_SPAN_MAX_TERMS + 2 * SA_SPAN_NBINS)
+#define SA_SPAN_CNT_WRAP (2 * SA_SPAN_MAX_TERMS)
+__global__ void __launch_bounds__(256) sa_k_span_wrap_flag(const SpanTerms st, u32* __restrict__ cnt) {
+    if (blockIdx.x != 0) return;
+    if (cnt && threadIdx.x < SA_SPAN_CNT_WORDS && threadIdx.x != SA_SPAN_CNT_WRAP) cnt[threadIdx.x] = 0u;
+    if (threadIdx.x != 0) return;
+    u32* wrap = cnt + SA_SPAN_CNT_WRAP;
+    bool L = true;
+    const u32 m0 = sa_header_triple(st.words[0], st.len[0], 0ull);
+    for (int i = 1; i < st.T; i++) {
+        const u32 mi = sa_header_triple(st.words[i], st.len[i], 0ull);
+        const bool a0m = m0 & 1u, a0 = m0 & 2u, bim = mi & 1u, bi = mi & 2u;
+        L &= (a0 && bi) || (bi && a0m) || (a0 && bim);
+    }
+    *wrap = L ? 1u : 0u;
+}
 
 // stage 1a: keep-flag of every word of every term (one launch; the predicate costs one search
 // per phrase term and is evaluated once, the compaction below only reads the flags).  The same launch clears the
@@ -131,25 +149,10 @@ __device__ __forceinline__ bool sa_span_keep(const u32* m, int T, bool wrap) {
 // instructions on indexing them), 0: any number.
 template <int TT>
 __global__ void __launch_bounds__(256)
-sa_k_span_flags(const SpanTerms st, u32* __restrict__ cnt, unsigned char* __restrict__ flags, float* __restrict__ counts) {
+sa_k_span_flags(const SpanTerms st, const u32* __restrict__ wrap, unsigned char* __restrict__ flags, float* __restrict__ counts) {
     const int T = TT ? TT : st.T;
     const u32 total = st.off[T];
-    if (blockIdx.x == 0 && threadIdx.x < SA_SPAN_CNT_WORDS) cnt[threadIdx.x] = 0u;      // (read by the kernels that follow)
-    // header 0 in L?  (the `L - 1` widening is lost then, see the top of the file.)  Membership of header 0 and of
-    // its wrapped predecessor -- the largest header -- is a matter of a sorted list's first and last word: a few
-    // uniform loads, the same for every thread.
-    bool wr = true;
-    {
-        const bool a0 = st.len[0] != 0 && (st.words[0][0] & SA_HEADER_MASK) == 0;
-        const bool a0m = st.len[0] != 0 && (st.words[0][st.len[0] - 1u] & SA_HEADER_MASK) == SA_HEADER_MASK;
-#pragma unroll
-        for (int i = 1; i < (TT ? TT : SA_SPAN_MAX_TERMS); i++) {
-            if (i >= T) break;
-            const bool bi = st.len[i] != 0 && (st.words[i][0] & SA_HEADER_MASK) == 0;
-            const bool bim = st.len[i] != 0 && (st.words[i][st.len[i] - 1u] & SA_HEADER_MASK) == SA_HEADER_MASK;
-            wr &= (a0 && bi) || (bi && a0m) || (a0 && bim);
-        }
-    }
+    const bool wr = *wrap != 0;
     for (u64 d = (u64)blockIdx.x * blockDim.x + threadIdx.x; d < st.n_docs; d += (u64)gridDim.x * blockDim.x) counts[d] = 0.f;
     for (u32 g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
         int t = 0;
@@ -523,51 +526,57 @@ __device__ __forceinline__ bool sa_span_doc(const SpanMachineParams& p, const u3
     return true;
 }
 
-// Work order for the fast pass.  With one document per lane a wave runs as long as its busiest document, and the
+// Work bins for the fast pass.  With one document per lane a wave runs as long as its busiest document, and the
 // machine's work grows with the square of a document's positions: taken in index order, a wave's busiest document
-// has ~4 x the average work.  So the document groups are sorted by their number of positions -- a counting sort over
-// SA_SPAN_NBINS bins inside blocks of SA_SPAN_SORT_BLOCK groups (one launch, no global pass: a bin of a block holds a
-// few waves' worth of groups, so nearly every wave is homogeneous), busiest bins first -- and a wave takes 64
-// neighbours of that order.
-#define SA_SPAN_SORT_BLOCK 8192
+// has ~4 x the average work.  So the document groups are sorted by their number of positions (a counting sort over
+// SA_SPAN_NBINS bins: sizes, then a scatter through per-bin cursors) and a wave takes 64 neighbours of that order.
+// Busiest bins FIRST: the long waves start while the grid is full and the short ones fill the gaps (measured: lightest
+// first costs +17 us on the heaviest 2-term query, and so does sorting inside blocks of 8192 groups in one launch --
+// the same wave homogeneity, but every block's long waves start late).
 struct SpanBinParams {
     const unsigned char* gpos[SA_SPAN_MAX_TERMS];
     const u32* n_heads[SA_SPAN_MAX_TERMS];
     int T;
-    u32* order;                               // [n_heads[0]] out: document groups, block by block, busiest bin first
+    unsigned char* bin;                       // [n_heads[0]] bin of each document group
+    u32* sizes;                               // [NBINS] (zeroed by sa_k_span_wrap_flag)
+    u32* cursors;                             // [NBINS]
+    u32* order;                               // [n_heads[0]] out: document groups, busiest bin first
 };
 
-__global__ void __launch_bounds__(1024) sa_k_span_sort_blocks(const SpanBinParams bp) {
-    constexpr int PER = SA_SPAN_SORT_BLOCK / 1024;
-    __shared__ u32 h[SA_SPAN_NBINS], at[SA_SPAN_NBINS];
+__global__ void __launch_bounds__(1024) sa_k_span_bin_count(const SpanBinParams bp) {
+    __shared__ u32 h[SA_SPAN_NBINS];
+    if (threadIdx.x < SA_SPAN_NBINS) h[threadIdx.x] = 0;
+    __syncthreads();
     const u32 n = *bp.n_heads[0];
-    for (u32 base = blockIdx.x * (u32)SA_SPAN_SORT_BLOCK; base < n; base += gridDim.x * (u32)SA_SPAN_SORT_BLOCK) {
-        if (threadIdx.x < SA_SPAN_NBINS) h[threadIdx.x] = 0;
-        __syncthreads();
-        u32 bin[PER];
-#pragma unroll
-        for (int j = 0; j < PER; j++) {
-            const u32 k = base + (u32)j * 1024u + threadIdx.x;
-            u32 np = 0;
-            if (k < n)
-                for (int t = 0; t < bp.T; t++) if (k < *bp.n_heads[t]) np += bp.gpos[t][k];
-            bin[j] = np < (u32)SA_SPAN_NBINS - 1u ? np : (u32)SA_SPAN_NBINS - 1u;
-            if (k < n) atomicAdd(&h[bin[j]], 1u);
-        }
-        __syncthreads();
-        if (threadIdx.x < SA_SPAN_NBINS) {
-            u32 start = 0;                                       // bins in descending order
-            for (u32 b = threadIdx.x + 1u; b < (u32)SA_SPAN_NBINS; b++) start += h[b];
-            at[threadIdx.x] = base + start;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < PER; j++) {
-            const u32 k = base + (u32)j * 1024u + threadIdx.x;
-            if (k < n) bp.order[atomicAdd(&at[bin[j]], 1u)] = k;
-        }
-        __syncthreads();
+    const u32 per = (n + gridDim.x - 1) / gridDim.x;
+    const u32 lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (u32 k = lo + threadIdx.x; k < hi; k += blockDim.x) {
+        u32 np = 0;
+        for (int t = 0; t < bp.T; t++) if (k < *bp.n_heads[t]) np += bp.gpos[t][k];
+        const u32 b = np < (u32)SA_SPAN_NBINS - 1u ? np : (u32)SA_SPAN_NBINS - 1u;
+        bp.bin[k] = (unsigned char)b;
+        atomicAdd(&h[b], 1u);
     }
+    __syncthreads();
+    if (threadIdx.x < SA_SPAN_NBINS && h[threadIdx.x]) atomicAdd(&bp.sizes[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(1024) sa_k_span_bin_scatter(const SpanBinParams bp) {
+    __shared__ u32 h[SA_SPAN_NBINS], at[SA_SPAN_NBINS];
+    if (threadIdx.x < SA_SPAN_NBINS) h[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 n = *bp.n_heads[0];
+    const u32 per = (n + gridDim.x - 1) / gridDim.x;
+    const u32 lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (u32 k = lo + threadIdx.x; k < hi; k += blockDim.x) atomicAdd(&h[bp.bin[k]], 1u);
+    __syncthreads();
+    if (threadIdx.x < SA_SPAN_NBINS) {
+        u32 start = 0;                                           // bins in descending order
+        for (u32 b = threadIdx.x + 1u; b < (u32)SA_SPAN_NBINS; b++) start += bp.sizes[b];
+        at[threadIdx.x] = h[threadIdx.x] ? start + atomicAdd(&bp.cursors[threadIdx.x], h[threadIdx.x]) : 0u;
+    }
+    __syncthreads();
+    for (u32 k = lo + threadIdx.x; k < hi; k += blockDim.x) bp.order[atomicAdd(&at[bp.bin[k]], 1u)] = k;
 }
 
 // Fast pass: thread k = document group k, span table of CE entries per lane in LDS.
@@ -945,19 +954,20 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
     size_t used = 0;
     auto take = [&](size_t bytes) { char* p = base + used; used += (bytes + 255) & ~(size_t)255; return p; };
     float* running = (float*)take((N + 1) * 4);
-    u32* cnt = (u32*)take(SA_SPAN_CNT_WORDS * 4);          // [t] n_cand, [16 + t] n_heads, [48 + t] filter scratch, [64] abandoned groups
+    u32* cnt = (u32*)take(SA_SPAN_CNT_WORDS * 4);          // [t] n_cand, [16 + t] n_heads, [32] wrap flag, [48 + t] filter scratch, [64] abandoned groups
     u32* chunks = (u32*)take(chunk_words * 4);
     SpanEnt* ents = (SpanEnt*)take((size_t)G * SA_NSPANS * sizeof(SpanEnt));
     u64* col = (u64*)take((size_t)G * SA_NSPANS * sizeof(u64));
     unsigned char* flags = (unsigned char*)take(total_len + 64);
     u32* over_list = (u32*)take(((size_t)terms_dev.len[0] + 64) * 4);
     u32* order = (u32*)take(((size_t)terms_dev.len[0] + 64) * 4);
+    unsigned char* bins = (unsigned char*)take((size_t)terms_dev.len[0] + 64);
     *d_out = running;
     if (!known || N == 0 || total_len == 0) {
         SA_HIP(hipMemsetAsync(running, 0, N * sizeof(float), st));
         return SA_OK;
     }
-    // (no fills: sa_k_span_flags clears the counters and the dense result the machines add into)
+    // (no fills: sa_k_span_wrap_flag clears the counters, sa_k_span_flags the dense result the machines add into)
     if (filt.active) {
         const u64* ptrs[SA_SPAN_MAX_TERMS];
         u64* bufs[SA_SPAN_MAX_TERMS];
@@ -976,14 +986,16 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
         SA_HIP(hipMemsetAsync(running, 0, N * sizeof(float), st));
         return SA_OK;
     }
+    hipLaunchKernelGGL(sa_k_span_wrap_flag, dim3(1), dim3(256), 0, st, terms_dev, cnt);
     {
         const u32 total = terms_dev.off[T];
         const u32 grid = total / 256 + 1 < 16384 ? total / 256 + 1 : 16384;
+        const u32* wrap = cnt + SA_SPAN_CNT_WRAP;
         switch (T) {
-        case 2: hipLaunchKernelGGL(sa_k_span_flags<2>, dim3(grid), dim3(256), 0, st, terms_dev, cnt, flags, running); break;
-        case 3: hipLaunchKernelGGL(sa_k_span_flags<3>, dim3(grid), dim3(256), 0, st, terms_dev, cnt, flags, running); break;
-        case 4: hipLaunchKernelGGL(sa_k_span_flags<4>, dim3(grid), dim3(256), 0, st, terms_dev, cnt, flags, running); break;
-        default: hipLaunchKernelGGL(sa_k_span_flags<0>, dim3(grid), dim3(256), 0, st, terms_dev, cnt, flags, running); break;
+        case 2: hipLaunchKernelGGL(sa_k_span_flags<2>, dim3(grid), dim3(256), 0, st, terms_dev, wrap, flags, running); break;
+        case 3: hipLaunchKernelGGL(sa_k_span_flags<3>, dim3(grid), dim3(256), 0, st, terms_dev, wrap, flags, running); break;
+        case 4: hipLaunchKernelGGL(sa_k_span_flags<4>, dim3(grid), dim3(256), 0, st, terms_dev, wrap, flags, running); break;
+        default: hipLaunchKernelGGL(sa_k_span_flags<0>, dim3(grid), dim3(256), 0, st, terms_dev, wrap, flags, running); break;
         }
     }
     SpanMachineParams mp;
@@ -1019,9 +1031,10 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
             SpanBinParams bp;
             memset(&bp, 0, sizeof(bp));
             for (int t = 0; t < T; t++) { bp.gpos[t] = co.gpos[t]; bp.n_heads[t] = mp.n_heads[t]; }
-            bp.T = T; bp.order = order;
-            const u32 bg = std::max<u32>(1u, std::min<u32>(1024u, (terms_dev.len[0] + SA_SPAN_SORT_BLOCK - 1u) / SA_SPAN_SORT_BLOCK));
-            hipLaunchKernelGGL(sa_k_span_sort_blocks, dim3(bg), dim3(1024), 0, st, bp);
+            bp.T = T; bp.bin = bins; bp.sizes = cnt + SA_SPAN_CNT_BINS; bp.cursors = cnt + SA_SPAN_CNT_BINS + SA_SPAN_NBINS; bp.order = order;
+            const u32 bg = std::max<u32>(1u, std::min<u32>(256u, (terms_dev.len[0] + 2047u) / 2048u));
+            hipLaunchKernelGGL(sa_k_span_bin_count, dim3(bg), dim3(1024), 0, st, bp);
+            hipLaunchKernelGGL(sa_k_span_bin_scatter, dim3(bg), dim3(1024), 0, st, bp);
             mp.order = order;
         }
         const dim3 fg((terms_dev.len[0] + 63u) / 64u);
