@@ -4,7 +4,7 @@ O=$R/gpurun_out
 mkdir -p $O; rm -rf $O/prof_slop2 $O/prof_slop3
 export TMPDIR=/tmp
 cd /tmp
-( timeout 200 python $R/scripts/slop_heavy.py --terms 2,3 --ce ${CES:-8,12,16,24} --reps 3 ) > $O/slop_ce.log 2>&1
+( timeout 200 python $R/scripts/slop_heavy.py --terms 2,3 --reps 3 ) > $O/slop_ce.log 2>&1
 grep '^{' $O/slop_ce.log
 for t in 2 3; do
 ( timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_slop$t -- python $R/scripts/slop_heavy.py --terms $t --reps 5 ) > $O/prof_slop$t.log 2>&1

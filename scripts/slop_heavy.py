@@ -18,7 +18,6 @@ def main():
     ap.add_argument("--docs", type=int, default=1_000_000)
     ap.add_argument("--vocab", type=int, default=100_000)
     ap.add_argument("--terms", default="2")
-    ap.add_argument("--ce", default="12", help="fast-pass table sizes to try (SA_SPAN_CE)")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--slop", type=int, default=2)
     args = ap.parse_args()
@@ -27,15 +26,14 @@ def main():
     words, counts = synth.encode_batch(lens, terms, V)
     out_words, term_off = synth.concat_term_major([(words, counts)], V)
     index = DeviceIndex(out_words, term_off, lens.astype(np.float32), api=_lib.api())
-    for ce in [int(x) for x in args.ce.split(",")]:
-        os.environ["SA_SPAN_CE"] = str(ce)
+    for ce in (0,):
         for nt in [int(x) for x in args.terms.split(",")]:
             ph = list(range(nt))
             ms = []
             for _ in range(args.reps + 1):
                 r = index.phrase_freqs_dense(ph, slop=args.slop)
                 ms.append(round(index.last_profile()[0], 4))
-            print(json.dumps({"ce": ce, "phrase": ph, "slop": args.slop, "device_ms": ms, "matches": int(r.sum())}), flush=True)
+            print(json.dumps({"phrase": ph, "slop": args.slop, "device_ms": ms, "matches": int(r.sum())}), flush=True)
 
 
 if __name__ == "__main__":

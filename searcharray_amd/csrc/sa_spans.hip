@@ -589,7 +589,8 @@ __global__ void __launch_bounds__(1024) sa_k_span_bin_scatter(const SpanBinParam
 // spans, then visit one span": a wave runs as long as its busiest document, and the loop holds no global load.
 // Documents with more than PMAX positions or more than CE spans are ABANDONED (nothing counted) to p.over_list for
 // the heavy pass -- one counter update per wave, the abandoned lanes take consecutive slots.
-template <int CE, int PMAX>
+// TT: the number of terms when it is 2 or 3 (the loops over the terms resolve at compile time), 0: any number.
+template <int CE, int PMAX, int TT>
 __global__ void __launch_bounds__(64) sa_k_span_machine_flat(const SpanMachineParams p) {
     __shared__ alignas(16) SpanEnt s_ents[(CE + 1) * 64];        // lane L's entry i at (i * 64 + L): conflict-free whatever i each lane is at; row CE: scratch
     __shared__ u32 s_pos[PMAX * 64];                             // term << 24 | position
@@ -612,7 +613,8 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_flat(const SpanMachinePa
     const u32 n_items = *p.n_heads[0];
     const u32 item = blockIdx.x * 64u + lane;
     const u32 k = (item < n_items && p.order) ? p.order[item] : item;
-    const u32 num_terms = (u32)p.T;
+    const int T = TT ? TT : p.T;
+    const u32 num_terms = (u32)T;
     const int max_span_width = (int)(num_terms + p.slop);
     const EntCol ents{s_ents + lane};
     bool abandoned = false;
@@ -643,7 +645,7 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_flat(const SpanMachinePa
 #pragma unroll
         for (int t = 0; t < TU; t++) {
             lo[t] = 0; hi[t] = 0;
-            if (t < p.T) {
+            if (t < T) {
                 const u32 ng = *p.n_heads[t];
                 if (k < ng) {                                    // (else: this term has no k-th document group)
                     lo[t] = p.heads[t][k];
@@ -663,7 +665,7 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_flat(const SpanMachinePa
             if (hi[t] > lo[t] + 1u) push_word(t, w1[t]);
             for (u32 wi = lo[t] + 2u; wi < hi[t]; wi++) push_word(t, p.cand[t][wi]);
         }
-        for (int t = TU; t < p.T; t++) {
+        for (int t = TU; t < T; t++) {
             const u32 ng = *p.n_heads[t];
             if (k >= ng) continue;
             const u32 l = p.heads[t][k];
@@ -1041,13 +1043,9 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
         // table size: two-term documents rarely need more than 12 spans; with three terms and more 15 % of them do
         // (3 % more than 16, < 1 % more than 20), and the heavy pass (a wave per document) costs more than the lower
         // residency of a larger table
-        switch ((getenv("SA_SPAN_CE") ? atoi(getenv("SA_SPAN_CE")) : (T <= 2 ? SA_SPAN_LDS : 20))) {      // (SA_SPAN_CE: measurement knob)
-        case 8: hipLaunchKernelGGL((sa_k_span_machine_flat<8, 12>), fg, dim3(64), 0, st, mp); break;
-        case 16: hipLaunchKernelGGL((sa_k_span_machine_flat<16, 16>), fg, dim3(64), 0, st, mp); break;
-        case 20: hipLaunchKernelGGL((sa_k_span_machine_flat<20, 20>), fg, dim3(64), 0, st, mp); break;
-        case 24: hipLaunchKernelGGL((sa_k_span_machine_flat<24, 24>), fg, dim3(64), 0, st, mp); break;
-        default: hipLaunchKernelGGL((sa_k_span_machine_flat<SA_SPAN_LDS, SA_SPAN_PMAX>), fg, dim3(64), 0, st, mp); break;
-        }
+        if (T == 2) hipLaunchKernelGGL((sa_k_span_machine_flat<SA_SPAN_LDS, SA_SPAN_PMAX, 2>), fg, dim3(64), 0, st, mp);
+        else if (T == 3) hipLaunchKernelGGL((sa_k_span_machine_flat<20, 20, 3>), fg, dim3(64), 0, st, mp);
+        else hipLaunchKernelGGL((sa_k_span_machine_flat<20, 20, 0>), fg, dim3(64), 0, st, mp);
         mp.in_list = over_list; mp.in_cnt = cnt + 4 * SA_SPAN_MAX_TERMS;
         const u32 g2 = std::min<u32>(8192u, terms_dev.len[0]);
         hipLaunchKernelGGL(sa_k_span_machine_wave, dim3(g2), dim3(64), 0, st, mp);
