@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Per-query HBM traffic of the slop pipeline from the two --pmc passes of scripts/gpu_slop_pmc.sh.
+slop_heavy.py runs the 2-term phrase reps+1 times, then the 3-term phrase reps+1 times; a query's kernels are the span
+kernels between two sa_k_span_wrap_flag launches.  Counter units as in bench.py: FETCH_SIZE and WRITE_SIZE in KiB;
+FETCH_SIZE under-reports wide coalesced reads on gfx950 (exactly 1/2 for 16 bytes per lane, MI355X_MICROARCH.md), and
+these kernels mix 1-, 4-, 8- and 16-byte accesses, so the read traffic is given as the raw figure (a lower bound) and
+as twice it (the upper bound)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def queries(path):
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    out, cur = [], None
+    for r in rows:
+        name = r["Kernel_Name"]
+        if "span" not in name:
+            continue
+        if "sa_k_span_wrap_flag" in name:
+            cur = collections.defaultdict(lambda: collections.defaultdict(float))
+            out.append(cur)
+        if cur is not None:
+            cur[name.split("(")[0]][r["Counter_Name"]] += float(r["Counter_Value"])
+    return out
+
+
+def main():
+    base = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    f = sorted(glob.glob(f"{base}/pmc_slop_f/*/*counter_collection.csv"), key=os.path.getmtime)[-1]
+    w = sorted(glob.glob(f"{base}/pmc_slop_w/*/*counter_collection.csv"), key=os.path.getmtime)[-1]
+    qf, qw = queries(f), queries(w)
+    res = {}
+    for label, sl in (("2_terms", slice(1, reps + 1)), ("3_terms", slice(reps + 2, 2 * reps + 2))):
+        kern = collections.defaultdict(lambda: collections.defaultdict(float))
+        n = 0
+        for a, b in zip(qf[sl], qw[sl]):
+            n += 1
+            for k, v in a.items():
+                for c, x in v.items():
+                    kern[k][c] += x
+            for k, v in b.items():
+                for c, x in v.items():
+                    kern[k][c] += x
+        per = {}
+        tot_r = tot_w = 0.0
+        for k, v in kern.items():
+            rd = v.get("FETCH_SIZE", 0.0) / n * 1024.0
+            wr = v.get("WRITE_SIZE", 0.0) / n * 1024.0
+            hit, miss = v.get("TCC_HIT_sum", 0.0), v.get("TCC_MISS_sum", 0.0)
+            per[k] = {"read_MB_raw": round(rd / 1e6, 2), "write_MB": round(wr / 1e6, 2),
+                      "l2_hit_rate": round(hit / (hit + miss), 3) if hit + miss else None}
+            tot_r += rd
+            tot_w += wr
+        res[label] = {"hbm_read_MB_raw": round(tot_r / 1e6, 2), "hbm_read_MB_x2": round(2 * tot_r / 1e6, 2),
+                      "hbm_write_MB": round(tot_w / 1e6, 2), "kernels": per}
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

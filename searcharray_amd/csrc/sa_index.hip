@@ -145,6 +145,21 @@ sa_k_build_docdir(const u64* __restrict__ words, u32 n, u32* __restrict__ row, u
     }
 }
 
+// per term: bit 0 = its first word has header 0 (doc 0, block 0), bit 1 = its last word has the largest header.
+// sa_spans.hip needs "header 0 in L" per slop query; with these it is host arithmetic instead of a launch.
+__global__ void __launch_bounds__(256)
+sa_k_term_edges(const u64* __restrict__ words, const u64* __restrict__ term_off, u32 n_terms, unsigned char* __restrict__ out) {
+    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < n_terms; t += gridDim.x * blockDim.x) {
+        const u64 a = term_off[t], b = term_off[t + 1];
+        unsigned char e = 0;
+        if (b > a) {
+            if ((words[a] & SA_HEADER_MASK) == 0) e |= 1;
+            if ((words[b - 1] & SA_HEADER_MASK) == SA_HEADER_MASK) e |= 2;
+        }
+        out[t] = e;
+    }
+}
+
 // dense tf row of one term from its fat postings
 __global__ void __launch_bounds__(256)
 sa_k_build_tf8(const u64* __restrict__ tfp, u32 n, unsigned char* __restrict__ row, u32* __restrict__ bits) {
@@ -473,6 +488,20 @@ int sa_index_derive(sa_index* ix) {
         hipError_t e2 = hipStreamSynchronize(st);
         hipFree(d_top);
         if (e1 != hipSuccess || e2 != hipSuccess) { sa_set_error("doc directory build failed"); return SA_ERR_HIP; }
+    }
+    // ---- first / last header of every term (slop queries: sa_spans.hip) ----
+    {
+        ix->h_term_edge.assign((size_t)V + 1, 0);
+        if (V > 0) {
+            unsigned char* d_edge = nullptr;
+            SA_HIP(hipMalloc(&d_edge, (size_t)V));
+            hipLaunchKernelGGL(sa_k_term_edges, dim3(V / 256 + 1 < 4096 ? V / 256 + 1 : 4096), dim3(256), 0, st,
+                               (const u64*)ix->d_words, (const u64*)ix->d_term_off, V, d_edge);
+            hipError_t e1 = hipMemcpyAsync(ix->h_term_edge.data(), d_edge, (size_t)V, hipMemcpyDeviceToHost, st);
+            hipError_t e2 = hipStreamSynchronize(st);
+            hipFree(d_edge);
+            if (e1 != hipSuccess || e2 != hipSuccess) { sa_set_error("term edge flags failed"); return SA_ERR_HIP; }
+        }
     }
     SA_HIP(hipStreamSynchronize(st));
     SA_HIP(hipGetLastError());

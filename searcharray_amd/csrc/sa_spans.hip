@@ -149,10 +149,14 @@ __global__ void __launch_bounds__(256) sa_k_span_wrap_flag(const SpanTerms st, u
 // instructions on indexing them), 0: any number.
 template <int TT>
 __global__ void __launch_bounds__(256)
-sa_k_span_flags(const SpanTerms st, const u32* __restrict__ wrap, unsigned char* __restrict__ flags, float* __restrict__ counts) {
+sa_k_span_flags(const SpanTerms st, const u32* __restrict__ wrap, const int wrap_host, u32* __restrict__ cnt_clear,
+                unsigned char* __restrict__ flags, float* __restrict__ counts) {
     const int T = TT ? TT : st.T;
     const u32 total = st.off[T];
-    const bool wr = *wrap != 0;
+    // "header 0 in L": from sa_k_span_wrap_flag (filtered lists), or worked out on the host from the index's per-term
+    // edge flags -- then this launch also clears the query's counters and no launch precedes it
+    const bool wr = wrap ? *wrap != 0 : wrap_host != 0;
+    if (cnt_clear && blockIdx.x == 0 && threadIdx.x < SA_SPAN_CNT_WORDS) cnt_clear[threadIdx.x] = 0u;
     for (u64 d = (u64)blockIdx.x * blockDim.x + threadIdx.x; d < st.n_docs; d += (u64)gridDim.x * blockDim.x) counts[d] = 0.f;
     for (u32 g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
         int t = 0;
@@ -988,16 +992,33 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
         SA_HIP(hipMemsetAsync(running, 0, N * sizeof(float), st));
         return SA_OK;
     }
-    hipLaunchKernelGGL(sa_k_span_wrap_flag, dim3(1), dim3(256), 0, st, terms_dev, cnt);
+    // header 0 in L?  Whole lists: host arithmetic on the index's per-term edge flags (sa_k_term_edges); lists cut
+    // by a position filter: sa_k_span_wrap_flag looks at the filtered words.
+    const u32* wrap_dev = nullptr;
+    int wrap_host = 0;
+    u32* cnt_clear = cnt;
+    if (filt.active || ix->h_term_edge.size() < (size_t)ix->n_terms) {
+        hipLaunchKernelGGL(sa_k_span_wrap_flag, dim3(1), dim3(256), 0, st, terms_dev, cnt);
+        wrap_dev = cnt + SA_SPAN_CNT_WRAP;
+        cnt_clear = nullptr;
+    } else {
+        const unsigned char e0 = ix->h_term_edge[terms[0]];
+        bool L = true;
+        for (int i = 1; i < T; i++) {
+            const unsigned char ei = ix->h_term_edge[terms[i]];
+            const bool a0 = e0 & 1, a0m = e0 & 2, bi = ei & 1, bim = ei & 2;
+            L &= (a0 && bi) || (bi && a0m) || (a0 && bim);
+        }
+        wrap_host = L ? 1 : 0;
+    }
     {
         const u32 total = terms_dev.off[T];
         const u32 grid = total / 256 + 1 < 16384 ? total / 256 + 1 : 16384;
-        const u32* wrap = cnt + SA_SPAN_CNT_WRAP;
         switch (T) {
-        case 2: hipLaunchKernelGGL(sa_k_span_flags<2>, dim3(grid), dim3(256), 0, st, terms_dev, wrap, flags, running); break;
-        case 3: hipLaunchKernelGGL(sa_k_span_flags<3>, dim3(grid), dim3(256), 0, st, terms_dev, wrap, flags, running); break;
-        case 4: hipLaunchKernelGGL(sa_k_span_flags<4>, dim3(grid), dim3(256), 0, st, terms_dev, wrap, flags, running); break;
-        default: hipLaunchKernelGGL(sa_k_span_flags<0>, dim3(grid), dim3(256), 0, st, terms_dev, wrap, flags, running); break;
+        case 2: hipLaunchKernelGGL(sa_k_span_flags<2>, dim3(grid), dim3(256), 0, st, terms_dev, wrap_dev, wrap_host, cnt_clear, flags, running); break;
+        case 3: hipLaunchKernelGGL(sa_k_span_flags<3>, dim3(grid), dim3(256), 0, st, terms_dev, wrap_dev, wrap_host, cnt_clear, flags, running); break;
+        case 4: hipLaunchKernelGGL(sa_k_span_flags<4>, dim3(grid), dim3(256), 0, st, terms_dev, wrap_dev, wrap_host, cnt_clear, flags, running); break;
+        default: hipLaunchKernelGGL(sa_k_span_flags<0>, dim3(grid), dim3(256), 0, st, terms_dev, wrap_dev, wrap_host, cnt_clear, flags, running); break;
         }
     }
     SpanMachineParams mp;
