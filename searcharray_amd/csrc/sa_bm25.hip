@@ -816,6 +816,8 @@ __device__ __forceinline__ void sa_static_while_below(u32 n, F&& f) {
 // s_waitcnt with vmcnt = 0 and the other counters open (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14])
 #define SA_WAIT_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)
 
+#define SA_GRP_REFRESH_STEP 32
+
 template <int TILE>
 __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, const GroupParams gp) {
     constexpr int NH = SA_GRP_NH;
@@ -1014,6 +1016,9 @@ __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, 
         // final scores of the touched docs; base values back
         __builtin_amdgcn_wave_barrier();
         u64 anyk = 0ull;
+        u64 kb[NH];                                             // per half: the lanes whose doc reaches the bound (scalar registers)
+#pragma unroll
+        for (int h = 0; h < NH; h++) kb[h] = 0ull;
         sa_static_while_below<0, NH, 2>(nh, [&](auto hc) {
             constexpr int h2 = decltype(hc)::value;
 #pragma unroll
@@ -1022,15 +1027,15 @@ __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, 
                 const u32 fin = at(sl) & 0x7FFFFFFFu;
                 at(sl) = ro[h];
                 ro[h] = fin;
-                anyk |= __ballot(sl != spare && fin >= thr);
+                kb[h] = __ballot(sl != spare && fin >= thr);
+                anyk |= kb[h];
             }
         });
         __builtin_amdgcn_wave_barrier();
         if (anyk == 0ull) return;                               // the usual case once the bound stands
         u32 c = 0;
 #pragma unroll
-        for (int i = 0; i < NH; i++)
-            if ((u32)(i & ~1) < nh) c += (u32)__popcll(__ballot(rs[i] != spare && ro[i] >= thr));
+        for (int i = 0; i < NH; i++) c += (u32)__popcll(kb[i]);
         if (c > 16u) { deferred |= 1ull << qi; return; }        // bound still far off: the per-query item's histogram path refines it first
         u32* qh = p.hist + (u64)q * SA_HBINS;
         u64* qcand = p.cand + (u64)q * p.cand_cap;
@@ -1038,21 +1043,24 @@ __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, 
         u32 cbase = 0;
         if (lane == 0) cbase = atomicAdd(&p.cand_cnt[q], c);
         cbase = (u32)__builtin_amdgcn_readfirstlane((int)cbase);
+        const u32 cb0 = cbase;
 #pragma unroll
         for (int i = 0; i < NH; i++) {
-            if ((u32)(i & ~1) < nh) {
-                const bool keep = rs[i] != spare && ro[i] >= thr;
-                const u64 bl = __ballot(keep);
-                if (keep) {
+            if (kb[i]) {                                        // (uniform: halves without survivors cost a scalar test)
+                if ((kb[i] >> lane) & 1ull) {
                     atomicAdd(&qh[sa_score_bin(ro[i])], 1u);
-                    const u32 pos = cbase + (u32)__popcll(bl & lt);
+                    const u32 pos = cbase + (u32)__popcll(kb[i] & lt);
                     const u64 doc = p.doc_base + tile_base + (u64)(rs[i] >> 2);
                     if (pos < p.cand_cap) qcand[pos] = ((u64)ro[i] << 32) | (u64)(u32)(~(u32)doc);
                 }
-                cbase += (u32)__popcll(bl);
+                cbase += (u32)__popcll(kb[i]);
             }
         }
-        if (((tile + q) & 7u) == 0u) sa_hist_refresh(qh, &p.gthr[q], p.k, lane);
+        // the bound moves when candidates arrive: re-derive it whenever the query's list crosses a multiple of
+        // SA_GRP_REFRESH_STEP entries (reading the histogram is a round trip to L2 under contention -- per
+        // (tile, query) pair with survivors it cost 0.2 ms of the 1.3 ms step at k = 1000; measured: step 8 / 32 /
+        // 128 / 512 -> 1.44 / 1.18 / 1.20 / 1.24 ms at k = 1000, 0.614 / 0.601 / 0.615 / 0.641 ms at k = 10)
+        if (cb0 / (u32)SA_GRP_REFRESH_STEP != (cb0 + c) / (u32)SA_GRP_REFRESH_STEP) sa_hist_refresh(qh, &p.gthr[q], p.k, lane);
     };
 
     // ---- the queries of the group, two per round so that the prefetch buffers swap without copies.  Before the
