@@ -48,11 +48,26 @@ def main():
             open(os.path.join(PROF, f"group_ab_{RND}.jsonl"), "w").write("\n".join(lines) + "\n")
             print("wrote", f"group_ab_{RND}.jsonl")
     for sub, dst in [("prof_stats", f"{RND}_bench_kernel_stats.csv"), ("prof_phrase", f"{RND}_phrase_bench_kernel_stats.csv"),
-                     ("prof_slop", f"{RND}_slop_bench_kernel_stats.csv")]:
+                     ("prof_slop", f"{RND}_slop_bench_kernel_stats.csv"),
+                     ("prof_slop2", f"{RND}_slop_heaviest_2term_kernel_stats.csv"),      # scripts/slop_heavy.py: 6 runs of ONE query
+                     ("prof_slop3", f"{RND}_slop_heaviest_3term_kernel_stats.csv")]:
         f = newest(os.path.join(OUT, sub, "**", "*kernel_stats.csv"))
         if f:
             shutil.copy(f, os.path.join(PROF, dst))
             print("wrote", dst)
+    # HBM traffic of the slop pipeline (scripts/gpu_slop_pmc.sh + scripts/slop_pmc.py)
+    if newest(os.path.join(OUT, "pmc_slop_f", "**", "*counter_collection.csv")):
+        import subprocess
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "slop_pmc.py"), OUT], capture_output=True, text=True)
+        if r.returncode == 0 and r.stdout.strip().startswith("{"):
+            open(os.path.join(PROF, f"{RND}_slop_pmc_traffic.json"), "w").write(r.stdout)
+            print("wrote", f"{RND}_slop_pmc_traffic.json")
+    hv = os.path.join(OUT, "slop_heavy.log")
+    if os.path.exists(hv):
+        lines = [ln for ln in open(hv).read().splitlines() if ln.startswith("{")]
+        if lines:
+            open(os.path.join(PROF, f"slop_heaviest_{RND}.jsonl"), "w").write("\n".join(lines) + "\n")
+            print("wrote", f"slop_heaviest_{RND}.jsonl")
     # SQ counters of the scoring kernels (two passes of 8 counters), mean per dispatch
     sq = {}
     for sub in ("prof_grp_sq", "prof_grp_sq2"):

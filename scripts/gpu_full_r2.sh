@@ -27,6 +27,9 @@ cd /tmp
 ( timeout 120 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/prof_grp_sq2 -- python $R/scripts/group_ab.py --corpus-cache /tmp/corpus --ks 10 --only 1 --qsets baseline --steps 2 ) > $O/prof_grp_sq2.log 2>&1
 ( timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_phrase -- python $R/scripts/phrase_bench.py --phrases 16 --cpu-phrases 1 ) > $O/prof_phrase.log 2>&1
 ( timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_slop -- python $R/scripts/slop_bench.py --phrases 16 --cpu-phrases 1 ) > $O/prof_slop.log 2>&1
+bash $R/scripts/gpu_slop_prof.sh > $O/slop_heavy.log 2>&1
+bash $R/scripts/gpu_slop_pmc.sh > $O/slop_pmc.log 2>&1
+cd /tmp
 find $O -name "*.db" -delete 2>/dev/null
 find $O -type f -size +8M -delete 2>/dev/null
 grep -E "passed|failed" $O/pytest_gpu.log

@@ -162,7 +162,14 @@ sa_k_span_flags(const SpanTerms st, const u32* __restrict__ wrap, const int wrap
         int t = 0;
 #pragma unroll
         for (int i = 1; i < (TT ? TT : SA_SPAN_MAX_TERMS); i++) t += (i < T && g >= st.off[i]) ? 1 : 0;
-        const u64 h = st.words[t][g - st.off[t]] & SA_HEADER_MASK;
+        const u32 gi = g - st.off[t], gn = st.len[t];
+        const u64* const own = st.words[t];
+        const u64 h = own[gi] & SA_HEADER_MASK;
+        // the word's OWN term needs no probe: headers are unique and sorted within a term, so h - 1 / h + 1 are in the
+        // list iff they are the neighbouring words' headers (the wrapped neighbours of header 0 / of the largest
+        // header: the list's last / first word) -- two loads from the lines the wave is reading anyway
+        const u64 own_prev = own[gi > 0u ? gi - 1u : gn - 1u] & SA_HEADER_MASK;
+        const u64 own_next = own[gi + 1u < gn ? gi + 1u : 0u] & SA_HEADER_MASK;
         u32 m[TT ? TT : SA_SPAN_MAX_TERMS];
         bool possible = true;
 #pragma unroll
@@ -180,7 +187,7 @@ sa_k_span_flags(const SpanTerms st, const u32* __restrict__ wrap, const int wrap
         bool via[TU];
 #pragma unroll
         for (int i = 0; i < TU; i++) {
-            via[i] = i < T && st.dd[i] != nullptr && plain;
+            via[i] = i < T && i != t && st.dd[i] != nullptr && plain;
             jj[i] = via[i] ? st.dd[i][doc] : SA_DD_ABSENT;
         }
 #pragma unroll
@@ -206,6 +213,8 @@ sa_k_span_flags(const SpanTerms st, const u32* __restrict__ wrap, const int wrap
                         for (u32 j = jj[i] + 2u; j < st.len[i]; j++)
                             if (!step(st.words[i][j])) break;
                     m[i] = bits;
+                } else if (i == t) {
+                    m[i] = 2u | (own_prev == hm ? 1u : 0u) | (own_next == hp ? 4u : 0u);
                 } else {
                     m[i] = st.dd[i] ? sa_header_triple_dd(st.words[i], st.len[i], st.dd[i], st.n_docs, h)
                                     : sa_header_triple(st.words[i], st.len[i], h);
@@ -215,8 +224,9 @@ sa_k_span_flags(const SpanTerms st, const u32* __restrict__ wrap, const int wrap
             }
         }
         for (int i = TU; i < T && possible; i++) {
-            m[i] = st.dd[i] ? sa_header_triple_dd(st.words[i], st.len[i], st.dd[i], st.n_docs, h)
-                            : sa_header_triple(st.words[i], st.len[i], h);
+            if (i == t) m[i] = 2u | (own_prev == hm ? 1u : 0u) | (own_next == hp ? 4u : 0u);
+            else m[i] = st.dd[i] ? sa_header_triple_dd(st.words[i], st.len[i], st.dd[i], st.n_docs, h)
+                                 : sa_header_triple(st.words[i], st.len[i], h);
             if (m[i] == 0) possible = false;
         }
         flags[g] = (possible && sa_span_keep<TT>(m, T, wr)) ? 1 : 0;
