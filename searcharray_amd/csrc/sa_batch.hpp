@@ -58,6 +58,7 @@ struct sa_batch {
     u64* d_local = nullptr;         // [B][k] per-shard result
     u64* d_gather = nullptr;        // [2][nranks][B][k] (multi-GPU, double-buffered like d_xlocal)
     u64* d_xlocal = nullptr;        // [2][B][k] per-shard results handed to the exchange stream
+    hipEvent_t ev_side[2] = {nullptr, nullptr};       // side stream: [0] the run's state is reset (index stream), [1] the ungrouped rows are scored (side stream)
     hipEvent_t ev_scored[2] = {nullptr, nullptr};     // d_xlocal[b] written (index stream)
     hipEvent_t ev_exchanged[2] = {nullptr, nullptr};  // d_xlocal[b] / d_gather[b] consumed (exchange stream)
     bool exchanged_valid[2] = {false, false};

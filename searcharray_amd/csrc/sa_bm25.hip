@@ -817,6 +817,7 @@ __device__ __forceinline__ void sa_static_while_below(u32 n, F&& f) {
 #define SA_WAIT_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)
 
 #define SA_GRP_REFRESH_STEP 32
+#define SA_GRP_LOOSE_POSTINGS 384   // loose groups: expected postings of a query per tile, all terms together (<= 6 of the 12 halves)
 
 template <int TILE>
 __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, const GroupParams gp) {
@@ -835,7 +836,10 @@ __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, 
     const u32 trel = chunk * 8u + (r & 7u);
     if (trel >= gp.n_tiles_run) return;
     const u32 tile = gp.tile0 + trel;
-    const u32 row0 = gp.grp[2 * g], n = gp.grp[2 * g + 1];
+    // a LOOSE group (bit 31 of the size): queries that share nothing -- no base, ALL their terms are overlaid on
+    // cleared accumulators (0 + s0 = s0, so the sums are the same); what they share is the item's fixed cost
+    const u32 row0 = gp.grp[2 * g], n_raw = gp.grp[2 * g + 1], n = n_raw & 0x7FFFFFFFu;
+    const bool loose = (n_raw >> 31) != 0u;
     const u32 T = p.T;
     const u64 tile_base = (u64)tile * TILE;
     const u32 tile_base_b = (u32)tile_base * 4u;
@@ -846,7 +850,7 @@ __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, 
     // ---- the shared first term
     const u32 qt0 = row0 * T;
     const u32* hrow = p.bounds + (u64)qt0 * (p.n_tiles + 1) + tile;
-    const u32 h0 = hrow[0], h1 = hrow[1];
+    const u32 h0 = loose ? 0u : hrow[0], h1 = loose ? 0u : hrow[1];
     const sa_u64x2 hbs = ((const sa_u64x2*)p.qbase_imp)[qt0];
     const float hidf = p.idf[qt0];
 
@@ -856,7 +860,7 @@ __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, 
     struct Pre { u32 r0, r1; u64 base; float idf; };
     auto pre_load = [&](u32 ps) -> Pre {
         Pre x; x.r0 = 0; x.r1 = 0; x.base = 0; x.idf = 0.f;
-        const u32 qi = ps * QPP + (lane >> tsh), t = 1u + (lane & (TT - 1u));
+        const u32 qi = ps * QPP + (lane >> tsh), t = (loose ? 0u : 1u) + (lane & (TT - 1u));
         if (qi < n && t < T) {
             const u32 qt = (row0 + qi) * T + t;
             const u32* row = p.bounds + (u64)qt * (p.n_tiles + 1) + tile;
@@ -1469,6 +1473,7 @@ void sa_batch_free(sa_batch* bt) {
     if (bt->d_gather) hipFree(bt->d_gather);
     if (bt->d_xlocal) hipFree(bt->d_xlocal);
     for (int i = 0; i < 2; i++) {
+        if (bt->ev_side[i]) hipEventDestroy(bt->ev_side[i]);
         if (bt->ev_scored[i]) hipEventDestroy(bt->ev_scored[i]);
         if (bt->ev_exchanged[i]) hipEventDestroy(bt->ev_exchanged[i]);
     }
@@ -1583,9 +1588,14 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
     // groups are cut into balanced pieces of at most `maxq` queries), the others keep their order behind them.
     std::vector<u32> h_grp;
     {
+        // lanes per query while the half tables are built: a power of two >= the terms overlaid -- T - 1 for groups
+        // with a shared first term, T for loose groups (decided below; loose groups are only formed if the wider
+        // table still takes SA_GRP_MAXQ queries)
         u32 tt = 1, tsh = 0;
         while (tt + 1u < T) { tt <<= 1; tsh++; }               // power of two >= max(T - 1, 1)
-        bt->grp_tt = tt; bt->grp_tt_shift = tsh;
+        u32 tt_loose = 1, tsh_loose = 0;
+        while (tt_loose < T) { tt_loose <<= 1; tsh_loose++; }
+        const bool loose_on = sa_env_int("SA_GROUP_LOOSE", 1) != 0 && 128u / tt_loose >= SA_GRP_MAXQ;
         const u32 maxq = std::min<u32>(SA_GRP_MAXQ, 128u / tt);
         const u32 gmin = (u32)std::max(1, sa_env_int("SA_GROUP_MIN", 2));
         bool idf_ok = k1 >= 0.f && b >= 0.f && b <= 1.f;       // scores must be non-negative (the sign bit is a mark)
@@ -1618,11 +1628,41 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
                     done += sz;
                 }
             }
+            // Loose groups: queries left over whose terms are all sparse per tile (what a (tile, query) pair of the
+            // per-query kernel costs is clearing and scanning the tile's accumulators, 2048 slots for ~130 postings;
+            // as an overlay on accumulators that are cleared once per 16 queries and touched only where the postings
+            // are, it costs the postings).  Eligible: an expected sum of postings per tile that fits the overlay's
+            // half table with room to spare; the others keep the per-query kernel (their tiles are dense).
+            if (loose_on && ix->n_tiles > 0) {
+                std::vector<u32> sparse_rows, dense_rows;
+                for (u32 q : rest) {
+                    u64 dfsum = 0;
+                    for (u32 t = 0; t < T; t++) {
+                        const u32 term = terms[(size_t)q * T + t];
+                        if (term < ix->n_terms) dfsum += ix->h_tf_off[term + 1] - ix->h_tf_off[term];
+                    }
+                    if (dfsum > 0 && dfsum / ix->n_tiles <= (u64)SA_GRP_LOOSE_POSTINGS) sparse_rows.push_back(q);
+                    else dense_rows.push_back(q);
+                }
+                if (sparse_rows.size() >= 2) {
+                    const u32 pieces = ((u32)sparse_rows.size() + SA_GRP_MAXQ - 1) / SA_GRP_MAXQ;
+                    u32 done = 0;
+                    for (u32 pc = 0; pc < pieces; pc++) {
+                        const u32 sz = ((u32)sparse_rows.size() - done + (pieces - pc) - 1) / (pieces - pc);
+                        h_grp.push_back((u32)order.size()); h_grp.push_back(sz | 0x80000000u);
+                        for (u32 i = 0; i < sz; i++) order.push_back(sparse_rows[done + i]);
+                        done += sz;
+                    }
+                    rest = dense_rows;
+                    tt = tt_loose; tsh = tsh_loose;
+                }
+            }
             bt->n_grouped_rows = (u32)order.size();
             bt->n_groups = (u32)(h_grp.size() / 2);
             order.insert(order.end(), rest.begin(), rest.end());
             bt->perm = order;
         }
+        bt->grp_tt = tt; bt->grp_tt_shift = tsh;
     }
     std::vector<u32> h_terms((size_t)B * T);
     std::vector<float> h_idf((size_t)B * T);
@@ -1860,15 +1900,32 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
                 u32 warm = std::max<u32>(16u, bt->k / 4u);
                 if (const char* v = getenv("SA_GROUP_WARM")) warm = (u32)atoi(v);
                 warm = std::min(warm, ix->n_tiles);
-                Bm25Params pa = p;
-                pa.qlist = bt->d_iota; pa.nq = bt->n_grouped_rows; pa.tile0 = 0; pa.tile_end = warm;
-                SA_TRY(sa_launch_bm25(ix, pa, st));
+                // The ungrouped rows (per-query kernel over all tiles) share nothing with the grouped ones -- not a
+                // query, not a counter -- so they run on the side stream BESIDE the warm-up tiles and the grouped kernel
+                // (a few dense queries are a small grid of long workgroups: alone on the device they took 0.28 ms of a
+                // 0.82 ms step on a batch without shared terms); the merge waits for both.
+                bool side = false;
                 if (bt->n_grouped_rows < bt->B) {
                     Bm25Params pu = p;
                     pu.qlist = bt->d_iota + bt->n_grouped_rows; pu.nq = bt->B - bt->n_grouped_rows;
-                    SA_TRY(sa_launch_bm25(ix, pu, st));
+                    side = sa_env_int("SA_GROUP_SIDE", 1) != 0;
+                    if (side) {
+                        if (!ix->sstream) SA_HIP(hipStreamCreateWithFlags(&ix->sstream, hipStreamNonBlocking));
+                        for (int i = 0; i < 2; i++)
+                            if (!bt->ev_side[i]) SA_HIP(hipEventCreateWithFlags(&bt->ev_side[i], hipEventDisableTiming));
+                        SA_HIP(hipEventRecord(bt->ev_side[0], st));               // (after the reset: the launches above)
+                        SA_HIP(hipStreamWaitEvent(ix->sstream, bt->ev_side[0], 0));
+                        SA_TRY(sa_launch_bm25(ix, pu, ix->sstream));
+                        SA_HIP(hipEventRecord(bt->ev_side[1], ix->sstream));
+                    } else {
+                        SA_TRY(sa_launch_bm25(ix, pu, st));
+                    }
                 }
+                Bm25Params pa = p;
+                pa.qlist = bt->d_iota; pa.nq = bt->n_grouped_rows; pa.tile0 = 0; pa.tile_end = warm;
+                SA_TRY(sa_launch_bm25(ix, pa, st));
                 if (ix->n_tiles > warm) SA_TRY(sa_launch_bm25_groups(ix, bt, p, warm, st));
+                if (side) SA_HIP(hipStreamWaitEvent(st, bt->ev_side[1], 0));
             } else {
                 SA_TRY(sa_launch_bm25(ix, p, st));
             }

@@ -227,6 +227,7 @@ void sa_index_free(sa_index* ix) {
     if (ix->d_sim_scratch) hipFree(ix->d_sim_scratch);
     if (ix->ev0) hipEventDestroy(ix->ev0);
     if (ix->ev1) hipEventDestroy(ix->ev1);
+    if (ix->sstream) hipStreamDestroy(ix->sstream);
     if (ix->xstream) hipStreamDestroy(ix->xstream);
     if (ix->stream) hipStreamDestroy(ix->stream);
     delete ix;
@@ -757,6 +758,7 @@ extern "C" int sa_index_synchronize(sa_index_t* ix) {
     SA_ARG(ix, "null index");
     SA_HIP(hipSetDevice(ix->device));
     SA_HIP(hipStreamSynchronize(ix->stream));
+    if (ix->sstream) SA_HIP(hipStreamSynchronize(ix->sstream));
     if (ix->xstream) SA_HIP(hipStreamSynchronize(ix->xstream));
     SA_HIP(hipGetLastError());
     return SA_OK;

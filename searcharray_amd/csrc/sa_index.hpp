@@ -106,6 +106,7 @@ struct sa_index {
     std::shared_ptr<sa_impacts> impacts;
 
     sa_comm* comm = nullptr;
+    hipStream_t sstream = nullptr;   // side stream: the per-query kernel over a batch's ungrouped rows runs beside the grouped kernel
     hipStream_t xstream = nullptr;   // exchange stream: all-gather + cross-rank merge overlap the next batch's scoring
 
     // profile counters (sa_index_stats)

@@ -110,3 +110,29 @@ def test_negative_idf_disables_grouping(api, corpus, monkeypatch):
     monkeypatch.setenv("SA_GROUP", "0")
     want = check(api, corpus, queries, 5, idf=idf)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+@pytest.mark.parametrize("T,k", [(2, 5), (4, 10), (5, 40), (8, 10)])
+def test_loose_groups_equal_oracle_and_per_query_kernel(api, corpus, monkeypatch, T, k):
+    """queries that share NO first term: those whose terms are sparse per tile are scored as LOOSE groups (no base,
+    every term overlaid on cleared accumulators), the dense ones by the per-query kernel -- same results as the
+    oracle, and as with loose groups switched off (SA_GROUP_LOOSE=0)"""
+    monkeypatch.setenv("SA_SPARSE", "0")
+    rng = np.random.default_rng(500 + T)
+    # distinct first terms; a few dense heads (terms 0..3) among mostly rare terms, repeated and unknown terms
+    firsts = rng.permutation(np.arange(4, 300))[:36]
+    queries = []
+    for i, f in enumerate(firsts):
+        q = [int(f)] + [int(x) for x in rng.integers(20, VOCAB, T - 1)]
+        if i % 9 == 0 and T > 1:
+            q[1] = int(rng.integers(0, 4))                         # a dense term somewhere but first
+        if i % 11 == 0 and T > 2:
+            q[2] = q[1]                                            # a repeated term
+        if i % 13 == 0:
+            q[-1] = VOCAB + 5                                      # an unknown term
+        queries.append(q)
+    queries.append([0] + [int(x) for x in rng.integers(20, VOCAB, T - 1)])       # a dense first term: per-query kernel
+    got = check(api, corpus, queries, k, tile_docs=1024)
+    monkeypatch.setenv("SA_GROUP_LOOSE", "0")
+    ref = check(api, corpus, queries, k, tile_docs=1024)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
