@@ -817,6 +817,7 @@ __device__ __forceinline__ void sa_static_while_below(u32 n, F&& f) {
 #define SA_WAIT_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)
 
 #define SA_GRP_REFRESH_STEP 32
+#define SA_GRP_SURV_CAP 128         // survivors an item buffers before it writes them out (a pair has at most 16)
 #define SA_GRP_LOOSE_POSTINGS 384   // loose groups: expected postings of a query per tile, all terms together (<= 6 of the 12 halves)
 
 template <int TILE>
@@ -825,6 +826,7 @@ __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, 
     __shared__ alignas(16) u64 smem[sa_tile_smem_u64<TILE, 1>()];
     __shared__ alignas(16) SaGrpHalf s_half[SA_GRP_MAXQ][NH];
     __shared__ u32 s_nh[SA_GRP_MAXQ];
+    __shared__ u64 s_surv[SA_GRP_SURV_CAP];                     // survivors waiting for their places: score bits << 32 | accumulator offset << 4 | query
     u32* const accu = (u32*)smem;
     const u32 lane = threadIdx.x;
     // XCD-aware item order: consecutive blocks go to consecutive XCDs (block b runs on XCD b % 8), so the
@@ -989,8 +991,45 @@ __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, 
 
     // queries left to the per-query kernel (work list at the end)
     u64 deferred = 0ull;
+    // survivors out: one reservation per query with survivors (lane qi reserves for query qi: the atomics travel
+    // together), every buffered entry to its place (the buffer is in query order: an entry's offset inside its query
+    // is its index minus the exclusive prefix of the per-query counts), bounds re-derived where a list crossed a
+    // multiple of SA_GRP_REFRESH_STEP entries
+    u32 nsurv = 0, my_surv = 0;                                  // buffered (wave-uniform); lane qi: those of query qi
+    auto flush = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        u32 cbase = 0;
+        if (my_surv) cbase = atomicAdd(&p.cand_cnt[row0 + lane], my_surv);
+        u32 start = my_surv;
+#pragma unroll
+        for (int o = 1; o < SA_GRP_MAXQ; o <<= 1) {
+            const u32 up = (u32)__shfl_up((int)start, (unsigned)o, SA_WAVE);
+            if (lane >= (u32)o) start += up;
+        }
+        start -= my_surv;
+        for (u32 e0 = 0; e0 < nsurv; e0 += (u32)SA_WAVE) {
+            const u32 e = e0 + lane;
+            const bool have = e < nsurv;
+            const u64 ent = s_surv[have ? e : 0u];
+            const u32 eq = (u32)ent & 0xFu, sl = (u32)ent >> 4, fin = (u32)(ent >> 32);
+            const u32 qb = (u32)__shfl((int)cbase, (int)eq, SA_WAVE), qs = (u32)__shfl((int)start, (int)eq, SA_WAVE);
+            if (have) {
+                const u32 q = row0 + eq;
+                atomicAdd(&p.hist[(u64)q * SA_HBINS + sa_score_bin(fin)], 1u);
+                const u32 pos = qb + (e - qs);
+                const u64 doc = p.doc_base + tile_base + (u64)(sl >> 2);
+                if (pos < p.cand_cap) p.cand[(u64)q * p.cand_cap + pos] = ((u64)fin << 32) | (u64)(u32)(~(u32)doc);
+            }
+        }
+        const bool crossed = my_surv != 0u && cbase / (u32)SA_GRP_REFRESH_STEP != (cbase + my_surv) / (u32)SA_GRP_REFRESH_STEP;
+        for (u64 m = __ballot(crossed); m; m &= m - 1ull) {
+            const u32 q = row0 + (u32)__builtin_ctzll(m);
+            sa_hist_refresh(p.hist + (u64)q * SA_HBINS, &p.gthr[q], p.k, lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+        nsurv = 0; my_surv = 0;
+    };
     auto process = [&](u32 qi, const Q& X) {
-        const u32 q = row0 + qi;
         const u32 nh = (u32)__builtin_amdgcn_readfirstlane((int)X.dcnt) >> 8;
         const u32 thr_q = (u32)__builtin_amdgcn_readlane((int)thr_all, (int)qi);
         const u32 thr = thr_q > 1u ? thr_q : 1u;
@@ -1041,30 +1080,20 @@ __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, 
 #pragma unroll
         for (int i = 0; i < NH; i++) c += (u32)__popcll(kb[i]);
         if (c > 16u) { deferred |= 1ull << qi; return; }        // bound still far off: the per-query item's histogram path refines it first
-        u32* qh = p.hist + (u64)q * SA_HBINS;
-        u64* qcand = p.cand + (u64)q * p.cand_cap;
+        // Survivors are buffered in LDS and written out together (flush below): reserving places in a query's
+        // candidate list is an atomic WITH a return value -- a round trip to L2 the wave sits out; per surviving pair
+        // that was most of the 0.45 ms the candidates cost at k = 1000.  Flushed, the reservations of all queries of
+        // the item travel together.
+        if (nsurv + c > (u32)SA_GRP_SURV_CAP) flush();
         const u64 lt = (1ull << lane) - 1ull;
-        u32 cbase = 0;
-        if (lane == 0) cbase = atomicAdd(&p.cand_cnt[q], c);
-        cbase = (u32)__builtin_amdgcn_readfirstlane((int)cbase);
-        const u32 cb0 = cbase;
 #pragma unroll
         for (int i = 0; i < NH; i++) {
             if (kb[i]) {                                        // (uniform: halves without survivors cost a scalar test)
-                if ((kb[i] >> lane) & 1ull) {
-                    atomicAdd(&qh[sa_score_bin(ro[i])], 1u);
-                    const u32 pos = cbase + (u32)__popcll(kb[i] & lt);
-                    const u64 doc = p.doc_base + tile_base + (u64)(rs[i] >> 2);
-                    if (pos < p.cand_cap) qcand[pos] = ((u64)ro[i] << 32) | (u64)(u32)(~(u32)doc);
-                }
-                cbase += (u32)__popcll(kb[i]);
+                if ((kb[i] >> lane) & 1ull) s_surv[nsurv + (u32)__popcll(kb[i] & lt)] = ((u64)ro[i] << 32) | (u64)(rs[i] << 4) | (u64)qi;
+                nsurv += (u32)__popcll(kb[i]);
             }
         }
-        // the bound moves when candidates arrive: re-derive it whenever the query's list crosses a multiple of
-        // SA_GRP_REFRESH_STEP entries (reading the histogram is a round trip to L2 under contention -- per
-        // (tile, query) pair with survivors it cost 0.2 ms of the 1.3 ms step at k = 1000; measured: step 8 / 32 /
-        // 128 / 512 -> 1.44 / 1.18 / 1.20 / 1.24 ms at k = 1000, 0.614 / 0.601 / 0.615 / 0.641 ms at k = 10)
-        if (cb0 / (u32)SA_GRP_REFRESH_STEP != (cb0 + c) / (u32)SA_GRP_REFRESH_STEP) sa_hist_refresh(qh, &p.gthr[q], p.k, lane);
+        if (lane == qi) my_surv = c;
     };
 
     // ---- the queries of the group, two per round so that the prefetch buffers swap without copies.  Before the
@@ -1080,6 +1109,7 @@ __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, 
             process(qi + 1u, B);
         }
     }
+    if (nsurv) flush();
     // ---- general path: hand the (tile, query) pairs to the per-query kernel that follows (sa_k_bm25_tiles_wl)
     if (deferred) {
         const u32 c = (u32)__popcll(deferred);
