@@ -159,13 +159,15 @@ def test_slop_more_doc_groups_than_resident_threads(api, monkeypatch):
         assert np.array_equal(dev.phrase_freqs_dense(terms, slop=slop), want), f"slop {terms} {slop}"
 
 
-@pytest.mark.parametrize("fast,docdir", [("1", "1"), ("0", "1"), ("1", "0")])
-def test_slop_table_placements_and_probe_routes_agree(api, monkeypatch, fast, docdir):
+@pytest.mark.parametrize("fast,docdir,sort", [("1", "1", "1"), ("0", "1", "1"), ("1", "0", "1"), ("1", "1", "0")])
+def test_slop_table_placements_and_probe_routes_agree(api, monkeypatch, fast, docdir, sort):
     """the fast pass (span tables in LDS, abandoned documents redone with full tables) vs the full-table pass alone
     (SA_SPAN_FAST=0), and header probes through the doc directory vs binary searches (SA_SPAN_DOCDIR=0): docs
     with few positions and docs whose table outgrows the LDS column (> 12 spans), against the oracle (a table
-    beyond the reference's 512 spans is undefined behaviour there -- see the fuzz test)"""
+    beyond the reference's 512 spans is undefined behaviour there -- see the fuzz test); document groups in work
+    order vs index order (SA_SPAN_SORT=0)"""
     monkeypatch.setenv("SA_SPAN_FAST", fast)
+    monkeypatch.setenv("SA_SPAN_SORT", sort)
     monkeypatch.setenv("SA_SPAN_DOCDIR", docdir)
     monkeypatch.setenv("SA_DOCDIR_DIV", "1000000")          # a doc directory for every term of >= 64 words
     rng = np.random.default_rng(3)
