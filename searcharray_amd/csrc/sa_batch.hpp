@@ -72,6 +72,7 @@ struct sa_batch {
     u64 alg_bytes = 0, postings_bytes = 0;
     bool ran = false;
     // grouped exhaustive scoring (sa_k_bm25_group_tiles): device rows [0, n_grouped_rows) belong to groups of
+    u32 n_shared_rows = 0;          // of them: rows in groups with a SHARED first term (the others are loose groups)
     // queries that share their first term, the others follow
     u32* d_grp = nullptr;           // [n_groups][2] first row, rows
     u64* d_wl = nullptr;            // (tile, row) items the grouped kernel leaves to the per-query kernel

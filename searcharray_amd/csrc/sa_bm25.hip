@@ -1658,6 +1658,7 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
                     done += sz;
                 }
             }
+            bt->n_shared_rows = (u32)order.size();                   // rows in groups with a shared first term
             // Loose groups: queries left over whose terms are all sparse per tile (what a (tile, query) pair of the
             // per-query kernel costs is clearing and scanning the tile's accumulators, 2048 slots for ~130 postings;
             // as an overlay on accumulators that are cleared once per 16 queries and touched only where the postings
@@ -1894,7 +1895,11 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     // result (10 M docs: 2.2x at k = 10, 1.9x at k = 100, but the exhaustive kernel is 1.2x faster at k = 1000;
     // 1.25 M docs, k = 1000: exhaustive 1.8x faster) -- on from 32768 docs per result.  SA_SPARSE=1 / 0 force it.
     const int sparse_env = sa_env_int("SA_SPARSE", -1);
-    const bool sparse_wanted = sparse_env >= 0 ? sparse_env != 0 : ix->n_docs >= (u64)bt->k * 32768ull;
+    // Round 2: when most queries of the batch share their first terms, the grouped exhaustive kernel is as fast at
+    // k = 10 and faster above (10 M docs, BASELINE batch: 369 K vs 341 K queries/s at k = 100, 236 K vs 114 K at
+    // k = 1000) -- such batches score every posting from k = 32 on.
+    const bool shared_heads = bt->n_shared_rows * 4u >= bt->B * 3u && bt->k >= 32u && sa_env_int("SA_GROUP", 1) != 0;
+    const bool sparse_wanted = sparse_env >= 0 ? sparse_env != 0 : (ix->n_docs >= (u64)bt->k * 32768ull && !shared_heads);
     const bool sparse = hist_possible && ix->tile_docs <= 8192 && bt->sparse_ok && ix->avg_doc_len != 0.f && ix->n_tiles > 0 &&
                         sparse_wanted;
     const bool use_hist = hist_possible &&
