@@ -71,10 +71,11 @@ struct sa_batch {
     u32 ev_n = 0;                       // runs recorded since the last sa_batch_profile
     u64 alg_bytes = 0, postings_bytes = 0;
     bool ran = false;
-    // grouped exhaustive scoring (sa_k_bm25_group_tiles): device rows [0, n_grouped_rows) belong to groups of
-    u32 n_shared_rows = 0;          // of them: rows in groups with a SHARED first term (the others are loose groups)
-    // queries that share their first term, the others follow
-    u32* d_grp = nullptr;           // [n_groups][2] first row, rows
+    // grouped exhaustive scoring (sa_k_bm25_group_tiles): device rows [0, n_grouped_rows) belong to groups --
+    // first the groups of queries that share their first term (rows [0, n_shared_rows)), then the loose groups;
+    // the ungrouped rows follow
+    u32 n_shared_rows = 0;
+    u32* d_grp = nullptr;           // [n_groups][2] first row, rows (bit 31: a loose group)
     u64* d_wl = nullptr;            // (tile, row) items the grouped kernel leaves to the per-query kernel
     u32* d_wl_cnt = nullptr;
     u32* d_iota = nullptr;          // [B] 0 .. B-1 (query lists of the per-query kernel: rows [a, b) = d_iota + a)
