@@ -515,6 +515,36 @@ def cpu_baseline(r, queries, scores, docs):
     return out, ("ok" if ok else "MISMATCH"), n_warm
 
 
+def sharded_parity(r, queries, scores, docs, n_check=8):
+    """N > 1: every rank scores the first n_check queries on ITS doc range with the CPU oracle (global df / avgdl /
+    corpus size, the reference's op order), the per-shard top-k lists travel through the library's all-reduce (one slot
+    per rank in a zero array, summed), and rank 0 merges them -- score descending, doc id ascending -- and compares with
+    the device result.  Collective: every rank calls it."""
+    from oracle import refimpl as O                    # the checker
+    a, c = r.args, r.corpus
+    k, D, V = a.k, a.docs, a.vocab
+    n_local = r.hi - r.lo
+    orc = O.OracleIndex(c.words, np.arange(V), c.term_off, c.doc_lens, n_local)
+    Q = min(n_check, len(queries))
+    slots = np.zeros((r.world, Q, k, 2), dtype=np.float64)
+    for qi in range(Q):
+        vecs = [O.bm25(orc.termfreqs(int(t)).copy(), np.asarray([r.df[int(t)]]), c.doc_lens, r.avgdl, D) for t in queries[qi]]
+        ws, wd = O.topk(np.sum(vecs, axis=0), k)
+        slots[r.rank, qi, :len(ws), 0] = ws
+        slots[r.rank, qi, :len(ws), 1] = wd.astype(np.float64) + r.lo
+    if r.use_comm:
+        slots = r.index.comm_allreduce(slots.reshape(-1), "sum").reshape(r.world, Q, k, 2)
+    if r.rank != 0:
+        return "n/a"
+    ok = True
+    for qi in range(Q):
+        cs, cd = slots[:, qi, :, 0].reshape(-1), slots[:, qi, :, 1].reshape(-1)
+        order = np.lexsort((cd, -cs))[:k]
+        ws, wd = cs[order].astype(np.float32), cd[order].astype(np.uint64)
+        ok &= bool(np.allclose(scores[qi], ws, rtol=1e-5, atol=0)) and bool(np.array_equal(docs[qi][ws > 0], wd[ws > 0]))
+    return f"ok ({Q} queries, per-shard CPU oracle merged over {r.world} rank(s))" if ok else "MISMATCH"
+
+
 # ------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
@@ -580,8 +610,10 @@ def main():
     qps = B * K / dt
 
     cpu, parity = None, "skipped"
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not r.use_comm and not args.no_cpu_baseline:
         cpu, parity, _ = cpu_baseline(r, queries, scores, docs)
+    elif r.use_comm:
+        parity = sharded_parity(r, queries, scores, docs)            # (collective)
 
     if rank == 0:
         n_tiles, waves = int(r.info.n_tiles), None
