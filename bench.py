@@ -629,6 +629,12 @@ def main():
         prn_block = roofline_block("sa_k_sparse_lead + route + scan + rest + score (+ sa_k_bm25_tiles_list)", prn_ms, alg_bytes, comp,
                                    dominant(pmc.get("dynamic_pruning"), ("sa_k_sparse", "sa_k_bm25")), prn_note)
         exh_block["workgroups_per_launch"] = B * n_tiles
+        # how the exhaustive path grouped the batch; the grouped kernel runs one WAVE per (tile, group) item
+        gi = batch.group_info()
+        exh_block["grouping"] = dict(gi, items_per_launch=(gi["groups"] + gi["per_query_kernel"]) * n_tiles,
+                                     ns_per_pair=round(exh_ms * 1e6 / max(1, B * n_tiles), 3) if exh_ms else None,
+                                     note="items: one wave per (tile, group) + one workgroup per (tile, ungrouped query); "
+                                          "ns_per_pair = scoring-kernel time / (tile, query) pairs")
         other = {"value": round(B * K2 / dt2, 2), "unit": "queries/s", "steps": K2, "ms_per_step": round(dt2 / K2 * 1e3, 4),
                  "roofline": prn_block if exhaustive else exh_block, "same_results": same}
         out = {
@@ -655,6 +661,7 @@ def main():
             out["distinct_terms"] = {
                 "value": round(B * K2 / dt3, 2), "unit": "queries/s", "steps": K2, "ms_per_step": round(dt3 / K2 * 1e3, 4),
                 "workload": f"{B} x 4 pairwise-distinct terms (ranks 1..{4 * B}, one per quarter per query), exhaustive, top-{args.k}",
+                "grouping": batch_d.group_info(),
                 "roofline": roofline_block("sa_k_bm25_* (exhaustive)", kernel_ms3, alg3, comp_d,
                                            dominant(pmc.get("distinct_terms"), ("sa_k_bm25",)),
                                            "no posting list is shared between queries: compulsory_bytes = all posting bytes of the batch")}

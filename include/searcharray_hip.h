@@ -289,6 +289,10 @@ int sa_batch_profile(sa_batch_t* batch, double* kernel_ms_out, uint64_t* alg_byt
  * the sparse path scores (one extra atomic each: not for timed runs); returns the count accumulated
  * since the previous call and how many queries of the last run were answered without a tile scan. */
 int sa_batch_stats(sa_batch_t* batch, int enable, uint64_t* sparse_candidates_out, uint64_t* sparse_queries_out);
+/* How the exhaustive path groups the batch (csrc/sa_bm25.hip, sa_k_bm25_group_tiles): out[0] = groups, out[1] = queries
+ * in groups, out[2] = of them in groups that share their first term (the others are loose groups), out[3] = queries
+ * left to the per-query kernel.  Diagnostics for benchmarks and tests; no reference counterpart. */
+int sa_batch_group_info(sa_batch_t* batch, uint32_t out[4]);
 int sa_batch_destroy(sa_batch_t* batch);
 
 typedef struct sa_index_info {

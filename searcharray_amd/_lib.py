@@ -93,6 +93,7 @@ PROTOTYPES = {
     "sa_batch_merge_gathered": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "sa_batch_fetch": (c_int, [c_void_p, f32p, u64p]),
     "sa_batch_profile": (c_int, [c_void_p, POINTER(c_double), u64p, u64p]),
+    "sa_batch_group_info": (c_int, [c_void_p, POINTER(c_uint32)]),
     "sa_batch_stats": (c_int, [c_void_p, c_int, u64p, u64p]),
     "sa_batch_destroy": (c_int, [c_void_p]),
     "sa_index_select_rows": (c_int, [c_void_p, u64p, c_uint64]),

@@ -2211,6 +2211,12 @@ extern "C" int sa_batch_profile(sa_batch_t* bt, double* kernel_ms_out, uint64_t*
     return SA_OK;
 }
 
+extern "C" int sa_batch_group_info(sa_batch_t* bt, uint32_t out[4]) {
+    SA_ARG(bt && out, "null argument");
+    out[0] = bt->n_groups; out[1] = bt->n_grouped_rows; out[2] = bt->n_shared_rows; out[3] = bt->B - bt->n_grouped_rows;
+    return SA_OK;
+}
+
 extern "C" int sa_batch_destroy(sa_batch_t* bt) {
     if (!bt) return SA_OK;
     sa_batch_free(bt);

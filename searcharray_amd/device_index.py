@@ -459,6 +459,13 @@ class QueryBatch:
         self.api.call("sa_batch_profile", self._h, ctypes.byref(ms), ctypes.byref(alg), ctypes.byref(post))
         return ms.value, alg.value, post.value
 
+    def group_info(self) -> dict:
+        """how the exhaustive path groups this batch: groups, queries in groups, of them with a shared first term
+        (the others are loose groups), queries left to the per-query kernel"""
+        out = (_lib.c_uint32 * 4)()
+        self.api.call("sa_batch_group_info", self._h, out)
+        return {"groups": int(out[0]), "grouped_queries": int(out[1]), "shared_first_term": int(out[2]), "per_query_kernel": int(out[3])}
+
     def stats(self, enable: bool = True) -> Tuple[int, int]:
         """(candidate docs scored by the sparse path since the last call, queries of the last run that
         were answered without a tile scan); diagnostics, switches the counting on / off."""

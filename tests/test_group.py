@@ -133,6 +133,16 @@ def test_loose_groups_equal_oracle_and_per_query_kernel(api, corpus, monkeypatch
         queries.append(q)
     queries.append([0] + [int(x) for x in rng.integers(20, VOCAB, T - 1)])       # a dense first term: per-query kernel
     got = check(api, corpus, queries, k, tile_docs=1024)
+    words, off, lens, _ = corpus
+    dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api)
+    bt = dev.batch(np.asarray(queries), k=k)
+    gi = bt.group_info()
+    bt.close()
+    dev.close()
+    # no first term is shared; loose groups exist (when the half tables take all T terms of 16 queries) and the
+    # query with the dense first term stays with the per-query kernel
+    assert gi["shared_first_term"] == 0 and gi["per_query_kernel"] >= 1
+    assert gi["groups"] >= 2 and gi["grouped_queries"] >= 20
     monkeypatch.setenv("SA_GROUP_LOOSE", "0")
     ref = check(api, corpus, queries, k, tile_docs=1024)
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
