@@ -223,6 +223,10 @@ void sa_index_free(sa_index* ix) {
     if (ix->d_tf8_slot) hipFree(ix->d_tf8_slot);
     ix->impacts.reset();
     if (ix->d_scratch) hipFree(ix->d_scratch);
+    for (int i = 0; i < 3; i++) {
+        if (ix->lane_scratch[i]) hipFree(ix->lane_scratch[i]);
+        if (ix->lane_stream[i]) hipStreamDestroy(ix->lane_stream[i]);
+    }
     if (ix->d_rows_scratch) hipFree(ix->d_rows_scratch);
     if (ix->d_sim_scratch) hipFree(ix->d_sim_scratch);
     if (ix->ev0) hipEventDestroy(ix->ev0);
@@ -759,6 +763,7 @@ extern "C" int sa_index_synchronize(sa_index_t* ix) {
     SA_HIP(hipSetDevice(ix->device));
     SA_HIP(hipStreamSynchronize(ix->stream));
     if (ix->sstream) SA_HIP(hipStreamSynchronize(ix->sstream));
+    for (int i = 0; i < 3; i++) if (ix->lane_stream[i]) SA_HIP(hipStreamSynchronize(ix->lane_stream[i]));
     if (ix->xstream) SA_HIP(hipStreamSynchronize(ix->xstream));
     SA_HIP(hipGetLastError());
     return SA_OK;

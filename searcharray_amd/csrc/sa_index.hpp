@@ -95,6 +95,11 @@ struct sa_index {
     // reusable device scratch (grown on demand, guarded by mu)
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    // further lanes of batched dense-route phrases (sa_phrase_batch.hip swaps a lane's stream and scratch in around
+    // the single-phrase kernels): SA_PHRASE_LANES - 1 of them
+    hipStream_t lane_stream[3] = {nullptr, nullptr, nullptr};
+    void* lane_scratch[3] = {nullptr, nullptr, nullptr};
+    size_t lane_bytes[3] = {0, 0, 0};
 
     // row selection scratch (sa_index_select_rows): device copy of the selected doc ids + gathered values
     void* d_rows_scratch = nullptr;
