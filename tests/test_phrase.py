@@ -442,6 +442,39 @@ def test_phrase_batch_takes_every_phrase_score_takes(api):
     dev.close()
 
 
+@pytest.mark.parametrize("lanes", ["1", "2", "4"])
+def test_slop_batch_replays_and_scratch_moves(api, monkeypatch, lanes):
+    """A batch of slop phrases run again and again on 1, 2 and 4 lanes (streams with their own scratch areas, swapped
+    in around the single-phrase kernels): every run must give the oracle's top-k, also after a larger dense query has
+    grown and moved the first lane's scratch area."""
+    monkeypatch.setenv("SA_PHRASE_LANES", lanes)
+    g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_small")
+    words, wt = rz.encode_sorted(t, d, p)
+    orc = O.OracleIndex.from_triples(t, d, p, num_docs, doc_lens=lens)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    rng = np.random.default_rng(17)
+    phrases = [[int(x) for x in rng.choice(min(vocab, 30), 2, replace=False)] for _ in range(7)] + [[3, 1, 2]]
+    slops = [int(x) for x in rng.integers(1, 4, len(phrases))]
+    k = 5
+    want = [O.topk(orc.score(list(ph), slop=sl), k) for ph, sl in zip(phrases, slops)]
+    bt = dev.phrase_batch(phrases, k=k, slop=slops)
+
+    def check(tag):
+        bt.run()
+        scores, docs = bt.fetch()
+        for i, (ws, wd) in enumerate(want):
+            n = int((ws > 0).sum())
+            assert np.array_equal(scores[i, :n], ws[:n]) and np.array_equal(docs[i, :n], wd[:n]), f"{tag}: phrase {phrases[i]} slop {slops[i]}"
+    for r in range(4):
+        check(f"run {r}")
+    # a dense slop query over the most frequent terms needs more scratch than the batch did: the areas move
+    dev.phrase_freqs_dense([0, 1, 2, 3, 4, 5], slop=3)
+    for r in range(3):
+        check(f"run {r} after the scratch moved")
+    bt.close()
+    dev.close()
+
+
 def test_search_phrases_with_repeated_tokens_and_slop(default_api):
     """SearchArray.search_phrases == top-k of SearchArray.score for phrases with repeated tokens and for slop"""
     from searcharray_amd import SearchArray
