@@ -4,6 +4,7 @@ corpora).  One seeded zipf-1M corpus (V = 100k, Poisson(32) lengths, 
   config 2  256 x 4-term disjunctive BM25, top-10 and top-1000: grouped exhaustive kernel, per-query exhaustive
             kernel and dynamic pruning agree on every query; 16 queries equal the oracle's dense scores + top-k
             (reference shapes: test/test_msmarco.py:345-395, utils/sort.py:24)
+            + the same on 256 queries of pairwise-distinct terms (loose groups, side stream)
   config 3  the 64 sampled consecutive trigrams + `t0 t1 t2` + the same-term set: match counts np.array_equal
             the oracle's (reference shapes: test/test_msmarco.py:227-295, test_phrase_matches.py:73-117)
   config 5  32 two-term slop-2 queries on mid-frequency terms (ranks 50-5000): counts exact, BM25 within 1e-5
@@ -69,6 +70,30 @@ def test_config2_bm25_topk_at_1m_docs(zipf1m, k):
         n = int((ws > 0).sum())
         assert np.array_equal(grouped[0][qi, :n], ws[:n]), f"q{qi} scores vs oracle"
         assert np.array_equal(grouped[1][qi, :n], wd[:n]), f"q{qi} docs vs oracle"
+
+
+@pytest.mark.parametrize("k", [10, 100])
+def test_config2_queries_without_shared_terms_at_1m_docs(zipf1m, k):
+    """256 queries of pairwise-distinct terms (no posting list shared): the exhaustive path scores the sparse ones as
+    LOOSE groups and the ones with a dense term with the per-query kernel on the side stream -- equal to the
+    per-query kernel alone, to dynamic pruning, and (16 queries) to the oracle"""
+    dev, orc, _, _ = zipf1m
+    queries = synth.bm25_queries_distinct(256, vocab=V)
+    bt = dev.batch(queries, k=k)
+    gi = bt.group_info()
+    bt.close()
+    assert gi["shared_first_term"] == 0 and gi["grouped_queries"] >= 128 and gi["per_query_kernel"] >= 1, gi
+    loose = run_batch(dev, queries, k, {"SA_SPARSE": "0", "SA_GROUP": "1"})
+    per_query = run_batch(dev, queries, k, {"SA_SPARSE": "0", "SA_GROUP": "0"})
+    pruned = run_batch(dev, queries, k, {"SA_SPARSE": "1"})
+    for name, got in (("per-query", per_query), ("pruned", pruned)):
+        assert np.array_equal(loose[0], got[0]), f"scores: loose groups vs {name}"
+        assert np.array_equal(loose[1], got[1]), f"docs: loose groups vs {name}"
+    for qi in list(range(8)) + list(range(200, 208)):
+        ws, wd = O.topk(orc.score_terms_sum([int(t) for t in queries[qi]]), k)
+        n = int((ws > 0).sum())
+        assert np.array_equal(loose[0][qi, :n], ws[:n]), f"q{qi} scores vs oracle"
+        assert np.array_equal(loose[1][qi, :n], wd[:n]), f"q{qi} docs vs oracle"
 
 
 def test_config3_trigram_counts_at_1m_docs(zipf1m):
