@@ -176,23 +176,35 @@ __global__ void __launch_bounds__(THREADS) sa_k_phrase_tiles(const PhraseTilePar
                                        p.cand_cap, p.cand_cnt);
 }
 
-// Ranking of a dense score vector (one phrase of the dense route): a workgroup loads a tile of scores and runs the
-// same pruned selection as the phrase tiles
+// Ranking of a dense count vector (one phrase of the dense route): a workgroup loads a tile of counts, turns them
+// into BM25 scores (reference bm25.pyx:11-25, the op order of sa_k_bm25_from_tf -- fused here: one launch less per
+// phrase, and a batch of short phrases is bound by the host's launch rate) and runs the same pruned selection as
+// the phrase tiles
 template <int TILE, int THREADS>
 __global__ void __launch_bounds__(THREADS)
-sa_k_dense_topk_tiles(const float* __restrict__ scores, u64 n_docs, u64 doc_base, u32 q, u32 k, u32* __restrict__ slots,
+sa_k_dense_topk_tiles(const float* __restrict__ counts, const float* __restrict__ dl, float avgdl, float idf, float k1, float b,
+                      u64 n_docs, u64 doc_base, u32 q, u32 k, u32* __restrict__ slots,
                       u64* __restrict__ cand, u32 cand_cap, u32* __restrict__ cand_cnt) {
     constexpr int E = TILE / THREADS;
     __shared__ float acc[TILE];
     const u32 tid = threadIdx.x, tile = blockIdx.x;
     const u64 tile_base = (u64)tile * TILE;
+    const float one_minus_b = 1.0f - b;
     u32 slot_val = 0xFFFFFFFFu;
     if ((tid & (SA_WAVE - 1)) < 32u)
         slot_val = __hip_atomic_load(&slots[q * 32u + (tid & 31u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int j = 0; j < E; j++) {                    // (a thread loads exactly the elements it owns in the selection)
         const u64 d = tile_base + (u64)(j * THREADS) + tid;
-        acc[j * THREADS + tid] = d < n_docs ? scores[d] : 0.f;
+        float sc = 0.f;
+        if (d < n_docs) {
+            const float t = counts[d];
+            if (t != 0.f) {                                      // (0 / (0 + norm) * idf = 0: docs without a match are not ranked)
+                const float norm = __fmul_rn(k1, __fadd_rn(one_minus_b, __fmul_rn(b, __fdiv_rn(dl[d], avgdl))));
+                sc = __fmul_rn(__fdiv_rn(t, __fadd_rn(t, norm)), idf);
+            }
+        }
+        acc[j * THREADS + tid] = sc;
     }
     sa_tile_topk_pruned<TILE, THREADS>(acc, slot_val, q, tile, doc_base + tile_base, k, slots, cand, cand_cap, cand_cnt);
 }
@@ -259,12 +271,13 @@ int sa_launch_phrase_tiles(sa_batch* bt, hipStream_t st) {
         Lane lane(ix, j);
         float* d_scores = nullptr;
         SA_TRY(sa_phrase_dense_counts_device(ix, &bt->h_pterms[(size_t)row * bt->T], bt->h_pn[row], bt->h_pslop[row], &d_scores));
-        sa_launch_bm25_from_tf(ix, d_scores, bt->h_pidf[row], bt->k1, bt->b);
         if (bt->ptile == 2048)
             hipLaunchKernelGGL((sa_k_dense_topk_tiles<2048, SA_PTHREADS>), dim3(bt->pn_tiles), dim3(SA_PTHREADS), 0, ls, (const float*)d_scores,
+                               (const float*)ix->d_doc_lens, ix->avg_doc_len, bt->h_pidf[row], bt->k1, bt->b,
                                ix->n_docs, ix->doc_base, row, bt->k, bt->d_slots, bt->d_cand, bt->cand_cap, bt->d_cand_cnt);
         else
             hipLaunchKernelGGL((sa_k_dense_topk_tiles<4096, SA_PTHREADS>), dim3(bt->pn_tiles), dim3(SA_PTHREADS), 0, ls, (const float*)d_scores,
+                               (const float*)ix->d_doc_lens, ix->avg_doc_len, bt->h_pidf[row], bt->k1, bt->b,
                                ix->n_docs, ix->doc_base, row, bt->k, bt->d_slots, bt->d_cand, bt->cand_cap, bt->d_cand_cnt);
     }
     for (int j = 0; j + 1 < n_lanes; j++) {                    // the merge waits for every lane

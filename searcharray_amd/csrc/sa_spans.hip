@@ -123,6 +123,7 @@ __device__ __forceinline__ bool sa_span_keep(const u32* m, int T, bool wrap) {
 
 // header 0 in L?  (the `L - 1` widening is lost then, see the top of the file).  Also clears the query's device
 // counters (cnt layout: sa_span_counts_device), so no separate fill is enqueued for them.
+#define SA_SPAN_INLINE_SCAN 4096       // up to this many chunks (8 M words) the emit pass scans the chunk counts itself
 #define SA_SPAN_NBINS 32                 // work bins of the fast pass (positions of a document group, saturated)
 #define SA_SPAN_CNT_BINS (5 * SA_SPAN_MAX_TERMS)                     // [.. + NBINS) bin sizes, [.. + 2 NBINS) bin cursors
 #define SA_SPAN_CNT_WORDS (5 * SA_SPAN_MAX_TERMS + 2 * SA_SPAN_NBINS)
@@ -304,8 +305,9 @@ sa_k_span_compact_scan(const SpanChunkTab ck, int T, u32* __restrict__ chunk_cou
 
 __global__ void __launch_bounds__(SA_CT)
 sa_k_span_compact_emit(const SpanTerms st, const SpanChunkTab ck, const unsigned char* __restrict__ flags,
-                       const u32* __restrict__ chunk_off, u32 n_chunks, const SpanCompactOut out) {
+                       const u32* __restrict__ chunk_off, u32 n_chunks, const SpanCompactOut out, u32* __restrict__ totals) {
     __shared__ u32 wc[SA_CI][SA_CW];
+    __shared__ u32 red[2][SA_CW];
     const int lane = sa_lane(), wave = sa_wave_id();
     const u64 lt = (1ull << lane) - 1ull;
     for (u32 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
@@ -327,7 +329,26 @@ sa_k_span_compact_emit(const SpanTerms st, const SpanChunkTab ck, const unsigned
             mine |= ((fl ? 1u : 0u) << j) | ((hd ? 1u : 0u) << (8 + j));
         }
         __syncthreads();
-        u32 off_c = chunk_off[c], off_h = chunk_off[n_chunks + c];
+        u32 off_c, off_h;
+        if (totals) {
+            // no scan launch: chunk_off still holds the COUNTS, and the block adds up those of the term's chunks in
+            // front of its own (a few hundred values at most -- the host takes this route for <= SA_SPAN_INLINE_SCAN
+            // chunks); the term's last chunk publishes the totals
+            u32 sc = 0, sh = 0;
+            for (u32 x = ck.coff[t] + threadIdx.x; x < c; x += SA_CT) { sc += chunk_off[x]; sh += chunk_off[n_chunks + x]; }
+            sc = sa_wave_sum(sc); sh = sa_wave_sum(sh);
+            if (lane == 0) { red[0][wave] = sc; red[1][wave] = sh; }
+            __syncthreads();
+            off_c = 0; off_h = 0;
+#pragma unroll
+            for (int wv = 0; wv < SA_CW; wv++) { off_c += red[0][wv]; off_h += red[1][wv]; }
+            if (c + 1u == ck.coff[t + 1] && threadIdx.x == 0) {
+                totals[t] = off_c + chunk_off[c];
+                totals[SA_SPAN_MAX_TERMS + t] = off_h + chunk_off[n_chunks + c];
+            }
+        } else {
+            off_c = chunk_off[c]; off_h = chunk_off[n_chunks + c];
+        }
         u64* cand = out.cand[t];
         u32* heads = out.heads[t];
 #pragma unroll
@@ -1053,8 +1074,10 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
         const u32 n_chunks = ck.coff[T];                       // (> 0: total_len > 0)
         const u32 grid = n_chunks < 16384u ? n_chunks : 16384u;
         hipLaunchKernelGGL(sa_k_span_compact_count, dim3(grid), dim3(SA_CT), 0, st, terms_dev, ck, (const unsigned char*)flags, chunks, n_chunks);
-        hipLaunchKernelGGL(sa_k_span_compact_scan, dim3(2 * T), dim3(1024), 0, st, ck, T, chunks, n_chunks, cnt);
-        hipLaunchKernelGGL(sa_k_span_compact_emit, dim3(grid), dim3(SA_CT), 0, st, terms_dev, ck, (const unsigned char*)flags, (const u32*)chunks, n_chunks, co);
+        const bool inline_scan = n_chunks <= (u32)SA_SPAN_INLINE_SCAN && n_chunks <= 16384u;       // (one chunk per block)
+        if (!inline_scan) hipLaunchKernelGGL(sa_k_span_compact_scan, dim3(2 * T), dim3(1024), 0, st, ck, T, chunks, n_chunks, cnt);
+        hipLaunchKernelGGL(sa_k_span_compact_emit, dim3(grid), dim3(SA_CT), 0, st, terms_dev, ck, (const unsigned char*)flags,
+                           (const u32*)chunks, n_chunks, co, inline_scan ? cnt : (u32*)nullptr);
     }
     // fast pass (tables in LDS, one thread per document group), then the groups it abandoned with full tables
     const char* fast_env = getenv("SA_SPAN_FAST");

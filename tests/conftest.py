@@ -44,3 +44,11 @@ def default_api(api):
     _lib.use_api(api)
     yield api
     _lib.use_api(old)
+
+
+@pytest.fixture
+def on_emu(request):
+    """True when the test runs on the host-emulated kernels (CPU suite): the heaviest parametrisations are thinned
+    there -- the GPU run keeps all of them."""
+    cs = getattr(request.node, "callspec", None)
+    return bool(cs and cs.params.get("api") == "emu")

@@ -117,10 +117,12 @@ def test_topk_massive_ties_takes_fallback_path(api, n, cap, monkeypatch):
 
 
 @pytest.mark.parametrize("seg_words", ["1", "37", "700"])
-def test_segmented_posting_derivation(api, seg_words, monkeypatch):
+def test_segmented_posting_derivation(api, seg_words, monkeypatch, on_emu):
     """Shards beyond 2^32 words derive their TF postings in segments of whole terms (< 2^31 words
     each); SA_SEG_WORDS forces tiny segments so the same code runs here -- down to one term per
     segment -- and must give the postings of the one-segment build."""
+    if on_emu:                        # (one term per segment is thousands of emulated launches, 45 s: the GPU run does that;
+        seg_words = {"1": "150", "37": "400"}.get(seg_words, seg_words)   #  here a few dozen segments of whole terms)
     g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_sparse")
     words, wt = rz.encode_sorted(t, d, p)
     off = rz.term_offsets(wt, vocab)

@@ -222,7 +222,7 @@ def test_slop_random_differential(api, seed):
 
 
 @pytest.mark.parametrize("seed", range(3))
-def test_slop_five_to_eight_terms(api, seed, monkeypatch):
+def test_slop_five_to_eight_terms(api, seed, monkeypatch, on_emu):
     """phrases of more terms than the span kernels are specialised for (flags: 2-4 terms; the fast pass requests the
     first four terms' loads together): the generic paths, with and without the doc directory, vs the oracle"""
     from oracle import spans as S
@@ -234,7 +234,7 @@ def test_slop_five_to_eight_terms(api, seed, monkeypatch):
     dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
     orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
     checked = 0
-    for T in (5, 6, 7, 8, 5, 6):
+    for T in ((5, 8, 6) if on_emu else (5, 6, 7, 8, 5, 6)):
         terms = [int(x) for x in rng.integers(0, vocab, T)]
         slop = int(rng.integers(1, 4))
         enc = [orc.enc(x) if orc.has_term(x) else np.empty(0, np.uint64) for x in terms]
@@ -443,10 +443,12 @@ def test_phrase_batch_takes_every_phrase_score_takes(api):
 
 
 @pytest.mark.parametrize("lanes", ["1", "2", "4"])
-def test_slop_batch_replays_and_scratch_moves(api, monkeypatch, lanes):
+def test_slop_batch_replays_and_scratch_moves(api, monkeypatch, lanes, on_emu):
     """A batch of slop phrases run again and again on 1, 2 and 4 lanes (streams with their own scratch areas, swapped
     in around the single-phrase kernels): every run must give the oracle's top-k, also after a larger dense query has
     grown and moved the first lane's scratch area."""
+    if on_emu and lanes == "1":
+        pytest.skip("one lane is what every other batch test of the CPU suite runs with SA_PHRASE_LANES unset on a single phrase")
     monkeypatch.setenv("SA_PHRASE_LANES", lanes)
     g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_small")
     words, wt = rz.encode_sorted(t, d, p)
@@ -465,11 +467,11 @@ def test_slop_batch_replays_and_scratch_moves(api, monkeypatch, lanes):
         for i, (ws, wd) in enumerate(want):
             n = int((ws > 0).sum())
             assert np.array_equal(scores[i, :n], ws[:n]) and np.array_equal(docs[i, :n], wd[:n]), f"{tag}: phrase {phrases[i]} slop {slops[i]}"
-    for r in range(4):
+    for r in range(2 if on_emu else 4):
         check(f"run {r}")
     # a dense slop query over the most frequent terms needs more scratch than the batch did: the areas move
     dev.phrase_freqs_dense([0, 1, 2, 3, 4, 5], slop=3)
-    for r in range(3):
+    for r in range(1 if on_emu else 3):
         check(f"run {r} after the scratch moved")
     bt.close()
     dev.close()
