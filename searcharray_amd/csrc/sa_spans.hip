@@ -123,6 +123,7 @@ __device__ __forceinline__ bool sa_span_keep(const u32* m, int T, bool wrap) {
 
 // header 0 in L?  (the `L - 1` widening is lost then, see the top of the file).  Also clears the query's device
 // counters (cnt layout: sa_span_counts_device), so no separate fill is enqueued for them.
+#define SA_SPAN_SORT_MIN 131072         // words of term 0 (an upper bound of the document groups) from which the groups are put in work order
 #define SA_SPAN_INLINE_SCAN 4096       // up to this many chunks (8 M words) the emit pass scans the chunk counts itself
 #define SA_SPAN_NBINS 32                 // work bins of the fast pass (positions of a document group, saturated)
 #define SA_SPAN_CNT_BINS (5 * SA_SPAN_MAX_TERMS)                     // [.. + NBINS) bin sizes, [.. + 2 NBINS) bin cursors
@@ -1083,7 +1084,10 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
     const char* fast_env = getenv("SA_SPAN_FAST");
     if (!(fast_env && atoi(fast_env) == 0) && terms_dev.len[0] > 0) {
         mp.over_list = over_list; mp.over_cnt = cnt + 4 * SA_SPAN_MAX_TERMS;
-        if (!(getenv("SA_SPAN_SORT") && atoi(getenv("SA_SPAN_SORT")) == 0)) {
+        // (work order only when the document groups outnumber the lanes the device keeps resident -- 256 CUs x 13 waves
+        //  x 64: below that every wave starts at once, the order changes nothing, and a light phrase saves two launches)
+        const int sort_env = getenv("SA_SPAN_SORT") ? atoi(getenv("SA_SPAN_SORT")) : -1;
+        if (sort_env != 0 && (sort_env > 0 || terms_dev.len[0] > (u32)SA_SPAN_SORT_MIN)) {
             SpanBinParams bp;
             memset(&bp, 0, sizeof(bp));
             for (int t = 0; t < T; t++) { bp.gpos[t] = co.gpos[t]; bp.n_heads[t] = mp.n_heads[t]; }

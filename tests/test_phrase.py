@@ -159,7 +159,7 @@ def test_slop_more_doc_groups_than_resident_threads(api, monkeypatch):
         assert np.array_equal(dev.phrase_freqs_dense(terms, slop=slop), want), f"slop {terms} {slop}"
 
 
-@pytest.mark.parametrize("fast,docdir,sort", [("1", "1", "1"), ("0", "1", "1"), ("1", "0", "1"), ("1", "1", "0")])
+@pytest.mark.parametrize("fast,docdir,sort", [("1", "1", "1"), ("0", "1", "1"), ("1", "0", "1"), ("1", "1", "0"), ("1", "1", "-1")])
 def test_slop_table_placements_and_probe_routes_agree(api, monkeypatch, fast, docdir, sort):
     """the fast pass (span tables in LDS, abandoned documents redone with full tables) vs the full-table pass alone
     (SA_SPAN_FAST=0), and header probes through the doc directory vs binary searches (SA_SPAN_DOCDIR=0): docs
@@ -167,7 +167,8 @@ def test_slop_table_placements_and_probe_routes_agree(api, monkeypatch, fast, do
     beyond the reference's 512 spans is undefined behaviour there -- see the fuzz test); document groups in work
     order vs index order (SA_SPAN_SORT=0)"""
     monkeypatch.setenv("SA_SPAN_FAST", fast)
-    monkeypatch.setenv("SA_SPAN_SORT", sort)
+    if sort != "-1":                                       # ("1" forces the work order on this small corpus, unset leaves it to the size rule)
+        monkeypatch.setenv("SA_SPAN_SORT", sort)
     monkeypatch.setenv("SA_SPAN_DOCDIR", docdir)
     monkeypatch.setenv("SA_DOCDIR_DIV", "1000000")          # a doc directory for every term of >= 64 words
     rng = np.random.default_rng(3)
@@ -197,9 +198,11 @@ def test_slop_scenarios_from_reference_tests(api):
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_slop_random_differential(api, seed):
-    """random corpora / queries: device span search == oracle (which is pinned to the reference)"""
+def test_slop_random_differential(api, seed, monkeypatch):
+    """random corpora / queries: device span search == oracle (which is pinned to the reference); document groups in
+    work order (forced: the size rule would leave these small corpora in index order) on the odd seeds"""
     from oracle import spans as S
+    monkeypatch.setenv("SA_SPAN_SORT", str(seed % 2))
     rng = np.random.default_rng(100 + seed)
     n_docs, vocab = int(rng.integers(200, 900)), int(rng.integers(8, 40))
     t, d, p, lens = synth.corpus_triples(n_docs, vocab, int(rng.integers(10, 70)), seed=seed)
@@ -227,6 +230,7 @@ def test_slop_five_to_eight_terms(api, seed, monkeypatch, on_emu):
     first four terms' loads together): the generic paths, with and without the doc directory, vs the oracle"""
     from oracle import spans as S
     monkeypatch.setenv("SA_DOCDIR_DIV", "1000000" if seed % 2 else "0")
+    monkeypatch.setenv("SA_SPAN_SORT", "1" if seed != 1 else "0")     # (work order forced / off)
     rng = np.random.default_rng(300 + seed)
     n_docs, vocab = int(rng.integers(300, 700)), int(rng.integers(6, 12))
     t, d, p, lens = synth.corpus_triples(n_docs, vocab, int(rng.integers(20, 50)), seed=40 + seed)
