@@ -11,8 +11,8 @@ cd $R
 ( time timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1
 ( time timeout 1200 python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1
 ( time timeout 600 python bench.py --corpus-cache /tmp/corpus ) > $O/bench.log 2>&1
-( time timeout 300 python bench.py --corpus-cache /tmp/corpus --k 100 --no-cpu-baseline --steps 10 ) > $O/bench_k100.log 2>&1
-( time timeout 300 python bench.py --corpus-cache /tmp/corpus --k 1000 --no-cpu-baseline --steps 5 ) > $O/bench_k1000.log 2>&1
+( time timeout 300 python bench.py --corpus-cache /tmp/corpus --k 100 --no-cpu-baseline --steps 20 ) > $O/bench_k100.log 2>&1
+( time timeout 300 python bench.py --corpus-cache /tmp/corpus --k 1000 --no-cpu-baseline --steps 20 ) > $O/bench_k1000.log 2>&1
 ( time SA_GROUP=0 timeout 300 python bench.py --corpus-cache /tmp/corpus --no-cpu-baseline ) > $O/bench_nogroup.log 2>&1
 ( time SA_BENCH_FORCE_COMM=1 timeout 300 python bench.py --corpus-cache /tmp/corpus --no-cpu-baseline --no-pmc ) > $O/bench_comm1.log 2>&1
 ( time RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_PORT=29533 SA_BENCH_FORCE_COMM=1 timeout 300 python bench.py --corpus-cache /tmp/corpus --no-cpu-baseline --no-pmc --docs 1250000 ) > $O/dist1_rccl.log 2>&1
