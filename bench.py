@@ -520,25 +520,37 @@ def sharded_parity(r, queries, scores, docs, n_check=8):
     corpus size, the reference's op order), the per-shard top-k lists travel through the library's all-reduce (one slot
     per rank in a zero array, summed), and rank 0 merges them -- score descending, doc id ascending -- and compares with
     the device result.  Collective: every rank calls it."""
-    from oracle import refimpl as O                    # the checker
     a, c = r.args, r.corpus
     k, D, V = a.k, a.docs, a.vocab
     n_local = r.hi - r.lo
-    orc = O.OracleIndex(c.words, np.arange(V), c.term_off, c.doc_lens, n_local)
     Q = min(n_check, len(queries))
-    slots = np.zeros((r.world, Q, k, 2), dtype=np.float64)
-    for qi in range(Q):
-        vecs = [O.bm25(orc.termfreqs(int(t)).copy(), np.asarray([r.df[int(t)]]), c.doc_lens, r.avgdl, D) for t in queries[qi]]
-        ws, wd = O.topk(np.sum(vecs, axis=0), k)
-        slots[r.rank, qi, :len(ws), 0] = ws
-        slots[r.rank, qi, :len(ws), 1] = wd.astype(np.float64) + r.lo
+    # one extra element per rank says "my part is there": a rank whose oracle cannot run (library not built on that box)
+    # must still take part in the all-reduce, or the others would wait for it forever
+    slots = np.zeros((r.world, Q * k * 2 + 1), dtype=np.float64)
+    err = ""
+    try:
+        from oracle import refimpl as O                # the checker
+        orc = O.OracleIndex(c.words, np.arange(V), c.term_off, c.doc_lens, n_local)
+        mine = slots[r.rank, :Q * k * 2].reshape(Q, k, 2)
+        for qi in range(Q):
+            vecs = [O.bm25(orc.termfreqs(int(t)).copy(), np.asarray([r.df[int(t)]]), c.doc_lens, r.avgdl, D) for t in queries[qi]]
+            ws, wd = O.topk(np.sum(vecs, axis=0), k)
+            mine[qi, :len(ws), 0] = ws
+            mine[qi, :len(ws), 1] = wd.astype(np.float64) + r.lo
+        slots[r.rank, -1] = 1.0
+    except Exception as e:                             # noqa: BLE001 -- reported in the JSON line, never fatal for the bench
+        err = f"{type(e).__name__}: {e}"
+        slots[r.rank, :] = 0.0
     if r.use_comm:
-        slots = r.index.comm_allreduce(slots.reshape(-1), "sum").reshape(r.world, Q, k, 2)
+        slots = r.index.comm_allreduce(slots.reshape(-1), "sum").reshape(r.world, Q * k * 2 + 1)
     if r.rank != 0:
         return "n/a"
+    if not (slots[:, -1] == 1.0).all():
+        return f"skipped (the CPU oracle did not run on every rank{': ' + err if err else ''})"
+    lists = slots[:, :Q * k * 2].reshape(r.world, Q, k, 2)
     ok = True
     for qi in range(Q):
-        cs, cd = slots[:, qi, :, 0].reshape(-1), slots[:, qi, :, 1].reshape(-1)
+        cs, cd = lists[:, qi, :, 0].reshape(-1), lists[:, qi, :, 1].reshape(-1)
         order = np.lexsort((cd, -cs))[:k]
         ws, wd = cs[order].astype(np.float32), cd[order].astype(np.uint64)
         ok &= bool(np.allclose(scores[qi], ws, rtol=1e-5, atol=0)) and bool(np.array_equal(docs[qi][ws > 0], wd[ws > 0]))
