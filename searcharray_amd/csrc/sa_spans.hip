@@ -21,10 +21,12 @@
 // header, and the final sorted slice never reaches it.  The goldens (outputs of the reference
 // itself) pin this: e.g. query [8, 1, 3] on tests/golden/zipf_small.
 //
-// Stage 2 runs one thread per document group (documents are independent), a resident grid of
-// threads striding over the groups.  A thread takes the k-th document group of EVERY term -- the reference walks the terms' cursors in lock step
-// (spans.pyx:223-304) and does not re-align them by key -- and replays the state machine with the
-// span table in a per-thread column of a global slab (16-byte entries, interleaved across threads).  Two quirks of the reference are part of the
+// Stage 2 takes the k-th document group of EVERY term together -- the reference walks the terms' cursors in lock
+// step (spans.pyx:223-304) and does not re-align them by key -- and replays the state machine per group: one
+// thread per group with its span table in LDS, groups in work order (sa_k_span_machine_flat); the groups whose table
+// outgrows the LDS column again with a whole wave each (sa_k_span_machine_wave).  One pipeline per query, on one
+// stream, nothing read back: flags -> one compaction for all terms (candidate words + document heads) -> work order
+// -> the two machines, accumulating into the dense float result.  Two quirks of the reference are part of the
 // observable behaviour and are reproduced: position bits are `1 << (p % 64)` evaluated as a 32-bit
 // shift (count mod 32, sign-extended), and a rejected extension leaves its position bit set.
 // A document that fills the 512-entry table is undefined behaviour in the reference (it indexes
