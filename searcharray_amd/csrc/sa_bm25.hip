@@ -818,7 +818,9 @@ __device__ __forceinline__ void sa_static_while_below(u32 n, F&& f) {
 
 #define SA_GRP_REFRESH_STEP 32
 #define SA_GRP_SURV_CAP 128         // survivors an item buffers before it writes them out (a pair has at most 16)
-#define SA_GRP_LOOSE_POSTINGS 384   // loose groups: expected postings of a query per tile, all terms together (<= 6 of the 12 halves)
+#define SA_GRP_LOOSE_POSTINGS 128   // loose groups: expected postings of a query per tile, all terms together (measured on the
+                                    // distinct-terms batch, 10 M docs: 64 / 96 / 128 / 192 / 256 / 384 / 512 -> 0.82 / 0.74 / 0.74 / 0.73 / 0.75 / 0.80 / 0.81 ms
+                                    // at k = 10, 128 best at k = 1000: above it the overlay loses to the per-query kernel's dense tile)
 
 template <int TILE>
 __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, const GroupParams gp) {
