@@ -18,6 +18,9 @@ _api = None
 def emu_api():
     global _api
     if _api is None:
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "searcharray_amd", "csrc"), "emu"])
-        _api = _lib.bind(ctypes.CDLL(EMU_SO), EMU_SO)
+        so = os.environ.get("SA_EMU_SO")                # e.g. the same sources built with -fsanitize=address (run pytest under
+        if not so:                                      #      LD_PRELOAD=libasan.so: every kernel access becomes a checked access)
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "searcharray_amd", "csrc"), "emu"])
+            so = EMU_SO
+        _api = _lib.bind(ctypes.CDLL(so), so)
     return _api
