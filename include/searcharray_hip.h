@@ -269,6 +269,16 @@ int sa_phrase_batch_create(sa_index_t* ix, const uint32_t* terms, const int32_t*
  * device; only the B x k results leave it. */
 int sa_phrase_batch_create_ex(sa_index_t* ix, const uint32_t* terms, const int32_t* n_terms, const int32_t* slop,
                               const float* idf, int n_phrases, int max_terms, int k, float k1, float b, sa_batch_t** out);
+/* A NEW set of queries in an existing batch (same n_queries, n_query_terms, k, k1, b as at creation): what
+ * SearchArray.score does per call on a fresh query (reference postings.py:652-680; the loop timed by
+ * test/test_msmarco.py:345-395), for a stream of batches.  The host derives the query-dependent tables into a
+ * page-locked image; ONE asynchronous copy and one kernel (the slice table) are enqueued on the index stream behind the
+ * runs still in flight.  Nothing is allocated and nothing is waited for: with two batches used alternately the host
+ * prepares query set i+1 while the device scores query set i.  Fetch a batch's results before resetting it. */
+int sa_batch_reset(sa_batch_t* batch, const uint32_t* terms, const float* idf);
+/* the same for a phrase batch (same n_phrases and max_terms; slop == NULL: all exact) */
+int sa_phrase_batch_reset(sa_batch_t* batch, const uint32_t* terms, const int32_t* n_terms, const int32_t* slop,
+                          const float* idf);
 /* one pass of the hot path over the batch; asynchronous on the index stream unless sync != 0.
  * If the index has a communicator (Part 3) the per-shard top-k are exchanged and merged. */
 int sa_batch_run(sa_batch_t* batch, int sync);
@@ -278,7 +288,9 @@ int sa_batch_run(sa_batch_t* batch, int sync);
  * [nranks][B][k] (DEVICE pointer) into the final top-k. */
 int sa_batch_run_local(sa_batch_t* batch, void* local_keys_out_device, int sync);
 int sa_batch_merge_gathered(sa_batch_t* batch, const void* gathered_keys_device, int nranks, int sync);
-/* wait for completion; copies results to host: scores f32[B][k], docs u64[B][k] */
+/* Results to the host: scores f32[B][k], docs u64[B][k].  Every sa_batch_run ends with an asynchronous copy of its
+ * B*k keys into a page-locked buffer of the batch; fetch waits for THAT copy only (not for the streams), so other
+ * batches of the index keep running behind it. */
 int sa_batch_fetch(sa_batch_t* batch, float* scores_out, uint64_t* docs_out);
 /* Mean HIP-event time (ms, events recorded on the index stream around the scoring kernel) over
  * the runs since the previous call, and the algorithmic bytes of one run: sum over queries of

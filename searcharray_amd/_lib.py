@@ -88,6 +88,8 @@ PROTOTYPES = {
                                        c_float, POINTER(c_void_p)]),
     "sa_phrase_batch_create_ex": (c_int, [c_void_p, u32p, POINTER(ctypes.c_int32), POINTER(ctypes.c_int32), f32p, c_int, c_int,
                                           c_int, c_float, c_float, POINTER(c_void_p)]),
+    "sa_batch_reset": (c_int, [c_void_p, u32p, f32p]),
+    "sa_phrase_batch_reset": (c_int, [c_void_p, u32p, POINTER(ctypes.c_int32), POINTER(ctypes.c_int32), f32p]),
     "sa_batch_run": (c_int, [c_void_p, c_int]),
     "sa_batch_run_local": (c_int, [c_void_p, c_void_p, c_int]),
     "sa_batch_merge_gathered": (c_int, [c_void_p, c_void_p, c_int, c_int]),

@@ -17,6 +17,26 @@ struct sa_batch {
     u32 B = 0, T = 0, k = 0;
     float k1 = 1.2f, b = 0.75f;
     std::vector<u32> perm;          // device row r holds caller query perm[r] (results: caller order)
+    // Everything a NEW set of queries changes on the device is one contiguous UPLOAD BLOCK (d_up) with a
+    // page-locked host image: sa_batch_reset fills the image and enqueues ONE hipMemcpyAsync (+ the slice-table
+    // kernel) -- no allocation, no blocking copy, no synchronisation.  The pointers below (d_terms ... d_bloom_off
+    // of a BM25 batch; d_terms, d_idf, d_perm, d_plan of a phrase batch) point into it.  Two images alternate so
+    // that a reset can be prepared while the copy of the previous one may still be in flight.
+    char* d_up = nullptr;
+    char* h_up[2] = {nullptr, nullptr};
+    size_t up_bytes = 0;
+    hipEvent_t ev_up[2] = {nullptr, nullptr};   // image i has been copied
+    bool up_used[2] = {false, false};
+    u32 up_n = 0;                   // resets so far (image = up_n & 1)
+    // results to the host without a stream synchronisation: every run ends with an async copy of the B*k keys and
+    // the overflow flag into a page-locked buffer on the exchange stream; sa_batch_fetch waits for ITS event only
+    u64* h_res = nullptr;           // [B*k + 1]
+    hipEvent_t ev_final = nullptr;  // d_final written (stream of the last merge)
+    hipEvent_t ev_res = nullptr;    // h_res written (exchange stream)
+    bool res_pending = false;
+    u32* d_xflag = nullptr;         // sharded: OR over the ranks of the overflow flags (travels with the all-gather)
+    u32 wl_cap = 0;                 // entries of d_wl
+    size_t bloom_cap = 0;           // bytes of d_bloom (worst case of this shard, allocated by the first pruned run)
     u32* d_terms = nullptr;
     u32* d_perm = nullptr;
     float* d_idf = nullptr;
@@ -105,6 +125,10 @@ int sa_comm_allreduce_max_u32(sa_index* ix, u32* d_val, hipStream_t st);
 int sa_launch_phrase_tiles(sa_batch* bt, hipStream_t st);
 // shared by the two batch kinds (sa_bm25.hip)
 int sa_batch_alloc_topk(sa_batch* bt, u32 n_tiles, u32 waves);
+// the upload block (sa_batch.hpp: d_up / h_up): allocate, take the next host image, enqueue its copy
+int sa_batch_alloc_upload(sa_batch* bt, size_t bytes);
+int sa_batch_upload_begin(sa_batch* bt, char** image);
+int sa_batch_upload_commit(sa_batch* bt);
 void sa_batch_free(sa_batch* bt);
 // dynamic pruning: lead-term candidates, routing, remaining essential candidates (sa_sparse.hip)
 int sa_launch_sparse(sa_batch* bt, hipStream_t st);

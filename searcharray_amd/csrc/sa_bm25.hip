@@ -1487,13 +1487,26 @@ extern "C" int sa_index_bm25_dense(sa_index_t* ix, const uint32_t* terms, const 
 void sa_batch_free(sa_batch* bt) {
     if (!bt) return;
     if (bt->ix) {
+        // every stream a run of this batch may have used: the index stream, the side stream (ungrouped rows), the
+        // exchange stream (all-gather, cross-rank merge, result copies) and the lanes of dense-route phrases
         hipSetDevice(bt->ix->device);
         hipStreamSynchronize(bt->ix->stream);
+        if (bt->ix->sstream) hipStreamSynchronize(bt->ix->sstream);
         if (bt->ix->xstream) hipStreamSynchronize(bt->ix->xstream);
+        for (int j = 0; j < 3; j++)
+            if (bt->ix->lane_stream[j]) hipStreamSynchronize(bt->ix->lane_stream[j]);
     }
-    if (bt->d_terms) hipFree(bt->d_terms);
-    if (bt->d_perm) hipFree(bt->d_perm);
-    if (bt->d_idf) hipFree(bt->d_idf);
+    // (d_terms, d_idf, d_perm, d_grp, d_ub, d_ub_order, d_lead, d_p1_off, d_qdf, d_qrow8, d_bloom_off, d_bloom_shift,
+    //  d_plan live inside the upload block)
+    if (bt->d_up) hipFree(bt->d_up);
+    for (int i = 0; i < 2; i++) {
+        if (bt->h_up[i]) hipHostFree(bt->h_up[i]);
+        if (bt->ev_up[i]) hipEventDestroy(bt->ev_up[i]);
+    }
+    if (bt->h_res) hipHostFree(bt->h_res);
+    if (bt->ev_final) hipEventDestroy(bt->ev_final);
+    if (bt->ev_res) hipEventDestroy(bt->ev_res);
+    if (bt->d_xflag) hipFree(bt->d_xflag);
     if (bt->d_cand) hipFree(bt->d_cand);
     if (bt->d_bounds) hipFree(bt->d_bounds);
     if (bt->d_sattab) hipFree(bt->d_sattab);
@@ -1511,32 +1524,53 @@ void sa_batch_free(sa_batch* bt) {
     }
     if (bt->d_final) hipFree(bt->d_final);
     if (bt->d_xcand) hipFree(bt->d_xcand);
-    if (bt->d_plan) hipFree(bt->d_plan);
     if (bt->d_wbounds) hipFree(bt->d_wbounds);
     if (bt->d_wbase) hipFree(bt->d_wbase);
     if (bt->d_wlen) hipFree(bt->d_wlen);
-    if (bt->d_ub) hipFree(bt->d_ub);
-    if (bt->d_ub_order) hipFree(bt->d_ub_order);
     if (bt->d_stats) hipFree(bt->d_stats);
-    if (bt->d_grp) hipFree(bt->d_grp);
     if (bt->d_wl) hipFree(bt->d_wl);
     if (bt->d_wl_cnt) hipFree(bt->d_wl_cnt);
     if (bt->d_iota) hipFree(bt->d_iota);
-    if (bt->d_lead) hipFree(bt->d_lead);
-    if (bt->d_p1_off) hipFree(bt->d_p1_off);
     if (bt->d_route) hipFree(bt->d_route);
     if (bt->d_emask) hipFree(bt->d_emask);
     if (bt->d_p2_off) hipFree(bt->d_p2_off);
     if (bt->d_tile_q) hipFree(bt->d_tile_q);
-    if (bt->d_qdf) hipFree(bt->d_qdf);
-    if (bt->d_qrow8) hipFree(bt->d_qrow8);
     if (bt->d_surv) hipFree(bt->d_surv);
     if (bt->d_bloom) hipFree(bt->d_bloom);
-    if (bt->d_bloom_off) hipFree(bt->d_bloom_off);
-    if (bt->d_bloom_shift) hipFree(bt->d_bloom_shift);
     for (hipEvent_t e : bt->ev0) hipEventDestroy(e);
     for (hipEvent_t e : bt->ev1) hipEventDestroy(e);
     delete bt;
+}
+
+// The upload block of a batch: `bytes` on the device + two page-locked host images (see sa_batch.hpp).
+int sa_batch_alloc_upload(sa_batch* bt, size_t bytes) {
+    bt->up_bytes = (bytes + 15) & ~(size_t)15;
+    SA_HIP(hipMalloc(&bt->d_up, bt->up_bytes));
+    for (int i = 0; i < 2; i++) {
+        SA_HIP(hipHostMalloc(&bt->h_up[i], bt->up_bytes, 0));
+        memset(bt->h_up[i], 0, bt->up_bytes);
+        SA_HIP(hipEventCreateWithFlags(&bt->ev_up[i], hipEventDisableTiming));
+    }
+    return SA_OK;
+}
+
+// The host image the next reset fills (waits, if it must, until the copy that last used it is done -- two resets
+// ago, so in a steady stream this never blocks).
+int sa_batch_upload_begin(sa_batch* bt, char** image) {
+    const u32 i = bt->up_n & 1u;
+    if (bt->up_used[i]) SA_HIP(hipEventSynchronize(bt->ev_up[i]));
+    *image = bt->h_up[i];
+    return SA_OK;
+}
+
+// one async copy of the whole image, on the index stream: ordered behind the runs that still read the old tables
+int sa_batch_upload_commit(sa_batch* bt) {
+    const u32 i = bt->up_n & 1u;
+    SA_HIP(hipMemcpyAsync(bt->d_up, bt->h_up[i], bt->up_bytes, hipMemcpyHostToDevice, bt->ix->stream));
+    SA_HIP(hipEventRecord(bt->ev_up[i], bt->ix->stream));
+    bt->up_used[i] = true;
+    bt->up_n++;
+    return SA_OK;
 }
 
 // Candidate lists, pruning slots, result buffers and the timing-event ring of a batch whose tile
@@ -1571,6 +1605,11 @@ int sa_batch_alloc_topk(sa_batch* bt, u32 n_tiles, u32 waves) {
     SA_HIP(hipMalloc(&bt->d_final, (size_t)B * bt->k * sizeof(u64)));
     SA_HIP(hipMemset(bt->d_final, 0, (size_t)B * bt->k * sizeof(u64)));
     SA_HIP(hipMemset(bt->d_local, 0, (size_t)B * bt->k * sizeof(u64)));
+    SA_HIP(hipHostMalloc(&bt->h_res, ((size_t)B * bt->k + 1) * sizeof(u64), 0));
+    SA_HIP(hipEventCreateWithFlags(&bt->ev_final, hipEventDisableTiming));
+    SA_HIP(hipEventCreateWithFlags(&bt->ev_res, hipEventDisableTiming));
+    SA_HIP(hipMalloc(&bt->d_xflag, sizeof(u32)));
+    SA_HIP(hipMemset(bt->d_xflag, 0, sizeof(u32)));
     for (int i = 0; i < SA_EVENT_RING; i++) {
         hipEvent_t a = nullptr, c = nullptr;
         SA_HIP(hipEventCreate(&a));
@@ -1581,19 +1620,111 @@ int sa_batch_alloc_topk(sa_batch* bt, u32 n_tiles, u32 waves) {
     return SA_OK;
 }
 
-extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const float* idf, int n_queries,
-                               int n_query_terms, int k, float k1, float b, sa_batch_t** out) {
-    SA_ARG(ix && out && terms && idf, "null argument");
-    SA_ARG(n_queries > 0 && n_query_terms > 0, "empty batch");
-    SA_ARG(n_query_terms <= SA_MAX_QTERMS, "more than 32 terms per query is not supported");
-    SA_ARG(k > 0 && k <= SA_KMAX, "k must be in [1, 1024]");
-    SA_ARG(ix->doc_base + ix->n_docs <= 0xFFFFFFFFull, "global doc ids must fit 32 bits for top-k");
-    std::lock_guard<std::mutex> g(ix->mu);
-    SA_HIP(hipSetDevice(ix->device));
-    sa_batch* bt = new (std::nothrow) sa_batch();
-    if (!bt) { sa_set_error("out of host memory"); return SA_ERR_NOMEM; }
-    bt->ix = ix; bt->B = (u32)n_queries; bt->T = (u32)n_query_terms; bt->k = (u32)k; bt->k1 = k1; bt->b = b;
+static u64 sa_pow2_cells(u64 df) {                     // Bloom cells of a lead term: the power of two in [8, 16) x df, at least 1024
+    u32 bits = 10;
+    while ((1ull << bits) < 8 * df && bits < 30) bits++;
+    return 1ull << bits;
+}
+
+// ---- a BM25 batch in two steps: sa_batch_alloc_bm25 sizes every device buffer ONCE from (B, T, k, the shard's
+//      tiles), sa_batch_fill computes everything that depends on the queries into the upload image and enqueues the
+//      copy and the slice-table kernel.  sa_batch_create = alloc + fill + one synchronisation; sa_batch_reset = fill.
+static int sa_batch_alloc_bm25(sa_batch* bt) {
+    sa_index* ix = bt->ix;
+    const size_t B = bt->B, T = bt->T;
+    // upload block (8-byte fields first)
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 7) & ~(size_t)7; return o; };
+    const size_t o_p1 = take((B + 1) * 8), o_boff = take(B * 8), o_terms = take(B * T * 4), o_idf = take(B * T * 4),
+                 o_perm = take(B * 4), o_grp = take(2 * B * 4), o_ub = take(B * (T + 1) * 4), o_ord = take(B * T * 4),
+                 o_lead = take(B * 4), o_qdf = take(B * T * 4), o_row8 = take(B * T * 4), o_bsh = take(B * 4);
+    SA_TRY(sa_batch_alloc_upload(bt, off));
+    char* u = bt->d_up;
+    bt->d_p1_off = (u64*)(u + o_p1); bt->d_bloom_off = (u64*)(u + o_boff);
+    bt->d_terms = (u32*)(u + o_terms); bt->d_idf = (float*)(u + o_idf); bt->d_perm = (u32*)(u + o_perm);
+    bt->d_grp = (u32*)(u + o_grp); bt->d_ub = (float*)(u + o_ub); bt->d_ub_order = (u32*)(u + o_ord);
+    bt->d_lead = (u32*)(u + o_lead); bt->d_qdf = (u32*)(u + o_qdf); bt->d_qrow8 = (u32*)(u + o_row8);
+    bt->d_bloom_shift = (u32*)(u + o_bsh);
+    {
+        std::vector<u32> iota(B);
+        for (u32 i = 0; i < B; i++) iota[i] = i;
+        SA_HIP(hipMalloc(&bt->d_iota, B * sizeof(u32)));
+        SA_HIP(hipMemcpy(bt->d_iota, iota.data(), B * sizeof(u32), hipMemcpyHostToDevice));
+    }
+    // work list of the grouped kernel: at most one entry per (tile, row)
+    bt->wl_cap = (u32)std::max<size_t>(1, (size_t)ix->n_tiles * B);
+    SA_HIP(hipMalloc(&bt->d_wl, (size_t)bt->wl_cap * sizeof(u64)));
+    SA_HIP(hipMalloc(&bt->d_wl_cnt, sizeof(u32)));
+    SA_HIP(hipMemset(bt->d_wl_cnt, 0, sizeof(u32)));
+    SA_TRY(sa_batch_alloc_topk(bt, ix->n_tiles, sa_tile_waves(ix->tile_docs)));
+    SA_HIP(hipMalloc(&bt->d_bounds, (B * T * (ix->n_tiles + 1) + 1) * sizeof(u32)));
+    SA_HIP(hipMalloc(&bt->d_qbase, B * T * sizeof(u64)));
+    SA_HIP(hipMalloc(&bt->d_sattab, SA_SAT_NTF * SA_SAT_WMAX * sizeof(float)));
+    // dynamic pruning (sa_sparse.hip): device-only tables
+    SA_HIP(hipMalloc(&bt->d_route, B * sizeof(u32)));
+    SA_HIP(hipMalloc(&bt->d_emask, B * sizeof(u32)));
+    SA_HIP(hipMalloc(&bt->d_p2_off, (B + 1) * sizeof(u64)));
+    SA_HIP(hipMalloc(&bt->d_tile_q, (B + 2) * sizeof(u32)));
+    SA_HIP(hipMemset(bt->d_route, 0xFF, B * sizeof(u32)));
+    {
+        // survivors of the phase-2 bound check: a few percent of the candidates; capped, the rest is scored in place
+        u64 cap = (u64)B * 65536;
+        if (cap > (16u << 20)) cap = 16u << 20;
+        bt->surv_cap = (u32)cap;
+        SA_HIP(hipMalloc(&bt->d_surv, (size_t)cap * 2 * sizeof(u64)));
+    }
+    SA_TRY(sa_launch_make_sattab(ix, bt->d_sattab, &bt->tab_w, bt->k1, bt->b, ix->stream));
+    // the impact stream of this (k1, b): shared through the index, built on first use
+    bt->impacts = sa_impacts_get(ix, bt->k1, bt->b);
+    if (bt->impacts) SA_HIP(hipMalloc(&bt->d_qbase_imp, B * T * 2 * sizeof(u64)));
+    return SA_OK;
+}
+
+// lead terms of dynamic pruning: up to 1/64 of the shard's docs (phase 1 scores every one of them), and never more
+// postings than fit the candidate list while the bound is still unknown
+static u64 sa_batch_lead_limit(const sa_batch* bt) {
+    const sa_index* ix = bt->ix;
+    u64 limit1 = ix->n_docs / 64 > 4096 ? ix->n_docs / 64 : 4096;
+    if (limit1 > (u64)bt->cand_cap * 3 / 4) limit1 = (u64)bt->cand_cap * 3 / 4;
+    return limit1;
+}
+
+// The Bloom filters of the lead terms are sized per query set; the buffer holds the worst case of this shard
+// (B lead terms of lead-limit postings each) and is allocated by the first run that prunes -- never by a reset.
+int sa_batch_ensure_bloom(sa_batch* bt) {
+    if (bt->d_bloom) return SA_OK;
+    const u64 limit1 = sa_batch_lead_limit(bt);
+    u64 maxdf = 0;
+    const sa_index* ix = bt->ix;
+    for (u32 t = 0; t < ix->n_terms; t++) {
+        const u64 df = ix->h_tf_off[t + 1] - ix->h_tf_off[t];
+        if (df <= limit1 && df > maxdf) maxdf = df;
+    }
+    bt->bloom_cap = (size_t)bt->B * sa_pow2_cells(maxdf);
+    SA_HIP(hipMalloc(&bt->d_bloom, bt->bloom_cap));
+    return SA_OK;
+}
+
+static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) {
+    sa_index* ix = bt->ix;
     const u32 B = bt->B, T = bt->T;
+    const float k1 = bt->k1, b = bt->b;
+    char* img = nullptr;
+    SA_TRY(sa_batch_upload_begin(bt, &img));
+    auto at = [&](const void* dptr) { return img + ((const char*)dptr - bt->d_up); };
+    u64* h_p1 = (u64*)at(bt->d_p1_off);
+    u64* h_boff = (u64*)at(bt->d_bloom_off);
+    u32* h_terms = (u32*)at(bt->d_terms);
+    float* h_idf = (float*)at(bt->d_idf);
+    u32* h_perm = (u32*)at(bt->d_perm);
+    u32* h_grpd = (u32*)at(bt->d_grp);
+    float* h_ub = (float*)at(bt->d_ub);
+    u32* h_ord = (u32*)at(bt->d_ub_order);
+    u32* h_lead = (u32*)at(bt->d_lead);
+    u32* h_qdf = (u32*)at(bt->d_qdf);
+    u32* h_row8 = (u32*)at(bt->d_qrow8);
+    u32* h_bshift = (u32*)at(bt->d_bloom_shift);
+
     // Order queries by their most frequent term so XCD groups share posting tiles in L2.
     bt->perm.resize(B);
     for (u32 i = 0; i < B; i++) bt->perm[i] = i;
@@ -1619,6 +1750,7 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
     // shared term once per (tile, group).  Grouped queries take the first device rows, group by group (big
     // groups are cut into balanced pieces of at most `maxq` queries), the others keep their order behind them.
     std::vector<u32> h_grp;
+    bt->n_groups = 0; bt->n_grouped_rows = 0; bt->n_shared_rows = 0;
     {
         // lanes per query while the half tables are built: a power of two >= the terms overlaid -- T - 1 for groups
         // with a shared first term, T for loose groups (decided below; loose groups are only formed if the wider
@@ -1697,64 +1829,34 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
         }
         bt->grp_tt = tt; bt->grp_tt_shift = tsh;
     }
-    std::vector<u32> h_terms((size_t)B * T);
-    std::vector<float> h_idf((size_t)B * T);
     for (u32 r = 0; r < B; r++) {
         memcpy(&h_terms[(size_t)r * T], &terms[(size_t)bt->perm[r] * T], T * sizeof(u32));
         memcpy(&h_idf[(size_t)r * T], &idf[(size_t)bt->perm[r] * T], T * sizeof(float));
+        h_perm[r] = bt->perm[r];
     }
-    int rc = SA_OK;
-    auto fail = [&](int code) { sa_batch_free(bt); return code; };
-#define SA_HIP_B(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { sa_set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return fail(SA_ERR_HIP); } } while (0)
-    SA_HIP_B(hipMalloc(&bt->d_terms, h_terms.size() * sizeof(u32)));
-    SA_HIP_B(hipMalloc(&bt->d_idf, h_idf.size() * sizeof(float)));
-    SA_HIP_B(hipMalloc(&bt->d_perm, (size_t)B * sizeof(u32)));
-    SA_HIP_B(hipMemcpy(bt->d_perm, bt->perm.data(), (size_t)B * sizeof(u32), hipMemcpyHostToDevice));
-    {
-        std::vector<u32> iota(B);
-        for (u32 i = 0; i < B; i++) iota[i] = i;
-        SA_HIP_B(hipMalloc(&bt->d_iota, (size_t)B * sizeof(u32)));
-        SA_HIP_B(hipMemcpy(bt->d_iota, iota.data(), (size_t)B * sizeof(u32), hipMemcpyHostToDevice));
-        if (bt->n_groups) {
-            SA_HIP_B(hipMalloc(&bt->d_wl, std::max<size_t>(1, (size_t)ix->n_tiles * bt->n_grouped_rows) * sizeof(u64)));
-            SA_HIP_B(hipMalloc(&bt->d_wl_cnt, sizeof(u32)));
-            SA_HIP_B(hipMemset(bt->d_wl_cnt, 0, sizeof(u32)));
-            SA_HIP_B(hipMalloc(&bt->d_grp, h_grp.size() * sizeof(u32)));
-            SA_HIP_B(hipMemcpy(bt->d_grp, h_grp.data(), h_grp.size() * sizeof(u32), hipMemcpyHostToDevice));
-        }
-    }
-    if (sa_batch_alloc_topk(bt, ix->n_tiles, sa_tile_waves(ix->tile_docs)) != SA_OK) return fail(SA_ERR_HIP);
-    SA_HIP_B(hipMemcpy(bt->d_terms, h_terms.data(), h_terms.size() * sizeof(u32), hipMemcpyHostToDevice));
-    SA_HIP_B(hipMemcpy(bt->d_idf, h_idf.data(), h_idf.size() * sizeof(float), hipMemcpyHostToDevice));
-    SA_HIP_B(hipMalloc(&bt->d_bounds, ((size_t)B * T * (ix->n_tiles + 1) + 1) * sizeof(u32)));
-    SA_HIP_B(hipMalloc(&bt->d_qbase, (size_t)B * T * sizeof(u64)));
-    SA_HIP_B(hipMalloc(&bt->d_sattab, SA_SAT_NTF * SA_SAT_WMAX * sizeof(float)));
+    memset(h_grpd, 0, (size_t)2 * B * sizeof(u32));
+    if (!h_grp.empty()) memcpy(h_grpd, h_grp.data(), h_grp.size() * sizeof(u32));     // (at most B groups)
     {
         // Dynamic pruning tables (sa_sparse.hip).  Per query: the terms in ascending idf order with the
         // prefix sums of their idf -- what the j cheapest terms can add to a score at most, since
         // tf/(tf+norm) <= 1 (needs k1 >= 0 and 0 <= b <= 1; a negative or non-finite idf switches the
         // pruning off) -- and the LEAD term: the highest-idf term with postings in this shard.
-        std::vector<float> h_ub((size_t)B * (T + 1), 0.f);
-        std::vector<u32> h_ord((size_t)B * T, 0), h_lead(B, 0xFFFFFFFFu);
-        std::vector<u64> h_p1((size_t)B + 1, 0);
         const bool formula_ok = k1 >= 0.f && b >= 0.f && b <= 1.f;
-        // lead terms up to 1/64 of the shard's docs (phase 1 scores every one of them), and never more
-        // postings than fit the candidate list while the bound is still unknown
-        u64 limit1 = ix->n_docs / 64 > 4096 ? ix->n_docs / 64 : 4096;
-        if (limit1 > (u64)bt->cand_cap * 3 / 4) limit1 = (u64)bt->cand_cap * 3 / 4;
+        const u64 limit1 = sa_batch_lead_limit(bt);
         bt->sparse_limit2 = ix->n_docs / (u64)sa_env_int("SA_SPARSE_DIV", 8) > 4096 ? ix->n_docs / (u64)sa_env_int("SA_SPARSE_DIV", 8) : 4096;
-        bool all_ok = formula_ok;
+        std::pair<float, u32> v[SA_MAX_QTERMS];
+        h_p1[0] = 0;
         for (u32 r = 0; r < B; r++) {
-            std::vector<std::pair<float, u32>> v;
             bool ok = formula_ok;
             for (u32 t = 0; t < T; t++) {
                 const bool known = h_terms[(size_t)r * T + t] < ix->n_terms;
                 const float w = known ? h_idf[(size_t)r * T + t] : 0.f;
                 if (!(w >= 0.f) || w > 3.0e38f) ok = false;
-                v.push_back({w, t});
+                v[t] = {w, t};
             }
-            std::stable_sort(v.begin(), v.end(), [](const std::pair<float, u32>& a, const std::pair<float, u32>& c) { return a.first < c.first; });
+            std::stable_sort(v, v + T, [](const std::pair<float, u32>& a, const std::pair<float, u32>& c) { return a.first < c.first; });
             double acc = 0.0;
+            h_ub[(size_t)r * (T + 1)] = 0.f;
             for (u32 j = 0; j < T; j++) {
                 h_ord[(size_t)r * T + j] = v[j].second;
                 acc += (double)v[j].first;
@@ -1764,6 +1866,8 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
                 h_ub[(size_t)r * (T + 1) + j + 1] = ok ? ubf : INFINITY;
             }
             // lead: highest idf among the terms with postings here; too frequent -> scan the tiles
+            h_lead[r] = 0xFFFFFFFFu;
+            h_p1[r + 1] = 0;
             if (ok) {
                 for (int j = (int)T - 1; j >= 0; j--) {
                     const u32 t = v[(size_t)j].second;
@@ -1775,7 +1879,6 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
                     break;
                 }
             }
-            all_ok = all_ok && ok;
         }
         {
             // Lead-phase work items: 1024 postings each when there is plenty of work (measured best at
@@ -1784,85 +1887,98 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
             u64 lead_postings = 0;
             for (u32 r = 0; r < B; r++) lead_postings += h_p1[r + 1];
             bt->sparse_chunk1 = lead_postings >= (1ull << 19) ? SA_SP_CHUNK : SA_SP_CHUNK_LEAD;
-            if (const char* v = getenv("SA_SP_CHUNK1")) { const int c = atoi(v); if (c >= 64) bt->sparse_chunk1 = (u32)c; }
+            if (const char* e = getenv("SA_SP_CHUNK1")) { const int c = atoi(e); if (c >= 64) bt->sparse_chunk1 = (u32)c; }
             for (u32 r = 0; r < B; r++) h_p1[r + 1] = (h_p1[r + 1] + bt->sparse_chunk1 - 1) / bt->sparse_chunk1;
         }
         for (u32 r = 0; r < B; r++) h_p1[r + 1] += h_p1[r];
         bt->sparse_p1_total = h_p1[B];
         bt->sparse_ok = true;
-        SA_HIP_B(hipMalloc(&bt->d_ub, h_ub.size() * sizeof(float)));
-        SA_HIP_B(hipMalloc(&bt->d_ub_order, h_ord.size() * sizeof(u32)));
-        SA_HIP_B(hipMalloc(&bt->d_lead, (size_t)B * sizeof(u32)));
-        SA_HIP_B(hipMalloc(&bt->d_p1_off, ((size_t)B + 1) * sizeof(u64)));
-        SA_HIP_B(hipMalloc(&bt->d_route, (size_t)B * sizeof(u32)));
-        SA_HIP_B(hipMalloc(&bt->d_emask, (size_t)B * sizeof(u32)));
-        SA_HIP_B(hipMalloc(&bt->d_p2_off, ((size_t)B + 1) * sizeof(u64)));
-        SA_HIP_B(hipMalloc(&bt->d_tile_q, ((size_t)B + 2) * sizeof(u32)));
-        {
-            std::vector<u32> h_qdf((size_t)B * T, 0), h_row8((size_t)B * T, SA_DD_NONE);
-            for (size_t i = 0; i < (size_t)B * T; i++) {
-                const u32 term = h_terms[i];
-                if (term >= ix->n_terms) continue;
-                h_qdf[i] = (u32)(ix->h_tf_off[term + 1] - ix->h_tf_off[term]);
-                bt->sparse_p2_max += ((u64)h_qdf[i] + SA_SP_CHUNK - 1) / SA_SP_CHUNK;
-                if (!ix->h_tf8_slot.empty()) h_row8[i] = ix->h_tf8_slot[term];
-            }
-            SA_HIP_B(hipMalloc(&bt->d_qdf, h_qdf.size() * sizeof(u32)));
-            SA_HIP_B(hipMalloc(&bt->d_qrow8, h_row8.size() * sizeof(u32)));
-            SA_HIP_B(hipMemcpy(bt->d_qdf, h_qdf.data(), h_qdf.size() * sizeof(u32), hipMemcpyHostToDevice));
-            SA_HIP_B(hipMemcpy(bt->d_qrow8, h_row8.data(), h_row8.size() * sizeof(u32), hipMemcpyHostToDevice));
-            // survivors of the phase-2 bound check: a few percent of the candidates; capped, the rest is scored in place
-            u64 cap = (u64)B * 65536;
-            if (cap > (16u << 20)) cap = 16u << 20;
-            bt->surv_cap = (u32)cap;
-            SA_HIP_B(hipMalloc(&bt->d_surv, (size_t)cap * 2 * sizeof(u64)));
-            // Bloom filter of every lead term: the power of two in [8, 16) x df cells, at least 1024
-            std::vector<u64> h_boff(B, 0);
-            std::vector<u32> h_bshift(B, 22);
-            size_t bytes = 0;
-            for (u32 r = 0; r < B; r++) {
-                const u64 df = h_lead[r] == 0xFFFFFFFFu ? 0 : h_qdf[(size_t)r * T + h_lead[r]];
-                u32 bits = 10;
-                while ((1ull << bits) < 8 * df && bits < 30) bits++;
-                h_boff[r] = bytes;
-                h_bshift[r] = 32 - bits;
-                bytes += (size_t)1 << bits;
-            }
-            bt->bloom_bytes = bytes;
-            SA_HIP_B(hipMalloc(&bt->d_bloom, bytes));
-            SA_HIP_B(hipMalloc(&bt->d_bloom_off, (size_t)B * sizeof(u64)));
-            SA_HIP_B(hipMalloc(&bt->d_bloom_shift, (size_t)B * sizeof(u32)));
-            SA_HIP_B(hipMemcpy(bt->d_bloom_off, h_boff.data(), (size_t)B * sizeof(u64), hipMemcpyHostToDevice));
-            SA_HIP_B(hipMemcpy(bt->d_bloom_shift, h_bshift.data(), (size_t)B * sizeof(u32), hipMemcpyHostToDevice));
+        bt->sparse_p2_max = 0;
+        for (size_t i = 0; i < (size_t)B * T; i++) {
+            const u32 term = h_terms[i];
+            h_qdf[i] = 0; h_row8[i] = SA_DD_NONE;
+            if (term >= ix->n_terms) continue;
+            h_qdf[i] = (u32)(ix->h_tf_off[term + 1] - ix->h_tf_off[term]);
+            bt->sparse_p2_max += ((u64)h_qdf[i] + SA_SP_CHUNK - 1) / SA_SP_CHUNK;
+            if (!ix->h_tf8_slot.empty()) h_row8[i] = ix->h_tf8_slot[term];
         }
-        SA_HIP_B(hipMemcpy(bt->d_ub, h_ub.data(), h_ub.size() * sizeof(float), hipMemcpyHostToDevice));
-        SA_HIP_B(hipMemcpy(bt->d_ub_order, h_ord.data(), h_ord.size() * sizeof(u32), hipMemcpyHostToDevice));
-        SA_HIP_B(hipMemcpy(bt->d_lead, h_lead.data(), (size_t)B * sizeof(u32), hipMemcpyHostToDevice));
-        SA_HIP_B(hipMemcpy(bt->d_p1_off, h_p1.data(), ((size_t)B + 1) * sizeof(u64), hipMemcpyHostToDevice));
-        SA_HIP_B(hipMemset(bt->d_route, 0xFF, (size_t)B * sizeof(u32)));
+        // Bloom filter of every lead term: the power of two in [8, 16) x df cells, at least 1024
+        size_t bytes = 0;
+        for (u32 r = 0; r < B; r++) {
+            const u64 df = h_lead[r] == 0xFFFFFFFFu ? 0 : h_qdf[(size_t)r * T + h_lead[r]];
+            const u64 cells = sa_pow2_cells(df);
+            h_boff[r] = bytes;
+            h_bshift[r] = 32u - (u32)__builtin_ctzll(cells);
+            bytes += (size_t)cells;
+        }
+        bt->bloom_bytes = bytes;
     }
-    if (sa_launch_make_sattab(ix, bt->d_sattab, &bt->tab_w, k1, b, ix->stream) != SA_OK) return fail(SA_ERR_HIP);
-    // the impact stream of this (k1, b): shared through the index, built on first use
-    bt->impacts = sa_impacts_get(ix, k1, b);
-    if (bt->impacts) SA_HIP_B(hipMalloc(&bt->d_qbase_imp, (size_t)B * T * 2 * sizeof(u64)));
-    if (sa_launch_make_bounds(ix, bt->d_terms, B * T, bt->d_bounds, bt->d_qbase, ix->stream, bt->d_qbase_imp) != SA_OK) return fail(SA_ERR_HIP);
-    SA_HIP_B(hipStreamSynchronize(ix->stream));
-#undef SA_HIP_B
-    (void)rc;
+    SA_TRY(sa_batch_upload_commit(bt));
+    SA_TRY(sa_launch_make_bounds(ix, bt->d_terms, B * T, bt->d_bounds, bt->d_qbase, ix->stream, bt->d_qbase_imp));
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+
+extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const float* idf, int n_queries,
+                               int n_query_terms, int k, float k1, float b, sa_batch_t** out) {
+    SA_ARG(ix && out && terms && idf, "null argument");
+    SA_ARG(n_queries > 0 && n_query_terms > 0, "empty batch");
+    SA_ARG(n_query_terms <= SA_MAX_QTERMS, "more than 32 terms per query is not supported");
+    SA_ARG(k > 0 && k <= SA_KMAX, "k must be in [1, 1024]");
+    SA_ARG(ix->doc_base + ix->n_docs <= 0xFFFFFFFFull, "global doc ids must fit 32 bits for top-k");
+    std::lock_guard<std::mutex> g(ix->mu);
+    SA_HIP(hipSetDevice(ix->device));
+    sa_batch* bt = new (std::nothrow) sa_batch();
+    if (!bt) { sa_set_error("out of host memory"); return SA_ERR_NOMEM; }
+    bt->ix = ix; bt->B = (u32)n_queries; bt->T = (u32)n_query_terms; bt->k = (u32)k; bt->k1 = k1; bt->b = b;
+    int rc = sa_batch_alloc_bm25(bt);
+    if (rc == SA_OK) rc = sa_batch_fill(bt, terms, idf);
+    if (rc == SA_OK && hipStreamSynchronize(ix->stream) != hipSuccess) {
+        sa_set_error("sa_batch_create: hipStreamSynchronize failed");
+        rc = SA_ERR_HIP;
+    }
+    if (rc != SA_OK) { sa_batch_free(bt); return rc; }
     *out = bt;
     return SA_OK;
 }
 
-// regroup an all-gather result [rank][B][k] into per-query candidate rows [B][rank*k]
-__global__ void sa_k_regroup(const u64* __restrict__ gathered, u32 nranks, u32 B, u32 k, u64* __restrict__ out) {
-    const u64 total = (u64)nranks * B * k;
+// A NEW set of queries in an existing batch (same B, T, k, k1, b): the host derives grouping, pruning tables and
+// statistics into a page-locked image, ONE hipMemcpyAsync replaces the device tables and sa_k_make_bounds rebuilds
+// the slice table -- all enqueued on the index stream behind the runs still in flight, nothing allocated, nothing
+// waited for.  The caller idiom it serves is the reference's score() on a fresh query (postings.py:652-680; timed
+// as test/test_msmarco.py:345-395 times it): two batches used alternately keep the device busy while the host
+// prepares the next query set.
+extern "C" int sa_batch_reset(sa_batch_t* bt, const uint32_t* terms, const float* idf) {
+    SA_ARG(bt && bt->ix && terms && idf, "null argument");
+    SA_ARG(bt->kind == 0, "sa_batch_reset takes a BM25 batch (phrase batches: sa_phrase_batch_reset)");
+    sa_index* ix = bt->ix;
+    std::lock_guard<std::mutex> g(ix->mu);
+    SA_HIP(hipSetDevice(ix->device));
+    return sa_batch_fill(bt, terms, idf);
+}
+
+// regroup an all-gather result [rank][B*k (+ extra)] into per-query candidate rows [B][rank*k]; `extra` = 1: every
+// rank's block ends with its overflow flag, OR-ed into *xflag (a candidate list ran over on SOME rank: all ranks
+// learn it from the exchange itself and redo the batch together at fetch)
+__global__ void sa_k_regroup(const u64* __restrict__ gathered, u32 nranks, u32 B, u32 k, u32 extra, u64* __restrict__ out,
+                             u32* __restrict__ xflag) {
+    const u64 per = (u64)B * k;
+    const u64 total = (u64)nranks * per;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x) {
         const u32 j = (u32)(i % k);
         const u32 q = (u32)((i / k) % B);
-        const u32 r = (u32)(i / ((u64)k * B));
-        out[((u64)q * nranks + r) * k + j] = gathered[i];
+        const u32 r = (u32)(i / per);
+        out[((u64)q * nranks + r) * k + j] = gathered[(u64)r * (per + extra) + (i - (u64)r * per)];
+    }
+    if (extra && xflag && blockIdx.x == 0 && threadIdx.x == 0) {
+        u32 any = 0;
+        for (u32 r = 0; r < nranks; r++) any |= gathered[(u64)r * (per + extra) + per] != 0ull ? 1u : 0u;
+        if (any) *xflag = 1u;
     }
 }
+
+// the rank's overflow flag behind its B*k keys (exchange stream, before the all-gather)
+__global__ void sa_k_put_flag(u64* __restrict__ cell, const u32* __restrict__ flag) { *cell = (u64)*flag; }
 
 // stage 1 (tile scoring + per-tile top-k) and stage 2 (per-shard merge) on the index stream
 // defer_check: an overflowing candidate list is only flagged on the device; sa_batch_fetch re-runs the
@@ -1900,7 +2016,11 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     // Round 2: when most queries of the batch share their first terms, the grouped exhaustive kernel is as fast at
     // k = 10 and faster above (10 M docs, BASELINE batch: 369 K vs 341 K queries/s at k = 100, 236 K vs 114 K at
     // k = 1000) -- such batches score every posting from k = 32 on.
-    const bool shared_heads = bt->n_shared_rows * 4u >= bt->B * 3u && bt->k >= 32u && sa_env_int("SA_GROUP", 1) != 0;
+    // (only where the grouped kernel can actually run: impact stream, histogram bound, its tile sizes -- otherwise the
+    //  batch would fall to the per-query exhaustive kernel, which pruning beats 2x)
+    const bool group_can_run = bt->n_groups && p.pruned && hist_possible && p.imp && !p.no_topk && sa_env_int("SA_GROUP", 1) != 0 &&
+                               (ix->tile_docs == 1024 || ix->tile_docs == 2048 || ix->tile_docs == 4096);
+    const bool shared_heads = bt->n_shared_rows * 4u >= bt->B * 3u && bt->k >= 32u && group_can_run;
     const bool sparse_wanted = sparse_env >= 0 ? sparse_env != 0 : (ix->n_docs >= (u64)bt->k * 32768ull && !shared_heads);
     const bool sparse = hist_possible && ix->tile_docs <= 8192 && bt->sparse_ok && ix->avg_doc_len != 0.f && ix->n_tiles > 0 &&
                         sparse_wanted;
@@ -1909,6 +2029,7 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     p.hist = use_hist ? bt->d_hist : nullptr;
     p.gthr = use_hist ? bt->d_gthr : nullptr;
     p.qlist = nullptr; p.nq = bt->B;
+    if (sparse) SA_TRY(sa_batch_ensure_bloom(bt));
     if (p.pruned) {
         // one launch clears the per-run state: bound slots / cursors / histograms and, for dynamic
         // pruning, the lead terms' Bloom filters (two memsets cost two launches and a gap)
@@ -1930,7 +2051,7 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
                 SA_TRY(sa_launch_sparse(bt, st));
                 p.qlist = bt->d_tile_q; p.nq_dev = bt->d_tile_q + bt->B;
                 SA_TRY(sa_launch_bm25_list(ix, p, st));
-            } else if (bt->n_groups && p.pruned && p.hist && p.imp && !p.no_topk && sa_env_int("SA_GROUP", 1) != 0) {
+            } else if (group_can_run && p.hist) {
                 // Queries that share their first term: the first tiles through the per-query kernel, which
                 // establishes every query's bound (k-th best score so far), then one wave per (tile, group).
                 // Queries without a group go through the per-query kernel over all tiles.
@@ -1942,6 +2063,7 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
                 // (a few dense queries are a small grid of long workgroups: alone on the device they took 0.28 ms of a
                 // 0.82 ms step on a batch without shared terms); the merge waits for both.
                 bool side = false;
+                int rc_side = SA_OK;
                 if (bt->n_grouped_rows < bt->B) {
                     Bm25Params pu = p;
                     pu.qlist = bt->d_iota + bt->n_grouped_rows; pu.nq = bt->B - bt->n_grouped_rows;
@@ -1952,17 +2074,23 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
                             if (!bt->ev_side[i]) SA_HIP(hipEventCreateWithFlags(&bt->ev_side[i], hipEventDisableTiming));
                         SA_HIP(hipEventRecord(bt->ev_side[0], st));               // (after the reset: the launches above)
                         SA_HIP(hipStreamWaitEvent(ix->sstream, bt->ev_side[0], 0));
-                        SA_TRY(sa_launch_bm25(ix, pu, ix->sstream));
+                        rc_side = sa_launch_bm25(ix, pu, ix->sstream);
                         SA_HIP(hipEventRecord(bt->ev_side[1], ix->sstream));
                     } else {
                         SA_TRY(sa_launch_bm25(ix, pu, st));
                     }
                 }
-                Bm25Params pa = p;
-                pa.qlist = bt->d_iota; pa.nq = bt->n_grouped_rows; pa.tile0 = 0; pa.tile_end = warm;
-                SA_TRY(sa_launch_bm25(ix, pa, st));
-                if (ix->n_tiles > warm) SA_TRY(sa_launch_bm25_groups(ix, bt, p, warm, st));
+                // (whatever fails from here on, the index stream still joins the side stream: nothing of this run
+                //  may be in flight on a stream that sa_batch_free does not wait for in order)
+                int rc_main = rc_side;
+                if (rc_main == SA_OK) {
+                    Bm25Params pa = p;
+                    pa.qlist = bt->d_iota; pa.nq = bt->n_grouped_rows; pa.tile0 = 0; pa.tile_end = warm;
+                    rc_main = sa_launch_bm25(ix, pa, st);
+                }
+                if (rc_main == SA_OK && ix->n_tiles > warm) rc_main = sa_launch_bm25_groups(ix, bt, p, warm, st);
                 if (side) SA_HIP(hipStreamWaitEvent(st, bt->ev_side[1], 0));
+                SA_TRY(rc_main);
             } else {
                 SA_TRY(sa_launch_bm25(ix, p, st));
             }
@@ -1993,6 +2121,8 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
         }
     }
     const u32 n_cand = p.pruned ? p.cand_cap : (n_tiles ? n_tiles : 1) * p.cand_per_tile;
+    // (the previous run's result copy reads d_final on the exchange stream: long done, but the order is stated)
+    if (shard_out == bt->d_final && bt->res_pending) SA_HIP(hipStreamWaitEvent(st, bt->ev_res, 0));
     hipLaunchKernelGGL(sa_k_topk_merge, dim3(bt->B), dim3(1024), 0, st, bt->d_cand, n_cand, bt->k, shard_out,
                        (const u32*)bt->d_perm, 0u, (const u32*)(p.pruned ? bt->d_cand_cnt : nullptr),
                        (const u32*)(p.pruned && !p.hist ? bt->d_slots : nullptr),
@@ -2002,8 +2132,8 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     return SA_OK;
 }
 
-// stage 3: merge the per-rank top-k lists [nranks][B][k] (device memory) into d_final
-static int sa_batch_merge_ranks(sa_batch* bt, const u64* d_gathered, int nranks, hipStream_t st) {
+// stage 3: merge the per-rank top-k lists [nranks][B*k (+ extra)] (device memory) into d_final
+static int sa_batch_merge_ranks(sa_batch* bt, const u64* d_gathered, int nranks, hipStream_t st, u32 extra = 0) {
     const size_t count = (size_t)bt->B * bt->k;
     if (!bt->d_xcand || bt->xcand_ranks < nranks) {
         if (bt->d_xcand) SA_HIP(hipFree(bt->d_xcand));
@@ -2013,11 +2143,31 @@ static int sa_batch_merge_ranks(sa_batch* bt, const u64* d_gathered, int nranks,
     }
     const u64 total = (u64)nranks * count;
     const u32 grid = total / 256 + 1 < 4096 ? (u32)(total / 256 + 1) : 4096;
-    hipLaunchKernelGGL(sa_k_regroup, dim3(grid), dim3(256), 0, st, d_gathered, (u32)nranks, bt->B, bt->k, bt->d_xcand);
+    hipLaunchKernelGGL(sa_k_regroup, dim3(grid), dim3(256), 0, st, d_gathered, (u32)nranks, bt->B, bt->k, extra, bt->d_xcand,
+                       bt->d_xflag);
     // every rank's block is its sorted top-k: group leaders = rank maxima
     hipLaunchKernelGGL(sa_k_topk_merge, dim3(bt->B), dim3(1024), 0, st, bt->d_xcand, (u32)nranks * bt->k, bt->k, bt->d_final,
                        (const u32*)nullptr, bt->k, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr,
                        (u32*)nullptr);
+    return SA_OK;
+}
+
+// Results to the host without synchronising a stream: the keys and the overflow flag are copied into the batch's
+// page-locked result buffer on the exchange stream, behind `src_stream`'s work so far; sa_batch_fetch waits for the
+// copy's event only.  The next run's merge waits for the copy (it is long done by then).
+static int sa_batch_queue_result_copy(sa_batch* bt, hipStream_t src_stream, const u32* d_flag) {
+    sa_index* ix = bt->ix;
+    if (!ix->xstream) SA_HIP(hipStreamCreateWithFlags(&ix->xstream, hipStreamNonBlocking));
+    hipStream_t xs = ix->xstream;
+    const size_t n = (size_t)bt->B * bt->k;
+    if (src_stream != xs) {
+        SA_HIP(hipEventRecord(bt->ev_final, src_stream));
+        SA_HIP(hipStreamWaitEvent(xs, bt->ev_final, 0));
+    }
+    SA_HIP(hipMemcpyAsync(bt->h_res, bt->d_final, n * sizeof(u64), hipMemcpyDeviceToHost, xs));
+    SA_HIP(hipMemcpyAsync(bt->h_res + n, d_flag, sizeof(u32), hipMemcpyDeviceToHost, xs));
+    SA_HIP(hipEventRecord(bt->ev_res, xs));
+    bt->res_pending = true;
     return SA_OK;
 }
 
@@ -2030,13 +2180,16 @@ extern "C" int sa_batch_run(sa_batch_t* bt, int sync) {
     if (ix->comm) {
         // Scoring runs on the index stream; the all-gather of the per-shard top-k and the
         // cross-rank merge run on the exchange stream, double-buffered, so they overlap the next
-        // run's scoring kernels (the exchange is latency-bound: B*k*8 bytes per rank).
+        // run's scoring kernels (the exchange is latency-bound: B*k*8 bytes per rank).  Every rank's block ends
+        // with one extra cell, its overflow flag: the ranks learn from the exchange itself whether any of them
+        // has to redo the batch unpruned (sa_batch_fetch) -- no separate collective, no host round trip.
         int nranks = 1;
         const size_t count = (size_t)bt->B * bt->k;
+        const size_t cell = count + 1;
         hipStream_t xs = ix->xstream;
         SA_TRY(sa_comm_allgather_topk(ix, nullptr, nullptr, 0, &nranks, xs));
         if (!bt->d_xlocal) {
-            SA_HIP(hipMalloc(&bt->d_xlocal, 2 * count * sizeof(u64)));
+            SA_HIP(hipMalloc(&bt->d_xlocal, 2 * cell * sizeof(u64)));
             for (int i = 0; i < 2; i++) {
                 SA_HIP(hipEventCreateWithFlags(&bt->ev_scored[i], hipEventDisableTiming));
                 SA_HIP(hipEventCreateWithFlags(&bt->ev_exchanged[i], hipEventDisableTiming));
@@ -2046,25 +2199,29 @@ extern "C" int sa_batch_run(sa_batch_t* bt, int sync) {
             SA_HIP(hipStreamSynchronize(xs));
             if (bt->d_gather) SA_HIP(hipFree(bt->d_gather));
             bt->d_gather = nullptr;
-            SA_HIP(hipMalloc(&bt->d_gather, 2 * (size_t)nranks * count * sizeof(u64)));
+            SA_HIP(hipMalloc(&bt->d_gather, 2 * (size_t)nranks * cell * sizeof(u64)));
             bt->gather_ranks = nranks;
         }
         if (!bt->d_xcand || bt->xcand_ranks < nranks) SA_HIP(hipStreamSynchronize(xs));   // merge_ranks reallocates
         const u32 bsel = bt->xstep & 1;
         bt->xstep++;
-        u64* xl = bt->d_xlocal + bsel * count;
-        u64* xg = bt->d_gather + bsel * (size_t)nranks * count;
+        u64* xl = bt->d_xlocal + bsel * cell;
+        u64* xg = bt->d_gather + bsel * (size_t)nranks * cell;
         if (bt->exchanged_valid[bsel]) SA_HIP(hipStreamWaitEvent(st, bt->ev_exchanged[bsel], 0));
         SA_TRY(sa_batch_run_shard(bt, xl, true));
         SA_HIP(hipEventRecord(bt->ev_scored[bsel], st));
         SA_HIP(hipStreamWaitEvent(xs, bt->ev_scored[bsel], 0));
-        SA_TRY(sa_comm_allgather_topk(ix, xl, xg, count, &nranks, xs));
-        SA_TRY(sa_batch_merge_ranks(bt, xg, nranks, xs));
+        hipLaunchKernelGGL(sa_k_put_flag, dim3(1), dim3(1), 0, xs, xl + count, (const u32*)bt->d_overflow);
+        SA_TRY(sa_comm_allgather_topk(ix, xl, xg, cell, &nranks, xs));
+        SA_TRY(sa_batch_merge_ranks(bt, xg, nranks, xs, 1u));
+        SA_TRY(sa_batch_queue_result_copy(bt, xs, bt->d_xflag));
         SA_HIP(hipEventRecord(bt->ev_exchanged[bsel], xs));
         bt->exchanged_valid[bsel] = true;
         if (sync) SA_HIP(hipStreamSynchronize(xs));
     } else {
         SA_TRY(sa_batch_run_shard(bt, bt->d_final, true));
+        SA_TRY(sa_batch_queue_result_copy(bt, st, bt->d_overflow));
+        if (sync) SA_HIP(hipStreamSynchronize(ix->xstream));
     }
     if (sync) {
         SA_HIP(hipStreamSynchronize(st));
@@ -2111,24 +2268,23 @@ extern "C" int sa_batch_fetch(sa_batch_t* bt, float* scores_out, uint64_t* docs_
     std::lock_guard<std::mutex> g(ix->mu);
     SA_HIP(hipSetDevice(ix->device));
     const size_t n = (size_t)bt->B * bt->k;
-    std::vector<u64> keys(n);
-    SA_HIP(hipStreamSynchronize(ix->stream));
-    if (ix->xstream) SA_HIP(hipStreamSynchronize(ix->xstream));
-    SA_HIP(hipGetLastError());
-    if (bt->d_overflow) {
-        // A run since the last fetch overflowed a candidate list (only possible when the bound could
-        // not rise: degenerate score distributions): redo the batch with the unpruned selection.
-        // Sharded: the ranks agree first (every rank calls fetch), then all of them redo the exchange.
-        if (ix->comm) {
-            SA_TRY(sa_comm_allreduce_max_u32(ix, bt->d_overflow, ix->xstream));
-            SA_HIP(hipStreamSynchronize(ix->xstream));
-        }
-        u32 over = 0;
-        SA_HIP(hipMemcpy(&over, bt->d_overflow, sizeof(u32), hipMemcpyDeviceToHost));
+    const u64* keys = nullptr;
+    std::vector<u64> legacy;
+    if (bt->res_pending) {
+        // the usual route (sa_batch_run): wait for THIS batch's result copy, nothing else -- other batches of the
+        // index may be in flight behind it
+        SA_HIP(hipEventSynchronize(bt->ev_res));
+        u32 over = (u32)bt->h_res[n];
         if (over) {
+            // A run overflowed a candidate list (only possible when the bound could not rise: degenerate score
+            // distributions): redo the batch with the unpruned selection.  Sharded: every rank saw the same flag
+            // (it travelled with the all-gather) and every rank calls fetch, so all of them redo the exchange.
+            SA_HIP(hipStreamSynchronize(ix->stream));
+            if (ix->xstream) SA_HIP(hipStreamSynchronize(ix->xstream));
             SA_HIP(hipMemset(bt->d_overflow, 0, sizeof(u32)));
+            SA_HIP(hipMemset(bt->d_xflag, 0, sizeof(u32)));
             if (ix->comm) {
-                const size_t count = (size_t)bt->B * bt->k;
+                const size_t count = n;
                 int nranks = 1;
                 SA_TRY(sa_comm_allgather_topk(ix, nullptr, nullptr, 0, &nranks, ix->xstream));
                 SA_TRY(sa_batch_run_shard(bt, bt->d_xlocal, false, true));
@@ -2141,9 +2297,19 @@ extern "C" int sa_batch_fetch(sa_batch_t* bt, float* scores_out, uint64_t* docs_
                 SA_HIP(hipStreamSynchronize(ix->stream));
             }
             SA_HIP(hipGetLastError());
+            SA_HIP(hipMemcpy(bt->h_res, bt->d_final, n * sizeof(u64), hipMemcpyDeviceToHost));
+            bt->h_res[n] = 0;
         }
+        keys = bt->h_res;
+    } else {
+        // external-collective route (sa_batch_run_local / sa_batch_merge_gathered): the caller's last call decides
+        legacy.resize(n);
+        SA_HIP(hipStreamSynchronize(ix->stream));
+        if (ix->xstream) SA_HIP(hipStreamSynchronize(ix->xstream));
+        SA_HIP(hipGetLastError());
+        SA_HIP(hipMemcpy(legacy.data(), bt->d_final, n * sizeof(u64), hipMemcpyDeviceToHost));
+        keys = legacy.data();
     }
-    SA_HIP(hipMemcpy(keys.data(), bt->d_final, n * sizeof(u64), hipMemcpyDeviceToHost));
     for (u32 r = 0; r < bt->B; r++) {
         const u32 qi = r;                        // results are stored in caller order
         for (u32 j = 0; j < bt->k; j++) {

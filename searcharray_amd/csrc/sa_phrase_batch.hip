@@ -292,19 +292,16 @@ extern "C" int sa_phrase_batch_create(sa_index_t* ix, const uint32_t* terms, con
     return sa_phrase_batch_create_ex(ix, terms, n_terms, nullptr, idf, n_phrases, max_terms, k, k1, b, out);
 }
 
-extern "C" int sa_phrase_batch_create_ex(sa_index_t* ix, const uint32_t* terms, const int32_t* n_terms, const int32_t* slop,
-                                         const float* idf, int n_phrases, int max_terms, int k, float k1, float b,
-                                         sa_batch_t** out) {
-    SA_ARG(ix && out && terms && n_terms && idf, "null argument");
-    SA_ARG(n_phrases > 0 && max_terms >= 2, "empty batch");
-    SA_ARG(k > 0 && k <= SA_KMAX, "k must be in [1, 1024]");
-    SA_ARG(ix->doc_base + ix->n_docs <= 0xFFFFFFFFull, "global doc ids must fit 32 bits for top-k");
-    const u32 B = (u32)n_phrases, T = (u32)max_terms;
+// everything of a phrase batch that depends on the phrases: validation, the plan per phrase, the upload image, the
+// word-slice table -- enqueued on the index stream, nothing allocated, nothing waited for
+static int sa_phrase_batch_fill(sa_batch* bt, const uint32_t* terms, const int32_t* n_terms, const int32_t* slop, const float* idf) {
+    sa_index* ix = bt->ix;
+    const u32 B = bt->B, T = bt->T;
     std::vector<u32> dense_rows;
     for (u32 i = 0; i < B; i++) {
         // reference middle_out.py:425-426
         if (n_terms[i] < 2) { sa_set_error("Must have at least two terms"); return SA_ERR_ARG; }
-        SA_ARG(n_terms[i] <= max_terms, "n_terms[i] > max_terms");
+        SA_ARG(n_terms[i] <= (int)T, "n_terms[i] > max_terms");
         SA_ARG(!slop || slop[i] >= 0, "slop < 0");
         if (n_terms[i] > 128) { sa_set_error("phrase too long (max 128 terms)"); return SA_ERR_UNSUPPORTED; }
         if (slop && slop[i] > 0 && n_terms[i] > 16) { sa_set_error("slop phrases support at most 16 terms"); return SA_ERR_UNSUPPORTED; }
@@ -317,20 +314,19 @@ extern "C" int sa_phrase_batch_create_ex(sa_index_t* ix, const uint32_t* terms, 
                 if (terms[(size_t)i * T + t] == terms[(size_t)i * T + u] && terms[(size_t)i * T + t] < ix->n_terms) dense = true;
         if (dense) dense_rows.push_back(i);
     }
-    std::lock_guard<std::mutex> g(ix->mu);
-    SA_HIP(hipSetDevice(ix->device));
-    sa_batch* bt = new (std::nothrow) sa_batch();
-    if (!bt) { sa_set_error("out of host memory"); return SA_ERR_NOMEM; }
-    bt->ix = ix; bt->B = B; bt->T = T; bt->k = (u32)k; bt->k1 = k1; bt->b = b;
-    bt->kind = 1;
-    bt->ptile = SA_PTILE;
-    if (const char* v = getenv("SA_PTILE")) { if (atoi(v) == 2048 || atoi(v) == 4096) bt->ptile = (u32)atoi(v); }
-    bt->pn_tiles = (u32)((ix->n_docs + bt->ptile - 1) / bt->ptile);
+    char* img = nullptr;
+    SA_TRY(sa_batch_upload_begin(bt, &img));
+    auto at = [&](const void* dptr) { return img + ((const char*)dptr - bt->d_up); };
+    u32* h_terms = (u32*)at(bt->d_terms);
+    float* h_idf = (float*)at(bt->d_idf);
+    u32* h_perm = (u32*)at(bt->d_perm);
+    u32* plan = (u32*)at(bt->d_plan);
     bt->perm.resize(B);
-    for (u32 i = 0; i < B; i++) bt->perm[i] = i;
+    for (u32 i = 0; i < B; i++) { bt->perm[i] = i; h_perm[i] = i; }
     // plan per phrase (host): reference compute_phrase_freqs, middle_out.py:154-168
-    std::vector<u32> plan((size_t)B * 4, 0);
-    std::vector<u32> h_terms((size_t)B * T, SA_NO_TERM);
+    memset(plan, 0, (size_t)B * 4 * sizeof(u32));
+    for (size_t i = 0; i < (size_t)B * T; i++) h_terms[i] = SA_NO_TERM;
+    memcpy(h_idf, idf, (size_t)B * sizeof(float));
     bt->alg_bytes = 0; bt->postings_bytes = 0;
     bt->dense_rows = dense_rows;
     bt->h_pterms.assign(terms, terms + (size_t)B * T);
@@ -374,20 +370,7 @@ extern "C" int sa_phrase_batch_create_ex(sa_index_t* ix, const uint32_t* terms, 
         plan[(size_t)i * 4 + 3] = split ? anchor_of((int)split, Tq) : 0u;
     }
     bt->alg_bytes = bt->postings_bytes;
-    auto fail = [&](int code) { sa_batch_free(bt); return code; };
-#define SA_HIP_B(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { sa_set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return fail(SA_ERR_HIP); } } while (0)
-    SA_HIP_B(hipMalloc(&bt->d_terms, h_terms.size() * sizeof(u32)));
-    SA_HIP_B(hipMalloc(&bt->d_idf, (size_t)B * sizeof(float)));
-    SA_HIP_B(hipMalloc(&bt->d_perm, (size_t)B * sizeof(u32)));
-    SA_HIP_B(hipMalloc(&bt->d_plan, plan.size() * sizeof(u32)));
-    SA_HIP_B(hipMalloc(&bt->d_wbounds, ((size_t)B * T * (bt->pn_tiles + 1) + 1) * sizeof(u32)));
-    SA_HIP_B(hipMalloc(&bt->d_wbase, (size_t)B * T * sizeof(u64)));
-    SA_HIP_B(hipMalloc(&bt->d_wlen, (size_t)B * T * sizeof(u32)));
-    SA_HIP_B(hipMemcpy(bt->d_perm, bt->perm.data(), (size_t)B * sizeof(u32), hipMemcpyHostToDevice));
-    SA_HIP_B(hipMemcpy(bt->d_terms, h_terms.data(), h_terms.size() * sizeof(u32), hipMemcpyHostToDevice));
-    SA_HIP_B(hipMemcpy(bt->d_idf, idf, (size_t)B * sizeof(float), hipMemcpyHostToDevice));
-    SA_HIP_B(hipMemcpy(bt->d_plan, plan.data(), plan.size() * sizeof(u32), hipMemcpyHostToDevice));
-    if (sa_batch_alloc_topk(bt, bt->pn_tiles, SA_PTHREADS / SA_WAVE) != SA_OK) return fail(SA_ERR_HIP);
+    SA_TRY(sa_batch_upload_commit(bt));
     {
         const u64 total = (u64)B * T * (bt->pn_tiles + 1);
         const u32 grid = total / 256 + 1 < 65535 ? (u32)(total / 256 + 1) : 65535u;
@@ -395,9 +378,57 @@ extern "C" int sa_phrase_batch_create_ex(sa_index_t* ix, const uint32_t* terms, 
                            ix->n_terms, bt->pn_tiles, bt->ptile, (const u32*)bt->d_terms, B * T, bt->d_wbounds,
                            bt->d_wbase, bt->d_wlen);
     }
-    SA_HIP_B(hipStreamSynchronize(ix->stream));
-    SA_HIP_B(hipGetLastError());
-#undef SA_HIP_B
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+
+extern "C" int sa_phrase_batch_create_ex(sa_index_t* ix, const uint32_t* terms, const int32_t* n_terms, const int32_t* slop,
+                                         const float* idf, int n_phrases, int max_terms, int k, float k1, float b,
+                                         sa_batch_t** out) {
+    SA_ARG(ix && out && terms && n_terms && idf, "null argument");
+    SA_ARG(n_phrases > 0 && max_terms >= 2, "empty batch");
+    SA_ARG(k > 0 && k <= SA_KMAX, "k must be in [1, 1024]");
+    SA_ARG(ix->doc_base + ix->n_docs <= 0xFFFFFFFFull, "global doc ids must fit 32 bits for top-k");
+    const u32 B = (u32)n_phrases, T = (u32)max_terms;
+    std::lock_guard<std::mutex> g(ix->mu);
+    SA_HIP(hipSetDevice(ix->device));
+    sa_batch* bt = new (std::nothrow) sa_batch();
+    if (!bt) { sa_set_error("out of host memory"); return SA_ERR_NOMEM; }
+    bt->ix = ix; bt->B = B; bt->T = T; bt->k = (u32)k; bt->k1 = k1; bt->b = b;
+    bt->kind = 1;
+    bt->ptile = SA_PTILE;
+    if (const char* v = getenv("SA_PTILE")) { if (atoi(v) == 2048 || atoi(v) == 4096) bt->ptile = (u32)atoi(v); }
+    bt->pn_tiles = (u32)((ix->n_docs + bt->ptile - 1) / bt->ptile);
+    auto alloc = [&]() -> int {
+        // upload block: terms [B][T], idf [B], perm [B], plan [B][4]
+        const size_t o_terms = 0, o_idf = o_terms + (size_t)B * T * 4, o_perm = o_idf + (size_t)B * 4, o_plan = o_perm + (size_t)B * 4;
+        SA_TRY(sa_batch_alloc_upload(bt, o_plan + (size_t)B * 16));
+        bt->d_terms = (u32*)(bt->d_up + o_terms); bt->d_idf = (float*)(bt->d_up + o_idf);
+        bt->d_perm = (u32*)(bt->d_up + o_perm); bt->d_plan = (u32*)(bt->d_up + o_plan);
+        SA_HIP(hipMalloc(&bt->d_wbounds, ((size_t)B * T * (bt->pn_tiles + 1) + 1) * sizeof(u32)));
+        SA_HIP(hipMalloc(&bt->d_wbase, (size_t)B * T * sizeof(u64)));
+        SA_HIP(hipMalloc(&bt->d_wlen, (size_t)B * T * sizeof(u32)));
+        SA_TRY(sa_batch_alloc_topk(bt, bt->pn_tiles, SA_PTHREADS / SA_WAVE));
+        return SA_OK;
+    };
+    int rc = alloc();
+    if (rc == SA_OK) rc = sa_phrase_batch_fill(bt, terms, n_terms, slop, idf);
+    if (rc == SA_OK && hipStreamSynchronize(ix->stream) != hipSuccess) {
+        sa_set_error("sa_phrase_batch_create: hipStreamSynchronize failed");
+        rc = SA_ERR_HIP;
+    }
+    if (rc != SA_OK) { sa_batch_free(bt); return rc; }
     *out = bt;
     return SA_OK;
+}
+
+// A new set of phrases (same number, same max_terms, k, k1, b) in an existing phrase batch: see sa_batch_reset.
+extern "C" int sa_phrase_batch_reset(sa_batch_t* bt, const uint32_t* terms, const int32_t* n_terms, const int32_t* slop,
+                                     const float* idf) {
+    SA_ARG(bt && bt->ix && terms && n_terms && idf, "null argument");
+    SA_ARG(bt->kind == 1, "sa_phrase_batch_reset takes a phrase batch");
+    sa_index* ix = bt->ix;
+    std::lock_guard<std::mutex> g(ix->mu);
+    SA_HIP(hipSetDevice(ix->device));
+    return sa_phrase_batch_fill(bt, terms, n_terms, slop, idf);
 }

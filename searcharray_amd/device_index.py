@@ -436,6 +436,19 @@ class QueryBatch:
         self.api.call("sa_batch_create", index._h, p_u32(as_u32(terms)), p_f32(idf), self.B, self.T,
                       self.k, np.float32(k1), np.float32(b), ctypes.byref(self._h))
 
+    def reset(self, queries: np.ndarray, idf: Optional[np.ndarray] = None):
+        """A new set of B x T queries in this batch (the caller idiom of a query STREAM: ``score()`` on queries the
+        device has not seen).  One async copy + one kernel behind the runs in flight; no allocation, no
+        synchronisation (``sa_batch_reset``).  Fetch the previous results first."""
+        q = np.asarray(queries, dtype=np.int64)
+        if q.shape != (self.B, self.T):
+            raise ValueError(f"reset takes [{self.B}][{self.T}] term ids")
+        terms = np.where((q >= 0) & (q < self.index.n_terms), q, NO_TERM).astype(np.uint32)
+        if idf is None:
+            idf = self.index.idfs(q.reshape(-1)).reshape(self.B, self.T)
+        idf = as_f32(idf)
+        self.api.call("sa_batch_reset", self._h, p_u32(as_u32(terms)), p_f32(idf))
+
     def run(self, sync: bool = True):
         self.api.call("sa_batch_run", self._h, 1 if sync else 0)
 
@@ -504,6 +517,21 @@ class PhraseBatch(QueryBatch):
         n_terms = np.asarray([len(p) for p in phrases], dtype=np.int32)
         self.T = int(max(2, n_terms.max()))
         self.k = int(k)
+        terms, n_terms, slops, idf = self._pack(phrases, idf, slop)
+        self._h = ctypes.c_void_p()
+        self.api.call("sa_phrase_batch_create_ex", index._h, p_u32(terms),
+                      n_terms.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                      slops.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), p_f32(idf), self.B, self.T,
+                      self.k, np.float32(k1), np.float32(b), ctypes.byref(self._h))
+        index._track(self)
+
+    def _pack(self, phrases, idf, slop):
+        index = self.index
+        if len(phrases) != self.B:
+            raise ValueError(f"this batch holds {self.B} phrases")
+        n_terms = np.asarray([len(p) for p in phrases], dtype=np.int32)
+        if n_terms.max() > self.T:
+            raise ValueError(f"this batch holds phrases of at most {self.T} terms")
         terms = np.full((self.B, self.T), NO_TERM, dtype=np.uint32)
         for i, ph in enumerate(phrases):
             row = np.asarray(ph, dtype=np.int64)
@@ -514,15 +542,17 @@ class PhraseBatch(QueryBatch):
                                           np.asarray([index.docfreq(int(t)) if 0 <= int(t) < index.n_terms else 0
                                                       for t in ph])) for ph in phrases], dtype=np.float32)
         self._n_terms = n_terms
-        self._h = ctypes.c_void_p()
         slops = np.ascontiguousarray(np.broadcast_to(np.asarray(slop, dtype=np.int32), (self.B,)))   # one slop, or one per phrase
         if (slops < 0).any():
             raise ValueError("slop must be >= 0")
-        self.api.call("sa_phrase_batch_create_ex", index._h, p_u32(as_u32(terms)),
+        return as_u32(terms), n_terms, slops, as_f32(idf)
+
+    def reset(self, phrases: Sequence[Sequence[int]], idf: Optional[np.ndarray] = None, slop=0):
+        """A new set of B phrases (none longer than the batch's max_terms) in this batch: ``sa_phrase_batch_reset``."""
+        terms, n_terms, slops, idf = self._pack(phrases, idf, slop)
+        self.api.call("sa_phrase_batch_reset", self._h, p_u32(terms),
                       n_terms.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
-                      slops.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), p_f32(as_f32(idf)), self.B, self.T,
-                      self.k, np.float32(k1), np.float32(b), ctypes.byref(self._h))
-        index._track(self)
+                      slops.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), p_f32(idf))
 
 
 class DeviceVec:
