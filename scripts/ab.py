@@ -1,0 +1,90 @@
+#!/usr/bin/env python
+"""Same-box A/B of builds and switches of the exhaustive scoring path on the bench workload.
+
+  python scripts/ab.py --libs searcharray_amd/libsearcharray_hip_base.so,searcharray_amd/libsearcharray_hip.so \
+                       --envs "SA_GROUP=1;SA_GROUP=1,SA_GROUP_WARM=8" --ks 10,1000 --qsets baseline,distinct
+
+Every (library, environment) pair scores the same resident batch; results must be identical to the first
+configuration's.  One JSON line per configuration (ms per step by the host clock over `--steps` asynchronous runs,
+kernel ms by HIP events).  Libraries are loaded side by side in one process (ctypes, RTLD_LOCAL), each builds its own
+index from the same corpus."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from searcharray_amd import synth, _lib                                     # noqa: E402
+from searcharray_amd.device_index import DeviceIndex, QueryBatch, compute_idf   # noqa: E402
+
+KEYS = ("SA_GROUP", "SA_GROUP_WARM", "SA_GROUP_MIN", "SA_GROUP_LOOSE", "SA_GROUP_SIDE", "SA_SPARSE", "SA_GRP_VARIANT")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--docs", type=int, default=10_000_000)
+    ap.add_argument("--vocab", type=int, default=100_000)
+    ap.add_argument("--corpus-cache", default="")
+    ap.add_argument("--ks", default="10")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--libs", default="searcharray_amd/libsearcharray_hip.so")
+    ap.add_argument("--envs", default="SA_SPARSE=0", help="';'-separated configurations of ','-separated NAME=VALUE")
+    ap.add_argument("--qsets", default="baseline")
+    ap.add_argument("--queries", type=int, default=256)
+    args = ap.parse_args()
+    D, V = args.docs, args.vocab
+    cpath = os.path.join(args.corpus_cache, f"zipf_{D}_{V}_0_{D}.npz") if args.corpus_cache else ""
+    if cpath and os.path.exists(cpath):
+        z = np.load(cpath)
+        corpus = synth.EncodedCorpus(z["words"], z["term_off"], z["doc_lens"], D, V, 0)
+    else:
+        corpus = synth.zipf_corpus(D, vocab=V, workers=8)
+        if cpath:
+            os.makedirs(args.corpus_cache, exist_ok=True)
+            np.savez(cpath, words=corpus.words, term_off=corpus.term_off, doc_lens=corpus.doc_lens)
+    B = args.queries
+    qsets = {"baseline": synth.bm25_queries(B, vocab=V), "distinct": synth.bm25_queries_distinct(B, vocab=V) if 4 * B <= V else None}
+    qsets = {k_: v for k_, v in qsets.items() if k_ in args.qsets.split(",") and v is not None}
+    envs = [dict(kv.split("=") for kv in cfg.split(",") if kv) for cfg in args.envs.split(";")]
+    ref = {}
+    for lib in args.libs.split(","):
+        path = lib if os.path.isabs(lib) else os.path.join(ROOT, lib)
+        api = _lib.bind(ctypes.CDLL(path), path)
+        index = DeviceIndex(corpus.words, corpus.term_off, corpus.doc_lens, tile_docs=args.tile, api=api)
+        df = index.docfreqs()
+        for qname, queries in qsets.items():
+            idf = np.asarray([[compute_idf(D, np.asarray([df[t]])) for t in q] for q in queries], dtype=np.float32)
+            for k in [int(x) for x in args.ks.split(",")]:
+                for cfg in envs:
+                    for key in KEYS:
+                        os.environ.pop(key, None)
+                    os.environ["SA_SPARSE"] = "0"
+                    os.environ.update(cfg)
+                    batch = QueryBatch(index, queries, k=k, idf=idf)
+                    for _ in range(3):
+                        batch.run(sync=False)
+                    index.synchronize()
+                    batch.profile()
+                    t0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        batch.run(sync=False)
+                    index.synchronize()
+                    dt = (time.perf_counter() - t0) / args.steps
+                    kms, _, _ = batch.profile()
+                    res = batch.fetch()
+                    r0 = ref.setdefault((qname, k), res)
+                    same = bool(np.array_equal(r0[0], res[0]) and np.array_equal(r0[1], res[1]))
+                    print(json.dumps({"lib": os.path.basename(lib), "queries": qname, "k": k, "docs": D, **cfg,
+                                      "ms_per_step": round(dt * 1e3, 4), "kernel_ms": round(kms, 4), "same_results": same}), flush=True)
+                    batch.close()
+        index.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -785,7 +785,7 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles_list(const Bm25Params
 // requested before the current one is processed (fixed number of loads per query, so the compiler can
 // count them and wait for the current query's data only).
 // ---------------------------------------------------------------------------------------------
-#define SA_GRP_NH 12        // 64-posting halves of a query's further terms held in registers (768 postings per tile and query)
+#define SA_GRP_NH 10        // 64-posting halves of a query's further terms held in registers (640 postings per tile and query)
 #define SA_GRP_MAXQ 16      // queries per group item (bigger groups are cut into balanced pieces)
 
 struct GroupParams {
@@ -798,8 +798,17 @@ struct GroupParams {
 };
 
 // One HALF = up to 64 postings of ONE term of one query in this tile, one per lane (8-byte loads): every LDS
-// instruction of the overlay touches the postings of a single term, i.e. pairwise distinct docs.
-struct alignas(16) SaGrpHalf { u64 addr; float idf; u32 cnt; };
+// instruction of the overlay touches the postings of a single term, i.e. pairwise distinct docs.  Its descriptor is
+// ONE 8-byte LDS cell:
+//   [47:0]  address of the half's first posting (impact stream)      [54:48] postings (0 .. 64)
+//   [59:55] which of the query's overlaid terms (its weight sits in the item's idf table at [query][term])
+//   [63:60] entry 0 of a query only: its number of halves (15: more than the table holds -> per-query kernel)
+// (round 2 kept 16-byte entries with the weight inside: 3 KiB of table; with 8-byte entries, a 256 / 512-byte weight
+//  table and a 32-entry survivor buffer an item needs 10 KiB of LDS -- 16 waves per CU instead of 12.)
+#define SA_GRPH_CNT_SHIFT 48
+#define SA_GRPH_TERM_SHIFT 55
+#define SA_GRPH_NH_SHIFT 60
+#define SA_GRPH_OVER 15u
 
 // f(0), f(STEP), f(2 STEP), ... while the index is below n (< NH): nested tests, so the chain is left at the first
 // index that is not, and every index is a compile-time constant (arrays indexed by it stay in registers)
@@ -817,17 +826,20 @@ __device__ __forceinline__ void sa_static_while_below(u32 n, F&& f) {
 #define SA_WAIT_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)
 
 #define SA_GRP_REFRESH_STEP 32
-#define SA_GRP_SURV_CAP 128         // survivors an item buffers before it writes them out (a pair has at most 16)
+#define SA_GRP_SURV_CAP 32          // survivors an item buffers before it writes them out (a pair has at most 16)
 #define SA_GRP_LOOSE_POSTINGS 128   // loose groups: expected postings of a query per tile, all terms together (measured on the
                                     // distinct-terms batch, 10 M docs: 64 / 96 / 128 / 192 / 256 / 384 / 512 -> 0.82 / 0.74 / 0.74 / 0.73 / 0.75 / 0.80 / 0.81 ms
                                     // at k = 10, 128 best at k = 1000: above it the overlay loses to the per-query kernel's dense tile)
 
-template <int TILE>
-__global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, const GroupParams gp) {
+// IDFN: cells of the item's weight table = queries x lanes-per-query of the table build (64: up to 4 overlaid terms per
+// query -- the BASELINE shape --, 128: anything else the host admits, n * tt <= 128)
+template <int TILE, int IDFN>
+__global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params p, const GroupParams gp) {
     constexpr int NH = SA_GRP_NH;
+    static_assert(NH < (int)SA_GRPH_OVER, "half count field");
     __shared__ alignas(16) u64 smem[sa_tile_smem_u64<TILE, 1>()];
-    __shared__ alignas(16) SaGrpHalf s_half[SA_GRP_MAXQ][NH];
-    __shared__ u32 s_nh[SA_GRP_MAXQ];
+    __shared__ u64 s_half[SA_GRP_MAXQ][NH];
+    __shared__ float s_idf[IDFN];
     __shared__ u64 s_surv[SA_GRP_SURV_CAP];                     // survivors waiting for their places: score bits << 32 | accumulator offset << 4 | query
     u32* const accu = (u32*)smem;
     const u32 lane = threadIdx.x;
@@ -850,6 +862,7 @@ __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, 
     const u32 spare = ((u32)TILE + lane) * 4u;                  // byte offset of this lane's spare slot
     const u64* const stream = p.imp;
     auto at = [&](u32 byte_off) -> u32& { return *(u32*)((char*)accu + byte_off); };
+    auto ballot = [](bool c) -> u64 { return (u64)__builtin_amdgcn_ballot_w64(c); };
 
     // ---- the shared first term
     const u32 qt0 = row0 * T;
@@ -885,22 +898,17 @@ __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, 
         const u32 excl = incl - halves;
         const u32 total = (u32)__shfl((int)incl, (int)(lane | (TT - 1u)), SA_WAVE);
         if (qi < n) {
+            s_idf[qi * TT + tl] = x.idf;
             const u64 first = (u64)(stream + x.base + x.r0);
+            const u64 nhf = (u64)(total <= (u32)NH ? total : SA_GRPH_OVER) << SA_GRPH_NH_SHIFT;
             for (u32 j = 0; j < halves && excl + j < (u32)NH; j++) {
-                SaGrpHalf d;
-                d.addr = first + (u64)j * 512ull;
-                d.idf = x.idf;
-                d.cnt = (np - j * 64u < 64u ? np - j * 64u : 64u) | (excl + j == 0u ? total << 8 : 0u);
-                s_half[qi][excl + j] = d;
+                const u32 cnt = np - j * 64u < 64u ? np - j * 64u : 64u;
+                s_half[qi][excl + j] = (first + (u64)j * 512ull) | ((u64)cnt << SA_GRPH_CNT_SHIFT) | ((u64)tl << SA_GRPH_TERM_SHIFT) |
+                                       (excl + j == 0u ? nhf : 0ull);
             }
-            if (tl == 0u) {
-                s_nh[qi] = total;
-                if (total == 0u || ((total & 1u) && total < (u32)NH)) {   // halves are taken two at a time: an odd count gets an empty partner
-                    SaGrpHalf d;
-                    d.addr = (u64)stream; d.idf = 0.f; d.cnt = 0u;          // (entry 0 of a query without postings: 0 halves)
-                    s_half[qi][total] = d;
-                }
-            }
+            // halves are taken two at a time: an odd count gets an empty partner; a query without postings an entry 0
+            // that says "0 halves"
+            if (tl == 0u && (total == 0u || ((total & 1u) && total < (u32)NH))) s_half[qi][total] = (u64)stream;
         }
     };
     const u32 NP = (n + QPP - 1u) / QPP;                        // 1 or 2 passes (host: n * TT <= 128)
@@ -917,26 +925,28 @@ __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, 
     __builtin_amdgcn_wave_barrier();
     {
         // nothing to score in this tile at all?
-        const u32 mine = lane < n ? s_nh[lane] : 0u;
-        if (h1 == h0 && __ballot(mine != 0u) == 0ull) return;
+        const u32 mine = lane < n ? (u32)(s_half[lane][0] >> SA_GRPH_NH_SHIFT) : 0u;
+        if (h1 == h0 && ballot(mine != 0u) == 0ull) return;
     }
 
     // The half descriptors of a query reach the scalar registers with ONE LDS instruction: lane h reads entry h
-    // (16 bytes) and v_readlane hands the fields out -- no LDS round trip per half.  Entry 0 carries the
-    // query's number of halves in bits 8.. of its count field.
-    struct Q { u64 v[NH]; u32 dlo, dhi, dcnt; float didf; };
+    // (8 bytes) and v_readlane hands the fields out -- no LDS round trip per half; a second one brings the query's
+    // weights (lane t: term t).
+    struct Q { u64 v[NH]; u32 dlo, dhi; float w; };
     typedef const __attribute__((address_space(1))) u64* gptr_u64;
     // request the postings of query qi's halves (dynamic number of loads: the caller has made sure that no
     // older load is outstanding, so "everything landed" is an exact wait for them later) and its bound
     auto prefetch = [&](u32 qi, Q& X) {
-        const SaGrpHalf d = s_half[qi][lane < (u32)NH ? lane : 0u];
-        X.dlo = (u32)d.addr; X.dhi = (u32)(d.addr >> 32); X.dcnt = d.cnt; X.didf = d.idf;
-        const u32 nh_raw = (u32)__builtin_amdgcn_readfirstlane((int)d.cnt) >> 8;
+        const u64 d = s_half[qi][lane < (u32)NH ? lane : 0u];
+        X.w = s_idf[qi * TT + (lane & (TT - 1u))];
+        X.dlo = (u32)d; X.dhi = (u32)(d >> 32);
+        const u32 nh_raw = (u32)__builtin_amdgcn_readfirstlane((int)X.dhi) >> (SA_GRPH_NH_SHIFT - 32);
         const u32 nh = nh_raw <= (u32)NH ? nh_raw : 0u;         // (too many: the pair goes to the per-query kernel)
         sa_static_while_below<0, NH, 1>(nh, [&](auto hc) {       // (a query has ~4 halves on average)
             constexpr int h = decltype(hc)::value;
-            const u64 a = (u64)(u32)__builtin_amdgcn_readlane((int)X.dlo, h) | ((u64)(u32)__builtin_amdgcn_readlane((int)X.dhi, h) << 32);
-            const u32 cnt = (u32)__builtin_amdgcn_readlane((int)X.dcnt, h) & 0xFFu;
+            const u32 hi = (u32)__builtin_amdgcn_readlane((int)X.dhi, h);
+            const u64 a = (u64)(u32)__builtin_amdgcn_readlane((int)X.dlo, h) | ((u64)(hi & 0xFFFFu) << 32);
+            const u32 cnt = (hi >> (SA_GRPH_CNT_SHIFT - 32)) & 0x7Fu;
             const u32 j = lane < cnt ? lane : cnt - 1u;         // lanes past the end re-read the last posting (masked when scored)
             X.v[h] = ((gptr_u64)a)[j];
         });
@@ -1024,7 +1034,7 @@ __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, 
             }
         }
         const bool crossed = my_surv != 0u && cbase / (u32)SA_GRP_REFRESH_STEP != (cbase + my_surv) / (u32)SA_GRP_REFRESH_STEP;
-        for (u64 m = __ballot(crossed); m; m &= m - 1ull) {
+        for (u64 m = ballot(crossed); m; m &= m - 1ull) {
             const u32 q = row0 + (u32)__builtin_ctzll(m);
             sa_hist_refresh(p.hist + (u64)q * SA_HBINS, &p.gthr[q], p.k, lane);
         }
@@ -1032,7 +1042,7 @@ __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, 
         nsurv = 0; my_surv = 0;
     };
     auto process = [&](u32 qi, const Q& X) {
-        const u32 nh = (u32)__builtin_amdgcn_readfirstlane((int)X.dcnt) >> 8;
+        const u32 nh = (u32)__builtin_amdgcn_readfirstlane((int)X.dhi) >> (SA_GRPH_NH_SHIFT - 32);
         const u32 thr_q = (u32)__builtin_amdgcn_readlane((int)thr_all, (int)qi);
         const u32 thr = thr_q > 1u ? thr_q : 1u;
         if (nh > (u32)NH || base_max >= thr) { deferred |= 1ull << qi; return; }
@@ -1045,8 +1055,10 @@ __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, 
 #pragma unroll
                 for (int h = h2; h < h2 + 2; h++) {
                     __builtin_amdgcn_wave_barrier();            // a half sees the previous half's (other lanes') writes
-                    const u32 cnt = (u32)__builtin_amdgcn_readlane((int)X.dcnt, h) & 0xFFu;
-                    const float w = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(X.didf), h));
+                    const u32 hi = (u32)__builtin_amdgcn_readlane((int)X.dhi, h);
+                    const u32 cnt = (hi >> (SA_GRPH_CNT_SHIFT - 32)) & 0x7Fu;
+                    const u32 tl = (hi >> (SA_GRPH_TERM_SHIFT - 32)) & 0x1Fu;
+                    const float w = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(X.w), (int)tl));
                     const bool valid = lane < cnt;
                     const u64 v = X.v[h];
                     const u32 sl = valid ? (u32)(v >> 32) - tile_base_b : spare;
@@ -1061,9 +1073,6 @@ __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, 
         // final scores of the touched docs; base values back
         __builtin_amdgcn_wave_barrier();
         u64 anyk = 0ull;
-        u64 kb[NH];                                             // per half: the lanes whose doc reaches the bound (scalar registers)
-#pragma unroll
-        for (int h = 0; h < NH; h++) kb[h] = 0ull;
         sa_static_while_below<0, NH, 2>(nh, [&](auto hc) {
             constexpr int h2 = decltype(hc)::value;
 #pragma unroll
@@ -1072,15 +1081,20 @@ __global__ void __launch_bounds__(64) sa_k_bm25_group_tiles(const Bm25Params p, 
                 const u32 fin = at(sl) & 0x7FFFFFFFu;
                 at(sl) = ro[h];
                 ro[h] = fin;
-                kb[h] = __ballot(sl != spare && fin >= thr);
-                anyk |= kb[h];
+                anyk |= ballot(sl != spare && fin >= thr);
             }
         });
         __builtin_amdgcn_wave_barrier();
         if (anyk == 0ull) return;                               // the usual case once the bound stands
+        // (rare from here on: the per-half masks of the lanes whose doc reaches the bound are formed again from the
+        //  values kept in registers -- holding them across the common path cost 2 NH scalar registers and spills)
+        u64 kb[NH];
         u32 c = 0;
 #pragma unroll
-        for (int i = 0; i < NH; i++) c += (u32)__popcll(kb[i]);
+        for (int i = 0; i < NH; i++) {
+            kb[i] = (u32)i < nh ? ballot(rs[i] != spare && ro[i] >= thr) : 0ull;
+            c += (u32)__popcll(kb[i]);
+        }
         if (c > 16u) { deferred |= 1ull << qi; return; }        // bound still far off: the per-query item's histogram path refines it first
         // Survivors are buffered in LDS and written out together (flush below): reserving places in a query's
         // candidate list is an atomic WITH a return value -- a round trip to L2 the wave sits out; per surviving pair
@@ -1414,23 +1428,25 @@ static int sa_launch_bm25_groups(sa_index* ix, const sa_batch* bt, const Bm25Par
     gp.wl = bt->d_wl; gp.wl_cnt = bt->d_wl_cnt;
     const u64 worst = (u64)gp.n_tiles_run * bt->n_grouped_rows;
     const u32 wgrid = worst < 2048 ? (u32)worst : 2048u;
+    // (weight table: n * tt cells; 64 cover up to 4 overlaid terms per query at 16 queries per item)
+    const bool small = (u32)SA_GRP_MAXQ * gp.tt <= 64u;
+#define SA_LAUNCH_GROUP(TILE, THREADS)                                                                                     \
+    {                                                                                                                      \
+        if (small) hipLaunchKernelGGL((sa_k_bm25_group_tiles<TILE, 64>), dim3((u32)blocks), dim3(64), 0, st, p, gp);       \
+        else hipLaunchKernelGGL((sa_k_bm25_group_tiles<TILE, 128>), dim3((u32)blocks), dim3(64), 0, st, p, gp);            \
+        hipLaunchKernelGGL((sa_k_bm25_tiles_wl<TILE, THREADS>), dim3(wgrid), dim3(THREADS), 0, st, p, (const u64*)gp.wl,   \
+                           (const u32*)gp.wl_cnt);                                                                         \
+    }                                                                                                                      \
+    break
     switch (ix->tile_docs) {
-        case 1024:
-            hipLaunchKernelGGL((sa_k_bm25_group_tiles<1024>), dim3((u32)blocks), dim3(64), 0, st, p, gp);
-            hipLaunchKernelGGL((sa_k_bm25_tiles_wl<1024, 128>), dim3(wgrid), dim3(128), 0, st, p, (const u64*)gp.wl, (const u32*)gp.wl_cnt);
-            break;
-        case 2048:
-            hipLaunchKernelGGL((sa_k_bm25_group_tiles<2048>), dim3((u32)blocks), dim3(64), 0, st, p, gp);
-            hipLaunchKernelGGL((sa_k_bm25_tiles_wl<2048, 64>), dim3(wgrid), dim3(64), 0, st, p, (const u64*)gp.wl, (const u32*)gp.wl_cnt);
-            break;
-        case 4096:
-            hipLaunchKernelGGL((sa_k_bm25_group_tiles<4096>), dim3((u32)blocks), dim3(64), 0, st, p, gp);
-            hipLaunchKernelGGL((sa_k_bm25_tiles_wl<4096, 128>), dim3(wgrid), dim3(128), 0, st, p, (const u64*)gp.wl, (const u32*)gp.wl_cnt);
-            break;
+        case 1024: SA_LAUNCH_GROUP(1024, 128);
+        case 2048: SA_LAUNCH_GROUP(2048, 64);
+        case 4096: SA_LAUNCH_GROUP(4096, 128);
         default:
             sa_set_error("unsupported tile_docs %u for the grouped kernel", ix->tile_docs);
             return SA_ERR_STATE;
     }
+#undef SA_LAUNCH_GROUP
     return SA_OK;
 }
 

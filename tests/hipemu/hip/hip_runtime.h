@@ -279,6 +279,7 @@ template <class T> inline T __shfl_up(T v, unsigned d, int width = 64) {
 inline unsigned long long __ballot(int pred) {
     return hipemu::wave_collective(hipemu::OP_BALLOT, pred ? 1 : 0, 0);
 }
+inline unsigned long long __builtin_amdgcn_ballot_w64(bool pred) { return __ballot(pred ? 1 : 0); }
 inline int __any(int pred) { return __ballot(pred) != 0; }
 inline int __all(int pred) {
     // all participating lanes true <=> no participating lane false
