@@ -48,6 +48,7 @@ struct Bm25Params {
     const u64* qbase;      // [B][T] posting base of each query term
     const u64* imp;        // impact stream (sa_impacts, sa_index.hpp) or null: score the TF postings
     const u64* qbase_imp;  // [B][T][2] impact stream: first cell of each query term, first cell of the sentinel pair behind it
+    u64 imp_tail;          // a cell of the impact stream that is a sentinel whatever happens (its last pair)
     u32 B, T, k;
     u32 tile0, tile_end;   // tiles [tile0, tile_end) of this launch (sa_k_bm25_tiles)
     float k1, b, avgdl;
@@ -162,6 +163,10 @@ static std::shared_ptr<sa_impacts> sa_impacts_get(sa_index* ix, float k1, float 
     hipLaunchKernelGGL(sa_k_make_impacts, dim3(grid), dim3(256), 0, st, ix->d_tfp, ix->d_tf_off, ix->d_doc_lens,
                        ix->n_terms, ix->n_postings, ix->dl_packed ? 1 : 0, k1, b, ix->avg_doc_len, im->d_imp);
     if (hipGetLastError() != hipSuccess) return nullptr;
+    // the stream's last pair: a sentinel with the factor 0.0 (doc field all ones like every sentinel) -- what the grouped
+    // kernel's empty half entries point at: their lanes add 0 to their spare slots instead of a NaN
+    static const u64 tail[2] = {0xFFFFFFFF00000000ull, 0xFFFFFFFF00000000ull};
+    if (hipMemcpyAsync(im->d_imp + im->n - 2, tail, sizeof(tail), hipMemcpyHostToDevice, st) != hipSuccess) return nullptr;
     ix->impacts = im;
     return im;
 }
@@ -800,13 +805,17 @@ struct GroupParams {
 // One HALF = up to 64 postings of ONE term of one query in this tile, one per lane (8-byte loads): every LDS
 // instruction of the overlay touches the postings of a single term, i.e. pairwise distinct docs.  Its descriptor is
 // ONE 8-byte LDS cell:
-//   [47:0]  address of the half's first posting (impact stream)      [54:48] postings (0 .. 64)
-//   [59:55] which of the query's overlaid terms (its weight sits in the item's idf table at [query][term])
+//   [47:0]  address of the half's first posting (impact stream)
+//   [53:48] lim: the half's last posting; lane L loads posting min(L, lim).  The lanes past the half's postings so
+//           hold COPIES of its last posting, and copies are harmless in a read-modify-write of one LDS instruction:
+//           all of them read the same value, write the same value and later put the same value back -- the overlay
+//           needs no per-lane validity test (the rare evaluation below does: a doc must be reported once)
+//   [58:54] which of the query's overlaid terms (its weight sits in the item's weight table at [query][term])
 //   [63:60] entry 0 of a query only: its number of halves (15: more than the table holds -> per-query kernel)
 // (round 2 kept 16-byte entries with the weight inside: 3 KiB of table; with 8-byte entries, a 256 / 512-byte weight
 //  table and a 32-entry survivor buffer an item needs 10 KiB of LDS -- 16 waves per CU instead of 12.)
-#define SA_GRPH_CNT_SHIFT 48
-#define SA_GRPH_TERM_SHIFT 55
+#define SA_GRPH_LIM_SHIFT 48
+#define SA_GRPH_TERM_SHIFT 54
 #define SA_GRPH_NH_SHIFT 60
 #define SA_GRPH_OVER 15u
 
@@ -836,7 +845,7 @@ __device__ __forceinline__ void sa_static_while_below(u32 n, F&& f) {
 template <int TILE, int IDFN>
 __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params p, const GroupParams gp) {
     constexpr int NH = SA_GRP_NH;
-    static_assert(NH < (int)SA_GRPH_OVER, "half count field");
+    static_assert(NH < (int)SA_GRPH_OVER && NH % 2 == 0, "half count field; halves are taken in pairs");
     __shared__ alignas(16) u64 smem[sa_tile_smem_u64<TILE, 1>()];
     __shared__ u64 s_half[SA_GRP_MAXQ][NH];
     __shared__ float s_idf[IDFN];
@@ -874,14 +883,15 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
     // ---- half tables of the queries' further terms: lane (qi, t) looks up term t's slice of query qi in this
     //      tile and writes one entry per 64 postings, in query-term order
     const u32 TT = gp.tt, tsh = gp.tt_shift, QPP = 64u >> tsh;
-    struct Pre { u32 r0, r1; u64 base; float idf; };
+    struct Pre { u32 r0, r1; u64 base, send; float idf; };
     auto pre_load = [&](u32 ps) -> Pre {
-        Pre x; x.r0 = 0; x.r1 = 0; x.base = 0; x.idf = 0.f;
+        Pre x; x.r0 = 0; x.r1 = 0; x.base = 0; x.send = 0; x.idf = 0.f;
         const u32 qi = ps * QPP + (lane >> tsh), t = (loose ? 0u : 1u) + (lane & (TT - 1u));
         if (qi < n && t < T) {
             const u32 qt = (row0 + qi) * T + t;
             const u32* row = p.bounds + (u64)qt * (p.n_tiles + 1) + tile;
-            x.base = p.qbase_imp[2 * (u64)qt];
+            const sa_u64x2 bs = ((const sa_u64x2*)p.qbase_imp)[qt];
+            x.base = bs.x; x.send = bs.y;
             x.r0 = row[0]; x.r1 = row[1]; x.idf = p.idf[qt];
         }
         return x;
@@ -899,16 +909,17 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
         const u32 total = (u32)__shfl((int)incl, (int)(lane | (TT - 1u)), SA_WAVE);
         if (qi < n) {
             s_idf[qi * TT + tl] = x.idf;
-            const u64 first = (u64)(stream + x.base + x.r0);
+            const u64 c0 = x.base + x.r0;                       // first cell of the slice
             const u64 nhf = (u64)(total <= (u32)NH ? total : SA_GRPH_OVER) << SA_GRPH_NH_SHIFT;
             for (u32 j = 0; j < halves && excl + j < (u32)NH; j++) {
-                const u32 cnt = np - j * 64u < 64u ? np - j * 64u : 64u;
-                s_half[qi][excl + j] = (first + (u64)j * 512ull) | ((u64)cnt << SA_GRPH_CNT_SHIFT) | ((u64)tl << SA_GRPH_TERM_SHIFT) |
+                const u64 c = c0 + (u64)j * 64ull;
+                const u64 lim = (np - j * 64u < 64u ? np - j * 64u : 64u) - 1u;     // last posting of the half
+                s_half[qi][excl + j] = (u64)(stream + c) | (lim << SA_GRPH_LIM_SHIFT) | ((u64)tl << SA_GRPH_TERM_SHIFT) |
                                        (excl + j == 0u ? nhf : 0ull);
             }
-            // halves are taken two at a time: an odd count gets an empty partner; a query without postings an entry 0
-            // that says "0 halves"
-            if (tl == 0u && (total == 0u || ((total & 1u) && total < (u32)NH))) s_half[qi][total] = (u64)stream;
+            // halves are taken two at a time: an odd count gets an empty partner (every lane reads one sentinel cell with
+            // the factor 0.0 and adds it to its spare slot); a query without postings an entry 0 that says "0 halves"
+            if (tl == 0u && (total == 0u || ((total & 1u) && total < (u32)NH))) s_half[qi][total] = (u64)(stream + p.imp_tail);
         }
     };
     const u32 NP = (n + QPP - 1u) / QPP;                        // 1 or 2 passes (host: n * TT <= 128)
@@ -941,14 +952,15 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
         X.w = s_idf[qi * TT + (lane & (TT - 1u))];
         X.dlo = (u32)d; X.dhi = (u32)(d >> 32);
         const u32 nh_raw = (u32)__builtin_amdgcn_readfirstlane((int)X.dhi) >> (SA_GRPH_NH_SHIFT - 32);
-        const u32 nh = nh_raw <= (u32)NH ? nh_raw : 0u;         // (too many: the pair goes to the per-query kernel)
+        // (too many: the pair goes to the per-query kernel; an odd count: the empty partner entry is loaded too --
+        //  nothing masks a half's lanes, its postings must be the sentinel's)
+        const u32 nh = nh_raw <= (u32)NH ? (nh_raw + 1u) & ~1u : 0u;
         sa_static_while_below<0, NH, 1>(nh, [&](auto hc) {       // (a query has ~4 halves on average)
             constexpr int h = decltype(hc)::value;
             const u32 hi = (u32)__builtin_amdgcn_readlane((int)X.dhi, h);
             const u64 a = (u64)(u32)__builtin_amdgcn_readlane((int)X.dlo, h) | ((u64)(hi & 0xFFFFu) << 32);
-            const u32 cnt = (hi >> (SA_GRPH_CNT_SHIFT - 32)) & 0x7Fu;
-            const u32 j = lane < cnt ? lane : cnt - 1u;         // lanes past the end re-read the last posting (masked when scored)
-            X.v[h] = ((gptr_u64)a)[j];
+            const u32 lim = (hi >> (SA_GRPH_LIM_SHIFT - 32)) & 0x3Fu;
+            X.v[h] = ((gptr_u64)a)[lane < lim ? lane : lim];     // lanes past the end: copies of the last posting
         });
     };
     // the queries' bounds, one per lane, read once per item (a bound only ever rises: a stale one is valid)
@@ -998,6 +1010,8 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
             }
         }
         __builtin_amdgcn_wave_barrier();
+        at(spare) = 0u;                                         // (took the base's out-of-tile postings; the overlay's spare values start at 0)
+        __builtin_amdgcn_wave_barrier();
         base_max = sa_wave_max_u32(lmax);
     }
 
@@ -1041,60 +1055,73 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
         __builtin_amdgcn_wave_barrier();
         nsurv = 0; my_surv = 0;
     };
+    // One query of the item.  Per half, IN QUERY-TERM ORDER: read the docs' accumulators, add, write back with the sign
+    // bit set ("touched by this query"; written as -(|o| + s), one instruction), remember what was read.  Nothing is
+    // decided per lane: a lane outside the half's postings holds a copy of its last posting (an empty partner half:
+    // the zero sentinel, which min(d, spare) sends to the lane's spare slot).  Then the base values go back -- every lane rewrites what it READ, the halves
+    // in REVERSE order, so that for a doc touched by several terms the value read first (the base) is written last:
+    // no lane needs to know whether it was the first to touch its doc.  The final scores are only looked at when the
+    // largest value any lane wrote reaches the query's bound (one compare per query instead of a read, a mask and
+    // two compares per half): then every doc's final value is read before the restore and the first touchers
+    // (sign bit of what they read) report the docs that reach the bound.
     auto process = [&](u32 qi, const Q& X) {
-        const u32 nh = (u32)__builtin_amdgcn_readfirstlane((int)X.dhi) >> (SA_GRPH_NH_SHIFT - 32);
+        const u32 nh_raw = (u32)__builtin_amdgcn_readfirstlane((int)X.dhi) >> (SA_GRPH_NH_SHIFT - 32);
         const u32 thr_q = (u32)__builtin_amdgcn_readlane((int)thr_all, (int)qi);
         const u32 thr = thr_q > 1u ? thr_q : 1u;
-        if (nh > (u32)NH || base_max >= thr) { deferred |= 1ull << qi; return; }
-        if (nh == 0u) return;                                   // the query scores exactly the base here: all below its bound
+        if (nh_raw > (u32)NH || base_max >= thr) { deferred |= 1ull << qi; return; }
+        if (nh_raw == 0u) return;                               // the query scores exactly the base here: all below its bound
+        const u32 nh = (nh_raw + 1u) & ~1u;                     // halves go two at a time (NH is even; the partner of an odd count is empty)
         u32 rs[NH], ro[NH];
-        // overlay: the query's further postings, in query-term order, in place
-        sa_static_while_below<0, NH, 2>(nh, [&](auto hc) {
-            constexpr int h2 = decltype(hc)::value;
-            {
-#pragma unroll
-                for (int h = h2; h < h2 + 2; h++) {
-                    __builtin_amdgcn_wave_barrier();            // a half sees the previous half's (other lanes') writes
-                    const u32 hi = (u32)__builtin_amdgcn_readlane((int)X.dhi, h);
-                    const u32 cnt = (hi >> (SA_GRPH_CNT_SHIFT - 32)) & 0x7Fu;
-                    const u32 tl = (hi >> (SA_GRPH_TERM_SHIFT - 32)) & 0x1Fu;
-                    const float w = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(X.w), (int)tl));
-                    const bool valid = lane < cnt;
-                    const u64 v = X.v[h];
-                    const u32 sl = valid ? (u32)(v >> 32) - tile_base_b : spare;
-                    const u32 o = at(sl);
-                    at(sl) = __float_as_uint(__fadd_rn(__uint_as_float(o & 0x7FFFFFFFu), __fmul_rn(__uint_as_float((u32)v), w))) | 0x80000000u;
-                    // the lane that found the doc untouched owns its evaluation and puts the base value back
-                    rs[h] = (valid && !(o >> 31)) ? sl : spare;
-                    ro[h] = o;
-                }
-            }
-        });
-        // final scores of the touched docs; base values back
-        __builtin_amdgcn_wave_barrier();
-        u64 anyk = 0ull;
+        u32 wmax = 0u;                                          // largest value written (sign bit set)
         sa_static_while_below<0, NH, 2>(nh, [&](auto hc) {
             constexpr int h2 = decltype(hc)::value;
 #pragma unroll
             for (int h = h2; h < h2 + 2; h++) {
-                const u32 sl = rs[h];
-                const u32 fin = at(sl) & 0x7FFFFFFFu;
-                at(sl) = ro[h];
-                ro[h] = fin;
-                anyk |= ballot(sl != spare && fin >= thr);
+                __builtin_amdgcn_wave_barrier();                // a half sees the previous half's (other lanes') writes
+                const u32 hi = (u32)__builtin_amdgcn_readlane((int)X.dhi, h);
+                const u32 tl = (hi >> (SA_GRPH_TERM_SHIFT - 32)) & 0x1Fu;
+                const float w = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(X.w), (int)tl));
+                const u64 v = X.v[h];
+                const u32 d = (u32)(v >> 32) - tile_base_b;
+                const u32 sl = d < spare ? d : spare;           // (a doc outside the tile: d >= TILE * 4)
+                const u32 o = at(sl);
+                __builtin_amdgcn_wave_barrier();                // (all lanes have read -- copies of a posting read the same value -- before any writes)
+                const u32 nw = __float_as_uint(__fsub_rn(-fabsf(__uint_as_float(o)), __fmul_rn(__uint_as_float((u32)v), w)));
+                at(sl) = nw;
+                wmax = nw > wmax ? nw : wmax;
+                rs[h] = sl;
+                ro[h] = o;
             }
         });
         __builtin_amdgcn_wave_barrier();
-        if (anyk == 0ull) return;                               // the usual case once the bound stands
-        // (rare from here on: the per-half masks of the lanes whose doc reaches the bound are formed again from the
-        //  values kept in registers -- holding them across the common path cost 2 NH scalar registers and spills)
+        const bool look = ballot(wmax >= (thr | 0x80000000u)) != 0ull;
+        u32 fin[NH];
+        if (look) {                                             // (rare once the bound stands)
+#pragma unroll
+            for (int h = 0; h < NH; h++) fin[h] = (u32)h < nh ? at(rs[h]) & 0x7FFFFFFFu : 0u;
+            __builtin_amdgcn_wave_barrier();
+        }
+        // base values back, last half first
+#pragma unroll
+        for (int h = NH - 1; h >= 0; h--) {
+            if ((u32)h < nh) {
+                at(rs[h]) = ro[h];
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (!look) return;
         u64 kb[NH];
         u32 c = 0;
 #pragma unroll
         for (int i = 0; i < NH; i++) {
-            kb[i] = (u32)i < nh ? ballot(rs[i] != spare && ro[i] >= thr) : 0ull;
+            kb[i] = 0ull;
+            if ((u32)i < nh) {
+                const u32 lim = ((u32)__builtin_amdgcn_readlane((int)X.dhi, i) >> (SA_GRPH_LIM_SHIFT - 32)) & 0x3Fu;
+                kb[i] = ballot(lane <= lim && rs[i] < (u32)TILE * 4u && !(ro[i] >> 31) && fin[i] >= thr);
+            }
             c += (u32)__popcll(kb[i]);
         }
+        if (c == 0u) return;
         if (c > 16u) { deferred |= 1ull << qi; return; }        // bound still far off: the per-query item's histogram path refines it first
         // Survivors are buffered in LDS and written out together (flush below): reserving places in a query's
         // candidate list is an atomic WITH a return value -- a round trip to L2 the wave sits out; per surviving pair
@@ -1105,7 +1132,7 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
 #pragma unroll
         for (int i = 0; i < NH; i++) {
             if (kb[i]) {                                        // (uniform: halves without survivors cost a scalar test)
-                if ((kb[i] >> lane) & 1ull) s_surv[nsurv + (u32)__popcll(kb[i] & lt)] = ((u64)ro[i] << 32) | (u64)(rs[i] << 4) | (u64)qi;
+                if ((kb[i] >> lane) & 1ull) s_surv[nsurv + (u32)__popcll(kb[i] & lt)] = ((u64)fin[i] << 32) | (u64)(rs[i] << 4) | (u64)qi;
                 nsurv += (u32)__popcll(kb[i]);
             }
         }
@@ -2010,6 +2037,7 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     p.bounds = bt->d_bounds; p.qbase = bt->d_qbase;
     if (bt->impacts && bt->kind == 0 && sa_env_int("SA_IMPACT", 1) != 0) {
         p.imp = bt->impacts->d_imp; p.qbase_imp = bt->d_qbase_imp;
+        p.imp_tail = bt->impacts->n - 2;
     }
     p.sattab = bt->d_sattab; p.tab_w = bt->tab_w;
     p.pruned = (sa_env_int("SA_PRUNED_TOPK", 1) && !force_unpruned) ? 1 : 0;   // pruned wave-level selection (any k <= 1024)
