@@ -845,7 +845,7 @@ __device__ __forceinline__ void sa_static_while_below(u32 n, F&& f) {
 template <int TILE, int IDFN>
 __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params p, const GroupParams gp) {
     constexpr int NH = SA_GRP_NH;
-    static_assert(NH < (int)SA_GRPH_OVER && NH % 2 == 0, "half count field; halves are taken in pairs");
+    static_assert(NH < (int)SA_GRPH_OVER && NH % 2 == 0 && NH >= 8, "half count field; halves are taken in pairs");
     __shared__ alignas(16) u64 smem[sa_tile_smem_u64<TILE, 1>()];
     __shared__ u64 s_half[SA_GRP_MAXQ][NH];
     __shared__ float s_idf[IDFN];
@@ -949,8 +949,8 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
     // older load is outstanding, so "everything landed" is an exact wait for them later) and its bound
     auto prefetch = [&](u32 qi, Q& X) {
         const u64 d = s_half[qi][lane < (u32)NH ? lane : 0u];
-        X.w = s_idf[qi * TT + (lane & (TT - 1u))];
         X.dlo = (u32)d; X.dhi = (u32)(d >> 32);
+        X.w = s_idf[qi * TT + ((X.dhi >> (SA_GRPH_TERM_SHIFT - 32)) & 0x1Fu)];     // lane h: the weight of half h's term
         const u32 nh_raw = (u32)__builtin_amdgcn_readfirstlane((int)X.dhi) >> (SA_GRPH_NH_SHIFT - 32);
         // (too many: the pair goes to the per-query kernel; an odd count: the empty partner entry is loaded too --
         //  nothing masks a half's lanes, its postings must be the sentinel's)
@@ -1078,9 +1078,7 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
 #pragma unroll
             for (int h = h2; h < h2 + 2; h++) {
                 __builtin_amdgcn_wave_barrier();                // a half sees the previous half's (other lanes') writes
-                const u32 hi = (u32)__builtin_amdgcn_readlane((int)X.dhi, h);
-                const u32 tl = (hi >> (SA_GRPH_TERM_SHIFT - 32)) & 0x1Fu;
-                const float w = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(X.w), (int)tl));
+                const float w = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(X.w), h));
                 const u64 v = X.v[h];
                 const u32 d = (u32)(v >> 32) - tile_base_b;
                 const u32 sl = d < spare ? d : spare;           // (a doc outside the tile: d >= TILE * 4)
@@ -1101,13 +1099,27 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
             for (int h = 0; h < NH; h++) fin[h] = (u32)h < nh ? at(rs[h]) & 0x7FFFFFFFu : 0u;
             __builtin_amdgcn_wave_barrier();
         }
-        // base values back, last half first
-#pragma unroll
-        for (int h = NH - 1; h >= 0; h--) {
-            if ((u32)h < nh) {
-                at(rs[h]) = ro[h];
-                __builtin_amdgcn_wave_barrier();
-            }
+        // base values back, last half first (nh is even, 2 .. NH: one jump, then straight-line stores)
+        auto back = [&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            at(rs[h + 1]) = ro[h + 1];
+            __builtin_amdgcn_wave_barrier();
+            at(rs[h]) = ro[h];
+            __builtin_amdgcn_wave_barrier();
+        };
+        static_assert(NH <= 12, "restore switch");
+        switch (nh) {
+            case 12: if constexpr (NH >= 12) back(std::integral_constant<int, NH >= 12 ? 10 : 0>{});
+            [[fallthrough]];
+            case 10: if constexpr (NH >= 10) back(std::integral_constant<int, NH >= 10 ? 8 : 0>{});
+            [[fallthrough]];
+            case 8: back(std::integral_constant<int, 6>{});
+            [[fallthrough]];
+            case 6: back(std::integral_constant<int, 4>{});
+            [[fallthrough]];
+            case 4: back(std::integral_constant<int, 2>{});
+            [[fallthrough]];
+            default: back(std::integral_constant<int, 0>{});
         }
         if (!look) return;
         u64 kb[NH];
