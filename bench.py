@@ -79,6 +79,7 @@ def parse_args():
                          "posting like the reference; the other mode is always reported beside it)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of each CPU baseline leg")
     ap.add_argument("--query-sets", type=int, default=8, help="seeded query sets the main leg rotates through")
+    ap.add_argument("--pipeline", type=int, default=6, help="batch objects (= batches in flight, one stream each) of the main leg")
     ap.add_argument("--no-phrase-legs", action="store_true", help="skip the zipf-1M phrase / slop legs")
     ap.add_argument("--phrase-docs", type=int, default=1_000_000)
     ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)      # internal: run under rocprofv3, print nothing
@@ -262,36 +263,41 @@ class Rank:
         self.barrier()
         return self.allmax(time.perf_counter() - t0)
 
-    def timed_fresh(self, pair, sets, n_warm, n_steps):
-        """The query stream: step i resets batch i & 1 to query set i mod len(sets) (idf computed here, on the host),
-        runs it and -- two steps later, before that batch object is reset again -- fetches its results.  n_warm untimed
-        steps, then n_steps bracketed by barrier + synchronize; max over ranks.  -> (seconds, {set: (scores, docs)})"""
-        pending = [None, None]
+    def timed_fresh(self, ring, sets, n_warm, n_steps):
+        """The query stream: step i resets batch object i mod P to query set i mod len(sets) (idf computed here, on the
+        host), runs it and -- P steps later, before that batch object is reset again -- fetches its results: P batches
+        are in flight, each on its own stream.  n_warm untimed steps, then n_steps bracketed by barrier + synchronize;
+        max over ranks.  -> (seconds, {set: (scores, docs)})"""
+        P = len(ring)
+        pending = [None] * P
         results = {}
 
         def drain(b):
             if pending[b] is not None:
-                results[pending[b]] = pair[b].fetch()
+                results[pending[b]] = ring[b].fetch()
                 pending[b] = None
 
         def step(i):
-            b = i & 1
+            b = i % P
             drain(b)
             si = i % len(sets)
-            pair[b].reset(sets[si], idf=self.idf_of(sets[si]))
-            pair[b].run(sync=False)
+            ring[b].reset(sets[si], idf=self.idf_of(sets[si]))
+            ring[b].run(sync=False)
             pending[b] = si
 
         for i in range(n_warm):
             step(i)
-        drain(0), drain(1)
+        for b in range(P):
+            drain(b)
         self.barrier()
-        pair[0].profile(), pair[1].profile()                  # reset the kernel-event rings
+        for b in ring:
+            b.profile()                                       # reset the kernel-event rings
         self.barrier()
         t0 = time.perf_counter()
         for i in range(n_steps):
             step(n_warm + i)
-        drain(0), drain(1)
+        for b in range(P):
+            drain(b)
         self.barrier()
         return self.allmax(time.perf_counter() - t0), results
 
@@ -799,15 +805,18 @@ def main():
     # results); it is timed right after on the resident set 0.  --pruned swaps the two.
     exhaustive = not args.pruned
     os.environ["SA_SPARSE"] = "0" if exhaustive else "1"
-    pair = [r.make_batch(sets[0]), r.make_batch(sets[1])]
-    dt, fresh_results = r.timed_fresh(pair, sets, max(W, 2), K)
-    prof = [b.profile() for b in pair]
-    kernel_ms = (prof[0][0] + prof[1][0]) / 2
+    P = max(1, args.pipeline)
+    pair = [r.make_batch(sets[i % len(sets)]) for i in range(P)]
+    dt, fresh_results = r.timed_fresh(pair, sets, max(W, P), K)
+    # (HIP events around one batch's scoring kernels: with P batches in flight on P streams they overlap the other
+    #  batches' kernels, so this is a batch's latency share, not the device time per step -- the replay leg's is)
+    kernel_ms_fresh = float(np.mean([b.profile()[0] for b in pair]))
     scores, docs = fresh_results[0] if 0 in fresh_results else (None, None)
 
     # replay of the resident set 0 (rounds 1-2 reported this as `value`)
     dt_r = r.timed(batch, max(W, 1), K)
     kernel_ms_r, alg_bytes, post_bytes = batch.profile()
+    kernel_ms = kernel_ms_r
     post_total = r.allsum(float(post_bytes))
     scores_r, docs_r = batch.fetch()
     if scores is None:                                   # (fewer timed + warm steps than sets: cannot happen with the defaults)
@@ -850,10 +859,11 @@ def main():
         n_tiles = int(r.info.n_tiles)
         exh_ms, prn_ms = (kernel_ms, kernel_ms2) if exhaustive else (kernel_ms2, kernel_ms)
         comp = compulsory_bytes(r.df if world == 1 else r.index.docfreqs(), queries, B, args.k)
-        exh_note = ("every posting of every query term scored (reference behaviour); kernel_ms = HIP events on the index "
-                    "stream around the scoring kernel(s) of a step, mean over the timed FRESH-batch steps (the slice-table "
-                    "kernel of the next batch's reset runs between two steps' scoring kernels and is outside the events); "
-                    "compulsory bytes / counter traffic are those of set 0 (all sets have the same shape); rank 0's shard")
+        exh_note = ("every posting of every query term scored (reference behaviour); kernel_ms = HIP events on the batch's "
+                    "stream around the scoring kernel(s) of a step, mean over the steps of the REPLAY leg (one batch alone on "
+                    "the device: in the fresh-batch leg the batches in flight overlap, so per-batch event times are latencies, "
+                    "reported as fresh_batch_latency_ms); compulsory bytes / counter traffic are those of set 0 (all sets "
+                    "have the same shape); rank 0's shard")
         prn_note = ("dynamic pruning: postings of non-essential terms are never read (by design traffic < compulsory_bytes of the "
                     "exhaustive leg is possible); byte model = the posting lists the routing keeps ESSENTIAL plus probes, so the "
                     "bound is gather latency / sector traffic, reported as traffic-based GB/s; results identical (same_results)")
@@ -880,11 +890,13 @@ def main():
                                    f"(k1=1.2 b=0.75; set 0 = the BASELINE set), host idf + sa_batch_reset + run + fetch per step, "
                                    f"top-{args.k}, {'exhaustive' if exhaustive else 'dynamic pruning'}",
                        "docs": D, "queries_per_step": B, "terms_per_query": 4, "k": args.k, "query_sets": len(sets),
+                       "batches_in_flight": P,
                        "distinct_terms_in_batch": int(len(np.unique(queries))),
                        "tile_docs": int(r.info.tile_docs), "parallelism": f"doc-range shards x{world}",
                        "collective": r.collective, "launcher": "torch-free: ranks rendezvous through an id file, "
                                                                "collectives = libsearcharray_hip.so's RCCL communicator"},
             "postings_scanned_GBps": round(post_total * K / dt / 1e9, 2),
+            "fresh_batch_latency_ms": round(kernel_ms_fresh, 4),
             "replay": {"value": round(B * K / dt_r, 2), "unit": "queries/s", "ms_per_step": round(dt_r / K * 1e3, 4),
                        "kernel_ms": round(kernel_ms_r, 4), "fresh_over_replay": round(dt_r / dt, 4),
                        "fresh_equals_replay": fresh_equals_replay,

@@ -14,6 +14,9 @@
 
 struct sa_batch {
     sa_index* ix = nullptr;
+    hipStream_t st = nullptr;       // the stream this batch's work is enqueued on: its own (BM25 batches), or the index stream
+    bool own_stream = false;
+    bool state_clean = false;       // per-run state (bound slots, cursors, histograms, work-list cursor) is zero: the last merge left it so
     u32 B = 0, T = 0, k = 0;
     float k1 = 1.2f, b = 0.75f;
     std::vector<u32> perm;          // device row r holds caller query perm[r] (results: caller order)
@@ -30,11 +33,11 @@ struct sa_batch {
     u32 up_n = 0;                   // resets so far (image = up_n & 1)
     // results to the host without a stream synchronisation: every run ends with an async copy of the B*k keys and
     // the overflow flag into a page-locked buffer on the exchange stream; sa_batch_fetch waits for ITS event only
-    u64* h_res = nullptr;           // [B*k + 1]
-    hipEvent_t ev_final = nullptr;  // d_final written (stream of the last merge)
+    u64* h_res = nullptr;           // [B*k + 2]: keys, this shard's overflow flag, the ranks' overflow flag
+    hipEvent_t ev_final = nullptr;  // d_final written (the stream of the last merge)
     hipEvent_t ev_res = nullptr;    // h_res written (exchange stream)
     bool res_pending = false;
-    u32* d_xflag = nullptr;         // sharded: OR over the ranks of the overflow flags (travels with the all-gather)
+    u32* d_xflag = nullptr;         // sharded: OR over the ranks of the overflow flags (travels with the all-gather); behind d_final
     u32 wl_cap = 0;                 // entries of d_wl
     size_t bloom_cap = 0;           // bytes of d_bloom (worst case of this shard, allocated by the first pruned run)
     u32* d_terms = nullptr;
@@ -74,7 +77,7 @@ struct sa_batch {
     u64 sparse_p1_total = 0, sparse_limit2 = 0, sparse_p2_max = 0;
     u32 sparse_chunk1 = SA_SP_CHUNK_LEAD;
     bool sparse_ok = false;         // tables built and the scoring formula admits the idf bound
-    u32* d_overflow = nullptr;      // set by the merge kernel when a candidate list ran over (checked at fetch)
+    u32* d_overflow = nullptr;      // set by the merge kernel when a candidate list ran over (checked at fetch); behind d_final
     u64* d_local = nullptr;         // [B][k] per-shard result
     u64* d_gather = nullptr;        // [2][nranks][B][k] (multi-GPU, double-buffered like d_xlocal)
     u64* d_xlocal = nullptr;        // [2][B][k] per-shard results handed to the exchange stream

@@ -761,10 +761,8 @@ extern "C" int sa_index_termfreqs_sparse(sa_index_t* ix, uint32_t term, uint64_t
 extern "C" int sa_index_synchronize(sa_index_t* ix) {
     SA_ARG(ix, "null index");
     SA_HIP(hipSetDevice(ix->device));
-    SA_HIP(hipStreamSynchronize(ix->stream));
-    if (ix->sstream) SA_HIP(hipStreamSynchronize(ix->sstream));
-    for (int i = 0; i < 3; i++) if (ix->lane_stream[i]) SA_HIP(hipStreamSynchronize(ix->lane_stream[i]));
-    if (ix->xstream) SA_HIP(hipStreamSynchronize(ix->xstream));
+    // (everything enqueued for this device: the index's streams and the streams of its batches)
+    SA_HIP(hipDeviceSynchronize());
     SA_HIP(hipGetLastError());
     return SA_OK;
 }

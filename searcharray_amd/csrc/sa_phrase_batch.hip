@@ -396,6 +396,7 @@ extern "C" int sa_phrase_batch_create_ex(sa_index_t* ix, const uint32_t* terms, 
     if (!bt) { sa_set_error("out of host memory"); return SA_ERR_NOMEM; }
     bt->ix = ix; bt->B = B; bt->T = T; bt->k = (u32)k; bt->k1 = k1; bt->b = b;
     bt->kind = 1;
+    bt->st = ix->stream;           // (the dense route swaps lanes in and out of the index: phrase batches stay on its stream)
     bt->ptile = SA_PTILE;
     if (const char* v = getenv("SA_PTILE")) { if (atoi(v) == 2048 || atoi(v) == 4096) bt->ptile = (u32)atoi(v); }
     bt->pn_tiles = (u32)((ix->n_docs + bt->ptile - 1) / bt->ptile);
