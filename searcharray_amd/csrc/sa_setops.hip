@@ -11,9 +11,11 @@
 // compaction (sa_scan.hpp), which yields the same index pairs: for a value present on both sides
 // the reference reports (first lhs index of the run, first rhs index of the run) in "drop" mode
 // and every member of both runs in "keep" mode.
-// One documented deviation: the reference's drop variants start with `last = all ones`
-// (intersect.pyx:40,147,223), so a match whose masked value equals the mask itself would be
-// skipped there; roaringish headers never take that value and the kernels do not reproduce it.
+// The reference's drop variants start with `last = all ones` (intersect.pyx:39,146,224-225) and report a match
+// only if `(last & mask) != (lhs & mask)`: a common value whose masked bits are ALL ones is dropped when it would be
+// the FIRST pair reported -- being the largest value it is then the only one, so the list comes out empty; after any
+// other match `last` has moved and it is reported like every value.  Reproduced (sa_pairs_drop, after the
+// compaction) and pinned by tests/test_setops.py against outputs of the reference itself.
 #include "sa_common.hpp"
 #include "sa_scan.hpp"
 #include "../../include/searcharray_hip.h"
@@ -101,6 +103,8 @@ static int sa_pairs_drop(const uint64_t* lhs, int64_t nl, const uint64_t* rhs, i
     SA_HIP(hipMemcpy(&g, d_total, 4, hipMemcpyDeviceToHost));
     SA_HIP(hipMemcpy(lhs_idx, d_lo, (size_t)g * 8, hipMemcpyDeviceToHost));
     SA_HIP(hipMemcpy(rhs_idx, d_ro, (size_t)g * 8, hipMemcpyDeviceToHost));
+    // the reference's `last = all ones` start value (see the header): a lone all-ones match is not reported
+    if (g == 1 && (lhs[lhs_idx[0]] & mask) == mask) g = 0;
     *n_out = g;
     return SA_OK;
 }

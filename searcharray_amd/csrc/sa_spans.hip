@@ -30,8 +30,9 @@
 // observable behaviour and are reproduced: position bits are `1 << (p % 64)` evaluated as a 32-bit
 // shift (count mod 32, sign-extended), and a rejected extension leaves its position bit set.
 // A document that fills the 512-entry table is undefined behaviour in the reference (it indexes
-// past the arrays); here, as in oracle/spans.c, it takes the reference's "full" rule
-// (min over terms of the summed popcounts).
+// past the arrays); here it behaves exactly as oracle/spans.c's guarded restatement does -- the reference's "full"
+// rule (min over terms of the summed popcounts), incl. which words still count (sa_span_doc) -- and the tests
+// compare such documents bit for bit like all others.
 #include "sa_index.hpp"
 #include "sa_scan.hpp"
 #include "../../include/searcharray_hip.h"
@@ -547,8 +548,12 @@ __device__ __forceinline__ bool sa_span_doc(const SpanMachineParams& p, const u3
                 if (cursor >= SA_NSPANS) break;
             }
             // reference compaction (spans.pyx:140-154) never removes a span (widths are bounded by
-            // construction), so a full table stays full: skip the rest of this term's words
-            if (cursor >= SA_NSPANS) gave_up = true;
+            // construction), so a full table stays full.  The reference then looks for the term's next DOCUMENT and
+            // continues there (spans.pyx:283-291): the rest of this document's words of the term is skipped -- unless
+            // this is the term's last document group: its search finds no other key, nothing is skipped and every
+            // remaining word still adds to the term's summed popcounts (the "full" rule's input).  Kept, like
+            // oracle/spans.c: tests/test_phrase.py::test_slop_span_table_overflow_matches_the_oracle.
+            if (cursor >= SA_NSPANS && k + 1 < ng) gave_up = true;
         }
     }
     u32 incr;
@@ -868,7 +873,7 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_wave(const SpanMachinePa
                     __builtin_amdgcn_wave_barrier();
                     if (cursor >= SA_NSPANS) break;
                 }
-                if (cursor >= SA_NSPANS) gave_up = true;
+                if (cursor >= SA_NSPANS && k + 1 < ng) gave_up = true;       // (not in the term's last document group: see sa_span_doc)
             }
         }
         u32 incr;

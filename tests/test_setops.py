@@ -103,3 +103,36 @@ def test_reference_fixture_arrays(api, tag):
     assert np.array_equal(al, g[f"{tag}_adj_l"]) and np.array_equal(ar, g[f"{tag}_adj_r"])
     assert np.array_equal(ops.merge(lhs, rhs, api=api), g[f"{tag}_merge"])
     assert np.array_equal(ops.merge(lhs, rhs, drop_duplicates=True, api=api), g[f"{tag}_merge_drop"])
+
+
+def test_all_ones_header_quirk_of_the_drop_variants(api):
+    """reference intersect.pyx:39,146,224-225: `last` starts as all ones, so a common value whose masked bits are all
+    ones is dropped when it would be the first pair reported (it is then the only one) and reported after any other
+    match.  Expected values are outputs of the reference itself (oracle/_ref) on these arrays; the oracle restates them."""
+    mask = np.uint64(0xFFFFFFFFFFFC0000)
+    top = 0xFFFFFFFFFFFC0000
+    lone_l, lone_r = np.asarray([top | 7], dtype=np.uint64), np.asarray([3 << 18, top | 1], dtype=np.uint64)
+    li, ri = ops.intersect(lone_l, lone_r, mask=mask, api=api)
+    assert len(li) == 0 and len(ri) == 0
+    got = ops.intersect_with_adjacents(lone_l, lone_r, mask=mask, api=api)
+    assert all(len(x) == 0 for x in got)
+    assert all(len(x) == 0 for x in O.intersect(lone_l, lone_r, mask=mask))
+    lk, rk = ops.intersect(lone_l, lone_r, mask=mask, drop_duplicates=False, api=api)       # keep mode has no `last`
+    assert np.array_equal(lk, [0]) and np.array_equal(rk, [1])
+    lhs = np.asarray([1 << 18 | 3, 5 << 18 | 1, top | 7], dtype=np.uint64)
+    rhs = np.asarray([1 << 18 | 1, 6 << 18 | 2, top | 1], dtype=np.uint64)
+    li, ri = ops.intersect(lhs, rhs, mask=mask, api=api)
+    assert np.array_equal(li, [0, 2]) and np.array_equal(ri, [0, 2])                         # reference: ([0, 2], [0, 2])
+    al, ar = ops.adjacent(lhs, rhs, mask=mask, api=api)
+    assert np.array_equal(al, [1]) and np.array_equal(ar, [1])                               # reference: ([1], [1])
+    got = ops.intersect_with_adjacents(lhs, rhs, mask=mask, api=api)
+    want = O.intersect_with_adjacents(lhs, rhs, mask=mask)
+    for g_, w_ in zip(got, want):
+        assert np.array_equal(g_, w_)
+    assert np.array_equal(want[0], [0, 2]) and np.array_equal(want[2], [1])
+    m8 = np.uint64(0xF0)
+    l2, r2 = np.asarray([0x10, 0x25, 0xF3], dtype=np.uint64), np.asarray([0x00, 0x11, 0x30, 0xF1], dtype=np.uint64)
+    li, ri = ops.intersect(l2, r2, mask=m8, api=api)
+    assert np.array_equal(li, [0, 2]) and np.array_equal(ri, [1, 3])                         # reference: ([0, 2], [1, 3])
+    li, ri = ops.intersect(l2[2:], r2, mask=m8, api=api)
+    assert len(li) == 0

@@ -90,3 +90,33 @@ def test_search_array_search_over_devices(default_api):
     p1 = arr.search_phrases([["bar", "bar"], ["foo", "bar"]], k=3)
     p2 = arr.search_phrases([["bar", "bar"], ["foo", "bar"]], k=3, devices=list(range(G)))
     assert np.array_equal(p1[0], p2[0]) and np.array_equal(p1[1], p2[1])
+
+
+@pytest.mark.parametrize("shards,k", [(2, 5), (3, 700)])
+def test_sharded_candidate_overflow_and_wide_merge(api, shards, k, monkeypatch):
+    """Every doc identical -> every score ties -> the bound cuts nothing and a 100-key candidate list runs over on every
+    shard: the flag travels with the all-gather (one extra cell per rank), every shard sees it at fetch and all of them
+    redo the batch unpruned.  k = 700 on 3 shards: 2100 gathered keys per query do not fit the merge's LDS list, so the
+    exchange takes the regroup route instead of the fused one."""
+    monkeypatch.setenv("SA_CAND_CAP", "100")
+    n = 4000
+    t = np.repeat(np.arange(3), n).astype(np.uint32)
+    d = np.tile(np.arange(n), 3).astype(np.uint64)
+    p = np.repeat(np.arange(3), n).astype(np.uint64)
+    words, wt = rz.encode_sorted(t, d, p)
+    G = n_devices(api, shards)
+    ix = ShardedIndex(words, rz.term_offsets(wt, 3), np.full(n, 3, np.float32), devices=list(range(G)), tile_docs=1024, api=api)
+    try:
+        bt = ix.batch(np.asarray([[0, 1, 2], [2, 1, 0]]), k=k)
+        for _ in range(2):
+            bt.run()
+        scores, docs = bt.fetch()
+        for qi in range(2):
+            assert np.array_equal(docs[qi], np.arange(k, dtype=np.uint64))       # ties -> smallest doc ids, over all shards
+            assert (scores[qi] == scores[qi, 0]).all() and scores[qi, 0] > 0
+        bt.run()                                                                 # (and the state is clean again)
+        s2, d2 = bt.fetch()
+        assert np.array_equal(s2, scores) and np.array_equal(d2, docs)
+        bt.close()
+    finally:
+        ix.close()
