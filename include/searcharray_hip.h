@@ -356,6 +356,38 @@ int sa_index_comm_allreduce(sa_index_t* ix, void* host_inout, uint64_t n, int dt
 /* all ranks arrived and everything enqueued on this index's streams has finished */
 int sa_index_comm_barrier(sa_index_t* ix);
 
+/* Part 3b -- N devices behind ONE handle.  The corpus (an encoded index: words / term_off as for sa_index_create,
+ * doc_lens for all docs) is cut into n_dev doc-id ranges [g * n_docs / n_dev, (g + 1) * n_docs / n_dev) -- a
+ * contiguous run of every term's word list, what the reference's key_partition computes (roaringish.py:227-243) --,
+ * shard g is built on device_ids[g] with the GLOBAL corpus size and avg_doc_len, the shards join one RCCL
+ * communicator (one host thread per device inside the library) and the document frequencies are summed over the
+ * shards.  avg_doc_len is the caller's (the reference forms it as np.mean over the float32 lengths of the whole
+ * corpus, indexing.py:282-284).  A batch of the handle is one resident batch per shard: run scores every shard's doc
+ * range, all-gathers the per-shard top-k keys and merges them on every device; fetch returns the merged result
+ * (identical to a single index over the whole corpus).  Dense drop-in calls go to the shards (sa_sharded_shard
+ * lends their handles; they stay owned by the sharded handle): a dense result is the shard vectors in doc order. */
+typedef struct sa_sharded sa_sharded_t;
+typedef struct sa_sharded_batch sa_sharded_batch_t;
+int sa_sharded_create(const int* device_ids, int n_dev, uint64_t n_docs, uint32_t n_terms, const uint64_t* words,
+                      const uint64_t* term_off, const float* doc_lens, float avg_doc_len, uint32_t tile_docs,
+                      sa_sharded_t** out);
+int sa_sharded_destroy(sa_sharded_t* sh);
+/* number of shards and their doc-id cuts (bounds_out: n_shards + 1 entries, or NULL) */
+int sa_sharded_info(sa_sharded_t* sh, int* n_shards_out, uint64_t* bounds_out);
+int sa_sharded_shard(sa_sharded_t* sh, int g, sa_index_t** out);
+/* corpus-wide document frequency of every term (what idf must be computed from) */
+int sa_sharded_docfreqs(sa_sharded_t* sh, uint64_t* df_out);
+/* the batch entry points of Part 2 over all shards: same arguments, same results as on a single index */
+int sa_sharded_batch_create(sa_sharded_t* sh, const uint32_t* terms, const float* idf, int n_queries, int n_query_terms,
+                            int k, float k1, float b, sa_sharded_batch_t** out);
+int sa_sharded_phrase_batch_create(sa_sharded_t* sh, const uint32_t* terms, const int32_t* n_terms, const int32_t* slop,
+                                   const float* idf, int n_phrases, int max_terms, int k, float k1, float b,
+                                   sa_sharded_batch_t** out);
+int sa_sharded_batch_reset(sa_sharded_batch_t* batch, const uint32_t* terms, const float* idf);
+int sa_sharded_batch_run(sa_sharded_batch_t* batch, int sync);
+int sa_sharded_batch_fetch(sa_sharded_batch_t* batch, float* scores_out, uint64_t* docs_out);
+int sa_sharded_batch_destroy(sa_sharded_batch_t* batch);
+
 /* ------------------------------------------------------------------------------------- */
 /* Part 4 -- dense vectors on the device: the combine step of Solr-style multi-field queries */
 /* ------------------------------------------------------------------------------------- */

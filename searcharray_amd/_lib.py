@@ -98,6 +98,18 @@ PROTOTYPES = {
     "sa_batch_group_info": (c_int, [c_void_p, POINTER(c_uint32)]),
     "sa_batch_stats": (c_int, [c_void_p, c_int, u64p, u64p]),
     "sa_batch_destroy": (c_int, [c_void_p]),
+    "sa_sharded_create": (c_int, [POINTER(c_int), c_int, c_uint64, c_uint32, u64p, u64p, f32p, c_float, c_uint32, POINTER(c_void_p)]),
+    "sa_sharded_destroy": (c_int, [c_void_p]),
+    "sa_sharded_info": (c_int, [c_void_p, POINTER(c_int), u64p]),
+    "sa_sharded_shard": (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
+    "sa_sharded_docfreqs": (c_int, [c_void_p, u64p]),
+    "sa_sharded_batch_create": (c_int, [c_void_p, u32p, f32p, c_int, c_int, c_int, c_float, c_float, POINTER(c_void_p)]),
+    "sa_sharded_phrase_batch_create": (c_int, [c_void_p, u32p, POINTER(ctypes.c_int32), POINTER(ctypes.c_int32), f32p, c_int, c_int,
+                                               c_int, c_float, c_float, POINTER(c_void_p)]),
+    "sa_sharded_batch_reset": (c_int, [c_void_p, u32p, f32p]),
+    "sa_sharded_batch_run": (c_int, [c_void_p, c_int]),
+    "sa_sharded_batch_fetch": (c_int, [c_void_p, f32p, u64p]),
+    "sa_sharded_batch_destroy": (c_int, [c_void_p]),
     "sa_index_select_rows": (c_int, [c_void_p, u64p, c_uint64]),
     "sa_host_alloc": (c_int, [c_uint64, POINTER(c_void_p)]),
     "sa_host_free": (c_int, [c_void_p]),

@@ -24,6 +24,7 @@
 //    For distinct terms the reference's chain equals the exact count of positions p with
 //    t0@p, t1@p+1, ... (and, for the middle-out plan, the min of the two sub-phrase counts).
 #include "sa_index.hpp"
+#include <vector>
 #include "sa_scan.hpp"
 #include "sa_phrase_dev.hpp"
 #include "../../include/searcharray_hip.h"
@@ -31,7 +32,8 @@
 #include <stdlib.h>
 
 #define SA_NONE 0xFFFFFFFFu
-#define SA_MAX_PHRASE 128     // terms per phrase (general chain); the fused kernel takes sub-phrases of up to SA_MAX_FUSED
+// (no limit on the terms of a phrase: the general chain takes them one bigram at a time, like the reference's
+//  compute_phrase_freqs, middle_out.py:73-168; the fused kernel takes sub-phrases of up to SA_MAX_FUSED)
 #define SA_MAX_FUSED 18
 
 enum { CONT_LHS = 0, CONT_RHS = 1 };
@@ -271,11 +273,6 @@ static int sa_bigram_step(hipStream_t st, const DArr& lhs, const DArr& rhs, int 
     return SA_OK;
 }
 
-struct PhrasePlan {
-    int T;
-    u32 terms[SA_MAX_PHRASE];
-};
-
 // min_posn / max_posn filter: the reference slices every term's words with payload_slice before
 // matching (middle_out.py:434-437, roaringish.py:266-282), comparing the UNSHIFTED
 // (word & msb_mask) with min_posn // 18 and max_posn // 18 -- kept as is.
@@ -310,8 +307,8 @@ int sa_posn_filter_terms(sa_index* ix, const PosnFilter& f, int T, const u64** p
         sa_compact(ps, (const u32*)nullptr, lens[t], d_chunks, d_counts + t, st);
         ptrs[t] = bufs[t];
     }
-    u32 h[SA_MAX_PHRASE];
-    SA_HIP(hipMemcpyAsync(h, d_counts, (size_t)T * sizeof(u32), hipMemcpyDeviceToHost, st));
+    std::vector<u32> h((size_t)T);
+    SA_HIP(hipMemcpyAsync(h.data(), d_counts, (size_t)T * sizeof(u32), hipMemcpyDeviceToHost, st));
     SA_HIP(hipStreamSynchronize(st));
     for (int t = 0; t < T; t++) if (lens[t]) lens[t] = h[t];
     return SA_OK;
@@ -323,8 +320,10 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
                                    float** d_running_out) {
     hipStream_t st = ix->stream;
     const u64 N = ix->n_docs;
-    u32 lens[SA_MAX_PHRASE];
-    const u64* ptrs[SA_MAX_PHRASE];
+    std::vector<u32> lens_v((size_t)T);
+    std::vector<const u64*> ptrs_v((size_t)T);
+    u32* const lens = lens_v.data();
+    const u64** const ptrs = ptrs_v.data();
     u32 maxlen = 0;
     size_t total_len = 0;
     bool known = true, distinct = true;
@@ -340,7 +339,7 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
     const size_t M = (size_t)maxlen + 64;
     const size_t chunk_words = sa_compact_chunks((u32)(2 * M)) + 8;
     const size_t filt_bytes = filt.active ? (total_len + 64 * (size_t)T) * 8 : 0;
-    const size_t need = (N + 64) * 12 + M * (3 * 4 + 3 * 8 + 2 * 8 * 2) + chunk_words * 4 + filt_bytes + 16 * 1024;
+    const size_t need = (N + 64) * 12 + M * (3 * 4 + 3 * 8 + 2 * 8 * 2) + chunk_words * 4 + filt_bytes + (size_t)T * 4 + 16 * 1024;
     void* scratch;
     SA_TRY(sa_index_scratch(ix, need, &scratch));
     Arena ar;
@@ -348,7 +347,7 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
     float* running = ar.take<float>(N + 1);
     float* running2 = ar.take<float>(N + 1);
     u32* step = ar.take<u32>(N + 1);
-    u32* lens_dev = ar.take<u32>(SA_MAX_PHRASE + 8);          // [t] term lengths, then ping-pong counters
+    u32* lens_dev = ar.take<u32>((size_t)T + 8);              // [t] term lengths, then ping-pong counters
     StepScratch s;
     s.cap = (u32)M;
     s.jin = ar.take<u32>(M); s.jadj = ar.take<u32>(M); s.absorbed = ar.take<u32>(M);
@@ -361,7 +360,8 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
     SA_HIP(hipMemsetAsync(step, 0, N * sizeof(u32), st));
     if (!known || N == 0) return SA_OK;                         // TermMissingError -> zeros (postings.py:705-708)
     if (filt.active) {
-        u64* bufs[SA_MAX_PHRASE];
+        std::vector<u64*> bufs_v((size_t)T);
+        u64** const bufs = bufs_v.data();
         for (int t = 0; t < T; t++) {
             bufs[t] = ar.take<u64>((size_t)lens[t] + 1);
             if (!bufs[t]) { sa_set_error("internal: phrase arena exhausted"); return SA_ERR_STATE; }
@@ -369,7 +369,7 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
         SA_TRY(sa_posn_filter_terms(ix, filt, T, ptrs, lens, bufs, lens_dev, s.chunks));
     }
     SA_HIP(hipMemcpyAsync(lens_dev, lens, (size_t)T * sizeof(u32), hipMemcpyHostToDevice, st));
-    u32* ppn = lens_dev + SA_MAX_PHRASE;                        // two ping-pong length counters
+    u32* ppn = lens_dev + T;                                    // two ping-pong length counters
 
     // plan: reference compute_phrase_freqs, middle_out.py:154-168 (first shortest on ties)
     int shortest = 0;
@@ -377,7 +377,8 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
     const bool l2r_only = shortest <= 1, r2l_only = !l2r_only && shortest >= T - 2;
 
     // doc directory rows (valid for the unfiltered term lists only)
-    const u32* dd_rows[SA_MAX_PHRASE];
+    std::vector<const u32*> dd_rows_v((size_t)T);
+    const u32** const dd_rows = dd_rows_v.data();
     {
         const char* v = getenv("SA_PHRASE_DOCDIR");
         const bool use_dd = !filt.active && ix->n_dd_terms > 0 && !(v && atoi(v) == 0);
@@ -514,7 +515,6 @@ static int sa_phrase_or_span(sa_index* ix, const u32* terms, int n_terms, int sl
 // for the phrase batches (sa_phrase_batch.hip): dense counts of any phrase / slop in the index scratch, and
 // counts -> BM25 in place; the caller holds the index lock and enqueues on ix->stream
 int sa_phrase_dense_counts_device(sa_index* ix, const u32* terms, int n_terms, int slop, float** d_out) {
-    if (n_terms > SA_MAX_PHRASE) { sa_set_error("phrase too long (max 128 terms)"); return SA_ERR_UNSUPPORTED; }
     PosnFilter filt;
     return sa_phrase_or_span(ix, terms, n_terms, slop, filt, d_out);
 }
@@ -528,7 +528,6 @@ extern "C" int sa_index_phrase_freqs_dense_posn(sa_index_t* ix, const uint32_t* 
     SA_ARG(ix && out && terms, "null argument");
     // reference middle_out.py:425-426
     if (n_terms < 2) { sa_set_error("Must have at least two terms"); return SA_ERR_ARG; }
-    SA_ARG(n_terms <= SA_MAX_PHRASE, "phrase too long (max 128 terms)");
     SA_ARG(slop >= 0, "slop < 0");
     PosnFilter filt;
     SA_TRY(sa_posn_filter_bounds(min_posn, max_posn, &filt));
@@ -555,7 +554,6 @@ extern "C" int sa_index_bm25_phrase_dense_posn(sa_index_t* ix, const uint32_t* t
                                                float* out) {
     SA_ARG(ix && out && terms, "null argument");
     if (n_terms < 2) { sa_set_error("Must have at least two terms"); return SA_ERR_ARG; }
-    SA_ARG(n_terms <= SA_MAX_PHRASE, "phrase too long (max 128 terms)");
     SA_ARG(slop >= 0, "slop < 0");
     PosnFilter filt;
     SA_TRY(sa_posn_filter_bounds(min_posn, max_posn, &filt));

@@ -303,8 +303,7 @@ static int sa_phrase_batch_fill(sa_batch* bt, const uint32_t* terms, const int32
         if (n_terms[i] < 2) { sa_set_error("Must have at least two terms"); return SA_ERR_ARG; }
         SA_ARG(n_terms[i] <= (int)T, "n_terms[i] > max_terms");
         SA_ARG(!slop || slop[i] >= 0, "slop < 0");
-        if (n_terms[i] > 128) { sa_set_error("phrase too long (max 128 terms)"); return SA_ERR_UNSUPPORTED; }
-        if (slop && slop[i] > 0 && n_terms[i] > 16) { sa_set_error("slop phrases support at most 16 terms"); return SA_ERR_UNSUPPORTED; }
+        if (slop && slop[i] > 0 && n_terms[i] > 32) { sa_set_error("slop phrases support at most 32 terms"); return SA_ERR_UNSUPPORTED; }
         // the tile kernel takes exact phrases of up to 18 pairwise-distinct terms; everything else the reference's
         // score() accepts -- repeated terms (same-term rule, bigram_freqs.py:48-101), longer phrases, slop > 0
         // (spans.py:71-187) -- is scored through the dense single-phrase path and ranked on the device

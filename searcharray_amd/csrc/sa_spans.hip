@@ -39,7 +39,7 @@
 #include <stdlib.h>
 #include <algorithm>
 
-#define SA_SPAN_MAX_TERMS 16
+#define SA_SPAN_MAX_TERMS 32
 #define SA_NSPANS 512
 #define SA_SPAN_THREADS 65536            // resident state-machine threads (12 KiB of span table each)
 

@@ -182,8 +182,10 @@ class _IndexCore:
         return int(h.words.nbytes)                       # nothing resident yet: host encode
 
     def sharded(self, devices) -> "ShardedIndex":
-        """The same index as doc-range shards over several GPUs (searcharray_amd/sharded.py), kept for
-        the next batched search on the same device list."""
+        """The same index as doc-range shards over several GPUs (searcharray_amd/sharded.py ->
+        sa_sharded_create), kept for the next batched search on the same device list.  The library cuts the shards out
+        of the encoded words on the HOST: an index that so far only lives in a .dat file or in HBM is read back once
+        here (``host.words``) -- a one-time cost of asking for another device layout."""
         from .sharded import ShardedIndex
         key = tuple(int(d) for d in devices)
         cached = getattr(self, "_sharded", None)
@@ -698,7 +700,8 @@ class SearchArray(ExtensionArray):
         B = len(toks)
         if B == 0 or len(self._core.doc_lens) == 0:
             return np.zeros((B, k), np.float32), np.full((B, k), NO_DOC, np.uint64)
-        dev = self._core.sharded(devices) if devices is not None and len(devices) > 1 else self._core.device()
+        # (an explicit device list is honoured even when it names ONE device: a one-shard handle on that GPU)
+        dev = self._core.sharded(devices) if devices is not None and len(devices) >= 1 else self._core.device()
         unknown = dev.n_terms                                   # any id >= n_terms matches nothing
         ids = [[t if (t := self._term_id(tok)) >= 0 else unknown for tok in q] for q in toks]
         if phrases:

@@ -526,3 +526,47 @@ def test_search_phrases_with_repeated_tokens_and_slop(default_api):
         ws, wd = O.topk(arr.score(ph, slop=3), 4)
         n = int((ws > 0).sum())
         assert np.array_equal(s[i, :n], ws[:n]) and np.array_equal(dd[i, :n], wd[:n]), ph
+
+
+def test_phrases_of_any_length_and_slop_phrases_up_to_32_terms(api):
+    """The reference has no limit on the terms of a phrase (compute_phrase_freqs chains bigrams, middle_out.py:73-168;
+    PosnBitArray.phrase_freqs, :418-446) -- neither has the device's general chain (rounds 1-2 stopped at 128 terms);
+    slop phrases go up to 32 terms (the span machine's term sets are 32-bit).  Device counts == oracle, dense calls
+    and a phrase batch."""
+    rng = np.random.default_rng(77)
+    n_docs, vocab = 60, 6
+    lens = rng.integers(150, 400, n_docs)
+    toks = [rng.integers(0, vocab, int(n)) for n in lens]
+    t = np.concatenate(toks).astype(np.uint32)
+    d = np.repeat(np.arange(n_docs), lens).astype(np.uint64)
+    p = np.concatenate([np.arange(int(n)) for n in lens]).astype(np.uint64)
+    order = np.lexsort((p, d, t))
+    t, d, p = t[order], d[order], p[order]
+    words, wt = rz.encode_sorted(t, d, p)
+    dl = lens.astype(np.float32)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), dl, tile_docs=1024, api=api)
+    orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=dl)
+    long_phrases = []
+    for n, doc, start in ((130, 3, 5), (200, 17, 40), (19, 9, 0)):
+        ph = [int(x) for x in toks[doc][start:start + n]]
+        got = dev.phrase_freqs_dense(ph)
+        want = orc.phrase_freqs(ph)
+        assert np.array_equal(got, want), f"{n}-term phrase"
+        assert got[doc] >= 1
+        long_phrases.append(ph)
+    for n, doc, start, slop in ((17, 4, 10, 1), (24, 30, 0, 2), (32, 11, 7, 1)):
+        ph = [int(x) for x in toks[doc][start:start + n]]
+        got = dev.phrase_freqs_dense(ph, slop=slop)
+        want = orc.phrase_freqs(ph, slop=slop)
+        assert np.array_equal(got, want), f"{n}-term slop-{slop} phrase"
+    with pytest.raises(Exception):
+        dev.phrase_freqs_dense([int(x) for x in toks[0][:33]], slop=1)
+    pb = dev.phrase_batch(long_phrases + [[0, 1]], k=4)
+    pb.run()
+    ps, pd_ = pb.fetch()
+    for i, ph in enumerate(long_phrases + [[0, 1]]):
+        ws, wd = O.topk(orc.score(ph), 4)
+        n = int((ws > 0).sum())
+        assert np.array_equal(ps[i, :n], ws[:n]) and np.array_equal(pd_[i, :n], wd[:n]), f"batch phrase {i}"
+    pb.close()
+    dev.close()
