@@ -14,6 +14,8 @@
 struct sa_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
+    void* d_buf = nullptr;          // device staging of the host-side reductions (grown on demand, kept)
+    size_t buf_bytes = 0;
 };
 
 #define SA_NCCL(expr)                                                                        \
@@ -68,6 +70,7 @@ extern "C" int sa_index_comm_destroy(sa_index_t* ix) {
     hipStreamSynchronize(ix->stream);
     if (ix->xstream) hipStreamSynchronize(ix->xstream);
     ncclCommDestroy(ix->comm->comm);
+    if (ix->comm->d_buf) hipFree(ix->comm->d_buf);
     delete ix->comm;
     ix->comm = nullptr;
     return SA_OK;
@@ -101,8 +104,15 @@ extern "C" int sa_index_comm_allreduce(sa_index_t* ix, void* host_inout, uint64_
     if (!ix->comm) { sa_set_error("index has no communicator"); return SA_ERR_STATE; }
     if (n == 0) return SA_OK;
     SA_HIP(hipSetDevice(ix->device));
-    void* d = nullptr;
-    SA_HIP(hipMalloc(&d, n * 8));
+    sa_comm* c = ix->comm;
+    if (c->buf_bytes < n * 8) {                       // (barriers and timing reductions reuse the same few bytes)
+        if (c->d_buf) SA_HIP(hipFree(c->d_buf));
+        c->d_buf = nullptr; c->buf_bytes = 0;
+        const size_t want = n * 8 < 4096 ? 4096 : n * 8;
+        SA_HIP(hipMalloc(&c->d_buf, want));
+        c->buf_bytes = want;
+    }
+    void* d = c->d_buf;
     hipStream_t xs = ix->xstream;
     int rc = SA_OK;
     if (hipMemcpyAsync(d, host_inout, n * 8, hipMemcpyHostToDevice, xs) != hipSuccess) rc = SA_ERR_HIP;
@@ -113,7 +123,6 @@ extern "C" int sa_index_comm_allreduce(sa_index_t* ix, void* host_inout, uint64_
     }
     if (rc == SA_OK && hipMemcpyAsync(host_inout, d, n * 8, hipMemcpyDeviceToHost, xs) != hipSuccess) rc = SA_ERR_HIP;
     if (hipStreamSynchronize(xs) != hipSuccess && rc == SA_OK) rc = SA_ERR_HIP;
-    hipFree(d);
     if (rc == SA_ERR_HIP) sa_set_error("sa_index_comm_allreduce: HIP copy / synchronize failed");
     return rc;
 }

@@ -480,7 +480,11 @@ int sa_index_derive(sa_index* ix) {
         if (dd_bytes) SA_HIP(hipMemsetAsync(ix->d_docdir, 0xFF, dd_bytes, st));
         u32* d_top = nullptr;
         SA_HIP(hipMalloc(&d_top, ((size_t)ix->n_dd_terms + 1) * sizeof(u32)));
-        SA_HIP(hipMemsetAsync(d_top, 0, ((size_t)ix->n_dd_terms + 1) * sizeof(u32), st));
+        if (hipMemsetAsync(d_top, 0, ((size_t)ix->n_dd_terms + 1) * sizeof(u32), st) != hipSuccess) {
+            hipFree(d_top);
+            sa_set_error("doc directory build failed (memset)");
+            return SA_ERR_HIP;
+        }
         for (u32 r = 0; r < ix->n_dd_terms; r++) {
             const u32 t = cand[r].second;
             const u32 n = (u32)cand[r].first;

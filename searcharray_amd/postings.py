@@ -536,7 +536,17 @@ class SearchArray(ExtensionArray):
                 # (the reference compares term_mat rows and doc_lens, postings.py:463-464)
                 ra, rb = self._row_ids(), other._row_ids()
                 out = ra == rb
-                for i in np.flatnonzero(~out):
+                # cheap invariants first, vectorised: equal docs have equal lengths and equally many distinct terms;
+                # then the term-id slices of the doc -> term CSR; positions are only decoded (tf per term) for the
+                # few pairs that survive all of that (`arr == arr.take(perm)` on a large array used to decode every
+                # differing row on the host)
+                h = self._core.host
+                ptr = h.doc_term_ptr
+                maybe = ~out & (h.doc_lens[ra] == h.doc_lens[rb]) & ((ptr[ra + 1] - ptr[ra]) == (ptr[rb + 1] - ptr[rb]))
+                for i in np.flatnonzero(maybe):
+                    a0, a1, b0, b1 = int(ptr[ra[i]]), int(ptr[ra[i] + 1]), int(ptr[rb[i]]), int(ptr[rb[i] + 1])
+                    if not np.array_equal(h.doc_term_ids[a0:a1], h.doc_term_ids[b0:b1]):
+                        continue
                     out[i] = bool(self._core.doc_as_terms(int(ra[i])) == self._core.doc_as_terms(int(rb[i])))
                 return out
             a, b = self._as_terms_list(), other._as_terms_list()

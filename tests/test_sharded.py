@@ -62,6 +62,14 @@ def test_sharded_topk_is_bit_identical_to_the_single_index_oracle(api, corpus, s
             ws, wd = O.topk(orc.score_terms_sum([int(x) for x in q]), K)
             assert np.array_equal(scores[qi], ws), f"q{qi}"
             assert np.array_equal(docs[qi][ws > 0], wd[ws > 0]), f"q{qi}"
+        # a fresh query set in the same batch (sa_sharded_batch_reset on every shard), still bit-identical
+        fresh = QUERIES[::-1].copy()
+        bt.reset(fresh)
+        bt.run(sync=False)
+        scores, docs = bt.fetch()
+        for qi, q in enumerate(fresh):
+            ws, wd = O.topk(orc.score_terms_sum([int(x) for x in q if 0 <= int(x) < VOCAB]), K)
+            assert np.array_equal(scores[qi], ws) and np.array_equal(docs[qi][ws > 0], wd[ws > 0]), f"reset q{qi}"
         bt.close()
         pb = ix.phrase_batch(PHRASES, k=K)
         pb.run()
