@@ -1,0 +1,23 @@
+#!/usr/bin/env python
+"""The bench's slop_batch / phrase_batch legs alone (zipf-1M, 32 two-token slop-2 phrases of ranks 50-5000; 256 sampled
+trigrams), for rocprofv3 --kernel-trace --stats."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench                                             # noqa: E402
+from searcharray_amd import _lib                         # noqa: E402
+
+api = _lib.api()
+side = bench.PhraseSide(api, 1_000_000, 100_000)
+out = {}
+for name, b in side.legs():
+    if len(sys.argv) > 1 and sys.argv[1] not in name:
+        continue
+    dt, kms = side.timed(b, 3, 20)
+    out[name] = {"ms_per_step": round(dt / 20 * 1e3, 4), "kernel_ms": round(kms, 4)}
+print(json.dumps(out))
+side.close()

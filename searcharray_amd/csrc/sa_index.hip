@@ -227,6 +227,10 @@ void sa_index_free(sa_index* ix) {
         if (ix->lane_scratch[i]) hipFree(ix->lane_scratch[i]);
         if (ix->lane_stream[i]) hipStreamDestroy(ix->lane_stream[i]);
     }
+    if (ix->d_span_batch) hipFree(ix->d_span_batch);
+    if (ix->d_span_counts) hipFree(ix->d_span_counts);
+    if (ix->h_span_jobs) hipHostFree(ix->h_span_jobs);
+    if (ix->ev_span_jobs) hipEventDestroy(ix->ev_span_jobs);
     if (ix->d_rows_scratch) hipFree(ix->d_rows_scratch);
     if (ix->d_sim_scratch) hipFree(ix->d_sim_scratch);
     if (ix->ev0) hipEventDestroy(ix->ev0);

@@ -101,6 +101,17 @@ struct sa_index {
     void* lane_scratch[3] = {nullptr, nullptr, nullptr};
     size_t lane_bytes[3] = {0, 0, 0};
 
+    // slop phrases of a phrase batch in shared launches (sa_span_counts_batch): job array + per-phrase scratch, and the
+    // page-locked image the jobs are uploaded from
+    void* d_span_batch = nullptr;
+    size_t span_batch_bytes = 0;
+    void* h_span_jobs = nullptr;
+    size_t span_jobs_host_bytes = 0;
+    hipEvent_t ev_span_jobs = nullptr;
+    float* d_span_counts = nullptr;  // pool of dense count vectors of that route, all zeros between runs (the ranking launch cleans up)
+    size_t span_counts_cap = 0;      // floats
+    bool span_counts_dirty = false;
+
     // row selection scratch (sa_index_select_rows): device copy of the selected doc ids + gathered values
     void* d_rows_scratch = nullptr;
     size_t rows_scratch_bytes = 0;
@@ -151,3 +162,8 @@ int sa_posn_filter_terms(sa_index* ix, const PosnFilter& f, int T, const u64** p
 int sa_phrase_dense_counts_device(sa_index* ix, const u32* terms, int n_terms, int slop, float** d_out);
 void sa_launch_bm25_from_tf(sa_index* ix, float* d_tf, float idf, float k1, float b);
 int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const PosnFilter& filt, float** d_out);
+// one phrase of the dense route to rank: dense counts (float[n_docs]), the phrase's idf, its row in the batch
+struct sa_dense_rank_job { const float* counts; float idf; u32 row; };
+int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* terms, const int* T, const int* slop,
+                         const float* idf, const u32* rows, float** d_out, unsigned char* handled,
+                         const sa_dense_rank_job** d_rank_jobs, int* n_rank_jobs);

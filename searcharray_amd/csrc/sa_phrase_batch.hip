@@ -209,6 +209,38 @@ sa_k_dense_topk_tiles(const float* __restrict__ counts, const float* __restrict_
     sa_tile_topk_pruned<TILE, THREADS>(acc, slot_val, q, tile, doc_base + tile_base, k, slots, cand, cand_cap, cand_cnt);
 }
 
+// the same for several dense-route phrases in ONE launch: blockIdx.y picks the phrase (its counts, idf and batch row)
+template <int TILE, int THREADS>
+__global__ void __launch_bounds__(THREADS)
+sa_k_dense_topk_tiles_multi(const sa_dense_rank_job* __restrict__ jobs, const float* __restrict__ dl, float avgdl, float k1, float b,
+                            u64 n_docs, u64 doc_base, u32 k, u32* __restrict__ slots, u64* __restrict__ cand, u32 cand_cap,
+                            u32* __restrict__ cand_cnt) {
+    constexpr int E = TILE / THREADS;
+    __shared__ float acc[TILE];
+    const sa_dense_rank_job J = jobs[blockIdx.y];
+    const u32 tid = threadIdx.x, tile = blockIdx.x, q = J.row;
+    const u64 tile_base = (u64)tile * TILE;
+    const float one_minus_b = 1.0f - b;
+    u32 slot_val = 0xFFFFFFFFu;
+    if ((tid & (SA_WAVE - 1)) < 32u)
+        slot_val = __hip_atomic_load(&slots[q * 32u + (tid & 31u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        const u64 d = tile_base + (u64)(j * THREADS) + tid;
+        float sc = 0.f;
+        if (d < n_docs) {
+            const float t = J.counts[d];
+            if (t != 0.f) {
+                ((float*)J.counts)[d] = 0.f;                     // the count vectors of this route are all zeros between runs (sa_span_counts_batch)
+                const float norm = __fmul_rn(k1, __fadd_rn(one_minus_b, __fmul_rn(b, __fdiv_rn(dl[d], avgdl))));
+                sc = __fmul_rn(__fdiv_rn(t, __fadd_rn(t, norm)), J.idf);
+            }
+        }
+        acc[j * THREADS + tid] = sc;
+    }
+    sa_tile_topk_pruned<TILE, THREADS>(acc, slot_val, q, tile, doc_base + tile_base, k, slots, cand, cand_cap, cand_cnt);
+}
+
 int sa_launch_phrase_tiles(sa_batch* bt, hipStream_t st) {
     sa_index* ix = bt->ix;
     if (bt->pn_tiles == 0 || bt->B == 0) return SA_OK;
@@ -264,8 +296,42 @@ int sa_launch_phrase_tiles(sa_batch* bt, hipStream_t st) {
             SA_HIP(hipStreamWaitEvent(ix->lane_stream[j], bt->ev_side[0], 0));
         }
     }
+    // slop phrases first, ALL of them in shared launches (sa_span_counts_batch: five launches per class of phrases instead of
+    // five per phrase) and ranked by one launch; what that route does not take (an unknown term, very long lists) and
+    // the exact dense-route phrases (repeated terms, more than 18 terms) follow one by one
+    std::vector<unsigned char> taken(bt->B, 0);
+    {
+        std::vector<const u32*> tp;
+        std::vector<int> tn, ts;
+        std::vector<u32> rows;
+        for (u32 row : bt->dense_rows)
+            if (bt->h_pslop[row] > 0) { rows.push_back(row); tp.push_back(&bt->h_pterms[(size_t)row * bt->T]); tn.push_back(bt->h_pn[row]); ts.push_back(bt->h_pslop[row]); }
+        if (!rows.empty()) {
+            std::vector<float*> outs(rows.size(), nullptr);
+            std::vector<unsigned char> handled(rows.size(), 0);
+            std::vector<float> idfs(rows.size());
+            for (size_t i = 0; i < rows.size(); i++) idfs[i] = bt->h_pidf[rows[i]];
+            const sa_dense_rank_job* d_rj = nullptr;
+            int n_rj = 0;
+            SA_TRY(sa_span_counts_batch(ix, st, (int)rows.size(), tp.data(), tn.data(), ts.data(), idfs.data(), rows.data(), outs.data(),
+                                        handled.data(), &d_rj, &n_rj));
+            for (size_t i = 0; i < rows.size(); i++) if (handled[i]) taken[rows[i]] = 1;
+            if (n_rj > 0) {
+                if (bt->ptile == 2048)
+                    hipLaunchKernelGGL((sa_k_dense_topk_tiles_multi<2048, SA_PTHREADS>), dim3(bt->pn_tiles, (u32)n_rj), dim3(SA_PTHREADS), 0, st,
+                                       d_rj, (const float*)ix->d_doc_lens, ix->avg_doc_len, bt->k1, bt->b, ix->n_docs,
+                                       ix->doc_base, bt->k, bt->d_slots, bt->d_cand, bt->cand_cap, bt->d_cand_cnt);
+                else
+                    hipLaunchKernelGGL((sa_k_dense_topk_tiles_multi<4096, SA_PTHREADS>), dim3(bt->pn_tiles, (u32)n_rj), dim3(SA_PTHREADS), 0, st,
+                                       d_rj, (const float*)ix->d_doc_lens, ix->avg_doc_len, bt->k1, bt->b, ix->n_docs,
+                                       ix->doc_base, bt->k, bt->d_slots, bt->d_cand, bt->cand_cap, bt->d_cand_cnt);
+                ix->span_counts_dirty = false;
+            }
+        }
+    }
     u32 nth = 0;
     for (u32 row : bt->dense_rows) {
+        if (taken[row]) continue;
         const int j = (int)(nth++ % (u32)n_lanes) - 1;
         const hipStream_t ls = j < 0 ? st : ix->lane_stream[j];
         Lane lane(ix, j);

@@ -152,18 +152,22 @@ __global__ void __launch_bounds__(256) sa_k_span_wrap_flag(const SpanTerms st, u
 // dense per-doc counts the state machines accumulate into.  TT: the number of terms when it is 2, 3 or 4 (the loops
 // over the terms unroll and the per-term results stay in registers -- the generic code spends most of its
 // instructions on indexing them), 0: any number.
+// (bx / gx: the block's index and the number of blocks of THIS phrase's launch -- blockIdx.x / gridDim.x for a launch of
+//  its own, or the phrase's share of a batched launch whose blockIdx.y picks the phrase: sa_k_span_*_multi below)
 template <int TT>
-__global__ void __launch_bounds__(256)
-sa_k_span_flags(const SpanTerms st, const u32* __restrict__ wrap, const int wrap_host, u32* __restrict__ cnt_clear,
-                unsigned char* __restrict__ flags, float* __restrict__ counts) {
+__device__ __forceinline__ void
+sa_span_flags_body(const SpanTerms& st, const u32* __restrict__ wrap, const int wrap_host, u32* __restrict__ cnt_clear,
+                   unsigned char* __restrict__ flags, float* __restrict__ counts, const u32 bx, const u32 gx) {
     const int T = TT ? TT : st.T;
     const u32 total = st.off[T];
     // "header 0 in L": from sa_k_span_wrap_flag (filtered lists), or worked out on the host from the index's per-term
     // edge flags -- then this launch also clears the query's counters and no launch precedes it
     const bool wr = wrap ? *wrap != 0 : wrap_host != 0;
-    if (cnt_clear && blockIdx.x == 0 && threadIdx.x < SA_SPAN_CNT_WORDS) cnt_clear[threadIdx.x] = 0u;
-    for (u64 d = (u64)blockIdx.x * blockDim.x + threadIdx.x; d < st.n_docs; d += (u64)gridDim.x * blockDim.x) counts[d] = 0.f;
-    for (u32 g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
+    if (cnt_clear && bx == 0 && threadIdx.x < SA_SPAN_CNT_WORDS) cnt_clear[threadIdx.x] = 0u;
+    // (counts == null: the batched route's count vectors are kept zero by the launch that ranks them)
+    if (counts)
+        for (u64 d = (u64)bx * blockDim.x + threadIdx.x; d < st.n_docs; d += (u64)gx * blockDim.x) counts[d] = 0.f;
+    for (u32 g = bx * blockDim.x + threadIdx.x; g < total; g += gx * blockDim.x) {
         int t = 0;
 #pragma unroll
         for (int i = 1; i < (TT ? TT : SA_SPAN_MAX_TERMS); i++) t += (i < T && g >= st.off[i]) ? 1 : 0;
@@ -238,6 +242,13 @@ sa_k_span_flags(const SpanTerms st, const u32* __restrict__ wrap, const int wrap
     }
 }
 
+template <int TT>
+__global__ void __launch_bounds__(256)
+sa_k_span_flags(const SpanTerms st, const u32* __restrict__ wrap, const int wrap_host, u32* __restrict__ cnt_clear,
+                unsigned char* __restrict__ flags, float* __restrict__ counts) {
+    sa_span_flags_body<TT>(st, wrap, wrap_host, cnt_clear, flags, counts, blockIdx.x, gridDim.x);
+}
+
 // stage 1b: ONE stable compaction for all terms and both outputs -- the candidate words of each term, and the index
 // (in the compacted array) of the first candidate word of each document: count per chunk, a scan per (term, output),
 // emit.  A candidate word opens a document group iff no earlier word of the same doc (they are neighbours in the
@@ -264,11 +275,11 @@ __device__ __forceinline__ bool sa_span_opens_doc(const u64* __restrict__ w, con
     return true;
 }
 
-__global__ void __launch_bounds__(SA_CT)
-sa_k_span_compact_count(const SpanTerms st, const SpanChunkTab ck, const unsigned char* __restrict__ flags,
-                        u32* __restrict__ chunk_counts, u32 n_chunks) {
+__device__ __forceinline__ void
+sa_span_compact_count_body(const SpanTerms& st, const SpanChunkTab& ck, const unsigned char* __restrict__ flags,
+                           u32* __restrict__ chunk_counts, u32 n_chunks, const u32 bx, const u32 gx) {
     __shared__ u32 red[SA_CW + 1];
-    for (u32 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    for (u32 c = bx; c < n_chunks; c += gx) {
         int t = 0;
         while (c >= ck.coff[t + 1]) t++;
         const u32 base = (c - ck.coff[t]) * SA_CHUNK, n = st.len[t];
@@ -286,6 +297,12 @@ sa_k_span_compact_count(const SpanTerms st, const SpanChunkTab ck, const unsigne
         const u32 tot = sa_block_sum<SA_CW>(nc | (nh << 16), red);          // (a chunk has 2048 elements)
         if (threadIdx.x == 0) { chunk_counts[c] = tot & 0xFFFFu; chunk_counts[n_chunks + c] = tot >> 16; }
     }
+}
+
+__global__ void __launch_bounds__(SA_CT)
+sa_k_span_compact_count(const SpanTerms st, const SpanChunkTab ck, const unsigned char* __restrict__ flags,
+                        u32* __restrict__ chunk_counts, u32 n_chunks) {
+    sa_span_compact_count_body(st, ck, flags, chunk_counts, n_chunks, blockIdx.x, gridDim.x);
 }
 
 // block b: exclusive scan of the chunk counts of term b % T, output b / T; totals -> cnt[t] / cnt[16 + t]
@@ -307,14 +324,15 @@ sa_k_span_compact_scan(const SpanChunkTab ck, int T, u32* __restrict__ chunk_cou
     if (threadIdx.x == 0) cnt[kind * SA_SPAN_MAX_TERMS + t] = carry;
 }
 
-__global__ void __launch_bounds__(SA_CT)
-sa_k_span_compact_emit(const SpanTerms st, const SpanChunkTab ck, const unsigned char* __restrict__ flags,
-                       const u32* __restrict__ chunk_off, u32 n_chunks, const SpanCompactOut out, u32* __restrict__ totals) {
+__device__ __forceinline__ void
+sa_span_compact_emit_body(const SpanTerms& st, const SpanChunkTab& ck, const unsigned char* __restrict__ flags,
+                          const u32* __restrict__ chunk_off, u32 n_chunks, const SpanCompactOut& out, u32* __restrict__ totals,
+                          const u32 bx, const u32 gx) {
     __shared__ u32 wc[SA_CI][SA_CW];
     __shared__ u32 red[2][SA_CW];
     const int lane = sa_lane(), wave = sa_wave_id();
     const u64 lt = (1ull << lane) - 1ull;
-    for (u32 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    for (u32 c = bx; c < n_chunks; c += gx) {
         int t = 0;
         while (c >= ck.coff[t + 1]) t++;
         const u32 base = (c - ck.coff[t]) * SA_CHUNK, n = st.len[t];
@@ -387,6 +405,12 @@ sa_k_span_compact_emit(const SpanTerms st, const SpanChunkTab ck, const unsigned
         }
         __syncthreads();
     }
+}
+
+__global__ void __launch_bounds__(SA_CT)
+sa_k_span_compact_emit(const SpanTerms st, const SpanChunkTab ck, const unsigned char* __restrict__ flags,
+                       const u32* __restrict__ chunk_off, u32 n_chunks, const SpanCompactOut out, u32* __restrict__ totals) {
+    sa_span_compact_emit_body(st, ck, flags, chunk_off, n_chunks, out, totals, blockIdx.x, gridDim.x);
 }
 
 // document-group heads of a compacted candidate array
@@ -634,7 +658,7 @@ __global__ void __launch_bounds__(1024) sa_k_span_bin_scatter(const SpanBinParam
 // the heavy pass -- one counter update per wave, the abandoned lanes take consecutive slots.
 // TT: the number of terms when it is 2 or 3 (the loops over the terms resolve at compile time), 0: any number.
 template <int CE, int PMAX, int TT>
-__global__ void __launch_bounds__(64) sa_k_span_machine_flat(const SpanMachineParams p) {
+__device__ __forceinline__ void sa_span_machine_flat_body(const SpanMachineParams& p, const u32 bx) {
     __shared__ alignas(16) SpanEnt s_ents[(CE + 1) * 64];        // lane L's entry i at (i * 64 + L): conflict-free whatever i each lane is at; row CE: scratch
     __shared__ u32 s_pos[PMAX * 64];                             // term << 24 | position
     struct EntCol {
@@ -654,7 +678,7 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_flat(const SpanMachinePa
     };
     const u32 lane = threadIdx.x;
     const u32 n_items = *p.n_heads[0];
-    const u32 item = blockIdx.x * 64u + lane;
+    const u32 item = bx * 64u + lane;
     const u32 k = (item < n_items && p.order) ? p.order[item] : item;
     const int T = TT ? TT : p.T;
     const u32 num_terms = (u32)T;
@@ -782,6 +806,11 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_flat(const SpanMachinePa
     }
 }
 
+template <int CE, int PMAX, int TT>
+__global__ void __launch_bounds__(64) sa_k_span_machine_flat(const SpanMachineParams p) {
+    sa_span_machine_flat_body<CE, PMAX, TT>(p, blockIdx.x);
+}
+
 // Heavy documents: ONE WAVE per document group.  The span table (the reference's full 512 entries) is in LDS; the
 // positions are still taken one after the other, but what the reference does for one position -- visit every
 // span that existed before it, extend / fork -- is done for 64 spans at a time, one per lane: the visits are
@@ -789,7 +818,7 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_flat(const SpanMachinePa
 // existed, in span order -- a ballot prefix gives each fork its slot -- and are not visited for the same
 // position).  The cost of a document drops from positions x spans dependent steps of one lane to
 // positions x ceil(spans / 64) steps of a wave, and heavy documents no longer form the kernel's tail.
-__global__ void __launch_bounds__(64) sa_k_span_machine_wave(const SpanMachineParams p) {
+__device__ __forceinline__ void sa_span_machine_wave_body(const SpanMachineParams& p, const u32 bx, const u32 gx) {
     __shared__ alignas(16) SpanEnt s_ents[SA_NSPANS];
     u64* const s_col2 = (u64*)s_ents;                            // collected span c in the (dead) slot of span c: s_col2[2 c]
     const u32 lane = threadIdx.x;
@@ -797,7 +826,7 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_wave(const SpanMachinePa
     const u32 n_items = *p.in_cnt;
     const u32 num_terms = (u32)p.T;
     const int max_span_width = (int)(num_terms + p.slop);
-    for (u32 item = blockIdx.x; item < n_items; item += gridDim.x) {
+    for (u32 item = bx; item < n_items; item += gx) {
         const u32 k = p.in_list[item];
         u32 cursor = 0;
         bool full = false;
@@ -920,6 +949,60 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_wave(const SpanMachinePa
         }
         if (lane == 0) sa_span_add(p, last_key, incr);
     }
+}
+
+__global__ void __launch_bounds__(64) sa_k_span_machine_wave(const SpanMachineParams p) {
+    sa_span_machine_wave_body(p, blockIdx.x, gridDim.x);
+}
+
+// ---- B slop phrases in SHARED launches (phrase batches, BASELINE config 5) ------------------------------------------
+// A sampled slop phrase is five short launches, and a batch of them is bound by the host's launch rate (round 2: 25 K
+// phrases/s over two streams).  Here every stage is ONE launch for all phrases of a class (2, 3, 4 terms, more):
+// blockIdx.y picks the phrase, whose parameters -- exactly the structs the single-phrase kernels take by value -- sit
+// in a device array, and blockIdx.x is the block's index in the phrase's own share of the grid.
+struct SpanJob {
+    SpanTerms st;
+    SpanChunkTab ck;
+    SpanCompactOut co;
+    SpanMachineParams mp;
+    int wrap_host;
+    u32* cnt;
+    unsigned char* flags;
+    u32* chunks;
+    u32 n_chunks;
+    u32 g_flags, g_chunks, g_flat, g_wave;                       // blocks of this phrase in the shared launches
+};
+
+template <int TT>
+__global__ void __launch_bounds__(256) sa_k_span_flags_multi(const SpanJob* __restrict__ jobs) {
+    const SpanJob& J = jobs[blockIdx.y];
+    if (blockIdx.x >= J.g_flags) return;
+    sa_span_flags_body<TT>(J.st, (const u32*)nullptr, J.wrap_host, J.cnt, J.flags, (float*)nullptr, blockIdx.x, J.g_flags);
+}
+
+__global__ void __launch_bounds__(SA_CT) sa_k_span_compact_count_multi(const SpanJob* __restrict__ jobs) {
+    const SpanJob& J = jobs[blockIdx.y];
+    if (blockIdx.x >= J.g_chunks) return;
+    sa_span_compact_count_body(J.st, J.ck, J.flags, J.chunks, J.n_chunks, blockIdx.x, J.g_chunks);
+}
+
+__global__ void __launch_bounds__(SA_CT) sa_k_span_compact_emit_multi(const SpanJob* __restrict__ jobs) {
+    const SpanJob& J = jobs[blockIdx.y];
+    if (blockIdx.x >= J.g_chunks) return;
+    sa_span_compact_emit_body(J.st, J.ck, J.flags, J.chunks, J.n_chunks, J.co, J.cnt, blockIdx.x, J.g_chunks);   // (inline scan: the host checks)
+}
+
+template <int CE, int PMAX, int TT>
+__global__ void __launch_bounds__(64) sa_k_span_machine_flat_multi(const SpanJob* __restrict__ jobs) {
+    const SpanJob& J = jobs[blockIdx.y];
+    if (blockIdx.x >= J.g_flat) return;
+    sa_span_machine_flat_body<CE, PMAX, TT>(J.mp, blockIdx.x);
+}
+
+__global__ void __launch_bounds__(64) sa_k_span_machine_wave_multi(const SpanJob* __restrict__ jobs) {
+    const SpanJob& J = jobs[blockIdx.y];
+    if (blockIdx.x >= J.g_wave) return;
+    sa_span_machine_wave_body(J.mp, blockIdx.x, J.g_wave);
 }
 
 // slow pass: a resident grid strides over the listed document groups (all of them when over_list is null:
@@ -1117,6 +1200,190 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
     } else {
         hipLaunchKernelGGL(sa_k_span_machine, dim3(G / 64), dim3(64), 0, st, mp);       // every group, full tables in the global slab
     }
+    return SA_OK;
+}
+
+// The slop phrases of a phrase batch through the shared launches above (sa_k_span_*_multi).  Phrase i = terms[i][0 .. T[i]),
+// slop[i]; on return handled[i] != 0 says that its dense counts are (being) accumulated in d_out[i] (float[n_docs] inside
+// the index's batch scratch, valid until the next call); the other phrases -- an unknown term, lists long enough for
+// the work-order sort or the separate chunk scan, forced test switches -- are left to sa_span_counts_device.
+// Everything is enqueued on `st`; the caller holds the index lock.
+int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* terms, const int* T, const int* slop,
+                         const float* idf, const u32* rows, float** d_out, unsigned char* handled,
+                         const sa_dense_rank_job** d_rank_jobs, int* n_rank_jobs) {
+    for (int i = 0; i < n; i++) { handled[i] = 0; d_out[i] = nullptr; }
+    *d_rank_jobs = nullptr; *n_rank_jobs = 0;
+    const u64 N = ix->n_docs;
+    if (n <= 0 || N == 0) return SA_OK;
+    {
+        const char* fast_env = getenv("SA_SPAN_FAST");
+        const char* sort_env = getenv("SA_SPAN_SORT");
+        const char* multi_env = getenv("SA_SPAN_MULTI");
+        if ((fast_env && atoi(fast_env) == 0) || (sort_env && atoi(sort_env) > 0) || (multi_env && atoi(multi_env) == 0)) return SA_OK;
+        if (ix->h_term_edge.size() < (size_t)ix->n_terms) return SA_OK;
+    }
+    const char* ddenv = getenv("SA_SPAN_DOCDIR");
+    const bool use_dd = ix->n_dd_terms > 0 && !(ddenv && atoi(ddenv) == 0);
+    std::vector<SpanJob> jobs;
+    std::vector<int> job_row, job_class;
+    std::vector<size_t> job_off;                       // scratch offset of each job
+    size_t used = 0;
+    auto take = [&](size_t bytes) { const size_t o = used; used += (bytes + 255) & ~(size_t)255; return o; };
+    for (int i = 0; i < n; i++) {
+        const int Ti = T[i];
+        if (Ti < 2 || Ti > SA_SPAN_MAX_TERMS || slop[i] <= 0) continue;
+        SpanJob J;
+        memset(&J, 0, sizeof(J));
+        J.st.T = Ti; J.st.n_docs = N;
+        bool ok = true;
+        size_t total_len = 0;
+        for (int t = 0; t < Ti && ok; t++) {
+            const u32 term = terms[i][t];
+            if (term >= ix->n_terms) { ok = false; break; }
+            const u64 off = ix->h_term_off[term];
+            J.st.words[t] = ix->d_words + off;
+            J.st.len[t] = (u32)(ix->h_term_off[term + 1] - off);
+            if (use_dd) {
+                const u32 sl = ix->h_dd_slot[term];
+                if (sl != SA_DD_NONE && sl < ix->h_dd_top.size() && ix->h_dd_top[sl] == 0) J.st.dd[t] = ix->d_docdir + (size_t)sl * N;
+            }
+            total_len += J.st.len[t];
+        }
+        if (!ok || total_len == 0 || J.st.len[0] == 0 || total_len > 0x7FFFFFF0ull) continue;
+        if (J.st.len[0] > (u32)SA_SPAN_SORT_MIN) continue;                         // (would be put in work order)
+        for (int t = 0; t < Ti; t++) J.st.off[t + 1] = J.st.off[t] + J.st.len[t];
+        for (int t = 0; t < Ti; t++) J.ck.coff[t + 1] = J.ck.coff[t] + sa_compact_chunks(J.st.len[t]);
+        for (int t = Ti; t < SA_SPAN_MAX_TERMS; t++) J.ck.coff[t + 1] = J.ck.coff[t];
+        J.n_chunks = J.ck.coff[Ti];
+        if (J.n_chunks == 0 || J.n_chunks > (u32)SA_SPAN_INLINE_SCAN) continue;
+        {
+            // header 0 in L?  (host arithmetic on the index's per-term edge flags, as in sa_span_counts_device)
+            const unsigned char e0 = ix->h_term_edge[terms[i][0]];
+            bool L = true;
+            for (int t = 1; t < Ti; t++) {
+                const unsigned char ei = ix->h_term_edge[terms[i][t]];
+                const bool a0 = e0 & 1, a0m = e0 & 2, bi = ei & 1, bim = ei & 2;
+                L &= (a0 && bi) || (bi && a0m) || (a0 && bim);
+            }
+            J.wrap_host = L ? 1 : 0;
+        }
+        // scratch of this phrase (offsets now, addresses once the buffer is known)
+        job_off.push_back(used);
+        take(SA_SPAN_CNT_WORDS * 4);
+        take(((size_t)2 * J.n_chunks + 8) * 4);
+        take(total_len + 64);
+        take(((size_t)J.st.len[0] + 64) * 4);                        // groups the fast pass abandons
+        for (int t = 0; t < Ti; t++) { take(((size_t)J.st.len[t] + 1) * 8); take(((size_t)J.st.len[t] + 1) * 4); take((size_t)J.st.len[t] + 1); }
+        J.mp.T = Ti; J.mp.slop = (u32)slop[i]; J.mp.n_docs = N;
+        J.g_flags = std::min<u32>(16384u, J.st.off[Ti] / 256u + 1u);
+        J.g_chunks = std::min<u32>(16384u, J.n_chunks);
+        J.g_flat = (J.st.len[0] + 63u) / 64u;
+        J.g_wave = std::min<u32>(128u, J.st.len[0]);                // (the fast pass abandons a few per cent of the groups at most; the blocks stride)
+        jobs.push_back(J);
+        job_row.push_back(i);
+        job_class.push_back(Ti == 2 ? 0 : Ti == 3 ? 1 : Ti == 4 ? 2 : 3);
+    }
+    const int nj = (int)jobs.size();
+    if (nj == 0) return SA_OK;
+    // jobs of a class are neighbours in the device array
+    std::vector<int> order((size_t)nj);
+    for (int j = 0; j < nj; j++) order[(size_t)j] = j;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return job_class[(size_t)a] < job_class[(size_t)b]; });
+    // (the ranking jobs -- counts, idf, batch row of every phrase taken -- ride behind the span jobs in the same upload)
+    const size_t span_jobs_bytes = ((size_t)nj * sizeof(SpanJob) + 255) & ~(size_t)255;
+    const size_t jobs_bytes = span_jobs_bytes + (((size_t)nj * sizeof(sa_dense_rank_job) + 255) & ~(size_t)255);
+    const size_t need = jobs_bytes + used + 4096;
+    if (ix->span_batch_bytes < need) {
+        SA_HIP(hipStreamSynchronize(st));
+        if (ix->d_span_batch) SA_HIP(hipFree(ix->d_span_batch));
+        ix->d_span_batch = nullptr; ix->span_batch_bytes = 0;
+        SA_HIP(hipMalloc(&ix->d_span_batch, need + need / 4));
+        ix->span_batch_bytes = need + need / 4;
+    }
+    if (ix->span_jobs_host_bytes < jobs_bytes) {
+        if (ix->ev_span_jobs) SA_HIP(hipEventSynchronize(ix->ev_span_jobs));
+        if (ix->h_span_jobs) SA_HIP(hipHostFree(ix->h_span_jobs));
+        ix->h_span_jobs = nullptr; ix->span_jobs_host_bytes = 0;
+        SA_HIP(hipHostMalloc(&ix->h_span_jobs, jobs_bytes * 2, 0));
+        ix->span_jobs_host_bytes = jobs_bytes * 2;
+    }
+    // The dense count vectors come from a pool of their own that is all zeros between runs: the launch that ranks a
+    // vector puts back a zero wherever it read a count (sa_k_dense_topk_tiles_multi), so no run clears B x n_docs
+    // floats.  A run that did not get as far as its ranking launch leaves the pool marked dirty: cleared here.
+    const size_t cstride = (size_t)((N + 64) & ~(u64)63);
+    if (ix->span_counts_cap < (size_t)nj * cstride) {
+        SA_HIP(hipStreamSynchronize(st));
+        if (ix->d_span_counts) SA_HIP(hipFree(ix->d_span_counts));
+        ix->d_span_counts = nullptr; ix->span_counts_cap = 0;
+        SA_HIP(hipMalloc(&ix->d_span_counts, (size_t)nj * cstride * sizeof(float)));
+        ix->span_counts_cap = (size_t)nj * cstride;
+        ix->span_counts_dirty = true;
+    }
+    if (ix->span_counts_dirty) SA_HIP(hipMemsetAsync(ix->d_span_counts, 0, ix->span_counts_cap * sizeof(float), st));
+    ix->span_counts_dirty = true;                                   // (until the caller has enqueued the ranking launch)
+    if (!ix->ev_span_jobs) SA_HIP(hipEventCreateWithFlags(&ix->ev_span_jobs, hipEventDisableTiming));
+    else SA_HIP(hipEventSynchronize(ix->ev_span_jobs));             // (the previous upload has left the host image)
+    char* base = (char*)ix->d_span_batch + jobs_bytes;
+    SpanJob* hj = (SpanJob*)ix->h_span_jobs;
+    sa_dense_rank_job* hr = (sa_dense_rank_job*)((char*)ix->h_span_jobs + span_jobs_bytes);
+    int class_first[5] = {0, 0, 0, 0, 0};
+    for (int q = 0; q < nj; q++) {
+        const int j = order[(size_t)q];
+        SpanJob J = jobs[(size_t)j];
+        size_t o = job_off[(size_t)j];
+        auto next = [&](size_t bytes) { char* p = base + o; o += (bytes + 255) & ~(size_t)255; return p; };
+        const int Ti = J.st.T;
+        float* running = ix->d_span_counts + (size_t)q * cstride;
+        J.cnt = (u32*)next(SA_SPAN_CNT_WORDS * 4);
+        J.chunks = (u32*)next(((size_t)2 * J.n_chunks + 8) * 4);
+        J.flags = (unsigned char*)next((size_t)J.st.off[Ti] + 64);
+        u32* over_list = (u32*)next(((size_t)J.st.len[0] + 64) * 4);
+        for (int t = 0; t < Ti; t++) {
+            u64* cand = (u64*)next(((size_t)J.st.len[t] + 1) * 8);
+            u32* heads = (u32*)next(((size_t)J.st.len[t] + 1) * 4);
+            J.co.cand[t] = cand; J.co.heads[t] = heads;
+            J.co.gpos[t] = (unsigned char*)next((size_t)J.st.len[t] + 1);
+            J.mp.cand[t] = cand; J.mp.n_cand[t] = J.cnt + t; J.mp.heads[t] = heads; J.mp.n_heads[t] = J.cnt + SA_SPAN_MAX_TERMS + t;
+        }
+        J.mp.fcounts = running;
+        J.mp.over_list = over_list; J.mp.over_cnt = J.cnt + 4 * SA_SPAN_MAX_TERMS;
+        J.mp.in_list = over_list; J.mp.in_cnt = J.cnt + 4 * SA_SPAN_MAX_TERMS;
+        hj[q] = J;
+        hr[q].counts = running; hr[q].idf = idf[job_row[(size_t)j]]; hr[q].row = rows[job_row[(size_t)j]];
+        d_out[job_row[(size_t)j]] = running;
+        handled[job_row[(size_t)j]] = 1;
+        class_first[job_class[(size_t)j] + 1] = q + 1;
+    }
+    for (int c = 1; c <= 4; c++) if (class_first[c] < class_first[c - 1]) class_first[c] = class_first[c - 1];
+    SA_HIP(hipMemcpyAsync(ix->d_span_batch, hj, jobs_bytes, hipMemcpyHostToDevice, st));
+    *d_rank_jobs = (const sa_dense_rank_job*)((char*)ix->d_span_batch + span_jobs_bytes);
+    *n_rank_jobs = nj;
+    SA_HIP(hipEventRecord(ix->ev_span_jobs, st));
+    const SpanJob* dj = (const SpanJob*)ix->d_span_batch;
+    for (int c = 0; c < 4; c++) {
+        const int a = class_first[c], b = class_first[c + 1];
+        if (b <= a) continue;
+        u32 gf = 1, gc = 1, gl = 1, gw = 1;
+        for (int q = a; q < b; q++) {
+            gf = std::max(gf, hj[q].g_flags); gc = std::max(gc, hj[q].g_chunks);
+            gl = std::max(gl, hj[q].g_flat); gw = std::max(gw, hj[q].g_wave);
+        }
+        const u32 nb = (u32)(b - a);
+        const SpanJob* jc = dj + a;
+        switch (c) {
+        case 0: hipLaunchKernelGGL(sa_k_span_flags_multi<2>, dim3(gf, nb), dim3(256), 0, st, jc); break;
+        case 1: hipLaunchKernelGGL(sa_k_span_flags_multi<3>, dim3(gf, nb), dim3(256), 0, st, jc); break;
+        case 2: hipLaunchKernelGGL(sa_k_span_flags_multi<4>, dim3(gf, nb), dim3(256), 0, st, jc); break;
+        default: hipLaunchKernelGGL(sa_k_span_flags_multi<0>, dim3(gf, nb), dim3(256), 0, st, jc); break;
+        }
+        hipLaunchKernelGGL(sa_k_span_compact_count_multi, dim3(gc, nb), dim3(SA_CT), 0, st, jc);
+        hipLaunchKernelGGL(sa_k_span_compact_emit_multi, dim3(gc, nb), dim3(SA_CT), 0, st, jc);
+        if (c == 0) hipLaunchKernelGGL((sa_k_span_machine_flat_multi<SA_SPAN_LDS, SA_SPAN_PMAX, 2>), dim3(gl, nb), dim3(64), 0, st, jc);
+        else if (c == 1) hipLaunchKernelGGL((sa_k_span_machine_flat_multi<20, 20, 3>), dim3(gl, nb), dim3(64), 0, st, jc);
+        else hipLaunchKernelGGL((sa_k_span_machine_flat_multi<20, 20, 0>), dim3(gl, nb), dim3(64), 0, st, jc);
+        hipLaunchKernelGGL(sa_k_span_machine_wave_multi, dim3(gw, nb), dim3(64), 0, st, jc);
+    }
+    SA_HIP(hipGetLastError());
     return SA_OK;
 }
 

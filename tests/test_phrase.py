@@ -570,3 +570,37 @@ def test_phrases_of_any_length_and_slop_phrases_up_to_32_terms(api):
         assert np.array_equal(ps[i, :n], ws[:n]) and np.array_equal(pd_[i, :n], wd[:n]), f"batch phrase {i}"
     pb.close()
     dev.close()
+
+
+def test_slop_phrases_of_a_batch_share_their_launches(api, monkeypatch):
+    """Phrase batches score their slop phrases in SHARED launches (sa_span_counts_batch: blockIdx.y picks the phrase; one
+    launch per stage and class of phrases -- 2, 3, 4, more terms -- and one ranking launch for all of them).  Mixed term
+    counts and slops, an unknown term, an exact and a repeated-term phrase beside them: top-k equal to the oracle's and to
+    the one-phrase-at-a-time route (SA_SPAN_MULTI=0)."""
+    g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_small")
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    orc = O.OracleIndex.from_triples(t, d, p, num_docs, doc_lens=lens)
+    rng = np.random.default_rng(3)
+    phrases, slops = [], []
+    for T in (2, 2, 3, 2, 4, 3, 5, 2, 6, 2, 3, 4):
+        phrases.append([int(x) for x in rng.choice(min(vocab, 30), T, replace=False)])
+        slops.append(int(rng.integers(1, 4)))
+    phrases += [[0, 1], [2, 2, 3], [1, vocab + 7]]
+    slops += [0, 0, 2]
+    k = 8
+    results = {}
+    for multi in ("1", "0"):
+        monkeypatch.setenv("SA_SPAN_MULTI", multi)
+        pb = dev.phrase_batch(phrases, k=k, slop=slops)
+        for _ in range(2):
+            pb.run()
+        results[multi] = pb.fetch()
+        pb.close()
+    assert np.array_equal(results["1"][0], results["0"][0]) and np.array_equal(results["1"][1], results["0"][1])
+    ps, pd_ = results["1"]
+    for i, (ph, sl) in enumerate(zip(phrases, slops)):
+        ws, wd = O.topk(orc.score(list(ph), slop=sl), k)
+        n = int((ws > 0).sum())
+        assert np.array_equal(ps[i, :n], ws[:n]) and np.array_equal(pd_[i, :n], wd[:n]), f"phrase {ph} slop {sl}"
+    dev.close()
