@@ -79,6 +79,8 @@ def parse_args():
                          "posting like the reference; the other mode is always reported beside it)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of each CPU baseline leg")
     ap.add_argument("--query-sets", type=int, default=8, help="seeded query sets the main leg rotates through")
+    ap.add_argument("--scaled-queries", type=int, default=2048,
+                    help="queries per step of the scaled_batch leg (sharded runs: per-rank work does not shrink with N); 0: off")
     ap.add_argument("--pipeline", type=int, default=6, help="batch objects (= batches in flight, one stream each) of the main leg")
     ap.add_argument("--no-phrase-legs", action="store_true", help="skip the zipf-1M phrase / slop legs")
     ap.add_argument("--phrase-docs", type=int, default=1_000_000)
@@ -166,6 +168,7 @@ class Rank:
         # SA_BENCH_FORCE_COMM=1: take the communicator path with a single rank too (exercises the RCCL
         # bootstrap, all-reduce, barrier and exchange on a one-GPU box)
         self.use_comm = self.world > 1 or os.environ.get("SA_BENCH_FORCE_COMM") == "1"
+        self.idf_table = None
 
     # -- corpus (host only: nothing here touches the GPU) -----------------------------------------
     def generate(self):
@@ -223,15 +226,20 @@ class Rank:
     def idf_of(self, queries):
         """idf weights [B][T] as the reference forms them per term -- float64 numpy, then float32 (similarity.py:19-21,
         bm25.pyx:31) -- for a whole batch at once: this is host work of every NEW batch and is inside the timed step"""
-        dfs = self.df[np.asarray(queries, dtype=np.int64)]
-        return np.log(1 + (self.args.docs - dfs + 0.5) / (dfs + 0.5)).astype(np.float32)
+        if self.idf_table is None:
+            # one float64 log per TERM of the vocabulary, once (index-time statistics, as df itself); a batch gathers
+            dfs = self.df
+            self.idf_table = np.log(1 + (self.args.docs - dfs + 0.5) / (dfs + 0.5)).astype(np.float32)
+        return self.idf_table[queries]
 
-    def make_batch(self, queries):
+    def make_batch(self, queries, check=True):
         from searcharray_amd.device_index import QueryBatch, compute_idf
         D = self.args.docs
-        idf = np.asarray([[compute_idf(D, np.asarray([self.df[t]])) for t in q] for q in queries], dtype=np.float32)
-        if not np.array_equal(idf, self.idf_of(queries)):
-            raise AssertionError("vectorised idf differs from the reference's per-term compute_idf")
+        idf = self.idf_of(queries)
+        if check:                                            # (the vectorised table against the reference's per-term arithmetic)
+            ref = np.asarray([[compute_idf(D, np.asarray([self.df[t]])) for t in q] for q in queries], dtype=np.float32)
+            if not np.array_equal(ref, idf):
+                raise AssertionError("vectorised idf differs from the reference's per-term compute_idf")
         return QueryBatch(self.index, queries, k=self.args.k, idf=idf)
 
     # -- collectives over the library's communicator -----------------------------------------------
@@ -823,6 +831,22 @@ def main():
         scores, docs = scores_r, docs_r
     fresh_equals_replay = bool(np.array_equal(scores, scores_r) and np.array_equal(docs, docs_r))
 
+    # sharded runs: the same stream with bigger batches -- per-rank device work shrinks with N, the host's cost per batch
+    # (idf gather, reset, ~15 launches, fetch) does not; 8 x the queries per step keeps a rank's step at the 1-GPU size
+    scaled = None
+    if r.use_comm and args.scaled_queries > B:
+        B2 = args.scaled_queries
+        sets2 = [np.concatenate([synth.bm25_queries(B, vocab=V, seed=5000 + 97 * i + j) for j in range(B2 // B)])[:B2]
+                 for i in range(4)]
+        ring2 = [r.make_batch(sets2[i % len(sets2)], check=False) for i in range(min(P, 4))]
+        Ks = max(4, K // 4)
+        dts, _ = r.timed_fresh(ring2, sets2, len(ring2), Ks)
+        scaled = {"value": round(B2 * Ks / dts, 2), "unit": "queries/s", "queries_per_step": B2, "steps": Ks,
+                  "ms_per_step": round(dts / Ks * 1e3, 4), "batches_in_flight": len(ring2),
+                  "note": "fresh batches of 8 x the queries (rotating sets, reset + run + fetch per step), same index"}
+        for b in ring2:
+            b.close()
+
     os.environ["SA_SPARSE"] = "1" if exhaustive else "0"
     K2 = max(3, min(K, 10))
     dt2 = r.timed(batch, 2, K2)
@@ -902,6 +926,7 @@ def main():
                        "fresh_equals_replay": fresh_equals_replay,
                        "note": "set 0 resident, sa_batch_run only -- no reset, no fetch (rounds 1-2 reported this as `value`)"},
             "roofline": exh_block if exhaustive else prn_block,
+            "scaled_batch": scaled,
             ("dynamic_pruning" if exhaustive else "exhaustive"): other,
             "cpu_baseline": cpu,
             "parity_check": parity,
