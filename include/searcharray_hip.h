@@ -112,7 +112,7 @@ int sa_payload_slice(const uint64_t* arr, int64_t n, uint64_t payload_msb_mask, 
 /* span_search(posns, lengths, phrase_freqs, slop, key_mask, header_mask, key_bits, lsb_bits)
  * reference searcharray/roaringish/spans.pyx:189-330: the slop > 0 span state machine over the
  * terms' candidate words, term t = posns[lengths[t] : lengths[t + 1]] (what phrase/spans.py:171-187
- * passes after _intersect_all; default 28 / 18 / 18 layout, at most 16 terms).  Returns the documents
+ * passes after _intersect_all; default 28 / 18 / 18 layout, at most 32 terms).  Returns the documents
  * whose count the walk raised, ascending, and the increments -- the values the reference adds into its
  * Counter.  Outputs sized by the number of distinct doc ids in the input (<= lengths[n_terms] - lengths[0]). */
 int sa_span_search(const uint64_t* posns, const uint64_t* lengths, int n_terms, uint64_t slop,
@@ -200,7 +200,7 @@ int sa_index_bm25_dense(sa_index_t* ix, const uint32_t* terms, const float* idf,
  * (postings.py:705-708); n_terms < 2 is an error (middle_out.py:425-426).
  * slop > 0 runs the reference's span search (phrase/spans.py:71-187, roaringish/spans.pyx:189-319):
  * header-set candidate selection + one thread per document replaying the 512-span state machine,
- * with the reference's observable quirks; at most 16 terms. */
+ * with the reference's observable quirks; at most 32 terms. */
 int sa_index_phrase_freqs_dense(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop, float* out);
 
 /* The same with the reference's min_posn / max_posn restriction (-1 = None): every term's words are
@@ -253,7 +253,7 @@ int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const float* idf, int
  * caller loop `for phrase in phrases: top_k(arr.score(phrase))` around reference
  * SearchArray.score (postings.py:652-680) -> PosnBitArray.phrase_freqs (middle_out.py:418-446) ->
  * compute_phrase_freqs (middle_out.py:73-168) -> bm25 (similarity.py:24-38).  terms is
- * [B][max_terms] row-major, phrase i uses its first n_terms[i] entries (2 <= n_terms[i] <= 128; fewer
+ * [B][max_terms] row-major, phrase i uses its first n_terms[i] entries (n_terms[i] >= 2, no upper limit; fewer
  * than two terms is SA_ERR_ARG like the reference's ValueError, middle_out.py:425-426).  Exact phrases of
  * up to 18 pairwise-distinct terms are scored tile by tile; the others take the dense route described at
  * sa_phrase_batch_create_ex.  idf[B] is the per-phrase idf the host sums over the phrase's
@@ -263,10 +263,10 @@ int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const float* idf, int
 int sa_phrase_batch_create(sa_index_t* ix, const uint32_t* terms, const int32_t* n_terms, const float* idf,
                            int n_phrases, int max_terms, int k, float k1, float b, sa_batch_t** out);
 /* The same with a slop per phrase (slop == NULL: all exact): slop[i] > 0 scores phrase i with the reference's span
- * search (phrase/spans.py:71-187, roaringish/spans.pyx:189-319; at most 16 terms), as SearchArray.score(phrase,
+ * search (phrase/spans.py:71-187, roaringish/spans.pyx:189-319; at most 32 terms), as SearchArray.score(phrase,
  * slop=...) does.  Any phrase score() accepts is accepted: phrases with repeated terms, with more than 18 terms
- * (up to 128) or with slop > 0 are counted over the whole shard by the single-phrase kernels and ranked on the
- * device; only the B x k results leave it. */
+ * or with slop > 0 are counted over the whole shard -- the slop phrases of a batch in SHARED launches -- and ranked on
+ * the device; only the B x k results leave it. */
 int sa_phrase_batch_create_ex(sa_index_t* ix, const uint32_t* terms, const int32_t* n_terms, const int32_t* slop,
                               const float* idf, int n_phrases, int max_terms, int k, float k1, float b, sa_batch_t** out);
 /* A NEW set of queries in an existing batch (same n_queries, n_query_terms, k, k1, b as at creation): what

@@ -50,12 +50,18 @@ def main():
             np.savez(cpath, words=corpus.words, term_off=corpus.term_off, doc_lens=corpus.doc_lens)
     B = args.queries
     qsets = {"baseline": synth.bm25_queries(B, vocab=V), "distinct": synth.bm25_queries_distinct(B, vocab=V) if 4 * B <= V else None}
+    # "hot": every query's further terms drawn from FOUR terms per band, so their posting slices stay in L2 -- what the
+    # kernel costs when memory latency is out of the picture
+    hot = qsets["baseline"].copy()
+    for c in (1, 2, 3):
+        hot[:, c] = hot[:4, c][np.arange(B) % 4]
+    qsets["hot"] = hot
     qsets = {k_: v for k_, v in qsets.items() if k_ in args.qsets.split(",") and v is not None}
     envs = [dict(kv.split("=") for kv in cfg.split(",") if kv) for cfg in args.envs.split(";")]
     ref = {}
     for lib in args.libs.split(","):
         path = lib if os.path.isabs(lib) else os.path.join(ROOT, lib)
-        api = _lib.bind(ctypes.CDLL(path), path)
+        api = _lib.bind(ctypes.CDLL(path), path, allow_missing=True)         # (an older build lacks the newer entry points)
         index = DeviceIndex(corpus.words, corpus.term_off, corpus.doc_lens, tile_docs=args.tile, api=api)
         df = index.docfreqs()
         for qname, queries in qsets.items():

@@ -1,28 +1,34 @@
 #!/usr/bin/env python
-"""Copy the outputs of scripts/gpu_full_r2.sh from gpurun_out/ into profiles/ (tracked), named per round:
+"""Copy the outputs of scripts/gpu_full_r3.sh from gpurun_out/ (scratch) into profiles/ (tracked), named per round:
 bench JSON lines (which carry their own PMC traffic / L2 hit rates: bench.py profiles itself under rocprofv3),
-rocprofv3 kernel stats, and the SQ counters of the scoring kernels."""
+rocprofv3 kernel stats per leg, SQ counters of the scoring kernels, the HIP-API summary of the fresh-batch loop's
+steady state, PMC traffic of the phrase and slop kernels."""
 import csv
 import glob
 import json
 import os
 import shutil
+import subprocess
 import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 PROF = os.path.join(ROOT, "profiles")
-RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
-def last_json_line(path):
+def json_lines(path):
     if not os.path.exists(path):
-        return None
-    for line in reversed(open(path).read().splitlines()):
+        return []
+    out = []
+    for line in open(path).read().splitlines():
         if line.startswith("{"):
-            return json.loads(line)
-    return None
+            try:
+                out.append(json.loads(line))
+            except ValueError:
+                pass
+    return out
 
 
 def newest(pattern):
@@ -30,65 +36,121 @@ def newest(pattern):
     return fs[-1] if fs else None
 
 
+def hip_api_counts(sub):
+    """{api: (calls, total ns)} from a rocprofv3 --hip-trace --stats run"""
+    f = newest(os.path.join(OUT, sub, "**", "*hip_api_stats.csv")) or newest(os.path.join(OUT, sub, "**", "*hip_stats.csv"))
+    if not f:
+        return None
+    res = {}
+    for r in csv.DictReader(open(f)):
+        res[r["Name"]] = (int(r["Calls"]), int(float(r["TotalDurationNs"])))
+    return res
+
+
+def pmc_per_kernel(fetch_dir, write_dir, prefix="sa_k_"):
+    """mean per dispatch: FETCH_SIZE (KiB, raw), WRITE_SIZE (KiB), L2 hit rate, duration"""
+    acc = defaultdict(lambda: defaultdict(list))
+    for sub in (fetch_dir, write_dir):
+        f = newest(os.path.join(OUT, sub, "**", "*counter_collection.csv"))
+        if not f:
+            continue
+        per = defaultdict(lambda: defaultdict(float))
+        meta = {}
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            if not k.startswith(prefix):
+                continue
+            did = int(r["Dispatch_Id"])
+            meta[did] = (k, int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            per[did][r["Counter_Name"]] += float(r["Counter_Value"])
+        for did, cs in per.items():
+            k, dur = meta[did]
+            for c, v in cs.items():
+                acc[k][c].append(v)
+            acc[k]["_dur_" + sub].append(dur)
+    out = {}
+    for k, cs in acc.items():
+        e = {"dispatches": max(len(v) for v in cs.values())}
+        if "FETCH_SIZE" in cs:
+            e["fetch_KiB_raw"] = round(sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]), 1)
+            e["fetch_bytes_x2_wide_read_correction"] = int(e["fetch_KiB_raw"] * 1024 * 2)
+        if "WRITE_SIZE" in cs:
+            e["write_KiB"] = round(sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]), 1)
+        h, m = sum(cs.get("TCC_HIT_sum", [])), sum(cs.get("TCC_MISS_sum", []))
+        if h + m > 0:
+            e["l2_hit_rate"] = round(h / (h + m), 4)
+        durs = [x for kk, v in cs.items() if kk.startswith("_dur_") for x in v]
+        if durs:
+            e["mean_us_under_pmc"] = round(sum(durs) / len(durs) / 1e3, 2)
+        out[k] = e
+    return out
+
+
 def main():
     os.makedirs(PROF, exist_ok=True)
     for src, dst in [("bench.log", f"bench_{RND}.json"), ("bench_k100.log", f"bench_{RND}_k100.json"),
-                     ("bench_k1000.log", f"bench_{RND}_k1000.json"), ("bench_nogroup.log", f"bench_{RND}_per_query_kernel.json"),
-                     ("bench_comm1.log", f"bench_{RND}_comm_1rank.json"), ("dist1_rccl.log", f"bench_{RND}_dist1rank_1250k.json"),
-                     ("phrase_bench.log", f"phrase_bench_{RND}.json"), ("slop_bench.log", f"slop_bench_{RND}.json"),
-                     ("io_bench.log", f"io_bench_{RND}.json"), ("sim_bench.log", f"sim_bench_{RND}.json")]:
-        j = last_json_line(os.path.join(OUT, src))
-        if j is not None:
-            json.dump(j, open(os.path.join(PROF, dst), "w"), indent=1)
+                     ("bench_k1000.log", f"bench_{RND}_k1000.json"), ("bench_comm1.log", f"bench_{RND}_comm_1rank.json"),
+                     ("dist1_rccl.log", f"bench_{RND}_dist1rank_1250k.json"), ("rank_nocomm.log", f"bench_{RND}_rank_sized_1250k_nocomm.json"),
+                     ("phrase_bench.log", f"phrase_bench_{RND}.json"), ("slop_bench.log", f"slop_bench_{RND}.json")]:
+        js = json_lines(os.path.join(OUT, src))
+        if js:
+            json.dump(js[-1], open(os.path.join(PROF, dst), "w"), indent=1)
             print("wrote", dst)
-    ab = os.path.join(OUT, "group_ab.log")
-    if os.path.exists(ab):
-        lines = [ln for ln in open(ab).read().splitlines() if ln.startswith("{")]
-        if lines:
-            open(os.path.join(PROF, f"group_ab_{RND}.jsonl"), "w").write("\n".join(lines) + "\n")
-            print("wrote", f"group_ab_{RND}.jsonl")
-    for sub, dst in [("prof_stats", f"{RND}_bench_kernel_stats.csv"), ("prof_phrase", f"{RND}_phrase_bench_kernel_stats.csv"),
-                     ("prof_slop", f"{RND}_slop_bench_kernel_stats.csv"),
-                     ("prof_slop2", f"{RND}_slop_heaviest_2term_kernel_stats.csv"),      # scripts/slop_heavy.py: 6 runs of ONE query
+    for src, dst in [("kernel_ab.log", f"kernel_ab_{RND}.jsonl"), ("host_cost.log", f"host_cost_{RND}.jsonl"),
+                     ("slop_heavy.log", f"slop_heaviest_{RND}.jsonl")]:
+        js = json_lines(os.path.join(OUT, src))
+        if js:
+            open(os.path.join(PROF, dst), "w").write("\n".join(json.dumps(j) for j in js) + "\n")
+            print("wrote", dst)
+    for sub, dst in [("prof_main", f"{RND}_main_leg_kernel_stats.csv"), ("prof_distinct", f"{RND}_distinct_leg_kernel_stats.csv"),
+                     ("prof_bench", f"{RND}_bench_kernel_stats.csv"), ("prof_phrase", f"{RND}_phrase_bench_kernel_stats.csv"),
+                     ("prof_slop", f"{RND}_slop_bench_kernel_stats.csv"), ("prof_slopb", f"{RND}_phrase_slop_batch_legs_kernel_stats.csv"),
+                     ("prof_slop2", f"{RND}_slop_heaviest_2term_kernel_stats.csv"),
                      ("prof_slop3", f"{RND}_slop_heaviest_3term_kernel_stats.csv")]:
         f = newest(os.path.join(OUT, sub, "**", "*kernel_stats.csv"))
         if f:
             shutil.copy(f, os.path.join(PROF, dst))
             print("wrote", dst)
-    # HBM traffic of the slop pipeline (scripts/gpu_slop_pmc.sh + scripts/slop_pmc.py)
+    sq = os.path.join(OUT, "sq_summary.json")
+    if os.path.exists(sq) and os.path.getsize(sq) > 10:
+        out = {"command": "rocprofv3 --pmc <8 SQ counters> --kernel-trace -- python scripts/ab.py --ks 10 --steps 2 (two passes); 10M docs, "
+                          "256 x 4-term BASELINE queries, top-10, one resident batch (grouped exhaustive path); mean per dispatch; "
+                          "SQ_WAVE_CYCLES / SQ_BUSY_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles",
+               "kernels": json.load(open(sq))}
+        json.dump(out, open(os.path.join(PROF, f"{RND}_scoring_kernels_sq_counters.json"), "w"), indent=1)
+        print("wrote", f"{RND}_scoring_kernels_sq_counters.json")
+    # the steady state of the fresh-batch loop: HIP API calls of 600 steps minus those of 100 steps, per step
+    a, b = hip_api_counts("prof_hip_a"), hip_api_counts("prof_hip_b")
+    if a and b:
+        la, lb = json_lines(os.path.join(OUT, "prof_hip_a.log")), json_lines(os.path.join(OUT, "prof_hip_b.log"))
+        sa, sb = (la[-1]["steps"] if la else 100), (lb[-1]["steps"] if lb else 600)
+        per_step = {}
+        for name in sorted(set(a) | set(b)):
+            d = b.get(name, (0, 0))[0] - a.get(name, (0, 0))[0]
+            if d:
+                per_step[name] = round(d / (sb - sa), 3)
+        alloc = {n: (a.get(n, (0, 0))[0], b.get(n, (0, 0))[0]) for n in sorted(set(a) | set(b))
+                 if any(x in n for x in ("Malloc", "Free", "HostRegister", "hipMemcpy ", "hipMemcpy\"")) or n in ("hipMemcpy", "hipStreamSynchronize", "hipDeviceSynchronize")}
+        json.dump({"command": f"rocprofv3 --hip-trace --stats -- python scripts/fresh_trace.py --steps {sa} | {sb} (10 M docs, 8 rotating query "
+                              "sets, 6 batches in flight: idf gather + sa_batch_reset + sa_batch_run + sa_batch_fetch per step)",
+                   "runs": [la[-1] if la else None, lb[-1] if lb else None],
+                   "hip_calls_per_steady_state_step": per_step,
+                   "allocation_and_blocking_calls_total_in_run_a_vs_run_b": alloc,
+                   "note": "identical totals in both runs = none of these is called in the steady state"},
+                  open(os.path.join(PROF, f"{RND}_fresh_batches_hip_api.json"), "w"), indent=1)
+        print("wrote", f"{RND}_fresh_batches_hip_api.json")
+    ph = pmc_per_kernel("pmc_phrase_f", "pmc_phrase_w", prefix="sa_k_phrase")
+    if ph:
+        json.dump({"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace -- python scripts/phrase_bench.py "
+                              "--phrases 16 --cpu-phrases 1 (zipf-1M; single dense calls: sa_k_phrase_fused; 256-phrase batches: sa_k_phrase_tiles); "
+                              "mean per dispatch", "kernels": ph},
+                  open(os.path.join(PROF, f"{RND}_phrase_pmc_traffic.json"), "w"), indent=1)
+        print("wrote", f"{RND}_phrase_pmc_traffic.json")
     if newest(os.path.join(OUT, "pmc_slop_f", "**", "*counter_collection.csv")):
-        import subprocess
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "slop_pmc.py"), OUT], capture_output=True, text=True)
         if r.returncode == 0 and r.stdout.strip().startswith("{"):
             open(os.path.join(PROF, f"{RND}_slop_pmc_traffic.json"), "w").write(r.stdout)
             print("wrote", f"{RND}_slop_pmc_traffic.json")
-    hv = os.path.join(OUT, "slop_heavy.log")
-    if os.path.exists(hv):
-        lines = [ln for ln in open(hv).read().splitlines() if ln.startswith("{")]
-        if lines:
-            open(os.path.join(PROF, f"slop_heaviest_{RND}.jsonl"), "w").write("\n".join(lines) + "\n")
-            print("wrote", f"slop_heaviest_{RND}.jsonl")
-    # SQ counters of the scoring kernels (two passes of 8 counters), mean per dispatch
-    sq = {}
-    for sub in ("prof_grp_sq", "prof_grp_sq2"):
-        f = newest(os.path.join(OUT, sub, "**", "*counter_collection.csv"))
-        if not f:
-            continue
-        acc = defaultdict(lambda: defaultdict(list))
-        for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-            if "bm25" in k or "topk_merge" in k:
-                acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        for k, v in acc.items():
-            sq.setdefault(k, {}).update({c: round(sum(x) / len(x)) for c, x in v.items()})
-            sq[k]["dispatches"] = len(next(iter(v.values())))
-    if sq:
-        out = {"command": "rocprofv3 --pmc <8 SQ counters> --kernel-trace -- python scripts/group_ab.py --ks 10 --only 1 --qsets baseline --steps 2 "
-                          "(two passes); 10M docs, 256 x 4-term BASELINE queries, top-10, grouped exhaustive path; mean per dispatch; "
-                          "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)",
-               "kernels": sq}
-        json.dump(out, open(os.path.join(PROF, f"{RND}_scoring_kernels_sq_counters.json"), "w"), indent=1)
-        print("wrote", f"{RND}_scoring_kernels_sq_counters.json")
 
 
 if __name__ == "__main__":

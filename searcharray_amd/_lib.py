@@ -143,7 +143,7 @@ class HipApi:
     """Bound C ABI.  ``api.sa_xxx(...)`` returns the raw status; ``api.call('sa_xxx', ...)``
     raises SearchArrayHipError on a non-zero status."""
 
-    def __init__(self, cdll: ctypes.CDLL, path: str):
+    def __init__(self, cdll: ctypes.CDLL, path: str, allow_missing: bool = False):
         self._cdll = cdll
         self.path = path
         missing = []
@@ -156,7 +156,7 @@ class HipApi:
             fn.restype = restype
             fn.argtypes = argtypes
             setattr(self, name, fn)
-        if missing:
+        if missing and not allow_missing:       # (allow_missing: scripts/ab.py binding an OLDER build of the library for a same-box A/B)
             raise SearchArrayHipError(f"{path} does not export: {', '.join(missing)}")
 
     def last_error(self) -> str:
@@ -169,8 +169,8 @@ class HipApi:
             raise SearchArrayHipError(f"{name} failed ({rc}): {self.last_error()}")
 
 
-def bind(cdll: ctypes.CDLL, path: str = "<cdll>") -> HipApi:
-    return HipApi(cdll, path)
+def bind(cdll: ctypes.CDLL, path: str = "<cdll>", allow_missing: bool = False) -> HipApi:
+    return HipApi(cdll, path, allow_missing)
 
 
 _api = None

@@ -2123,7 +2123,9 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     //  batch would fall to the per-query exhaustive kernel, which pruning beats 2x)
     const bool group_can_run = bt->n_groups && p.pruned && hist_possible && p.imp && !p.no_topk && sa_env_int("SA_GROUP", 1) != 0 &&
                                (ix->tile_docs == 1024 || ix->tile_docs == 2048 || ix->tile_docs == 4096);
-    const bool shared_heads = bt->n_shared_rows * 4u >= bt->B * 3u && bt->k >= 32u && group_can_run;
+    // Round 3: the grouped kernel (4 waves per SIMD, ~100 VALU instructions per (tile, query) pair) beats pruning on such
+    // batches from k = 10 on (10 M docs, BASELINE batch, k = 10: 0.46 vs 0.63 ms per step) -- no lower limit on k any more.
+    const bool shared_heads = bt->n_shared_rows * 4u >= bt->B * 3u && group_can_run;
     const bool sparse_wanted = sparse_env >= 0 ? sparse_env != 0 : (ix->n_docs >= (u64)bt->k * 32768ull && !shared_heads);
     const bool sparse = hist_possible && ix->tile_docs <= 8192 && bt->sparse_ok && ix->avg_doc_len != 0.f && ix->n_tiles > 0 &&
                         sparse_wanted;
@@ -2160,7 +2162,7 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
                 // Queries that share their first term: the first tiles through the per-query kernel, which
                 // establishes every query's bound (k-th best score so far), then one wave per (tile, group).
                 // Queries without a group go through the per-query kernel over all tiles.
-                u32 warm = std::max<u32>(16u, bt->k / 4u);
+                u32 warm = std::max<u32>(16u, bt->k / 8u);     // (k = 1000, 10 M docs: 250 / 128 / 64 warm-up tiles -> 1.07 / 1.02 / 1.05 ms per step)
                 if (const char* v = getenv("SA_GROUP_WARM")) warm = (u32)atoi(v);
                 warm = std::min(warm, ix->n_tiles);
                 // The ungrouped rows (per-query kernel over all tiles) share nothing with the grouped ones -- not a

@@ -1195,9 +1195,9 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
         else if (T == 3) hipLaunchKernelGGL((sa_k_span_machine_flat<20, 20, 3>), fg, dim3(64), 0, st, mp);
         else hipLaunchKernelGGL((sa_k_span_machine_flat<20, 20, 0>), fg, dim3(64), 0, st, mp);
         mp.in_list = over_list; mp.in_cnt = cnt + 4 * SA_SPAN_MAX_TERMS;
-        // (the fast pass abandons a few per cent of the groups at most and the blocks stride over the list: a grid of
-        //  8192 mostly empty blocks cost ~10 us of dispatch on the heaviest query)
-        const u32 g2 = std::min<u32>(1024u, terms_dev.len[0]);
+        // (a wave per abandoned group; 1024 blocks striding over the list were measured slower on the heaviest 2-term
+        //  query, 0.155 vs 0.140 ms: it abandons thousands of groups)
+        const u32 g2 = std::min<u32>(8192u, terms_dev.len[0]);
         hipLaunchKernelGGL(sa_k_span_machine_wave, dim3(g2), dim3(64), 0, st, mp);
     } else {
         hipLaunchKernelGGL(sa_k_span_machine, dim3(G / 64), dim3(64), 0, st, mp);       // every group, full tables in the global slab

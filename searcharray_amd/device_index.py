@@ -500,7 +500,7 @@ class QueryBatch:
 
 
 class PhraseBatch(QueryBatch):
-    """B phrases (lists of term ids; any phrase ``score()`` takes: repeated terms, up to 128 terms, ``slop`` --
+    """B phrases (lists of term ids; any phrase ``score()`` takes: repeated terms, any length, ``slop`` (up to 32 terms) --
     one value or one per phrase) resident on the device; ``run()`` scores every phrase with BM25 over its match
     counts and keeps the top k docs.
 
