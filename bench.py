@@ -20,7 +20,10 @@ top-k keys and a final merge when N > 1) + an async copy of the B x k results to
 two steps later.  Eight seeded query sets rotate through two batch objects, so nothing is replayed: what is timed is
 what a query stream gets (the reference's unit of work is score() on a fresh query, postings.py:652-680, timed as
 test/test_msmarco.py:345-395).  The 10M-doc corpus is sharded by doc-id range (10M / N docs per GPU, global BM25
-statistics), so scaling is STRONG.  The index is resident in HBM before the timed region.  Rank 0 prints one JSON line.
+statistics); every rank scores every query of a batch on its docs.  N > 1 runs take N x 256 queries per step in the main
+region, so that the work of a GPU per step is what it is at N = 1 (`"scaling": "weak"`; the 256-query batch -- strong
+scaling -- is timed beside it as `fixed_batch`; `--strong` swaps them).  The index is resident in HBM before the timed
+region.  Rank 0 prints one JSON line.
 
 Legs (all on the same resident index; only the first is `value`):
   main (fresh)      8 rotating BASELINE-shaped query sets (256 x 4 terms, one rank from each of 1-10 / 11-100 /
@@ -80,7 +83,11 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of each CPU baseline leg")
     ap.add_argument("--query-sets", type=int, default=8, help="seeded query sets the main leg rotates through")
     ap.add_argument("--scaled-queries", type=int, default=2048,
-                    help="queries per step of the scaled_batch leg (sharded runs: per-rank work does not shrink with N); 0: off")
+                    help="queries per step of the scaled_batch leg of a ONE-rank communicator run (SA_BENCH_FORCE_COMM=1); 0: off")
+    ap.add_argument("--batch-mult", type=int, default=1, help=argparse.SUPPRESS)
+    ap.add_argument("--strong", action="store_true",
+                    help="N > 1: keep --queries per step whatever N (strong scaling) in the main region; default: --queries x N "
+                         "(weak scaling: the work of a GPU per step is fixed), the fixed batch is reported beside it")
     ap.add_argument("--pipeline", type=int, default=6, help="batch objects (= batches in flight, one stream each) of the main leg")
     ap.add_argument("--no-phrase-legs", action="store_true", help="skip the zipf-1M phrase / slop legs")
     ap.add_argument("--phrase-docs", type=int, default=1_000_000)
@@ -765,7 +772,14 @@ def main():
     r = Rank(args)
     rank, world = r.rank, r.world
     from searcharray_amd import synth
-    D, V, B, K, W = args.docs, args.vocab, args.queries, args.steps, args.warmup
+    D, V, Bq, K, W = args.docs, args.vocab, args.queries, args.steps, args.warmup
+    # N > 1: every rank scores EVERY query of a batch on its 1/N of the docs, so with a fixed batch a rank's device work
+    # per step shrinks with N while the host's cost per batch (idf gather, reset, ~15 enqueues, fetch) does not.  The main
+    # region therefore takes N x --queries per step -- the work of a GPU per step is what it is at N = 1: WEAK scaling --
+    # and the fixed batch (strong scaling) is timed beside it; --strong swaps the two.
+    mult = max(world, args.batch_mult)                      # (--batch-mult: the N > 1 batch logic on one GPU, for testing)
+    weak = mult > 1 and not args.strong
+    B = Bq * mult if weak else Bq
     r.generate()
     phrase_legs_on = world == 1 and not r.use_comm and not args.no_phrase_legs
     leg_names = ["main", "dynamic_pruning"] + (["distinct_terms"] if 4 * B <= V else []) + \
@@ -780,7 +794,13 @@ def main():
         log(rank, f"PMC child runs: {'ok' if pmc else pmc_err} ({time.time()-t0:.0f}s)")
     r.build()
     n_sets = max(2, args.query_sets)
-    sets = [synth.bm25_queries(B, vocab=V)] + [synth.bm25_queries(B, vocab=V, seed=1000 + i) for i in range(1, n_sets)]
+
+    def query_set(i, n):
+        """n queries = n / --queries seeded BASELINE-shaped blocks; block 0 of set 0 is THE BASELINE set (seed 42)"""
+        blocks = [synth.bm25_queries(Bq, vocab=V) if (i == 0 and j == 0) else synth.bm25_queries(Bq, vocab=V, seed=1000 + 131 * i + j)
+                  for j in range(max(1, n // Bq))]
+        return np.concatenate(blocks)[:n]
+    sets = [query_set(i, B) for i in range(n_sets)]
     queries = sets[0]
     batch = r.make_batch(queries)
     q_distinct = synth.bm25_queries_distinct(B, vocab=V) if 4 * B <= V else None
@@ -813,8 +833,8 @@ def main():
     # results); it is timed right after on the resident set 0.  --pruned swaps the two.
     exhaustive = not args.pruned
     os.environ["SA_SPARSE"] = "0" if exhaustive else "1"
-    P = max(1, args.pipeline)
-    pair = [r.make_batch(sets[i % len(sets)]) for i in range(P)]
+    P = max(1, args.pipeline if B <= 1024 else min(args.pipeline, 4))
+    pair = [r.make_batch(sets[i % len(sets)], check=(i == 0)) for i in range(P)]
     dt, fresh_results = r.timed_fresh(pair, sets, max(W, P), K)
     # (HIP events around one batch's scoring kernels: with P batches in flight on P streams they overlap the other
     #  batches' kernels, so this is a batch's latency share, not the device time per step -- the replay leg's is)
@@ -831,19 +851,19 @@ def main():
         scores, docs = scores_r, docs_r
     fresh_equals_replay = bool(np.array_equal(scores, scores_r) and np.array_equal(docs, docs_r))
 
-    # sharded runs: the same stream with bigger batches -- per-rank device work shrinks with N, the host's cost per batch
-    # (idf gather, reset, ~15 launches, fetch) does not; 8 x the queries per step keeps a rank's step at the 1-GPU size
+    # the other batch size of a sharded run, as a fresh stream too: the fixed batch beside the scaled one (N > 1), or the
+    # scaled one beside the fixed one (one-rank communicator runs, --strong)
     scaled = None
-    if r.use_comm and args.scaled_queries > B:
-        B2 = args.scaled_queries
-        sets2 = [np.concatenate([synth.bm25_queries(B, vocab=V, seed=5000 + 97 * i + j) for j in range(B2 // B)])[:B2]
-                 for i in range(4)]
-        ring2 = [r.make_batch(sets2[i % len(sets2)], check=False) for i in range(min(P, 4))]
-        Ks = max(4, K // 4)
+    B2 = Bq if weak else (args.scaled_queries if r.use_comm or args.batch_mult > 1 else 0)
+    if B2 and B2 != B:
+        sets2 = [query_set(20 + i, B2) for i in range(4)]
+        ring2 = [r.make_batch(sets2[i % len(sets2)], check=False) for i in range(min(args.pipeline, 4) if B2 > 1024 else max(1, args.pipeline))]
+        Ks = K if B2 <= B else max(4, K // 4)
         dts, _ = r.timed_fresh(ring2, sets2, len(ring2), Ks)
         scaled = {"value": round(B2 * Ks / dts, 2), "unit": "queries/s", "queries_per_step": B2, "steps": Ks,
                   "ms_per_step": round(dts / Ks * 1e3, 4), "batches_in_flight": len(ring2),
-                  "note": "fresh batches of 8 x the queries (rotating sets, reset + run + fetch per step), same index"}
+                  "scaling": "strong" if weak else "weak",
+                  "note": "the same fresh-batch stream (rotating sets, reset + run + fetch per step) with the other batch size, same index"}
         for b in ring2:
             b.close()
 
@@ -907,11 +927,13 @@ def main():
         out = {
             "metric": "queries/sec, 4-term disjunctive BM25 + top-k over 10M synthetic Zipf docs",
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"zipf-{D} (V={V}, Poisson(32) doc lengths, seed 1234) sharded by doc-id range, "
                                    f"FRESH batches: {len(sets)} rotating seeded sets of {B} x 4-term disjunctive BM25 queries "
-                                   f"(k1=1.2 b=0.75; set 0 = the BASELINE set), host idf + sa_batch_reset + run + fetch per step, "
+                                   f"(k1=1.2 b=0.75; {'the first ' + str(Bq) + ' of ' if B > Bq else ''}set 0 = the BASELINE set"
+                                   f"{'; ' + str(Bq) + ' queries per GPU and step: every rank scores all of them on its docs' if weak else ''}), "
+                                   f"host idf + sa_batch_reset + run + fetch per step, "
                                    f"top-{args.k}, {'exhaustive' if exhaustive else 'dynamic pruning'}",
                        "docs": D, "queries_per_step": B, "terms_per_query": 4, "k": args.k, "query_sets": len(sets),
                        "batches_in_flight": P,
@@ -926,7 +948,7 @@ def main():
                        "fresh_equals_replay": fresh_equals_replay,
                        "note": "set 0 resident, sa_batch_run only -- no reset, no fetch (rounds 1-2 reported this as `value`)"},
             "roofline": exh_block if exhaustive else prn_block,
-            "scaled_batch": scaled,
+            ("fixed_batch" if weak else "scaled_batch"): scaled,
             ("dynamic_pruning" if exhaustive else "exhaustive"): other,
             "cpu_baseline": cpu,
             "parity_check": parity,
