@@ -892,6 +892,37 @@ def main():
     elif r.use_comm:
         parity = sharded_parity(r, queries, scores, docs)            # (collective)
 
+    # the drop-in call itself: SearchArray.score's device call for ONE term with the dense float32[n_docs] result copied to
+    # the host (what the reference returns) -- PCIe-bound -- and the same with the result left in HBM (score_device)
+    dense_out = None
+    if rank == 0 and world == 1 and not r.use_comm:
+        from searcharray_amd.device_index import DeviceVec
+        terms = [int(t) for t in queries[0]]
+        idf1 = r.idf_of(np.asarray([terms]))[0]
+        nd = 20
+        r.index.bm25_dense(terms[:1], idf=idf1[:1])
+        t0 = time.perf_counter()
+        for i in range(nd):
+            keep = r.index.bm25_dense([terms[i % 4]], idf=idf1[i % 4: i % 4 + 1])
+        dt_host = (time.perf_counter() - t0) / nd
+        del keep
+        vec = DeviceVec(r.api, r.index.n_docs, False)
+        from searcharray_amd._lib import p_u32, p_f32
+        tarr = [np.asarray([t], dtype=np.uint32) for t in terms]
+        warr = [np.asarray([w], dtype=np.float32) for w in idf1]
+        r.index.into_vec(vec, None, "sa_index_bm25_dense", p_u32(tarr[0]), p_f32(warr[0]), 1, np.float32(1.2), np.float32(0.75))
+        r.index.synchronize()
+        t0 = time.perf_counter()
+        for i in range(nd):
+            r.index.into_vec(vec, None, "sa_index_bm25_dense", p_u32(tarr[i % 4]), p_f32(warr[i % 4]), 1, np.float32(1.2), np.float32(0.75))
+        r.index.synchronize()
+        dt_dev = (time.perf_counter() - t0) / nd
+        vec.close()
+        dense_out = {"to_host_ms_per_call": round(dt_host * 1e3, 4), "to_host_GBps": round(4 * D / dt_host / 1e9, 1),
+                     "device_resident_ms_per_call": round(dt_dev * 1e3, 4), "calls": nd,
+                     "note": f"single-term BM25 over {D} docs: sa_index_bm25_dense with the float32[{D}] result copied into a page-locked "
+                             "host buffer (the drop-in SearchArray.score: PCIe-bound) vs left in a device vector (SearchArray.score_device)"}
+
     phrase_out = {}
     if side is not None and rank == 0:
         os.environ.pop("SA_SPARSE", None)
@@ -962,6 +993,7 @@ def main():
                 "roofline": roofline_block("sa_k_bm25_* (exhaustive)", kernel_ms3, alg3, comp_d,
                                            dominant(pmc.get("distinct_terms"), ("sa_k_bm25",)),
                                            "no posting list is shared between queries: compulsory_bytes = all posting bytes of the batch")}
+        out["dense_score"] = dense_out
         out.update(phrase_out)
         if pmc:
             out["pmc_kernels"] = {leg: pmc[leg]["kernels"] for leg in pmc}

@@ -617,6 +617,37 @@ class SearchArray(ExtensionArray):
     def doclengths(self) -> np.ndarray:
         return self.doc_lens
 
+    def score_device(self, token: Union[str, List[str]], similarity=default_bm25, slop: int = 0):
+        """``score()`` with the result LEFT ON THE DEVICE: a ``DeviceVec`` (float32[len(index)]; ``.fetch()`` copies it
+        to the host, ``.close()`` frees it).  The drop-in ``score()`` returns a dense host array as the reference does
+        (postings.py:652-680), which makes a call PCIe-bound (40 MB at 10 M docs); a caller that combines or ranks scores
+        on the GPU -- as ``searcharray_amd.solr.edismax`` does -- keeps them in HBM this way.  Stock BM25 similarity, whole
+        (unsliced) arrays."""
+        from .device_index import DeviceVec
+        from ._lib import p_u32
+        token = self._check_token_arg(token)
+        self._check_posn_args(slop, None, None)
+        if getattr(similarity, "kind", None) != "bm25" or self._rows is not None:
+            raise ValueError("score_device needs a stock BM25 similarity and a whole (unsliced) array")
+        tokens = [token] if isinstance(token, str) else token
+        dfs = np.asarray([self.docfreq(t) for t in tokens])
+        dev = self._core.device()
+        idf = np.float32(compute_idf(self.corpus_size, dfs))
+        unknown = dev.n_terms
+        tarr = np.asarray([t if (t := self._term_id(tok)) >= 0 else unknown for tok in tokens], dtype=np.uint32)
+        out = DeviceVec(dev.api, dev.n_docs, False)
+        k1, b = np.float32(similarity.k1), np.float32(similarity.b)
+        try:
+            if len(tokens) == 1:
+                dev.into_vec(out, None, "sa_index_bm25_dense", p_u32(tarr), np.asarray([idf], np.float32).ctypes.data_as(
+                    _lib.ctypes.POINTER(_lib.ctypes.c_float)), 1, k1, b)
+            else:
+                dev.into_vec(out, None, "sa_index_bm25_phrase_dense_posn", p_u32(tarr), len(tarr), int(slop), -1, -1, idf, k1, b)
+        except Exception:
+            out.close()
+            raise
+        return out
+
     def score(self, token: Union[str, List[str]], similarity=default_bm25, slop: int = 0,
               min_posn: Optional[int] = None, max_posn: Optional[int] = None) -> np.ndarray:
         """BM25 (or any Similarity) of one term or one phrase for every doc (reference

@@ -372,3 +372,18 @@ def test_nbytes_does_not_materialise_device_built_words(default_api):
     assert n > 0 and arr.posns.nbytes > 0
     assert host.has_words == had                            # asking for sizes downloaded nothing
     assert arr.posns.nbytes == host.words.nbytes            # and the size was right
+
+
+def test_score_device_keeps_the_result_in_hbm(data):
+    """``score_device``: the same scores as ``score()`` (reference postings.py:652-680), left in a device vector --
+    single terms, phrases, slop, unknown terms; slices and other similarities are refused"""
+    for token, slop in (("bar", 0), (["foo", "bar"], 0), (["foo", "baz"], 2), ("not_present", 0), (["bunny", "nope"], 0)):
+        vec = data.score_device(token, slop=slop)
+        try:
+            assert np.array_equal(vec.fetch(), data.score(token, slop=slop)), (token, slop)
+        finally:
+            vec.close()
+    with pytest.raises(ValueError):
+        data[:10].score_device("bar")
+    with pytest.raises(ValueError):
+        data.score_device("bar", similarity=classic_similarity())
