@@ -83,9 +83,17 @@ struct Bm25Params {
 // kept beside the TF postings in the layout the tile kernel wants (sa_impacts in sa_index.hpp): per
 // posting the kernel is left with a subtract, a compare, a multiply and the LDS read-modify-write.
 sa_impacts::~sa_impacts() {
-    if (d_imp) {
-        hipSetDevice(device);
-        hipFree(d_imp);
+    if (d_imp || d_dense) hipSetDevice(device);
+    if (d_imp) hipFree(d_imp);
+    if (d_dense) hipFree(d_dense);
+}
+
+// dense factor row of one term (sa_impacts::d_dense): row[doc] = factor bits of the term's posting of doc; the row is zeroed before
+__global__ void __launch_bounds__(256)
+sa_k_make_dense_row(const u64* __restrict__ imp, u64 first, u64 df, float* __restrict__ row) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < df; i += (u64)gridDim.x * blockDim.x) {
+        const u64 c = imp[first + i];
+        row[(u32)(c >> 32) >> 2] = __uint_as_float((u32)c);
     }
 }
 
@@ -139,6 +147,11 @@ sa_k_make_impacts(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, c
 // The impact stream of (k1, b) for this index: the cached one, or a new one (the cache keeps the most
 // recent; batches built earlier keep theirs alive).  Null when switched off (SA_IMPACT=0), for an empty
 // shard, or when HBM is short -- the tile kernel then scores the TF postings.  Call with the index lock held.
+static int sa_env_int_early(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 static std::shared_ptr<sa_impacts> sa_impacts_get(sa_index* ix, float k1, float b) {
     const char* env = getenv("SA_IMPACT");
     if (env && atoi(env) == 0) return nullptr;
@@ -167,6 +180,37 @@ static std::shared_ptr<sa_impacts> sa_impacts_get(sa_index* ix, float k1, float 
     // kernel's empty half entries point at: their lanes add 0 to their spare slots instead of a NaN
     static const u64 tail[2] = {0xFFFFFFFF00000000ull, 0xFFFFFFFF00000000ull};
     if (hipMemcpyAsync(im->d_imp + im->n - 2, tail, sizeof(tail), hipMemcpyHostToDevice, st) != hipSuccess) return nullptr;
+    // dense factor rows of the terms with df >= n_docs / SA_DENSE_DIV (default 4; 0: none), at most 16, most frequent first
+    im->dense_slot.assign(ix->n_terms, 0xFFFFFFFFu);
+    {
+        const int div = sa_env_int_early("SA_DENSE_DIV", 4);
+        std::vector<std::pair<u64, u32>> cand;
+        if (div > 0 && ix->n_tiles > 0)
+            for (u32 t = 0; t < ix->n_terms; t++) {
+                const u64 df = ix->h_tf_off[t + 1] - ix->h_tf_off[t];
+                if (df * (u64)div >= ix->n_docs && df > 0) cand.push_back({df, t});
+            }
+        std::sort(cand.begin(), cand.end(), [](const std::pair<u64, u32>& a, const std::pair<u64, u32>& c) { return a.first > c.first || (a.first == c.first && a.second < c.second); });
+        if (cand.size() > 16) cand.resize(16);
+        if (!cand.empty()) {
+            im->dense_stride = (u64)ix->n_tiles * ix->tile_docs;
+            const size_t bytes = cand.size() * im->dense_stride * sizeof(float);
+            if (hipMalloc(&im->d_dense, bytes) == hipSuccess && hipMemsetAsync(im->d_dense, 0, bytes, st) == hipSuccess) {
+                for (size_t r = 0; r < cand.size(); r++) {
+                    const u32 t = cand[r].second;
+                    const u64 df = cand[r].first;
+                    const u32 grid = df / 256 + 1 < 8192 ? (u32)(df / 256 + 1) : 8192u;
+                    hipLaunchKernelGGL(sa_k_make_dense_row, dim3(grid), dim3(256), 0, st, (const u64*)im->d_imp,
+                                       sa_imp_base(ix->h_tf_off[t], t), df, im->d_dense + r * im->dense_stride);
+                    im->dense_slot[t] = (u32)r;
+                }
+                im->n_dense = (u32)cand.size();
+            } else {
+                (void)hipGetLastError();
+                if (im->d_dense) { hipFree(im->d_dense); im->d_dense = nullptr; }   // (HBM short: the postings serve)
+            }
+        }
+    }
     ix->impacts = im;
     return im;
 }
@@ -794,7 +838,9 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles_list(const Bm25Params
 #define SA_GRP_MAXQ 16      // queries per group item (bigger groups are cut into balanced pieces)
 
 struct GroupParams {
-    const u32* grp;         // [n_groups][2]: first device row, number of rows (rows of a group are contiguous)
+    const u32* grp;         // [n_groups][3]: first device row, number of rows (rows of a group are contiguous), dense factor row of the shared first term or 0xFFFFFFFF
+    const float* dense;     // dense factor rows (sa_impacts::d_dense), or null
+    u64 dense_stride;
     u32 n_groups;
     u32 tile0, n_tiles_run; // tiles [tile0, tile0 + n_tiles_run)
     u32 tt, tt_shift;       // lanes per query while the step tables are built: power of two >= max(T - 1, 1)
@@ -863,7 +909,8 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
     const u32 tile = gp.tile0 + trel;
     // a LOOSE group (bit 31 of the size): queries that share nothing -- no base, ALL their terms are overlaid on
     // cleared accumulators (0 + s0 = s0, so the sums are the same); what they share is the item's fixed cost
-    const u32 row0 = gp.grp[2 * g], n_raw = gp.grp[2 * g + 1], n = n_raw & 0x7FFFFFFFu;
+    const u32 row0 = gp.grp[3 * g], n_raw = gp.grp[3 * g + 1], n = n_raw & 0x7FFFFFFFu;
+    const u32 dslot = gp.dense ? gp.grp[3 * g + 2] : 0xFFFFFFFFu;
     const bool loose = (n_raw >> 31) != 0u;
     const u32 T = p.T;
     const u64 tile_base = (u64)tile * TILE;
@@ -970,7 +1017,30 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
 
     // ---- base: clear, then the first term's slice scored once (write-only: 0 + s0 = s0)
     u32 base_max;
-    {
+    if (dslot != 0xFFFFFFFFu) {
+        // the shared term has a dense factor row: lane = doc, four docs per 16-byte load and LDS store, no unpacking and no
+        // scatter (docs without the term hold 0.0 -> 0.0 * idf = +0.0, what the cleared accumulator holds)
+        const float4* row4 = (const float4*)(gp.dense + (u64)dslot * gp.dense_stride + tile_base);
+        float4* a4 = (float4*)accu;
+        float4 v[TILE / 256];
+#pragma unroll
+        for (int j = 0; j < TILE / 256; j++) v[j] = row4[j * 64 + (int)lane];
+        u32 lmax = 0;
+#pragma unroll
+        for (int j = 0; j < TILE / 256; j++) {
+            float4 w;
+            w.x = __fmul_rn(v[j].x, hidf); w.y = __fmul_rn(v[j].y, hidf); w.z = __fmul_rn(v[j].z, hidf); w.w = __fmul_rn(v[j].w, hidf);
+            a4[j * 64 + (int)lane] = w;
+            const u32 m0 = __float_as_uint(w.x) > __float_as_uint(w.y) ? __float_as_uint(w.x) : __float_as_uint(w.y);
+            const u32 m1 = __float_as_uint(w.z) > __float_as_uint(w.w) ? __float_as_uint(w.z) : __float_as_uint(w.w);
+            const u32 m = m0 > m1 ? m0 : m1;
+            lmax = m > lmax ? m : lmax;
+        }
+        __builtin_amdgcn_wave_barrier();
+        at(spare) = 0u;
+        __builtin_amdgcn_wave_barrier();
+        base_max = sa_wave_max_u32(lmax);
+    } else {
         float4* a4 = (float4*)accu;
 #pragma unroll
         for (int j = 0; j < TILE / 256; j++) a4[j * 64 + (int)lane] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1501,6 +1571,8 @@ static int sa_launch_bm25_groups(sa_index* ix, const sa_batch* bt, const Bm25Par
     gp.grp = bt->d_grp; gp.n_groups = bt->n_groups;
     gp.tile0 = tile0; gp.n_tiles_run = ix->n_tiles - tile0;
     gp.tt = bt->grp_tt; gp.tt_shift = bt->grp_tt_shift;
+    gp.dense = (bt->impacts && sa_env_int("SA_GROUP_DENSE", 1) != 0) ? bt->impacts->d_dense : nullptr;
+    gp.dense_stride = bt->impacts ? bt->impacts->dense_stride : 0;
     const u64 blocks = (u64)((gp.n_tiles_run + 7u) / 8u) * 8u * gp.n_groups;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) { sa_set_error("grouped launch: bad grid"); return SA_ERR_STATE; }
     gp.wl = bt->d_wl; gp.wl_cnt = bt->d_wl_cnt;
@@ -1739,7 +1811,7 @@ static int sa_batch_alloc_bm25(sa_batch* bt) {
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 7) & ~(size_t)7; return o; };
     const size_t o_p1 = take((B + 1) * 8), o_boff = take(B * 8), o_terms = take(B * T * 4), o_idf = take(B * T * 4),
-                 o_perm = take(B * 4), o_grp = take(2 * B * 4), o_ub = take(B * (T + 1) * 4), o_ord = take(B * T * 4),
+                 o_perm = take(B * 4), o_grp = take(3 * B * 4), o_ub = take(B * (T + 1) * 4), o_ord = take(B * T * 4),
                  o_lead = take(B * 4), o_qdf = take(B * T * 4), o_row8 = take(B * T * 4), o_bsh = take(B * 4);
     SA_TRY(sa_batch_alloc_upload(bt, off));
     char* u = bt->d_up;
@@ -1893,6 +1965,11 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
                 for (u32 pc = 0; pc < pieces; pc++) {
                     const u32 sz = ((u32)m.size() - done + (pieces - pc) - 1) / (pieces - pc);
                     h_grp.push_back((u32)order.size()); h_grp.push_back(sz);
+                    {
+                        const u32 t0 = terms[(size_t)m[done] * T];
+                        const bool have = bt->impacts && bt->impacts->d_dense && t0 < bt->impacts->dense_slot.size();
+                        h_grp.push_back(have ? bt->impacts->dense_slot[t0] : 0xFFFFFFFFu);
+                    }
                     for (u32 i = 0; i < sz; i++) order.push_back(m[done + i]);
                     done += sz;
                 }
@@ -1919,7 +1996,7 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
                     u32 done = 0;
                     for (u32 pc = 0; pc < pieces; pc++) {
                         const u32 sz = ((u32)sparse_rows.size() - done + (pieces - pc) - 1) / (pieces - pc);
-                        h_grp.push_back((u32)order.size()); h_grp.push_back(sz | 0x80000000u);
+                        h_grp.push_back((u32)order.size()); h_grp.push_back(sz | 0x80000000u); h_grp.push_back(0xFFFFFFFFu);
                         for (u32 i = 0; i < sz; i++) order.push_back(sparse_rows[done + i]);
                         done += sz;
                     }
@@ -1928,7 +2005,7 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
                 }
             }
             bt->n_grouped_rows = (u32)order.size();
-            bt->n_groups = (u32)(h_grp.size() / 2);
+            bt->n_groups = (u32)(h_grp.size() / 3);
             order.insert(order.end(), rest.begin(), rest.end());
             bt->perm = order;
         }
@@ -1939,7 +2016,7 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
         memcpy(&h_idf[(size_t)r * T], &idf[(size_t)bt->perm[r] * T], T * sizeof(float));
         h_perm[r] = bt->perm[r];
     }
-    memset(h_grpd, 0, (size_t)2 * B * sizeof(u32));
+    memset(h_grpd, 0, (size_t)3 * B * sizeof(u32));
     if (!h_grp.empty()) memcpy(h_grpd, h_grp.data(), h_grp.size() * sizeof(u32));     // (at most B groups)
     {
         // Dynamic pruning tables (sa_sparse.hip).  Per query: the terms in ascending idf order with the

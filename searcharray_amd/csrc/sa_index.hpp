@@ -46,6 +46,15 @@ struct sa_impacts {
     float k1 = 0.f, b = 0.f, avgdl = 0.f;
     u64* d_imp = nullptr;
     u64 n = 0;                      // u64 cells incl. padding
+    // Dense factor rows of the most frequent terms (df >= n_docs / 4): dense[slot][doc] = the term's factor in doc, 0 where
+    // the doc lacks it.  The grouped kernel builds the BASE of a (tile, group) item from the row of the group's shared
+    // first term -- lane = doc, 16-byte loads, a multiply and a 16-byte LDS store per four docs -- instead of unpacking and
+    // scattering up to 1900 postings per tile; for such terms the row is no more bytes than the postings (4 B per doc
+    // against 8 B per posting).
+    float* d_dense = nullptr;
+    u64 dense_stride = 0;           // floats per row (n_docs rounded up to whole tiles)
+    std::vector<u32> dense_slot;    // [n_terms] row of a term, or 0xFFFFFFFF (host)
+    u32 n_dense = 0;
     ~sa_impacts();
 };
 
