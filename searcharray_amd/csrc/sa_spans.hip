@@ -525,6 +525,10 @@ __device__ __forceinline__ bool sa_span_doc(const SpanMachineParams& p, const u3
         const u32 lo = p.heads[t][k];
         const u32 hi = (k + 1 < ng) ? p.heads[t][k + 1] : *p.n_cand[t];
         const u32 curr_term_mask = 1u << t;
+        // Spans appended while term t's positions are taken -- its fresh spans and its forks -- all contain term t, and
+        // the reference's visit of such a span changes nothing (spans.pyx: "term already in the span"); the spans
+        // from before the term never contain it.  So a position only VISITS the spans that existed when its term began.
+        const u32 tstart = cursor;
         bool gave_up = false;
         for (u32 wi = lo; wi < hi && !gave_up; wi++) {
             const u64 w = p.cand[t][wi];
@@ -541,7 +545,7 @@ __device__ __forceinline__ bool sa_span_doc(const SpanMachineParams& p, const u3
                 SpanEnt fresh;
                 fresh.terms = curr_term_mask; fresh.posns = posn_mask; fresh.beg = curr_posn; fresh.end = curr_posn;
                 ents[cursor] = fresh;
-                const u32 end = cursor;
+                const u32 end = tstart;
                 cursor++;
                 for (u32 si = 0; si < end; si++) {
                     SpanEnt e = ents[si];
@@ -657,25 +661,93 @@ __global__ void __launch_bounds__(1024) sa_k_span_bin_scatter(const SpanBinParam
 // Documents with more than PMAX positions or more than CE spans are ABANDONED (nothing counted) to p.over_list for
 // the heavy pass -- one counter update per wave, the abandoned lanes take consecutive slots.
 // TT: the number of terms when it is 2 or 3 (the loops over the terms resolve at compile time), 0: any number.
+// lane L's span table in LDS: entry i at (i * 64 + L); the collected spans reuse the table's own storage -- collecting
+// walks the spans in order and has at most as many collected spans as spans already visited, so collected span c lives
+// in the (dead) slot of span c
+struct SpanEntCol {
+    SpanEnt* base;
+    struct Ref {
+        SpanEnt* q;
+        __device__ __forceinline__ operator SpanEnt() const { return *q; }
+        __device__ __forceinline__ void operator=(const SpanEnt& e) const { *q = e; }
+    };
+    __device__ __forceinline__ Ref operator[](u32 i) const { return Ref{base + i * 64u}; }
+};
+struct SpanColCol {
+    u64* base;
+    __device__ __forceinline__ u64& operator[](u32 i) const { return base[i * 128u]; }
+};
+
+// The machine (sa_span_doc's loops, flattened) over the lane's position list s_pos[q * 64 + lane] = term << 24 | position,
+// q < npos, in the machine's order (term by term).  The iteration is branch-free -- the kernel is bound by instruction
+// issue, and on divergent branches most of what is issued is exec-mask bookkeeping: every lane computes both outcomes
+// and writes through selected addresses, row CE of the table being a scratch row for the writes that do not happen.
+// A position visits the spans that existed when its TERM began (see sa_span_doc).  Returns false when the table
+// outgrew CE entries (nothing counted); else *incr_out = the document's count.
+template <int CE, int PMAX>
+__device__ __forceinline__ bool sa_span_flat_loop(const SpanEntCol& ents, const u32* s_pos, const u32 lane, const u32 npos,
+                                                  const u32 num_terms, const int max_span_width, u32* incr_out) {
+    u32 cursor = 0, pi = 0, si = 0, end = 0, curr_term_mask = 0, tstart = 0;
+    int curr_posn = 0, posn_mask = 0;
+    bool abandoned = false;
+    bool alive = true;
+    while (alive) {
+        // the current position has visited every span it has to: take the next one
+        const bool need = si >= end;
+        const bool done = need && pi >= npos;
+        const bool fresh_it = need && !done;
+        const u32 pv = s_pos[(pi < (u32)PMAX ? pi : (u32)PMAX - 1u) * 64u + lane];
+        const u32 new_mask = 1u << (pv >> 24);
+        tstart = (fresh_it && new_mask != curr_term_mask) ? cursor : tstart;
+        curr_posn = fresh_it ? (int)(pv & 0xFFFFFFu) : curr_posn;
+        curr_term_mask = fresh_it ? new_mask : curr_term_mask;
+        posn_mask = sa_posn_mask32(curr_posn);
+        const bool over_f = fresh_it && cursor >= (u32)CE;
+        {
+            SpanEnt fresh;
+            fresh.terms = curr_term_mask; fresh.posns = posn_mask; fresh.beg = curr_posn; fresh.end = curr_posn;
+            ents[(fresh_it && !over_f) ? cursor : (u32)CE] = fresh;
+        }
+        end = fresh_it ? tstart : end;
+        si = fresh_it ? 0u : si;
+        cursor += fresh_it ? 1u : 0u;
+        pi += fresh_it ? 1u : 0u;
+        // visit span si
+        const bool vis = !done && !over_f && si < end;
+        const u32 slot = vis ? si : (u32)CE;
+        const SpanEnt e = ents[slot];
+        const u32 nt = (u32)__popc(e.terms), np = sa_popc_sext(e.posns);
+        const bool act = vis && !((nt < num_terms && np == num_terms) || (e.terms & curr_term_mask));
+        const int sp2 = e.posns | posn_mask;
+        const u32 new_unique = sa_popc_sext(sp2);
+        const int proposed = sa_iabs32(curr_posn - e.beg);
+        const bool rej = np == new_unique || proposed > max_span_width;    // (the position bit stays even if rejected)
+        const bool fork_it = act && !rej;
+        const bool over_k = fork_it && cursor >= (u32)CE;
+        SpanEnt upd, fork;
+        upd.terms = fork_it ? (e.terms | curr_term_mask) : e.terms;
+        upd.posns = act ? sp2 : e.posns;
+        upd.beg = e.beg;
+        upd.end = fork_it ? curr_posn : e.end;
+        ents[slot] = upd;
+        fork.terms = e.terms | curr_term_mask; fork.posns = sp2 & ~posn_mask; fork.beg = e.beg; fork.end = e.end;
+        ents[(fork_it && !over_k) ? cursor : (u32)CE] = fork;
+        cursor += (fork_it && !over_k) ? 1u : 0u;
+        si += vis ? 1u : 0u;
+        abandoned = over_f || over_k;
+        alive = !done && !abandoned;
+    }
+    if (abandoned) return false;
+    u32 incr = 0;
+    sa_span_collect<SA_NSPANS>(ents, SpanColCol{(u64*)ents.base}, cursor, num_terms, max_span_width, &incr);
+    *incr_out = incr;
+    return true;
+}
+
 template <int CE, int PMAX, int TT>
 __device__ __forceinline__ void sa_span_machine_flat_body(const SpanMachineParams& p, const u32 bx) {
     __shared__ alignas(16) SpanEnt s_ents[(CE + 1) * 64];        // lane L's entry i at (i * 64 + L): conflict-free whatever i each lane is at; row CE: scratch
     __shared__ u32 s_pos[PMAX * 64];                             // term << 24 | position
-    struct EntCol {
-        SpanEnt* base;
-        struct Ref {
-            SpanEnt* q;
-            __device__ __forceinline__ operator SpanEnt() const { return *q; }
-            __device__ __forceinline__ void operator=(const SpanEnt& e) const { *q = e; }
-        };
-        __device__ __forceinline__ Ref operator[](u32 i) const { return Ref{base + i * 64u}; }
-    };
-    // The collected spans reuse the table's own storage: collecting walks the spans in order and has at most as
-    // many collected spans as spans already visited, so collected span c lives in the (dead) slot of span c.
-    struct ColCol {
-        u64* base;
-        __device__ __forceinline__ u64& operator[](u32 i) const { return base[i * 128u]; }
-    };
     const u32 lane = threadIdx.x;
     const u32 n_items = *p.n_heads[0];
     const u32 item = bx * 64u + lane;
@@ -683,7 +755,7 @@ __device__ __forceinline__ void sa_span_machine_flat_body(const SpanMachineParam
     const int T = TT ? TT : p.T;
     const u32 num_terms = (u32)T;
     const int max_span_width = (int)(num_terms + p.slop);
-    const EntCol ents{s_ents + lane};
+    const SpanEntCol ents{s_ents + lane};
     bool abandoned = false;
     if (item < n_items) {
         // ---- the document's positions, in the machine's order.  The loads are what this kernel waits for (group
@@ -740,61 +812,10 @@ __device__ __forceinline__ void sa_span_machine_flat_body(const SpanMachineParam
             for (u32 wi = l; wi < h; wi++) push_word(t, p.cand[t][wi]);
         }
         abandoned = npos > (u32)PMAX;
-        // ---- the machine (sa_span_doc's loops, flattened).  The iteration is branch-free -- the kernel is bound by
-        //      instruction issue, and on divergent branches most of what is issued is exec-mask bookkeeping: every
-        //      lane computes both outcomes and writes through selected addresses, row CE of the table being a
-        //      scratch row for the writes that do not happen.
-        u32 cursor = 0, pi = 0, si = 0, end = 0, curr_term_mask = 0;
-        int curr_posn = 0, posn_mask = 0;
-        bool alive = !abandoned;
-        while (alive) {
-            // the current position has visited every span that existed before it: take the next one
-            const bool need = si >= end;
-            const bool done = need && pi >= npos;
-            const bool fresh_it = need && !done;
-            const u32 pv = s_pos[(pi < (u32)PMAX ? pi : (u32)PMAX - 1u) * 64u + lane];
-            curr_posn = fresh_it ? (int)(pv & 0xFFFFFFu) : curr_posn;
-            curr_term_mask = fresh_it ? 1u << (pv >> 24) : curr_term_mask;
-            posn_mask = sa_posn_mask32(curr_posn);
-            const bool over_f = fresh_it && cursor >= (u32)CE;
-            {
-                SpanEnt fresh;
-                fresh.terms = curr_term_mask; fresh.posns = posn_mask; fresh.beg = curr_posn; fresh.end = curr_posn;
-                ents[(fresh_it && !over_f) ? cursor : (u32)CE] = fresh;
-            }
-            end = fresh_it ? cursor : end;
-            si = fresh_it ? 0u : si;
-            cursor += fresh_it ? 1u : 0u;
-            pi += fresh_it ? 1u : 0u;
-            // visit span si
-            const bool vis = !done && !over_f && si < end;
-            const u32 slot = vis ? si : (u32)CE;
-            const SpanEnt e = ents[slot];
-            const u32 nt = (u32)__popc(e.terms), np = sa_popc_sext(e.posns);
-            const bool act = vis && !((nt < num_terms && np == num_terms) || (e.terms & curr_term_mask));
-            const int sp2 = e.posns | posn_mask;
-            const u32 new_unique = sa_popc_sext(sp2);
-            const int proposed = sa_iabs32(curr_posn - e.beg);
-            const bool rej = np == new_unique || proposed > max_span_width;    // (the position bit stays even if rejected)
-            const bool fork_it = act && !rej;
-            const bool over_k = fork_it && cursor >= (u32)CE;
-            SpanEnt upd, fork;
-            upd.terms = fork_it ? (e.terms | curr_term_mask) : e.terms;
-            upd.posns = act ? sp2 : e.posns;
-            upd.beg = e.beg;
-            upd.end = fork_it ? curr_posn : e.end;
-            ents[slot] = upd;
-            fork.terms = e.terms | curr_term_mask; fork.posns = sp2 & ~posn_mask; fork.beg = e.beg; fork.end = e.end;
-            ents[(fork_it && !over_k) ? cursor : (u32)CE] = fork;
-            cursor += (fork_it && !over_k) ? 1u : 0u;
-            si += vis ? 1u : 0u;
-            abandoned = over_f || over_k;
-            alive = !done && !abandoned;
-        }
         if (!abandoned) {
             u32 incr = 0;
-            sa_span_collect<SA_NSPANS>(ents, ColCol{(u64*)(s_ents + lane)}, cursor, num_terms, max_span_width, &incr);
-            sa_span_add(p, last_key, incr);
+            if (sa_span_flat_loop<CE, PMAX>(ents, s_pos, lane, npos, num_terms, max_span_width, &incr)) sa_span_add(p, last_key, incr);
+            else abandoned = true;
         }
     }
     const u64 ab = __ballot(abandoned);
@@ -818,11 +839,122 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_flat(const SpanMachinePa
 // existed, in span order -- a ballot prefix gives each fork its slot -- and are not visited for the same
 // position).  The cost of a document drops from positions x spans dependent steps of one lane to
 // positions x ceil(spans / 64) steps of a wave, and heavy documents no longer form the kernel's tail.
+// one word of term `curr_term_mask`: its positions, one after the other, against the spans that existed when the term
+// began (tstart; see sa_span_doc), 64 spans at a time.  Stops when the table is full.
+__device__ __forceinline__ void sa_span_wave_word(SpanEnt* s_ents, const u64 w, const u32 curr_term_mask, const u32 tstart,
+                                                  const u32 num_terms, const int max_span_width, const u32 lane,
+                                                  u32& cursor, bool& full) {
+    const u64 lt = (1ull << lane) - 1ull;
+    const int payload_base = (int)(((w >> SA_LSB_BITS) & SA_LSB_MASK) * SA_LSB_BITS);
+    u32 bits = (u32)(w & SA_LSB_MASK);
+    while (bits != 0) {
+        const int curr_posn = payload_base + (__ffs((int)bits) - 1);
+        bits &= bits - 1;
+        const int posn_mask = sa_posn_mask32(curr_posn);
+        if (cursor >= SA_NSPANS) { full = true; break; }
+        if (lane == 0) {
+            SpanEnt fresh;
+            fresh.terms = curr_term_mask; fresh.posns = posn_mask; fresh.beg = curr_posn; fresh.end = curr_posn;
+            s_ents[cursor] = fresh;
+        }
+        const u32 end = tstart;
+        cursor++;
+        for (u32 base = 0; base < end; base += 64u) {
+            const u32 si = base + lane;
+            bool fork_it = false;
+            SpanEnt e;
+            e.terms = 0; e.posns = 0; e.beg = 0; e.end = 0;
+            if (si < end) {
+                e = s_ents[si];
+                const u32 nt = (u32)__popc(e.terms), np = sa_popc_sext(e.posns);
+                const bool skip = (nt < num_terms && np == num_terms) || (e.terms & curr_term_mask);
+                if (!skip) {
+                    const int sp2 = e.posns | posn_mask;
+                    const u32 new_unique = sa_popc_sext(sp2);
+                    const int proposed = sa_iabs32(curr_posn - e.beg);
+                    if (np == new_unique || proposed > max_span_width) {
+                        if (sp2 != e.posns) { e.posns = sp2; s_ents[si] = e; }   // the position bit stays even if rejected
+                    } else {
+                        fork_it = true;
+                    }
+                }
+            }
+            // forks of this chunk, in span order, behind what is already there
+            const u64 fb = __ballot(fork_it);
+            if (fb) {
+                const u32 rank = (u32)__popcll(fb & lt), total = (u32)__popcll(fb);
+                const u32 room = SA_NSPANS - cursor;                   // (cursor <= 512 here)
+                if (fork_it) {
+                    const int sp2 = e.posns | posn_mask;
+                    if (rank < room) {
+                        SpanEnt fork;
+                        fork.terms = e.terms | curr_term_mask; fork.posns = sp2 & ~posn_mask;
+                        fork.beg = e.beg; fork.end = e.end;
+                        s_ents[cursor + rank] = fork;
+                    }
+                    e.terms |= curr_term_mask; e.posns = sp2; e.end = curr_posn;
+                    s_ents[si] = e;
+                }
+                // the reference takes the forks one by one: successes while there is room, then failures
+                full = total > room;
+                cursor += total < room ? total : room;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (cursor >= SA_NSPANS) break;
+    }
+}
+
+// the document's count once its words are through: the reference's "full" rule (min over the terms of the summed
+// popcounts; lane t holds term t's sum) or _collect_spans (spans.pyx:157-186), spans in order; the search for the
+// first collected span a new one overlaps and undercuts runs over 64 collected spans at a time
+__device__ __forceinline__ u32 sa_span_wave_finish(SpanEnt* s_ents, const u32 cursor, const bool full, const u32 my_sum,
+                                                   const int T, const int max_span_width, const u32 lane) {
+    const u32 num_terms = (u32)T;
+    u64* const s_col2 = (u64*)s_ents;                            // collected span c in the (dead) slot of span c: s_col2[2 c]
+    if (full) {
+        u32 mn = 0;
+        for (int t = 0; t < T; t++) {
+            const u32 sp = (u32)__builtin_amdgcn_readlane((int)my_sum, t);
+            if (mn == 0 || sp < mn) mn = sp;
+        }
+        return mn;
+    }
+    u32 ncol = 0;
+    for (u32 si = 0; si < cursor; si++) {
+        const SpanEnt e = s_ents[si];
+        __builtin_amdgcn_wave_barrier();                 // every lane has the span before its slot is reused below
+        const bool complete = ((u32)__popc(e.terms) == num_terms) || (sa_popc_sext(e.posns) == num_terms);
+        const int b = e.beg, en = e.end;
+        const int width = sa_iabs32(en - b);
+        if (!complete || width >= max_span_width) continue;
+        bool replaced = false;
+        for (u32 cb0 = 0; cb0 < ncol && !replaced; cb0 += 64u) {
+            const u32 c = cb0 + lane;
+            bool hit = false;
+            if (c < ncol) {
+                const u64 cc = s_col2[2u * c];
+                const int cb = (int)(cc >> 32), ce = (int)(cc & 0xFFFFFFFFull);
+                hit = b <= ce && en >= cb && width < sa_iabs32(ce - cb);
+            }
+            const u64 hb = __ballot(hit);
+            if (hb) {
+                if (lane == (u32)__builtin_ctzll(hb)) s_col2[2u * c] = ((u64)(u32)b << 32) | (u64)(u32)en;
+                replaced = true;
+            }
+        }
+        if (!replaced) {
+            if (lane == 0) s_col2[2u * ncol] = ((u64)(u32)b << 32) | (u64)(u32)en;
+            ncol++;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return ncol;
+}
+
 __device__ __forceinline__ void sa_span_machine_wave_body(const SpanMachineParams& p, const u32 bx, const u32 gx) {
     __shared__ alignas(16) SpanEnt s_ents[SA_NSPANS];
-    u64* const s_col2 = (u64*)s_ents;                            // collected span c in the (dead) slot of span c: s_col2[2 c]
     const u32 lane = threadIdx.x;
-    const u64 lt = (1ull << lane) - 1ull;
     const u32 n_items = *p.in_cnt;
     const u32 num_terms = (u32)p.T;
     const int max_span_width = (int)(num_terms + p.slop);
@@ -838,115 +970,17 @@ __device__ __forceinline__ void sa_span_machine_wave_body(const SpanMachineParam
             if (k >= ng) continue;
             const u32 lo = p.heads[t][k];
             const u32 hi = (k + 1 < ng) ? p.heads[t][k + 1] : *p.n_cand[t];
-            const u32 curr_term_mask = 1u << t;
+            const u32 tstart = cursor;
             bool gave_up = false;
             for (u32 wi = lo; wi < hi && !gave_up; wi++) {
                 const u64 w = p.cand[t][wi];
                 last_key = w >> SA_KEY_SHIFT;
-                const int payload_base = (int)(((w >> SA_LSB_BITS) & SA_LSB_MASK) * SA_LSB_BITS);
-                u32 bits = (u32)(w & SA_LSB_MASK);
-                if (lane == (u32)t) my_sum += (u32)__popc(bits);
-                while (bits != 0) {
-                    const int curr_posn = payload_base + (__ffs((int)bits) - 1);
-                    bits &= bits - 1;
-                    const int posn_mask = sa_posn_mask32(curr_posn);
-                    if (cursor >= SA_NSPANS) { full = true; break; }
-                    if (lane == 0) {
-                        SpanEnt fresh;
-                        fresh.terms = curr_term_mask; fresh.posns = posn_mask; fresh.beg = curr_posn; fresh.end = curr_posn;
-                        s_ents[cursor] = fresh;
-                    }
-                    const u32 end = cursor;
-                    cursor++;
-                    for (u32 base = 0; base < end; base += 64u) {
-                        const u32 si = base + lane;
-                        bool fork_it = false;
-                        SpanEnt e;
-                        e.terms = 0; e.posns = 0; e.beg = 0; e.end = 0;
-                        if (si < end) {
-                            e = s_ents[si];
-                            const u32 nt = (u32)__popc(e.terms), np = sa_popc_sext(e.posns);
-                            const bool skip = (nt < num_terms && np == num_terms) || (e.terms & curr_term_mask);
-                            if (!skip) {
-                                const int sp2 = e.posns | posn_mask;
-                                const u32 new_unique = sa_popc_sext(sp2);
-                                const int proposed = sa_iabs32(curr_posn - e.beg);
-                                if (np == new_unique || proposed > max_span_width) {
-                                    if (sp2 != e.posns) { e.posns = sp2; s_ents[si] = e; }   // the position bit stays even if rejected
-                                } else {
-                                    fork_it = true;
-                                }
-                            }
-                        }
-                        // forks of this chunk, in span order, behind what is already there
-                        const u64 fb = __ballot(fork_it);
-                        if (fb) {
-                            const u32 rank = (u32)__popcll(fb & lt), total = (u32)__popcll(fb);
-                            const u32 room = SA_NSPANS - cursor;                   // (cursor <= 512 here)
-                            if (fork_it) {
-                                const int sp2 = e.posns | posn_mask;
-                                if (rank < room) {
-                                    SpanEnt fork;
-                                    fork.terms = e.terms | curr_term_mask; fork.posns = sp2 & ~posn_mask;
-                                    fork.beg = e.beg; fork.end = e.end;
-                                    s_ents[cursor + rank] = fork;
-                                }
-                                e.terms |= curr_term_mask; e.posns = sp2; e.end = curr_posn;
-                                s_ents[si] = e;
-                            }
-                            // the reference takes the forks one by one: successes while there is room, then failures
-                            full = total > room;
-                            cursor += total < room ? total : room;
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    if (cursor >= SA_NSPANS) break;
-                }
+                if (lane == (u32)t) my_sum += (u32)__popc((u32)(w & SA_LSB_MASK));
+                sa_span_wave_word(s_ents, w, 1u << t, tstart, num_terms, max_span_width, lane, cursor, full);
                 if (cursor >= SA_NSPANS && k + 1 < ng) gave_up = true;       // (not in the term's last document group: see sa_span_doc)
             }
         }
-        u32 incr;
-        if (full) {
-            u32 mn = 0;
-            for (int t = 0; t < p.T; t++) {
-                const u32 sp = (u32)__builtin_amdgcn_readlane((int)my_sum, t);
-                if (mn == 0 || sp < mn) mn = sp;
-            }
-            incr = mn;
-        } else {
-            // _collect_spans (spans.pyx:157-186), spans in order; the search for the first collected span a new one
-            // overlaps and undercuts runs over 64 collected spans at a time
-            u32 ncol = 0;
-            for (u32 si = 0; si < cursor; si++) {
-                const SpanEnt e = s_ents[si];
-                __builtin_amdgcn_wave_barrier();                 // every lane has the span before its slot is reused below
-                const bool complete = ((u32)__popc(e.terms) == num_terms) || (sa_popc_sext(e.posns) == num_terms);
-                const int b = e.beg, en = e.end;
-                const int width = sa_iabs32(en - b);
-                if (!complete || width >= max_span_width) continue;
-                bool replaced = false;
-                for (u32 cb0 = 0; cb0 < ncol && !replaced; cb0 += 64u) {
-                    const u32 c = cb0 + lane;
-                    bool hit = false;
-                    if (c < ncol) {
-                        const u64 cc = s_col2[2u * c];
-                        const int cb = (int)(cc >> 32), ce = (int)(cc & 0xFFFFFFFFull);
-                        hit = b <= ce && en >= cb && width < sa_iabs32(ce - cb);
-                    }
-                    const u64 hb = __ballot(hit);
-                    if (hb) {
-                        if (lane == (u32)__builtin_ctzll(hb)) s_col2[2u * c] = ((u64)(u32)b << 32) | (u64)(u32)en;
-                        replaced = true;
-                    }
-                }
-                if (!replaced) {
-                    if (lane == 0) s_col2[2u * ncol] = ((u64)(u32)b << 32) | (u64)(u32)en;
-                    ncol++;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            incr = ncol;
-        }
+        const u32 incr = sa_span_wave_finish(s_ents, cursor, full, my_sum, p.T, max_span_width, lane);
         if (lane == 0) sa_span_add(p, last_key, incr);
     }
 }
