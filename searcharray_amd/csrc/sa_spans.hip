@@ -664,19 +664,24 @@ __global__ void __launch_bounds__(1024) sa_k_span_bin_scatter(const SpanBinParam
 // lane L's span table in LDS: entry i at (i * 64 + L); the collected spans reuse the table's own storage -- collecting
 // walks the spans in order and has at most as many collected spans as spans already visited, so collected span c lives
 // in the (dead) slot of span c
-struct SpanEntCol {
+// (S: lanes that share the table -- 64 documents per wave, or 32 / 16 with tables of twice / four times the rows in the
+//  same LDS: the doc-parallel route's documents with many positions)
+template <int S = 64>
+struct SpanEntColS {
     SpanEnt* base;
     struct Ref {
         SpanEnt* q;
         __device__ __forceinline__ operator SpanEnt() const { return *q; }
         __device__ __forceinline__ void operator=(const SpanEnt& e) const { *q = e; }
     };
-    __device__ __forceinline__ Ref operator[](u32 i) const { return Ref{base + i * 64u}; }
+    __device__ __forceinline__ Ref operator[](u32 i) const { return Ref{base + i * (u32)S}; }
 };
-struct SpanColCol {
+template <int S = 64>
+struct SpanColColS {
     u64* base;
-    __device__ __forceinline__ u64& operator[](u32 i) const { return base[i * 128u]; }
+    __device__ __forceinline__ u64& operator[](u32 i) const { return base[i * (u32)(2 * S)]; }
 };
+typedef SpanEntColS<64> SpanEntCol;
 
 // The machine (sa_span_doc's loops, flattened) over the lane's position list s_pos[q * 64 + lane] = term << 24 | position,
 // q < npos, in the machine's order (term by term).  The iteration is branch-free -- the kernel is bound by instruction
@@ -684,8 +689,8 @@ struct SpanColCol {
 // and writes through selected addresses, row CE of the table being a scratch row for the writes that do not happen.
 // A position visits the spans that existed when its TERM began (see sa_span_doc).  Returns false when the table
 // outgrew CE entries (nothing counted); else *incr_out = the document's count.
-template <int CE, int PMAX>
-__device__ __forceinline__ bool sa_span_flat_loop(const SpanEntCol& ents, const u32* s_pos, const u32 lane, const u32 npos,
+template <int CE, int PMAX, int S = 64>
+__device__ __forceinline__ bool sa_span_flat_loop(const SpanEntColS<S>& ents, const u32* s_pos, const u32 lane, const u32 npos,
                                                   const u32 num_terms, const int max_span_width, u32* incr_out) {
     u32 cursor = 0, pi = 0, si = 0, end = 0, curr_term_mask = 0, tstart = 0;
     int curr_posn = 0, posn_mask = 0;
@@ -696,7 +701,7 @@ __device__ __forceinline__ bool sa_span_flat_loop(const SpanEntCol& ents, const 
         const bool need = si >= end;
         const bool done = need && pi >= npos;
         const bool fresh_it = need && !done;
-        const u32 pv = s_pos[(pi < (u32)PMAX ? pi : (u32)PMAX - 1u) * 64u + lane];
+        const u32 pv = s_pos[(pi < (u32)PMAX ? pi : (u32)PMAX - 1u) * (u32)S + lane];
         const u32 new_mask = 1u << (pv >> 24);
         tstart = (fresh_it && new_mask != curr_term_mask) ? cursor : tstart;
         curr_posn = fresh_it ? (int)(pv & 0xFFFFFFu) : curr_posn;
@@ -739,7 +744,7 @@ __device__ __forceinline__ bool sa_span_flat_loop(const SpanEntCol& ents, const 
     }
     if (abandoned) return false;
     u32 incr = 0;
-    sa_span_collect<SA_NSPANS>(ents, SpanColCol{(u64*)ents.base}, cursor, num_terms, max_span_width, &incr);
+    sa_span_collect<SA_NSPANS>(ents, SpanColColS<S>{(u64*)ents.base}, cursor, num_terms, max_span_width, &incr);
     *incr_out = incr;
     return true;
 }
@@ -989,6 +994,442 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_wave(const SpanMachinePa
     sa_span_machine_wave_body(p, blockIdx.x, gridDim.x);
 }
 
+// ---- the doc-parallel route: frequent terms, whole lists ---------------------------------------------------------------
+// When every term of the phrase has a doc directory row and no word in a document's last 18-position block (the
+// directory's own condition, sa_header_triple_dd), and header 0 is not in L (no wrapped `L - 1`, see the top of the
+// file; with two terms that widening is redundant and the condition is not needed), the candidate predicate of a word
+// only looks at words of the word's OWN document, in every term.  Then
+// (a) whether a word is a candidate can be worked out by the thread that holds the document's words, no flag array;
+// (b) a document has candidate words in ALL terms or in none: L(h) needs every term at h or h - 1 and term 0 at h or
+//     h - 1, and each of those words is itself kept (by L(h) or by L((h - 1) + 1)); R(h), R(h - 1), L(h + 1) alike.
+//     So the k-th document group of every term is the SAME document, and "the k-th group of every term" (what the
+//     reference's lock-step walk takes, and what the general route reproduces through stable compactions) is "the
+//     document" -- no ranks, no compaction, any order.
+// Three launches, everything read and written in whole lines, no device-wide atomics (a same-line atomic from every
+// block costs more than the kernels: measured) and nothing to clear:
+//   count   one thread per document (lane = doc: the directory rows and the documents' words are read in doc order):
+//           candidate words, their positions -> the document's bin: 0 none, npos for npos <= PMAX, else heavy; a
+//           histogram per BLOCK, stored; the dense result cleared;
+//   emit    every block sums the histograms (all: bin sizes; the blocks before it: its share of each bin), then the
+//           same again (the lists come from the Infinity Cache this time), now writing each document's position
+//           list -- doc, then term << 24 | position in the machine's order -- as a fixed-size record into ITS BIN's
+//           region, bins in descending order: what the general route's counting sort + scattered gathers produce
+//           (waves of equal work, busiest first), but as dense records;
+//   machine a wave takes neighbouring records of one bin, one document per lane, sa_span_flat_loop on the records read
+//           as they lie.  Bins up to PA positions: 64 documents per wave; up to 2 PA: 32, each with twice the table
+//           rows and positions in the same LDS; up to 4 PA: 16 with four times -- so that a document with many
+//           positions (whose table would outgrow a 64-lane column) still runs as a lane, not as a wave.  Documents
+//           beyond that (heavy) come first, a wave each (sa_span_wave_doc: the words through the directory, candidate
+//           test per lane, the 512-span table in LDS); a lane whose table still outgrows its column is redone by its
+//           own wave the same way.
+#define SA_SPAN_DW 4                     // words of one term per document the count / emit passes hold in registers
+#define SA_SPAN_DB 48                    // bins: [npos] for 1 <= npos <= 4 PA (<= 40), [4 PA + 1] heavy
+#define SA_SPAN_DT 512                   // threads of a count / emit block
+#define SA_SPAN_DG 512                   // at most this many count / emit blocks (each sums all the histograms)
+
+struct SpanDocParams {
+    SpanTerms st;                        // dd[t] != null for every term
+    u32 slop;
+    u32 pa;                              // positions of a document a full wave's lane takes; pmax = 4 pa
+    u32 docs_per_block;                  // count / emit: block x takes documents [x, x + 1) * docs_per_block
+    float* counts;                       // the dense result
+    unsigned char* dbin;                 // [n_docs] the document's bin, 0: no candidate
+    u32* hist;                           // [blocks][SA_SPAN_DB] per-block bin sizes; [.][0]: the block's last candidate doc + 1
+    u32* sizes;                          // [SA_SPAN_DB] bin sizes; [0]: last candidate doc + 1 (written by emit's block 0)
+    u32* recs;                           // position records, bin 4 PA first: sizes[b] x (b + 1) words
+    u32* heavy;                          // doc ids of the heavy bin
+};
+
+// candidate predicate of the word with header h, probing every term through its doc directory
+template <int TT>
+__device__ __forceinline__ bool sa_span_keep_word(const SpanTerms& st, const u64 h) {
+    u32 m[TT];
+#pragma unroll
+    for (int i = 0; i < TT; i++) m[i] = 0;
+    bool possible = true;
+#pragma unroll
+    for (int i = 0; i < TT; i++) {
+        if (possible) m[i] = sa_header_triple_dd(st.words[i], st.len[i], st.dd[i], st.n_docs, h);
+        if (m[i] == 0) possible = false;
+    }
+    return possible && sa_span_keep<TT>(m, TT, false);
+}
+
+// positions of the document's candidate words, any number of words (the count pass, documents with more than
+// SA_SPAN_DW words of a term)
+template <int TT>
+__device__ __forceinline__ u32 sa_span_doc_npos_slow(const SpanTerms& st, const u64 doc) {
+    u32 npos = 0;
+#pragma unroll
+    for (int t = 0; t < TT; t++) {
+        const u32 n = st.len[t];
+        for (u32 j = st.dd[t][doc]; j < n; j++) {
+            const u64 w = st.words[t][j];
+            if ((w >> SA_KEY_SHIFT) != doc) break;
+            if (sa_span_keep_word<TT>(st, w & SA_HEADER_MASK)) npos += (u32)__popc((u32)(w & SA_LSB_MASK));
+        }
+    }
+    return npos;
+}
+
+// The document's words of every term (at most SA_SPAN_DW each within 60 blocks, else *many) and which of them are
+// candidates (bit q of keep[t]), from the document's own words in registers.
+template <int TT>
+__device__ __forceinline__ bool sa_span_doc_words(const SpanTerms& st, const u64 doc, u64 (&W)[TT][SA_SPAN_DW], u32 (&c)[TT],
+                                                  u32 (&keep)[TT], bool* many) {
+    u32 j0[TT];
+    bool all = true;
+#pragma unroll
+    for (int t = 0; t < TT; t++) { j0[t] = st.dd[t][doc]; all = all && j0[t] != SA_DD_ABSENT; }
+#pragma unroll
+    for (int t = 0; t < TT; t++) { c[t] = 0; keep[t] = 0; }
+    *many = false;
+    if (!all) return false;
+    u64 X[TT];                                                   // the word behind the ones held
+#pragma unroll
+    for (int t = 0; t < TT; t++) {
+#pragma unroll
+        for (int q = 0; q < SA_SPAN_DW; q++) {
+            const u32 idx = j0[t] + (u32)q;
+            W[t][q] = idx < st.len[t] ? st.words[t][idx] : ~0ull;
+        }
+        const u32 idx = j0[t] + (u32)SA_SPAN_DW;
+        X[t] = idx < st.len[t] ? st.words[t][idx] : ~0ull;
+    }
+#pragma unroll
+    for (int t = 0; t < TT; t++) {
+        bool run = true;
+#pragma unroll
+        for (int q = 0; q < SA_SPAN_DW; q++) {
+            run = run && (W[t][q] >> SA_KEY_SHIFT) == doc;
+            c[t] += run ? 1u : 0u;
+        }
+        if (run && (X[t] >> SA_KEY_SHIFT) == doc) *many = true;
+    }
+    if (*many) return true;
+    // Presence of each term per 18-position block, as bits relative to the document's first block (bit 1 = that
+    // block): the sets of the top of the file become shifts and ANDs over all the document's words at once --
+    // in_i(h - 1) at bit h is P[i] << 1, in_i(h + 1) is P[i] >> 1 -- instead of three compares per pair of words.
+    u32 lo_blk = 0xFFFFFFFFu, hi_blk = 0;
+#pragma unroll
+    for (int t = 0; t < TT; t++)
+#pragma unroll
+        for (int q = 0; q < SA_SPAN_DW; q++)
+            if ((u32)q < c[t]) {
+                const u32 blk = (u32)(W[t][q] >> SA_LSB_BITS) & (u32)SA_LSB_MASK;
+                lo_blk = blk < lo_blk ? blk : lo_blk;
+                hi_blk = blk > hi_blk ? blk : hi_blk;
+            }
+    if (hi_blk - lo_blk > 60u) { *many = true; return true; }   // (a document longer than 1000 positions: the slow path)
+    u64 P[TT];
+#pragma unroll
+    for (int t = 0; t < TT; t++) {
+        P[t] = 0;
+#pragma unroll
+        for (int q = 0; q < SA_SPAN_DW; q++)
+            if ((u32)q < c[t]) P[t] |= 1ull << (((u32)(W[t][q] >> SA_LSB_BITS) & (u32)SA_LSB_MASK) - lo_blk + 1u);
+    }
+    u64 L = ~0ull, R = ~0ull;
+#pragma unroll
+    for (int i = 1; i < TT; i++) {
+        L &= (P[0] & P[i]) | (P[i] & (P[0] << 1)) | (P[0] & (P[i] << 1));        // spans.py:79-90
+        R &= (P[0] & P[i]) | (P[0] & (P[i] >> 1)) | (P[i] & (P[0] >> 1));
+    }
+    const u64 K = L | R | (R << 1) | (L >> 1);                   // L(h) | R(h) | R(h - 1) | L(h + 1)   (spans.py:106-118)
+#pragma unroll
+    for (int t = 0; t < TT; t++)
+#pragma unroll
+        for (int q = 0; q < SA_SPAN_DW; q++)
+            if ((u32)q < c[t] && ((K >> (((u32)(W[t][q] >> SA_LSB_BITS) & (u32)SA_LSB_MASK) - lo_blk + 1u)) & 1ull)) keep[t] |= 1u << q;
+    return true;
+}
+
+template <int TT>
+__global__ void __launch_bounds__(SA_SPAN_DT) sa_k_span_doc_count(const SpanDocParams p) {
+    __shared__ u32 s_h[SA_SPAN_DB];
+    if (threadIdx.x < SA_SPAN_DB) s_h[threadIdx.x] = 0;          // ([0]: last candidate doc + 1)
+    __syncthreads();
+    const u32 pmax = 4u * p.pa, heavy_bin = pmax + 1u;
+    const u64 lo = (u64)blockIdx.x * p.docs_per_block;
+    const u64 hi = lo + p.docs_per_block < p.st.n_docs ? lo + p.docs_per_block : p.st.n_docs;
+    u64 W[TT][SA_SPAN_DW];
+    u32 c[TT], keep[TT];
+    bool many = false;
+    for (u64 doc = lo + threadIdx.x; doc < hi; doc += SA_SPAN_DT) {
+        u32 bin = 0;
+        p.counts[doc] = 0.f;
+        if (sa_span_doc_words<TT>(p.st, doc, W, c, keep, &many)) {
+            u32 npos = 0;
+            if (many) {
+                npos = sa_span_doc_npos_slow<TT>(p.st, doc);
+            } else {
+#pragma unroll
+                for (int t = 0; t < TT; t++)
+#pragma unroll
+                    for (int q = 0; q < SA_SPAN_DW; q++)
+                        if ((keep[t] >> q) & 1u) npos += (u32)__popc((u32)(W[t][q] & SA_LSB_MASK));
+            }
+            bin = npos == 0 ? 0u : ((many || npos > pmax) ? heavy_bin : npos);
+        }
+        p.dbin[doc] = (unsigned char)bin;
+        if (bin) { atomicAdd(&s_h[bin], 1u); atomicMax(&s_h[0], (u32)doc + 1u); }
+    }
+    __syncthreads();
+    if (threadIdx.x < SA_SPAN_DB) p.hist[(size_t)blockIdx.x * SA_SPAN_DB + threadIdx.x] = s_h[threadIdx.x];
+}
+
+template <int TT>
+__global__ void __launch_bounds__(SA_SPAN_DT) sa_k_span_doc_emit(const SpanDocParams p) {
+    __shared__ u32 s_tot[SA_SPAN_DB], s_pre[SA_SPAN_DB], s_base[SA_SPAN_DB];
+    if (threadIdx.x < SA_SPAN_DB) { s_tot[threadIdx.x] = 0; s_pre[threadIdx.x] = 0; }
+    __syncthreads();
+    // bin sizes, and how much of each bin the blocks before this one fill
+    {
+        const u32 n = gridDim.x * SA_SPAN_DB, mine = blockIdx.x * SA_SPAN_DB;
+        for (u32 i = threadIdx.x; i < n; i += SA_SPAN_DT) {
+            const u32 v = p.hist[i], x = i % SA_SPAN_DB;
+            if (v == 0) continue;
+            if (x == 0) { atomicMax(&s_tot[0], v); continue; }
+            atomicAdd(&s_tot[x], v);
+            if (i < mine) atomicAdd(&s_pre[x], v);
+        }
+    }
+    __syncthreads();
+    const u32 pmax = 4u * p.pa, heavy_bin = pmax + 1u;
+    if (threadIdx.x == 0) {
+        u32 base = 0;
+        for (u32 b = pmax; b >= 1u; b--) { s_base[b] = base; base += s_tot[b] * (b + 1u); }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < SA_SPAN_DB) p.sizes[threadIdx.x] = s_tot[threadIdx.x];
+    __syncthreads();
+    const u64 lo = (u64)blockIdx.x * p.docs_per_block;
+    const u64 hi = lo + p.docs_per_block < p.st.n_docs ? lo + p.docs_per_block : p.st.n_docs;
+    u64 W[TT][SA_SPAN_DW];
+    u32 c[TT], keep[TT];
+    bool many = false;
+    for (u64 doc = lo + threadIdx.x; doc < hi; doc += SA_SPAN_DT) {
+        const u32 bin = p.dbin[doc];
+        if (!bin) continue;
+        const u32 slot = atomicAdd(&s_pre[bin], 1u);
+        if (bin == heavy_bin) {
+            p.heavy[slot] = (u32)doc;
+            continue;
+        }
+        sa_span_doc_words<TT>(p.st, doc, W, c, keep, &many);
+        u32* rec = p.recs + s_base[bin] + (size_t)slot * (bin + 1u);
+        rec[0] = (u32)doc;
+        u32 n = 0;
+#pragma unroll
+        for (int t = 0; t < TT; t++)
+#pragma unroll
+            for (int q = 0; q < SA_SPAN_DW; q++)
+                if ((keep[t] >> q) & 1u) {
+                    const u64 w = W[t][q];
+                    const u32 payload_base = (u32)((w >> SA_LSB_BITS) & SA_LSB_MASK) * (u32)SA_LSB_BITS;
+                    u32 bits = (u32)(w & SA_LSB_MASK);
+                    while (bits != 0 && n < bin) {
+                        rec[1u + n] = ((u32)t << 24) | (payload_base + (u32)(__ffs((int)bits) - 1));
+                        bits &= bits - 1;
+                        n++;
+                    }
+                }
+    }
+}
+
+// one document through the wave machine: its words through the directory, 64 at a time -- candidate test per lane,
+// then the candidates one after the other.  last_doc1: the last document with candidates + 1 (the overflow rule's
+// "last document group of the term": with aligned groups, of every term).
+template <int TT>
+__device__ __forceinline__ void sa_span_wave_doc(const SpanDocParams& p, const u64 doc, SpanEnt* s_ents, const u32 lane, const u32 last_doc1) {
+#pragma unroll
+    for (int t = 0; t < TT; t++)
+        if (p.st.dd[t][doc] == SA_DD_ABSENT) return;
+    const int max_span_width = (int)((u32)TT + p.slop);
+    const bool is_last = (u32)doc + 1u == last_doc1;
+    u32 cursor = 0, my_sum = 0;
+    bool full = false;
+    __builtin_amdgcn_wave_barrier();
+    for (int t = 0; t < TT; t++) {
+        const u32 tstart = cursor;
+        const u32 n = p.st.len[t];
+        const u64* const w = p.st.words[t];
+        bool gave_up = false;
+        for (u32 j = p.st.dd[t][doc]; j < n && !gave_up; j += 64u) {
+            const u32 idx = j + lane;
+            const u64 wv = idx < n ? w[idx] : ~0ull;
+            const bool same = (wv >> SA_KEY_SHIFT) == doc;
+            const bool kp = same && sa_span_keep_word<TT>(p.st, wv & SA_HEADER_MASK);
+            const u64 sb = __ballot(same);
+            u64 todo = __ballot(kp);
+            // (the document's words are a prefix of the 64: candidates behind a word of another document do not exist)
+            while (todo != 0 && !gave_up) {
+                const int l = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)wv, l);
+                const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(wv >> 32), l);
+                const u64 wl = ((u64)hi << 32) | lo;
+                if (lane == (u32)t) my_sum += (u32)__popc((u32)(wl & SA_LSB_MASK));
+                sa_span_wave_word(s_ents, wl, 1u << t, tstart, (u32)TT, max_span_width, lane, cursor, full);
+                if (cursor >= SA_NSPANS && !is_last) gave_up = true;       // (see sa_span_doc)
+            }
+            if (sb != ~0ull) break;
+        }
+    }
+    const u32 incr = sa_span_wave_finish(s_ents, cursor, full, my_sum, TT, max_span_width, lane);
+    if (lane == 0 && incr) p.counts[doc] = (float)incr;
+    __builtin_amdgcn_wave_barrier();
+}
+
+// S lanes of the wave take S neighbouring records of bin b (b positions each); CE / PM: table rows and positions of a lane
+template <int CE, int PM, int S, int TT>
+__device__ __forceinline__ void sa_span_doc_chunk(const SpanDocParams& p, SpanEnt* s_ents, u32* s_pos, const u32 lane, const u32* recs_b,
+                                                  const u32 b, const u32 i0, const u32 sz, const u32 last_doc1) {
+    const u32 i = i0 + lane;
+    const bool have = lane < (u32)S && i < sz;
+    u32 doc = 0;
+    if (have) {
+        const u32* rec = recs_b + (size_t)i * (b + 1u);
+        doc = rec[0];
+        for (u32 q = 0; q < b; q++) s_pos[q * (u32)S + lane] = rec[1u + q];
+    }
+    u32 incr = 0;
+    const bool ok = sa_span_flat_loop<CE, PM, S>(SpanEntColS<S>{s_ents + (have ? lane : 0u)}, s_pos, have ? lane : 0u, have ? b : 0u, (u32)TT,
+                                                 (int)((u32)TT + p.slop), &incr);
+    if (ok && have && incr) p.counts[doc] = (float)incr;
+    // a lane whose table outgrew its column: the document again, with the whole wave
+    u64 ab = __ballot(have && !ok);
+    while (ab != 0) {
+        const int l = __builtin_ctzll(ab);
+        ab &= ab - 1;
+        const u32 d = (u32)__builtin_amdgcn_readlane((int)doc, l);
+        sa_span_wave_doc<TT>(p, d, s_ents, lane, last_doc1);
+    }
+}
+
+// CA: table rows of a lane when all 64 lanes of the wave hold a document; PA: positions (template copy of p.pa)
+template <int CA, int PA, int TT>
+__global__ void __launch_bounds__(64) sa_k_span_doc_machine(const SpanDocParams p) {
+    constexpr int ROWS = CA + 1;                                 // (+ the scratch row of sa_span_flat_loop)
+    __shared__ alignas(16) SpanEnt s_ents[ROWS * 64];
+    __shared__ u32 s_pos[PA * 64];
+    static_assert(ROWS * 64 >= SA_NSPANS, "the lane tables must hold one full table");
+    const u32 lane = threadIdx.x;
+    const u32 last_doc1 = p.sizes[0];
+    constexpr u32 PMAXB = 4u * PA;
+    // the heavy documents first (the longest single items), a wave each
+    const u32 nh = p.sizes[PMAXB + 1u];
+    for (u32 item = blockIdx.x; item < nh; item += gridDim.x) sa_span_wave_doc<TT>(p, p.heavy[item], s_ents, lane, last_doc1);
+    // then the records: the bins with the most positions first.  Lane x holds bin PMAXB - x: where its chunks and its
+    // records start (a wave scan), so that a chunk finds its bin with one ballot.
+    const u32 my_bin = lane < PMAXB ? PMAXB - lane : 0u;
+    const u32 my_per = my_bin > 2u * PA ? 16u : (my_bin > (u32)PA ? 32u : 64u);
+    const u32 my_sz = my_bin ? p.sizes[my_bin] : 0u;
+    u32 my_first = (my_sz + my_per - 1u) / my_per, my_rbase = my_sz * (my_bin + 1u);        // inclusive scans first
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 a = __shfl_up(my_first, o, SA_WAVE), c = __shfl_up(my_rbase, o, SA_WAVE);
+        if (lane >= (u32)o) { my_first += a; my_rbase += c; }
+    }
+    const u32 n_chunks = (u32)__builtin_amdgcn_readlane((int)my_first, 63);
+    my_first -= (my_sz + my_per - 1u) / my_per;                  // exclusive
+    my_rbase -= my_sz * (my_bin + 1u);
+    for (u32 ck = blockIdx.x; ck < n_chunks; ck += gridDim.x) {
+        // the chunk's bin: the last one (going down) that starts at or before it
+        const u64 at = __ballot(my_bin != 0u && ck >= my_first);
+        const int idx = 63 - __builtin_clzll(at);                // (lane 0 starts at chunk 0: never empty)
+        const u32 b = PMAXB - (u32)idx;
+        const u32 first_b = (u32)__builtin_amdgcn_readlane((int)my_first, idx);
+        const u32 rbase_b = (u32)__builtin_amdgcn_readlane((int)my_rbase, idx);
+        const u32 sz = (u32)__builtin_amdgcn_readlane((int)my_sz, idx);
+        __builtin_amdgcn_wave_barrier();
+        if (b > 2u * PA) sa_span_doc_chunk<4 * ROWS - 1, 4 * PA, 16, TT>(p, s_ents, s_pos, lane, p.recs + rbase_b, b, (ck - first_b) * 16u, sz, last_doc1);
+        else if (b > (u32)PA) sa_span_doc_chunk<2 * ROWS - 1, 2 * PA, 32, TT>(p, s_ents, s_pos, lane, p.recs + rbase_b, b, (ck - first_b) * 32u, sz, last_doc1);
+        else sa_span_doc_chunk<CA, PA, 64, TT>(p, s_ents, s_pos, lane, p.recs + rbase_b, b, (ck - first_b) * 64u, sz, last_doc1);
+    }
+}
+
+static int sa_env_int_span(const char* name, int dflt) {
+    const char* v = getenv(name);
+    if (!v) return dflt;
+    const int x = atoi(v);
+    return x > 0 ? x : dflt;
+}
+
+static bool sa_env_span_doc() {
+    const char* v = getenv("SA_SPAN_DOC");
+    return !(v && atoi(v) == 0);
+}
+
+template <int TT>
+static void sa_span_doc_launch(const SpanDocParams& p, dim3 fg, dim3 mg, hipStream_t st) {
+    hipLaunchKernelGGL((sa_k_span_doc_count<TT>), fg, dim3(SA_SPAN_DT), 0, st, p);
+    hipLaunchKernelGGL((sa_k_span_doc_emit<TT>), fg, dim3(SA_SPAN_DT), 0, st, p);
+    if (getenv("SA_SPAN_TRACE") && atoi(getenv("SA_SPAN_TRACE")) >= 2) {
+        u32 h[SA_SPAN_DB];
+        hipStreamSynchronize(st);
+        hipMemcpy(h, p.sizes, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "slop doc route: bin sizes");
+        for (u32 b = 1; b <= 4 * p.pa + 1; b++) fprintf(stderr, " %u", h[b]);
+        fprintf(stderr, " last doc + 1 %u\n", h[0]);
+    }
+    if (TT == 2) {
+        if (p.pa == 8) hipLaunchKernelGGL((sa_k_span_doc_machine<SA_SPAN_LDS, 8, TT>), mg, dim3(64), 0, st, p);
+        else hipLaunchKernelGGL((sa_k_span_doc_machine<SA_SPAN_LDS, 10, TT>), mg, dim3(64), 0, st, p);
+    } else {
+        if (p.pa == 8) hipLaunchKernelGGL((sa_k_span_doc_machine<16, 8, TT>), mg, dim3(64), 0, st, p);
+        else hipLaunchKernelGGL((sa_k_span_doc_machine<16, 10, TT>), mg, dim3(64), 0, st, p);
+    }
+}
+
+static int sa_span_counts_doc_route(sa_index* ix, const SpanTerms& terms_dev, int T, int slop, float** d_out) {
+    hipStream_t st = ix->stream;
+    const u64 N = ix->n_docs;
+    u64 min_len = terms_dev.len[0], total_len = 0;
+    for (int t = 0; t < T; t++) { min_len = std::min<u64>(min_len, terms_dev.len[t]); total_len += terms_dev.len[t]; }
+    u32 pa = 8;
+    if (const char* v = getenv("SA_SPAN_DOC_PA")) { if (atoi(v) == 10) pa = 10; }
+    const u32 pmax = 4 * pa;
+    // count / emit blocks: at most SA_SPAN_DG (every emit block reads all the histograms), whole multiples of the block size each
+    u64 per_block = (N + SA_SPAN_DG - 1) / SA_SPAN_DG;
+    per_block = std::max<u64>(4 * SA_SPAN_DT, (per_block + SA_SPAN_DT - 1) / SA_SPAN_DT * SA_SPAN_DT);   // (4 documents per thread: measured, 2 / 4 / 8 / 16)
+    if (const char* v = getenv("SA_SPAN_DOC_PER_BLOCK")) { const int x = atoi(v); if (x >= 1) per_block = (u64)x; }   // tests: many small blocks
+    const u32 fgrid = (u32)((N + per_block - 1) / per_block);
+    // a document in a lane bin has <= pmax positions and is a document of the rarest term; every position is a bit of a word
+    const u64 rec_words = std::min<u64>(min_len * (pmax + 1), total_len * SA_LSB_BITS + min_len) + 64;
+    const size_t need = (N + 64) * 4 + (N + 256) + rec_words * 4 + (min_len + 64) * 4 + ((size_t)fgrid + 2) * SA_SPAN_DB * 4 + 4096;
+    void* scratch;
+    SA_TRY(sa_index_scratch(ix, need, &scratch));
+    char* base = (char*)scratch;
+    size_t used = 0;
+    auto take = [&](size_t bytes) { char* q = base + used; used += (bytes + 255) & ~(size_t)255; return q; };
+    SpanDocParams p;
+    memset(&p, 0, sizeof(p));
+    p.st = terms_dev;
+    p.st.off[0] = 0;
+    for (int t = 0; t < T; t++) p.st.off[t + 1] = p.st.off[t] + p.st.len[t];
+    p.slop = (u32)slop;
+    p.pa = pa;
+    p.docs_per_block = (u32)per_block;
+    p.counts = (float*)take((N + 1) * 4);
+    p.dbin = (unsigned char*)take(N + 1);
+    p.hist = (u32*)take((size_t)fgrid * SA_SPAN_DB * 4);
+    p.sizes = (u32*)take(SA_SPAN_DB * 4);
+    p.recs = (u32*)take(rec_words * 4);
+    p.heavy = (u32*)take((min_len + 1) * 4);
+    if (used > need) { sa_set_error("internal: span scratch exhausted"); return SA_ERR_STATE; }
+    *d_out = p.counts;
+    // the machine: resident waves striding over the chunks (no more waves than there can be chunks)
+    const u32 mgrid = (u32)std::min<u64>(min_len / 16 + pmax + 1, (u64)sa_env_int_span("SA_SPAN_DOC_GRID", 4096));
+    const dim3 fg(fgrid), mg(mgrid);
+    switch (T) {
+    case 2: sa_span_doc_launch<2>(p, fg, mg, st); break;
+    case 3: sa_span_doc_launch<3>(p, fg, mg, st); break;
+    default: sa_span_doc_launch<4>(p, fg, mg, st); break;
+    }
+    SA_HIP(hipGetLastError());
+    return SA_OK;
+}
+
 // ---- B slop phrases in SHARED launches (phrase batches, BASELINE config 5) ------------------------------------------
 // A sampled slop phrase is five short launches, and a batch of them is bound by the host's launch rate (round 2: 25 K
 // phrases/s over two streams).  Here every stage is ONE launch for all phrases of a class (2, 3, 4 terms, more):
@@ -1097,6 +1538,25 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
         if (terms_dev.len[t] > max_len) max_len = terms_dev.len[t];
     }
     if (total_len > 0xFFFFFFF0ull) { sa_set_error("slop phrase: more than 2^32 words in the phrase's terms"); return SA_ERR_UNSUPPORTED; }
+    // the doc-parallel route: 2..4 known terms, all with a directory row (whole lists, no word in a last block), header
+    // 0 not in L (host arithmetic on the per-term edge flags, as below)
+    if (known && !filt.active && T >= 2 && T <= 4 && N > 0 && N < 0xFFFFFFF0ull && sa_env_span_doc() &&
+        ix->h_term_edge.size() >= (size_t)ix->n_terms) {
+        bool all_dd = true;
+        for (int t = 0; t < T; t++) all_dd = all_dd && terms_dev.dd[t] != nullptr && terms_dev.len[t] > 0;
+        const unsigned char e0 = ix->h_term_edge[terms[0]];
+        bool L = true;
+        for (int i = 1; i < T; i++) {
+            const unsigned char ei = ix->h_term_edge[terms[i]];
+            const bool a0 = e0 & 1, a0m = e0 & 2, bi = ei & 1, bim = ei & 2;
+            L &= (a0 && bi) || (bi && a0m) || (a0 && bim);
+        }
+        // (two terms: the `L - 1` widening adds nothing -- a word at h with L(h + 1) has R(h), whichever clause of
+        //  Lset(h + 1) holds and whichever term the word is of -- so its loss changes nothing either)
+        const bool take = all_dd && (T == 2 || !L);
+        if (getenv("SA_SPAN_TRACE")) fprintf(stderr, "slop route: %s (T %d, directory rows %d, header 0 in L %d)\n", take ? "doc-parallel" : "general", T, (int)all_dd, (int)L);
+        if (take) return sa_span_counts_doc_route(ix, terms_dev, T, slop, d_out);
+    }
     // resident state-machine threads: no more than there can be document groups
     u32 G = (u32)((terms_dev.len[0] + 63u) & ~63u);
     u32 g_max = SA_SPAN_THREADS;

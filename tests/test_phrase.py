@@ -223,6 +223,59 @@ def test_slop_random_differential(api, seed, monkeypatch):
         assert np.array_equal(got, want), f"seed {seed} terms {terms} slop {slop}: {np.flatnonzero(got != want)[:5]}"
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_slop_doc_parallel_route(api, seed, monkeypatch, capfd):
+    """The doc-parallel slop route (sa_spans.hip: frequent terms with directory rows -- count / emit / machine over
+    per-document position records) against the oracle AND the general route, on corpora that reach each of its parts:
+    documents in every lane bin, documents with more positions than a lane takes (heavy: a wave each), documents with
+    more than four words of a term (the count pass's slow path), lane tables that outgrow their column (redone by the
+    lane's own wave).  Two-term phrases take it whether or not header 0 is in L; three and four terms only when it is
+    not -- doc 0 is kept free of the frequent terms on the even seeds so that both cases occur."""
+    from oracle import spans as S
+    monkeypatch.setenv("SA_SPAN_TRACE", "1")
+    rng = np.random.default_rng(700 + seed)
+    n_docs, vocab = int(rng.integers(300, 600)), 6
+    t, d, p, lens = synth.corpus_triples(n_docs, vocab, int(rng.integers(8, 30)), seed=60 + seed)
+    # a few long documents: many positions, many words per term
+    extra_t, extra_d, extra_p = [], [], []
+    for doc in rng.choice(np.arange(1, n_docs), 12, replace=False):
+        base = int(lens[doc])
+        n = int(rng.integers(40, 260))
+        extra_t.append(rng.integers(0, vocab, n)); extra_d.append(np.full(n, doc)); extra_p.append(base + np.arange(n))
+        lens[doc] += n
+    t = np.concatenate([t] + extra_t); d = np.concatenate([d] + extra_d); p = np.concatenate([p] + extra_p)
+    if seed % 2 == 0:                                    # no frequent term at the very start of doc 0: header 0 not in L
+        keep = ~((d == 0) & (p < 40))
+        t, d, p = t[keep], d[keep], p[keep]
+    order = np.lexsort((p, d, t))
+    t, d, p = t[order], d[order], p[order]
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
+    routes = {"doc-parallel": 0, "general": 0}
+    for T in (2, 2, 3, 3, 4):
+        terms = [int(x) for x in rng.integers(0, vocab, T)]
+        slop = int(rng.integers(1, 7))
+        enc = [orc.enc(x) for x in terms]
+        ids, counts, overflow = S.span_search(enc, slop, return_overflow=True)
+        want = np.zeros(n_docs, dtype=np.float32)
+        want[ids.astype(np.int64)] = counts
+        capfd.readouterr()
+        got = dev.phrase_freqs_dense(terms, slop=slop)
+        err = capfd.readouterr().err
+        for r in routes:
+            routes[r] += f"slop route: {r}" in err
+        assert np.array_equal(got, want), f"seed {seed} terms {terms} slop {slop}: {np.flatnonzero(got != want)[:5]}"
+        monkeypatch.setenv("SA_SPAN_DOC", "0")
+        other = dev.phrase_freqs_dense(terms, slop=slop)
+        monkeypatch.delenv("SA_SPAN_DOC")
+        assert np.array_equal(other, want), f"general route: seed {seed} terms {terms} slop {slop}"
+    dev.close()
+    assert routes["doc-parallel"] >= 2, routes
+    if seed % 2 == 0:
+        assert routes["doc-parallel"] == 5, routes
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_slop_five_to_eight_terms(api, seed, monkeypatch, on_emu):
     """phrases of more terms than the span kernels are specialised for (flags: 2-4 terms; the fast pass requests the
