@@ -1005,39 +1005,47 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_wave(const SpanMachinePa
 //     So the k-th document group of every term is the SAME document, and "the k-th group of every term" (what the
 //     reference's lock-step walk takes, and what the general route reproduces through stable compactions) is "the
 //     document" -- no ranks, no compaction, any order.
-// Three launches, everything read and written in whole lines, no device-wide atomics (a same-line atomic from every
-// block costs more than the kernels: measured) and nothing to clear:
-//   count   one thread per document (lane = doc: the directory rows and the documents' words are read in doc order):
-//           candidate words, their positions -> the document's bin: 0 none, npos for npos <= PMAX, else heavy; a
-//           histogram per BLOCK, stored; the dense result cleared;
-//   emit    every block sums the histograms (all: bin sizes; the blocks before it: its share of each bin), then the
-//           same again (the lists come from the Infinity Cache this time), now writing each document's position
-//           list -- doc, then term << 24 | position in the machine's order -- as a fixed-size record into ITS BIN's
-//           region, bins in descending order: what the general route's counting sort + scattered gathers produce
-//           (waves of equal work, busiest first), but as dense records;
-//   machine a wave takes neighbouring records of one bin, one document per lane, sa_span_flat_loop on the records read
-//           as they lie.  Bins up to PA positions: 64 documents per wave; up to 2 PA: 32, each with twice the table
-//           rows and positions in the same LDS; up to 4 PA: 16 with four times -- so that a document with many
-//           positions (whose table would outgrow a 64-lane column) still runs as a lane, not as a wave.  Documents
-//           beyond that (heavy) come first, a wave each (sa_span_wave_doc: the words through the directory, candidate
-//           test per lane, the 512-span table in LDS); a lane whose table still outgrows its column is redone by its
-//           own wave the same way.
-#define SA_SPAN_DW 4                     // words of one term per document the count / emit passes hold in registers
-#define SA_SPAN_DB 48                    // bins: [npos] for 1 <= npos <= 4 PA (<= 40), [4 PA + 1] heavy
-#define SA_SPAN_DT 512                   // threads of a count / emit block
-#define SA_SPAN_DG 512                   // at most this many count / emit blocks (each sums all the histograms)
+// Two launches, everything read and written in whole lines, a handful of device-wide atomics per block (a same-line
+// atomic costs ~3 ns whoever issues it: 10 K of them were the first version's whole run time):
+//   sort    a block takes SA_SPAN_DPB neighbouring documents, one per thread and round (lane = doc: the directory
+//           rows and the documents' words are read in doc order).  Round one: candidate words, their positions -> the
+//           document's bin (0 none, npos up to 4 PA, else heavy), a histogram in LDS, the dense result cleared.  Then
+//           the block orders ITS documents by bin, most positions first, reserves its share of the record buffer
+//           (one atomic), and round two writes each document's position list -- doc, then term << 24 | position in
+//           the machine's order -- where the order puts it, plus the record's offset and npos in a table in the same
+//           order.  Finally it cuts its order into chunks -- 16 records while they have more than 2 PA positions, 32
+//           above PA, else 64 -- and appends the chunks to four work lists (heaviest class first; one atomic per list);
+//   machine resident waves take the heavy documents first (sa_span_wave_doc: a wave each, the words through the
+//           directory, candidate test per lane, the 512-span table in LDS), then the chunks list by list: one
+//           document per lane, sa_span_flat_loop on the records read as they lie.  16- and 32-lane chunks give a
+//           lane four times / twice the table rows and positions in the same LDS -- so that a document with many
+//           positions (whose table would outgrow a 64-lane column) still runs as a lane, not as a wave.  A lane whose
+//           table outgrows its column even so is redone by its own wave the heavy way.
+// What the general route's counting sort + scattered gathers produce (waves of equal work, busiest first) is here the
+// order of dense records; neighbouring records of a block differ by at most a position or two.
+#define SA_SPAN_DW 4                     // words of one term per document the sort rounds hold in registers
+#define SA_SPAN_DB 64                    // bins: [npos] for 1 <= npos <= 4 PA (<= 40), [4 PA + 1] heavy
+#define SA_SPAN_DPB 2048                 // documents of a sort block
+#define SA_SPAN_PC 8                     // positions of a document round one keeps in LDS for round two
+#define SA_SPAN_DIR 4                    // directory row of a sort block: records, offset of its records, last candidate doc + 1
+#define SA_SPAN_NLIST 4                  // work lists: 16-lane chunks, 32-lane chunks, 64-lane chunks with more / fewer than PA / 2 positions
+#define SA_SPAN_CNT 8                    // counters: the lists' sizes, record words, heavy documents
 
 struct SpanDocParams {
     SpanTerms st;                        // dd[t] != null for every term
     u32 slop;
     u32 pa;                              // positions of a document a full wave's lane takes; pmax = 4 pa
-    u32 docs_per_block;                  // count / emit: block x takes documents [x, x + 1) * docs_per_block
+    u32 list_cap;
     float* counts;                       // the dense result
-    unsigned char* dbin;                 // [n_docs] the document's bin, 0: no candidate
-    u32* hist;                           // [blocks][SA_SPAN_DB] per-block bin sizes; [.][0]: the block's last candidate doc + 1
-    u32* sizes;                          // [SA_SPAN_DB] bin sizes; [0]: last candidate doc + 1 (written by emit's block 0)
-    u32* recs;                           // position records, bin 4 PA first: sizes[b] x (b + 1) words
-    u32* heavy;                          // doc ids of the heavy bin
+    u32* dir;                            // [blocks][SA_SPAN_DIR]
+    u32* roff;                           // [blocks][SA_SPAN_DPB] record offset (in the block's share) | npos << 24, in the block's order
+    u32* recs;                           // position records
+    u32* heavy;                          // doc ids of the heavy documents
+    u32* lists;                          // [SA_SPAN_NLIST][list_cap] chunks: sort block << 12 | first record
+    u32* cnt;                            // counters of this query (zeros on entry)
+    u32* cnt_next;                       // the next query's (the sort pass clears them)
+    u32 n_blocks;
+    u32 dpb;                             // documents of a sort block
 };
 
 // candidate predicate of the word with header h, probing every term through its doc directory
@@ -1144,108 +1152,162 @@ __device__ __forceinline__ bool sa_span_doc_words(const SpanTerms& st, const u64
     return true;
 }
 
+// the positions of the document's candidate words, in the machine's order (term by term, word by word, bit by bit), at
+// most `cap` of them: dst[n * stride] = term << 24 | position
 template <int TT>
-__global__ void __launch_bounds__(SA_SPAN_DT) sa_k_span_doc_count(const SpanDocParams p) {
-    __shared__ u32 s_h[SA_SPAN_DB];
-    if (threadIdx.x < SA_SPAN_DB) s_h[threadIdx.x] = 0;          // ([0]: last candidate doc + 1)
-    __syncthreads();
-    const u32 pmax = 4u * p.pa, heavy_bin = pmax + 1u;
-    const u64 lo = (u64)blockIdx.x * p.docs_per_block;
-    const u64 hi = lo + p.docs_per_block < p.st.n_docs ? lo + p.docs_per_block : p.st.n_docs;
-    u64 W[TT][SA_SPAN_DW];
-    u32 c[TT], keep[TT];
-    bool many = false;
-    for (u64 doc = lo + threadIdx.x; doc < hi; doc += SA_SPAN_DT) {
-        u32 bin = 0;
-        p.counts[doc] = 0.f;
-        if (sa_span_doc_words<TT>(p.st, doc, W, c, keep, &many)) {
-            u32 npos = 0;
-            if (many) {
-                npos = sa_span_doc_npos_slow<TT>(p.st, doc);
-            } else {
+__device__ __forceinline__ void sa_span_doc_positions(const u64 (&W)[TT][SA_SPAN_DW], const u32 (&keep)[TT], u32* dst, const u32 stride, const u32 cap) {
+    u32 n = 0;
 #pragma unroll
-                for (int t = 0; t < TT; t++)
+    for (int t = 0; t < TT; t++)
 #pragma unroll
-                    for (int q = 0; q < SA_SPAN_DW; q++)
-                        if ((keep[t] >> q) & 1u) npos += (u32)__popc((u32)(W[t][q] & SA_LSB_MASK));
+        for (int q = 0; q < SA_SPAN_DW; q++)
+            if ((keep[t] >> q) & 1u) {
+                const u64 w = W[t][q];
+                const u32 payload_base = (u32)((w >> SA_LSB_BITS) & SA_LSB_MASK) * (u32)SA_LSB_BITS;
+                u32 bits = (u32)(w & SA_LSB_MASK);
+                while (bits != 0 && n < cap) {
+                    dst[n * stride] = ((u32)t << 24) | (payload_base + (u32)(__ffs((int)bits) - 1));
+                    bits &= bits - 1;
+                    n++;
+                }
             }
-            bin = npos == 0 ? 0u : ((many || npos > pmax) ? heavy_bin : npos);
-        }
-        p.dbin[doc] = (unsigned char)bin;
-        if (bin) { atomicAdd(&s_h[bin], 1u); atomicMax(&s_h[0], (u32)doc + 1u); }
-    }
-    __syncthreads();
-    if (threadIdx.x < SA_SPAN_DB) p.hist[(size_t)blockIdx.x * SA_SPAN_DB + threadIdx.x] = s_h[threadIdx.x];
 }
 
-template <int TT>
-__global__ void __launch_bounds__(SA_SPAN_DT) sa_k_span_doc_emit(const SpanDocParams p) {
-    __shared__ u32 s_tot[SA_SPAN_DB], s_pre[SA_SPAN_DB], s_base[SA_SPAN_DB];
-    if (threadIdx.x < SA_SPAN_DB) { s_tot[threadIdx.x] = 0; s_pre[threadIdx.x] = 0; }
-    __syncthreads();
-    // bin sizes, and how much of each bin the blocks before this one fill
-    {
-        const u32 n = gridDim.x * SA_SPAN_DB, mine = blockIdx.x * SA_SPAN_DB;
-        for (u32 i = threadIdx.x; i < n; i += SA_SPAN_DT) {
-            const u32 v = p.hist[i], x = i % SA_SPAN_DB;
-            if (v == 0) continue;
-            if (x == 0) { atomicMax(&s_tot[0], v); continue; }
-            atomicAdd(&s_tot[x], v);
-            if (i < mine) atomicAdd(&s_pre[x], v);
-        }
-    }
+// DT: threads of a block (1024 while the registers allow: every thread waits for its document's loads, and the block's
+// documents in flight are what hides that)
+template <int TT, int DT, int DPB>
+__global__ void __launch_bounds__(DT) sa_k_span_doc_sort(const SpanDocParams p) {
+    __shared__ u32 s_plist[SA_SPAN_PC * DPB];            // round one's position lists (documents of up to SA_SPAN_PC positions), position-major
+    __shared__ unsigned char s_bin[DPB];
+    __shared__ u32 s_h[SA_SPAN_DB], s_first[SA_SPAN_DB], s_woff[SA_SPAN_DB], s_cur[SA_SPAN_DB];
+    __shared__ u32 s_misc[16];
+    constexpr int ROUNDS = DPB / DT;
+    if (threadIdx.x < SA_SPAN_DB) { s_h[threadIdx.x] = 0; s_cur[threadIdx.x] = 0; }
+    if (threadIdx.x < 16) s_misc[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < SA_SPAN_CNT) p.cnt_next[threadIdx.x] = 0u;
     __syncthreads();
     const u32 pmax = 4u * p.pa, heavy_bin = pmax + 1u;
-    if (threadIdx.x == 0) {
-        u32 base = 0;
-        for (u32 b = pmax; b >= 1u; b--) { s_base[b] = base; base += s_tot[b] * (b + 1u); }
-    }
-    if (blockIdx.x == 0 && threadIdx.x < SA_SPAN_DB) p.sizes[threadIdx.x] = s_tot[threadIdx.x];
-    __syncthreads();
-    const u64 lo = (u64)blockIdx.x * p.docs_per_block;
-    const u64 hi = lo + p.docs_per_block < p.st.n_docs ? lo + p.docs_per_block : p.st.n_docs;
+    const u64 lo = (u64)blockIdx.x * DPB;
     u64 W[TT][SA_SPAN_DW];
     u32 c[TT], keep[TT];
-    bool many = false;
-    for (u64 doc = lo + threadIdx.x; doc < hi; doc += SA_SPAN_DT) {
-        const u32 bin = p.dbin[doc];
+    // ---- round one: bins (and the short position lists, kept for round two)
+#pragma unroll 1
+    for (int r = 0; r < ROUNDS; r++) {
+        const u32 local = (u32)r * DT + threadIdx.x;
+        const u64 doc = lo + local;
+        u32 bin = 0;
+        if (doc < p.st.n_docs) {
+            p.counts[doc] = 0.f;
+            bool many = false;
+            if (sa_span_doc_words<TT>(p.st, doc, W, c, keep, &many)) {
+                u32 npos = 0;
+                if (many) {
+                    npos = sa_span_doc_npos_slow<TT>(p.st, doc);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < TT; t++)
+#pragma unroll
+                        for (int q = 0; q < SA_SPAN_DW; q++)
+                            if ((keep[t] >> q) & 1u) npos += (u32)__popc((u32)(W[t][q] & SA_LSB_MASK));
+                    if (npos != 0 && npos <= (u32)SA_SPAN_PC) sa_span_doc_positions<TT>(W, keep, s_plist + local, DPB, npos);
+                }
+                bin = npos == 0 ? 0u : ((many || npos > pmax) ? heavy_bin : npos);
+            }
+            if (bin) { atomicAdd(&s_h[bin], 1u); atomicMax(&s_misc[0], (u32)doc + 1u); }
+        }
+        s_bin[local] = (unsigned char)bin;
+    }
+    __syncthreads();
+    // ---- the block's order: bins with the most positions first; where each bin's documents and records start; its
+    //      chunks: 16 records while they have more than 2 PA positions, then 32 above PA, then 64
+    if (threadIdx.x == 0) {
+        u32 n = 0, words = 0, n_c = 0, n_b = 0, n_hi = 0;          // records, their words, records of the classes
+        for (u32 b = pmax; b >= 1u; b--) {
+            s_first[b] = n; s_woff[b] = words; n += s_h[b]; words += s_h[b] * (b + 1u);
+            if (b > 2u * p.pa) n_c += s_h[b];
+            else if (b > p.pa) n_b += s_h[b];
+            else if (2u * b > p.pa) n_hi += s_h[b];
+        }
+        s_first[heavy_bin] = 0;
+        const u32 k_c = (n_c + 15u) / 16u;
+        const u32 start_b = 16u * k_c < n ? 16u * k_c : n;
+        const u32 k_b = n_c + n_b > start_b ? (n_c + n_b - start_b + 31u) / 32u : 0u;
+        const u32 start_a = start_b + 32u * k_b < n ? start_b + 32u * k_b : n;
+        const u32 k_a = (n - start_a + 63u) / 64u;
+        const u32 hi_end = n_c + n_b + n_hi;                     // a 64-lane chunk that starts before this is of the busier kind
+        const u32 k_hi = hi_end > start_a ? ((hi_end - start_a + 63u) / 64u < k_a ? (hi_end - start_a + 63u) / 64u : k_a) : 0u;
+        s_misc[1] = n;
+        s_misc[4] = k_c; s_misc[5] = k_b; s_misc[6] = k_hi; s_misc[7] = k_a - k_hi;
+        s_misc[12] = start_b; s_misc[13] = start_a;
+        s_misc[14] = words; s_misc[15] = s_h[heavy_bin];
+    }
+    __syncthreads();
+    // the block's reservations: its chunks in the four lists, its record words, its heavy documents -- one lane each,
+    // so that the six round trips overlap
+    if (threadIdx.x < 6) {
+        const u32 amount = threadIdx.x < 4 ? s_misc[4 + threadIdx.x] : s_misc[14 + (threadIdx.x - 4)];
+        s_misc[threadIdx.x < 4 ? 8 + threadIdx.x : threadIdx.x - 2] = amount ? atomicAdd(&p.cnt[threadIdx.x], amount) : 0u;        // [8..11] lists, [2] words, [3] heavy
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32* d = p.dir + (size_t)blockIdx.x * SA_SPAN_DIR;
+        d[0] = s_misc[1]; d[1] = s_misc[2]; d[2] = s_misc[0];
+    }
+    {
+        const u32 k_c = s_misc[4], k_b = s_misc[5], k_hi = s_misc[6], k_lo = s_misc[7], start_b = s_misc[12], start_a = s_misc[13];
+        const u32 desc = blockIdx.x << 12;
+        for (u32 i = threadIdx.x; i < k_c + k_b + k_hi + k_lo; i += DT) {
+            if (i < k_c) p.lists[s_misc[8] + i] = desc | (16u * i);
+            else if (i < k_c + k_b) p.lists[(size_t)p.list_cap + s_misc[9] + (i - k_c)] = desc | (start_b + 32u * (i - k_c));
+            else if (i < k_c + k_b + k_hi) p.lists[2 * (size_t)p.list_cap + s_misc[10] + (i - k_c - k_b)] = desc | (start_a + 64u * (i - k_c - k_b));
+            else p.lists[3 * (size_t)p.list_cap + s_misc[11] + (i - k_c - k_b - k_hi)] = desc | (start_a + 64u * (i - k_c - k_b));
+        }
+    }
+    // ---- round two: the records, in the block's order
+    u32* const recs = p.recs + s_misc[2];
+    u32* const roff = p.roff + (size_t)blockIdx.x * DPB;
+#pragma unroll 1
+    for (int r = 0; r < ROUNDS; r++) {
+        const u32 local = (u32)r * DT + threadIdx.x;
+        const u64 doc = lo + local;
+        const u32 bin = s_bin[local];
         if (!bin) continue;
-        const u32 slot = atomicAdd(&s_pre[bin], 1u);
+        const u32 k = atomicAdd(&s_cur[bin], 1u);
         if (bin == heavy_bin) {
-            p.heavy[slot] = (u32)doc;
+            p.heavy[s_misc[3] + k] = (u32)doc;
             continue;
         }
-        sa_span_doc_words<TT>(p.st, doc, W, c, keep, &many);
-        u32* rec = p.recs + s_base[bin] + (size_t)slot * (bin + 1u);
+        const u32 off = s_woff[bin] + k * (bin + 1u);
+        roff[s_first[bin] + k] = off | (bin << 24);
+        u32* rec = recs + off;
         rec[0] = (u32)doc;
-        u32 n = 0;
-#pragma unroll
-        for (int t = 0; t < TT; t++)
-#pragma unroll
-            for (int q = 0; q < SA_SPAN_DW; q++)
-                if ((keep[t] >> q) & 1u) {
-                    const u64 w = W[t][q];
-                    const u32 payload_base = (u32)((w >> SA_LSB_BITS) & SA_LSB_MASK) * (u32)SA_LSB_BITS;
-                    u32 bits = (u32)(w & SA_LSB_MASK);
-                    while (bits != 0 && n < bin) {
-                        rec[1u + n] = ((u32)t << 24) | (payload_base + (u32)(__ffs((int)bits) - 1));
-                        bits &= bits - 1;
-                        n++;
-                    }
-                }
+        if (bin <= (u32)SA_SPAN_PC) {
+            for (u32 q = 0; q < bin; q++) rec[1u + q] = s_plist[q * DPB + local];
+        } else {
+            bool many = false;
+            sa_span_doc_words<TT>(p.st, doc, W, c, keep, &many);
+            sa_span_doc_positions<TT>(W, keep, rec + 1, 1u, bin);
+        }
     }
+}
+
+// the last document with candidates + 1: the maximum over the sort blocks (looked up when a table fills, i.e. hardly ever)
+__device__ __forceinline__ u32 sa_span_doc_last(const SpanDocParams& p, const u32 lane) {
+    u32 m = 0;
+    for (u32 i = lane; i < p.n_blocks; i += 64u) { const u32 v = p.dir[(size_t)i * SA_SPAN_DIR + 2]; m = v > m ? v : m; }
+    return sa_wave_max(m);
 }
 
 // one document through the wave machine: its words through the directory, 64 at a time -- candidate test per lane,
-// then the candidates one after the other.  last_doc1: the last document with candidates + 1 (the overflow rule's
-// "last document group of the term": with aligned groups, of every term).
+// then the candidates one after the other.  (The overflow rule's "last document group of the term" is, with aligned
+// groups, the last document with candidates: sa_span_doc_last.)
 template <int TT>
-__device__ __forceinline__ void sa_span_wave_doc(const SpanDocParams& p, const u64 doc, SpanEnt* s_ents, const u32 lane, const u32 last_doc1) {
+__device__ __forceinline__ void sa_span_wave_doc(const SpanDocParams& p, const u64 doc, SpanEnt* s_ents, const u32 lane) {
 #pragma unroll
     for (int t = 0; t < TT; t++)
         if (p.st.dd[t][doc] == SA_DD_ABSENT) return;
     const int max_span_width = (int)((u32)TT + p.slop);
-    const bool is_last = (u32)doc + 1u == last_doc1;
+    u32 last_doc1 = 0xFFFFFFFFu;                                 // (not looked up yet)
     u32 cursor = 0, my_sum = 0;
     bool full = false;
     __builtin_amdgcn_wave_barrier();
@@ -1270,7 +1332,10 @@ __device__ __forceinline__ void sa_span_wave_doc(const SpanDocParams& p, const u
                 const u64 wl = ((u64)hi << 32) | lo;
                 if (lane == (u32)t) my_sum += (u32)__popc((u32)(wl & SA_LSB_MASK));
                 sa_span_wave_word(s_ents, wl, 1u << t, tstart, (u32)TT, max_span_width, lane, cursor, full);
-                if (cursor >= SA_NSPANS && !is_last) gave_up = true;       // (see sa_span_doc)
+                if (cursor >= SA_NSPANS) {                                 // (see sa_span_doc)
+                    if (last_doc1 == 0xFFFFFFFFu) last_doc1 = sa_span_doc_last(p, lane);
+                    if ((u32)doc + 1u != last_doc1) gave_up = true;
+                }
             }
             if (sb != ~0ull) break;
         }
@@ -1280,20 +1345,25 @@ __device__ __forceinline__ void sa_span_wave_doc(const SpanDocParams& p, const u
     __builtin_amdgcn_wave_barrier();
 }
 
-// S lanes of the wave take S neighbouring records of bin b (b positions each); CE / PM: table rows and positions of a lane
+// S lanes of the wave take S neighbouring records of a sort block's order; CE / PM: table rows and positions of a lane
 template <int CE, int PM, int S, int TT>
-__device__ __forceinline__ void sa_span_doc_chunk(const SpanDocParams& p, SpanEnt* s_ents, u32* s_pos, const u32 lane, const u32* recs_b,
-                                                  const u32 b, const u32 i0, const u32 sz, const u32 last_doc1) {
-    const u32 i = i0 + lane;
-    const bool have = lane < (u32)S && i < sz;
-    u32 doc = 0;
+__device__ __forceinline__ void sa_span_doc_chunk(const SpanDocParams& p, SpanEnt* s_ents, u32* s_pos, const u32 lane, const u32 desc) {
+    const u32 blk = desc >> 12, start = desc & 0xFFFu;
+    const u32* const d = p.dir + (size_t)blk * SA_SPAN_DIR;
+    const u32 n_rec = d[0];
+    const u32* const recs = p.recs + d[1];
+    const u32 i = start + lane;
+    const bool have = lane < (u32)S && i < n_rec;
+    u32 doc = 0, npos = 0;
     if (have) {
-        const u32* rec = recs_b + (size_t)i * (b + 1u);
+        const u32 ro = p.roff[(size_t)blk * p.dpb + i];
+        npos = ro >> 24;
+        const u32* rec = recs + (ro & 0xFFFFFFu);
         doc = rec[0];
-        for (u32 q = 0; q < b; q++) s_pos[q * (u32)S + lane] = rec[1u + q];
+        for (u32 q = 0; q < npos; q++) s_pos[q * (u32)S + lane] = rec[1u + q];
     }
     u32 incr = 0;
-    const bool ok = sa_span_flat_loop<CE, PM, S>(SpanEntColS<S>{s_ents + (have ? lane : 0u)}, s_pos, have ? lane : 0u, have ? b : 0u, (u32)TT,
+    const bool ok = sa_span_flat_loop<CE, PM, S>(SpanEntColS<S>{s_ents + (have ? lane : 0u)}, s_pos, have ? lane : 0u, npos, (u32)TT,
                                                  (int)((u32)TT + p.slop), &incr);
     if (ok && have && incr) p.counts[doc] = (float)incr;
     // a lane whose table outgrew its column: the document again, with the whole wave
@@ -1301,8 +1371,8 @@ __device__ __forceinline__ void sa_span_doc_chunk(const SpanDocParams& p, SpanEn
     while (ab != 0) {
         const int l = __builtin_ctzll(ab);
         ab &= ab - 1;
-        const u32 d = (u32)__builtin_amdgcn_readlane((int)doc, l);
-        sa_span_wave_doc<TT>(p, d, s_ents, lane, last_doc1);
+        const u32 dd = (u32)__builtin_amdgcn_readlane((int)doc, l);
+        sa_span_wave_doc<TT>(p, dd, s_ents, lane);
     }
 }
 
@@ -1314,37 +1384,17 @@ __global__ void __launch_bounds__(64) sa_k_span_doc_machine(const SpanDocParams 
     __shared__ u32 s_pos[PA * 64];
     static_assert(ROWS * 64 >= SA_NSPANS, "the lane tables must hold one full table");
     const u32 lane = threadIdx.x;
-    const u32 last_doc1 = p.sizes[0];
-    constexpr u32 PMAXB = 4u * PA;
     // the heavy documents first (the longest single items), a wave each
-    const u32 nh = p.sizes[PMAXB + 1u];
-    for (u32 item = blockIdx.x; item < nh; item += gridDim.x) sa_span_wave_doc<TT>(p, p.heavy[item], s_ents, lane, last_doc1);
-    // then the records: the bins with the most positions first.  Lane x holds bin PMAXB - x: where its chunks and its
-    // records start (a wave scan), so that a chunk finds its bin with one ballot.
-    const u32 my_bin = lane < PMAXB ? PMAXB - lane : 0u;
-    const u32 my_per = my_bin > 2u * PA ? 16u : (my_bin > (u32)PA ? 32u : 64u);
-    const u32 my_sz = my_bin ? p.sizes[my_bin] : 0u;
-    u32 my_first = (my_sz + my_per - 1u) / my_per, my_rbase = my_sz * (my_bin + 1u);        // inclusive scans first
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const u32 a = __shfl_up(my_first, o, SA_WAVE), c = __shfl_up(my_rbase, o, SA_WAVE);
-        if (lane >= (u32)o) { my_first += a; my_rbase += c; }
-    }
-    const u32 n_chunks = (u32)__builtin_amdgcn_readlane((int)my_first, 63);
-    my_first -= (my_sz + my_per - 1u) / my_per;                  // exclusive
-    my_rbase -= my_sz * (my_bin + 1u);
-    for (u32 ck = blockIdx.x; ck < n_chunks; ck += gridDim.x) {
-        // the chunk's bin: the last one (going down) that starts at or before it
-        const u64 at = __ballot(my_bin != 0u && ck >= my_first);
-        const int idx = 63 - __builtin_clzll(at);                // (lane 0 starts at chunk 0: never empty)
-        const u32 b = PMAXB - (u32)idx;
-        const u32 first_b = (u32)__builtin_amdgcn_readlane((int)my_first, idx);
-        const u32 rbase_b = (u32)__builtin_amdgcn_readlane((int)my_rbase, idx);
-        const u32 sz = (u32)__builtin_amdgcn_readlane((int)my_sz, idx);
+    const u32 nh = p.cnt[SA_SPAN_NLIST + 1];
+    for (u32 item = blockIdx.x; item < nh; item += gridDim.x) sa_span_wave_doc<TT>(p, p.heavy[item], s_ents, lane);
+    // then the chunks, list after list
+    const u32 n0 = p.cnt[0], n1 = n0 + p.cnt[1], n2 = n1 + p.cnt[2], n3 = n2 + p.cnt[3];
+    for (u32 it = blockIdx.x; it < n3; it += gridDim.x) {
         __builtin_amdgcn_wave_barrier();
-        if (b > 2u * PA) sa_span_doc_chunk<4 * ROWS - 1, 4 * PA, 16, TT>(p, s_ents, s_pos, lane, p.recs + rbase_b, b, (ck - first_b) * 16u, sz, last_doc1);
-        else if (b > (u32)PA) sa_span_doc_chunk<2 * ROWS - 1, 2 * PA, 32, TT>(p, s_ents, s_pos, lane, p.recs + rbase_b, b, (ck - first_b) * 32u, sz, last_doc1);
-        else sa_span_doc_chunk<CA, PA, 64, TT>(p, s_ents, s_pos, lane, p.recs + rbase_b, b, (ck - first_b) * 64u, sz, last_doc1);
+        if (it < n0) sa_span_doc_chunk<4 * ROWS - 1, 4 * PA, 16, TT>(p, s_ents, s_pos, lane, p.lists[it]);
+        else if (it < n1) sa_span_doc_chunk<2 * ROWS - 1, 2 * PA, 32, TT>(p, s_ents, s_pos, lane, p.lists[(size_t)p.list_cap + (it - n0)]);
+        else if (it < n2) sa_span_doc_chunk<CA, PA, 64, TT>(p, s_ents, s_pos, lane, p.lists[2 * (size_t)p.list_cap + (it - n1)]);
+        else sa_span_doc_chunk<CA, PA, 64, TT>(p, s_ents, s_pos, lane, p.lists[3 * (size_t)p.list_cap + (it - n2)]);
     }
 }
 
@@ -1362,41 +1412,58 @@ static bool sa_env_span_doc() {
 
 template <int TT>
 static void sa_span_doc_launch(const SpanDocParams& p, dim3 fg, dim3 mg, hipStream_t st) {
-    hipLaunchKernelGGL((sa_k_span_doc_count<TT>), fg, dim3(SA_SPAN_DT), 0, st, p);
-    hipLaunchKernelGGL((sa_k_span_doc_emit<TT>), fg, dim3(SA_SPAN_DT), 0, st, p);
+    constexpr int DT = TT == 2 ? 1024 : 512;                     // (three and four terms: more than 64 registers)
+    if (p.dpb == 1024) hipLaunchKernelGGL((sa_k_span_doc_sort<TT, 512, 1024>), fg, dim3(512), 0, st, p);
+    else if (p.dpb == 1025) { SpanDocParams q = p; q.dpb = 1024; hipLaunchKernelGGL((sa_k_span_doc_sort<TT, DT, 1024>), fg, dim3(DT), 0, st, q); }
+    else if (p.dpb == 2049) { SpanDocParams q = p; q.dpb = 2048; hipLaunchKernelGGL((sa_k_span_doc_sort<TT, 512, 2048>), fg, dim3(512), 0, st, q); }
+    else hipLaunchKernelGGL((sa_k_span_doc_sort<TT, DT, 2048>), fg, dim3(DT), 0, st, p);
     if (getenv("SA_SPAN_TRACE") && atoi(getenv("SA_SPAN_TRACE")) >= 2) {
-        u32 h[SA_SPAN_DB];
+        u32 h[SA_SPAN_CNT];
         hipStreamSynchronize(st);
-        hipMemcpy(h, p.sizes, sizeof(h), hipMemcpyDeviceToHost);
-        fprintf(stderr, "slop doc route: bin sizes");
-        for (u32 b = 1; b <= 4 * p.pa + 1; b++) fprintf(stderr, " %u", h[b]);
-        fprintf(stderr, " last doc + 1 %u\n", h[0]);
+        hipMemcpy(h, p.cnt, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "slop doc route: chunks of 16 / 32 / 64 busy / 64: %u %u %u %u, record words %u, heavy documents %u\n", h[0], h[1], h[2], h[3], h[4], h[5]);
     }
-    if (TT == 2) {
-        if (p.pa == 8) hipLaunchKernelGGL((sa_k_span_doc_machine<SA_SPAN_LDS, 8, TT>), mg, dim3(64), 0, st, p);
-        else hipLaunchKernelGGL((sa_k_span_doc_machine<SA_SPAN_LDS, 10, TT>), mg, dim3(64), 0, st, p);
-    } else {
-        if (p.pa == 8) hipLaunchKernelGGL((sa_k_span_doc_machine<16, 8, TT>), mg, dim3(64), 0, st, p);
-        else hipLaunchKernelGGL((sa_k_span_doc_machine<16, 10, TT>), mg, dim3(64), 0, st, p);
-    }
+    constexpr int CA = TT == 2 ? SA_SPAN_LDS : 16;
+    SpanDocParams pm = p;
+    pm.dpb = p.dpb & ~1u;
+    if (p.pa == 8) hipLaunchKernelGGL((sa_k_span_doc_machine<CA, 8, TT>), mg, dim3(64), 0, st, pm);
+    else hipLaunchKernelGGL((sa_k_span_doc_machine<CA, 10, TT>), mg, dim3(64), 0, st, pm);
 }
 
 static int sa_span_counts_doc_route(sa_index* ix, const SpanTerms& terms_dev, int T, int slop, float** d_out) {
     hipStream_t st = ix->stream;
     const u64 N = ix->n_docs;
+    // the counters of this stream: two sets, a query clears the next one's
+    const size_t cnt_bytes = 2 * SA_SPAN_CNT * sizeof(u32);
+    int cs = -1;
+    for (int i = 0; i < 4 && cs < 0; i++)
+        if (ix->d_span_doc_cnt[i] && ix->span_doc_cnt_stream[i] == st) cs = i;
+    for (int i = 0; i < 4 && cs < 0; i++)
+        if (!ix->d_span_doc_cnt[i]) {
+            SA_HIP(hipMalloc(&ix->d_span_doc_cnt[i], cnt_bytes));
+            ix->span_doc_cnt_stream[i] = st;
+            ix->span_doc_dirty[i] = true;
+            ix->span_doc_parity[i] = 0;
+            cs = i;
+        }
+    if (cs < 0) { sa_set_error("internal: no counter block for this stream"); return SA_ERR_STATE; }
+    if (ix->span_doc_dirty[cs]) SA_HIP(hipMemsetAsync(ix->d_span_doc_cnt[cs], 0, cnt_bytes, st));
+    ix->span_doc_dirty[cs] = true;                               // (until the launches are enqueued)
     u64 min_len = terms_dev.len[0], total_len = 0;
     for (int t = 0; t < T; t++) { min_len = std::min<u64>(min_len, terms_dev.len[t]); total_len += terms_dev.len[t]; }
     u32 pa = 8;
     if (const char* v = getenv("SA_SPAN_DOC_PA")) { if (atoi(v) == 10) pa = 10; }
     const u32 pmax = 4 * pa;
-    // count / emit blocks: at most SA_SPAN_DG (every emit block reads all the histograms), whole multiples of the block size each
-    u64 per_block = (N + SA_SPAN_DG - 1) / SA_SPAN_DG;
-    per_block = std::max<u64>(4 * SA_SPAN_DT, (per_block + SA_SPAN_DT - 1) / SA_SPAN_DT * SA_SPAN_DT);   // (4 documents per thread: measured, 2 / 4 / 8 / 16)
-    if (const char* v = getenv("SA_SPAN_DOC_PER_BLOCK")) { const int x = atoi(v); if (x >= 1) per_block = (u64)x; }   // tests: many small blocks
-    const u32 fgrid = (u32)((N + per_block - 1) / per_block);
-    // a document in a lane bin has <= pmax positions and is a document of the rarest term; every position is a bit of a word
+    u32 dpb_sel = (u32)sa_env_int_span("SA_SPAN_DOC_DPB", SA_SPAN_DPB);      // 2048 / 1024; + 1: the other block size (experiments)
+    if (dpb_sel != 1024 && dpb_sel != 1025 && dpb_sel != 2049) dpb_sel = SA_SPAN_DPB;
+    const u32 dpb = dpb_sel & ~1u;
+    const u64 n_blocks = (N + dpb - 1) / dpb;
+    if (n_blocks >= (1u << 20)) { sa_set_error("internal: too many documents for the doc-parallel slop route"); return SA_ERR_STATE; }
+    // a document with a record has <= pmax positions and is a document of the rarest term; every position is a bit of a word
     const u64 rec_words = std::min<u64>(min_len * (pmax + 1), total_len * SA_LSB_BITS + min_len) + 64;
-    const size_t need = (N + 64) * 4 + (N + 256) + rec_words * 4 + (min_len + 64) * 4 + ((size_t)fgrid + 2) * SA_SPAN_DB * 4 + 4096;
+    const u64 list_cap = min_len / 16 + 3 * n_blocks + 64;       // (a block adds at most one partly filled chunk per class)
+    const size_t need = (N + 64) * 4 + n_blocks * (SA_SPAN_DIR * 4 + (size_t)dpb * 4) + rec_words * 4 + (min_len + 64) * 4 +
+                        SA_SPAN_NLIST * list_cap * 4 + 8192;
     void* scratch;
     SA_TRY(sa_index_scratch(ix, need, &scratch));
     char* base = (char*)scratch;
@@ -1409,24 +1476,30 @@ static int sa_span_counts_doc_route(sa_index* ix, const SpanTerms& terms_dev, in
     for (int t = 0; t < T; t++) p.st.off[t + 1] = p.st.off[t] + p.st.len[t];
     p.slop = (u32)slop;
     p.pa = pa;
-    p.docs_per_block = (u32)per_block;
+    p.n_blocks = (u32)n_blocks;
+    p.list_cap = (u32)list_cap;
     p.counts = (float*)take((N + 1) * 4);
-    p.dbin = (unsigned char*)take(N + 1);
-    p.hist = (u32*)take((size_t)fgrid * SA_SPAN_DB * 4);
-    p.sizes = (u32*)take(SA_SPAN_DB * 4);
+    p.dir = (u32*)take(n_blocks * SA_SPAN_DIR * 4);
+    p.roff = (u32*)take(n_blocks * dpb * 4);
+    p.dpb = dpb_sel;
     p.recs = (u32*)take(rec_words * 4);
     p.heavy = (u32*)take((min_len + 1) * 4);
+    p.lists = (u32*)take(SA_SPAN_NLIST * list_cap * 4);
+    p.cnt = ix->d_span_doc_cnt[cs] + (ix->span_doc_parity[cs] ? SA_SPAN_CNT : 0);
+    p.cnt_next = ix->d_span_doc_cnt[cs] + (ix->span_doc_parity[cs] ? 0 : SA_SPAN_CNT);
     if (used > need) { sa_set_error("internal: span scratch exhausted"); return SA_ERR_STATE; }
     *d_out = p.counts;
-    // the machine: resident waves striding over the chunks (no more waves than there can be chunks)
-    const u32 mgrid = (u32)std::min<u64>(min_len / 16 + pmax + 1, (u64)sa_env_int_span("SA_SPAN_DOC_GRID", 4096));
-    const dim3 fg(fgrid), mg(mgrid);
+    // the machine: resident waves striding over the work lists (no more waves than there can be chunks)
+    const u32 mgrid = (u32)std::min<u64>(list_cap, (u64)sa_env_int_span("SA_SPAN_DOC_GRID", 8192));
+    const dim3 fg((u32)n_blocks), mg(mgrid);
     switch (T) {
     case 2: sa_span_doc_launch<2>(p, fg, mg, st); break;
     case 3: sa_span_doc_launch<3>(p, fg, mg, st); break;
     default: sa_span_doc_launch<4>(p, fg, mg, st); break;
     }
     SA_HIP(hipGetLastError());
+    ix->span_doc_parity[cs] ^= 1;
+    ix->span_doc_dirty[cs] = false;
     return SA_OK;
 }
 

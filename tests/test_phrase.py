@@ -225,16 +225,16 @@ def test_slop_random_differential(api, seed, monkeypatch):
 
 @pytest.mark.parametrize("seed", range(4))
 def test_slop_doc_parallel_route(api, seed, monkeypatch, capfd):
-    """The doc-parallel slop route (sa_spans.hip: frequent terms with directory rows -- count / emit / machine over
-    per-document position records) against the oracle AND the general route, on corpora that reach each of its parts:
-    documents in every lane bin, documents with more positions than a lane takes (heavy: a wave each), documents with
-    more than four words of a term (the count pass's slow path), lane tables that outgrow their column (redone by the
-    lane's own wave).  Two-term phrases take it whether or not header 0 is in L; three and four terms only when it is
+    """The doc-parallel slop route (sa_spans.hip: frequent terms with directory rows -- sort blocks write per-document
+    position records in work order, the machine takes them a lane each) against the oracle AND the general route, on
+    corpora that reach each of its parts: 64-, 32- and 16-lane chunks, documents with more positions than a lane takes
+    (heavy: a wave each), documents with more than four words of a term (the sort pass's slow path), lane tables that
+    outgrow their column (redone by the lane's own wave), one and several sort blocks.  Two-term phrases take it whether or not header 0 is in L; three and four terms only when it is
     not -- doc 0 is kept free of the frequent terms on the even seeds so that both cases occur."""
     from oracle import spans as S
     monkeypatch.setenv("SA_SPAN_TRACE", "1")
     rng = np.random.default_rng(700 + seed)
-    n_docs, vocab = int(rng.integers(300, 600)), 6
+    n_docs, vocab = (int(rng.integers(300, 600)) if seed < 2 else int(rng.integers(4500, 7000))), 6     # (one / several sort blocks)
     t, d, p, lens = synth.corpus_triples(n_docs, vocab, int(rng.integers(8, 30)), seed=60 + seed)
     # a few long documents: many positions, many words per term
     extra_t, extra_d, extra_p = [], [], []
