@@ -229,7 +229,6 @@ void sa_index_free(sa_index* ix) {
     }
     if (ix->d_span_batch) hipFree(ix->d_span_batch);
     if (ix->d_span_counts) hipFree(ix->d_span_counts);
-    for (int i = 0; i < 4; i++) if (ix->d_span_doc_cnt[i]) hipFree(ix->d_span_doc_cnt[i]);
     if (ix->h_span_jobs) hipHostFree(ix->h_span_jobs);
     if (ix->ev_span_jobs) hipEventDestroy(ix->ev_span_jobs);
     if (ix->d_rows_scratch) hipFree(ix->d_rows_scratch);

@@ -120,12 +120,6 @@ struct sa_index {
     float* d_span_counts = nullptr;  // pool of dense count vectors of that route, all zeros between runs (the ranking launch cleans up)
     size_t span_counts_cap = 0;      // floats
     bool span_counts_dirty = false;
-    // counters of the doc-parallel slop route (sa_spans.hip): two sets of 8 per stream the route is enqueued on (the
-    // index's own and the phrase batches' lanes, which swap `stream`); a query uses one set and clears the other
-    u32* d_span_doc_cnt[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipStream_t span_doc_cnt_stream[4] = {nullptr, nullptr, nullptr, nullptr};
-    int span_doc_parity[4] = {0, 0, 0, 0};
-    bool span_doc_dirty[4] = {false, false, false, false};     // a query failed half-way: clear both sets before the next one
 
     // row selection scratch (sa_index_select_rows): device copy of the selected doc ids + gathered values
     void* d_rows_scratch = nullptr;

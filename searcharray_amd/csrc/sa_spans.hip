@@ -1005,47 +1005,36 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_wave(const SpanMachinePa
 //     So the k-th document group of every term is the SAME document, and "the k-th group of every term" (what the
 //     reference's lock-step walk takes, and what the general route reproduces through stable compactions) is "the
 //     document" -- no ranks, no compaction, any order.
-// Two launches, everything read and written in whole lines, a handful of device-wide atomics per block (a same-line
-// atomic costs ~3 ns whoever issues it: 10 K of them were the first version's whole run time):
-//   sort    a block takes SA_SPAN_DPB neighbouring documents, one per thread and round (lane = doc: the directory
-//           rows and the documents' words are read in doc order).  Round one: candidate words, their positions -> the
-//           document's bin (0 none, npos up to 4 PA, else heavy), a histogram in LDS, the dense result cleared.  Then
-//           the block orders ITS documents by bin, most positions first, reserves its share of the record buffer
-//           (one atomic), and round two writes each document's position list -- doc, then term << 24 | position in
-//           the machine's order -- where the order puts it, plus the record's offset and npos in a table in the same
-//           order.  Finally it cuts its order into chunks -- 16 records while they have more than 2 PA positions, 32
-//           above PA, else 64 -- and appends the chunks to four work lists (heaviest class first; one atomic per list);
-//   machine resident waves take the heavy documents first (sa_span_wave_doc: a wave each, the words through the
-//           directory, candidate test per lane, the 512-span table in LDS), then the chunks list by list: one
-//           document per lane, sa_span_flat_loop on the records read as they lie.  16- and 32-lane chunks give a
-//           lane four times / twice the table rows and positions in the same LDS -- so that a document with many
-//           positions (whose table would outgrow a 64-lane column) still runs as a lane, not as a wave.  A lane whose
-//           table outgrows its column even so is redone by its own wave the heavy way.
-// What the general route's counting sort + scattered gathers produce (waves of equal work, busiest first) is here the
-// order of dense records; neighbouring records of a block differ by at most a position or two.
-#define SA_SPAN_DW 4                     // words of one term per document the sort rounds hold in registers
-#define SA_SPAN_DB 64                    // bins: [npos] for 1 <= npos <= 4 PA (<= 40), [4 PA + 1] heavy
-#define SA_SPAN_DPB 2048                 // documents of a sort block
-#define SA_SPAN_PC 8                     // positions of a document round one keeps in LDS for round two
-#define SA_SPAN_DIR 4                    // directory row of a sort block: records, offset of its records, last candidate doc + 1
-#define SA_SPAN_NLIST 4                  // work lists: 16-lane chunks, 32-lane chunks, 64-lane chunks with more / fewer than PA / 2 positions
-#define SA_SPAN_CNT 8                    // counters: the lists' sizes, record words, heavy documents
+// ONE launch, nothing but the lists read and the dense result written (earlier forms of this route -- count / emit /
+// machine over record buffers in HBM, then sort blocks + work lists -- moved 2-3 x the lists and were bound by what
+// bound the general route: passes that wait for memory, then a pass that waits for instruction issue, one after the
+// other).  A block of 256 threads takes 512 neighbouring documents:
+//   gather  one document per thread and round (lane = doc: the directory rows and the documents' words are read in
+//           doc order): candidate words, their positions -> the document's bin (0 none, npos up to 32, else heavy) and,
+//           for up to 8 positions, the position list -- term << 24 | position in the machine's order -- in LDS;
+//   order   the block's documents by bin, most positions first (counting sort in LDS);
+//   machine each wave takes chunks of that order, one document per lane, sa_span_flat_loop8 on the lists where they
+//           lie: what the general route's global counting sort + scattered gathers produce (waves of equal work,
+//           busiest first) without leaving the CU.  Chunks of 16 documents while they have more than 16 positions, of
+//           32 above 8, else 64: a lane of a 16- / 32-lane chunk gets three times / one and a half times the table rows
+//           in the wave's 8 KiB, and its positions (read again from the lists) a place behind them -- so that a
+//           document with many positions, whose table would outgrow a 64-lane column, still runs as a lane;
+//   heavy   documents beyond that, and lanes whose table outgrew its column even so: a wave each (sa_span_wave_doc:
+//           the words through the directory, candidate test per lane, the 512-span table in the wave's 8 KiB).
+// Blocks in different phases share a CU (three fit), so the gather's memory latency hides behind other blocks'
+// machines.  Span entries are 8 bytes here (position bits 32, first position 23, last - first 5, terms 4): T + slop <= 15.
+#define SA_SPAN_DW 4                     // words of one term per document the gather holds in registers
+#define SA_SPAN_DB 64                    // bins: [npos] for 1 <= npos <= 32, [33] heavy
+#define SA_SPAN_FT 256                   // threads of a block
+#define SA_SPAN_FD 512                   // documents of a block
+#define SA_SPAN_PC 8                     // positions of a document the gather keeps in LDS (= positions of a 64-lane chunk's lane)
+#define SA_SPAN_PMAXF 32                 // positions of a document a lane takes at all
+#define SA_SPAN_FROWS 16                 // table rows of a lane of a 64-lane chunk, incl. the scratch row: 16 x 64 x 8 = 8 KiB per wave
 
 struct SpanDocParams {
     SpanTerms st;                        // dd[t] != null for every term
     u32 slop;
-    u32 pa;                              // positions of a document a full wave's lane takes; pmax = 4 pa
-    u32 list_cap;
     float* counts;                       // the dense result
-    u32* dir;                            // [blocks][SA_SPAN_DIR]
-    u32* roff;                           // [blocks][SA_SPAN_DPB] record offset (in the block's share) | npos << 24, in the block's order
-    u32* recs;                           // position records
-    u32* heavy;                          // doc ids of the heavy documents
-    u32* lists;                          // [SA_SPAN_NLIST][list_cap] chunks: sort block << 12 | first record
-    u32* cnt;                            // counters of this query (zeros on entry)
-    u32* cnt_next;                       // the next query's (the sort pass clears them)
-    u32 n_blocks;
-    u32 dpb;                             // documents of a sort block
 };
 
 // candidate predicate of the word with header h, probing every term through its doc directory
@@ -1173,134 +1162,112 @@ __device__ __forceinline__ void sa_span_doc_positions(const u64 (&W)[TT][SA_SPAN
             }
 }
 
-// DT: threads of a block (1024 while the registers allow: every thread waits for its document's loads, and the block's
-// documents in flight are what hides that)
-template <int TT, int DT, int DPB>
-__global__ void __launch_bounds__(DT) sa_k_span_doc_sort(const SpanDocParams p) {
-    __shared__ u32 s_plist[SA_SPAN_PC * DPB];            // round one's position lists (documents of up to SA_SPAN_PC positions), position-major
-    __shared__ unsigned char s_bin[DPB];
-    __shared__ u32 s_h[SA_SPAN_DB], s_first[SA_SPAN_DB], s_woff[SA_SPAN_DB], s_cur[SA_SPAN_DB];
-    __shared__ u32 s_misc[16];
-    constexpr int ROUNDS = DPB / DT;
-    if (threadIdx.x < SA_SPAN_DB) { s_h[threadIdx.x] = 0; s_cur[threadIdx.x] = 0; }
-    if (threadIdx.x < 16) s_misc[threadIdx.x] = 0;
-    if (blockIdx.x == 0 && threadIdx.x < SA_SPAN_CNT) p.cnt_next[threadIdx.x] = 0u;
-    __syncthreads();
-    const u32 pmax = 4u * p.pa, heavy_bin = pmax + 1u;
-    const u64 lo = (u64)blockIdx.x * DPB;
-    u64 W[TT][SA_SPAN_DW];
-    u32 c[TT], keep[TT];
-    // ---- round one: bins (and the short position lists, kept for round two)
-#pragma unroll 1
-    for (int r = 0; r < ROUNDS; r++) {
-        const u32 local = (u32)r * DT + threadIdx.x;
-        const u64 doc = lo + local;
-        u32 bin = 0;
-        if (doc < p.st.n_docs) {
-            p.counts[doc] = 0.f;
-            bool many = false;
-            if (sa_span_doc_words<TT>(p.st, doc, W, c, keep, &many)) {
-                u32 npos = 0;
-                if (many) {
-                    npos = sa_span_doc_npos_slow<TT>(p.st, doc);
-                } else {
-#pragma unroll
-                    for (int t = 0; t < TT; t++)
-#pragma unroll
-                        for (int q = 0; q < SA_SPAN_DW; q++)
-                            if ((keep[t] >> q) & 1u) npos += (u32)__popc((u32)(W[t][q] & SA_LSB_MASK));
-                    if (npos != 0 && npos <= (u32)SA_SPAN_PC) sa_span_doc_positions<TT>(W, keep, s_plist + local, DPB, npos);
-                }
-                bin = npos == 0 ? 0u : ((many || npos > pmax) ? heavy_bin : npos);
-            }
-            if (bin) { atomicAdd(&s_h[bin], 1u); atomicMax(&s_misc[0], (u32)doc + 1u); }
-        }
-        s_bin[local] = (unsigned char)bin;
-    }
-    __syncthreads();
-    // ---- the block's order: bins with the most positions first; where each bin's documents and records start; its
-    //      chunks: 16 records while they have more than 2 PA positions, then 32 above PA, then 64
-    if (threadIdx.x == 0) {
-        u32 n = 0, words = 0, n_c = 0, n_b = 0, n_hi = 0;          // records, their words, records of the classes
-        for (u32 b = pmax; b >= 1u; b--) {
-            s_first[b] = n; s_woff[b] = words; n += s_h[b]; words += s_h[b] * (b + 1u);
-            if (b > 2u * p.pa) n_c += s_h[b];
-            else if (b > p.pa) n_b += s_h[b];
-            else if (2u * b > p.pa) n_hi += s_h[b];
-        }
-        s_first[heavy_bin] = 0;
-        const u32 k_c = (n_c + 15u) / 16u;
-        const u32 start_b = 16u * k_c < n ? 16u * k_c : n;
-        const u32 k_b = n_c + n_b > start_b ? (n_c + n_b - start_b + 31u) / 32u : 0u;
-        const u32 start_a = start_b + 32u * k_b < n ? start_b + 32u * k_b : n;
-        const u32 k_a = (n - start_a + 63u) / 64u;
-        const u32 hi_end = n_c + n_b + n_hi;                     // a 64-lane chunk that starts before this is of the busier kind
-        const u32 k_hi = hi_end > start_a ? ((hi_end - start_a + 63u) / 64u < k_a ? (hi_end - start_a + 63u) / 64u : k_a) : 0u;
-        s_misc[1] = n;
-        s_misc[4] = k_c; s_misc[5] = k_b; s_misc[6] = k_hi; s_misc[7] = k_a - k_hi;
-        s_misc[12] = start_b; s_misc[13] = start_a;
-        s_misc[14] = words; s_misc[15] = s_h[heavy_bin];
-    }
-    __syncthreads();
-    // the block's reservations: its chunks in the four lists, its record words, its heavy documents -- one lane each,
-    // so that the six round trips overlap
-    if (threadIdx.x < 6) {
-        const u32 amount = threadIdx.x < 4 ? s_misc[4 + threadIdx.x] : s_misc[14 + (threadIdx.x - 4)];
-        s_misc[threadIdx.x < 4 ? 8 + threadIdx.x : threadIdx.x - 2] = amount ? atomicAdd(&p.cnt[threadIdx.x], amount) : 0u;        // [8..11] lists, [2] words, [3] heavy
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u32* d = p.dir + (size_t)blockIdx.x * SA_SPAN_DIR;
-        d[0] = s_misc[1]; d[1] = s_misc[2]; d[2] = s_misc[0];
-    }
-    {
-        const u32 k_c = s_misc[4], k_b = s_misc[5], k_hi = s_misc[6], k_lo = s_misc[7], start_b = s_misc[12], start_a = s_misc[13];
-        const u32 desc = blockIdx.x << 12;
-        for (u32 i = threadIdx.x; i < k_c + k_b + k_hi + k_lo; i += DT) {
-            if (i < k_c) p.lists[s_misc[8] + i] = desc | (16u * i);
-            else if (i < k_c + k_b) p.lists[(size_t)p.list_cap + s_misc[9] + (i - k_c)] = desc | (start_b + 32u * (i - k_c));
-            else if (i < k_c + k_b + k_hi) p.lists[2 * (size_t)p.list_cap + s_misc[10] + (i - k_c - k_b)] = desc | (start_a + 64u * (i - k_c - k_b));
-            else p.lists[3 * (size_t)p.list_cap + s_misc[11] + (i - k_c - k_b - k_hi)] = desc | (start_a + 64u * (i - k_c - k_b));
-        }
-    }
-    // ---- round two: the records, in the block's order
-    u32* const recs = p.recs + s_misc[2];
-    u32* const roff = p.roff + (size_t)blockIdx.x * DPB;
-#pragma unroll 1
-    for (int r = 0; r < ROUNDS; r++) {
-        const u32 local = (u32)r * DT + threadIdx.x;
-        const u64 doc = lo + local;
-        const u32 bin = s_bin[local];
-        if (!bin) continue;
-        const u32 k = atomicAdd(&s_cur[bin], 1u);
-        if (bin == heavy_bin) {
-            p.heavy[s_misc[3] + k] = (u32)doc;
-            continue;
-        }
-        const u32 off = s_woff[bin] + k * (bin + 1u);
-        roff[s_first[bin] + k] = off | (bin << 24);
-        u32* rec = recs + off;
-        rec[0] = (u32)doc;
-        if (bin <= (u32)SA_SPAN_PC) {
-            for (u32 q = 0; q < bin; q++) rec[1u + q] = s_plist[q * DPB + local];
-        } else {
-            bool many = false;
-            sa_span_doc_words<TT>(p.st, doc, W, c, keep, &many);
-            sa_span_doc_positions<TT>(W, keep, rec + 1, 1u, bin);
-        }
-    }
+// ---- span entries in 8 bytes: position bits [0, 32), first position [32, 55), last - first + 16 [55, 60), terms [60, 64)
+//      (|last - first| <= T + slop: a span's end only moves to a position within the window of its start)
+__device__ __forceinline__ u64 sa_ent8_pack(const u32 terms, const int posns, const int beg, const int end) {
+    return (u64)(u32)posns | ((u64)((u32)beg & 0x7FFFFFu) << 32) | ((u64)((u32)(end - beg + 16) & 31u) << 55) | ((u64)(terms & 15u) << 60);
+}
+__device__ __forceinline__ SpanEnt sa_ent8_unpack(const u64 v) {
+    SpanEnt e;
+    e.posns = (int)(u32)v;
+    e.beg = (int)((u32)(v >> 32) & 0x7FFFFFu);
+    e.end = e.beg + (int)((u32)(v >> 55) & 31u) - 16;
+    e.terms = (u32)(v >> 60);
+    return e;
 }
 
-// the last document with candidates + 1: the maximum over the sort blocks (looked up when a table fills, i.e. hardly ever)
+// sa_span_flat_loop over 8-byte entries: the lane's entry i at ents[i * S] (row CE: scratch), its positions at
+// pos[q * pstride], q < npos.  Returns false when the table outgrew CE entries.
+template <int CE, int PM, int S>
+__device__ __forceinline__ bool sa_span_flat_loop8(u64* ents, const u32* pos, const u32 pstride, const u32 npos, const u32 num_terms,
+                                                   const int max_span_width, u32* incr_out) {
+    u32 cursor = 0, pi = 0, si = 0, end = 0, curr_term_mask = 0, tstart = 0;
+    int curr_posn = 0, posn_mask = 0;
+    bool abandoned = false;
+    bool alive = true;
+    while (alive) {
+        const bool need = si >= end;
+        const bool done = need && pi >= npos;
+        const bool fresh_it = need && !done;
+        const u32 pv = pos[(pi < (u32)PM ? pi : (u32)PM - 1u) * pstride];
+        const u32 new_mask = 1u << (pv >> 24);
+        tstart = (fresh_it && new_mask != curr_term_mask) ? cursor : tstart;
+        curr_posn = fresh_it ? (int)(pv & 0xFFFFFFu) : curr_posn;
+        curr_term_mask = fresh_it ? new_mask : curr_term_mask;
+        posn_mask = sa_posn_mask32(curr_posn);
+        const bool over_f = fresh_it && cursor >= (u32)CE;
+        ents[((fresh_it && !over_f) ? cursor : (u32)CE) * (u32)S] = sa_ent8_pack(curr_term_mask, posn_mask, curr_posn, curr_posn);
+        end = fresh_it ? tstart : end;
+        si = fresh_it ? 0u : si;
+        cursor += fresh_it ? 1u : 0u;
+        pi += fresh_it ? 1u : 0u;
+        const bool vis = !done && !over_f && si < end;
+        const u32 slot = vis ? si : (u32)CE;
+        const SpanEnt e = sa_ent8_unpack(ents[slot * (u32)S]);
+        const u32 nt = (u32)__popc(e.terms), np = sa_popc_sext(e.posns);
+        const bool act = vis && !((nt < num_terms && np == num_terms) || (e.terms & curr_term_mask));
+        const int sp2 = e.posns | posn_mask;
+        const u32 new_unique = sa_popc_sext(sp2);
+        const int proposed = sa_iabs32(curr_posn - e.beg);
+        const bool rej = np == new_unique || proposed > max_span_width;    // (the position bit stays even if rejected)
+        const bool fork_it = act && !rej;
+        const bool over_k = fork_it && cursor >= (u32)CE;
+        ents[slot * (u32)S] = sa_ent8_pack(fork_it ? (e.terms | curr_term_mask) : e.terms, act ? sp2 : e.posns, e.beg, fork_it ? curr_posn : e.end);
+        ents[((fork_it && !over_k) ? cursor : (u32)CE) * (u32)S] = sa_ent8_pack(e.terms | curr_term_mask, sp2 & ~posn_mask, e.beg, e.end);
+        cursor += (fork_it && !over_k) ? 1u : 0u;
+        si += vis ? 1u : 0u;
+        abandoned = over_f || over_k;
+        alive = !done && !abandoned;
+    }
+    if (abandoned) return false;
+    // _collect_spans (sa_span_collect): collected span c in the (dead) slot of span c, as first << 32 | last
+    u32 ncol = 0;
+    for (u32 i = 0; i < cursor; i++) {
+        const SpanEnt e = sa_ent8_unpack(ents[i * (u32)S]);
+        const bool complete = ((u32)__popc(e.terms) == num_terms) || (sa_popc_sext(e.posns) == num_terms);
+        const int b = e.beg, en = e.end;
+        const int width = sa_iabs32(en - b);
+        if (!complete || width >= max_span_width) continue;
+        bool replaced = false;
+        for (u32 c = 0; c < ncol; c++) {
+            const u64 cc = ents[c * (u32)S];
+            const int cb = (int)(cc >> 32), ce = (int)(cc & 0xFFFFFFFFull);
+            if (b <= ce && en >= cb && width < sa_iabs32(ce - cb)) {
+                ents[c * (u32)S] = ((u64)(u32)b << 32) | (u64)(u32)en;
+                replaced = true;
+                break;
+            }
+        }
+        if (!replaced) {
+            ents[ncol * (u32)S] = ((u64)(u32)b << 32) | (u64)(u32)en;
+            ncol++;
+        }
+    }
+    *incr_out = ncol;
+    return true;
+}
+
+// The last document with candidate words + 1 (the overflow rule's "last document group of the term": with aligned groups,
+// of every term).  Looked up when a table fills, i.e. hardly ever: from the end of the collection, 64 documents at a time.
+template <int TT>
 __device__ __forceinline__ u32 sa_span_doc_last(const SpanDocParams& p, const u32 lane) {
-    u32 m = 0;
-    for (u32 i = lane; i < p.n_blocks; i += 64u) { const u32 v = p.dir[(size_t)i * SA_SPAN_DIR + 2]; m = v > m ? v : m; }
-    return sa_wave_max(m);
+    for (u64 top = p.st.n_docs; top > 0; top = top > 64 ? top - 64 : 0) {
+        const u64 doc = top - 1 - lane;
+        bool has = false;
+        if (lane < top) {
+            bool all = true;
+#pragma unroll
+            for (int t = 0; t < TT; t++) all = all && p.st.dd[t][doc] != SA_DD_ABSENT;
+            has = all && sa_span_doc_npos_slow<TT>(p.st, doc) != 0;
+        }
+        const u64 m = __ballot(has);
+        if (m) return (u32)(top - (u64)__builtin_ctzll(m));           // lane l holds doc top - 1 - l: the lowest lane is the last doc
+    }
+    return 0;
 }
 
 // one document through the wave machine: its words through the directory, 64 at a time -- candidate test per lane,
-// then the candidates one after the other.  (The overflow rule's "last document group of the term" is, with aligned
-// groups, the last document with candidates: sa_span_doc_last.)
+// then the candidates one after the other.
 template <int TT>
 __device__ __forceinline__ void sa_span_wave_doc(const SpanDocParams& p, const u64 doc, SpanEnt* s_ents, const u32 lane) {
 #pragma unroll
@@ -1333,7 +1300,7 @@ __device__ __forceinline__ void sa_span_wave_doc(const SpanDocParams& p, const u
                 if (lane == (u32)t) my_sum += (u32)__popc((u32)(wl & SA_LSB_MASK));
                 sa_span_wave_word(s_ents, wl, 1u << t, tstart, (u32)TT, max_span_width, lane, cursor, full);
                 if (cursor >= SA_NSPANS) {                                 // (see sa_span_doc)
-                    if (last_doc1 == 0xFFFFFFFFu) last_doc1 = sa_span_doc_last(p, lane);
+                    if (last_doc1 == 0xFFFFFFFFu) last_doc1 = sa_span_doc_last<TT>(p, lane);
                     if ((u32)doc + 1u != last_doc1) gave_up = true;
                 }
             }
@@ -1345,57 +1312,133 @@ __device__ __forceinline__ void sa_span_wave_doc(const SpanDocParams& p, const u
     __builtin_amdgcn_wave_barrier();
 }
 
-// S lanes of the wave take S neighbouring records of a sort block's order; CE / PM: table rows and positions of a lane
+// S lanes of wave `w` take S neighbours of the block's order, from `start`
 template <int CE, int PM, int S, int TT>
-__device__ __forceinline__ void sa_span_doc_chunk(const SpanDocParams& p, SpanEnt* s_ents, u32* s_pos, const u32 lane, const u32 desc) {
-    const u32 blk = desc >> 12, start = desc & 0xFFFu;
-    const u32* const d = p.dir + (size_t)blk * SA_SPAN_DIR;
-    const u32 n_rec = d[0];
-    const u32* const recs = p.recs + d[1];
-    const u32 i = start + lane;
-    const bool have = lane < (u32)S && i < n_rec;
-    u32 doc = 0, npos = 0;
-    if (have) {
-        const u32 ro = p.roff[(size_t)blk * p.dpb + i];
-        npos = ro >> 24;
-        const u32* rec = recs + (ro & 0xFFFFFFu);
-        doc = rec[0];
-        for (u32 q = 0; q < npos; q++) s_pos[q * (u32)S + lane] = rec[1u + q];
+__device__ __forceinline__ void sa_span_doc_chunk(const SpanDocParams& p, u64* tab, const u32* s_plist, const unsigned char* s_bin,
+                                                  const unsigned short* s_order, unsigned short* s_heavy, u32* n_heavy, const u64 lo,
+                                                  const u32 lane, const u32 start, const u32 n) {
+    const bool have = lane < (u32)S && start + lane < n;
+    const u32 local = have ? s_order[start + lane] : 0u;
+    const u32 npos = have ? s_bin[local] : 0u;
+    const u64 doc = lo + local;
+    const u32* pos = s_plist + local;
+    u32 pstride = SA_SPAN_FD;
+    if (S < 64) {
+        // the lane's positions behind the tables: from the gather's list if it holds them, else from the words again
+        u32* const s_pos = (u32*)(tab + (size_t)(CE + 1) * S);
+        if (have) {
+            if (npos <= (u32)SA_SPAN_PC) {
+                for (u32 q = 0; q < npos; q++) s_pos[q * (u32)S + lane] = s_plist[q * SA_SPAN_FD + local];
+            } else {
+                u64 W[TT][SA_SPAN_DW];
+                u32 c[TT], keep[TT];
+                bool many = false;
+                sa_span_doc_words<TT>(p.st, doc, W, c, keep, &many);
+                sa_span_doc_positions<TT>(W, keep, s_pos + lane, (u32)S, npos);
+            }
+        }
+        pos = s_pos + lane;
+        pstride = (u32)S;
     }
     u32 incr = 0;
-    const bool ok = sa_span_flat_loop<CE, PM, S>(SpanEntColS<S>{s_ents + (have ? lane : 0u)}, s_pos, have ? lane : 0u, npos, (u32)TT,
-                                                 (int)((u32)TT + p.slop), &incr);
-    if (ok && have && incr) p.counts[doc] = (float)incr;
-    // a lane whose table outgrew its column: the document again, with the whole wave
-    u64 ab = __ballot(have && !ok);
-    while (ab != 0) {
-        const int l = __builtin_ctzll(ab);
-        ab &= ab - 1;
-        const u32 dd = (u32)__builtin_amdgcn_readlane((int)doc, l);
-        sa_span_wave_doc<TT>(p, dd, s_ents, lane);
+    const bool ok = sa_span_flat_loop8<CE, PM, S>(tab + (have ? lane : 0u), pos, pstride, npos, (u32)TT, (int)((u32)TT + p.slop), &incr);
+    if (have) {
+        if (ok) { if (incr) p.counts[doc] = (float)incr; }
+        else s_heavy[atomicAdd(n_heavy, 1u)] = (unsigned short)local;          // its table outgrew the column: a wave of its own below
     }
 }
 
-// CA: table rows of a lane when all 64 lanes of the wave hold a document; PA: positions (template copy of p.pa)
-template <int CA, int PA, int TT>
-__global__ void __launch_bounds__(64) sa_k_span_doc_machine(const SpanDocParams p) {
-    constexpr int ROWS = CA + 1;                                 // (+ the scratch row of sa_span_flat_loop)
-    __shared__ alignas(16) SpanEnt s_ents[ROWS * 64];
-    __shared__ u32 s_pos[PA * 64];
-    static_assert(ROWS * 64 >= SA_NSPANS, "the lane tables must hold one full table");
-    const u32 lane = threadIdx.x;
-    // the heavy documents first (the longest single items), a wave each
-    const u32 nh = p.cnt[SA_SPAN_NLIST + 1];
-    for (u32 item = blockIdx.x; item < nh; item += gridDim.x) sa_span_wave_doc<TT>(p, p.heavy[item], s_ents, lane);
-    // then the chunks, list after list
-    const u32 n0 = p.cnt[0], n1 = n0 + p.cnt[1], n2 = n1 + p.cnt[2], n3 = n2 + p.cnt[3];
-    for (u32 it = blockIdx.x; it < n3; it += gridDim.x) {
-        __builtin_amdgcn_wave_barrier();
-        if (it < n0) sa_span_doc_chunk<4 * ROWS - 1, 4 * PA, 16, TT>(p, s_ents, s_pos, lane, p.lists[it]);
-        else if (it < n1) sa_span_doc_chunk<2 * ROWS - 1, 2 * PA, 32, TT>(p, s_ents, s_pos, lane, p.lists[(size_t)p.list_cap + (it - n0)]);
-        else if (it < n2) sa_span_doc_chunk<CA, PA, 64, TT>(p, s_ents, s_pos, lane, p.lists[2 * (size_t)p.list_cap + (it - n1)]);
-        else sa_span_doc_chunk<CA, PA, 64, TT>(p, s_ents, s_pos, lane, p.lists[3 * (size_t)p.list_cap + (it - n2)]);
+template <int TT>
+__global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused(const SpanDocParams p) {
+    constexpr int NW = SA_SPAN_FT / 64, ROUNDS = SA_SPAN_FD / SA_SPAN_FT;
+    __shared__ u32 s_plist[SA_SPAN_PC * SA_SPAN_FD];             // position-major: position q of local document d at [q * FD + d]
+    __shared__ alignas(16) u64 s_tab[NW][SA_SPAN_FROWS * 64];    // a wave's tables (8 KiB: also one full 512-span table of 16-byte entries)
+    __shared__ unsigned char s_bin[SA_SPAN_FD];
+    __shared__ unsigned short s_order[SA_SPAN_FD], s_heavy[SA_SPAN_FD];
+    __shared__ u32 s_h[SA_SPAN_DB], s_first[SA_SPAN_DB], s_cur[SA_SPAN_DB];
+    __shared__ u32 s_nheavy;
+    static_assert(SA_SPAN_FROWS * 64 * 8 >= SA_NSPANS * sizeof(SpanEnt), "a wave's tables must hold one full table");
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x < SA_SPAN_DB) { s_h[threadIdx.x] = 0; s_cur[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) s_nheavy = 0;
+    __syncthreads();
+    constexpr u32 PMAX = SA_SPAN_PMAXF, HEAVY = SA_SPAN_PMAXF + 1;
+    const u64 lo = (u64)blockIdx.x * SA_SPAN_FD;
+    // ---- gather: bins and short position lists
+    {
+        u64 W[TT][SA_SPAN_DW];
+        u32 c[TT], keep[TT];
+#pragma unroll 1
+        for (int r = 0; r < ROUNDS; r++) {
+            const u32 local = (u32)r * SA_SPAN_FT + threadIdx.x;
+            const u64 doc = lo + local;
+            u32 bin = 0;
+            if (doc < p.st.n_docs) {
+                p.counts[doc] = 0.f;
+                bool many = false;
+                if (sa_span_doc_words<TT>(p.st, doc, W, c, keep, &many)) {
+                    u32 npos = 0;
+                    if (many) {
+                        npos = sa_span_doc_npos_slow<TT>(p.st, doc);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < TT; t++)
+#pragma unroll
+                            for (int q = 0; q < SA_SPAN_DW; q++)
+                                if ((keep[t] >> q) & 1u) npos += (u32)__popc((u32)(W[t][q] & SA_LSB_MASK));
+                        if (npos != 0 && npos <= (u32)SA_SPAN_PC) sa_span_doc_positions<TT>(W, keep, s_plist + local, SA_SPAN_FD, npos);
+                    }
+                    bin = npos == 0 ? 0u : ((many || npos > PMAX) ? HEAVY : npos);
+                }
+                if (bin) atomicAdd(&s_h[bin], 1u);
+            }
+            s_bin[local] = (unsigned char)bin;
+        }
     }
+    __syncthreads();
+    // ---- order: s_first[b] = documents with more than b positions (lane x of wave 0: bin PMAX - x)
+    if (wave == 0) {
+        const u32 b = lane <= PMAX ? PMAX - lane : 0u;
+        const u32 mine = (lane < PMAX) ? s_h[b] : 0u;             // (bin 0: no document)
+        u32 incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 a = __shfl_up(incl, o, SA_WAVE);
+            if (lane >= (u32)o) incl += a;
+        }
+        if (lane <= PMAX) s_first[b] = incl - mine;              // (lane PMAX: bin 0 = all of them)
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int r = 0; r < ROUNDS; r++) {
+        const u32 local = (u32)r * SA_SPAN_FT + threadIdx.x;
+        const u32 bin = s_bin[local];
+        if (bin == HEAVY) s_heavy[atomicAdd(&s_nheavy, 1u)] = (unsigned short)local;
+        else if (bin) s_order[s_first[bin] + atomicAdd(&s_cur[bin], 1u)] = (unsigned short)local;
+    }
+    __syncthreads();
+    // ---- machine: chunks of 16 while the documents have more than 16 positions, 32 above 8, else 64
+    {
+        const u32 n = s_first[0], n_c = s_first[2 * SA_SPAN_PC], n_cb = s_first[SA_SPAN_PC];
+        const u32 k_c = (n_c + 15u) / 16u;
+        const u32 start_b = 16u * k_c < n ? 16u * k_c : n;
+        const u32 k_b = n_cb > start_b ? (n_cb - start_b + 31u) / 32u : 0u;
+        const u32 start_a = start_b + 32u * k_b < n ? start_b + 32u * k_b : n;
+        const u32 k_a = (n - start_a + 63u) / 64u;
+        u64* const tab = s_tab[wave];
+        constexpr int R = SA_SPAN_FROWS;
+        // 16 lanes: 48 rows x 16 x 8 = 6 KiB + 32 positions x 16 x 4 = 2 KiB; 32 lanes: 24 rows x 32 x 8 = 6 KiB + 16 x 32 x 4 = 2 KiB
+        for (u32 ck = wave; ck < k_c + k_b + k_a; ck += NW) {
+            __builtin_amdgcn_wave_barrier();
+            if (ck < k_c) sa_span_doc_chunk<3 * R - 1, 4 * SA_SPAN_PC, 16, TT>(p, tab, s_plist, s_bin, s_order, s_heavy, &s_nheavy, lo, lane, 16u * ck, n);
+            else if (ck < k_c + k_b) sa_span_doc_chunk<3 * R / 2 - 1, 2 * SA_SPAN_PC, 32, TT>(p, tab, s_plist, s_bin, s_order, s_heavy, &s_nheavy, lo, lane, start_b + 32u * (ck - k_c), n);
+            else sa_span_doc_chunk<R - 1, SA_SPAN_PC, 64, TT>(p, tab, s_plist, s_bin, s_order, s_heavy, &s_nheavy, lo, lane, start_a + 64u * (ck - k_c - k_b), n);
+        }
+    }
+    __syncthreads();
+    // ---- heavy documents and outgrown tables: a wave each
+    const u32 nh = s_nheavy;
+    for (u32 i = wave; i < nh; i += NW) sa_span_wave_doc<TT>(p, lo + s_heavy[i], (SpanEnt*)s_tab[wave], lane);
 }
 
 static int sa_env_int_span(const char* name, int dflt) {
@@ -1411,95 +1454,30 @@ static bool sa_env_span_doc() {
 }
 
 template <int TT>
-static void sa_span_doc_launch(const SpanDocParams& p, dim3 fg, dim3 mg, hipStream_t st) {
-    constexpr int DT = TT == 2 ? 1024 : 512;                     // (three and four terms: more than 64 registers)
-    if (p.dpb == 1024) hipLaunchKernelGGL((sa_k_span_doc_sort<TT, 512, 1024>), fg, dim3(512), 0, st, p);
-    else if (p.dpb == 1025) { SpanDocParams q = p; q.dpb = 1024; hipLaunchKernelGGL((sa_k_span_doc_sort<TT, DT, 1024>), fg, dim3(DT), 0, st, q); }
-    else if (p.dpb == 2049) { SpanDocParams q = p; q.dpb = 2048; hipLaunchKernelGGL((sa_k_span_doc_sort<TT, 512, 2048>), fg, dim3(512), 0, st, q); }
-    else hipLaunchKernelGGL((sa_k_span_doc_sort<TT, DT, 2048>), fg, dim3(DT), 0, st, p);
-    if (getenv("SA_SPAN_TRACE") && atoi(getenv("SA_SPAN_TRACE")) >= 2) {
-        u32 h[SA_SPAN_CNT];
-        hipStreamSynchronize(st);
-        hipMemcpy(h, p.cnt, sizeof(h), hipMemcpyDeviceToHost);
-        fprintf(stderr, "slop doc route: chunks of 16 / 32 / 64 busy / 64: %u %u %u %u, record words %u, heavy documents %u\n", h[0], h[1], h[2], h[3], h[4], h[5]);
-    }
-    constexpr int CA = TT == 2 ? SA_SPAN_LDS : 16;
-    SpanDocParams pm = p;
-    pm.dpb = p.dpb & ~1u;
-    if (p.pa == 8) hipLaunchKernelGGL((sa_k_span_doc_machine<CA, 8, TT>), mg, dim3(64), 0, st, pm);
-    else hipLaunchKernelGGL((sa_k_span_doc_machine<CA, 10, TT>), mg, dim3(64), 0, st, pm);
+static void sa_span_doc_launch(const SpanDocParams& p, dim3 fg, hipStream_t st) {
+    hipLaunchKernelGGL((sa_k_span_doc_fused<TT>), fg, dim3(SA_SPAN_FT), 0, st, p);
 }
 
 static int sa_span_counts_doc_route(sa_index* ix, const SpanTerms& terms_dev, int T, int slop, float** d_out) {
     hipStream_t st = ix->stream;
     const u64 N = ix->n_docs;
-    // the counters of this stream: two sets, a query clears the next one's
-    const size_t cnt_bytes = 2 * SA_SPAN_CNT * sizeof(u32);
-    int cs = -1;
-    for (int i = 0; i < 4 && cs < 0; i++)
-        if (ix->d_span_doc_cnt[i] && ix->span_doc_cnt_stream[i] == st) cs = i;
-    for (int i = 0; i < 4 && cs < 0; i++)
-        if (!ix->d_span_doc_cnt[i]) {
-            SA_HIP(hipMalloc(&ix->d_span_doc_cnt[i], cnt_bytes));
-            ix->span_doc_cnt_stream[i] = st;
-            ix->span_doc_dirty[i] = true;
-            ix->span_doc_parity[i] = 0;
-            cs = i;
-        }
-    if (cs < 0) { sa_set_error("internal: no counter block for this stream"); return SA_ERR_STATE; }
-    if (ix->span_doc_dirty[cs]) SA_HIP(hipMemsetAsync(ix->d_span_doc_cnt[cs], 0, cnt_bytes, st));
-    ix->span_doc_dirty[cs] = true;                               // (until the launches are enqueued)
-    u64 min_len = terms_dev.len[0], total_len = 0;
-    for (int t = 0; t < T; t++) { min_len = std::min<u64>(min_len, terms_dev.len[t]); total_len += terms_dev.len[t]; }
-    u32 pa = 8;
-    if (const char* v = getenv("SA_SPAN_DOC_PA")) { if (atoi(v) == 10) pa = 10; }
-    const u32 pmax = 4 * pa;
-    u32 dpb_sel = (u32)sa_env_int_span("SA_SPAN_DOC_DPB", SA_SPAN_DPB);      // 2048 / 1024; + 1: the other block size (experiments)
-    if (dpb_sel != 1024 && dpb_sel != 1025 && dpb_sel != 2049) dpb_sel = SA_SPAN_DPB;
-    const u32 dpb = dpb_sel & ~1u;
-    const u64 n_blocks = (N + dpb - 1) / dpb;
-    if (n_blocks >= (1u << 20)) { sa_set_error("internal: too many documents for the doc-parallel slop route"); return SA_ERR_STATE; }
-    // a document with a record has <= pmax positions and is a document of the rarest term; every position is a bit of a word
-    const u64 rec_words = std::min<u64>(min_len * (pmax + 1), total_len * SA_LSB_BITS + min_len) + 64;
-    const u64 list_cap = min_len / 16 + 3 * n_blocks + 64;       // (a block adds at most one partly filled chunk per class)
-    const size_t need = (N + 64) * 4 + n_blocks * (SA_SPAN_DIR * 4 + (size_t)dpb * 4) + rec_words * 4 + (min_len + 64) * 4 +
-                        SA_SPAN_NLIST * list_cap * 4 + 8192;
     void* scratch;
-    SA_TRY(sa_index_scratch(ix, need, &scratch));
-    char* base = (char*)scratch;
-    size_t used = 0;
-    auto take = [&](size_t bytes) { char* q = base + used; used += (bytes + 255) & ~(size_t)255; return q; };
+    SA_TRY(sa_index_scratch(ix, (N + 64) * 4, &scratch));
     SpanDocParams p;
     memset(&p, 0, sizeof(p));
     p.st = terms_dev;
     p.st.off[0] = 0;
     for (int t = 0; t < T; t++) p.st.off[t + 1] = p.st.off[t] + p.st.len[t];
     p.slop = (u32)slop;
-    p.pa = pa;
-    p.n_blocks = (u32)n_blocks;
-    p.list_cap = (u32)list_cap;
-    p.counts = (float*)take((N + 1) * 4);
-    p.dir = (u32*)take(n_blocks * SA_SPAN_DIR * 4);
-    p.roff = (u32*)take(n_blocks * dpb * 4);
-    p.dpb = dpb_sel;
-    p.recs = (u32*)take(rec_words * 4);
-    p.heavy = (u32*)take((min_len + 1) * 4);
-    p.lists = (u32*)take(SA_SPAN_NLIST * list_cap * 4);
-    p.cnt = ix->d_span_doc_cnt[cs] + (ix->span_doc_parity[cs] ? SA_SPAN_CNT : 0);
-    p.cnt_next = ix->d_span_doc_cnt[cs] + (ix->span_doc_parity[cs] ? 0 : SA_SPAN_CNT);
-    if (used > need) { sa_set_error("internal: span scratch exhausted"); return SA_ERR_STATE; }
+    p.counts = (float*)scratch;
     *d_out = p.counts;
-    // the machine: resident waves striding over the work lists (no more waves than there can be chunks)
-    const u32 mgrid = (u32)std::min<u64>(list_cap, (u64)sa_env_int_span("SA_SPAN_DOC_GRID", 8192));
-    const dim3 fg((u32)n_blocks), mg(mgrid);
+    const dim3 fg((u32)((N + SA_SPAN_FD - 1) / SA_SPAN_FD));
     switch (T) {
-    case 2: sa_span_doc_launch<2>(p, fg, mg, st); break;
-    case 3: sa_span_doc_launch<3>(p, fg, mg, st); break;
-    default: sa_span_doc_launch<4>(p, fg, mg, st); break;
+    case 2: sa_span_doc_launch<2>(p, fg, st); break;
+    case 3: sa_span_doc_launch<3>(p, fg, st); break;
+    default: sa_span_doc_launch<4>(p, fg, st); break;
     }
     SA_HIP(hipGetLastError());
-    ix->span_doc_parity[cs] ^= 1;
-    ix->span_doc_dirty[cs] = false;
     return SA_OK;
 }
 
@@ -1613,7 +1591,7 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
     if (total_len > 0xFFFFFFF0ull) { sa_set_error("slop phrase: more than 2^32 words in the phrase's terms"); return SA_ERR_UNSUPPORTED; }
     // the doc-parallel route: 2..4 known terms, all with a directory row (whole lists, no word in a last block), header
     // 0 not in L (host arithmetic on the per-term edge flags, as below)
-    if (known && !filt.active && T >= 2 && T <= 4 && N > 0 && N < 0xFFFFFFF0ull && sa_env_span_doc() &&
+    if (known && !filt.active && T >= 2 && T <= 4 && T + slop <= 15 && N > 0 && N < 0xFFFFFFF0ull && sa_env_span_doc() &&
         ix->h_term_edge.size() >= (size_t)ix->n_terms) {
         bool all_dd = true;
         for (int t = 0; t < T; t++) all_dd = all_dd && terms_dev.dd[t] != nullptr && terms_dev.len[t] > 0;

@@ -322,10 +322,14 @@ def test_slop_span_table_overflow_matches_the_oracle(api, seed, monkeypatch):
     dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
     orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
     seen_overflow = 0
-    for terms, slop in (([0, 1], 97), ([2, 0], 48), ([1, 2], 203)):
+    # (wide windows: the general route; T + slop <= 15: the doc-parallel route's wave-per-document machine and its
+    #  lookup of the last document with candidates)
+    small = 0
+    for terms, slop in (([0, 1], 97), ([2, 0], 48), ([1, 2], 203), ([0, 1], 9), ([2, 0], 4), ([1, 2, 0], 11)):
         enc = [orc.enc(x) for x in terms]
         ids, counts, overflow = S.span_search(enc, slop, return_overflow=True)
         seen_overflow += overflow
+        small += overflow if len(terms) + slop <= 15 else 0
         want = np.zeros(n_docs, dtype=np.float32)
         want[ids.astype(np.int64)] = counts
         for fast in ("1", "0"):
@@ -333,7 +337,7 @@ def test_slop_span_table_overflow_matches_the_oracle(api, seed, monkeypatch):
             got = dev.phrase_freqs_dense(terms, slop=slop)
             assert np.array_equal(got, want), f"seed {seed} terms {terms} slop {slop} fast {fast}: {np.flatnonzero(got != want)[:5]}"
     dev.close()
-    assert seen_overflow > 0
+    assert seen_overflow > 0 and small > 0
     del rng
 
 
