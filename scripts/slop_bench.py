@@ -38,6 +38,7 @@ def main():
         phrases = [list(range(length))] + [[int(t) for t in p]
                                            for p in synth.phrase_queries_from_tokens(lens, terms, args.phrases, length, seed=5)]
         index.phrase_freqs_dense(phrases[0], slop=args.slop)
+        index.phrase_freqs_dense([5000 + j for j in range(length)], slop=args.slop)      # (the general route's kernels loaded too: terms without a directory row)
         t0 = time.perf_counter()
         outs, kms, kbytes = [], 0.0, 0
         for i, p in enumerate(phrases):

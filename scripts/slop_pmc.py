@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-query HBM traffic of the slop pipeline from the two --pmc passes of scripts/gpu_slop_pmc.sh.
 slop_heavy.py runs the 2-term phrase reps+1 times, then the 3-term phrase reps+1 times; a query's kernels are the span
-kernels from one sa_k_span_flags launch to the next.  Counter units as in bench.py: FETCH_SIZE and WRITE_SIZE in KiB;
+kernels from one sa_k_span_flags (or sa_k_span_doc_fused: the doc-parallel route's single launch) to the next.  Counter units as in bench.py: FETCH_SIZE and WRITE_SIZE in KiB;
 FETCH_SIZE under-reports wide coalesced reads on gfx950 (exactly 1/2 for 16 bytes per lane, MI355X_MICROARCH.md), and
 these kernels mix 1-, 4-, 8- and 16-byte accesses, so the read traffic is given as the raw figure (a lower bound) and
 as twice it (the upper bound)."""
@@ -23,7 +23,7 @@ def queries(path):
         name = r["Kernel_Name"]
         if "span" not in name:
             continue
-        if "sa_k_span_flags" in name:                          # the first launch of a query
+        if "sa_k_span_flags" in name or "sa_k_span_doc_fused" in name:      # the first launch of a query (the doc-parallel route: its only one)
             cur = collections.defaultdict(lambda: collections.defaultdict(float))
             out.append(cur)
         if cur is not None:

@@ -270,10 +270,10 @@ def test_slop_doc_parallel_route(api, seed, monkeypatch, capfd):
         other = dev.phrase_freqs_dense(terms, slop=slop)
         monkeypatch.delenv("SA_SPAN_DOC")
         assert np.array_equal(other, want), f"general route: seed {seed} terms {terms} slop {slop}"
-    dev.close()
     assert routes["doc-parallel"] >= 2, routes
     if seed % 2 == 0:
         assert routes["doc-parallel"] == 5, routes
+    dev.close()
 
 
 @pytest.mark.parametrize("seed", range(3))
