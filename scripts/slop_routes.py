@@ -20,6 +20,7 @@ def main():
     index = DeviceIndex(out_words, term_off, lens.astype(np.float32), api=_lib.api())
     nwords = np.diff(term_off)
     phrases = [(0, 1), (0, 2), (1, 2), (2, 3), (0, 5), (3, 4), (0, 10), (5, 6), (1, 20), (0, 30), (10, 11), (8, 9), (20, 30), (15, 16), (1, 2, 3), (3, 4, 5), (5, 8, 9)]
+    phrases += [tuple(int(t) for t in q) for q in synth.phrase_queries_from_tokens(lens, terms, 32, 2, seed=5)]      # (slop_bench.py's sample)
     for ph in phrases:
         row = {"phrase": list(ph), "words": [int(nwords[t]) for t in ph]}
         for mode in ("2", "0"):
@@ -29,6 +30,7 @@ def main():
                 r = index.phrase_freqs_dense(list(ph), slop=2)
                 ms.append(index.last_profile()[0])
             row["doc_route_ms" if mode == "2" else "general_ms"] = round(min(ms[1:]), 4)
+            row["first_ms_doc" if mode == "2" else "first_ms_general"] = round(ms[0], 4)
             row["matches"] = int(r.sum())
         print(json.dumps(row), flush=True)
 

@@ -1698,7 +1698,11 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
     }
     {
         const u32 total = terms_dev.off[T];
-        const u32 grid = total / 256 + 1 < 16384 ? total / 256 + 1 : 16384;
+        // (at least a block per 4096 documents: the launch also clears the dense result -- with one block for two
+        //  50-word lists that was 0.12 ms of a 0.15 ms query on 1 M documents)
+        const u32 by_words = total / 256 + 1 < 16384 ? total / 256 + 1 : 16384;
+        const u32 by_docs = (u32)std::min<u64>(N / 4096 + 1, 1024);
+        const u32 grid = std::max(by_words, by_docs);
         switch (T) {
         case 2: hipLaunchKernelGGL(sa_k_span_flags<2>, dim3(grid), dim3(256), 0, st, terms_dev, wrap_dev, wrap_host, cnt_clear, flags, running); break;
         case 3: hipLaunchKernelGGL(sa_k_span_flags<3>, dim3(grid), dim3(256), 0, st, terms_dev, wrap_dev, wrap_host, cnt_clear, flags, running); break;
