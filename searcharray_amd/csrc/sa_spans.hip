@@ -1029,7 +1029,7 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_wave(const SpanMachinePa
 #define SA_SPAN_FD 512                   // documents of a block
 #define SA_SPAN_PC 8                     // positions of a document the gather keeps in LDS (= positions of a 64-lane chunk's lane)
 #define SA_SPAN_PMAXF 32                 // positions of a document a lane takes at all
-#define SA_SPAN_FROWS 16                 // table rows of a lane of a 64-lane chunk, incl. the scratch row: 16 x 64 x 8 = 8 KiB per wave
+#define SA_SPAN_FROWS 12                 // table rows of a lane of a 64-lane chunk, incl. the scratch row: 12 x 64 x 8 = 6 KiB per wave
 
 struct SpanDocParams {
     SpanTerms st;                        // dd[t] != null for every term
@@ -1073,7 +1073,7 @@ __device__ __forceinline__ u32 sa_span_doc_npos_slow(const SpanTerms& st, const 
 // candidates (bit q of keep[t]), from the document's own words in registers.
 template <int TT>
 __device__ __forceinline__ bool sa_span_doc_words(const SpanTerms& st, const u64 doc, u64 (&W)[TT][SA_SPAN_DW], u32 (&c)[TT],
-                                                  u32 (&keep)[TT], bool* many) {
+                                                  u32 (&keep)[TT], bool* many, u32* first_blk = nullptr) {
     u32 j0[TT];
     bool all = true;
 #pragma unroll
@@ -1120,6 +1120,7 @@ __device__ __forceinline__ bool sa_span_doc_words(const SpanTerms& st, const u64
             }
         }
     if (hi_blk - lo_blk > 29u) { *many = true; return true; }   // (a document longer than 500 positions: the slow path)
+    if (first_blk) *first_blk = lo_blk;
     u32 P[TT];
 #pragma unroll
     for (int t = 0; t < TT; t++) {
@@ -1164,6 +1165,28 @@ __device__ __forceinline__ void sa_span_doc_positions(const u64 (&W)[TT][SA_SPAN
             }
 }
 
+// the same as 16-bit entries relative to the document's first block (the gather's lists in LDS): term << 10 | position -
+// 18 * first_blk (< 540: sa_span_doc_words keeps documents within 30 blocks)
+template <int TT>
+__device__ __forceinline__ void sa_span_doc_positions16(const u64 (&W)[TT][SA_SPAN_DW], const u32 (&keep)[TT], const u32 first_blk,
+                                                        unsigned short* dst, const u32 stride, const u32 cap) {
+    u32 n = 0;
+#pragma unroll
+    for (int t = 0; t < TT; t++)
+#pragma unroll
+        for (int q = 0; q < SA_SPAN_DW; q++)
+            if ((keep[t] >> q) & 1u) {
+                const u64 w = W[t][q];
+                const u32 rel_base = ((u32)((w >> SA_LSB_BITS) & SA_LSB_MASK) - first_blk) * (u32)SA_LSB_BITS;
+                u32 bits = (u32)(w & SA_LSB_MASK);
+                while (bits != 0 && n < cap) {
+                    dst[n * stride] = (unsigned short)(((u32)t << 10) | (rel_base + (u32)(__ffs((int)bits) - 1)));
+                    bits &= bits - 1;
+                    n++;
+                }
+            }
+}
+
 // ---- span entries in 8 bytes: position bits [0, 32), first position [32, 55), last - first + 16 [55, 60), terms [60, 64)
 //      (|last - first| <= T + slop: a span's end only moves to a position within the window of its start)
 __device__ __forceinline__ u64 sa_ent8_pack(const u32 terms, const int posns, const int beg, const int end) {
@@ -1180,8 +1203,9 @@ __device__ __forceinline__ SpanEnt sa_ent8_unpack(const u64 v) {
 
 // sa_span_flat_loop over 8-byte entries: the lane's entry i at ents[i * S] (row CE: scratch), its positions at
 // pos[q * pstride], q < npos.  Returns false when the table outgrew CE entries.
-template <int CE, int PM, int S>
-__device__ __forceinline__ bool sa_span_flat_loop8(u64* ents, const u32* pos, const u32 pstride, const u32 npos, const u32 num_terms,
+// pos(q): the lane's q-th position as term << 24 | position
+template <int CE, int PM, int S, class Pos>
+__device__ __forceinline__ bool sa_span_flat_loop8(u64* ents, const Pos& pos, const u32 npos, const u32 num_terms,
                                                    const int max_span_width, u32* incr_out) {
     u32 cursor = 0, pi = 0, si = 0, end = 0, curr_term_mask = 0, tstart = 0;
     int curr_posn = 0, posn_mask = 0;
@@ -1190,10 +1214,10 @@ __device__ __forceinline__ bool sa_span_flat_loop8(u64* ents, const u32* pos, co
     // the first term's positions only open spans -- there is nothing for them to visit: a loop of its own, a fraction
     // of the general iteration
     if (npos != 0) {
-        const u32 first_term = pos[0] >> 24;
+        const u32 first_term = pos(0u) >> 24;
         curr_term_mask = 1u << first_term;
         while (pi < npos && cursor < (u32)CE) {
-            const u32 pv = pos[pi * pstride];
+            const u32 pv = pos(pi);
             if ((pv >> 24) != first_term) break;
             const int q = (int)(pv & 0xFFFFFFu);
             ents[cursor * (u32)S] = sa_ent8_pack(curr_term_mask, sa_posn_mask32(q), q, q);
@@ -1204,7 +1228,7 @@ __device__ __forceinline__ bool sa_span_flat_loop8(u64* ents, const u32* pos, co
         const bool need = si >= end;
         const bool done = need && pi >= npos;
         const bool fresh_it = need && !done;
-        const u32 pv = pos[(pi < (u32)PM ? pi : (u32)PM - 1u) * pstride];
+        const u32 pv = pos(pi < (u32)PM ? pi : (u32)PM - 1u);
         const u32 new_mask = 1u << (pv >> 24);
         tstart = (fresh_it && new_mask != curr_term_mask) ? cursor : tstart;
         curr_posn = fresh_it ? (int)(pv & 0xFFFFFFu) : curr_posn;
@@ -1327,23 +1351,34 @@ __device__ __forceinline__ void sa_span_wave_doc(const SpanDocParams& p, const u
     __builtin_amdgcn_wave_barrier();
 }
 
-// S lanes of wave `w` take S neighbours of the block's order, from `start`
+// S lanes of a wave take S neighbours of the block's order, from `start`.  64 lanes: the positions where the gather
+// left them; fewer: behind the tables (PM x S words), from the gather's list if it holds them, else from the words again.
 template <int CE, int PM, int S, int TT>
-__device__ __forceinline__ void sa_span_doc_chunk(const SpanDocParams& p, u64* tab, const u32* s_plist, const unsigned char* s_bin,
-                                                  const unsigned short* s_order, unsigned short* s_heavy, u32* n_heavy, const u64 lo,
-                                                  const u32 lane, const u32 start, const u32 n) {
+__device__ __forceinline__ void sa_span_doc_chunk(const SpanDocParams& p, u64* tab, const unsigned short* s_plist, const u32* s_pbase,
+                                                  const unsigned char* s_bin, const unsigned short* s_order, unsigned short* s_heavy,
+                                                  u32* n_heavy, const u64 lo, const u32 lane, const u32 start, const u32 n) {
     const bool have = lane < (u32)S && start + lane < n;
     const u32 local = have ? s_order[start + lane] : 0u;
     const u32 npos = have ? s_bin[local] : 0u;
     const u64 doc = lo + local;
-    const u32* pos = s_plist + local;
-    u32 pstride = SA_SPAN_FD;
-    if (S < 64) {
-        // the lane's positions behind the tables: from the gather's list if it holds them, else from the words again
+    u32 incr = 0;
+    bool ok;
+    if (S == 64) {
+        const unsigned short* const pl = s_plist + local;
+        const u32 base = s_pbase[local];
+        ok = sa_span_flat_loop8<CE, PM, S>(tab + lane, [&](const u32 q) -> u32 {
+            const u32 v = pl[q * SA_SPAN_FD];
+            return ((v >> 10) << 24) | (base + (v & 1023u));
+        }, npos, (u32)TT, (int)((u32)TT + p.slop), &incr);
+    } else {
         u32* const s_pos = (u32*)(tab + (size_t)(CE + 1) * S);
         if (have) {
             if (npos <= (u32)SA_SPAN_PC) {
-                for (u32 q = 0; q < npos; q++) s_pos[q * (u32)S + lane] = s_plist[q * SA_SPAN_FD + local];
+                const u32 base = s_pbase[local];
+                for (u32 q = 0; q < npos; q++) {
+                    const u32 v = s_plist[q * SA_SPAN_FD + local];
+                    s_pos[q * (u32)S + lane] = ((v >> 10) << 24) | (base + (v & 1023u));
+                }
             } else {
                 u64 W[TT][SA_SPAN_DW];
                 u32 c[TT], keep[TT];
@@ -1352,11 +1387,10 @@ __device__ __forceinline__ void sa_span_doc_chunk(const SpanDocParams& p, u64* t
                 sa_span_doc_positions<TT>(W, keep, s_pos + lane, (u32)S, npos);
             }
         }
-        pos = s_pos + lane;
-        pstride = (u32)S;
+        const u32* const pl = s_pos + (have ? lane : 0u);
+        ok = sa_span_flat_loop8<CE, PM, S>(tab + (have ? lane : 0u), [&](const u32 q) -> u32 { return pl[q * (u32)S]; },
+                                           npos, (u32)TT, (int)((u32)TT + p.slop), &incr);
     }
-    u32 incr = 0;
-    const bool ok = sa_span_flat_loop8<CE, PM, S>(tab + (have ? lane : 0u), pos, pstride, npos, (u32)TT, (int)((u32)TT + p.slop), &incr);
     if (have) {
         if (ok) { if (incr) p.counts[doc] = (float)incr; }
         else s_heavy[atomicAdd(n_heavy, 1u)] = (unsigned short)local;          // its table outgrew the column: a wave of its own below
@@ -1366,16 +1400,19 @@ __device__ __forceinline__ void sa_span_doc_chunk(const SpanDocParams& p, u64* t
 template <int TT>
 __global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused(const SpanDocParams p) {
     constexpr int NW = SA_SPAN_FT / 64, ROUNDS = SA_SPAN_FD / SA_SPAN_FT;
-    __shared__ u32 s_plist[SA_SPAN_PC * SA_SPAN_FD];             // position-major: position q of local document d at [q * FD + d]
-    __shared__ alignas(16) u64 s_tab[NW][SA_SPAN_FROWS * 64];    // a wave's tables (8 KiB: also one full 512-span table of 16-byte entries)
+    constexpr int TABW = SA_SPAN_FROWS * 64;                     // a wave's tables, in 8-byte words
+    __shared__ unsigned short s_plist[SA_SPAN_PC * SA_SPAN_FD];  // position-major: position q of local document d at [q * FD + d]
+    __shared__ u32 s_pbase[SA_SPAN_FD];                          // 18 x the document's first block
+    __shared__ alignas(16) u64 s_tab[NW * TABW];
     __shared__ unsigned char s_bin[SA_SPAN_FD];
     __shared__ unsigned short s_order[SA_SPAN_FD], s_heavy[SA_SPAN_FD];
     __shared__ u32 s_h[SA_SPAN_DB], s_first[SA_SPAN_DB], s_cur[SA_SPAN_DB];
-    __shared__ u32 s_nheavy;
-    static_assert(SA_SPAN_FROWS * 64 * 8 >= SA_NSPANS * sizeof(SpanEnt), "a wave's tables must hold one full table");
+    __shared__ u32 s_nheavy, s_next;
+    constexpr int HW = (int)(NW * TABW * 8 / (SA_NSPANS * sizeof(SpanEnt)));      // waves that find room for a full 512-span table afterwards
+    static_assert(HW >= 1, "the block's tables must hold one full table");
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (threadIdx.x < SA_SPAN_DB) { s_h[threadIdx.x] = 0; s_cur[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) s_nheavy = 0;
+    if (threadIdx.x == 0) { s_nheavy = 0; s_next = 0; }
     __syncthreads();
     constexpr u32 PMAX = SA_SPAN_PMAXF, HEAVY = SA_SPAN_PMAXF + 1;
     const u64 lo = (u64)blockIdx.x * SA_SPAN_FD;
@@ -1391,7 +1428,8 @@ __global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused(const SpanDocP
             if (doc < p.st.n_docs) {
                 p.counts[doc] = 0.f;
                 bool many = false;
-                if (sa_span_doc_words<TT>(p.st, doc, W, c, keep, &many)) {
+                u32 first_blk = 0;
+                if (sa_span_doc_words<TT>(p.st, doc, W, c, keep, &many, &first_blk)) {
                     u32 npos = 0;
                     if (many) {
                         npos = sa_span_doc_npos_slow<TT>(p.st, doc);
@@ -1401,7 +1439,10 @@ __global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused(const SpanDocP
 #pragma unroll
                             for (int q = 0; q < SA_SPAN_DW; q++)
                                 if ((keep[t] >> q) & 1u) npos += (u32)__popc((u32)(W[t][q] & SA_LSB_MASK));
-                        if (npos != 0 && npos <= (u32)SA_SPAN_PC) sa_span_doc_positions<TT>(W, keep, s_plist + local, SA_SPAN_FD, npos);
+                        if (npos != 0 && npos <= (u32)SA_SPAN_PC) {
+                            sa_span_doc_positions16<TT>(W, keep, first_blk, s_plist + local, SA_SPAN_FD, npos);
+                            s_pbase[local] = first_blk * (u32)SA_LSB_BITS;
+                        }
                     }
                     bin = npos == 0 ? 0u : ((many || npos > PMAX) ? HEAVY : npos);
                 }
@@ -1432,28 +1473,38 @@ __global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused(const SpanDocP
         else if (bin) s_order[s_first[bin] + atomicAdd(&s_cur[bin], 1u)] = (unsigned short)local;
     }
     __syncthreads();
-    // ---- machine: chunks of 16 while the documents have more than 16 positions, 32 above 8, else 64
+    // ---- machine: chunks of 8 documents while they have more than 16 positions, of 16 above 8, else 64; a wave takes the
+    //      next chunk when it is done with its last (the first chunks are the long ones)
     {
         const u32 n = s_first[0], n_c = s_first[2 * SA_SPAN_PC], n_cb = s_first[SA_SPAN_PC];
-        const u32 k_c = (n_c + 15u) / 16u;
-        const u32 start_b = 16u * k_c < n ? 16u * k_c : n;
-        const u32 k_b = n_cb > start_b ? (n_cb - start_b + 31u) / 32u : 0u;
-        const u32 start_a = start_b + 32u * k_b < n ? start_b + 32u * k_b : n;
-        const u32 k_a = (n - start_a + 63u) / 64u;
-        u64* const tab = s_tab[wave];
+        const u32 k_c = (n_c + 7u) / 8u;
+        const u32 start_b = 8u * k_c < n ? 8u * k_c : n;
+        const u32 k_b = n_cb > start_b ? (n_cb - start_b + 15u) / 16u : 0u;
+        const u32 start_a = start_b + 16u * k_b < n ? start_b + 16u * k_b : n;
+        // (three and four terms: 15 % of the documents need more than 12 spans, 3 % more than 16 -- 32 documents per
+        //  wave with 20 rows each there, a wave of their own for the rest)
+        constexpr u32 AL = TT == 2 ? 64u : 32u;
+        const u32 k_a = (n - start_a + AL - 1u) / AL;
+        u64* const tab = s_tab + (size_t)wave * TABW;
         constexpr int R = SA_SPAN_FROWS;
-        // 16 lanes: 48 rows x 16 x 8 = 6 KiB + 32 positions x 16 x 4 = 2 KiB; 32 lanes: 24 rows x 32 x 8 = 6 KiB + 16 x 32 x 4 = 2 KiB
-        for (u32 ck = wave; ck < k_c + k_b + k_a; ck += NW) {
+        // 8 lanes: 32 positions x 8 x 4 B = 1 KiB behind (TABW - 128) / 8 rows; 16 lanes: 16 x 16 x 4 B = 1 KiB behind (TABW - 128) / 16 rows
+        for (;;) {
+            u32 ck = 0;
+            if (lane == 0) ck = atomicAdd(&s_next, 1u);
+            ck = (u32)__builtin_amdgcn_readfirstlane((int)ck);
+            if (ck >= k_c + k_b + k_a) break;
+            if (ck < k_c) sa_span_doc_chunk<(TABW - 128) / 8 - 1, 4 * SA_SPAN_PC, 8, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, lo, lane, 8u * ck, n);
+            else if (ck < k_c + k_b) sa_span_doc_chunk<(TABW - 128) / 16 - 1, 2 * SA_SPAN_PC, 16, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, lo, lane, start_b + 16u * (ck - k_c), n);
+            else if (TT == 2) sa_span_doc_chunk<R - 1, SA_SPAN_PC, 64, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, lo, lane, start_a + 64u * (ck - k_c - k_b), n);
+            else sa_span_doc_chunk<(TABW - 128) / 32 - 1, SA_SPAN_PC, 32, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, lo, lane, start_a + 32u * (ck - k_c - k_b), n);
             __builtin_amdgcn_wave_barrier();
-            if (ck < k_c) sa_span_doc_chunk<3 * R - 1, 4 * SA_SPAN_PC, 16, TT>(p, tab, s_plist, s_bin, s_order, s_heavy, &s_nheavy, lo, lane, 16u * ck, n);
-            else if (ck < k_c + k_b) sa_span_doc_chunk<3 * R / 2 - 1, 2 * SA_SPAN_PC, 32, TT>(p, tab, s_plist, s_bin, s_order, s_heavy, &s_nheavy, lo, lane, start_b + 32u * (ck - k_c), n);
-            else sa_span_doc_chunk<R - 1, SA_SPAN_PC, 64, TT>(p, tab, s_plist, s_bin, s_order, s_heavy, &s_nheavy, lo, lane, start_a + 64u * (ck - k_c - k_b), n);
         }
     }
     __syncthreads();
-    // ---- heavy documents and outgrown tables: a wave each
+    // ---- heavy documents and outgrown tables: a wave each, the block's tables now being free (HW full tables fit)
     const u32 nh = s_nheavy;
-    for (u32 i = wave; i < nh; i += NW) sa_span_wave_doc<TT>(p, lo + s_heavy[i], (SpanEnt*)s_tab[wave], lane);
+    if (wave < (u32)HW)
+        for (u32 i = wave; i < nh; i += (u32)HW) sa_span_wave_doc<TT>(p, lo + s_heavy[i], (SpanEnt*)s_tab + (size_t)wave * SA_NSPANS, lane);
 }
 
 static int sa_env_int_span(const char* name, int dflt) {
