@@ -38,6 +38,7 @@
 #include "../../include/searcharray_hip.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 #define SA_SPAN_MAX_TERMS 32
 #define SA_NSPANS 512
@@ -1351,6 +1352,106 @@ __device__ __forceinline__ void sa_span_wave_doc(const SpanDocParams& p, const u
     __builtin_amdgcn_wave_barrier();
 }
 
+// The same with an ACTIVE SET per term (CE < 64).  A span a position skips -- its table is blocked (a partial span whose
+// position bits already number T) or it already holds the position's term -- is skipped by every later position of that
+// term as well: skipped spans do not change, a blocked span stays blocked, an extended one keeps the term.  So the
+// spans a term's positions still have to visit are a set that only shrinks: a bit mask (all spans from before the term
+// when it begins), walked by find-first-set; a span leaves it when a visit finds or makes it dead.  The visits that remain
+// happen in the same order (position by position, spans ascending), so forks are appended exactly as before.  Two terms:
+// the first position of term 1 settles nearly every span of term 0 (extended or blocked), the others only open their own
+// span -- a + b + a iterations instead of a + a x b.
+template <int CE, int PM, int S, class Pos>
+__device__ __forceinline__ bool sa_span_flat_loop8a(u64* ents, const Pos& pos, const u32 npos, const u32 num_terms,
+                                                    const int max_span_width, u32* incr_out) {
+    static_assert(CE < 64, "the active set is a 64-bit mask");
+    typedef typename std::conditional<(CE < 32), u32, u64>::type M;
+    u32 cursor = 0, pi = 0, curr_term_mask = 0;
+    M active = 0, todo = 0;
+    int curr_posn = 0, posn_mask = 0;
+    bool abandoned = false;
+    bool alive = true;
+    if (npos != 0) {                                             // (the first term's positions only open spans)
+        const u32 first_term = pos(0u) >> 24;
+        curr_term_mask = 1u << first_term;
+        while (pi < npos && cursor < (u32)CE) {
+            const u32 pv = pos(pi);
+            if ((pv >> 24) != first_term) break;
+            const int q = (int)(pv & 0xFFFFFFu);
+            ents[cursor * (u32)S] = sa_ent8_pack(curr_term_mask, sa_posn_mask32(q), q, q);
+            cursor++; pi++;
+        }
+    }
+    while (alive) {
+        const bool need = todo == 0;
+        const bool done = need && pi >= npos;
+        const bool fresh_it = need && !done;
+        const u32 pv = pos(pi < (u32)PM ? pi : (u32)PM - 1u);
+        const u32 new_mask = 1u << (pv >> 24);
+        active = (fresh_it && new_mask != curr_term_mask) ? (M)(((M)1 << cursor) - (M)1) : active;     // (cursor <= CE)
+        curr_posn = fresh_it ? (int)(pv & 0xFFFFFFu) : curr_posn;
+        curr_term_mask = fresh_it ? new_mask : curr_term_mask;
+        posn_mask = sa_posn_mask32(curr_posn);
+        const bool over_f = fresh_it && cursor >= (u32)CE;
+        ents[((fresh_it && !over_f) ? cursor : (u32)CE) * (u32)S] = sa_ent8_pack(curr_term_mask, posn_mask, curr_posn, curr_posn);
+        todo = fresh_it ? active : todo;
+        cursor += fresh_it ? 1u : 0u;
+        pi += fresh_it ? 1u : 0u;
+        // visit the next span of the set
+        const bool vis = !done && !over_f && todo != 0;
+        const u32 si = vis ? (u32)(sizeof(M) == 4 ? __builtin_ctz((u32)todo) : __builtin_ctzll((u64)todo)) : (u32)CE;
+        todo = vis ? (M)(todo & (todo - (M)1)) : todo;
+        const SpanEnt e = sa_ent8_unpack(ents[si * (u32)S]);
+        const u32 nt = (u32)__popc(e.terms), np = sa_popc_sext(e.posns);
+        const bool act = vis && !((nt < num_terms && np == num_terms) || (e.terms & curr_term_mask));
+        const int sp2 = e.posns | posn_mask;
+        const u32 new_unique = sa_popc_sext(sp2);
+        const int proposed = sa_iabs32(curr_posn - e.beg);
+        const bool rej = np == new_unique || proposed > max_span_width;    // (the position bit stays even if rejected)
+        const bool fork_it = act && !rej;
+        const bool over_k = fork_it && cursor >= (u32)CE;
+        ents[si * (u32)S] = sa_ent8_pack(fork_it ? (e.terms | curr_term_mask) : e.terms, act ? sp2 : e.posns, e.beg, fork_it ? curr_posn : e.end);
+        ents[((fork_it && !over_k) ? cursor : (u32)CE) * (u32)S] = sa_ent8_pack(e.terms | curr_term_mask, sp2 & ~posn_mask, e.beg, e.end);
+        cursor += (fork_it && !over_k) ? 1u : 0u;
+        // dead for this term from here on: skipped now, extended now, or blocked by the bit this visit left
+        const bool dead = !act || fork_it || (nt < num_terms && new_unique == num_terms);
+        active = (vis && dead) ? (M)(active & ~((M)1 << si)) : active;
+        abandoned = over_f || over_k;
+        alive = !done && !abandoned;
+    }
+    if (abandoned) return false;
+    u32 ncol = 0;                                                // (_collect_spans: as in sa_span_flat_loop8)
+    for (u32 i = 0; i < cursor; i++) {
+        const SpanEnt e = sa_ent8_unpack(ents[i * (u32)S]);
+        const bool complete = ((u32)__popc(e.terms) == num_terms) || (sa_popc_sext(e.posns) == num_terms);
+        const int b = e.beg, en = e.end;
+        const int width = sa_iabs32(en - b);
+        if (!complete || width >= max_span_width) continue;
+        bool replaced = false;
+        for (u32 c = 0; c < ncol; c++) {
+            const u64 cc = ents[c * (u32)S];
+            const int cb = (int)(cc >> 32), ce = (int)(cc & 0xFFFFFFFFull);
+            if (b <= ce && en >= cb && width < sa_iabs32(ce - cb)) {
+                ents[c * (u32)S] = ((u64)(u32)b << 32) | (u64)(u32)en;
+                replaced = true;
+                break;
+            }
+        }
+        if (!replaced) {
+            ents[ncol * (u32)S] = ((u64)(u32)b << 32) | (u64)(u32)en;
+            ncol++;
+        }
+    }
+    *incr_out = ncol;
+    return true;
+}
+
+template <int CE, int PM, int S, class Pos>
+__device__ __forceinline__ bool sa_span_lane_machine(u64* ents, const Pos& pos, const u32 npos, const u32 num_terms,
+                                                     const int max_span_width, u32* incr_out) {
+    if constexpr (CE < 64) return sa_span_flat_loop8a<CE, PM, S>(ents, pos, npos, num_terms, max_span_width, incr_out);
+    else return sa_span_flat_loop8<CE, PM, S>(ents, pos, npos, num_terms, max_span_width, incr_out);
+}
+
 // S lanes of a wave take S neighbours of the block's order, from `start`.  64 lanes: the positions where the gather
 // left them; fewer: behind the tables (PM x S words), from the gather's list if it holds them, else from the words again.
 template <int CE, int PM, int S, int TT>
@@ -1366,7 +1467,7 @@ __device__ __forceinline__ void sa_span_doc_chunk(const SpanDocParams& p, u64* t
     if (S == 64) {
         const unsigned short* const pl = s_plist + local;
         const u32 base = s_pbase[local];
-        ok = sa_span_flat_loop8<CE, PM, S>(tab + lane, [&](const u32 q) -> u32 {
+        ok = sa_span_lane_machine<CE, PM, S>(tab + lane, [&](const u32 q) -> u32 {
             const u32 v = pl[q * SA_SPAN_FD];
             return ((v >> 10) << 24) | (base + (v & 1023u));
         }, npos, (u32)TT, (int)((u32)TT + p.slop), &incr);
@@ -1388,7 +1489,7 @@ __device__ __forceinline__ void sa_span_doc_chunk(const SpanDocParams& p, u64* t
             }
         }
         const u32* const pl = s_pos + (have ? lane : 0u);
-        ok = sa_span_flat_loop8<CE, PM, S>(tab + (have ? lane : 0u), [&](const u32 q) -> u32 { return pl[q * (u32)S]; },
+        ok = sa_span_lane_machine<CE, PM, S>(tab + (have ? lane : 0u), [&](const u32 q) -> u32 { return pl[q * (u32)S]; },
                                            npos, (u32)TT, (int)((u32)TT + p.slop), &incr);
     }
     if (have) {
