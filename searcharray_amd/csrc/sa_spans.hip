@@ -693,18 +693,23 @@ typedef SpanEntColS<64> SpanEntCol;
 template <int CE, int PMAX, int S = 64>
 __device__ __forceinline__ bool sa_span_flat_loop(const SpanEntColS<S>& ents, const u32* s_pos, const u32 lane, const u32 npos,
                                                   const u32 num_terms, const int max_span_width, u32* incr_out) {
-    u32 cursor = 0, pi = 0, si = 0, end = 0, curr_term_mask = 0, tstart = 0;
+    // The spans a term's positions still have to visit are a set that only shrinks -- a skipped span (blocked, or
+    // already holding the term) is skipped by every later position of the term, skipped spans do not change -- kept as a
+    // bit mask: all spans from before the term when it begins, walked by find-first-set, a span leaves it when a visit
+    // finds or makes it dead.  The visits that remain happen in the same order, so forks are appended exactly as before.
+    static_assert(CE < 32, "the active set is a 32-bit mask");
+    u32 cursor = 0, pi = 0, curr_term_mask = 0, active = 0, todo = 0;
     int curr_posn = 0, posn_mask = 0;
     bool abandoned = false;
     bool alive = true;
     while (alive) {
         // the current position has visited every span it has to: take the next one
-        const bool need = si >= end;
+        const bool need = todo == 0;
         const bool done = need && pi >= npos;
         const bool fresh_it = need && !done;
         const u32 pv = s_pos[(pi < (u32)PMAX ? pi : (u32)PMAX - 1u) * (u32)S + lane];
         const u32 new_mask = 1u << (pv >> 24);
-        tstart = (fresh_it && new_mask != curr_term_mask) ? cursor : tstart;
+        active = (fresh_it && new_mask != curr_term_mask) ? (1u << cursor) - 1u : active;      // (cursor <= CE < 32)
         curr_posn = fresh_it ? (int)(pv & 0xFFFFFFu) : curr_posn;
         curr_term_mask = fresh_it ? new_mask : curr_term_mask;
         posn_mask = sa_posn_mask32(curr_posn);
@@ -714,13 +719,13 @@ __device__ __forceinline__ bool sa_span_flat_loop(const SpanEntColS<S>& ents, co
             fresh.terms = curr_term_mask; fresh.posns = posn_mask; fresh.beg = curr_posn; fresh.end = curr_posn;
             ents[(fresh_it && !over_f) ? cursor : (u32)CE] = fresh;
         }
-        end = fresh_it ? tstart : end;
-        si = fresh_it ? 0u : si;
+        todo = fresh_it ? active : todo;
         cursor += fresh_it ? 1u : 0u;
         pi += fresh_it ? 1u : 0u;
-        // visit span si
-        const bool vis = !done && !over_f && si < end;
-        const u32 slot = vis ? si : (u32)CE;
+        // visit the next span of the set
+        const bool vis = !done && !over_f && todo != 0;
+        const u32 slot = vis ? (u32)__builtin_ctz(todo) : (u32)CE;
+        todo = vis ? todo & (todo - 1u) : todo;
         const SpanEnt e = ents[slot];
         const u32 nt = (u32)__popc(e.terms), np = sa_popc_sext(e.posns);
         const bool act = vis && !((nt < num_terms && np == num_terms) || (e.terms & curr_term_mask));
@@ -739,7 +744,9 @@ __device__ __forceinline__ bool sa_span_flat_loop(const SpanEntColS<S>& ents, co
         fork.terms = e.terms | curr_term_mask; fork.posns = sp2 & ~posn_mask; fork.beg = e.beg; fork.end = e.end;
         ents[(fork_it && !over_k) ? cursor : (u32)CE] = fork;
         cursor += (fork_it && !over_k) ? 1u : 0u;
-        si += vis ? 1u : 0u;
+        // dead for this term from here on: skipped now, extended now, or blocked by the bit this visit left
+        const bool dead = !act || fork_it || (nt < num_terms && new_unique == num_terms);
+        active = (vis && dead) ? active & ~(1u << slot) : active;
         abandoned = over_f || over_k;
         alive = !done && !abandoned;
     }
