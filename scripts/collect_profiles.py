@@ -97,7 +97,7 @@ def main():
             json.dump(js[-1], open(os.path.join(PROF, dst), "w"), indent=1)
             print("wrote", dst)
     for src, dst in [("kernel_ab.log", f"kernel_ab_{RND}.jsonl"), ("host_cost.log", f"host_cost_{RND}.jsonl"),
-                     ("slop_heavy.log", f"slop_heaviest_{RND}.jsonl")]:
+                     ("slop_heavy.log", f"slop_heaviest_{RND}.jsonl"), ("slop_routes.log", f"slop_routes_{RND}.jsonl")]:
         js = json_lines(os.path.join(OUT, src))
         if js:
             open(os.path.join(PROF, dst), "w").write("\n".join(json.dumps(j) for j in js) + "\n")

@@ -24,6 +24,7 @@ cd $R
 ( time timeout 300 python scripts/host_cost.py --docs 1250000 --comm ) >> $O/host_cost.log 2>&1
 ( time timeout 300 python scripts/phrase_bench.py ) > $O/phrase_bench.log 2>&1
 ( time timeout 300 python scripts/slop_bench.py ) > $O/slop_bench.log 2>&1
+( time timeout 300 python scripts/slop_routes.py ) > $O/slop_routes.log 2>&1
 cd /tmp
 # kernel stats per leg: the main leg alone (one resident batch replayed), the distinct-terms leg alone, then the whole bench
 ( timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_main -- python $R/scripts/ab.py --corpus-cache $C --ks 10 --qsets baseline --steps 12 ) > $O/prof_main.log 2>&1
