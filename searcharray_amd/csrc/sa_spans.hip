@@ -1615,13 +1615,6 @@ __global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused(const SpanDocP
         for (u32 i = wave; i < nh; i += (u32)HW) sa_span_wave_doc<TT>(p, lo + s_heavy[i], (SpanEnt*)s_tab + (size_t)wave * SA_NSPANS, lane);
 }
 
-static int sa_env_int_span(const char* name, int dflt) {
-    const char* v = getenv(name);
-    if (!v) return dflt;
-    const int x = atoi(v);
-    return x > 0 ? x : dflt;
-}
-
 static bool sa_env_span_doc() {
     const char* v = getenv("SA_SPAN_DOC");
     return !(v && atoi(v) == 0);
