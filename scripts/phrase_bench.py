@@ -57,6 +57,26 @@ def main():
                      "t0t1t2_device_ms": round(ms0, 4), "t0t1t2_alg_GBps": round(ab0 / ms0 / 1e6, 1)}
         res[mode + "_outs"] = outs
     os.environ.pop("SA_PHRASE_MODE", None)
+    # phrases with repeated terms: the chain per document (one launch) vs the general chain (SA_PHRASE_DOCS=0), device ms
+    rep = {}
+    rep_ok = True
+    for ph in ([0, 0, 1], [0, 0], [1, 2, 2], [3, 0, 0, 5], [0, 1, 0, 1], [7, 7, 9]):
+        row = {}
+        for name, env in (("per_document_ms", None), ("general_chain_ms", "0")):
+            if env is None:
+                os.environ.pop("SA_PHRASE_DOCS", None)
+            else:
+                os.environ["SA_PHRASE_DOCS"] = env
+            best = 1e9
+            for _ in range(4):
+                r = index.phrase_freqs_dense(ph)
+                best = min(best, index.last_profile()[0])
+            row[name] = round(best, 4)
+            row.setdefault("matches", int(r.sum()))
+            rep_ok &= row["matches"] == int(r.sum())
+        os.environ.pop("SA_PHRASE_DOCS", None)
+        rep[" ".join(f"t{t}" for t in ph)] = row
+    rep_ok &= bool(np.array_equal(index.phrase_freqs_dense([0, 0, 1]), orc.phrase_freqs([0, 0, 1])))
     # phrase batches: B phrases -> BM25 -> top-10, resident on the device
     import itertools
     batches = {
@@ -99,6 +119,7 @@ def main():
     want0 = orc.phrase_freqs([0, 1, 2])
     cpu0 = time.perf_counter() - t0
     print(json.dumps({"config": f"zipf-{D} 3-token phrases x{len(phrases)}", "fused": res["fused"], "general": res["general"], "batch_top10": bres,
+                      "repeated_terms": rep, "repeated_terms_equal": rep_ok,
                       "cpu_oracle_ms_per_phrase": round(cpu_dt / ncpu * 1e3, 2), "cpu_oracle_t0t1t2_ms": round(cpu0 * 1e3, 2),
                       "t0t1t2_matches": int(want0.sum()), "counts_bit_exact": ok}))
 

@@ -230,6 +230,8 @@ void sa_index_free(sa_index* ix) {
     if (ix->d_span_batch) hipFree(ix->d_span_batch);
     if (ix->d_span_counts) hipFree(ix->d_span_counts);
     if (ix->h_span_jobs) hipHostFree(ix->h_span_jobs);
+    if (ix->h_flags) hipHostFree(ix->h_flags);
+    if (ix->d_flags) hipFree(ix->d_flags);
     if (ix->ev_span_jobs) hipEventDestroy(ix->ev_span_jobs);
     if (ix->d_rows_scratch) hipFree(ix->d_rows_scratch);
     if (ix->d_sim_scratch) hipFree(ix->d_sim_scratch);

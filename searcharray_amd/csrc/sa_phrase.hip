@@ -203,6 +203,192 @@ __global__ void __launch_bounds__(256) sa_k_phrase_fused(const FusedPhraseParams
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// the chain per DOCUMENT (phrases with repeated terms, frequent terms)
+// ---------------------------------------------------------------------------------------
+// Every operation of a bigram step -- intersect on the header, the header + 1 adjacency, the continuation words, the
+// adjacency bit absorbed into the inner word of the same header, the merge -- relates words of ONE document, provided no
+// term has a word in a document's last 18-position block (header + 1 would be the next document's block 0; the doc
+// directory records that per term).  So for terms that have a doc directory row the whole chain can run per document:
+// one thread per document gathers the document's words of every term through the directory (a handful) and runs the
+// general chain's steps on them in LDS -- the same formulas as InnerBigram / AdjBigram / sa_k_absorb_adj /
+// sa_k_merge_by_rank above, the per-step counts summed over the document, the running minimum over the steps
+// (_intersect_bigram_matches: absent = 0) -- one launch instead of ~20 per bigram.
+// The one thing that is NOT local is the reference's same-term test, `np.all(lhs_int == rhs_int)` over ALL matched pairs of
+// a step (bigram_freqs.py:140).  It is predicted -- true exactly for a chain's first step over twice the same term -- and
+// checked: every step the prediction calls "different" records whether it had a matched pair and whether one differed;
+// "pairs, none different" (degenerate data) makes the host fall back to the general chain, and so does a document with
+// more words of a term, or of a continuation, than a thread holds.
+#define SA_PD_MAXT 8                     // terms of a phrase this route takes
+#define SA_PD_THREADS 128
+
+struct PhraseDocParams {
+    const u64* words[SA_PD_MAXT];        // by phrase position
+    const u32* dd[SA_PD_MAXT];
+    u32 len[SA_PD_MAXT];
+    int T;
+    int plan;                            // 0: left to right, 1: right to left, 2: middle out at `shortest`
+    int shortest;
+    u32 same_mask;                       // bit s: step s (in execution order) is predicted "same term"
+    u64 n_docs;
+    float* counts;
+    u32* flags;                          // [0] a document did not fit; [1 + 2 s] step s had a matched pair, [2 + 2 s] a pair that differed
+};
+
+// thread-private arrays in LDS: element i of this thread at a[i * SA_PD_THREADS]
+struct PdArr {
+    u64* a;
+    __device__ __forceinline__ u64& operator[](u32 i) const { return a[i * SA_PD_THREADS]; }
+};
+
+// the document's words of the term at phrase position t -> dst; false: more than CAP words.  (All requested at once: one
+// after the other, each waiting for the last to see whether the document goes on, they are a chain of round trips.)
+template <int CAP>
+__device__ __forceinline__ bool sa_pd_load(const PhraseDocParams& p, const int t, const u64 doc, const PdArr& dst, u32* n_out) {
+    u32 n = 0;
+    const u32 j0 = p.dd[t][doc];
+    if (j0 != SA_DD_ABSENT) {
+        const u64* const w = p.words[t];
+        const u32 len = p.len[t];
+        u64 x[CAP + 1];
+#pragma unroll
+        for (int q = 0; q <= CAP; q++) x[q] = j0 + (u32)q < len ? w[j0 + (u32)q] : ~0ull;
+        bool run = true;
+#pragma unroll
+        for (int q = 0; q <= CAP; q++) {
+            run = run && (x[q] >> SA_KEY_SHIFT) == doc;
+            if (run && q < CAP) dst[(u32)q] = x[q];
+            n += run ? 1u : 0u;
+        }
+        if (n > CAP) return false;
+    }
+    *n_out = n;
+    return true;
+}
+
+// One bigram step on the document's words: lhs (nl) x rhs (nr) -> the continuation in `out` (*nout), the step's count.
+// ni / na: scratch.  Returns false when the continuation does not fit.
+template <int CAP>
+__device__ __forceinline__ bool sa_pd_step(const PdArr& lhs, const u32 nl, const PdArr& rhs, const u32 nr, const int cont, const bool same,
+                                           const PdArr& ni_arr, const PdArr& na_arr, const PdArr& out, u32* nout, u32* count_out,
+                                           bool* any_pair, bool* any_diff) {
+    const u64 unit = 1ull << SA_LSB_BITS;
+    u32 ni = 0, na = 0, count = 0;
+    for (u32 i = 0; i < nl; i++) {
+        const u64 l = lhs[i];
+        const u64 h = l & SA_HEADER_MASK;
+        u32 jin = SA_NONE, jadj = SA_NONE;
+        for (u32 j = 0; j < nr; j++) {                          // (sa_k_probe: headers are unique within a list)
+            const u64 rh = rhs[j] & SA_HEADER_MASK;
+            if (rh == h) jin = j;
+            if (rh == h + unit) jadj = j;
+        }
+        if (jin != SA_NONE) {                                   // InnerBigram
+            const u64 r = rhs[jin];
+            *any_pair = true;
+            if (r != l) *any_diff = true;
+            u64 nxt;
+            if (same) {
+                const u64 ov = l & (r << 1);
+                const int adj = __popcll(ov & SA_LSB_MASK);
+                const int cons = __popcll((ov & (ov << 1)) & SA_LSB_MASK);
+                count += (u32)(adj - ((cons + 1) >> 1));
+                const u64 msbs = l & ~SA_LSB_MASK;
+                nxt = (cont == CONT_RHS) ? ((((r << 1) & r) & SA_LSB_MASK) | msbs) : (msbs | ((l & (l >> 1)) & SA_LSB_MASK));
+            } else {
+                const u64 ov = (l & SA_LSB_MASK) & ((r & SA_LSB_MASK) >> 1);
+                count += (u32)__popcll(ov);
+                nxt = (cont == CONT_RHS) ? (((ov << 1) & SA_LSB_MASK) | (r & SA_HEADER_MASK)) : (ov | (l & SA_HEADER_MASK));
+            }
+            ni_arr[ni++] = nxt;                                 // (ni <= nl <= CAP)
+        }
+        if (jadj != SA_NONE && (l & SA_UPPER_BIT) != 0 && (rhs[jadj] & 1ull) != 0) {      // AdjBigram
+            na_arr[na++] = (cont == CONT_RHS) ? ((rhs[jadj] & SA_HEADER_MASK) | 1ull) : ((l & SA_HEADER_MASK) | SA_UPPER_BIT);
+            count += 1u;
+        }
+    }
+    // sa_k_absorb_adj: the adjacency bit into the inner continuation word of the same header; the others stay words of their own
+    const u64 bit = (cont == CONT_RHS) ? 1ull : SA_UPPER_BIT;
+    u32 nu = 0;
+    for (u32 a = 0; a < na; a++) {
+        const u64 x = na_arr[a];
+        const u64 ha = x & SA_HEADER_MASK;
+        bool found = false;
+        for (u32 i = 0; i < ni; i++)
+            if ((ni_arr[i] & SA_HEADER_MASK) == ha) { ni_arr[i] = ni_arr[i] | bit; found = true; }
+        if (!found) na_arr[nu++] = x;                           // (nu <= a: in place)
+    }
+    // sa_k_merge_by_rank: both ascending, headers disjoint
+    if (ni + nu > CAP) return false;
+    u32 i = 0, a = 0, n = 0;
+    while (i < ni || a < nu) {
+        const bool take_inner = a >= nu || (i < ni && ni_arr[i] < na_arr[a]);
+        out[n++] = take_inner ? ni_arr[i] : na_arr[a];
+        i += take_inner ? 1u : 0u;
+        a += take_inner ? 0u : 1u;
+    }
+    *nout = n;
+    *count_out = count;
+    return true;
+}
+
+template <int CAP>
+__global__ void __launch_bounds__(SA_PD_THREADS) sa_k_phrase_docs(const PhraseDocParams p) {
+    __shared__ u64 s_arr[4 * CAP * SA_PD_THREADS];
+    __shared__ u32 s_flags[2 + 2 * SA_PD_MAXT];
+    if (threadIdx.x < 2 + 2 * SA_PD_MAXT) s_flags[threadIdx.x] = 0;
+    __syncthreads();
+    const PdArr A{s_arr + threadIdx.x}, B{s_arr + CAP * SA_PD_THREADS + threadIdx.x},
+                NI{s_arr + 2 * CAP * SA_PD_THREADS + threadIdx.x}, NA{s_arr + 3 * CAP * SA_PD_THREADS + threadIdx.x};
+    const u64 doc = (u64)blockIdx.x * SA_PD_THREADS + threadIdx.x;
+    if (doc < p.n_docs) {
+        bool present = true;
+        for (int t = 0; t < p.T; t++) present = present && p.dd[t][doc] != SA_DD_ABSENT;
+        float result = 0.f;                                     // (a term without a word here: that step counts 0, and so does the minimum)
+        bool fits = true;
+        if (present) {
+            u32 best = 0xFFFFFFFFu;
+            int step = 0;
+            // chain over positions [a, b): left to right (the continuation replaces the left operand) or right to left
+            auto chain = [&](const int a, const int b, const bool l2r) {
+                u32 nl = 0, nr = 0;
+                if (l2r) fits = fits && sa_pd_load<CAP>(p, a, doc, A, &nl);
+                else fits = fits && sa_pd_load<CAP>(p, b - 1, doc, B, &nr);
+                for (int k = 1; k < b - a && fits; k++) {
+                    if (l2r) fits = sa_pd_load<CAP>(p, a + k, doc, B, &nr);
+                    else fits = sa_pd_load<CAP>(p, b - 1 - k, doc, A, &nl);
+                    if (!fits) break;
+                    const bool same = (p.same_mask >> step) & 1u;
+                    bool any_pair = false, any_diff = false;
+                    u32 nout = 0, cnt = 0;
+                    // the continuation goes where the operand it replaces was (sa_pd_step reads both operands before it writes)
+                    fits = sa_pd_step<CAP>(A, nl, B, nr, l2r ? CONT_RHS : CONT_LHS, same, NI, NA, l2r ? A : B, &nout, &cnt, &any_pair, &any_diff);
+                    if (!fits) break;
+                    if (l2r) nl = nout; else nr = nout;
+                    best = cnt < best ? cnt : best;
+                    if (any_pair) s_flags[1 + 2 * step] = 1u;
+                    if (any_diff) s_flags[2 + 2 * step] = 1u;
+                    step++;
+                }
+            };
+            if (p.plan == 0) chain(0, p.T, true);
+            else if (p.plan == 1) chain(0, p.T, false);
+            else { chain(0, p.shortest, true); chain(p.shortest, p.T, false); }
+            result = best == 0xFFFFFFFFu ? 0.f : (float)best;
+        }
+        if (!fits) s_flags[0] = 1u;
+        p.counts[doc] = result;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 + 2 * SA_PD_MAXT && s_flags[threadIdx.x]) p.flags[threadIdx.x] = 1u;
+}
+
+// the checks' flags to a page-locked host array (a store from the device instead of a copy engine round trip); the device
+// copy is left cleared for the next use
+__global__ void __launch_bounds__(64) sa_k_flags_out(u32* __restrict__ d_flags, u32* __restrict__ h_flags, u32 n) {
+    if (threadIdx.x < n) { h_flags[threadIdx.x] = d_flags[threadIdx.x]; d_flags[threadIdx.x] = 0u; }
+}
+
 // tf (phrase counts) -> BM25 in place; reference bm25.pyx:11-25 over the dense phrase_freqs
 __global__ void __launch_bounds__(256)
 sa_k_bm25_from_tf(float* __restrict__ tf, const float* __restrict__ dl, float avgdl, float idf, float k1, float b, u64 n) {
@@ -356,9 +542,10 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
     u64* pp[2] = {ar.take<u64>(2 * M), ar.take<u64>(2 * M)};
     if (!pp[1] || !s.ua || !running2) { sa_set_error("internal: phrase arena exhausted"); return SA_ERR_STATE; }
     *d_running_out = running;
-    SA_HIP(hipMemsetAsync(running, 0, N * sizeof(float), st));
-    SA_HIP(hipMemsetAsync(step, 0, N * sizeof(u32), st));
-    if (!known || N == 0) return SA_OK;                         // TermMissingError -> zeros (postings.py:705-708)
+    if (!known || N == 0) {                                     // TermMissingError -> zeros (postings.py:705-708)
+        SA_HIP(hipMemsetAsync(running, 0, N * sizeof(float), st));
+        return SA_OK;
+    }
     if (filt.active) {
         std::vector<u64*> bufs_v((size_t)T);
         u64** const bufs = bufs_v.data();
@@ -388,6 +575,58 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
             dd_rows[t] = sl != SA_DD_NONE ? ix->d_docdir + (size_t)sl * ix->n_docs : nullptr;
         }
     }
+    // phrases with repeated terms, every term with a directory row and no word in a last block: the chain per document
+    // (sa_k_phrase_docs) -- unless its checks say that the prediction of the same-term test failed or a document did not fit
+    {
+        const char* v = getenv("SA_PHRASE_DOCS");
+        bool take = mode == 0 && !distinct && !(v && atoi(v) == 0) && !filt.active && T >= 2 && T <= SA_PD_MAXT && N < 0xFFFFFFF0ull;
+        for (int t = 0; t < T && take; t++) {
+            const u32 sl = ix->h_dd_slot.empty() ? SA_DD_NONE : ix->h_dd_slot[terms[t]];
+            take = dd_rows[t] != nullptr && sl != SA_DD_NONE && sl < ix->h_dd_top.size() && ix->h_dd_top[sl] == 0 && lens[t] > 0;
+        }
+        if (take) {
+            PhraseDocParams pd;
+            memset(&pd, 0, sizeof(pd));
+            for (int t = 0; t < T; t++) { pd.words[t] = ptrs[t]; pd.dd[t] = dd_rows[t]; pd.len[t] = lens[t]; }
+            pd.T = T; pd.n_docs = N; pd.counts = running;
+            pd.plan = l2r_only ? 0 : (r2l_only ? 1 : 2);
+            pd.shortest = shortest;
+            // the chain's first step over twice the same term is the one whose matched pairs are all equal
+            int n_steps = T - 1;
+            if (pd.plan == 0) pd.same_mask = terms[0] == terms[1] ? 1u : 0u;
+            else if (pd.plan == 1) pd.same_mask = terms[T - 2] == terms[T - 1] ? 1u : 0u;
+            else {
+                n_steps = T - 2;                                   // (shortest - 1) + (T - shortest - 1)
+                pd.same_mask = (terms[0] == terms[1] ? 1u : 0u) | (terms[T - 2] == terms[T - 1] ? 1u << (shortest - 1) : 0u);
+            }
+            if (!ix->h_flags) SA_HIP(hipHostMalloc((void**)&ix->h_flags, 64 * sizeof(u32), 0));
+            if (!ix->d_flags) {
+                SA_HIP(hipMalloc(&ix->d_flags, 64 * sizeof(u32)));
+                SA_HIP(hipMemsetAsync(ix->d_flags, 0, 64 * sizeof(u32), st));
+            }
+            u32* const flags = ix->d_flags;                        // (zeros: every use ends with sa_k_flags_out, and the call waits for it)
+            pd.flags = flags;
+            u32* const h_flags = ix->h_flags;
+            const dim3 grid((u32)((N + SA_PD_THREADS - 1) / SA_PD_THREADS));
+            bool ok = false;
+            // four words per list first (twenty waves per CU); eight if a document does not fit
+            for (int attempt = 0; attempt < 2 && !ok; attempt++) {
+                if (attempt == 0) hipLaunchKernelGGL(sa_k_phrase_docs<4>, grid, dim3(SA_PD_THREADS), 0, st, pd);
+                else hipLaunchKernelGGL(sa_k_phrase_docs<8>, grid, dim3(SA_PD_THREADS), 0, st, pd);
+                hipLaunchKernelGGL(sa_k_flags_out, dim3(1), dim3(64), 0, st, flags, h_flags, (u32)(2 + 2 * SA_PD_MAXT));
+                SA_HIP(hipStreamSynchronize(st));
+                if (h_flags[0] != 0) continue;                    // a document did not fit (its steps' records are incomplete)
+                ok = true;
+                for (int k = 0; k < n_steps && ok; k++)
+                    if (!((pd.same_mask >> k) & 1u) && h_flags[1 + 2 * k] != 0 && h_flags[2 + 2 * k] == 0) ok = false;
+                break;                                            // (a failed same-term prediction: no capacity helps)
+            }
+            if (getenv("SA_PHRASE_TRACE")) fprintf(stderr, "phrase route: chain per document %s\n", ok ? "taken" : "abandoned (general chain)");
+            if (ok) return SA_OK;
+        }
+    }
+    SA_HIP(hipMemsetAsync(running, 0, N * sizeof(float), st));     // (the routes below accumulate)
+    SA_HIP(hipMemsetAsync(step, 0, N * sizeof(u32), st));
     // (a sub-phrase the fused kernel would have to take whole must fit its 18-position window: longer ones go
     //  through the general chain, which has no such limit)
     const int longest_part = (l2r_only || r2l_only) ? T : (shortest > T - shortest ? shortest : T - shortest);

@@ -119,6 +119,73 @@ def test_fused_equals_general_on_random_distinct_phrases(api):
     os.environ.pop("SA_PHRASE_MODE", None)
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_repeated_term_phrases_chain_per_document(api, seed, monkeypatch, capfd):
+    """Phrases with repeated terms over frequent terms run the bigram chain PER DOCUMENT in one launch (sa_k_phrase_docs:
+    the general chain's steps on the document's few words, gathered through the doc directory) instead of ~20 launches per
+    bigram: counts equal to the oracle's (which is pinned to the reference, same-term rule and all) and to the general
+    chain's, for every plan (left to right, right to left, middle out) and repeat pattern."""
+    monkeypatch.setenv("SA_PHRASE_TRACE", "1")
+    rng = np.random.default_rng(40 + seed)
+    n_docs, vocab = int(rng.integers(400, 2500)), 5
+    t, d, p, lens = synth.corpus_triples(n_docs, vocab, int(rng.integers(6, 40)), seed=70 + seed)
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
+    phrases = [[0, 0], [1, 1], [0, 0, 1], [1, 0, 0], [0, 1, 0], [0, 0, 0], [0, 0, 0, 0], [2, 1, 1, 0], [0, 1, 1, 0, 2], [3, 3, 0, 1, 1],
+               [4, 0, 0, 4], [1, 2, 3, 0, 0, 4, 1], [0, 1, 2, 3, 4, 0, 1, 2]]
+    phrases += [[int(x) for x in rng.integers(0, vocab, int(rng.integers(2, 9)))] for _ in range(8)]
+    taken = 0
+    for ph in phrases:
+        if len(set(ph)) == len(ph):
+            continue
+        want = orc.phrase_freqs(ph)
+        capfd.readouterr()
+        got = dev.phrase_freqs_dense(ph)
+        taken += "chain per document taken" in capfd.readouterr().err
+        assert np.array_equal(got, want), f"seed {seed} phrase {ph}: {np.flatnonzero(got != want)[:5]}"
+        monkeypatch.setenv("SA_PHRASE_DOCS", "0")
+        other = dev.phrase_freqs_dense(ph)
+        monkeypatch.delenv("SA_PHRASE_DOCS")
+        assert np.array_equal(other, want), f"general chain: seed {seed} phrase {ph}"
+    dev.close()
+    assert taken >= 10, taken
+
+
+def test_chain_per_document_gives_way_when_its_checks_fail(api, monkeypatch, capfd):
+    """The per-document chain predicts the reference's same-term test (`np.all(lhs_int == rhs_int)`, global over a step's
+    matched pairs) and holds six words per list; it must step aside -- and the general chain give the reference's
+    answer -- (a) when a step it calls "different" has matched pairs that are ALL equal: `a b b` over documents in which
+    every `b` follows an `a` (the continuation of `a b` then equals b's words), (b) when a document has more than six
+    words of a term."""
+    monkeypatch.setenv("SA_PHRASE_TRACE", "1")
+    # (a) 200 documents "a b a b ... " (+ a few with other terms so that every term is frequent)
+    docs = ["a b " * int(1 + i % 7) for i in range(200)]
+    vocab_o, dev = _device_from_strings(docs, api)
+    vocab2, orc = _index_strings(docs)
+    assert vocab2 == vocab_o
+    for ph in (["a", "b", "b"], ["a", "a", "b"], ["b", "a", "b", "b"]):
+        ids = [vocab_o[x] for x in ph]
+        capfd.readouterr()
+        got = dev.phrase_freqs_dense(ids)
+        err = capfd.readouterr().err
+        assert np.array_equal(got, orc.phrase_freqs(ids)), ph
+        if ph == ["a", "b", "b"]:
+            assert "abandoned" in err, err
+    dev.close()
+    # (b) long documents: many words per term
+    t, d, p, lens = synth.corpus_triples(60, 3, 500, seed=9)
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, 3), lens, tile_docs=1024, api=api)
+    orc = O.OracleIndex.from_triples(t, d, p, 60, doc_lens=lens)
+    for ph in ([0, 0], [1, 0, 0], [2, 2, 1, 2]):
+        capfd.readouterr()
+        got = dev.phrase_freqs_dense(ph)
+        assert "abandoned" in capfd.readouterr().err
+        assert np.array_equal(got, orc.phrase_freqs(ph)), ph
+    dev.close()
+
+
 def test_phrase_errors_and_unknown_terms(api):
     vocab, dev = _device_from_strings(["foo bar", "bar foo"], api)
     with pytest.raises(ValueError):
