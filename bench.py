@@ -402,6 +402,48 @@ class PhraseSide:
         return {"counts_bit_exact": ok_counts, "top10_matches": ok_top, "phrases_vs_reference": n_ref,
                 "phrases_vs_oracle_port": n_orc, "of": len(phrases)}
 
+    def single_queries(self, cpu_s):
+        """One phrase per call (the reference's own unit: PosnBitArray.phrase_freqs): device ms (HIP events) of the heaviest
+        two-term slop-2 query and of a phrase with a repeated term, each through its one-launch route and through the
+        general route; counts of the slop query bit-exact against the C oracle when the CPU budget allows it."""
+        from oracle import refimpl as O
+        out = {}
+
+        def best_ms(ph, slop, env):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                ms = []
+                for _ in range(4):
+                    r = self.index.phrase_freqs_dense(ph, slop=slop)
+                    ms.append(self.index.last_profile()[0])
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            return round(min(ms[1:]), 4), r
+
+        ms, got = best_ms([0, 1], 2, {})
+        ms_g, got_g = best_ms([0, 1], 2, {"SA_SPAN_DOC": "0"})
+        row = {"phrase": "t0 t1", "slop": 2, "device_ms": ms, "general_route_device_ms": ms_g, "matches": int(got.sum()),
+               "routes_agree": bool(np.array_equal(got, got_g)),
+               "algorithmic_bytes": self.word_bytes([[0, 1]]) + 4 * self.docs}
+        row["algorithmic_GBps"] = round(row["algorithmic_bytes"] / ms / 1e6, 1)
+        if cpu_s >= 5:
+            orc = O.OracleIndex(self.words, np.arange(self.vocab), self.term_off, self.doc_lens, self.docs)
+            t0 = time.perf_counter()
+            want = orc.phrase_freqs([0, 1], slop=2)
+            row["cpu_oracle_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+            row["counts_bit_exact"] = bool(np.array_equal(got, want))
+        out["slop_heaviest_two_terms"] = row
+        ms, got = best_ms([0, 0, 1], 0, {})
+        ms_g, got_g = best_ms([0, 0, 1], 0, {"SA_PHRASE_DOCS": "0"})
+        out["phrase_repeated_term"] = {"phrase": "t0 t0 t1", "device_ms": ms, "general_chain_device_ms": ms_g, "matches": int(got.sum()),
+                                       "routes_agree": bool(np.array_equal(got, got_g))}
+        return out
+
     def close(self):
         self.pb.close()
         self.sb.close()
@@ -938,6 +980,7 @@ def main():
         cpu_s = 0.0 if args.no_cpu_baseline else 8.0
         phrase_out["phrase_batch"] = phrase_leg_block(side, "phrase_batch", side.trigrams, 0, side.pb, pmc, K2, cpu_s)
         phrase_out["slop_batch"] = phrase_leg_block(side, "slop_batch", side.slop2, 2, side.sb, pmc, K2, cpu_s)
+        phrase_out["single_phrase_queries"] = side.single_queries(cpu_s)
 
     if rank == 0:
         n_tiles = int(r.info.n_tiles)
