@@ -1019,18 +1019,23 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_wave(const SpanMachinePa
 // other).  A block of 256 threads takes 512 neighbouring documents:
 //   gather  one document per thread and round (lane = doc: the directory rows and the documents' words are read in
 //           doc order): candidate words, their positions -> the document's bin (0 none, npos up to 32, else heavy) and,
-//           for up to 8 positions, the position list -- term << 24 | position in the machine's order -- in LDS;
+//           for up to 8 positions, the position list -- term << 10 | position - 18 x the document's first block, 16
+//           bits, in the machine's order -- in LDS;
 //   order   the block's documents by bin, most positions first (counting sort in LDS);
-//   machine each wave takes chunks of that order, one document per lane, sa_span_flat_loop8 on the lists where they
-//           lie: what the general route's global counting sort + scattered gathers produce (waves of equal work,
-//           busiest first) without leaving the CU.  Chunks of 16 documents while they have more than 16 positions, of
-//           32 above 8, else 64: a lane of a 16- / 32-lane chunk gets three times / one and a half times the table rows
-//           in the wave's 8 KiB, and its positions (read again from the lists) a place behind them -- so that a
-//           document with many positions, whose table would outgrow a 64-lane column, still runs as a lane;
-//   heavy   documents beyond that, and lanes whose table outgrew its column even so: a wave each (sa_span_wave_doc:
-//           the words through the directory, candidate test per lane, the 512-span table in the wave's 8 KiB).
-// Blocks in different phases share a CU (three fit), so the gather's memory latency hides behind other blocks'
-// machines.  Span entries are 8 bytes here (position bits 32, first position 23, last - first 5, terms 4): T + slop <= 15.
+//   machine each wave takes the next chunk of that order when it is done with its last (an LDS counter: the first
+//           chunks are the long ones), one document per lane, the lane machine (sa_span_flat_loop8a) on the lists
+//           where they lie: what the general route's global counting sort + scattered gathers produce (waves of equal
+//           work, busiest first) without leaving the CU.  Chunks of 8 documents while they have more than 16 positions,
+//           of 16 above 8, else 64 (two terms; 32 for three and four): a lane of an 8- / 16- / 32-lane chunk gets 80 /
+//           40 / 20 table rows instead of 12 in the wave's 6 KiB, and its positions (unpacked, or read again from the
+//           lists) a place behind them -- so that a document with many positions, whose table would outgrow a 64-lane
+//           column, still runs as a lane;
+//   heavy   documents beyond that, and lanes whose table outgrew its column even so: a wave each, once the block's lane
+//           work is done and its tables are free (sa_span_wave_doc: the words through the directory, candidate test
+//           per lane, the 512-span table of 16-byte entries in 8 KiB of them).
+// Blocks in different phases share a CU (four fit: 38 KB of LDS each), so the gather's memory latency hides behind
+// other blocks' machines.  Span entries are 8 bytes here (position bits 32, first position 23, last - first 5, terms
+// 4): T + slop <= 15.
 #define SA_SPAN_DW 4                     // words of one term per document the gather holds in registers
 #define SA_SPAN_DB 64                    // bins: [npos] for 1 <= npos <= 32, [33] heavy
 #define SA_SPAN_FT 256                   // threads of a block
