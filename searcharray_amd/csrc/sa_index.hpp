@@ -174,7 +174,9 @@ int sa_phrase_dense_counts_device(sa_index* ix, const u32* terms, int n_terms, i
 void sa_launch_bm25_from_tf(sa_index* ix, float* d_tf, float idf, float k1, float b);
 int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const PosnFilter& filt, float** d_out);
 // one phrase of the dense route to rank: dense counts (float[n_docs]), the phrase's idf, its row in the batch
-struct sa_dense_rank_job { const float* counts; float idf; u32 row; };
+// (touched[tile]: the vector has a count in that ranking tile -- set by the span machines, cleared by the ranking launch,
+//  which leaves the other tiles' 8 KB unread)
+struct sa_dense_rank_job { const float* counts; unsigned char* touched; float idf; u32 row; };
 int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* terms, const int* T, const int* slop,
                          const float* idf, const u32* rows, float** d_out, unsigned char* handled,
-                         const sa_dense_rank_job** d_rank_jobs, int* n_rank_jobs);
+                         const sa_dense_rank_job** d_rank_jobs, int* n_rank_jobs, u32 rank_tile_shift);

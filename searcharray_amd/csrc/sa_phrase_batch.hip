@@ -219,6 +219,9 @@ sa_k_dense_topk_tiles_multi(const sa_dense_rank_job* __restrict__ jobs, const fl
     __shared__ float acc[TILE];
     const sa_dense_rank_job J = jobs[blockIdx.y];
     const u32 tid = threadIdx.x, tile = blockIdx.x, q = J.row;
+    if (J.touched[tile] == 0) return;                          // no count in this tile: nothing to rank, nothing to put back
+    __syncthreads();
+    if (tid == 0) J.touched[tile] = 0;
     const u64 tile_base = (u64)tile * TILE;
     const float one_minus_b = 1.0f - b;
     u32 slot_val = 0xFFFFFFFFu;
@@ -314,7 +317,7 @@ int sa_launch_phrase_tiles(sa_batch* bt, hipStream_t st) {
             const sa_dense_rank_job* d_rj = nullptr;
             int n_rj = 0;
             SA_TRY(sa_span_counts_batch(ix, st, (int)rows.size(), tp.data(), tn.data(), ts.data(), idfs.data(), rows.data(), outs.data(),
-                                        handled.data(), &d_rj, &n_rj));
+                                        handled.data(), &d_rj, &n_rj, bt->ptile == 2048 ? 11u : 12u));
             for (size_t i = 0; i < rows.size(); i++) if (handled[i]) taken[rows[i]] = 1;
             if (n_rj > 0) {
                 if (bt->ptile == 2048)

@@ -444,12 +444,15 @@ struct SpanMachineParams {
     const u32* in_list;                       // heavy pass: the groups the fast pass abandoned
     const u32* in_cnt;
     const u32* order;                         // fast pass: the document groups sorted by work (sa_k_span_bin_*), or null
+    unsigned char* touched;                   // batched route: [key >> touch_shift] = 1 wherever a count is added (the ranking
+    u32 touch_shift;                          //   launch reads the touched tiles only), or null
 };
 
 __device__ __forceinline__ void sa_span_add(const SpanMachineParams& p, u64 key, u32 incr) {
     if (incr == 0 || key >= p.n_docs) return;
     if (p.fcounts) unsafeAtomicAdd(&p.fcounts[key], (float)incr);
     else atomicAdd(&p.counts[key], incr);
+    if (p.touched) p.touched[key >> p.touch_shift] = 1;
 }
 
 // reference spans.pyx:108-109 as compiled: `1 << (p % 64)` is a 32-bit shift (count mod 32) whose
@@ -1936,7 +1939,7 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
 // Everything is enqueued on `st`; the caller holds the index lock.
 int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* terms, const int* T, const int* slop,
                          const float* idf, const u32* rows, float** d_out, unsigned char* handled,
-                         const sa_dense_rank_job** d_rank_jobs, int* n_rank_jobs) {
+                         const sa_dense_rank_job** d_rank_jobs, int* n_rank_jobs, u32 rank_tile_shift) {
     for (int i = 0; i < n; i++) { handled[i] = 0; d_out[i] = nullptr; }
     *d_rank_jobs = nullptr; *n_rank_jobs = 0;
     const u64 N = ix->n_docs;
@@ -2036,7 +2039,9 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
     // The dense count vectors come from a pool of their own that is all zeros between runs: the launch that ranks a
     // vector puts back a zero wherever it read a count (sa_k_dense_topk_tiles_multi), so no run clears B x n_docs
     // floats.  A run that did not get as far as its ranking launch leaves the pool marked dirty: cleared here.
-    const size_t cstride = (size_t)((N + 64) & ~(u64)63);
+    // (behind each vector: a byte per ranking tile, "has a count" -- same life cycle)
+    const size_t cvec = (size_t)((N + 64) & ~(u64)63);
+    const size_t cstride = cvec + ((((size_t)(N >> rank_tile_shift) + 1 + 3) / 4 + 63) & ~(size_t)63);
     if (ix->span_counts_cap < (size_t)nj * cstride) {
         SA_HIP(hipStreamSynchronize(st));
         if (ix->d_span_counts) SA_HIP(hipFree(ix->d_span_counts));
@@ -2072,10 +2077,12 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
             J.mp.cand[t] = cand; J.mp.n_cand[t] = J.cnt + t; J.mp.heads[t] = heads; J.mp.n_heads[t] = J.cnt + SA_SPAN_MAX_TERMS + t;
         }
         J.mp.fcounts = running;
+        J.mp.touched = (unsigned char*)(running + cvec); J.mp.touch_shift = rank_tile_shift;
         J.mp.over_list = over_list; J.mp.over_cnt = J.cnt + 4 * SA_SPAN_MAX_TERMS;
         J.mp.in_list = over_list; J.mp.in_cnt = J.cnt + 4 * SA_SPAN_MAX_TERMS;
         hj[q] = J;
-        hr[q].counts = running; hr[q].idf = idf[job_row[(size_t)j]]; hr[q].row = rows[job_row[(size_t)j]];
+        hr[q].counts = running; hr[q].touched = (unsigned char*)(running + cvec);
+        hr[q].idf = idf[job_row[(size_t)j]]; hr[q].row = rows[job_row[(size_t)j]];
         d_out[job_row[(size_t)j]] = running;
         handled[job_row[(size_t)j]] = 1;
         class_first[job_class[(size_t)j] + 1] = q + 1;
