@@ -60,7 +60,7 @@ def main():
     # phrases with repeated terms: the chain per document (one launch) vs the general chain (SA_PHRASE_DOCS=0), device ms
     rep = {}
     rep_ok = True
-    for ph in ([0, 0, 1], [0, 0], [1, 2, 2], [3, 0, 0, 5], [0, 1, 0, 1], [7, 7, 9]):
+    for ph in ([0, 0, 1], [0, 0], [1, 2, 2], [3, 0, 0, 5], [0, 1, 0, 1], [7, 7, 9], [300, 300, 2], [5000, 40, 40], [900, 900]):
         row = {}
         for name, env in (("per_document_ms", None), ("general_chain_ms", "0")):
             if env is None:

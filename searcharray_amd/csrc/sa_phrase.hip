@@ -207,18 +207,20 @@ __global__ void __launch_bounds__(256) sa_k_phrase_fused(const FusedPhraseParams
 // the chain per DOCUMENT (phrases with repeated terms, frequent terms)
 // ---------------------------------------------------------------------------------------
 // Every operation of a bigram step -- intersect on the header, the header + 1 adjacency, the continuation words, the
-// adjacency bit absorbed into the inner word of the same header, the merge -- relates words of ONE document, provided no
-// term has a word in a document's last 18-position block (header + 1 would be the next document's block 0; the doc
-// directory records that per term).  So for terms that have a doc directory row the whole chain can run per document:
-// one thread per document gathers the document's words of every term through the directory (a handful) and runs the
-// general chain's steps on them in LDS -- the same formulas as InnerBigram / AdjBigram / sa_k_absorb_adj /
-// sa_k_merge_by_rank above, the per-step counts summed over the document, the running minimum over the steps
-// (_intersect_bigram_matches: absent = 0) -- one launch instead of ~20 per bigram.
-// The one thing that is NOT local is the reference's same-term test, `np.all(lhs_int == rhs_int)` over ALL matched pairs of
-// a step (bigram_freqs.py:140).  It is predicted -- true exactly for a chain's first step over twice the same term -- and
-// checked: every step the prediction calls "different" records whether it had a matched pair and whether one differed;
-// "pairs, none different" (degenerate data) makes the host fall back to the general chain, and so does a document with
-// more words of a term, or of a continuation, than a thread holds.
+// adjacency bit absorbed into the inner word of the same header, the merge -- relates words of ONE document, unless a
+// word sits in a document's last 18-position block (header + 1 is then the next document's block 0).  So the whole chain
+// can run per document: one thread per document of the rarest term (or per document, when that list is about as long as
+// the collection) finds the document's words of every term -- through the term's doc directory row, or by a search on
+// the key -- and runs the general chain's steps on them in LDS: the same formulas as InnerBigram / AdjBigram /
+// sa_k_absorb_adj / sa_k_merge_by_rank above, the per-step counts summed over the document, the running minimum over
+// the steps (_intersect_bigram_matches: absent = 0) -- one launch instead of ~20 per bigram.
+// Two things are checked, and the general chain takes the phrase if a check fails:
+//   * the reference's same-term test, `np.all(lhs_int == rhs_int)` over ALL matched pairs of a step (bigram_freqs.py:140),
+//     is not local.  It is predicted -- true exactly for a chain's first step over twice the same term -- and every step
+//     the prediction calls "different" records whether it had a matched pair and whether one differed: "pairs, none
+//     different" (degenerate data) is a failed prediction;
+//   * a document with more words of a term, or of a continuation, than a thread holds (four, then eight), or with a word
+//     in a last block.
 #define SA_PD_MAXT 8                     // terms of a phrase this route takes
 #define SA_PD_THREADS 128
 
@@ -230,6 +232,8 @@ struct PhraseDocParams {
     int plan;                            // 0: left to right, 1: right to left, 2: middle out at `shortest`
     int shortest;
     u32 same_mask;                       // bit s: step s (in execution order) is predicted "same term"
+    int anchor;                          // phrase position of the rarest term: its documents are the ones looked at; -1: every
+                                         //   document (a thread per doc: cheaper when the rarest list is about as long as that)
     u64 n_docs;
     float* counts;
     u32* flags;                          // [0] a document did not fit; [1 + 2 s] step s had a matched pair, [2 + 2 s] a pair that differed
@@ -241,12 +245,21 @@ struct PdArr {
     __device__ __forceinline__ u64& operator[](u32 i) const { return a[i * SA_PD_THREADS]; }
 };
 
-// the document's words of the term at phrase position t -> dst; false: more than CAP words.  (All requested at once: one
+// index of the document's first word in the list at phrase position t (through the directory row if the term has one,
+// else a search on the 28-bit key), or SA_DD_ABSENT
+__device__ __forceinline__ u32 sa_pd_first(const PhraseDocParams& p, const int t, const u64 doc) {
+    if (p.dd[t]) return p.dd[t][doc];
+    const u32 j = sa_lower_bound(p.words[t], 0, p.len[t], doc << SA_KEY_SHIFT, SA_KEY_MASK);
+    return (j < p.len[t] && (p.words[t][j] >> SA_KEY_SHIFT) == doc) ? j : SA_DD_ABSENT;
+}
+
+// the document's words of the term at phrase position t -> dst; false: more than CAP words, or a word in the document's
+// last 18-position block (its header + 1 is the next document's block 0: the chain is not local to the document then).  (All requested at once: one
 // after the other, each waiting for the last to see whether the document goes on, they are a chain of round trips.)
 template <int CAP>
 __device__ __forceinline__ bool sa_pd_load(const PhraseDocParams& p, const int t, const u64 doc, const PdArr& dst, u32* n_out) {
     u32 n = 0;
-    const u32 j0 = p.dd[t][doc];
+    const u32 j0 = sa_pd_first(p, t, doc);
     if (j0 != SA_DD_ABSENT) {
         const u64* const w = p.words[t];
         const u32 len = p.len[t];
@@ -258,6 +271,7 @@ __device__ __forceinline__ bool sa_pd_load(const PhraseDocParams& p, const int t
         for (int q = 0; q <= CAP; q++) {
             run = run && (x[q] >> SA_KEY_SHIFT) == doc;
             if (run && q < CAP) dst[(u32)q] = x[q];
+            if (run && ((x[q] >> SA_LSB_BITS) & SA_LSB_MASK) == SA_LSB_MASK) return false;
             n += run ? 1u : 0u;
         }
         if (n > CAP) return false;
@@ -340,10 +354,22 @@ __global__ void __launch_bounds__(SA_PD_THREADS) sa_k_phrase_docs(const PhraseDo
     __syncthreads();
     const PdArr A{s_arr + threadIdx.x}, B{s_arr + CAP * SA_PD_THREADS + threadIdx.x},
                 NI{s_arr + 2 * CAP * SA_PD_THREADS + threadIdx.x}, NA{s_arr + 3 * CAP * SA_PD_THREADS + threadIdx.x};
-    const u64 doc = (u64)blockIdx.x * SA_PD_THREADS + threadIdx.x;
-    if (doc < p.n_docs) {
+    // one thread per document of the rarest term -- per word of its list that opens a document -- or per document
+    const u64 i = (u64)blockIdx.x * SA_PD_THREADS + threadIdx.x;
+    bool opener = false;
+    u64 doc = 0;
+    if (p.anchor < 0) {
+        doc = i;
+        opener = doc < p.n_docs;
+    } else if (i < p.len[p.anchor]) {
+        const u64* const aw = p.words[p.anchor];
+        doc = aw[i] >> SA_KEY_SHIFT;
+        opener = (i == 0 || (aw[i - 1] >> SA_KEY_SHIFT) != doc) && doc < p.n_docs;
+    }
+    if (opener) {
         bool present = true;
-        for (int t = 0; t < p.T; t++) present = present && p.dd[t][doc] != SA_DD_ABSENT;
+        for (int t = 0; t < p.T && present; t++) present = t == p.anchor || sa_pd_first(p, t, doc) != SA_DD_ABSENT;
+        // (a term repeated in the phrase is looked up once per position: the second lookup hits the same lines)
         float result = 0.f;                                     // (a term without a word here: that step counts 0, and so does the minimum)
         bool fits = true;
         if (present) {
@@ -377,7 +403,7 @@ __global__ void __launch_bounds__(SA_PD_THREADS) sa_k_phrase_docs(const PhraseDo
             result = best == 0xFFFFFFFFu ? 0.f : (float)best;
         }
         if (!fits) s_flags[0] = 1u;
-        p.counts[doc] = result;
+        if (result != 0.f || p.anchor < 0) p.counts[doc] = result;       // (anchored: the vector is cleared before the launch)
     }
     __syncthreads();
     if (threadIdx.x < 2 + 2 * SA_PD_MAXT && s_flags[threadIdx.x]) p.flags[threadIdx.x] = 1u;
@@ -575,15 +601,12 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
             dd_rows[t] = sl != SA_DD_NONE ? ix->d_docdir + (size_t)sl * ix->n_docs : nullptr;
         }
     }
-    // phrases with repeated terms, every term with a directory row and no word in a last block: the chain per document
-    // (sa_k_phrase_docs) -- unless its checks say that the prediction of the same-term test failed or a document did not fit
+    // phrases with repeated terms: the chain per document (sa_k_phrase_docs) -- unless its checks say that the prediction
+    // of the same-term test failed or a document did not fit
     {
         const char* v = getenv("SA_PHRASE_DOCS");
         bool take = mode == 0 && !distinct && !(v && atoi(v) == 0) && !filt.active && T >= 2 && T <= SA_PD_MAXT && N < 0xFFFFFFF0ull;
-        for (int t = 0; t < T && take; t++) {
-            const u32 sl = ix->h_dd_slot.empty() ? SA_DD_NONE : ix->h_dd_slot[terms[t]];
-            take = dd_rows[t] != nullptr && sl != SA_DD_NONE && sl < ix->h_dd_top.size() && ix->h_dd_top[sl] == 0 && lens[t] > 0;
-        }
+        for (int t = 0; t < T && take; t++) take = lens[t] > 0;
         if (take) {
             PhraseDocParams pd;
             memset(&pd, 0, sizeof(pd));
@@ -591,6 +614,8 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
             pd.T = T; pd.n_docs = N; pd.counts = running;
             pd.plan = l2r_only ? 0 : (r2l_only ? 1 : 2);
             pd.shortest = shortest;
+            // (a rarest list about as long as the collection: a thread per document, nothing to clear)
+            pd.anchor = 2 * (u64)lens[shortest] >= N ? -1 : shortest;
             // the chain's first step over twice the same term is the one whose matched pairs are all equal
             int n_steps = T - 1;
             if (pd.plan == 0) pd.same_mask = terms[0] == terms[1] ? 1u : 0u;
@@ -607,10 +632,11 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
             u32* const flags = ix->d_flags;                        // (zeros: every use ends with sa_k_flags_out, and the call waits for it)
             pd.flags = flags;
             u32* const h_flags = ix->h_flags;
-            const dim3 grid((u32)((N + SA_PD_THREADS - 1) / SA_PD_THREADS));
+            const dim3 grid((u32)(((pd.anchor < 0 ? N : (u64)lens[shortest]) + SA_PD_THREADS - 1) / SA_PD_THREADS));
             bool ok = false;
             // four words per list first (twenty waves per CU); eight if a document does not fit
             for (int attempt = 0; attempt < 2 && !ok; attempt++) {
+                if (pd.anchor >= 0) SA_HIP(hipMemsetAsync(running, 0, N * sizeof(float), st));
                 if (attempt == 0) hipLaunchKernelGGL(sa_k_phrase_docs<4>, grid, dim3(SA_PD_THREADS), 0, st, pd);
                 else hipLaunchKernelGGL(sa_k_phrase_docs<8>, grid, dim3(SA_PD_THREADS), 0, st, pd);
                 hipLaunchKernelGGL(sa_k_flags_out, dim3(1), dim3(64), 0, st, flags, h_flags, (u32)(2 + 2 * SA_PD_MAXT));

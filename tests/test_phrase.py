@@ -119,13 +119,15 @@ def test_fused_equals_general_on_random_distinct_phrases(api):
     os.environ.pop("SA_PHRASE_MODE", None)
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", range(4))
 def test_repeated_term_phrases_chain_per_document(api, seed, monkeypatch, capfd):
-    """Phrases with repeated terms over frequent terms run the bigram chain PER DOCUMENT in one launch (sa_k_phrase_docs:
-    the general chain's steps on the document's few words, gathered through the doc directory) instead of ~20 launches per
-    bigram: counts equal to the oracle's (which is pinned to the reference, same-term rule and all) and to the general
+    """Phrases with repeated terms run the bigram chain PER DOCUMENT in one launch (sa_k_phrase_docs: a thread per document
+    of the rarest term, the general chain's steps on the document's few words, found through the doc directory or by
+    search) instead of ~20 launches per bigram: counts equal to the oracle's (which is pinned to the reference, same-term rule and all) and to the general
     chain's, for every plan (left to right, right to left, middle out) and repeat pattern."""
     monkeypatch.setenv("SA_PHRASE_TRACE", "1")
+    if seed == 3:
+        monkeypatch.setenv("SA_DOCDIR_DIV", "0")         # no doc directory: the documents' words are found by search
     rng = np.random.default_rng(40 + seed)
     n_docs, vocab = int(rng.integers(400, 2500)), 5
     t, d, p, lens = synth.corpus_triples(n_docs, vocab, int(rng.integers(6, 40)), seed=70 + seed)
