@@ -120,8 +120,8 @@ struct sa_index {
     float* d_span_counts = nullptr;  // pool of dense count vectors of that route, all zeros between runs (the ranking launch cleans up)
     size_t span_counts_cap = 0;      // floats
     bool span_counts_dirty = false;
-    u32* h_flags = nullptr;          // 64 page-locked words: small device results the host decides on (sa_phrase.hip)
-    u32* d_flags = nullptr;          // their device side: 64 words, all zeros between uses (sa_k_flags_out clears them)
+    u32* h_flags = nullptr;          // 128 page-locked words: small device results the host decides on (sa_phrase.hip)
+    u32* d_flags = nullptr;          // their device side: 128 words, all zeros between uses (sa_k_flags_out clears them)
 
     // row selection scratch (sa_index_select_rows): device copy of the selected doc ids + gathered values
     void* d_rows_scratch = nullptr;

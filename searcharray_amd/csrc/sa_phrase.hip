@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(256) sa_k_phrase_fused(const FusedPhraseParams
 //     different" (degenerate data) is a failed prediction;
 //   * a document with more words of a term, or of a continuation, than a thread holds (four, then eight), or with a word
 //     in a last block.
-#define SA_PD_MAXT 8                     // terms of a phrase this route takes
+#define SA_PD_MAXT 32                    // terms of a phrase this route takes
 #define SA_PD_THREADS 128
 
 struct PhraseDocParams {
@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(SA_PD_THREADS) sa_k_phrase_docs(const PhraseDo
 
 // the checks' flags to a page-locked host array (a store from the device instead of a copy engine round trip); the device
 // copy is left cleared for the next use
-__global__ void __launch_bounds__(64) sa_k_flags_out(u32* __restrict__ d_flags, u32* __restrict__ h_flags, u32 n) {
+__global__ void __launch_bounds__(128) sa_k_flags_out(u32* __restrict__ d_flags, u32* __restrict__ h_flags, u32 n) {
     if (threadIdx.x < n) { h_flags[threadIdx.x] = d_flags[threadIdx.x]; d_flags[threadIdx.x] = 0u; }
 }
 
@@ -605,7 +605,10 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
     // of the same-term test failed or a document did not fit
     {
         const char* v = getenv("SA_PHRASE_DOCS");
-        bool take = mode == 0 && !distinct && !(v && atoi(v) == 0) && !filt.active && T >= 2 && T <= SA_PD_MAXT && N < 0xFFFFFFF0ull;
+        // (pairwise-distinct terms: only where the fused kernel cannot take the phrase -- a sub-phrase of more than 18 terms)
+        const int part = (l2r_only || r2l_only) ? T : (shortest > T - shortest ? shortest : T - shortest);
+        const bool fused_can = distinct && part <= SA_MAX_FUSED;
+        bool take = mode == 0 && !fused_can && !(v && atoi(v) == 0) && !filt.active && T >= 2 && T <= SA_PD_MAXT && N < 0xFFFFFFF0ull;
         for (int t = 0; t < T && take; t++) take = lens[t] > 0;
         if (take) {
             PhraseDocParams pd;
@@ -624,10 +627,10 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
                 n_steps = T - 2;                                   // (shortest - 1) + (T - shortest - 1)
                 pd.same_mask = (terms[0] == terms[1] ? 1u : 0u) | (terms[T - 2] == terms[T - 1] ? 1u << (shortest - 1) : 0u);
             }
-            if (!ix->h_flags) SA_HIP(hipHostMalloc((void**)&ix->h_flags, 64 * sizeof(u32), 0));
+            if (!ix->h_flags) SA_HIP(hipHostMalloc((void**)&ix->h_flags, 128 * sizeof(u32), 0));
             if (!ix->d_flags) {
-                SA_HIP(hipMalloc(&ix->d_flags, 64 * sizeof(u32)));
-                SA_HIP(hipMemsetAsync(ix->d_flags, 0, 64 * sizeof(u32), st));
+                SA_HIP(hipMalloc(&ix->d_flags, 128 * sizeof(u32)));
+                SA_HIP(hipMemsetAsync(ix->d_flags, 0, 128 * sizeof(u32), st));
             }
             u32* const flags = ix->d_flags;                        // (zeros: every use ends with sa_k_flags_out, and the call waits for it)
             pd.flags = flags;
@@ -639,7 +642,7 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
                 if (pd.anchor >= 0) SA_HIP(hipMemsetAsync(running, 0, N * sizeof(float), st));
                 if (attempt == 0) hipLaunchKernelGGL(sa_k_phrase_docs<4>, grid, dim3(SA_PD_THREADS), 0, st, pd);
                 else hipLaunchKernelGGL(sa_k_phrase_docs<8>, grid, dim3(SA_PD_THREADS), 0, st, pd);
-                hipLaunchKernelGGL(sa_k_flags_out, dim3(1), dim3(64), 0, st, flags, h_flags, (u32)(2 + 2 * SA_PD_MAXT));
+                hipLaunchKernelGGL(sa_k_flags_out, dim3(1), dim3(128), 0, st, flags, h_flags, (u32)(2 + 2 * SA_PD_MAXT));
                 SA_HIP(hipStreamSynchronize(st));
                 if (h_flags[0] != 0) continue;                    // a document did not fit (its steps' records are incomplete)
                 ok = true;

@@ -135,7 +135,7 @@ def test_repeated_term_phrases_chain_per_document(api, seed, monkeypatch, capfd)
     dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
     orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
     phrases = [[0, 0], [1, 1], [0, 0, 1], [1, 0, 0], [0, 1, 0], [0, 0, 0], [0, 0, 0, 0], [2, 1, 1, 0], [0, 1, 1, 0, 2], [3, 3, 0, 1, 1],
-               [4, 0, 0, 4], [1, 2, 3, 0, 0, 4, 1], [0, 1, 2, 3, 4, 0, 1, 2]]
+               [4, 0, 0, 4], [1, 2, 3, 0, 0, 4, 1], [0, 1, 2, 3, 4, 0, 1, 2], [0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1], [2, 2, 1, 0, 3, 4, 4, 1, 0, 2, 3, 1, 0, 0, 2, 4]]
     phrases += [[int(x) for x in rng.integers(0, vocab, int(rng.integers(2, 9)))] for _ in range(8)]
     taken = 0
     for ph in phrases:
@@ -152,6 +152,35 @@ def test_repeated_term_phrases_chain_per_document(api, seed, monkeypatch, capfd)
         assert np.array_equal(other, want), f"general chain: seed {seed} phrase {ph}"
     dev.close()
     assert taken >= 10, taken
+
+
+def test_long_distinct_phrases_chain_per_document(api, monkeypatch, capfd):
+    """Pairwise-distinct phrases of 19-32 terms (more than the fused kernel's window) take the chain per document too;
+    every plan: the rarest term at the front, at the end, in the middle."""
+    monkeypatch.setenv("SA_PHRASE_TRACE", "1")
+    rng = np.random.default_rng(8)
+    toks = [f"w{i}" for i in range(34)]
+    docs = []
+    for i in range(300):
+        a, b = sorted(int(x) for x in rng.integers(0, 34, 2))
+        body = toks[a:b + 1] if i % 3 else toks                   # runs of the sequence, whole or partial
+        noise = [toks[int(x)] for x in rng.integers(0, 34, int(rng.integers(0, 6)))]
+        docs.append(" ".join(noise + body + noise))
+    docs += ["w5 " * 3, "w17 w17", "w30"] * 20                     # makes some terms much more frequent than others
+    vocab_o, dev = _device_from_strings(docs, api)
+    vocab2, orc = _index_strings(docs)
+    assert vocab2 == vocab_o
+    taken = 0
+    for a, b in ((0, 19), (3, 27), (0, 31), (10, 31), (2, 33), (14, 33)):
+        ids = [vocab_o[t] for t in toks[a:b + 1]]
+        capfd.readouterr()
+        got = dev.phrase_freqs_dense(ids)
+        taken += "chain per document taken" in capfd.readouterr().err
+        want = orc.phrase_freqs(ids)
+        assert np.array_equal(got, want), (a, b, np.flatnonzero(got != want)[:5])
+        assert want.sum() > 0
+    dev.close()
+    assert taken == 6, taken
 
 
 def test_chain_per_document_gives_way_when_its_checks_fail(api, monkeypatch, capfd):
