@@ -160,6 +160,15 @@ sa_k_term_edges(const u64* __restrict__ words, const u64* __restrict__ term_off,
     }
 }
 
+// does any word sit in a document's last 18-position block?  (*flag |= 1)
+__global__ void __launch_bounds__(256)
+sa_k_any_top_block(const u64* __restrict__ words, u64 n, u32* __restrict__ flag) {
+    bool any = false;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
+        any = any || ((words[i] >> SA_LSB_BITS) & SA_LSB_MASK) == SA_LSB_MASK;
+    if (any) *flag = 1u;
+}
+
 // dense tf row of one term from its fat postings
 __global__ void __launch_bounds__(256)
 sa_k_build_tf8(const u64* __restrict__ tfp, u32 n, unsigned char* __restrict__ row, u32* __restrict__ bits) {
@@ -509,13 +518,21 @@ int sa_index_derive(sa_index* ix) {
         ix->h_term_edge.assign((size_t)V + 1, 0);
         if (V > 0) {
             unsigned char* d_edge = nullptr;
-            SA_HIP(hipMalloc(&d_edge, (size_t)V));
+            SA_HIP(hipMalloc(&d_edge, (size_t)V + 8));                  // (+ a word for sa_k_any_top_block)
+            u32* d_any = (u32*)(d_edge + (((size_t)V + 3) & ~(size_t)3));
+            u32 h_any = 0;
+            SA_HIP(hipMemsetAsync(d_any, 0, sizeof(u32), st));
+            if (ix->n_words > 0)
+                hipLaunchKernelGGL(sa_k_any_top_block, dim3((u32)std::min<u64>(ix->n_words / 1024 + 1, 4096)), dim3(256), 0, st,
+                                   (const u64*)ix->d_words, ix->n_words, d_any);
+            hipError_t e0 = hipMemcpyAsync(&h_any, d_any, sizeof(u32), hipMemcpyDeviceToHost, st);
             hipLaunchKernelGGL(sa_k_term_edges, dim3(V / 256 + 1 < 4096 ? V / 256 + 1 : 4096), dim3(256), 0, st,
                                (const u64*)ix->d_words, (const u64*)ix->d_term_off, V, d_edge);
             hipError_t e1 = hipMemcpyAsync(ix->h_term_edge.data(), d_edge, (size_t)V, hipMemcpyDeviceToHost, st);
             hipError_t e2 = hipStreamSynchronize(st);
             hipFree(d_edge);
-            if (e1 != hipSuccess || e2 != hipSuccess) { sa_set_error("term edge flags failed"); return SA_ERR_HIP; }
+            if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess) { sa_set_error("term edge flags failed"); return SA_ERR_HIP; }
+            ix->any_top_block = h_any != 0;
         }
     }
     SA_HIP(hipStreamSynchronize(st));

@@ -1048,12 +1048,44 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_wave(const SpanMachinePa
 #define SA_SPAN_FROWS 12                 // table rows of a lane of a 64-lane chunk, incl. the scratch row: 12 x 64 x 8 = 6 KiB per wave
 
 struct SpanDocParams {
-    SpanTerms st;                        // dd[t] != null for every term
+    SpanTerms st;                        // (dd[t] == null: a term without a directory row, its documents are found by search)
     u32 slop;
+    int anchor;                          // the rarest term: a block takes 512 words of ITS list and looks at the documents they open
+                                         //   (the dense result is cleared beforehand); -1: 512 documents (and clears their results)
     float* counts;                       // the dense result
 };
 
-// candidate predicate of the word with header h, probing every term through its doc directory
+// index of the document's first word in term t's list -- through the term's doc directory row, or, for a term without
+// one, by a search on the 28-bit key -- or SA_DD_ABSENT
+__device__ __forceinline__ u32 sa_span_first(const SpanTerms& st, const int t, const u64 doc) {
+    if (st.dd[t]) return st.dd[t][doc];
+    const u32 j = sa_lower_bound(st.words[t], 0, st.len[t], doc << SA_KEY_SHIFT, SA_KEY_MASK);
+    return (j < st.len[t] && (st.words[t][j] >> SA_KEY_SHIFT) == doc) ? j : SA_DD_ABSENT;
+}
+
+// sa_header_triple_dd with the document's first word found as above (no word of these lists sits in a last block)
+__device__ __forceinline__ u32 sa_header_triple_doc(const SpanTerms& st, const int t, const u64 h) {
+    const u64 unit = 1ull << SA_LSB_BITS;
+    const u64 doc = h >> SA_KEY_SHIFT;
+    if (doc >= st.n_docs) return 0;
+    u32 j = sa_span_first(st, t, doc);
+    if (j == SA_DD_ABSENT) return 0;
+    const u64* const a = st.words[t];
+    const u32 n = st.len[t];
+    const u64 hm = h - unit, hp = h + unit;
+    const bool has_prev = (h & ~SA_KEY_MASK) != 0;                      // block > 0: h - 1 is in the same doc
+    u32 bits = 0;
+    for (; j < n; j++) {
+        const u64 x = a[j] & SA_HEADER_MASK;
+        if ((x >> SA_KEY_SHIFT) != doc || x > hp) break;
+        if (x == h) bits |= 2u;
+        else if (has_prev && x == hm) bits |= 1u;
+        else if (x == hp) bits |= 4u;
+    }
+    return bits;
+}
+
+// candidate predicate of the word with header h, probing every term within the word's document
 template <int TT>
 __device__ __forceinline__ bool sa_span_keep_word(const SpanTerms& st, const u64 h) {
     u32 m[TT];
@@ -1062,7 +1094,7 @@ __device__ __forceinline__ bool sa_span_keep_word(const SpanTerms& st, const u64
     bool possible = true;
 #pragma unroll
     for (int i = 0; i < TT; i++) {
-        if (possible) m[i] = sa_header_triple_dd(st.words[i], st.len[i], st.dd[i], st.n_docs, h);
+        if (possible) m[i] = sa_header_triple_doc(st, i, h);
         if (m[i] == 0) possible = false;
     }
     return possible && sa_span_keep<TT>(m, TT, false);
@@ -1076,7 +1108,7 @@ __device__ __forceinline__ u32 sa_span_doc_npos_slow(const SpanTerms& st, const 
 #pragma unroll
     for (int t = 0; t < TT; t++) {
         const u32 n = st.len[t];
-        for (u32 j = st.dd[t][doc]; j < n; j++) {
+        for (u32 j = sa_span_first(st, t, doc); j < n; j++) {
             const u64 w = st.words[t][j];
             if ((w >> SA_KEY_SHIFT) != doc) break;
             if (sa_span_keep_word<TT>(st, w & SA_HEADER_MASK)) npos += (u32)__popc((u32)(w & SA_LSB_MASK));
@@ -1093,7 +1125,7 @@ __device__ __forceinline__ bool sa_span_doc_words(const SpanTerms& st, const u64
     u32 j0[TT];
     bool all = true;
 #pragma unroll
-    for (int t = 0; t < TT; t++) { j0[t] = st.dd[t][doc]; all = all && j0[t] != SA_DD_ABSENT; }
+    for (int t = 0; t < TT; t++) { j0[t] = all ? sa_span_first(st, t, doc) : SA_DD_ABSENT; all = all && j0[t] != SA_DD_ABSENT; }
 #pragma unroll
     for (int t = 0; t < TT; t++) { c[t] = 0; keep[t] = 0; }
     *many = false;
@@ -1312,7 +1344,7 @@ __device__ __forceinline__ u32 sa_span_doc_last(const SpanDocParams& p, const u3
         if (lane < top) {
             bool all = true;
 #pragma unroll
-            for (int t = 0; t < TT; t++) all = all && p.st.dd[t][doc] != SA_DD_ABSENT;
+            for (int t = 0; t < TT; t++) all = all && sa_span_first(p.st, t, doc) != SA_DD_ABSENT;
             has = all && sa_span_doc_npos_slow<TT>(p.st, doc) != 0;
         }
         const u64 m = __ballot(has);
@@ -1327,7 +1359,7 @@ template <int TT>
 __device__ __forceinline__ void sa_span_wave_doc(const SpanDocParams& p, const u64 doc, SpanEnt* s_ents, const u32 lane) {
 #pragma unroll
     for (int t = 0; t < TT; t++)
-        if (p.st.dd[t][doc] == SA_DD_ABSENT) return;
+        if (sa_span_first(p.st, t, doc) == SA_DD_ABSENT) return;
     const int max_span_width = (int)((u32)TT + p.slop);
     u32 last_doc1 = 0xFFFFFFFFu;                                 // (not looked up yet)
     u32 cursor = 0, my_sum = 0;
@@ -1338,7 +1370,7 @@ __device__ __forceinline__ void sa_span_wave_doc(const SpanDocParams& p, const u
         const u32 n = p.st.len[t];
         const u64* const w = p.st.words[t];
         bool gave_up = false;
-        for (u32 j = p.st.dd[t][doc]; j < n && !gave_up; j += 64u) {
+        for (u32 j = sa_span_first(p.st, t, doc); j < n && !gave_up; j += 64u) {
             const u32 idx = j + lane;
             const u64 wv = idx < n ? w[idx] : ~0ull;
             const bool same = (wv >> SA_KEY_SHIFT) == doc;
@@ -1472,11 +1504,11 @@ __device__ __forceinline__ bool sa_span_lane_machine(u64* ents, const Pos& pos, 
 template <int CE, int PM, int S, int TT>
 __device__ __forceinline__ void sa_span_doc_chunk(const SpanDocParams& p, u64* tab, const unsigned short* s_plist, const u32* s_pbase,
                                                   const unsigned char* s_bin, const unsigned short* s_order, unsigned short* s_heavy,
-                                                  u32* n_heavy, const u64 lo, const u32 lane, const u32 start, const u32 n) {
+                                                  u32* n_heavy, const u32* s_doc, const u32 lane, const u32 start, const u32 n) {
     const bool have = lane < (u32)S && start + lane < n;
     const u32 local = have ? s_order[start + lane] : 0u;
     const u32 npos = have ? s_bin[local] : 0u;
-    const u64 doc = lo + local;
+    const u64 doc = s_doc[local];
     u32 incr = 0;
     bool ok;
     if (S == 64) {
@@ -1519,6 +1551,7 @@ __global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused(const SpanDocP
     constexpr int TABW = SA_SPAN_FROWS * 64;                     // a wave's tables, in 8-byte words
     __shared__ unsigned short s_plist[SA_SPAN_PC * SA_SPAN_FD];  // position-major: position q of local document d at [q * FD + d]
     __shared__ u32 s_pbase[SA_SPAN_FD];                          // 18 x the document's first block
+    __shared__ u32 s_doc[SA_SPAN_FD];                            // the slot's document
     __shared__ alignas(16) u64 s_tab[NW * TABW];
     __shared__ unsigned char s_bin[SA_SPAN_FD];
     __shared__ unsigned short s_order[SA_SPAN_FD], s_heavy[SA_SPAN_FD];
@@ -1539,10 +1572,24 @@ __global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused(const SpanDocP
 #pragma unroll 1
         for (int r = 0; r < ROUNDS; r++) {
             const u32 local = (u32)r * SA_SPAN_FT + threadIdx.x;
-            const u64 doc = lo + local;
-            u32 bin = 0;
-            if (doc < p.st.n_docs) {
+            // the slot's document: the (lo + local)-th document, or the one the (lo + local)-th word of the rarest
+            // term's list opens (a word whose predecessor belongs to the same document opens none)
+            u64 doc = lo + local;
+            bool valid = doc < p.st.n_docs;
+            if (p.anchor >= 0) {
+                const u64* const aw = p.st.words[p.anchor];
+                valid = doc < p.st.len[p.anchor];
+                if (valid) {
+                    const u64 i = doc;
+                    doc = aw[i] >> SA_KEY_SHIFT;
+                    valid = (i == 0 || (aw[i - 1] >> SA_KEY_SHIFT) != doc) && doc < p.st.n_docs;
+                }
+            } else if (valid) {
                 p.counts[doc] = 0.f;
+            }
+            s_doc[local] = (u32)doc;
+            u32 bin = 0;
+            if (valid) {
                 bool many = false;
                 u32 first_blk = 0;
                 if (sa_span_doc_words<TT>(p.st, doc, W, c, keep, &many, &first_blk)) {
@@ -1609,10 +1656,10 @@ __global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused(const SpanDocP
             if (lane == 0) ck = atomicAdd(&s_next, 1u);
             ck = (u32)__builtin_amdgcn_readfirstlane((int)ck);
             if (ck >= k_c + k_b + k_a) break;
-            if (ck < k_c) sa_span_doc_chunk<(TABW - 128) / 8 - 1, 4 * SA_SPAN_PC, 8, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, lo, lane, 8u * ck, n);
-            else if (ck < k_c + k_b) sa_span_doc_chunk<(TABW - 128) / 16 - 1, 2 * SA_SPAN_PC, 16, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, lo, lane, start_b + 16u * (ck - k_c), n);
-            else if (TT == 2) sa_span_doc_chunk<R - 1, SA_SPAN_PC, 64, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, lo, lane, start_a + 64u * (ck - k_c - k_b), n);
-            else sa_span_doc_chunk<(TABW - 128) / 32 - 1, SA_SPAN_PC, 32, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, lo, lane, start_a + 32u * (ck - k_c - k_b), n);
+            if (ck < k_c) sa_span_doc_chunk<(TABW - 128) / 8 - 1, 4 * SA_SPAN_PC, 8, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, s_doc, lane, 8u * ck, n);
+            else if (ck < k_c + k_b) sa_span_doc_chunk<(TABW - 128) / 16 - 1, 2 * SA_SPAN_PC, 16, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, s_doc, lane, start_b + 16u * (ck - k_c), n);
+            else if (TT == 2) sa_span_doc_chunk<R - 1, SA_SPAN_PC, 64, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, s_doc, lane, start_a + 64u * (ck - k_c - k_b), n);
+            else sa_span_doc_chunk<(TABW - 128) / 32 - 1, SA_SPAN_PC, 32, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, s_doc, lane, start_a + 32u * (ck - k_c - k_b), n);
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -1620,7 +1667,7 @@ __global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused(const SpanDocP
     // ---- heavy documents and outgrown tables: a wave each, the block's tables now being free (HW full tables fit)
     const u32 nh = s_nheavy;
     if (wave < (u32)HW)
-        for (u32 i = wave; i < nh; i += (u32)HW) sa_span_wave_doc<TT>(p, lo + s_heavy[i], (SpanEnt*)s_tab + (size_t)wave * SA_NSPANS, lane);
+        for (u32 i = wave; i < nh; i += (u32)HW) sa_span_wave_doc<TT>(p, s_doc[s_heavy[i]], (SpanEnt*)s_tab + (size_t)wave * SA_NSPANS, lane);
 }
 
 static bool sa_env_span_doc() {
@@ -1646,7 +1693,15 @@ static int sa_span_counts_doc_route(sa_index* ix, const SpanTerms& terms_dev, in
     p.slop = (u32)slop;
     p.counts = (float*)scratch;
     *d_out = p.counts;
-    const dim3 fg((u32)((N + SA_SPAN_FD - 1) / SA_SPAN_FD));
+    // the documents to look at: those of the rarest term -- unless its list is about as long as the collection (then
+    // every document, in doc order: no search for the openers, nothing to clear beforehand)
+    int rarest = 0;
+    for (int t = 1; t < T; t++) if (terms_dev.len[t] < terms_dev.len[rarest]) rarest = t;
+    p.anchor = 2 * (u64)terms_dev.len[rarest] >= N ? -1 : rarest;
+    if (p.anchor >= 0) SA_HIP(hipMemsetAsync(p.counts, 0, N * sizeof(float), st));
+    if (getenv("SA_SPAN_TRACE")) fprintf(stderr, "slop doc route: %s\n", p.anchor >= 0 ? "over the rarest term's documents" : "over all documents");
+    const u64 slots = p.anchor >= 0 ? (u64)terms_dev.len[rarest] : N;
+    const dim3 fg((u32)((slots + SA_SPAN_FD - 1) / SA_SPAN_FD));
     switch (T) {
     case 2: sa_span_doc_launch<2>(p, fg, st); break;
     case 3: sa_span_doc_launch<3>(p, fg, st); break;
@@ -1768,8 +1823,11 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
     // 0 not in L (host arithmetic on the per-term edge flags, as below)
     if (known && !filt.active && T >= 2 && T <= 4 && T + slop <= 15 && N > 0 && N < 0xFFFFFFF0ull && sa_env_span_doc() &&
         ix->h_term_edge.size() >= (size_t)ix->n_terms) {
-        bool all_dd = true;
-        for (int t = 0; t < T; t++) all_dd = all_dd && terms_dev.dd[t] != nullptr && terms_dev.len[t] > 0;
+        // no word of these lists in a document's last 18-position block: no such word in the index at all (the usual case),
+        // or every term with a directory row that says so
+        bool all_dd = true, nonempty = true;
+        for (int t = 0; t < T; t++) { all_dd = all_dd && terms_dev.dd[t] != nullptr; nonempty = nonempty && terms_dev.len[t] > 0; }
+        const bool local = nonempty && (all_dd || !ix->any_top_block);
         const unsigned char e0 = ix->h_term_edge[terms[0]];
         bool L = true;
         for (int i = 1; i < T; i++) {
@@ -1779,10 +1837,9 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
         }
         // (two terms: the `L - 1` widening adds nothing -- a word at h with L(h + 1) has R(h), whichever clause of
         //  Lset(h + 1) holds and whichever term the word is of -- so its loss changes nothing either)
-        // (the route reads every document's directory entries whatever the lists hold, but it wins on short lists too:
-        //  zipf-1M, slop 2, [0 1] 0.114 vs 0.130 ms, [5 6] 0.036 vs 0.060, [20 30] 0.025 vs 0.034, [5 8 9] 0.046 vs 0.070 --
-        //  one launch against seven)
-        const bool take = all_dd && (T == 2 || !L);
+        // (it wins on every phrase measured, short lists included -- zipf-1M, slop 2, [0 1] 0.078 vs 0.130 ms, [5 6] 0.030 vs
+        //  0.059, [20 30] 0.022 vs 0.034, [5 8 9] 0.040 vs 0.070: one launch against seven)
+        const bool take = local && (T == 2 || !L);
         if (getenv("SA_SPAN_TRACE")) fprintf(stderr, "slop route: %s (T %d, directory rows %d, header 0 in L %d)\n", take ? "doc-parallel" : "general", T, (int)all_dd, (int)L);
         if (take) return sa_span_counts_doc_route(ix, terms_dev, T, slop, d_out);
     }

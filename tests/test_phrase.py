@@ -332,7 +332,9 @@ def test_slop_doc_parallel_route(api, seed, monkeypatch, capfd):
     from oracle import spans as S
     monkeypatch.setenv("SA_SPAN_TRACE", "1")
     rng = np.random.default_rng(700 + seed)
-    n_docs, vocab = (int(rng.integers(300, 600)) if seed < 2 else int(rng.integers(4500, 7000))), 6     # (one / several sort blocks)
+    # (one / several blocks; seed 3: a Zipf vocabulary of 60 -- rare terms without a directory row, found by search, and
+    #  blocks over the rarest term's documents instead of over all documents)
+    n_docs, vocab = (int(rng.integers(300, 600)) if seed < 2 else int(rng.integers(4500, 7000))), (6 if seed < 3 else 60)
     t, d, p, lens = synth.corpus_triples(n_docs, vocab, int(rng.integers(8, 30)), seed=60 + seed)
     # a few long documents: many positions, many words per term
     extra_t, extra_d, extra_p = [], [], []
@@ -350,11 +352,15 @@ def test_slop_doc_parallel_route(api, seed, monkeypatch, capfd):
     words, wt = rz.encode_sorted(t, d, p)
     dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
     orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
-    routes = {"doc-parallel": 0, "general": 0}
-    for T in (2, 2, 3, 3, 4):
+    routes = {"doc-parallel": 0, "general": 0, "doc route: over the rarest": 0, "doc route: over all": 0}
+    for T in (2, 2, 3, 3, 4) if seed < 3 else (2, 2, 2, 3, 3, 3, 4, 4):
         terms = [int(x) for x in rng.integers(0, vocab, T)]
+        if seed == 3:
+            terms[0] = int(rng.integers(0, 4))           # a frequent term beside the rare ones: some documents do match
         slop = int(rng.integers(1, 7))
-        enc = [orc.enc(x) for x in terms]
+        enc = [orc.enc(x) if orc.has_term(x) else np.empty(0, np.uint64) for x in terms]
+        if any(len(e) == 0 for e in enc):
+            continue
         ids, counts, overflow = S.span_search(enc, slop, return_overflow=True)
         want = np.zeros(n_docs, dtype=np.float32)
         want[ids.astype(np.int64)] = counts
@@ -362,7 +368,7 @@ def test_slop_doc_parallel_route(api, seed, monkeypatch, capfd):
         got = dev.phrase_freqs_dense(terms, slop=slop)
         err = capfd.readouterr().err
         for r in routes:
-            routes[r] += f"slop route: {r}" in err
+            routes[r] += (f"slop route: {r}" in err) or (f"slop {r}" in err)
         assert np.array_equal(got, want), f"seed {seed} terms {terms} slop {slop}: {np.flatnonzero(got != want)[:5]}"
         monkeypatch.setenv("SA_SPAN_DOC", "0")
         other = dev.phrase_freqs_dense(terms, slop=slop)
@@ -371,6 +377,10 @@ def test_slop_doc_parallel_route(api, seed, monkeypatch, capfd):
     assert routes["doc-parallel"] >= 2, routes
     if seed % 2 == 0:
         assert routes["doc-parallel"] == 5, routes
+    if seed == 3:
+        assert routes["doc route: over the rarest"] >= 2, routes
+    else:
+        assert routes["doc route: over all"] >= 2, routes
     dev.close()
 
 
