@@ -1005,9 +1005,10 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_wave(const SpanMachinePa
     sa_span_machine_wave_body(p, blockIdx.x, gridDim.x);
 }
 
-// ---- the doc-parallel route: frequent terms, whole lists ---------------------------------------------------------------
-// When every term of the phrase has a doc directory row and no word in a document's last 18-position block (the
-// directory's own condition, sa_header_triple_dd), and header 0 is not in L (no wrapped `L - 1`, see the top of the
+// ---- the doc-parallel route: whole lists, two to four terms -----------------------------------------------------------
+// When no word of the phrase's lists sits in a document's last 18-position block (no such word in the whole index:
+// sa_index::any_top_block, from the build; or every term with a doc directory row, which records it per term:
+// sa_header_triple_dd), and header 0 is not in L (no wrapped `L - 1`, see the top of the
 // file; with two terms that widening is redundant and the condition is not needed), the candidate predicate of a word
 // only looks at words of the word's OWN document, in every term.  Then
 // (a) whether a word is a candidate can be worked out by the thread that holds the document's words, no flag array;
@@ -1019,9 +1020,11 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_wave(const SpanMachinePa
 // ONE launch, nothing but the lists read and the dense result written (earlier forms of this route -- count / emit /
 // machine over record buffers in HBM, then sort blocks + work lists -- moved 2-3 x the lists and were bound by what
 // bound the general route: passes that wait for memory, then a pass that waits for instruction issue, one after the
-// other).  A block of 256 threads takes 512 neighbouring documents:
-//   gather  one document per thread and round (lane = doc: the directory rows and the documents' words are read in
-//           doc order): candidate words, their positions -> the document's bin (0 none, npos up to 32, else heavy) and,
+// other).  A block of 256 threads takes 512 neighbouring documents -- of the RAREST term's list (512 neighbouring words
+// of it: the ones that open a document stand for it; the dense result is cleared beforehand) or, when that list is
+// about as long as the collection, of the collection itself (SpanDocParams::anchor):
+//   gather  one document per thread and round (the documents' words are read in doc order; a term's words of the
+//           document are found through its directory row or by a search on the key: sa_span_first): candidate words, their positions -> the document's bin (0 none, npos up to 32, else heavy) and,
 //           for up to 8 positions, the position list -- term << 10 | position - 18 x the document's first block, 16
 //           bits, in the machine's order -- in LDS;
 //   order   the block's documents by bin, most positions first (counting sort in LDS);
