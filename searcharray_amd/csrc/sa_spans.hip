@@ -1039,7 +1039,7 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_wave(const SpanMachinePa
 //   heavy   documents beyond that, and lanes whose table outgrew its column even so: a wave each, once the block's lane
 //           work is done and its tables are free (sa_span_wave_doc: the words through the directory, candidate test
 //           per lane, the 512-span table of 16-byte entries in 8 KiB of them).
-// Blocks in different phases share a CU (four fit: 38 KB of LDS each), so the gather's memory latency hides behind
+// Blocks in different phases share a CU (four fit: 40 KB of LDS each), so the gather's memory latency hides behind
 // other blocks' machines.  Span entries are 8 bytes here (position bits 32, first position 23, last - first 5, terms
 // 4): T + slop <= 15.
 #define SA_SPAN_DW 4                     // words of one term per document the gather holds in registers
