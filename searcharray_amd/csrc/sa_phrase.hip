@@ -179,7 +179,9 @@ struct FusedPhraseParams {
     u32 len[SA_MAX_FUSED];
     const u32* dd[SA_MAX_FUSED];     // doc directory row of the term (whole, unfiltered list), or null
     int T, anchor;
-    u32* step;                   // dense per-doc match counts (u32, atomically accumulated)
+    u32* step;                   // dense per-doc match counts (u32, atomically accumulated) -- or
+    float* fcounts;              //   the dense float result itself (one sub-phrase: no minimum to take; small integers,
+                                 //   exact in any order)
 };
 
 __global__ void __launch_bounds__(256) sa_k_phrase_fused(const FusedPhraseParams p) {
@@ -199,7 +201,10 @@ __global__ void __launch_bounds__(256) sa_k_phrase_fused(const FusedPhraseParams
             if (want_next) win |= sa_payload_at(a, n, h + delta, hint) << 36;
             return win;
         });
-        if (m) atomicAdd(&p.step[w >> SA_KEY_SHIFT], (u32)__popcll(m));
+        if (m) {
+            if (p.fcounts) unsafeAtomicAdd(&p.fcounts[w >> SA_KEY_SHIFT], (float)__popcll(m));
+            else atomicAdd(&p.step[w >> SA_KEY_SHIFT], (u32)__popcll(m));
+        }
     }
 }
 
@@ -655,7 +660,6 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
         }
     }
     SA_HIP(hipMemsetAsync(running, 0, N * sizeof(float), st));     // (the routes below accumulate)
-    SA_HIP(hipMemsetAsync(step, 0, N * sizeof(u32), st));
     // (a sub-phrase the fused kernel would have to take whole must fit its 18-position window: longer ones go
     //  through the general chain, which has no such limit)
     const int longest_part = (l2r_only || r2l_only) ? T : (shortest > T - shortest ? shortest : T - shortest);
@@ -666,11 +670,14 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
         int parts[2][2] = {{0, T}, {0, 0}};
         int nparts = 1;
         if (!l2r_only && !r2l_only) { parts[0][1] = shortest; parts[1][0] = shortest; parts[1][1] = T; nparts = 2; }
+        // (one sub-phrase: its counts ARE the result -- straight into the float vector, no count vector to clear and to fold)
+        if (nparts > 1) SA_HIP(hipMemsetAsync(step, 0, N * sizeof(u32), st));
         for (int pi = 0; pi < nparts; pi++) {
             const int a = parts[pi][0], b = parts[pi][1];
             FusedPhraseParams fp;
             memset(&fp, 0, sizeof(fp));
             fp.T = b - a; fp.step = step;
+            fp.fcounts = nparts == 1 ? running : nullptr;
             int anchor = 0;
             for (int t = a; t < b; t++) {
                 fp.ptr[t - a] = ptrs[t]; fp.len[t - a] = lens[t];
@@ -681,12 +688,13 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
             if (fp.T > SA_MAX_FUSED) { sa_set_error("fused phrase kernel: sub-phrase longer than 18 terms"); return SA_ERR_UNSUPPORTED; }
             if (fp.len[anchor] > 0)
                 hipLaunchKernelGGL(sa_k_phrase_fused, dim3(sa_grid_for(fp.len[anchor])), dim3(256), 0, st, fp);
-            hipLaunchKernelGGL(sa_k_min_step, dim3(sa_grid_for(N)), dim3(256), 0, st, running, step, N, pi == 0 ? 1 : 0);
+            if (nparts > 1) hipLaunchKernelGGL(sa_k_min_step, dim3(sa_grid_for(N)), dim3(256), 0, st, running, step, N, pi == 0 ? 1 : 0);
         }
         return SA_OK;
     }
 
     // general chain
+    SA_HIP(hipMemsetAsync(step, 0, N * sizeof(u32), st));
     auto term_arr = [&](int t) {
         DArr a; a.data = ptrs[t]; a.n_dev = lens_dev + t; a.bound = lens[t]; return a;
     };
