@@ -612,7 +612,7 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
         const char* v = getenv("SA_PHRASE_DOCS");
         // (pairwise-distinct terms: only where the fused kernel cannot take the phrase -- a sub-phrase of more than 18 terms)
         const int part = (l2r_only || r2l_only) ? T : (shortest > T - shortest ? shortest : T - shortest);
-        const bool fused_can = distinct && part <= SA_MAX_FUSED;
+        const bool fused_can = distinct && part <= SA_MAX_FUSED && !ix->any_top_block;
         bool take = mode == 0 && !fused_can && !(v && atoi(v) == 0) && !filt.active && T >= 2 && T <= SA_PD_MAXT && N < 0xFFFFFFF0ull;
         for (int t = 0; t < T && take; t++) take = lens[t] > 0;
         if (take) {
@@ -663,7 +663,10 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
     // (a sub-phrase the fused kernel would have to take whole must fit its 18-position window: longer ones go
     //  through the general chain, which has no such limit)
     const int longest_part = (l2r_only || r2l_only) ? T : (shortest > T - shortest ? shortest : T - shortest);
-    const bool use_fused = (mode == 2) || (mode == 0 && distinct && longest_part <= SA_MAX_FUSED);
+    // (and no word in a document's last 18-position block: a match across two documents -- bit 17 of one's last block, bit 0
+    //  of the next one's first -- is the LEFT document's in the chain, the anchor's in the fused kernel; the reference's
+    //  encoder cannot produce such words, hand-made ones take the chain)
+    const bool use_fused = (mode == 2) || (mode == 0 && distinct && longest_part <= SA_MAX_FUSED && !ix->any_top_block);
     if (use_fused) {
         if (!distinct) { sa_set_error("fused phrase kernel needs pairwise-distinct terms"); return SA_ERR_ARG; }
         // sub-phrases the reference evaluates: the whole phrase (l2r / r2l plans) or the two halves

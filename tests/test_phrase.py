@@ -183,6 +183,43 @@ def test_long_distinct_phrases_chain_per_document(api, monkeypatch, capfd):
     assert taken == 6, taken
 
 
+def test_words_in_a_documents_last_block_keep_the_general_routes(api, monkeypatch, capfd):
+    """A word in a document's LAST 18-position block (positions >= 18 * (2^18 - 1)) has `header + 1` = the next document's
+    block 0, so neither the bigram chain nor the slop candidate sets are local to a document then.  The index records
+    whether any such word exists; with one, slop phrases of terms without a directory row take the general route, the
+    phrase chain per document steps aside when it meets such a word -- and the answers stay the oracle's."""
+    monkeypatch.setenv("SA_SPAN_TRACE", "1")
+    monkeypatch.setenv("SA_PHRASE_TRACE", "1")
+    monkeypatch.setenv("SA_DOCDIR_DIV", "0")                 # no directory rows: only the index-wide flag can vouch for locality
+    rng = np.random.default_rng(21)
+    n_docs, vocab = 120, 4
+    t, d, p, lens = synth.corpus_triples(n_docs, vocab, 12, seed=5)
+    t = np.concatenate([t, [0, 1, 2]]); d = np.concatenate([d, [7, 8, 8]]); p = np.concatenate([p, [200, 0, 1]])
+    order = np.lexsort((p, d, t))
+    t, d, p = t[order], d[order], p[order]
+    words, wt = rz.encode_sorted(t, d, p)
+    off = rz.term_offsets(wt, vocab)
+    # (the encoder takes positions < 2^18 only, like the reference's: the word is put into the last block by hand -- doc 7's
+    #  last word of term 0, position bits 16 and 17)
+    w0 = words[off[0]:off[1]]
+    i = int(off[0]) + int(np.flatnonzero((w0 >> np.uint64(36)) == 7)[-1])
+    words = words.copy()
+    words[i] = (np.uint64(7) << np.uint64(36)) | (np.uint64(0x3FFFF) << np.uint64(18)) | np.uint64(0x30000)
+    dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api)
+    orc = O.OracleIndex(words, np.arange(vocab), off, lens, n_docs)
+    for ph, slop in (([0, 1], 2), ([1, 0, 2], 3), ([0, 0], 0), ([0, 0, 1], 0), ([1, 1, 2, 0], 0), ([0, 1], 0), ([0, 1, 2], 0)):
+        capfd.readouterr()
+        got = dev.phrase_freqs_dense(ph, slop=slop)
+        err = capfd.readouterr().err
+        assert np.array_equal(got, orc.phrase_freqs(ph, slop=slop)), (ph, slop)
+        if slop:
+            assert "slop route: general" in err, err
+        elif len(set(ph)) < len(ph) and 0 in ph:
+            assert "abandoned" in err, err
+    dev.close()
+    del rng
+
+
 def test_chain_per_document_gives_way_when_its_checks_fail(api, monkeypatch, capfd):
     """The per-document chain predicts the reference's same-term test (`np.all(lhs_int == rhs_int)`, global over a step's
     matched pairs) and holds six words per list; it must step aside -- and the general chain give the reference's
