@@ -18,8 +18,10 @@ cd $R
 ( time SA_BENCH_FORCE_COMM=1 timeout 300 python bench.py --corpus-cache $C --no-cpu-baseline --no-pmc ) > $O/bench_comm1.log 2>&1
 ( time RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_PORT=29533 SA_BENCH_FORCE_COMM=1 timeout 300 python bench.py --no-cpu-baseline --no-pmc --docs 1250000 --steps 100 ) > $O/dist1_rccl.log 2>&1
 ( time timeout 300 python bench.py --no-cpu-baseline --no-pmc --no-phrase-legs --docs 1250000 --steps 100 --pipeline 8 ) > $O/rank_nocomm.log 2>&1
+if [ -f searcharray_amd/libsearcharray_hip_r2.so ]; then     # (round 2's library, rebuilt from commit dfc26d0 into the tree for the A/B)
 ( time timeout 600 python scripts/ab.py --corpus-cache $C --libs searcharray_amd/libsearcharray_hip_r2.so,searcharray_amd/libsearcharray_hip.so --ks 10,100,1000 --qsets baseline,distinct ) > $O/kernel_ab.log 2>&1
 ( time timeout 300 python scripts/ab.py --docs 1250000 --steps 50 --libs searcharray_amd/libsearcharray_hip_r2.so,searcharray_amd/libsearcharray_hip.so --ks 10 --qsets baseline ) >> $O/kernel_ab.log 2>&1
+fi
 ( time timeout 300 python scripts/host_cost.py --docs 1250000 ) > $O/host_cost.log 2>&1
 ( time timeout 300 python scripts/host_cost.py --docs 1250000 --comm ) >> $O/host_cost.log 2>&1
 ( time timeout 300 python scripts/phrase_bench.py ) > $O/phrase_bench.log 2>&1
