@@ -18,6 +18,7 @@
 #include "sa_index.hpp"
 #include "sa_topk.hpp"
 #include "sa_batch.hpp"
+#include "sa_bm25_params.hpp"
 #include "../../include/searcharray_hip.h"
 
 #include <algorithm>
@@ -26,54 +27,6 @@
 #include <stdlib.h>
 #include <math.h>
 
-
-struct alignas(16) sa_u64x2 { u64 x, y; };
-
-struct Bm25Params {
-    // index
-    const u64* tfp;
-    const u64* tf_off;
-    const u32* dir_slot;
-    const u32* tile_dir;
-    const float* doc_lens;
-    u32 n_terms, n_tiles;
-    u64 n_docs, doc_base;
-    int dl_packed;
-    // batch
-    const u32* terms;      // [B][T]
-    const float* idf;      // [B][T]
-    const float* sattab;   // [SA_SAT_NTF][tab_w] saturation table (sa_k_make_sattab)
-    u32 tab_w;             // 0: no table (doc lengths not packed in the postings); else 64/128
-    const u32* bounds;     // [B][T][n_tiles+1] slice table (sa_k_make_bounds)
-    const u64* qbase;      // [B][T] posting base of each query term
-    const u64* imp;        // impact stream (sa_impacts, sa_index.hpp) or null: score the TF postings
-    const u64* qbase_imp;  // [B][T][2] impact stream: first cell of each query term, first cell of the sentinel pair behind it
-    u64 imp_tail;          // a cell of the impact stream that is a sentinel whatever happens (its last pair)
-    u32 B, T, k;
-    u32 tile0, tile_end;   // tiles [tile0, tile_end) of this launch (sa_k_bm25_tiles)
-    float k1, b, avgdl;
-    int pruned;            // 1: wave-level selection against a global bound (MODE 1); 0: block-level selection (MODE 0)
-    int no_topk;           // timing experiments only: skip the per-tile selection
-    u32 cand_per_tile;     // general mode: candidate slots per (query, tile) = k
-    u32 cand_cap;          // pruned mode: capacity of each query's append list
-    u32* cand_cnt;         // pruned mode: [B] append cursors
-    u32* slots;            // pruned mode: [B][32] pruning slots (score bits)
-    u32* hist;             // pruned mode, k > 32: [B][SA_HBINS] score histograms (null: use the slots)
-    u32* gthr;             // pruned mode, k > 32: [B] cached bound (score bits)
-    // dynamic pruning (MaxScore): per query the terms in ascending idf order and the score a doc
-    // can reach at most from the j smallest-idf terms alone
-    const float* ub;       // [B][T+1] upper bounds (ub[0] = 0), or null: exhaustive scoring
-    const u32* ub_order;   // [B][T] query-term index of the j-th smallest idf
-    const unsigned char* tf8;   // index dense tf rows [n_tf8_terms][n_docs]
-    const u32* tf8_slot;   // [n_terms]
-    u32* stats;            // diagnostics (sa_batch_stats): [B] candidates scored by the sparse path, or null
-    const u32* qlist;      // queries to scan (after the sparse path took the others), or null: all B
-    u32 nq;                // number of queries to scan (= B without a list)
-    const u32* nq_dev;     // the same on the device (sa_k_bm25_tiles_list)
-    // outputs
-    float* dense_out;      // [B][n_docs] or null
-    u64* cand;             // [B][n_tiles][k] composite keys (global doc ids) or null
-};
 
 // ---- impact stream ---------------------------------------------------------------------------------
 // The exhaustive tile kernel is bound by instruction issue per posting, not by posting bytes.
@@ -1567,23 +1520,26 @@ static int sa_launch_bm25_list(sa_index* ix, const Bm25Params& p, hipStream_t st
 }
 
 static int sa_launch_bm25_groups(sa_index* ix, const sa_batch* bt, const Bm25Params& p, u32 tile0, hipStream_t st) {
+    // head groups (sa_bm25_hg.hip) first: the first n_hg_groups entries of the group table
+    SA_TRY(sa_launch_bm25_headgroups(ix, bt, p, tile0, st));
     GroupParams gp;
-    gp.grp = bt->d_grp; gp.n_groups = bt->n_groups;
+    gp.grp = bt->d_grp + 3u * bt->n_hg_groups; gp.n_groups = bt->n_groups - bt->n_hg_groups;
     gp.tile0 = tile0; gp.n_tiles_run = ix->n_tiles - tile0;
     gp.tt = bt->grp_tt; gp.tt_shift = bt->grp_tt_shift;
     gp.dense = (bt->impacts && sa_env_int("SA_GROUP_DENSE", 1) != 0) ? bt->impacts->d_dense : nullptr;
     gp.dense_stride = bt->impacts ? bt->impacts->dense_stride : 0;
     const u64 blocks = (u64)((gp.n_tiles_run + 7u) / 8u) * 8u * gp.n_groups;
-    if (blocks == 0 || blocks > 0x7FFFFFFFull) { sa_set_error("grouped launch: bad grid"); return SA_ERR_STATE; }
+    if (blocks > 0x7FFFFFFFull) { sa_set_error("grouped launch: bad grid"); return SA_ERR_STATE; }
     gp.wl = bt->d_wl; gp.wl_cnt = bt->d_wl_cnt;
     const u64 worst = (u64)gp.n_tiles_run * bt->n_grouped_rows;
     const u32 wgrid = worst < 2048 ? (u32)worst : 2048u;
+    if (wgrid == 0) return SA_OK;
     // (weight table: n * tt cells; 64 cover up to 4 overlaid terms per query at 16 queries per item)
     const bool small = (u32)SA_GRP_MAXQ * gp.tt <= 64u;
 #define SA_LAUNCH_GROUP(TILE, THREADS)                                                                                     \
     {                                                                                                                      \
-        if (small) hipLaunchKernelGGL((sa_k_bm25_group_tiles<TILE, 64>), dim3((u32)blocks), dim3(64), 0, st, p, gp);       \
-        else hipLaunchKernelGGL((sa_k_bm25_group_tiles<TILE, 128>), dim3((u32)blocks), dim3(64), 0, st, p, gp);            \
+        if (blocks && small) hipLaunchKernelGGL((sa_k_bm25_group_tiles<TILE, 64>), dim3((u32)blocks), dim3(64), 0, st, p, gp);       \
+        else if (blocks) hipLaunchKernelGGL((sa_k_bm25_group_tiles<TILE, 128>), dim3((u32)blocks), dim3(64), 0, st, p, gp);            \
         hipLaunchKernelGGL((sa_k_bm25_tiles_wl<TILE, THREADS>), dim3(wgrid), dim3(THREADS), 0, st, p, (const u64*)gp.wl,   \
                            (const u32*)gp.wl_cnt);                                                                         \
     }                                                                                                                      \
@@ -1812,7 +1768,8 @@ static int sa_batch_alloc_bm25(sa_batch* bt) {
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 7) & ~(size_t)7; return o; };
     const size_t o_p1 = take((B + 1) * 8), o_boff = take(B * 8), o_terms = take(B * T * 4), o_idf = take(B * T * 4),
                  o_perm = take(B * 4), o_grp = take(3 * B * 4), o_ub = take(B * (T + 1) * 4), o_ord = take(B * T * 4),
-                 o_lead = take(B * 4), o_qdf = take(B * T * 4), o_row8 = take(B * T * 4), o_bsh = take(B * 4);
+                 o_lead = take(B * 4), o_qdf = take(B * T * 4), o_row8 = take(B * T * 4), o_bsh = take(B * 4),
+                 o_role = take(B * T * 4);
     SA_TRY(sa_batch_alloc_upload(bt, off));
     char* u = bt->d_up;
     bt->d_p1_off = (u64*)(u + o_p1); bt->d_bloom_off = (u64*)(u + o_boff);
@@ -1820,6 +1777,7 @@ static int sa_batch_alloc_bm25(sa_batch* bt) {
     bt->d_grp = (u32*)(u + o_grp); bt->d_ub = (float*)(u + o_ub); bt->d_ub_order = (u32*)(u + o_ord);
     bt->d_lead = (u32*)(u + o_lead); bt->d_qdf = (u32*)(u + o_qdf); bt->d_qrow8 = (u32*)(u + o_row8);
     bt->d_bloom_shift = (u32*)(u + o_bsh);
+    bt->d_qrole = (u32*)(u + o_role);
     {
         std::vector<u32> iota(B);
         for (u32 i = 0; i < B; i++) iota[i] = i;
@@ -1852,6 +1810,8 @@ static int sa_batch_alloc_bm25(sa_batch* bt) {
     // the impact stream of this (k1, b): shared through the index, built on first use (on the index stream: done
     // before this batch's stream goes on)
     bt->impacts = sa_impacts_get(ix, bt->k1, bt->b);
+    // rank bitmaps of the frequent terms (head-group kernel): built once per index
+    if (bt->impacts && sa_env_int("SA_HG", 1) != 0) SA_TRY(sa_index_ensure_sbits(ix));
     SA_HIP(hipStreamSynchronize(ix->stream));
     if (bt->impacts) SA_HIP(hipMalloc(&bt->d_qbase_imp, B * T * 2 * sizeof(u64)));
     return SA_OK;
@@ -1927,6 +1887,7 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
     // shared term once per (tile, group).  Grouped queries take the first device rows, group by group (big
     // groups are cut into balanced pieces of at most `maxq` queries), the others keep their order behind them.
     std::vector<u32> h_grp;
+    std::vector<u32> qrole_all((size_t)B * T, SA_HG_SKIP);    // head groups: role of every query term, per caller query
     bt->n_groups = 0; bt->n_grouped_rows = 0; bt->n_shared_rows = 0;
     {
         // lanes per query while the half tables are built: a power of two >= the terms overlaid -- T - 1 for groups
@@ -1943,6 +1904,39 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
         for (size_t i = 0; i < (size_t)B * T && idf_ok; i++) idf_ok = idf[i] >= 0.f && idf[i] <= 3.0e38f;
         const bool on = sa_env_int("SA_GROUP", 1) != 0 && idf_ok && maxq >= 1 &&
                         (ix->tile_docs == 1024 || ix->tile_docs == 2048 || ix->tile_docs == 4096);
+        // head groups: roles of the query terms (SA_HG_* in sa_bm25_params.hpp), per caller query
+        const bool hg_on = on && sa_env_int("SA_HG", 1) != 0 && T <= (u32)SA_HG_MAXT && ix->tile_docs == 2048 && bt->impacts &&
+                           ix->n_tiles > 0;
+        const u32 hg_min = (u32)std::max(1, sa_env_int("SA_HG_MIN", 2));
+        const double hg_cand_exp = (double)sa_env_int("SA_HG_CAND_EXP", 44);     // expected candidate postings per tile a query may have
+        const double hg_s_min = (double)sa_env_int("SA_HG_S_MIN", 12);           // a term below that many postings per tile is a candidate
+        auto hg_roles = [&](u32 q, bool head, u64* sdf_out) -> bool {
+            u32* role = &qrole_all[(size_t)q * T];
+            u64 df[SA_HG_MAXT] = {0, 0, 0, 0};
+            int s = -1;
+            for (u32 t = 0; t < T; t++) {
+                role[t] = SA_HG_SKIP;
+                if (head && t == 0) { role[t] = SA_HG_HEAD; continue; }
+                const u32 term = terms[(size_t)q * T + t];
+                if (term >= ix->n_terms) continue;
+                df[t] = ix->h_tf_off[term + 1] - ix->h_tf_off[term];
+                if (df[t] == 0) continue;
+                role[t] = SA_HG_CAND;
+                if (ix->d_sbits && ix->h_sbits_slot[term] != SA_DD_NONE && (s < 0 || df[t] > df[s])) s = (int)t;
+            }
+            if (s >= 0 && (double)df[s] / ix->n_tiles <= hg_s_min) s = -1;
+            double exp_c = 0.0;
+            for (u32 t = 0; t < T; t++)
+                if (role[t] == SA_HG_CAND && (int)t != s) exp_c += (double)df[t] / ix->n_tiles;
+            if (exp_c > hg_cand_exp) return false;
+            *sdf_out = 0;
+            if (s >= 0) {
+                role[s] = SA_HG_STREAM | (ix->h_sbits_slot[terms[(size_t)q * T + s]] << 4);
+                *sdf_out = df[s];
+            }
+            return true;
+        };
+        bt->n_hg_groups = 0; bt->n_hg_rows = 0;
         if (on) {
             std::vector<std::vector<u32>> members;              // in order of first appearance
             std::vector<std::pair<u32, u32>> keys;
@@ -1958,6 +1952,34 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
                 members[gi].push_back(q);
             }
             std::vector<u32> order;
+            // Head groups first (sa_k_bm25_headgroup, sa_bm25_hg.hip): the queries of a shared-first-term group whose
+            // further terms are ONE dense term with a rank bitmap (the stream term) plus sparse terms with few postings
+            // per tile (the candidates) -- or sparse terms only.  No limit on the group size: the base is read-only
+            // there and every wave of a workgroup takes its own queries.  Members are dealt to the waves round-robin,
+            // so they are ordered by the stream term's length (the longest slices go to different waves).
+            if (hg_on) {
+                for (auto& m : members) {
+                    std::vector<std::pair<u64, u32>> el;            // (stream df, query)
+                    std::vector<u32> other;
+                    for (u32 q : m) {
+                        u64 sdf = 0;
+                        if (hg_roles(q, true, &sdf)) el.push_back({sdf, q}); else other.push_back(q);
+                    }
+                    if (el.size() < hg_min) continue;
+                    std::stable_sort(el.begin(), el.end(), [](const std::pair<u64, u32>& a, const std::pair<u64, u32>& c) { return a.first > c.first; });
+                    h_grp.push_back((u32)order.size()); h_grp.push_back((u32)el.size());
+                    {
+                        const u32 t0 = terms[(size_t)el[0].second * T];
+                        const bool have = bt->impacts && bt->impacts->d_dense && t0 < bt->impacts->dense_slot.size() &&
+                                          sa_env_int("SA_GROUP_DENSE", 1) != 0;
+                        h_grp.push_back(have ? bt->impacts->dense_slot[t0] : 0xFFFFFFFFu);
+                    }
+                    for (auto& e : el) order.push_back(e.second);
+                    m = other;
+                }
+                bt->n_hg_groups = (u32)(h_grp.size() / 3);
+                bt->n_hg_rows = (u32)order.size();
+            }
             for (auto& m : members) {
                 if (m.size() < gmin) { rest.insert(rest.end(), m.begin(), m.end()); continue; }
                 const u32 pieces = ((u32)m.size() + maxq - 1) / maxq;
@@ -2018,6 +2040,11 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
     }
     memset(h_grpd, 0, (size_t)3 * B * sizeof(u32));
     if (!h_grp.empty()) memcpy(h_grpd, h_grp.data(), h_grp.size() * sizeof(u32));     // (at most B groups)
+    {
+        u32* h_role = (u32*)at(bt->d_qrole);
+        for (u32 r = 0; r < B; r++)
+            for (u32 t = 0; t < T; t++) h_role[(size_t)r * T + t] = r < bt->n_hg_rows ? qrole_all[(size_t)bt->perm[r] * T + t] : SA_HG_SKIP;
+    }
     {
         // Dynamic pruning tables (sa_sparse.hip).  Per query: the terms in ascending idf order with the
         // prefix sums of their idf -- what the j cheapest terms can add to a score at most, since
@@ -2582,6 +2609,12 @@ extern "C" int sa_batch_profile(sa_batch_t* bt, double* kernel_ms_out, uint64_t*
 extern "C" int sa_batch_group_info(sa_batch_t* bt, uint32_t out[4]) {
     SA_ARG(bt && out, "null argument");
     out[0] = bt->n_groups; out[1] = bt->n_grouped_rows; out[2] = bt->n_shared_rows; out[3] = bt->B - bt->n_grouped_rows;
+    return SA_OK;
+}
+
+extern "C" int sa_batch_headgroup_info(sa_batch_t* bt, uint32_t out[2]) {
+    SA_ARG(bt && out, "null argument");
+    out[0] = bt->n_hg_groups; out[1] = bt->n_hg_rows;
     return SA_OK;
 }
 

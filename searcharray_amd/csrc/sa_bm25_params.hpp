@@ -1,0 +1,80 @@
+// sa_bm25_params.hpp -- kernel parameter blocks shared by the BM25 scoring kernels (sa_bm25.hip: per-query and
+// grouped tile kernels; sa_bm25_hg.hip: the head-group kernel).
+#pragma once
+#include "sa_index.hpp"
+
+struct alignas(16) sa_u64x2 { u64 x, y; };
+
+struct Bm25Params {
+    // index
+    const u64* tfp;
+    const u64* tf_off;
+    const u32* dir_slot;
+    const u32* tile_dir;
+    const float* doc_lens;
+    u32 n_terms, n_tiles;
+    u64 n_docs, doc_base;
+    int dl_packed;
+    // batch
+    const u32* terms;      // [B][T]
+    const float* idf;      // [B][T]
+    const float* sattab;   // [SA_SAT_NTF][tab_w] saturation table (sa_k_make_sattab)
+    u32 tab_w;             // 0: no table (doc lengths not packed in the postings); else 64/128
+    const u32* bounds;     // [B][T][n_tiles+1] slice table (sa_k_make_bounds)
+    const u64* qbase;      // [B][T] posting base of each query term
+    const u64* imp;        // impact stream (sa_impacts, sa_index.hpp) or null: score the TF postings
+    const u64* qbase_imp;  // [B][T][2] impact stream: first cell of each query term, first cell of the sentinel pair behind it
+    u64 imp_tail;          // a cell of the impact stream that is a sentinel whatever happens (its last pair)
+    u32 B, T, k;
+    u32 tile0, tile_end;   // tiles [tile0, tile_end) of this launch (sa_k_bm25_tiles)
+    float k1, b, avgdl;
+    int pruned;            // 1: wave-level selection against a global bound (MODE 1); 0: block-level selection (MODE 0)
+    int no_topk;           // timing experiments only: skip the per-tile selection
+    u32 cand_per_tile;     // general mode: candidate slots per (query, tile) = k
+    u32 cand_cap;          // pruned mode: capacity of each query's append list
+    u32* cand_cnt;         // pruned mode: [B] append cursors
+    u32* slots;            // pruned mode: [B][32] pruning slots (score bits)
+    u32* hist;             // pruned mode, k > 32: [B][SA_HBINS] score histograms (null: use the slots)
+    u32* gthr;             // pruned mode, k > 32: [B] cached bound (score bits)
+    // dynamic pruning (MaxScore): per query the terms in ascending idf order and the score a doc
+    // can reach at most from the j smallest-idf terms alone
+    const float* ub;       // [B][T+1] upper bounds (ub[0] = 0), or null: exhaustive scoring
+    const u32* ub_order;   // [B][T] query-term index of the j-th smallest idf
+    const unsigned char* tf8;   // index dense tf rows [n_tf8_terms][n_docs]
+    const u32* tf8_slot;   // [n_terms]
+    u32* stats;            // diagnostics (sa_batch_stats): [B] candidates scored by the sparse path, or null
+    const u32* qlist;      // queries to scan (after the sparse path took the others), or null: all B
+    u32 nq;                // number of queries to scan (= B without a list)
+    const u32* nq_dev;     // the same on the device (sa_k_bm25_tiles_list)
+    // outputs
+    float* dense_out;      // [B][n_docs] or null
+    u64* cand;             // [B][n_tiles][k] composite keys (global doc ids) or null
+};
+
+// ---- head-group kernel (sa_bm25_hg.hip) ------------------------------------------------------------
+// Role of a query term inside a head group, one u32 per (query, term) in the batch's upload block:
+//   bits [3:0]  kind          bits [31:4]  rank-bitmap row of the term (stream terms only)
+#define SA_HG_SKIP 0u       // unknown term / no postings in this shard
+#define SA_HG_HEAD 1u       // the group's shared first term: its scores are the tile's base in LDS
+#define SA_HG_STREAM 2u     // the query's dense further term: streamed against the base, looked up through its rank bitmap
+#define SA_HG_CAND 3u       // sparse terms: their postings are the candidate docs, one per lane
+#define SA_HG_MAXT 4        // query terms the kernel takes (positions 0 .. 3)
+#define SA_HG_NOHEAD 0xFFFFFFFEu   // grp[3g + 2]: a group without a shared term (no base)
+
+struct HgParams {
+    const u32* grp;         // [n_groups][3]: first device row, rows, dense factor row of the head / 0xFFFFFFFF (head scored from its postings) / SA_HG_NOHEAD
+    const u32* qrole;       // [B][T]
+    const float* dense;     // dense factor rows (sa_impacts::d_dense), or null
+    u64 dense_stride;
+    const u64* sbits;       // rank bitmaps (sa_index::d_sbits): row r = sbits[r * sbits_stride ...], bit d of the row = doc d has the term
+    u64 sbits_stride;       // u64 words per row (whole tiles)
+    u32 n_groups;
+    u32 tile0, n_tiles_run; // tiles [tile0, tile0 + n_tiles_run)
+    u64* wl;                // work list of (tile << 32 | device row) items left to the per-query kernel
+    u32* wl_cnt;
+};
+
+struct sa_batch;
+// rank bitmaps of the index (built once, on the first batch that can use them); call with the index lock held
+int sa_index_ensure_sbits(sa_index* ix);
+int sa_launch_bm25_headgroups(sa_index* ix, const sa_batch* bt, const Bm25Params& p, u32 tile0, hipStream_t st);

@@ -297,6 +297,10 @@ inline void __builtin_amdgcn_s_waitcnt(int) {}          // memory is synchronous
 inline int __builtin_amdgcn_readlane(int v, int lane) {
     return (int)(uint32_t)hipemu::wave_collective(hipemu::OP_SHFL, (uint64_t)(uint32_t)v, lane);
 }
+// ds_bpermute_b32: lane L reads the value of lane (addr / 4) mod 64
+inline int __builtin_amdgcn_ds_bpermute(int addr, int v) {
+    return (int)(uint32_t)hipemu::wave_collective(hipemu::OP_SHFL, (uint64_t)(uint32_t)v, (addr >> 2) & 63);
+}
 inline int __builtin_amdgcn_readfirstlane(int v) {
     return (int)hipemu::wave_collective(hipemu::OP_FIRST, (uint64_t)(uint32_t)v, 0);
 }
