@@ -22,7 +22,8 @@ sys.path.insert(0, ROOT)
 from searcharray_amd import synth, _lib                                     # noqa: E402
 from searcharray_amd.device_index import DeviceIndex, QueryBatch, compute_idf   # noqa: E402
 
-KEYS = ("SA_GROUP", "SA_GROUP_WARM", "SA_GROUP_MIN", "SA_GROUP_LOOSE", "SA_GROUP_SIDE", "SA_SPARSE", "SA_GRP_VARIANT")
+KEYS = ("SA_GROUP", "SA_GROUP_WARM", "SA_GROUP_MIN", "SA_GROUP_LOOSE", "SA_GROUP_SIDE", "SA_SPARSE", "SA_GRP_VARIANT", "SA_HG", "SA_HG_MIN",
+        "SA_HG_CAND_EXP", "SA_HG_S_MIN")
 
 
 def main():

@@ -1810,8 +1810,6 @@ static int sa_batch_alloc_bm25(sa_batch* bt) {
     // the impact stream of this (k1, b): shared through the index, built on first use (on the index stream: done
     // before this batch's stream goes on)
     bt->impacts = sa_impacts_get(ix, bt->k1, bt->b);
-    // rank bitmaps of the frequent terms (head-group kernel): built once per index
-    if (bt->impacts && sa_env_int("SA_HG", 1) != 0) SA_TRY(sa_index_ensure_sbits(ix));
     SA_HIP(hipStreamSynchronize(ix->stream));
     if (bt->impacts) SA_HIP(hipMalloc(&bt->d_qbase_imp, B * T * 2 * sizeof(u64)));
     return SA_OK;
@@ -1905,15 +1903,18 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
         const bool on = sa_env_int("SA_GROUP", 1) != 0 && idf_ok && maxq >= 1 &&
                         (ix->tile_docs == 1024 || ix->tile_docs == 2048 || ix->tile_docs == 4096);
         // head groups: roles of the query terms (SA_HG_* in sa_bm25_params.hpp), per caller query
-        const bool hg_on = on && sa_env_int("SA_HG", 1) != 0 && T <= (u32)SA_HG_MAXT && ix->tile_docs == 2048 && bt->impacts &&
+        const bool hg_on = on && sa_env_int("SA_HG", 0) != 0 && T <= (u32)SA_HG_MAXT && ix->tile_docs == 2048 && bt->impacts &&
                            ix->n_tiles > 0;
         const u32 hg_min = (u32)std::max(1, sa_env_int("SA_HG_MIN", 2));
-        const double hg_cand_exp = (double)sa_env_int("SA_HG_CAND_EXP", 44);     // expected candidate postings per tile a query may have
-        const double hg_s_min = (double)sa_env_int("SA_HG_S_MIN", 12);           // a term below that many postings per tile is a candidate
+        // a query's further terms: the one with the longest list is streamed, the postings of the others are its candidate docs
+        // (at most two such lists; their expected postings per super-tile -- 2 index tiles -- must fit the kernel's candidate map
+        //  with room to spare, else the query keeps the grouped / per-query kernels)
+        const double hg_cand_exp = (double)sa_env_int("SA_HG_CAND_EXP", 112);
         auto hg_roles = [&](u32 q, bool head, u64* sdf_out) -> bool {
             u32* role = &qrole_all[(size_t)q * T];
             u64 df[SA_HG_MAXT] = {0, 0, 0, 0};
-            int s = -1;
+            int lists[SA_HG_MAXT];
+            u32 n_lists = 0;
             for (u32 t = 0; t < T; t++) {
                 role[t] = SA_HG_SKIP;
                 if (head && t == 0) { role[t] = SA_HG_HEAD; continue; }
@@ -1921,19 +1922,36 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
                 if (term >= ix->n_terms) continue;
                 df[t] = ix->h_tf_off[term + 1] - ix->h_tf_off[term];
                 if (df[t] == 0) continue;
-                role[t] = SA_HG_CAND;
-                if (ix->d_sbits && ix->h_sbits_slot[term] != SA_DD_NONE && (s < 0 || df[t] > df[s])) s = (int)t;
+                lists[n_lists++] = (int)t;
             }
-            if (s >= 0 && (double)df[s] / ix->n_tiles <= hg_s_min) s = -1;
-            double exp_c = 0.0;
-            for (u32 t = 0; t < T; t++)
-                if (role[t] == SA_HG_CAND && (int)t != s) exp_c += (double)df[t] / ix->n_tiles;
-            if (exp_c > hg_cand_exp) return false;
             *sdf_out = 0;
-            if (s >= 0) {
-                role[s] = SA_HG_STREAM | (ix->h_sbits_slot[terms[(size_t)q * T + s]] << 4);
-                *sdf_out = df[s];
-            }
+            if (!head || n_lists > 3) return false;
+            // longest list first
+            std::stable_sort(lists, lists + n_lists, [&](int x, int y) { return df[x] > df[y]; });
+            // expected postings per super-tile (2 index tiles): the first candidate list takes two vectors, the second one
+            const double per_st = 2.0 / (double)ix->n_tiles;
+            if (n_lists > 1 && (double)df[lists[1]] * per_st > hg_cand_exp) return false;
+            if (n_lists > 2 && (double)df[lists[2]] * per_st > hg_cand_exp / 2.0) return false;
+            static const u32 kinds[3] = {SA_HG_STREAM, SA_HG_CAND0, SA_HG_CAND1};
+            for (u32 i = 0; i < n_lists; i++) role[lists[i]] = kinds[i];
+            if (n_lists) *sdf_out = df[lists[0]];
+            // the orders of the sums over the term positions 1 .. 3 (a role the query lacks takes a free position: it adds +0.0)
+            int pos_of[3] = {-1, -1, -1};                       // position of the stream list, the first, the second candidate list
+            bool used[4] = {true, false, false, false};
+            for (u32 i = 0; i < n_lists; i++) { pos_of[i] = lists[i]; used[lists[i]] = true; }
+            for (int i = 0; i < 3; i++)
+                if (pos_of[i] < 0)
+                    for (int t = 1; t < 4; t++)
+                        if (!used[t]) { pos_of[i] = t; used[t] = true; break; }
+            auto order = [](int p_own, int p_s, int p_oth) -> u32 {
+                // sa_hg_fold: 0 own,s,oth  1 own,oth,s  2 s,own,oth  3 s,oth,own  4 oth,own,s  5 oth,s,own
+                if (p_own == 1) return p_s == 2 ? 0u : 1u;
+                if (p_s == 1) return p_own == 2 ? 2u : 3u;
+                return p_own == 2 ? 4u : 5u;
+            };
+            const u32 ordA = order(pos_of[1], pos_of[0], pos_of[2]);     // docs of the first candidate list: own = its value, oth = the second list's
+            const u32 ordB = order(pos_of[2], pos_of[0], pos_of[1]);     // docs of the second: own = its value, oth = nothing (+0.0)
+            role[0] |= (ordA | (ordB << 3)) << 4;
             return true;
         };
         bt->n_hg_groups = 0; bt->n_hg_rows = 0;
@@ -2271,6 +2289,7 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
                 // Queries without a group go through the per-query kernel over all tiles.
                 u32 warm = std::max<u32>(16u, bt->k / 8u);     // (k = 1000, 10 M docs: 250 / 128 / 64 warm-up tiles -> 1.07 / 1.02 / 1.05 ms per step)
                 if (const char* v = getenv("SA_GROUP_WARM")) warm = (u32)atoi(v);
+                if (bt->n_hg_groups) warm = (warm + 3u) & ~3u;   // (the head-group kernel scores super-tiles of up to 4 index tiles)
                 warm = std::min(warm, ix->n_tiles);
                 // The ungrouped rows (per-query kernel over all tiles) share nothing with the grouped ones -- not a
                 // query, not a counter -- so they run on the side stream BESIDE the warm-up tiles and the grouped kernel

@@ -52,29 +52,16 @@ struct Bm25Params {
 };
 
 // ---- head-group kernel (sa_bm25_hg.hip) ------------------------------------------------------------
-// Role of a query term inside a head group, one u32 per (query, term) in the batch's upload block:
-//   bits [3:0]  kind          bits [31:4]  rank-bitmap row of the term (stream terms only)
+// Role of a query term inside a head group, one u32 per (query, term) in the batch's upload block: bits [3:0] the kind;
+// the head's word also carries, from bit 4 on, the orders in which a candidate's sum takes (own value, stream value, other
+// list's value) over the term positions 1 .. 3: bits [6:4] for docs of the first candidate list, [9:7] of the second
+// (sa_hg_fold in sa_bm25_hg.hip).
 #define SA_HG_SKIP 0u       // unknown term / no postings in this shard
-#define SA_HG_HEAD 1u       // the group's shared first term: its scores are the tile's base in LDS
-#define SA_HG_STREAM 2u     // the query's dense further term: streamed against the base, looked up through its rank bitmap
-#define SA_HG_CAND 3u       // sparse terms: their postings are the candidate docs, one per lane
+#define SA_HG_HEAD 1u       // the group's shared first term: its scores are the super-tile's base in LDS
+#define SA_HG_STREAM 2u     // the query's longest further list: streamed against the base
+#define SA_HG_CAND0 3u      // the further terms with shorter lists: their postings are the candidate docs (first / second list)
+#define SA_HG_CAND1 4u
 #define SA_HG_MAXT 4        // query terms the kernel takes (positions 0 .. 3)
-#define SA_HG_NOHEAD 0xFFFFFFFEu   // grp[3g + 2]: a group without a shared term (no base)
-
-struct HgParams {
-    const u32* grp;         // [n_groups][3]: first device row, rows, dense factor row of the head / 0xFFFFFFFF (head scored from its postings) / SA_HG_NOHEAD
-    const u32* qrole;       // [B][T]
-    const float* dense;     // dense factor rows (sa_impacts::d_dense), or null
-    u64 dense_stride;
-    const u64* sbits;       // rank bitmaps (sa_index::d_sbits): row r = sbits[r * sbits_stride ...], bit d of the row = doc d has the term
-    u64 sbits_stride;       // u64 words per row (whole tiles)
-    u32 n_groups;
-    u32 tile0, n_tiles_run; // tiles [tile0, tile0 + n_tiles_run)
-    u64* wl;                // work list of (tile << 32 | device row) items left to the per-query kernel
-    u32* wl_cnt;
-};
 
 struct sa_batch;
-// rank bitmaps of the index (built once, on the first batch that can use them); call with the index lock held
-int sa_index_ensure_sbits(sa_index* ix);
 int sa_launch_bm25_headgroups(sa_index* ix, const sa_batch* bt, const Bm25Params& p, u32 tile0, hipStream_t st);

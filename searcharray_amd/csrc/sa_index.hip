@@ -230,7 +230,6 @@ void sa_index_free(sa_index* ix) {
     if (ix->d_tf8) hipFree(ix->d_tf8);
     if (ix->d_tfbits) hipFree(ix->d_tfbits);
     if (ix->d_tf8_slot) hipFree(ix->d_tf8_slot);
-    if (ix->d_sbits) hipFree(ix->d_sbits);
     ix->impacts.reset();
     if (ix->d_scratch) hipFree(ix->d_scratch);
     for (int i = 0; i < 3; i++) {

@@ -95,15 +95,6 @@ struct sa_index {
     u64 tfbits_words = 0;            // u32 words per bitmap row = ceil(n_docs / 32)
     u32* d_tf8_slot = nullptr;       // [n_terms] row of a term, or SA_DD_NONE
 
-    // Rank bitmaps of the frequent terms (head-group BM25 kernel, sa_bm25_hg.hip): sbits[slot][w] = 64 presence bits of
-    // docs 64 w .. 64 w + 63.  A candidate doc finds a frequent term's posting without a search: bit test, then
-    // rank = popcount of the tile's bits below it = index into the term's tile slice.  Built by the first BM25 batch.
-    u64* d_sbits = nullptr;          // [n_sbits_terms][sbits_stride]
-    u64 sbits_stride = 0;            // u64 words per row: whole tiles
-    u32 n_sbits_terms = 0;
-    bool sbits_built = false;
-    std::vector<u32> h_sbits_slot;   // [n_terms] row of a term, or SA_DD_NONE
-
     std::vector<u64> h_term_off, h_tf_off;
     std::vector<u32> h_dd_slot;      // host copy of d_dd_slot
     std::vector<unsigned char> h_term_edge;   // [n_terms] bit 0: first word has header 0, bit 1: last word has the largest header

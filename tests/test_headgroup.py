@@ -1,9 +1,10 @@
-"""Head-group kernel (csrc/sa_bm25_hg.hip, sa_k_bm25_headgroup): queries that share their FIRST term are scored against
-a read-only base of that term -- their one dense further term is streamed (base + s), the postings of their sparse
-terms are candidate docs that gather every contribution (base from LDS, the stream term through its rank bitmap, the
-other sparse terms by doc-id comparison across lanes) and add them in query-term order.  Results must equal the oracle's
-dense score (the reference's np.sum of per-term score vectors, test/test_msmarco.py:353-354) + deterministic top-k bit
-for bit, and the grouped / per-query kernels' (SA_HG=0, SA_GROUP=0)."""
+"""Head-group kernel (csrc/sa_bm25_hg.hip, sa_k_bm25_headgroup; the alternative to the grouped kernel, SA_HG=1): queries
+that share their FIRST term are scored against a read-only base of that term, one workgroup per (super-tile of 4096 docs,
+group).  A query's longest further list is streamed (base + s); the postings of its other terms are candidate docs,
+registered in a per-wave candidate map in LDS, that collect every contribution of their doc through mailboxes -- the
+streamed term's factor, the other sparse list's value -- and add them in query-term order.  Results must equal the oracle's
+dense score (the reference's np.sum of per-term score vectors, test/test_msmarco.py:353-354) + deterministic top-k bit for
+bit, and the grouped / per-query kernels' (SA_HG=0, SA_GROUP=0)."""
 import numpy as np
 import pytest
 
@@ -12,6 +13,11 @@ from searcharray_amd import roaringish as rz, synth
 from searcharray_amd.device_index import DeviceIndex
 
 N_DOCS, VOCAB = 11000, 400          # 6 tiles of 2048 docs; df of rank r ~ 23 K / r
+
+
+@pytest.fixture(autouse=True)
+def head_groups_on(monkeypatch):
+    monkeypatch.setenv("SA_HG", "1")
 
 
 @pytest.fixture(scope="module")
@@ -87,18 +93,17 @@ def test_headgroup_roles_and_odd_queries(api, corpus, monkeypatch):
     check(api, corpus, queries[:14], 8, want_hg=13)
 
 
-def test_candidate_lists_longer_than_a_wave_and_dense_sparse_terms(api, corpus, monkeypatch):
-    """SA_HG_CAND_EXP raised: terms with ~100 postings per tile count as sparse -- pairs whose candidate lists exceed 64
-    postings go to the per-query kernel through the work list; the others compare long lists with many shared docs.
-    SA_HG_S_MIN raised: no term is streamed, up to three candidate lists per query"""
+def test_candidate_lists_beyond_the_map_and_dense_candidate_terms(api, corpus, monkeypatch):
+    """SA_HG_CAND_EXP raised: terms with hundreds of postings per super-tile count as candidates -- pairs whose candidate
+    lists exceed the map (128 / 64 postings) go to the per-query kernel through the work list; the others register long
+    lists with many docs in both"""
     monkeypatch.setenv("SA_SPARSE", "0")
     monkeypatch.setenv("SA_GROUP_WARM", "1")
     monkeypatch.setenv("SA_HG_CAND_EXP", "100000")
     rng = np.random.default_rng(5)
     queries = shaped(rng, 24, 4, heads=[0, 2], bands=[(5, 40), (30, 120), (60, 400)])
     check(api, corpus, queries, 10, want_hg=24)
-    monkeypatch.setenv("SA_HG_S_MIN", "100000")
-    queries = shaped(rng, 24, 4, heads=[0, 2], bands=[(90, 400), (120, 400), (150, 400)])
+    queries = shaped(rng, 24, 4, heads=[0, 2], bands=[(120, 400), (150, 400), (200, 400)])
     check(api, corpus, queries, 10, want_hg=24)
 
 
