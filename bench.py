@@ -12,18 +12,21 @@ environment; the ranks find each other through a 128-byte id file and everything
 max-over-ranks timing, barriers, the per-batch exchange of the per-shard top-k -- goes through
 libsearcharray_hip.so's own RCCL communicator (include/searcharray_hip.h Part 3).
 
-A "step" = one pass of the hot path over one batch of 256 queries THE DEVICE HAS NOT SEEN: the host computes the
-batch's idf weights (float64 numpy, the reference's arithmetic) and calls sa_batch_reset (grouping + pruning tables
-into a page-locked image, one async copy, the slice-table kernel), then sa_batch_run: scoring kernel(s) (postings
+A "step" = one pass of the hot path over one batch of 256 queries THE DEVICE HAS NOT SEEN, ONE library call
+(sa_batch_step): the batch's idf weights are gathered from the index's per-term table (float64 numpy arithmetic of the
+reference, formed once like df itself), sa_batch_reset (grouping + pruning tables into a page-locked image, one async
+copy, the slice-table kernel), then sa_batch_run: scoring kernel(s) (postings
 stream -> LDS accumulators -> pruned per-tile selection) + per-shard merge (+ RCCL all-gather of the per-shard
 top-k keys and a final merge when N > 1) + an async copy of the B x k results to the host, which the loop fetches
 two steps later.  Eight seeded query sets rotate through two batch objects, so nothing is replayed: what is timed is
 what a query stream gets (the reference's unit of work is score() on a fresh query, postings.py:652-680, timed as
 test/test_msmarco.py:345-395).  The 10M-doc corpus is sharded by doc-id range (10M / N docs per GPU, global BM25
-statistics); every rank scores every query of a batch on its docs.  N > 1 runs take N x 256 queries per step in the main
-region, so that the work of a GPU per step is what it is at N = 1 (`"scaling": "weak"`; the 256-query batch -- strong
-scaling -- is timed beside it as `fixed_batch`; `--strong` swaps them).  The index is resident in HBM before the timed
-region.  Rank 0 prints one JSON line.
+statistics); every rank scores every query of a batch on its docs.  The main region takes 256 queries per step at EVERY N
+(`"scaling": "strong"`: value(N) / value(1) is a like-for-like speed-up), and a WIDE batch of 2048 queries per step is timed
+beside it at every N, N = 1 included (`wide_batch`: wide_batch(N) / wide_batch(1) is the same-batch speed-up of a
+deployment that batches wider -- a rank's device work per step shrinks with N, the host's cost per batch does not).  The
+timed region of --steps steps is repeated --repeats times (5): `value` is the median region, min / max are in `repeats`.
+The index is resident in HBM before the timed region.  Rank 0 prints one JSON line.
 
 Legs (all on the same resident index; only the first is `value`):
   main (fresh)      8 rotating BASELINE-shaped query sets (256 x 4 terms, one rank from each of 1-10 / 11-100 /
@@ -57,6 +60,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB
 MARKER = "sa_k_stream8"    # PMC child: two dispatches of this kernel separate the legs
 CALIB = "sa_k_stream16"    # PMC child: a known byte count read with 16-byte loads (FETCH_SIZE calibration)
 CALIB_BYTES = 1 << 30
+LOADS_8B = ("sa_k_bm25_group_tiles", "sa_k_bm25_headgroup")   # kernels whose posting loads are 8 bytes per lane
 
 
 def log(rank, *a):
@@ -83,11 +87,11 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of each CPU baseline leg")
     ap.add_argument("--query-sets", type=int, default=8, help="seeded query sets the main leg rotates through")
     ap.add_argument("--scaled-queries", type=int, default=2048,
-                    help="queries per step of the scaled_batch leg of a ONE-rank communicator run (SA_BENCH_FORCE_COMM=1); 0: off")
+                    help="queries per step of the wide_batch leg, timed at EVERY N beside the main stream (0: off)")
     ap.add_argument("--batch-mult", type=int, default=1, help=argparse.SUPPRESS)
-    ap.add_argument("--strong", action="store_true",
-                    help="N > 1: keep --queries per step whatever N (strong scaling) in the main region; default: --queries x N "
-                         "(weak scaling: the work of a GPU per step is fixed), the fixed batch is reported beside it")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; value = the median region")
+    ap.add_argument("--weak", action="store_true", help="N > 1: N x --queries per step in the main region (default: --queries at every N)")
+    ap.add_argument("--strong", action="store_true", help=argparse.SUPPRESS)     # (round 3's switch; the default now)
     ap.add_argument("--pipeline", type=int, default=6, help="batch objects (= batches in flight, one stream each) of the main leg")
     ap.add_argument("--no-phrase-legs", action="store_true", help="skip the zipf-1M phrase / slop legs")
     ap.add_argument("--phrase-docs", type=int, default=1_000_000)
@@ -237,6 +241,7 @@ class Rank:
             # one float64 log per TERM of the vocabulary, once (index-time statistics, as df itself); a batch gathers
             dfs = self.df
             self.idf_table = np.log(1 + (self.args.docs - dfs + 0.5) / (dfs + 0.5)).astype(np.float32)
+            self.index.set_idf_table(self.idf_table)         # (sa_batch_step gathers a query set's weights from it)
         return self.idf_table[queries]
 
     def make_batch(self, queries, check=True):
@@ -278,14 +283,16 @@ class Rank:
         self.barrier()
         return self.allmax(time.perf_counter() - t0)
 
-    def timed_fresh(self, ring, sets, n_warm, n_steps):
-        """The query stream: step i resets batch object i mod P to query set i mod len(sets) (idf computed here, on the
-        host), runs it and -- P steps later, before that batch object is reset again -- fetches its results: P batches
-        are in flight, each on its own stream.  n_warm untimed steps, then n_steps bracketed by barrier + synchronize;
-        max over ranks.  -> (seconds, {set: (scores, docs)})"""
+    def timed_fresh(self, ring, sets, n_warm, n_steps, repeats=1):
+        """The query stream: step i hands batch object i mod P the query set i mod len(sets) -- ONE library call per step
+        (sa_batch_step: the set's idf weights gathered from the index's table, sa_batch_reset, sa_batch_run) -- and, P steps
+        later, before that batch object is used again, fetches its results: P batches are in flight, each on its own stream.
+        n_warm untimed steps, then `repeats` timed regions of EXACTLY n_steps each, every one bracketed by barrier +
+        synchronize; max over ranks per region.  -> ([seconds per region], {set: (scores, docs)})"""
         P = len(ring)
         pending = [None] * P
         results = {}
+        sets_u32 = [np.ascontiguousarray(q, dtype=np.uint32) for q in sets]
 
         def drain(b):
             if pending[b] is not None:
@@ -296,8 +303,7 @@ class Rank:
             b = i % P
             drain(b)
             si = i % len(sets)
-            ring[b].reset(sets[si], idf=self.idf_of(sets[si]))
-            ring[b].run(sync=False)
+            ring[b].step(sets_u32[si])
             pending[b] = si
 
         for i in range(n_warm):
@@ -307,14 +313,18 @@ class Rank:
         self.barrier()
         for b in ring:
             b.profile()                                       # reset the kernel-event rings
-        self.barrier()
-        t0 = time.perf_counter()
-        for i in range(n_steps):
-            step(n_warm + i)
-        for b in range(P):
-            drain(b)
-        self.barrier()
-        return self.allmax(time.perf_counter() - t0), results
+        dts, i0 = [], n_warm
+        for _ in range(max(1, repeats)):
+            self.barrier()
+            t0 = time.perf_counter()
+            for i in range(n_steps):
+                step(i0 + i)
+            for b in range(P):
+                drain(b)
+            self.barrier()
+            dts.append(self.allmax(time.perf_counter() - t0))
+            i0 += n_steps
+        return dts, results
 
     def close(self):
         if self.index is not None:
@@ -460,15 +470,10 @@ def phrase_leg_block(side, name, phrases, slop, batch, pmc, K, cpu_s):
             "around the batch's scoring kernels (all lanes joined), mean over the timed runs")
     blk = roofline_block("sa_k_phrase_tiles (+ merge)" if slop == 0 else "sa_k_span_* per phrase + sa_k_dense_topk_tiles (+ merge)",
                          kms, wb, wb, d, note)
-    # per the bench contract: achieved = ALGORITHMIC bytes / kernel time (here it cannot exceed the peak by construction of
-    # the byte model only if the kernel really streams; the doc directory lets it read LESS, so the counter traffic and
-    # its rate are reported beside it)
-    if blk.get("traffic"):
-        blk["traffic_GBps"] = blk["achieved"]
-        blk["traffic_frac"] = blk["frac"]
-    blk["achieved"] = blk["algorithmic_GBps"]
-    blk["frac"] = round(blk["algorithmic_GBps"] / HBM_PEAK_GBS, 4)
-    blk["frac_basis"] = "algorithmic_bytes"
+    # (for a phrase batch the byte model IS the compulsory one -- every word of every phrase term once: wb is passed as both --
+    #  so `achieved` / `frac` are algorithmic bytes / kernel time as the bench contract asks; the doc directory lets the tile
+    #  route read LESS than that, which the counter traffic beside it shows)
+    blk["frac_basis"] = "algorithmic_bytes (= compulsory for a phrase batch)"
     out = {"value": round(len(phrases) * K / dt, 1), "unit": "phrases/s", "steps": K, "ms_per_step": round(dt / K * 1e3, 4),
            "workload": (f"zipf-{side.docs}: {len(phrases)} consecutive trigrams sampled from random docs -> BM25 -> top-10 (one resident phrase batch)"
                         if slop == 0 else
@@ -487,31 +492,33 @@ def compulsory_bytes(df, queries, B, k):
 
 
 def roofline_block(kernel, kernel_ms, alg_bytes, compulsory, pmc, note):
-    """bound / achieved / peak / unit / frac / traffic per the bench contract, built so that `frac` is a
-    fraction of the HBM peak that cannot exceed 1:
-      traffic      HBM bytes per launch from the PMC counters (FETCH_SIZE x calibration + WRITE_SIZE), or null
-      achieved     traffic / kernel time when the counters were collected, else compulsory bytes / kernel time
-      compulsory_bytes   distinct posting lists once + outputs; wasted = traffic / compulsory_bytes
-      algorithmic_GBps   SURVEY 8d's per-query bytes (sum_t 8 df_t + 4 n_docs, every query counted in full)
-                         over the kernel time: a THROUGHPUT (it counts bytes that caches serve), not a fraction
+    """bound / achieved / peak / unit / frac / traffic per the bench contract.  The headline `frac` is what the design
+    cannot avoid moving over the time it takes -- a fraction of the HBM peak that cannot exceed 1 and that wasted traffic
+    cannot raise:
+      compulsory_bytes   distinct posting lists of the batch once + outputs
+      achieved / frac    compulsory_bytes / kernel time (GB/s; / the 8 TB/s peak)
+      traffic            HBM bytes per launch from the PMC counters (FETCH_SIZE x the calibration of the kernel's load
+                         width + WRITE_SIZE), or null; traffic_GBps / traffic_frac = the same over the kernel time;
+                         wasted = traffic / compulsory_bytes (re-reads across the XCDs' L2s)
+      logical_*          SURVEY 8d's per-query bytes (sum_t 8 df_t + 4 n_docs, every query counted in full) over the
+                         kernel time: a LOGICAL rate -- it counts bytes that the shared first terms and the caches serve --
+                         not a bandwidth and not a fraction of anything
     """
     sec = kernel_ms * 1e-3
+    gbps = (lambda x: round(x / sec / 1e9, 1) if sec > 0 else 0.0)
     r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": kernel, "kernel_ms": round(kernel_ms, 4),
          "compulsory_bytes": int(compulsory),
-         "compulsory_GBps": round(compulsory / sec / 1e9, 1) if sec > 0 else 0.0,
-         "compulsory_frac": round(compulsory / sec / 1e9 / HBM_PEAK_GBS, 4) if sec > 0 else 0.0,
-         "algorithmic_bytes_per_launch": int(alg_bytes),
-         "algorithmic_GBps": round(alg_bytes / sec / 1e9, 1) if sec > 0 else 0.0}
+         "achieved": gbps(compulsory), "frac": round(gbps(compulsory) / HBM_PEAK_GBS, 4), "frac_basis": "compulsory_bytes",
+         "logical_bytes_per_launch": int(alg_bytes), "logical_GBps": gbps(alg_bytes)}
     if pmc and pmc.get("hbm_bytes"):
         hb = pmc["hbm_bytes"]
-        r.update({"traffic": int(hb), "traffic_source": pmc["source"], "achieved": round(hb / sec / 1e9, 1),
-                  "frac": round(hb / sec / 1e9 / HBM_PEAK_GBS, 4), "frac_basis": "traffic",
+        r.update({"traffic": int(hb), "traffic_source": pmc["source"], "traffic_GBps": gbps(hb),
+                  "traffic_frac": round(gbps(hb) / HBM_PEAK_GBS, 4),
                   "wasted": round(hb / compulsory, 3) if compulsory else None,
                   "l2_hit_rate": pmc.get("l2_hit_rate"), "fetch_calibration": pmc.get("fetch_calibration"),
                   "pmc_kernel_ms": pmc.get("kernel_ms")})
     else:
-        r.update({"traffic": None, "traffic_source": None, "achieved": r["compulsory_GBps"], "frac": r["compulsory_frac"],
-                  "frac_basis": "compulsory_bytes"})
+        r.update({"traffic": None, "traffic_source": None})
     r["note"] = note
     return r
 
@@ -530,6 +537,9 @@ def pmc_child(r, legs):
     import ctypes
     g = ctypes.c_double(0)
     r.api.call("sa_stream_probe", CALIB_BYTES, 1, 1, ctypes.byref(g))
+    # the same byte count read with 8-byte loads (the width of the scoring kernels' posting loads): the marker kernel with a
+    # big argument, right in front of the first marker (consecutive markers count as one)
+    r.api.call("sa_stream_probe", CALIB_BYTES, 0, 1, ctypes.byref(g))
     for name, batch, sparse in legs:
         if sparse is not None:
             os.environ["SA_SPARSE"] = sparse
@@ -602,6 +612,9 @@ def parse_pmc_csv(path, leg_names):
     if calib:
         for cname in calib[-1]["c"]:
             out["calib"][cname] = calib[-1]["c"][cname]           # the second (warm) dispatch
+    # 8-byte-load calibration: the marker kernel's dispatches over CALIB_BYTES (the plain markers read 1 MiB)
+    calib8 = [e for e in seq if e["kernel"].startswith(MARKER) and e["c"].get("FETCH_SIZE", 0.0) * 1024.0 > CALIB_BYTES / 8]
+    out["calib8"] = dict(calib8[-1]["c"]) if calib8 else {}
     started = False
     for e in seq:
         name = e["kernel"]
@@ -630,6 +643,12 @@ def merge_pmc(per_pass, leg_names):
     factor = (CALIB_BYTES / (raw * 1024.0)) if raw else 2.0
     if not (1.0 <= factor <= 4.0):
         factor = 2.0
+    # ... and on the same read with 8-byte loads: the width of the posting loads of the grouped / head-group kernels (their
+    # dense base rows are 16-byte loads: the smaller part of their traffic)
+    raw8 = fetch.get("calib8", {}).get("FETCH_SIZE")
+    factor8 = (CALIB_BYTES / (raw8 * 1024.0)) if raw8 else factor
+    if not (0.5 <= factor8 <= 4.0):
+        factor8 = factor
     res = {}
     for leg in leg_names:
         f, w = fetch.get(leg, {}), write.get(leg, {})
@@ -640,17 +659,19 @@ def merge_pmc(per_pass, leg_names):
             hit, miss = sum(w.get(kname, {}).get("TCC_HIT_sum", [])), sum(w.get(kname, {}).get("TCC_MISS_sum", []))
             n = max(len(fv), len(wv), 1)
             per_step = n / PMC_STEPS                               # dispatches of this kernel per step
-            fb = (sum(fv) / len(fv) * 1024.0 * factor) if fv else 0.0
+            kf = factor8 if kname.startswith(LOADS_8B) else factor
+            fb = (sum(fv) / len(fv) * 1024.0 * kf) if fv else 0.0
             wb = (sum(wv) / len(wv) * 1024.0) if wv else 0.0
             durs = f.get("_dur", {}).get(kname, [])
             kernels[kname] = {"hbm_bytes_per_dispatch": int(fb + wb), "dispatches_per_step": round(per_step, 2),
-                              "fetch_KiB_raw": round(sum(fv) / len(fv), 1) if fv else None,
+                              "fetch_KiB_raw": round(sum(fv) / len(fv), 1) if fv else None, "fetch_factor": round(kf, 3),
                               "write_KiB_raw": round(sum(wv) / len(wv), 1) if wv else None,
                               "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss > 0 else None,
                               "ms_under_pmc": round(sum(durs) / len(durs) / 1e6, 4) if durs else None}
-        res[leg] = {"kernels": kernels, "fetch_calibration": round(factor, 3),
+        res[leg] = {"kernels": kernels, "fetch_calibration": {"16B_loads": round(factor, 3), "8B_loads": round(factor8, 3)},
                     "source": "rocprofv3 --pmc child runs of this bench.py invocation (FETCH_SIZE | WRITE_SIZE TCC_HIT_sum "
-                              "TCC_MISS_sum, kernel trace only); FETCH_SIZE x calibration measured on a 1 GiB 16-byte-load stream"}
+                              "TCC_MISS_sum, kernel trace only); FETCH_SIZE x a calibration measured on a 1 GiB stream read with "
+                              "the kernel's load width (8-byte loads: grouped / head-group kernels; 16-byte loads: the others)"}
     return res
 
 
@@ -824,12 +845,13 @@ def main():
     rank, world = r.rank, r.world
     from searcharray_amd import synth
     D, V, Bq, K, W = args.docs, args.vocab, args.queries, args.steps, args.warmup
-    # N > 1: every rank scores EVERY query of a batch on its 1/N of the docs, so with a fixed batch a rank's device work
-    # per step shrinks with N while the host's cost per batch (idf gather, reset, ~15 enqueues, fetch) does not.  The main
-    # region therefore takes N x --queries per step -- the work of a GPU per step is what it is at N = 1: WEAK scaling --
-    # and the fixed batch (strong scaling) is timed beside it; --strong swaps the two.
+    # N > 1: every rank scores EVERY query of a batch on its 1/N of the docs.  The main region keeps --queries per step at
+    # every N (the same stream as N = 1: value(N) / value(1) is a like-for-like speed-up), and a WIDE batch (--scaled-queries,
+    # 2048) is timed beside it at every N too -- N = 1 included -- because a rank's device work per step shrinks with N while
+    # the host's cost per batch does not: wide_batch(N) / wide_batch(1) is the same-batch speed-up of a deployment that
+    # batches wider.  Nothing is ever divided across batch sizes.  (--weak: N x --queries in the main region.)
     mult = max(world, args.batch_mult)                      # (--batch-mult: the N > 1 batch logic on one GPU, for testing)
-    weak = mult > 1 and not args.strong
+    weak = mult > 1 and args.weak
     B = Bq * mult if weak else Bq
     r.generate()
     phrase_legs_on = world == 1 and not r.use_comm and not args.no_phrase_legs
@@ -886,7 +908,9 @@ def main():
     os.environ["SA_SPARSE"] = "0" if exhaustive else "1"
     P = max(1, args.pipeline if B <= 1024 else min(args.pipeline, 4))
     pair = [r.make_batch(sets[i % len(sets)], check=(i == 0)) for i in range(P)]
-    dt, fresh_results = r.timed_fresh(pair, sets, max(W, P), K)
+    R = max(1, args.repeats)
+    dts, fresh_results = r.timed_fresh(pair, sets, max(W, P), K, repeats=R)
+    dt = float(np.median(dts))
     # (HIP events around one batch's scoring kernels: with P batches in flight on P streams they overlap the other
     #  batches' kernels, so this is a batch's latency share, not the device time per step -- the replay leg's is)
     kernel_ms_fresh = float(np.mean([b.profile()[0] for b in pair]))
@@ -902,19 +926,20 @@ def main():
         scores, docs = scores_r, docs_r
     fresh_equals_replay = bool(np.array_equal(scores, scores_r) and np.array_equal(docs, docs_r))
 
-    # the other batch size of a sharded run, as a fresh stream too: the fixed batch beside the scaled one (N > 1), or the
-    # scaled one beside the fixed one (one-rank communicator runs, --strong)
+    # the WIDE batch as a fresh stream too, at every N (and, with --weak, the fixed batch beside the scaled one)
     scaled = None
-    B2 = Bq if weak else (args.scaled_queries if r.use_comm or args.batch_mult > 1 else 0)
+    B2 = Bq if weak else args.scaled_queries
     if B2 and B2 != B:
         sets2 = [query_set(20 + i, B2) for i in range(4)]
         ring2 = [r.make_batch(sets2[i % len(sets2)], check=False) for i in range(min(args.pipeline, 4) if B2 > 1024 else max(1, args.pipeline))]
         Ks = K if B2 <= B else max(4, K // 4)
-        dts, _ = r.timed_fresh(ring2, sets2, len(ring2), Ks)
-        scaled = {"value": round(B2 * Ks / dts, 2), "unit": "queries/s", "queries_per_step": B2, "steps": Ks,
-                  "ms_per_step": round(dts / Ks * 1e3, 4), "batches_in_flight": len(ring2),
-                  "scaling": "strong" if weak else "weak",
-                  "note": "the same fresh-batch stream (rotating sets, reset + run + fetch per step) with the other batch size, same index"}
+        dts2, _ = r.timed_fresh(ring2, sets2, len(ring2), Ks, repeats=3)
+        d2 = float(np.median(dts2))
+        scaled = {"value": round(B2 * Ks / d2, 2), "unit": "queries/s", "queries_per_step": B2, "steps": Ks,
+                  "ms_per_step": round(d2 / Ks * 1e3, 4), "ms_per_step_min_max": [round(min(dts2) / Ks * 1e3, 4), round(max(dts2) / Ks * 1e3, 4)],
+                  "batches_in_flight": len(ring2), "n_gpus": world,
+                  "note": "the same fresh-batch stream (rotating sets, one sa_batch_step + fetch per step) with the other batch size, "
+                          "same index; compare with the SAME leg of the N = 1 line, never with `value`"}
         for b in ring2:
             b.close()
 
@@ -982,7 +1007,14 @@ def main():
         phrase_out["slop_batch"] = phrase_leg_block(side, "slop_batch", side.slop2, 2, side.sb, pmc, K2, cpu_s)
         phrase_out["single_phrase_queries"] = side.single_queries(cpu_s)
 
+    if cpu is not None:
+        cpu["parity"] = parity                               # (inside cpu_baseline too: the checker that timed it is the one that compared)
     if rank == 0:
+        from searcharray_amd.device_index import DeviceIndex
+        try:
+            comm_lib = DeviceIndex.comm_library_info(r.api)
+        except Exception as e:                               # noqa: BLE001
+            comm_lib = (None, f"{type(e).__name__}: {e}")
         n_tiles = int(r.info.n_tiles)
         exh_ms, prn_ms = (kernel_ms, kernel_ms2) if exhaustive else (kernel_ms2, kernel_ms)
         comp = compulsory_bytes(r.df if world == 1 else r.index.docfreqs(), queries, B, args.k)
@@ -1011,6 +1043,9 @@ def main():
             "metric": "queries/sec, 4-term disjunctive BM25 + top-k over 10M synthetic Zipf docs",
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak" if weak else "strong",
+            "repeats": {"regions": R, "steps_per_region": K, "value_from": "median region",
+                        "ms_per_step_min": round(min(dts) / K * 1e3, 4), "ms_per_step_median": round(dt / K * 1e3, 4),
+                        "ms_per_step_max": round(max(dts) / K * 1e3, 4)},
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"zipf-{D} (V={V}, Poisson(32) doc lengths, seed 1234) sharded by doc-id range, "
                                    f"FRESH batches: {len(sets)} rotating seeded sets of {B} x 4-term disjunctive BM25 queries "
@@ -1022,7 +1057,8 @@ def main():
                        "batches_in_flight": P,
                        "distinct_terms_in_batch": int(len(np.unique(queries))),
                        "tile_docs": int(r.info.tile_docs), "parallelism": f"doc-range shards x{world}",
-                       "collective": r.collective, "launcher": "torch-free: ranks rendezvous through an id file, "
+                       "collective": r.collective, "collective_library": dict(zip(("nccl_version", "path"), comm_lib)),
+                       "launcher": "torch-free: ranks rendezvous through an id file, "
                                                                "collectives = libsearcharray_hip.so's RCCL communicator"},
             "postings_scanned_GBps": round(post_total * K / dt / 1e9, 2),
             "fresh_batch_latency_ms": round(kernel_ms_fresh, 4),
@@ -1031,7 +1067,7 @@ def main():
                        "fresh_equals_replay": fresh_equals_replay,
                        "note": "set 0 resident, sa_batch_run only -- no reset, no fetch (rounds 1-2 reported this as `value`)"},
             "roofline": exh_block if exhaustive else prn_block,
-            ("fixed_batch" if weak else "scaled_batch"): scaled,
+            ("fixed_batch" if weak else "wide_batch"): scaled,
             ("dynamic_pruning" if exhaustive else "exhaustive"): other,
             "cpu_baseline": cpu,
             "parity_check": parity,

@@ -288,6 +288,12 @@ int sa_batch_run(sa_batch_t* batch, int sync);
  * [nranks][B][k] (DEVICE pointer) into the final top-k. */
 int sa_batch_run_local(sa_batch_t* batch, void* local_keys_out_device, int sync);
 int sa_batch_merge_gathered(sa_batch_t* batch, const void* gathered_keys_device, int nranks, int sync);
+/* One step of a query STREAM in ONE call: a new query set (terms u32[B][T]) is weighted from the index's idf table
+ * (sa_index_set_idf_table: one float32 per term, formed by the host exactly as similarity.py:19-21 forms it -- the
+ * per-step gather is the only arithmetic-free part and moves into the library), then sa_batch_reset + sa_batch_run
+ * (sync = 0).  What the caller loop score() -> top-k is per query (postings.py:652-680), per batch. */
+int sa_index_set_idf_table(sa_index_t* ix, const float* idf_per_term, uint32_t n_terms);
+int sa_batch_step(sa_batch_t* batch, const uint32_t* terms);
 /* Results to the host: scores f32[B][k], docs u64[B][k].  Every sa_batch_run ends with an asynchronous copy of its
  * B*k keys into a page-locked buffer of the batch; fetch waits for THAT copy only (not for the streams), so other
  * batches of the index keep running behind it. */
@@ -329,6 +335,32 @@ int sa_index_info(sa_index_t* ix, sa_index_info_t* out);
  * rows must stay valid until it returns.  rows == NULL clears a pending selection. */
 int sa_index_select_rows(sa_index_t* ix, const uint64_t* rows, uint64_t n_rows);
 
+/* The same WITHOUT state between calls: every dense call above has a `_to` twin that takes its destination as an argument --
+ * `rows` != NULL: out[i] = dense[rows[i]] for i < n_rows (the subset of sa_index_select_rows); `vec` != NULL: the result
+ * (x boost if has_boost) goes into that device vector (Part 4, sa_index_select_vec) and `out` is not written; both NULL (or
+ * dest == NULL): the whole vector into `out`.  A binder in any language can use these alone; the select calls stay for
+ * callers that already use them. */
+typedef struct sa_dense_dest {
+    const uint64_t* rows; uint64_t n_rows;      /* subset of the docs, gathered on the device */
+    struct sa_vec* vec; float boost; int has_boost;   /* or: a float32 device vector */
+} sa_dense_dest_t;
+int sa_index_termfreqs_dense_to(sa_index_t* ix, uint32_t term, const sa_dense_dest_t* dest, float* out);
+int sa_index_termfreqs_dense_posn_to(sa_index_t* ix, uint32_t term, int64_t min_posn, int64_t max_posn,
+                                     const sa_dense_dest_t* dest, float* out);
+int sa_index_bm25_dense_to(sa_index_t* ix, const uint32_t* terms, const float* idf, int n_query_terms, float k1, float b,
+                           const sa_dense_dest_t* dest, float* out);
+int sa_index_phrase_freqs_dense_to(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop,
+                                   const sa_dense_dest_t* dest, float* out);
+int sa_index_phrase_freqs_dense_posn_to(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop, int64_t min_posn,
+                                        int64_t max_posn, const sa_dense_dest_t* dest, float* out);
+int sa_index_bm25_phrase_dense_to(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop, float idf, float k1, float b,
+                                  const sa_dense_dest_t* dest, float* out);
+int sa_index_bm25_phrase_dense_posn_to(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop, int64_t min_posn,
+                                       int64_t max_posn, float idf, float k1, float b, const sa_dense_dest_t* dest, float* out);
+int sa_index_similarity_dense_to(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop, int64_t min_posn,
+                                 int64_t max_posn, int kind, double idf, double k1, double b, const sa_dense_dest_t* dest,
+                                 void* out);
+
 /* Page-locked host buffers for dense results (optional): any host pointer works as `out` of the
  * dense calls above; a buffer from sa_host_alloc is filled at full PCIe rate and can be recycled by
  * the binding without first-touch page faults (searcharray_amd/device_index.py keeps a small pool). */
@@ -343,6 +375,9 @@ int sa_host_free(void* p);
  * idf.  The only collective is an all-gather of B*k 8-byte ranking keys per batch. */
 #define SA_COMM_ID_BYTES 128
 int sa_comm_unique_id(char* id_out, int len);                    /* rank 0: ncclGetUniqueId */
+/* which collective library this process resolved: ncclGetVersion() and the path of the shared object that provides it
+ * (benchmarks record both: an environment can put another RCCL in front of /opt/rocm's) */
+int sa_comm_library_info(int* version_out, char* path_out, int path_len);
 int sa_index_comm_init(sa_index_t* ix, int rank, int nranks, const char* id_bytes, int len);
 int sa_index_comm_destroy(sa_index_t* ix);
 /* rank / number of ranks of the index's communicator (0 / 1 without one) */

@@ -71,6 +71,35 @@ def main():
     out.update({"docs": D, "queries": B, "comm": args.comm, "us_per_step_total": round(total / args.steps * 1e6, 1),
                 "unit": "microseconds of host time per step (fetch includes waiting for the device)"})
     print(json.dumps(out))
+    # the same stream through ONE library call per step (sa_batch_step: idf gathered from the index's table inside)
+    dfs = df.astype(np.float64)
+    index.set_idf_table(np.log(1 + (D - dfs + 0.5) / (dfs + 0.5)).astype(np.float32))
+    sets_u32 = [np.ascontiguousarray(q, dtype=np.uint32) for q in sets]
+    for b in (0, 1):
+        pair[b].fetch()
+    ts = {"step": 0.0, "fetch": 0.0}
+    pend = [False, False]
+    for phase in ("warm", "timed"):
+        n = 20 if phase == "warm" else args.steps
+        ts = {"step": 0.0, "fetch": 0.0}
+        index.synchronize()
+        t00 = time.perf_counter()
+        for i in range(n):
+            b = i & 1
+            t0 = time.perf_counter()
+            if pend[b]:
+                pair[b].fetch()
+            t1 = time.perf_counter()
+            pair[b].step(sets_u32[i % 8])
+            t2 = time.perf_counter()
+            pend[b] = True
+            ts["fetch"] += t1 - t0; ts["step"] += t2 - t1
+        index.synchronize()
+        total = time.perf_counter() - t00
+    out = {k_: round(v / args.steps * 1e6, 1) for k_, v in ts.items()}
+    out.update({"docs": D, "queries": B, "comm": args.comm, "us_per_step_total": round(total / args.steps * 1e6, 1),
+                "call": "sa_batch_step (idf gather + reset + run in one call)"})
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -36,6 +36,11 @@ class IndexInfo(ctypes.Structure):
 
 
 # name -> (restype, argtypes).  Every symbol declared in include/searcharray_hip.h.
+class DenseDest(ctypes.Structure):
+    """sa_dense_dest_t (include/searcharray_hip.h): where a `_to` dense call puts its result"""
+    _fields_ = [("rows", POINTER(c_uint64)), ("n_rows", c_uint64), ("vec", c_void_p), ("boost", c_float), ("has_boost", c_int)]
+
+
 PROTOTYPES = {
     "sa_last_error": (c_char_p, []),
     "sa_abi_version": (c_int, []),
@@ -95,6 +100,9 @@ PROTOTYPES = {
     "sa_batch_merge_gathered": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "sa_batch_fetch": (c_int, [c_void_p, f32p, u64p]),
     "sa_batch_profile": (c_int, [c_void_p, POINTER(c_double), u64p, u64p]),
+    "sa_index_set_idf_table": (c_int, [c_void_p, f32p, c_uint32]),
+    "sa_batch_step": (c_int, [c_void_p, u32p]),
+    "sa_comm_library_info": (c_int, [POINTER(c_int), ctypes.c_char_p, c_int]),
     "sa_batch_group_info": (c_int, [c_void_p, POINTER(c_uint32)]),
     "sa_batch_headgroup_info": (c_int, [c_void_p, POINTER(c_uint32)]),
     "sa_batch_stats": (c_int, [c_void_p, c_int, u64p, u64p]),
@@ -138,6 +146,13 @@ PROTOTYPES = {
     "sa_index_comm_allreduce": (c_int, [c_void_p, c_void_p, c_uint64, c_int, c_int]),
     "sa_index_comm_barrier": (c_int, [c_void_p]),
 }
+
+# the dense calls with an explicit destination: `name`_to(ix, <args of `name` without out>, const sa_dense_dest_t*, out)
+for _n in ("sa_index_termfreqs_dense", "sa_index_termfreqs_dense_posn", "sa_index_bm25_dense", "sa_index_phrase_freqs_dense",
+           "sa_index_phrase_freqs_dense_posn", "sa_index_bm25_phrase_dense", "sa_index_bm25_phrase_dense_posn",
+           "sa_index_similarity_dense"):
+    _r, _a = PROTOTYPES[_n]
+    PROTOTYPES[_n + "_to"] = (_r, _a[:-1] + [POINTER(DenseDest), _a[-1]])
 
 
 class HipApi:

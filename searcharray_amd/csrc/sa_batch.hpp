@@ -20,6 +20,7 @@ struct sa_batch {
     u32 B = 0, T = 0, k = 0;
     float k1 = 1.2f, b = 0.75f;
     std::vector<u32> perm;          // device row r holds caller query perm[r] (results: caller order)
+    std::vector<float> step_idf;    // sa_batch_step: the query set's weights, gathered from the index's idf table
     // Everything a NEW set of queries changes on the device is one contiguous UPLOAD BLOCK (d_up) with a
     // page-locked host image: sa_batch_reset fills the image and enqueues ONE hipMemcpyAsync (+ the slice-table
     // kernel) -- no allocation, no blocking copy, no synchronisation.  The pointers below (d_terms ... d_bloom_off
@@ -37,6 +38,7 @@ struct sa_batch {
     hipEvent_t ev_final = nullptr;  // d_final written (the stream of the last merge)
     hipEvent_t ev_res = nullptr;    // h_res written (exchange stream)
     bool res_pending = false;
+    bool unfetched = false;         // a run's results have been queued for the host and not been fetched yet
     u32* d_xflag = nullptr;         // sharded: OR over the ranks of the overflow flags (travels with the all-gather); behind d_final
     u32 wl_cap = 0;                 // entries of d_wl
     size_t bloom_cap = 0;           // bytes of d_bloom (worst case of this shard, allocated by the first pruned run)

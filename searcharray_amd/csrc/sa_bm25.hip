@@ -2181,7 +2181,18 @@ extern "C" int sa_batch_reset(sa_batch_t* bt, const uint32_t* terms, const float
     sa_index* ix = bt->ix;
     std::lock_guard<std::mutex> g(ix->mu);
     SA_HIP(hipSetDevice(ix->device));
+    // a run whose results have not been fetched: its merge (on the exchange stream when sharded) still reads the row order this
+    // reset replaces -- wait for that run's result copy first (landed long ago in the run / fetch / reset idiom: no cost there)
+    if (bt->res_pending && bt->unfetched) SA_HIP(hipEventSynchronize(bt->ev_res));
     return sa_batch_fill(bt, terms, idf);
+}
+
+extern "C" int sa_index_set_idf_table(sa_index_t* ix, const float* idf_per_term, uint32_t n_terms) {
+    SA_ARG(ix && (idf_per_term || n_terms == 0), "null argument");
+    SA_ARG(n_terms == ix->n_terms, "one idf per term of the index");
+    std::lock_guard<std::mutex> g(ix->mu);
+    ix->h_idf.assign(idf_per_term, idf_per_term + n_terms);
+    return SA_OK;
 }
 
 // regroup an all-gather result [rank][B*k (+ extra)] into per-query candidate rows [B][rank*k]; `extra` = 1: every
@@ -2411,6 +2422,7 @@ static int sa_batch_queue_result_copy(sa_batch* bt, hipStream_t src_stream) {
     SA_HIP(hipMemcpyAsync(bt->h_res, bt->d_final, n * sizeof(u64), hipMemcpyDeviceToHost, src_stream));
     SA_HIP(hipEventRecord(bt->ev_res, src_stream));
     bt->res_pending = true;
+    bt->unfetched = true;
     return SA_OK;
 }
 
@@ -2473,6 +2485,24 @@ extern "C" int sa_batch_run(sa_batch_t* bt, int sync) {
     return SA_OK;
 }
 
+// One step of a query stream in one call: idf gathered from the index's table, reset, run (header, Part 2).
+extern "C" int sa_batch_step(sa_batch_t* bt, const uint32_t* terms) {
+    SA_ARG(bt && bt->ix && terms, "null argument");
+    SA_ARG(bt->kind == 0, "sa_batch_step takes a BM25 batch");
+    sa_index* ix = bt->ix;
+    {
+        std::lock_guard<std::mutex> g(ix->mu);
+        SA_ARG(ix->h_idf.size() == ix->n_terms, "sa_index_set_idf_table has not been called");
+        SA_HIP(hipSetDevice(ix->device));
+        const size_t n = (size_t)bt->B * bt->T;
+        bt->step_idf.resize(n);
+        for (size_t i = 0; i < n; i++) bt->step_idf[i] = terms[i] < ix->n_terms ? ix->h_idf[terms[i]] : 0.f;
+        if (bt->res_pending && bt->unfetched) SA_HIP(hipEventSynchronize(bt->ev_res));
+        SA_TRY(sa_batch_fill(bt, terms, bt->step_idf.data()));
+    }
+    return sa_batch_run(bt, 0);
+}
+
 // External-collective variant (the caller owns the exchange, e.g. torch.distributed over RCCL,
 // or gloo in the CPU tests): run this shard, hand out its top-k keys, merge gathered keys.
 extern "C" int sa_batch_run_local(sa_batch_t* bt, void* local_keys_out_device, int sync) {
@@ -2480,6 +2510,7 @@ extern "C" int sa_batch_run_local(sa_batch_t* bt, void* local_keys_out_device, i
     sa_index* ix = bt->ix;
     std::lock_guard<std::mutex> g(ix->mu);
     SA_HIP(hipSetDevice(ix->device));
+    bt->res_pending = false;                           // (the external-collective route: fetch reads d_final, not the page-locked copy of an earlier sa_batch_run)
     SA_TRY(sa_batch_run_shard(bt, bt->d_local, false));
     if (local_keys_out_device)
         SA_HIP(hipMemcpyAsync(local_keys_out_device, bt->d_local, (size_t)bt->B * bt->k * sizeof(u64),
@@ -2497,6 +2528,7 @@ extern "C" int sa_batch_merge_gathered(sa_batch_t* bt, const void* gathered_keys
     sa_index* ix = bt->ix;
     std::lock_guard<std::mutex> g(ix->mu);
     SA_HIP(hipSetDevice(ix->device));
+    bt->res_pending = false;
     SA_TRY(sa_batch_merge_ranks(bt, (const u64*)gathered_keys_device, nranks, bt->st));
     if (sync) {
         SA_HIP(hipStreamSynchronize(bt->st));
@@ -2517,6 +2549,7 @@ extern "C" int sa_batch_fetch(sa_batch_t* bt, float* scores_out, uint64_t* docs_
         // the usual route (sa_batch_run): wait for THIS batch's result copy, nothing else -- other batches of the
         // index may be in flight behind it
         SA_HIP(hipEventSynchronize(bt->ev_res));
+        bt->unfetched = false;
         const u32 over = (u32)bt->h_res[n + (ix->comm ? 1 : 0)];
         if (over) {
             // A run overflowed a candidate list (only possible when the bound could not rise: degenerate score

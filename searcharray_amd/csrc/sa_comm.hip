@@ -9,6 +9,7 @@
 #include "sa_index.hpp"
 #include "../../include/searcharray_hip.h"
 #include <rccl/rccl.h>
+#include <dlfcn.h>
 #include <new>
 
 struct sa_comm {
@@ -32,6 +33,23 @@ extern "C" int sa_comm_unique_id(char* id_out, int len) {
     ncclUniqueId id;
     SA_NCCL(ncclGetUniqueId(&id));
     memcpy(id_out, &id, sizeof(id));
+    return SA_OK;
+}
+
+extern "C" int sa_comm_library_info(int* version_out, char* path_out, int path_len) {
+    if (version_out) {
+        int v = 0;
+        SA_NCCL(ncclGetVersion(&v));
+        *version_out = v;
+    }
+    if (path_out && path_len > 0) {
+        path_out[0] = 0;
+        Dl_info info;
+        if (dladdr((void*)&ncclGetVersion, &info) && info.dli_fname) {
+            strncpy(path_out, info.dli_fname, (size_t)path_len - 1);
+            path_out[path_len - 1] = 0;
+        }
+    }
     return SA_OK;
 }
 

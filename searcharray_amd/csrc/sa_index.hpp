@@ -96,6 +96,7 @@ struct sa_index {
     u32* d_tf8_slot = nullptr;       // [n_terms] row of a term, or SA_DD_NONE
 
     std::vector<u64> h_term_off, h_tf_off;
+    std::vector<float> h_idf;        // idf of every term as the host formed it (sa_index_set_idf_table; sa_batch_step gathers from it)
     std::vector<u32> h_dd_slot;      // host copy of d_dd_slot
     std::vector<unsigned char> h_term_edge;   // [n_terms] bit 0: first word has header 0, bit 1: last word has the largest header
     bool any_top_block = true;       // some word of the index sits in a document's LAST 18-position block (positions >= 4.7 M:

@@ -15,6 +15,7 @@
 #include "../../include/searcharray_hip.h"
 
 #include <condition_variable>
+#include <algorithm>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -93,6 +94,10 @@ struct sa_sharded {
     std::vector<u64> df;                     // global document frequencies
     bool comm = false;
     std::vector<std::unique_ptr<Worker>> workers;
+    // batches created on this handle and not destroyed yet: sa_sharded_destroy takes their per-shard parts down with the
+    // shards and orphans them (sh = null: every later call on such a batch is refused, its destroy only frees the shell)
+    std::mutex live_mu;
+    std::vector<struct sa_sharded_batch*> live;
 
     // fn(g) on every shard's thread; the first failure's code and message are the call's
     int all(const std::function<int(int)>& fn) {
@@ -119,6 +124,13 @@ struct sa_sharded_batch {
 extern "C" int sa_sharded_destroy(sa_sharded_t* sh) {
     if (!sh) return SA_OK;
     if (!sh->workers.empty()) {
+        std::vector<sa_sharded_batch*> live;
+        { std::lock_guard<std::mutex> g(sh->live_mu); live.swap(sh->live); }
+        for (sa_sharded_batch* bt : live) {
+            sh->all([&](int g) { return bt->parts[(size_t)g] ? sa_batch_destroy(bt->parts[(size_t)g]) : SA_OK; });
+            bt->parts.assign(bt->parts.size(), nullptr);
+            bt->sh = nullptr;
+        }
         if (sh->comm) sh->all([sh](int g) { return sh->shards[(size_t)g] ? sa_index_comm_destroy(sh->shards[(size_t)g]) : SA_OK; });
         sh->all([sh](int g) { return sh->shards[(size_t)g] ? sa_index_destroy(sh->shards[(size_t)g]) : SA_OK; });
         for (auto& w : sh->workers) w->stop();
@@ -229,6 +241,7 @@ static int sa_sharded_batch_finish(sa_sharded* sh, sa_sharded_batch* bt, int rc,
     bt->B = (u32)B; bt->k = (u32)k;
     bt->scores.assign((size_t)sh->G, std::vector<float>((size_t)B * (size_t)k));
     bt->docs.assign((size_t)sh->G, std::vector<uint64_t>((size_t)B * (size_t)k));
+    { std::lock_guard<std::mutex> g(sh->live_mu); sh->live.push_back(bt); }
     *out = bt;
     return SA_OK;
 }
@@ -285,7 +298,10 @@ extern "C" int sa_sharded_batch_fetch(sa_sharded_batch_t* bt, float* scores_out,
 
 extern "C" int sa_sharded_batch_destroy(sa_sharded_batch_t* bt) {
     if (!bt) return SA_OK;
-    if (bt->sh) bt->sh->all([&](int g) { return bt->parts[(size_t)g] ? sa_batch_destroy(bt->parts[(size_t)g]) : SA_OK; });
+    if (bt->sh) {
+        { std::lock_guard<std::mutex> g(bt->sh->live_mu); auto& l = bt->sh->live; l.erase(std::remove(l.begin(), l.end(), bt), l.end()); }
+        bt->sh->all([&](int g) { return bt->parts[(size_t)g] ? sa_batch_destroy(bt->parts[(size_t)g]) : SA_OK; });
+    }
     delete bt;
     return SA_OK;
 }

@@ -253,3 +253,65 @@ bool sa_emit_to_vec(sa_index* ix, const float* d_vec) {
     else hipMemsetAsync(v->d, 0, (size_t)v->n * 4, ix->stream);
     return true;
 }
+
+
+// ---- the dense calls with an explicit destination (header: sa_dense_dest_t): the subset / device-vector routes without a
+//      selection that outlives a call.  The selection mechanism underneath is per thread and is armed and consumed inside one
+//      call here; a failed call disarms it.
+static int sa_dest_arm(sa_index_t* ix, const sa_dense_dest_t* d) {
+    if (!d) return SA_OK;
+    SA_ARG(!(d->rows && d->vec), "sa_dense_dest: rows or vec, not both");
+    if (d->vec) return sa_index_select_vec(ix, d->vec, d->boost, d->has_boost);
+    if (d->rows) return sa_index_select_rows(ix, d->rows, d->n_rows);
+    return SA_OK;
+}
+static int sa_dest_done(sa_index_t* ix, const sa_dense_dest_t* d, int rc) {
+    if (rc != SA_OK && d) {
+        const std::string keep = sa_last_error();
+        if (d->vec) sa_index_select_vec(ix, nullptr, 1.f, 0);
+        if (d->rows) sa_index_select_rows(ix, nullptr, 0);
+        sa_set_error("%s", keep.c_str());
+    }
+    return rc;
+}
+#define SA_TO(call)                                   \
+    SA_ARG(ix, "null index");                         \
+    float dummy_ = 0.f;                               \
+    void* out_ = (dest && dest->vec) ? (void*)&dummy_ : (void*)out; \
+    (void)out_;                                       \
+    SA_TRY(sa_dest_arm(ix, dest));                    \
+    return sa_dest_done(ix, dest, call)
+
+extern "C" int sa_index_termfreqs_dense_to(sa_index_t* ix, uint32_t term, const sa_dense_dest_t* dest, float* out) {
+    SA_TO(sa_index_termfreqs_dense(ix, term, (float*)out_));
+}
+extern "C" int sa_index_termfreqs_dense_posn_to(sa_index_t* ix, uint32_t term, int64_t min_posn, int64_t max_posn,
+                                                const sa_dense_dest_t* dest, float* out) {
+    SA_TO(sa_index_termfreqs_dense_posn(ix, term, min_posn, max_posn, (float*)out_));
+}
+extern "C" int sa_index_bm25_dense_to(sa_index_t* ix, const uint32_t* terms, const float* idf, int n_query_terms, float k1, float b,
+                                      const sa_dense_dest_t* dest, float* out) {
+    SA_TO(sa_index_bm25_dense(ix, terms, idf, n_query_terms, k1, b, (float*)out_));
+}
+extern "C" int sa_index_phrase_freqs_dense_to(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop,
+                                              const sa_dense_dest_t* dest, float* out) {
+    SA_TO(sa_index_phrase_freqs_dense(ix, terms, n_terms, slop, (float*)out_));
+}
+extern "C" int sa_index_phrase_freqs_dense_posn_to(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop, int64_t min_posn,
+                                                   int64_t max_posn, const sa_dense_dest_t* dest, float* out) {
+    SA_TO(sa_index_phrase_freqs_dense_posn(ix, terms, n_terms, slop, min_posn, max_posn, (float*)out_));
+}
+extern "C" int sa_index_bm25_phrase_dense_to(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop, float idf, float k1,
+                                             float b, const sa_dense_dest_t* dest, float* out) {
+    SA_TO(sa_index_bm25_phrase_dense(ix, terms, n_terms, slop, idf, k1, b, (float*)out_));
+}
+extern "C" int sa_index_bm25_phrase_dense_posn_to(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop, int64_t min_posn,
+                                                  int64_t max_posn, float idf, float k1, float b, const sa_dense_dest_t* dest,
+                                                  float* out) {
+    SA_TO(sa_index_bm25_phrase_dense_posn(ix, terms, n_terms, slop, min_posn, max_posn, idf, k1, b, (float*)out_));
+}
+extern "C" int sa_index_similarity_dense_to(sa_index_t* ix, const uint32_t* terms, int n_terms, int slop, int64_t min_posn,
+                                            int64_t max_posn, int kind, double idf, double k1, double b,
+                                            const sa_dense_dest_t* dest, void* out) {
+    SA_TO(sa_index_similarity_dense(ix, terms, n_terms, slop, min_posn, max_posn, kind, idf, k1, b, out_));
+}

@@ -244,6 +244,21 @@ class DeviceIndex:
             self._local_df = out
         return self._local_df
 
+    def set_idf_table(self, idf: np.ndarray):
+        """one float32 idf per term, formed by the caller as the reference forms it (similarity.py:19-21);
+        ``QueryBatch.step`` gathers a query set's weights from it inside the library"""
+        t = as_f32(idf)
+        self.api.call("sa_index_set_idf_table", self._h, p_f32(t), len(t))
+
+    @staticmethod
+    def comm_library_info(api=None):
+        """(ncclGetVersion(), path of the shared object that provides the collectives in this process)"""
+        api = api or _lib.api()
+        ver = ctypes.c_int(0)
+        buf = ctypes.create_string_buffer(1024)
+        api.call("sa_comm_library_info", ctypes.byref(ver), buf, 1024)
+        return int(ver.value), buf.value.decode(errors="replace")
+
     def set_global_docfreqs(self, df: np.ndarray):
         """Sharded operation: BM25 idf must use corpus-wide df (sum over shards)."""
         self._global_df = np.asarray(df, dtype=np.uint64)
@@ -256,7 +271,8 @@ class DeviceIndex:
     def _dense(self, fn: str, rows: Optional[np.ndarray], *args, dtype=np.float32) -> np.ndarray:
         """Run a dense C-ABI call (its last argument is the float32 -- or ``dtype`` -- output).  rows
         given: only those doc ids come back (gathered on the device: the copy is proportional to the
-        subset)."""
+        subset) -- through the call's `_to` twin, which takes the destination as an argument (no selection
+        outlives a call)."""
         ptr = p_f32 if dtype == np.float32 else (lambda a: a.ctypes.data_as(ctypes.c_void_p))
         if rows is None:
             out = _pool(self.api).empty(self.n_docs, dtype)
@@ -264,25 +280,15 @@ class DeviceIndex:
             return out
         rows = as_u64(rows)
         out = np.empty(len(rows), dtype=dtype)
-        self.api.call("sa_index_select_rows", self._h, p_u64(rows), len(rows))
-        try:
-            self.api.call(fn, self._h, *args, ptr(out))
-        except Exception:
-            self.api.call("sa_index_select_rows", self._h, None, 0)      # an argument error leaves it pending
-            raise
+        dest = _lib.DenseDest(p_u64(rows), len(rows), None, np.float32(1.0), 0)
+        self.api.call(fn + "_to", self._h, *args, ctypes.byref(dest), ptr(out))
         return out
 
     def into_vec(self, vec: "DeviceVec", boost: Optional[float], fn: str, *args) -> None:
         """Run a dense C-ABI call with its result diverted into ``vec`` (float32[n_docs] on the device),
-        multiplied by ``boost`` if given."""
-        dummy = np.zeros(1, dtype=np.float32)
-        self.api.call("sa_index_select_vec", self._h, vec._h, np.float32(1.0 if boost is None else boost),
-                      0 if boost is None else 1)
-        try:
-            self.api.call(fn, self._h, *args, p_f32(dummy))
-        except Exception:
-            self.api.call("sa_index_select_vec", self._h, None, np.float32(1.0), 0)
-            raise
+        multiplied by ``boost`` if given (the call's `_to` twin: the destination is an argument)."""
+        dest = _lib.DenseDest(None, 0, vec._h, np.float32(1.0 if boost is None else boost), 0 if boost is None else 1)
+        self.api.call(fn + "_to", self._h, *args, ctypes.byref(dest), None)
 
     # -- term frequencies
     @staticmethod
@@ -448,6 +454,14 @@ class QueryBatch:
             idf = self.index.idfs(q.reshape(-1)).reshape(self.B, self.T)
         idf = as_f32(idf)
         self.api.call("sa_batch_reset", self._h, p_u32(as_u32(terms)), p_f32(idf))
+
+    def step(self, queries: np.ndarray):
+        """reset + run(sync=False) in ONE library call, the weights gathered from the index's idf table
+        (``DeviceIndex.set_idf_table``): a step of a query stream (``sa_batch_step``)"""
+        q = np.ascontiguousarray(queries, dtype=np.uint32)
+        if q.shape != (self.B, self.T):
+            raise ValueError(f"step takes [{self.B}][{self.T}] term ids")
+        self.api.call("sa_batch_step", self._h, p_u32(q))
 
     def run(self, sync: bool = True):
         self.api.call("sa_batch_run", self._h, 1 if sync else 0)

@@ -545,7 +545,8 @@ class SearchArray(ExtensionArray):
                 maybe = ~out & (h.doc_lens[ra] == h.doc_lens[rb]) & ((ptr[ra + 1] - ptr[ra]) == (ptr[rb + 1] - ptr[rb]))
                 for i in np.flatnonzero(maybe):
                     a0, a1, b0, b1 = int(ptr[ra[i]]), int(ptr[ra[i] + 1]), int(ptr[rb[i]]), int(ptr[rb[i] + 1])
-                    if not np.array_equal(h.doc_term_ids[a0:a1], h.doc_term_ids[b0:b1]):
+                    # (as SETS: an index built from Terms / dict postings keeps a doc's term ids in insertion order)
+                    if not np.array_equal(np.sort(h.doc_term_ids[a0:a1]), np.sort(h.doc_term_ids[b0:b1])):
                         continue
                     out[i] = bool(self._core.doc_as_terms(int(ra[i])) == self._core.doc_as_terms(int(rb[i])))
                 return out

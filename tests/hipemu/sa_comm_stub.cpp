@@ -33,6 +33,12 @@ std::mutex g_mu;
 std::map<std::string, std::shared_ptr<Group>> g_groups;
 }   // namespace
 
+extern "C" int sa_comm_library_info(int* version_out, char* path_out, int path_len) {
+    if (version_out) *version_out = 0;
+    if (path_out && path_len > 0) { strncpy(path_out, "in-process test communicator", (size_t)path_len - 1); path_out[path_len - 1] = 0; }
+    return SA_OK;
+}
+
 struct sa_comm {
     std::shared_ptr<Group> g;
     std::string key;

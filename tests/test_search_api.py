@@ -362,6 +362,15 @@ def test_eq_compares_content_when_rows_differ(default_api):
     assert np.array_equal(arr[[0, 1, 2]] == arr[[4, 2, 6]], [True, False, True])
 
 
+def test_eq_ignores_the_key_order_of_dict_postings(default_api):
+    """an index built from Terms / dict postings keeps a doc's term ids in insertion order: equal content with permuted
+    keys is equal (the reference compares term_mat rows, postings.py:463-464: order-insensitive)"""
+    a = SearchArray([Terms({"a": 1, "b": 2}, doc_len=3), Terms({"b": 2, "a": 1}, doc_len=3), Terms({"a": 1, "c": 2}, doc_len=3)])
+    assert np.array_equal(a == a.take([1, 0, 2]), [True, True, True])
+    assert np.array_equal(a == a.take([2, 2, 0]), [False, False, False])
+    assert bool(a[0] == a[1])
+
+
 def test_nbytes_does_not_materialise_device_built_words(default_api):
     from searcharray_amd import SearchArray
     arr = SearchArray.index(["foo bar bar baz", "data2", "data3 bar", "bunny funny wunny"] * 25)

@@ -128,3 +128,25 @@ def test_sharded_candidate_overflow_and_wide_merge(api, shards, k, monkeypatch):
         bt.close()
     finally:
         ix.close()
+
+
+def test_a_batch_that_outlives_its_sharded_handle_is_refused_not_freed_twice(api, corpus):
+    """sa_sharded_destroy takes the per-shard parts of the batches still alive down with the shards and orphans them: later
+    calls on such a batch fail with an error, its close only frees the shell (it used to touch joined worker threads and
+    destroyed indexes)"""
+    from searcharray_amd._lib import SearchArrayHipError
+    words, off, lens, _ = corpus
+    ix = ShardedIndex(words, off, lens, devices=list(range(n_devices(api, 2))), tile_docs=1024, api=api)
+    bt = ix.batch(QUERIES, k=K)
+    bt.run()
+    want = bt.fetch()
+    bt2 = ix.batch(QUERIES, k=K)
+    bt2.close()                                                      # (a batch closed before the index leaves the registry)
+    ix.close()
+    with pytest.raises(SearchArrayHipError):
+        bt.run()
+    with pytest.raises(SearchArrayHipError):
+        bt.fetch()
+    bt.close()
+    bt.close()
+    assert want[0].shape == (len(QUERIES), K)

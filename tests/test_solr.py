@@ -169,3 +169,27 @@ def test_negative_boost_takes_the_host_route(default_api):
     g = solr._Field("title", 1.0, arr, ["foo"], default_bm25)
     assert solr._DeviceCombiner.usable([g], 3)
     assert not solr._DeviceCombiner.usable([f], 3)
+
+
+def test_edismax_threaded_matches_single_threaded_on_the_device_combiner():
+    """reference test/test_tmdb.py:262-312: edismax from a thread pool must equal the serial results, and a repeated pass must
+    equal the first.  Here on the DEVICE combination (`_DeviceCombiner`: dense calls diverted into device vectors per
+    thread), with pf / pf2 / pf3 and a tie, three workers like the reference's test."""
+    from concurrent.futures import ThreadPoolExecutor, as_completed
+    g = np.load(GOLDEN, allow_pickle=False)
+    frame = pd.DataFrame({"title": SearchArray.index(list(g["field_title"])),
+                          "body": SearchArray.index(list(g["field_body"]))})
+    words = sorted({w for doc in list(g["field_title"])[:40] for w in str(doc).split()})[:12]
+    queries = [" ".join(words[i:i + 3]) for i in range(0, 9)] + [words[0], " ".join(words[:2])]
+    kw = dict(mm=2, qf=["title^1.0", "body^0.5"], pf=["title^1.0", "body^0.5"], pf2=["title^1.0", "body^0.5"],
+              pf3=["title^1.0", "body^0.5"], tie=0.3, use_device=True)
+    serial = {q: edismax(frame, q=q, **kw)[0] for q in queries}
+    for q in queries:                                         # (repeated matches: test_tmdb.py:262-282)
+        assert np.array_equal(edismax(frame, q=q, **kw)[0], serial[q]), q
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        futs = {ex.submit(edismax, frame, q=q, **kw): q for q in queries * 3}
+        for f in as_completed(futs):
+            assert np.array_equal(f.result()[0], serial[futs[f]]), f"query {futs[f]!r}: threaded result differs"
+    host = {q: edismax(frame, q=q, **dict(kw, use_device=False))[0] for q in queries}
+    for q in queries:
+        assert np.array_equal(host[q], serial[q]), q
