@@ -613,11 +613,16 @@ def parse_pmc_csv(path, leg_names):
         for cname in calib[-1]["c"]:
             out["calib"][cname] = calib[-1]["c"][cname]           # the second (warm) dispatch
     # 8-byte-load calibration: the marker kernel's dispatches over CALIB_BYTES (the plain markers read 1 MiB)
-    calib8 = [e for e in seq if e["kernel"].startswith(MARKER) and e["c"].get("FETCH_SIZE", 0.0) * 1024.0 > CALIB_BYTES / 8]
+    # (recognised by their duration: a 1 GiB read takes >= 0.1 ms, a 1 MiB marker a few microseconds -- the pass that does
+    #  not collect FETCH_SIZE must skip them too)
+    calib8 = [e for e in seq if e["kernel"].startswith(MARKER) and e["dur"] > 60_000]
     out["calib8"] = dict(calib8[-1]["c"]) if calib8 else {}
     started = False
+    big = [id(e) for e in calib8]
     for e in seq:
         name = e["kernel"]
+        if id(e) in big:                                          # (the 8-byte calibration reads: not markers)
+            continue
         if name.startswith(MARKER):
             if not in_marker:
                 seg += 1

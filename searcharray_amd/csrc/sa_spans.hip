@@ -1056,7 +1056,17 @@ struct SpanDocParams {
     int anchor;                          // the rarest term: a block takes 512 words of ITS list and looks at the documents they open
                                          //   (the dense result is cleared beforehand); -1: 512 documents (and clears their results)
     float* counts;                       // the dense result
+    // batched route (sa_k_span_doc_fused_multi): the result vector comes from a pool that is all zeros between runs, so nothing is
+    // cleared; [doc >> touch_shift] of `touched` = 1 wherever a count is written (the ranking launch reads those tiles only)
+    unsigned char* touched;
+    u32 touch_shift;
+    u32 block0, n_blocks;                // the phrase's blocks in the shared launch: [block0, block0 + n_blocks)
 };
+
+__device__ __forceinline__ void sa_span_doc_put(const SpanDocParams& p, u64 doc, u32 incr) {
+    p.counts[doc] = (float)incr;
+    if (p.touched) p.touched[doc >> p.touch_shift] = 1;
+}
 
 // index of the document's first word in term t's list -- through the term's doc directory row, or, for a term without
 // one, by a search on the 28-bit key -- or SA_DD_ABSENT
@@ -1398,7 +1408,7 @@ __device__ __forceinline__ void sa_span_wave_doc(const SpanDocParams& p, const u
         }
     }
     const u32 incr = sa_span_wave_finish(s_ents, cursor, full, my_sum, TT, max_span_width, lane);
-    if (lane == 0 && incr) p.counts[doc] = (float)incr;
+    if (lane == 0 && incr) sa_span_doc_put(p, doc, incr);
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -1543,13 +1553,13 @@ __device__ __forceinline__ void sa_span_doc_chunk(const SpanDocParams& p, u64* t
                                            npos, (u32)TT, (int)((u32)TT + p.slop), &incr);
     }
     if (have) {
-        if (ok) { if (incr) p.counts[doc] = (float)incr; }
+        if (ok) { if (incr) sa_span_doc_put(p, doc, incr); }
         else s_heavy[atomicAdd(n_heavy, 1u)] = (unsigned short)local;          // its table outgrew the column: a wave of its own below
     }
 }
 
 template <int TT>
-__global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused(const SpanDocParams p) {
+__device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, const u32 block) {
     constexpr int NW = SA_SPAN_FT / 64, ROUNDS = SA_SPAN_FD / SA_SPAN_FT;
     constexpr int TABW = SA_SPAN_FROWS * 64;                     // a wave's tables, in 8-byte words
     __shared__ unsigned short s_plist[SA_SPAN_PC * SA_SPAN_FD];  // position-major: position q of local document d at [q * FD + d]
@@ -1567,7 +1577,7 @@ __global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused(const SpanDocP
     if (threadIdx.x == 0) { s_nheavy = 0; s_next = 0; }
     __syncthreads();
     constexpr u32 PMAX = SA_SPAN_PMAXF, HEAVY = SA_SPAN_PMAXF + 1;
-    const u64 lo = (u64)blockIdx.x * SA_SPAN_FD;
+    const u64 lo = (u64)block * SA_SPAN_FD;
     // ---- gather: bins and short position lists
     {
         u64 W[TT][SA_SPAN_DW];
@@ -1587,7 +1597,7 @@ __global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused(const SpanDocP
                     doc = aw[i] >> SA_KEY_SHIFT;
                     valid = (i == 0 || (aw[i - 1] >> SA_KEY_SHIFT) != doc) && doc < p.st.n_docs;
                 }
-            } else if (valid) {
+            } else if (valid && !p.touched) {
                 p.counts[doc] = 0.f;
             }
             s_doc[local] = (u32)doc;
@@ -1671,6 +1681,25 @@ __global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused(const SpanDocP
     const u32 nh = s_nheavy;
     if (wave < (u32)HW)
         for (u32 i = wave; i < nh; i += (u32)HW) sa_span_wave_doc<TT>(p, s_doc[s_heavy[i]], (SpanEnt*)s_tab + (size_t)wave * SA_NSPANS, lane);
+}
+
+template <int TT>
+__global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused(const SpanDocParams p) {
+    sa_span_doc_fused_body<TT>(p, blockIdx.x);
+}
+
+// B phrases in ONE launch: the blocks of all phrases back to back, block b belongs to the phrase j with
+// jobs[j].block0 <= b < jobs[j].block0 + jobs[j].n_blocks (found by bisection: the jobs are sorted by block0)
+template <int TT>
+__global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused_multi(const SpanDocParams* __restrict__ jobs, u32 n_jobs) {
+    u32 lo = 0, hi = n_jobs;
+    while (hi - lo > 1u) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if (jobs[mid].block0 <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    const SpanDocParams p = jobs[lo];
+    if (blockIdx.x - p.block0 >= p.n_blocks) return;
+    sa_span_doc_fused_body<TT>(p, blockIdx.x - p.block0);
 }
 
 static bool sa_env_span_doc() {
@@ -2014,6 +2043,9 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
     const char* ddenv = getenv("SA_SPAN_DOCDIR");
     const bool use_dd = ix->n_dd_terms > 0 && !(ddenv && atoi(ddenv) == 0);
     std::vector<SpanJob> jobs;
+    std::vector<SpanDocParams> djobs[3];               // phrases of 2 / 3 / 4 terms on the doc-parallel route
+    std::vector<int> drow[3];
+    const bool doc_route = sa_env_span_doc() && !(getenv("SA_SPAN_DOC_MULTI") && atoi(getenv("SA_SPAN_DOC_MULTI")) == 0);
     std::vector<int> job_row, job_class;
     std::vector<size_t> job_off;                       // scratch offset of each job
     size_t used = 0;
@@ -2039,6 +2071,36 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
             total_len += J.st.len[t];
         }
         if (!ok || total_len == 0 || J.st.len[0] == 0 || total_len > 0x7FFFFFF0ull) continue;
+        // the doc-parallel route (sa_k_span_doc_fused: gather, work order and span machines per block of documents, nothing but
+        // the lists read) where the phrase qualifies -- the conditions of sa_span_counts_device -- whatever the lists' lengths:
+        // ALL such phrases of the batch share one launch per term count
+        if (doc_route && Ti <= 4 && Ti + slop[i] <= 15 && N < 0xFFFFFFF0ull) {
+            bool all_dd = true, nonempty = true;
+            for (int t = 0; t < Ti; t++) { all_dd = all_dd && J.st.dd[t] != nullptr; nonempty = nonempty && J.st.len[t] > 0; }
+            const unsigned char e0 = ix->h_term_edge[terms[i][0]];
+            bool L = true;
+            for (int t = 1; t < Ti; t++) {
+                const unsigned char ei = ix->h_term_edge[terms[i][t]];
+                const bool a0 = e0 & 1, a0m = e0 & 2, bi = ei & 1, bim = ei & 2;
+                L &= (a0 && bi) || (bi && a0m) || (a0 && bim);
+            }
+            if (nonempty && (all_dd || !ix->any_top_block) && (Ti == 2 || !L)) {
+                SpanDocParams P;
+                memset(&P, 0, sizeof(P));
+                P.st = J.st;
+                P.st.off[0] = 0;
+                for (int t = 0; t < Ti; t++) P.st.off[t + 1] = P.st.off[t] + P.st.len[t];
+                P.slop = (u32)slop[i];
+                int rarest = 0;
+                for (int t = 1; t < Ti; t++) if (P.st.len[t] < P.st.len[rarest]) rarest = t;
+                P.anchor = 2 * (u64)P.st.len[rarest] >= N ? -1 : rarest;
+                const u64 slots = P.anchor >= 0 ? (u64)P.st.len[rarest] : N;
+                P.n_blocks = (u32)((slots + SA_SPAN_FD - 1) / SA_SPAN_FD);
+                djobs[Ti - 2].push_back(P);
+                drow[Ti - 2].push_back(i);
+                continue;
+            }
+        }
         if (J.st.len[0] > (u32)SA_SPAN_SORT_MIN) continue;                         // (would be put in work order)
         for (int t = 0; t < Ti; t++) J.st.off[t + 1] = J.st.off[t] + J.st.len[t];
         for (int t = 0; t < Ti; t++) J.ck.coff[t + 1] = J.ck.coff[t] + sa_compact_chunks(J.st.len[t]);
@@ -2073,14 +2135,17 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
         job_class.push_back(Ti == 2 ? 0 : Ti == 3 ? 1 : Ti == 4 ? 2 : 3);
     }
     const int nj = (int)jobs.size();
-    if (nj == 0) return SA_OK;
+    const int nd = (int)(djobs[0].size() + djobs[1].size() + djobs[2].size());
+    const int nv = nj + nd;                            // count vectors / ranking jobs
+    if (nv == 0) return SA_OK;
     // jobs of a class are neighbours in the device array
     std::vector<int> order((size_t)nj);
     for (int j = 0; j < nj; j++) order[(size_t)j] = j;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return job_class[(size_t)a] < job_class[(size_t)b]; });
     // (the ranking jobs -- counts, idf, batch row of every phrase taken -- ride behind the span jobs in the same upload)
     const size_t span_jobs_bytes = ((size_t)nj * sizeof(SpanJob) + 255) & ~(size_t)255;
-    const size_t jobs_bytes = span_jobs_bytes + (((size_t)nj * sizeof(sa_dense_rank_job) + 255) & ~(size_t)255);
+    const size_t rank_jobs_bytes = ((size_t)nv * sizeof(sa_dense_rank_job) + 255) & ~(size_t)255;
+    const size_t jobs_bytes = span_jobs_bytes + rank_jobs_bytes + (((size_t)nd * sizeof(SpanDocParams) + 255) & ~(size_t)255);
     const size_t need = jobs_bytes + used + 4096;
     if (ix->span_batch_bytes < need) {
         SA_HIP(hipStreamSynchronize(st));
@@ -2102,12 +2167,12 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
     // (behind each vector: a byte per ranking tile, "has a count" -- same life cycle)
     const size_t cvec = (size_t)((N + 64) & ~(u64)63);
     const size_t cstride = cvec + ((((size_t)(N >> rank_tile_shift) + 1 + 3) / 4 + 63) & ~(size_t)63);
-    if (ix->span_counts_cap < (size_t)nj * cstride) {
+    if (ix->span_counts_cap < (size_t)nv * cstride) {
         SA_HIP(hipStreamSynchronize(st));
         if (ix->d_span_counts) SA_HIP(hipFree(ix->d_span_counts));
         ix->d_span_counts = nullptr; ix->span_counts_cap = 0;
-        SA_HIP(hipMalloc(&ix->d_span_counts, (size_t)nj * cstride * sizeof(float)));
-        ix->span_counts_cap = (size_t)nj * cstride;
+        SA_HIP(hipMalloc(&ix->d_span_counts, (size_t)nv * cstride * sizeof(float)));
+        ix->span_counts_cap = (size_t)nv * cstride;
         ix->span_counts_dirty = true;
     }
     if (ix->span_counts_dirty) SA_HIP(hipMemsetAsync(ix->d_span_counts, 0, ix->span_counts_cap * sizeof(float), st));
@@ -2148,9 +2213,37 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
         class_first[job_class[(size_t)j] + 1] = q + 1;
     }
     for (int c = 1; c <= 4; c++) if (class_first[c] < class_first[c - 1]) class_first[c] = class_first[c - 1];
+    // the doc-parallel phrases: vectors nj .. nv - 1 of the pool, their parameter blocks behind the ranking jobs
+    SpanDocParams* hd = (SpanDocParams*)((char*)ix->h_span_jobs + span_jobs_bytes + rank_jobs_bytes);
+    const SpanDocParams* dd_dev = (const SpanDocParams*)((char*)ix->d_span_batch + span_jobs_bytes + rank_jobs_bytes);
+    u32 dfirst[4] = {0, 0, 0, 0}, dblocks[3] = {0, 0, 0};
+    {
+        int q = nj;
+        u32 k = 0;
+        for (int c = 0; c < 3; c++) {
+            dfirst[c] = k;
+            u32 b0 = 0;
+            for (size_t j = 0; j < djobs[c].size(); j++, q++, k++) {
+                SpanDocParams P = djobs[c][j];
+                float* running = ix->d_span_counts + (size_t)q * cstride;
+                P.counts = running;
+                P.touched = (unsigned char*)(running + cvec); P.touch_shift = rank_tile_shift;
+                P.block0 = b0;
+                b0 += P.n_blocks;
+                hd[k] = P;
+                const int row = drow[c][j];
+                hr[q].counts = running; hr[q].touched = P.touched;
+                hr[q].idf = idf[row]; hr[q].row = rows[row];
+                d_out[row] = running;
+                handled[row] = 1;
+            }
+            dblocks[c] = b0;
+        }
+        dfirst[3] = k;
+    }
     SA_HIP(hipMemcpyAsync(ix->d_span_batch, hj, jobs_bytes, hipMemcpyHostToDevice, st));
     *d_rank_jobs = (const sa_dense_rank_job*)((char*)ix->d_span_batch + span_jobs_bytes);
-    *n_rank_jobs = nj;
+    *n_rank_jobs = nv;
     SA_HIP(hipEventRecord(ix->ev_span_jobs, st));
     const SpanJob* dj = (const SpanJob*)ix->d_span_batch;
     for (int c = 0; c < 4; c++) {
@@ -2175,6 +2268,14 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
         else if (c == 1) hipLaunchKernelGGL((sa_k_span_machine_flat_multi<20, 20, 3>), dim3(gl, nb), dim3(64), 0, st, jc);
         else hipLaunchKernelGGL((sa_k_span_machine_flat_multi<20, 20, 0>), dim3(gl, nb), dim3(64), 0, st, jc);
         hipLaunchKernelGGL(sa_k_span_machine_wave_multi, dim3(gw, nb), dim3(64), 0, st, jc);
+    }
+    for (int c = 0; c < 3; c++) {
+        const u32 cnt = dfirst[c + 1] - dfirst[c];
+        if (cnt == 0 || dblocks[c] == 0) continue;
+        const SpanDocParams* jc = dd_dev + dfirst[c];
+        if (c == 0) hipLaunchKernelGGL(sa_k_span_doc_fused_multi<2>, dim3(dblocks[c]), dim3(SA_SPAN_FT), 0, st, jc, cnt);
+        else if (c == 1) hipLaunchKernelGGL(sa_k_span_doc_fused_multi<3>, dim3(dblocks[c]), dim3(SA_SPAN_FT), 0, st, jc, cnt);
+        else hipLaunchKernelGGL(sa_k_span_doc_fused_multi<4>, dim3(dblocks[c]), dim3(SA_SPAN_FT), 0, st, jc, cnt);
     }
     SA_HIP(hipGetLastError());
     return SA_OK;

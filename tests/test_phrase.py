@@ -778,7 +778,8 @@ def test_slop_phrases_of_a_batch_share_their_launches(api, monkeypatch):
     """Phrase batches score their slop phrases in SHARED launches (sa_span_counts_batch: blockIdx.y picks the phrase; one
     launch per stage and class of phrases -- 2, 3, 4, more terms -- and one ranking launch for all of them).  Mixed term
     counts and slops, an unknown term, an exact and a repeated-term phrase beside them: top-k equal to the oracle's and to
-    the one-phrase-at-a-time route (SA_SPAN_MULTI=0)."""
+    the one-phrase-at-a-time route (SA_SPAN_MULTI=0).  Phrases of 2 - 4 terms that qualify take the doc-parallel kernel, ALL of a
+    term count in one launch (sa_k_span_doc_fused_multi; SA_SPAN_DOC_MULTI=0: the five-stage shared launches for them too)."""
     g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_small")
     words, wt = rz.encode_sorted(t, d, p)
     dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
@@ -792,15 +793,17 @@ def test_slop_phrases_of_a_batch_share_their_launches(api, monkeypatch):
     slops += [0, 0, 2]
     k = 8
     results = {}
-    for multi in ("1", "0"):
+    for multi, docm in (("1", "1"), ("1", "0"), ("0", "1")):
         monkeypatch.setenv("SA_SPAN_MULTI", multi)
+        monkeypatch.setenv("SA_SPAN_DOC_MULTI", docm)
         pb = dev.phrase_batch(phrases, k=k, slop=slops)
         for _ in range(2):
             pb.run()
-        results[multi] = pb.fetch()
+        results[multi + docm] = pb.fetch()
         pb.close()
-    assert np.array_equal(results["1"][0], results["0"][0]) and np.array_equal(results["1"][1], results["0"][1])
-    ps, pd_ = results["1"]
+    for other in ("10", "01"):
+        assert np.array_equal(results["11"][0], results[other][0]) and np.array_equal(results["11"][1], results[other][1]), other
+    ps, pd_ = results["11"]
     for i, (ph, sl) in enumerate(zip(phrases, slops)):
         ws, wd = O.topk(orc.score(list(ph), slop=sl), k)
         n = int((ws > 0).sum())
