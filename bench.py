@@ -37,7 +37,7 @@ Legs (all on the same resident index; only the first is `value`):
   distinct_terms    256 x 4 pairwise-distinct terms (ranks 1..1024), exhaustive: no posting list is shared
                     between queries, so cache reuse cannot flatter the bandwidth figure
   phrase_batch      BASELINE config 3: 256 sampled 3-token phrases -> BM25 -> top-10 on a resident zipf-1M index
-  slop_batch        BASELINE config 5 (synthetic stand-in): 32 two-token slop-2 phrases -> top-10, same index
+  slop_batch        BASELINE config 5 (synthetic stand-in): 256 two-token slop-2 phrases (half on ranks 1-50) -> top-10, same index
 Roofline blocks are per leg; see roofline_block().
 """
 import argparse
@@ -339,8 +339,8 @@ class Rank:
 # ------------------------------------------------------------------------------------------------
 class PhraseSide:
     """zipf-`docs` index beside the main one + the two phrase workloads of SURVEY 8d: 256 consecutive trigrams
-    sampled from random docs (config 3) and 32 two-token slop-2 queries on mid-frequency terms, ranks 50-5000
-    (config 5's stand-in for MSMARCO)."""
+    sampled from random docs (config 3) and 256 two-token slop-2 queries, half on mid-frequency terms (ranks 50-5000:
+    config 5's stand-in for MSMARCO), half on ranks 1-50."""
 
     def __init__(self, api, docs, vocab, device=0):
         from searcharray_amd import synth
@@ -354,9 +354,12 @@ class PhraseSide:
         self.index = DeviceIndex(words, term_off, self.doc_lens, device=device, api=api)
         self.trigrams = [[int(t) for t in p] for p in synth.phrase_queries_from_tokens(lens, terms, 256, 3, seed=77)]
         rng = np.random.default_rng(5)
+        # 256 two-token slop-2 queries: half on mid-frequency terms (ranks 50-5000, SURVEY 8d's stand-in for MSMARCO), half on
+        # the most frequent terms (ranks 1-50: lists of 10^5 .. 10^6 words, the ones that load the device)
         self.slop2 = []
-        for _ in range(32):
-            a, b = (int(x) for x in rng.integers(49, min(5000, vocab - 1), 2))
+        for i in range(256):
+            lo, hi = (49, min(5000, vocab - 1)) if i % 2 == 0 else (0, min(50, vocab - 1))
+            a, b = (int(x) for x in rng.integers(lo, hi, 2))
             self.slop2.append([a, b + 1 if a == b else b])
         self.pb = self.index.phrase_batch(self.trigrams, k=10)
         self.sb = self.index.phrase_batch(self.slop2, k=10, slop=2)
@@ -477,7 +480,7 @@ def phrase_leg_block(side, name, phrases, slop, batch, pmc, K, cpu_s):
     out = {"value": round(len(phrases) * K / dt, 1), "unit": "phrases/s", "steps": K, "ms_per_step": round(dt / K * 1e3, 4),
            "workload": (f"zipf-{side.docs}: {len(phrases)} consecutive trigrams sampled from random docs -> BM25 -> top-10 (one resident phrase batch)"
                         if slop == 0 else
-                        f"zipf-{side.docs}: {len(phrases)} two-token slop-{slop} phrases, terms of ranks 50-5000 -> BM25 -> top-10 (one resident phrase batch)"),
+                        f"zipf-{side.docs}: {len(phrases)} two-token slop-{slop} phrases, half on terms of ranks 50-5000, half on ranks 1-50 -> BM25 -> top-10 (one resident phrase batch)"),
            "roofline": blk}
     if cpu_s > 0:
         out["parity"] = side.check(phrases, slop, batch, cpu_s)

@@ -1369,7 +1369,7 @@ __device__ __forceinline__ u32 sa_span_doc_last(const SpanDocParams& p, const u3
 // one document through the wave machine: its words through the directory, 64 at a time -- candidate test per lane,
 // then the candidates one after the other.
 template <int TT>
-__device__ __forceinline__ void sa_span_wave_doc(const SpanDocParams& p, const u64 doc, SpanEnt* s_ents, const u32 lane) {
+__device__ __forceinline__ void sa_span_wave_doc(const SpanDocParams& p, const u64 doc, SpanEnt* s_ents, const u32 lane, u32* slot = nullptr) {
 #pragma unroll
     for (int t = 0; t < TT; t++)
         if (sa_span_first(p.st, t, doc) == SA_DD_ABSENT) return;
@@ -1408,7 +1408,8 @@ __device__ __forceinline__ void sa_span_wave_doc(const SpanDocParams& p, const u
         }
     }
     const u32 incr = sa_span_wave_finish(s_ents, cursor, full, my_sum, TT, max_span_width, lane);
-    if (lane == 0 && incr) sa_span_doc_put(p, doc, incr);
+    if (lane == 0 && slot) *slot = incr;                                     // (the block stores its documents' counts together)
+    else if (lane == 0 && incr) sa_span_doc_put(p, doc, incr);
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -1515,9 +1516,10 @@ __device__ __forceinline__ bool sa_span_lane_machine(u64* ents, const Pos& pos, 
 // S lanes of a wave take S neighbours of the block's order, from `start`.  64 lanes: the positions where the gather
 // left them; fewer: behind the tables (PM x S words), from the gather's list if it holds them, else from the words again.
 template <int CE, int PM, int S, int TT>
-__device__ __forceinline__ void sa_span_doc_chunk(const SpanDocParams& p, u64* tab, const unsigned short* s_plist, const u32* s_pbase,
+__device__ __forceinline__ void sa_span_doc_chunk(const SpanDocParams& p, u64* tab, const unsigned short* s_plist, u32* s_pbase,
                                                   const unsigned char* s_bin, const unsigned short* s_order, unsigned short* s_heavy,
-                                                  u32* n_heavy, const u32* s_doc, const u32 lane, const u32 start, const u32 n) {
+                                                  u32* n_heavy, const u32* s_doc, const u32 lane, const u32 start, const u32 n,
+                                                  const bool staged) {
     const bool have = lane < (u32)S && start + lane < n;
     const u32 local = have ? s_order[start + lane] : 0u;
     const u32 npos = have ? s_bin[local] : 0u;
@@ -1552,9 +1554,12 @@ __device__ __forceinline__ void sa_span_doc_chunk(const SpanDocParams& p, u64* t
         ok = sa_span_lane_machine<CE, PM, S>(tab + (have ? lane : 0u), [&](const u32 q) -> u32 { return pl[q * (u32)S]; },
                                            npos, (u32)TT, (int)((u32)TT + p.slop), &incr);
     }
+    if (staged) __builtin_amdgcn_wave_barrier();                               // (every lane has read its s_pbase before any slot is reused)
     if (have) {
-        if (ok) { if (incr) sa_span_doc_put(p, doc, incr); }
-        else s_heavy[atomicAdd(n_heavy, 1u)] = (unsigned short)local;          // its table outgrew the column: a wave of its own below
+        // staged: the document's slot of s_pbase -- its position base is not needed any more -- takes the count
+        if (staged) s_pbase[local] = ok ? incr : 0u;
+        else if (ok && incr) sa_span_doc_put(p, doc, incr);
+        if (!ok) s_heavy[atomicAdd(n_heavy, 1u)] = (unsigned short)local;      // its table outgrew the column: a wave of its own below
     }
 }
 
@@ -1578,6 +1583,11 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
     __syncthreads();
     constexpr u32 PMAX = SA_SPAN_PMAXF, HEAVY = SA_SPAN_PMAXF + 1;
     const u64 lo = (u64)block * SA_SPAN_FD;
+    // Batched route over ALL documents (a heavy phrase of a batch): the block's counts are STAGED in LDS -- a document's slot of
+    // s_pbase, free once its machine has read it -- and stored together at the end, 2 KB of whole lines: the L2 writes through,
+    // so a 4-byte store per matching document is a partial-line write to HBM each (measured: 5.3 GB of writes for 0.5 GB of
+    // count vectors on the bench's 256-phrase batch).
+    const bool staged = p.touched != nullptr && p.anchor < 0;
     // ---- gather: bins and short position lists
     {
         u64 W[TT][SA_SPAN_DW];
@@ -1624,6 +1634,7 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
                 }
                 if (bin) atomicAdd(&s_h[bin], 1u);
             }
+            if (staged && (bin == 0u || bin == HEAVY)) s_pbase[local] = 0u;      // (no machine in the chunks: nothing counted so far)
             s_bin[local] = (unsigned char)bin;
         }
     }
@@ -1669,10 +1680,10 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
             if (lane == 0) ck = atomicAdd(&s_next, 1u);
             ck = (u32)__builtin_amdgcn_readfirstlane((int)ck);
             if (ck >= k_c + k_b + k_a) break;
-            if (ck < k_c) sa_span_doc_chunk<(TABW - 128) / 8 - 1, 4 * SA_SPAN_PC, 8, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, s_doc, lane, 8u * ck, n);
-            else if (ck < k_c + k_b) sa_span_doc_chunk<(TABW - 128) / 16 - 1, 2 * SA_SPAN_PC, 16, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, s_doc, lane, start_b + 16u * (ck - k_c), n);
-            else if (TT == 2) sa_span_doc_chunk<R - 1, SA_SPAN_PC, 64, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, s_doc, lane, start_a + 64u * (ck - k_c - k_b), n);
-            else sa_span_doc_chunk<(TABW - 128) / 32 - 1, SA_SPAN_PC, 32, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, s_doc, lane, start_a + 32u * (ck - k_c - k_b), n);
+            if (ck < k_c) sa_span_doc_chunk<(TABW - 128) / 8 - 1, 4 * SA_SPAN_PC, 8, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, s_doc, lane, 8u * ck, n, staged);
+            else if (ck < k_c + k_b) sa_span_doc_chunk<(TABW - 128) / 16 - 1, 2 * SA_SPAN_PC, 16, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, s_doc, lane, start_b + 16u * (ck - k_c), n, staged);
+            else if (TT == 2) sa_span_doc_chunk<R - 1, SA_SPAN_PC, 64, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, s_doc, lane, start_a + 64u * (ck - k_c - k_b), n, staged);
+            else sa_span_doc_chunk<(TABW - 128) / 32 - 1, SA_SPAN_PC, 32, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, s_doc, lane, start_a + 32u * (ck - k_c - k_b), n, staged);
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -1680,7 +1691,23 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
     // ---- heavy documents and outgrown tables: a wave each, the block's tables now being free (HW full tables fit)
     const u32 nh = s_nheavy;
     if (wave < (u32)HW)
-        for (u32 i = wave; i < nh; i += (u32)HW) sa_span_wave_doc<TT>(p, s_doc[s_heavy[i]], (SpanEnt*)s_tab + (size_t)wave * SA_NSPANS, lane);
+        for (u32 i = wave; i < nh; i += (u32)HW)
+            sa_span_wave_doc<TT>(p, s_doc[s_heavy[i]], (SpanEnt*)s_tab + (size_t)wave * SA_NSPANS, lane, staged ? &s_pbase[s_heavy[i]] : nullptr);
+    if (staged) {
+        __syncthreads();
+        bool any = false;
+        for (int r = 0; r < ROUNDS; r++) {
+            const u32 local = (u32)r * SA_SPAN_FT + threadIdx.x;
+            const u64 doc = lo + local;
+            const u32 c = s_pbase[local];
+            if (doc < p.st.n_docs) p.counts[doc] = (float)c;              // (zeros too: whole lines)
+            any = any || (doc < p.st.n_docs && c != 0u);
+        }
+        if (__any(any) && (threadIdx.x & 63u) == 0u) {
+            p.touched[lo >> p.touch_shift] = 1;
+            p.touched[(lo + SA_SPAN_FD - 1 < p.st.n_docs ? lo + SA_SPAN_FD - 1 : p.st.n_docs - 1) >> p.touch_shift] = 1;
+        }
+    }
 }
 
 template <int TT>

@@ -791,6 +791,10 @@ def test_slop_phrases_of_a_batch_share_their_launches(api, monkeypatch):
         slops.append(int(rng.integers(1, 4)))
     phrases += [[0, 1], [2, 2, 3], [1, vocab + 7]]
     slops += [0, 0, 2]
+    # the most frequent terms (their lists are longer than half the collection: the doc-parallel kernel walks ALL documents and,
+    # in a batch, stages a block's counts in LDS and stores them together), incl. documents with many positions
+    phrases += [[0, 1], [1, 0], [0, 2, 1], [3, 0], [1, 2, 0, 3]]
+    slops += [2, 3, 2, 1, 3]
     k = 8
     results = {}
     for multi, docm in (("1", "1"), ("1", "0"), ("0", "1")):
