@@ -180,6 +180,12 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
 // (touched[tile]: the vector has a count in that ranking tile -- set by the span machines, cleared by the ranking launch,
 //  which leaves the other tiles' 8 KB unread)
 struct sa_dense_rank_job { const float* counts; unsigned char* touched; float idf; u32 row; };
+// the ranking state of a phrase batch, for kernels that rank their documents themselves (sa_k_span_doc_fused_multi): BM25
+// parameters, the batch's bound slots and candidate lists (cand == null: nothing to rank into)
+struct SpanRankCtx {
+    const float* doc_lens; float avgdl, k1, b; u32 k;
+    u32* slots; u64* cand; u32 cand_cap; u32* cand_cnt; u64 doc_base;
+};
 int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* terms, const int* T, const int* slop,
                          const float* idf, const u32* rows, float** d_out, unsigned char* handled,
-                         const sa_dense_rank_job** d_rank_jobs, int* n_rank_jobs, u32 rank_tile_shift);
+                         const sa_dense_rank_job** d_rank_jobs, int* n_rank_jobs, u32 rank_tile_shift, const SpanRankCtx* rank);

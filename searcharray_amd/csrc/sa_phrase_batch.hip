@@ -316,8 +316,11 @@ int sa_launch_phrase_tiles(sa_batch* bt, hipStream_t st) {
             for (size_t i = 0; i < rows.size(); i++) idfs[i] = bt->h_pidf[rows[i]];
             const sa_dense_rank_job* d_rj = nullptr;
             int n_rj = 0;
+            SpanRankCtx rc;
+            rc.doc_lens = ix->d_doc_lens; rc.avgdl = ix->avg_doc_len; rc.k1 = bt->k1; rc.b = bt->b; rc.k = bt->k;
+            rc.slots = bt->d_slots; rc.cand = bt->d_cand; rc.cand_cap = bt->cand_cap; rc.cand_cnt = bt->d_cand_cnt; rc.doc_base = ix->doc_base;
             SA_TRY(sa_span_counts_batch(ix, st, (int)rows.size(), tp.data(), tn.data(), ts.data(), idfs.data(), rows.data(), outs.data(),
-                                        handled.data(), &d_rj, &n_rj, bt->ptile == 2048 ? 11u : 12u));
+                                        handled.data(), &d_rj, &n_rj, bt->ptile == 2048 ? 11u : 12u, &rc));
             for (size_t i = 0; i < rows.size(); i++) if (handled[i]) taken[rows[i]] = 1;
             if (n_rj > 0) {
                 if (bt->ptile == 2048)
@@ -477,7 +480,9 @@ extern "C" int sa_phrase_batch_create_ex(sa_index_t* ix, const uint32_t* terms, 
         SA_HIP(hipMalloc(&bt->d_wbounds, ((size_t)B * T * (bt->pn_tiles + 1) + 1) * sizeof(u32)));
         SA_HIP(hipMalloc(&bt->d_wbase, (size_t)B * T * sizeof(u64)));
         SA_HIP(hipMalloc(&bt->d_wlen, (size_t)B * T * sizeof(u32)));
-        SA_TRY(sa_batch_alloc_topk(bt, bt->pn_tiles, SA_PTHREADS / SA_WAVE));
+        // (every wave of a ranking unit appends at most k keys: 4 waves per tile of the tile route -- and per block of 512 documents
+        //  of the slop phrases that rank inside the span kernel, sa_k_span_doc_fused_multi: 4 such blocks per 2048-doc tile)
+        SA_TRY(sa_batch_alloc_topk(bt, bt->pn_tiles, (SA_PTHREADS / SA_WAVE) * (bt->ptile / 512u)));
         return SA_OK;
     };
     int rc = alloc();

@@ -34,6 +34,7 @@
 // rule (min over terms of the summed popcounts), incl. which words still count (sa_span_doc) -- and the tests
 // compare such documents bit for bit like all others.
 #include "sa_index.hpp"
+#include "sa_topk.hpp"
 #include "sa_scan.hpp"
 #include "../../include/searcharray_hip.h"
 #include <stdlib.h>
@@ -1061,6 +1062,12 @@ struct SpanDocParams {
     unsigned char* touched;
     u32 touch_shift;
     u32 block0, n_blocks;                // the phrase's blocks in the shared launch: [block0, block0 + n_blocks)
+    // ... or no result vector at all (rank.cand != null): the block turns its documents' counts into BM25 scores and ranks them
+    // itself -- the batch's pruned top-k selection over the block's 512 documents -- so only candidates above the phrase's
+    // bound leave the kernel
+    SpanRankCtx rank;
+    float idf;
+    u32 row;                             // the phrase's row in the batch
 };
 
 __device__ __forceinline__ void sa_span_doc_put(const SpanDocParams& p, u64 doc, u32 incr) {
@@ -1587,7 +1594,8 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
     // s_pbase, free once its machine has read it -- and stored together at the end, 2 KB of whole lines: the L2 writes through,
     // so a 4-byte store per matching document is a partial-line write to HBM each (measured: 5.3 GB of writes for 0.5 GB of
     // count vectors on the bench's 256-phrase batch).
-    const bool staged = p.touched != nullptr && p.anchor < 0;
+    const bool ranked = p.rank.cand != nullptr;
+    const bool staged = ranked || (p.touched != nullptr && p.anchor < 0);
     // ---- gather: bins and short position lists
     {
         u64 W[TT][SA_SPAN_DW];
@@ -1607,7 +1615,7 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
                     doc = aw[i] >> SA_KEY_SHIFT;
                     valid = (i == 0 || (aw[i - 1] >> SA_KEY_SHIFT) != doc) && doc < p.st.n_docs;
                 }
-            } else if (valid && !p.touched) {
+            } else if (valid && !p.touched && !ranked) {
                 p.counts[doc] = 0.f;
             }
             s_doc[local] = (u32)doc;
@@ -1634,7 +1642,7 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
                 }
                 if (bin) atomicAdd(&s_h[bin], 1u);
             }
-            if (staged && (bin == 0u || bin == HEAVY)) s_pbase[local] = 0u;      // (no machine in the chunks: nothing counted so far)
+            if (staged && (bin == 0u || bin == HEAVY)) s_pbase[local] = 0u;      // (no machine in the chunks: nothing counted so far; a slot without a document never counts)
             s_bin[local] = (unsigned char)bin;
         }
     }
@@ -1693,7 +1701,30 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
     if (wave < (u32)HW)
         for (u32 i = wave; i < nh; i += (u32)HW)
             sa_span_wave_doc<TT>(p, s_doc[s_heavy[i]], (SpanEnt*)s_tab + (size_t)wave * SA_NSPANS, lane, staged ? &s_pbase[s_heavy[i]] : nullptr);
-    if (staged) {
+    if (ranked) {
+        // counts -> BM25 (the reference's operation order, similarity.py:24-38 / bm25.pyx:19-23, as sa_k_dense_topk_tiles forms it)
+        // in place, then the pruned selection of the phrase batches over the block's documents (s_doc: their ids)
+        __syncthreads();
+        const float one_minus_b = 1.0f - p.rank.b;
+        u32 slot_val = 0xFFFFFFFFu;
+        if ((threadIdx.x & 63u) < 32u)
+            slot_val = __hip_atomic_load(&p.rank.slots[p.row * 32u + (threadIdx.x & 31u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float* const acc = (float*)s_pbase;
+        for (int r = 0; r < ROUNDS; r++) {
+            const u32 local = (u32)r * SA_SPAN_FT + threadIdx.x;
+            const u32 c = s_pbase[local];
+            float sc = 0.f;
+            if (c != 0u) {
+                const float t = (float)c;
+                const float norm = __fmul_rn(p.rank.k1, __fadd_rn(one_minus_b, __fmul_rn(p.rank.b, __fdiv_rn(p.rank.doc_lens[s_doc[local]], p.rank.avgdl))));
+                sc = __fmul_rn(__fdiv_rn(t, __fadd_rn(t, norm)), p.idf);
+            }
+            acc[local] = sc;                                             // (each thread rewrites its own two slots)
+        }
+        __syncthreads();
+        sa_tile_topk_pruned<SA_SPAN_FD, SA_SPAN_FT>(acc, slot_val, p.row, block, p.rank.doc_base, p.rank.k, p.rank.slots, p.rank.cand,
+                                                    p.rank.cand_cap, p.rank.cand_cnt, s_doc);
+    } else if (staged) {
         __syncthreads();
         bool any = false;
         for (int r = 0; r < ROUNDS; r++) {
@@ -2055,7 +2086,7 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
 // Everything is enqueued on `st`; the caller holds the index lock.
 int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* terms, const int* T, const int* slop,
                          const float* idf, const u32* rows, float** d_out, unsigned char* handled,
-                         const sa_dense_rank_job** d_rank_jobs, int* n_rank_jobs, u32 rank_tile_shift) {
+                         const sa_dense_rank_job** d_rank_jobs, int* n_rank_jobs, u32 rank_tile_shift, const SpanRankCtx* rank) {
     for (int i = 0; i < n; i++) { handled[i] = 0; d_out[i] = nullptr; }
     *d_rank_jobs = nullptr; *n_rank_jobs = 0;
     const u64 N = ix->n_docs;
@@ -2073,6 +2104,8 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
     std::vector<SpanDocParams> djobs[3];               // phrases of 2 / 3 / 4 terms on the doc-parallel route
     std::vector<int> drow[3];
     const bool doc_route = sa_env_span_doc() && !(getenv("SA_SPAN_DOC_MULTI") && atoi(getenv("SA_SPAN_DOC_MULTI")) == 0);
+    // the doc-parallel phrases rank their documents inside the kernel (no count vector) when the caller hands its ranking state
+    const bool fused_rank = rank && rank->cand && !(getenv("SA_SPAN_DOC_RANK") && atoi(getenv("SA_SPAN_DOC_RANK")) == 0);
     std::vector<int> job_row, job_class;
     std::vector<size_t> job_off;                       // scratch offset of each job
     size_t used = 0;
@@ -2163,7 +2196,7 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
     }
     const int nj = (int)jobs.size();
     const int nd = (int)(djobs[0].size() + djobs[1].size() + djobs[2].size());
-    const int nv = nj + nd;                            // count vectors / ranking jobs
+    const int nv = nj + (fused_rank ? 0 : nd);         // count vectors / ranking jobs
     if (nv == 0) return SA_OK;
     // jobs of a class are neighbours in the device array
     std::vector<int> order((size_t)nj);
@@ -2252,16 +2285,21 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
             u32 b0 = 0;
             for (size_t j = 0; j < djobs[c].size(); j++, q++, k++) {
                 SpanDocParams P = djobs[c][j];
-                float* running = ix->d_span_counts + (size_t)q * cstride;
-                P.counts = running;
-                P.touched = (unsigned char*)(running + cvec); P.touch_shift = rank_tile_shift;
+                const int row = drow[c][j];
                 P.block0 = b0;
                 b0 += P.n_blocks;
+                if (fused_rank) {
+                    P.rank = *rank; P.idf = idf[row]; P.row = rows[row];
+                    q--;                                           // (no vector of the pool)
+                } else {
+                    float* running = ix->d_span_counts + (size_t)q * cstride;
+                    P.counts = running;
+                    P.touched = (unsigned char*)(running + cvec); P.touch_shift = rank_tile_shift;
+                    hr[q].counts = running; hr[q].touched = P.touched;
+                    hr[q].idf = idf[row]; hr[q].row = rows[row];
+                    d_out[row] = running;
+                }
                 hd[k] = P;
-                const int row = drow[c][j];
-                hr[q].counts = running; hr[q].touched = P.touched;
-                hr[q].idf = idf[row]; hr[q].row = rows[row];
-                d_out[row] = running;
                 handled[row] = 1;
             }
             dblocks[c] = b0;

@@ -96,10 +96,11 @@ __device__ __forceinline__ void sa_block_bitonic_desc(u64* a, u32 n_pow2) {
 // pruning (slots grow monotonically); the final top-k is exact and deterministic.
 // `slot_val`: lanes 0..31 of every wave hold slots[q*32 + lane] (loaded early by the caller to
 // hide the latency), the other lanes 0xFFFFFFFF.  No barriers inside: waves finish independently.
+// `docs` (LDS) given: element e is the doc doc0 + docs[e] instead of doc0 + e (a block of documents that are not neighbours).
 template <int TILE, int THREADS>
 __device__ __forceinline__ void sa_tile_topk_pruned(float* acc, u32 slot_val, u32 q, u32 tile, u64 doc0, u32 k,
                                                     u32* __restrict__ slots, u64* __restrict__ cand, u32 cand_cap,
-                                                    u32* __restrict__ cand_cnt) {
+                                                    u32* __restrict__ cand_cnt, const u32* docs = nullptr) {
     constexpr int NW = THREADS / SA_WAVE;
     constexpr int E = TILE / THREADS;
     const u32 tid = threadIdx.x;
@@ -150,7 +151,7 @@ __device__ __forceinline__ void sa_tile_topk_pruned(float* acc, u32 slot_val, u3
             const u64 b = __ballot(keep);
             if (keep) {
                 const u32 pos = base + (u32)__popcll(b & lt);
-                const u64 doc = doc0 + e;
+                const u64 doc = doc0 + (docs ? (u64)docs[e] : (u64)e);
                 if (pos < cand_cap) qcand[pos] = ((u64)x << 32) | (u64)(u32)(~(u32)doc);
             }
             base += (u32)__popcll(b);
@@ -187,7 +188,7 @@ __device__ __forceinline__ void sa_tile_topk_pruned(float* acc, u32 slot_val, u3
         const bool owner = (e1 == emin);
         if (owner) {
             acc[emin] = 0.f;
-            const u64 doc = doc0 + emin;
+            const u64 doc = doc0 + (docs ? (u64)docs[emin] : (u64)emin);
             if (cbase + r < cand_cap) qcand[cbase + r] = ((u64)m << 32) | (u64)(u32)(~(u32)doc);
         }
         const bool need = owner && stale;
