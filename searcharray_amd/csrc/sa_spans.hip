@@ -2197,7 +2197,7 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
     const int nj = (int)jobs.size();
     const int nd = (int)(djobs[0].size() + djobs[1].size() + djobs[2].size());
     const int nv = nj + (fused_rank ? 0 : nd);         // count vectors / ranking jobs
-    if (nv == 0) return SA_OK;
+    if (nj + nd == 0) return SA_OK;
     // jobs of a class are neighbours in the device array
     std::vector<int> order((size_t)nj);
     for (int j = 0; j < nj; j++) order[(size_t)j] = j;
@@ -2235,8 +2235,8 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
         ix->span_counts_cap = (size_t)nv * cstride;
         ix->span_counts_dirty = true;
     }
-    if (ix->span_counts_dirty) SA_HIP(hipMemsetAsync(ix->d_span_counts, 0, ix->span_counts_cap * sizeof(float), st));
-    ix->span_counts_dirty = true;                                   // (until the caller has enqueued the ranking launch)
+    if (ix->span_counts_dirty && ix->span_counts_cap) SA_HIP(hipMemsetAsync(ix->d_span_counts, 0, ix->span_counts_cap * sizeof(float), st));
+    ix->span_counts_dirty = nv > 0;                                 // (until the caller has enqueued the ranking launch)
     if (!ix->ev_span_jobs) SA_HIP(hipEventCreateWithFlags(&ix->ev_span_jobs, hipEventDisableTiming));
     else SA_HIP(hipEventSynchronize(ix->ev_span_jobs));             // (the previous upload has left the host image)
     char* base = (char*)ix->d_span_batch + jobs_bytes;

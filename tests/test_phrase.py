@@ -812,4 +812,17 @@ def test_slop_phrases_of_a_batch_share_their_launches(api, monkeypatch):
         ws, wd = O.topk(orc.score(list(ph), slop=sl), k)
         n = int((ws > 0).sum())
         assert np.array_equal(ps[i, :n], ws[:n]) and np.array_equal(pd_[i, :n], wd[:n]), f"phrase {ph} slop {sl}"
+    # a batch of two-term slop phrases only: every phrase ranks inside the doc-parallel kernel, no count vector, no ranking launch
+    monkeypatch.delenv("SA_SPAN_MULTI", raising=False)
+    monkeypatch.delenv("SA_SPAN_DOC_MULTI", raising=False)
+    pairs = [[int(a), int(b)] for a, b in rng.choice(min(vocab, 40), (24, 2)) if a != b] + [[0, 1], [1, 0], [2, 0]]
+    pb = dev.phrase_batch(pairs, k=k, slop=2)
+    for _ in range(2):
+        pb.run()
+    ps, pd_ = pb.fetch()
+    pb.close()
+    for i, ph in enumerate(pairs):
+        ws, wd = O.topk(orc.score(list(ph), slop=2), k)
+        n = int((ws > 0).sum())
+        assert np.array_equal(ps[i, :n], ws[:n]) and np.array_equal(pd_[i, :n], wd[:n]), f"phrase {ph} slop 2 (pairs only)"
     dev.close()
