@@ -1755,7 +1755,9 @@ __global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused_multi(const Sp
         const u32 mid = lo + ((hi - lo) >> 1);
         if (jobs[mid].block0 <= blockIdx.x) lo = mid; else hi = mid;
     }
-    const SpanDocParams p = jobs[lo];
+    // (a reference, not a copy: a private copy of the job lives in scratch -- its term arrays are indexed at run time -- and
+    // every access of it is HBM traffic; through the pointer the fields are scalar loads at a wave-uniform address)
+    const SpanDocParams& p = jobs[lo];
     if (blockIdx.x - p.block0 >= p.n_blocks) return;
     sa_span_doc_fused_body<TT>(p, blockIdx.x - p.block0);
 }
