@@ -796,6 +796,7 @@ struct GroupParams {
     u64 dense_stride;
     u32 n_groups;
     u32 tile0, n_tiles_run; // tiles [tile0, tile0 + n_tiles_run)
+    u32 tpx;                // tiles per XCD: XCD x takes the RANGE [x * tpx, (x + 1) * tpx) of the run's tiles (0: tiles t = x mod 8)
     u32 tt, tt_shift;       // lanes per query while the step tables are built: power of two >= max(T - 1, 1)
     u64* wl;                // work list of (tile << 32 | device row) items left to the per-query kernel
     u32* wl_cnt;
@@ -857,7 +858,10 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
     const u32 per = 8u * gp.n_groups;
     const u32 chunk = blockIdx.x / per, r = blockIdx.x % per;
     const u32 g = r >> 3;
-    const u32 trel = chunk * 8u + (r & 7u);
+    // ... and an XCD walks a RANGE of consecutive tiles: a term's slices of neighbouring tiles are neighbours in memory, and
+    // with tiles dealt round-robin the cache line a tile's slice shares with the next tile's was fetched into two L2s -- for a
+    // sparse term (4 postings = 32 bytes per tile) every line into four.
+    const u32 trel = gp.tpx ? (r & 7u) * gp.tpx + chunk : chunk * 8u + (r & 7u);
     if (trel >= gp.n_tiles_run) return;
     const u32 tile = gp.tile0 + trel;
     // a LOOSE group (bit 31 of the size): queries that share nothing -- no base, ALL their terms are overlaid on
@@ -1529,6 +1533,7 @@ static int sa_launch_bm25_groups(sa_index* ix, const sa_batch* bt, const Bm25Par
     gp.dense = (bt->impacts && sa_env_int("SA_GROUP_DENSE", 1) != 0) ? bt->impacts->d_dense : nullptr;
     gp.dense_stride = bt->impacts ? bt->impacts->dense_stride : 0;
     const u64 blocks = (u64)((gp.n_tiles_run + 7u) / 8u) * 8u * gp.n_groups;
+    gp.tpx = sa_env_int("SA_XCD_RANGE", 1) != 0 ? (gp.n_tiles_run + 7u) / 8u : 0u;
     if (blocks > 0x7FFFFFFFull) { sa_set_error("grouped launch: bad grid"); return SA_ERR_STATE; }
     gp.wl = bt->d_wl; gp.wl_cnt = bt->d_wl_cnt;
     const u64 worst = (u64)gp.n_tiles_run * bt->n_grouped_rows;

@@ -63,6 +63,7 @@ struct HgArgs {
     u32* gthr; u32* hist; u64* cand; u32* cand_cnt; u64* wl; u32* wl_cnt;
     u64 doc_base;
     u32 n_tiles, T, k, cand_cap, group0, n_groups, tile0, n_tiles_run;
+    u32 spx;                // super-tiles per XCD (an XCD takes a range of consecutive super-tiles), 0: dealt round-robin
 };
 
 // survivors of a vector -> the query's histogram and candidate list (as sa_tile_topk_hist); rare once the bounds stand, so
@@ -107,7 +108,7 @@ __global__ void __launch_bounds__(SA_HG_NW * 64, 4) sa_k_bm25_headgroup(const Hg
     const u32 per = 8u * a.n_groups;
     const u32 chunk = blockIdx.x / per, r = blockIdx.x % per;
     const u32 g = a.group0 + (r >> 3);
-    const u32 srel = chunk * 8u + (r & 7u);
+    const u32 srel = a.spx ? (r & 7u) * a.spx + chunk : chunk * 8u + (r & 7u);     // (an XCD walks a range of super-tiles: see the grouped kernel)
     if (srel * (u32)ST >= a.n_tiles_run) return;
     const u32 tile_lo = a.tile0 + srel * (u32)ST;
     const u32 tile_end = a.tile0 + a.n_tiles_run;
@@ -429,6 +430,8 @@ int sa_launch_bm25_headgroups(sa_index* ix, const sa_batch* bt, const Bm25Params
     if (ix->tile_docs != 2048u) { sa_set_error("head-group kernel: tile_docs %u", ix->tile_docs); return SA_ERR_STATE; }
     const u32 n_st = (a.n_tiles_run + (u32)SA_HG_ST - 1u) / (u32)SA_HG_ST;
     const u64 blocks = (u64)((n_st + 7u) / 8u) * 8u * a.n_groups;
+    const char* xr = getenv("SA_XCD_RANGE");
+    a.spx = (xr && atoi(xr) == 0) ? 0u : (n_st + 7u) / 8u;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) { sa_set_error("head-group launch: bad grid"); return SA_ERR_STATE; }
     hipLaunchKernelGGL(sa_k_bm25_headgroup, dim3((u32)blocks), dim3(SA_HG_NW * 64), 0, st, a);
     return SA_OK;
