@@ -83,6 +83,7 @@ def main():
         n = 20 if phase == "warm" else args.steps
         ts = {"step": 0.0, "fetch": 0.0}
         index.synchronize()
+        h0 = [pair[b].host_times() for b in (0, 1)]
         t00 = time.perf_counter()
         for i in range(n):
             b = i & 1
@@ -97,7 +98,11 @@ def main():
         index.synchronize()
         total = time.perf_counter() - t00
     out = {k_: round(v / args.steps * 1e6, 1) for k_, v in ts.items()}
+    h1 = [pair[b].host_times() for b in (0, 1)]
+    fills = sum(h1[b]["fills"] - h0[b]["fills"] for b in (0, 1))
+    inside = {k_: round(sum(h1[b][k_] - h0[b][k_] for b in (0, 1)) / max(fills, 1), 1) for k_ in ("fill_cpu_us", "fill_enqueue_us", "run_enqueue_us")}
     out.update({"docs": D, "queries": B, "comm": args.comm, "us_per_step_total": round(total / args.steps * 1e6, 1),
+                "inside_the_library": inside,
                 "call": "sa_batch_step (idf gather + reset + run in one call)"})
     print(json.dumps(out))
 

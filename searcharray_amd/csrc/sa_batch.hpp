@@ -4,6 +4,7 @@
 #include "sa_index.hpp"
 #include "sa_topk.hpp"
 #include <vector>
+#include <time.h>
 
 #define SA_MAX_QTERMS 32
 #define SA_KMAX 1024
@@ -20,6 +21,7 @@ struct sa_batch {
     u32 B = 0, T = 0, k = 0;
     float k1 = 1.2f, b = 0.75f;
     std::vector<u32> perm;          // device row r holds caller query perm[r] (results: caller order)
+    u64 host_ns[4] = {0, 0, 0, 0};  // sa_batch_host_times
     std::vector<float> step_idf;    // sa_batch_step: the query set's weights, gathered from the index's idf table
     // Everything a NEW set of queries changes on the device is one contiguous UPLOAD BLOCK (d_up) with a
     // page-locked host image: sa_batch_reset fills the image and enqueues ONE hipMemcpyAsync (+ the slice-table
@@ -135,6 +137,12 @@ int sa_launch_phrase_tiles(sa_batch* bt, hipStream_t st);
 int sa_batch_alloc_topk(sa_batch* bt, u32 n_tiles, u32 waves);
 // the upload block (sa_batch.hpp: d_up / h_up): allocate, take the next host image, enqueue its copy
 int sa_batch_alloc_upload(sa_batch* bt, size_t bytes);
+// host time of the step's parts, cumulative nanoseconds (sa_batch_host_times): [0] sa_batch_fill up to the upload (grouping, pruning
+// tables: CPU only), [1] its enqueues (upload copy + bounds launch), [2] sa_batch_run's enqueues, [3] number of fills
+static inline u64 sa_now_ns() {
+    timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (u64)ts.tv_sec * 1000000000ull + (u64)ts.tv_nsec;
+}
 int sa_batch_upload_begin(sa_batch* bt, char** image);
 int sa_batch_upload_commit(sa_batch* bt);
 void sa_batch_free(sa_batch* bt);

@@ -1850,6 +1850,7 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
     const u32 B = bt->B, T = bt->T;
     const float k1 = bt->k1, b = bt->b;
     char* img = nullptr;
+    const u64 t_begin = sa_now_ns();
     SA_TRY(sa_batch_upload_begin(bt, &img));
     auto at = [&](const void* dptr) { return img + ((const char*)dptr - bt->d_up); };
     u64* h_p1 = (u64*)at(bt->d_p1_off);
@@ -2145,9 +2146,12 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
         }
         bt->bloom_bytes = bytes;
     }
+    const u64 t_host = sa_now_ns();
     SA_TRY(sa_batch_upload_commit(bt));
     SA_TRY(sa_launch_make_bounds(ix, bt->d_terms, B * T, bt->d_bounds, bt->d_qbase, bt->st, bt->d_qbase_imp));
     SA_HIP(hipGetLastError());
+    const u64 t_end = sa_now_ns();
+    bt->host_ns[0] += t_host - t_begin; bt->host_ns[1] += t_end - t_host; bt->host_ns[3]++;
     return SA_OK;
 }
 
@@ -2437,6 +2441,8 @@ extern "C" int sa_batch_run(sa_batch_t* bt, int sync) {
     std::lock_guard<std::mutex> g(ix->mu);
     SA_HIP(hipSetDevice(ix->device));
     hipStream_t st = bt->st;
+    const u64 t_run = sa_now_ns();
+    struct RunClock { sa_batch* b; u64 t0; ~RunClock() { b->host_ns[2] += sa_now_ns() - t0; } } run_clock{bt, t_run};
     if (ix->comm) {
         // Scoring runs on the index stream; the all-gather of the per-shard top-k and the
         // cross-rank merge run on the exchange stream, double-buffered, so they overlap the next
@@ -2506,6 +2512,12 @@ extern "C" int sa_batch_step(sa_batch_t* bt, const uint32_t* terms) {
         SA_TRY(sa_batch_fill(bt, terms, bt->step_idf.data()));
     }
     return sa_batch_run(bt, 0);
+}
+
+extern "C" int sa_batch_host_times(sa_batch_t* bt, uint64_t* out4) {
+    SA_ARG(bt && out4, "null argument");
+    for (int i = 0; i < 4; i++) out4[i] = bt->host_ns[i];
+    return SA_OK;
 }
 
 // External-collective variant (the caller owns the exchange, e.g. torch.distributed over RCCL,

@@ -496,6 +496,12 @@ class QueryBatch:
         return {"groups": int(out[0]), "grouped_queries": int(out[1]), "shared_first_term": int(out[2]), "per_query_kernel": int(out[3]),
                 "head_groups": int(hg[0]), "head_group_queries": int(hg[1])}
 
+    def host_times(self) -> dict:
+        """host microseconds this batch's steps have cost so far, by part (sa_batch_host_times), and the number of query sets"""
+        out = (_lib.c_uint64 * 4)()
+        self.api.call("sa_batch_host_times", self._h, out)
+        return {"fill_cpu_us": out[0] / 1e3, "fill_enqueue_us": out[1] / 1e3, "run_enqueue_us": out[2] / 1e3, "fills": int(out[3])}
+
     def stats(self, enable: bool = True) -> Tuple[int, int]:
         """(candidate docs scored by the sparse path since the last call, queries of the last run that
         were answered without a tile scan); diagnostics, switches the counting on / off."""

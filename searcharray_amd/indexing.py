@@ -155,27 +155,73 @@ def _triples(lens: np.ndarray, terms: np.ndarray):
     return tokens_to_triples(lens, terms)
 
 
+def _batches(array: Iterable, batch_size: int):
+    """lists of at most batch_size docs, in order (the reference's batch_iterator, indexing.py:176-188)"""
+    batch: list = []
+    for doc in array:
+        batch.append(doc)
+        if len(batch) >= batch_size:
+            yield batch
+            batch = []
+    if batch:
+        yield batch
+
+
 def build_index_from_tokenizer(array: Iterable, tokenizer: Callable, truncate: bool = False,
-                               batch_size: int = 100000) -> HostIndex:
-    """reference indexing.py:235-296 (single pass; batch_size is accepted for signature parity).
-    Host work is the tokenizer and the term dictionary only; the result carries the token stream."""
+                               batch_size: int = 100000, workers: int = 4) -> HostIndex:
+    """reference indexing.py:235-296: the docs are taken ``batch_size`` at a time; a batch's token ids end as ONE uint32
+    array (4 bytes per token) and its Python objects are dropped before the next batch is touched, so the transient host
+    memory is a batch's, not the collection's (the reference's design size of 1 M docs is ~32 M tokens: > 1 GB as Python
+    ints in one list, 128 MB as these arrays).  ``workers`` > 1 runs the TOKENIZER of up to ``workers`` batches ahead on
+    a thread pool, as the reference does; term ids are still assigned by this thread in document order -- unlike the
+    reference's (its workers race for the shared dictionary, indexing.py:190-209), so an index does not depend on the
+    thread timing.  Host work is the tokenizer and the term dictionary only; the result carries the token stream, which
+    is sorted and roaringish-encoded on the device (csrc/sa_build.hip)."""
+    if batch_size < 1:
+        raise ValueError("batch_size must be positive")
     term_dict = TermDict()
     add_terms = term_dict.add_terms
     max_posn = rz.MAX_POSN
-    flat: List[int] = []
-    lens: List[int] = []
-    for doc in array:
-        toks = add_terms(tokenizer(doc))
-        if len(toks) > max_posn:
-            if truncate:
-                toks = toks[:max_posn]                      # reference indexing.py:120-122,76-78
-            else:
-                raise ValueError(f"Document length exceeds maximum of {max_posn}")    # indexing.py:141-142
-        flat.extend(toks)
-        lens.append(len(toks))
-    n_docs = len(lens)
-    lens_a = np.asarray(lens, dtype=np.int64) if n_docs else np.empty(0, np.int64)
-    tokens = np.asarray(flat, dtype=np.uint32) if flat else np.empty(0, np.uint32)
+    chunks: List[np.ndarray] = []
+    len_chunks: List[np.ndarray] = []
+
+    def take(tokenized: list):
+        """one batch of tokenized docs -> its ids and lengths as arrays"""
+        flat: List[int] = []
+        lens = np.empty(len(tokenized), dtype=np.int64)
+        for i, toks in enumerate(tokenized):
+            ids = add_terms(toks)
+            if len(ids) > max_posn:
+                if truncate:
+                    ids = ids[:max_posn]                    # reference indexing.py:120-122,76-78
+                else:
+                    raise ValueError(f"Document length exceeds maximum of {max_posn}")    # indexing.py:141-142
+            flat.extend(ids)
+            lens[i] = len(ids)
+        chunks.append(np.asarray(flat, dtype=np.uint32) if flat else np.empty(0, np.uint32))
+        len_chunks.append(lens)
+
+    def tokenize(batch: list) -> list:
+        return [tokenizer(doc) for doc in batch]
+
+    if workers is None or workers <= 1:
+        for batch in _batches(array, batch_size):
+            take(tokenize(batch))
+    else:
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        pending: deque = deque()
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            for batch in _batches(array, batch_size):
+                pending.append(pool.submit(tokenize, batch))
+                if len(pending) >= workers:
+                    take(pending.popleft().result())
+            while pending:
+                take(pending.popleft().result())
+    lens_a = np.concatenate(len_chunks) if len_chunks else np.empty(0, np.int64)
+    tokens = np.concatenate(chunks) if chunks else np.empty(0, np.uint32)
+    chunks.clear()
+    n_docs = len(lens_a)
     doc_ptr = np.zeros(n_docs + 1, dtype=np.uint64)
     np.cumsum(lens_a, out=doc_ptr[1:])
     return HostIndex(term_dict, lens_a.astype(np.float32), tokens=tokens, doc_ptr=doc_ptr)

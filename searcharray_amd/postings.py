@@ -287,16 +287,17 @@ class SearchArray(ExtensionArray):
     def index(cls, array: Iterable, tokenizer=ws_tokenizer, truncate=False, batch_size=100000,
               avoid_copies=True, workers=4, cache_gt_than=25, data_dir: Optional[str] = None,
               autowarm=True) -> 'SearchArray':
-        """Index strings with ``tokenizer`` (reference postings.py:249-300).  ``workers`` and
-        ``cache_gt_than`` are accepted for signature compatibility: index build is a single host pass
-        and the derived tf/df live on the device.  ``data_dir``: as in the reference
+        """Index strings with ``tokenizer`` (reference postings.py:249-300).  The docs are tokenised ``batch_size`` at a
+        time, ``workers`` batches ahead on a thread pool (indexing.build_index_from_tokenizer; reference
+        indexing.py:235-296); ``cache_gt_than`` is accepted for signature compatibility: the derived tf/df live on the
+        device.  ``data_dir``: as in the reference
         (indexing.py:291-293 -> PosnBitArray.memmap, middle_out.py:333-335) the encoded positions are
         written to ``<data_dir>/<number of files in it>.dat`` as raw uint64 and pickles of the array
         then carry the filename instead of the words; here the file is written from, and read back
         into, HBM directly (csrc/sa_io.hip)."""
         if not is_list_like(array):
             raise TypeError(f"Expected list-like object, got {type(array)}")
-        host = build_index_from_tokenizer(array, tokenizer, truncate=truncate, batch_size=batch_size)
+        host = build_index_from_tokenizer(array, tokenizer, truncate=truncate, batch_size=batch_size, workers=workers)
         arr = cls.__new__(cls)
         arr.avoid_copies = avoid_copies
         arr.tokenizer = tokenizer
