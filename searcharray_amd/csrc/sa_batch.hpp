@@ -43,7 +43,7 @@ struct sa_batch {
     bool unfetched = false;         // a run's results have been queued for the host and not been fetched yet
     u32* d_xflag = nullptr;         // sharded: OR over the ranks of the overflow flags (travels with the all-gather); behind d_final
     u32 wl_cap = 0;                 // entries of d_wl
-    size_t bloom_cap = 0;           // bytes of d_bloom (worst case of this shard, allocated by the first pruned run)
+    size_t bloom_cap = 0;           // bytes of d_bloom (what the query sets so far needed x 1.5; grows in sa_batch_ensure_bloom)
     u32* d_terms = nullptr;
     u32* d_perm = nullptr;
     float* d_idf = nullptr;

@@ -1829,19 +1829,24 @@ static u64 sa_batch_lead_limit(const sa_batch* bt) {
     return limit1;
 }
 
-// The Bloom filters of the lead terms are sized per query set; the buffer holds the worst case of this shard
-// (B lead terms of lead-limit postings each) and is allocated by the first run that prunes -- never by a reset.
+// The Bloom filters of the lead terms are sized per query set (bt->bloom_bytes, sa_batch_fill).  The buffer holds what the
+// query sets seen so far needed, with half as much again: a run whose set needs more waits for the batch's stream (older runs
+// of this batch read the old buffer), frees it and allocates the larger one -- after the first few sets of a stream never
+// again.  (Round 3 allocated the worst case of the shard -- B lead terms of lead-limit postings each: 512 MiB per 256-query
+// batch at 10 M docs where a BASELINE set needs ~20 MiB.)
 int sa_batch_ensure_bloom(sa_batch* bt) {
-    if (bt->d_bloom) return SA_OK;
-    const u64 limit1 = sa_batch_lead_limit(bt);
-    u64 maxdf = 0;
-    const sa_index* ix = bt->ix;
-    for (u32 t = 0; t < ix->n_terms; t++) {
-        const u64 df = ix->h_tf_off[t + 1] - ix->h_tf_off[t];
-        if (df <= limit1 && df > maxdf) maxdf = df;
+    const size_t need = bt->bloom_bytes;
+    if (bt->d_bloom && bt->bloom_cap >= need) return SA_OK;
+    if (bt->d_bloom) {
+        SA_HIP(hipStreamSynchronize(bt->st));
+        SA_HIP(hipFree(bt->d_bloom));
+        bt->d_bloom = nullptr; bt->bloom_cap = 0;
     }
-    bt->bloom_cap = (size_t)bt->B * sa_pow2_cells(maxdf);
-    SA_HIP(hipMalloc(&bt->d_bloom, bt->bloom_cap));
+    size_t cap = need + need / 2;
+    const size_t floor_bytes = (size_t)std::max(1024, sa_env_int("SA_BLOOM_FLOOR", 1 << 20));      // (tests: small, so that the buffer has to grow)
+    if (cap < floor_bytes) cap = floor_bytes;
+    SA_HIP(hipMalloc(&bt->d_bloom, cap));
+    bt->bloom_cap = cap;
     return SA_OK;
 }
 

@@ -79,6 +79,28 @@ def test_reset_equals_fresh_batch_and_oracle(api, corpus, monkeypatch, mode, k):
     dev.close()
 
 
+def test_bloom_buffer_grows_with_the_query_sets(api, corpus, monkeypatch):
+    """dynamic pruning: the lead terms' Bloom filters live in a buffer sized from the query sets seen so far
+    (sa_batch_ensure_bloom) -- sets whose lead terms get longer and longer make it grow between runs, with a run in flight"""
+    monkeypatch.setenv("SA_SPARSE", "1")
+    monkeypatch.setenv("SA_BLOOM_FLOOR", "1024")
+    words, off, lens, orc = corpus
+    dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api)
+    rng = np.random.default_rng(9)
+    B, k = 24, 7
+    sets = [rng.integers(lo, hi, (B, 3)) for lo, hi in [(380, 400), (200, 260), (60, 90), (12, 30), (0, 6), (300, 400)]]
+    bt = dev.batch(sets[0], k=k)
+    for i, qs in enumerate(sets):
+        if i:
+            bt.reset(qs)
+        bt.run(sync=False)
+        bt.run(sync=False)
+        scores, docs = bt.fetch()
+        assert_batch(orc, qs, scores, docs, k, f"bloom growth, set {i}")
+    bt.close()
+    dev.close()
+
+
 def test_two_batches_alternating_without_waiting(api, corpus, monkeypatch):
     """the pipeline of bench.py's fresh_batches leg: reset + run of batch i+1 are enqueued before batch i's results are
     fetched; every fetch waits for its own batch only"""
