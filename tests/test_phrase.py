@@ -826,3 +826,29 @@ def test_slop_phrases_of_a_batch_share_their_launches(api, monkeypatch):
         n = int((ws > 0).sum())
         assert np.array_equal(ps[i, :n], ws[:n]) and np.array_equal(pd_[i, :n], wd[:n]), f"phrase {ph} slop 2 (pairs only)"
     dev.close()
+
+
+@pytest.mark.parametrize("div", ["0", "32", "1000000"])
+def test_fused_kernel_routes_dd_staged_and_searched(api, monkeypatch, div):
+    """sa_k_phrase_fused (csrc/sa_phrase.hip): a wave takes 256 consecutive anchor words; another term's words around them come
+    through the term's doc directory row (SA_DOCDIR_DIV=1000000: every term of >= 64 words has one), from the slice of the
+    term's list the wave stages in LDS (found by the wave-cooperative lower bound), or -- a slice longer than 1024 words:
+    frequent terms without rows, SA_DOCDIR_DIV=0 -- by a search in global memory from the slice's start.  All equal the
+    oracle's counts (the reference's phrase_freqs, bigram_freqs.py:48-307 + middle_out.py:73-168), on lists long enough for
+    several chunks per anchor, anchors in every phrase position, lists that end inside a wave's last round"""
+    monkeypatch.setenv("SA_DOCDIR_DIV", div)
+    monkeypatch.setenv("SA_PHRASE_MODE", "fused")
+    n_docs, vocab = 6000, 300
+    t, d, p, lens = synth.corpus_triples(n_docs, vocab, 40, seed=21)
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
+    rng = np.random.default_rng(3)
+    phrases = [[0, 1], [1, 0], [0, 1, 2], [2, 0, 1], [5, 0], [0, 40], [40, 0, 1], [1, 120, 0], [0, 1, 2, 3, 4], [7, 3, 0, 250],
+               [299, 0], [0, 299], [150, 151], [30, 2, 31]]
+    phrases += [[int(x) for x in rng.choice(60, 3, replace=False)] for _ in range(6)]
+    for ph in phrases:
+        got = dev.phrase_freqs_dense(ph)
+        want = orc.phrase_freqs(ph)
+        assert np.array_equal(got, want), f"phrase {ph} (SA_DOCDIR_DIV={div}): {int((got != want).sum())} docs differ"
+    dev.close()
