@@ -184,6 +184,35 @@ struct FusedPhraseParams {
                                  //   exact in any order)
 };
 
+__global__ void __launch_bounds__(256) sa_k_phrase_fused(const FusedPhraseParams p) {
+    const u64* anc = p.ptr[p.anchor];
+    const u32 na = p.len[p.anchor];
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < na; i += gridDim.x * blockDim.x) {
+        const u64 w = anc[i];
+        const u64 m = sa_phrase_anchor_mask_win(w, p.T, p.anchor, [&](int t, u64 h, bool want_prev, bool want_next) -> u64 {
+            const u64* a = p.ptr[t];
+            const u32 n = p.len[t];
+            if (p.dd[t]) return sa_window_docdir(a, n, p.dd[t], h, want_prev, want_next);   // uniform per term
+            const u64 delta = 1ull << SA_LSB_BITS;
+            u32 hint = 0;
+            u64 win = 0;
+            if (want_prev) win |= sa_payload_at(a, n, h - delta, hint);
+            win |= sa_payload_at(a, n, h, hint) << 18;
+            if (want_next) win |= sa_payload_at(a, n, h + delta, hint) << 36;
+            return win;
+        });
+        if (m) {
+            if (p.fcounts) unsafeAtomicAdd(&p.fcounts[w >> SA_KEY_SHIFT], (float)__popcll(m));
+            else atomicAdd(&p.step[w >> SA_KEY_SHIFT], (u32)__popcll(m));
+        }
+    }
+}
+
+// ---- the alternative, measured and NOT the default (SA_PHRASE_FUSED_COOP=1 selects it): on zipf-1M it is slower than
+//      the kernel above on every phrase -- 12.8 - 19.5 us against <= 15.9 on `t0 t1 t2` (anchor of 720 K words, directory rows: the loads
+//      per anchor word are the same, only their grouping changes, and the texture path, not latency, bounds them), 10 - 37 us
+//      against 4 - 8 on phrases of rare terms (anchor of < 1024 words = ONE wave: its lower bound, staging rounds and LDS
+//      searches are a longer dependent chain than 15 probes of a list whose top levels sit in L2)
 // Wave-cooperative lower bound on the header: first index in [0, n) whose (word & SA_HEADER_MASK) >= key.  Every round the 64
 // lanes probe 64 evenly spaced words of what is left and a ballot keeps the one interval the answer lies in: log64(n) global
 // round trips (3 for a list of 100 K words) where a lane on its own takes log2(n) = 17 dependent ones.
@@ -217,7 +246,7 @@ __device__ __forceinline__ u32 sa_wave_lower_bound(const u64* __restrict__ a, u3
 #define SA_PF_WPL 4
 #define SA_PF_CAP 1024
 
-__global__ void __launch_bounds__(256) sa_k_phrase_fused(const FusedPhraseParams p) {
+__global__ void __launch_bounds__(256) sa_k_phrase_fused_coop(const FusedPhraseParams p) {
     __shared__ u64 s_stage[4][SA_PF_CAP];
     const u32 lane = threadIdx.x & 63u;
     const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -812,7 +841,13 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
             fp.anchor = anchor;
             if (fp.T > SA_MAX_FUSED) { sa_set_error("fused phrase kernel: sub-phrase longer than 18 terms"); return SA_ERR_UNSUPPORTED; }
             if (fp.len[anchor] > 0)
-                hipLaunchKernelGGL(sa_k_phrase_fused, dim3(sa_grid_for(((u64)fp.len[anchor] + SA_PF_WPL - 1) / SA_PF_WPL)), dim3(256), 0, st, fp);
+                {
+                const char* coop = getenv("SA_PHRASE_FUSED_COOP");
+                if (coop && atoi(coop) != 0)
+                    hipLaunchKernelGGL(sa_k_phrase_fused_coop, dim3(sa_grid_for(((u64)fp.len[anchor] + SA_PF_WPL - 1) / SA_PF_WPL)), dim3(256), 0, st, fp);
+                else
+                    hipLaunchKernelGGL(sa_k_phrase_fused, dim3(sa_grid_for(fp.len[anchor])), dim3(256), 0, st, fp);
+            }
             if (nparts > 1) hipLaunchKernelGGL(sa_k_min_step, dim3(sa_grid_for(N)), dim3(256), 0, st, running, step, N, pi == 0 ? 1 : 0);
         }
         return SA_OK;
