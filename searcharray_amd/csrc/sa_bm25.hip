@@ -1242,6 +1242,27 @@ sa_k_run_reset(u32* __restrict__ slots, u64 words, u64* __restrict__ bloom, u64 
     for (u64 i = t; i < n8; i += stride) bloom[i] = 0ull;
 }
 
+// OPTIMISTIC bounds for big k (grouped exhaustive path).  The warm-up tiles are a sample of the shard: a fraction f of its
+// docs.  The bound they establish -- the k-th best score of the sample -- is safe but far below the k-th best of the shard
+// (k = 1000, f = 1/150: the sample's 1000th best is the shard's ~150 000th), so the grouped kernel that follows reports
+// thousands of survivors per query before the bound has risen.  Of the shard's top k, the sample holds about k f (Poisson):
+// its j-th best, j = k f + 4.5 sqrt(k f) + 5, lies BELOW the shard's k-th best unless the sample holds j or more of the top
+// k -- a 1e-6 event.  This kernel raises every query's bound to that score (lower edge of its histogram bin).  "Unless" is
+// checked, not assumed: the merge finds fewer than k keys at or above a bound that was too high (sa_k_topk_merge sets the
+// run's redo flag to 2) and sa_batch_fetch redoes the batch without bounds, as for an overflowing candidate list -- and
+// switches the seeding off for this index (doc ids that correlate with scores break the sampling assumption every time).
+__global__ void __launch_bounds__(256)
+sa_k_seed_bounds(const u32* __restrict__ hist, u32* __restrict__ gthr, u32 n_rows, u32 j) {
+    const u32 lane = threadIdx.x & 63u;
+    const u32 q = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (q >= n_rows) return;                                    // (wave-uniform)
+    u32 tot[SA_HBINS / SA_WAVE];
+#pragma unroll
+    for (int i = 0; i < SA_HBINS / SA_WAVE; i++) tot[i] = hist[(u64)q * SA_HBINS + lane * (SA_HBINS / SA_WAVE) + i];
+    const u32 g = sa_hist_bound(tot, j, lane);
+    if (lane == 0 && g) atomicMax(&gthr[q], g);
+}
+
 __global__ void __launch_bounds__(1024)
 sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__ out,
                 const u32* __restrict__ out_row, u32 rank_stride, const u32* __restrict__ cnt,
@@ -1384,6 +1405,9 @@ sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__
         __syncthreads();
         n_sel = s_n;
     }
+    // fewer than k keys at or above a bound: with bounds derived from k counted docs that cannot happen -- the bound was an
+    // optimistic one (sa_k_seed_bounds) and too high
+    if (gthr && overflow && n_sel < k && tid == 0 && gthr[q] != 0u) atomicMax(overflow, 2u);
     n_sel = n_sel < SA_MERGE_LIST ? n_sel : SA_MERGE_LIST;
     if (n_sel <= SA_WAVE) {                           // uniform
         // short list: one wave sorts it in registers (bitonic over lanes, no barriers)
@@ -2313,6 +2337,10 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
                 // establishes every query's bound (k-th best score so far), then one wave per (tile, group).
                 // Queries without a group go through the per-query kernel over all tiles.
                 u32 warm = std::max<u32>(16u, bt->k / 8u);     // (k = 1000, 10 M docs: 250 / 128 / 64 warm-up tiles -> 1.07 / 1.02 / 1.05 ms per step)
+                // optimistic bounds from the warm-up sample (sa_k_seed_bounds): from k = 32 on, where the flag the check
+                // needs travels with the results (defer_check), unless a check has failed on this index before
+                const bool seed_on = sa_env_int("SA_SEED", 1) != 0 && !ix->seed_off && defer_check && bt->k >= 32u;
+                if (seed_on) warm = std::max<u32>(16u, bt->k / (u32)std::max(1, sa_env_int("SA_SEED_WARM_DIV", 32)));
                 if (const char* v = getenv("SA_GROUP_WARM")) warm = (u32)atoi(v);
                 if (bt->n_hg_groups) warm = (warm + 3u) & ~3u;   // (the head-group kernel scores super-tiles of up to 4 index tiles)
                 warm = std::min(warm, ix->n_tiles);
@@ -2345,6 +2373,15 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
                     Bm25Params pa = p;
                     pa.qlist = bt->d_iota; pa.nq = bt->n_grouped_rows; pa.tile0 = 0; pa.tile_end = warm;
                     rc_main = sa_launch_bm25(ix, pa, st);
+                }
+                if (rc_main == SA_OK && seed_on && warm > 0 && ix->n_tiles > warm && bt->n_grouped_rows) {
+                    const double warm_docs = std::min<double>((double)warm * ix->tile_docs, (double)ix->n_docs);
+                    const double mu = (double)bt->k * warm_docs / (double)ix->n_docs;
+                    u32 j = (u32)ceil(mu + 4.5 * sqrt(mu) + 5.0);
+                    if (const char* v = getenv("SA_SEED_J")) j = (u32)std::max(1, atoi(v));      // (tests: 1 = far too optimistic, every check fails)
+                    if (j < bt->k)
+                        hipLaunchKernelGGL(sa_k_seed_bounds, dim3((bt->n_grouped_rows + 3u) / 4u), dim3(256), 0, st, (const u32*)bt->d_hist,
+                                           bt->d_gthr, bt->n_grouped_rows, j);
                 }
                 if (rc_main == SA_OK && ix->n_tiles > warm) rc_main = sa_launch_bm25_groups(ix, bt, p, warm, st);
                 if (side) SA_HIP(hipStreamWaitEvent(st, bt->ev_side[1], 0));
@@ -2574,6 +2611,10 @@ extern "C" int sa_batch_fetch(sa_batch_t* bt, float* scores_out, uint64_t* docs_
         bt->unfetched = false;
         const u32 over = (u32)bt->h_res[n + (ix->comm ? 1 : 0)];
         if (over) {
+            // (2: an optimistic bound was too high -- sa_k_seed_bounds; behind the exchange the flag is a plain "redo": with
+            //  bounds seeded at this k it counts as that too)
+            if (over >= 2u || (ix->comm && bt->k >= 32u)) ix->seed_off = true;
+            if (getenv("SA_SEED_TRACE")) fprintf(stderr, "sa_batch_fetch: redo without bounds (flag %u)%s\n", over, ix->seed_off ? ", optimistic bounds off" : "");
             // A run overflowed a candidate list (only possible when the bound could not rise: degenerate score
             // distributions): redo the batch with the unpruned selection.  Sharded: every rank saw the same flag
             // (it travelled with the all-gather) and every rank calls fetch, so all of them redo the exchange.

@@ -146,3 +146,31 @@ def test_loose_groups_equal_oracle_and_per_query_kernel(api, corpus, monkeypatch
     monkeypatch.setenv("SA_GROUP_LOOSE", "0")
     ref = check(api, corpus, queries, k, tile_docs=1024)
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+
+
+@pytest.mark.parametrize("k", [40, 100])
+@pytest.mark.parametrize("seed_env", [{}, {"SA_SEED": "0"}, {"SA_SEED_J": "1"}, {"SA_SEED_J": "3"}])
+def test_optimistic_bounds_from_the_warm_up_sample(api, corpus, monkeypatch, k, seed_env):
+    """k >= 32: after the warm-up tiles (2 of 9 here) every grouped query's bound is raised to the sample's j-th best score
+    (sa_k_seed_bounds), j from the sampling fraction -- or forced far too small (SA_SEED_J=1 / 3): then the merge finds fewer
+    than k keys above the bound, flags the run and fetch redoes the batch without bounds.  Results equal the oracle's either
+    way, in every run of the batch (the second run after a failed check is unseeded: the index has switched seeding off)"""
+    monkeypatch.setenv("SA_SPARSE", "0")
+    monkeypatch.setenv("SA_GROUP_WARM", "2")
+    for name, v in seed_env.items():
+        monkeypatch.setenv(name, v)
+    rng = np.random.default_rng(17 + k)
+    queries = band_queries(rng, 36, 4, heads=[0, 1, 2])
+    words, off, lens, orc = corpus
+    dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api)
+    bt = dev.batch(np.asarray(queries), k=k)
+    for run in range(3):
+        bt.run(sync=False)
+        scores, docs = bt.fetch()
+        for qi, q in enumerate(queries):
+            ws, wd = O.topk(orc.score_terms_sum([int(x) for x in q]), k)
+            n = int((ws > 0).sum())
+            assert np.array_equal(scores[qi, :n], ws[:n]), f"run {run} q{qi} {q} scores"
+            assert np.array_equal(docs[qi, :n], wd[:n]), f"run {run} q{qi} {q} docs"
+    bt.close()
+    dev.close()
