@@ -939,7 +939,13 @@ def main():
     B2 = Bq if weak else args.scaled_queries
     if B2 and B2 != B:
         sets2 = [query_set(20 + i, B2) for i in range(4)]
-        ring2 = [r.make_batch(sets2[i % len(sets2)], check=False) for i in range(min(args.pipeline, 4) if B2 > 1024 else max(1, args.pipeline))]
+        # (a batch's candidate lists: B x min(tiles x k, 2^20) keys of 8 bytes -- 16 GiB at 2048 queries and k = 1000; the batches
+        #  in flight of this leg stay within 40 GiB)
+        inf = r.index.info()
+        per_batch = B2 * min(max(int(inf.n_docs) // 2048, 1) * args.k, 1 << 20) * 8
+        n_ring2 = min(args.pipeline, 4) if B2 > 1024 else max(1, args.pipeline)
+        n_ring2 = max(1, min(n_ring2, int((40 << 30) // max(per_batch, 1))))
+        ring2 = [r.make_batch(sets2[i % len(sets2)], check=False) for i in range(n_ring2)]
         Ks = K if B2 <= B else max(4, K // 4)
         dts2, _ = r.timed_fresh(ring2, sets2, len(ring2), Ks, repeats=3)
         d2 = float(np.median(dts2))
