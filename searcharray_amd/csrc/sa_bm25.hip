@@ -1134,20 +1134,16 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
             at(rs[h]) = ro[h];
             __builtin_amdgcn_wave_barrier();
         };
-        static_assert(NH <= 12, "restore switch");
-        switch (nh) {
-            case 12: if constexpr (NH >= 12) back(std::integral_constant<int, NH >= 12 ? 10 : 0>{});
-            [[fallthrough]];
-            case 10: if constexpr (NH >= 10) back(std::integral_constant<int, NH >= 10 ? 8 : 0>{});
-            [[fallthrough]];
-            case 8: back(std::integral_constant<int, 6>{});
-            [[fallthrough]];
-            case 6: back(std::integral_constant<int, 4>{});
-            [[fallthrough]];
-            case 4: back(std::integral_constant<int, 2>{});
-            [[fallthrough]];
-            default: back(std::integral_constant<int, 0>{});
+        // (nh is even, 2 .. NH; the usual 2 or 4 halves cost one or two scalar tests -- as a switch with fall-through the
+        //  compiler built a chain of ~25 scalar flag operations in front of the two stores of the usual case)
+        static_assert(NH == 10, "restore chain");
+        if (nh > 4u) {
+            if (nh > 8u) back(std::integral_constant<int, 8>{});
+            if (nh > 6u) back(std::integral_constant<int, 6>{});
+            back(std::integral_constant<int, 4>{});
         }
+        if (nh > 2u) back(std::integral_constant<int, 2>{});
+        back(std::integral_constant<int, 0>{});
         if (!look) return;
         u64 kb[NH];
         u32 c = 0;
