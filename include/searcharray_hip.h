@@ -319,6 +319,10 @@ int sa_batch_headgroup_info(sa_batch_t* batch, uint32_t out[2]);
  * (grouping + pruning tables: CPU work only), out[1] = its enqueues (the upload copy, the slice-table launch), out[2] =
  * sa_batch_run's enqueues, out[3] = number of query sets filled.  Diagnostics (scripts/host_cost.py); no reference counterpart. */
 int sa_batch_host_times(sa_batch_t* batch, uint64_t out[4]);
+/* The bound every query of the current set STARTS with (a score; 0: none), in caller order: the best, over the query's terms, of
+ * weight x a lower bound of the term's k-th largest BM25 factor in this shard (the rank tables built with the impact stream,
+ * csrc/sa_bm25.hip sa_k_make_topf) -- never above the query's k-th best score.  Diagnostics / tests; no reference counterpart. */
+int sa_batch_seeds(sa_batch_t* batch, float* out);
 int sa_batch_destroy(sa_batch_t* batch);
 
 typedef struct sa_index_info {

@@ -106,6 +106,7 @@ PROTOTYPES = {
     "sa_batch_group_info": (c_int, [c_void_p, POINTER(c_uint32)]),
     "sa_batch_headgroup_info": (c_int, [c_void_p, POINTER(c_uint32)]),
     "sa_batch_host_times": (c_int, [c_void_p, POINTER(c_uint64)]),
+    "sa_batch_seeds": (c_int, [c_void_p, POINTER(c_float)]),
     "sa_batch_stats": (c_int, [c_void_p, c_int, u64p, u64p]),
     "sa_batch_destroy": (c_int, [c_void_p]),
     "sa_sharded_create": (c_int, [POINTER(c_int), c_int, c_uint64, c_uint32, u64p, u64p, f32p, c_float, c_uint32, POINTER(c_void_p)]),

@@ -21,6 +21,8 @@ struct sa_batch {
     u32 B = 0, T = 0, k = 0;
     float k1 = 1.2f, b = 0.75f;
     std::vector<u32> perm;          // device row r holds caller query perm[r] (results: caller order)
+    u32* d_seed = nullptr;          // [B] (upload block, zeroed by the host) the queries' starting bounds, raised by sa_k_make_bounds
+    bool seed_on = false;           // the current query set has them (non-negative weights, k1 >= 0, 0 <= b <= 1, rank tables built)
     u64 host_ns[4] = {0, 0, 0, 0};  // sa_batch_host_times
     std::vector<float> step_idf;    // sa_batch_step: the query set's weights, gathered from the index's idf table
     // Everything a NEW set of queries changes on the device is one contiguous UPLOAD BLOCK (d_up) with a

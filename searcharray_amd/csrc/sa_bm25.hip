@@ -39,6 +39,7 @@ sa_impacts::~sa_impacts() {
     if (d_imp || d_dense) hipSetDevice(device);
     if (d_imp) hipFree(d_imp);
     if (d_dense) hipFree(d_dense);
+    if (d_topf) hipFree(d_topf);
 }
 
 // dense factor row of one term (sa_impacts::d_dense): row[doc] = factor bits of the term's posting of doc; the row is zeroed before
@@ -55,6 +56,58 @@ sa_k_make_dense_row(const u64* __restrict__ imp, u64 first, u64 df, float* __res
 __host__ __device__ __forceinline__ u64 sa_imp_base(u64 tf_base, u32 term) { return (tf_base + 4ull * term + 1ull) & ~1ull; }
 // first cell of that sentinel pair, for a term of df postings starting at `ibase`
 __host__ __device__ __forceinline__ u64 sa_imp_sentinel(u64 ibase, u64 df) { return ibase + ((df + 1ull) & ~1ull); }
+
+// Rank table of a term's factors (sa_impacts::d_topf): one workgroup per term builds a histogram of its postings' factor
+// bits -- 512 bins per octave over [1/16, 1): (bits >> 14) - (123 << 9), clamped -- and reads off, from the top, the bin
+// that holds the r-th largest factor for each tabulated rank r; the bin's LOWER edge is what is stored.
+#define SA_TOPF_BINS 2048
+#define SA_TOPF_LO (123u << 9)
+struct TopfRanks { u32 r[SA_TOPF_NR]; };
+__global__ void __launch_bounds__(256)
+sa_k_make_topf(const u64* __restrict__ imp, const u64* __restrict__ tf_off, u32 n_terms, const TopfRanks ranks, float* __restrict__ topf) {
+    __shared__ u32 s_h[SA_TOPF_BINS];
+    __shared__ u32 s_part[256];
+    const u32 tid = threadIdx.x;
+    for (u32 t = blockIdx.x; t < n_terms; t += gridDim.x) {
+        const u64 base = tf_off[t], df = tf_off[t + 1] - base;
+        float* const row = topf + (u64)t * SA_TOPF_NR;
+        if (df == 0) {                                           // (uniform)
+            if (tid < (u32)SA_TOPF_NR) row[tid] = 0.f;
+            continue;
+        }
+        for (u32 i = tid; i < (u32)SA_TOPF_BINS; i += 256) s_h[i] = 0;
+        __syncthreads();
+        const u64* const cells = imp + sa_imp_base(base, t);
+        for (u64 i = tid; i < df; i += 256) {
+            const u32 e = (u32)cells[i] >> 14;
+            const u32 b = e <= SA_TOPF_LO ? 0u : (e - SA_TOPF_LO > (u32)(SA_TOPF_BINS - 1) ? (u32)(SA_TOPF_BINS - 1) : e - SA_TOPF_LO);
+            atomicAdd(&s_h[b], 1u);
+        }
+        __syncthreads();
+        // thread i owns bins [8 i, 8 i + 8); above[i] = postings in the bins above its eight
+        u32 mine = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) mine += s_h[tid * 8u + (u32)j];
+        s_part[tid] = mine;
+        __syncthreads();
+        u32 above = 0;
+        for (u32 j = tid + 1; j < 256; j++) above += s_part[j];
+        // bin b holds the r-th largest iff  count(bins > b) < r <= count(bins >= b)
+        u32 cum = above;
+        for (int j = 7; j >= 0; j--) {
+            const u32 b = tid * 8u + (u32)j;
+            const u32 c = s_h[b];
+            for (int x = 0; x < SA_TOPF_NR; x++)
+                if (c && cum < ranks.r[x] && ranks.r[x] <= cum + c)
+                    row[x] = b == 0u ? 0.f : __uint_as_float((b + SA_TOPF_LO) << 14);
+            cum += c;
+        }
+        // ranks beyond the term's postings: no bound
+        if (tid < (u32)SA_TOPF_NR && ranks.r[tid] > df) row[tid] = 0.f;
+        __syncthreads();
+    }
+}
+
 
 __global__ void __launch_bounds__(256)
 sa_k_make_impacts(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, const float* __restrict__ doc_lens,
@@ -164,6 +217,21 @@ static std::shared_ptr<sa_impacts> sa_impacts_get(sa_index* ix, float k1, float 
             }
         }
     }
+    // rank table of every term's factors: the bounds a query starts with (SA_TERM_SEED=0 at batch creation / reset: not used)
+    {
+        const size_t bytes = (size_t)ix->n_terms * SA_TOPF_NR * sizeof(float);
+        if (hipMalloc(&im->d_topf, bytes) == hipSuccess) {
+            TopfRanks rk;
+            for (int i = 0; i < SA_TOPF_NR; i++) rk.r[i] = sa_topf_ranks[i];
+            const u32 grid = ix->n_terms < 16384u ? ix->n_terms : 16384u;
+            hipLaunchKernelGGL(sa_k_make_topf, dim3(grid), dim3(256), 0, st, (const u64*)im->d_imp, (const u64*)ix->d_tf_off, ix->n_terms, rk,
+                               im->d_topf);
+            if (hipGetLastError() != hipSuccess) { hipFree(im->d_topf); im->d_topf = nullptr; }
+        } else {
+            (void)hipGetLastError();
+            im->d_topf = nullptr;
+        }
+    }
     ix->impacts = im;
     return im;
 }
@@ -196,7 +264,8 @@ __global__ void __launch_bounds__(256)
 sa_k_make_bounds(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, const u32* __restrict__ dir_slot,
                  const u32* __restrict__ tile_dir, u32 n_terms, u32 n_tiles, u32 tile_docs,
                  const u32* __restrict__ terms, u32 BT, u32* __restrict__ bounds, u64* __restrict__ qbase,
-                 u64* __restrict__ qbase_imp) {
+                 u64* __restrict__ qbase_imp, const float* __restrict__ topf, const float* __restrict__ idf, u32 T, u32 rank_idx,
+                 u32* __restrict__ seed) {
     const u64 total = (u64)BT * (n_tiles + 1);
     for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (u64)gridDim.x * blockDim.x) {
         const u32 qt = (u32)(e / (n_tiles + 1)), tile = (u32)(e % (n_tiles + 1));
@@ -216,6 +285,12 @@ sa_k_make_bounds(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, co
         if (tile == 0) {
             qbase[qt] = base;
             if (qbase_imp) { qbase_imp[2 * (u64)qt] = ibase; qbase_imp[2 * (u64)qt + 1] = isent; }
+            // the query's starting bound: the best of  weight x (k-th largest factor of the term, or of a rank beyond k)
+            // over its terms (sa_impacts::d_topf; seed[] arrives zeroed with the upload)
+            if (seed && term < n_terms) {
+                const float s = __fmul_rn(topf[(u64)term * SA_TOPF_NR + rank_idx], idf[qt]);
+                if (s > 0.f) atomicMax(&seed[qt / T], __float_as_uint(s));
+            }
         }
     }
 }
@@ -278,7 +353,10 @@ __device__ __forceinline__ void sa_bm25_tile_item(const Bm25Params& p, const u32
     u32 slot_val = 0xFFFFFFFFu;
     if (MODE == 1 && !use_hist && (tid & (SA_WAVE - 1)) < 32u)
         slot_val = __hip_atomic_load(&p.slots[q * 32u + (tid & 31u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (use_hist) slot_val = __hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (use_hist) {
+        slot_val = __hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p.seed) { const u32 sd = p.seed[q]; slot_val = sd > slot_val ? sd : slot_val; }
+    }
 
     // 1. this tile's slice [lo, hi) of every query term: one dependent load from the batch's slice
     //    table.  Lane t of EVERY wave requests term t's entries (the same few cache lines), so the
@@ -968,7 +1046,8 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
         });
     };
     // the queries' bounds, one per lane, read once per item (a bound only ever rises: a stale one is valid)
-    const u32 thr_all = lane < n ? __hip_atomic_load(&p.gthr[row0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    u32 thr_all = lane < n ? __hip_atomic_load(&p.gthr[row0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    if (p.seed && lane < n) { const u32 sd = p.seed[row0 + lane]; thr_all = sd > thr_all ? sd : thr_all; }
     Q A, B;
     prefetch(0, A);                                             // in flight while the base is built
 
@@ -1476,12 +1555,16 @@ static int sa_launch_make_sattab(sa_index* ix, float* d_tab, u32* tab_w_out, flo
 }
 
 static int sa_launch_make_bounds(sa_index* ix, const u32* d_terms, u32 BT, u32* d_bounds, u64* d_qbase, hipStream_t st,
-                                 u64* d_qbase_imp = nullptr) {
+                                 u64* d_qbase_imp = nullptr, const float* d_topf = nullptr, const float* d_idf = nullptr, u32 T = 1,
+                                 u32 k = 1, u32* d_seed = nullptr) {
     const u64 total = (u64)BT * (ix->n_tiles + 1);
     if (total == 0) return SA_OK;
     const u32 grid = total / 256 + 1 < 8192 ? (u32)(total / 256 + 1) : 8192;
+    u32 rank_idx = SA_TOPF_NR - 1;                               // the smallest tabulated rank >= k
+    for (int i = SA_TOPF_NR - 1; i >= 0; i--) if (sa_topf_ranks[i] >= k) rank_idx = (u32)i;
     hipLaunchKernelGGL(sa_k_make_bounds, dim3(grid), dim3(256), 0, st, ix->d_tfp, ix->d_tf_off, ix->d_dir_slot,
-                       ix->d_tile_dir, ix->n_terms, ix->n_tiles, ix->tile_docs, d_terms, BT, d_bounds, d_qbase, d_qbase_imp);
+                       ix->d_tile_dir, ix->n_terms, ix->n_tiles, ix->tile_docs, d_terms, BT, d_bounds, d_qbase, d_qbase_imp,
+                       d_topf, d_idf, T, rank_idx, (d_topf && d_idf) ? d_seed : (u32*)nullptr);
     return SA_OK;
 }
 
@@ -1794,7 +1877,7 @@ static int sa_batch_alloc_bm25(sa_batch* bt) {
     const size_t o_p1 = take((B + 1) * 8), o_boff = take(B * 8), o_terms = take(B * T * 4), o_idf = take(B * T * 4),
                  o_perm = take(B * 4), o_grp = take(3 * B * 4), o_ub = take(B * (T + 1) * 4), o_ord = take(B * T * 4),
                  o_lead = take(B * 4), o_qdf = take(B * T * 4), o_row8 = take(B * T * 4), o_bsh = take(B * 4),
-                 o_role = take(B * T * 4);
+                 o_role = take(B * T * 4), o_seed = take(B * 4);
     SA_TRY(sa_batch_alloc_upload(bt, off));
     char* u = bt->d_up;
     bt->d_p1_off = (u64*)(u + o_p1); bt->d_bloom_off = (u64*)(u + o_boff);
@@ -1803,6 +1886,7 @@ static int sa_batch_alloc_bm25(sa_batch* bt) {
     bt->d_lead = (u32*)(u + o_lead); bt->d_qdf = (u32*)(u + o_qdf); bt->d_qrow8 = (u32*)(u + o_row8);
     bt->d_bloom_shift = (u32*)(u + o_bsh);
     bt->d_qrole = (u32*)(u + o_role);
+    bt->d_seed = (u32*)(u + o_seed);
     {
         std::vector<u32> iota(B);
         for (u32 i = 0; i < B; i++) iota[i] = i;
@@ -2171,9 +2255,16 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
         }
         bt->bloom_bytes = bytes;
     }
+    memset(at(bt->d_seed), 0, (size_t)B * sizeof(u32));
+    {
+        bool w_ok = k1 >= 0.f && b >= 0.f && b <= 1.f;
+        for (size_t i = 0; i < (size_t)B * T && w_ok; i++) w_ok = idf[i] >= 0.f && idf[i] <= 3.0e38f;
+        bt->seed_on = w_ok && bt->impacts && bt->impacts->d_topf && bt->k <= 1024u && sa_env_int("SA_TERM_SEED", 1) != 0;
+    }
     const u64 t_host = sa_now_ns();
     SA_TRY(sa_batch_upload_commit(bt));
-    SA_TRY(sa_launch_make_bounds(ix, bt->d_terms, B * T, bt->d_bounds, bt->d_qbase, bt->st, bt->d_qbase_imp));
+    SA_TRY(sa_launch_make_bounds(ix, bt->d_terms, B * T, bt->d_bounds, bt->d_qbase, bt->st, bt->d_qbase_imp,
+                                 bt->seed_on ? bt->impacts->d_topf : nullptr, bt->d_idf, T, bt->k, bt->d_seed));
     SA_HIP(hipGetLastError());
     const u64 t_end = sa_now_ns();
     bt->host_ns[0] += t_host - t_begin; bt->host_ns[1] += t_end - t_host; bt->host_ns[3]++;
@@ -2303,6 +2394,8 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
                           (sparse || bt->k >= (u32)sa_env_int("SA_TOPK_HIST_MINK", defer_check ? 1 : 33));
     p.hist = use_hist ? bt->d_hist : nullptr;
     p.gthr = use_hist ? bt->d_gthr : nullptr;
+    // the bounds the queries start with (exhaustive kernels only: the pruning path derives its own from the lead terms)
+    p.seed = (use_hist && !sparse && bt->kind == 0 && bt->seed_on && p.imp) ? bt->d_seed : nullptr;
     p.qlist = nullptr; p.nq = bt->B;
     if (sparse) SA_TRY(sa_batch_ensure_bloom(bt));
     if (p.pruned && (!bt->state_clean || sparse)) {
@@ -2550,6 +2643,23 @@ extern "C" int sa_batch_step(sa_batch_t* bt, const uint32_t* terms) {
         SA_TRY(sa_batch_fill(bt, terms, bt->step_idf.data()));
     }
     return sa_batch_run(bt, 0);
+}
+
+extern "C" int sa_batch_seeds(sa_batch_t* bt, float* out) {
+    SA_ARG(bt && bt->ix && out, "null argument");
+    SA_ARG(bt->kind == 0, "sa_batch_seeds takes a BM25 batch");
+    sa_index* ix = bt->ix;
+    std::lock_guard<std::mutex> g(ix->mu);
+    SA_HIP(hipSetDevice(ix->device));
+    SA_HIP(hipStreamSynchronize(bt->st));
+    std::vector<u32> rows(bt->B);
+    SA_HIP(hipMemcpy(rows.data(), bt->d_seed, (size_t)bt->B * sizeof(u32), hipMemcpyDeviceToHost));
+    for (u32 r = 0; r < bt->B; r++) {                           // device row r holds caller query perm[r]
+        float f;
+        memcpy(&f, &rows[r], 4);
+        out[bt->perm[r]] = bt->seed_on ? f : 0.f;
+    }
+    return SA_OK;
 }
 
 extern "C" int sa_batch_host_times(sa_batch_t* bt, uint64_t* out4) {

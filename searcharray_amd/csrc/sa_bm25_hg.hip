@@ -60,7 +60,7 @@ struct HgArgs {
     const u64* imp; u64 imp_tail;
     const u32* bounds; const u64* qbase_imp; const float* idf; const u32* qrole; const u32* grp;
     const float* dense; u64 dense_stride;
-    u32* gthr; u32* hist; u64* cand; u32* cand_cnt; u64* wl; u32* wl_cnt;
+    u32* gthr; const u32* seed; u32* hist; u64* cand; u32* cand_cnt; u64* wl; u32* wl_cnt;
     u64 doc_base;
     u32 n_tiles, T, k, cand_cap, group0, n_groups, tile0, n_tiles_run;
     u32 spx;                // super-tiles per XCD (an XCD takes a range of consecutive super-tiles), 0: dealt round-robin
@@ -148,7 +148,10 @@ __global__ void __launch_bounds__(SA_HG_NW * 64, 4) sa_k_bm25_headgroup(const Hg
             r0 = row[tile_lo]; r1 = row[tile_hi];
             cb = a.qbase_imp[2 * (u64)qt];
             w = a.idf[qt];
-            if (t == 0u) thr = __hip_atomic_load(&a.gthr[row0 + qloc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == 0u) {
+                thr = __hip_atomic_load(&a.gthr[row0 + qloc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.seed) { const u32 sd = a.seed[row0 + qloc]; thr = sd > thr ? sd : thr; }
+            }
         }
         const u32 kind = role & 0xFu;
         const u64 adr = (u64)(stream + cb + r0);                // the slice's first cell
@@ -423,7 +426,7 @@ int sa_launch_bm25_headgroups(sa_index* ix, const sa_batch* bt, const Bm25Params
     a.bounds = p.bounds; a.qbase_imp = p.qbase_imp; a.idf = p.idf; a.qrole = bt->d_qrole; a.grp = bt->d_grp;
     a.dense = bt->impacts ? bt->impacts->d_dense : nullptr;
     a.dense_stride = bt->impacts ? bt->impacts->dense_stride : 0;
-    a.gthr = p.gthr; a.hist = p.hist; a.cand = p.cand; a.cand_cnt = p.cand_cnt; a.wl = bt->d_wl; a.wl_cnt = bt->d_wl_cnt;
+    a.gthr = p.gthr; a.seed = p.seed; a.hist = p.hist; a.cand = p.cand; a.cand_cnt = p.cand_cnt; a.wl = bt->d_wl; a.wl_cnt = bt->d_wl_cnt;
     a.doc_base = p.doc_base;
     a.n_tiles = p.n_tiles; a.T = p.T; a.k = p.k; a.cand_cap = p.cand_cap;
     a.group0 = 0; a.n_groups = bt->n_hg_groups; a.tile0 = tile0; a.n_tiles_run = ix->n_tiles - tile0;

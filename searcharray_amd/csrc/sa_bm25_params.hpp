@@ -36,6 +36,7 @@ struct Bm25Params {
     u32* slots;            // pruned mode: [B][32] pruning slots (score bits)
     u32* hist;             // pruned mode, k > 32: [B][SA_HBINS] score histograms (null: use the slots)
     u32* gthr;             // pruned mode, k > 32: [B] cached bound (score bits)
+    const u32* seed;       // [B] the bound every query STARTS with (score bits; sa_k_make_bounds from the terms' rank tables), or null
     // dynamic pruning (MaxScore): per query the terms in ascending idf order and the score a doc
     // can reach at most from the j smallest-idf terms alone
     const float* ub;       // [B][T+1] upper bounds (ub[0] = 0), or null: exhaustive scoring

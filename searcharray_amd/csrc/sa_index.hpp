@@ -41,6 +41,9 @@ struct sa_comm;   // RCCL communicator wrapper (sa_comm.hip)
 // 16-byte-aligned pair of sentinels, so a 16-byte pair load never sees another term's posting, loads
 // can be clamped to that pair instead of bounds-tested per lane, and "doc inside this tile" is the
 // only validity test a posting needs.
+#define SA_TOPF_NR 22
+static const unsigned sa_topf_ranks[SA_TOPF_NR] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64, 100, 128, 200, 256, 512, 1000, 1024};
+
 struct sa_impacts {
     int device = 0;
     float k1 = 0.f, b = 0.f, avgdl = 0.f;
@@ -55,6 +58,12 @@ struct sa_impacts {
     u64 dense_stride = 0;           // floats per row (n_docs rounded up to whole tiles)
     std::vector<u32> dense_slot;    // [n_terms] row of a term, or 0xFFFFFFFF (host)
     u32 n_dense = 0;
+    // Rank table of every term's factors (sa_k_make_topf): topf[t][i] = a lower bound (bin edge, within 0.2 %) of the
+    // SA_TOPF_RANK(i)-th LARGEST factor among the term's postings in this shard, 0 where the term has fewer postings or
+    // the factor is below 1/16.  w_t * topf[t][rank >= k] is a bound of the k-th best score of ANY query that holds t
+    // with weight w_t >= 0 (all contributions are non-negative and fp32 sums of non-negatives never fall below a
+    // summand): every query starts with the best such bound over its terms instead of 0 (sa_k_make_bounds).
+    float* d_topf = nullptr;
     ~sa_impacts();
 };
 

@@ -496,6 +496,12 @@ class QueryBatch:
         return {"groups": int(out[0]), "grouped_queries": int(out[1]), "shared_first_term": int(out[2]), "per_query_kernel": int(out[3]),
                 "head_groups": int(hg[0]), "head_group_queries": int(hg[1])}
 
+    def seeds(self) -> np.ndarray:
+        """the bound every query of the current set starts with (sa_batch_seeds), float32[B], 0 = none"""
+        out = np.zeros(self.B, dtype=np.float32)
+        self.api.call("sa_batch_seeds", self._h, p_f32(out))
+        return out
+
     def host_times(self) -> dict:
         """host microseconds this batch's steps have cost so far, by part (sa_batch_host_times), and the number of query sets"""
         out = (_lib.c_uint64 * 4)()

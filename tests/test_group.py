@@ -174,3 +174,63 @@ def test_optimistic_bounds_from_the_warm_up_sample(api, corpus, monkeypatch, k, 
             assert np.array_equal(docs[qi, :n], wd[:n]), f"run {run} q{qi} {q} docs"
     bt.close()
     dev.close()
+
+
+@pytest.mark.parametrize("k", [1, 2, 7, 10, 33, 100])
+@pytest.mark.parametrize("group", ["1", "0"])
+def test_starting_bounds_from_the_terms_rank_tables(api, corpus, monkeypatch, k, group):
+    """every query starts with the bound  max over its terms of  weight x (k-th largest factor of the term)  (sa_k_make_topf /
+    sa_k_make_bounds).  No warm-up tiles here, so it is the only bound the first items see.  ONE-term queries are the sharp
+    case: the k-th best doc's score IS weight x k-th largest factor, a bound one rank too high would lose it -- terms with
+    fewer than k postings (no bound), exactly k, and thousands; then 2- and 4-term queries, repeated terms, zero weights"""
+    monkeypatch.setenv("SA_SPARSE", "0")
+    monkeypatch.setenv("SA_GROUP_WARM", "0")
+    monkeypatch.setenv("SA_GROUP", group)
+    words, off, lens, orc = corpus
+    dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api)
+    df = dev.docfreqs()
+    by_df = np.argsort(df)
+    exact = [int(t) for t in np.nonzero(df == k)[0][:3]]
+    singles = [0, 1, 5, 40, 200, 399] + [int(by_df[i]) for i in (0, 1, len(by_df) // 2)] + exact
+    for T, queries in ((1, [[t] for t in singles]),
+                       (2, [[0, t] for t in singles] + [[t, t] for t in singles[:4]]),
+                       (4, band_queries(np.random.default_rng(3 + k), 24, 4, heads=[0, 2]).tolist())):
+        queries = np.asarray(queries)
+        bt = dev.batch(queries, k=k)
+        seeds = bt.seeds()
+        for qi, q in enumerate(queries):
+            ws, _ = O.topk(orc.score_terms_sum([int(x) for x in q]), k)
+            kth = float(ws[k - 1]) if len(ws) >= k else 0.0
+            assert seeds[qi] <= kth, f"T={T} q{qi} {q}: starting bound {seeds[qi]} above the k-th best score {kth}"
+            if T == 1:                       # ... and tight: the lower edge of the bin (512 per octave) of the tabulated rank >= k
+                rank = min(r for r in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64, 100, 128, 200, 256, 512, 1000, 1024) if r >= k)
+                if df[int(q[0])] >= rank:
+                    wr, _ = O.topk(orc.score_terms_sum([int(q[0])]), rank)
+                    f_r = float(wr[rank - 1]) / float(O.compute_idf(N_DOCS, np.asarray([df[int(q[0])]])))      # the factor itself
+                    assert seeds[qi] >= float(wr[rank - 1]) * 0.995 or f_r < 1.0 / 16, f"T=1 q{qi} {q}: bound {seeds[qi]} far below {wr[rank - 1]}"
+                else:
+                    assert seeds[qi] == 0.0
+        for _ in range(2):
+            bt.run(sync=False)
+            scores, docs = bt.fetch()
+            for qi, q in enumerate(queries):
+                ws, wd = O.topk(orc.score_terms_sum([int(x) for x in q]), k)
+                n = int((ws > 0).sum())
+                assert np.array_equal(scores[qi, :n], ws[:n]), f"T={T} q{qi} {q} scores"
+                assert np.array_equal(docs[qi, :n], wd[:n]), f"T={T} q{qi} {q} docs"
+        bt.close()
+    # explicit weights with zeros: a zero weight contributes no bound
+    queries = np.asarray([[0, 5, 40, 200]] * 6)
+    idf = np.asarray([[1.0, 0.0, 2.0, 0.0], [0.0, 0.0, 0.0, 3.0], [0.0, 0.0, 0.0, 0.0], [5.0, 1.0, 1.0, 1.0], [0.5, 8.0, 0.0, 0.1], [1.0, 1.0, 1.0, 1.0]],
+                     dtype=np.float32)
+    bt = dev.batch(queries, k=k, idf=idf)
+    bt.run()
+    got = bt.fetch()
+    bt.close()
+    monkeypatch.setenv("SA_TERM_SEED", "0")
+    bt = dev.batch(queries, k=k, idf=idf)
+    bt.run()
+    want = bt.fetch()
+    bt.close()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    dev.close()
