@@ -1338,13 +1338,16 @@ sa_k_seed_bounds(const u32* __restrict__ hist, u32* __restrict__ gthr, u32 n_row
     if (lane == 0 && g) atomicMax(&gthr[q], g);
 }
 
-__global__ void __launch_bounds__(1024)
+// (THREADS: 1024, or 256 for small k -- a workgroup of 16 waves needs 16 free wave slots and 17 KiB of LDS on ONE CU at once, which a
+//  device full of one-wave scoring workgroups hands out slowly; for k <= 64 a query has a few dozen candidates and four waves do)
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
 sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__ out,
                 const u32* __restrict__ out_row, u32 rank_stride, const u32* __restrict__ cnt,
                 const u32* __restrict__ slots, const u32* __restrict__ gthr, u32* __restrict__ overflow,
                 u32* __restrict__ clr_state, u32 clr_B, u32 clr_hist, u32* __restrict__ clr_one,
                 u32 gather_stride, u32* __restrict__ xflag) {
-    constexpr int NW = 1024 / SA_WAVE;
+    constexpr int NW = THREADS / SA_WAVE;
     __shared__ u64 red64[NW + 1];
     __shared__ u64 sel[SA_MERGE_LIST];
     __shared__ u32 s_n;
@@ -1354,10 +1357,10 @@ sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__
         // key i % k of rank i / k; the extra cell of every rank's block is its overflow flag, OR-ed into *xflag.
         // Only rows that fit the LDS list take this route (the host checks), so nothing is compacted in place.
         if (tid == 0) s_n = 0;
-        for (u32 i = tid; i < SA_MERGE_LIST; i += 1024) sel[i] = 0;
+        for (u32 i = tid; i < SA_MERGE_LIST; i += THREADS) sel[i] = 0;
         __syncthreads();
         const u32 B_ = gridDim.x;
-        for (u32 i = tid; i < n_cand_max; i += 1024) {
+        for (u32 i = tid; i < n_cand_max; i += THREADS) {
             const u32 r = i / rank_stride, j = i % rank_stride;
             const u64 x = cand[(u64)r * gather_stride + (u64)q * rank_stride + j];
             if (x) { const u32 pos = atomicAdd(&s_n, 1u); sel[pos] = x; }
@@ -1373,7 +1376,7 @@ sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__
         while (np2 < n_sel) np2 <<= 1;
         sa_block_bitonic_desc(sel, np2);
         const u32 row_ = out_row ? out_row[q] : q;
-        for (u32 i = tid; i < k; i += 1024) out[(u64)row_ * k + i] = (i < SA_MERGE_LIST) ? sel[i] : 0ull;
+        for (u32 i = tid; i < k; i += THREADS) out[(u64)row_ * k + i] = (i < SA_MERGE_LIST) ? sel[i] : 0ull;
         return;
     }
     u64* c = cand + (u64)q * n_cand_max;
@@ -1385,14 +1388,14 @@ sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__
         if (have > n_cand_max && overflow && tid == 0) atomicMax(overflow, 1u);   // the list ran over: see sa_batch_fetch
     }
     const u32 row = out_row ? out_row[q] : q;       // device row q holds caller query out_row[q]
-    for (u32 i = tid; i < SA_MERGE_LIST; i += 1024) sel[i] = 0;
+    for (u32 i = tid; i < SA_MERGE_LIST; i += THREADS) sel[i] = 0;
     if (tid == 0) s_n = 0;
     __syncthreads();
 
     // MSB-first bisection (2 bits per step) for the k-th largest of c[0 : n : stride]
     auto kth_largest = [&](u32 n, u32 stride) -> u64 {
         u64 m = 0;
-        for (u32 i = tid; i < n; i += 1024) { const u64 x = c[(u64)i * stride]; m = x > m ? x : m; }
+        for (u32 i = tid; i < n; i += THREADS) { const u64 x = c[(u64)i * stride]; m = x > m ? x : m; }
         m = sa_block_max64<NW>(m, red64);
         if (m == 0 || n < k) return 0;
         int top = 63 - __clzll((long long)m);
@@ -1401,7 +1404,7 @@ sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__
         for (int bit = top; bit >= 1; bit -= 2) {
             const u64 c1 = prefix | (1ull << (bit - 1)), c2 = prefix | (2ull << (bit - 1)), c3 = prefix | (3ull << (bit - 1));
             u64 packed = 0;
-            for (u32 i = tid; i < n; i += 1024) {
+            for (u32 i = tid; i < n; i += THREADS) {
                 const u64 x = c[(u64)i * stride];
                 packed += (x >= c1 ? 1ull : 0ull) + (x >= c2 ? (1ull << 21) : 0ull) + (x >= c3 ? (1ull << 42) : 0ull);
             }
@@ -1435,7 +1438,7 @@ sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__
         }
         if (thr < 1) thr = 1;
     }
-    for (u32 i = tid; i < n_cand; i += 1024) {
+    for (u32 i = tid; i < n_cand; i += THREADS) {
         const u64 x = c[i];
         if (x >= thr) {
             const u32 pos = atomicAdd(&s_n, 1u);
@@ -1450,11 +1453,11 @@ sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__
         // end: at most as many survivors as keys read so far), then bisect over them only
         if (tid == 0) s_n = 0;
         __syncthreads();
-        for (u32 base = 0; base < n_cand; base += 4096) {
+        for (u32 base = 0; base < n_cand; base += 4 * THREADS) {
             u64 x[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const u32 i = base + j * 1024 + tid;
+                const u32 i = base + j * THREADS + tid;
                 x[j] = i < n_cand ? c[i] : 0ull;
             }
             __syncthreads();
@@ -1467,10 +1470,10 @@ sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__
         __syncthreads();
         const u64 g = kth_largest(n_surv, 1);         // exact: keys are distinct, so exactly k keys are >= g
         thr = g > 1 ? g : 1;
-        for (u32 i = tid; i < SA_MERGE_LIST; i += 1024) sel[i] = 0;
+        for (u32 i = tid; i < SA_MERGE_LIST; i += THREADS) sel[i] = 0;
         if (tid == 0) s_n = 0;
         __syncthreads();
-        for (u32 i = tid; i < n_surv; i += 1024) {
+        for (u32 i = tid; i < n_surv; i += THREADS) {
             const u64 x = c[i];
             if (x >= thr) {
                 const u32 pos = atomicAdd(&s_n, 1u);
@@ -1507,7 +1510,7 @@ sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__
         while (np2 < n_sel) np2 <<= 1;
         sa_block_bitonic_desc(sel, np2);
     }
-    for (u32 i = tid; i < k; i += 1024) out[(u64)row * k + i] = (i < SA_MERGE_LIST) ? sel[i] : 0ull;
+    for (u32 i = tid; i < k; i += THREADS) out[(u64)row * k + i] = (i < SA_MERGE_LIST) ? sel[i] : 0ull;
     // The merge is the last reader of the run's per-query state, so it leaves it zeroed for the next run of the
     // batch -- bound slots [B][32], cursors [B], cached bounds [B], histograms [B][SA_HBINS] (layout: sa_batch_alloc_topk),
     // the grouped kernel's work-list cursor -- instead of a reset launch in front of every run.
@@ -1515,10 +1518,18 @@ sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__
         if (tid < 32u) clr_state[(u64)q * 32u + tid] = 0u;
         if (tid == 32u) clr_state[(u64)clr_B * 32u + q] = 0u;
         if (tid == 33u) clr_state[(u64)clr_B * 33u + q] = 0u;
-        if (clr_hist && tid >= 64u && tid < 64u + (u32)SA_HBINS) clr_state[(u64)clr_B * 34u + (u64)q * SA_HBINS + (tid - 64u)] = 0u;
+        if (clr_hist) for (u32 i = tid; i < (u32)SA_HBINS; i += THREADS) clr_state[(u64)clr_B * 34u + (u64)q * SA_HBINS + i] = 0u;
         if (clr_one && q == 0u && tid == 34u) *clr_one = 0u;
     }
 }
+
+#define SA_MERGE_LAUNCH(K_, B_, ST_, ...)                                                                                  \
+    do {                                                                                                               \
+        if ((K_) <= 64u && sa_env_int("SA_MERGE_SMALL", 1) != 0)                                                          \
+            hipLaunchKernelGGL(sa_k_topk_merge<256>, dim3(B_), dim3(256), 0, ST_, __VA_ARGS__);                          \
+        else                                                                                                           \
+            hipLaunchKernelGGL(sa_k_topk_merge<1024>, dim3(B_), dim3(1024), 0, ST_, __VA_ARGS__);                        \
+    } while (0)
 
 // ---------------------------------------------------------------------------------------
 // host side
@@ -2510,7 +2521,7 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
         }
     }
     const u32 n_cand = p.pruned ? p.cand_cap : (n_tiles ? n_tiles : 1) * p.cand_per_tile;
-    hipLaunchKernelGGL(sa_k_topk_merge, dim3(bt->B), dim3(1024), 0, st, bt->d_cand, n_cand, bt->k, shard_out,
+    SA_MERGE_LAUNCH(bt->k, bt->B, st, bt->d_cand, n_cand, bt->k, shard_out,
                        (const u32*)bt->d_perm, 0u, (const u32*)(p.pruned ? bt->d_cand_cnt : nullptr),
                        (const u32*)(p.pruned && !p.hist ? bt->d_slots : nullptr),
                        (const u32*)(p.pruned && p.hist ? bt->d_gthr : nullptr),
@@ -2526,7 +2537,7 @@ static int sa_batch_merge_ranks(sa_batch* bt, const u64* d_gathered, int nranks,
     const size_t count = (size_t)bt->B * bt->k;
     if ((u64)nranks * bt->k <= (u64)SA_MERGE_LIST) {
         // the usual case: the gathered keys of a query fit the merge's LDS list -- one launch reads them where they are
-        hipLaunchKernelGGL(sa_k_topk_merge, dim3(bt->B), dim3(1024), 0, st, (u64*)d_gathered, (u32)nranks * bt->k, bt->k, bt->d_final,
+        SA_MERGE_LAUNCH(bt->k, bt->B, st, (u64*)d_gathered, (u32)nranks * bt->k, bt->k, bt->d_final,
                            (const u32*)nullptr, bt->k, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr,
                            (u32*)nullptr, (u32*)nullptr, 0u, 0u, (u32*)nullptr, (u32)(count + extra), extra ? bt->d_xflag : (u32*)nullptr);
         return SA_OK;
@@ -2542,7 +2553,7 @@ static int sa_batch_merge_ranks(sa_batch* bt, const u64* d_gathered, int nranks,
     hipLaunchKernelGGL(sa_k_regroup, dim3(grid), dim3(256), 0, st, d_gathered, (u32)nranks, bt->B, bt->k, extra, bt->d_xcand,
                        bt->d_xflag);
     // every rank's block is its sorted top-k: group leaders = rank maxima
-    hipLaunchKernelGGL(sa_k_topk_merge, dim3(bt->B), dim3(1024), 0, st, bt->d_xcand, (u32)nranks * bt->k, bt->k, bt->d_final,
+    SA_MERGE_LAUNCH(bt->k, bt->B, st, bt->d_xcand, (u32)nranks * bt->k, bt->k, bt->d_final,
                        (const u32*)nullptr, bt->k, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr,
                        (u32*)nullptr, (u32*)nullptr, 0u, 0u, (u32*)nullptr, 0u, (u32*)nullptr);
     return SA_OK;
