@@ -99,7 +99,7 @@ def main():
             print("wrote", dst)
     for src, dst in [("kernel_ab.log", f"kernel_ab_{RND}.jsonl"), ("host_cost.log", f"host_cost_{RND}.jsonl"),
                      ("ab_hg.log", f"headgroup_kernel_ab_{RND}.jsonl"), ("ab_xcd.log", f"xcd_tile_ranges_ab_{RND}.jsonl"),
-                     ("ab_seed.log", f"optimistic_bounds_ab_{RND}.jsonl"), ("ab_rank.log", f"rank_sized_shard_ab_{RND}.jsonl"),
+                     ("ab_seed.log", f"optimistic_bounds_ab_{RND}.jsonl"), ("ab_termseed.log", f"starting_bounds_ab_{RND}.jsonl"), ("ab_rank.log", f"rank_sized_shard_ab_{RND}.jsonl"),
                      ("slop_heavy.log", f"slop_heaviest_{RND}.jsonl"), ("slop_routes.log", f"slop_routes_{RND}.jsonl")]:
         js = json_lines(os.path.join(OUT, src))
         if js:

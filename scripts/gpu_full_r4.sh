@@ -24,7 +24,8 @@ A="--no-cpu-baseline --no-pmc --no-phrase-legs --docs 1250000 --steps 200 --pipe
 ( time timeout 600 python scripts/ab.py --corpus-cache $C --ks 10,100,1000 --qsets baseline,distinct --envs "SA_HG=0;SA_HG=1" ) > $O/ab_hg.log 2>&1
 ( time timeout 300 python scripts/ab.py --corpus-cache $C --ks 10 --qsets baseline,distinct --envs "SA_XCD_RANGE=0;SA_XCD_RANGE=1" ) > $O/ab_xcd.log 2>&1
 ( time timeout 600 python scripts/ab.py --corpus-cache $C --ks 100,1000 --qsets baseline,distinct --envs "SA_SEED=0;SA_SEED=1" ) > $O/ab_seed.log 2>&1
-( time timeout 300 python scripts/ab.py --docs 1250000 --steps 50 --ks 10 --qsets baseline --envs "SA_HG=0;SA_HG=1;SA_XCD_RANGE=0" ) > $O/ab_rank.log 2>&1
+( time timeout 600 python scripts/ab.py --corpus-cache $C --ks 10,100,1000 --qsets baseline,distinct --envs "SA_TERM_SEED=0;SA_TERM_SEED=1;SA_TERM_SEED=1,SA_GROUP_WARM=16;SA_TERM_SEED=1,SA_MERGE_SMALL=0" ) > $O/ab_termseed.log 2>&1
+( time timeout 300 python scripts/ab.py --docs 1250000 --steps 50 --ks 10 --qsets baseline --envs "SA_HG=0;SA_HG=1;SA_XCD_RANGE=0;SA_TERM_SEED=0;SA_TERM_SEED=1,SA_GROUP_WARM=16;SA_MERGE_SMALL=0" ) > $O/ab_rank.log 2>&1
 ( time timeout 300 python scripts/host_cost.py --docs 1250000 ) > $O/host_cost.log 2>&1
 ( time timeout 300 python scripts/host_cost.py --docs 1250000 --comm ) >> $O/host_cost.log 2>&1
 ( time timeout 300 python scripts/phrase_bench.py ) > $O/phrase_bench.log 2>&1
