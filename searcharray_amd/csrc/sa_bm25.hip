@@ -923,7 +923,7 @@ __device__ __forceinline__ void sa_static_while_below(u32 n, F&& f) {
 template <int TILE, int IDFN>
 __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params p, const GroupParams gp) {
     constexpr int NH = SA_GRP_NH;
-    static_assert(NH < (int)SA_GRPH_OVER && NH % 2 == 0 && NH >= 8, "half count field; halves are taken in pairs");
+    static_assert(NH < (int)SA_GRPH_OVER && NH >= 8, "half count field");
     __shared__ alignas(16) u64 smem[sa_tile_smem_u64<TILE, 1>()];
     __shared__ u64 s_half[SA_GRP_MAXQ][NH];
     __shared__ float s_idf[IDFN];
@@ -999,9 +999,8 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
                 s_half[qi][excl + j] = (u64)(stream + c) | (lim << SA_GRPH_LIM_SHIFT) | ((u64)tl << SA_GRPH_TERM_SHIFT) |
                                        (excl + j == 0u ? nhf : 0ull);
             }
-            // halves are taken two at a time: an odd count gets an empty partner (every lane reads one sentinel cell with
-            // the factor 0.0 and adds it to its spare slot); a query without postings an entry 0 that says "0 halves"
-            if (tl == 0u && (total == 0u || ((total & 1u) && total < (u32)NH))) s_half[qi][total] = (u64)(stream + p.imp_tail);
+            // a query without postings: an entry 0 that says "0 halves"
+            if (tl == 0u && total == 0u) s_half[qi][0] = (u64)(stream + p.imp_tail);
         }
     };
     const u32 NP = (n + QPP - 1u) / QPP;                        // 1 or 2 passes (host: n * TT <= 128)
@@ -1036,8 +1035,8 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
         const u32 nh_raw = (u32)__builtin_amdgcn_readfirstlane((int)X.dhi) >> (SA_GRPH_NH_SHIFT - 32);
         // (too many: the pair goes to the per-query kernel; an odd count: the empty partner entry is loaded too --
         //  nothing masks a half's lanes, its postings must be the sentinel's)
-        const u32 nh = nh_raw <= (u32)NH ? (nh_raw + 1u) & ~1u : 0u;
-        sa_static_while_below<0, NH, 1>(nh, [&](auto hc) {       // (a query has ~4 halves on average)
+        const u32 nh = nh_raw <= (u32)NH ? nh_raw : 0u;
+        sa_static_while_below<0, NH, 1>(nh, [&](auto hc) {       // (a query has ~3 halves on average)
             constexpr int h = decltype(hc)::value;
             const u32 hi = (u32)__builtin_amdgcn_readlane((int)X.dhi, h);
             const u64 a = (u64)(u32)__builtin_amdgcn_readlane((int)X.dlo, h) | ((u64)(hi & 0xFFFFu) << 32);
@@ -1176,13 +1175,12 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
         const u32 thr = thr_q > 1u ? thr_q : 1u;
         if (nh_raw > (u32)NH || base_max >= thr) { deferred |= 1ull << qi; return; }
         if (nh_raw == 0u) return;                               // the query scores exactly the base here: all below its bound
-        const u32 nh = (nh_raw + 1u) & ~1u;                     // halves go two at a time (NH is even; the partner of an odd count is empty)
+        const u32 nh = nh_raw;                                  // (round 4: an odd count no longer gets an empty partner half)
         u32 rs[NH], ro[NH];
         u32 wmax = 0u;                                          // largest value written (sign bit set)
-        sa_static_while_below<0, NH, 2>(nh, [&](auto hc) {
-            constexpr int h2 = decltype(hc)::value;
-#pragma unroll
-            for (int h = h2; h < h2 + 2; h++) {
+        sa_static_while_below<0, NH, 1>(nh, [&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            {
                 __builtin_amdgcn_wave_barrier();                // a half sees the previous half's (other lanes') writes
                 const float w = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(X.w), h));
                 const u64 v = X.v[h];
@@ -1205,23 +1203,23 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
             for (int h = 0; h < NH; h++) fin[h] = (u32)h < nh ? at(rs[h]) & 0x7FFFFFFFu : 0u;
             __builtin_amdgcn_wave_barrier();
         }
-        // base values back, last half first (nh is even, 2 .. NH: one jump, then straight-line stores)
+        // base values back, last half first
         auto back = [&](auto hc) {
             constexpr int h = decltype(hc)::value;
-            at(rs[h + 1]) = ro[h + 1];
-            __builtin_amdgcn_wave_barrier();
             at(rs[h]) = ro[h];
             __builtin_amdgcn_wave_barrier();
         };
-        // (nh is even, 2 .. NH; the usual 2 or 4 halves cost one or two scalar tests -- as a switch with fall-through the
-        //  compiler built a chain of ~25 scalar flag operations in front of the two stores of the usual case)
+        // (nh = 1 .. NH; the usual 2 or 3 halves cost three or four scalar tests -- as a switch with fall-through the compiler
+        //  built a chain of ~25 scalar flag operations in front of the stores of the usual case)
         static_assert(NH == 10, "restore chain");
         if (nh > 4u) {
-            if (nh > 8u) back(std::integral_constant<int, 8>{});
-            if (nh > 6u) back(std::integral_constant<int, 6>{});
+            if (nh > 8u) { if (nh > 9u) back(std::integral_constant<int, 9>{}); back(std::integral_constant<int, 8>{}); }
+            if (nh > 6u) { if (nh > 7u) back(std::integral_constant<int, 7>{}); back(std::integral_constant<int, 6>{}); }
+            if (nh > 5u) back(std::integral_constant<int, 5>{});
             back(std::integral_constant<int, 4>{});
         }
-        if (nh > 2u) back(std::integral_constant<int, 2>{});
+        if (nh > 2u) { if (nh > 3u) back(std::integral_constant<int, 3>{}); back(std::integral_constant<int, 2>{}); }
+        if (nh > 1u) back(std::integral_constant<int, 1>{});
         back(std::integral_constant<int, 0>{});
         if (!look) return;
         u64 kb[NH];
