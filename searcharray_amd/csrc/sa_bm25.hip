@@ -2053,7 +2053,7 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
             // longest list first
             std::stable_sort(lists, lists + n_lists, [&](int x, int y) { return df[x] > df[y]; });
             // expected postings per super-tile (2 index tiles): the first candidate list takes two vectors, the second one
-            const double per_st = 2.0 / (double)ix->n_tiles;
+            const double per_st = (double)SA_HG_ST / (double)ix->n_tiles;
             if (n_lists > 1 && (double)df[lists[1]] * per_st > hg_cand_exp) return false;
             if (n_lists > 2 && (double)df[lists[2]] * per_st > hg_cand_exp / 2.0) return false;
             static const u32 kinds[3] = {SA_HG_STREAM, SA_HG_CAND0, SA_HG_CAND1};

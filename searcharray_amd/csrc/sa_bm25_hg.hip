@@ -43,7 +43,6 @@
 #include <stdlib.h>
 
 #define SA_HG_NW 4          // waves per workgroup: they share the super-tile's base
-#define SA_HG_ST 2          // index tiles (of 2048 docs) per super-tile
 #define SA_HG_QPR 16        // queries per wave and round (lane = 4 * query + slot)
 #define SA_HG_CH 4          // 64-posting vectors per chunk of the stream pass
 #define SA_HG_NCV 3         // candidate vectors of a (super-tile, query) pair: two of the first candidate list, one of the second

@@ -62,7 +62,10 @@ struct Bm25Params {
 #define SA_HG_STREAM 2u     // the query's longest further list: streamed against the base
 #define SA_HG_CAND0 3u      // the further terms with shorter lists: their postings are the candidate docs (first / second list)
 #define SA_HG_CAND1 4u
-#define SA_HG_MAXT 4        // query terms the kernel takes (positions 0 .. 3)
+#define SA_HG_MAXT 4
+#ifndef SA_HG_ST
+#define SA_HG_ST 2          // index tiles (of 2048 docs) per super-tile of the head-group kernel (1, 2 or 4)
+#endif        // query terms the kernel takes (positions 0 .. 3)
 
 struct sa_batch;
 int sa_launch_bm25_headgroups(sa_index* ix, const sa_batch* bt, const Bm25Params& p, u32 tile0, hipStream_t st);
