@@ -2020,7 +2020,10 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
         u32 tt_loose = 1, tsh_loose = 0;
         while (tt_loose < T) { tt_loose <<= 1; tsh_loose++; }
         const bool loose_on = sa_env_int("SA_GROUP_LOOSE", 1) != 0 && 128u / tt_loose >= SA_GRP_MAXQ;
-        const u32 maxq = std::min<u32>(SA_GRP_MAXQ, 128u / tt);
+        u32 maxq = std::min<u32>(SA_GRP_MAXQ, 128u / tt);
+        // (a shard whose (tile, group) items do not fill the device for many rounds is better cut into more, shorter items:
+        //  SA_GROUP_MAXQ; measured on a 1.25 M-doc shard below)
+        maxq = std::min<u32>(maxq, (u32)std::max(1, sa_env_int("SA_GROUP_MAXQ", (int)SA_GRP_MAXQ)));
         const u32 gmin = (u32)std::max(1, sa_env_int("SA_GROUP_MIN", 2));
         bool idf_ok = k1 >= 0.f && b >= 0.f && b <= 1.f;       // scores must be non-negative (the sign bit is a mark)
         for (size_t i = 0; i < (size_t)B * T && idf_ok; i++) idf_ok = idf[i] >= 0.f && idf[i] <= 3.0e38f;
