@@ -1065,7 +1065,7 @@ def main():
                                    f"FRESH batches: {len(sets)} rotating seeded sets of {B} x 4-term disjunctive BM25 queries "
                                    f"(k1=1.2 b=0.75; {'the first ' + str(Bq) + ' of ' if B > Bq else ''}set 0 = the BASELINE set"
                                    f"{'; ' + str(Bq) + ' queries per GPU and step: every rank scores all of them on its docs' if weak else ''}), "
-                                   f"host idf + sa_batch_reset + run + fetch per step, "
+                                   f"one sa_batch_step (idf gathered from the index table, reset, run) + fetch per step, "
                                    f"top-{args.k}, {'exhaustive' if exhaustive else 'dynamic pruning'}",
                        "docs": D, "queries_per_step": B, "terms_per_query": 4, "k": args.k, "query_sets": len(sets),
                        "batches_in_flight": P,
