@@ -58,6 +58,16 @@ def test_grouped_equals_oracle(api, corpus, monkeypatch, T, k):
     check(api, corpus, queries, k)
 
 
+@pytest.mark.parametrize("maxq", ["1", "5", "12"])
+def test_grouped_items_of_fewer_queries(api, corpus, monkeypatch, maxq):
+    """SA_GROUP_MAXQ: groups cut into pieces of at most 1 / 5 / 12 queries instead of 16 (more, shorter items)"""
+    monkeypatch.setenv("SA_SPARSE", "0")
+    monkeypatch.setenv("SA_GROUP_MAXQ", maxq)
+    rng = np.random.default_rng(19)
+    queries = band_queries(rng, 40, 4, heads=[0, 1, 7])
+    check(api, corpus, queries, 10)
+
+
 @pytest.mark.parametrize("warm", ["0", "2"])
 @pytest.mark.parametrize("tile_docs", [1024, 2048, 4096])
 def test_grouped_without_warm_tiles_and_other_tile_sizes(api, corpus, monkeypatch, warm, tile_docs):
