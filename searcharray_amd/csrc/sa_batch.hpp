@@ -83,6 +83,7 @@ struct sa_batch {
     u64 sparse_p1_total = 0, sparse_limit2 = 0, sparse_p2_max = 0;
     u32 sparse_chunk1 = SA_SP_CHUNK_LEAD;
     bool sparse_ok = false;         // tables built and the scoring formula admits the idf bound
+    bool sparse_lazy = false;       // the pruning tables of the current query set have not been derived (sa_batch_fill_prune_tables on demand)
     u32* d_overflow = nullptr;      // set by the merge kernel when a candidate list ran over (checked at fetch); behind d_final
     u64* d_local = nullptr;         // [B][k] per-shard result
     u64* d_gather = nullptr;        // [2][nranks][B][k] (multi-GPU, double-buffered like d_xlocal)

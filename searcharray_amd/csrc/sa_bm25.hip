@@ -1963,6 +1963,103 @@ int sa_batch_ensure_bloom(sa_batch* bt) {
     return SA_OK;
 }
 
+// Dynamic pruning tables of the current query set (sa_sparse.hip), derived into the upload image `img` from the rows already
+// placed there (terms / idf in device-row order).  ~9 us for 256 x 4 terms: sa_batch_fill only calls it when the run may take
+// the pruning path (SA_SPARSE, or the default rule with few grouped rows); a run that wants the path after all -- the
+// switch changed between reset and run -- derives them then and uploads the image again (sa_batch_ensure_sparse_tables).
+static void sa_batch_fill_prune_tables(sa_batch* bt, char* img) {
+    sa_index* ix = bt->ix;
+    const u32 B = bt->B, T = bt->T;
+    const float k1 = bt->k1, b = bt->b;
+    auto at = [&](const void* dptr) { return img + ((const char*)dptr - bt->d_up); };
+    u64* h_p1 = (u64*)at(bt->d_p1_off);
+    u64* h_boff = (u64*)at(bt->d_bloom_off);
+    u32* h_terms = (u32*)at(bt->d_terms);
+    float* h_idf = (float*)at(bt->d_idf);
+    float* h_ub = (float*)at(bt->d_ub);
+    u32* h_ord = (u32*)at(bt->d_ub_order);
+    u32* h_lead = (u32*)at(bt->d_lead);
+    u32* h_qdf = (u32*)at(bt->d_qdf);
+    u32* h_row8 = (u32*)at(bt->d_qrow8);
+    u32* h_bshift = (u32*)at(bt->d_bloom_shift);
+        // Dynamic pruning tables (sa_sparse.hip).  Per query: the terms in ascending idf order with the
+        // prefix sums of their idf -- what the j cheapest terms can add to a score at most, since
+        // tf/(tf+norm) <= 1 (needs k1 >= 0 and 0 <= b <= 1; a negative or non-finite idf switches the
+        // pruning off) -- and the LEAD term: the highest-idf term with postings in this shard.
+        const bool formula_ok = k1 >= 0.f && b >= 0.f && b <= 1.f;
+        const u64 limit1 = sa_batch_lead_limit(bt);
+        bt->sparse_limit2 = ix->n_docs / (u64)sa_env_int("SA_SPARSE_DIV", 8) > 4096 ? ix->n_docs / (u64)sa_env_int("SA_SPARSE_DIV", 8) : 4096;
+        std::pair<float, u32> v[SA_MAX_QTERMS];
+        h_p1[0] = 0;
+        for (u32 r = 0; r < B; r++) {
+            bool ok = formula_ok;
+            for (u32 t = 0; t < T; t++) {
+                const bool known = h_terms[(size_t)r * T + t] < ix->n_terms;
+                const float w = known ? h_idf[(size_t)r * T + t] : 0.f;
+                if (!(w >= 0.f) || w > 3.0e38f) ok = false;
+                v[t] = {w, t};
+            }
+            std::stable_sort(v, v + T, [](const std::pair<float, u32>& a, const std::pair<float, u32>& c) { return a.first < c.first; });
+            double acc = 0.0;
+            h_ub[(size_t)r * (T + 1)] = 0.f;
+            for (u32 j = 0; j < T; j++) {
+                h_ord[(size_t)r * T + j] = v[j].second;
+                acc += (double)v[j].first;
+                // rounded up: the fp32 sum the kernels form can exceed the exact sum by a few ulps
+                float ubf = (float)(acc * (1.0 + 1e-5));
+                ubf = nextafterf(ubf, INFINITY);
+                h_ub[(size_t)r * (T + 1) + j + 1] = ok ? ubf : INFINITY;
+            }
+            // lead: highest idf among the terms with postings here; too frequent -> scan the tiles
+            h_lead[r] = 0xFFFFFFFFu;
+            h_p1[r + 1] = 0;
+            if (ok) {
+                for (int j = (int)T - 1; j >= 0; j--) {
+                    const u32 t = v[(size_t)j].second;
+                    const u32 term = h_terms[(size_t)r * T + t];
+                    if (term >= ix->n_terms) continue;
+                    const u64 df = ix->h_tf_off[term + 1] - ix->h_tf_off[term];
+                    if (df == 0) continue;
+                    if (df <= limit1) { h_lead[r] = t; h_p1[r + 1] = df; }          // postings; turned into items below
+                    break;
+                }
+            }
+        }
+        {
+            // Lead-phase work items: 1024 postings each when there is plenty of work (measured best at
+            // 10 M docs: 0.66 vs 0.79 ms per step with 256), 256 when the shard is small and the phase
+            // would otherwise not fill the GPU (1.25 M docs: 0.157 vs 0.169 ms).
+            u64 lead_postings = 0;
+            for (u32 r = 0; r < B; r++) lead_postings += h_p1[r + 1];
+            bt->sparse_chunk1 = lead_postings >= (1ull << 19) ? SA_SP_CHUNK : SA_SP_CHUNK_LEAD;
+            if (const char* e = getenv("SA_SP_CHUNK1")) { const int c = atoi(e); if (c >= 64) bt->sparse_chunk1 = (u32)c; }
+            for (u32 r = 0; r < B; r++) h_p1[r + 1] = (h_p1[r + 1] + bt->sparse_chunk1 - 1) / bt->sparse_chunk1;
+        }
+        for (u32 r = 0; r < B; r++) h_p1[r + 1] += h_p1[r];
+        bt->sparse_p1_total = h_p1[B];
+        bt->sparse_ok = true;
+        bt->sparse_p2_max = 0;
+        for (size_t i = 0; i < (size_t)B * T; i++) {
+            const u32 term = h_terms[i];
+            h_qdf[i] = 0; h_row8[i] = SA_DD_NONE;
+            if (term >= ix->n_terms) continue;
+            h_qdf[i] = (u32)(ix->h_tf_off[term + 1] - ix->h_tf_off[term]);
+            bt->sparse_p2_max += ((u64)h_qdf[i] + SA_SP_CHUNK - 1) / SA_SP_CHUNK;
+            if (!ix->h_tf8_slot.empty()) h_row8[i] = ix->h_tf8_slot[term];
+        }
+        // Bloom filter of every lead term: the power of two in [8, 16) x df cells, at least 1024
+        size_t bytes = 0;
+        for (u32 r = 0; r < B; r++) {
+            const u64 df = h_lead[r] == 0xFFFFFFFFu ? 0 : h_qdf[(size_t)r * T + h_lead[r]];
+            const u64 cells = sa_pow2_cells(df);
+            h_boff[r] = bytes;
+            h_bshift[r] = 32u - (u32)__builtin_ctzll(cells);
+            bytes += (size_t)cells;
+        }
+        bt->bloom_bytes = bytes;
+        bt->sparse_lazy = false;
+}
+
 static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) {
     sa_index* ix = bt->ix;
     const u32 B = bt->B, T = bt->T;
@@ -2191,81 +2288,12 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
             for (u32 t = 0; t < T; t++) h_role[(size_t)r * T + t] = r < bt->n_hg_rows ? qrole_all[(size_t)bt->perm[r] * T + t] : SA_HG_SKIP;
     }
     {
-        // Dynamic pruning tables (sa_sparse.hip).  Per query: the terms in ascending idf order with the
-        // prefix sums of their idf -- what the j cheapest terms can add to a score at most, since
-        // tf/(tf+norm) <= 1 (needs k1 >= 0 and 0 <= b <= 1; a negative or non-finite idf switches the
-        // pruning off) -- and the LEAD term: the highest-idf term with postings in this shard.
-        const bool formula_ok = k1 >= 0.f && b >= 0.f && b <= 1.f;
-        const u64 limit1 = sa_batch_lead_limit(bt);
-        bt->sparse_limit2 = ix->n_docs / (u64)sa_env_int("SA_SPARSE_DIV", 8) > 4096 ? ix->n_docs / (u64)sa_env_int("SA_SPARSE_DIV", 8) : 4096;
-        std::pair<float, u32> v[SA_MAX_QTERMS];
-        h_p1[0] = 0;
-        for (u32 r = 0; r < B; r++) {
-            bool ok = formula_ok;
-            for (u32 t = 0; t < T; t++) {
-                const bool known = h_terms[(size_t)r * T + t] < ix->n_terms;
-                const float w = known ? h_idf[(size_t)r * T + t] : 0.f;
-                if (!(w >= 0.f) || w > 3.0e38f) ok = false;
-                v[t] = {w, t};
-            }
-            std::stable_sort(v, v + T, [](const std::pair<float, u32>& a, const std::pair<float, u32>& c) { return a.first < c.first; });
-            double acc = 0.0;
-            h_ub[(size_t)r * (T + 1)] = 0.f;
-            for (u32 j = 0; j < T; j++) {
-                h_ord[(size_t)r * T + j] = v[j].second;
-                acc += (double)v[j].first;
-                // rounded up: the fp32 sum the kernels form can exceed the exact sum by a few ulps
-                float ubf = (float)(acc * (1.0 + 1e-5));
-                ubf = nextafterf(ubf, INFINITY);
-                h_ub[(size_t)r * (T + 1) + j + 1] = ok ? ubf : INFINITY;
-            }
-            // lead: highest idf among the terms with postings here; too frequent -> scan the tiles
-            h_lead[r] = 0xFFFFFFFFu;
-            h_p1[r + 1] = 0;
-            if (ok) {
-                for (int j = (int)T - 1; j >= 0; j--) {
-                    const u32 t = v[(size_t)j].second;
-                    const u32 term = h_terms[(size_t)r * T + t];
-                    if (term >= ix->n_terms) continue;
-                    const u64 df = ix->h_tf_off[term + 1] - ix->h_tf_off[term];
-                    if (df == 0) continue;
-                    if (df <= limit1) { h_lead[r] = t; h_p1[r + 1] = df; }          // postings; turned into items below
-                    break;
-                }
-            }
-        }
-        {
-            // Lead-phase work items: 1024 postings each when there is plenty of work (measured best at
-            // 10 M docs: 0.66 vs 0.79 ms per step with 256), 256 when the shard is small and the phase
-            // would otherwise not fill the GPU (1.25 M docs: 0.157 vs 0.169 ms).
-            u64 lead_postings = 0;
-            for (u32 r = 0; r < B; r++) lead_postings += h_p1[r + 1];
-            bt->sparse_chunk1 = lead_postings >= (1ull << 19) ? SA_SP_CHUNK : SA_SP_CHUNK_LEAD;
-            if (const char* e = getenv("SA_SP_CHUNK1")) { const int c = atoi(e); if (c >= 64) bt->sparse_chunk1 = (u32)c; }
-            for (u32 r = 0; r < B; r++) h_p1[r + 1] = (h_p1[r + 1] + bt->sparse_chunk1 - 1) / bt->sparse_chunk1;
-        }
-        for (u32 r = 0; r < B; r++) h_p1[r + 1] += h_p1[r];
-        bt->sparse_p1_total = h_p1[B];
-        bt->sparse_ok = true;
-        bt->sparse_p2_max = 0;
-        for (size_t i = 0; i < (size_t)B * T; i++) {
-            const u32 term = h_terms[i];
-            h_qdf[i] = 0; h_row8[i] = SA_DD_NONE;
-            if (term >= ix->n_terms) continue;
-            h_qdf[i] = (u32)(ix->h_tf_off[term + 1] - ix->h_tf_off[term]);
-            bt->sparse_p2_max += ((u64)h_qdf[i] + SA_SP_CHUNK - 1) / SA_SP_CHUNK;
-            if (!ix->h_tf8_slot.empty()) h_row8[i] = ix->h_tf8_slot[term];
-        }
-        // Bloom filter of every lead term: the power of two in [8, 16) x df cells, at least 1024
-        size_t bytes = 0;
-        for (u32 r = 0; r < B; r++) {
-            const u64 df = h_lead[r] == 0xFFFFFFFFu ? 0 : h_qdf[(size_t)r * T + h_lead[r]];
-            const u64 cells = sa_pow2_cells(df);
-            h_boff[r] = bytes;
-            h_bshift[r] = 32u - (u32)__builtin_ctzll(cells);
-            bytes += (size_t)cells;
-        }
-        bt->bloom_bytes = bytes;
+        // the pruning tables: now, if the run may prune (the rule of sa_batch_run_shard, with what is known here); else on demand
+        const int sp_env = sa_env_int("SA_SPARSE", -1);
+        const bool grouped_default = bt->n_grouped_rows * 2u >= B && bt->impacts;
+        const bool maybe_sparse = sp_env >= 0 ? sp_env != 0 : !grouped_default;
+        if (maybe_sparse || sa_env_int("SA_SPARSE_LAZY", 1) == 0) sa_batch_fill_prune_tables(bt, img);
+        else { bt->sparse_ok = false; bt->sparse_lazy = true; bt->bloom_bytes = 0; bt->sparse_p1_total = 0; bt->sparse_p2_max = 0; }
     }
     memset(at(bt->d_seed), 0, (size_t)B * sizeof(u32));
     {
@@ -2400,6 +2428,18 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     // at least half of the batch's queries are in groups of either kind.
     const bool shared_heads = bt->n_grouped_rows * 2u >= bt->B && group_can_run;
     const bool sparse_wanted = sparse_env >= 0 ? sparse_env != 0 : (ix->n_docs >= (u64)bt->k * 32768ull && !shared_heads);
+    if (sparse_wanted && bt->sparse_lazy && bt->kind == 0) {
+        // the tables were left out at reset (the run was expected to score every posting): derive them into the image of the
+        // current query set -- once its upload has left the host buffer -- and upload it again, behind everything on this stream
+        const u32 last = (bt->up_n - 1u) & 1u;
+        SA_HIP(hipEventSynchronize(bt->ev_up[last]));
+        sa_batch_fill_prune_tables(bt, bt->h_up[last]);
+        SA_HIP(hipMemcpyAsync(bt->d_up, bt->h_up[last], bt->up_bytes, hipMemcpyHostToDevice, st));
+        SA_HIP(hipEventRecord(bt->ev_up[last], st));
+        // (the image carries the starting bounds as the host left them -- zeros: the slice-table kernel forms them again)
+        SA_TRY(sa_launch_make_bounds(ix, bt->d_terms, bt->B * bt->T, bt->d_bounds, bt->d_qbase, st, bt->d_qbase_imp,
+                                     bt->seed_on ? bt->impacts->d_topf : nullptr, bt->d_idf, bt->T, bt->k, bt->d_seed));
+    }
     const bool sparse = hist_possible && ix->tile_docs <= 8192 && bt->sparse_ok && ix->avg_doc_len != 0.f && ix->n_tiles > 0 &&
                         sparse_wanted;
     const bool use_hist = hist_possible &&

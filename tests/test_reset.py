@@ -186,3 +186,30 @@ def test_phrase_batch_reset(api, corpus):
     pb.close()
     dev.close()
     del rng
+
+
+def test_pruning_tables_on_demand(api, corpus, monkeypatch):
+    """a batch whose queries are grouped is reset WITHOUT the pruning tables (the run scores every posting); SA_SPARSE switched
+    on between reset and run -- what bench.py's pruning leg does with a resident batch -- derives them at that run and uploads
+    the image again; back to the exhaustive path the starting bounds are still there (the slice-table kernel forms them again)"""
+    words, off, lens, orc = corpus
+    dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api)
+    sets = query_sets()
+    monkeypatch.delenv("SA_SPARSE", raising=False)
+    bt = dev.batch(sets[0], k=9)                         # shared heads: grouped by default, no tables
+    for i, qs in enumerate([sets[0], sets[3], sets[0]]):
+        if i:
+            monkeypatch.delenv("SA_SPARSE", raising=False)
+            bt.reset(qs)
+        for mode in (None, "1", "0", None):
+            if mode is None:
+                monkeypatch.delenv("SA_SPARSE", raising=False)
+            else:
+                monkeypatch.setenv("SA_SPARSE", mode)
+            bt.run(sync=False)
+            scores, docs = bt.fetch()
+            assert_batch(orc, qs, scores, docs, 9, f"set {i} SA_SPARSE={mode}")
+        if i == 0:
+            assert bt.seeds().max() > 0
+    bt.close()
+    dev.close()
