@@ -914,9 +914,12 @@ __device__ __forceinline__ void sa_static_while_below(u32 n, F&& f) {
 
 #define SA_GRP_REFRESH_STEP 32
 #define SA_GRP_SURV_CAP 32          // survivors an item buffers before it writes them out (a pair has at most 16)
-#define SA_GRP_LOOSE_POSTINGS 128   // loose groups: expected postings of a query per tile, all terms together (measured on the
-                                    // distinct-terms batch, 10 M docs: 64 / 96 / 128 / 192 / 256 / 384 / 512 -> 0.82 / 0.74 / 0.74 / 0.73 / 0.75 / 0.80 / 0.81 ms
-                                    // at k = 10, 128 best at k = 1000: above it the overlay loses to the per-query kernel's dense tile)
+#define SA_GRP_LOOSE_POSTINGS 400   // loose groups: expected postings of a query per tile, all terms together (SA_LOOSE_POSTINGS).  Round 3,
+                                    // distinct-terms batch, 10 M docs: 64 / 96 / 128 / 192 / 256 / 384 / 512 -> 0.82 / 0.74 / 0.74 / 0.73 / 0.75 /
+                                    // 0.80 / 0.81 ms at k = 10, hence 128.  Round 4, with the starting bounds (the per-query kernel AND the
+                                    // overlay both start with a bound): 32 / 64 / 96 / 128 / 192 / 256 / 320 / 400 / 500 / 640 / 900 / all ->
+                                    // 1.00 / 0.80 / 0.62 / 0.54 / 0.50 / 0.47 / 0.457 / 0.459 / 0.468 / 0.476 / 0.483 / 0.485 ms at k = 10;
+                                    // k = 1000: 128 / 320 / 400 / 500 / 640 -> 0.89 / 0.84 / 0.81 / 0.77 / 0.81
 
 // IDFN: cells of the item's weight table = queries x lanes-per-query of the table build (64: up to 4 overlaid terms per
 // query -- the BASELINE shape --, 128: anything else the host admits, n * tt <= 128)
@@ -2252,7 +2255,7 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
                         const u32 term = terms[(size_t)q * T + t];
                         if (term < ix->n_terms) dfsum += ix->h_tf_off[term + 1] - ix->h_tf_off[term];
                     }
-                    if (dfsum > 0 && dfsum / ix->n_tiles <= (u64)SA_GRP_LOOSE_POSTINGS) sparse_rows.push_back(q);
+                    if (dfsum > 0 && dfsum / ix->n_tiles <= (u64)std::max(1, sa_env_int("SA_LOOSE_POSTINGS", SA_GRP_LOOSE_POSTINGS))) sparse_rows.push_back(q);
                     else dense_rows.push_back(q);
                 }
                 if (sparse_rows.size() >= 2) {
