@@ -2483,7 +2483,9 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
                 u32 warm = std::max<u32>(16u, bt->k / 8u);     // (k = 1000, 10 M docs: 250 / 128 / 64 warm-up tiles -> 1.07 / 1.02 / 1.05 ms per step)
                 // optimistic bounds from the warm-up sample (sa_k_seed_bounds): from k = 32 on, where the flag the check
                 // needs travels with the results (defer_check), unless a check has failed on this index before
-                const bool seed_on = sa_env_int("SA_SEED", 1) != 0 && !ix->seed_off && defer_check && bt->k >= 32u;
+                // (opt-in since the starting bounds exist: with them the sample adds nothing on the BASELINE batch -- k = 100: 0.434 ms
+                //  without, 0.446 with its 16 warm-up tiles; k = 1000: 0.581 / 0.587 -- and 4 % on the pairwise-distinct one at k = 1000)
+                const bool seed_on = sa_env_int("SA_SEED", 0) != 0 && !ix->seed_off && defer_check && bt->k >= 32u;
                 if (seed_on) warm = std::max<u32>(16u, bt->k / (u32)std::max(1, sa_env_int("SA_SEED_WARM_DIV", 32)));
                 // the queries start with bounds from their terms' rank tables (p.seed) and nothing is sampled for optimistic
                 // ones: no warm-up tiles at all -- the grouped kernel finds bounds above the base values from its first item

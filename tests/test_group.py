@@ -159,10 +159,11 @@ def test_loose_groups_equal_oracle_and_per_query_kernel(api, corpus, monkeypatch
 
 
 @pytest.mark.parametrize("k", [40, 100])
-@pytest.mark.parametrize("seed_env", [{}, {"SA_SEED": "0"}, {"SA_SEED_J": "1"}, {"SA_SEED_J": "3"}])
+@pytest.mark.parametrize("seed_env", [{"SA_SEED": "1"}, {"SA_SEED": "0"}, {"SA_SEED": "1", "SA_SEED_J": "1"}, {"SA_SEED": "1", "SA_SEED_J": "3"},
+                                      {"SA_SEED": "1", "SA_TERM_SEED": "0"}, {"SA_SEED": "1", "SA_TERM_SEED": "0", "SA_SEED_J": "1"}])
 def test_optimistic_bounds_from_the_warm_up_sample(api, corpus, monkeypatch, k, seed_env):
-    """k >= 32: after the warm-up tiles (2 of 9 here) every grouped query's bound is raised to the sample's j-th best score
-    (sa_k_seed_bounds), j from the sampling fraction -- or forced far too small (SA_SEED_J=1 / 3): then the merge finds fewer
+    """SA_SEED=1 (opt-in), k >= 32: after the warm-up tiles (2 of 9 here) every grouped query's bound is raised to the sample's
+    j-th best score (sa_k_seed_bounds), j from the sampling fraction -- or forced far too small (SA_SEED_J=1 / 3): then the merge finds fewer
     than k keys above the bound, flags the run and fetch redoes the batch without bounds.  Results equal the oracle's either
     way, in every run of the batch (the second run after a failed check is unseeded: the index has switched seeding off)"""
     monkeypatch.setenv("SA_SPARSE", "0")
