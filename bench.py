@@ -60,7 +60,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB
 MARKER = "sa_k_stream8"    # PMC child: two dispatches of this kernel separate the legs
 CALIB = "sa_k_stream16"    # PMC child: a known byte count read with 16-byte loads (FETCH_SIZE calibration)
 CALIB_BYTES = 1 << 30
-LOADS_8B = ("sa_k_bm25_group_tiles", "sa_k_bm25_headgroup")   # kernels whose posting loads are 8 bytes per lane
+LOADS_8B = ("sa_k_bm25_group_tiles",)   # kernels whose posting loads are 8 bytes per lane
 
 
 def log(rank, *a):

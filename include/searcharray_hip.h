@@ -311,10 +311,6 @@ int sa_batch_stats(sa_batch_t* batch, int enable, uint64_t* sparse_candidates_ou
  * in groups, out[2] = of them in groups that share their first term (the others are loose groups), out[3] = queries
  * left to the per-query kernel.  Diagnostics for benchmarks and tests; no reference counterpart. */
 int sa_batch_group_info(sa_batch_t* batch, uint32_t out[4]);
-/* The part of those groups scored by the head-group kernel (csrc/sa_bm25_hg.hip, sa_k_bm25_headgroup: the shared first
- * term is a read-only base, the further terms are one streamed dense term + candidate docs of the sparse ones):
- * out[0] = head groups, out[1] = queries in them.  Diagnostics; no reference counterpart. */
-int sa_batch_headgroup_info(sa_batch_t* batch, uint32_t out[2]);
 /* Host time this batch's steps have cost, cumulative nanoseconds by part: out[0] = sa_batch_reset / _step up to the upload
  * (grouping + pruning tables: CPU work only), out[1] = its enqueues (the upload copy, the slice-table launch), out[2] =
  * sa_batch_run's enqueues, out[3] = number of query sets filled.  Diagnostics (scripts/host_cost.py); no reference counterpart. */

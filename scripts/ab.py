@@ -22,8 +22,8 @@ sys.path.insert(0, ROOT)
 from searcharray_amd import synth, _lib                                     # noqa: E402
 from searcharray_amd.device_index import DeviceIndex, QueryBatch, compute_idf   # noqa: E402
 
-KEYS = ("SA_GROUP", "SA_GROUP_WARM", "SA_GROUP_MIN", "SA_GROUP_LOOSE", "SA_GROUP_SIDE", "SA_SPARSE", "SA_GRP_VARIANT", "SA_HG", "SA_HG_MIN",
-        "SA_HG_CAND_EXP", "SA_HG_S_MIN", "SA_SEED", "SA_SEED_WARM_DIV", "SA_SEED_J", "SA_XCD_RANGE", "SA_TERM_SEED", "SA_MERGE_SMALL", "SA_GROUP_MAXQ", "SA_LOOSE_POSTINGS")
+KEYS = ("SA_GROUP", "SA_GROUP_FX", "SA_GROUP_ST", "SA_GROUP_WARM", "SA_GROUP_MIN", "SA_GROUP_LOOSE", "SA_GROUP_SIDE", "SA_SPARSE", "SA_GRP_VARIANT",
+        "SA_SEED", "SA_SEED_WARM_DIV", "SA_SEED_J", "SA_XCD_RANGE", "SA_TERM_SEED", "SA_MERGE_SMALL", "SA_GROUP_MAXQ", "SA_LOOSE_POSTINGS")
 
 
 def main():

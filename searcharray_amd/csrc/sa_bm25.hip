@@ -874,10 +874,18 @@ struct GroupParams {
     u64 dense_stride;
     u32 n_groups;
     u32 tile0, n_tiles_run; // tiles [tile0, tile0 + n_tiles_run)
+    u32 n_items_run;        // sa_k_bm25_group_fx: items of ST index tiles each that cover them
     u32 tpx;                // tiles per XCD: XCD x takes the RANGE [x * tpx, (x + 1) * tpx) of the run's tiles (0: tiles t = x mod 8)
     u32 tt, tt_shift;       // lanes per query while the step tables are built: power of two >= max(T - 1, 1)
     u64* wl;                // work list of (tile << 32 | device row) items left to the per-query kernel
     u32* wl_cnt;
+    float fx_scale;         // sa_k_bm25_group_fx: 2^F, the unit of the integer image of the scores
+    u32 fx_slack;           // ... and what the integer sum of a doc may lack against its exact fp32 score, in units
+    const u32* qdes;        // ... [B] per device row: the term position whose postings COUNT docs for the query's bound (sa_batch_fill)
+    u32 fx_slack_lo;        // ... what the exact fp32 score of a doc may lack against its integer sum, in units
+    u64* fxc;               // ... its list of postings that passed the filter (sa_k_bm25_fx_rescore scores their docs exactly)
+    u32* fxc_cnt;
+    u32 fxc_cap;
 };
 
 // One HALF = up to 64 postings of ONE term of one query in this tile, one per lane (8-byte loads): every LDS
@@ -1294,6 +1302,8 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles_wl(const Bm25Params p
     }
 }
 
+#include "sa_bm25_group.hpp"
+
 // Merge n_cand candidate keys per query into the k best, sorted descending.
 // One workgroup of 1024 threads per query.
 //
@@ -1313,7 +1323,7 @@ __global__ void __launch_bounds__(256)
 sa_k_run_reset(u32* __restrict__ slots, u64 words, u64* __restrict__ bloom, u64 n8, u32* __restrict__ one_more) {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0 && one_more) *one_more = 0u;
+    if (t <= (u64)SA_FXC_LISTS && one_more) one_more[t * SA_FXC_CNT_STRIDE] = 0u;     // (work-list and rescoring-list cursors)
     for (u64 i = t; i < words; i += stride) slots[i] = 0u;
     for (u64 i = t; i < n8; i += stride) bloom[i] = 0ull;
 }
@@ -1520,7 +1530,7 @@ sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__
         if (tid == 32u) clr_state[(u64)clr_B * 32u + q] = 0u;
         if (tid == 33u) clr_state[(u64)clr_B * 33u + q] = 0u;
         if (clr_hist) for (u32 i = tid; i < (u32)SA_HBINS; i += THREADS) clr_state[(u64)clr_B * 34u + (u64)q * SA_HBINS + i] = 0u;
-        if (clr_one && q == 0u && tid == 34u) *clr_one = 0u;
+        if (clr_one && q == 0u && tid >= 34u && tid < 35u + (u32)SA_FXC_LISTS) clr_one[(tid - 34u) * SA_FXC_CNT_STRIDE] = 0u;    // (work-list and rescoring-list cursors)
     }
 }
 
@@ -1638,17 +1648,18 @@ static int sa_launch_bm25_list(sa_index* ix, const Bm25Params& p, hipStream_t st
     return SA_OK;
 }
 
-static int sa_launch_bm25_groups(sa_index* ix, const sa_batch* bt, const Bm25Params& p, u32 tile0, hipStream_t st) {
-    // head groups (sa_bm25_hg.hip) first: the first n_hg_groups entries of the group table
-    SA_TRY(sa_launch_bm25_headgroups(ix, bt, p, tile0, st));
+static int sa_launch_bm25_groups(sa_index* ix, const sa_batch* bt, const Bm25Params& p, u32 tile0, hipStream_t st, u32* overflow_cell) {
     GroupParams gp;
-    gp.grp = bt->d_grp + 3u * bt->n_hg_groups; gp.n_groups = bt->n_groups - bt->n_hg_groups;
+    gp.grp = bt->d_grp; gp.n_groups = bt->n_groups;
     gp.tile0 = tile0; gp.n_tiles_run = ix->n_tiles - tile0;
     gp.tt = bt->grp_tt; gp.tt_shift = bt->grp_tt_shift;
     gp.dense = (bt->impacts && sa_env_int("SA_GROUP_DENSE", 1) != 0) ? bt->impacts->d_dense : nullptr;
     gp.dense_stride = bt->impacts ? bt->impacts->dense_stride : 0;
-    const u64 blocks = (u64)((gp.n_tiles_run + 7u) / 8u) * 8u * gp.n_groups;
-    gp.tpx = sa_env_int("SA_XCD_RANGE", 1) != 0 ? (gp.n_tiles_run + 7u) / 8u : 0u;
+    const bool fx = bt->fx_on && bt->d_fxc;
+    const u32 st_items = fx ? (u32)std::max(1, std::min(2, sa_env_int("SA_GROUP_ST", 1))) : 1u;     // index tiles per item
+    gp.n_items_run = (gp.n_tiles_run + st_items - 1u) / st_items;
+    const u64 blocks = (u64)((gp.n_items_run + 7u) / 8u) * 8u * gp.n_groups;
+    gp.tpx = sa_env_int("SA_XCD_RANGE", 1) != 0 ? (gp.n_items_run + 7u) / 8u : 0u;
     if (blocks > 0x7FFFFFFFull) { sa_set_error("grouped launch: bad grid"); return SA_ERR_STATE; }
     gp.wl = bt->d_wl; gp.wl_cnt = bt->d_wl_cnt;
     const u64 worst = (u64)gp.n_tiles_run * bt->n_grouped_rows;
@@ -1656,10 +1667,21 @@ static int sa_launch_bm25_groups(sa_index* ix, const sa_batch* bt, const Bm25Par
     if (wgrid == 0) return SA_OK;
     // (weight table: n * tt cells; 64 cover up to 4 overlaid terms per query at 16 queries per item)
     const bool small = (u32)SA_GRP_MAXQ * gp.tt <= 64u;
+    gp.fx_scale = bt->fx_scale; gp.fx_slack = bt->fx_slack;
+    gp.qdes = bt->d_qdes; gp.fx_slack_lo = bt->fx_slack_lo;
+    gp.fxc = bt->d_fxc; gp.fxc_cnt = bt->d_wl_cnt + SA_FXC_CNT_STRIDE; gp.fxc_cap = bt->fxc_cap / (u32)SA_FXC_LISTS;
+    u32 tile_shift = 0;
+    while ((1u << tile_shift) < ix->tile_docs) tile_shift++;
 #define SA_LAUNCH_GROUP(TILE, THREADS)                                                                                     \
     {                                                                                                                      \
-        if (blocks && small) hipLaunchKernelGGL((sa_k_bm25_group_tiles<TILE, 64>), dim3((u32)blocks), dim3(64), 0, st, p, gp);       \
+        if (blocks && fx && small && st_items == 2) hipLaunchKernelGGL((sa_k_bm25_group_fx<TILE, 64, 2>), dim3((u32)blocks), dim3(64 * SA_GFX_NW), 0, st, p, gp); \
+        else if (blocks && fx && small) hipLaunchKernelGGL((sa_k_bm25_group_fx<TILE, 64, 1>), dim3((u32)blocks), dim3(64 * SA_GFX_NW), 0, st, p, gp); \
+        else if (blocks && fx && st_items == 2) hipLaunchKernelGGL((sa_k_bm25_group_fx<TILE, 128, 2>), dim3((u32)blocks), dim3(64 * SA_GFX_NW), 0, st, p, gp); \
+        else if (blocks && fx) hipLaunchKernelGGL((sa_k_bm25_group_fx<TILE, 128, 1>), dim3((u32)blocks), dim3(64 * SA_GFX_NW), 0, st, p, gp);   \
+        else if (blocks && small) hipLaunchKernelGGL((sa_k_bm25_group_tiles<TILE, 64>), dim3((u32)blocks), dim3(64), 0, st, p, gp);  \
         else if (blocks) hipLaunchKernelGGL((sa_k_bm25_group_tiles<TILE, 128>), dim3((u32)blocks), dim3(64), 0, st, p, gp);            \
+        if (blocks && fx) hipLaunchKernelGGL(sa_k_bm25_fx_rescore, dim3(8 * SA_FXC_LISTS), dim3(256), 0, st, p, (const u64*)gp.fxc, \
+                                             (const u32*)gp.fxc_cnt, gp.fxc_cap, tile_shift, overflow_cell);                        \
         hipLaunchKernelGGL((sa_k_bm25_tiles_wl<TILE, THREADS>), dim3(wgrid), dim3(THREADS), 0, st, p, (const u64*)gp.wl,   \
                            (const u32*)gp.wl_cnt);                                                                         \
     }                                                                                                                      \
@@ -1773,6 +1795,7 @@ void sa_batch_free(sa_batch* bt) {
     if (bt->d_stats) hipFree(bt->d_stats);
     if (bt->d_wl) hipFree(bt->d_wl);
     if (bt->d_wl_cnt) hipFree(bt->d_wl_cnt);
+    if (bt->d_fxc) hipFree(bt->d_fxc);
     if (bt->d_iota) hipFree(bt->d_iota);
     if (bt->d_route) hipFree(bt->d_route);
     if (bt->d_emask) hipFree(bt->d_emask);
@@ -1889,7 +1912,7 @@ static int sa_batch_alloc_bm25(sa_batch* bt) {
     const size_t o_p1 = take((B + 1) * 8), o_boff = take(B * 8), o_terms = take(B * T * 4), o_idf = take(B * T * 4),
                  o_perm = take(B * 4), o_grp = take(3 * B * 4), o_ub = take(B * (T + 1) * 4), o_ord = take(B * T * 4),
                  o_lead = take(B * 4), o_qdf = take(B * T * 4), o_row8 = take(B * T * 4), o_bsh = take(B * 4),
-                 o_role = take(B * T * 4), o_seed = take(B * 4);
+                 o_seed = take(B * 4), o_qdes = take(B * 4);
     SA_TRY(sa_batch_alloc_upload(bt, off));
     char* u = bt->d_up;
     bt->d_p1_off = (u64*)(u + o_p1); bt->d_bloom_off = (u64*)(u + o_boff);
@@ -1897,8 +1920,8 @@ static int sa_batch_alloc_bm25(sa_batch* bt) {
     bt->d_grp = (u32*)(u + o_grp); bt->d_ub = (float*)(u + o_ub); bt->d_ub_order = (u32*)(u + o_ord);
     bt->d_lead = (u32*)(u + o_lead); bt->d_qdf = (u32*)(u + o_qdf); bt->d_qrow8 = (u32*)(u + o_row8);
     bt->d_bloom_shift = (u32*)(u + o_bsh);
-    bt->d_qrole = (u32*)(u + o_role);
     bt->d_seed = (u32*)(u + o_seed);
+    bt->d_qdes = (u32*)(u + o_qdes);
     {
         std::vector<u32> iota(B);
         for (u32 i = 0; i < B; i++) iota[i] = i;
@@ -1908,8 +1931,13 @@ static int sa_batch_alloc_bm25(sa_batch* bt) {
     // work list of the grouped kernel: at most one entry per (tile, row)
     bt->wl_cap = (u32)std::max<size_t>(1, (size_t)ix->n_tiles * B);
     SA_HIP(hipMalloc(&bt->d_wl, (size_t)bt->wl_cap * sizeof(u64)));
-    SA_HIP(hipMalloc(&bt->d_wl_cnt, sizeof(u32)));
-    SA_HIP(hipMemset(bt->d_wl_cnt, 0, sizeof(u32)));
+    // cursors: [0] work list, [(1 + i) * SA_FXC_CNT_STRIDE] sub-list i of the rescoring list (all zeroed by the merge)
+    SA_HIP(hipMalloc(&bt->d_wl_cnt, (size_t)(1 + SA_FXC_LISTS) * SA_FXC_CNT_STRIDE * sizeof(u32)));
+    SA_HIP(hipMemset(bt->d_wl_cnt, 0, (size_t)(1 + SA_FXC_LISTS) * SA_FXC_CNT_STRIDE * sizeof(u32)));
+    // rescoring list of sa_k_bm25_group_fx: postings that passed the integer filter (a few per query once the bounds stand;
+    // thousands per query for k = 1000).  A list that runs over is detected on the device and the batch redone.
+    bt->fxc_cap = (u32)std::min<u64>(1ull << 24, std::max<u64>(1ull << 20, (u64)B * 8192ull));
+    SA_HIP(hipMalloc(&bt->d_fxc, (size_t)bt->fxc_cap * sizeof(u64)));
     SA_TRY(sa_batch_alloc_topk(bt, ix->n_tiles, sa_tile_waves(ix->tile_docs)));
     SA_HIP(hipMalloc(&bt->d_bounds, (B * T * (ix->n_tiles + 1) + 1) * sizeof(u32)));
     SA_HIP(hipMalloc(&bt->d_qbase, B * T * sizeof(u64)));
@@ -2109,7 +2137,6 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
     // shared term once per (tile, group).  Grouped queries take the first device rows, group by group (big
     // groups are cut into balanced pieces of at most `maxq` queries), the others keep their order behind them.
     std::vector<u32> h_grp;
-    std::vector<u32> qrole_all((size_t)B * T, SA_HG_SKIP);    // head groups: role of every query term, per caller query
     bt->n_groups = 0; bt->n_grouped_rows = 0; bt->n_shared_rows = 0;
     {
         // lanes per query while the half tables are built: a power of two >= the terms overlaid -- T - 1 for groups
@@ -2121,6 +2148,24 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
         while (tt_loose < T) { tt_loose <<= 1; tsh_loose++; }
         const bool loose_on = sa_env_int("SA_GROUP_LOOSE", 1) != 0 && 128u / tt_loose >= SA_GRP_MAXQ;
         u32 maxq = std::min<u32>(SA_GRP_MAXQ, 128u / tt);
+        // sa_k_bm25_group_fx (sa_bm25_group.hpp): SA_GFX_NW waves share an item, each takes up to maxq of its queries.  The unit of
+        // the integer image: 2^F with (S + 1) * 2^F < 2^16 (a wave's sums live in a 16-bit field of the accumulators; S = the largest
+        // weight sum of a query); weights too large for F >= 4 keep the fp32 overlay.
+        bool fx = sa_env_int("SA_GROUP_FX", 1) != 0;
+        {
+            double S = 0.0;
+            for (u32 i = 0; i < B; i++) {
+                double sq = 0.0;
+                for (u32 t = 0; t < T; t++) { const float w = idf[(size_t)i * T + t]; if (w > 0.f && w <= 3.0e38f) sq += (double)w; }
+                S = std::max(S, sq);
+            }
+            int F = 15;
+            while (F >= 0 && (S + 1.0) * std::ldexp(1.0, F) >= 65536.0) F--;
+            if (F < 4) fx = false;
+            bt->fx_scale = F >= 0 ? (float)std::ldexp(1.0, F) : 1.f;
+            bt->fx_slack = T + 2u + (u32)std::ceil(S * std::ldexp(1.0, F > 0 ? F : 0) * (double)T / 8388608.0);
+            bt->fx_slack_lo = 1u + (u32)std::ceil(S * std::ldexp(1.0, F > 0 ? F : 0) * (double)T / 8388608.0);
+        }
         // (a shard whose (tile, group) items do not fill the device for many rounds is better cut into more, shorter items:
         //  SA_GROUP_MAXQ; measured on a 1.25 M-doc shard below)
         maxq = std::min<u32>(maxq, (u32)std::max(1, sa_env_int("SA_GROUP_MAXQ", (int)SA_GRP_MAXQ)));
@@ -2129,59 +2174,6 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
         for (size_t i = 0; i < (size_t)B * T && idf_ok; i++) idf_ok = idf[i] >= 0.f && idf[i] <= 3.0e38f;
         const bool on = sa_env_int("SA_GROUP", 1) != 0 && idf_ok && maxq >= 1 &&
                         (ix->tile_docs == 1024 || ix->tile_docs == 2048 || ix->tile_docs == 4096);
-        // head groups: roles of the query terms (SA_HG_* in sa_bm25_params.hpp), per caller query
-        const bool hg_on = on && sa_env_int("SA_HG", 0) != 0 && T <= (u32)SA_HG_MAXT && ix->tile_docs == 2048 && bt->impacts &&
-                           ix->n_tiles > 0;
-        const u32 hg_min = (u32)std::max(1, sa_env_int("SA_HG_MIN", 2));
-        // a query's further terms: the one with the longest list is streamed, the postings of the others are its candidate docs
-        // (at most two such lists; their expected postings per super-tile -- 2 index tiles -- must fit the kernel's candidate map
-        //  with room to spare, else the query keeps the grouped / per-query kernels)
-        const double hg_cand_exp = (double)sa_env_int("SA_HG_CAND_EXP", 112);
-        auto hg_roles = [&](u32 q, bool head, u64* sdf_out) -> bool {
-            u32* role = &qrole_all[(size_t)q * T];
-            u64 df[SA_HG_MAXT] = {0, 0, 0, 0};
-            int lists[SA_HG_MAXT];
-            u32 n_lists = 0;
-            for (u32 t = 0; t < T; t++) {
-                role[t] = SA_HG_SKIP;
-                if (head && t == 0) { role[t] = SA_HG_HEAD; continue; }
-                const u32 term = terms[(size_t)q * T + t];
-                if (term >= ix->n_terms) continue;
-                df[t] = ix->h_tf_off[term + 1] - ix->h_tf_off[term];
-                if (df[t] == 0) continue;
-                lists[n_lists++] = (int)t;
-            }
-            *sdf_out = 0;
-            if (!head || n_lists > 3) return false;
-            // longest list first
-            std::stable_sort(lists, lists + n_lists, [&](int x, int y) { return df[x] > df[y]; });
-            // expected postings per super-tile (2 index tiles): the first candidate list takes two vectors, the second one
-            const double per_st = (double)SA_HG_ST / (double)ix->n_tiles;
-            if (n_lists > 1 && (double)df[lists[1]] * per_st > hg_cand_exp) return false;
-            if (n_lists > 2 && (double)df[lists[2]] * per_st > hg_cand_exp / 2.0) return false;
-            static const u32 kinds[3] = {SA_HG_STREAM, SA_HG_CAND0, SA_HG_CAND1};
-            for (u32 i = 0; i < n_lists; i++) role[lists[i]] = kinds[i];
-            if (n_lists) *sdf_out = df[lists[0]];
-            // the orders of the sums over the term positions 1 .. 3 (a role the query lacks takes a free position: it adds +0.0)
-            int pos_of[3] = {-1, -1, -1};                       // position of the stream list, the first, the second candidate list
-            bool used[4] = {true, false, false, false};
-            for (u32 i = 0; i < n_lists; i++) { pos_of[i] = lists[i]; used[lists[i]] = true; }
-            for (int i = 0; i < 3; i++)
-                if (pos_of[i] < 0)
-                    for (int t = 1; t < 4; t++)
-                        if (!used[t]) { pos_of[i] = t; used[t] = true; break; }
-            auto order = [](int p_own, int p_s, int p_oth) -> u32 {
-                // sa_hg_fold: 0 own,s,oth  1 own,oth,s  2 s,own,oth  3 s,oth,own  4 oth,own,s  5 oth,s,own
-                if (p_own == 1) return p_s == 2 ? 0u : 1u;
-                if (p_s == 1) return p_own == 2 ? 2u : 3u;
-                return p_own == 2 ? 4u : 5u;
-            };
-            const u32 ordA = order(pos_of[1], pos_of[0], pos_of[2]);     // docs of the first candidate list: own = its value, oth = the second list's
-            const u32 ordB = order(pos_of[2], pos_of[0], pos_of[1]);     // docs of the second: own = its value, oth = nothing (+0.0)
-            role[0] |= (ordA | (ordB << 3)) << 4;
-            return true;
-        };
-        bt->n_hg_groups = 0; bt->n_hg_rows = 0;
         if (on) {
             std::vector<std::vector<u32>> members;              // in order of first appearance
             std::vector<std::pair<u32, u32>> keys;
@@ -2197,37 +2189,10 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
                 members[gi].push_back(q);
             }
             std::vector<u32> order;
-            // Head groups first (sa_k_bm25_headgroup, sa_bm25_hg.hip): the queries of a shared-first-term group whose
-            // further terms are ONE dense term with a rank bitmap (the stream term) plus sparse terms with few postings
-            // per tile (the candidates) -- or sparse terms only.  No limit on the group size: the base is read-only
-            // there and every wave of a workgroup takes its own queries.  Members are dealt to the waves round-robin,
-            // so they are ordered by the stream term's length (the longest slices go to different waves).
-            if (hg_on) {
-                for (auto& m : members) {
-                    std::vector<std::pair<u64, u32>> el;            // (stream df, query)
-                    std::vector<u32> other;
-                    for (u32 q : m) {
-                        u64 sdf = 0;
-                        if (hg_roles(q, true, &sdf)) el.push_back({sdf, q}); else other.push_back(q);
-                    }
-                    if (el.size() < hg_min) continue;
-                    std::stable_sort(el.begin(), el.end(), [](const std::pair<u64, u32>& a, const std::pair<u64, u32>& c) { return a.first > c.first; });
-                    h_grp.push_back((u32)order.size()); h_grp.push_back((u32)el.size());
-                    {
-                        const u32 t0 = terms[(size_t)el[0].second * T];
-                        const bool have = bt->impacts && bt->impacts->d_dense && t0 < bt->impacts->dense_slot.size() &&
-                                          sa_env_int("SA_GROUP_DENSE", 1) != 0;
-                        h_grp.push_back(have ? bt->impacts->dense_slot[t0] : 0xFFFFFFFFu);
-                    }
-                    for (auto& e : el) order.push_back(e.second);
-                    m = other;
-                }
-                bt->n_hg_groups = (u32)(h_grp.size() / 3);
-                bt->n_hg_rows = (u32)order.size();
-            }
             for (auto& m : members) {
                 if (m.size() < gmin) { rest.insert(rest.end(), m.begin(), m.end()); continue; }
-                const u32 pieces = ((u32)m.size() + maxq - 1) / maxq;
+                const u32 gmax = fx ? maxq * (u32)SA_GFX_NW : maxq;
+                const u32 pieces = ((u32)m.size() + gmax - 1) / gmax;
                 u32 done = 0;
                 for (u32 pc = 0; pc < pieces; pc++) {
                     const u32 sz = ((u32)m.size() - done + (pieces - pc) - 1) / (pieces - pc);
@@ -2259,7 +2224,8 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
                     else dense_rows.push_back(q);
                 }
                 if (sparse_rows.size() >= 2) {
-                    const u32 pieces = ((u32)sparse_rows.size() + SA_GRP_MAXQ - 1) / SA_GRP_MAXQ;
+                    const u32 lmax = fx ? (u32)SA_GRP_MAXQ * (u32)SA_GFX_NW : (u32)SA_GRP_MAXQ;
+                    const u32 pieces = ((u32)sparse_rows.size() + lmax - 1) / lmax;
                     u32 done = 0;
                     for (u32 pc = 0; pc < pieces; pc++) {
                         const u32 sz = ((u32)sparse_rows.size() - done + (pieces - pc) - 1) / (pieces - pc);
@@ -2277,6 +2243,25 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
             bt->perm = order;
         }
         bt->grp_tt = tt; bt->grp_tt_shift = tsh;
+        bt->fx_on = fx && on;
+    }
+    {
+        // sa_k_bm25_group_fx counts a doc for the query's bound at ONE of its postings -- the designated term position's: the
+        // rarest overlaid term that still has 8 k postings (the best docs hold the rare terms; a term with fewer postings than
+        // k would never establish a bound), else the most frequent one
+        u32* h_qdes = (u32*)at(bt->d_qdes);
+        for (u32 r = 0; r < B; r++) {
+            const u32 q = bt->perm[r];
+            const u32 t_lo = (r < bt->n_shared_rows && T > 1u) ? 1u : 0u;
+            u32 best = t_lo; u64 best_df = 0; bool best_ok = false;
+            for (u32 t = t_lo; t < T; t++) {
+                const u32 term = terms[(size_t)q * T + t];
+                const u64 df = term < ix->n_terms ? ix->h_tf_off[term + 1] - ix->h_tf_off[term] : 0;
+                const bool ok = df >= 8ull * bt->k;
+                if ((ok && (!best_ok || df < best_df)) || (!ok && !best_ok && df > best_df)) { best = t; best_df = df; best_ok = ok; }
+            }
+            h_qdes[r] = best;
+        }
     }
     for (u32 r = 0; r < B; r++) {
         memcpy(&h_terms[(size_t)r * T], &terms[(size_t)bt->perm[r] * T], T * sizeof(u32));
@@ -2285,11 +2270,6 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
     }
     memset(h_grpd, 0, (size_t)3 * B * sizeof(u32));
     if (!h_grp.empty()) memcpy(h_grpd, h_grp.data(), h_grp.size() * sizeof(u32));     // (at most B groups)
-    {
-        u32* h_role = (u32*)at(bt->d_qrole);
-        for (u32 r = 0; r < B; r++)
-            for (u32 t = 0; t < T; t++) h_role[(size_t)r * T + t] = r < bt->n_hg_rows ? qrole_all[(size_t)bt->perm[r] * T + t] : SA_HG_SKIP;
-    }
     {
         // the pruning tables: now, if the run may prune (the rule of sa_batch_run_shard, with what is known here); else on demand
         const int sp_env = sa_env_int("SA_SPARSE", -1);
@@ -2493,7 +2473,6 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
                 //  starting bounds 0.420; 1.25 M-doc shard: 0.096 / 0.094 / - / 0.0825 against 0.126)
                 else if (p.seed) warm = 0;
                 if (const char* v = getenv("SA_GROUP_WARM")) warm = (u32)atoi(v);
-                if (bt->n_hg_groups) warm = (warm + 3u) & ~3u;   // (the head-group kernel scores super-tiles of up to 4 index tiles)
                 warm = std::min(warm, ix->n_tiles);
                 // The ungrouped rows (per-query kernel over all tiles) share nothing with the grouped ones -- not a
                 // query, not a counter -- so they run on the side stream BESIDE the warm-up tiles and the grouped kernel
@@ -2534,7 +2513,7 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
                         hipLaunchKernelGGL(sa_k_seed_bounds, dim3((bt->n_grouped_rows + 3u) / 4u), dim3(256), 0, st, (const u32*)bt->d_hist,
                                            bt->d_gthr, bt->n_grouped_rows, j);
                 }
-                if (rc_main == SA_OK && ix->n_tiles > warm) rc_main = sa_launch_bm25_groups(ix, bt, p, warm, st);
+                if (rc_main == SA_OK && ix->n_tiles > warm) rc_main = sa_launch_bm25_groups(ix, bt, p, warm, st, defer_check ? (overflow_cell ? overflow_cell : bt->d_overflow) : (u32*)nullptr);
                 if (side) SA_HIP(hipStreamWaitEvent(st, bt->ev_side[1], 0));
                 SA_TRY(rc_main);
             } else {
@@ -2892,12 +2871,6 @@ extern "C" int sa_batch_profile(sa_batch_t* bt, double* kernel_ms_out, uint64_t*
 extern "C" int sa_batch_group_info(sa_batch_t* bt, uint32_t out[4]) {
     SA_ARG(bt && out, "null argument");
     out[0] = bt->n_groups; out[1] = bt->n_grouped_rows; out[2] = bt->n_shared_rows; out[3] = bt->B - bt->n_grouped_rows;
-    return SA_OK;
-}
-
-extern "C" int sa_batch_headgroup_info(sa_batch_t* bt, uint32_t out[2]) {
-    SA_ARG(bt && out, "null argument");
-    out[0] = bt->n_hg_groups; out[1] = bt->n_hg_rows;
     return SA_OK;
 }
 

@@ -1,5 +1,5 @@
 // sa_bm25_params.hpp -- kernel parameter blocks shared by the BM25 scoring kernels (sa_bm25.hip: per-query and
-// grouped tile kernels; sa_bm25_hg.hip: the head-group kernel).
+// grouped tile kernels).
 #pragma once
 #include "sa_index.hpp"
 
@@ -51,21 +51,3 @@ struct Bm25Params {
     float* dense_out;      // [B][n_docs] or null
     u64* cand;             // [B][n_tiles][k] composite keys (global doc ids) or null
 };
-
-// ---- head-group kernel (sa_bm25_hg.hip) ------------------------------------------------------------
-// Role of a query term inside a head group, one u32 per (query, term) in the batch's upload block: bits [3:0] the kind;
-// the head's word also carries, from bit 4 on, the orders in which a candidate's sum takes (own value, stream value, other
-// list's value) over the term positions 1 .. 3: bits [6:4] for docs of the first candidate list, [9:7] of the second
-// (sa_hg_fold in sa_bm25_hg.hip).
-#define SA_HG_SKIP 0u       // unknown term / no postings in this shard
-#define SA_HG_HEAD 1u       // the group's shared first term: its scores are the super-tile's base in LDS
-#define SA_HG_STREAM 2u     // the query's longest further list: streamed against the base
-#define SA_HG_CAND0 3u      // the further terms with shorter lists: their postings are the candidate docs (first / second list)
-#define SA_HG_CAND1 4u
-#define SA_HG_MAXT 4
-#ifndef SA_HG_ST
-#define SA_HG_ST 2          // index tiles (of 2048 docs) per super-tile of the head-group kernel (1, 2 or 4)
-#endif        // query terms the kernel takes (positions 0 .. 3)
-
-struct sa_batch;
-int sa_launch_bm25_headgroups(sa_index* ix, const sa_batch* bt, const Bm25Params& p, u32 tile0, hipStream_t st);

@@ -208,157 +208,6 @@ __global__ void __launch_bounds__(256) sa_k_phrase_fused(const FusedPhraseParams
     }
 }
 
-// ---- the alternative, measured and NOT the default (SA_PHRASE_FUSED_COOP=1 selects it): on zipf-1M it is slower than
-//      the kernel above on every phrase -- 12.8 - 19.5 us against <= 15.9 on `t0 t1 t2` (anchor of 720 K words, directory rows: the loads
-//      per anchor word are the same, only their grouping changes, and the texture path, not latency, bounds them), 10 - 37 us
-//      against 4 - 8 on phrases of rare terms (anchor of < 1024 words = ONE wave: its lower bound, staging rounds and LDS
-//      searches are a longer dependent chain than 15 probes of a list whose top levels sit in L2)
-// Wave-cooperative lower bound on the header: first index in [0, n) whose (word & SA_HEADER_MASK) >= key.  Every round the 64
-// lanes probe 64 evenly spaced words of what is left and a ballot keeps the one interval the answer lies in: log64(n) global
-// round trips (3 for a list of 100 K words) where a lane on its own takes log2(n) = 17 dependent ones.
-__device__ __forceinline__ u32 sa_wave_lower_bound(const u64* __restrict__ a, u32 n, u64 key, u32 lane) {
-    u32 lo = 0, hi = n;                                      // the answer is in [lo, hi]
-    while (hi - lo > 64u) {
-        const u32 step = (hi - lo + 63u) >> 6;               // >= 2
-        const u32 idx = lo + lane * step;
-        const bool below = idx < hi && (a[idx < hi ? idx : hi - 1u] & SA_HEADER_MASK) < key;
-        const u32 c = (u32)__popcll((u64)__builtin_amdgcn_ballot_w64(below));   // lanes 0 .. c-1 are below the key (sorted)
-        const u32 nhi = lo + c * step;
-        if (c) lo = lo + (c - 1u) * step + 1u;
-        if (nhi < hi) hi = nhi;
-    }
-    const u32 idx = lo + lane;
-    const bool below = idx < hi && (a[idx < hi ? idx : (hi ? hi - 1u : 0u)] & SA_HEADER_MASK) < key;
-    return lo + (u32)__popcll((u64)__builtin_amdgcn_ballot_w64(below));
-}
-
-// A wave takes SA_PF_WPL x 64 consecutive words of the anchor list, SA_PF_WPL per lane (coalesced 8-byte loads, all in flight
-// together).  The anchor list is sorted by (doc, block), so the words of another term that can match them are ONE contiguous
-// slice of that term's list:
-//   * a term with a doc directory row: the row gives every lane its doc's first word directly (sa_window_docdir) -- the
-//     loads of a lane's SA_PF_WPL words are independent of each other;
-//   * any other term: the slice is found by the wave together (sa_wave_lower_bound on the chunk's first header), staged in
-//     LDS in rounds of 256 words until it covers the chunk's last header, and every lane finds its three neighbouring
-//     blocks by a binary search in LDS.  A slice longer than SA_PF_CAP words (a term much more frequent than the anchor,
-//     yet without a directory row) is searched in global memory from the slice's start.
-// The positional test itself is the AND / shift of 18-bit payloads in sa_phrase_anchor_mask_win; a wave whose words have all
-// lost their candidates skips the remaining terms.
-#define SA_PF_WPL 4
-#define SA_PF_CAP 1024
-
-__global__ void __launch_bounds__(256) sa_k_phrase_fused_coop(const FusedPhraseParams p) {
-    __shared__ u64 s_stage[4][SA_PF_CAP];
-    const u32 lane = threadIdx.x & 63u;
-    const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    u64* const stage = s_stage[wave];
-    const u64* const anc = p.ptr[p.anchor];
-    const u32 na = p.len[p.anchor];
-    const u64 delta = 1ull << SA_LSB_BITS;
-    constexpr u32 CH = 64u * SA_PF_WPL;
-    const u32 n_chunks = (na + CH - 1u) / CH;
-    for (u32 chunk = blockIdx.x * 4u + wave; chunk < n_chunks; chunk += gridDim.x * 4u) {
-        const u32 base = chunk * CH;
-        u64 w[SA_PF_WPL], m[SA_PF_WPL];
-#pragma unroll
-        for (int j = 0; j < SA_PF_WPL; j++) {
-            const u32 i = base + (u32)j * 64u + lane;
-            w[j] = anc[i < na ? i : na - 1u];
-            m[j] = i < na ? (w[j] & SA_LSB_MASK) : 0ull;
-        }
-        const u32 last = base + CH <= na ? base + CH - 1u : na - 1u;
-        const u64 h_first = anc[base] & SA_HEADER_MASK, h_last = anc[last] & SA_HEADER_MASK;     // (uniform addresses)
-        const u64 key_lo = h_first >= delta ? h_first - delta : 0ull, key_hi = h_last + delta;
-        for (int t = 0; t < p.T; t++) {
-            if (t == p.anchor) continue;
-            bool any = false;
-#pragma unroll
-            for (int j = 0; j < SA_PF_WPL; j++) any |= m[j] != 0ull;
-            if (__builtin_amdgcn_ballot_w64(any) == 0ull) break;
-            const int d = t - p.anchor;
-            const u64* const a = p.ptr[t];
-            const u32 n = p.len[t];
-            // which neighbours a word's window needs (sa_phrase_anchor_mask_win)
-            auto want = [&](u64 wj, bool& prev, bool& next) {
-                const u64 h = wj & SA_HEADER_MASK, doc_key = wj & SA_KEY_MASK;
-                prev = d < 0 && (h & ~SA_KEY_MASK & SA_HEADER_MASK) != 0 && ((h - delta) & SA_KEY_MASK) == doc_key;
-                next = d > 0 && ((h + delta) & SA_KEY_MASK) == doc_key;
-            };
-            u64 win[SA_PF_WPL];
-            if (p.dd[t]) {
-#pragma unroll
-                for (int j = 0; j < SA_PF_WPL; j++) {
-                    bool prev, next;
-                    want(w[j], prev, next);
-                    win[j] = m[j] ? sa_window_docdir(a, n, p.dd[t], w[j] & SA_HEADER_MASK, prev, next) : 0ull;
-                }
-            } else {
-                const u32 lo = sa_wave_lower_bound(a, n, key_lo, lane);
-                // stage the slice, 256 words a round, until it reaches past the chunk's last header (or the list ends)
-                u32 cnt = 0;
-                bool covered = lo >= n;
-                while (!covered && cnt < (u32)SA_PF_CAP) {
-                    u64 x[4];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const u32 i = lo + cnt + (u32)r * 64u + lane;
-                        x[r] = i < n ? a[i] : ~0ull;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; r++) stage[cnt + (u32)r * 64u + lane] = x[r];
-                    cnt += 256u;
-                    const u32 hi_lo = (u32)__builtin_amdgcn_readlane((int)(u32)x[3], 63), hi_hi = (u32)__builtin_amdgcn_readlane((int)(u32)(x[3] >> 32), 63);
-                    const u64 tail = ((u64)hi_hi << 32) | (u64)hi_lo;                    // the round's last word (all ones: past the list)
-                    covered = (tail & SA_HEADER_MASK) > key_hi;
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (covered) {
-                    // (words past the list are all ones: their header is above every key, so the search never lands on them
-                    //  as a match)
-#pragma unroll
-                    for (int j = 0; j < SA_PF_WPL; j++) {
-                        bool prev, next;
-                        want(w[j], prev, next);
-                        const u64 h = w[j] & SA_HEADER_MASK;
-                        u64 wn = 0;
-                        if (m[j]) {
-                            u32 hint = 0;
-                            if (prev) wn |= sa_payload_at(stage, cnt, h - delta, hint);
-                            wn |= sa_payload_at(stage, cnt, h, hint) << 18;
-                            if (next) wn |= sa_payload_at(stage, cnt, h + delta, hint) << 36;
-                        }
-                        win[j] = wn;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < SA_PF_WPL; j++) {
-                        bool prev, next;
-                        want(w[j], prev, next);
-                        const u64 h = w[j] & SA_HEADER_MASK;
-                        u64 wn = 0;
-                        if (m[j]) {
-                            u32 hint = lo;
-                            if (prev) wn |= sa_payload_at(a, n, h - delta, hint);
-                            wn |= sa_payload_at(a, n, h, hint) << 18;
-                            if (next) wn |= sa_payload_at(a, n, h + delta, hint) << 36;
-                        }
-                        win[j] = wn;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();                        // (the stage is reused by the next term)
-            }
-#pragma unroll
-            for (int j = 0; j < SA_PF_WPL; j++) m[j] &= (win[j] >> (18 + d)) & SA_LSB_MASK;
-        }
-#pragma unroll
-        for (int j = 0; j < SA_PF_WPL; j++) {
-            if (m[j]) {
-                if (p.fcounts) unsafeAtomicAdd(&p.fcounts[w[j] >> SA_KEY_SHIFT], (float)__popcll(m[j]));
-                else atomicAdd(&p.step[w[j] >> SA_KEY_SHIFT], (u32)__popcll(m[j]));
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------
 // the chain per DOCUMENT (phrases with repeated terms, frequent terms)
 // ---------------------------------------------------------------------------------------
@@ -841,13 +690,7 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
             fp.anchor = anchor;
             if (fp.T > SA_MAX_FUSED) { sa_set_error("fused phrase kernel: sub-phrase longer than 18 terms"); return SA_ERR_UNSUPPORTED; }
             if (fp.len[anchor] > 0)
-                {
-                const char* coop = getenv("SA_PHRASE_FUSED_COOP");
-                if (coop && atoi(coop) != 0)
-                    hipLaunchKernelGGL(sa_k_phrase_fused_coop, dim3(sa_grid_for(((u64)fp.len[anchor] + SA_PF_WPL - 1) / SA_PF_WPL)), dim3(256), 0, st, fp);
-                else
-                    hipLaunchKernelGGL(sa_k_phrase_fused, dim3(sa_grid_for(fp.len[anchor])), dim3(256), 0, st, fp);
-            }
+                hipLaunchKernelGGL(sa_k_phrase_fused, dim3(sa_grid_for(fp.len[anchor])), dim3(256), 0, st, fp);
             if (nparts > 1) hipLaunchKernelGGL(sa_k_min_step, dim3(sa_grid_for(N)), dim3(256), 0, st, running, step, N, pi == 0 ? 1 : 0);
         }
         return SA_OK;

@@ -491,10 +491,7 @@ class QueryBatch:
         (the others are loose groups), queries left to the per-query kernel"""
         out = (_lib.c_uint32 * 4)()
         self.api.call("sa_batch_group_info", self._h, out)
-        hg = (_lib.c_uint32 * 2)()
-        self.api.call("sa_batch_headgroup_info", self._h, hg)
-        return {"groups": int(out[0]), "grouped_queries": int(out[1]), "shared_first_term": int(out[2]), "per_query_kernel": int(out[3]),
-                "head_groups": int(hg[0]), "head_group_queries": int(hg[1])}
+        return {"groups": int(out[0]), "grouped_queries": int(out[1]), "shared_first_term": int(out[2]), "per_query_kernel": int(out[3])}
 
     def seeds(self) -> np.ndarray:
         """the bound every query of the current set starts with (sa_batch_seeds), float32[B], 0 = none"""

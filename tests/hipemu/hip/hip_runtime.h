@@ -27,6 +27,7 @@
 #include <vector>
 
 #define __global__
+#define SA_OPAQUE_U32(x) ((void)(x))
 #define __device__
 #define __host__
 #define __forceinline__ inline
@@ -41,6 +42,8 @@ struct dim3 {
 struct uint3_emu { unsigned x, y, z; };
 struct alignas(16) float4 { float x, y, z, w; };
 inline float4 make_float4(float x, float y, float z, float w) { float4 v; v.x = x; v.y = y; v.z = z; v.w = w; return v; }
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 v; v.x = x; v.y = y; v.z = z; v.w = w; return v; }
 
 typedef int hipError_t;
 typedef struct hipemu_stream* hipStream_t;
@@ -294,6 +297,7 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
 // scheduling barrier on the GPU; here the lanes of a wave are fibers, so it must really line them up
 inline void __builtin_amdgcn_wave_barrier() { (void)__ballot(1); }
 inline void __builtin_amdgcn_s_waitcnt(int) {}          // memory is synchronous here
+inline void __builtin_amdgcn_sched_barrier(int) {}      // instruction scheduling only
 inline int __builtin_amdgcn_readlane(int v, int lane) {
     return (int)(uint32_t)hipemu::wave_collective(hipemu::OP_SHFL, (uint64_t)(uint32_t)v, lane);
 }
@@ -315,6 +319,8 @@ inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return
 inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
 inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+// v_cvt_u32_f32: truncates toward zero, saturates, NaN -> 0
+inline unsigned __float2uint_rz(float x) { return x >= 4294967296.f ? 0xFFFFFFFFu : (x > 0.f ? (unsigned)x : 0u); }
 inline float __fdiv_rn(float a, float b) { return a / b; }
 inline float __fsqrt_rn(float a) { return sqrtf(a); }
 inline float __fmul_rn(float a, float b) { return a * b; }

@@ -1,6 +1,6 @@
 """BASELINE config 4 at its FULL size under pytest (GPU only): the zipf-10M corpus, the 256 x 4-term BASELINE query set
-(seed 42), top-10.  Every exhaustive route of the library -- the grouped kernel (the default), the head-group
-kernel (SA_HG=1), the per-query tile kernel (SA_GROUP=0) -- and dynamic pruning (SA_SPARSE=1) must return the same keys for
+(seed 42), top-10.  Every exhaustive route of the library -- the grouped kernel (the default), the per-query tile
+kernel (SA_GROUP=0) -- and dynamic pruning (SA_SPARSE=1) must return the same keys for
 ALL 256 queries, and the first 16 queries plus the probe query must equal the CPU oracle's dense scores (the reference's
 np.sum of per-term score vectors, test/test_msmarco.py:345-395) + deterministic top-k, bit for bit.  A fresh query set
 through sa_batch_step (the bench's step) is checked the same way.
@@ -43,7 +43,7 @@ def zipf10m():
 
 
 def run(dev, queries, env, monkeypatch):
-    for k_ in ("SA_SPARSE", "SA_GROUP", "SA_HG"):
+    for k_ in ("SA_SPARSE", "SA_GROUP"):
         monkeypatch.delenv(k_, raising=False)
     for k_, v in env.items():
         monkeypatch.setenv(k_, v)
@@ -68,11 +68,9 @@ def test_config4_all_routes_agree_and_equal_the_oracle(zipf10m, monkeypatch):
     queries = synth.bm25_queries(256, vocab=V)
     (grouped, gi) = run(dev, queries, {"SA_SPARSE": "0"}, monkeypatch)
     assert gi["grouped_queries"] >= 200, gi
-    (head, gih) = run(dev, queries, {"SA_SPARSE": "0", "SA_HG": "1"}, monkeypatch)
-    assert gih["head_group_queries"] >= 200, gih
     (per_query, _) = run(dev, queries, {"SA_SPARSE": "0", "SA_GROUP": "0"}, monkeypatch)
     (pruned, _) = run(dev, queries, {"SA_SPARSE": "1"}, monkeypatch)
-    for name, got in (("head-group", head), ("per-query", per_query), ("pruned", pruned)):
+    for name, got in (("per-query", per_query), ("pruned", pruned)):
         assert np.array_equal(grouped[0], got[0]), f"scores: grouped vs {name}"
         assert np.array_equal(grouped[1], got[1]), f"docs: grouped vs {name}"
     check_oracle(orc, queries, grouped[0], grouped[1], range(17))       # the probe query t0 t9 t99 t999 and 16 more

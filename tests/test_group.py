@@ -152,7 +152,7 @@ def test_loose_groups_equal_oracle_and_per_query_kernel(api, corpus, monkeypatch
     # no first term is shared; loose groups exist (when the half tables take all T terms of 16 queries) and the
     # query with the dense first term stays with the per-query kernel
     assert gi["shared_first_term"] == 0 and gi["per_query_kernel"] >= 1
-    assert gi["groups"] >= 2 and gi["grouped_queries"] >= 20
+    assert gi["groups"] >= 1 and gi["grouped_queries"] >= 20     # (an item's four waves take up to 64 loose queries)
     monkeypatch.setenv("SA_GROUP_LOOSE", "0")
     ref = check(api, corpus, queries, k, tile_docs=1024)
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])

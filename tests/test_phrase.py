@@ -828,19 +828,15 @@ def test_slop_phrases_of_a_batch_share_their_launches(api, monkeypatch):
     dev.close()
 
 
-@pytest.mark.parametrize("coop", ["0", "1"])
 @pytest.mark.parametrize("div", ["0", "32", "1000000"])
-def test_fused_kernel_routes_dd_staged_and_searched(api, monkeypatch, div, coop):
-    """sa_k_phrase_fused (csrc/sa_phrase.hip), one anchor word per lane, and its wave-cooperative alternative
-    (SA_PHRASE_FUSED_COOP=1, sa_k_phrase_fused_coop -- measured slower, kept selectable): a wave takes 256 consecutive anchor words; another term's words around them come
-    through the term's doc directory row (SA_DOCDIR_DIV=1000000: every term of >= 64 words has one), from the slice of the
-    term's list the wave stages in LDS (found by the wave-cooperative lower bound), or -- a slice longer than 1024 words:
-    frequent terms without rows, SA_DOCDIR_DIV=0 -- by a search in global memory from the slice's start.  All equal the
+def test_fused_kernel_routes_dd_and_searched(api, monkeypatch, div):
+    """sa_k_phrase_fused (csrc/sa_phrase.hip), one anchor word per lane: another term's words around it come through the
+    term's doc directory row (SA_DOCDIR_DIV=1000000: every term of >= 64 words has one) or -- frequent terms without
+    rows, SA_DOCDIR_DIV=0 -- by a search of the term's list.  All equal the
     oracle's counts (the reference's phrase_freqs, bigram_freqs.py:48-307 + middle_out.py:73-168), on lists long enough for
     several chunks per anchor, anchors in every phrase position, lists that end inside a wave's last round"""
     monkeypatch.setenv("SA_DOCDIR_DIV", div)
     monkeypatch.setenv("SA_PHRASE_MODE", "fused")
-    monkeypatch.setenv("SA_PHRASE_FUSED_COOP", coop)
     n_docs, vocab = 6000, 300
     t, d, p, lens = synth.corpus_triples(n_docs, vocab, 40, seed=21)
     words, wt = rz.encode_sorted(t, d, p)
