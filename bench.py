@@ -422,24 +422,17 @@ class PhraseSide:
         from oracle import refimpl as O
         out = {}
 
-        def best_ms(ph, slop, env):
-            old = {k: os.environ.get(k) for k in env}
-            os.environ.update(env)
-            try:
+        def best_ms(ph, slop, opts):
+            from searcharray_amd import options as sa_options
+            with sa_options.scoped(**opts):                  # (the route is an option of the call's handle, not of the process)
                 ms = []
                 for _ in range(4):
                     r = self.index.phrase_freqs_dense(ph, slop=slop)
                     ms.append(self.index.last_profile()[0])
-            finally:
-                for k, v in old.items():
-                    if v is None:
-                        os.environ.pop(k, None)
-                    else:
-                        os.environ[k] = v
             return round(min(ms[1:]), 4), r
 
         ms, got = best_ms([0, 1], 2, {})
-        ms_g, got_g = best_ms([0, 1], 2, {"SA_SPAN_DOC": "0"})
+        ms_g, got_g = best_ms([0, 1], 2, {"span_doc": 0})
         row = {"phrase": "t0 t1", "slop": 2, "device_ms": ms, "general_route_device_ms": ms_g, "matches": int(got.sum()),
                "routes_agree": bool(np.array_equal(got, got_g)),
                "algorithmic_bytes": self.word_bytes([[0, 1]]) + 4 * self.docs}
@@ -452,7 +445,7 @@ class PhraseSide:
             row["counts_bit_exact"] = bool(np.array_equal(got, want))
         out["slop_heaviest_two_terms"] = row
         ms, got = best_ms([0, 0, 1], 0, {})
-        ms_g, got_g = best_ms([0, 0, 1], 0, {"SA_PHRASE_DOCS": "0"})
+        ms_g, got_g = best_ms([0, 0, 1], 0, {"phrase_docs": 0})
         out["phrase_repeated_term"] = {"phrase": "t0 t0 t1", "device_ms": ms, "general_chain_device_ms": ms_g, "matches": int(got.sum()),
                                        "routes_agree": bool(np.array_equal(got, got_g))}
         return out
@@ -545,7 +538,7 @@ def pmc_child(r, legs):
     r.api.call("sa_stream_probe", CALIB_BYTES, 0, 1, ctypes.byref(g))
     for name, batch, sparse in legs:
         if sparse is not None:
-            os.environ["SA_SPARSE"] = sparse
+            batch.set_options(sparse=int(sparse))
         r.api.call("sa_stream_probe", 1 << 20, 0, 1, ctypes.byref(g))     # marker: the leg's untimed warm-up run follows
         batch.run(sync=True)
         r.api.call("sa_stream_probe", 1 << 20, 0, 1, ctypes.byref(g))     # marker: the leg's PMC_STEPS counted runs follow
@@ -913,7 +906,9 @@ def main():
     # batches is dynamic pruning (csrc/sa_sparse.hip: only docs that can still reach the top-k are scored; identical
     # results); it is timed right after on the resident set 0.  --pruned swaps the two.
     exhaustive = not args.pruned
-    os.environ["SA_SPARSE"] = "0" if exhaustive else "1"
+    from searcharray_amd import options as sa_options
+    route = sa_options.Scope()                              # the scoring route of the legs below: an OPTION of the batches (thread-scoped here)
+    route.set(sparse=0 if exhaustive else 1)
     P = max(1, args.pipeline if B <= 1024 else min(args.pipeline, 4))
     pair = [r.make_batch(sets[i % len(sets)], check=(i == 0)) for i in range(P)]
     R = max(1, args.repeats)
@@ -957,7 +952,7 @@ def main():
         for b in ring2:
             b.close()
 
-    os.environ["SA_SPARSE"] = "1" if exhaustive else "0"
+    route.set(sparse=1 if exhaustive else 0)
     K2 = max(3, min(K, 10))
     dt2 = r.timed(batch, 2, K2)
     kernel_ms2, _, _ = batch.profile()
@@ -966,11 +961,11 @@ def main():
 
     dt3 = kernel_ms3 = alg3 = None
     if batch_d is not None:
-        os.environ["SA_SPARSE"] = "0"
+        route.set(sparse=0)
         dt3 = r.timed(batch_d, 2, K2)
         kernel_ms3, alg3, post3 = batch_d.profile()
         batch_d.fetch()
-    os.environ["SA_SPARSE"] = "0" if exhaustive else "1"
+    route.set(sparse=0 if exhaustive else 1)
 
     qps = B * K / dt
 
@@ -1015,7 +1010,7 @@ def main():
 
     phrase_out = {}
     if side is not None and rank == 0:
-        os.environ.pop("SA_SPARSE", None)
+        route.unset("sparse")
         cpu_s = 0.0 if args.no_cpu_baseline else 8.0
         phrase_out["phrase_batch"] = phrase_leg_block(side, "phrase_batch", side.trigrams, 0, side.pb, pmc, K2, cpu_s)
         phrase_out["slop_batch"] = phrase_leg_block(side, "slop_batch", side.slop2, 2, side.sb, pmc, K2, cpu_s)

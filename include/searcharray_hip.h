@@ -43,6 +43,83 @@ int sa_device_count(int* out_count);
 int sa_device_name(int device, char* buf, int buf_len);
 
 /* ------------------------------------------------------------------------------------- */
+/* Part 0 -- options                                                                       */
+/* ------------------------------------------------------------------------------------- */
+/* The library's switches travel as DATA, per index handle and per batch -- the counterpart of the keyword arguments of
+ * the reference's objects (searcharray/postings.py:250-258 SearchArray.index(...), :652-656 score(...)); nothing the scoring
+ * path does depends on the process environment.  Every field is an int64; SA_OPT_UNSET = "the library decides" (its default
+ * or its automatic rule).  A handle starts from the process defaults: all unset, plus the debug override
+ * SA_OPTS="name=value,name=value" that is read ONCE when the library first needs it.  Options at CREATION (an index's
+ * directory thresholds, a batch's capacities): sa_options_set_thread_defaults -- every index handle the calling thread creates
+ * afterwards starts from them, every batch too (without thread defaults a batch starts from its index's options); other threads
+ * are not affected.  sa_index_set_options / sa_batch_set_options replace a handle's options later (index: the switches of its
+ * dense calls and what batches created afterwards start from; batch: effective from its next reset / run; the switches read at
+ * creation keep what they were).  Bindings that do not want to mirror the struct fill it by name:
+ * sa_options_init + sa_options_set(&o, "sparse", 0); sa_option_count / sa_option_name enumerate the fields in struct order. */
+#define SA_OPT_UNSET INT64_MIN
+typedef struct sa_options {
+    uint64_t struct_size;           /* sizeof(sa_options_t) of the caller's header */
+    int64_t sparse;          /* 1: dynamic pruning (MaxScore), 0: exhaustive scoring; unset: the rule of sa_batch_run_shard */
+    int64_t group;           /* 0: no grouped kernel (queries that share their first term are scored one by one) */
+    int64_t group_loose;     /* 0: no loose groups */
+    int64_t group_side;      /* 0: ungrouped rows on the batch's own stream instead of the side stream */
+    int64_t group_dense;     /* 0: the grouped kernel builds its base from postings even where a dense factor row exists */
+    int64_t group_min;       /* smallest group (default 2) */
+    int64_t group_maxq;      /* queries per grouped item (default and at most 16) */
+    int64_t group_warm;      /* tiles scored by the per-query kernel first to establish bounds (default: none with starting bounds) */
+    int64_t loose_postings;  /* loose groups: expected postings of a query per tile at most (default 400) */
+    int64_t xcd_range;       /* 0: tiles dealt round-robin to the XCDs instead of ranges */
+    int64_t term_seed;       /* 0: no starting bounds from the terms' rank tables */
+    int64_t seed_scale_pct;  /* TEST HOOK: starting bounds scaled by this percentage (> 100 makes them too high: the redo path) */
+    int64_t merge_small;     /* 0: the 1024-thread merge also for k <= 64 */
+    int64_t impact;          /* 0: score the TF postings, no impact stream */
+    int64_t pruned_topk;     /* 0: block-level selection (no bounds) */
+    int64_t no_topk;         /* timing experiments: skip the per-tile selection */
+    int64_t topk_hist;       /* 0: slot bound instead of the histogram bound */
+    int64_t topk_hist_mink;  /* smallest k that takes the histogram bound */
+    int64_t cand_cap;        /* TEST HOOK: candidate-list capacity per query (forces the overflow handling) */
+    int64_t sparse_div;      /* pruning: a lead term has at most n_docs / this postings (default 8) */
+    int64_t sparse_lazy;     /* 0: pruning tables derived at every reset, needed or not */
+    int64_t bloom_floor;     /* TEST HOOK: smallest Bloom buffer in bytes */
+    int64_t sp_chunk1;       /* pruning: postings per lead work item */
+    int64_t batch_stream;    /* 0: batches share the index stream */
+    int64_t res_xs;          /* 0: result copies on the batches' own streams */
+    int64_t dense_div;       /* dense factor rows for terms with df >= n_docs / this (default 4) */
+    int64_t dir_div;         /* tile directory rows for terms with df >= n_tiles / this */
+    int64_t docdir_div;      /* doc directory rows for terms with >= n_docs / this words (0: none) */
+    int64_t tf8_div;         /* dense tf rows for terms with df >= n_docs / this */
+    int64_t tf8_maxrows;     /* ... at most this many */
+    int64_t seg_words;       /* TEST HOOK: words per segment of the posting derivation */
+    int64_t phrase_mode;     /* 0 auto, 1 general chain, 2 fused kernel */
+    int64_t phrase_docdir;   /* 0: no doc directory probes */
+    int64_t phrase_docs;     /* 0: no chain per document */
+    int64_t phrase_lanes;    /* phrase tiles: lanes per phrase */
+    int64_t ptile;           /* docs per phrase tile (2048 / 4096) */
+    int64_t span_doc;        /* 0: no doc-parallel route */
+    int64_t span_docdir;     /* 0: no doc directory */
+    int64_t span_doc_multi;  /* 0: one launch per phrase */
+    int64_t span_doc_rank;   /* 0: ranking in its own launch */
+    int64_t span_fast;       /* 0: general state machine only */
+    int64_t span_multi;      /* 0: no multi-phrase launch of the general route */
+    int64_t span_sort;       /* 1 / 0: force / forbid sorting the docs by work */
+    int64_t span_threads;    /* TEST HOOK: grid cap (forces the stride loop) */
+    int64_t io_piece_bytes;  /* bytes per staged piece */
+    int64_t io_threads;      /* file threads */
+    int64_t trace;           /* 1: route decisions to stderr */
+} sa_options_t;
+void sa_options_init(sa_options_t* opts);                                  /* all unset */
+int sa_options_set(sa_options_t* opts, const char* name, int64_t value);
+int sa_options_get(const sa_options_t* opts, const char* name, int64_t* value_out);
+int sa_option_count(void);
+const char* sa_option_name(int i);                                          /* NULL past the end */
+int sa_options_process_defaults_get(sa_options_t* out);                    /* all unset + the SA_OPTS override */
+int sa_options_set_thread_defaults(const sa_options_t* opts);              /* NULL: this thread creates from the process defaults again */
+int sa_index_set_options(sa_index_t* ix, const sa_options_t* opts);
+int sa_index_get_options(sa_index_t* ix, sa_options_t* out);
+int sa_batch_set_options(sa_batch_t* batch, const sa_options_t* opts);
+int sa_batch_get_options(sa_batch_t* batch, sa_options_t* out);
+
+/* ------------------------------------------------------------------------------------- */
 /* Part 1 -- kernel-level mirrors of the reference's native entry points                   */
 /* ------------------------------------------------------------------------------------- */
 

@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 from searcharray_amd import synth, _lib                                     # noqa: E402
 from searcharray_amd.device_index import DeviceIndex, QueryBatch, compute_idf   # noqa: E402
 
-KEYS = ("SA_GROUP", "SA_GROUP_FX", "SA_GROUP_ST", "SA_GROUP_WARM", "SA_GROUP_MIN", "SA_GROUP_LOOSE", "SA_GROUP_SIDE", "SA_SPARSE", "SA_GRP_VARIANT",
+KEYS = ("SA_GROUP",  "SA_GROUP_WARM", "SA_GROUP_MIN", "SA_GROUP_LOOSE", "SA_GROUP_SIDE", "SA_SPARSE", "SA_GRP_VARIANT",
         "SA_SEED", "SA_SEED_WARM_DIV", "SA_SEED_J", "SA_XCD_RANGE", "SA_TERM_SEED", "SA_MERGE_SMALL", "SA_GROUP_MAXQ", "SA_LOOSE_POSTINGS")
 
 
@@ -69,11 +69,13 @@ def main():
             idf = np.asarray([[compute_idf(D, np.asarray([df[t]])) for t in q] for q in queries], dtype=np.float32)
             for k in [int(x) for x in args.ks.split(",")]:
                 for cfg in envs:
+                    # the switches of a configuration: options of the batch (this round's library) -- and, for a build from
+                    # before the options existed (--libs), the environment variables it read
                     for key in KEYS:
                         os.environ.pop(key, None)
                     os.environ["SA_SPARSE"] = "0"
                     os.environ.update(cfg)
-                    batch = QueryBatch(index, queries, k=k, idf=idf)
+                    batch = QueryBatch(index, queries, k=k, idf=idf, opts=dict({"sparse": 0}, **cfg))
                     for _ in range(3):
                         batch.run(sync=False)
                     index.synchronize()

@@ -1,4 +1,5 @@
 """How long the first batch with a new (k1, b) takes at 10 M docs: impact stream + dense rows + rank tables are built then."""
+import _envopts  # noqa: F401  (SA_* environment -> library options, scripts/_envopts.py)
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np

@@ -2,6 +2,7 @@
 """The fresh-batch loop of bench.py alone (10 M docs, rotating query sets, P batches in flight), `--steps` steps after the
 warm-up: run under `rocprofv3 --hip-trace --stats` with two step counts, the difference of the two HIP-API summaries is
 what the steady state calls -- no hipMalloc / hipFree / hipHostMalloc / blocking hipMemcpy among it."""
+import _envopts  # noqa: F401  (SA_* environment -> library options, scripts/_envopts.py)
 import argparse
 import json
 import os

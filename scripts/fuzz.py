@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Randomised differential run (development tool): the tests/test_fuzz.py loops with many iterations,
 on the GPU library (default) or the host stand-in (--emu)."""
+import _envopts  # noqa: F401  (SA_* environment -> library options, scripts/_envopts.py)
 import argparse
 import os
 import sys

@@ -2,6 +2,7 @@
 """Same-box A/B of the exhaustive scoring paths on the bench workload: per-query kernel (SA_GROUP=0) vs grouped
 kernel (shared first term) with different warm-up tile counts / minimum group sizes; BASELINE and
 pairwise-distinct query sets; identical results required.  One JSON line per configuration."""
+import _envopts  # noqa: F401  (SA_* environment -> library options, scripts/_envopts.py)
 import argparse
 import json
 import os

@@ -2,6 +2,7 @@
 """Host-side cost of one fresh-batch step, by call: idf (numpy), QueryBatch.reset (Python packing + sa_batch_reset),
 run (kernel launches), fetch.  The device is kept idle-free or starved depending on --docs: with a small shard the host
 is the bottleneck and these are what a step costs."""
+import _envopts  # noqa: F401  (SA_* environment -> library options, scripts/_envopts.py)
 import argparse
 import json
 import os

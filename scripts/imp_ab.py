@@ -4,6 +4,7 @@
 SA_IMPACT=0: TF postings + saturation table; 1: impact stream (the default).  One index per corpus size,
 one batch, every route timed on the same box; results of all routes must be identical.  --slots / --empty
 time subsets of the query terms (what a phase costs).  Prints one JSON line per (docs, k, route)."""
+import _envopts  # noqa: F401  (SA_* environment -> library options, scripts/_envopts.py)
 import argparse
 import json
 import os

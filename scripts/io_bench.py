@@ -3,6 +3,7 @@
 stream it back file -> page-locked ring -> HBM, next to the route through numpy (np.fromfile +
 upload of a pageable array) and to what the reference does with the file (np.memmap + first touch
 of every page)."""
+import _envopts  # noqa: F401  (SA_* environment -> library options, scripts/_envopts.py)
 import argparse
 import json
 import os

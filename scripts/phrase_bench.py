@@ -2,6 +2,7 @@
 """Config 3 (BASELINE.json): 1M synthetic docs, 3-token exact phrases on one MI355X.
 Times the fused kernel and the general bigram chain per phrase (dense float32[N] result copied to
 the host, as SearchArray.termfreqs returns it) next to the CPU oracle, and checks counts bit-exact."""
+import _envopts  # noqa: F401  (SA_* environment -> library options, scripts/_envopts.py)
 import argparse
 import json
 import os

@@ -3,6 +3,7 @@
 terms of zipf-1M, each through the one-launch route (doc-parallel slop / phrase chain per document) and through the
 general route (SA_SPAN_DOC=0 / SA_PHRASE_DOCS=0), which tests pin to the oracle -- dense counts must be identical; a few
 are checked against the CPU oracle as well."""
+import _envopts  # noqa: F401  (SA_* environment -> library options, scripts/_envopts.py)
 import argparse
 import json
 import os

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """The bench's slop_batch / phrase_batch legs alone (zipf-1M, 32 two-token slop-2 phrases of ranks 50-5000; 256 sampled
 trigrams), for rocprofv3 --kernel-trace --stats."""
+import _envopts  # noqa: F401  (SA_* environment -> library options, scripts/_envopts.py)
 import json
 import os
 import sys

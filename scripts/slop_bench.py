@@ -3,6 +3,7 @@
 3-token phrases with slop=2 on one MI355X.  Times SearchArray.termfreqs-style dense results
 (float32[N] copied to the host) and the device-only part, next to the CPU oracle (the C restatement
 of the reference's span search), and checks the counts bit-exact."""
+import _envopts  # noqa: F401  (SA_* environment -> library options, scripts/_envopts.py)
 import argparse
 import json
 import os

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Device time of single slop-2 phrases through the doc-parallel route (SA_SPAN_DOC=2: whenever the phrase qualifies) and
 the general route (SA_SPAN_DOC=0), zipf-1M: where the list-length rule of sa_span_counts_device should sit."""
+import _envopts  # noqa: F401  (SA_* environment -> library options, scripts/_envopts.py)
 import json
 import os
 import sys

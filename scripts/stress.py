@@ -2,6 +2,7 @@
 """GPU stress (development tool): a few-million-doc corpus, random query batches of every shape;
 dynamic pruning, the exhaustive kernel with the histogram bound, with the slot bound and with the
 block-level selection must return identical top-k lists."""
+import _envopts  # noqa: F401  (SA_* environment -> library options, scripts/_envopts.py)
 import argparse, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

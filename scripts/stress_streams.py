@@ -3,6 +3,7 @@
 (groups with a shared first term + loose groups + queries for the per-query kernel on the side stream) and a slop
 batch (two lanes) are run many times back to back, asynchronously and interleaved, and every fetch must equal the
 first one (which tests/test_config_scale.py checks against the oracle)."""
+import _envopts  # noqa: F401  (SA_* environment -> library options, scripts/_envopts.py)
 import os
 import sys
 

@@ -2,6 +2,7 @@
 """GPU tuning sweep (development tool): one corpus, several tile sizes / kernel modes.
 
 Prints one JSON line per configuration: queries/s, scoring-kernel ms, algorithmic GB/s."""
+import _envopts  # noqa: F401  (SA_* environment -> library options, scripts/_envopts.py)
 import argparse
 import json
 import os

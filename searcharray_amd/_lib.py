@@ -43,6 +43,18 @@ class DenseDest(ctypes.Structure):
 
 PROTOTYPES = {
     "sa_last_error": (c_char_p, []),
+    # Part 0: options (sa_options_t is passed by address: searcharray_amd/options.py builds it from sa_option_name)
+    "sa_options_init": (None, [c_void_p]),
+    "sa_options_set": (c_int, [c_void_p, c_char_p, c_int64]),
+    "sa_options_get": (c_int, [c_void_p, c_char_p, i64p]),
+    "sa_option_count": (c_int, []),
+    "sa_option_name": (c_char_p, [c_int]),
+    "sa_options_process_defaults_get": (c_int, [c_void_p]),
+    "sa_options_set_thread_defaults": (c_int, [c_void_p]),
+    "sa_index_set_options": (c_int, [c_void_p, c_void_p]),
+    "sa_index_get_options": (c_int, [c_void_p, c_void_p]),
+    "sa_batch_set_options": (c_int, [c_void_p, c_void_p]),
+    "sa_batch_get_options": (c_int, [c_void_p, c_void_p]),
     "sa_abi_version": (c_int, []),
     "sa_device_count": (c_int, [POINTER(c_int)]),
     "sa_device_name": (c_int, [c_int, ctypes.c_char_p, c_int]),

@@ -14,6 +14,7 @@
 #define SA_SP_CHUNK 1024
 
 struct sa_batch {
+    sa_options_t opts;              // the batch's switches: the creating thread's defaults, else its index's; sa_batch_set_options
     sa_index* ix = nullptr;
     hipStream_t st = nullptr;       // the stream this batch's work is enqueued on: its own (BM25 batches), or the index stream
     bool own_stream = false;
@@ -107,15 +108,9 @@ struct sa_batch {
     u32 n_shared_rows = 0;
     u32* d_grp = nullptr;           // [n_groups][2] first row, rows (bit 31: a loose group)
     u64* d_wl = nullptr;            // (tile, row) items the grouped kernel leaves to the per-query kernel
-    u32* d_wl_cnt = nullptr;        // [2]: work-list cursor, rescoring-list cursor
-    u64* d_fxc = nullptr;           // rescoring list of sa_k_bm25_group_fx (sa_bm25_group.hpp)
-    u32 fxc_cap = 0;
+    u32* d_wl_cnt = nullptr;
     u32* d_iota = nullptr;          // [B] 0 .. B-1 (query lists of the per-query kernel: rows [a, b) = d_iota + a)
     u32 n_groups = 0, n_grouped_rows = 0, grp_tt = 1, grp_tt_shift = 0;
-    bool fx_on = false;             // the groups are scored by sa_k_bm25_group_fx (integer image of the scores, sa_bm25_group.hpp)
-    float fx_scale = 1.f;           // its unit 2^F and the slack of its filter (sa_batch_fill)
-    u32 fx_slack = 0, fx_slack_lo = 0;
-    u32* d_qdes = nullptr;          // [B] (upload block) the term position whose postings count docs for the query's bound
     // phrase batches (sa_phrase_batch.hip): kind == 1
     int kind = 0;                   // 0: disjunctive BM25 over terms, 1: exact phrases
     u32 ptile = 0, pn_tiles = 0;    // docs per phrase tile and their number

@@ -151,16 +151,10 @@ sa_k_make_impacts(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, c
 }
 
 // The impact stream of (k1, b) for this index: the cached one, or a new one (the cache keeps the most
-// recent; batches built earlier keep theirs alive).  Null when switched off (SA_IMPACT=0), for an empty
+// recent; batches built earlier keep theirs alive).  Null when switched off (option impact = 0), for an empty
 // shard, or when HBM is short -- the tile kernel then scores the TF postings.  Call with the index lock held.
-static int sa_env_int_early(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
-static std::shared_ptr<sa_impacts> sa_impacts_get(sa_index* ix, float k1, float b) {
-    const char* env = getenv("SA_IMPACT");
-    if (env && atoi(env) == 0) return nullptr;
+static std::shared_ptr<sa_impacts> sa_impacts_get(sa_index* ix, float k1, float b, const sa_options_t& o) {
+    if (sa_opt(o.impact, 1) == 0) return nullptr;
     if (ix->n_postings == 0 || ix->n_terms == 0 || ix->avg_doc_len == 0.f) return nullptr;
     // (bit patterns: a NaN parameter must still find its own stream)
     auto same = [](float x, float y) { return memcmp(&x, &y, sizeof(float)) == 0; };
@@ -186,10 +180,10 @@ static std::shared_ptr<sa_impacts> sa_impacts_get(sa_index* ix, float k1, float 
     // kernel's empty half entries point at: their lanes add 0 to their spare slots instead of a NaN
     static const u64 tail[2] = {0xFFFFFFFF00000000ull, 0xFFFFFFFF00000000ull};
     if (hipMemcpyAsync(im->d_imp + im->n - 2, tail, sizeof(tail), hipMemcpyHostToDevice, st) != hipSuccess) return nullptr;
-    // dense factor rows of the terms with df >= n_docs / SA_DENSE_DIV (default 4; 0: none), at most 16, most frequent first
+    // dense factor rows of the terms with df >= n_docs / dense_div (index option; default 4; 0: none), at most 16, most frequent first
     im->dense_slot.assign(ix->n_terms, 0xFFFFFFFFu);
     {
-        const int div = sa_env_int_early("SA_DENSE_DIV", 4);
+        const int div = (int)sa_opt(ix->opts.dense_div, 4);
         std::vector<std::pair<u64, u32>> cand;
         if (div > 0 && ix->n_tiles > 0)
             for (u32 t = 0; t < ix->n_terms; t++) {
@@ -265,7 +259,7 @@ sa_k_make_bounds(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, co
                  const u32* __restrict__ tile_dir, u32 n_terms, u32 n_tiles, u32 tile_docs,
                  const u32* __restrict__ terms, u32 BT, u32* __restrict__ bounds, u64* __restrict__ qbase,
                  u64* __restrict__ qbase_imp, const float* __restrict__ topf, const float* __restrict__ idf, u32 T, u32 rank_idx,
-                 u32* __restrict__ seed) {
+                 u32* __restrict__ seed, float seed_scale) {
     const u64 total = (u64)BT * (n_tiles + 1);
     for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (u64)gridDim.x * blockDim.x) {
         const u32 qt = (u32)(e / (n_tiles + 1)), tile = (u32)(e % (n_tiles + 1));
@@ -288,7 +282,8 @@ sa_k_make_bounds(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, co
             // the query's starting bound: the best of  weight x (k-th largest factor of the term, or of a rank beyond k)
             // over its terms (sa_impacts::d_topf; seed[] arrives zeroed with the upload)
             if (seed && term < n_terms) {
-                const float s = __fmul_rn(topf[(u64)term * SA_TOPF_NR + rank_idx], idf[qt]);
+                // (seed_scale: 1.0 -- x * 1.0 = x bit for bit -- except under the test hook that forces bounds which are too high)
+                const float s = __fmul_rn(__fmul_rn(topf[(u64)term * SA_TOPF_NR + rank_idx], idf[qt]), seed_scale);
                 if (s > 0.f) atomicMax(&seed[qt / T], __float_as_uint(s));
             }
         }
@@ -874,18 +869,10 @@ struct GroupParams {
     u64 dense_stride;
     u32 n_groups;
     u32 tile0, n_tiles_run; // tiles [tile0, tile0 + n_tiles_run)
-    u32 n_items_run;        // sa_k_bm25_group_fx: items of ST index tiles each that cover them
     u32 tpx;                // tiles per XCD: XCD x takes the RANGE [x * tpx, (x + 1) * tpx) of the run's tiles (0: tiles t = x mod 8)
     u32 tt, tt_shift;       // lanes per query while the step tables are built: power of two >= max(T - 1, 1)
     u64* wl;                // work list of (tile << 32 | device row) items left to the per-query kernel
     u32* wl_cnt;
-    float fx_scale;         // sa_k_bm25_group_fx: 2^F, the unit of the integer image of the scores
-    u32 fx_slack;           // ... and what the integer sum of a doc may lack against its exact fp32 score, in units
-    const u32* qdes;        // ... [B] per device row: the term position whose postings COUNT docs for the query's bound (sa_batch_fill)
-    u32 fx_slack_lo;        // ... what the exact fp32 score of a doc may lack against its integer sum, in units
-    u64* fxc;               // ... its list of postings that passed the filter (sa_k_bm25_fx_rescore scores their docs exactly)
-    u32* fxc_cnt;
-    u32 fxc_cap;
 };
 
 // One HALF = up to 64 postings of ONE term of one query in this tile, one per lane (8-byte loads): every LDS
@@ -1302,8 +1289,6 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles_wl(const Bm25Params p
     }
 }
 
-#include "sa_bm25_group.hpp"
-
 // Merge n_cand candidate keys per query into the k best, sorted descending.
 // One workgroup of 1024 threads per query.
 //
@@ -1323,30 +1308,9 @@ __global__ void __launch_bounds__(256)
 sa_k_run_reset(u32* __restrict__ slots, u64 words, u64* __restrict__ bloom, u64 n8, u32* __restrict__ one_more) {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t <= (u64)SA_FXC_LISTS && one_more) one_more[t * SA_FXC_CNT_STRIDE] = 0u;     // (work-list and rescoring-list cursors)
+    if (t == 0 && one_more) *one_more = 0u;
     for (u64 i = t; i < words; i += stride) slots[i] = 0u;
     for (u64 i = t; i < n8; i += stride) bloom[i] = 0ull;
-}
-
-// OPTIMISTIC bounds for big k (grouped exhaustive path).  The warm-up tiles are a sample of the shard: a fraction f of its
-// docs.  The bound they establish -- the k-th best score of the sample -- is safe but far below the k-th best of the shard
-// (k = 1000, f = 1/150: the sample's 1000th best is the shard's ~150 000th), so the grouped kernel that follows reports
-// thousands of survivors per query before the bound has risen.  Of the shard's top k, the sample holds about k f (Poisson):
-// its j-th best, j = k f + 4.5 sqrt(k f) + 5, lies BELOW the shard's k-th best unless the sample holds j or more of the top
-// k -- a 1e-6 event.  This kernel raises every query's bound to that score (lower edge of its histogram bin).  "Unless" is
-// checked, not assumed: the merge finds fewer than k keys at or above a bound that was too high (sa_k_topk_merge sets the
-// run's redo flag to 2) and sa_batch_fetch redoes the batch without bounds, as for an overflowing candidate list -- and
-// switches the seeding off for this index (doc ids that correlate with scores break the sampling assumption every time).
-__global__ void __launch_bounds__(256)
-sa_k_seed_bounds(const u32* __restrict__ hist, u32* __restrict__ gthr, u32 n_rows, u32 j) {
-    const u32 lane = threadIdx.x & 63u;
-    const u32 q = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (q >= n_rows) return;                                    // (wave-uniform)
-    u32 tot[SA_HBINS / SA_WAVE];
-#pragma unroll
-    for (int i = 0; i < SA_HBINS / SA_WAVE; i++) tot[i] = hist[(u64)q * SA_HBINS + lane * (SA_HBINS / SA_WAVE) + i];
-    const u32 g = sa_hist_bound(tot, j, lane);
-    if (lane == 0 && g) atomicMax(&gthr[q], g);
 }
 
 // (THREADS: 1024, or 256 for small k -- a workgroup of 16 waves needs 16 free wave slots and 17 KiB of LDS on ONE CU at once, which a
@@ -1357,7 +1321,7 @@ sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__
                 const u32* __restrict__ out_row, u32 rank_stride, const u32* __restrict__ cnt,
                 const u32* __restrict__ slots, const u32* __restrict__ gthr, u32* __restrict__ overflow,
                 u32* __restrict__ clr_state, u32 clr_B, u32 clr_hist, u32* __restrict__ clr_one,
-                u32 gather_stride, u32* __restrict__ xflag) {
+                u32 gather_stride, u32* __restrict__ xflag, const u32* __restrict__ seed) {
     constexpr int NW = THREADS / SA_WAVE;
     __shared__ u64 red64[NW + 1];
     __shared__ u64 sel[SA_MERGE_LIST];
@@ -1494,9 +1458,10 @@ sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__
         __syncthreads();
         n_sel = s_n;
     }
-    // fewer than k keys at or above a bound: with bounds derived from k counted docs that cannot happen -- the bound was an
-    // optimistic one (sa_k_seed_bounds) and too high
-    if (gthr && overflow && n_sel < k && tid == 0 && gthr[q] != 0u) atomicMax(overflow, 2u);
+    // Fewer than k keys at or above a bound: with bounds derived from k counted docs, or from a term's k-th largest factor,
+    // that cannot happen -- a safety net under the starting bounds (a rank table out of step with the impact stream, a
+    // scoring path whose rounding broke the monotonicity argument): the run is flagged and redone without bounds.
+    if (gthr && overflow && n_sel < k && tid == 0 && (gthr[q] != 0u || (seed && seed[q] != 0u))) atomicMax(overflow, 2u);
     n_sel = n_sel < SA_MERGE_LIST ? n_sel : SA_MERGE_LIST;
     if (n_sel <= SA_WAVE) {                           // uniform
         // short list: one wave sorts it in registers (bitonic over lanes, no barriers)
@@ -1530,13 +1495,13 @@ sa_k_topk_merge(u64* __restrict__ cand, u32 n_cand_max, u32 k, u64* __restrict__
         if (tid == 32u) clr_state[(u64)clr_B * 32u + q] = 0u;
         if (tid == 33u) clr_state[(u64)clr_B * 33u + q] = 0u;
         if (clr_hist) for (u32 i = tid; i < (u32)SA_HBINS; i += THREADS) clr_state[(u64)clr_B * 34u + (u64)q * SA_HBINS + i] = 0u;
-        if (clr_one && q == 0u && tid >= 34u && tid < 35u + (u32)SA_FXC_LISTS) clr_one[(tid - 34u) * SA_FXC_CNT_STRIDE] = 0u;    // (work-list and rescoring-list cursors)
+        if (clr_one && q == 0u && tid == 34u) *clr_one = 0u;
     }
 }
 
 #define SA_MERGE_LAUNCH(K_, B_, ST_, ...)                                                                                  \
     do {                                                                                                               \
-        if ((K_) <= 64u && sa_env_int("SA_MERGE_SMALL", 1) != 0)                                                          \
+        if ((K_) <= 64u && sa_opt(bt->opts.merge_small, 1) != 0)                                                          \
             hipLaunchKernelGGL(sa_k_topk_merge<256>, dim3(B_), dim3(256), 0, ST_, __VA_ARGS__);                          \
         else                                                                                                           \
             hipLaunchKernelGGL(sa_k_topk_merge<1024>, dim3(B_), dim3(1024), 0, ST_, __VA_ARGS__);                        \
@@ -1578,7 +1543,7 @@ static int sa_launch_make_sattab(sa_index* ix, float* d_tab, u32* tab_w_out, flo
 
 static int sa_launch_make_bounds(sa_index* ix, const u32* d_terms, u32 BT, u32* d_bounds, u64* d_qbase, hipStream_t st,
                                  u64* d_qbase_imp = nullptr, const float* d_topf = nullptr, const float* d_idf = nullptr, u32 T = 1,
-                                 u32 k = 1, u32* d_seed = nullptr) {
+                                 u32 k = 1, u32* d_seed = nullptr, float seed_scale = 1.f) {
     const u64 total = (u64)BT * (ix->n_tiles + 1);
     if (total == 0) return SA_OK;
     const u32 grid = total / 256 + 1 < 8192 ? (u32)(total / 256 + 1) : 8192;
@@ -1586,13 +1551,8 @@ static int sa_launch_make_bounds(sa_index* ix, const u32* d_terms, u32 BT, u32* 
     for (int i = SA_TOPF_NR - 1; i >= 0; i--) if (sa_topf_ranks[i] >= k) rank_idx = (u32)i;
     hipLaunchKernelGGL(sa_k_make_bounds, dim3(grid), dim3(256), 0, st, ix->d_tfp, ix->d_tf_off, ix->d_dir_slot,
                        ix->d_tile_dir, ix->n_terms, ix->n_tiles, ix->tile_docs, d_terms, BT, d_bounds, d_qbase, d_qbase_imp,
-                       d_topf, d_idf, T, rank_idx, (d_topf && d_idf) ? d_seed : (u32*)nullptr);
+                       d_topf, d_idf, T, rank_idx, (d_topf && d_idf) ? d_seed : (u32*)nullptr, seed_scale);
     return SA_OK;
-}
-
-static int sa_env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
 }
 
 #define SA_LAUNCH_TILE(TILE, THREADS)                                                              \
@@ -1648,18 +1608,15 @@ static int sa_launch_bm25_list(sa_index* ix, const Bm25Params& p, hipStream_t st
     return SA_OK;
 }
 
-static int sa_launch_bm25_groups(sa_index* ix, const sa_batch* bt, const Bm25Params& p, u32 tile0, hipStream_t st, u32* overflow_cell) {
+static int sa_launch_bm25_groups(sa_index* ix, const sa_batch* bt, const Bm25Params& p, u32 tile0, hipStream_t st) {
     GroupParams gp;
     gp.grp = bt->d_grp; gp.n_groups = bt->n_groups;
     gp.tile0 = tile0; gp.n_tiles_run = ix->n_tiles - tile0;
     gp.tt = bt->grp_tt; gp.tt_shift = bt->grp_tt_shift;
-    gp.dense = (bt->impacts && sa_env_int("SA_GROUP_DENSE", 1) != 0) ? bt->impacts->d_dense : nullptr;
+    gp.dense = (bt->impacts && sa_opt(bt->opts.group_dense, 1) != 0) ? bt->impacts->d_dense : nullptr;
     gp.dense_stride = bt->impacts ? bt->impacts->dense_stride : 0;
-    const bool fx = bt->fx_on && bt->d_fxc;
-    const u32 st_items = fx ? (u32)std::max(1, std::min(2, sa_env_int("SA_GROUP_ST", 1))) : 1u;     // index tiles per item
-    gp.n_items_run = (gp.n_tiles_run + st_items - 1u) / st_items;
-    const u64 blocks = (u64)((gp.n_items_run + 7u) / 8u) * 8u * gp.n_groups;
-    gp.tpx = sa_env_int("SA_XCD_RANGE", 1) != 0 ? (gp.n_items_run + 7u) / 8u : 0u;
+    const u64 blocks = (u64)((gp.n_tiles_run + 7u) / 8u) * 8u * gp.n_groups;
+    gp.tpx = sa_opt(bt->opts.xcd_range, 1) != 0 ? (gp.n_tiles_run + 7u) / 8u : 0u;
     if (blocks > 0x7FFFFFFFull) { sa_set_error("grouped launch: bad grid"); return SA_ERR_STATE; }
     gp.wl = bt->d_wl; gp.wl_cnt = bt->d_wl_cnt;
     const u64 worst = (u64)gp.n_tiles_run * bt->n_grouped_rows;
@@ -1667,21 +1624,10 @@ static int sa_launch_bm25_groups(sa_index* ix, const sa_batch* bt, const Bm25Par
     if (wgrid == 0) return SA_OK;
     // (weight table: n * tt cells; 64 cover up to 4 overlaid terms per query at 16 queries per item)
     const bool small = (u32)SA_GRP_MAXQ * gp.tt <= 64u;
-    gp.fx_scale = bt->fx_scale; gp.fx_slack = bt->fx_slack;
-    gp.qdes = bt->d_qdes; gp.fx_slack_lo = bt->fx_slack_lo;
-    gp.fxc = bt->d_fxc; gp.fxc_cnt = bt->d_wl_cnt + SA_FXC_CNT_STRIDE; gp.fxc_cap = bt->fxc_cap / (u32)SA_FXC_LISTS;
-    u32 tile_shift = 0;
-    while ((1u << tile_shift) < ix->tile_docs) tile_shift++;
 #define SA_LAUNCH_GROUP(TILE, THREADS)                                                                                     \
     {                                                                                                                      \
-        if (blocks && fx && small && st_items == 2) hipLaunchKernelGGL((sa_k_bm25_group_fx<TILE, 64, 2>), dim3((u32)blocks), dim3(64 * SA_GFX_NW), 0, st, p, gp); \
-        else if (blocks && fx && small) hipLaunchKernelGGL((sa_k_bm25_group_fx<TILE, 64, 1>), dim3((u32)blocks), dim3(64 * SA_GFX_NW), 0, st, p, gp); \
-        else if (blocks && fx && st_items == 2) hipLaunchKernelGGL((sa_k_bm25_group_fx<TILE, 128, 2>), dim3((u32)blocks), dim3(64 * SA_GFX_NW), 0, st, p, gp); \
-        else if (blocks && fx) hipLaunchKernelGGL((sa_k_bm25_group_fx<TILE, 128, 1>), dim3((u32)blocks), dim3(64 * SA_GFX_NW), 0, st, p, gp);   \
-        else if (blocks && small) hipLaunchKernelGGL((sa_k_bm25_group_tiles<TILE, 64>), dim3((u32)blocks), dim3(64), 0, st, p, gp);  \
+        if (blocks && small) hipLaunchKernelGGL((sa_k_bm25_group_tiles<TILE, 64>), dim3((u32)blocks), dim3(64), 0, st, p, gp);       \
         else if (blocks) hipLaunchKernelGGL((sa_k_bm25_group_tiles<TILE, 128>), dim3((u32)blocks), dim3(64), 0, st, p, gp);            \
-        if (blocks && fx) hipLaunchKernelGGL(sa_k_bm25_fx_rescore, dim3(8 * SA_FXC_LISTS), dim3(256), 0, st, p, (const u64*)gp.fxc, \
-                                             (const u32*)gp.fxc_cnt, gp.fxc_cap, tile_shift, overflow_cell);                        \
         hipLaunchKernelGGL((sa_k_bm25_tiles_wl<TILE, THREADS>), dim3(wgrid), dim3(THREADS), 0, st, p, (const u64*)gp.wl,   \
                            (const u32*)gp.wl_cnt);                                                                         \
     }                                                                                                                      \
@@ -1795,7 +1741,6 @@ void sa_batch_free(sa_batch* bt) {
     if (bt->d_stats) hipFree(bt->d_stats);
     if (bt->d_wl) hipFree(bt->d_wl);
     if (bt->d_wl_cnt) hipFree(bt->d_wl_cnt);
-    if (bt->d_fxc) hipFree(bt->d_fxc);
     if (bt->d_iota) hipFree(bt->d_iota);
     if (bt->d_route) hipFree(bt->d_route);
     if (bt->d_emask) hipFree(bt->d_emask);
@@ -1852,8 +1797,8 @@ int sa_batch_alloc_topk(sa_batch* bt, u32 n_tiles, u32 waves) {
     if (cap < mode0) cap = mode0;                      // the unpruned layout [n_tiles][k] must fit too
     // the sparse candidate path appends every doc of a lead term that is scored before the bound exists
     if (bt->kind == 0 && cap < (1ull << 17)) cap = 1ull << 17;
-    if (const char* v = getenv("SA_CAND_CAP")) {       // tests: force the overflow handling
-        const u64 forced = (u64)atoll(v);
+    if (sa_opt_is_set(bt->opts.cand_cap)) {            // tests: force the overflow handling
+        const u64 forced = (u64)bt->opts.cand_cap;
         cap = forced > mode0 ? forced : mode0;
     }
     bt->cand_cap = (u32)cap;
@@ -1900,9 +1845,9 @@ static int sa_batch_alloc_bm25(sa_batch* bt) {
     const size_t B = bt->B, T = bt->T;
     // A BM25 batch has a stream of its own: batches of one index share nothing but the (read-only) index, so two
     // batches used alternately by a query stream overlap -- the tail of one batch's scoring kernels (the last, partly
-    // filled round of workgroups) and its merge run beside the head of the next.  SA_BATCH_STREAM=0: the index stream.
+    // filled round of workgroups) and its merge run beside the head of the next.  Option batch_stream = 0: the index stream.
     bt->st = ix->stream;
-    if (sa_env_int("SA_BATCH_STREAM", 1) != 0) {
+    if (sa_opt(bt->opts.batch_stream, 1) != 0) {
         SA_HIP(hipStreamCreateWithFlags(&bt->st, hipStreamNonBlocking));
         bt->own_stream = true;
     }
@@ -1912,7 +1857,7 @@ static int sa_batch_alloc_bm25(sa_batch* bt) {
     const size_t o_p1 = take((B + 1) * 8), o_boff = take(B * 8), o_terms = take(B * T * 4), o_idf = take(B * T * 4),
                  o_perm = take(B * 4), o_grp = take(3 * B * 4), o_ub = take(B * (T + 1) * 4), o_ord = take(B * T * 4),
                  o_lead = take(B * 4), o_qdf = take(B * T * 4), o_row8 = take(B * T * 4), o_bsh = take(B * 4),
-                 o_seed = take(B * 4), o_qdes = take(B * 4);
+                 o_seed = take(B * 4);
     SA_TRY(sa_batch_alloc_upload(bt, off));
     char* u = bt->d_up;
     bt->d_p1_off = (u64*)(u + o_p1); bt->d_bloom_off = (u64*)(u + o_boff);
@@ -1921,7 +1866,6 @@ static int sa_batch_alloc_bm25(sa_batch* bt) {
     bt->d_lead = (u32*)(u + o_lead); bt->d_qdf = (u32*)(u + o_qdf); bt->d_qrow8 = (u32*)(u + o_row8);
     bt->d_bloom_shift = (u32*)(u + o_bsh);
     bt->d_seed = (u32*)(u + o_seed);
-    bt->d_qdes = (u32*)(u + o_qdes);
     {
         std::vector<u32> iota(B);
         for (u32 i = 0; i < B; i++) iota[i] = i;
@@ -1931,13 +1875,8 @@ static int sa_batch_alloc_bm25(sa_batch* bt) {
     // work list of the grouped kernel: at most one entry per (tile, row)
     bt->wl_cap = (u32)std::max<size_t>(1, (size_t)ix->n_tiles * B);
     SA_HIP(hipMalloc(&bt->d_wl, (size_t)bt->wl_cap * sizeof(u64)));
-    // cursors: [0] work list, [(1 + i) * SA_FXC_CNT_STRIDE] sub-list i of the rescoring list (all zeroed by the merge)
-    SA_HIP(hipMalloc(&bt->d_wl_cnt, (size_t)(1 + SA_FXC_LISTS) * SA_FXC_CNT_STRIDE * sizeof(u32)));
-    SA_HIP(hipMemset(bt->d_wl_cnt, 0, (size_t)(1 + SA_FXC_LISTS) * SA_FXC_CNT_STRIDE * sizeof(u32)));
-    // rescoring list of sa_k_bm25_group_fx: postings that passed the integer filter (a few per query once the bounds stand;
-    // thousands per query for k = 1000).  A list that runs over is detected on the device and the batch redone.
-    bt->fxc_cap = (u32)std::min<u64>(1ull << 24, std::max<u64>(1ull << 20, (u64)B * 8192ull));
-    SA_HIP(hipMalloc(&bt->d_fxc, (size_t)bt->fxc_cap * sizeof(u64)));
+    SA_HIP(hipMalloc(&bt->d_wl_cnt, sizeof(u32)));
+    SA_HIP(hipMemset(bt->d_wl_cnt, 0, sizeof(u32)));
     SA_TRY(sa_batch_alloc_topk(bt, ix->n_tiles, sa_tile_waves(ix->tile_docs)));
     SA_HIP(hipMalloc(&bt->d_bounds, (B * T * (ix->n_tiles + 1) + 1) * sizeof(u32)));
     SA_HIP(hipMalloc(&bt->d_qbase, B * T * sizeof(u64)));
@@ -1958,7 +1897,7 @@ static int sa_batch_alloc_bm25(sa_batch* bt) {
     SA_TRY(sa_launch_make_sattab(ix, bt->d_sattab, &bt->tab_w, bt->k1, bt->b, bt->st));
     // the impact stream of this (k1, b): shared through the index, built on first use (on the index stream: done
     // before this batch's stream goes on)
-    bt->impacts = sa_impacts_get(ix, bt->k1, bt->b);
+    bt->impacts = sa_impacts_get(ix, bt->k1, bt->b, bt->opts);
     SA_HIP(hipStreamSynchronize(ix->stream));
     if (bt->impacts) SA_HIP(hipMalloc(&bt->d_qbase_imp, B * T * 2 * sizeof(u64)));
     return SA_OK;
@@ -1987,7 +1926,7 @@ int sa_batch_ensure_bloom(sa_batch* bt) {
         bt->d_bloom = nullptr; bt->bloom_cap = 0;
     }
     size_t cap = need + need / 2;
-    const size_t floor_bytes = (size_t)std::max(1024, sa_env_int("SA_BLOOM_FLOOR", 1 << 20));      // (tests: small, so that the buffer has to grow)
+    const size_t floor_bytes = (size_t)std::max<long long>(1024, sa_opt(bt->opts.bloom_floor, 1 << 20));      // (tests: small, so that the buffer has to grow)
     if (cap < floor_bytes) cap = floor_bytes;
     SA_HIP(hipMalloc(&bt->d_bloom, cap));
     bt->bloom_cap = cap;
@@ -2019,7 +1958,8 @@ static void sa_batch_fill_prune_tables(sa_batch* bt, char* img) {
         // pruning off) -- and the LEAD term: the highest-idf term with postings in this shard.
         const bool formula_ok = k1 >= 0.f && b >= 0.f && b <= 1.f;
         const u64 limit1 = sa_batch_lead_limit(bt);
-        bt->sparse_limit2 = ix->n_docs / (u64)sa_env_int("SA_SPARSE_DIV", 8) > 4096 ? ix->n_docs / (u64)sa_env_int("SA_SPARSE_DIV", 8) : 4096;
+        const u64 sp_div = (u64)std::max<long long>(1, sa_opt(bt->opts.sparse_div, 8));
+        bt->sparse_limit2 = ix->n_docs / sp_div > 4096 ? ix->n_docs / sp_div : 4096;
         std::pair<float, u32> v[SA_MAX_QTERMS];
         h_p1[0] = 0;
         for (u32 r = 0; r < B; r++) {
@@ -2063,7 +2003,7 @@ static void sa_batch_fill_prune_tables(sa_batch* bt, char* img) {
             u64 lead_postings = 0;
             for (u32 r = 0; r < B; r++) lead_postings += h_p1[r + 1];
             bt->sparse_chunk1 = lead_postings >= (1ull << 19) ? SA_SP_CHUNK : SA_SP_CHUNK_LEAD;
-            if (const char* e = getenv("SA_SP_CHUNK1")) { const int c = atoi(e); if (c >= 64) bt->sparse_chunk1 = (u32)c; }
+            if (sa_opt(bt->opts.sp_chunk1, 0) >= 64) bt->sparse_chunk1 = (u32)bt->opts.sp_chunk1;
             for (u32 r = 0; r < B; r++) h_p1[r + 1] = (h_p1[r + 1] + bt->sparse_chunk1 - 1) / bt->sparse_chunk1;
         }
         for (u32 r = 0; r < B; r++) h_p1[r + 1] += h_p1[r];
@@ -2099,18 +2039,10 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
     const u64 t_begin = sa_now_ns();
     SA_TRY(sa_batch_upload_begin(bt, &img));
     auto at = [&](const void* dptr) { return img + ((const char*)dptr - bt->d_up); };
-    u64* h_p1 = (u64*)at(bt->d_p1_off);
-    u64* h_boff = (u64*)at(bt->d_bloom_off);
     u32* h_terms = (u32*)at(bt->d_terms);
     float* h_idf = (float*)at(bt->d_idf);
     u32* h_perm = (u32*)at(bt->d_perm);
     u32* h_grpd = (u32*)at(bt->d_grp);
-    float* h_ub = (float*)at(bt->d_ub);
-    u32* h_ord = (u32*)at(bt->d_ub_order);
-    u32* h_lead = (u32*)at(bt->d_lead);
-    u32* h_qdf = (u32*)at(bt->d_qdf);
-    u32* h_row8 = (u32*)at(bt->d_qrow8);
-    u32* h_bshift = (u32*)at(bt->d_bloom_shift);
 
     // Order queries by their most frequent term so XCD groups share posting tiles in L2.
     bt->perm.resize(B);
@@ -2146,33 +2078,15 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
         while (tt + 1u < T) { tt <<= 1; tsh++; }               // power of two >= max(T - 1, 1)
         u32 tt_loose = 1, tsh_loose = 0;
         while (tt_loose < T) { tt_loose <<= 1; tsh_loose++; }
-        const bool loose_on = sa_env_int("SA_GROUP_LOOSE", 1) != 0 && 128u / tt_loose >= SA_GRP_MAXQ;
+        const bool loose_on = sa_opt(bt->opts.group_loose, 1) != 0 && 128u / tt_loose >= SA_GRP_MAXQ;
         u32 maxq = std::min<u32>(SA_GRP_MAXQ, 128u / tt);
-        // sa_k_bm25_group_fx (sa_bm25_group.hpp): SA_GFX_NW waves share an item, each takes up to maxq of its queries.  The unit of
-        // the integer image: 2^F with (S + 1) * 2^F < 2^16 (a wave's sums live in a 16-bit field of the accumulators; S = the largest
-        // weight sum of a query); weights too large for F >= 4 keep the fp32 overlay.
-        bool fx = sa_env_int("SA_GROUP_FX", 1) != 0;
-        {
-            double S = 0.0;
-            for (u32 i = 0; i < B; i++) {
-                double sq = 0.0;
-                for (u32 t = 0; t < T; t++) { const float w = idf[(size_t)i * T + t]; if (w > 0.f && w <= 3.0e38f) sq += (double)w; }
-                S = std::max(S, sq);
-            }
-            int F = 15;
-            while (F >= 0 && (S + 1.0) * std::ldexp(1.0, F) >= 65536.0) F--;
-            if (F < 4) fx = false;
-            bt->fx_scale = F >= 0 ? (float)std::ldexp(1.0, F) : 1.f;
-            bt->fx_slack = T + 2u + (u32)std::ceil(S * std::ldexp(1.0, F > 0 ? F : 0) * (double)T / 8388608.0);
-            bt->fx_slack_lo = 1u + (u32)std::ceil(S * std::ldexp(1.0, F > 0 ? F : 0) * (double)T / 8388608.0);
-        }
         // (a shard whose (tile, group) items do not fill the device for many rounds is better cut into more, shorter items:
         //  SA_GROUP_MAXQ; measured on a 1.25 M-doc shard below)
-        maxq = std::min<u32>(maxq, (u32)std::max(1, sa_env_int("SA_GROUP_MAXQ", (int)SA_GRP_MAXQ)));
-        const u32 gmin = (u32)std::max(1, sa_env_int("SA_GROUP_MIN", 2));
+        maxq = std::min<u32>(maxq, (u32)std::max<long long>(1, sa_opt(bt->opts.group_maxq, SA_GRP_MAXQ)));
+        const u32 gmin = (u32)std::max<long long>(1, sa_opt(bt->opts.group_min, 2));
         bool idf_ok = k1 >= 0.f && b >= 0.f && b <= 1.f;       // scores must be non-negative (the sign bit is a mark)
         for (size_t i = 0; i < (size_t)B * T && idf_ok; i++) idf_ok = idf[i] >= 0.f && idf[i] <= 3.0e38f;
-        const bool on = sa_env_int("SA_GROUP", 1) != 0 && idf_ok && maxq >= 1 &&
+        const bool on = sa_opt(bt->opts.group, 1) != 0 && idf_ok && maxq >= 1 &&
                         (ix->tile_docs == 1024 || ix->tile_docs == 2048 || ix->tile_docs == 4096);
         if (on) {
             std::vector<std::vector<u32>> members;              // in order of first appearance
@@ -2191,8 +2105,7 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
             std::vector<u32> order;
             for (auto& m : members) {
                 if (m.size() < gmin) { rest.insert(rest.end(), m.begin(), m.end()); continue; }
-                const u32 gmax = fx ? maxq * (u32)SA_GFX_NW : maxq;
-                const u32 pieces = ((u32)m.size() + gmax - 1) / gmax;
+                const u32 pieces = ((u32)m.size() + maxq - 1) / maxq;
                 u32 done = 0;
                 for (u32 pc = 0; pc < pieces; pc++) {
                     const u32 sz = ((u32)m.size() - done + (pieces - pc) - 1) / (pieces - pc);
@@ -2220,12 +2133,11 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
                         const u32 term = terms[(size_t)q * T + t];
                         if (term < ix->n_terms) dfsum += ix->h_tf_off[term + 1] - ix->h_tf_off[term];
                     }
-                    if (dfsum > 0 && dfsum / ix->n_tiles <= (u64)std::max(1, sa_env_int("SA_LOOSE_POSTINGS", SA_GRP_LOOSE_POSTINGS))) sparse_rows.push_back(q);
+                    if (dfsum > 0 && dfsum / ix->n_tiles <= (u64)std::max<long long>(1, sa_opt(bt->opts.loose_postings, SA_GRP_LOOSE_POSTINGS))) sparse_rows.push_back(q);
                     else dense_rows.push_back(q);
                 }
                 if (sparse_rows.size() >= 2) {
-                    const u32 lmax = fx ? (u32)SA_GRP_MAXQ * (u32)SA_GFX_NW : (u32)SA_GRP_MAXQ;
-                    const u32 pieces = ((u32)sparse_rows.size() + lmax - 1) / lmax;
+                    const u32 pieces = ((u32)sparse_rows.size() + SA_GRP_MAXQ - 1) / SA_GRP_MAXQ;
                     u32 done = 0;
                     for (u32 pc = 0; pc < pieces; pc++) {
                         const u32 sz = ((u32)sparse_rows.size() - done + (pieces - pc) - 1) / (pieces - pc);
@@ -2243,25 +2155,6 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
             bt->perm = order;
         }
         bt->grp_tt = tt; bt->grp_tt_shift = tsh;
-        bt->fx_on = fx && on;
-    }
-    {
-        // sa_k_bm25_group_fx counts a doc for the query's bound at ONE of its postings -- the designated term position's: the
-        // rarest overlaid term that still has 8 k postings (the best docs hold the rare terms; a term with fewer postings than
-        // k would never establish a bound), else the most frequent one
-        u32* h_qdes = (u32*)at(bt->d_qdes);
-        for (u32 r = 0; r < B; r++) {
-            const u32 q = bt->perm[r];
-            const u32 t_lo = (r < bt->n_shared_rows && T > 1u) ? 1u : 0u;
-            u32 best = t_lo; u64 best_df = 0; bool best_ok = false;
-            for (u32 t = t_lo; t < T; t++) {
-                const u32 term = terms[(size_t)q * T + t];
-                const u64 df = term < ix->n_terms ? ix->h_tf_off[term + 1] - ix->h_tf_off[term] : 0;
-                const bool ok = df >= 8ull * bt->k;
-                if ((ok && (!best_ok || df < best_df)) || (!ok && !best_ok && df > best_df)) { best = t; best_df = df; best_ok = ok; }
-            }
-            h_qdes[r] = best;
-        }
     }
     for (u32 r = 0; r < B; r++) {
         memcpy(&h_terms[(size_t)r * T], &terms[(size_t)bt->perm[r] * T], T * sizeof(u32));
@@ -2272,22 +2165,23 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
     if (!h_grp.empty()) memcpy(h_grpd, h_grp.data(), h_grp.size() * sizeof(u32));     // (at most B groups)
     {
         // the pruning tables: now, if the run may prune (the rule of sa_batch_run_shard, with what is known here); else on demand
-        const int sp_env = sa_env_int("SA_SPARSE", -1);
+        const int sp_env = (int)sa_opt(bt->opts.sparse, -1);
         const bool grouped_default = bt->n_grouped_rows * 2u >= B && bt->impacts;
         const bool maybe_sparse = sp_env >= 0 ? sp_env != 0 : !grouped_default;
-        if (maybe_sparse || sa_env_int("SA_SPARSE_LAZY", 1) == 0) sa_batch_fill_prune_tables(bt, img);
+        if (maybe_sparse || sa_opt(bt->opts.sparse_lazy, 1) == 0) sa_batch_fill_prune_tables(bt, img);
         else { bt->sparse_ok = false; bt->sparse_lazy = true; bt->bloom_bytes = 0; bt->sparse_p1_total = 0; bt->sparse_p2_max = 0; }
     }
     memset(at(bt->d_seed), 0, (size_t)B * sizeof(u32));
     {
         bool w_ok = k1 >= 0.f && b >= 0.f && b <= 1.f;
         for (size_t i = 0; i < (size_t)B * T && w_ok; i++) w_ok = idf[i] >= 0.f && idf[i] <= 3.0e38f;
-        bt->seed_on = w_ok && bt->impacts && bt->impacts->d_topf && bt->k <= 1024u && sa_env_int("SA_TERM_SEED", 1) != 0;
+        bt->seed_on = w_ok && bt->impacts && bt->impacts->d_topf && bt->k <= 1024u && sa_opt(bt->opts.term_seed, 1) != 0;
     }
     const u64 t_host = sa_now_ns();
     SA_TRY(sa_batch_upload_commit(bt));
     SA_TRY(sa_launch_make_bounds(ix, bt->d_terms, B * T, bt->d_bounds, bt->d_qbase, bt->st, bt->d_qbase_imp,
-                                 bt->seed_on ? bt->impacts->d_topf : nullptr, bt->d_idf, T, bt->k, bt->d_seed));
+                                 bt->seed_on ? bt->impacts->d_topf : nullptr, bt->d_idf, T, bt->k, bt->d_seed,
+                                 (float)sa_opt(bt->opts.seed_scale_pct, 100) / 100.f));
     SA_HIP(hipGetLastError());
     const u64 t_end = sa_now_ns();
     bt->host_ns[0] += t_host - t_begin; bt->host_ns[1] += t_end - t_host; bt->host_ns[3]++;
@@ -2305,6 +2199,7 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
     SA_HIP(hipSetDevice(ix->device));
     sa_batch* bt = new (std::nothrow) sa_batch();
     if (!bt) { sa_set_error("out of host memory"); return SA_ERR_NOMEM; }
+    bt->opts = sa_options_for_new_handle(&ix->opts);
     bt->ix = ix; bt->B = (u32)n_queries; bt->T = (u32)n_query_terms; bt->k = (u32)k; bt->k1 = k1; bt->b = b;
     int rc = sa_batch_alloc_bm25(bt);
     if (rc == SA_OK) rc = sa_batch_fill(bt, terms, idf);
@@ -2323,6 +2218,8 @@ extern "C" int sa_batch_create(sa_index_t* ix, const uint32_t* terms, const floa
 // waited for.  The caller idiom it serves is the reference's score() on a fresh query (postings.py:652-680; timed
 // as test/test_msmarco.py:345-395 times it): two batches used alternately keep the device busy while the host
 // prepares the next query set.
+static int sa_batch_redo_if_flagged(sa_batch* bt);
+
 extern "C" int sa_batch_reset(sa_batch_t* bt, const uint32_t* terms, const float* idf) {
     SA_ARG(bt && bt->ix && terms && idf, "null argument");
     SA_ARG(bt->kind == 0, "sa_batch_reset takes a BM25 batch (phrase batches: sa_phrase_batch_reset)");
@@ -2331,13 +2228,19 @@ extern "C" int sa_batch_reset(sa_batch_t* bt, const uint32_t* terms, const float
     SA_HIP(hipSetDevice(ix->device));
     // a run whose results have not been fetched: its merge (on the exchange stream when sharded) still reads the row order this
     // reset replaces -- wait for that run's result copy first (landed long ago in the run / fetch / reset idiom: no cost there)
-    if (bt->res_pending && bt->unfetched) SA_HIP(hipEventSynchronize(bt->ev_res));
+    if (bt->res_pending && bt->unfetched) {
+        SA_HIP(hipEventSynchronize(bt->ev_res));
+        SA_TRY(sa_batch_redo_if_flagged(bt));                   // (a flagged run is redone while the tables still hold ITS query set)
+    }
     return sa_batch_fill(bt, terms, idf);
 }
 
 extern "C" int sa_index_set_idf_table(sa_index_t* ix, const float* idf_per_term, uint32_t n_terms) {
     SA_ARG(ix && (idf_per_term || n_terms == 0), "null argument");
     SA_ARG(n_terms == ix->n_terms, "one idf per term of the index");
+    // (weights that are negative or not finite keep their batches off the grouped kernel, the starting bounds and the pruning --
+    //  every step, silently: the table is checked once, here)
+    for (uint32_t t = 0; t < n_terms; t++) SA_ARG(idf_per_term[t] >= 0.f && idf_per_term[t] <= 3.0e38f, "idf table: weights must be finite and >= 0");
     std::lock_guard<std::mutex> g(ix->mu);
     ix->h_idf.assign(idf_per_term, idf_per_term + n_terms);
     return SA_OK;
@@ -2375,14 +2278,14 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     p.terms = bt->d_terms; p.idf = bt->d_idf; p.B = bt->B; p.T = bt->T; p.k = bt->k;
     p.k1 = bt->k1; p.b = bt->b;
     p.bounds = bt->d_bounds; p.qbase = bt->d_qbase;
-    if (bt->impacts && bt->kind == 0 && sa_env_int("SA_IMPACT", 1) != 0) {
+    if (bt->impacts && bt->kind == 0 && sa_opt(bt->opts.impact, 1) != 0) {
         p.imp = bt->impacts->d_imp; p.qbase_imp = bt->d_qbase_imp;
         p.imp_tail = bt->impacts->n - 2;
     }
     p.sattab = bt->d_sattab; p.tab_w = bt->tab_w;
-    p.pruned = (sa_env_int("SA_PRUNED_TOPK", 1) && !force_unpruned) ? 1 : 0;   // pruned wave-level selection (any k <= 1024)
+    p.pruned = (sa_opt(bt->opts.pruned_topk, 1) && !force_unpruned) ? 1 : 0;   // pruned wave-level selection (any k <= 1024)
     p.dense_out = nullptr; p.cand = bt->d_cand;
-    p.no_topk = sa_env_int("SA_NO_TOPK", 0);
+    p.no_topk = (int)sa_opt(bt->opts.no_topk, 0);
     p.cand_per_tile = bt->k;
     p.cand_cap = bt->cand_cap;
     p.cand_cnt = bt->d_cand_cnt;
@@ -2392,17 +2295,17 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     // dynamic pruning (sa_sparse.hip; SA_SPARSE=0: score every posting, the exhaustive reference
     // behaviour): needs the histogram bound for every k
     const bool hist_possible = p.pruned && bt->kind == 0 && sa_tile_waves(ix->tile_docs) <= 8 &&
-                               sa_env_int("SA_TOPK_HIST", 1) != 0;
+                               sa_opt(bt->opts.topk_hist, 1) != 0;
     // Unset, SA_SPARSE follows the measurements: pruning pays while the shard holds many docs per requested
     // result (10 M docs: 2.2x at k = 10, 1.9x at k = 100, but the exhaustive kernel is 1.2x faster at k = 1000;
     // 1.25 M docs, k = 1000: exhaustive 1.8x faster) -- on from 32768 docs per result.  SA_SPARSE=1 / 0 force it.
-    const int sparse_env = sa_env_int("SA_SPARSE", -1);
+    const int sparse_env = (int)sa_opt(bt->opts.sparse, -1);
     // Round 2: when most queries of the batch share their first terms, the grouped exhaustive kernel is as fast at
     // k = 10 and faster above (10 M docs, BASELINE batch: 369 K vs 341 K queries/s at k = 100, 236 K vs 114 K at
     // k = 1000) -- such batches score every posting from k = 32 on.
     // (only where the grouped kernel can actually run: impact stream, histogram bound, its tile sizes -- otherwise the
     //  batch would fall to the per-query exhaustive kernel, which pruning beats 2x)
-    const bool group_can_run = bt->n_groups && p.pruned && hist_possible && p.imp && !p.no_topk && sa_env_int("SA_GROUP", 1) != 0 &&
+    const bool group_can_run = bt->n_groups && p.pruned && hist_possible && p.imp && !p.no_topk && sa_opt(bt->opts.group, 1) != 0 &&
                                (ix->tile_docs == 1024 || ix->tile_docs == 2048 || ix->tile_docs == 4096);
     // Round 3: the grouped kernel (4 waves per SIMD, ~100 VALU instructions per (tile, query) pair) beats pruning on such
     // batches from k = 10 on (10 M docs, BASELINE batch, k = 10: 0.46 vs 0.63 ms per step) -- no lower limit on k any more.
@@ -2421,12 +2324,13 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
         SA_HIP(hipEventRecord(bt->ev_up[last], st));
         // (the image carries the starting bounds as the host left them -- zeros: the slice-table kernel forms them again)
         SA_TRY(sa_launch_make_bounds(ix, bt->d_terms, bt->B * bt->T, bt->d_bounds, bt->d_qbase, st, bt->d_qbase_imp,
-                                     bt->seed_on ? bt->impacts->d_topf : nullptr, bt->d_idf, bt->T, bt->k, bt->d_seed));
+                                     bt->seed_on ? bt->impacts->d_topf : nullptr, bt->d_idf, bt->T, bt->k, bt->d_seed,
+                                     (float)sa_opt(bt->opts.seed_scale_pct, 100) / 100.f));
     }
     const bool sparse = hist_possible && ix->tile_docs <= 8192 && bt->sparse_ok && ix->avg_doc_len != 0.f && ix->n_tiles > 0 &&
                         sparse_wanted;
     const bool use_hist = hist_possible &&
-                          (sparse || bt->k >= (u32)sa_env_int("SA_TOPK_HIST_MINK", defer_check ? 1 : 33));
+                          (sparse || bt->k >= (u32)sa_opt(bt->opts.topk_hist_mink, defer_check ? 1 : 33));
     p.hist = use_hist ? bt->d_hist : nullptr;
     p.gthr = use_hist ? bt->d_gthr : nullptr;
     // the bounds the queries start with (exhaustive kernels only: the pruning path derives its own from the lead terms)
@@ -2461,18 +2365,12 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
                 // establishes every query's bound (k-th best score so far), then one wave per (tile, group).
                 // Queries without a group go through the per-query kernel over all tiles.
                 u32 warm = std::max<u32>(16u, bt->k / 8u);     // (k = 1000, 10 M docs: 250 / 128 / 64 warm-up tiles -> 1.07 / 1.02 / 1.05 ms per step)
-                // optimistic bounds from the warm-up sample (sa_k_seed_bounds): from k = 32 on, where the flag the check
-                // needs travels with the results (defer_check), unless a check has failed on this index before
-                // (opt-in since the starting bounds exist: with them the sample adds nothing on the BASELINE batch -- k = 100: 0.434 ms
-                //  without, 0.446 with its 16 warm-up tiles; k = 1000: 0.581 / 0.587 -- and 4 % on the pairwise-distinct one at k = 1000)
-                const bool seed_on = sa_env_int("SA_SEED", 0) != 0 && !ix->seed_off && defer_check && bt->k >= 32u;
-                if (seed_on) warm = std::max<u32>(16u, bt->k / (u32)std::max(1, sa_env_int("SA_SEED_WARM_DIV", 32)));
-                // the queries start with bounds from their terms' rank tables (p.seed) and nothing is sampled for optimistic
-                // ones: no warm-up tiles at all -- the grouped kernel finds bounds above the base values from its first item
+                // the queries start with bounds from their terms' rank tables (p.seed): no warm-up tiles at all -- the grouped
+                // kernel finds bounds above the base values from its first item
                 // (10 M docs, k = 10: 16 / 4 / 1 / 0 warm-up tiles 0.394 / 0.396 / 0.388 / 0.383 ms of kernels, without the
                 //  starting bounds 0.420; 1.25 M-doc shard: 0.096 / 0.094 / - / 0.0825 against 0.126)
-                else if (p.seed) warm = 0;
-                if (const char* v = getenv("SA_GROUP_WARM")) warm = (u32)atoi(v);
+                if (p.seed) warm = 0;
+                if (sa_opt_is_set(bt->opts.group_warm)) warm = (u32)std::max<long long>(0, bt->opts.group_warm);
                 warm = std::min(warm, ix->n_tiles);
                 // The ungrouped rows (per-query kernel over all tiles) share nothing with the grouped ones -- not a
                 // query, not a counter -- so they run on the side stream BESIDE the warm-up tiles and the grouped kernel
@@ -2483,7 +2381,7 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
                 if (bt->n_grouped_rows < bt->B) {
                     Bm25Params pu = p;
                     pu.qlist = bt->d_iota + bt->n_grouped_rows; pu.nq = bt->B - bt->n_grouped_rows;
-                    side = sa_env_int("SA_GROUP_SIDE", 1) != 0;
+                    side = sa_opt(bt->opts.group_side, 1) != 0;
                     if (side) {
                         if (!ix->sstream) SA_HIP(hipStreamCreateWithFlags(&ix->sstream, hipStreamNonBlocking));
                         for (int i = 0; i < 2; i++)
@@ -2504,16 +2402,7 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
                     pa.qlist = bt->d_iota; pa.nq = bt->n_grouped_rows; pa.tile0 = 0; pa.tile_end = warm;
                     rc_main = sa_launch_bm25(ix, pa, st);
                 }
-                if (rc_main == SA_OK && seed_on && warm > 0 && ix->n_tiles > warm && bt->n_grouped_rows) {
-                    const double warm_docs = std::min<double>((double)warm * ix->tile_docs, (double)ix->n_docs);
-                    const double mu = (double)bt->k * warm_docs / (double)ix->n_docs;
-                    u32 j = (u32)ceil(mu + 4.5 * sqrt(mu) + 5.0);
-                    if (const char* v = getenv("SA_SEED_J")) j = (u32)std::max(1, atoi(v));      // (tests: 1 = far too optimistic, every check fails)
-                    if (j < bt->k)
-                        hipLaunchKernelGGL(sa_k_seed_bounds, dim3((bt->n_grouped_rows + 3u) / 4u), dim3(256), 0, st, (const u32*)bt->d_hist,
-                                           bt->d_gthr, bt->n_grouped_rows, j);
-                }
-                if (rc_main == SA_OK && ix->n_tiles > warm) rc_main = sa_launch_bm25_groups(ix, bt, p, warm, st, defer_check ? (overflow_cell ? overflow_cell : bt->d_overflow) : (u32*)nullptr);
+                if (rc_main == SA_OK && ix->n_tiles > warm) rc_main = sa_launch_bm25_groups(ix, bt, p, warm, st);
                 if (side) SA_HIP(hipStreamWaitEvent(st, bt->ev_side[1], 0));
                 SA_TRY(rc_main);
             } else {
@@ -2551,7 +2440,7 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
                        (const u32*)(p.pruned && !p.hist ? bt->d_slots : nullptr),
                        (const u32*)(p.pruned && p.hist ? bt->d_gthr : nullptr),
                        (may_overflow && defer_check) ? (overflow_cell ? overflow_cell : bt->d_overflow) : (u32*)nullptr,
-                       bt->d_slots, bt->B, 1u, bt->d_wl_cnt, 0u, (u32*)nullptr);
+                       bt->d_slots, bt->B, 1u, bt->d_wl_cnt, 0u, (u32*)nullptr, (const u32*)p.seed);
     bt->state_clean = true;
     bt->ran = true;
     return SA_OK;
@@ -2564,7 +2453,8 @@ static int sa_batch_merge_ranks(sa_batch* bt, const u64* d_gathered, int nranks,
         // the usual case: the gathered keys of a query fit the merge's LDS list -- one launch reads them where they are
         SA_MERGE_LAUNCH(bt->k, bt->B, st, (u64*)d_gathered, (u32)nranks * bt->k, bt->k, bt->d_final,
                            (const u32*)nullptr, bt->k, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr,
-                           (u32*)nullptr, (u32*)nullptr, 0u, 0u, (u32*)nullptr, (u32)(count + extra), extra ? bt->d_xflag : (u32*)nullptr);
+                           (u32*)nullptr, (u32*)nullptr, 0u, 0u, (u32*)nullptr, (u32)(count + extra), extra ? bt->d_xflag : (u32*)nullptr,
+                           (const u32*)nullptr);
         return SA_OK;
     }
     if (!bt->d_xcand || bt->xcand_ranks < nranks) {
@@ -2580,7 +2470,47 @@ static int sa_batch_merge_ranks(sa_batch* bt, const u64* d_gathered, int nranks,
     // every rank's block is its sorted top-k: group leaders = rank maxima
     SA_MERGE_LAUNCH(bt->k, bt->B, st, bt->d_xcand, (u32)nranks * bt->k, bt->k, bt->d_final,
                        (const u32*)nullptr, bt->k, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr,
-                       (u32*)nullptr, (u32*)nullptr, 0u, 0u, (u32*)nullptr, 0u, (u32*)nullptr);
+                       (u32*)nullptr, (u32*)nullptr, 0u, 0u, (u32*)nullptr, 0u, (u32*)nullptr, (const u32*)nullptr);
+    return SA_OK;
+}
+
+// A run whose result copy has landed (bt->h_res): was it flagged?  1: a candidate list overflowed (only possible when the
+// bound could not rise: degenerate score distributions); 2: fewer than k keys at or above a bound (a starting bound was too
+// high).  The batch is then REDONE with the unpruned selection -- against the device tables of the query set that run scored,
+// which is why sa_batch_reset / sa_batch_step call this for a run nobody has fetched yet BEFORE they replace those tables
+// (round 4 redid at fetch time only: a flagged run followed by reset + fetch returned the new set's results as the old set's).
+// Sharded: every rank saw the same flag (it travelled with the all-gather) and every rank makes the same calls, so all of
+// them redo the exchange.  Call with the index lock held, after ev_res has fired.
+static int sa_batch_redo_if_flagged(sa_batch* bt) {
+    sa_index* ix = bt->ix;
+    const size_t n = (size_t)bt->B * bt->k;
+    const u32 over = (u32)bt->h_res[n + (ix->comm ? 1 : 0)];
+    if (!over) return SA_OK;
+    if (sa_opt(bt->opts.trace, 0)) fprintf(stderr, "sa_batch: run redone without bounds (flag %u)\n", over);
+    SA_HIP(hipStreamSynchronize(bt->st));
+    if (ix->xstream) SA_HIP(hipStreamSynchronize(ix->xstream));
+    SA_HIP(hipMemset(bt->d_overflow, 0, sizeof(u32)));
+    SA_HIP(hipMemset(bt->d_xflag, 0, sizeof(u32)));
+    if (bt->d_xlocal) {
+        SA_HIP(hipMemset(bt->d_xlocal + n, 0, sizeof(u64)));
+        SA_HIP(hipMemset(bt->d_xlocal + 2 * n + 1, 0, sizeof(u64)));
+    }
+    if (ix->comm) {
+        const size_t count = n;
+        int nranks = 1;
+        SA_TRY(sa_comm_allgather_topk(ix, nullptr, nullptr, 0, &nranks, ix->xstream));
+        SA_TRY(sa_batch_run_shard(bt, bt->d_xlocal, false, true));
+        SA_HIP(hipStreamSynchronize(bt->st));
+        SA_TRY(sa_comm_allgather_topk(ix, bt->d_xlocal, bt->d_gather, count, &nranks, ix->xstream));
+        SA_TRY(sa_batch_merge_ranks(bt, bt->d_gather, nranks, ix->xstream));
+        SA_HIP(hipStreamSynchronize(ix->xstream));
+    } else {
+        SA_TRY(sa_batch_run_shard(bt, bt->d_final, false, true));
+        SA_HIP(hipStreamSynchronize(bt->st));
+    }
+    SA_HIP(hipGetLastError());
+    SA_HIP(hipMemcpy(bt->h_res, bt->d_final, (n + 2) * sizeof(u64), hipMemcpyDeviceToHost));
+    bt->h_res[n] = 0; bt->h_res[n + 1] = 0;                     // (the image now holds the redone results: nothing left to flag)
     return SA_OK;
 }
 
@@ -2592,7 +2522,7 @@ static int sa_batch_merge_ranks(sa_batch* bt, const u64* d_gathered, int nranks,
 static int sa_batch_queue_result_copy(sa_batch* bt, hipStream_t src_stream) {
     const size_t n = (size_t)bt->B * bt->k + 2;
     sa_index* ix = bt->ix;
-    if (sa_env_int("SA_RES_XS", 1) != 0) {
+    if (sa_opt(bt->opts.res_xs, 1) != 0) {
         if (!ix->xstream) SA_HIP(hipStreamCreateWithFlags(&ix->xstream, hipStreamNonBlocking));
         if (src_stream != ix->xstream) {
             SA_HIP(hipEventRecord(bt->ev_final, src_stream));
@@ -2607,10 +2537,10 @@ static int sa_batch_queue_result_copy(sa_batch* bt, hipStream_t src_stream) {
     return SA_OK;
 }
 
-extern "C" int sa_batch_run(sa_batch_t* bt, int sync) {
-    SA_ARG(bt && bt->ix, "null batch");
+// sa_batch_run with the index lock held (sa_batch_step fills and runs under ONE lock: no other thread's call on the batch
+// or the index lands between the two)
+static int sa_batch_run_locked(sa_batch* bt, int sync) {
     sa_index* ix = bt->ix;
-    std::lock_guard<std::mutex> g(ix->mu);
     SA_HIP(hipSetDevice(ix->device));
     hipStream_t st = bt->st;
     const u64 t_run = sa_now_ns();
@@ -2668,22 +2598,29 @@ extern "C" int sa_batch_run(sa_batch_t* bt, int sync) {
     return SA_OK;
 }
 
-// One step of a query stream in one call: idf gathered from the index's table, reset, run (header, Part 2).
+extern "C" int sa_batch_run(sa_batch_t* bt, int sync) {
+    SA_ARG(bt && bt->ix, "null batch");
+    std::lock_guard<std::mutex> g(bt->ix->mu);
+    return sa_batch_run_locked(bt, sync);
+}
+
+// One step of a query stream in one call: idf gathered from the index's table, reset, run (header, Part 2) -- under one lock.
 extern "C" int sa_batch_step(sa_batch_t* bt, const uint32_t* terms) {
     SA_ARG(bt && bt->ix && terms, "null argument");
     SA_ARG(bt->kind == 0, "sa_batch_step takes a BM25 batch");
     sa_index* ix = bt->ix;
-    {
-        std::lock_guard<std::mutex> g(ix->mu);
-        SA_ARG(ix->h_idf.size() == ix->n_terms, "sa_index_set_idf_table has not been called");
-        SA_HIP(hipSetDevice(ix->device));
-        const size_t n = (size_t)bt->B * bt->T;
-        bt->step_idf.resize(n);
-        for (size_t i = 0; i < n; i++) bt->step_idf[i] = terms[i] < ix->n_terms ? ix->h_idf[terms[i]] : 0.f;
-        if (bt->res_pending && bt->unfetched) SA_HIP(hipEventSynchronize(bt->ev_res));
-        SA_TRY(sa_batch_fill(bt, terms, bt->step_idf.data()));
+    std::lock_guard<std::mutex> g(ix->mu);
+    SA_ARG(ix->h_idf.size() == ix->n_terms, "sa_index_set_idf_table has not been called");
+    SA_HIP(hipSetDevice(ix->device));
+    const size_t n = (size_t)bt->B * bt->T;
+    bt->step_idf.resize(n);
+    for (size_t i = 0; i < n; i++) bt->step_idf[i] = terms[i] < ix->n_terms ? ix->h_idf[terms[i]] : 0.f;
+    if (bt->res_pending && bt->unfetched) {
+        SA_HIP(hipEventSynchronize(bt->ev_res));
+        SA_TRY(sa_batch_redo_if_flagged(bt));                   // (a flagged run is redone while the tables still hold ITS query set)
     }
-    return sa_batch_run(bt, 0);
+    SA_TRY(sa_batch_fill(bt, terms, bt->step_idf.data()));
+    return sa_batch_run_locked(bt, 0);
 }
 
 extern "C" int sa_batch_seeds(sa_batch_t* bt, float* out) {
@@ -2756,39 +2693,7 @@ extern "C" int sa_batch_fetch(sa_batch_t* bt, float* scores_out, uint64_t* docs_
         // index may be in flight behind it
         SA_HIP(hipEventSynchronize(bt->ev_res));
         bt->unfetched = false;
-        const u32 over = (u32)bt->h_res[n + (ix->comm ? 1 : 0)];
-        if (over) {
-            // (2: an optimistic bound was too high -- sa_k_seed_bounds; behind the exchange the flag is a plain "redo": with
-            //  bounds seeded at this k it counts as that too)
-            if (over >= 2u || (ix->comm && bt->k >= 32u)) ix->seed_off = true;
-            if (getenv("SA_SEED_TRACE")) fprintf(stderr, "sa_batch_fetch: redo without bounds (flag %u)%s\n", over, ix->seed_off ? ", optimistic bounds off" : "");
-            // A run overflowed a candidate list (only possible when the bound could not rise: degenerate score
-            // distributions): redo the batch with the unpruned selection.  Sharded: every rank saw the same flag
-            // (it travelled with the all-gather) and every rank calls fetch, so all of them redo the exchange.
-            SA_HIP(hipStreamSynchronize(bt->st));
-            if (ix->xstream) SA_HIP(hipStreamSynchronize(ix->xstream));
-            SA_HIP(hipMemset(bt->d_overflow, 0, sizeof(u32)));
-            SA_HIP(hipMemset(bt->d_xflag, 0, sizeof(u32)));
-            if (bt->d_xlocal) {
-                SA_HIP(hipMemset(bt->d_xlocal + n, 0, sizeof(u64)));
-                SA_HIP(hipMemset(bt->d_xlocal + 2 * n + 1, 0, sizeof(u64)));
-            }
-            if (ix->comm) {
-                const size_t count = n;
-                int nranks = 1;
-                SA_TRY(sa_comm_allgather_topk(ix, nullptr, nullptr, 0, &nranks, ix->xstream));
-                SA_TRY(sa_batch_run_shard(bt, bt->d_xlocal, false, true));
-                SA_HIP(hipStreamSynchronize(bt->st));
-                SA_TRY(sa_comm_allgather_topk(ix, bt->d_xlocal, bt->d_gather, count, &nranks, ix->xstream));
-                SA_TRY(sa_batch_merge_ranks(bt, bt->d_gather, nranks, ix->xstream));
-                SA_HIP(hipStreamSynchronize(ix->xstream));
-            } else {
-                SA_TRY(sa_batch_run_shard(bt, bt->d_final, false, true));
-                SA_HIP(hipStreamSynchronize(bt->st));
-            }
-            SA_HIP(hipGetLastError());
-            SA_HIP(hipMemcpy(bt->h_res, bt->d_final, (n + 2) * sizeof(u64), hipMemcpyDeviceToHost));
-        }
+        SA_TRY(sa_batch_redo_if_flagged(bt));
         keys = bt->h_res;
     } else {
         // external-collective route (sa_batch_run_local / sa_batch_merge_gathered): the caller's last call decides
@@ -2871,6 +2776,22 @@ extern "C" int sa_batch_profile(sa_batch_t* bt, double* kernel_ms_out, uint64_t*
 extern "C" int sa_batch_group_info(sa_batch_t* bt, uint32_t out[4]) {
     SA_ARG(bt && out, "null argument");
     out[0] = bt->n_groups; out[1] = bt->n_grouped_rows; out[2] = bt->n_shared_rows; out[3] = bt->B - bt->n_grouped_rows;
+    return SA_OK;
+}
+
+// A batch's switches after its creation: effective from its next reset / run (what was sized at creation -- candidate
+// capacity, streams, the phrase tile size -- keeps what it was).
+extern "C" int sa_batch_set_options(sa_batch_t* bt, const sa_options_t* o) {
+    SA_ARG(bt && bt->ix && o, "null argument");
+    SA_ARG(o->struct_size == sizeof(sa_options_t), "sa_options_t: wrong struct_size (fill it with sa_options_init)");
+    std::lock_guard<std::mutex> g(bt->ix->mu);
+    bt->opts = *o;
+    return SA_OK;
+}
+extern "C" int sa_batch_get_options(sa_batch_t* bt, sa_options_t* out) {
+    SA_ARG(bt && bt->ix && out, "null argument");
+    std::lock_guard<std::mutex> g(bt->ix->mu);
+    *out = bt->opts;
     return SA_OK;
 }
 

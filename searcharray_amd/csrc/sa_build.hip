@@ -101,6 +101,7 @@ extern "C" int sa_index_create_from_tokens(int device, uint64_t n_docs, uint64_t
 
     sa_index* ix = new (std::nothrow) sa_index();
     if (!ix) { sa_set_error("out of host memory"); return SA_ERR_NOMEM; }
+    ix->opts = sa_options_for_new_handle(nullptr);
     ix->device = device;
     ix->n_docs = n_docs; ix->doc_base = doc_base; ix->corpus_size = corpus_size;
     ix->n_terms = n_terms; ix->avg_doc_len = avg_doc_len; ix->n_words = 0;

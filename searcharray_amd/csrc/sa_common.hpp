@@ -86,13 +86,6 @@ __device__ __forceinline__ u64 sa_wave_max64(u64 v) {
 // Full-wave (64 lanes, all active) unsigned max / min through the DPP data path: a row scan by
 // row_shr 1/2/4/8, then row_bcast:15 and row_bcast:31 fold the four rows into lane 63.  Pure
 // VALU (no LDS crossbar round trips like ds_bpermute-based __shfl), result is wave-uniform.
-// hides a wave-uniform value's history from the optimiser (no instruction): code behind it is compiled once, not once per
-// value the paths in front of it have established
-#define SA_NOINLINE __attribute__((noinline))
-#ifndef SA_OPAQUE_U32
-#define SA_OPAQUE_U32(x) asm volatile("" : "+s"(x))
-#endif
-
 #define SA_DPP_ROW_SHR(n) (0x110 + (n))
 #define SA_DPP_ROW_BCAST15 0x142
 #define SA_DPP_ROW_BCAST31 0x143

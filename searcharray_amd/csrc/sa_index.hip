@@ -31,6 +31,116 @@ void sa_set_error(const char* fmt, ...) {
 extern "C" const char* sa_last_error(void) { return g_sa_error.c_str(); }
 extern "C" int sa_abi_version(void) { return SA_ABI_VERSION; }
 
+// ---------------------------------------------------------------------------------------------
+// Options (include/searcharray_hip.h, Part 0; sa_options.hpp)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct SaOptName { const char* name; size_t off; };
+static const SaOptName g_sa_opt_names[] = {
+#define SA_X(f) {#f, offsetof(sa_options_fields, f)},
+    SA_OPTION_LIST(SA_X)
+#undef SA_X
+};
+constexpr int SA_N_OPTS = (int)(sizeof(g_sa_opt_names) / sizeof(g_sa_opt_names[0]));
+static int64_t* sa_opt_slot(sa_options_t* o, const char* name) {
+    for (int i = 0; i < SA_N_OPTS; i++)
+        if (!strcmp(g_sa_opt_names[i].name, name)) return (int64_t*)((char*)o + g_sa_opt_names[i].off);
+    return nullptr;
+}
+thread_local bool t_sa_opts_set = false;
+thread_local sa_options_t t_sa_opts;
+}  // namespace
+
+extern "C" void sa_options_init(sa_options_t* o) {
+    if (!o) return;
+    o->struct_size = sizeof(sa_options_t);
+    for (int i = 0; i < SA_N_OPTS; i++) *(int64_t*)((char*)o + g_sa_opt_names[i].off) = SA_OPT_UNSET;
+}
+extern "C" int sa_option_count(void) { return SA_N_OPTS; }
+extern "C" const char* sa_option_name(int i) { return i >= 0 && i < SA_N_OPTS ? g_sa_opt_names[i].name : nullptr; }
+extern "C" int sa_options_set(sa_options_t* o, const char* name, int64_t value) {
+    SA_ARG(o && name, "null argument");
+    int64_t* slot = sa_opt_slot(o, name);
+    if (!slot) { sa_set_error("unknown option '%s'", name); return SA_ERR_ARG; }
+    *slot = value;
+    return SA_OK;
+}
+extern "C" int sa_options_get(const sa_options_t* o, const char* name, int64_t* value_out) {
+    SA_ARG(o && name && value_out, "null argument");
+    const int64_t* slot = sa_opt_slot(const_cast<sa_options_t*>(o), name);
+    if (!slot) { sa_set_error("unknown option '%s'", name); return SA_ERR_ARG; }
+    *value_out = *slot;
+    return SA_OK;
+}
+// The process defaults: everything unset, plus the ONE environment variable the library reads -- SA_OPTS="name=value,name=value"
+// (a debug override for binaries whose caller cannot pass options), parsed once.
+const sa_options_t& sa_options_process_defaults() {
+    static const sa_options_t defaults = [] {
+        sa_options_t o;
+        sa_options_init(&o);
+        if (const char* env = getenv("SA_OPTS")) {
+            std::string spec(env);
+            size_t pos = 0;
+            while (pos < spec.size()) {
+                size_t end = spec.find(',', pos);
+                if (end == std::string::npos) end = spec.size();
+                const std::string item = spec.substr(pos, end - pos);
+                const size_t eq = item.find('=');
+                if (eq != std::string::npos) {
+                    const std::string name = item.substr(0, eq);
+                    if (int64_t* slot = sa_opt_slot(&o, name.c_str())) *slot = (int64_t)strtoll(item.c_str() + eq + 1, nullptr, 10);
+                    else fprintf(stderr, "libsearcharray_hip: SA_OPTS: unknown option '%s' ignored\n", name.c_str());
+                }
+                pos = end + 1;
+            }
+        }
+        return o;
+    }();
+    return defaults;
+}
+extern "C" int sa_options_process_defaults_get(sa_options_t* out) {
+    SA_ARG(out, "null argument");
+    *out = sa_options_process_defaults();
+    return SA_OK;
+}
+static int sa_options_check(const sa_options_t* o) {
+    if (o && o->struct_size != sizeof(sa_options_t)) {
+        sa_set_error("sa_options_t: struct_size %llu, this library expects %zu (fill it with sa_options_init)", (unsigned long long)o->struct_size, sizeof(sa_options_t));
+        return SA_ERR_ARG;
+    }
+    return SA_OK;
+}
+extern "C" int sa_options_set_thread_defaults(const sa_options_t* o) {
+    SA_TRY(sa_options_check(o));
+    t_sa_opts_set = o != nullptr;
+    if (o) t_sa_opts = *o;
+    return SA_OK;
+}
+// what a handle created by this thread starts from: the thread's defaults, else `fallback` (a batch: its index's options), else the
+// process defaults
+sa_options_t sa_options_for_new_handle(const sa_options_t* fallback) {
+    if (t_sa_opts_set) return t_sa_opts;
+    return fallback ? *fallback : sa_options_process_defaults();
+}
+bool sa_options_thread_defaults(sa_options_t* out) {
+    if (t_sa_opts_set && out) *out = t_sa_opts;
+    return t_sa_opts_set;
+}
+extern "C" int sa_index_set_options(sa_index_t* ix, const sa_options_t* o) {
+    SA_ARG(ix && o, "null argument");
+    SA_TRY(sa_options_check(o));
+    std::lock_guard<std::mutex> g(ix->mu);
+    ix->opts = *o;
+    return SA_OK;
+}
+extern "C" int sa_index_get_options(sa_index_t* ix, sa_options_t* out) {
+    SA_ARG(ix && out, "null argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    *out = ix->opts;
+    return SA_OK;
+}
+
+
 extern "C" int sa_device_count(int* out_count) {
     SA_ARG(out_count, "out_count is null");
     int n = 0;
@@ -303,8 +413,8 @@ int sa_index_derive(sa_index* ix) {
     std::vector<Seg> segs;
     {
         u64 SEG_MAX = 1ull << 31;
-        if (const char* sv = getenv("SA_SEG_WORDS")) {           // test hook: force small segments
-            const u64 v = strtoull(sv, nullptr, 10);
+        if (sa_opt_is_set(ix->opts.seg_words)) {                // test hook: force small segments
+            const u64 v = (u64)ix->opts.seg_words;
             if (v > 0 && v < SEG_MAX) SEG_MAX = v;
         }
         u32 t = 0;
@@ -400,8 +510,7 @@ int sa_index_derive(sa_index* ix) {
     {
         // terms with at least ~1/8 posting per tile get a directory row; rarer terms are short
         // enough that a workgroup's lower-bound search stays inside a few cache lines
-        const char* dv = getenv("SA_DIR_DIV");
-        const int div = dv ? atoi(dv) : 8;
+        const int div = (int)sa_opt(ix->opts.dir_div, 8);
         ix->dir_min_df = div > 0 ? ix->n_tiles / (u32)div : 4 * ix->n_tiles;
         if (div < 0) ix->dir_min_df = (u32)(-div) * ix->n_tiles;
         if (ix->dir_min_df < 64) ix->dir_min_df = 64;
@@ -430,8 +539,7 @@ int sa_index_derive(sa_index* ix) {
     }
     // ---- dense tf rows of the frequent terms (dynamic pruning looks candidates up in them) ----
     {
-        const char* dv = getenv("SA_TF8_DIV");
-        const int div = dv ? atoi(dv) : 128;
+        const int div = (int)sa_opt(ix->opts.tf8_div, 128);
         std::vector<std::pair<u64, u32>> cand;
         if (div > 0 && ix->n_docs > 0)
             for (u32 t = 0; t < V; t++) {
@@ -442,7 +550,7 @@ int sa_index_derive(sa_index* ix) {
             return a.first != b.first ? a.first > b.first : a.second < b.second;
         });
         u64 budget_rows = ix->n_docs ? (ix->n_postings * 8 + (64ull << 20)) / ix->n_docs : 0;
-        if (const char* mr = getenv("SA_TF8_MAXROWS")) budget_rows = strtoull(mr, nullptr, 10);
+        if (sa_opt_is_set(ix->opts.tf8_maxrows)) budget_rows = (u64)ix->opts.tf8_maxrows;
         if (cand.size() > budget_rows) cand.resize((size_t)budget_rows);
         if (cand.size() > 4096) cand.resize(4096);
         ix->n_tf8_terms = (u32)cand.size();
@@ -470,8 +578,7 @@ int sa_index_derive(sa_index* ix) {
     {
         // terms with at least one word per SA_DOCDIR_DIV docs (default 32), most frequent first,
         // within a memory budget of the size of the word array itself
-        const char* dv = getenv("SA_DOCDIR_DIV");
-        const int div = dv ? atoi(dv) : 32;
+        const int div = (int)sa_opt(ix->opts.docdir_div, 32);
         std::vector<std::pair<u64, u32>> cand;
         if (div > 0 && ix->n_docs > 0)
             for (u32 t = 0; t < V; t++) {
@@ -559,6 +666,7 @@ extern "C" int sa_index_create(int device, uint64_t n_docs, uint64_t doc_base, u
 
     sa_index* ix = new (std::nothrow) sa_index();
     if (!ix) { sa_set_error("out of host memory"); return SA_ERR_NOMEM; }
+    ix->opts = sa_options_for_new_handle(nullptr);
     ix->device = device;
     ix->n_docs = n_docs; ix->doc_base = doc_base; ix->corpus_size = corpus_size;
     ix->n_terms = n_terms; ix->avg_doc_len = avg_doc_len; ix->n_words = W;

@@ -17,6 +17,7 @@
 //   dir_slot  u32[V]      row of term t in tile_dir, or 0xFFFFFFFF
 //   doc_lens  f32[n_docs]
 #pragma once
+#include "sa_options.hpp"
 #include "sa_common.hpp"
 #include <memory>
 #include <mutex>
@@ -68,6 +69,7 @@ struct sa_impacts {
 };
 
 struct sa_index {
+    sa_options_t opts;              // the handle's switches (sa_options.hpp): the creating thread's defaults, or sa_index_set_options
     int device = 0;
     int n_cus = 1;                  // compute units of the device (persistent grid sizing)
     hipStream_t stream = nullptr;
@@ -108,7 +110,6 @@ struct sa_index {
     std::vector<float> h_idf;        // idf of every term as the host formed it (sa_index_set_idf_table; sa_batch_step gathers from it)
     std::vector<u32> h_dd_slot;      // host copy of d_dd_slot
     std::vector<unsigned char> h_term_edge;   // [n_terms] bit 0: first word has header 0, bit 1: last word has the largest header
-    bool seed_off = false;           // an optimistic bound (sa_k_seed_bounds, sa_bm25.hip) failed its check on this index once: no more of them
     bool any_top_block = true;       // some word of the index sits in a document's LAST 18-position block (positions >= 4.7 M:
                                      //   hardly ever) -- only then can `header + 1` of a word be another document's block 0
     std::vector<u32> h_dd_top;       // [n_dd_terms] 1: the term has a word in the last 18-position block (sa_spans.hip)

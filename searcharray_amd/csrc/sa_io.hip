@@ -24,20 +24,22 @@
 
 namespace {
 
-// bytes per staged piece (SA_IO_PIECE_BYTES: test hook, lets small files exercise the ring's wrap-around)
+// what the calling thread's options say (the file routines run before / without an index handle)
+static sa_options_t sa_io_opts() { return sa_options_for_new_handle(nullptr); }
+// bytes per staged piece (option io_piece_bytes: test hook, lets small files exercise the ring's wrap-around)
 static size_t sa_io_piece() {
     size_t v = 4u << 20;      // larger pieces only add page-locking time (~0.5 ms per MiB of ring), measured
-    if (const char* e = getenv("SA_IO_PIECE_BYTES")) {
-        const size_t x = (size_t)strtoull(e, nullptr, 10);
+    const sa_options_t o = sa_io_opts();
+    if (sa_opt_is_set(o.io_piece_bytes)) {
+        const size_t x = (size_t)o.io_piece_bytes;
         if (x >= 64 && x <= (256u << 20)) v = x & ~(size_t)7;
     }
     return v;
 }
 constexpr int SA_IO_SLOTS = 12;
-// file threads: a single pread / pwrite stream tops out near 10 GB/s (SA_IO_THREADS: 1..SA_IO_SLOTS / 2)
+// file threads: a single pread / pwrite stream tops out near 10 GB/s (option io_threads: 1..SA_IO_SLOTS / 2)
 static int sa_io_workers() {
-    int v = 4;
-    if (const char* e = getenv("SA_IO_THREADS")) v = atoi(e);
+    const int v = (int)sa_opt(sa_io_opts().io_threads, 4);
     return v < 1 ? 1 : (v > SA_IO_SLOTS / 2 ? SA_IO_SLOTS / 2 : v);
 }
 
@@ -336,6 +338,7 @@ extern "C" int sa_index_create_from_file(int device, uint64_t n_docs, uint64_t d
 
     sa_index* ix = new (std::nothrow) sa_index();
     if (!ix) { sa_set_error("out of host memory"); return SA_ERR_NOMEM; }
+    ix->opts = sa_options_for_new_handle(nullptr);
     ix->device = device;
     ix->n_docs = n_docs; ix->doc_base = doc_base; ix->corpus_size = corpus_size;
     ix->n_terms = n_terms; ix->avg_doc_len = avg_doc_len; ix->n_words = W;

@@ -598,8 +598,7 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
     std::vector<const u32*> dd_rows_v((size_t)T);
     const u32** const dd_rows = dd_rows_v.data();
     {
-        const char* v = getenv("SA_PHRASE_DOCDIR");
-        const bool use_dd = !filt.active && ix->n_dd_terms > 0 && !(v && atoi(v) == 0);
+        const bool use_dd = !filt.active && ix->n_dd_terms > 0 && sa_opt(ix->opts.phrase_docdir, 1) != 0;
         std::vector<u32>& slots = ix->h_dd_slot;
         for (int t = 0; t < T; t++) {
             const u32 sl = (use_dd && terms[t] < ix->n_terms) ? slots[terms[t]] : SA_DD_NONE;
@@ -609,11 +608,10 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
     // phrases with repeated terms: the chain per document (sa_k_phrase_docs) -- unless its checks say that the prediction
     // of the same-term test failed or a document did not fit
     {
-        const char* v = getenv("SA_PHRASE_DOCS");
         // (pairwise-distinct terms: only where the fused kernel cannot take the phrase -- a sub-phrase of more than 18 terms)
         const int part = (l2r_only || r2l_only) ? T : (shortest > T - shortest ? shortest : T - shortest);
         const bool fused_can = distinct && part <= SA_MAX_FUSED && !ix->any_top_block;
-        bool take = mode == 0 && !fused_can && !(v && atoi(v) == 0) && !filt.active && T >= 2 && T <= SA_PD_MAXT && N < 0xFFFFFFF0ull;
+        bool take = mode == 0 && !fused_can && sa_opt(ix->opts.phrase_docs, 1) != 0 && !filt.active && T >= 2 && T <= SA_PD_MAXT && N < 0xFFFFFFF0ull;
         for (int t = 0; t < T && take; t++) take = lens[t] > 0;
         if (take) {
             PhraseDocParams pd;
@@ -655,7 +653,7 @@ static int sa_phrase_counts_device(sa_index* ix, const u32* terms, int T, int mo
                     if (!((pd.same_mask >> k) & 1u) && h_flags[1 + 2 * k] != 0 && h_flags[2 + 2 * k] == 0) ok = false;
                 break;                                            // (a failed same-term prediction: no capacity helps)
             }
-            if (getenv("SA_PHRASE_TRACE")) fprintf(stderr, "phrase route: chain per document %s\n", ok ? "taken" : "abandoned (general chain)");
+            if (sa_opt(ix->opts.trace, 0)) fprintf(stderr, "phrase route: chain per document %s\n", ok ? "taken" : "abandoned (general chain)");
             if (ok) return SA_OK;
         }
     }
@@ -778,16 +776,14 @@ extern "C" int sa_index_last_profile(sa_index_t* ix, double* kernel_ms_out, uint
     return SA_OK;
 }
 
-static int sa_phrase_mode() {
-    const char* v = getenv("SA_PHRASE_MODE");
-    if (!v) return 0;
-    if (!strcmp(v, "general")) return 1;
-    if (!strcmp(v, "fused")) return 2;
-    return 0;
+// option phrase_mode: 0 the library chooses, 1 the general chain, 2 the fused kernel
+static int sa_phrase_mode(const sa_index* ix) {
+    const long long m = sa_opt(ix->opts.phrase_mode, 0);
+    return m == 1 || m == 2 ? (int)m : 0;
 }
 
 static int sa_phrase_or_span(sa_index* ix, const u32* terms, int n_terms, int slop, const PosnFilter& filt, float** d_out) {
-    if (slop == 0) return sa_phrase_counts_device(ix, terms, n_terms, sa_phrase_mode(), filt, d_out);
+    if (slop == 0) return sa_phrase_counts_device(ix, terms, n_terms, sa_phrase_mode(ix), filt, d_out);
     return sa_span_counts_device(ix, terms, n_terms, slop, filt, d_out);
 }
 

@@ -247,6 +247,9 @@ sa_k_dense_topk_tiles_multi(const sa_dense_rank_job* __restrict__ jobs, const fl
 int sa_launch_phrase_tiles(sa_batch* bt, hipStream_t st) {
     sa_index* ix = bt->ix;
     if (bt->pn_tiles == 0 || bt->B == 0) return SA_OK;
+    // the batch's options rule while it runs (the dense routes below read the index's; the caller holds the index lock)
+    struct OptsScope { sa_index* ix; sa_options_t saved; ~OptsScope() { ix->opts = saved; } } opts_scope{ix, ix->opts};
+    ix->opts = bt->opts;
     PhraseTileParams p;
     memset(&p, 0, sizeof(p));
     p.words = ix->d_words; p.doc_lens = ix->d_doc_lens;
@@ -256,7 +259,7 @@ int sa_launch_phrase_tiles(sa_batch* bt, hipStream_t st) {
     p.cand_cap = bt->cand_cap; p.cand_cnt = bt->d_cand_cnt; p.slots = bt->d_slots; p.cand = bt->d_cand;
     p.terms = bt->d_terms; p.wlen = bt->d_wlen; p.docdir = ix->d_docdir; p.dd_slot = ix->d_dd_slot;
     p.use_docdir = ix->n_dd_terms > 0 ? 1 : 0;
-    if (const char* v = getenv("SA_PHRASE_DOCDIR")) { if (atoi(v) == 0) p.use_docdir = 0; }
+    if (sa_opt(bt->opts.phrase_docdir, 1) == 0) p.use_docdir = 0;
     const u64 n_items = (u64)bt->B * bt->pn_tiles;
     if (bt->dense_rows.size() < bt->B) {             // (rows on the dense route have plan[0] == 0: their items leave at once)
         if (bt->ptile == 2048)
@@ -287,7 +290,7 @@ int sa_launch_phrase_tiles(sa_batch* bt, hipStream_t st) {
         }
     };
     int n_lanes = 2;
-    if (const char* v = getenv("SA_PHRASE_LANES")) n_lanes = atoi(v);
+    n_lanes = (int)sa_opt(bt->opts.phrase_lanes, n_lanes);
     n_lanes = std::max(1, std::min(n_lanes, 4));
     if ((size_t)n_lanes > bt->dense_rows.size()) n_lanes = (int)bt->dense_rows.size();
     if (n_lanes > 1) {
@@ -465,11 +468,12 @@ extern "C" int sa_phrase_batch_create_ex(sa_index_t* ix, const uint32_t* terms, 
     SA_HIP(hipSetDevice(ix->device));
     sa_batch* bt = new (std::nothrow) sa_batch();
     if (!bt) { sa_set_error("out of host memory"); return SA_ERR_NOMEM; }
+    bt->opts = sa_options_for_new_handle(&ix->opts);
     bt->ix = ix; bt->B = B; bt->T = T; bt->k = (u32)k; bt->k1 = k1; bt->b = b;
     bt->kind = 1;
     bt->st = ix->stream;           // (the dense route swaps lanes in and out of the index: phrase batches stay on its stream)
     bt->ptile = SA_PTILE;
-    if (const char* v = getenv("SA_PTILE")) { if (atoi(v) == 2048 || atoi(v) == 4096) bt->ptile = (u32)atoi(v); }
+    if (bt->opts.ptile == 2048 || bt->opts.ptile == 4096) bt->ptile = (u32)bt->opts.ptile;
     bt->pn_tiles = (u32)((ix->n_docs + bt->ptile - 1) / bt->ptile);
     auto alloc = [&]() -> int {
         // upload block: terms [B][T], idf [B], perm [B], plan [B][4]

@@ -12,6 +12,7 @@
 // Host code only: everything below goes through the single-device entry points of this library (Part 2 / Part 3), so a
 // binder in any language gets N GPUs behind one handle -- what searcharray_amd/sharded.py did in Python until round 3.
 #include "sa_common.hpp"
+#include "sa_options.hpp"
 #include "../../include/searcharray_hip.h"
 
 #include <condition_variable>
@@ -101,7 +102,16 @@ struct sa_sharded {
 
     // fn(g) on every shard's thread; the first failure's code and message are the call's
     int all(const std::function<int(int)>& fn) {
-        for (int g = 0; g < G; g++) workers[(size_t)g]->post([fn, g] { return fn(g); });
+        // (the shard threads create handles on behalf of the caller: they start from the CALLER's thread defaults)
+        sa_options_t caller_opts;
+        const bool have_opts = sa_options_thread_defaults(&caller_opts);
+        for (int g = 0; g < G; g++)
+            workers[(size_t)g]->post([fn, g, have_opts, caller_opts] {
+                sa_options_set_thread_defaults(have_opts ? &caller_opts : nullptr);
+                const int r = fn(g);
+                sa_options_set_thread_defaults(nullptr);
+                return r;
+            });
         int rc = SA_OK;
         std::string err;
         for (int g = 0; g < G; g++) {

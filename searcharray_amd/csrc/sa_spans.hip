@@ -1762,10 +1762,7 @@ __global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused_multi(const Sp
     sa_span_doc_fused_body<TT>(p, blockIdx.x - p.block0);
 }
 
-static bool sa_env_span_doc() {
-    const char* v = getenv("SA_SPAN_DOC");
-    return !(v && atoi(v) == 0);
-}
+static bool sa_opt_span_doc(const sa_index* ix) { return sa_opt(ix->opts.span_doc, 1) != 0; }
 
 template <int TT>
 static void sa_span_doc_launch(const SpanDocParams& p, dim3 fg, hipStream_t st) {
@@ -1791,7 +1788,7 @@ static int sa_span_counts_doc_route(sa_index* ix, const SpanTerms& terms_dev, in
     for (int t = 1; t < T; t++) if (terms_dev.len[t] < terms_dev.len[rarest]) rarest = t;
     p.anchor = 2 * (u64)terms_dev.len[rarest] >= N ? -1 : rarest;
     if (p.anchor >= 0) SA_HIP(hipMemsetAsync(p.counts, 0, N * sizeof(float), st));
-    if (getenv("SA_SPAN_TRACE")) fprintf(stderr, "slop doc route: %s\n", p.anchor >= 0 ? "over the rarest term's documents" : "over all documents");
+    if (sa_opt(ix->opts.trace, 0)) fprintf(stderr, "slop doc route: %s\n", p.anchor >= 0 ? "over the rarest term's documents" : "over all documents");
     const u64 slots = p.anchor >= 0 ? (u64)terms_dev.len[rarest] : N;
     const dim3 fg((u32)((slots + SA_SPAN_FD - 1) / SA_SPAN_FD));
     switch (T) {
@@ -1901,8 +1898,7 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
         terms_dev.words[t] = ix->d_words + off;
         terms_dev.len[t] = (u32)(ix->h_term_off[terms[t] + 1] - off);
         // probes through the doc directory (whole, unfiltered lists of frequent terms without a top-block word)
-        const char* ddenv = getenv("SA_SPAN_DOCDIR");
-        if (!filt.active && ix->n_dd_terms > 0 && !(ddenv && atoi(ddenv) == 0)) {
+        if (!filt.active && ix->n_dd_terms > 0 && sa_opt(ix->opts.span_docdir, 1) != 0) {
             const u32 sl = ix->h_dd_slot[terms[t]];
             if (sl != SA_DD_NONE && sl < ix->h_dd_top.size() && ix->h_dd_top[sl] == 0)
                 terms_dev.dd[t] = ix->d_docdir + (size_t)sl * ix->n_docs;
@@ -1913,7 +1909,7 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
     if (total_len > 0xFFFFFFF0ull) { sa_set_error("slop phrase: more than 2^32 words in the phrase's terms"); return SA_ERR_UNSUPPORTED; }
     // the doc-parallel route: 2..4 known terms, all with a directory row (whole lists, no word in a last block), header
     // 0 not in L (host arithmetic on the per-term edge flags, as below)
-    if (known && !filt.active && T >= 2 && T <= 4 && T + slop <= 15 && N > 0 && N < 0xFFFFFFF0ull && sa_env_span_doc() &&
+    if (known && !filt.active && T >= 2 && T <= 4 && T + slop <= 15 && N > 0 && N < 0xFFFFFFF0ull && sa_opt_span_doc(ix) &&
         ix->h_term_edge.size() >= (size_t)ix->n_terms) {
         // no word of these lists in a document's last 18-position block: no such word in the index at all (the usual case),
         // or every term with a directory row that says so
@@ -1932,13 +1928,13 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
         // (it wins on every phrase measured, short lists included -- zipf-1M, slop 2, [0 1] 0.078 vs 0.130 ms, [5 6] 0.030 vs
         //  0.059, [20 30] 0.022 vs 0.034, [5 8 9] 0.040 vs 0.070: one launch against seven)
         const bool take = local && (T == 2 || !L);
-        if (getenv("SA_SPAN_TRACE")) fprintf(stderr, "slop route: %s (T %d, directory rows %d, header 0 in L %d)\n", take ? "doc-parallel" : "general", T, (int)all_dd, (int)L);
+        if (sa_opt(ix->opts.trace, 0)) fprintf(stderr, "slop route: %s (T %d, directory rows %d, header 0 in L %d)\n", take ? "doc-parallel" : "general", T, (int)all_dd, (int)L);
         if (take) return sa_span_counts_doc_route(ix, terms_dev, T, slop, d_out);
     }
     // resident state-machine threads: no more than there can be document groups
     u32 G = (u32)((terms_dev.len[0] + 63u) & ~63u);
     u32 g_max = SA_SPAN_THREADS;
-    if (const char* v = getenv("SA_SPAN_THREADS")) { const int x = atoi(v); if (x >= 64) g_max = ((u32)x + 63u) & ~63u; }   // tests: force the stride loop
+    if (sa_opt(ix->opts.span_threads, 0) >= 64) g_max = ((u32)ix->opts.span_threads + 63u) & ~63u;   // tests: force the stride loop
     if (G > g_max) G = g_max;
     if (G == 0) G = 64;
     const size_t slab_bytes = (size_t)G * SA_NSPANS * (sizeof(SpanEnt) + sizeof(u64));
@@ -2047,12 +2043,11 @@ int sa_span_counts_device(sa_index* ix, const u32* terms, int T, int slop, const
                            (const u32*)chunks, n_chunks, co, inline_scan ? cnt : (u32*)nullptr);
     }
     // fast pass (tables in LDS, one thread per document group), then the groups it abandoned with full tables
-    const char* fast_env = getenv("SA_SPAN_FAST");
-    if (!(fast_env && atoi(fast_env) == 0) && terms_dev.len[0] > 0) {
+    if (sa_opt(ix->opts.span_fast, 1) != 0 && terms_dev.len[0] > 0) {
         mp.over_list = over_list; mp.over_cnt = cnt + 4 * SA_SPAN_MAX_TERMS;
         // (work order only when the document groups outnumber the lanes the device keeps resident -- 256 CUs x 13 waves
         //  x 64: below that every wave starts at once, the order changes nothing, and a light phrase saves two launches)
-        const int sort_env = getenv("SA_SPAN_SORT") ? atoi(getenv("SA_SPAN_SORT")) : -1;
+        const int sort_env = (int)sa_opt(ix->opts.span_sort, -1);
         if (sort_env != 0 && (sort_env > 0 || terms_dev.len[0] > (u32)SA_SPAN_SORT_MIN)) {
             SpanBinParams bp;
             memset(&bp, 0, sizeof(bp));
@@ -2094,20 +2089,16 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
     const u64 N = ix->n_docs;
     if (n <= 0 || N == 0) return SA_OK;
     {
-        const char* fast_env = getenv("SA_SPAN_FAST");
-        const char* sort_env = getenv("SA_SPAN_SORT");
-        const char* multi_env = getenv("SA_SPAN_MULTI");
-        if ((fast_env && atoi(fast_env) == 0) || (sort_env && atoi(sort_env) > 0) || (multi_env && atoi(multi_env) == 0)) return SA_OK;
+        if (sa_opt(ix->opts.span_fast, 1) == 0 || sa_opt(ix->opts.span_sort, -1) > 0 || sa_opt(ix->opts.span_multi, 1) == 0) return SA_OK;
         if (ix->h_term_edge.size() < (size_t)ix->n_terms) return SA_OK;
     }
-    const char* ddenv = getenv("SA_SPAN_DOCDIR");
-    const bool use_dd = ix->n_dd_terms > 0 && !(ddenv && atoi(ddenv) == 0);
+    const bool use_dd = ix->n_dd_terms > 0 && sa_opt(ix->opts.span_docdir, 1) != 0;
     std::vector<SpanJob> jobs;
     std::vector<SpanDocParams> djobs[3];               // phrases of 2 / 3 / 4 terms on the doc-parallel route
     std::vector<int> drow[3];
-    const bool doc_route = sa_env_span_doc() && !(getenv("SA_SPAN_DOC_MULTI") && atoi(getenv("SA_SPAN_DOC_MULTI")) == 0);
+    const bool doc_route = sa_opt_span_doc(ix) && sa_opt(ix->opts.span_doc_multi, 1) != 0;
     // the doc-parallel phrases rank their documents inside the kernel (no count vector) when the caller hands its ranking state
-    const bool fused_rank = rank && rank->cand && !(getenv("SA_SPAN_DOC_RANK") && atoi(getenv("SA_SPAN_DOC_RANK")) == 0);
+    const bool fused_rank = rank && rank->cand && sa_opt(ix->opts.span_doc_rank, 1) != 0;
     std::vector<int> job_row, job_class;
     std::vector<size_t> job_off;                       // scratch offset of each job
     size_t used = 0;
@@ -2403,7 +2394,10 @@ extern "C" int sa_span_search(const uint64_t* posns, const uint64_t* lengths, in
     SA_HIP(hipMemcpyAsync(d_cnt, h_cnt, sizeof(h_cnt), hipMemcpyHostToDevice, st));
     u32 G = (h_cnt[0] + 63u) & ~63u;
     u32 g_max = SA_SPAN_THREADS;
-    if (const char* v = getenv("SA_SPAN_THREADS")) { const int x = atoi(v); if (x >= 64) g_max = ((u32)x + 63u) & ~63u; }
+    {
+        const sa_options_t o = sa_options_for_new_handle(nullptr);      // (a Part-1 mirror: no index handle; the calling thread's options)
+        if (sa_opt(o.span_threads, 0) >= 64) g_max = ((u32)o.span_threads + 63u) & ~63u;
+    }
     if (G > g_max) G = g_max;
     SpanEnt* ents; u64* col;
     SA_TRY(bufs.take((void**)&ents, (size_t)G * SA_NSPANS * sizeof(SpanEnt)));

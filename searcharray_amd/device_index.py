@@ -15,6 +15,7 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
+from . import options as _options
 from ._lib import IndexInfo, as_f32, as_u32, as_u64, p_f32, p_u32, p_u64
 
 NO_TERM = 0xFFFFFFFF
@@ -87,11 +88,13 @@ def _pool(api) -> _PinnedPool:
     return pool
 
 
-class DeviceIndex:
+class DeviceIndex(_options.OptionsMixin):
+    _opt_setter = "sa_index_set_options"
+
     def __init__(self, words: np.ndarray, term_off: np.ndarray, doc_lens: np.ndarray,
                  avg_doc_len: Optional[float] = None, corpus_size: Optional[int] = None,
                  doc_base: int = 0, device: int = 0, tile_docs: int = 0, api=None,
-                 global_df: Optional[np.ndarray] = None):
+                 global_df: Optional[np.ndarray] = None, opts=None):
         self.api = api if api is not None else _lib.api()
         words = as_u64(words)
         term_off = as_u64(term_off)
@@ -103,9 +106,11 @@ class DeviceIndex:
                                       else (avg_doc_len or 0.0))
         self.corpus_size = int(self.n_docs if corpus_size is None else corpus_size)
         self._h = ctypes.c_void_p()
-        self.api.call("sa_index_create", int(device), self.n_docs, self.doc_base, self.n_terms,
-                      p_u64(words), p_u64(term_off), p_f32(doc_lens), self.avg_doc_len,
-                      self.corpus_size, int(tile_docs), ctypes.byref(self._h))
+        with _options.creating(self.api, opts):
+            self.api.call("sa_index_create", int(device), self.n_docs, self.doc_base, self.n_terms,
+                          p_u64(words), p_u64(term_off), p_f32(doc_lens), self.avg_doc_len,
+                          self.corpus_size, int(tile_docs), ctypes.byref(self._h))
+        self._init_opts(opts)
         self._local_df = None
         self._global_df = None if global_df is None else np.asarray(global_df, dtype=np.uint64)
 
@@ -113,7 +118,7 @@ class DeviceIndex:
     def from_tokens(cls, tokens: np.ndarray, doc_ptr: np.ndarray, n_terms: int,
                     doc_lens: Optional[np.ndarray] = None, avg_doc_len: Optional[float] = None,
                     corpus_size: Optional[int] = None, doc_base: int = 0, device: int = 0, tile_docs: int = 0,
-                    api=None, global_df: Optional[np.ndarray] = None) -> "DeviceIndex":
+                    api=None, global_df: Optional[np.ndarray] = None, opts=None) -> "DeviceIndex":
         """Build the index on the device from the token stream: ``tokens[doc_ptr[d]:doc_ptr[d+1]]`` are
         the term ids of doc ``d`` in position order (what a tokenizer + term dictionary produce).
         Sort by term and roaringish encoding happen on the GPU (reference indexing.py:102-115,
@@ -132,9 +137,11 @@ class DeviceIndex:
                                       else (avg_doc_len or 0.0))
         self.corpus_size = int(self.n_docs if corpus_size is None else corpus_size)
         self._h = ctypes.c_void_p()
-        self.api.call("sa_index_create_from_tokens", int(device), self.n_docs, self.doc_base, self.n_terms,
-                      p_u32(tokens), p_u64(doc_ptr), p_f32(doc_lens), self.avg_doc_len,
-                      self.corpus_size, int(tile_docs), ctypes.byref(self._h))
+        with _options.creating(self.api, opts):
+            self.api.call("sa_index_create_from_tokens", int(device), self.n_docs, self.doc_base, self.n_terms,
+                          p_u32(tokens), p_u64(doc_ptr), p_f32(doc_lens), self.avg_doc_len,
+                          self.corpus_size, int(tile_docs), ctypes.byref(self._h))
+        self._init_opts(opts)
         self._local_df = None
         self._global_df = None if global_df is None else np.asarray(global_df, dtype=np.uint64)
         return self
@@ -143,7 +150,7 @@ class DeviceIndex:
     def from_file(cls, path: str, metadata, doc_lens: np.ndarray, n_terms: Optional[int] = None,
                   avg_doc_len: Optional[float] = None, corpus_size: Optional[int] = None, doc_base: int = 0,
                   device: int = 0, tile_docs: int = 0, api=None,
-                  global_df: Optional[np.ndarray] = None) -> "DeviceIndex":
+                  global_df: Optional[np.ndarray] = None, opts=None) -> "DeviceIndex":
         """Stream an index from the reference's on-disk format straight into HBM: ``path`` is the raw
         uint64 ``.dat`` file MemoryMappedArrays writes (reference phrase/memmap_arrays.py:158-161) and
         ``metadata`` its ArrayDict metadata ``{term_id: {'offset': o, 'length': n}}`` (element units,
@@ -182,9 +189,11 @@ class DeviceIndex:
                                       else (avg_doc_len or 0.0))
         self.corpus_size = int(self.n_docs if corpus_size is None else corpus_size)
         self._h = ctypes.c_void_p()
-        self.api.call("sa_index_create_from_file", int(device), self.n_docs, self.doc_base, self.n_terms,
-                      os.fsencode(path), p_u64(src), p_u64(length), p_f32(doc_lens), self.avg_doc_len,
-                      self.corpus_size, int(tile_docs), ctypes.byref(self._h))
+        with _options.creating(self.api, opts):
+            self.api.call("sa_index_create_from_file", int(device), self.n_docs, self.doc_base, self.n_terms,
+                          os.fsencode(path), p_u64(src), p_u64(length), p_f32(doc_lens), self.avg_doc_len,
+                          self.corpus_size, int(tile_docs), ctypes.byref(self._h))
+        self._init_opts(opts)
         self._local_df = None
         self._global_df = None if global_df is None else np.asarray(global_df, dtype=np.uint64)
         return self
@@ -193,9 +202,9 @@ class DeviceIndex:
         """Write the resident words to ``path`` as one raw uint64 file (the reference's ``.dat``,
         phrase/memmap_arrays.py:158-161), device -> page-locked ring -> file.  Returns the term
         offsets ``uint64[V+1]`` that index it (term t = elements [off[t], off[t+1]))."""
-        self.api.call("sa_index_save", self._h, os.fsencode(path))
+        self._call("sa_index_save", self._h, os.fsencode(path))
         term_off = np.empty(self.n_terms + 1, dtype=np.uint64)
-        self.api.call("sa_index_words", self._h, None, p_u64(term_off))
+        self._call("sa_index_words", self._h, None, p_u64(term_off))
         return term_off
 
     def words(self) -> Tuple[np.ndarray, np.ndarray]:
@@ -203,7 +212,7 @@ class DeviceIndex:
         info = self.info()
         words = np.empty(int(info.n_words), dtype=np.uint64)
         term_off = np.empty(self.n_terms + 1, dtype=np.uint64)
-        self.api.call("sa_index_words", self._h, p_u64(words), p_u64(term_off))
+        self._call("sa_index_words", self._h, p_u64(words), p_u64(term_off))
         return words, term_off
 
     # -- lifetime
@@ -227,11 +236,11 @@ class DeviceIndex:
             pass
 
     def synchronize(self):
-        self.api.call("sa_index_synchronize", self._h)
+        self._call("sa_index_synchronize", self._h)
 
     def info(self) -> IndexInfo:
         out = IndexInfo()
-        self.api.call("sa_index_info", self._h, ctypes.byref(out))
+        self._call("sa_index_info", self._h, ctypes.byref(out))
         return out
 
     # -- statistics
@@ -240,7 +249,7 @@ class DeviceIndex:
         if self._local_df is None:
             out = np.empty(self.n_terms, dtype=np.uint64)
             if self.n_terms:
-                self.api.call("sa_index_docfreqs", self._h, p_u64(out))
+                self._call("sa_index_docfreqs", self._h, p_u64(out))
             self._local_df = out
         return self._local_df
 
@@ -248,7 +257,7 @@ class DeviceIndex:
         """one float32 idf per term, formed by the caller as the reference forms it (similarity.py:19-21);
         ``QueryBatch.step`` gathers a query set's weights from it inside the library"""
         t = as_f32(idf)
-        self.api.call("sa_index_set_idf_table", self._h, p_f32(t), len(t))
+        self._call("sa_index_set_idf_table", self._h, p_f32(t), len(t))
 
     @staticmethod
     def comm_library_info(api=None):
@@ -276,19 +285,19 @@ class DeviceIndex:
         ptr = p_f32 if dtype == np.float32 else (lambda a: a.ctypes.data_as(ctypes.c_void_p))
         if rows is None:
             out = _pool(self.api).empty(self.n_docs, dtype)
-            self.api.call(fn, self._h, *args, ptr(out))
+            self._call(fn, self._h, *args, ptr(out))
             return out
         rows = as_u64(rows)
         out = np.empty(len(rows), dtype=dtype)
         dest = _lib.DenseDest(p_u64(rows), len(rows), None, np.float32(1.0), 0)
-        self.api.call(fn + "_to", self._h, *args, ctypes.byref(dest), ptr(out))
+        self._call(fn + "_to", self._h, *args, ctypes.byref(dest), ptr(out))
         return out
 
     def into_vec(self, vec: "DeviceVec", boost: Optional[float], fn: str, *args) -> None:
         """Run a dense C-ABI call with its result diverted into ``vec`` (float32[n_docs] on the device),
         multiplied by ``boost`` if given (the call's `_to` twin: the destination is an argument)."""
         dest = _lib.DenseDest(None, 0, vec._h, np.float32(1.0 if boost is None else boost), 0 if boost is None else 1)
-        self.api.call(fn + "_to", self._h, *args, ctypes.byref(dest), None)
+        self._call(fn + "_to", self._h, *args, ctypes.byref(dest), None)
 
     # -- term frequencies
     @staticmethod
@@ -313,7 +322,7 @@ class DeviceIndex:
         ids = np.empty(df, dtype=np.uint64)
         tfs = np.empty(df, dtype=np.float32)
         n = _lib.c_int64(0)
-        self.api.call("sa_index_termfreqs_sparse", self._h, term, p_u64(ids), p_f32(tfs), n)
+        self._call("sa_index_termfreqs_sparse", self._h, term, p_u64(ids), p_f32(tfs), n)
         return ids[:n.value], tfs[:n.value]
 
     # -- scoring
@@ -372,23 +381,23 @@ class DeviceIndex:
         """(kernel ms, algorithmic bytes) of the last phrase call."""
         ms = _lib.c_double(0)
         ab = _lib.c_uint64(0)
-        self.api.call("sa_index_last_profile", self._h, ctypes.byref(ms), ctypes.byref(ab))
+        self._call("sa_index_last_profile", self._h, ctypes.byref(ms), ctypes.byref(ab))
         return ms.value, ab.value
 
     def batch(self, queries: np.ndarray, k: int = 10, k1: float = 1.2, b: float = 0.75,
-              idf: Optional[np.ndarray] = None) -> "QueryBatch":
-        return QueryBatch(self, queries, k=k, k1=k1, b=b, idf=idf)
+              idf: Optional[np.ndarray] = None, opts=None) -> "QueryBatch":
+        return QueryBatch(self, queries, k=k, k1=k1, b=b, idf=idf, opts=opts)
 
     def phrase_batch(self, phrases: Sequence[Sequence[int]], k: int = 10, k1: float = 1.2, b: float = 0.75,
-                     idf: Optional[np.ndarray] = None, slop=0) -> "PhraseBatch":
-        return PhraseBatch(self, phrases, k=k, k1=k1, b=b, idf=idf, slop=slop)
+                     idf: Optional[np.ndarray] = None, slop=0, opts=None) -> "PhraseBatch":
+        return PhraseBatch(self, phrases, k=k, k1=k1, b=b, idf=idf, slop=slop, opts=opts)
 
     # -- multi-GPU
     def comm_init(self, rank: int, nranks: int, unique_id: bytes):
-        self.api.call("sa_index_comm_init", self._h, rank, nranks, unique_id, len(unique_id))
+        self._call("sa_index_comm_init", self._h, rank, nranks, unique_id, len(unique_id))
 
     def comm_destroy(self):
-        self.api.call("sa_index_comm_destroy", self._h)
+        self._call("sa_index_comm_destroy", self._h)
 
     @staticmethod
     def comm_unique_id(api=None) -> bytes:
@@ -409,19 +418,21 @@ class DeviceIndex:
             raise TypeError("comm_allreduce takes uint64 or float64 arrays")
         if not arr.flags.c_contiguous or not arr.flags.writeable:
             raise ValueError("comm_allreduce works in place on a contiguous writable array")
-        self.api.call("sa_index_comm_allreduce", self._h, arr.ctypes.data_as(ctypes.c_void_p), arr.size, dt,
+        self._call("sa_index_comm_allreduce", self._h, arr.ctypes.data_as(ctypes.c_void_p), arr.size, dt,
                       {"sum": 0, "max": 1}[op])
         return arr
 
     def comm_barrier(self):
-        self.api.call("sa_index_comm_barrier", self._h)
+        self._call("sa_index_comm_barrier", self._h)
 
 
-class QueryBatch:
+class QueryBatch(_options.OptionsMixin):
+    _opt_setter = "sa_batch_set_options"
+
     """B queries x T terms resident on the device; ``run()`` is one pass of the hot path."""
 
     def __init__(self, index: DeviceIndex, queries: np.ndarray, k: int = 10, k1: float = 1.2,
-                 b: float = 0.75, idf: Optional[np.ndarray] = None):
+                 b: float = 0.75, idf: Optional[np.ndarray] = None, opts=None):
         self.index = index
         self.api = index.api
         q = np.asarray(queries, dtype=np.int64)
@@ -435,7 +446,10 @@ class QueryBatch:
             idf = flat.reshape(self.B, self.T)
         idf = as_f32(idf)
         self._h = ctypes.c_void_p()
-        self._create(index, terms, idf, k1, b)
+        base = _options.Options(index._opts_base, opts)          # a batch starts from its index's options + its own
+        with _options.creating(self.api, base):
+            self._create(index, terms, idf, k1, b)
+        self._init_opts(base)
         index._track(self)
 
     def _create(self, index, terms, idf, k1, b):
@@ -453,7 +467,7 @@ class QueryBatch:
         if idf is None:
             idf = self.index.idfs(q.reshape(-1)).reshape(self.B, self.T)
         idf = as_f32(idf)
-        self.api.call("sa_batch_reset", self._h, p_u32(as_u32(terms)), p_f32(idf))
+        self._call("sa_batch_reset", self._h, p_u32(as_u32(terms)), p_f32(idf))
 
     def step(self, queries: np.ndarray):
         """reset + run(sync=False) in ONE library call, the weights gathered from the index's idf table
@@ -461,48 +475,48 @@ class QueryBatch:
         q = np.ascontiguousarray(queries, dtype=np.uint32)
         if q.shape != (self.B, self.T):
             raise ValueError(f"step takes [{self.B}][{self.T}] term ids")
-        self.api.call("sa_batch_step", self._h, p_u32(q))
+        self._call("sa_batch_step", self._h, p_u32(q))
 
     def run(self, sync: bool = True):
-        self.api.call("sa_batch_run", self._h, 1 if sync else 0)
+        self._call("sa_batch_run", self._h, 1 if sync else 0)
 
     def run_local(self, local_keys_device_ptr: int = 0, sync: bool = True):
-        self.api.call("sa_batch_run_local", self._h, ctypes.c_void_p(local_keys_device_ptr), 1 if sync else 0)
+        self._call("sa_batch_run_local", self._h, ctypes.c_void_p(local_keys_device_ptr), 1 if sync else 0)
 
     def merge_gathered(self, gathered_device_ptr: int, nranks: int, sync: bool = True):
-        self.api.call("sa_batch_merge_gathered", self._h, ctypes.c_void_p(gathered_device_ptr), nranks,
+        self._call("sa_batch_merge_gathered", self._h, ctypes.c_void_p(gathered_device_ptr), nranks,
                       1 if sync else 0)
 
     def fetch(self) -> Tuple[np.ndarray, np.ndarray]:
         scores = np.empty((self.B, self.k), dtype=np.float32)
         docs = np.empty((self.B, self.k), dtype=np.uint64)
-        self.api.call("sa_batch_fetch", self._h, p_f32(scores), p_u64(docs))
+        self._call("sa_batch_fetch", self._h, p_f32(scores), p_u64(docs))
         return scores, docs
 
     def profile(self) -> Tuple[float, int, int]:
         ms = _lib.c_double(0)
         alg = _lib.c_uint64(0)
         post = _lib.c_uint64(0)
-        self.api.call("sa_batch_profile", self._h, ctypes.byref(ms), ctypes.byref(alg), ctypes.byref(post))
+        self._call("sa_batch_profile", self._h, ctypes.byref(ms), ctypes.byref(alg), ctypes.byref(post))
         return ms.value, alg.value, post.value
 
     def group_info(self) -> dict:
         """how the exhaustive path groups this batch: groups, queries in groups, of them with a shared first term
         (the others are loose groups), queries left to the per-query kernel"""
         out = (_lib.c_uint32 * 4)()
-        self.api.call("sa_batch_group_info", self._h, out)
+        self._call("sa_batch_group_info", self._h, out)
         return {"groups": int(out[0]), "grouped_queries": int(out[1]), "shared_first_term": int(out[2]), "per_query_kernel": int(out[3])}
 
     def seeds(self) -> np.ndarray:
         """the bound every query of the current set starts with (sa_batch_seeds), float32[B], 0 = none"""
         out = np.zeros(self.B, dtype=np.float32)
-        self.api.call("sa_batch_seeds", self._h, p_f32(out))
+        self._call("sa_batch_seeds", self._h, p_f32(out))
         return out
 
     def host_times(self) -> dict:
         """host microseconds this batch's steps have cost so far, by part (sa_batch_host_times), and the number of query sets"""
         out = (_lib.c_uint64 * 4)()
-        self.api.call("sa_batch_host_times", self._h, out)
+        self._call("sa_batch_host_times", self._h, out)
         return {"fill_cpu_us": out[0] / 1e3, "fill_enqueue_us": out[1] / 1e3, "run_enqueue_us": out[2] / 1e3, "fills": int(out[3])}
 
     def stats(self, enable: bool = True) -> Tuple[int, int]:
@@ -510,7 +524,7 @@ class QueryBatch:
         were answered without a tile scan); diagnostics, switches the counting on / off."""
         cands = _lib.c_uint64(0)
         nq = _lib.c_uint64(0)
-        self.api.call("sa_batch_stats", self._h, 1 if enable else 0, ctypes.byref(cands), ctypes.byref(nq))
+        self._call("sa_batch_stats", self._h, 1 if enable else 0, ctypes.byref(cands), ctypes.byref(nq))
         return cands.value, nq.value
 
     def close(self):
@@ -534,7 +548,7 @@ class PhraseBatch(QueryBatch):
     :meth:`DeviceIndex.bm25_phrase_dense` (reference ``SearchArray.score([...])``)."""
 
     def __init__(self, index: DeviceIndex, phrases: Sequence[Sequence[int]], k: int = 10, k1: float = 1.2,
-                 b: float = 0.75, idf: Optional[np.ndarray] = None, slop=0):
+                 b: float = 0.75, idf: Optional[np.ndarray] = None, slop=0, opts=None):
         self.index = index
         self.api = index.api
         self.B = len(phrases)
@@ -545,10 +559,13 @@ class PhraseBatch(QueryBatch):
         self.k = int(k)
         terms, n_terms, slops, idf = self._pack(phrases, idf, slop)
         self._h = ctypes.c_void_p()
-        self.api.call("sa_phrase_batch_create_ex", index._h, p_u32(terms),
-                      n_terms.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
-                      slops.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), p_f32(idf), self.B, self.T,
-                      self.k, np.float32(k1), np.float32(b), ctypes.byref(self._h))
+        base = _options.Options(index._opts_base, opts)
+        with _options.creating(self.api, base):
+            self.api.call("sa_phrase_batch_create_ex", index._h, p_u32(terms),
+                          n_terms.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                          slops.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), p_f32(idf), self.B, self.T,
+                          self.k, np.float32(k1), np.float32(b), ctypes.byref(self._h))
+        self._init_opts(base)
         index._track(self)
 
     def _pack(self, phrases, idf, slop):
@@ -576,7 +593,7 @@ class PhraseBatch(QueryBatch):
     def reset(self, phrases: Sequence[Sequence[int]], idf: Optional[np.ndarray] = None, slop=0):
         """A new set of B phrases (none longer than the batch's max_terms) in this batch: ``sa_phrase_batch_reset``."""
         terms, n_terms, slops, idf = self._pack(phrases, idf, slop)
-        self.api.call("sa_phrase_batch_reset", self._h, p_u32(terms),
+        self._call("sa_phrase_batch_reset", self._h, p_u32(terms),
                       n_terms.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                       slops.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), p_f32(idf))
 

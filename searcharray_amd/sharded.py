@@ -22,6 +22,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
+from . import options as _options
 from . import roaringish as rz
 from .device_index import NO_TERM, DeviceIndex, compute_idf
 
@@ -50,9 +51,10 @@ class _ShardView(DeviceIndex):
     """A shard of a sharded handle as a ``DeviceIndex`` (dense drop-in calls, statistics): the handle is BORROWED from
     ``sa_sharded_shard`` -- the sharded handle owns it and destroys it."""
 
-    def __init__(self, api, handle, n_docs, n_terms, doc_base, avg_doc_len, corpus_size, global_df):     # noqa: D107 (no create)
+    def __init__(self, api, handle, n_docs, n_terms, doc_base, avg_doc_len, corpus_size, global_df, opts=None):     # noqa: D107 (no create)
         self.api = api
         self._h = handle
+        self._init_opts(opts)
         self.n_docs, self.n_terms, self.doc_base = int(n_docs), int(n_terms), int(doc_base)
         self.avg_doc_len = np.float32(avg_doc_len)
         self.corpus_size = int(corpus_size)
@@ -70,8 +72,9 @@ class ShardedIndex:
     reference's float64 arithmetic) and fans the dense drop-in calls out to the shards."""
 
     def __init__(self, words: np.ndarray, term_off: np.ndarray, doc_lens: np.ndarray, devices: Sequence[int],
-                 avg_doc_len: Optional[float] = None, tile_docs: int = 0, api=None):
+                 avg_doc_len: Optional[float] = None, tile_docs: int = 0, api=None, opts=None):
         self.api = api if api is not None else _lib.api()
+        self._opts = _options.Options(opts)
         self.devices = [int(d) for d in devices]
         G = len(self.devices)
         if G < 1:
@@ -87,8 +90,9 @@ class ShardedIndex:
         self.avg_doc_len = np.float32(np.mean(doc_lens) if avg_doc_len is None and self.n_docs else (avg_doc_len or 0.0))
         self._h = ct.c_void_p()
         dev_arr = (ct.c_int * G)(*self.devices)
-        self.api.call("sa_sharded_create", dev_arr, G, self.n_docs, self.n_terms, _lib.p_u64(words), _lib.p_u64(term_off),
-                      _lib.p_f32(doc_lens), self.avg_doc_len, int(tile_docs), ct.byref(self._h))
+        with _options.creating(self.api, self._opts):          # (the shard threads of the library start from the caller's options)
+            self.api.call("sa_sharded_create", dev_arr, G, self.n_docs, self.n_terms, _lib.p_u64(words), _lib.p_u64(term_off),
+                          _lib.p_f32(doc_lens), self.avg_doc_len, int(tile_docs), ct.byref(self._h))
         bounds = np.zeros(G + 1, dtype=np.uint64)
         n = ct.c_int(0)
         self.api.call("sa_sharded_info", self._h, ct.byref(n), _lib.p_u64(bounds))
@@ -101,11 +105,19 @@ class ShardedIndex:
             h = ct.c_void_p()
             self.api.call("sa_sharded_shard", self._h, g, ct.byref(h))
             self.shards.append(_ShardView(self.api, h, self.bounds[g + 1] - self.bounds[g], self.n_terms, self.bounds[g],
-                                          self.avg_doc_len, self.n_docs, self._df))
+                                          self.avg_doc_len, self.n_docs, self._df, opts=self._opts))
 
     def map(self, fn):
         """fn(shard_index, DeviceIndex) on every shard concurrently (dense drop-in calls)."""
-        return list(self._pool.map(lambda g: fn(g, self.shards[g]), range(len(self.shards))))
+        amb = _options.ambient()                                # (the pool threads work under the CALLER's scoped options)
+
+        def run(g):
+            _options._set_ambient(amb)
+            try:
+                return fn(g, self.shards[g])
+            finally:
+                _options._set_ambient(_options.Options())
+        return list(self._pool.map(run, range(len(self.shards))))
 
     def docfreq(self, term: int) -> np.uint64:
         return self._df[term] if 0 <= term < self.n_terms else np.uint64(0)
@@ -131,18 +143,19 @@ class ShardedIndex:
         return np.concatenate(self.map(lambda g, s: s.bm25_phrase_dense(terms, k1=k1, b=b, slop=slop, idf=idf)))
 
     # -- resident top-k batches
-    def batch(self, queries: np.ndarray, k: int = 10, k1: float = 1.2, b: float = 0.75) -> "ShardedBatch":
+    def batch(self, queries: np.ndarray, k: int = 10, k1: float = 1.2, b: float = 0.75, opts=None) -> "ShardedBatch":
         q = np.asarray(queries, dtype=np.int64)
         if q.ndim != 2:
             raise ValueError("queries must be [B][T] term ids")
         idf = _lib.as_f32(self.idfs(q.reshape(-1)).reshape(q.shape))
         terms = _lib.as_u32(np.where((q >= 0) & (q < self.n_terms), q, NO_TERM).astype(np.uint32))
         h = _lib.ctypes.c_void_p()
-        self.api.call("sa_sharded_batch_create", self._h, _lib.p_u32(terms), _lib.p_f32(idf), q.shape[0], q.shape[1], int(k),
-                      np.float32(k1), np.float32(b), _lib.ctypes.byref(h))
+        with _options.creating(self.api, _options.Options(self._opts, opts)):
+            self.api.call("sa_sharded_batch_create", self._h, _lib.p_u32(terms), _lib.p_f32(idf), q.shape[0], q.shape[1], int(k),
+                          np.float32(k1), np.float32(b), _lib.ctypes.byref(h))
         return ShardedBatch(self, h, q.shape[0], int(k), n_terms=q.shape[1])
 
-    def phrase_batch(self, phrases, k: int = 10, k1: float = 1.2, b: float = 0.75, slop=0) -> "ShardedBatch":
+    def phrase_batch(self, phrases, k: int = 10, k1: float = 1.2, b: float = 0.75, slop=0, opts=None) -> "ShardedBatch":
         ct = _lib.ctypes
         B = len(phrases)
         if B == 0:
@@ -159,9 +172,10 @@ class ShardedIndex:
         if (slops < 0).any():
             raise ValueError("slop must be >= 0")
         h = ct.c_void_p()
-        self.api.call("sa_sharded_phrase_batch_create", self._h, _lib.p_u32(_lib.as_u32(terms)),
-                      n_terms.ctypes.data_as(ct.POINTER(ct.c_int32)), slops.ctypes.data_as(ct.POINTER(ct.c_int32)),
-                      _lib.p_f32(_lib.as_f32(idf)), B, T, int(k), np.float32(k1), np.float32(b), ct.byref(h))
+        with _options.creating(self.api, _options.Options(self._opts, opts)):
+            self.api.call("sa_sharded_phrase_batch_create", self._h, _lib.p_u32(_lib.as_u32(terms)),
+                          n_terms.ctypes.data_as(ct.POINTER(ct.c_int32)), slops.ctypes.data_as(ct.POINTER(ct.c_int32)),
+                          _lib.p_f32(_lib.as_f32(idf)), B, T, int(k), np.float32(k1), np.float32(b), ct.byref(h))
         return ShardedBatch(self, h, B, int(k))
 
     def close(self):

@@ -52,3 +52,14 @@ def on_emu(request):
     there -- the GPU run keeps all of them."""
     cs = getattr(request.node, "callspec", None)
     return bool(cs and cs.params.get("api") == "emu")
+
+
+@pytest.fixture(autouse=True)
+def _option_scope():
+    """library options set by a test (tests.helpers.set_opt) end with it"""
+    from searcharray_amd import options
+    from tests import helpers
+    helpers._scope = options.Scope()
+    yield
+    helpers._scope.close()
+    helpers._scope = None

@@ -30,3 +30,18 @@ def dense_from_sparse(idx, val, n):
     out = np.zeros(n, dtype=np.float32)
     out[idx.astype(np.int64)] = val
     return out
+
+
+# ---- library options in tests: named values, not environment variables (include/searcharray_hip.h, Part 0) -------------
+# tests/conftest.py opens a searcharray_amd.options.Scope around every test (autouse); set_opt / unset_opt change it, and
+# every handle the test's thread creates or uses from then on follows (the switches' former environment names --
+# "SA_SPARSE" -- are accepted as names, strings as values).
+_scope = None
+
+
+def set_opt(name=None, value=None, **kw):
+    _scope.set(name, value, **kw) if name is not None else _scope.set(**kw)
+
+
+def unset_opt(*names):
+    _scope.unset(*names)

@@ -27,7 +27,6 @@
 #include <vector>
 
 #define __global__
-#define SA_OPAQUE_U32(x) ((void)(x))
 #define __device__
 #define __host__
 #define __forceinline__ inline

@@ -11,7 +11,7 @@ from oracle import refimpl as O
 from searcharray_amd import ops, synth
 from searcharray_amd import roaringish as rz
 from searcharray_amd.device_index import DeviceIndex, NO_DOC
-from tests.helpers import golden_corpus, oracle_index
+from tests.helpers import golden_corpus, oracle_index, set_opt, unset_opt
 
 
 def build_pair(name, tile_docs=1024, api=None):
@@ -101,7 +101,7 @@ def test_topk_massive_ties_takes_fallback_path(api, n, cap, monkeypatch):
     overflow the merge kernel's LDS list (in-place compaction + bisection over the survivors), and with
     a candidate list of 100 keys the list itself runs over: the batch is redone unpruned at fetch."""
     if cap:
-        monkeypatch.setenv("SA_CAND_CAP", cap)
+        set_opt("SA_CAND_CAP", cap)
     t = np.repeat(np.arange(3), n).astype(np.uint32)
     d = np.tile(np.arange(n), 3).astype(np.uint64)
     p = np.repeat(np.arange(3), n).astype(np.uint64)
@@ -126,7 +126,7 @@ def test_segmented_posting_derivation(api, seg_words, monkeypatch, on_emu):
     g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_sparse")
     words, wt = rz.encode_sorted(t, d, p)
     off = rz.term_offsets(wt, vocab)
-    monkeypatch.setenv("SA_SEG_WORDS", seg_words)
+    set_opt("SA_SEG_WORDS", seg_words)
     dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api)
     assert np.array_equal(dev.docfreqs(), g["df"])
     assert dev.info().n_postings == int(np.sum(g["df"]))
@@ -261,7 +261,7 @@ def test_rccl_exchange_single_rank():
 def test_unpruned_block_selection_path(small, k, monkeypatch):
     """SA_PRUNED_TOPK=0 forces the block-level threshold selection (the overflow fallback of the
     pruned path): same exact results."""
-    monkeypatch.setenv("SA_PRUNED_TOPK", "0")
+    set_opt("SA_PRUNED_TOPK", "0")
     g, dev, orc, vocab = small
     queries = g["or_queries"][:4]
     bt = dev.batch(queries, k=k)
@@ -329,7 +329,7 @@ def test_device_index_build_edge_cases(api):
 def test_large_k_slot_bound_path(small, k, monkeypatch):
     """k > 32 defaults to the histogram bound; SA_TOPK_HIST=0 keeps the slot bound (also what tiles of
     more than 4 waves and phrase batches use)"""
-    monkeypatch.setenv("SA_TOPK_HIST", "0")
+    set_opt("SA_TOPK_HIST", "0")
     test_topk_batch_matches_oracle(small, k)
 
 
@@ -342,8 +342,8 @@ def test_dynamic_pruning_is_exact(api, monkeypatch, sparse, tf8_div, k):
     """rare + frequent terms: queries with a rare term are answered by scoring candidates only (checked
     through the diagnostics counters), with and without dense tf rows in the index; all-frequent
     queries fall back to the tile scan; the top-k equals the exhaustive oracle bit for bit"""
-    monkeypatch.setenv("SA_SPARSE", sparse)
-    monkeypatch.setenv("SA_TF8_DIV", tf8_div)
+    set_opt("SA_SPARSE", sparse)
+    set_opt("SA_TF8_DIV", tf8_div)
     n_docs, vocab = 60000, 3000
     t, d, p, lens = synth.corpus_triples(n_docs, vocab, 12, seed=5)
     words, wt = rz.encode_sorted(t, d, p)
@@ -416,7 +416,7 @@ def test_impact_stream_exhaustive_scan(api, monkeypatch, integer_lens):
     term frequencies (outside the saturation table), odd and even posting counts (padding), unknown and
     repeated terms, fractional doc lengths (doc_lens gathered at build time), two batches with different
     (k1, b) alive at once, and a batch that outlives the index's cached stream."""
-    monkeypatch.setenv("SA_SPARSE", "0")
+    set_opt("SA_SPARSE", "0")
     n_docs, vocab = 9000, 400
     t, d, p, lens = synth.corpus_triples(n_docs, vocab, 150, seed=11)        # mean length 150: dl >= 128, tf > 8
     if not integer_lens:
@@ -432,7 +432,7 @@ def test_impact_stream_exhaustive_scan(api, monkeypatch, integer_lens):
     _check_batch(c, orc, queries, 20, k1=1.7, b=0.3)
     s_a2, d_a2 = _check_batch(a, orc, queries, 20)                            # `a` still owns its stream
     assert np.array_equal(s_a, s_a2) and np.array_equal(d_a, d_a2)
-    monkeypatch.setenv("SA_IMPACT", "0")                                      # same batch, TF-posting route
+    set_opt("SA_IMPACT", "0")                                      # same batch, TF-posting route
     s_b, d_b = _check_batch(a, orc, queries, 20)
     assert np.array_equal(s_a, s_b) and np.array_equal(d_a, d_b)
     e = dev.batch(queries, k=20, k1=0.9, b=0.0)                               # built without a stream at all
@@ -441,11 +441,11 @@ def test_impact_stream_exhaustive_scan(api, monkeypatch, integer_lens):
         bt.close()
     # nine terms per query: three groups of term phases (4 + 4 + 1), long slices in every position of a group,
     # rare / unknown / repeated terms in between
-    monkeypatch.delenv("SA_IMPACT")
+    unset_opt("SA_IMPACT")
     wide = np.asarray([[0, 399, 1, 398, 2, 397, 3, 396, 4], [399, 398, 397, 396, 395, 0, 1, 2, 3],
                        [7, 7, 450, 8, 300, 0, 451, 9, 7], [390, 391, 392, 393, 394, 395, 396, 397, 398]])
     for env in ("1", "0"):
-        monkeypatch.setenv("SA_IMPACT", env)
+        set_opt("SA_IMPACT", env)
         w = dev.batch(wide, k=15)
         _check_batch(w, orc, wide, 15)
         w.close()
@@ -454,7 +454,7 @@ def test_impact_stream_exhaustive_scan(api, monkeypatch, integer_lens):
 def test_dynamic_pruning_default_policy(api, monkeypatch):
     """SA_SPARSE unset: dynamic pruning only while the shard holds at least 32768 docs per requested result
     (below that the exhaustive kernel is the faster one); either way the top-k equals the oracle."""
-    monkeypatch.delenv("SA_SPARSE", raising=False)
+    unset_opt("SA_SPARSE")
     n_docs, vocab = 60000, 3000
     t, d, p, lens = synth.corpus_triples(n_docs, vocab, 12, seed=5)
     words, wt = rz.encode_sorted(t, d, p)
@@ -475,7 +475,7 @@ def test_threaded_batches_share_impact_streams(api, monkeypatch):
     serialises calls per index handle; an impact stream lives as long as a batch uses it, the index caches only
     the most recent one): every result equals the oracle's."""
     from concurrent.futures import ThreadPoolExecutor
-    monkeypatch.setenv("SA_SPARSE", "0")
+    set_opt("SA_SPARSE", "0")
     n_docs, vocab = 6000, 300
     t, d, p, lens = synth.corpus_triples(n_docs, vocab, 40, seed=3)
     words, wt = rz.encode_sorted(t, d, p)

@@ -15,6 +15,7 @@ import pytest
 from oracle import refimpl as O
 from searcharray_amd import synth
 from searcharray_amd.device_index import DeviceIndex
+from tests.helpers import set_opt, unset_opt
 
 pytestmark = pytest.mark.gpu
 D, V, K = 10_000_000, 100_000, 10
@@ -44,9 +45,9 @@ def zipf10m():
 
 def run(dev, queries, env, monkeypatch):
     for k_ in ("SA_SPARSE", "SA_GROUP"):
-        monkeypatch.delenv(k_, raising=False)
+        unset_opt(k_)
     for k_, v in env.items():
-        monkeypatch.setenv(k_, v)
+        set_opt(k_, v)
     bt = dev.batch(queries, k=K)
     bt.run()
     res = bt.fetch()
@@ -79,7 +80,7 @@ def test_config4_all_routes_agree_and_equal_the_oracle(zipf10m, monkeypatch):
 def test_config4_fresh_query_sets_through_one_call_per_step(zipf10m, monkeypatch):
     """the bench's step: sa_batch_step (idf gathered from the index's table + reset + run) on batch objects in flight"""
     dev, orc = zipf10m
-    monkeypatch.setenv("SA_SPARSE", "0")
+    set_opt("SA_SPARSE", "0")
     df = dev.docfreqs().astype(np.float64)
     dev.set_idf_table(np.log(1 + (D - df + 0.5) / (df + 0.5)).astype(np.float32))
     sets = [synth.bm25_queries(256, vocab=V, seed=1000 + i) for i in range(3)]

@@ -39,20 +39,11 @@ def zipf1m():
 
 
 def run_batch(dev, queries, k, env):
-    old = {key: os.environ.get(key) for key in ("SA_SPARSE", "SA_GROUP")}
-    os.environ.update(env)
-    try:
-        bt = dev.batch(queries, k=k)
-        bt.run()
-        res = bt.fetch()
-        bt.close()
-        return res
-    finally:
-        for key, v in old.items():
-            if v is None:
-                os.environ.pop(key, None)
-            else:
-                os.environ[key] = v
+    bt = dev.batch(queries, k=k, opts=env)                     # (the routes are options of the batch: "SA_SPARSE" -> sparse, ...)
+    bt.run()
+    res = bt.fetch()
+    bt.close()
+    return res
 
 
 @pytest.mark.parametrize("k", [10, 1000])

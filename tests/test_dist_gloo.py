@@ -9,9 +9,9 @@ import socket
 import numpy as np
 import pytest
 
-torch = pytest.importorskip("torch")
-import torch.distributed as dist          # noqa: E402
-import torch.multiprocessing as mp        # noqa: E402
+# torch is imported INSIDE the test and its workers, never at collection: its wheel bundles a librccl.so whose SONAME matches
+# /opt/rocm's, and a process that has mapped torch's copy first resolves libsearcharray_hip.so's collectives against it -- the
+# GPU suite (which deselects this module) must load the RCCL the library was linked against (tests/test_sharded.py checks).
 
 N_DOCS, VOCAB, K = 6000, 300, 10
 QUERIES = np.asarray([[0, 5, 50, 200], [1, 2, 3, 4], [7, 90, 150, 299], [10, 11, 12, 13]])
@@ -32,6 +32,8 @@ def _corpus():
 
 
 def _worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from searcharray_amd import roaringish as rz
@@ -74,6 +76,8 @@ def _worker(rank, world, port, out_dir):
 
 
 def test_two_rank_sharded_topk_matches_single_index_oracle(tmp_path):
+    pytest.importorskip("torch")
+    import torch.multiprocessing as mp
     from oracle import refimpl as O
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)

@@ -7,6 +7,7 @@ from oracle import refimpl as O
 from searcharray_amd import roaringish as rz
 from searcharray_amd import synth
 from searcharray_amd.device_index import DeviceIndex, NO_DOC
+from tests.helpers import set_opt, unset_opt
 
 
 @pytest.mark.parametrize("seed", [11, 12, 13])
@@ -16,7 +17,7 @@ def test_random_bm25_batches_pruned_and_exhaustive(api, seed, monkeypatch):
         n_docs, vocab, mean = int(rng.integers(50, 6000)), int(rng.integers(5, 600)), int(rng.integers(2, 30))
         t, d, p, lens = synth.corpus_triples(n_docs, vocab, mean, seed=int(rng.integers(1 << 30)))
         words, wt = rz.encode_sorted(t, d, p)
-        monkeypatch.setenv("SA_TF8_DIV", str(rng.choice([0, 8, 128, 100000])))
+        set_opt("SA_TF8_DIV", str(rng.choice([0, 8, 128, 100000])))
         dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=int(rng.choice([1024, 2048, 4096])), api=api)
         orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
         T, B, k = int(rng.integers(1, 7)), int(rng.integers(1, 7)), int(rng.choice([1, 3, 10, 33, 100]))
@@ -25,7 +26,7 @@ def test_random_bm25_batches_pruned_and_exhaustive(api, seed, monkeypatch):
         k1, b = float(rng.choice([1.2, 0.4, 2.0])), float(rng.choice([0.75, 0.0, 1.0]))
         got = {}
         for sparse in ("1", "0"):
-            monkeypatch.setenv("SA_SPARSE", sparse)
+            set_opt("SA_SPARSE", sparse)
             bt = dev.batch(queries, k=k, k1=k1, b=b)
             bt.run()
             got[sparse] = bt.fetch()
@@ -48,8 +49,8 @@ def test_random_phrases_batches_and_slop(api, seed, monkeypatch):
         n_docs, vocab, mean = int(rng.integers(50, 5000)), int(rng.integers(4, 60)), int(rng.integers(3, 60))
         t, d, p, lens = synth.corpus_triples(n_docs, vocab, mean, seed=int(rng.integers(1 << 30)))
         words, wt = rz.encode_sorted(t, d, p)
-        monkeypatch.setenv("SA_DOCDIR_DIV", str(rng.choice([0, 4, 32, 100000])))
-        monkeypatch.setenv("SA_PTILE", str(rng.choice([2048, 4096])))
+        set_opt("SA_DOCDIR_DIV", str(rng.choice([0, 4, 32, 100000])))
+        set_opt("SA_PTILE", str(rng.choice([2048, 4096])))
         dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
         orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
         phrases = [[int(x) for x in rng.choice(vocab, int(rng.integers(2, min(8, vocab))), replace=False)]

@@ -8,6 +8,7 @@ import pytest
 from oracle import refimpl as O
 from searcharray_amd import roaringish as rz, synth
 from searcharray_amd.device_index import DeviceIndex
+from tests.helpers import set_opt, unset_opt
 
 N_DOCS, VOCAB = 9000, 400
 
@@ -52,7 +53,7 @@ def band_queries(rng, n, T, heads):
 @pytest.mark.parametrize("T", [1, 2, 3, 4, 6, 10])
 @pytest.mark.parametrize("k", [3, 50])
 def test_grouped_equals_oracle(api, corpus, monkeypatch, T, k):
-    monkeypatch.setenv("SA_SPARSE", "0")
+    set_opt("SA_SPARSE", "0")
     rng = np.random.default_rng(100 + T + k)
     queries = band_queries(rng, 40, T, heads=[0, 1, 2, 7, 350])
     check(api, corpus, queries, k)
@@ -61,8 +62,8 @@ def test_grouped_equals_oracle(api, corpus, monkeypatch, T, k):
 @pytest.mark.parametrize("maxq", ["1", "5", "12"])
 def test_grouped_items_of_fewer_queries(api, corpus, monkeypatch, maxq):
     """SA_GROUP_MAXQ: groups cut into pieces of at most 1 / 5 / 12 queries instead of 16 (more, shorter items)"""
-    monkeypatch.setenv("SA_SPARSE", "0")
-    monkeypatch.setenv("SA_GROUP_MAXQ", maxq)
+    set_opt("SA_SPARSE", "0")
+    set_opt("SA_GROUP_MAXQ", maxq)
     rng = np.random.default_rng(19)
     queries = band_queries(rng, 40, 4, heads=[0, 1, 7])
     check(api, corpus, queries, 10)
@@ -73,8 +74,8 @@ def test_grouped_items_of_fewer_queries(api, corpus, monkeypatch, maxq):
 def test_grouped_without_warm_tiles_and_other_tile_sizes(api, corpus, monkeypatch, warm, tile_docs):
     """SA_GROUP_WARM=0: no tile goes through the per-query kernel first, so every query starts below its base
     values (bound 0) and takes the general path until the bound stands"""
-    monkeypatch.setenv("SA_SPARSE", "0")
-    monkeypatch.setenv("SA_GROUP_WARM", warm)
+    set_opt("SA_SPARSE", "0")
+    set_opt("SA_GROUP_WARM", warm)
     rng = np.random.default_rng(7)
     queries = band_queries(rng, 24, 4, heads=[0, 3])
     check(api, corpus, queries, 10, tile_docs=tile_docs, doc_base=50_000)
@@ -84,13 +85,13 @@ def test_grouped_dense_further_terms_duplicates_unknowns(api, corpus, monkeypatc
     """further terms with more postings per tile than the overlay holds (general path), the shared term again
     among the further terms, repeated further terms, unknown terms, a group of one (SA_GROUP_MIN=1), more
     queries than one group item takes (split), and a batch where nothing is grouped"""
-    monkeypatch.setenv("SA_SPARSE", "0")
-    monkeypatch.setenv("SA_GROUP_WARM", "1")
+    set_opt("SA_SPARSE", "0")
+    set_opt("SA_GROUP_WARM", "1")
     queries = [[0, 1, 2, 3], [0, 0, 0, 5], [0, 2, 1, 1], [0, 390, 390, 9], [0, 4000, 17, 4001], [0, 4000, 4000, 4000],
                [5, 1, 0, 2], [5, 300, 301, 302], [4000, 0, 1, 2], [9, 8, 7, 6]]
     queries += [[0, 10 + i, 200 + i, 399 - i] for i in range(70)]
     check(api, corpus, queries, 7)
-    monkeypatch.setenv("SA_GROUP_MIN", "1")
+    set_opt("SA_GROUP_MIN", "1")
     check(api, corpus, queries[:12], 7)
     check(api, corpus, [[i, i + 1, i + 2, i + 3] for i in range(0, 40, 4)], 5)
 
@@ -98,26 +99,26 @@ def test_grouped_dense_further_terms_duplicates_unknowns(api, corpus, monkeypatc
 def test_grouped_and_per_query_kernels_agree(api, corpus, monkeypatch):
     """same results with explicit (non-reference) idf weights, incl. two idf values for one first term (two
     groups) -- compared with the per-query kernel, SA_GROUP=0"""
-    monkeypatch.setenv("SA_SPARSE", "0")
+    set_opt("SA_SPARSE", "0")
     rng = np.random.default_rng(11)
     queries = band_queries(rng, 30, 4, heads=[0, 1])
     idf = rng.uniform(0.1, 9.0, size=queries.shape).astype(np.float32)
     idf[:, 0] = np.where(rng.random(len(queries)) < 0.5, np.float32(0.25), np.float32(1.5))
     idf[3] = 0.0                                                     # a query that scores nothing
     got = check(api, corpus, queries, 20, idf=idf)
-    monkeypatch.setenv("SA_GROUP", "0")
+    set_opt("SA_GROUP", "0")
     want = check(api, corpus, queries, 20, idf=idf)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
 
 
 def test_negative_idf_disables_grouping(api, corpus, monkeypatch):
     """the overlay marks touched docs with the sign bit: batches with a negative weight use the per-query kernel"""
-    monkeypatch.setenv("SA_SPARSE", "0")
+    set_opt("SA_SPARSE", "0")
     queries = np.asarray([[0, 5, 9, 100]] * 3 + [[0, 6, 8, 101]])
     idf = np.full(queries.shape, 2.0, dtype=np.float32)
     idf[1, 2] = -1.0
     got = check(api, corpus, queries, 5, idf=idf)
-    monkeypatch.setenv("SA_GROUP", "0")
+    set_opt("SA_GROUP", "0")
     want = check(api, corpus, queries, 5, idf=idf)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
 
@@ -127,7 +128,7 @@ def test_loose_groups_equal_oracle_and_per_query_kernel(api, corpus, monkeypatch
     """queries that share NO first term: those whose terms are sparse per tile are scored as LOOSE groups (no base,
     every term overlaid on cleared accumulators), the dense ones by the per-query kernel -- same results as the
     oracle, and as with loose groups switched off (SA_GROUP_LOOSE=0)"""
-    monkeypatch.setenv("SA_SPARSE", "0")
+    set_opt("SA_SPARSE", "0")
     rng = np.random.default_rng(500 + T)
     # distinct first terms; a few dense heads (terms 0..3) among mostly rare terms, repeated and unknown terms
     firsts = rng.permutation(np.arange(120, 400))[:36]             # (rare enough for loose groups: <= 128 expected postings per tile)
@@ -152,37 +153,46 @@ def test_loose_groups_equal_oracle_and_per_query_kernel(api, corpus, monkeypatch
     # no first term is shared; loose groups exist (when the half tables take all T terms of 16 queries) and the
     # query with the dense first term stays with the per-query kernel
     assert gi["shared_first_term"] == 0 and gi["per_query_kernel"] >= 1
-    assert gi["groups"] >= 1 and gi["grouped_queries"] >= 20     # (an item's four waves take up to 64 loose queries)
-    monkeypatch.setenv("SA_GROUP_LOOSE", "0")
+    assert gi["groups"] >= 2 and gi["grouped_queries"] >= 20
+    set_opt("SA_GROUP_LOOSE", "0")
     ref = check(api, corpus, queries, k, tile_docs=1024)
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
 
 
-@pytest.mark.parametrize("k", [40, 100])
-@pytest.mark.parametrize("seed_env", [{"SA_SEED": "1"}, {"SA_SEED": "0"}, {"SA_SEED": "1", "SA_SEED_J": "1"}, {"SA_SEED": "1", "SA_SEED_J": "3"},
-                                      {"SA_SEED": "1", "SA_TERM_SEED": "0"}, {"SA_SEED": "1", "SA_TERM_SEED": "0", "SA_SEED_J": "1"}])
-def test_optimistic_bounds_from_the_warm_up_sample(api, corpus, monkeypatch, k, seed_env):
-    """SA_SEED=1 (opt-in), k >= 32: after the warm-up tiles (2 of 9 here) every grouped query's bound is raised to the sample's
-    j-th best score (sa_k_seed_bounds), j from the sampling fraction -- or forced far too small (SA_SEED_J=1 / 3): then the merge finds fewer
-    than k keys above the bound, flags the run and fetch redoes the batch without bounds.  Results equal the oracle's either
-    way, in every run of the batch (the second run after a failed check is unseeded: the index has switched seeding off)"""
-    monkeypatch.setenv("SA_SPARSE", "0")
-    monkeypatch.setenv("SA_GROUP_WARM", "2")
-    for name, v in seed_env.items():
-        monkeypatch.setenv(name, v)
+@pytest.mark.parametrize("k", [5, 40])
+@pytest.mark.parametrize("pct,warm", [(100, None), (400, None), (400, 2), (150, None)])
+def test_starting_bounds_that_are_too_high_are_caught_and_the_run_redone(api, corpus, k, pct, warm):
+    """the safety net under the starting bounds (sa_k_topk_merge: fewer than k keys at or above a bound -- the kernel's own
+    or the rank tables' -- flags the run; sa_batch_redo_if_flagged redoes it without bounds): forced with the test hook
+    seed_scale_pct, which multiplies every starting bound (400 %: far above the best score; 150 %: above the k-th best of
+    most queries).  Results equal the oracle's in every run, also when the flagged run's batch is RESET before its results
+    are fetched: the redo happens while the device tables still hold the query set that run scored (round 4 redid at fetch
+    time, against the new set's tables)."""
+    set_opt(sparse=0, seed_scale_pct=pct)
+    if warm is not None:
+        set_opt(group_warm=warm)
     rng = np.random.default_rng(17 + k)
     queries = band_queries(rng, 36, 4, heads=[0, 1, 2])
+    other = band_queries(rng, 36, 4, heads=[0, 1, 2])
     words, off, lens, orc = corpus
     dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api)
     bt = dev.batch(np.asarray(queries), k=k)
-    for run in range(3):
-        bt.run(sync=False)
-        scores, docs = bt.fetch()
-        for qi, q in enumerate(queries):
+
+    def check_set(qs, scores, docs, what):
+        for qi, q in enumerate(qs):
             ws, wd = O.topk(orc.score_terms_sum([int(x) for x in q]), k)
             n = int((ws > 0).sum())
-            assert np.array_equal(scores[qi, :n], ws[:n]), f"run {run} q{qi} {q} scores"
-            assert np.array_equal(docs[qi, :n], wd[:n]), f"run {run} q{qi} {q} docs"
+            assert np.array_equal(scores[qi, :n], ws[:n]), f"{what} q{qi} {q} scores"
+            assert np.array_equal(docs[qi, :n], wd[:n]), f"{what} q{qi} {q} docs"
+    for run in range(2):
+        bt.run(sync=False)
+        check_set(queries, *bt.fetch(), f"run {run}")
+    # run (flagged when pct > 100) -> reset to another set -> fetch: the FIRST set's results
+    bt.run(sync=False)
+    bt.reset(np.asarray(other))
+    check_set(queries, *bt.fetch(), "run, reset, fetch")
+    bt.run(sync=False)
+    check_set(other, *bt.fetch(), "the new set")
     bt.close()
     dev.close()
 
@@ -194,9 +204,9 @@ def test_starting_bounds_from_the_terms_rank_tables(api, corpus, monkeypatch, k,
     sa_k_make_bounds).  No warm-up tiles here, so it is the only bound the first items see.  ONE-term queries are the sharp
     case: the k-th best doc's score IS weight x k-th largest factor, a bound one rank too high would lose it -- terms with
     fewer than k postings (no bound), exactly k, and thousands; then 2- and 4-term queries, repeated terms, zero weights"""
-    monkeypatch.setenv("SA_SPARSE", "0")
-    monkeypatch.setenv("SA_GROUP_WARM", "0")
-    monkeypatch.setenv("SA_GROUP", group)
+    set_opt("SA_SPARSE", "0")
+    set_opt("SA_GROUP_WARM", "0")
+    set_opt("SA_GROUP", group)
     words, off, lens, orc = corpus
     dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api)
     df = dev.docfreqs()
@@ -238,7 +248,7 @@ def test_starting_bounds_from_the_terms_rank_tables(api, corpus, monkeypatch, k,
     bt.run()
     got = bt.fetch()
     bt.close()
-    monkeypatch.setenv("SA_TERM_SEED", "0")
+    set_opt("SA_TERM_SEED", "0")
     bt = dev.batch(queries, k=k, idf=idf)
     bt.run()
     want = bt.fetch()

@@ -11,7 +11,7 @@ import pytest
 from searcharray_amd import SearchArray, roaringish as rz
 from searcharray_amd._lib import SearchArrayHipError
 from searcharray_amd.device_index import DeviceIndex
-from tests.helpers import golden_corpus, load_golden
+from tests.helpers import golden_corpus, load_golden, set_opt, unset_opt
 
 
 def _golden_file(tmp_path):
@@ -74,7 +74,7 @@ def test_file_in_any_term_order_and_with_gaps(api, tmp_path):
 def test_ring_wraps_with_many_pieces(api, tmp_path, monkeypatch, piece):
     """Tiny staging pieces (SA_IO_PIECE_BYTES) push hundreds of pieces through the 12-slot ring and its
     4 file threads, both directions."""
-    monkeypatch.setenv("SA_IO_PIECE_BYTES", piece)
+    set_opt("SA_IO_PIECE_BYTES", piece)
     g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_small")
     words, wt = rz.encode_sorted(t, d, p)
     off = rz.term_offsets(wt, vocab)

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import refimpl as O
-from tests.helpers import load_golden, oracle_index, dense_from_sparse
+from tests.helpers import load_golden, oracle_index, dense_from_sparse, golden_corpus
 
 u64 = lambda x: np.asarray(x, dtype=np.uint64)  # noqa: E731
 
@@ -206,3 +206,83 @@ def test_slop_matches_reference(name):
         assert np.array_equal(got, want), f"slop {terms} {slop}"
         _, _, overflow = S.span_search([idx.enc(t) for t in terms], slop, return_overflow=True)
         assert overflow == 0            # no doc fills the 512-span table (reference UB territory)
+
+
+# ---- the goldens against the REFERENCE ITSELF (oracle/_ref: /root/reference compiled by oracle/build_ref.sh) ----------------
+# The fixtures were written by tests/golden/make_golden.py from the reference's outputs; this re-scores them through the built
+# tree whenever it is present (this container; not the GPU box), so a drift between the generator, the fixtures and the
+# reference shows up under pytest, not only in a reviewer's shell.
+def _ref_or_skip():
+    from oracle import ref_loader
+    if not ref_loader.available():
+        pytest.skip("oracle/_ref is not built (bash oracle/build_ref.sh where /root/reference exists)")
+    return ref_loader
+
+
+@pytest.mark.parametrize("name", ["zipf_small", "zipf_sparse"])
+def test_corpus_goldens_equal_the_built_reference(name):
+    """df of every term, sparse tf, single-term BM25 (default and custom k1 / b), 4-term disjunctions (np.sum of score vectors,
+    test/test_msmarco.py:353), phrase counts + scores and slop counts of tests/golden/<name>.npz, recomputed by the reference's
+    own code (SearchArray.score / termfreqs / docfreq over the same words) -- bit for bit"""
+    _ref_or_skip().reference()
+    from searcharray.postings import SearchArray                    # (oracle/_ref is first on sys.path once loaded)
+    from searcharray.similarity import bm25_similarity
+    g, _, lens, num_docs, vocab = golden_corpus(name)
+    # indexed as tests/golden/make_golden.py indexed it: the token stream as whitespace documents through SearchArray.index
+    starts = np.zeros(num_docs + 1, dtype=np.int64)
+    np.cumsum(g["lens"], out=starts[1:])
+    docs = [" ".join(f"t{t}" for t in g["terms"][starts[i]:starts[i + 1]]) for i in range(num_docs)]
+    sa = SearchArray.index(docs, autowarm=False)
+    assert np.float32(sa.avg_doc_length) == g["avg_doc_length"]
+    assert np.array_equal(np.asarray([sa.docfreq(f"t{x}") for x in range(vocab)], dtype=np.uint64), g["df"])
+
+    def dense(idx, val):
+        out = np.zeros(num_docs, dtype=np.float32)
+        out[idx] = val
+        return out
+    for x in g["tf_terms"]:
+        assert np.array_equal(sa.termfreqs(f"t{x}"), dense(g[f"tf_{x}_idx"], g[f"tf_{x}_val"])), f"tf t{x}"
+    custom = bm25_similarity(k1=1.7, b=0.3)
+    for x in g["score_terms"]:
+        assert np.array_equal(sa.score(f"t{x}"), g[f"score_{x}"]), f"score t{x}"
+        assert np.array_equal(sa.score(f"t{x}", similarity=custom), g[f"score_custom_{x}"]), f"custom score t{x}"
+    for q, want in zip(g["or_queries"], g["or_scores"]):
+        assert np.array_equal(np.sum([sa.score(f"t{x}") for x in q], axis=0), want), f"disjunction {q}"
+    for i in range(int(g["n_phrases"])):
+        toks = [f"t{x}" for x in g[f"phr_{i}_terms"]]
+        assert np.array_equal(sa.termfreqs(toks), dense(g[f"phr_{i}_idx"], g[f"phr_{i}_val"])), f"phrase counts {toks}"
+        assert np.array_equal(sa.score(toks), dense(g[f"phr_{i}_sidx"], g[f"phr_{i}_sval"])), f"phrase scores {toks}"
+    for i in range(int(g["n_slop"])):
+        toks = [f"t{x}" for x in g[f"slop_{i}_terms"]]
+        slop = int(g[f"slop_{i}_slop"])
+        assert np.array_equal(sa.termfreqs(toks, slop=slop), dense(g[f"slop_{i}_idx"], g[f"slop_{i}_val"])), f"slop {slop} {toks}"
+
+
+def test_snp_fixture_goldens_equal_the_built_reference():
+    """tests/golden/snp_fixtures.npz (intersect / adjacent / intersect_with_adjacents / merge / unique / popcount64_reduce on
+    arrays captured from a reference run) recomputed by the reference's Cython kernels, called as make_golden.py calls them"""
+    _ref_or_skip().reference()
+    from searcharray.roaringish.intersect import intersect, adjacent, intersect_with_adjacents
+    from searcharray.roaringish.merge import merge
+    from searcharray.roaringish.unique import unique
+    from searcharray.roaringish.popcount import popcount64_reduce
+    g = load_golden("snp_fixtures")
+    tags = sorted({k.split("_")[0] for k in g.files})
+    assert tags
+    lsb_mask = np.uint64((1 << 18) - 1)
+    for tag in tags:
+        lhs, rhs, mask = g[f"{tag}_lhs"], g[f"{tag}_rhs"], np.uint64(g[f"{tag}_mask"])
+        li, ri = intersect(lhs, rhs, mask=mask)
+        assert np.array_equal(li, g[f"{tag}_int_drop_l"]) and np.array_equal(ri, g[f"{tag}_int_drop_r"]), tag
+        lk, rk = intersect(lhs, rhs, mask=mask, drop_duplicates=False)
+        assert np.array_equal(lk, g[f"{tag}_int_keep_l"]) and np.array_equal(rk, g[f"{tag}_int_keep_r"]), tag
+        a, b, c, d = intersect_with_adjacents(lhs, rhs, mask=mask)
+        for got, key in ((a, "iwa_l"), (b, "iwa_r"), (c, "iwa_al"), (d, "iwa_ar")):
+            assert np.array_equal(got, g[f"{tag}_{key}"]), f"{tag} {key}"
+        al, ar = adjacent(lhs, rhs, mask=mask)
+        assert np.array_equal(al, g[f"{tag}_adj_l"]) and np.array_equal(ar, g[f"{tag}_adj_r"]), tag
+        assert np.array_equal(merge(lhs, rhs), g[f"{tag}_merge"]), tag
+        assert np.array_equal(merge(lhs, rhs, drop_duplicates=True), g[f"{tag}_merge_drop"]), tag
+        assert np.array_equal(unique(lhs, 36), g[f"{tag}_unique36"]), tag
+        keys, counts = popcount64_reduce(lhs, np.uint64(36), lsb_mask)
+        assert np.array_equal(keys, g[f"{tag}_pcr_keys"]) and np.array_equal(counts, g[f"{tag}_pcr_counts"]), tag

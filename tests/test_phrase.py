@@ -10,7 +10,7 @@ from oracle import refimpl as O
 from searcharray_amd import synth
 from searcharray_amd import roaringish as rz
 from searcharray_amd.device_index import DeviceIndex, NO_DOC
-from tests.helpers import golden_corpus, dense_from_sparse
+from tests.helpers import golden_corpus, dense_from_sparse, set_opt, unset_opt
 from tests.test_oracle_golden import PHRASE_SCENARIOS, _index_strings
 
 
@@ -30,16 +30,11 @@ def _device_from_strings(docs, api):
 
 @pytest.fixture(params=["general", "auto"])
 def phrase_mode(request):
-    old = os.environ.get("SA_PHRASE_MODE")
     if request.param == "general":
-        os.environ["SA_PHRASE_MODE"] = "general"
+        set_opt("phrase_mode", "general")
     else:
-        os.environ.pop("SA_PHRASE_MODE", None)
+        unset_opt("phrase_mode")
     yield request.param
-    if old is None:
-        os.environ.pop("SA_PHRASE_MODE", None)
-    else:
-        os.environ["SA_PHRASE_MODE"] = old
 
 
 @pytest.mark.parametrize("docs,phrase,expected", PHRASE_SCENARIOS[:23:2])
@@ -59,9 +54,9 @@ def test_all_reference_phrase_scenarios_and_offsets_on_the_device(mode, monkeypa
     from searcharray_amd import _lib
     api = _lib.api()
     if mode == "general":
-        monkeypatch.setenv("SA_PHRASE_MODE", "general")
+        set_opt("SA_PHRASE_MODE", "general")
     else:
-        monkeypatch.delenv("SA_PHRASE_MODE", raising=False)
+        unset_opt("SA_PHRASE_MODE")
     for docs, phrase, expected in PHRASE_SCENARIOS:
         vocab, dev = _device_from_strings(docs, api)
         got = dev.phrase_freqs_dense([vocab[t] for t in phrase.split()])
@@ -113,10 +108,10 @@ def test_fused_equals_general_on_random_distinct_phrases(api):
             terms = [int(x) for x in rng.choice(12, length, replace=False)]
             want = orc.phrase_freqs(terms)
             for mode in ("general", "fused"):
-                os.environ["SA_PHRASE_MODE"] = mode
+                set_opt("phrase_mode", mode)
                 got = dev.phrase_freqs_dense(terms)
                 assert np.array_equal(got, want), f"{mode} {terms}"
-    os.environ.pop("SA_PHRASE_MODE", None)
+    unset_opt("phrase_mode")
 
 
 @pytest.mark.parametrize("seed", range(4))
@@ -125,9 +120,9 @@ def test_repeated_term_phrases_chain_per_document(api, seed, monkeypatch, capfd)
     of the rarest term, the general chain's steps on the document's few words, found through the doc directory or by
     search) instead of ~20 launches per bigram: counts equal to the oracle's (which is pinned to the reference, same-term rule and all) and to the general
     chain's, for every plan (left to right, right to left, middle out) and repeat pattern."""
-    monkeypatch.setenv("SA_PHRASE_TRACE", "1")
+    set_opt("trace", "1")
     if seed == 3:
-        monkeypatch.setenv("SA_DOCDIR_DIV", "0")         # no doc directory: the documents' words are found by search
+        set_opt("SA_DOCDIR_DIV", "0")         # no doc directory: the documents' words are found by search
     rng = np.random.default_rng(40 + seed)
     n_docs, vocab = int(rng.integers(400, 2500)), 5
     t, d, p, lens = synth.corpus_triples(n_docs, vocab, int(rng.integers(6, 40)), seed=70 + seed)
@@ -146,9 +141,9 @@ def test_repeated_term_phrases_chain_per_document(api, seed, monkeypatch, capfd)
         got = dev.phrase_freqs_dense(ph)
         taken += "chain per document taken" in capfd.readouterr().err
         assert np.array_equal(got, want), f"seed {seed} phrase {ph}: {np.flatnonzero(got != want)[:5]}"
-        monkeypatch.setenv("SA_PHRASE_DOCS", "0")
+        set_opt("SA_PHRASE_DOCS", "0")
         other = dev.phrase_freqs_dense(ph)
-        monkeypatch.delenv("SA_PHRASE_DOCS")
+        unset_opt("SA_PHRASE_DOCS")
         assert np.array_equal(other, want), f"general chain: seed {seed} phrase {ph}"
     dev.close()
     assert taken >= 10, taken
@@ -157,7 +152,7 @@ def test_repeated_term_phrases_chain_per_document(api, seed, monkeypatch, capfd)
 def test_long_distinct_phrases_chain_per_document(api, monkeypatch, capfd):
     """Pairwise-distinct phrases of 19-32 terms (more than the fused kernel's window) take the chain per document too;
     every plan: the rarest term at the front, at the end, in the middle."""
-    monkeypatch.setenv("SA_PHRASE_TRACE", "1")
+    set_opt("trace", "1")
     rng = np.random.default_rng(8)
     toks = [f"w{i}" for i in range(34)]
     docs = []
@@ -188,9 +183,9 @@ def test_words_in_a_documents_last_block_keep_the_general_routes(api, monkeypatc
     block 0, so neither the bigram chain nor the slop candidate sets are local to a document then.  The index records
     whether any such word exists; with one, slop phrases of terms without a directory row take the general route, the
     phrase chain per document steps aside when it meets such a word -- and the answers stay the oracle's."""
-    monkeypatch.setenv("SA_SPAN_TRACE", "1")
-    monkeypatch.setenv("SA_PHRASE_TRACE", "1")
-    monkeypatch.setenv("SA_DOCDIR_DIV", "0")                 # no directory rows: only the index-wide flag can vouch for locality
+    set_opt("trace", "1")
+    set_opt("trace", "1")
+    set_opt("SA_DOCDIR_DIV", "0")                 # no directory rows: only the index-wide flag can vouch for locality
     rng = np.random.default_rng(21)
     n_docs, vocab = 120, 4
     t, d, p, lens = synth.corpus_triples(n_docs, vocab, 12, seed=5)
@@ -226,7 +221,7 @@ def test_chain_per_document_gives_way_when_its_checks_fail(api, monkeypatch, cap
     answer -- (a) when a step it calls "different" has matched pairs that are ALL equal: `a b b` over documents in which
     every `b` follows an `a` (the continuation of `a b` then equals b's words), (b) when a document has more than six
     words of a term."""
-    monkeypatch.setenv("SA_PHRASE_TRACE", "1")
+    set_opt("trace", "1")
     # (a) 200 documents "a b a b ... " (+ a few with other terms so that every term is frequent)
     docs = ["a b " * int(1 + i % 7) for i in range(200)]
     vocab_o, dev = _device_from_strings(docs, api)
@@ -283,7 +278,7 @@ def test_slop_counts_match_reference(api, name):
 def test_slop_more_doc_groups_than_resident_threads(api, monkeypatch):
     """the state-machine grid is resident (threads stride over the document groups): force a grid
     of 64 threads over ~1500 groups"""
-    monkeypatch.setenv("SA_SPAN_THREADS", "64")
+    set_opt("SA_SPAN_THREADS", "64")
     g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_small")
     words, wt = rz.encode_sorted(t, d, p)
     dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
@@ -301,11 +296,11 @@ def test_slop_table_placements_and_probe_routes_agree(api, monkeypatch, fast, do
     with few positions and docs whose table outgrows the LDS column (> 12 spans), against the oracle (a table
     beyond the reference's 512 spans is undefined behaviour there -- see the fuzz test); document groups in work
     order vs index order (SA_SPAN_SORT=0)"""
-    monkeypatch.setenv("SA_SPAN_FAST", fast)
+    set_opt("SA_SPAN_FAST", fast)
     if sort != "-1":                                       # ("1" forces the work order on this small corpus, unset leaves it to the size rule)
-        monkeypatch.setenv("SA_SPAN_SORT", sort)
-    monkeypatch.setenv("SA_SPAN_DOCDIR", docdir)
-    monkeypatch.setenv("SA_DOCDIR_DIV", "1000000")          # a doc directory for every term of >= 64 words
+        set_opt("SA_SPAN_SORT", sort)
+    set_opt("SA_SPAN_DOCDIR", docdir)
+    set_opt("SA_DOCDIR_DIV", "1000000")          # a doc directory for every term of >= 64 words
     rng = np.random.default_rng(3)
     docs = []
     for i in range(400):
@@ -337,7 +332,7 @@ def test_slop_random_differential(api, seed, monkeypatch):
     """random corpora / queries: device span search == oracle (which is pinned to the reference); document groups in
     work order (forced: the size rule would leave these small corpora in index order) on the odd seeds"""
     from oracle import spans as S
-    monkeypatch.setenv("SA_SPAN_SORT", str(seed % 2))
+    set_opt("SA_SPAN_SORT", str(seed % 2))
     rng = np.random.default_rng(100 + seed)
     n_docs, vocab = int(rng.integers(200, 900)), int(rng.integers(8, 40))
     t, d, p, lens = synth.corpus_triples(n_docs, vocab, int(rng.integers(10, 70)), seed=seed)
@@ -367,7 +362,7 @@ def test_slop_doc_parallel_route(api, seed, monkeypatch, capfd):
     outgrow their column (redone by the lane's own wave), one and several sort blocks.  Two-term phrases take it whether or not header 0 is in L; three and four terms only when it is
     not -- doc 0 is kept free of the frequent terms on the even seeds so that both cases occur."""
     from oracle import spans as S
-    monkeypatch.setenv("SA_SPAN_TRACE", "1")
+    set_opt("trace", "1")
     rng = np.random.default_rng(700 + seed)
     # (one / several blocks; seed 3: a Zipf vocabulary of 60 -- rare terms without a directory row, found by search, and
     #  blocks over the rarest term's documents instead of over all documents)
@@ -407,9 +402,9 @@ def test_slop_doc_parallel_route(api, seed, monkeypatch, capfd):
         for r in routes:
             routes[r] += (f"slop route: {r}" in err) or (f"slop {r}" in err)
         assert np.array_equal(got, want), f"seed {seed} terms {terms} slop {slop}: {np.flatnonzero(got != want)[:5]}"
-        monkeypatch.setenv("SA_SPAN_DOC", "0")
+        set_opt("SA_SPAN_DOC", "0")
         other = dev.phrase_freqs_dense(terms, slop=slop)
-        monkeypatch.delenv("SA_SPAN_DOC")
+        unset_opt("SA_SPAN_DOC")
         assert np.array_equal(other, want), f"general route: seed {seed} terms {terms} slop {slop}"
     assert routes["doc-parallel"] >= 2, routes
     if seed % 2 == 0:
@@ -426,8 +421,8 @@ def test_slop_five_to_eight_terms(api, seed, monkeypatch, on_emu):
     """phrases of more terms than the span kernels are specialised for (flags: 2-4 terms; the fast pass requests the
     first four terms' loads together): the generic paths, with and without the doc directory, vs the oracle"""
     from oracle import spans as S
-    monkeypatch.setenv("SA_DOCDIR_DIV", "1000000" if seed % 2 else "0")
-    monkeypatch.setenv("SA_SPAN_SORT", "1" if seed != 1 else "0")     # (work order forced / off)
+    set_opt("SA_DOCDIR_DIV", "1000000" if seed % 2 else "0")
+    set_opt("SA_SPAN_SORT", "1" if seed != 1 else "0")     # (work order forced / off)
     rng = np.random.default_rng(300 + seed)
     n_docs, vocab = int(rng.integers(300, 700)), int(rng.integers(6, 12))
     t, d, p, lens = synth.corpus_triples(n_docs, vocab, int(rng.integers(20, 50)), seed=40 + seed)
@@ -478,7 +473,7 @@ def test_slop_span_table_overflow_matches_the_oracle(api, seed, monkeypatch):
         want = np.zeros(n_docs, dtype=np.float32)
         want[ids.astype(np.int64)] = counts
         for fast in ("1", "0"):
-            monkeypatch.setenv("SA_SPAN_FAST", fast)
+            set_opt("SA_SPAN_FAST", fast)
             got = dev.phrase_freqs_dense(terms, slop=slop)
             assert np.array_equal(got, want), f"seed {seed} terms {terms} slop {slop} fast {fast}: {np.flatnonzero(got != want)[:5]}"
     dev.close()
@@ -547,9 +542,9 @@ def test_phrase_batch_tile_and_directory_variants(api, monkeypatch, ptile, docdi
     """both tile sizes; probes by binary search only, by the doc directory of the frequent terms, with
     a directory for every term of >= 64 words, and with no directory in the index at all.  The
     single-phrase fused kernel takes the same probes."""
-    monkeypatch.setenv("SA_PTILE", ptile)
-    monkeypatch.setenv("SA_PHRASE_DOCDIR", docdir)
-    monkeypatch.setenv("SA_DOCDIR_DIV", div)
+    set_opt("SA_PTILE", ptile)
+    set_opt("SA_PHRASE_DOCDIR", docdir)
+    set_opt("SA_DOCDIR_DIV", div)
     n_docs, vocab = 9000, 60
     t, d, p, lens = synth.corpus_triples(n_docs, vocab, 45, seed=3)
     words, wt = rz.encode_sorted(t, d, p)
@@ -684,7 +679,7 @@ def test_slop_batch_replays_and_scratch_moves(api, monkeypatch, lanes, on_emu):
     grown and moved the first lane's scratch area."""
     if on_emu and lanes == "1":
         pytest.skip("one lane is what every other batch test of the CPU suite runs with SA_PHRASE_LANES unset on a single phrase")
-    monkeypatch.setenv("SA_PHRASE_LANES", lanes)
+    set_opt("SA_PHRASE_LANES", lanes)
     g, (t, d, p), lens, num_docs, vocab = golden_corpus("zipf_small")
     words, wt = rz.encode_sorted(t, d, p)
     orc = O.OracleIndex.from_triples(t, d, p, num_docs, doc_lens=lens)
@@ -798,8 +793,8 @@ def test_slop_phrases_of_a_batch_share_their_launches(api, monkeypatch):
     k = 8
     results = {}
     for multi, docm in (("1", "1"), ("1", "0"), ("0", "1")):
-        monkeypatch.setenv("SA_SPAN_MULTI", multi)
-        monkeypatch.setenv("SA_SPAN_DOC_MULTI", docm)
+        set_opt("SA_SPAN_MULTI", multi)
+        set_opt("SA_SPAN_DOC_MULTI", docm)
         pb = dev.phrase_batch(phrases, k=k, slop=slops)
         for _ in range(2):
             pb.run()
@@ -813,8 +808,8 @@ def test_slop_phrases_of_a_batch_share_their_launches(api, monkeypatch):
         n = int((ws > 0).sum())
         assert np.array_equal(ps[i, :n], ws[:n]) and np.array_equal(pd_[i, :n], wd[:n]), f"phrase {ph} slop {sl}"
     # a batch of two-term slop phrases only: every phrase ranks inside the doc-parallel kernel, no count vector, no ranking launch
-    monkeypatch.delenv("SA_SPAN_MULTI", raising=False)
-    monkeypatch.delenv("SA_SPAN_DOC_MULTI", raising=False)
+    unset_opt("SA_SPAN_MULTI")
+    unset_opt("SA_SPAN_DOC_MULTI")
     pairs = [[int(a), int(b)] for a, b in rng.choice(min(vocab, 40), (24, 2)) if a != b] + [[0, 1], [1, 0], [2, 0]]
     pb = dev.phrase_batch(pairs, k=k, slop=2)
     for _ in range(2):
@@ -835,8 +830,8 @@ def test_fused_kernel_routes_dd_and_searched(api, monkeypatch, div):
     rows, SA_DOCDIR_DIV=0 -- by a search of the term's list.  All equal the
     oracle's counts (the reference's phrase_freqs, bigram_freqs.py:48-307 + middle_out.py:73-168), on lists long enough for
     several chunks per anchor, anchors in every phrase position, lists that end inside a wave's last round"""
-    monkeypatch.setenv("SA_DOCDIR_DIV", div)
-    monkeypatch.setenv("SA_PHRASE_MODE", "fused")
+    set_opt("SA_DOCDIR_DIV", div)
+    set_opt("SA_PHRASE_MODE", "fused")
     n_docs, vocab = 6000, 300
     t, d, p, lens = synth.corpus_triples(n_docs, vocab, 40, seed=21)
     words, wt = rz.encode_sorted(t, d, p)

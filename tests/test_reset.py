@@ -10,6 +10,7 @@ import pytest
 from oracle import refimpl as O
 from searcharray_amd import roaringish as rz, synth
 from searcharray_amd.device_index import DeviceIndex
+from tests.helpers import set_opt, unset_opt
 
 N_DOCS, VOCAB = 9000, 400
 
@@ -58,7 +59,7 @@ def assert_batch(orc, queries, scores, docs, k, what):
 @pytest.mark.parametrize("k", [5, 40])
 def test_reset_equals_fresh_batch_and_oracle(api, corpus, monkeypatch, mode, k):
     for name, v in mode.items():
-        monkeypatch.setenv(name, v)
+        set_opt(name, v)
     words, off, lens, orc = corpus
     dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api)
     sets = query_sets()
@@ -82,8 +83,8 @@ def test_reset_equals_fresh_batch_and_oracle(api, corpus, monkeypatch, mode, k):
 def test_bloom_buffer_grows_with_the_query_sets(api, corpus, monkeypatch):
     """dynamic pruning: the lead terms' Bloom filters live in a buffer sized from the query sets seen so far
     (sa_batch_ensure_bloom) -- sets whose lead terms get longer and longer make it grow between runs, with a run in flight"""
-    monkeypatch.setenv("SA_SPARSE", "1")
-    monkeypatch.setenv("SA_BLOOM_FLOOR", "1024")
+    set_opt("SA_SPARSE", "1")
+    set_opt("SA_BLOOM_FLOOR", "1024")
     words, off, lens, orc = corpus
     dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api)
     rng = np.random.default_rng(9)
@@ -104,7 +105,7 @@ def test_bloom_buffer_grows_with_the_query_sets(api, corpus, monkeypatch):
 def test_two_batches_alternating_without_waiting(api, corpus, monkeypatch):
     """the pipeline of bench.py's fresh_batches leg: reset + run of batch i+1 are enqueued before batch i's results are
     fetched; every fetch waits for its own batch only"""
-    monkeypatch.setenv("SA_SPARSE", "0")
+    set_opt("SA_SPARSE", "0")
     words, off, lens, orc = corpus
     dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api)
     sets = query_sets()
@@ -129,7 +130,7 @@ def test_two_batches_alternating_without_waiting(api, corpus, monkeypatch):
 
 
 def test_reset_with_explicit_weights_and_bad_shapes(api, corpus, monkeypatch):
-    monkeypatch.setenv("SA_SPARSE", "0")
+    set_opt("SA_SPARSE", "0")
     words, off, lens, orc = corpus
     dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api)
     sets = query_sets()
@@ -195,17 +196,17 @@ def test_pruning_tables_on_demand(api, corpus, monkeypatch):
     words, off, lens, orc = corpus
     dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api)
     sets = query_sets()
-    monkeypatch.delenv("SA_SPARSE", raising=False)
+    unset_opt("SA_SPARSE")
     bt = dev.batch(sets[0], k=9)                         # shared heads: grouped by default, no tables
     for i, qs in enumerate([sets[0], sets[3], sets[0]]):
         if i:
-            monkeypatch.delenv("SA_SPARSE", raising=False)
+            unset_opt("SA_SPARSE")
             bt.reset(qs)
         for mode in (None, "1", "0", None):
             if mode is None:
-                monkeypatch.delenv("SA_SPARSE", raising=False)
+                unset_opt("SA_SPARSE")
             else:
-                monkeypatch.setenv("SA_SPARSE", mode)
+                set_opt("SA_SPARSE", mode)
             bt.run(sync=False)
             scores, docs = bt.fetch()
             assert_batch(orc, qs, scores, docs, 9, f"set {i} SA_SPARSE={mode}")

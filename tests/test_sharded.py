@@ -6,12 +6,15 @@ many GPUs the box has (one on the round-end box: the N = 1 path, no communicator
 
 Sharded results must be BIT-identical to the single-index oracle: avgdl is np.mean over the float32
 lengths of the whole corpus (reference indexing.py:282-284), df is summed over the shards."""
+import os
+
 import numpy as np
 import pytest
 
 from oracle import refimpl as O
 from searcharray_amd import roaringish as rz, synth
 from searcharray_amd.sharded import ShardedIndex, split_by_doc_range
+from tests.helpers import set_opt, unset_opt
 
 N_DOCS, VOCAB, K = 5000, 250, 10
 QUERIES = np.asarray([[0, 5, 50, 200], [1, 2, 3, 4], [7, 90, 150, 249], [10, 11, 12, 13], [249, 248, 400, 3]])
@@ -106,7 +109,7 @@ def test_sharded_candidate_overflow_and_wide_merge(api, shards, k, monkeypatch):
     shard: the flag travels with the all-gather (one extra cell per rank), every shard sees it at fetch and all of them
     redo the batch unpruned.  k = 700 on 3 shards: 2100 gathered keys per query do not fit the merge's LDS list, so the
     exchange takes the regroup route instead of the fused one."""
-    monkeypatch.setenv("SA_CAND_CAP", "100")
+    set_opt("SA_CAND_CAP", "100")
     n = 4000
     t = np.repeat(np.arange(3), n).astype(np.uint32)
     d = np.tile(np.arange(n), 3).astype(np.uint64)
@@ -150,3 +153,18 @@ def test_a_batch_that_outlives_its_sharded_handle_is_refused_not_freed_twice(api
     bt.close()
     bt.close()
     assert want[0].shape == (len(QUERIES), K)
+
+
+@pytest.mark.gpu
+def test_collectives_come_from_the_rccl_the_library_was_linked_against():
+    """libsearcharray_hip.so links /opt/rocm's RCCL (DT_RPATH); a process that has imported torch first resolves the same
+    SONAME to the copy inside the torch wheel instead (round 4's GPU log showed exactly that).  Nothing the GPU suite collects
+    imports torch any more (tests/test_dist_gloo.py imports it inside its test): the collectives of this process must be
+    /opt/rocm's."""
+    import sys
+    from searcharray_amd import _lib
+    from searcharray_amd.device_index import DeviceIndex
+    assert "torch" not in sys.modules, "a collected test module imported torch at import time"
+    version, path = DeviceIndex.comm_library_info(_lib.api())
+    assert version > 0
+    assert os.path.realpath(path).startswith("/opt/rocm"), f"collectives resolved to {path}"
