@@ -2657,7 +2657,7 @@ extern "C" int sa_batch_run_local(sa_batch_t* bt, void* local_keys_out_device, i
     SA_TRY(sa_batch_run_shard(bt, bt->d_local, false));
     if (local_keys_out_device)
         SA_HIP(hipMemcpyAsync(local_keys_out_device, bt->d_local, (size_t)bt->B * bt->k * sizeof(u64),
-                              hipMemcpyDeviceToDevice, bt->st));
+                              hipMemcpyDefault, bt->st));      // (the caller's buffer: device memory, or page-locked host memory)
     if (sync) {
         SA_HIP(hipStreamSynchronize(bt->st));
         SA_HIP(hipGetLastError());
