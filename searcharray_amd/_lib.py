@@ -116,6 +116,7 @@ PROTOTYPES = {
     "sa_batch_step": (c_int, [c_void_p, u32p]),
     "sa_comm_library_info": (c_int, [POINTER(c_int), ctypes.c_char_p, c_int]),
     "sa_batch_group_info": (c_int, [c_void_p, POINTER(c_uint32)]),
+    "sa_batch_last_route": (c_int, [c_void_p, POINTER(c_int)]),
     "sa_batch_host_times": (c_int, [c_void_p, POINTER(c_uint64)]),
     "sa_batch_seeds": (c_int, [c_void_p, POINTER(c_float)]),
     "sa_batch_stats": (c_int, [c_void_p, c_int, u64p, u64p]),

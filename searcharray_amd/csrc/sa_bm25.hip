@@ -1654,8 +1654,10 @@ extern "C" int sa_index_bm25_dense(sa_index_t* ix, const uint32_t* terms, const 
     SA_ARG(ix && out, "null argument");
     SA_ARG(n_query_terms >= 0, "n_query_terms < 0");
     SA_ARG(n_query_terms == 0 || (terms && idf), "terms/idf null");
-    std::lock_guard<std::mutex> g(ix->mu);
+    std::unique_lock<std::mutex> g(ix->mu);
     SA_HIP(hipSetDevice(ix->device));
+    SaDenseLaneScope lane(ix, g);                               // (enqueue under the lock, wait outside it: sa_index.hpp, DenseLane)
+    SA_TRY(lane.rc);
     hipStream_t st = ix->stream;
     const u64 N = ix->n_docs;
     // reference similarity.py:31-32: avg_doc_lens == 0 -> zeros
@@ -1689,7 +1691,7 @@ extern "C" int sa_index_bm25_dense(sa_index_t* ix, const uint32_t* terms, const 
     SA_TRY(sa_launch_make_bounds(ix, d_terms, (u32)T, d_bounds, d_qbase, st));
     SA_TRY(sa_launch_bm25(ix, p, st));
     SA_TRY(sa_emit_dense(ix, d_out, out));
-    SA_HIP(hipStreamSynchronize(st));
+    SA_TRY(lane.finish());
     SA_HIP(hipGetLastError());
     return SA_OK;
 }
@@ -2166,8 +2168,8 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
     {
         // the pruning tables: now, if the run may prune (the rule of sa_batch_run_shard, with what is known here); else on demand
         const int sp_env = (int)sa_opt(bt->opts.sparse, -1);
-        const bool grouped_default = bt->n_grouped_rows * 2u >= B && bt->impacts;
-        const bool maybe_sparse = sp_env >= 0 ? sp_env != 0 : !grouped_default;
+        const bool impact_default = bt->impacts != nullptr && sa_opt(bt->opts.impact, 1) != 0;     // (the run's rule, with what is known here)
+        const bool maybe_sparse = sp_env >= 0 ? sp_env != 0 : !impact_default;
         if (maybe_sparse || sa_opt(bt->opts.sparse_lazy, 1) == 0) sa_batch_fill_prune_tables(bt, img);
         else { bt->sparse_ok = false; bt->sparse_lazy = true; bt->bloom_bytes = 0; bt->sparse_p1_total = 0; bt->sparse_p2_max = 0; }
     }
@@ -2312,8 +2314,14 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     // ... and so do the loose groups on batches WITHOUT shared terms (256 x 4 pairwise-distinct terms of ranks 1 .. 1024,
     // all of them frequent: 0.62 ms exhaustive vs 1.68 ms pruned at k = 10): the exhaustive path is the default whenever
     // at least half of the batch's queries are in groups of either kind.
-    const bool shared_heads = bt->n_grouped_rows * 2u >= bt->B && group_can_run;
-    const bool sparse_wanted = sparse_env >= 0 ? sparse_env != 0 : (ix->n_docs >= (u64)bt->k * 32768ull && !shared_heads);
+    // Round 5, measured instead of argued (scripts/route_rule.py, profiles/route_rule_r05*.jsonl: the share of the batch the grouped
+    // kernel can take x k, 10 M and 1.25 M docs): with the impact stream and the starting bounds the exhaustive path is within 5 % of
+    // pruning in EVERY cell and up to 2 x faster (k = 100, less than half of the batch groupable: 1.59 vs 2.92 ms -- round 4's rule
+    // picked pruning there); pruning keeps the batches the impact route cannot take (no impact stream, the histogram bound off,
+    // other tile sizes), where the per-query TF kernel is what it competes with.
+    const bool impact_route = p.pruned && hist_possible && p.imp && !p.no_topk &&
+                              (ix->tile_docs == 1024 || ix->tile_docs == 2048 || ix->tile_docs == 4096);
+    const bool sparse_wanted = sparse_env >= 0 ? sparse_env != 0 : (ix->n_docs >= (u64)bt->k * 32768ull && !impact_route);
     if (sparse_wanted && bt->sparse_lazy && bt->kind == 0) {
         // the tables were left out at reset (the run was expected to score every posting): derive them into the image of the
         // current query set -- once its upload has left the host buffer -- and upload it again, behind everything on this stream
@@ -2329,6 +2337,7 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     }
     const bool sparse = hist_possible && ix->tile_docs <= 8192 && bt->sparse_ok && ix->avg_doc_len != 0.f && ix->n_tiles > 0 &&
                         sparse_wanted;
+    bt->last_route_sparse = sparse;
     const bool use_hist = hist_possible &&
                           (sparse || bt->k >= (u32)sa_opt(bt->opts.topk_hist_mink, defer_check ? 1 : 33));
     p.hist = use_hist ? bt->d_hist : nullptr;
@@ -2770,6 +2779,13 @@ extern "C" int sa_batch_profile(sa_batch_t* bt, double* kernel_ms_out, uint64_t*
     if (kernel_ms_out) *kernel_ms_out = n ? sum / n : 0.0;
     if (alg_bytes_out) *alg_bytes_out = bt->alg_bytes;
     if (postings_bytes_out) *postings_bytes_out = bt->postings_bytes;
+    return SA_OK;
+}
+
+extern "C" int sa_batch_last_route(sa_batch_t* bt, int* pruned_out) {
+    SA_ARG(bt && bt->ix && pruned_out, "null argument");
+    std::lock_guard<std::mutex> g(bt->ix->mu);
+    *pruned_out = bt->last_route_sparse ? 1 : 0;
     return SA_OK;
 }
 

@@ -185,6 +185,51 @@ int sa_index_scratch(sa_index* ix, size_t bytes, void** out) {
     return SA_OK;
 }
 
+// A dense call on one of the index's lanes (sa_index.hpp, DenseLane).  Constructed with the index lock held: takes a free lane
+// (waits for one otherwise) and installs its stream and scratch as the index's, so the call's body -- written against
+// ix->stream and sa_index_scratch -- enqueues on the lane.  finish(): records the lane's event, puts the index's own state back,
+// RELEASES the lock and waits for the event outside it; other threads' calls enqueue meanwhile.  A call that fails before
+// finish() is wound up by the destructor (under the lock, synchronising the lane).
+SaDenseLaneScope::SaDenseLaneScope(sa_index* ix_, std::unique_lock<std::mutex>& lk_) : ix(ix_), lk(lk_) {
+    for (;;) {
+        for (auto& ln : ix->dense_lane)
+            if (!ln.busy) { lane = &ln; break; }
+        if (lane) break;
+        ix->dense_lane_cv.wait(lk);
+    }
+    lane->busy = true;
+    if (!lane->stream && hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking) != hipSuccess) { rc = SA_ERR_HIP; sa_set_error("dense lane: hipStreamCreate failed"); }
+    if (rc == SA_OK && !lane->done && hipEventCreateWithFlags(&lane->done, hipEventDisableTiming) != hipSuccess) { rc = SA_ERR_HIP; sa_set_error("dense lane: hipEventCreate failed"); }
+    swap();
+}
+void SaDenseLaneScope::swap() {
+    std::swap(ix->stream, lane->stream);
+    std::swap(ix->d_scratch, lane->scratch);
+    std::swap(ix->scratch_bytes, lane->scratch_bytes);
+    std::swap(ix->d_rows_scratch, lane->rows);
+    std::swap(ix->rows_scratch_bytes, lane->rows_bytes);
+    swapped = !swapped;
+}
+int SaDenseLaneScope::finish() {
+    hipEvent_t done = lane->done;
+    const hipError_t e = hipEventRecord(done, ix->stream);      // (ix->stream IS the lane's stream here)
+    swap();
+    if (e != hipSuccess) { sa_set_error("dense lane: hipEventRecord failed"); return SA_ERR_HIP; }
+    lk.unlock();
+    const hipError_t w = hipEventSynchronize(done);
+    lk.lock();
+    if (w != hipSuccess) { sa_set_error("dense call failed on the device: %s", hipGetErrorString(w)); return SA_ERR_HIP; }
+    return SA_OK;
+}
+SaDenseLaneScope::~SaDenseLaneScope() {
+    if (swapped) {                                              // (left early: nothing of this call may still be in flight on the lane)
+        hipStreamSynchronize(ix->stream);
+        swap();
+    }
+    lane->busy = false;
+    ix->dense_lane_cv.notify_one();
+}
+
 // ---------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------
@@ -342,6 +387,12 @@ void sa_index_free(sa_index* ix) {
     if (ix->d_tf8_slot) hipFree(ix->d_tf8_slot);
     ix->impacts.reset();
     if (ix->d_scratch) hipFree(ix->d_scratch);
+    for (auto& ln : ix->dense_lane) {
+        if (ln.stream) { hipStreamSynchronize(ln.stream); hipStreamDestroy(ln.stream); }
+        if (ln.done) hipEventDestroy(ln.done);
+        if (ln.scratch) hipFree(ln.scratch);
+        if (ln.rows) hipFree(ln.rows);
+    }
     for (int i = 0; i < 3; i++) {
         if (ix->lane_scratch[i]) hipFree(ix->lane_scratch[i]);
         if (ix->lane_stream[i]) hipStreamDestroy(ix->lane_stream[i]);
@@ -848,8 +899,10 @@ extern "C" int sa_index_similarity_dense(sa_index_t* ix, const uint32_t* terms, 
 
 extern "C" int sa_index_termfreqs_dense(sa_index_t* ix, uint32_t term, float* out) {
     SA_ARG(ix && out, "null argument");
-    std::lock_guard<std::mutex> g(ix->mu);
+    std::unique_lock<std::mutex> g(ix->mu);
     SA_HIP(hipSetDevice(ix->device));
+    SaDenseLaneScope lane(ix, g);
+    SA_TRY(lane.rc);
     void* scratch;
     SA_TRY(sa_index_scratch(ix, (ix->n_docs + 1) * sizeof(float), &scratch));
     float* d_out = (float*)scratch;
@@ -862,7 +915,7 @@ extern "C" int sa_index_termfreqs_dense(sa_index_t* ix, uint32_t term, float* ou
         }
     }
     SA_TRY(sa_emit_dense(ix, d_out, out));
-    SA_HIP(hipStreamSynchronize(ix->stream));
+    SA_TRY(lane.finish());
     SA_HIP(hipGetLastError());
     return SA_OK;
 }

@@ -19,6 +19,7 @@
 #pragma once
 #include "sa_options.hpp"
 #include "sa_common.hpp"
+#include <condition_variable>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -68,6 +69,8 @@ struct sa_impacts {
     ~sa_impacts();
 };
 
+struct sa_index;
+struct SaDenseLaneScope;
 struct sa_index {
     sa_options_t opts;              // the handle's switches (sa_options.hpp): the creating thread's defaults, or sa_index_set_options
     int device = 0;
@@ -123,6 +126,24 @@ struct sa_index {
     hipStream_t lane_stream[3] = {nullptr, nullptr, nullptr};
     void* lane_scratch[3] = {nullptr, nullptr, nullptr};
     size_t lane_bytes[3] = {0, 0, 0};
+
+    // LANES of the dense single-call entry points (sa_index_bm25_dense / sa_index_termfreqs_dense and their `_to` twins): a call
+    // holds the index lock only while it ENQUEUES -- on a lane's stream, into a lane's scratch -- and waits for its result
+    // outside the lock, so the kernels and device-to-host copies of several threads' calls on ONE handle overlap, the way the
+    // reference's GIL-releasing native kernels overlap under a ThreadPoolExecutor (reference test/test_tmdb.py:285-312,
+    // roaringish/intersect.pyx:306,316,338,384).  struct SaDenseLaneScope (sa_index.hip) swaps a lane in and out.
+    struct DenseLane {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        void* scratch = nullptr;
+        size_t scratch_bytes = 0;
+        void* rows = nullptr;
+        size_t rows_bytes = 0;
+        bool busy = false;
+    };
+    static constexpr int N_DENSE_LANES = 8;
+    DenseLane dense_lane[N_DENSE_LANES];
+    std::condition_variable dense_lane_cv;
 
     // slop phrases of a phrase batch in shared launches (sa_span_counts_batch): job array + per-phrase scratch, and the
     // page-locked image the jobs are uploaded from
@@ -200,3 +221,16 @@ struct SpanRankCtx {
 int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* terms, const int* T, const int* slop,
                          const float* idf, const u32* rows, float** d_out, unsigned char* handled,
                          const sa_dense_rank_job** d_rank_jobs, int* n_rank_jobs, u32 rank_tile_shift, const SpanRankCtx* rank);
+
+// a dense call on one of the index's lanes (sa_index.hip)
+struct SaDenseLaneScope {
+    sa_index* ix;
+    std::unique_lock<std::mutex>& lk;
+    sa_index::DenseLane* lane = nullptr;
+    bool swapped = false;
+    int rc = SA_OK;
+    SaDenseLaneScope(sa_index* ix_, std::unique_lock<std::mutex>& lk_);
+    ~SaDenseLaneScope();
+    int finish();
+    void swap();
+};

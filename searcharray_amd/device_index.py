@@ -66,10 +66,14 @@ class _PinnedPool:
             return np.empty(0, dtype=dtype)
         nbytes = dtype.itemsize * n
         stack = self.idle.get(nbytes)
+        addr = None
         if stack:
-            addr = stack.pop()
-            self.idle_bytes -= nbytes
-        else:
+            try:
+                addr = stack.pop()                  # (threads share the pool: another one may have taken the last buffer)
+                self.idle_bytes -= nbytes
+            except IndexError:
+                addr = None
+        if addr is None:
             ptr = ctypes.c_void_p()
             self.api.call("sa_host_alloc", nbytes, ctypes.byref(ptr))
             addr = ptr.value
@@ -506,6 +510,12 @@ class QueryBatch(_options.OptionsMixin):
         out = (_lib.c_uint32 * 4)()
         self._call("sa_batch_group_info", self._h, out)
         return {"groups": int(out[0]), "grouped_queries": int(out[1]), "shared_first_term": int(out[2]), "per_query_kernel": int(out[3])}
+
+    def last_route(self) -> str:
+        """the route the last run took: 'pruned' (dynamic pruning) or 'exhaustive'"""
+        out = ctypes.c_int(0)
+        self._call("sa_batch_last_route", self._h, ctypes.byref(out))
+        return "pruned" if out.value else "exhaustive"
 
     def seeds(self) -> np.ndarray:
         """the bound every query of the current set starts with (sa_batch_seeds), float32[B], 0 = none"""

@@ -425,3 +425,52 @@ def test_index_in_batches_with_workers_is_the_same_index(default_api, batch_size
         SearchArray.index(docs[:5] + [long_doc] + docs[5:9], batch_size=2, workers=3)
     cut = SearchArray.index(docs[:5] + [long_doc], batch_size=2, workers=3, truncate=True)
     assert cut.doclengths()[5] == rz.MAX_POSN
+
+
+def test_threaded_dense_calls_on_one_handle(api):
+    """the reference's callers score from thread pools (test/test_tmdb.py:285-312; its native kernels release the GIL): dense
+    calls of several threads on ONE index handle enqueue on separate lanes (csrc/sa_index.hpp, DenseLane) and wait outside the
+    index lock -- every thread must still get exactly its own result, single terms, disjunctions and row subsets mixed with
+    phrase calls (which keep the exclusive path)"""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import refimpl as O
+    from searcharray_amd import synth, roaringish as rz
+    from searcharray_amd.device_index import DeviceIndex
+    n_docs, vocab = 5000, 300
+    t, d, p, lens = synth.corpus_triples(n_docs, vocab, 14, seed=41)
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
+    rng = np.random.default_rng(8)
+    rows = np.sort(rng.choice(n_docs, 200, replace=False)).astype(np.uint64)
+    jobs = []
+    for i in range(96):
+        kind = i % 4
+        if kind == 0:
+            term = int(rng.integers(0, vocab))
+            jobs.append(("tf", term, orc.termfreqs(term)))
+        elif kind == 1:
+            q = [int(x) for x in rng.integers(0, vocab, 3)]
+            jobs.append(("bm25", q, orc.score_terms_sum(q)))
+        elif kind == 2:
+            q = [int(x) for x in rng.integers(0, 40, 2)]
+            jobs.append(("bm25_rows", q, orc.score_terms_sum(q)[rows.astype(np.int64)]))
+        else:
+            ph = [int(x) for x in rng.choice(12, 2, replace=False)]
+            jobs.append(("phrase", ph, orc.phrase_freqs(ph)))
+
+    def run(job):
+        kind, arg, want = job
+        if kind == "tf":
+            got = dev.termfreqs_dense(arg)
+        elif kind == "bm25":
+            got = dev.bm25_dense(arg)
+        elif kind == "bm25_rows":
+            got = dev.bm25_dense(arg, rows=rows)
+        else:
+            got = dev.phrase_freqs_dense(arg)
+        return bool(np.array_equal(np.array(got), want))
+    with ThreadPoolExecutor(8) as ex:
+        ok = list(ex.map(run, jobs * 2))
+    assert all(ok), f"{ok.count(False)} of {len(ok)} threaded calls returned another call's result"
+    dev.close()
