@@ -1070,6 +1070,7 @@ def main():
                        "launcher": "torch-free: ranks rendezvous through an id file, "
                                                                "collectives = libsearcharray_hip.so's RCCL communicator"},
             "postings_scanned_GBps": round(post_total * K / dt / 1e9, 2),
+            "collective_library": dict(zip(("nccl_version", "path"), comm_lib)),
             "fresh_batch_latency_ms": round(kernel_ms_fresh, 4),
             "replay": {"value": round(B * K / dt_r, 2), "unit": "queries/s", "ms_per_step": round(dt_r / K * 1e3, 4),
                        "kernel_ms": round(kernel_ms_r, 4), "fresh_over_replay": round(dt_r / dt, 4),
