@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Copy the outputs of scripts/gpu_full_r4.sh (r03: gpu_full_r3.sh) from gpurun_out/ (scratch) into profiles/ (tracked), named per round:
+"""Copy the outputs of scripts/gpu_full_r5.sh (r04: gpu_full_r4.sh, r03: gpu_full_r3.sh) from gpurun_out/ (scratch) into profiles/ (tracked), named per round:
 bench JSON lines (which carry their own PMC traffic / L2 hit rates: bench.py profiles itself under rocprofv3),
 rocprofv3 kernel stats per leg, SQ counters of the scoring kernels, the HIP-API summary of the fresh-batch loop's
 steady state, PMC traffic of the phrase and slop kernels."""
@@ -92,14 +92,14 @@ def main():
                      ("bench_k1000.log", f"bench_{RND}_k1000.json"), ("bench_comm1.log", f"bench_{RND}_comm_1rank.json"),
                      ("dist1_rccl.log", f"bench_{RND}_dist1rank_1250k.json"), ("rank_nocomm.log", f"bench_{RND}_rank_sized_1250k_nocomm.json"),
                      ("phrase_bench.log", f"phrase_bench_{RND}.json"), ("slop_bench.log", f"slop_bench_{RND}.json"),
-                     ("phrase_bench_coop.log", f"phrase_bench_{RND}_wave_cooperative_kernel.json")]:
+                     ("msmarco.log", f"msmarco_{RND}.json")]:
         js = json_lines(os.path.join(OUT, src))
         if js:
             json.dump(js[-1], open(os.path.join(PROF, dst), "w"), indent=1)
             print("wrote", dst)
     for src, dst in [("kernel_ab.log", f"kernel_ab_{RND}.jsonl"), ("host_cost.log", f"host_cost_{RND}.jsonl"),
-                     ("ab_hg.log", f"headgroup_kernel_ab_{RND}.jsonl"), ("ab_xcd.log", f"xcd_tile_ranges_ab_{RND}.jsonl"),
-                     ("ab_seed.log", f"optimistic_bounds_ab_{RND}.jsonl"), ("ab_termseed.log", f"starting_bounds_ab_{RND}.jsonl"), ("ab_rank.log", f"rank_sized_shard_ab_{RND}.jsonl"),
+                     ("route_rule.jsonl", f"route_rule_{RND}.jsonl"), ("route_rule_1250k.jsonl", f"route_rule_{RND}_1250k.jsonl"),
+                     ("dense_threads.jsonl", f"dense_threads_{RND}.jsonl"), ("issue_probe.jsonl", f"issue_probe_{RND}.jsonl"),
                      ("slop_heavy.log", f"slop_heaviest_{RND}.jsonl"), ("slop_routes.log", f"slop_routes_{RND}.jsonl")]:
         js = json_lines(os.path.join(OUT, src))
         if js:
@@ -108,9 +108,8 @@ def main():
     for sub, dst in [("prof_main", f"{RND}_main_leg_kernel_stats.csv"), ("prof_distinct", f"{RND}_distinct_leg_kernel_stats.csv"),
                      ("prof_bench", f"{RND}_bench_kernel_stats.csv"), ("prof_phrase", f"{RND}_phrase_bench_kernel_stats.csv"),
                      ("prof_slop", f"{RND}_slop_bench_kernel_stats.csv"), ("prof_slopb", f"{RND}_phrase_slop_batch_legs_kernel_stats.csv"),
-                     ("prof_hg", f"{RND}_main_leg_headgroup_kernel_stats.csv"), ("prof_k1000", f"{RND}_main_leg_k1000_kernel_stats.csv"),
+                     ("prof_k1000", f"{RND}_main_leg_k1000_kernel_stats.csv"),
                      ("prof_rank", f"{RND}_rank_sized_shard_exchange_kernel_stats.csv"),
-                     ("prof_phrase_coop", f"{RND}_phrase_bench_wave_cooperative_kernel_stats.csv"),
                      ("prof_slop2", f"{RND}_slop_heaviest_2term_kernel_stats.csv"),
                      ("prof_slop3", f"{RND}_slop_heaviest_3term_kernel_stats.csv")]:
         f = newest(os.path.join(OUT, sub, "**", "*kernel_stats.csv"))
@@ -125,12 +124,6 @@ def main():
                "kernels": json.load(open(sq))}
         json.dump(out, open(os.path.join(PROF, f"{RND}_scoring_kernels_sq_counters.json"), "w"), indent=1)
         print("wrote", f"{RND}_scoring_kernels_sq_counters.json")
-    hq = os.path.join(OUT, "hg_sq_summary.json")
-    if os.path.exists(hq) and os.path.getsize(hq) > 10:
-        out = {"command": "as the scoring kernels' counters, with SA_HG=1 (the head-group kernel, csrc/sa_bm25_hg.hip, takes the groups)",
-               "kernels": json.load(open(hq))}
-        json.dump(out, open(os.path.join(PROF, f"{RND}_headgroup_kernel_sq_counters.json"), "w"), indent=1)
-        print("wrote", f"{RND}_headgroup_kernel_sq_counters.json")
     # the steady state of the fresh-batch loop: HIP API calls of 600 steps minus those of 100 steps, per step
     a, b = hip_api_counts("prof_hip_a"), hip_api_counts("prof_hip_b")
     if a and b:
@@ -158,6 +151,12 @@ def main():
                               "mean per dispatch", "kernels": ph},
                   open(os.path.join(PROF, f"{RND}_phrase_pmc_traffic.json"), "w"), indent=1)
         print("wrote", f"{RND}_phrase_pmc_traffic.json")
+    sb = pmc_per_kernel("pmc_slopb_f_new", "pmc_slopb_w_new", prefix="sa_k_span")
+    if sb:
+        json.dump({"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace -- python scripts/slop_batch_prof.py "
+                              "(zipf-1M; bench.py's slop_batch leg: 256 two-token slop-2 phrases, half over terms of ranks 1-50); mean per dispatch",
+                   "kernels": sb}, open(os.path.join(PROF, f"{RND}_slop_batch_pmc_traffic.json"), "w"), indent=1)
+        print("wrote", f"{RND}_slop_batch_pmc_traffic.json")
     if newest(os.path.join(OUT, "pmc_slop_f", "**", "*counter_collection.csv")):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "slop_pmc.py"), OUT], capture_output=True, text=True)
         if r.returncode == 0 and r.stdout.strip().startswith("{"):

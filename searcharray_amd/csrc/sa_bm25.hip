@@ -211,23 +211,30 @@ static std::shared_ptr<sa_impacts> sa_impacts_get(sa_index* ix, float k1, float 
             }
         }
     }
-    // rank table of every term's factors: the bounds a query starts with (SA_TERM_SEED=0 at batch creation / reset: not used)
-    {
-        const size_t bytes = (size_t)ix->n_terms * SA_TOPF_NR * sizeof(float);
-        if (hipMalloc(&im->d_topf, bytes) == hipSuccess) {
-            TopfRanks rk;
-            for (int i = 0; i < SA_TOPF_NR; i++) rk.r[i] = sa_topf_ranks[i];
-            const u32 grid = ix->n_terms < 16384u ? ix->n_terms : 16384u;
-            hipLaunchKernelGGL(sa_k_make_topf, dim3(grid), dim3(256), 0, st, (const u64*)im->d_imp, (const u64*)ix->d_tf_off, ix->n_terms, rk,
-                               im->d_topf);
-            if (hipGetLastError() != hipSuccess) { hipFree(im->d_topf); im->d_topf = nullptr; }
-        } else {
-            (void)hipGetLastError();
-            im->d_topf = nullptr;
-        }
-    }
     ix->impacts = im;
     return im;
+}
+
+// Rank table of every term's factors (sa_impacts::d_topf: 88 bytes per term), built when the FIRST batch that can use starting
+// bounds asks for it -- not with the stream: a batch with term_seed = 0, with k > 1024 or on the pruning route never reads it.
+// Tried once per stream; when HBM is short the batches start from 0 as before round 4.  Call with the index lock held.
+static void sa_impacts_ensure_topf(sa_index* ix, sa_impacts* im) {
+    if (!im || im->d_topf || im->topf_tried) return;
+    im->topf_tried = true;
+    const size_t bytes = (size_t)ix->n_terms * SA_TOPF_NR * sizeof(float);
+    if (hipMalloc(&im->d_topf, bytes) != hipSuccess) { (void)hipGetLastError(); im->d_topf = nullptr; return; }
+    TopfRanks rk;
+    for (int i = 0; i < SA_TOPF_NR; i++) rk.r[i] = sa_topf_ranks[i];
+    const u32 grid = ix->n_terms < 16384u ? ix->n_terms : 16384u;
+    hipLaunchKernelGGL(sa_k_make_topf, dim3(grid), dim3(256), 0, ix->stream, (const u64*)im->d_imp, (const u64*)ix->d_tf_off, ix->n_terms, rk,
+                       im->d_topf);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ix->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        hipFree(im->d_topf); im->d_topf = nullptr;
+    }
+}
+static bool sa_batch_wants_seed(const sa_batch* bt) {
+    return bt->impacts && bt->k <= 1024u && sa_opt(bt->opts.term_seed, 1) != 0 && sa_opt(bt->opts.sparse, -1) != 1;
 }
 
 // Saturation table of a batch, laid out [dl][tf - 1].  For integer doc lengths dl < tab_w and term frequencies
@@ -2177,7 +2184,9 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
     {
         bool w_ok = k1 >= 0.f && b >= 0.f && b <= 1.f;
         for (size_t i = 0; i < (size_t)B * T && w_ok; i++) w_ok = idf[i] >= 0.f && idf[i] <= 3.0e38f;
-        bt->seed_on = w_ok && bt->impacts && bt->impacts->d_topf && bt->k <= 1024u && sa_opt(bt->opts.term_seed, 1) != 0;
+        const bool wanted = w_ok && sa_batch_wants_seed(bt);
+        if (wanted) sa_impacts_ensure_topf(ix, bt->impacts.get());
+        bt->seed_on = wanted && bt->impacts->d_topf;
     }
     const u64 t_host = sa_now_ns();
     SA_TRY(sa_batch_upload_commit(bt));

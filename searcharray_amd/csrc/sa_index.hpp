@@ -65,7 +65,8 @@ struct sa_impacts {
     // the factor is below 1/16.  w_t * topf[t][rank >= k] is a bound of the k-th best score of ANY query that holds t
     // with weight w_t >= 0 (all contributions are non-negative and fp32 sums of non-negatives never fall below a
     // summand): every query starts with the best such bound over its terms instead of 0 (sa_k_make_bounds).
-    float* d_topf = nullptr;
+    float* d_topf = nullptr;        // built by the first batch that can use it (sa_impacts_ensure_topf)
+    bool topf_tried = false;
     ~sa_impacts();
 };
 

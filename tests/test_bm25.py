@@ -452,8 +452,9 @@ def test_impact_stream_exhaustive_scan(api, monkeypatch, integer_lens):
 
 
 def test_dynamic_pruning_default_policy(api, monkeypatch):
-    """SA_SPARSE unset: dynamic pruning only while the shard holds at least 32768 docs per requested result
-    (below that the exhaustive kernel is the faster one); either way the top-k equals the oracle."""
+    """Option `sparse` unset (round 5's measured rule, scripts/route_rule.py): a batch that can take the impact stream with
+    histogram bounds is scored exhaustively; one that cannot (impact = 0) is pruned while the shard holds at least 32768 docs
+    per requested result.  Either way the top-k equals the oracle, and last_route() says which it was."""
     unset_opt("SA_SPARSE")
     n_docs, vocab = 60000, 3000
     t, d, p, lens = synth.corpus_triples(n_docs, vocab, 12, seed=5)
@@ -461,11 +462,12 @@ def test_dynamic_pruning_default_policy(api, monkeypatch):
     dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
     orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
     queries = np.asarray([[0, 40, 700, 2500], [2900, 1, 3, 1500], [2999, 2998, 0, 1]])
-    for k, pruned in ((1, True), (5, False)):                     # 60000 / 32768 = 1.8 results
-        bt = dev.batch(queries, k=k)
+    for impact, k, pruned in ((1, 1, False), (0, 1, True), (0, 5, False)):                     # 60000 / 32768 = 1.8 results
+        bt = dev.batch(queries, k=k, opts={"impact": impact})
         bt.stats(True)
         _check_batch(bt, orc, queries, k)
         cands, sparse_queries = bt.stats(False)
+        assert bt.last_route() == ("pruned" if pruned else "exhaustive")
         assert (sparse_queries > 0) == pruned and (cands > 0) == pruned
         bt.close()
 
