@@ -87,10 +87,24 @@ def main():
                     dt = (time.perf_counter() - t0) / args.steps
                     kms, _, _ = batch.profile()
                     res = batch.fetch()
+                    probe = None
+                    if hasattr(api._cdll, "sa_debug_probe_read"):          # a -DSA_PROBE build (scripts/build_probe.sh)
+                        buf = (ctypes.c_ulonglong * 16)()
+                        api._cdll.sa_debug_probe_read(buf, 1)              # (clear: counts of the runs so far)
+                        batch.run(sync=True)
+                        api._cdll.sa_debug_probe_read(buf, 1)
+                        v = list(buf)
+                        items, pairs = max(v[6], 1), max(v[7], 1)
+                        names = ["tables", "request_q0_and_base", "wait_for_postings", "request_next_query", "overlay_query", "flush_and_defer"]
+                        probe = {"items": v[6], "pairs": v[7], "deferred_pairs": v[8],
+                                 "cycles_per_item": {nm: round(v[i] / items, 1) for i, nm in enumerate(names)},
+                                 "cycles_per_pair_in_the_query_loop": {nm: round(v[i] / pairs, 1) for i, nm in enumerate(names) if 2 <= i <= 4},
+                                 "cycles_per_item_total": round(sum(v[:6]) / items, 1),
+                                 "note": "s_memtime ticks at 100 MHz x ... see DESIGN 3.1a; one launch; items that reach the overlay"}
                     r0 = ref.setdefault((qname, k), res)
                     same = bool(np.array_equal(r0[0], res[0]) and np.array_equal(r0[1], res[1]))
                     print(json.dumps({"lib": os.path.basename(lib), "queries": qname, "k": k, "docs": D, **cfg,
-                                      "ms_per_step": round(dt * 1e3, 4), "kernel_ms": round(kms, 4), "same_results": same}), flush=True)
+                                      "ms_per_step": round(dt * 1e3, 4), "kernel_ms": round(kms, 4), "same_results": same, **({"probe": probe} if probe else {})}), flush=True)
                     batch.close()
         index.close()
 

@@ -923,6 +923,25 @@ __device__ __forceinline__ void sa_static_while_below(u32 n, F&& f) {
                                     // 1.00 / 0.80 / 0.62 / 0.54 / 0.50 / 0.47 / 0.457 / 0.459 / 0.468 / 0.476 / 0.483 / 0.485 ms at k = 10;
                                     // k = 1000: 128 / 320 / 400 / 500 / 640 -> 0.89 / 0.84 / 0.81 / 0.77 / 0.81
 
+// -DSA_PROBE (scripts/build_probe.sh; never in the product build): where a wave of the grouped kernel spends its cycles --
+// s_memtime at the section boundaries, summed over the items that reach the overlay, read by sa_debug_probe_read.  Reading
+// the clock waits for the wave's LDS operations (lgkmcnt(0)): sections that end with LDS writes are charged their drain.
+#ifdef SA_PROBE
+#define SA_PROBE_SLOTS 4096
+__device__ unsigned long long g_sa_probe[SA_PROBE_SLOTS * 16];       // (slot = block mod SLOTS: no two waves in flight share cells)
+#define SA_PT(i) do { const u64 t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - plast; plast = t_; } while (0)
+extern "C" int sa_debug_probe_read(unsigned long long* out16, int clear) {
+    if (hipDeviceSynchronize() != hipSuccess) return SA_ERR_HIP;
+    std::vector<unsigned long long> h((size_t)SA_PROBE_SLOTS * 16, 0ull);
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_sa_probe), h.size() * 8) != hipSuccess) return SA_ERR_HIP;
+    for (int i = 0; i < 16; i++) { out16[i] = 0; for (int sl = 0; sl < SA_PROBE_SLOTS; sl++) out16[i] += h[(size_t)sl * 16 + i]; }
+    if (clear) { std::fill(h.begin(), h.end(), 0ull); if (hipMemcpyToSymbol(HIP_SYMBOL(g_sa_probe), h.data(), h.size() * 8) != hipSuccess) return SA_ERR_HIP; }
+    return SA_OK;
+}
+#else
+#define SA_PT(i) do { } while (0)
+#endif
+
 // IDFN: cells of the item's weight table = queries x lanes-per-query of the table build (64: up to 4 overlaid terms per
 // query -- the BASELINE shape --, 128: anything else the host admits, n * tt <= 128)
 template <int TILE, int IDFN>
@@ -935,6 +954,10 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
     __shared__ u64 s_surv[SA_GRP_SURV_CAP];                     // survivors waiting for their places: score bits << 32 | accumulator offset << 4 | query
     u32* const accu = (u32*)smem;
     const u32 lane = threadIdx.x;
+#ifdef SA_PROBE
+    u64 pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64 plast = __builtin_amdgcn_s_memtime();
+#endif
     // XCD-aware item order: consecutive blocks go to consecutive XCDs (block b runs on XCD b % 8), so the
     // eight tiles of a chunk sit on eight XCDs and ALL groups of a tile follow each other on the same XCD:
     // the slices of the further terms that queries of different groups share are fetched into one L2 only.
@@ -1025,6 +1048,7 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
         const u32 mine = lane < n ? (u32)(s_half[lane][0] >> SA_GRPH_NH_SHIFT) : 0u;
         if (h1 == h0 && ballot(mine != 0u) == 0ull) return;
     }
+    SA_PT(0);                                                   // tables of the item built
 
     // The half descriptors of a query reach the scalar registers with ONE LDS instruction: lane h reads entry h
     // (8 bytes) and v_readlane hands the fields out -- no LDS round trip per half; a second one brings the query's
@@ -1125,6 +1149,7 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
         base_max = sa_wave_max_u32(lmax);
     }
 
+    SA_PT(1);                                                   // first query requested, base built
     // queries left to the per-query kernel (work list at the end)
     u64 deferred = 0ull;
     // survivors out: one reservation per query with survivors (lane qi reserves for query qi: the atomics travel
@@ -1261,12 +1286,18 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
     //      loads are outstanding), so the current query is processed while exactly the next one's loads fly.
     for (u32 qi = 0; qi < n; qi += 2) {
         SA_WAIT_VMCNT0();
+        SA_PT(2);
         if (qi + 1u < n) prefetch(qi + 1u, B);
+        SA_PT(3);
         process(qi, A);
+        SA_PT(4);
         if (qi + 1u < n) {
             SA_WAIT_VMCNT0();
+            SA_PT(2);
             if (qi + 2u < n) prefetch(qi + 2u, A);
+            SA_PT(3);
             process(qi + 1u, B);
+            SA_PT(4);
         }
     }
     if (nsurv) flush();
@@ -1279,6 +1310,16 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
         if ((deferred >> lane) & 1ull)
             gp.wl[wbase + (u32)__popcll(deferred & ((1ull << lane) - 1ull))] = ((u64)tile << 32) | (u64)(row0 + lane);
     }
+#ifdef SA_PROBE
+    SA_PT(5);
+    if (lane == 0) {
+        unsigned long long* const ps = g_sa_probe + (size_t)(blockIdx.x % SA_PROBE_SLOTS) * 16;
+        for (int i = 0; i < 6; i++) atomicAdd(&ps[i], pacc[i]);
+        atomicAdd(&ps[6], 1ull);
+        atomicAdd(&ps[7], (unsigned long long)n);
+        atomicAdd(&ps[8], (unsigned long long)__popcll(deferred));
+    }
+#endif
 }
 
 // The (tile, query) items the grouped kernel left to the per-query path (usually none once the bounds stand):
