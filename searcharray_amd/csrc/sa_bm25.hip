@@ -1672,10 +1672,16 @@ static int sa_launch_bm25_groups(sa_index* ix, const sa_batch* bt, const Bm25Par
     if (wgrid == 0) return SA_OK;
     // (weight table: n * tt cells; 64 cover up to 4 overlaid terms per query at 16 queries per item)
     const bool small = (u32)SA_GRP_MAXQ * gp.tt <= 64u;
+#ifdef SA_PROBE
+    // (measurement build: unused dynamic LDS per workgroup lowers the resident waves per CU -- the occupancy experiment of DESIGN 3.1a)
+    const u32 lds_pad = getenv("SA_PROBE_LDS_PAD") ? (u32)atoi(getenv("SA_PROBE_LDS_PAD")) : 0u;
+#else
+    const u32 lds_pad = 0u;
+#endif
 #define SA_LAUNCH_GROUP(TILE, THREADS)                                                                                     \
     {                                                                                                                      \
-        if (blocks && small) hipLaunchKernelGGL((sa_k_bm25_group_tiles<TILE, 64>), dim3((u32)blocks), dim3(64), 0, st, p, gp);       \
-        else if (blocks) hipLaunchKernelGGL((sa_k_bm25_group_tiles<TILE, 128>), dim3((u32)blocks), dim3(64), 0, st, p, gp);            \
+        if (blocks && small) hipLaunchKernelGGL((sa_k_bm25_group_tiles<TILE, 64>), dim3((u32)blocks), dim3(64), lds_pad, st, p, gp);       \
+        else if (blocks) hipLaunchKernelGGL((sa_k_bm25_group_tiles<TILE, 128>), dim3((u32)blocks), dim3(64), lds_pad, st, p, gp);            \
         hipLaunchKernelGGL((sa_k_bm25_tiles_wl<TILE, THREADS>), dim3(wgrid), dim3(THREADS), 0, st, p, (const u64*)gp.wl,   \
                            (const u32*)gp.wl_cnt);                                                                         \
     }                                                                                                                      \
