@@ -99,7 +99,8 @@ def main():
                         probe = {"items": v[6], "pairs": v[7], "deferred_pairs": v[8],
                                  "cycles_per_item": {nm: round(v[i] / items, 1) for i, nm in enumerate(names)},
                                  "cycles_per_pair_in_the_query_loop": {nm: round(v[i] / pairs, 1) for i, nm in enumerate(names) if 2 <= i <= 4},
-                                 "cycles_per_item_total": round(sum(v[:6]) / items, 1),
+                                 "cycles_per_item_total": round((sum(v[:6]) + sum(v[9:12])) / items, 1),
+                                 "fine": {nm: round(v[i] / items, 1) for i, nm in ((9, "kernel_start_to_group_entry_loaded"), (10, "slice_bounds_loaded"), (11, "q0_postings_loaded_after_tables"))} if any(v[9:12]) else None,
                                  "note": "s_memtime ticks at 100 MHz x ... see DESIGN 3.1a; one launch; items that reach the overlay"}
                     r0 = ref.setdefault((qname, k), res)
                     same = bool(np.array_equal(r0[0], res[0]) and np.array_equal(r0[1], res[1]))

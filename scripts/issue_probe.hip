@@ -36,12 +36,13 @@ enum Mode {
     M_LDS_RWW4_RND = 12,   // 4 random reads in flight, wait, 4 adds, 4 writes, 4 more writes (read / write / restore of 4 overlay halves, unchained)
     M_LDS_ATOM4_RND = 13,  // 4 random ds_add_rtn_u32 in flight, wait, 4 adds, 4 ds_sub_u32 (the fixed-point overlay: 2 LDS ops per half)
     M_LDS_ATOM4_NORTN = 14,// 4 random ds_add_u32 (no return), 4 ds_sub_u32
+    M_LDS_FATOM4_RND = 15, // 4 random ds_add_rtn_f32 in flight, wait, 4 adds, 4 ds_write_b32 (the float overlay with LDS atomics)
     M_COUNT
 };
 static const char* mode_name[M_COUNT] = {"valu", "salu", "mix_1wave", "split_valu_salu", "valu_dep", "salu_dep", "lds_rmw",
                                           "lds_rmw_random", "readlane_salu_valu_chain", "lds_rmw_2_in_flight",
                                           "split_valu_ldsrmw", "mix_dependent", "lds_read4_write4_write4_random",
-                                          "lds_addrtn4_sub4_random", "lds_add4_sub4_noreturn_random"};
+                                          "lds_addrtn4_sub4_random", "lds_add4_sub4_noreturn_random", "lds_faddrtn4_write4_random"};
 
 #define REP4(x) x x x x
 #define REP16(x) REP4(REP4(x))
@@ -100,7 +101,7 @@ __global__ void __launch_bounds__(1024) probe(u64* __restrict__ out, u32* __rest
             asm volatile(REP16(REP4("ds_read_b32 %0, %2\n ds_read_b32 %1, %3\n s_waitcnt lgkmcnt(0)\n v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n"
                                     "ds_write_b32 %2, %0\n ds_write_b32 %3, %1\n v_add_u32 %0, %0, %4\n"))
                          : "+v"(a), "+v"(b) : "v"(addr0), "v"(addr1), "v"(one) : "memory");
-        } else if (MODE == M_LDS_RWW4_RND || MODE == M_LDS_ATOM4_RND || MODE == M_LDS_ATOM4_NORTN) {
+        } else if (MODE == M_LDS_RWW4_RND || MODE == M_LDS_ATOM4_RND || MODE == M_LDS_ATOM4_NORTN || MODE == M_LDS_FATOM4_RND) {
             // 16 rounds of 4 halves: 4 address updates (3 VALU each), then the LDS pattern
             const u32 base = (u32)(uintptr_t)(lds_ptr)win;
             u32 r0 = rnd, r1 = rnd * 3u + 1u, r2 = rnd * 5u + 2u, r3 = rnd * 7u + 3u, a0, a1, a2, a3, v0 = 0, v1 = 0, v2 = 0, v3 = 0;
@@ -121,6 +122,13 @@ __global__ void __launch_bounds__(1024) probe(u64* __restrict__ out, u32* __rest
                                    "ds_add_rtn_u32 %0, %8, %12\n ds_add_rtn_u32 %1, %9, %12\n ds_add_rtn_u32 %2, %10, %12\n ds_add_rtn_u32 %3, %11, %12\n s_waitcnt lgkmcnt(0)\n"
                                    "v_add_u32 %0, %0, %12\n v_add_u32 %1, %1, %12\n v_add_u32 %2, %2, %12\n v_add_u32 %3, %3, %12\n"
                                    "ds_sub_u32 %8, %12\n ds_sub_u32 %9, %12\n ds_sub_u32 %10, %12\n ds_sub_u32 %11, %12\n")
+                             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
+                             : "v"(one), "v"(base) : "memory");
+            } else if (MODE == M_LDS_FATOM4_RND) {
+                asm volatile(REP16(SA_ADDR4
+                                   "ds_add_rtn_f32 %0, %8, %12\n ds_add_rtn_f32 %1, %9, %12\n ds_add_rtn_f32 %2, %10, %12\n ds_add_rtn_f32 %3, %11, %12\n s_waitcnt lgkmcnt(0)\n"
+                                   "v_add_f32 %0, %0, %12\n v_add_f32 %1, %1, %12\n v_add_f32 %2, %2, %12\n v_add_f32 %3, %3, %12\n"
+                                   "ds_write_b32 %11, %3\n ds_write_b32 %10, %2\n ds_write_b32 %9, %1\n ds_write_b32 %8, %0\n")
                              : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
                              : "v"(one), "v"(base) : "memory");
             } else {
@@ -218,5 +226,6 @@ int main(int argc, char** argv) {
     sweep<M_LDS_RWW4_RND>(iters / 4 + 1, n_cu, d_out, d_hw, false);
     sweep<M_LDS_ATOM4_RND>(iters / 4 + 1, n_cu, d_out, d_hw, false);
     sweep<M_LDS_ATOM4_NORTN>(iters / 4 + 1, n_cu, d_out, d_hw, false);
+    sweep<M_LDS_FATOM4_RND>(iters / 4 + 1, n_cu, d_out, d_hw, false);
     return 0;
 }

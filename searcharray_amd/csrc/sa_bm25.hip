@@ -930,6 +930,11 @@ __device__ __forceinline__ void sa_static_while_below(u32 n, F&& f) {
 #define SA_PROBE_SLOTS 4096
 __device__ unsigned long long g_sa_probe[SA_PROBE_SLOTS * 16];       // (slot = block mod SLOTS: no two waves in flight share cells)
 #define SA_PT(i) do { const u64 t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - plast; plast = t_; } while (0)
+#ifdef SA_PROBE_FINE      // sub-sections of the item's preamble: vector loads are waited for where they are charged
+#define SA_PTV(i) do { __builtin_amdgcn_s_waitcnt(0x0F70); SA_PT(i); } while (0)
+#else
+#define SA_PTV(i) do { } while (0)
+#endif
 extern "C" int sa_debug_probe_read(unsigned long long* out16, int clear) {
     if (hipDeviceSynchronize() != hipSuccess) return SA_ERR_HIP;
     std::vector<unsigned long long> h((size_t)SA_PROBE_SLOTS * 16, 0ull);
@@ -940,6 +945,7 @@ extern "C" int sa_debug_probe_read(unsigned long long* out16, int clear) {
 }
 #else
 #define SA_PT(i) do { } while (0)
+#define SA_PTV(i) do { } while (0)
 #endif
 
 // IDFN: cells of the item's weight table = queries x lanes-per-query of the table build (64: up to 4 overlaid terms per
@@ -955,7 +961,7 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
     u32* const accu = (u32*)smem;
     const u32 lane = threadIdx.x;
 #ifdef SA_PROBE
-    u64 pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64 pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     u64 plast = __builtin_amdgcn_s_memtime();
 #endif
     // XCD-aware item order: consecutive blocks go to consecutive XCDs (block b runs on XCD b % 8), so the
@@ -1032,10 +1038,19 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
         }
     };
     const u32 NP = (n + QPP - 1u) / QPP;                        // 1 or 2 passes (host: n * TT <= 128)
+    // the shared term's dense factor row, requested BEFORE the tables are built (round 5: its latency used to start after them)
+    float4 dv[TILE / 256];
+    if (dslot != 0xFFFFFFFFu) {
+        const float4* row4 = (const float4*)(gp.dense + (u64)dslot * gp.dense_stride + tile_base);
+#pragma unroll
+        for (int j = 0; j < TILE / 256; j++) dv[j] = row4[j * 64 + (int)lane];
+    }
+    SA_PTV(9);                                                  // (fine: group entry, first term's slice bounds, stream base, weight)
     {
         const Pre x0 = pre_load(0);
         Pre x1 = x0;
         if (NP > 1u) x1 = pre_load(1);
+        SA_PTV(10);                                             // (fine: the further terms' slice bounds)
         pre_store(0, x0);
         if (NP > 1u) pre_store(1, x1);
     }
@@ -1078,22 +1093,19 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
     if (p.seed && lane < n) { const u32 sd = p.seed[row0 + lane]; thr_all = sd > thr_all ? sd : thr_all; }
     Q A, B;
     prefetch(0, A);                                             // in flight while the base is built
+    SA_PTV(11);                                                 // (fine: bounds + query 0's postings)
 
     // ---- base: clear, then the first term's slice scored once (write-only: 0 + s0 = s0)
     u32 base_max;
     if (dslot != 0xFFFFFFFFu) {
         // the shared term has a dense factor row: lane = doc, four docs per 16-byte load and LDS store, no unpacking and no
         // scatter (docs without the term hold 0.0 -> 0.0 * idf = +0.0, what the cleared accumulator holds)
-        const float4* row4 = (const float4*)(gp.dense + (u64)dslot * gp.dense_stride + tile_base);
         float4* a4 = (float4*)accu;
-        float4 v[TILE / 256];
-#pragma unroll
-        for (int j = 0; j < TILE / 256; j++) v[j] = row4[j * 64 + (int)lane];
         u32 lmax = 0;
 #pragma unroll
         for (int j = 0; j < TILE / 256; j++) {
             float4 w;
-            w.x = __fmul_rn(v[j].x, hidf); w.y = __fmul_rn(v[j].y, hidf); w.z = __fmul_rn(v[j].z, hidf); w.w = __fmul_rn(v[j].w, hidf);
+            w.x = __fmul_rn(dv[j].x, hidf); w.y = __fmul_rn(dv[j].y, hidf); w.z = __fmul_rn(dv[j].z, hidf); w.w = __fmul_rn(dv[j].w, hidf);
             a4[j * 64 + (int)lane] = w;
             const u32 m0 = __float_as_uint(w.x) > __float_as_uint(w.y) ? __float_as_uint(w.x) : __float_as_uint(w.y);
             const u32 m1 = __float_as_uint(w.z) > __float_as_uint(w.w) ? __float_as_uint(w.z) : __float_as_uint(w.w);
@@ -1315,6 +1327,7 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
     if (lane == 0) {
         unsigned long long* const ps = g_sa_probe + (size_t)(blockIdx.x % SA_PROBE_SLOTS) * 16;
         for (int i = 0; i < 6; i++) atomicAdd(&ps[i], pacc[i]);
+        for (int i = 9; i < 12; i++) atomicAdd(&ps[i], pacc[i]);
         atomicAdd(&ps[6], 1ull);
         atomicAdd(&ps[7], (unsigned long long)n);
         atomicAdd(&ps[8], (unsigned long long)__popcll(deferred));
