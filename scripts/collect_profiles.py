@@ -100,6 +100,8 @@ def main():
     for src, dst in [("kernel_ab.log", f"kernel_ab_{RND}.jsonl"), ("host_cost.log", f"host_cost_{RND}.jsonl"),
                      ("route_rule.jsonl", f"route_rule_{RND}.jsonl"), ("route_rule_1250k.jsonl", f"route_rule_{RND}_1250k.jsonl"),
                      ("dense_threads.jsonl", f"dense_threads_{RND}.jsonl"), ("issue_probe.jsonl", f"issue_probe_{RND}.jsonl"),
+                     ("probe_sections.jsonl", f"group_kernel_cycle_sections_{RND}.jsonl"), ("probe_sections_fine.jsonl", f"group_kernel_cycle_sections_fine_{RND}.jsonl"),
+                     ("occupancy.jsonl", f"group_kernel_occupancy_{RND}.jsonl"), ("lds_fadd_probe.json", f"lds_fadd_probe_{RND}.jsonl"),
                      ("slop_heavy.log", f"slop_heaviest_{RND}.jsonl"), ("slop_routes.log", f"slop_routes_{RND}.jsonl")]:
         js = json_lines(os.path.join(OUT, src))
         if js:
@@ -116,6 +118,12 @@ def main():
         if f:
             shutil.copy(f, os.path.join(PROF, dst))
             print("wrote", dst)
+    lat = os.path.join(OUT, "latency_summary.json")
+    if os.path.exists(lat) and os.path.getsize(lat) > 10:
+        json.dump({"command": "rocprofv3 --pmc VmemLatency | LdsLatency | SmemLatency --kernel-trace -- python scripts/ab.py --ks 10 --steps 2 (one pass per "
+                              "counter; derived counters: in-flight level accumulated per cycle / instructions of the class); cycles, mean per dispatch",
+                   "kernels": json.load(open(lat))}, open(os.path.join(PROF, f"{RND}_scoring_kernels_latency_counters.json"), "w"), indent=1)
+        print("wrote", f"{RND}_scoring_kernels_latency_counters.json")
     sq = os.path.join(OUT, "sq_summary.json")
     if os.path.exists(sq) and os.path.getsize(sq) > 10:
         out = {"command": "rocprofv3 --pmc <8 SQ counters> --kernel-trace -- python scripts/ab.py --ks 10 --steps 2 (two passes); 10M docs, "

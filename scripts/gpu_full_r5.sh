@@ -31,6 +31,16 @@ A="--no-cpu-baseline --no-pmc --no-phrase-legs --docs 1250000 --steps 200 --pipe
 ( time timeout 300 python scripts/slop_bench.py ) > $O/slop_bench.log 2>&1
 ( time timeout 300 python scripts/slop_routes.py ) > $O/slop_routes.log 2>&1
 ( time timeout 120 python scripts/msmarco.py ) > $O/msmarco.log 2>&1
+# where a wave of the grouped kernel spends its cycles (-DSA_PROBE builds: scripts/build_probe.sh), resident waves per SIMD 4 / 3 / 2 / 1
+( timeout 300 python scripts/ab.py --corpus-cache $C --ks 10 --qsets baseline,distinct,hot --libs build/libsearcharray_hip_probe.so --envs "SA_SPARSE=0" ) 2>&1 | grep "^{" > $O/probe_sections.jsonl
+( timeout 300 python scripts/ab.py --corpus-cache $C --ks 10 --docs 1250000 --qsets baseline --libs build/libsearcharray_hip_probe.so --envs "SA_SPARSE=0" ) 2>&1 | grep "^{" >> $O/probe_sections.jsonl
+( timeout 300 python scripts/ab.py --corpus-cache $C --ks 10 --qsets baseline --libs build/libsearcharray_hip_probe_fine.so --envs "SA_SPARSE=0" ) 2>&1 | grep "^{" > $O/probe_sections_fine.jsonl
+rm -f $O/occupancy.jsonl
+for pad in 0 3200 10240 30720; do
+  ( SA_PROBE_LDS_PAD=$pad timeout 300 python scripts/ab.py --corpus-cache $C --ks 10 --qsets baseline --libs build/libsearcharray_hip_probe.so --envs "SA_SPARSE=0" ) 2>&1 | grep "^{" | sed "s/^{/{\"lds_pad\": $pad, /" >> $O/occupancy.jsonl
+done
+( timeout 120 build/lds_fadd_probe ) > $O/lds_fadd_probe.json 2>&1
+bash $R/scripts/gpu_r5_latency.sh > $O/latency.log 2>&1
 cd /tmp
 ( timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_main -- python $R/scripts/ab.py --corpus-cache $C --ks 10 --qsets baseline --steps 12 ) > $O/prof_main.log 2>&1
 ( timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_distinct -- python $R/scripts/ab.py --corpus-cache $C --ks 10 --qsets distinct --steps 12 ) > $O/prof_distinct.log 2>&1

@@ -172,8 +172,10 @@ def build_index_from_tokenizer(array: Iterable, tokenizer: Callable, truncate: b
     """reference indexing.py:235-296: the docs are taken ``batch_size`` at a time; a batch's token ids end as ONE uint32
     array (4 bytes per token) and its Python objects are dropped before the next batch is touched, so the transient host
     memory is a batch's, not the collection's (the reference's design size of 1 M docs is ~32 M tokens: > 1 GB as Python
-    ints in one list, 128 MB as these arrays).  ``workers`` > 1 runs the TOKENIZER of up to ``workers`` batches ahead on
-    a thread pool, as the reference does; term ids are still assigned by this thread in document order -- unlike the
+    ints in one list, 128 MB as these arrays).  ``workers`` > 1 runs the TOKENIZER on a thread pool, as the reference does:
+    a batch is cut into ``workers`` pieces that are tokenized side by side, and at most TWO batches exist as Python lists at
+    any time (the one being taken and the one being tokenized) -- not ``workers`` of them.  Term ids are still assigned by
+    this thread in document order -- unlike the
     reference's (its workers race for the shared dictionary, indexing.py:190-209), so an index does not depend on the
     thread timing.  Host work is the tokenizer and the term dictionary only; the result carries the token stream, which
     is sorted and roaringish-encoded on the device (csrc/sa_build.hip)."""
@@ -211,13 +213,24 @@ def build_index_from_tokenizer(array: Iterable, tokenizer: Callable, truncate: b
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
         pending: deque = deque()
+
+        def submit(batch: list) -> list:
+            step = (len(batch) + workers - 1) // workers
+            return [pool.submit(tokenize, batch[i:i + step]) for i in range(0, len(batch), step)]
+
+        def collect(parts: list) -> list:
+            out: list = []
+            for f in parts:
+                out.extend(f.result())
+            return out
+
         with ThreadPoolExecutor(max_workers=workers) as pool:
             for batch in _batches(array, batch_size):
-                pending.append(pool.submit(tokenize, batch))
-                if len(pending) >= workers:
-                    take(pending.popleft().result())
+                pending.append(submit(batch))
+                if len(pending) >= 2:                       # (the next batch is tokenized while this one is taken)
+                    take(collect(pending.popleft()))
             while pending:
-                take(pending.popleft().result())
+                take(collect(pending.popleft()))
     lens_a = np.concatenate(len_chunks) if len_chunks else np.empty(0, np.int64)
     tokens = np.concatenate(chunks) if chunks else np.empty(0, np.uint32)
     chunks.clear()
