@@ -65,7 +65,8 @@ typedef struct sa_options {
     int64_t group_side;      /* 0: ungrouped rows on the batch's own stream instead of the side stream */
     int64_t group_dense;     /* 0: the grouped kernel builds its base from postings even where a dense factor row exists */
     int64_t group_min;       /* smallest group (default 2) */
-    int64_t group_maxq;      /* queries per grouped item (default and at most 16) */
+    int64_t group_maxq;      /* queries per table pass of a grouped item (default and at most 16) */
+    int64_t group_item;      /* queries per grouped item: passes of group_maxq queries over ONE base (at most 64; default 32 for big launches, else 16) */
     int64_t group_warm;      /* tiles scored by the per-query kernel first to establish bounds (default: none with starting bounds) */
     int64_t loose_postings;  /* loose groups: expected postings of a query per tile at most (default 400) */
     int64_t xcd_range;       /* 0: tiles dealt round-robin to the XCDs instead of ranges */

@@ -110,7 +110,7 @@ struct sa_batch {
     u64* d_wl = nullptr;            // (tile, row) items the grouped kernel leaves to the per-query kernel
     u32* d_wl_cnt = nullptr;
     u32* d_iota = nullptr;          // [B] 0 .. B-1 (query lists of the per-query kernel: rows [a, b) = d_iota + a)
-    u32 n_groups = 0, n_grouped_rows = 0, grp_tt = 1, grp_tt_shift = 0;
+    u32 n_groups = 0, n_grouped_rows = 0, grp_tt = 1, grp_tt_shift = 0, grp_cq = 16;
     bool last_route_sparse = false; // the last run took dynamic pruning (sa_batch_last_route)
     // phrase batches (sa_phrase_batch.hip): kind == 1
     int kind = 0;                   // 0: disjunctive BM25 over terms, 1: exact phrases

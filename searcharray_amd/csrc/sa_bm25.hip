@@ -868,7 +868,8 @@ __global__ void __launch_bounds__(THREADS) sa_k_bm25_tiles_list(const Bm25Params
 // count them and wait for the current query's data only).
 // ---------------------------------------------------------------------------------------------
 #define SA_GRP_NH 10        // 64-posting halves of a query's further terms held in registers (640 postings per tile and query)
-#define SA_GRP_MAXQ 16      // queries per group item (bigger groups are cut into balanced pieces)
+#define SA_GRP_MAXQ 16      // queries per table pass of a group item
+#define SA_GRP_ITEM_ROUNDS 16    // items of 32 queries (two table passes) from this many rounds of 4096 one-pass items on; option group_item
 
 struct GroupParams {
     const u32* grp;         // [n_groups][3]: first device row, number of rows (rows of a group are contiguous), dense factor row of the shared first term or 0xFFFFFFFF
@@ -878,6 +879,7 @@ struct GroupParams {
     u32 tile0, n_tiles_run; // tiles [tile0, tile0 + n_tiles_run)
     u32 tpx;                // tiles per XCD: XCD x takes the RANGE [x * tpx, (x + 1) * tpx) of the run's tiles (0: tiles t = x mod 8)
     u32 tt, tt_shift;       // lanes per query while the step tables are built: power of two >= max(T - 1, 1)
+    u32 cq;                 // queries per table pass: an item of more queries builds its tables pass after pass over ONE base
     u64* wl;                // work list of (tile << 32 | device row) items left to the per-query kernel
     u32* wl_cnt;
 };
@@ -957,7 +959,7 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
     __shared__ alignas(16) u64 smem[sa_tile_smem_u64<TILE, 1>()];
     __shared__ u64 s_half[SA_GRP_MAXQ][NH];
     __shared__ float s_idf[IDFN];
-    __shared__ u64 s_surv[SA_GRP_SURV_CAP];                     // survivors waiting for their places: score bits << 32 | accumulator offset << 4 | query
+    __shared__ u64 s_surv[SA_GRP_SURV_CAP];                     // survivors waiting for their places: score bits << 32 | accumulator offset << 6 | query of the item
     u32* const accu = (u32*)smem;
     const u32 lane = threadIdx.x;
 #ifdef SA_PROBE
@@ -999,12 +1001,16 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
     // ---- half tables of the queries' further terms: lane (qi, t) looks up term t's slice of query qi in this
     //      tile and writes one entry per 64 postings, in query-term order
     const u32 TT = gp.tt, tsh = gp.tt_shift, QPP = 64u >> tsh;
+    // round 5: an item holds up to 64 queries of its group and takes them in PASSES of gp.cq (<= 16): the tables are built per
+    // pass, the base -- and everything in front of it: block -> (tile, group), group entry, the shared term's slice and dense row --
+    // once per item (cq0: first query of the pass, nq: its queries)
+    u32 cq0 = 0u, nq = n < gp.cq ? n : gp.cq;
     struct Pre { u32 r0, r1; u64 base, send; float idf; };
     auto pre_load = [&](u32 ps) -> Pre {
         Pre x; x.r0 = 0; x.r1 = 0; x.base = 0; x.send = 0; x.idf = 0.f;
         const u32 qi = ps * QPP + (lane >> tsh), t = (loose ? 0u : 1u) + (lane & (TT - 1u));
-        if (qi < n && t < T) {
-            const u32 qt = (row0 + qi) * T + t;
+        if (qi < nq && t < T) {
+            const u32 qt = (row0 + cq0 + qi) * T + t;
             const u32* row = p.bounds + (u64)qt * (p.n_tiles + 1) + tile;
             const sa_u64x2 bs = ((const sa_u64x2*)p.qbase_imp)[qt];
             x.base = bs.x; x.send = bs.y;
@@ -1023,7 +1029,7 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
         }
         const u32 excl = incl - halves;
         const u32 total = (u32)__shfl((int)incl, (int)(lane | (TT - 1u)), SA_WAVE);
-        if (qi < n) {
+        if (qi < nq) {
             s_idf[qi * TT + tl] = x.idf;
             const u64 c0 = x.base + x.r0;                       // first cell of the slice
             const u64 nhf = (u64)(total <= (u32)NH ? total : SA_GRPH_OVER) << SA_GRPH_NH_SHIFT;
@@ -1037,7 +1043,6 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
             if (tl == 0u && total == 0u) s_half[qi][0] = (u64)(stream + p.imp_tail);
         }
     };
-    const u32 NP = (n + QPP - 1u) / QPP;                        // 1 or 2 passes (host: n * TT <= 128)
     // the shared term's dense factor row, requested BEFORE the tables are built (round 5: its latency used to start after them)
     float4 dv[TILE / 256];
     if (dslot != 0xFFFFFFFFu) {
@@ -1046,19 +1051,22 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
         for (int j = 0; j < TILE / 256; j++) dv[j] = row4[j * 64 + (int)lane];
     }
     SA_PTV(9);                                                  // (fine: group entry, first term's slice bounds, stream base, weight)
-    {
+    auto build_tables = [&]() {
+        const u32 NP = (nq + QPP - 1u) / QPP;                   // 1 or 2 lane passes (host: cq * TT <= 128)
+        __builtin_amdgcn_wave_barrier();
         const Pre x0 = pre_load(0);
         Pre x1 = x0;
         if (NP > 1u) x1 = pre_load(1);
         SA_PTV(10);                                             // (fine: the further terms' slice bounds)
         pre_store(0, x0);
         if (NP > 1u) pre_store(1, x1);
-    }
-    // One wave per workgroup: its LDS instructions execute in program order for all lanes, so lanes hand data
-    // to each other through LDS without s_barrier; the wave barriers below only pin the order of the accesses
-    // for the compiler (they emit no instruction).
-    __builtin_amdgcn_wave_barrier();
-    {
+        // One wave per workgroup: its LDS instructions execute in program order for all lanes, so lanes hand data
+        // to each other through LDS without s_barrier; the wave barriers only pin the order of the accesses
+        // for the compiler (they emit no instruction).
+        __builtin_amdgcn_wave_barrier();
+    };
+    build_tables();
+    if (n <= gp.cq) {
         // nothing to score in this tile at all?
         const u32 mine = lane < n ? (u32)(s_half[lane][0] >> SA_GRPH_NH_SHIFT) : 0u;
         if (h1 == h0 && ballot(mine != 0u) == 0ull) return;
@@ -1175,7 +1183,7 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
         if (my_surv) cbase = atomicAdd(&p.cand_cnt[row0 + lane], my_surv);
         u32 start = my_surv;
 #pragma unroll
-        for (int o = 1; o < SA_GRP_MAXQ; o <<= 1) {
+        for (int o = 1; o < SA_WAVE; o <<= 1) {
             const u32 up = (u32)__shfl_up((int)start, (unsigned)o, SA_WAVE);
             if (lane >= (u32)o) start += up;
         }
@@ -1184,7 +1192,7 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
             const u32 e = e0 + lane;
             const bool have = e < nsurv;
             const u64 ent = s_surv[have ? e : 0u];
-            const u32 eq = (u32)ent & 0xFu, sl = (u32)ent >> 4, fin = (u32)(ent >> 32);
+            const u32 eq = (u32)ent & 0x3Fu, sl = (u32)ent >> 6, fin = (u32)(ent >> 32);
             const u32 qb = (u32)__shfl((int)cbase, (int)eq, SA_WAVE), qs = (u32)__shfl((int)start, (int)eq, SA_WAVE);
             if (have) {
                 const u32 q = row0 + eq;
@@ -1213,9 +1221,10 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
     // (sign bit of what they read) report the docs that reach the bound.
     auto process = [&](u32 qi, const Q& X) {
         const u32 nh_raw = (u32)__builtin_amdgcn_readfirstlane((int)X.dhi) >> (SA_GRPH_NH_SHIFT - 32);
-        const u32 thr_q = (u32)__builtin_amdgcn_readlane((int)thr_all, (int)qi);
+        const u32 gq = cq0 + qi;                                // the query's place in the item (its lane of thr_all / my_surv, its bit of deferred)
+        const u32 thr_q = (u32)__builtin_amdgcn_readlane((int)thr_all, (int)gq);
         const u32 thr = thr_q > 1u ? thr_q : 1u;
-        if (nh_raw > (u32)NH || base_max >= thr) { deferred |= 1ull << qi; return; }
+        if (nh_raw > (u32)NH || base_max >= thr) { deferred |= 1ull << gq; return; }
         if (nh_raw == 0u) return;                               // the query scores exactly the base here: all below its bound
         const u32 nh = nh_raw;                                  // (round 4: an odd count no longer gets an empty partner half)
         u32 rs[NH], ro[NH];
@@ -1276,7 +1285,7 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
             c += (u32)__popcll(kb[i]);
         }
         if (c == 0u) return;
-        if (c > 16u) { deferred |= 1ull << qi; return; }        // bound still far off: the per-query item's histogram path refines it first
+        if (c > 16u) { deferred |= 1ull << gq; return; }        // bound still far off: the per-query item's histogram path refines it first
         // Survivors are buffered in LDS and written out together (flush below): reserving places in a query's
         // candidate list is an atomic WITH a return value -- a round trip to L2 the wave sits out; per surviving pair
         // that was most of the 0.45 ms the candidates cost at k = 1000.  Flushed, the reservations of all queries of
@@ -1286,31 +1295,39 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
 #pragma unroll
         for (int i = 0; i < NH; i++) {
             if (kb[i]) {                                        // (uniform: halves without survivors cost a scalar test)
-                if ((kb[i] >> lane) & 1ull) s_surv[nsurv + (u32)__popcll(kb[i] & lt)] = ((u64)fin[i] << 32) | (u64)(rs[i] << 4) | (u64)qi;
+                if ((kb[i] >> lane) & 1ull) s_surv[nsurv + (u32)__popcll(kb[i] & lt)] = ((u64)fin[i] << 32) | (u64)(rs[i] << 6) | (u64)gq;
                 nsurv += (u32)__popcll(kb[i]);
             }
         }
-        if (lane == qi) my_surv = c;
+        if (lane == gq) my_surv = c;
     };
 
     // ---- the queries of the group, two per round so that the prefetch buffers swap without copies.  Before the
     //      next query's loads are issued everything older has landed (an exact wait: only the current query's
     //      loads are outstanding), so the current query is processed while exactly the next one's loads fly.
-    for (u32 qi = 0; qi < n; qi += 2) {
-        SA_WAIT_VMCNT0();
-        SA_PT(2);
-        if (qi + 1u < n) prefetch(qi + 1u, B);
-        SA_PT(3);
-        process(qi, A);
-        SA_PT(4);
-        if (qi + 1u < n) {
+    for (;;) {
+        for (u32 qi = 0; qi < nq; qi += 2) {
             SA_WAIT_VMCNT0();
             SA_PT(2);
-            if (qi + 2u < n) prefetch(qi + 2u, A);
+            if (qi + 1u < nq) prefetch(qi + 1u, B);
             SA_PT(3);
-            process(qi + 1u, B);
+            process(qi, A);
             SA_PT(4);
+            if (qi + 1u < nq) {
+                SA_WAIT_VMCNT0();
+                SA_PT(2);
+                if (qi + 2u < nq) prefetch(qi + 2u, A);
+                SA_PT(3);
+                process(qi + 1u, B);
+                SA_PT(4);
+            }
         }
+        // the item's next pass: tables of its next queries over the same base
+        cq0 += nq;
+        if (cq0 >= n) break;
+        nq = n - cq0 < gp.cq ? n - cq0 : gp.cq;
+        build_tables();
+        prefetch(0, A);
     }
     if (nsurv) flush();
     // ---- general path: hand the (tile, query) pairs to the per-query kernel that follows (sa_k_bm25_tiles_wl)
@@ -1673,7 +1690,7 @@ static int sa_launch_bm25_groups(sa_index* ix, const sa_batch* bt, const Bm25Par
     GroupParams gp;
     gp.grp = bt->d_grp; gp.n_groups = bt->n_groups;
     gp.tile0 = tile0; gp.n_tiles_run = ix->n_tiles - tile0;
-    gp.tt = bt->grp_tt; gp.tt_shift = bt->grp_tt_shift;
+    gp.tt = bt->grp_tt; gp.tt_shift = bt->grp_tt_shift; gp.cq = bt->grp_cq;
     gp.dense = (bt->impacts && sa_opt(bt->opts.group_dense, 1) != 0) ? bt->impacts->d_dense : nullptr;
     gp.dense_stride = bt->impacts ? bt->impacts->dense_stride : 0;
     const u64 blocks = (u64)((gp.n_tiles_run + 7u) / 8u) * 8u * gp.n_groups;
@@ -2152,6 +2169,15 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
         // (a shard whose (tile, group) items do not fill the device for many rounds is better cut into more, shorter items:
         //  SA_GROUP_MAXQ; measured on a 1.25 M-doc shard below)
         maxq = std::min<u32>(maxq, (u32)std::max<long long>(1, sa_opt(bt->opts.group_maxq, SA_GRP_MAXQ)));
+        // queries per ITEM: an item takes its queries in passes of maxq over one base, so a group of 25 is ONE item (two passes), not
+        // two items that each pay the item's fixed cost (block -> tile, group entry, slice of the shared term, dense row, base:
+        // ~6 K of an item's ~34 K cycles)
+        //  Two passes per item are worth it where the launch has many rounds of items to run (same box, BASELINE batch, items of 16 vs
+        //  32 queries: 10 M docs 0.402 -> 0.381 ms, 7.5 M 0.311 -> 0.302, 5 M 0.2185 -> 0.218, 2.5 M 0.124 -> 0.134, 1.25 M 0.085 -> 0.094:
+        //  fewer, longer items lengthen the launch's tail) -- from 16 rounds of the device's 4096 resident waves on; loose groups have
+        //  no base to share and keep 16 (measured: 0.464 -> 0.483 ms with 32).
+        u32 item_q = maxq;                                      // (set below, once the groups are known)
+        bt->grp_cq = maxq;
         const u32 gmin = (u32)std::max<long long>(1, sa_opt(bt->opts.group_min, 2));
         bool idf_ok = k1 >= 0.f && b >= 0.f && b <= 1.f;       // scores must be non-negative (the sign bit is a mark)
         for (size_t i = 0; i < (size_t)B * T && idf_ok; i++) idf_ok = idf[i] >= 0.f && idf[i] <= 3.0e38f;
@@ -2171,10 +2197,16 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
                 if (gi == keys.size()) { keys.push_back({t0, ib}); members.emplace_back(); }
                 members[gi].push_back(q);
             }
+            {
+                u64 items16 = 0;
+                for (auto& m : members) if (m.size() >= gmin) items16 += (m.size() + maxq - 1) / maxq;
+                const long long dflt = items16 * (u64)ix->n_tiles >= (u64)SA_GRP_ITEM_ROUNDS * 4096u ? 32 : 16;
+                item_q = std::max<u32>(maxq, std::min<u32>(64u, (u32)std::max<long long>(1, sa_opt(bt->opts.group_item, dflt))) / maxq * maxq);
+            }
             std::vector<u32> order;
             for (auto& m : members) {
                 if (m.size() < gmin) { rest.insert(rest.end(), m.begin(), m.end()); continue; }
-                const u32 pieces = ((u32)m.size() + maxq - 1) / maxq;
+                const u32 pieces = ((u32)m.size() + item_q - 1) / item_q;
                 u32 done = 0;
                 for (u32 pc = 0; pc < pieces; pc++) {
                     const u32 sz = ((u32)m.size() - done + (pieces - pc) - 1) / (pieces - pc);
@@ -2206,7 +2238,8 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
                     else dense_rows.push_back(q);
                 }
                 if (sparse_rows.size() >= 2) {
-                    const u32 pieces = ((u32)sparse_rows.size() + SA_GRP_MAXQ - 1) / SA_GRP_MAXQ;
+                    const u32 item_l = sa_opt_is_set(bt->opts.group_item) ? std::max<u32>(SA_GRP_MAXQ, item_q / SA_GRP_MAXQ * SA_GRP_MAXQ) : (u32)SA_GRP_MAXQ;
+                    const u32 pieces = ((u32)sparse_rows.size() + item_l - 1) / item_l;
                     u32 done = 0;
                     for (u32 pc = 0; pc < pieces; pc++) {
                         const u32 sz = ((u32)sparse_rows.size() - done + (pieces - pc) - 1) / (pieces - pc);

@@ -44,7 +44,7 @@ def zipf10m():
 
 
 def run(dev, queries, env, monkeypatch):
-    for k_ in ("SA_SPARSE", "SA_GROUP"):
+    for k_ in ("SA_SPARSE", "SA_GROUP", "SA_GROUP_ITEM"):
         unset_opt(k_)
     for k_, v in env.items():
         set_opt(k_, v)
@@ -71,7 +71,11 @@ def test_config4_all_routes_agree_and_equal_the_oracle(zipf10m, monkeypatch):
     assert gi["grouped_queries"] >= 200, gi
     (per_query, _) = run(dev, queries, {"SA_SPARSE": "0", "SA_GROUP": "0"}, monkeypatch)
     (pruned, _) = run(dev, queries, {"SA_SPARSE": "1"}, monkeypatch)
-    for name, got in (("per-query", per_query), ("pruned", pruned)):
+    # the default at this size: items of up to 32 queries in two table passes; one-pass items and four-pass items beside it
+    (one_pass, g16) = run(dev, queries, {"SA_SPARSE": "0", "SA_GROUP_ITEM": "16"}, monkeypatch)
+    (four_pass, g64) = run(dev, queries, {"SA_SPARSE": "0", "SA_GROUP_ITEM": "64"}, monkeypatch)
+    assert g64["groups"] < gi["groups"] < g16["groups"], (g64, gi, g16)
+    for name, got in (("per-query", per_query), ("pruned", pruned), ("one-pass items", one_pass), ("four-pass items", four_pass)):
         assert np.array_equal(grouped[0], got[0]), f"scores: grouped vs {name}"
         assert np.array_equal(grouped[1], got[1]), f"docs: grouped vs {name}"
     check_oracle(orc, queries, grouped[0], grouped[1], range(17))       # the probe query t0 t9 t99 t999 and 16 more
