@@ -101,7 +101,7 @@ def main():
                      ("route_rule.jsonl", f"route_rule_{RND}.jsonl"), ("route_rule_1250k.jsonl", f"route_rule_{RND}_1250k.jsonl"),
                      ("dense_threads.jsonl", f"dense_threads_{RND}.jsonl"), ("issue_probe.jsonl", f"issue_probe_{RND}.jsonl"),
                      ("probe_sections.jsonl", f"group_kernel_cycle_sections_{RND}.jsonl"), ("probe_sections_fine.jsonl", f"group_kernel_cycle_sections_fine_{RND}.jsonl"),
-                     ("occupancy.jsonl", f"group_kernel_occupancy_{RND}.jsonl"), ("lds_fadd_probe.json", f"lds_fadd_probe_{RND}.jsonl"),
+                     ("occupancy.jsonl", f"group_kernel_occupancy_{RND}.jsonl"), ("item_ab.jsonl", f"group_item_passes_ab_{RND}.jsonl"), ("item_sweep.jsonl", f"group_item_passes_by_shard_size_{RND}.jsonl"), ("lds_fadd_probe.json", f"lds_fadd_probe_{RND}.jsonl"),
                      ("slop_heavy.log", f"slop_heaviest_{RND}.jsonl"), ("slop_routes.log", f"slop_routes_{RND}.jsonl")]:
         js = json_lines(os.path.join(OUT, src))
         if js:

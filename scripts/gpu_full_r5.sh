@@ -22,6 +22,8 @@ A="--no-cpu-baseline --no-pmc --no-phrase-legs --docs 1250000 --steps 200 --pipe
 ( time RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_PORT=29533 SA_BENCH_FORCE_COMM=1 timeout 300 python bench.py $A ) > $O/dist1_rccl.log 2>&1
 ( time timeout 300 python bench.py $A ) > $O/rank_nocomm.log 2>&1
 ( time timeout 600 python scripts/ab.py --corpus-cache $C --ks 10,100,1000 --qsets baseline,distinct --libs build/libsearcharray_hip_r04.so,searcharray_amd/libsearcharray_hip.so --envs "SA_SPARSE=0" ) > $O/kernel_ab.log 2>&1
+( timeout 400 python scripts/ab.py --corpus-cache $C --ks 10,100,1000 --qsets baseline,distinct --libs searcharray_amd/libsearcharray_hip.so --envs "SA_SPARSE=0,group_item=16;SA_SPARSE=0;SA_SPARSE=0,group_item=64" ) 2>&1 | grep "^{" > $O/item_ab.jsonl
+bash scripts/gpu_r5_item.sh > /dev/null 2>&1
 ( time timeout 300 python scripts/host_cost.py --docs 1250000 ) > $O/host_cost.log 2>&1
 ( time timeout 300 python scripts/host_cost.py --docs 1250000 --comm ) >> $O/host_cost.log 2>&1
 ( time timeout 900 python scripts/route_rule.py --steps 30 ) > $O/route_rule.jsonl 2> $O/route_rule.err
@@ -32,12 +34,12 @@ A="--no-cpu-baseline --no-pmc --no-phrase-legs --docs 1250000 --steps 200 --pipe
 ( time timeout 300 python scripts/slop_routes.py ) > $O/slop_routes.log 2>&1
 ( time timeout 120 python scripts/msmarco.py ) > $O/msmarco.log 2>&1
 # where a wave of the grouped kernel spends its cycles (-DSA_PROBE builds: scripts/build_probe.sh), resident waves per SIMD 4 / 3 / 2 / 1
-( timeout 300 python scripts/ab.py --corpus-cache $C --ks 10 --qsets baseline,distinct,hot --libs build/libsearcharray_hip_probe.so --envs "SA_SPARSE=0" ) 2>&1 | grep "^{" > $O/probe_sections.jsonl
+( timeout 300 python scripts/ab.py --corpus-cache $C --ks 10 --qsets baseline,distinct,hot --libs build/libsearcharray_hip_probe.so --envs "SA_SPARSE=0,group_item=16;SA_SPARSE=0" ) 2>&1 | grep "^{" > $O/probe_sections.jsonl
 ( timeout 300 python scripts/ab.py --corpus-cache $C --ks 10 --docs 1250000 --qsets baseline --libs build/libsearcharray_hip_probe.so --envs "SA_SPARSE=0" ) 2>&1 | grep "^{" >> $O/probe_sections.jsonl
-( timeout 300 python scripts/ab.py --corpus-cache $C --ks 10 --qsets baseline --libs build/libsearcharray_hip_probe_fine.so --envs "SA_SPARSE=0" ) 2>&1 | grep "^{" > $O/probe_sections_fine.jsonl
+( timeout 300 python scripts/ab.py --corpus-cache $C --ks 10 --qsets baseline --libs build/libsearcharray_hip_probe_fine.so --envs "SA_SPARSE=0,group_item=16" ) 2>&1 | grep "^{" > $O/probe_sections_fine.jsonl
 rm -f $O/occupancy.jsonl
 for pad in 0 3200 10240 30720; do
-  ( SA_PROBE_LDS_PAD=$pad timeout 300 python scripts/ab.py --corpus-cache $C --ks 10 --qsets baseline --libs build/libsearcharray_hip_probe.so --envs "SA_SPARSE=0" ) 2>&1 | grep "^{" | sed "s/^{/{\"lds_pad\": $pad, /" >> $O/occupancy.jsonl
+  ( SA_PROBE_LDS_PAD=$pad timeout 300 python scripts/ab.py --corpus-cache $C --ks 10 --qsets baseline --libs build/libsearcharray_hip_probe.so --envs "SA_SPARSE=0,group_item=16" ) 2>&1 | grep "^{" | sed "s/^{/{\"lds_pad\": $pad, /" >> $O/occupancy.jsonl
 done
 ( timeout 120 build/lds_fadd_probe ) > $O/lds_fadd_probe.json 2>&1
 bash $R/scripts/gpu_r5_latency.sh > $O/latency.log 2>&1

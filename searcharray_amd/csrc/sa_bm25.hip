@@ -1328,6 +1328,7 @@ __global__ void __launch_bounds__(64, 4) sa_k_bm25_group_tiles(const Bm25Params 
         nq = n - cq0 < gp.cq ? n - cq0 : gp.cq;
         build_tables();
         prefetch(0, A);
+        SA_PT(0);
     }
     if (nsurv) flush();
     // ---- general path: hand the (tile, query) pairs to the per-query kernel that follows (sa_k_bm25_tiles_wl)
