@@ -2176,7 +2176,8 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
         //  Two passes per item are worth it where the launch has many rounds of items to run (same box, BASELINE batch, items of 16 vs
         //  32 queries: 10 M docs 0.402 -> 0.381 ms, 7.5 M 0.311 -> 0.302, 5 M 0.2185 -> 0.218, 2.5 M 0.124 -> 0.134, 1.25 M 0.085 -> 0.094:
         //  fewer, longer items lengthen the launch's tail) -- from 16 rounds of the device's 4096 resident waves on; loose groups have
-        //  no base to share and keep 16 (measured: 0.464 -> 0.483 ms with 32).
+        //  no base to share and keep 16 (measured: 0.464 -> 0.483 ms with 32).  2048 queries per batch (groups of ~200, 155 rounds): items of
+        //  16 / 32 / 48 / 64 queries 2.339 / 2.213 / 2.172 / 2.168 ms -- four passes from 64 rounds on.
         u32 item_q = maxq;                                      // (set below, once the groups are known)
         bt->grp_cq = maxq;
         const u32 gmin = (u32)std::max<long long>(1, sa_opt(bt->opts.group_min, 2));
@@ -2201,7 +2202,8 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
             {
                 u64 items16 = 0;
                 for (auto& m : members) if (m.size() >= gmin) items16 += (m.size() + maxq - 1) / maxq;
-                const long long dflt = items16 * (u64)ix->n_tiles >= (u64)SA_GRP_ITEM_ROUNDS * 4096u ? 32 : 16;
+                const u64 rounds = items16 * (u64)ix->n_tiles / 4096u;          // of one-pass items over the device's resident waves
+                const long long dflt = rounds >= 4u * SA_GRP_ITEM_ROUNDS ? 64 : rounds >= (u64)SA_GRP_ITEM_ROUNDS ? 32 : 16;
                 item_q = std::max<u32>(maxq, std::min<u32>(64u, (u32)std::max<long long>(1, sa_opt(bt->opts.group_item, dflt))) / maxq * maxq);
             }
             std::vector<u32> order;
