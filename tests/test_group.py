@@ -69,28 +69,22 @@ def test_grouped_items_of_fewer_queries(api, corpus, monkeypatch, maxq):
     check(api, corpus, queries, 10)
 
 
-@pytest.mark.parametrize("item,maxq", [(32, 16), (64, 16), (64, 8), (24, 8), (16, 16)])
-@pytest.mark.parametrize("T,k", [(4, 3), (2, 50), (7, 5)])
+@pytest.mark.parametrize("item,maxq,T,k", [(32, 16, 4, 3), (64, 16, 2, 50), (64, 8, 7, 5), (24, 8, 4, 50)])
 def test_items_of_several_table_passes(api, corpus, item, maxq, T, k):
     """Round 5: an item holds up to 64 queries of its group and takes them in passes of `group_maxq` over ONE base (option
-    `group_item`).  Groups of 70 / 33 / 17 / 5 queries, shared-first-term and loose ones: every item size equals the oracle, the
-    one-pass items and the per-query kernel; survivors of late passes (k = 50) and deferred pairs of late passes included."""
+    `group_item`).  Groups of 70 / 33 / 17 / 5 queries, shared-first-term and loose ones: every item size equals the oracle (as
+    the one-pass items and the per-query kernel do in the tests around); survivors of late passes (k = 50) and deferred pairs of late passes included.
+    (tests/test_config_10m.py runs items of 16 / 32 / 64 queries at 10 M docs on the device.)"""
     set_opt("SA_SPARSE", "0")
     rng = np.random.default_rng(700 + item + maxq + T)
     heads = np.concatenate([np.full(70, 0), np.full(33, 1), np.full(17, 7), np.full(5, 350)])
     rng.shuffle(heads)
     queries = band_queries(rng, len(heads), T, heads=[0])
     queries[:, 0] = heads
-    loose = band_queries(rng, 40, T, heads=np.arange(150, 400))          # pairwise-different first terms: loose groups
+    loose = band_queries(rng, 24, T, heads=np.arange(150, 400))          # pairwise-different first terms: loose groups
     queries = np.concatenate([queries, loose])
     set_opt("SA_GROUP_ITEM", str(item)); set_opt("SA_GROUP_MAXQ", str(maxq))
-    got = check(api, corpus, queries, k)
-    set_opt("SA_GROUP_ITEM", "16"); set_opt("SA_GROUP_MAXQ", "16")
-    one_pass = check(api, corpus, queries, k)
-    set_opt("SA_GROUP", "0")
-    per_query = check(api, corpus, queries, k)
-    for a, b in ((got, one_pass), (got, per_query)):
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    check(api, corpus, queries, k)           # (the oracle pins it; one-pass items and the per-query kernel are pinned by the tests around)
 
 
 @pytest.mark.parametrize("warm", ["0", "2"])
