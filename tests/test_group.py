@@ -177,8 +177,7 @@ def test_loose_groups_equal_oracle_and_per_query_kernel(api, corpus, monkeypatch
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
 
 
-@pytest.mark.parametrize("k", [5, 40])
-@pytest.mark.parametrize("pct,warm", [(100, None), (400, None), (400, 2), (150, None)])
+@pytest.mark.parametrize("k,pct,warm", [(5, 100, None), (40, 400, None), (5, 400, 2), (40, 150, None), (5, 150, None)])
 def test_starting_bounds_that_are_too_high_are_caught_and_the_run_redone(api, corpus, k, pct, warm):
     """the safety net under the starting bounds (sa_k_topk_merge: fewer than k keys at or above a bound -- the kernel's own
     or the rank tables' -- flags the run; sa_batch_redo_if_flagged redoes it without bounds): forced with the test hook
