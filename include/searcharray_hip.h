@@ -83,6 +83,9 @@ typedef struct sa_options {
     int64_t sparse_lazy;     /* 0: pruning tables derived at every reset, needed or not */
     int64_t bloom_floor;     /* TEST HOOK: smallest Bloom buffer in bytes */
     int64_t sp_chunk1;       /* pruning: postings per lead work item */
+    int64_t stage;           /* staged-tile route (sa_stage.hip): 1 force where eligible, 0 off; unset: on where eligible and `sparse` is unset */
+    int64_t stage_docs;      /* docs per stage tile (multiple of 64; default: what fits the LDS stage for the query set's terms) */
+    int64_t stage_wgs;       /* staged-tile route: resident workgroups per CU (default 2) */
     int64_t batch_stream;    /* 0: batches share the index stream */
     int64_t res_xs;          /* 0: result copies on the batches' own streams */
     int64_t dense_div;       /* dense factor rows for terms with df >= n_docs / this (default 4) */

@@ -112,6 +112,17 @@ struct sa_batch {
     u32* d_iota = nullptr;          // [B] 0 .. B-1 (query lists of the per-query kernel: rows [a, b) = d_iota + a)
     u32 n_groups = 0, n_grouped_rows = 0, grp_tt = 1, grp_tt_shift = 0, grp_cq = 16;
     bool last_route_sparse = false; // the last run took dynamic pruning (sa_batch_last_route)
+    // staged-tile route (sa_stage.hip, round 6): the plan of the current query set lives in the upload block
+    bool stage_ok = false;          // the current query set has a plan (sa_stage_plan)
+    bool last_route_stage = false;  // the last run took the staged-tile route
+    bool bounds_valid = false;      // d_bounds / d_qbase / d_qbase_imp hold the current query set's slice table (the staged route does not need it)
+    u32 st_U = 0;                   // distinct terms of the query set
+    u32 st_docs = 0;                // docs per stage tile
+    u32 st_cb[3] = {0, 0, 0};       // copy classes: terms [0, cb0) are copied by 64 lanes each, [cb0, cb1) by 32, [cb1, cb2) by 16, the rest by 8
+    u32 st_tmax = 4;                // kernel instantiation: 4 or 8 terms per query
+    std::shared_ptr<sa_stagedir> st_dir;
+    char* d_st = nullptr;           // the plan's region of the upload block (sa_stage_bind carves it)
+    size_t st_bytes = 0;
     // phrase batches (sa_phrase_batch.hip): kind == 1
     int kind = 0;                   // 0: disjunctive BM25 over terms, 1: exact phrases
     u32 ptile = 0, pn_tiles = 0;    // docs per phrase tile and their number
@@ -148,5 +159,10 @@ static inline u64 sa_now_ns() {
 int sa_batch_upload_begin(sa_batch* bt, char** image);
 int sa_batch_upload_commit(sa_batch* bt);
 void sa_batch_free(sa_batch* bt);
+// staged-tile route (sa_stage.hip): bytes of a (B, T) plan in the upload block; plan a query set (device-row order) into the
+// host image -- sets bt->stage_ok; launch the scoring kernel of a planned set
+size_t sa_stage_upload_bytes(u32 B, u32 T);
+int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* row_idf);
+int sa_launch_stage(sa_batch* bt, const struct Bm25Params& p, hipStream_t st);
 // dynamic pruning: lead-term candidates, routing, remaining essential candidates (sa_sparse.hip)
 int sa_launch_sparse(sa_batch* bt, hipStream_t st);

@@ -40,6 +40,7 @@ sa_impacts::~sa_impacts() {
     if (d_imp) hipFree(d_imp);
     if (d_dense) hipFree(d_dense);
     if (d_topf) hipFree(d_topf);
+    if (d_maxf) hipFree(d_maxf);
 }
 
 // dense factor row of one term (sa_impacts::d_dense): row[doc] = factor bits of the term's posting of doc; the row is zeroed before
@@ -51,11 +52,7 @@ sa_k_make_dense_row(const u64* __restrict__ imp, u64 first, u64 df, float* __res
     }
 }
 
-// (4 cells of slack per term: a term's last posting is followed by at least one whole, 16-byte-aligned pair
-//  of sentinels before the next term starts -- the pair every load past a slice's term is clamped to)
-__host__ __device__ __forceinline__ u64 sa_imp_base(u64 tf_base, u32 term) { return (tf_base + 4ull * term + 1ull) & ~1ull; }
-// first cell of that sentinel pair, for a term of df postings starting at `ibase`
-__host__ __device__ __forceinline__ u64 sa_imp_sentinel(u64 ibase, u64 df) { return ibase + ((df + 1ull) & ~1ull); }
+// (sa_imp_base / sa_imp_sentinel: sa_bm25_params.hpp)
 
 // Rank table of a term's factors (sa_impacts::d_topf): one workgroup per term builds a histogram of its postings' factor
 // bits -- 512 bins per octave over [1/16, 1): (bits >> 14) - (123 << 9), clamped -- and reads off, from the top, the bin
@@ -64,26 +61,35 @@ __host__ __device__ __forceinline__ u64 sa_imp_sentinel(u64 ibase, u64 df) { ret
 #define SA_TOPF_LO (123u << 9)
 struct TopfRanks { u32 r[SA_TOPF_NR]; };
 __global__ void __launch_bounds__(256)
-sa_k_make_topf(const u64* __restrict__ imp, const u64* __restrict__ tf_off, u32 n_terms, const TopfRanks ranks, float* __restrict__ topf) {
+sa_k_make_topf(const u64* __restrict__ imp, const u64* __restrict__ tf_off, u32 n_terms, const TopfRanks ranks, float* __restrict__ topf,
+               float* __restrict__ maxf) {
     __shared__ u32 s_h[SA_TOPF_BINS];
     __shared__ u32 s_part[256];
+    __shared__ u32 s_max;
     const u32 tid = threadIdx.x;
     for (u32 t = blockIdx.x; t < n_terms; t += gridDim.x) {
         const u64 base = tf_off[t], df = tf_off[t + 1] - base;
         float* const row = topf + (u64)t * SA_TOPF_NR;
         if (df == 0) {                                           // (uniform)
             if (tid < (u32)SA_TOPF_NR) row[tid] = 0.f;
+            if (tid == 0 && maxf) maxf[t] = 0.f;
             continue;
         }
         for (u32 i = tid; i < (u32)SA_TOPF_BINS; i += 256) s_h[i] = 0;
+        if (tid == 0) s_max = 0u;
         __syncthreads();
         const u64* const cells = imp + sa_imp_base(base, t);
+        u32 mx = 0u;                                             // (factors are non-negative: their bit patterns order like the values)
         for (u64 i = tid; i < df; i += 256) {
-            const u32 e = (u32)cells[i] >> 14;
+            const u32 fb = (u32)cells[i];
+            mx = fb > mx ? fb : mx;
+            const u32 e = fb >> 14;
             const u32 b = e <= SA_TOPF_LO ? 0u : (e - SA_TOPF_LO > (u32)(SA_TOPF_BINS - 1) ? (u32)(SA_TOPF_BINS - 1) : e - SA_TOPF_LO);
             atomicAdd(&s_h[b], 1u);
         }
+        if (mx) atomicMax(&s_max, mx);
         __syncthreads();
+        if (tid == 0 && maxf) maxf[t] = __uint_as_float(s_max);
         // thread i owns bins [8 i, 8 i + 8); above[i] = postings in the bins above its eight
         u32 mine = 0;
 #pragma unroll
@@ -225,16 +231,36 @@ static void sa_impacts_ensure_topf(sa_index* ix, sa_impacts* im) {
     if (hipMalloc(&im->d_topf, bytes) != hipSuccess) { (void)hipGetLastError(); im->d_topf = nullptr; return; }
     TopfRanks rk;
     for (int i = 0; i < SA_TOPF_NR; i++) rk.r[i] = sa_topf_ranks[i];
+    if (hipMalloc(&im->d_maxf, (size_t)ix->n_terms * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); im->d_maxf = nullptr; }
     const u32 grid = ix->n_terms < 16384u ? ix->n_terms : 16384u;
     hipLaunchKernelGGL(sa_k_make_topf, dim3(grid), dim3(256), 0, ix->stream, (const u64*)im->d_imp, (const u64*)ix->d_tf_off, ix->n_terms, rk,
-                       im->d_topf);
+                       im->d_topf, im->d_maxf);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ix->stream) != hipSuccess) {
         (void)hipGetLastError();
         hipFree(im->d_topf); im->d_topf = nullptr;
+        if (im->d_maxf) { hipFree(im->d_maxf); im->d_maxf = nullptr; }
+        return;
+    }
+    // host copies (the staged-tile route plans a query set on the host: starting bounds, score bounds of its terms)
+    if (im->d_maxf) {
+        im->h_topf.resize((size_t)ix->n_terms * SA_TOPF_NR);
+        im->h_maxf.resize(ix->n_terms);
+        if (hipMemcpy(im->h_topf.data(), im->d_topf, bytes, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(im->h_maxf.data(), im->d_maxf, (size_t)ix->n_terms * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+            (void)hipGetLastError();
+            im->h_topf.clear(); im->h_maxf.clear();
+        }
     }
 }
 static bool sa_batch_wants_seed(const sa_batch* bt) {
     return bt->impacts && bt->k <= 1024u && sa_opt(bt->opts.term_seed, 1) != 0 && sa_opt(bt->opts.sparse, -1) != 1;
+}
+// the staged-tile route (sa_stage.hip) is asked for: option `stage` = 1, or unset while `sparse` is unset too (a caller that
+// sets `sparse` chooses between the two older routes)
+static bool sa_batch_stage_wanted(const sa_batch* bt) {
+    const long long s = sa_opt(bt->opts.stage, -1);
+    if (s >= 0) return s != 0;
+    return !sa_opt_is_set(bt->opts.sparse);
 }
 
 // Saturation table of a batch, laid out [dl][tf - 1].  For integer doc lengths dl < tab_w and term frequencies
@@ -1634,6 +1660,16 @@ static int sa_launch_make_bounds(sa_index* ix, const u32* d_terms, u32 BT, u32* 
     return SA_OK;
 }
 
+// the slice table of the batch's current query set (the staged-tile route leaves it out of the step: built when another route runs)
+static int sa_batch_ensure_bounds(sa_batch* bt, hipStream_t st) {
+    if (bt->bounds_valid) return SA_OK;
+    SA_TRY(sa_launch_make_bounds(bt->ix, bt->d_terms, bt->B * bt->T, bt->d_bounds, bt->d_qbase, st, bt->d_qbase_imp,
+                                 bt->seed_on ? bt->impacts->d_topf : nullptr, bt->d_idf, bt->T, bt->k, bt->d_seed,
+                                 (float)sa_opt(bt->opts.seed_scale_pct, 100) / 100.f));
+    bt->bounds_valid = true;
+    return SA_OK;
+}
+
 #define SA_LAUNCH_TILE(TILE, THREADS)                                                              \
     {                                                                                              \
         if (MODE == 1 && p.imp)                                                                    \
@@ -1945,6 +1981,9 @@ static int sa_batch_alloc_bm25(sa_batch* bt) {
                  o_perm = take(B * 4), o_grp = take(3 * B * 4), o_ub = take(B * (T + 1) * 4), o_ord = take(B * T * 4),
                  o_lead = take(B * 4), o_qdf = take(B * T * 4), o_row8 = take(B * T * 4), o_bsh = take(B * 4),
                  o_seed = take(B * 4);
+    bt->st_bytes = sa_stage_upload_bytes((u32)B, (u32)T);
+    off = (off + 15) & ~(size_t)15;
+    const size_t o_st = take(bt->st_bytes);
     SA_TRY(sa_batch_alloc_upload(bt, off));
     char* u = bt->d_up;
     bt->d_p1_off = (u64*)(u + o_p1); bt->d_bloom_off = (u64*)(u + o_boff);
@@ -1953,6 +1992,7 @@ static int sa_batch_alloc_bm25(sa_batch* bt) {
     bt->d_lead = (u32*)(u + o_lead); bt->d_qdf = (u32*)(u + o_qdf); bt->d_qrow8 = (u32*)(u + o_row8);
     bt->d_bloom_shift = (u32*)(u + o_bsh);
     bt->d_seed = (u32*)(u + o_seed);
+    bt->d_st = u + o_st;
     {
         std::vector<u32> iota(B);
         for (u32 i = 0; i < B; i++) iota[i] = i;
@@ -2284,11 +2324,16 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
         if (wanted) sa_impacts_ensure_topf(ix, bt->impacts.get());
         bt->seed_on = wanted && bt->impacts->d_topf;
     }
+    // the staged-tile route's plan (sa_stage.hip): distinct terms, per-query bound tables and the starting bounds, formed on the
+    // host into the same upload.  A set that has one does not need the slice table: sa_k_make_bounds is left out of the step and
+    // only runs if the run takes another route after all (sa_batch_ensure_bounds)
+    bt->stage_ok = false;
+    bt->st_dir.reset();
+    if (bt->seed_on && sa_batch_stage_wanted(bt)) SA_TRY(sa_stage_plan(bt, img, h_terms, h_idf));
     const u64 t_host = sa_now_ns();
     SA_TRY(sa_batch_upload_commit(bt));
-    SA_TRY(sa_launch_make_bounds(ix, bt->d_terms, B * T, bt->d_bounds, bt->d_qbase, bt->st, bt->d_qbase_imp,
-                                 bt->seed_on ? bt->impacts->d_topf : nullptr, bt->d_idf, T, bt->k, bt->d_seed,
-                                 (float)sa_opt(bt->opts.seed_scale_pct, 100) / 100.f));
+    bt->bounds_valid = false;
+    if (!bt->stage_ok) SA_TRY(sa_batch_ensure_bounds(bt, bt->st));
     SA_HIP(hipGetLastError());
     const u64 t_end = sa_now_ns();
     bt->host_ns[0] += t_host - t_begin; bt->host_ns[1] += t_end - t_host; bt->host_ns[3]++;
@@ -2427,7 +2472,8 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     const bool impact_route = p.pruned && hist_possible && p.imp && !p.no_topk &&
                               (ix->tile_docs == 1024 || ix->tile_docs == 2048 || ix->tile_docs == 4096);
     const bool sparse_wanted = sparse_env >= 0 ? sparse_env != 0 : (ix->n_docs >= (u64)bt->k * 32768ull && !impact_route);
-    if (sparse_wanted && bt->sparse_lazy && bt->kind == 0) {
+    if (sparse_wanted && bt->sparse_lazy && bt->kind == 0 &&
+        !(bt->stage_ok && sa_batch_stage_wanted(bt))) {
         // the tables were left out at reset (the run was expected to score every posting): derive them into the image of the
         // current query set -- once its upload has left the host buffer -- and upload it again, behind everything on this stream
         const u32 last = (bt->up_n - 1u) & 1u;
@@ -2436,15 +2482,20 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
         SA_HIP(hipMemcpyAsync(bt->d_up, bt->h_up[last], bt->up_bytes, hipMemcpyHostToDevice, st));
         SA_HIP(hipEventRecord(bt->ev_up[last], st));
         // (the image carries the starting bounds as the host left them -- zeros: the slice-table kernel forms them again)
-        SA_TRY(sa_launch_make_bounds(ix, bt->d_terms, bt->B * bt->T, bt->d_bounds, bt->d_qbase, st, bt->d_qbase_imp,
-                                     bt->seed_on ? bt->impacts->d_topf : nullptr, bt->d_idf, bt->T, bt->k, bt->d_seed,
-                                     (float)sa_opt(bt->opts.seed_scale_pct, 100) / 100.f));
+        bt->bounds_valid = false;
+        SA_TRY(sa_batch_ensure_bounds(bt, st));
     }
+    // Round 6: the staged-tile route (sa_stage.hip) takes every query set it has a plan for -- distinct terms staged in LDS once
+    // per tile, the queries answered from there; it needs the histogram bound and the impact stream like the grouped kernel
+    const bool stage = bt->kind == 0 && bt->stage_ok && sa_batch_stage_wanted(bt) && p.pruned && hist_possible && p.imp && !p.no_topk &&
+                       ix->avg_doc_len != 0.f;
+    bt->last_route_stage = stage;
+    if (!stage && bt->kind == 0) SA_TRY(sa_batch_ensure_bounds(bt, st));
     const bool sparse = hist_possible && ix->tile_docs <= 8192 && bt->sparse_ok && ix->avg_doc_len != 0.f && ix->n_tiles > 0 &&
-                        sparse_wanted;
+                        sparse_wanted && !stage;
     bt->last_route_sparse = sparse;
     const bool use_hist = hist_possible &&
-                          (sparse || bt->k >= (u32)sa_opt(bt->opts.topk_hist_mink, defer_check ? 1 : 33));
+                          (sparse || stage || bt->k >= (u32)sa_opt(bt->opts.topk_hist_mink, defer_check ? 1 : 33));
     p.hist = use_hist ? bt->d_hist : nullptr;
     p.gthr = use_hist ? bt->d_gthr : nullptr;
     // the bounds the queries start with (exhaustive kernels only: the pruning path derives its own from the lead terms)
@@ -2469,7 +2520,9 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     if (ix->avg_doc_len != 0.f && n_tiles > 0) {
         if (bt->kind == 1) SA_TRY(sa_launch_phrase_tiles(bt, st));
         else {
-            if (sparse) {
+            if (stage) {
+                SA_TRY(sa_launch_stage(bt, p, st));
+            } else if (sparse) {
                 // candidates first; a resident grid then scans the queries the sparse path gave back
                 SA_TRY(sa_launch_sparse(bt, st));
                 p.qlist = bt->d_tile_q; p.nq_dev = bt->d_tile_q + bt->B;
@@ -2890,7 +2943,7 @@ extern "C" int sa_batch_profile(sa_batch_t* bt, double* kernel_ms_out, uint64_t*
 extern "C" int sa_batch_last_route(sa_batch_t* bt, int* pruned_out) {
     SA_ARG(bt && bt->ix && pruned_out, "null argument");
     std::lock_guard<std::mutex> g(bt->ix->mu);
-    *pruned_out = bt->last_route_sparse ? 1 : 0;
+    *pruned_out = bt->last_route_stage ? 2 : bt->last_route_sparse ? 1 : 0;
     return SA_OK;
 }
 

@@ -5,6 +5,13 @@
 
 struct alignas(16) sa_u64x2 { u64 x, y; };
 
+// Impact stream layout (sa_impacts, sa_index.hpp): first cell of term `term` whose TF postings start at tf_base
+// (4 cells of slack per term: a term's last posting is followed by at least one whole, 16-byte-aligned pair
+//  of sentinels before the next term starts -- the pair every load past a slice's term is clamped to)
+__host__ __device__ __forceinline__ u64 sa_imp_base(u64 tf_base, u32 term) { return (tf_base + 4ull * term + 1ull) & ~1ull; }
+// first cell of that sentinel pair, for a term of df postings starting at `ibase`
+__host__ __device__ __forceinline__ u64 sa_imp_sentinel(u64 ibase, u64 df) { return ibase + ((df + 1ull) & ~1ull); }
+
 struct Bm25Params {
     // index
     const u64* tfp;

@@ -386,6 +386,7 @@ void sa_index_free(sa_index* ix) {
     if (ix->d_tfbits) hipFree(ix->d_tfbits);
     if (ix->d_tf8_slot) hipFree(ix->d_tf8_slot);
     ix->impacts.reset();
+    ix->stagedirs.clear();
     if (ix->d_scratch) hipFree(ix->d_scratch);
     for (auto& ln : ix->dense_lane) {
         if (ln.stream) { hipStreamSynchronize(ln.stream); hipStreamDestroy(ln.stream); }

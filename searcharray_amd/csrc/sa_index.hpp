@@ -67,7 +67,23 @@ struct sa_impacts {
     // summand): every query starts with the best such bound over its terms instead of 0 (sa_k_make_bounds).
     float* d_topf = nullptr;        // built by the first batch that can use it (sa_impacts_ensure_topf)
     bool topf_tried = false;
+    // round 6 (staged-tile route, sa_stage.hip): the LARGEST factor of every term, exact (an upper bound of what a
+    // posting of the term can contribute per unit of weight), built with the rank tables; host copies of both, so
+    // that a query set's starting bounds and its terms' score bounds are formed on the host with the upload
+    float* d_maxf = nullptr;        // [n_terms]
+    std::vector<float> h_topf, h_maxf;
     ~sa_impacts();
+};
+
+// Stage directory (sa_stage.hip): like tile_dir, for the staged-tile route's own (smaller) tiles of `docs` documents --
+// row r, entry j = first posting (relative to the term's base) whose doc >= j * docs, for the terms with at least one
+// posting per two tiles; rarer terms are walked by the kernel's cursors.  Built on first use, cached per tile size.
+struct sa_stagedir {
+    int device = 0;
+    u32 docs = 0, n_st = 0, n_rows = 0;
+    u32* d_dir = nullptr;           // [n_rows][n_st + 1]
+    std::vector<u32> row;           // [n_terms] row of a term, or 0xFFFFFFFF
+    ~sa_stagedir();
 };
 
 struct sa_index;
@@ -167,6 +183,7 @@ struct sa_index {
 
     // most recent impact stream (shared with the batches built for the same k1 / b)
     std::shared_ptr<sa_impacts> impacts;
+    std::vector<std::shared_ptr<sa_stagedir>> stagedirs;   // stage directories built so far (one per tile size in use)
 
     sa_comm* comm = nullptr;
     hipStream_t sstream = nullptr;   // side stream: the per-query kernel over a batch's ungrouped rows runs beside the grouped kernel

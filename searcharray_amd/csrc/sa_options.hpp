@@ -38,6 +38,9 @@
     X(sparse_lazy)     /* 0: pruning tables derived at every reset, needed or not */                                               \
     X(bloom_floor)     /* TEST HOOK: smallest Bloom buffer in bytes */                                                             \
     X(sp_chunk1)       /* pruning: postings per lead work item */                                                                  \
+    X(stage)           /* staged-tile route (sa_stage.hip): 1 force where eligible, 0 off; unset: on where eligible and `sparse` is unset */ \
+    X(stage_docs)      /* docs per stage tile (multiple of 64; default: what fits the LDS stage for the query set's terms) */                 \
+    X(stage_wgs)       /* staged-tile route: resident workgroups per CU (default 2) */                                              \
     X(batch_stream)    /* 0: batches share the index stream */                                                                     \
     X(res_xs)          /* 0: result copies on the batches' own streams */                                                          \
     /* ---- index creation (sa_index.hip, sa_bm25.hip) */                                                                          \

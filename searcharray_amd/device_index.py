@@ -512,10 +512,11 @@ class QueryBatch(_options.OptionsMixin):
         return {"groups": int(out[0]), "grouped_queries": int(out[1]), "shared_first_term": int(out[2]), "per_query_kernel": int(out[3])}
 
     def last_route(self) -> str:
-        """the route the last run took: 'pruned' (dynamic pruning) or 'exhaustive'"""
+        """the route the last run took: 'staged' (distinct terms staged in LDS per tile, sa_stage.hip), 'pruned' (dynamic
+        pruning) or 'exhaustive' (grouped / per-query overlay kernels)"""
         out = ctypes.c_int(0)
         self._call("sa_batch_last_route", self._h, ctypes.byref(out))
-        return "pruned" if out.value else "exhaustive"
+        return {0: "exhaustive", 1: "pruned", 2: "staged"}[out.value]
 
     def seeds(self) -> np.ndarray:
         """the bound every query of the current set starts with (sa_batch_seeds), float32[B], 0 = none"""
