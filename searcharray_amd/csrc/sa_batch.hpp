@@ -116,9 +116,9 @@ struct sa_batch {
     bool stage_ok = false;          // the current query set has a plan (sa_stage_plan)
     bool last_route_stage = false;  // the last run took the staged-tile route
     bool bounds_valid = false;      // d_bounds / d_qbase / d_qbase_imp hold the current query set's slice table (the staged route does not need it)
-    u32 st_U = 0;                   // distinct terms of the query set
+    u32 st_U = 0, st_ND = 0;        // distinct terms of the query set; the first st_ND are staged as dense factor rows
     u32 st_docs = 0;                // docs per stage tile
-    u32 st_cb[3] = {0, 0, 0};       // copy classes: terms [0, cb0) are copied by 64 lanes each, [cb0, cb1) by 32, [cb1, cb2) by 16, the rest by 8
+    u64 st_cell_base = 0;           // smallest impact-stream cell of the set's terms (the kernel's 32-bit offsets count from it)
     u32 st_tmax = 4;                // kernel instantiation: 4 or 8 terms per query
     std::shared_ptr<sa_stagedir> st_dir;
     char* d_st = nullptr;           // the plan's region of the upload block (sa_stage_bind carves it)

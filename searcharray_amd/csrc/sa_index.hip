@@ -208,6 +208,8 @@ void SaDenseLaneScope::swap() {
     std::swap(ix->scratch_bytes, lane->scratch_bytes);
     std::swap(ix->d_rows_scratch, lane->rows);
     std::swap(ix->rows_scratch_bytes, lane->rows_bytes);
+    std::swap(ix->d_sim_scratch, lane->sim);
+    std::swap(ix->sim_scratch_bytes, lane->sim_bytes);
     swapped = !swapped;
 }
 int SaDenseLaneScope::finish() {
@@ -386,13 +388,13 @@ void sa_index_free(sa_index* ix) {
     if (ix->d_tfbits) hipFree(ix->d_tfbits);
     if (ix->d_tf8_slot) hipFree(ix->d_tf8_slot);
     ix->impacts.reset();
-    ix->stagedirs.clear();
     if (ix->d_scratch) hipFree(ix->d_scratch);
     for (auto& ln : ix->dense_lane) {
         if (ln.stream) { hipStreamSynchronize(ln.stream); hipStreamDestroy(ln.stream); }
         if (ln.done) hipEventDestroy(ln.done);
         if (ln.scratch) hipFree(ln.scratch);
         if (ln.rows) hipFree(ln.rows);
+        if (ln.sim) hipFree(ln.sim);
     }
     for (int i = 0; i < 3; i++) {
         if (ix->lane_scratch[i]) hipFree(ix->lane_scratch[i]);

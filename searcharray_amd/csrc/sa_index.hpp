@@ -46,6 +46,22 @@ struct sa_comm;   // RCCL communicator wrapper (sa_comm.hip)
 #define SA_TOPF_NR 22
 static const unsigned sa_topf_ranks[SA_TOPF_NR] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64, 100, 128, 200, 256, 512, 1000, 1024};
 
+// Stage directory (sa_stage.hip) of one impact stream, for the staged-tile route's own tiles of `docs` documents.  For every
+// term with at least one posting per eight tiles (a ROW):
+//   abs[row][j]   first posting (relative to the term's base) whose doc >= j * docs -- where a workgroup's cursor starts
+//   cm[row][j]    postings of the term in tile j (low 16 bits) | the LARGEST factor among them, its fp32 pattern's upper 16 bits
+//                 rounded up (high 16 bits): what the term can add to a score in that tile at most, per unit of weight
+// Rarer terms are walked by the kernel's cursors and bounded by their largest factor in the shard.  Built on first use, cached
+// per tile size with the stream.
+struct sa_stagedir {
+    int device = 0;
+    u32 docs = 0, n_st = 0, n_rows = 0;
+    u32* d_abs = nullptr;           // [n_rows][n_st + 1]
+    u32* d_cm = nullptr;            // [n_rows][n_st]
+    std::vector<u32> row;           // [n_terms] row of a term, or 0xFFFFFFFF
+    ~sa_stagedir();
+};
+
 struct sa_impacts {
     int device = 0;
     float k1 = 0.f, b = 0.f, avgdl = 0.f;
@@ -72,18 +88,8 @@ struct sa_impacts {
     // that a query set's starting bounds and its terms' score bounds are formed on the host with the upload
     float* d_maxf = nullptr;        // [n_terms]
     std::vector<float> h_topf, h_maxf;
+    std::vector<std::shared_ptr<sa_stagedir>> stagedirs;   // stage directories built so far (one per tile size in use)
     ~sa_impacts();
-};
-
-// Stage directory (sa_stage.hip): like tile_dir, for the staged-tile route's own (smaller) tiles of `docs` documents --
-// row r, entry j = first posting (relative to the term's base) whose doc >= j * docs, for the terms with at least one
-// posting per two tiles; rarer terms are walked by the kernel's cursors.  Built on first use, cached per tile size.
-struct sa_stagedir {
-    int device = 0;
-    u32 docs = 0, n_st = 0, n_rows = 0;
-    u32* d_dir = nullptr;           // [n_rows][n_st + 1]
-    std::vector<u32> row;           // [n_terms] row of a term, or 0xFFFFFFFF
-    ~sa_stagedir();
 };
 
 struct sa_index;
@@ -156,6 +162,8 @@ struct sa_index {
         size_t scratch_bytes = 0;
         void* rows = nullptr;
         size_t rows_bytes = 0;
+        void* sim = nullptr;        // float64 results of the f64 similarities: per lane, a call's D2H copy is still in flight when the lock is dropped
+        size_t sim_bytes = 0;
         bool busy = false;
     };
     static constexpr int N_DENSE_LANES = 8;
@@ -183,7 +191,6 @@ struct sa_index {
 
     // most recent impact stream (shared with the batches built for the same k1 / b)
     std::shared_ptr<sa_impacts> impacts;
-    std::vector<std::shared_ptr<sa_stagedir>> stagedirs;   // stage directories built so far (one per tile size in use)
 
     sa_comm* comm = nullptr;
     hipStream_t sstream = nullptr;   // side stream: the per-query kernel over a batch's ungrouped rows runs beside the grouped kernel

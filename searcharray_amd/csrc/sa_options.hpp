@@ -41,6 +41,7 @@
     X(stage)           /* staged-tile route (sa_stage.hip): 1 force where eligible, 0 off; unset: on where eligible and `sparse` is unset */ \
     X(stage_docs)      /* docs per stage tile (multiple of 64; default: what fits the LDS stage for the query set's terms) */                 \
     X(stage_wgs)       /* staged-tile route: resident workgroups per CU (default 2) */                                              \
+    X(stage_dense)     /* 0: the staged-tile route stages every term as postings, also those with a dense factor row */            \
     X(batch_stream)    /* 0: batches share the index stream */                                                                     \
     X(res_xs)          /* 0: result copies on the batches' own streams */                                                          \
     /* ---- index creation (sa_index.hip, sa_bm25.hip) */                                                                          \

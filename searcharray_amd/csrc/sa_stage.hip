@@ -44,35 +44,38 @@
 #include <unordered_map>
 
 #define SA_ST_NT 512            // threads per workgroup
-#define SA_ST_UMAX 1024         // distinct terms of a query set
+#define SA_ST_UMAX 768          // distinct terms of a query set
 #define SA_ST_BMAX 256          // queries of a query set
-#define SA_ST_WL 768            // candidate records per work-list chunk
+#define SA_ST_NDMAX 16          // terms staged as dense rows
 #define SA_ST_REF 64            // queries whose bound is re-derived at the end of a tile pass
 #define SA_ST_NONE 0xFFFFu      // "no term" in the queries' term tables
+#define SA_ST_DENSE 0xFFFFu     // s_off: the term is staged as a dense row (start = its first cell)
 #define SA_ST_NOROW 0xFFFFFFFFu
 #define SA_ST_MARGIN 1.0000153f // 1 + 2^-16: covers the fp32 roundings of a sum of up to 8 non-negative terms taken in another order
 
-// postings an LDS stage holds (TMAX = 4: the BASELINE shape; 8: wider query tables, smaller stage); two workgroups per CU
-template <int TMAX> struct SaStCap { static constexpr int v = TMAX <= 4 ? 6528 : 4608; };
+// 8-byte cells an LDS stage holds (TMAX = 4: the BASELINE shape; 8: wider query tables, smaller stage); two workgroups per CU
+template <int TMAX> struct SaStCap { static constexpr int v = TMAX <= 4 ? 6400 : 5248; };
 
 struct alignas(16) StTerm {
     u64 cell0;                  // first cell of the term in the impact stream
     u32 df;
     u32 row;                    // row of the stage directory, or SA_ST_NOROW: the kernel's cursor walks the term
+    u32 dense;                  // dense factor row of the term (sa_impacts::d_dense) when it is staged as one, else 0xFFFFFFFF
+    u32 maxf;                   // fp32 pattern of the term's largest factor in the shard
+    u32 pad0, pad1;
 };
 
 struct StageParams {
     const u64* imp;
-    const u32* dir; u32 dir_stride;       // stage directory [rows][n_st + 1]
+    u64 cell_base;                        // smallest cell0 of the set's terms: the kernel addresses the stream with 32-bit offsets from it
+    const u32* abs; const u32* cm;        // stage directory (sa_stagedir): [rows][n_st + 1], [rows][n_st]
     u32 docs, n_st;                       // docs per stage tile, tiles
     u64 n_docs, doc_base;
-    const StTerm* terms; u32 U;
-    u32 cb[3];                            // copy classes (sa_batch::st_cb)
+    const StTerm* terms; u32 U, ND;       // distinct terms; the first ND are staged as dense rows
+    const float* dense; u64 dense_stride; // dense factor rows
     u32 B, T, k;
     const unsigned short* pu;             // [B][T] distinct-term index of the query's term at POSITION i (descending bound), SA_ST_NONE: absent
     const float* pw;                      // [B][T] its weight
-    const float* pub;                     // [B][T] its bound: weight x largest factor
-    const float* psfx;                    // [B][T+1] bound of the positions >= i together, with the margin (psfx[T] = 0)
     const u32* inv;                       // [B] position of query term s: 4 bits each
     const u32* seed;                      // [B] starting bounds (score bits)
     u32* gthr; u32* hist;                 // [B] cached histogram bounds, [B][SA_HBINS] histograms
@@ -81,7 +84,9 @@ struct StageParams {
 };
 
 sa_stagedir::~sa_stagedir() {
-    if (d_dir) { hipSetDevice(device); hipFree(d_dir); }
+    if (d_abs || d_cm) (void)hipSetDevice(device);
+    if (d_abs) (void)hipFree(d_abs);
+    if (d_cm) (void)hipFree(d_cm);
 }
 
 __global__ void __launch_bounds__(256)
@@ -97,60 +102,74 @@ sa_k_build_stagedir(const u64* __restrict__ tfp, const u64* __restrict__ tf_off,
     }
 }
 
-// the index's stage directory for tiles of `docs` documents (built on first use; call with the index lock held)
-static std::shared_ptr<sa_stagedir> sa_stagedir_get(sa_index* ix, u32 docs) {
-    for (auto& d : ix->stagedirs) if (d && d->docs == docs) return d;
+// cm[row][tile] = postings | largest factor's upper 16 bits, rounded up (a bound: the patterns of non-negative floats order like the values)
+__global__ void __launch_bounds__(256)
+sa_k_build_stagecm(const u64* __restrict__ imp, const u64* __restrict__ tf_off, const u32* __restrict__ row_terms, u32 n_rows,
+                   u32 n_st, const u32* __restrict__ abs, u32* __restrict__ cm) {
+    const u64 total = (u64)n_rows * n_st;
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (u64)gridDim.x * blockDim.x) {
+        const u32 r = (u32)(e / n_st), j = (u32)(e % n_st);
+        const u32 t = row_terms[r];
+        const u64* cells = imp + sa_imp_base(tf_off[t], t);
+        const u32 lo = abs[(u64)r * (n_st + 1) + j], hi = abs[(u64)r * (n_st + 1) + j + 1];
+        u32 mx = 0;
+        for (u32 i = lo; i < hi; i++) { const u32 f = (u32)cells[i]; mx = f > mx ? f : mx; }
+        const u32 cnt = hi - lo < 0xFFFFu ? hi - lo : 0xFFFFu;
+        cm[e] = cnt | (((mx + 0xFFFFu) >> 16) << 16);
+    }
+}
+
+// the stage directory of impact stream `im` for tiles of `docs` documents (built on first use; call with the index lock held)
+static std::shared_ptr<sa_stagedir> sa_stagedir_get(sa_index* ix, sa_impacts* im, u32 docs) {
+    for (auto& d : im->stagedirs) if (d && d->docs == docs) return d;
     std::shared_ptr<sa_stagedir> sd(new (std::nothrow) sa_stagedir());
     if (!sd) return nullptr;
     sd->device = ix->device; sd->docs = docs;
     sd->n_st = ix->n_docs ? sa_div_up(ix->n_docs, docs) : 0;
     sd->row.assign(ix->n_terms, SA_ST_NOROW);
     std::vector<u32> row_terms;
-    const u64 min_df = std::max<u64>(32, sd->n_st / 2);           // at least one posting per two tiles
+    const u64 min_df = std::max<u64>(32, sd->n_st / 8);           // at least one posting per eight tiles
     for (u32 t = 0; t < ix->n_terms; t++) {
         const u64 df = ix->h_tf_off[t + 1] - ix->h_tf_off[t];
         if (df >= min_df) { sd->row[t] = (u32)row_terms.size(); row_terms.push_back(t); }
     }
     sd->n_rows = (u32)row_terms.size();
-    const u64 entries = (u64)sd->n_rows * (sd->n_st + 1);
-    if (hipMalloc(&sd->d_dir, (entries ? entries : 1) * sizeof(u32)) != hipSuccess) { (void)hipGetLastError(); sd->d_dir = nullptr; return nullptr; }
-    if (entries) {
+    const u64 entries = (u64)sd->n_rows * (sd->n_st + 1), cms = (u64)sd->n_rows * sd->n_st;
+    if (hipMalloc(&sd->d_abs, (entries ? entries : 1) * sizeof(u32)) != hipSuccess) { (void)hipGetLastError(); sd->d_abs = nullptr; return nullptr; }
+    if (hipMalloc(&sd->d_cm, (cms ? cms : 1) * sizeof(u32)) != hipSuccess) { (void)hipGetLastError(); sd->d_cm = nullptr; return nullptr; }
+    if (cms) {
         u32* d_rt = nullptr;
         if (hipMalloc(&d_rt, row_terms.size() * sizeof(u32)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         bool ok = hipMemcpyAsync(d_rt, row_terms.data(), row_terms.size() * sizeof(u32), hipMemcpyHostToDevice, ix->stream) == hipSuccess;
         if (ok) {
             const u32 grid = entries / 256 + 1 < 65536 ? (u32)(entries / 256 + 1) : 65536u;
             hipLaunchKernelGGL(sa_k_build_stagedir, dim3(grid), dim3(256), 0, ix->stream, (const u64*)ix->d_tfp, (const u64*)ix->d_tf_off,
-                               (const u32*)d_rt, sd->n_rows, sd->n_st, docs, sd->d_dir);
+                               (const u32*)d_rt, sd->n_rows, sd->n_st, docs, sd->d_abs);
+            hipLaunchKernelGGL(sa_k_build_stagecm, dim3(grid), dim3(256), 0, ix->stream, (const u64*)im->d_imp, (const u64*)ix->d_tf_off,
+                               (const u32*)d_rt, sd->n_rows, sd->n_st, (const u32*)sd->d_abs, sd->d_cm);
             ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(ix->stream) == hipSuccess;
         }
-        hipFree(d_rt);
+        (void)hipFree(d_rt);
         if (!ok) { (void)hipGetLastError(); return nullptr; }
     }
-    if (ix->stagedirs.size() >= 4) ix->stagedirs.erase(ix->stagedirs.begin());     // (batches that still use an old one keep it alive)
-    ix->stagedirs.push_back(sd);
+    if (im->stagedirs.size() >= 4) im->stagedirs.erase(im->stagedirs.begin());     // (batches that still use an old one keep it alive)
+    im->stagedirs.push_back(sd);
     return sd;
 }
 
 // ---- the plan of a query set, in the batch's upload block ---------------------------------------------------
-struct StLayout { size_t terms, pw, pub, psfx, inv, pu, total; };
+struct StLayout { size_t terms, pw, inv, pu, total; };
 static StLayout sa_stage_layout(u32 B, u32 T) {
     StLayout L;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 15) & ~(size_t)15; return o; };
     L.terms = take((size_t)B * T * sizeof(StTerm));
-    L.pw = take((size_t)B * T * 4); L.pub = take((size_t)B * T * 4); L.psfx = take((size_t)B * (T + 1) * 4);
+    L.pw = take((size_t)B * T * 4);
     L.inv = take((size_t)B * 4); L.pu = take((size_t)B * T * 2);
     L.total = off;
     return L;
 }
 size_t sa_stage_upload_bytes(u32 B, u32 T) { return sa_stage_layout(B, T).total; }
-
-static float sa_float_up(double x) {                 // the smallest float >= x (x >= 0, finite)
-    float f = (float)x;
-    if ((double)f < x) f = nextafterf(f, INFINITY);
-    return f;
-}
 
 // Plan the query set (row_terms / row_idf: [B][T] in device-row order) into the upload image: distinct terms (most frequent
 // first), per query the terms by descending score bound with their weights, bounds and suffix bounds, the starting
@@ -165,53 +184,73 @@ int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* ro
     const StLayout L = sa_stage_layout(B, T);
     char* base = img + (bt->d_st - bt->d_up);
     StTerm* h_terms = (StTerm*)(base + L.terms);
-    float* h_pw = (float*)(base + L.pw); float* h_pub = (float*)(base + L.pub); float* h_psfx = (float*)(base + L.psfx);
+    float* h_pw = (float*)(base + L.pw);
     u32* h_inv = (u32*)(base + L.inv);
     unsigned short* h_pu = (unsigned short*)(base + L.pu);
     u32* h_seed = (u32*)(img + ((char*)bt->d_seed - bt->d_up));
 
-    // distinct terms, most frequent first
+    // distinct terms: those with a dense factor row first (they are staged as rows), then by document frequency
     std::unordered_map<u32, u32> idx;
     idx.reserve((size_t)B * T * 2);
-    std::vector<std::pair<u64, u32>> dist;               // (df, term)
+    struct DT { u64 df; u32 term; u32 dense; };
+    std::vector<DT> dist;
+    const bool dense_on = im->d_dense != nullptr && sa_opt(bt->opts.stage_dense, 1) != 0;
     for (size_t i = 0; i < (size_t)B * T; i++) {
         const u32 t = row_terms[i];
         if (t >= ix->n_terms) continue;
-        if (idx.emplace(t, 0u).second) dist.push_back({ix->h_tf_off[t + 1] - ix->h_tf_off[t], t});
+        if (idx.emplace(t, 0u).second)
+            dist.push_back({ix->h_tf_off[t + 1] - ix->h_tf_off[t], t, dense_on && t < im->dense_slot.size() ? im->dense_slot[t] : 0xFFFFFFFFu});
     }
     if (dist.empty() || dist.size() > SA_ST_UMAX) return SA_OK;
-    std::sort(dist.begin(), dist.end(), [](const std::pair<u64, u32>& a, const std::pair<u64, u32>& c) { return a.first > c.first || (a.first == c.first && a.second < c.second); });
+    std::sort(dist.begin(), dist.end(), [](const DT& a, const DT& c) {
+        const bool da = a.dense != 0xFFFFFFFFu, dc = c.dense != 0xFFFFFFFFu;
+        if (da != dc) return da;
+        return a.df > c.df || (a.df == c.df && a.term < c.term);
+    });
     const u32 U = (u32)dist.size();
+    u32 ND = 0;
+    while (ND < U && ND < (u32)SA_ST_NDMAX && dist[ND].dense != 0xFFFFFFFFu) ND++;
+    for (u32 u = ND; u < U; u++) dist[u].dense = 0xFFFFFFFFu;            // (more dense rows than the stage takes: the rest as postings)
+    std::sort(dist.begin() + ND, dist.end(), [](const DT& a, const DT& c) { return a.df > c.df || (a.df == c.df && a.term < c.term); });
     u64 dfsum = 0;
-    for (u32 u = 0; u < U; u++) { idx[dist[u].second] = u; dfsum += dist[u].first; }
-    // docs per stage tile: the largest of the sizes below whose expected postings fit the stage with room for the tiles above the mean
+    for (u32 u = 0; u < U; u++) { idx[dist[u].term] = u; if (u >= ND) dfsum += dist[u].df; }
+    // docs per stage tile: the largest of the sizes below whose expected cells -- half a cell per doc and dense row, one per posting
+    // of the other terms -- fit the stage with room for the tiles above the mean
     const u32 tmax = T <= 4 ? 4u : 8u;
     const double cap = tmax == 4 ? (double)SaStCap<4>::v : (double)SaStCap<8>::v;
     const double per_doc = (double)dfsum / (double)ix->n_docs;
     u32 docs = 0;
-    if (sa_opt_is_set(bt->opts.stage_docs)) docs = (u32)std::max<long long>(64, bt->opts.stage_docs) / 64u * 64u;
+    if (sa_opt_is_set(bt->opts.stage_docs)) docs = (u32)std::min<long long>(1024, std::max<long long>(64, bt->opts.stage_docs)) / 64u * 64u;
     else {
         static const u32 sizes[] = {1024, 768, 512, 384, 256, 192, 128, 64};
-        for (u32 s : sizes) if (per_doc * s + 4.0 * sqrt(per_doc * s) <= 0.97 * cap) { docs = s; break; }
+        for (u32 s : sizes) if (0.5 * ND * s + per_doc * s + 4.0 * sqrt(per_doc * s) <= 0.97 * cap) { docs = s; break; }
         if (!docs) return SA_OK;                          // (more than ~70 postings per doc over the set's terms: not this route)
     }
-    std::shared_ptr<sa_stagedir> sd = sa_stagedir_get(ix, docs);
+    if ((u64)ND * docs / 2u + SA_ST_UMAX > (u64)cap) {     // (forced tile size: fewer dense rows)
+        ND = 0;
+        for (u32 u = 0; u < U; u++) dist[u].dense = 0xFFFFFFFFu;
+        std::sort(dist.begin(), dist.end(), [](const DT& a, const DT& c) { return a.df > c.df || (a.df == c.df && a.term < c.term); });
+        for (u32 u = 0; u < U; u++) idx[dist[u].term] = u;
+    }
+    std::shared_ptr<sa_stagedir> sd = sa_stagedir_get(ix, im, docs);
     if (!sd) return SA_OK;
+    // the kernel addresses the stream with 32-bit offsets from the set's first term
+    u64 cell_lo = ~0ull, cell_hi = 0;
     for (u32 u = 0; u < U; u++) {
-        const u32 t = dist[u].second;
-        h_terms[u].cell0 = sa_imp_base(ix->h_tf_off[t], t);
-        h_terms[u].df = (u32)dist[u].first;
-        h_terms[u].row = sd->row[t];
+        const u32 t = dist[u].term;
+        StTerm& x = h_terms[u];
+        x.cell0 = sa_imp_base(ix->h_tf_off[t], t);
+        x.df = (u32)dist[u].df;
+        x.row = sd->row[t];
+        x.dense = dist[u].dense;
+        memcpy(&x.maxf, &im->h_maxf[t], 4);
+        x.pad0 = 0; x.pad1 = 0;
+        if (x.dense != 0xFFFFFFFFu && x.row == SA_ST_NOROW) return SA_OK;       // (cannot happen: a dense row means df >= n_docs / 4)
+        cell_lo = std::min<u64>(cell_lo, x.cell0);
+        cell_hi = std::max<u64>(cell_hi, x.cell0 + (u64)x.df + 4ull);
     }
-    // copy classes by the postings a tile is expected to hold
-    u32 cb[3] = {0, 0, 0};
-    for (u32 u = 0; u < U; u++) {
-        const double e = (double)dist[u].first * docs / (double)ix->n_docs;
-        if (e >= 40.0) cb[0] = u + 1;
-        if (e >= 20.0) cb[1] = u + 1;
-        if (e >= 10.0) cb[2] = u + 1;
-    }
-    // the queries
+    if (cell_hi - cell_lo >= 0xFFFFFFF0ull) return SA_OK;
+    // the queries: terms by descending bound (weight x largest factor in the shard), weights, starting bounds
     u32 rank_idx = SA_TOPF_NR - 1;
     for (int i = SA_TOPF_NR - 1; i >= 0; i--) if (sa_topf_ranks[i] >= bt->k) rank_idx = (u32)i;
     const float seed_scale = (float)sa_opt(bt->opts.seed_scale_pct, 100) / 100.f;
@@ -224,29 +263,24 @@ int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* ro
             ord[s] = s;
             if (t >= ix->n_terms) { ub[s] = 0.f; un[s] = SA_ST_NONE; continue; }
             un[s] = idx[t];
-            ub[s] = im->h_maxf[t] * w;                                   // (fp32 product: factor * w <= maxf * w, rounding is monotone)
+            ub[s] = im->h_maxf[t] * w;
             const float sd1 = (im->h_topf[(size_t)t * SA_TOPF_NR + rank_idx] * w) * seed_scale;   // (the arithmetic of sa_k_make_bounds)
             if (sd1 > seed) seed = sd1;
         }
         std::stable_sort(ord, ord + T, [&](u32 a, u32 c) { return ub[a] > ub[c]; });
         u32 inv = 0;
-        double sfx = 0.0;
-        h_psfx[(size_t)q * (T + 1) + T] = 0.f;
-        for (int i = (int)T - 1; i >= 0; i--) {
+        for (u32 i = 0; i < T; i++) {
             const u32 s = ord[i];
             h_pu[(size_t)q * T + i] = (unsigned short)un[s];
             h_pw[(size_t)q * T + i] = row_idf[(size_t)q * T + s];
-            h_pub[(size_t)q * T + i] = ub[s];
-            sfx += (double)ub[s];
-            h_psfx[(size_t)q * (T + 1) + i] = sfx > 0.0 ? sa_float_up(sfx * (double)SA_ST_MARGIN) : 0.f;
-            inv |= (u32)i << (4u * s);
+            inv |= i << (4u * s);
         }
         h_inv[q] = inv;
         u32 sb; memcpy(&sb, &seed, 4);
         h_seed[q] = seed > 0.f ? sb : 0u;
     }
-    bt->st_U = U; bt->st_docs = docs; bt->st_tmax = tmax;
-    bt->st_cb[0] = cb[0]; bt->st_cb[1] = cb[1]; bt->st_cb[2] = cb[2];
+    bt->st_U = U; bt->st_ND = ND; bt->st_docs = docs; bt->st_tmax = tmax;
+    bt->st_cell_base = cell_lo;
     bt->st_dir = sd;
     bt->stage_ok = true;
     return SA_OK;
@@ -272,26 +306,83 @@ __device__ __forceinline__ float sa_st_lookup(const u64* s_post, u32 pk, u32 d4,
     return 0.f;
 }
 
+// inclusive prefix sum over the 64 lanes of a wave through the DPP data path (no LDS crossbar round trips like the
+// ds_bpermute-based __shfl_up): Hillis-Steele inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 carry the rows' totals
+__device__ __forceinline__ u32 sa_st_wave_incl_scan(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, SA_DPP_ROW_SHR(1), 0xf, 0xf, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, SA_DPP_ROW_SHR(2), 0xf, 0xf, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, SA_DPP_ROW_SHR(4), 0xf, 0xf, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, SA_DPP_ROW_SHR(8), 0xf, 0xf, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, SA_DPP_ROW_BCAST15, 0xa, 0xf, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, SA_DPP_ROW_BCAST31, 0xc, 0xf, false);
+    return v;
+}
+// Block-wide exclusive scan of TWO u32 per thread behind ONE barrier: the waves' totals go to the half of `red` (2 x 2 NWAVES
+// words) that `parity` selects; the caller alternates the parity from call to call, so a wave that is still reading one half
+// cannot see the next call's totals (two calls apart there is a barrier every wave has passed).
+template <int NWAVES>
+__device__ __forceinline__ void sa_block_excl_scan2(u32 a, u32 b, u32* red, u32 parity, u32& ea, u32& eb, u32& ta, u32& tb) {
+    const u32 ia = sa_st_wave_incl_scan(a), ib = sa_st_wave_incl_scan(b);
+    u32* const r = red + parity * (2u * NWAVES);
+    if (sa_lane() == SA_WAVE - 1) { r[2 * sa_wave_id()] = ia; r[2 * sa_wave_id() + 1] = ib; }
+    __syncthreads();
+    u32 ba = 0, bb = 0; ta = 0; tb = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVES; w++) {
+        const u32 sa = r[2 * w], sb = r[2 * w + 1];
+        if (w < sa_wave_id()) { ba += sa; bb += sb; }
+        ta += sa; tb += sb;
+    }
+    ea = ba + ia - a; eb = bb + ib - b;
+}
+
+// -DSA_PROBE (scripts/build_probe.sh; never in the product build): cycles a workgroup spends per phase of a tile pass, summed
+// over the launch by wave 0 (s_memtime at the phase boundaries), read by sa_debug_stage_probe_read
+#ifdef SA_PROBE
+__device__ unsigned long long g_sa_stage_probe[16];
+#define SA_SPT(i) do { if (tid == 0) { const u64 t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - plast; plast = t_; } } while (0)
+extern "C" int sa_debug_stage_probe_read(unsigned long long* out16, int clear) {
+    if (hipDeviceSynchronize() != hipSuccess) return SA_ERR_HIP;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sa_stage_probe), 16 * 8) != hipSuccess) return SA_ERR_HIP;
+    if (clear) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sa_stage_probe), z, 16 * 8) != hipSuccess) return SA_ERR_HIP; }
+    return SA_OK;
+}
+#else
+#define SA_SPT(i) do { } while (0)
+#endif
+
 template <int TMAX>
-__global__ void __launch_bounds__(SA_ST_NT) sa_k_bm25_stage(const StageParams sp) {
+__global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams sp) {
     constexpr int CAP = SaStCap<TMAX>::v;
-    constexpr int NT = SA_ST_NT, NW = NT / SA_WAVE, KT = SA_ST_UMAX / NT;
+    constexpr int NT = SA_ST_NT, NW = NT / SA_WAVE, KT = (SA_ST_UMAX + NT - 1) / NT;
+    constexpr int NCH = CAP / 8 + SA_ST_UMAX;                    // 8-posting chunks a stage can hold at most; also the work list's cells
+    constexpr int KB = 10;                                       // chunk loads a lane issues before it waits
+    constexpr int KD = 2;                                        // 16-byte loads of the dense rows a lane issues before it waits
     static_assert(SA_ST_UMAX <= CAP, "a single document's postings must fit the stage");
-    static_assert(CAP <= 65535, "16-bit stage offsets");
-    __shared__ alignas(16) u64 s_post[CAP];                      // the stage: every distinct term's slice of this tile, doc-sorted
-    __shared__ u32 s_off[SA_ST_UMAX];                           // per distinct term: start << 16 | postings
-    __shared__ u32 s_lo[SA_ST_UMAX];                            // its first posting, relative to the term's base
-    __shared__ unsigned short s_pu[SA_ST_BMAX * TMAX];
-    __shared__ float s_pw[SA_ST_BMAX * TMAX];
-    __shared__ float s_pub[SA_ST_BMAX * TMAX];
-    __shared__ float s_psfx[SA_ST_BMAX * (TMAX + 1)];
+    static_assert(CAP <= 65535 && SA_ST_UMAX <= 1024, "16-bit stage offsets, 10-bit term index in a chunk descriptor");
+    __shared__ alignas(16) u64 s_post[CAP];                      // the stage: dense rows (fp32 per doc of the tile), then every other term's slice, doc-sorted
+    __shared__ u32 s_off[SA_ST_UMAX];                           // per distinct term: first cell << 16 | postings (SA_ST_DENSE: a dense row)
+    __shared__ u32 s_src[SA_ST_UMAX];                           // its first posting's cell in the stream, relative to sp.cell_base
+    __shared__ u32 s_tmax[SA_ST_UMAX];                          // bound (fp32 pattern) of its factors in this tile
+    __shared__ u32 s_cw[NCH];                                   // chunk descriptors of the copy (term | chunk << 10), then the candidate work list
+    __shared__ unsigned short s_pu[SA_ST_BMAX * TMAX];          // [query][position]: distinct-term index
+    __shared__ float s_pw[SA_ST_BMAX * TMAX];                   //   its weight
+    __shared__ float s_psfx[SA_ST_BMAX * (TMAX + 1)];           //   what the positions >= i can add in THIS tile (with the margin)
     __shared__ u32 s_thr[SA_ST_BMAX];
-    __shared__ u32 s_wl[SA_ST_WL];
     __shared__ u32 s_ref[SA_ST_REF];
-    __shared__ u32 s_nref;
-    __shared__ u32 s_red[NW + 1];
+    __shared__ u32 s_dsl[SA_ST_NDMAX];
+    __shared__ u32 s_nref, s_wlcnt;
+    __shared__ u32 s_red[4 * NW];
     const u32 tid = threadIdx.x, lane = tid & (SA_WAVE - 1), wave = tid / SA_WAVE;
-    const u32 T = sp.T, B = sp.B, U = sp.U;
+    const u32 T = sp.T, B = sp.B, U = sp.U, ND = sp.ND;
+    const u64* const imp0 = sp.imp + sp.cell_base;
+    const float* const sf = (const float*)s_post;
+    const u32 dense_cells = ND * (sp.docs >> 1);                 // cells the dense rows take at the front of the stage
+#ifdef SA_PROBE
+    u64 pacc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    u64 plast = __builtin_amdgcn_s_memtime();
+    u32 ptiles = 0, pcand = 0;
+#endif
     // XCD-aware tile ranges: block b runs on XCD b % 8; an XCD walks a contiguous range of tiles and its workgroups
     // contiguous sub-ranges -- a term's slices of neighbouring tiles are neighbours in memory, so the cache line a slice
     // shares with the next tile's is fetched into ONE L2
@@ -303,26 +394,36 @@ __global__ void __launch_bounds__(SA_ST_NT) sa_k_bm25_stage(const StageParams sp
     if (t_begin >= t_end) return;                               // (uniform)
 
     // the queries' tables, once per workgroup
-    for (u32 i = tid; i < B * T; i += NT) { s_pu[i] = sp.pu[i]; s_pw[i] = sp.pw[i]; s_pub[i] = sp.pub[i]; }
-    for (u32 i = tid; i < B * (T + 1u); i += NT) s_psfx[i] = sp.psfx[i];
-    if (tid == 0) s_nref = 0u;
+    for (u32 i = tid; i < B * T; i += NT) { s_pu[i] = sp.pu[i]; s_pw[i] = sp.pw[i]; }
+    if (tid < ND) s_dsl[tid] = sp.terms[tid].dense;
+    if (tid == 0) { s_nref = 0u; s_wlcnt = 0u; }
     const bool hasq = tid < B;
     const u32 seed = (hasq && sp.seed) ? sp.seed[tid] : 0u;
-    // this thread's terms: cursor = first posting not yet staged
-    u64 cell0[KT]; u32 row[KT], lo[KT];
+    u32 g_raw = 0u;
+    u32 parity = 0;
+    // this thread's terms.  lo: first posting not yet staged.  A term with a directory row: nx = its cm word (postings | bound of
+    // the factors) of the NEXT tile to take, read one tile ahead.  A term without one is WALKED: w0, w1 = doc keys of the
+    // postings at lo and lo + 1 (read one tile ahead too; the sentinel behind a term's postings has the doc field all ones: a
+    // walk stops there); its bound is its largest factor in the shard.
+    u32 src0[KT], row[KT], lo[KT], nx[KT], w1[KT];              // (nx: the cm word of a term with a row, the doc key at lo of a walked term)
+    auto key_at = [&](u32 cell) -> u32 { return ((const u32*)imp0)[2ull * cell + 1ull]; };      // (the doc key of a cell: its high word, a 4-byte load)
 #pragma unroll
     for (int kx = 0; kx < KT; kx++) {
         const u32 u = tid + (u32)kx * NT;
-        cell0[kx] = 0; row[kx] = SA_ST_NOROW; lo[kx] = 0;
+        src0[kx] = 0; row[kx] = SA_ST_NOROW; lo[kx] = 0; nx[kx] = 0xFFFFFFFFu; w1[kx] = 0xFFFFFFFFu;
         if (u < U) {
             const StTerm t = sp.terms[u];
-            cell0[kx] = t.cell0; row[kx] = t.row;
-            if (t.row != SA_ST_NOROW) lo[kx] = sp.dir[(u64)t.row * sp.dir_stride + t_begin];
-            else {
+            src0[kx] = (u32)(t.cell0 - sp.cell_base); row[kx] = t.row;
+            s_tmax[u] = t.maxf;                                 // (a walked term keeps this bound; a term with a row gets its tile's)
+            if (t.row != SA_ST_NOROW) {
+                lo[kx] = sp.abs[(u64)t.row * (sp.n_st + 1u) + t_begin];
+                nx[kx] = sp.cm[(u64)t.row * sp.n_st + t_begin];
+            } else {
                 const u32 key = (u32)((u64)t_begin * sp.docs) << 2;
                 u32 a = 0, b = t.df;
-                while (a < b) { const u32 mid = a + ((b - a) >> 1); if ((u32)(sp.imp[t.cell0 + mid] >> 32) < key) a = mid + 1u; else b = mid; }
+                while (a < b) { const u32 mid = a + ((b - a) >> 1); if (key_at(src0[kx] + mid) < key) a = mid + 1u; else b = mid; }
                 lo[kx] = a;
+                nx[kx] = key_at(src0[kx] + a); w1[kx] = key_at(src0[kx] + a + 1u);
             }
         }
     }
@@ -331,160 +432,259 @@ __global__ void __launch_bounds__(SA_ST_NT) sa_k_bm25_stage(const StageParams sp
     for (u32 tile = t_begin; tile < t_end; tile++) {
         const u64 tile_d0 = (u64)tile * sp.docs;
         const u64 tile_d1 = tile_d0 + sp.docs < sp.n_docs ? tile_d0 + sp.docs : sp.n_docs;
-        // the queries' bounds (a bound only ever rises: a stale one is valid)
-        u32 g = hasq ? __hip_atomic_load(&sp.gthr[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        g = g > seed ? g : seed;
-        // end of every term's slice of this tile
-        u32 hi_t[KT];
+        SA_SPT(11);
+        // end of every term's slice of this tile and the bound of its factors there, from what was read a tile ago
+        u32 hi_t[KT], tm[KT];
+        {
+            const u32 key = (u32)tile_d1 << 2;
 #pragma unroll
-        for (int kx = 0; kx < KT; kx++) {
-            const u32 u = tid + (u32)kx * NT;
-            hi_t[kx] = lo[kx];
-            if (u < U) {
-                if (row[kx] != SA_ST_NOROW) hi_t[kx] = sp.dir[(u64)row[kx] * sp.dir_stride + tile + 1u];
-                else {
-                    // (the sentinel behind a term's postings has the doc field all ones: the walk stops there)
-                    const u32 key = (u32)tile_d1 << 2;
-                    u32 c = lo[kx];
-                    while ((u32)(sp.imp[cell0[kx] + c] >> 32) < key) c++;
-                    hi_t[kx] = c;
+            for (int kx = 0; kx < KT; kx++) {
+                const u32 u = tid + (u32)kx * NT;
+                const bool have = u < U, rowed = have && row[kx] != SA_ST_NOROW, walked = have && !rowed;
+                const u32 cmw = nx[kx];
+                u32 c = lo[kx];
+                if (walked && cmw < key) {
+                    c++;
+                    if (w1[kx] < key) { c++; while (key_at(src0[kx] + c) < key) c++; }     // (three postings of a rare term in one tile: hardly ever)
                 }
+                hi_t[kx] = rowed ? (u >= ND ? lo[kx] + (cmw & 0xFFFFu) : lo[kx]) : c;
+                tm[kx] = cmw & 0xFFFF0000u;
             }
         }
+        // the queries' bounds (a bound only ever rises: a stale one is valid), read a tile ago
+        const u32 g_now = g_raw > seed ? g_raw : seed;
         // A tile whose postings do not fit the stage is taken in doc sub-ranges: halve the range until it fits (a single
-        // document holds at most U <= CAP postings), the slices' ends by a search of the posting lists.
+        // document holds at most U <= CAP - dense rows postings), the slices' ends by a search of the posting lists.
         u64 d_s = tile_d0;
         while (d_s < tile_d1) {                                 // (uniform)
             u64 d_e = tile_d1;
             u32 hi[KT];
 #pragma unroll
             for (int kx = 0; kx < KT; kx++) hi[kx] = hi_t[kx];
-            u32 excl, P;
-            for (;;) {
-                u32 mine = 0;
-#pragma unroll
-                for (int kx = 0; kx < KT; kx++) mine += hi[kx] - lo[kx];
-                excl = sa_block_excl_scan<NW>(mine, s_red, &P);
-                if (P <= (u32)CAP || d_e - d_s <= 1ull) break;
-                d_e = d_s + ((d_e - d_s) >> 1);
-                const u32 key = (u32)d_e << 2;
-#pragma unroll
-                for (int kx = 0; kx < KT; kx++) {
-                    u32 a = lo[kx], b = hi[kx];
-                    while (a < b) { const u32 mid = a + ((b - a) >> 1); if ((u32)(sp.imp[cell0[kx] + mid] >> 32) < key) a = mid + 1u; else b = mid; }
-                    hi[kx] = a;
-                }
-            }
+            u32 excl, exch, P, NC;
             {
-                u32 o = excl;
+                u32 mine = 0, mch = 0;
+#pragma unroll
+                for (int kx = 0; kx < KT; kx++) { mine += hi[kx] - lo[kx]; mch += (hi[kx] - lo[kx] + 7u) >> 3; }
+                sa_block_excl_scan2<NW>(mine, mch, s_red, parity, excl, exch, P, NC);
+                parity ^= 1u;
+            }
+            // (the rare case apart from the common path: a loop with loads in it makes the compiler wait for every load in flight at its head)
+            if (P + dense_cells > (u32)CAP && d_e - d_s > 1ull) {
+                do {
+                    d_e = d_s + ((d_e - d_s) >> 1);
+                    const u32 key = (u32)d_e << 2;
+                    u32 mine = 0, mch = 0;
+#pragma unroll
+                    for (int kx = 0; kx < KT; kx++) {
+                        u32 a = lo[kx], b = hi[kx];
+                        while (a < b) { const u32 mid = a + ((b - a) >> 1); if (key_at(src0[kx] + mid) < key) a = mid + 1u; else b = mid; }
+                        hi[kx] = a;
+                        mine += hi[kx] - lo[kx]; mch += (hi[kx] - lo[kx] + 7u) >> 3;
+                    }
+                    sa_block_excl_scan2<NW>(mine, mch, s_red, parity, excl, exch, P, NC);
+                    parity ^= 1u;
+                } while (P + dense_cells > (u32)CAP && d_e - d_s > 1ull);
+            }
+            SA_SPT(0);
+            {
+                // stage offsets, bounds and the copy's chunk list: one descriptor per 8 postings
+                u32 o = dense_cells + excl, oc = exch;
 #pragma unroll
                 for (int kx = 0; kx < KT; kx++) {
                     const u32 u = tid + (u32)kx * NT;
-                    if (u < U) { const u32 n = hi[kx] - lo[kx]; s_off[u] = (o << 16) | n; s_lo[u] = lo[kx]; o += n; }
-                }
-            }
-            __syncthreads();
-            // ---- stage: copy the slices.  Terms are ordered by df: the first classes get 64 / 32 / 16 lanes per term, the rest 8
-            {
-                u32 c0 = 0;
-#pragma unroll 1
-                for (int c = 0; c < 4; c++) {
-                    const u32 c1 = c < 3 ? (sp.cb[c] < U ? sp.cb[c] : U) : U;
-                    const u32 gsh = 6u - (u32)c, G = 1u << gsh, per = 64u >> gsh;      // lanes per term, terms per wave step
-                    const u32 nsteps = (c1 - c0 + per - 1u) / per;
-                    for (u32 step = wave; step < nsteps; step += NW) {
-                        const u32 u = c0 + step * per + (lane >> gsh);
-                        if (u < c1) {
-                            const u32 pk = s_off[u];
-                            const u32 start = pk >> 16, n = pk & 0xFFFFu;
-                            const u64* src = sp.imp + sp.terms[u].cell0 + s_lo[u];
-                            for (u32 j = lane & (G - 1u); j < n; j += 4u * G) {
-                                const u32 j1 = j + G, j2 = j + 2u * G, j3 = j + 3u * G;
-                                const u64 v0 = src[j];
-                                const u64 v1 = j1 < n ? src[j1] : 0ull;
-                                const u64 v2 = j2 < n ? src[j2] : 0ull;
-                                const u64 v3 = j3 < n ? src[j3] : 0ull;
-                                s_post[start + j] = v0;
-                                if (j1 < n) s_post[start + j1] = v1;
-                                if (j2 < n) s_post[start + j2] = v2;
-                                if (j3 < n) s_post[start + j3] = v3;
-                            }
+                    if (u < U) {
+                        if (row[kx] != SA_ST_NOROW) s_tmax[u] = tm[kx];
+                        if (u < ND) s_off[u] = ((u * (sp.docs >> 1)) << 16) | SA_ST_DENSE;
+                        else {
+                            const u32 n = hi[kx] - lo[kx], nch = (n + 7u) >> 3;
+                            s_off[u] = (o << 16) | n; s_src[u] = src0[kx] + lo[kx];
+                            for (u32 ci = 0; ci < nch; ci++) s_cw[oc + ci] = u | (ci << 10);
+                            o += n; oc += nch;
                         }
                     }
-                    c0 = c1;
                 }
             }
+            SA_SPT(1);
             __syncthreads();
-            // ---- the queries: bound, essential positions, candidates
-            u32 ncand = 0, ness = 0;
+            SA_SPT(2);
+            // ---- the reads for the NEXT tile: cm words, the walked terms' next doc keys, the queries' bounds.  Every load is
+            //      UNCONDITIONAL (a lane without the case reads a harmless cell) and its result is only looked at a tile later: a
+            //      load inside a branch makes the compiler wait for everything in flight where the branch joins.  Issued in
+            //      front of the stage's loads, so that they have landed when those have -- the loops further down contain
+            //      (rare) loads, and at the head of such a loop the compiler waits for every load in flight.
+            {
+                const u32 tnext = tile + 1u < t_end ? tile + 1u : tile;
+#pragma unroll
+                for (int kx = 0; kx < KT; kx++) {
+                    const u32 u = tid + (u32)kx * NT;
+                    const bool have = u < U, rowed = have && row[kx] != SA_ST_NOROW, walked = have && !rowed;
+                    const u32 wc = walked ? src0[kx] + hi_t[kx] : 0u;
+                    const u32* const a0 = rowed ? sp.cm + ((u64)row[kx] * sp.n_st + tnext) : (const u32*)imp0 + (2ull * wc + 1ull);
+                    nx[kx] = *a0; w1[kx] = key_at(wc + 1u);
+                }
+                g_raw = __hip_atomic_load(&sp.gthr[hasq ? tid : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // ---- stage.  Dense rows: the tile's docs of each row, 16 bytes per lane.  Postings: eight lanes per chunk.  A lane
+            //      issues all its loads (KD + KB) before it waits for the first.
+            {
+                const u32 grp = tid >> 3, sub = tid & 7u;
+                const u32 d4n = sp.docs >> 2, n_d4 = ND * d4n;           // float4 per row, in all
+                float4* const s4 = (float4*)s_post;
+                const float* const dbase = ND ? sp.dense : (const float*)sp.imp;       // (no dense rows: nobody uses what is read)
+                u32 y0 = 0, x0 = 0;
+                do {                                                    // (uniform)
+                    float4 dv[KD];
+                    u64 v[KB]; u32 dst2[KB / 2];                       // (two 16-bit stage cells per register; 0xFFFF: nothing to write)
+                    // (unconditional loads: a lane without an item reads cell 0 and writes nothing)
+#pragma unroll
+                    for (int i = 0; i < KD; i++) {
+                        const u32 y = y0 + (u32)i * NT + tid;
+                        const bool have = y < n_d4;
+                        const u32 yy = have ? y : 0u;
+                        const u32 r = yy / d4n, c = yy - r * d4n;
+                        const u64 doc0 = tile_d0 + 4ull * c;
+                        const bool in = have && doc0 + 4ull <= sp.dense_stride;
+                        const float4 x4 = *(const float4*)(dbase + (in ? (u64)s_dsl[r] * sp.dense_stride + doc0 : 0ull));
+                        dv[i] = in ? x4 : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int i = 0; i < KB; i++) {
+                        const u32 x = x0 + (u32)i * (NT / 8) + grp;
+                        const u32 d = s_cw[x < NC ? x : 0u];
+                        const u32 u = d & 1023u, j = (d >> 10) * 8u + sub;
+                        const u32 pk = s_off[u];
+                        const bool ok = x < NC && j < (pk & 0xFFFFu);
+                        const u32 dd = ok ? (pk >> 16) + j : 0xFFFFu;
+                        if (i & 1) dst2[i / 2] |= dd << 16; else dst2[i / 2] = dd;
+                        v[i] = imp0[ok ? s_src[u] + j : 0u];
+                    }
+                    SA_SPT(3);
+#pragma unroll
+                    for (int i = 0; i < KD; i++) { const u32 y = y0 + (u32)i * NT + tid; if (y < n_d4) s4[y] = dv[i]; }
+#pragma unroll
+                    for (int i = 0; i < KB; i++) { const u32 dd = (dst2[i / 2] >> (16 * (i & 1))) & 0xFFFFu; if (dd != 0xFFFFu) s_post[dd] = v[i]; }
+                    y0 += (u32)KD * NT; x0 += (u32)(KB * (NT / 8));
+                } while (y0 < n_d4 || x0 < NC);
+            }
+            SA_SPT(4);
+            __syncthreads();
+            SA_SPT(5);
+            // ---- the queries: bound; what every position can add at most in THIS tile (weight x bound of the term's factors here);
+            //      essential positions; their postings are the candidates, reserved in the work list with one LDS atomic
+            const u32 pass_docs = (u32)(d_e - d_s), pass_o = (u32)(d_s - tile_d0);
+            auto npos = [&](u32 u) -> u32 {                         // candidates position u contributes when it is essential
+                if (u == SA_ST_NONE) return 0u;
+                const u32 n = s_off[u] & 0xFFFFu;
+                return n == SA_ST_DENSE ? pass_docs : n;
+            };
+            u32 ncand = 0, ness = 0, done = 0;
             if (hasq) {
-                const u32 thr = g > 1u ? g : 1u;
+                const u32 thr = g_now > 1u ? g_now : 1u;
                 const float thr_f = __uint_as_float(thr);
-                for (u32 i = 0; i < T; i++) if (s_psfx[tid * (T + 1u) + i] >= thr_f) ness = i + 1u;
-                for (u32 i = 0; i < ness; i++) ncand += s_off[s_pu[tid * T + i]] & 0xFFFFu;
+                float sfx = 0.f;
+                s_psfx[tid * (T + 1u) + T] = 0.f;
+                for (u32 ii = 0; ii < T; ii++) {
+                    const u32 i = T - 1u - ii;
+                    const u32 u = s_pu[tid * T + i];
+                    if (u != SA_ST_NONE) sfx = __fadd_rn(sfx, __fmul_rn(__uint_as_float(s_tmax[u]), s_pw[tid * T + i]));
+                    const float sm = __fmul_rn(sfx, SA_ST_MARGIN);
+                    s_psfx[tid * (T + 1u) + i] = sm;
+                    if (sm >= thr_f && ness == 0u) ness = i + 1u;
+                }
+                for (u32 i = 0; i < ness; i++) ncand += npos(s_pu[tid * T + i]);
                 s_thr[tid] = thr;
             }
-            u32 C;
-            const u32 o_q = sa_block_excl_scan<NW>(ncand, s_red, &C);
-            for (u32 c0 = 0; c0 < C; c0 += (u32)SA_ST_WL) {      // (uniform)
-                // thread q writes the records of its candidates that fall into this chunk: query | position << 9 | posting << 12
-                if (ncand) {
-                    const u32 a = o_q > c0 ? o_q : c0;
-                    const u32 e = o_q + ncand < c0 + (u32)SA_ST_WL ? o_q + ncand : c0 + (u32)SA_ST_WL;
-                    if (a < e) {
-                        u32 r = a - o_q, i = 0;
-                        u32 ni = s_off[s_pu[tid * T]] & 0xFFFFu;
-                        while (r >= ni) { r -= ni; i++; ni = s_off[s_pu[tid * T + i]] & 0xFFFFu; }
-                        for (u32 x = a; x < e; x++) {
-                            s_wl[x - c0] = tid | (i << 9) | (r << 12);
+            SA_SPT(6);
+            for (;;) {                                          // (uniform: rounds of at most NCH candidates)
+                // thread q writes the records of its next candidates: query | position << 9 | posting << 12
+                if (ncand > done) {
+                    const u32 want = ncand - done;
+                    const u32 o = atomicAdd(&s_wlcnt, want);
+                    const u32 take = o < (u32)NCH ? (want < (u32)NCH - o ? want : (u32)NCH - o) : 0u;
+                    if (take) {
+                        u32 r = done, i = 0;
+                        u32 ni = npos(s_pu[tid * T]);
+                        while (r >= ni) { r -= ni; i++; ni = npos(s_pu[tid * T + i]); }
+                        for (u32 x = 0; x < take; x++) {
+                            s_cw[o + x] = tid | (i << 9) | (r << 12);
                             r++;
-                            while (r >= ni && x + 1u < e) { r = 0; i++; ni = s_off[s_pu[tid * T + i]] & 0xFFFFu; }
+                            while (r >= ni && x + 1u < take) { r = 0; i++; ni = npos(s_pu[tid * T + i]); }
                         }
+                        done += take;
                     }
                 }
+                SA_SPT(7);
                 __syncthreads();
-                const u32 nchunk = C - c0 < (u32)SA_ST_WL ? C - c0 : (u32)SA_ST_WL;
+                SA_SPT(8);
+                const u32 reserved = s_wlcnt;
+                const u32 nchunk = reserved < (u32)NCH ? reserved : (u32)NCH;
+#ifdef SA_PROBE
+                pcand += nchunk;
+#endif
                 for (u32 x = tid; x < nchunk; x += NT) {
-                    const u32 rec = s_wl[x];
+                    const u32 rec = s_cw[x];
                     const u32 q = rec & 0x1FFu, i_src = (rec >> 9) & 7u, j = rec >> 12;
                     const u32 qb = q * T;
-                    const float thr_f = __uint_as_float(s_thr[q]);
-                    const u64 v = s_post[(s_off[s_pu[qb + i_src]] >> 16) + j];
-                    const u32 d4 = (u32)(v >> 32);
-                    float known = __fmul_rn(__uint_as_float((u32)v), s_pw[qb + i_src]);
-                    const float ub_src = s_pub[qb + i_src];
-                    bool alive = true;
-                    for (u32 i = 0; i < T; i++) {
-                        if (alive && i != i_src) {
-                            // what the positions from i on can still add (the candidate's own term is already in `known`)
-                            const float rem = s_psfx[q * (T + 1u) + i] - (i < i_src ? ub_src : 0.f);
-                            if (__fmul_rn(__fadd_rn(known, rem), SA_ST_MARGIN) < thr_f) alive = false;
-                            else {
-                                const u32 u = s_pu[qb + i];
-                                if (u != SA_ST_NONE) {
-                                    bool found;
-                                    const float f = sa_st_lookup(s_post, s_off[u], d4, found);
-                                    if (found) {
-                                        if (i < i_src) alive = false;    // the doc is the candidate of that (essential, higher) position
-                                        else known = __fadd_rn(known, __fmul_rn(f, s_pw[qb + i]));
+                    const u32 thr = s_thr[q];
+                    const float thr_f = __uint_as_float(thr);
+                    const u32 u_src = s_pu[qb + i_src];
+                    const u32 pk_src = s_off[u_src];
+                    u32 d4; float f_src;
+                    if ((pk_src & 0xFFFFu) == SA_ST_DENSE) {
+                        f_src = sf[(pk_src >> 16) * 2u + pass_o + j];
+                        d4 = (u32)(d_s + j) << 2;
+                    } else {
+                        const u64 v = s_post[(pk_src >> 16) + j];
+                        d4 = (u32)(v >> 32); f_src = __uint_as_float((u32)v);
+                    }
+                    const u32 o_doc = (d4 >> 2) - (u32)tile_d0;
+                    const float w_src = s_pw[qb + i_src];
+                    float known = __fmul_rn(f_src, w_src);
+                    const float ub_src = __fmul_rn(__uint_as_float(s_tmax[u_src]), w_src);
+                    bool alive = f_src != 0.f;                      // (a doc of the tile the dense row's term does not hold)
+                    float xs[TMAX];                                 // the terms' contributions, by position
+#pragma unroll
+                    for (int i = 0; i < TMAX; i++) {
+                        xs[i] = 0.f;
+                        if ((u32)i < T) {
+                            if ((u32)i == i_src) xs[i] = known;
+                            else if (alive) {
+                                // what the positions from i on can still add (the candidate's own term is already in `known`)
+                                const float rem = s_psfx[q * (T + 1u) + (u32)i] - ((u32)i < i_src ? ub_src : 0.f);
+                                if (__fmul_rn(__fadd_rn(known, rem), SA_ST_MARGIN) < thr_f) alive = false;
+                                else {
+                                    const u32 u = s_pu[qb + (u32)i];
+                                    if (u != SA_ST_NONE) {
+                                        const u32 pk = s_off[u];
+                                        float f; bool found;
+                                        if ((pk & 0xFFFFu) == SA_ST_DENSE) { f = sf[(pk >> 16) * 2u + o_doc]; found = f != 0.f; }
+                                        else f = sa_st_lookup(s_post, pk, d4, found);
+                                        if (found) {
+                                            if ((u32)i < i_src) alive = false;   // the doc is the candidate of that (essential, higher) position
+                                            else { xs[i] = __fmul_rn(f, s_pw[qb + (u32)i]); known = __fadd_rn(known, xs[i]); }
+                                        }
                                     }
                                 }
                             }
                         }
                     }
                     if (alive && __fmul_rn(known, SA_ST_MARGIN) >= thr_f) {
-                        // the exact score: factor * weight per term, summed in QUERY-TERM order (bm25.pyx:19-23, np.sum over the terms)
+                        // the exact score: factor * weight per term (held in xs), summed in QUERY-TERM order (bm25.pyx:19-23, np.sum over the terms)
                         const u32 inv = sp.inv[q];
                         float S = 0.f;
-                        for (u32 s = 0; s < T; s++) {
-                            const u32 i = (inv >> (4u * s)) & 15u;
-                            const u32 u = s_pu[qb + i];
-                            float xs = 0.f;
-                            if (u != SA_ST_NONE) { bool found; xs = __fmul_rn(sa_st_lookup(s_post, s_off[u], d4, found), s_pw[qb + i]); }
-                            S = __fadd_rn(S, xs);
+#pragma unroll
+                        for (int s = 0; s < TMAX; s++) {
+                            if ((u32)s < T) {
+                                const u32 pos = (inv >> (4u * (u32)s)) & 15u;
+                                float x = 0.f;
+#pragma unroll
+                                for (int i = 0; i < TMAX; i++) x = pos == (u32)i ? xs[i] : x;
+                                S = __fadd_rn(S, x);
+                            }
                         }
                         const u32 sb = __float_as_uint(S);
-                        if (sb >= s_thr[q]) {
+                        if (sb >= thr) {
                             const u64 doc = sp.doc_base + (u64)(d4 >> 2);
                             const u32 pos = atomicAdd(&sp.cand_cnt[q], 1u);
                             if (pos < sp.cand_cap) sp.cand[(u64)q * sp.cand_cap + pos] = ((u64)sb << 32) | (u64)(u32)(~(u32)doc);
@@ -493,10 +693,14 @@ __global__ void __launch_bounds__(SA_ST_NT) sa_k_bm25_stage(const StageParams sp
                         }
                     }
                 }
+                SA_SPT(9);
+                __syncthreads();
+                if (tid == 0) s_wlcnt = 0u;
+                if (reserved <= (u32)NCH) break;                // (uniform: nobody was cut short)
                 __syncthreads();
             }
+            SA_SPT(10);
             // bounds re-derived for the queries whose candidate list crossed a multiple of 32 entries
-            __syncthreads();
             const u32 nref = s_nref < (u32)SA_ST_REF ? s_nref : (u32)SA_ST_REF;
             if (nref) {                                         // (uniform)
                 for (u32 r = wave; r < nref; r += NW) {
@@ -509,25 +713,37 @@ __global__ void __launch_bounds__(SA_ST_NT) sa_k_bm25_stage(const StageParams sp
 #pragma unroll
             for (int kx = 0; kx < KT; kx++) lo[kx] = hi[kx];
             d_s = d_e;
+#ifdef SA_PROBE
+            ptiles++;
+#endif
         }
     }
+#ifdef SA_PROBE
+    SA_SPT(11);
+    if (tid == 0) {
+        for (int i = 0; i < 12; i++) atomicAdd(&g_sa_stage_probe[i], pacc[i]);
+        atomicAdd(&g_sa_stage_probe[12], (unsigned long long)ptiles);
+        atomicAdd(&g_sa_stage_probe[13], (unsigned long long)pcand);
+        atomicAdd(&g_sa_stage_probe[14], 1ull);
+    }
+#endif
 }
 
 int sa_launch_stage(sa_batch* bt, const Bm25Params& p, hipStream_t st) {
     sa_index* ix = bt->ix;
-    if (!bt->stage_ok || !bt->st_dir || !p.hist || !p.gthr || !p.imp) { sa_set_error("staged route: no plan"); return SA_ERR_STATE; }
+    if (!bt->stage_ok || !bt->st_dir || !bt->impacts || !p.hist || !p.gthr || !p.imp) { sa_set_error("staged route: no plan"); return SA_ERR_STATE; }
     const StLayout L = sa_stage_layout(bt->B, bt->T);
     StageParams sp;
     memset(&sp, 0, sizeof(sp));
-    sp.imp = p.imp;
-    sp.dir = bt->st_dir->d_dir; sp.dir_stride = bt->st_dir->n_st + 1u;
+    sp.imp = p.imp; sp.cell_base = bt->st_cell_base;
+    sp.abs = bt->st_dir->d_abs; sp.cm = bt->st_dir->d_cm;
     sp.docs = bt->st_docs; sp.n_st = bt->st_dir->n_st;
     sp.n_docs = ix->n_docs; sp.doc_base = ix->doc_base;
-    sp.terms = (const StTerm*)(bt->d_st + L.terms); sp.U = bt->st_U;
-    sp.cb[0] = bt->st_cb[0]; sp.cb[1] = bt->st_cb[1]; sp.cb[2] = bt->st_cb[2];
+    sp.terms = (const StTerm*)(bt->d_st + L.terms); sp.U = bt->st_U; sp.ND = bt->st_ND;
+    sp.dense = bt->impacts->d_dense; sp.dense_stride = bt->impacts->dense_stride;
     sp.B = bt->B; sp.T = bt->T; sp.k = bt->k;
     sp.pu = (const unsigned short*)(bt->d_st + L.pu);
-    sp.pw = (const float*)(bt->d_st + L.pw); sp.pub = (const float*)(bt->d_st + L.pub); sp.psfx = (const float*)(bt->d_st + L.psfx);
+    sp.pw = (const float*)(bt->d_st + L.pw);
     sp.inv = (const u32*)(bt->d_st + L.inv);
     sp.seed = p.seed;
     sp.gthr = p.gthr; sp.hist = p.hist;
