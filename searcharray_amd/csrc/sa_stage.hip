@@ -54,7 +54,7 @@
 #define SA_ST_MARGIN 1.0000153f // 1 + 2^-16: covers the fp32 roundings of a sum of up to 8 non-negative terms taken in another order
 
 // 8-byte cells an LDS stage holds (TMAX = 4: the BASELINE shape; 8: wider query tables, smaller stage); two workgroups per CU
-template <int TMAX> struct SaStCap { static constexpr int v = TMAX <= 4 ? 6400 : 5248; };
+template <int TMAX> struct SaStCap { static constexpr int v = TMAX <= 4 ? 6144 : 5120; };
 
 struct alignas(16) StTerm {
     u64 cell0;                  // first cell of the term in the impact stream
@@ -67,7 +67,8 @@ struct alignas(16) StTerm {
 
 struct StageParams {
     const u64* imp;
-    u64 cell_base;                        // smallest cell0 of the set's terms: the kernel addresses the stream with 32-bit offsets from it
+    u64 cell_base;                        // smallest cell0 of the set's terms: the kernel addresses the stream with 32-bit BYTE offsets from it
+    u32 imp_bytes, cm_bytes, dense_bytes; // sizes of the three buffers the kernel reads through buffer resources (a read past the end returns 0)
     const u32* abs; const u32* cm;        // stage directory (sa_stagedir): [rows][n_st + 1], [rows][n_st]
     u32 docs, n_st;                       // docs per stage tile, tiles
     u64 n_docs, doc_base;
@@ -208,30 +209,33 @@ int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* ro
         return a.df > c.df || (a.df == c.df && a.term < c.term);
     });
     const u32 U = (u32)dist.size();
-    u32 ND = 0;
-    while (ND < U && ND < (u32)SA_ST_NDMAX && dist[ND].dense != 0xFFFFFFFFu) ND++;
-    for (u32 u = ND; u < U; u++) dist[u].dense = 0xFFFFFFFFu;            // (more dense rows than the stage takes: the rest as postings)
-    std::sort(dist.begin() + ND, dist.end(), [](const DT& a, const DT& c) { return a.df > c.df || (a.df == c.df && a.term < c.term); });
-    u64 dfsum = 0;
-    for (u32 u = 0; u < U; u++) { idx[dist[u].term] = u; if (u >= ND) dfsum += dist[u].df; }
+    u32 ND0 = 0;
+    while (ND0 < U && ND0 < (u32)SA_ST_NDMAX && dist[ND0].dense != 0xFFFFFFFFu) ND0++;
     // docs per stage tile: the largest of the sizes below whose expected cells -- half a cell per doc and dense row, one per posting
-    // of the other terms -- fit the stage with room for the tiles above the mean
+    // of the other terms -- fit the stage with room for the tiles above the mean.  A tile's dense rows are at most 1024 pieces of
+    // 16 bytes (two per thread): the least frequent of the dense-row terms are staged as postings where a tile is bigger.
     const u32 tmax = T <= 4 ? 4u : 8u;
     const double cap = tmax == 4 ? (double)SaStCap<4>::v : (double)SaStCap<8>::v;
-    const double per_doc = (double)dfsum / (double)ix->n_docs;
+    auto nd_for = [&](u32 s) { return std::min<u32>(ND0, 4096u / s); };
+    auto fits = [&](u32 s) {
+        const u32 nd = nd_for(s);
+        double per_doc = 0.0;
+        for (u32 u = nd; u < U; u++) per_doc += (double)dist[u].df;
+        per_doc /= (double)ix->n_docs;
+        return 0.5 * nd * s + per_doc * s + 4.0 * sqrt(per_doc * s) <= 0.97 * cap;
+    };
     u32 docs = 0;
     if (sa_opt_is_set(bt->opts.stage_docs)) docs = (u32)std::min<long long>(1024, std::max<long long>(64, bt->opts.stage_docs)) / 64u * 64u;
     else {
         static const u32 sizes[] = {1024, 768, 512, 384, 256, 192, 128, 64};
-        for (u32 s : sizes) if (0.5 * ND * s + per_doc * s + 4.0 * sqrt(per_doc * s) <= 0.97 * cap) { docs = s; break; }
+        for (u32 s : sizes) if (fits(s)) { docs = s; break; }
         if (!docs) return SA_OK;                          // (more than ~70 postings per doc over the set's terms: not this route)
     }
-    if ((u64)ND * docs / 2u + SA_ST_UMAX > (u64)cap) {     // (forced tile size: fewer dense rows)
-        ND = 0;
-        for (u32 u = 0; u < U; u++) dist[u].dense = 0xFFFFFFFFu;
-        std::sort(dist.begin(), dist.end(), [](const DT& a, const DT& c) { return a.df > c.df || (a.df == c.df && a.term < c.term); });
-        for (u32 u = 0; u < U; u++) idx[dist[u].term] = u;
-    }
+    u32 ND = nd_for(docs);
+    if ((u64)ND * docs / 2u + SA_ST_UMAX > (u64)cap) ND = 0;          // (a forced tile size the dense rows do not fit)
+    for (u32 u = ND; u < U; u++) dist[u].dense = 0xFFFFFFFFu;            // (the others as postings, most frequent first)
+    std::sort(dist.begin() + ND, dist.end(), [](const DT& a, const DT& c) { return a.df > c.df || (a.df == c.df && a.term < c.term); });
+    for (u32 u = 0; u < U; u++) idx[dist[u].term] = u;
     std::shared_ptr<sa_stagedir> sd = sa_stagedir_get(ix, im, docs);
     if (!sd) return SA_OK;
     // the kernel addresses the stream with 32-bit offsets from the set's first term
@@ -249,7 +253,8 @@ int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* ro
         cell_lo = std::min<u64>(cell_lo, x.cell0);
         cell_hi = std::max<u64>(cell_hi, x.cell0 + (u64)x.df + 4ull);
     }
-    if (cell_hi - cell_lo >= 0xFFFFFFF0ull) return SA_OK;
+    if ((u64)sd->n_rows * sd->n_st >= (1ull << 30) || (im->d_dense && (u64)im->n_dense * im->dense_stride >= (1ull << 30))) return SA_OK;
+    if (cell_hi - cell_lo >= (1ull << 29)) return SA_OK;              // (32-bit BYTE offsets in the kernel: shards of up to ~18 M docs of this corpus; bigger ones keep the older routes)
     // the queries: terms by descending bound (weight x largest factor in the shard), weights, starting bounds
     u32 rank_idx = SA_TOPF_NR - 1;
     for (int i = SA_TOPF_NR - 1; i >= 0; i--) if (sa_topf_ranks[i] >= bt->k) rank_idx = (u32)i;
@@ -281,6 +286,7 @@ int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* ro
     }
     bt->st_U = U; bt->st_ND = ND; bt->st_docs = docs; bt->st_tmax = tmax;
     bt->st_cell_base = cell_lo;
+    bt->st_imp_bytes = (u32)((cell_hi - cell_lo) * 8ull);
     bt->st_dir = sd;
     bt->stage_ok = true;
     return SA_OK;
@@ -351,32 +357,44 @@ extern "C" int sa_debug_stage_probe_read(unsigned long long* out16, int clear) {
 #define SA_SPT(i) do { } while (0)
 #endif
 
+typedef unsigned int sa_v2u __attribute__((vector_size(8)));
+typedef unsigned int sa_v4u __attribute__((vector_size(16)));
+struct alignas(8) StChunk { u32 dc, off; };    // a copy chunk: first stage cell | postings (1 .. 8) << 13; byte offset of its first posting from the stream base
+
 template <int TMAX>
 __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams sp) {
     constexpr int CAP = SaStCap<TMAX>::v;
     constexpr int NT = SA_ST_NT, NW = NT / SA_WAVE, KT = (SA_ST_UMAX + NT - 1) / NT;
-    constexpr int NCH = CAP / 8 + SA_ST_UMAX;                    // 8-posting chunks a stage can hold at most; also the work list's cells
+    constexpr int NCH = CAP / 8 + SA_ST_UMAX;                    // 8-posting chunks a stage can hold at most
+    constexpr int NWL = 2 * NCH;                                 // work-list records that fit the chunk list's cells
     constexpr int KB = 10;                                       // chunk loads a lane issues before it waits
     constexpr int KD = 2;                                        // 16-byte loads of the dense rows a lane issues before it waits
+    static_assert(KT == 2, "two terms per thread");
     static_assert(SA_ST_UMAX <= CAP, "a single document's postings must fit the stage");
-    static_assert(CAP <= 65535 && SA_ST_UMAX <= 1024, "16-bit stage offsets, 10-bit term index in a chunk descriptor");
+    static_assert(CAP <= 8192 && SA_ST_UMAX <= 1024, "13-bit stage cells in a chunk descriptor");
+    static_assert(SA_ST_BMAX <= 256 && TMAX <= 8, "8-bit query, 3-bit position in a work-list record");
     __shared__ alignas(16) u64 s_post[CAP];                      // the stage: dense rows (fp32 per doc of the tile), then every other term's slice, doc-sorted
     __shared__ u32 s_off[SA_ST_UMAX];                           // per distinct term: first cell << 16 | postings (SA_ST_DENSE: a dense row)
-    __shared__ u32 s_src[SA_ST_UMAX];                           // its first posting's cell in the stream, relative to sp.cell_base
     __shared__ u32 s_tmax[SA_ST_UMAX];                          // bound (fp32 pattern) of its factors in this tile
-    __shared__ u32 s_cw[NCH];                                   // chunk descriptors of the copy (term | chunk << 10), then the candidate work list
-    __shared__ unsigned short s_pu[SA_ST_BMAX * TMAX];          // [query][position]: distinct-term index
-    __shared__ float s_pw[SA_ST_BMAX * TMAX];                   //   its weight
-    __shared__ float s_psfx[SA_ST_BMAX * (TMAX + 1)];           //   what the positions >= i can add in THIS tile (with the margin)
+    __shared__ StChunk s_cd[NCH];                               // the copy's chunk list; then the candidate work list (u32 records)
+    __shared__ unsigned short s_pu[SA_ST_BMAX * TMAX];          // [query][position]: distinct-term index (SA_ST_NONE: no term)
+    __shared__ alignas(16) float s_pw[SA_ST_BMAX * TMAX];       //   its weight
+    __shared__ alignas(16) float s_psfx[SA_ST_BMAX * TMAX];     //   what the positions >= i can add in THIS tile (with the margin)
     __shared__ u32 s_thr[SA_ST_BMAX];
     __shared__ u32 s_ref[SA_ST_REF];
-    __shared__ u32 s_dsl[SA_ST_NDMAX];
     __shared__ u32 s_nref, s_wlcnt;
     __shared__ u32 s_red[4 * NW];
     const u32 tid = threadIdx.x, lane = tid & (SA_WAVE - 1), wave = tid / SA_WAVE;
     const u32 T = sp.T, B = sp.B, U = sp.U, ND = sp.ND;
-    const u64* const imp0 = sp.imp + sp.cell_base;
+    // The stream, the cm words and the dense rows are read through BUFFER RESOURCES: a scalar base + a 32-bit byte offset per lane
+    // (no 64-bit address arithmetic, no address register pairs), and a lane without an item passes an offset past the end and reads 0.
+    const __amdgpu_buffer_rsrc_t r_imp = __builtin_amdgcn_make_buffer_rsrc((void*)(sp.imp + sp.cell_base), 0, (int)sp.imp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_cm = __builtin_amdgcn_make_buffer_rsrc((void*)sp.cm, 0, (int)sp.cm_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_dense = __builtin_amdgcn_make_buffer_rsrc((void*)(sp.dense ? (const void*)sp.dense : (const void*)sp.imp), 0, (int)sp.dense_bytes, 0x00020000);
+    auto cell_at = [&](u32 boff) -> u64 { const sa_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r_imp, boff, 0, 0); return ((u64)v[1] << 32) | (u64)v[0]; };
+    auto key_at = [&](u32 boff) -> u32 { return __builtin_amdgcn_raw_buffer_load_b32(r_imp, boff + 4u, 0, 0); };      // (the doc key of a cell: its high word)
     const float* const sf = (const float*)s_post;
+    u32* const s_wl = (u32*)s_cd;
     const u32 dense_cells = ND * (sp.docs >> 1);                 // cells the dense rows take at the front of the stage
 #ifdef SA_PROBE
     u64 pacc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -393,39 +411,59 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
     if (t_end > sp.n_st) t_end = sp.n_st;
     if (t_begin >= t_end) return;                               // (uniform)
 
-    // the queries' tables, once per workgroup
-    for (u32 i = tid; i < B * T; i += NT) { s_pu[i] = sp.pu[i]; s_pw[i] = sp.pw[i]; }
-    if (tid < ND) s_dsl[tid] = sp.terms[tid].dense;
+    // the queries' tables, once per workgroup, padded to TMAX positions (a position without a term adds nothing)
+    for (u32 i = tid; i < B * (u32)TMAX; i += NT) {
+        const u32 q = i / (u32)TMAX, c = i % (u32)TMAX;
+        s_pu[i] = c < T ? sp.pu[q * T + c] : (unsigned short)SA_ST_NONE;
+        s_pw[i] = c < T ? sp.pw[q * T + c] : 0.f;
+    }
     if (tid == 0) { s_nref = 0u; s_wlcnt = 0u; }
     const bool hasq = tid < B;
     const u32 seed = (hasq && sp.seed) ? sp.seed[tid] : 0u;
     u32 g_raw = 0u;
     u32 parity = 0;
-    // this thread's terms.  lo: first posting not yet staged.  A term with a directory row: nx = its cm word (postings | bound of
-    // the factors) of the NEXT tile to take, read one tile ahead.  A term without one is WALKED: w0, w1 = doc keys of the
-    // postings at lo and lo + 1 (read one tile ahead too; the sentinel behind a term's postings has the doc field all ones: a
-    // walk stops there); its bound is its largest factor in the shard.
-    u32 src0[KT], row[KT], lo[KT], nx[KT], w1[KT];              // (nx: the cm word of a term with a row, the doc key at lo of a walked term)
-    auto key_at = [&](u32 cell) -> u32 { return ((const u32*)imp0)[2ull * cell + 1ull]; };      // (the doc key of a cell: its high word, a 4-byte load)
+    // This thread's two terms (u = tid, tid + NT).  lo: first posting not yet staged.  A term with a directory row: nx = its cm
+    // word (postings | bound of the factors) of the NEXT tile to take, read one tile ahead through pcm.  A term without one is
+    // WALKED: nx, w1 = doc keys of the postings at lo and lo + 1 (read one tile ahead too; the sentinel behind a term's
+    // postings has the doc field all ones: a walk stops there); its bound is its largest factor in the shard.  A thread
+    // without a term walks a sentinel: nothing ever comes of it.
+    u32 src0[KT], lo[KT], nx[KT], w1[KT];
+    u32 cmi[KT];                                               // index of the term's cm word of the next tile to take
+    bool rowed[KT];
 #pragma unroll
     for (int kx = 0; kx < KT; kx++) {
         const u32 u = tid + (u32)kx * NT;
-        src0[kx] = 0; row[kx] = SA_ST_NOROW; lo[kx] = 0; nx[kx] = 0xFFFFFFFFu; w1[kx] = 0xFFFFFFFFu;
+        const StTerm t0 = sp.terms[0];
+        src0[kx] = (u32)(t0.cell0 - sp.cell_base) + t0.df;      // (term 0's sentinel)
+        lo[kx] = 0; nx[kx] = 0xFFFFFFFFu; w1[kx] = 0xFFFFFFFFu; rowed[kx] = false; cmi[kx] = 0u;
         if (u < U) {
             const StTerm t = sp.terms[u];
-            src0[kx] = (u32)(t.cell0 - sp.cell_base); row[kx] = t.row;
+            src0[kx] = (u32)(t.cell0 - sp.cell_base);
             s_tmax[u] = t.maxf;                                 // (a walked term keeps this bound; a term with a row gets its tile's)
+            if (u < ND) s_off[u] = ((u * (sp.docs >> 1)) << 16) | SA_ST_DENSE;
             if (t.row != SA_ST_NOROW) {
+                rowed[kx] = true;
                 lo[kx] = sp.abs[(u64)t.row * (sp.n_st + 1u) + t_begin];
-                nx[kx] = sp.cm[(u64)t.row * sp.n_st + t_begin];
+                cmi[kx] = t.row * sp.n_st + t_begin;
+                nx[kx] = __builtin_amdgcn_raw_buffer_load_b32(r_cm, cmi[kx] << 2, 0, 0);
             } else {
                 const u32 key = (u32)((u64)t_begin * sp.docs) << 2;
                 u32 a = 0, b = t.df;
-                while (a < b) { const u32 mid = a + ((b - a) >> 1); if (key_at(src0[kx] + mid) < key) a = mid + 1u; else b = mid; }
+                while (a < b) { const u32 mid = a + ((b - a) >> 1); if (key_at((src0[kx] + mid) << 3) < key) a = mid + 1u; else b = mid; }
                 lo[kx] = a;
-                nx[kx] = key_at(src0[kx] + a); w1[kx] = key_at(src0[kx] + a + 1u);
+                nx[kx] = key_at((src0[kx] + a) << 3); w1[kx] = key_at((src0[kx] + a + 1u) << 3);
             }
         }
+    }
+    // dense rows: this thread's two 16-byte pieces of a tile's rows (which row, where in it: the same for every tile)
+    const u32 d4n = sp.docs >> 2, n_d4 = ND * d4n;
+    u32 dro[KD];                                                // float index of the piece in the dense rows, relative to the tile's first doc
+#pragma unroll
+    for (int i = 0; i < KD; i++) {
+        const u32 y = (u32)i * NT + tid;
+        const u32 yy = y < n_d4 ? y : 0u;
+        const u32 r = yy / (d4n ? d4n : 1u), c = yy - r * d4n;
+        dro[i] = (ND ? sp.terms[r].dense * (u32)sp.dense_stride : 0u) + 4u * c;
     }
     __syncthreads();
 
@@ -433,56 +471,54 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
         const u64 tile_d0 = (u64)tile * sp.docs;
         const u64 tile_d1 = tile_d0 + sp.docs < sp.n_docs ? tile_d0 + sp.docs : sp.n_docs;
         SA_SPT(11);
-        // end of every term's slice of this tile and the bound of its factors there, from what was read a tile ago
-        u32 hi_t[KT], tm[KT];
+        // postings of this thread's terms in this tile and the bound of their factors there, from what was read a tile ago
+        u32 n_t[KT], tm[KT];
         {
             const u32 key = (u32)tile_d1 << 2;
 #pragma unroll
             for (int kx = 0; kx < KT; kx++) {
-                const u32 u = tid + (u32)kx * NT;
-                const bool have = u < U, rowed = have && row[kx] != SA_ST_NOROW, walked = have && !rowed;
                 const u32 cmw = nx[kx];
-                u32 c = lo[kx];
-                if (walked && cmw < key) {
-                    c++;
-                    if (w1[kx] < key) { c++; while (key_at(src0[kx] + c) < key) c++; }     // (three postings of a rare term in one tile: hardly ever)
+                u32 nw = 0;
+                if (!rowed[kx] && cmw < key) {
+                    nw = 1;
+                    if (w1[kx] < key) { nw = 2; while (key_at((src0[kx] + lo[kx] + nw) << 3) < key) nw++; }   // (three postings of a rare term in one tile: hardly ever)
                 }
-                hi_t[kx] = rowed ? (u >= ND ? lo[kx] + (cmw & 0xFFFFu) : lo[kx]) : c;
+                n_t[kx] = rowed[kx] ? cmw & 0xFFFFu : nw;
                 tm[kx] = cmw & 0xFFFF0000u;
             }
+            if (tid < ND) n_t[0] = 0u;                            // (a dense row is not staged as postings; dense terms are the first ND)
+        }
+        if (tile + 1u < t_end) {                                  // (uniform) the cm words the passes below read are the next tile's
+#pragma unroll
+            for (int kx = 0; kx < KT; kx++) cmi[kx] += rowed[kx] ? 1u : 0u;
         }
         // the queries' bounds (a bound only ever rises: a stale one is valid), read a tile ago
         const u32 g_now = g_raw > seed ? g_raw : seed;
         // A tile whose postings do not fit the stage is taken in doc sub-ranges: halve the range until it fits (a single
         // document holds at most U <= CAP - dense rows postings), the slices' ends by a search of the posting lists.
         u64 d_s = tile_d0;
+        u32 used[KT] = {0u, 0u};                                // postings of the tile already staged by earlier passes
         while (d_s < tile_d1) {                                 // (uniform)
             u64 d_e = tile_d1;
-            u32 hi[KT];
+            u32 n[KT];
 #pragma unroll
-            for (int kx = 0; kx < KT; kx++) hi[kx] = hi_t[kx];
+            for (int kx = 0; kx < KT; kx++) n[kx] = n_t[kx] - used[kx];
             u32 excl, exch, P, NC;
-            {
-                u32 mine = 0, mch = 0;
-#pragma unroll
-                for (int kx = 0; kx < KT; kx++) { mine += hi[kx] - lo[kx]; mch += (hi[kx] - lo[kx] + 7u) >> 3; }
-                sa_block_excl_scan2<NW>(mine, mch, s_red, parity, excl, exch, P, NC);
-                parity ^= 1u;
-            }
+            sa_block_excl_scan2<NW>(n[0] + n[1], ((n[0] + 7u) >> 3) + ((n[1] + 7u) >> 3), s_red, parity, excl, exch, P, NC);
+            parity ^= 1u;
             // (the rare case apart from the common path: a loop with loads in it makes the compiler wait for every load in flight at its head)
             if (P + dense_cells > (u32)CAP && d_e - d_s > 1ull) {
                 do {
                     d_e = d_s + ((d_e - d_s) >> 1);
                     const u32 key = (u32)d_e << 2;
-                    u32 mine = 0, mch = 0;
 #pragma unroll
                     for (int kx = 0; kx < KT; kx++) {
-                        u32 a = lo[kx], b = hi[kx];
-                        while (a < b) { const u32 mid = a + ((b - a) >> 1); if (key_at(src0[kx] + mid) < key) a = mid + 1u; else b = mid; }
-                        hi[kx] = a;
-                        mine += hi[kx] - lo[kx]; mch += (hi[kx] - lo[kx] + 7u) >> 3;
+                        u32 a = 0, b = n[kx];
+                        const u32 first = src0[kx] + lo[kx];
+                        while (a < b) { const u32 mid = a + ((b - a) >> 1); if (key_at((first + mid) << 3) < key) a = mid + 1u; else b = mid; }
+                        n[kx] = a;
                     }
-                    sa_block_excl_scan2<NW>(mine, mch, s_red, parity, excl, exch, P, NC);
+                    sa_block_excl_scan2<NW>(n[0] + n[1], ((n[0] + 7u) >> 3) + ((n[1] + 7u) >> 3), s_red, parity, excl, exch, P, NC);
                     parity ^= 1u;
                 } while (P + dense_cells > (u32)CAP && d_e - d_s > 1ull);
             }
@@ -493,14 +529,17 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
 #pragma unroll
                 for (int kx = 0; kx < KT; kx++) {
                     const u32 u = tid + (u32)kx * NT;
-                    if (u < U) {
-                        if (row[kx] != SA_ST_NOROW) s_tmax[u] = tm[kx];
-                        if (u < ND) s_off[u] = ((u * (sp.docs >> 1)) << 16) | SA_ST_DENSE;
-                        else {
-                            const u32 n = hi[kx] - lo[kx], nch = (n + 7u) >> 3;
-                            s_off[u] = (o << 16) | n; s_src[u] = src0[kx] + lo[kx];
-                            for (u32 ci = 0; ci < nch; ci++) s_cw[oc + ci] = u | (ci << 10);
-                            o += n; oc += nch;
+                    if (kx == 0 || u < U) {
+                        if (rowed[kx]) s_tmax[u] = tm[kx];
+                        if (kx != 0 || u >= ND) {
+                            s_off[u] = (o << 16) | n[kx];
+                            u32 boff = (src0[kx] + lo[kx]) << 3;
+                            for (u32 left = n[kx]; left; ) {
+                                const u32 c = left < 8u ? left : 8u;
+                                StChunk d; d.dc = o | (c << 13); d.off = boff;
+                                s_cd[oc] = d;
+                                o += c; oc++; boff += 64u; left -= c;
+                            }
                         }
                     }
                 }
@@ -514,58 +553,48 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
             //      front of the stage's loads, so that they have landed when those have -- the loops further down contain
             //      (rare) loads, and at the head of such a loop the compiler waits for every load in flight.
             {
-                const u32 tnext = tile + 1u < t_end ? tile + 1u : tile;
 #pragma unroll
                 for (int kx = 0; kx < KT; kx++) {
-                    const u32 u = tid + (u32)kx * NT;
-                    const bool have = u < U, rowed = have && row[kx] != SA_ST_NOROW, walked = have && !rowed;
-                    const u32 wc = walked ? src0[kx] + hi_t[kx] : 0u;
-                    const u32* const a0 = rowed ? sp.cm + ((u64)row[kx] * sp.n_st + tnext) : (const u32*)imp0 + (2ull * wc + 1ull);
-                    nx[kx] = *a0; w1[kx] = key_at(wc + 1u);
+                    const u32 kb = (src0[kx] + lo[kx] + (n_t[kx] - used[kx])) << 3;     // (the cell behind the tile's last posting, whatever the pass)
+                    const u32 c0 = __builtin_amdgcn_raw_buffer_load_b32(r_cm, cmi[kx] << 2, 0, 0), k0 = key_at(kb);
+                    nx[kx] = rowed[kx] ? c0 : k0;
+                    w1[kx] = key_at(kb + 8u);
                 }
                 g_raw = __hip_atomic_load(&sp.gthr[hasq ? tid : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             // ---- stage.  Dense rows: the tile's docs of each row, 16 bytes per lane.  Postings: eight lanes per chunk.  A lane
-            //      issues all its loads (KD + KB) before it waits for the first.
+            //      issues all its loads (KD + KB) before it waits for the first; a lane without an item reads cell 0 and writes nothing.
             {
                 const u32 grp = tid >> 3, sub = tid & 7u;
-                const u32 d4n = sp.docs >> 2, n_d4 = ND * d4n;           // float4 per row, in all
                 float4* const s4 = (float4*)s_post;
-                const float* const dbase = ND ? sp.dense : (const float*)sp.imp;       // (no dense rows: nobody uses what is read)
-                u32 y0 = 0, x0 = 0;
-                do {                                                    // (uniform)
-                    float4 dv[KD];
-                    u64 v[KB]; u32 dst2[KB / 2];                       // (two 16-bit stage cells per register; 0xFFFF: nothing to write)
-                    // (unconditional loads: a lane without an item reads cell 0 and writes nothing)
+                // dense rows (KD pieces per lane cover ND * docs / 4 <= KD * NT pieces: the plan sees to it; a piece past the rows' end reads 0)
+                float4 dv[KD];
 #pragma unroll
-                    for (int i = 0; i < KD; i++) {
-                        const u32 y = y0 + (u32)i * NT + tid;
-                        const bool have = y < n_d4;
-                        const u32 yy = have ? y : 0u;
-                        const u32 r = yy / d4n, c = yy - r * d4n;
-                        const u64 doc0 = tile_d0 + 4ull * c;
-                        const bool in = have && doc0 + 4ull <= sp.dense_stride;
-                        const float4 x4 = *(const float4*)(dbase + (in ? (u64)s_dsl[r] * sp.dense_stride + doc0 : 0ull));
-                        dv[i] = in ? x4 : make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
+                for (int i = 0; i < KD; i++) {
+                    const bool in = (u32)i * NT + tid < n_d4 && tile_d0 + (dro[i] % (u32)sp.dense_stride) + 4ull <= sp.dense_stride;
+                    const sa_v4u x4 = __builtin_amdgcn_raw_buffer_load_b128(r_dense, in ? (dro[i] + (u32)tile_d0) << 2 : 0xFFFFFFF0u, 0, 0);
+                    dv[i] = make_float4(__uint_as_float(x4[0]), __uint_as_float(x4[1]), __uint_as_float(x4[2]), __uint_as_float(x4[3]));
+                }
+                u32 x0 = 0;
+                do {                                                    // (uniform: one round unless the tile has more than KB * 64 chunks)
+                    u64 v[KB]; u32 dst[KB];
 #pragma unroll
                     for (int i = 0; i < KB; i++) {
                         const u32 x = x0 + (u32)i * (NT / 8) + grp;
-                        const u32 d = s_cw[x < NC ? x : 0u];
-                        const u32 u = d & 1023u, j = (d >> 10) * 8u + sub;
-                        const u32 pk = s_off[u];
-                        const bool ok = x < NC && j < (pk & 0xFFFFu);
-                        const u32 dd = ok ? (pk >> 16) + j : 0xFFFFu;
-                        if (i & 1) dst2[i / 2] |= dd << 16; else dst2[i / 2] = dd;
-                        v[i] = imp0[ok ? s_src[u] + j : 0u];
+                        const StChunk d = s_cd[x < NC ? x : 0u];
+                        const bool ok = x < NC && sub < (d.dc >> 13);
+                        dst[i] = ok ? (d.dc & 0x1FFFu) + sub : 0xFFFFFFFFu;
+                        v[i] = cell_at(ok ? d.off + (sub << 3) : 0xFFFFFFF0u);
+                    }
+                    if (x0 == 0) {
+#pragma unroll
+                        for (int i = 0; i < KD; i++) { const u32 y = (u32)i * NT + tid; if (y < n_d4) s4[y] = dv[i]; }
                     }
                     SA_SPT(3);
 #pragma unroll
-                    for (int i = 0; i < KD; i++) { const u32 y = y0 + (u32)i * NT + tid; if (y < n_d4) s4[y] = dv[i]; }
-#pragma unroll
-                    for (int i = 0; i < KB; i++) { const u32 dd = (dst2[i / 2] >> (16 * (i & 1))) & 0xFFFFu; if (dd != 0xFFFFu) s_post[dd] = v[i]; }
-                    y0 += (u32)KD * NT; x0 += (u32)(KB * (NT / 8));
-                } while (y0 < n_d4 || x0 < NC);
+                    for (int i = 0; i < KB; i++) if (dst[i] != 0xFFFFFFFFu) s_post[dst[i]] = v[i];
+                    x0 += (u32)(KB * (NT / 8));
+                } while (x0 < NC);
             }
             SA_SPT(4);
             __syncthreads();
@@ -573,59 +602,65 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
             // ---- the queries: bound; what every position can add at most in THIS tile (weight x bound of the term's factors here);
             //      essential positions; their postings are the candidates, reserved in the work list with one LDS atomic
             const u32 pass_docs = (u32)(d_e - d_s), pass_o = (u32)(d_s - tile_d0);
-            auto npos = [&](u32 u) -> u32 {                         // candidates position u contributes when it is essential
-                if (u == SA_ST_NONE) return 0u;
-                const u32 n = s_off[u] & 0xFFFFu;
-                return n == SA_ST_DENSE ? pass_docs : n;
-            };
-            u32 ncand = 0, ness = 0, done = 0;
+            u32 cum[TMAX];                                          // candidates of the essential positions <= i (this thread's query)
+            u32 ncand = 0, done = 0;
             if (hasq) {
                 const u32 thr = g_now > 1u ? g_now : 1u;
                 const float thr_f = __uint_as_float(thr);
-                float sfx = 0.f;
-                s_psfx[tid * (T + 1u) + T] = 0.f;
-                for (u32 ii = 0; ii < T; ii++) {
-                    const u32 i = T - 1u - ii;
-                    const u32 u = s_pu[tid * T + i];
-                    if (u != SA_ST_NONE) sfx = __fadd_rn(sfx, __fmul_rn(__uint_as_float(s_tmax[u]), s_pw[tid * T + i]));
-                    const float sm = __fmul_rn(sfx, SA_ST_MARGIN);
-                    s_psfx[tid * (T + 1u) + i] = sm;
-                    if (sm >= thr_f && ness == 0u) ness = i + 1u;
+                u32 pk[TMAX]; float ubv[TMAX];
+#pragma unroll
+                for (int i = 0; i < TMAX; i++) {
+                    const u32 u = s_pu[tid * (u32)TMAX + (u32)i];
+                    const bool have = u != SA_ST_NONE;
+                    const u32 uu = have ? u : 0u;
+                    pk[i] = have ? s_off[uu] : 0u;
+                    ubv[i] = have ? __fmul_rn(__uint_as_float(s_tmax[uu]), s_pw[tid * (u32)TMAX + (u32)i]) : 0.f;
                 }
-                for (u32 i = 0; i < ness; i++) ncand += npos(s_pu[tid * T + i]);
+                float sfx = 0.f;
+                u32 ness = 0;
+#pragma unroll
+                for (int i = TMAX - 1; i >= 0; i--) {
+                    sfx = __fadd_rn(sfx, ubv[i]);
+                    const float sm = __fmul_rn(sfx, SA_ST_MARGIN);
+                    s_psfx[tid * (u32)TMAX + (u32)i] = sm;
+                    if (sm >= thr_f && ness == 0u) ness = (u32)i + 1u;
+                }
+#pragma unroll
+                for (int i = 0; i < TMAX; i++) {
+                    const u32 nn = pk[i] & 0xFFFFu;
+                    if ((u32)i < ness) ncand += nn == SA_ST_DENSE ? pass_docs : nn;
+                    cum[i] = ncand;
+                }
                 s_thr[tid] = thr;
             }
             SA_SPT(6);
-            for (;;) {                                          // (uniform: rounds of at most NCH candidates)
-                // thread q writes the records of its next candidates: query | position << 9 | posting << 12
+            for (;;) {                                          // (uniform: rounds of at most NWL candidates)
+                // thread q writes the records of its next candidates: query | position << 8 | posting << 11
                 if (ncand > done) {
                     const u32 want = ncand - done;
                     const u32 o = atomicAdd(&s_wlcnt, want);
-                    const u32 take = o < (u32)NCH ? (want < (u32)NCH - o ? want : (u32)NCH - o) : 0u;
-                    if (take) {
-                        u32 r = done, i = 0;
-                        u32 ni = npos(s_pu[tid * T]);
-                        while (r >= ni) { r -= ni; i++; ni = npos(s_pu[tid * T + i]); }
-                        for (u32 x = 0; x < take; x++) {
-                            s_cw[o + x] = tid | (i << 9) | (r << 12);
-                            r++;
-                            while (r >= ni && x + 1u < take) { r = 0; i++; ni = npos(s_pu[tid * T + i]); }
-                        }
-                        done += take;
+                    const u32 take = o < (u32)NWL ? (want < (u32)NWL - o ? want : (u32)NWL - o) : 0u;
+                    for (u32 x = 0; x < take; x++) {
+                        const u32 r = done + x;
+                        u32 i = 0, base = 0;
+#pragma unroll
+                        for (int c = 0; c < TMAX - 1; c++) if (r >= cum[c]) { i = (u32)c + 1u; base = cum[c]; }
+                        s_wl[o + x] = tid | (i << 8) | ((r - base) << 11);
                     }
+                    done += take;
                 }
                 SA_SPT(7);
                 __syncthreads();
                 SA_SPT(8);
                 const u32 reserved = s_wlcnt;
-                const u32 nchunk = reserved < (u32)NCH ? reserved : (u32)NCH;
+                const u32 nchunk = reserved < (u32)NWL ? reserved : (u32)NWL;
 #ifdef SA_PROBE
                 pcand += nchunk;
 #endif
                 for (u32 x = tid; x < nchunk; x += NT) {
-                    const u32 rec = s_cw[x];
-                    const u32 q = rec & 0x1FFu, i_src = (rec >> 9) & 7u, j = rec >> 12;
-                    const u32 qb = q * T;
+                    const u32 rec = s_wl[x];
+                    const u32 q = rec & 0xFFu, i_src = (rec >> 8) & 7u, j = rec >> 11;
+                    const u32 qb = q * (u32)TMAX;
                     const u32 thr = s_thr[q];
                     const float thr_f = __uint_as_float(thr);
                     const u32 u_src = s_pu[qb + i_src];
@@ -647,23 +682,21 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
 #pragma unroll
                     for (int i = 0; i < TMAX; i++) {
                         xs[i] = 0.f;
-                        if ((u32)i < T) {
-                            if ((u32)i == i_src) xs[i] = known;
-                            else if (alive) {
-                                // what the positions from i on can still add (the candidate's own term is already in `known`)
-                                const float rem = s_psfx[q * (T + 1u) + (u32)i] - ((u32)i < i_src ? ub_src : 0.f);
-                                if (__fmul_rn(__fadd_rn(known, rem), SA_ST_MARGIN) < thr_f) alive = false;
-                                else {
-                                    const u32 u = s_pu[qb + (u32)i];
-                                    if (u != SA_ST_NONE) {
-                                        const u32 pk = s_off[u];
-                                        float f; bool found;
-                                        if ((pk & 0xFFFFu) == SA_ST_DENSE) { f = sf[(pk >> 16) * 2u + o_doc]; found = f != 0.f; }
-                                        else f = sa_st_lookup(s_post, pk, d4, found);
-                                        if (found) {
-                                            if ((u32)i < i_src) alive = false;   // the doc is the candidate of that (essential, higher) position
-                                            else { xs[i] = __fmul_rn(f, s_pw[qb + (u32)i]); known = __fadd_rn(known, xs[i]); }
-                                        }
+                        if ((u32)i == i_src) xs[i] = known;
+                        else if (alive) {
+                            // what the positions from i on can still add (the candidate's own term is already in `known`)
+                            const float rem = s_psfx[qb + (u32)i] - ((u32)i < i_src ? ub_src : 0.f);
+                            if (__fmul_rn(__fadd_rn(known, rem), SA_ST_MARGIN) < thr_f) alive = false;
+                            else {
+                                const u32 u = s_pu[qb + (u32)i];
+                                if (u != SA_ST_NONE) {
+                                    const u32 pk = s_off[u];
+                                    float f; bool found;
+                                    if ((pk & 0xFFFFu) == SA_ST_DENSE) { f = sf[(pk >> 16) * 2u + o_doc]; found = f != 0.f; }
+                                    else f = sa_st_lookup(s_post, pk, d4, found);
+                                    if (found) {
+                                        if ((u32)i < i_src) alive = false;   // the doc is the candidate of that (essential, higher) position
+                                        else { xs[i] = __fmul_rn(f, s_pw[qb + (u32)i]); known = __fadd_rn(known, xs[i]); }
                                     }
                                 }
                             }
@@ -675,13 +708,11 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                         float S = 0.f;
 #pragma unroll
                         for (int s = 0; s < TMAX; s++) {
-                            if ((u32)s < T) {
-                                const u32 pos = (inv >> (4u * (u32)s)) & 15u;
-                                float x = 0.f;
+                            const u32 pos = (u32)s < T ? (inv >> (4u * (u32)s)) & 15u : 15u;
+                            float x = 0.f;
 #pragma unroll
-                                for (int i = 0; i < TMAX; i++) x = pos == (u32)i ? xs[i] : x;
-                                S = __fadd_rn(S, x);
-                            }
+                            for (int i = 0; i < TMAX; i++) x = pos == (u32)i ? xs[i] : x;
+                            S = __fadd_rn(S, x);
                         }
                         const u32 sb = __float_as_uint(S);
                         if (sb >= thr) {
@@ -696,7 +727,7 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                 SA_SPT(9);
                 __syncthreads();
                 if (tid == 0) s_wlcnt = 0u;
-                if (reserved <= (u32)NCH) break;                // (uniform: nobody was cut short)
+                if (reserved <= (u32)NWL) break;                // (uniform: nobody was cut short)
                 __syncthreads();
             }
             SA_SPT(10);
@@ -711,7 +742,7 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                 if (tid == 0) s_nref = 0u;
             }
 #pragma unroll
-            for (int kx = 0; kx < KT; kx++) lo[kx] = hi[kx];
+            for (int kx = 0; kx < KT; kx++) { lo[kx] += n[kx]; used[kx] += n[kx]; }
             d_s = d_e;
 #ifdef SA_PROBE
             ptiles++;
@@ -741,6 +772,9 @@ int sa_launch_stage(sa_batch* bt, const Bm25Params& p, hipStream_t st) {
     sp.n_docs = ix->n_docs; sp.doc_base = ix->doc_base;
     sp.terms = (const StTerm*)(bt->d_st + L.terms); sp.U = bt->st_U; sp.ND = bt->st_ND;
     sp.dense = bt->impacts->d_dense; sp.dense_stride = bt->impacts->dense_stride;
+    sp.imp_bytes = bt->st_imp_bytes;
+    sp.cm_bytes = (u32)std::min<u64>(0xFFFFFFF0ull, (u64)bt->st_dir->n_rows * bt->st_dir->n_st * 4ull);
+    sp.dense_bytes = bt->impacts->d_dense ? (u32)std::min<u64>(0xFFFFFFF0ull, (u64)bt->impacts->n_dense * bt->impacts->dense_stride * 4ull) : 16u;
     sp.B = bt->B; sp.T = bt->T; sp.k = bt->k;
     sp.pu = (const unsigned short*)(bt->d_st + L.pu);
     sp.pw = (const float*)(bt->d_st + L.pw);

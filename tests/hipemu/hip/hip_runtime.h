@@ -308,6 +308,23 @@ inline int __builtin_amdgcn_readfirstlane(int v) {
     return (int)hipemu::wave_collective(hipemu::OP_FIRST, (uint64_t)(uint32_t)v, 0);
 }
 
+// buffer resources (raw buffer loads: base + 32-bit byte offset, a read past the end returns 0)
+struct __amdgpu_buffer_rsrc_t { const char* base; unsigned bytes; };
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int num_bytes, int) {
+    __amdgpu_buffer_rsrc_t r; r.base = (const char*)p; r.bytes = (unsigned)num_bytes; return r;
+}
+typedef unsigned int hipemu_v2u __attribute__((vector_size(8)));
+typedef unsigned int hipemu_v4u __attribute__((vector_size(16)));
+inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int) {
+    unsigned v = 0; if ((unsigned long long)voff + soff + 4 <= r.bytes) memcpy(&v, r.base + voff + soff, 4); return v;
+}
+inline hipemu_v2u __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int) {
+    hipemu_v2u v = {0, 0}; if ((unsigned long long)voff + soff + 8 <= r.bytes) memcpy(&v, r.base + voff + soff, 8); return v;
+}
+inline hipemu_v4u __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int) {
+    hipemu_v4u v = {0, 0, 0, 0}; if ((unsigned long long)voff + soff + 16 <= r.bytes) memcpy(&v, r.base + voff + soff, 16); return v;
+}
+
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __ffs(int x) { return __builtin_ffs(x); }
