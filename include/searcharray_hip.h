@@ -86,7 +86,8 @@ typedef struct sa_options {
     int64_t stage;           /* staged-tile route (sa_stage.hip): 1 force where eligible, 0 off; unset: on where eligible and `sparse` is unset */
     int64_t stage_docs;      /* docs per stage tile (multiple of 64; default: what fits the LDS stage for the query set's terms) */
     int64_t stage_wgs;       /* staged-tile route: resident workgroups per CU (default 2) */
-    int64_t stage_dense;     /* 0: the staged-tile route stages every term as postings, also those with a dense factor row */
+    int64_t stage_probe;     /* 0: the staged-tile route streams EVERY term of the batch; default: terms that cannot be essential are probed in dense rows */
+    int64_t probe_div;       /* probe rows (dense factor rows the staged-tile route probes) for terms with df >= n_docs / this (default 128; 0: none) */
     int64_t batch_stream;    /* 0: batches share the index stream */
     int64_t res_xs;          /* 0: result copies on the batches' own streams */
     int64_t dense_div;       /* dense factor rows for terms with df >= n_docs / this (default 4) */

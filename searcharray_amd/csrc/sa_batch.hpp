@@ -116,7 +116,7 @@ struct sa_batch {
     bool stage_ok = false;          // the current query set has a plan (sa_stage_plan)
     bool last_route_stage = false;  // the last run took the staged-tile route
     bool bounds_valid = false;      // d_bounds / d_qbase / d_qbase_imp hold the current query set's slice table (the staged route does not need it)
-    u32 st_U = 0, st_ND = 0;        // distinct terms of the query set; the first st_ND are staged as dense factor rows
+    u32 st_U = 0, st_NS = 0;        // distinct terms of the query set; the first st_NS are staged, the others probed in their probe rows
     u32 st_docs = 0;                // docs per stage tile
     u32 st_imp_bytes = 0;           // bytes of the stream from st_cell_base to the end of the set's last term
     u64 st_cell_base = 0;           // smallest impact-stream cell of the set's terms (the kernel's 32-bit offsets count from it)

@@ -88,6 +88,15 @@ struct sa_impacts {
     // that a query set's starting bounds and its terms' score bounds are formed on the host with the upload
     float* d_maxf = nullptr;        // [n_terms]
     std::vector<float> h_topf, h_maxf;
+    // PROBE ROWS (staged-tile route): dense factor rows like d_dense, for every term with df >= n_docs / probe_div (default 128;
+    // as many as a quarter of the free HBM takes, most frequent first).  A term that cannot be essential for a query
+    // is not streamed at all: the few documents that survive the bound test on the query's other terms read its factor with
+    // one 4-byte load from its row.  Built by the first batch that plans the route.
+    float* d_probe = nullptr;
+    u64 probe_stride = 0;           // floats per row (n_docs rounded up to 64)
+    std::vector<u32> probe_slot;    // [n_terms] row of a term, or 0xFFFFFFFF (host)
+    u32 n_probe = 0;
+    bool probe_tried = false;
     std::vector<std::shared_ptr<sa_stagedir>> stagedirs;   // stage directories built so far (one per tile size in use)
     ~sa_impacts();
 };

@@ -41,7 +41,8 @@
     X(stage)           /* staged-tile route (sa_stage.hip): 1 force where eligible, 0 off; unset: on where eligible and `sparse` is unset */ \
     X(stage_docs)      /* docs per stage tile (multiple of 64; default: what fits the LDS stage for the query set's terms) */                 \
     X(stage_wgs)       /* staged-tile route: resident workgroups per CU (default 2) */                                              \
-    X(stage_dense)     /* 0: the staged-tile route stages every term as postings, also those with a dense factor row */            \
+    X(stage_probe)     /* 0: the staged-tile route streams EVERY term of the batch; default: terms that cannot be essential are probed in dense rows */ \
+    X(probe_div)       /* probe rows (dense factor rows the staged-tile route probes) for terms with df >= n_docs / this (default 128; 0: none) */ \
     X(batch_stream)    /* 0: batches share the index stream */                                                                     \
     X(res_xs)          /* 0: result copies on the batches' own streams */                                                          \
     /* ---- index creation (sa_index.hip, sa_bm25.hip) */                                                                          \

@@ -5,21 +5,24 @@
 //     as_dense roaringish_ops.pyx:84-98 -> _bm25_score bm25.pyx:11-25)   ->   np.argpartition (utils/sort.py:24)
 // like sa_k_bm25_group_tiles does, with a different DECOMPOSITION:
 //
-//   * the unit of work is a TILE of `docs` documents (512 by default), not a (tile, query) pair.  A persistent workgroup
-//     walks a contiguous range of tiles.  Per tile it STAGES the slice of EVERY DISTINCT TERM of the batch -- the
-//     impact-stream postings  doc*4 << 32 | fp32 factor , doc-sorted -- from HBM into LDS, once: the posting lists
-//     are streamed from HBM exactly once per batch, whatever the number of queries that share a term, with coalesced
-//     8-byte loads (the slice of the stream a tile needs is contiguous);
+//   * the unit of work is a TILE of `docs` documents, not a (tile, query) pair.  A persistent workgroup walks a contiguous
+//     range of tiles.  Per tile it STAGES the slices of the batch's distinct terms -- the impact-stream postings
+//     doc*4 << 32 | fp32 factor , doc-sorted -- from HBM into LDS, once, whatever the number of queries that share a term,
+//     with coalesced 8-byte loads (the slice of the stream a tile needs is contiguous);
 //   * the queries are then answered FROM LDS.  A query starts with a bound G that at least k documents are known to
-//     reach (rank tables of its terms, then the histogram of the documents found so far: sa_topk.hpp).  Its terms are
-//     ordered by the most each can contribute (weight x largest factor of the term in this shard); the terms at the
-//     end of that order whose bounds TOGETHER stay below G are non-essential: a document that holds only such terms
-//     cannot reach G (fp32 sums of non-negatives are monotone; the rounding of the sum is covered by a margin).  Every
-//     other document of the tile with a chance appears in the slice of an ESSENTIAL term, so the candidates of a
-//     (tile, query) pair are the postings of its essential terms in this tile -- a few documents instead of every
-//     posting of every term;
+//     reach (rank tables of its terms, then the histogram of the documents found so far: sa_topk.hpp).  What a term can add
+//     to a score in THIS tile is bounded by weight x (largest factor among its postings of the tile) -- a block maximum the
+//     stage directory holds per (term, tile).  The query's terms are kept in descending order of their bound in the shard;
+//     the terms at the END of that order whose tile bounds TOGETHER stay below G are non-essential: a document that holds
+//     only such terms cannot reach G (fp32 sums of non-negatives are monotone; the rounding of the sum is covered by a
+//     margin).  Every other document of the tile with a chance appears in the slice of an ESSENTIAL term, so the
+//     candidates of a (tile, query) pair are the postings of its essential terms in this tile -- a few documents instead
+//     of every posting of every term;
+//   * a term that cannot be essential for ANY query of the batch -- by its bound in the shard and the queries' starting
+//     bounds -- and has a PROBE ROW (a dense fp32 factor row, sa_impacts::d_probe) is not streamed at all: it only
+//     enters the bounds, and the few documents that pass the test on the staged terms read its factor with one load;
 //   * candidates of all queries of the tile are flattened into one work list and taken one per LANE: the lane looks
-//     the document up in the query's other terms (binary search of the staged slices) in descending-bound order and
+//     the document up in the query's other staged terms (binary search of the staged slices) in descending-bound order and
 //     gives up as soon as what it has found plus what the remaining terms could add stays below G; a document found in
 //     an essential term of higher priority is that term's candidate (no document is evaluated twice);
 //   * the few documents that pass are scored EXACTLY as the reference does -- factor * idf per term, each product
@@ -30,7 +33,7 @@
 // Nothing here is approximate: a document is dropped only when an upper bound of its exact score is below a lower
 // bound of the k-th best score.  Results are bit-identical to the other routes and to the oracle.
 //
-// Roofline: HBM-bound streaming of the distinct posting lists (8 bytes per posting, once per batch) -- integer /
+// Roofline: HBM-bound streaming of the staged posting lists (8 bytes per posting, once per batch) -- integer /
 // compare work and a scalar fp32 multiply-add per looked-up posting, no MFMA.
 #include "sa_index.hpp"
 #include "sa_topk.hpp"
@@ -46,41 +49,41 @@
 #define SA_ST_NT 512            // threads per workgroup
 #define SA_ST_UMAX 768          // distinct terms of a query set
 #define SA_ST_BMAX 256          // queries of a query set
-#define SA_ST_NDMAX 16          // terms staged as dense rows
 #define SA_ST_REF 64            // queries whose bound is re-derived at the end of a tile pass
 #define SA_ST_NONE 0xFFFFu      // "no term" in the queries' term tables
-#define SA_ST_DENSE 0xFFFFu     // s_off: the term is staged as a dense row (start = its first cell)
+#define SA_ST_PROBE 0xFFFFu     // s_off: the term is not staged; its factors are probed in its probe row (high half: the row)
 #define SA_ST_NOROW 0xFFFFFFFFu
 #define SA_ST_MARGIN 1.0000153f // 1 + 2^-16: covers the fp32 roundings of a sum of up to 8 non-negative terms taken in another order
 
 // 8-byte cells an LDS stage holds (TMAX = 4: the BASELINE shape; 8: wider query tables, smaller stage); two workgroups per CU
-template <int TMAX> struct SaStCap { static constexpr int v = TMAX <= 4 ? 6144 : 5120; };
+template <int TMAX> struct SaStCap { static constexpr int v = TMAX <= 4 ? 6208 : 5056; };
 
 struct alignas(16) StTerm {
     u64 cell0;                  // first cell of the term in the impact stream
     u32 df;
     u32 row;                    // row of the stage directory, or SA_ST_NOROW: the kernel's cursor walks the term
-    u32 dense;                  // dense factor row of the term (sa_impacts::d_dense) when it is staged as one, else 0xFFFFFFFF
+    u32 probe;                  // probe row of a term that is not staged, else 0xFFFFFFFF
     u32 maxf;                   // fp32 pattern of the term's largest factor in the shard
     u32 pad0, pad1;
 };
 
 struct StageParams {
     const u64* imp;
-    u64 cell_base;                        // smallest cell0 of the set's terms: the kernel addresses the stream with 32-bit BYTE offsets from it
-    u32 imp_bytes, cm_bytes, dense_bytes; // sizes of the three buffers the kernel reads through buffer resources (a read past the end returns 0)
+    u64 cell_base;                        // smallest cell0 of the staged terms: the kernel addresses the stream with 32-bit BYTE offsets from it
+    u32 imp_bytes, cm_bytes;              // sizes of the buffers the kernel reads through buffer resources (a read past the end returns 0)
     const u32* abs; const u32* cm;        // stage directory (sa_stagedir): [rows][n_st + 1], [rows][n_st]
     u32 docs, n_st;                       // docs per stage tile, tiles
     u64 n_docs, doc_base;
-    const StTerm* terms; u32 U, ND;       // distinct terms; the first ND are staged as dense rows
-    const float* dense; u64 dense_stride; // dense factor rows
+    const StTerm* terms; u32 U, NS;       // distinct terms; the first NS are staged, the others probed
+    const float* probe; u64 probe_stride; // probe rows
     u32 B, T, k;
-    const unsigned short* pu;             // [B][T] distinct-term index of the query's term at POSITION i (descending bound), SA_ST_NONE: absent
+    const unsigned short* pu;             // [B][T] distinct-term index of the query's term at POSITION i (staged terms by descending bound, then the probed ones), SA_ST_NONE: absent
     const float* pw;                      // [B][T] its weight
     const u32* inv;                       // [B] position of query term s: 4 bits each
     const u32* seed;                      // [B] starting bounds (score bits)
     u32* gthr; u32* hist;                 // [B] cached histogram bounds, [B][SA_HBINS] histograms
     u64* cand; u32 cand_cap; u32* cand_cnt;
+    u32* flag;                            // set when a probed term turns out essential (cannot happen: the run is then redone on another route)
     u32 tpx, tpw;                         // tiles per XCD, per workgroup
 };
 
@@ -158,6 +161,59 @@ static std::shared_ptr<sa_stagedir> sa_stagedir_get(sa_index* ix, sa_impacts* im
     return sd;
 }
 
+// ---- probe rows ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+sa_k_make_probe_row(const u64* __restrict__ imp, u64 first, u64 df, float* __restrict__ row) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < df; i += (u64)gridDim.x * blockDim.x) {
+        const u64 c = imp[first + i];
+        row[(u32)(c >> 32) >> 2] = __uint_as_float((u32)c);
+    }
+}
+
+// the probe rows of impact stream `im` (built on first use; call with the index lock held)
+static void sa_probe_rows_ensure(sa_index* ix, sa_impacts* im, const sa_options_t& o) {
+    if (im->probe_tried) return;
+    im->probe_tried = true;
+    im->probe_slot.assign(ix->n_terms, 0xFFFFFFFFu);
+    const long long div = sa_opt(o.probe_div, 128);
+    if (div <= 0 || ix->n_docs == 0) return;
+    std::vector<std::pair<u64, u32>> cand;
+    for (u32 t = 0; t < ix->n_terms; t++) {
+        const u64 df = ix->h_tf_off[t + 1] - ix->h_tf_off[t];
+        if (df >= 64 && df * (u64)div >= ix->n_docs) cand.push_back({df, t});
+    }
+    if (cand.empty()) return;
+    std::sort(cand.begin(), cand.end(), [](const std::pair<u64, u32>& a, const std::pair<u64, u32>& c) { return a.first > c.first || (a.first == c.first && a.second < c.second); });
+    im->probe_stride = (ix->n_docs + 63ull) & ~63ull;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
+    const u64 max_rows = std::min<u64>(1024, (u64)(free_b / 4) / (im->probe_stride * sizeof(float)));
+    if (cand.size() > max_rows) cand.resize(max_rows);
+    if (cand.empty()) return;
+    const size_t bytes = cand.size() * im->probe_stride * sizeof(float);
+    hipStream_t st = ix->stream;
+    if (hipMalloc(&im->d_probe, bytes) != hipSuccess || hipMemsetAsync(im->d_probe, 0, bytes, st) != hipSuccess) {
+        (void)hipGetLastError();
+        if (im->d_probe) { (void)hipFree(im->d_probe); im->d_probe = nullptr; }
+        return;
+    }
+    for (size_t r = 0; r < cand.size(); r++) {
+        const u32 t = cand[r].second;
+        const u64 df = cand[r].first;
+        const u32 grid = df / 256 + 1 < 8192 ? (u32)(df / 256 + 1) : 8192u;
+        hipLaunchKernelGGL(sa_k_make_probe_row, dim3(grid), dim3(256), 0, st, (const u64*)im->d_imp, sa_imp_base(ix->h_tf_off[t], t), df,
+                           im->d_probe + r * im->probe_stride);
+        im->probe_slot[t] = (u32)r;
+    }
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(im->d_probe); im->d_probe = nullptr;
+        im->probe_slot.assign(ix->n_terms, 0xFFFFFFFFu);
+        return;
+    }
+    im->n_probe = (u32)cand.size();
+}
+
 // ---- the plan of a query set, in the batch's upload block ---------------------------------------------------
 struct StLayout { size_t terms, pw, inv, pu, total; };
 static StLayout sa_stage_layout(u32 B, u32 T) {
@@ -172,9 +228,12 @@ static StLayout sa_stage_layout(u32 B, u32 T) {
 }
 size_t sa_stage_upload_bytes(u32 B, u32 T) { return sa_stage_layout(B, T).total; }
 
-// Plan the query set (row_terms / row_idf: [B][T] in device-row order) into the upload image: distinct terms (most frequent
-// first), per query the terms by descending score bound with their weights, bounds and suffix bounds, the starting
-// bounds.  Leaves bt->stage_ok false when the set is not for this route (the caller then takes another one).
+// the bound the kernel forms from a cm word: the largest factor's fp32 pattern with its low 16 bits rounded UP
+static float sa_st_round_up16(float f) { u32 b; memcpy(&b, &f, 4); b = ((b + 0xFFFFu) >> 16) << 16; float r; memcpy(&r, &b, 4); return r; }
+
+// Plan the query set (row_terms / row_idf: [B][T] in device-row order) into the upload image: distinct terms (staged ones first, most
+// frequent first, then the probed ones), per query the terms in the kernel's order with their weights, the starting bounds.
+// Leaves bt->stage_ok false when the set is not for this route (the caller then takes another one).
 int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* row_idf) {
     bt->stage_ok = false;
     sa_index* ix = bt->ix;
@@ -182,6 +241,8 @@ int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* ro
     sa_impacts* im = bt->impacts.get();
     if (!im || im->h_maxf.size() != ix->n_terms || im->h_topf.size() != (size_t)ix->n_terms * SA_TOPF_NR) return SA_OK;
     if (B > SA_ST_BMAX || T > 8 || !bt->d_st || ix->n_docs == 0 || ix->n_docs > (1ull << 28)) return SA_OK;
+    const bool probing = sa_opt(bt->opts.stage_probe, 1) != 0;
+    if (probing) sa_probe_rows_ensure(ix, im, bt->opts);
     const StLayout L = sa_stage_layout(B, T);
     char* base = img + (bt->d_st - bt->d_up);
     StTerm* h_terms = (StTerm*)(base + L.terms);
@@ -190,101 +251,132 @@ int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* ro
     unsigned short* h_pu = (unsigned short*)(base + L.pu);
     u32* h_seed = (u32*)(img + ((char*)bt->d_seed - bt->d_up));
 
-    // distinct terms: those with a dense factor row first (they are staged as rows), then by document frequency
+    // distinct terms
     std::unordered_map<u32, u32> idx;
     idx.reserve((size_t)B * T * 2);
-    struct DT { u64 df; u32 term; u32 dense; };
+    struct DT { u64 df; u32 term; u32 probe; bool staged; };
     std::vector<DT> dist;
-    const bool dense_on = im->d_dense != nullptr && sa_opt(bt->opts.stage_dense, 1) != 0;
     for (size_t i = 0; i < (size_t)B * T; i++) {
         const u32 t = row_terms[i];
         if (t >= ix->n_terms) continue;
-        if (idx.emplace(t, 0u).second)
-            dist.push_back({ix->h_tf_off[t + 1] - ix->h_tf_off[t], t, dense_on && t < im->dense_slot.size() ? im->dense_slot[t] : 0xFFFFFFFFu});
+        auto it = idx.emplace(t, (u32)dist.size());
+        if (it.second) dist.push_back({ix->h_tf_off[t + 1] - ix->h_tf_off[t], t,
+                                       probing && im->d_probe && t < im->probe_slot.size() ? im->probe_slot[t] : 0xFFFFFFFFu, false});
     }
     if (dist.empty() || dist.size() > SA_ST_UMAX) return SA_OK;
-    std::sort(dist.begin(), dist.end(), [](const DT& a, const DT& c) {
-        const bool da = a.dense != 0xFFFFFFFFu, dc = c.dense != 0xFFFFFFFFu;
-        if (da != dc) return da;
-        return a.df > c.df || (a.df == c.df && a.term < c.term);
-    });
     const u32 U = (u32)dist.size();
-    u32 ND0 = 0;
-    while (ND0 < U && ND0 < (u32)SA_ST_NDMAX && dist[ND0].dense != 0xFFFFFFFFu) ND0++;
-    // docs per stage tile: the largest of the sizes below whose expected cells -- half a cell per doc and dense row, one per posting
-    // of the other terms -- fit the stage with room for the tiles above the mean.  A tile's dense rows are at most 1024 pieces of
-    // 16 bytes (two per thread): the least frequent of the dense-row terms are staged as postings where a tile is bigger.
-    const u32 tmax = T <= 4 ? 4u : 8u;
-    const double cap = tmax == 4 ? (double)SaStCap<4>::v : (double)SaStCap<8>::v;
-    auto nd_for = [&](u32 s) { return std::min<u32>(ND0, 4096u / s); };
-    auto fits = [&](u32 s) {
-        const u32 nd = nd_for(s);
-        double per_doc = 0.0;
-        for (u32 u = nd; u < U; u++) per_doc += (double)dist[u].df;
-        per_doc /= (double)ix->n_docs;
-        return 0.5 * nd * s + per_doc * s + 4.0 * sqrt(per_doc * s) <= 0.97 * cap;
-    };
-    u32 docs = 0;
-    if (sa_opt_is_set(bt->opts.stage_docs)) docs = (u32)std::min<long long>(1024, std::max<long long>(64, bt->opts.stage_docs)) / 64u * 64u;
-    else {
-        static const u32 sizes[] = {1024, 768, 512, 384, 256, 192, 128, 64};
-        for (u32 s : sizes) if (fits(s)) { docs = s; break; }
-        if (!docs) return SA_OK;                          // (more than ~70 postings per doc over the set's terms: not this route)
-    }
-    u32 ND = nd_for(docs);
-    if ((u64)ND * docs / 2u + SA_ST_UMAX > (u64)cap) ND = 0;          // (a forced tile size the dense rows do not fit)
-    for (u32 u = ND; u < U; u++) dist[u].dense = 0xFFFFFFFFu;            // (the others as postings, most frequent first)
-    std::sort(dist.begin() + ND, dist.end(), [](const DT& a, const DT& c) { return a.df > c.df || (a.df == c.df && a.term < c.term); });
-    for (u32 u = 0; u < U; u++) idx[dist[u].term] = u;
-    std::shared_ptr<sa_stagedir> sd = sa_stagedir_get(ix, im, docs);
-    if (!sd) return SA_OK;
-    // the kernel addresses the stream with 32-bit offsets from the set's first term
-    u64 cell_lo = ~0ull, cell_hi = 0;
-    for (u32 u = 0; u < U; u++) {
-        const u32 t = dist[u].term;
-        StTerm& x = h_terms[u];
-        x.cell0 = sa_imp_base(ix->h_tf_off[t], t);
-        x.df = (u32)dist[u].df;
-        x.row = sd->row[t];
-        x.dense = dist[u].dense;
-        memcpy(&x.maxf, &im->h_maxf[t], 4);
-        x.pad0 = 0; x.pad1 = 0;
-        if (x.dense != 0xFFFFFFFFu && x.row == SA_ST_NOROW) return SA_OK;       // (cannot happen: a dense row means df >= n_docs / 4)
-        cell_lo = std::min<u64>(cell_lo, x.cell0);
-        cell_hi = std::max<u64>(cell_hi, x.cell0 + (u64)x.df + 4ull);
-    }
-    if ((u64)sd->n_rows * sd->n_st >= (1ull << 30) || (im->d_dense && (u64)im->n_dense * im->dense_stride >= (1ull << 30))) return SA_OK;
-    if (cell_hi - cell_lo >= (1ull << 29)) return SA_OK;              // (32-bit BYTE offsets in the kernel: shards of up to ~18 M docs of this corpus; bigger ones keep the older routes)
-    // the queries: terms by descending bound (weight x largest factor in the shard), weights, starting bounds
+    // per query: the starting bound; the terms it can PROBE -- those with a probe row whose bounds in the shard, taken
+    // together from the smallest up, stay below the starting bound with the kernel's own arithmetic (so that the kernel,
+    // whose tile bounds are never above these and whose bound G is never below the starting one, can never find them
+    // essential); every other term must be STAGED, for every query
     u32 rank_idx = SA_TOPF_NR - 1;
     for (int i = SA_TOPF_NR - 1; i >= 0; i--) if (sa_topf_ranks[i] >= bt->k) rank_idx = (u32)i;
     const float seed_scale = (float)sa_opt(bt->opts.seed_scale_pct, 100) / 100.f;
+    std::vector<float> ubs((size_t)B * T, 0.f), seeds(B, 0.f);
+    std::vector<unsigned char> probed((size_t)B * T, 0);
     for (u32 q = 0; q < B; q++) {
-        float ub[8]; u32 un[8]; u32 ord[8];
         float seed = 0.f;
         for (u32 s = 0; s < T; s++) {
             const u32 t = row_terms[(size_t)q * T + s];
+            if (t >= ix->n_terms) continue;
             const float w = row_idf[(size_t)q * T + s];
-            ord[s] = s;
-            if (t >= ix->n_terms) { ub[s] = 0.f; un[s] = SA_ST_NONE; continue; }
-            un[s] = idx[t];
-            ub[s] = im->h_maxf[t] * w;
+            ubs[(size_t)q * T + s] = sa_st_round_up16(im->h_maxf[t]) * w;          // (what the kernel forms from a cm word, at most)
             const float sd1 = (im->h_topf[(size_t)t * SA_TOPF_NR + rank_idx] * w) * seed_scale;   // (the arithmetic of sa_k_make_bounds)
             if (sd1 > seed) seed = sd1;
         }
-        std::stable_sort(ord, ord + T, [&](u32 a, u32 c) { return ub[a] > ub[c]; });
+        seeds[q] = seed;
+        if (!(seed > 0.f)) continue;
+        // candidates for probing: smallest bound first
+        u32 cs[8]; u32 nc = 0;
+        for (u32 s = 0; s < T; s++) {
+            const u32 t = row_terms[(size_t)q * T + s];
+            if (t < ix->n_terms && dist[idx[t]].probe != 0xFFFFFFFFu) cs[nc++] = s;
+        }
+        std::stable_sort(cs, cs + nc, [&](u32 a, u32 c) { return ubs[(size_t)q * T + a] < ubs[(size_t)q * T + c]; });
+        float sfx = 0.f;
+        for (u32 j = 0; j < nc; j++) {
+            sfx = sfx + ubs[(size_t)q * T + cs[j]];
+            if (!(sfx * SA_ST_MARGIN * 1.0001f < seed)) break;
+            probed[(size_t)q * T + cs[j]] = 1;
+        }
+    }
+    for (u32 q = 0; q < B; q++)
+        for (u32 s = 0; s < T; s++) {
+            const u32 t = row_terms[(size_t)q * T + s];
+            if (t < ix->n_terms && !probed[(size_t)q * T + s]) dist[idx[t]].staged = true;
+        }
+    // staged terms first, most frequent first; then the probed ones
+    std::vector<u32> order(U);
+    for (u32 u = 0; u < U; u++) order[u] = u;
+    std::sort(order.begin(), order.end(), [&](u32 a, u32 c) {
+        if (dist[a].staged != dist[c].staged) return dist[a].staged;
+        return dist[a].df > dist[c].df || (dist[a].df == dist[c].df && dist[a].term < dist[c].term);
+    });
+    u32 NS = 0;
+    u64 dfsum = 0;
+    for (u32 r = 0; r < U; r++) { const DT& d = dist[order[r]]; idx[d.term] = r; if (d.staged) { NS++; dfsum += d.df; } }
+    // docs per stage tile: the largest of the sizes below whose expected postings fit the stage with room for the tiles above the
+    // mean, and that leave a workgroup of a full device a dozen tiles or more
+    const u32 tmax = T <= 4 ? 4u : 8u;
+    const double cap = tmax == 4 ? (double)SaStCap<4>::v : (double)SaStCap<8>::v;
+    const double per_doc = (double)dfsum / (double)ix->n_docs;
+    u32 docs = 0;
+    if (sa_opt_is_set(bt->opts.stage_docs)) docs = (u32)std::min<long long>(4096, std::max<long long>(64, bt->opts.stage_docs)) / 64u * 64u;
+    else {
+        static const u32 sizes[] = {4096, 3072, 2048, 1536, 1024, 768, 512, 384, 256, 192, 128, 64};
+        const u64 wgs = (u64)ix->n_cus * (u64)std::max<long long>(1, sa_opt(bt->opts.stage_wgs, 2));
+        for (u32 s : sizes) {
+            if (per_doc * s + 4.0 * sqrt(per_doc * s) > 0.97 * cap) continue;
+            if (!docs) docs = s;                             // (the largest that fits, unless a smaller one spreads the shard better)
+            if (ix->n_docs / s >= 12ull * wgs || s <= 512u) { docs = s; break; }
+        }
+        if (!docs) return SA_OK;                          // (more than ~70 staged postings per doc: not this route)
+    }
+    std::shared_ptr<sa_stagedir> sd = sa_stagedir_get(ix, im, docs);
+    if (!sd) return SA_OK;
+    if ((u64)sd->n_rows * sd->n_st >= (1ull << 30)) return SA_OK;
+    // the kernel addresses the stream with 32-bit byte offsets from the first staged term
+    u64 cell_lo = ~0ull, cell_hi = 0;
+    for (u32 r = 0; r < U; r++) {
+        const DT& d = dist[order[r]];
+        StTerm& x = h_terms[r];
+        x.cell0 = sa_imp_base(ix->h_tf_off[d.term], d.term);
+        x.df = (u32)d.df;
+        x.row = sd->row[d.term];
+        x.probe = d.staged ? 0xFFFFFFFFu : d.probe;
+        memcpy(&x.maxf, &im->h_maxf[d.term], 4);
+        x.pad0 = 0; x.pad1 = 0;
+        if (!d.staged && (x.row == SA_ST_NOROW || x.probe >= 65536u)) return SA_OK;       // (cannot happen: a probe row means df >= n_docs / 128)
+        if (d.staged) {
+            cell_lo = std::min<u64>(cell_lo, x.cell0);
+            cell_hi = std::max<u64>(cell_hi, x.cell0 + (u64)x.df + 4ull);
+        }
+    }
+    if (NS == 0) { cell_lo = h_terms[0].cell0; cell_hi = cell_lo + 4; }
+    if (cell_hi - cell_lo >= (1ull << 29)) return SA_OK;              // (32-bit BYTE offsets in the kernel: shards of up to ~18 M docs of this corpus; bigger ones keep the older routes)
+    // the queries: staged terms by descending bound, then the probed ones; weights; starting bounds
+    for (u32 q = 0; q < B; q++) {
+        u32 ord[8];
+        for (u32 s = 0; s < T; s++) ord[s] = s;
+        auto is_probed = [&](u32 s) { const u32 t = row_terms[(size_t)q * T + s]; return t < ix->n_terms && !dist[order[idx[t]]].staged; };
+        std::stable_sort(ord, ord + T, [&](u32 a, u32 c) {
+            const bool pa = is_probed(a), pc = is_probed(c);
+            if (pa != pc) return !pa;
+            return ubs[(size_t)q * T + a] > ubs[(size_t)q * T + c];
+        });
         u32 inv = 0;
         for (u32 i = 0; i < T; i++) {
             const u32 s = ord[i];
-            h_pu[(size_t)q * T + i] = (unsigned short)un[s];
+            const u32 t = row_terms[(size_t)q * T + s];
+            h_pu[(size_t)q * T + i] = (unsigned short)(t < ix->n_terms ? idx[t] : SA_ST_NONE);
             h_pw[(size_t)q * T + i] = row_idf[(size_t)q * T + s];
             inv |= i << (4u * s);
         }
         h_inv[q] = inv;
-        u32 sb; memcpy(&sb, &seed, 4);
-        h_seed[q] = seed > 0.f ? sb : 0u;
+        u32 sb; memcpy(&sb, &seeds[q], 4);
+        h_seed[q] = seeds[q] > 0.f ? sb : 0u;
     }
-    bt->st_U = U; bt->st_ND = ND; bt->st_docs = docs; bt->st_tmax = tmax;
+    bt->st_U = U; bt->st_NS = NS; bt->st_docs = docs; bt->st_tmax = tmax;
     bt->st_cell_base = cell_lo;
     bt->st_imp_bytes = (u32)((cell_hi - cell_lo) * 8ull);
     bt->st_dir = sd;
@@ -358,7 +450,6 @@ extern "C" int sa_debug_stage_probe_read(unsigned long long* out16, int clear) {
 #endif
 
 typedef unsigned int sa_v2u __attribute__((vector_size(8)));
-typedef unsigned int sa_v4u __attribute__((vector_size(16)));
 struct alignas(8) StChunk { u32 dc, off; };    // a copy chunk: first stage cell | postings (1 .. 8) << 13; byte offset of its first posting from the stream base
 
 template <int TMAX>
@@ -368,13 +459,12 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
     constexpr int NCH = CAP / 8 + SA_ST_UMAX;                    // 8-posting chunks a stage can hold at most
     constexpr int NWL = 2 * NCH;                                 // work-list records that fit the chunk list's cells
     constexpr int KB = 10;                                       // chunk loads a lane issues before it waits
-    constexpr int KD = 2;                                        // 16-byte loads of the dense rows a lane issues before it waits
     static_assert(KT == 2, "two terms per thread");
     static_assert(SA_ST_UMAX <= CAP, "a single document's postings must fit the stage");
     static_assert(CAP <= 8192 && SA_ST_UMAX <= 1024, "13-bit stage cells in a chunk descriptor");
     static_assert(SA_ST_BMAX <= 256 && TMAX <= 8, "8-bit query, 3-bit position in a work-list record");
-    __shared__ alignas(16) u64 s_post[CAP];                      // the stage: dense rows (fp32 per doc of the tile), then every other term's slice, doc-sorted
-    __shared__ u32 s_off[SA_ST_UMAX];                           // per distinct term: first cell << 16 | postings (SA_ST_DENSE: a dense row)
+    __shared__ alignas(16) u64 s_post[CAP];                      // the stage: every staged term's slice of this tile, doc-sorted
+    __shared__ u32 s_off[SA_ST_UMAX];                           // per distinct term: first cell << 16 | postings; a probed term: probe row << 16 | SA_ST_PROBE
     __shared__ u32 s_tmax[SA_ST_UMAX];                          // bound (fp32 pattern) of its factors in this tile
     __shared__ StChunk s_cd[NCH];                               // the copy's chunk list; then the candidate work list (u32 records)
     __shared__ unsigned short s_pu[SA_ST_BMAX * TMAX];          // [query][position]: distinct-term index (SA_ST_NONE: no term)
@@ -385,17 +475,14 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
     __shared__ u32 s_nref, s_wlcnt;
     __shared__ u32 s_red[4 * NW];
     const u32 tid = threadIdx.x, lane = tid & (SA_WAVE - 1), wave = tid / SA_WAVE;
-    const u32 T = sp.T, B = sp.B, U = sp.U, ND = sp.ND;
-    // The stream, the cm words and the dense rows are read through BUFFER RESOURCES: a scalar base + a 32-bit byte offset per lane
-    // (no 64-bit address arithmetic, no address register pairs), and a lane without an item passes an offset past the end and reads 0.
+    const u32 T = sp.T, B = sp.B, U = sp.U, NS = sp.NS;
+    // The stream and the cm words are read through BUFFER RESOURCES: a scalar base + a 32-bit byte offset per lane (no 64-bit
+    // address arithmetic, no address register pairs), and a lane without an item passes an offset past the end and reads 0.
     const __amdgpu_buffer_rsrc_t r_imp = __builtin_amdgcn_make_buffer_rsrc((void*)(sp.imp + sp.cell_base), 0, (int)sp.imp_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_cm = __builtin_amdgcn_make_buffer_rsrc((void*)sp.cm, 0, (int)sp.cm_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_dense = __builtin_amdgcn_make_buffer_rsrc((void*)(sp.dense ? (const void*)sp.dense : (const void*)sp.imp), 0, (int)sp.dense_bytes, 0x00020000);
     auto cell_at = [&](u32 boff) -> u64 { const sa_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r_imp, boff, 0, 0); return ((u64)v[1] << 32) | (u64)v[0]; };
     auto key_at = [&](u32 boff) -> u32 { return __builtin_amdgcn_raw_buffer_load_b32(r_imp, boff + 4u, 0, 0); };      // (the doc key of a cell: its high word)
-    const float* const sf = (const float*)s_post;
     u32* const s_wl = (u32*)s_cd;
-    const u32 dense_cells = ND * (sp.docs >> 1);                 // cells the dense rows take at the front of the stage
 #ifdef SA_PROBE
     u64 pacc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     u64 plast = __builtin_amdgcn_s_memtime();
@@ -423,27 +510,26 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
     u32 g_raw = 0u;
     u32 parity = 0;
     // This thread's two terms (u = tid, tid + NT).  lo: first posting not yet staged.  A term with a directory row: nx = its cm
-    // word (postings | bound of the factors) of the NEXT tile to take, read one tile ahead through pcm.  A term without one is
-    // WALKED: nx, w1 = doc keys of the postings at lo and lo + 1 (read one tile ahead too; the sentinel behind a term's
-    // postings has the doc field all ones: a walk stops there); its bound is its largest factor in the shard.  A thread
-    // without a term walks a sentinel: nothing ever comes of it.
-    u32 src0[KT], lo[KT], nx[KT], w1[KT];
-    u32 cmi[KT];                                               // index of the term's cm word of the next tile to take
+    // word (postings | bound of the factors) of the NEXT tile to take, read one tile ahead.  A term without one is WALKED: nx, w1
+    // = doc keys of the postings at lo and lo + 1 (read one tile ahead too; the sentinel behind a term's postings has the doc
+    // field all ones: a walk stops there); its bound is its largest factor in the shard.  A PROBED term (u >= NS) has a row:
+    // only its bound is taken.  A thread without a term walks a sentinel: nothing ever comes of it.
+    u32 src0[KT], lo[KT], nx[KT], w1[KT], cmi[KT];
     bool rowed[KT];
 #pragma unroll
     for (int kx = 0; kx < KT; kx++) {
         const u32 u = tid + (u32)kx * NT;
         const StTerm t0 = sp.terms[0];
-        src0[kx] = (u32)(t0.cell0 - sp.cell_base) + t0.df;      // (term 0's sentinel)
-        lo[kx] = 0; nx[kx] = 0xFFFFFFFFu; w1[kx] = 0xFFFFFFFFu; rowed[kx] = false; cmi[kx] = 0u;
+        src0[kx] = NS ? (u32)(t0.cell0 - sp.cell_base) + t0.df : 0u;       // (term 0's sentinel)
+        lo[kx] = 0; nx[kx] = 0xFFFFFFFFu; w1[kx] = 0xFFFFFFFFu; rowed[kx] = false; cmi[kx] = 0x3FFFFFFFu;
         if (u < U) {
             const StTerm t = sp.terms[u];
-            src0[kx] = (u32)(t.cell0 - sp.cell_base);
+            if (u < NS) src0[kx] = (u32)(t.cell0 - sp.cell_base);
             s_tmax[u] = t.maxf;                                 // (a walked term keeps this bound; a term with a row gets its tile's)
-            if (u < ND) s_off[u] = ((u * (sp.docs >> 1)) << 16) | SA_ST_DENSE;
+            if (u >= NS) s_off[u] = (t.probe << 16) | SA_ST_PROBE;
             if (t.row != SA_ST_NOROW) {
                 rowed[kx] = true;
-                lo[kx] = sp.abs[(u64)t.row * (sp.n_st + 1u) + t_begin];
+                lo[kx] = u < NS ? sp.abs[(u64)t.row * (sp.n_st + 1u) + t_begin] : 0u;
                 cmi[kx] = t.row * sp.n_st + t_begin;
                 nx[kx] = __builtin_amdgcn_raw_buffer_load_b32(r_cm, cmi[kx] << 2, 0, 0);
             } else {
@@ -454,16 +540,6 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                 nx[kx] = key_at((src0[kx] + a) << 3); w1[kx] = key_at((src0[kx] + a + 1u) << 3);
             }
         }
-    }
-    // dense rows: this thread's two 16-byte pieces of a tile's rows (which row, where in it: the same for every tile)
-    const u32 d4n = sp.docs >> 2, n_d4 = ND * d4n;
-    u32 dro[KD];                                                // float index of the piece in the dense rows, relative to the tile's first doc
-#pragma unroll
-    for (int i = 0; i < KD; i++) {
-        const u32 y = (u32)i * NT + tid;
-        const u32 yy = y < n_d4 ? y : 0u;
-        const u32 r = yy / (d4n ? d4n : 1u), c = yy - r * d4n;
-        dro[i] = (ND ? sp.terms[r].dense * (u32)sp.dense_stride : 0u) + 4u * c;
     }
     __syncthreads();
 
@@ -483,10 +559,9 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                     nw = 1;
                     if (w1[kx] < key) { nw = 2; while (key_at((src0[kx] + lo[kx] + nw) << 3) < key) nw++; }   // (three postings of a rare term in one tile: hardly ever)
                 }
-                n_t[kx] = rowed[kx] ? cmw & 0xFFFFu : nw;
+                n_t[kx] = rowed[kx] ? (tid + (u32)kx * NT < NS ? cmw & 0xFFFFu : 0u) : nw;
                 tm[kx] = cmw & 0xFFFF0000u;
             }
-            if (tid < ND) n_t[0] = 0u;                            // (a dense row is not staged as postings; dense terms are the first ND)
         }
         if (tile + 1u < t_end) {                                  // (uniform) the cm words the passes below read are the next tile's
 #pragma unroll
@@ -495,7 +570,7 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
         // the queries' bounds (a bound only ever rises: a stale one is valid), read a tile ago
         const u32 g_now = g_raw > seed ? g_raw : seed;
         // A tile whose postings do not fit the stage is taken in doc sub-ranges: halve the range until it fits (a single
-        // document holds at most U <= CAP - dense rows postings), the slices' ends by a search of the posting lists.
+        // document holds at most U <= CAP postings), the slices' ends by a search of the posting lists.
         u64 d_s = tile_d0;
         u32 used[KT] = {0u, 0u};                                // postings of the tile already staged by earlier passes
         while (d_s < tile_d1) {                                 // (uniform)
@@ -507,7 +582,7 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
             sa_block_excl_scan2<NW>(n[0] + n[1], ((n[0] + 7u) >> 3) + ((n[1] + 7u) >> 3), s_red, parity, excl, exch, P, NC);
             parity ^= 1u;
             // (the rare case apart from the common path: a loop with loads in it makes the compiler wait for every load in flight at its head)
-            if (P + dense_cells > (u32)CAP && d_e - d_s > 1ull) {
+            if (P > (u32)CAP && d_e - d_s > 1ull) {
                 do {
                     d_e = d_s + ((d_e - d_s) >> 1);
                     const u32 key = (u32)d_e << 2;
@@ -520,18 +595,18 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                     }
                     sa_block_excl_scan2<NW>(n[0] + n[1], ((n[0] + 7u) >> 3) + ((n[1] + 7u) >> 3), s_red, parity, excl, exch, P, NC);
                     parity ^= 1u;
-                } while (P + dense_cells > (u32)CAP && d_e - d_s > 1ull);
+                } while (P > (u32)CAP && d_e - d_s > 1ull);
             }
             SA_SPT(0);
             {
                 // stage offsets, bounds and the copy's chunk list: one descriptor per 8 postings
-                u32 o = dense_cells + excl, oc = exch;
+                u32 o = excl, oc = exch;
 #pragma unroll
                 for (int kx = 0; kx < KT; kx++) {
                     const u32 u = tid + (u32)kx * NT;
                     if (kx == 0 || u < U) {
                         if (rowed[kx]) s_tmax[u] = tm[kx];
-                        if (kx != 0 || u >= ND) {
+                        if (u < NS) {
                             s_off[u] = (o << 16) | n[kx];
                             u32 boff = (src0[kx] + lo[kx]) << 3;
                             for (u32 left = n[kx]; left; ) {
@@ -548,33 +623,25 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
             __syncthreads();
             SA_SPT(2);
             // ---- the reads for the NEXT tile: cm words, the walked terms' next doc keys, the queries' bounds.  Every load is
-            //      UNCONDITIONAL (a lane without the case reads a harmless cell) and its result is only looked at a tile later: a
-            //      load inside a branch makes the compiler wait for everything in flight where the branch joins.  Issued in
-            //      front of the stage's loads, so that they have landed when those have -- the loops further down contain
-            //      (rare) loads, and at the head of such a loop the compiler waits for every load in flight.
+            //      UNCONDITIONAL and its result is only looked at a tile later (a load inside a branch makes the compiler wait for
+            //      everything in flight where the branch joins); a lane without the case passes an offset past the buffer's end
+            //      and reads 0 without a memory access.  Issued in front of the stage's loads, so that they have landed when
+            //      those have -- the loops further down contain (rare) loads, and at the head of such a loop the compiler waits
+            //      for every load in flight.
             {
 #pragma unroll
                 for (int kx = 0; kx < KT; kx++) {
-                    const u32 kb = (src0[kx] + lo[kx] + (n_t[kx] - used[kx])) << 3;     // (the cell behind the tile's last posting, whatever the pass)
-                    const u32 c0 = __builtin_amdgcn_raw_buffer_load_b32(r_cm, cmi[kx] << 2, 0, 0), k0 = key_at(kb);
+                    const u32 kb = rowed[kx] ? 0xFFFFFFE0u : (src0[kx] + lo[kx] + (n_t[kx] - used[kx])) << 3;     // (the cell behind the tile's last posting, whatever the pass)
+                    const u32 c0 = __builtin_amdgcn_raw_buffer_load_b32(r_cm, rowed[kx] ? cmi[kx] << 2 : 0xFFFFFFF0u, 0, 0), k0 = key_at(kb);
                     nx[kx] = rowed[kx] ? c0 : k0;
                     w1[kx] = key_at(kb + 8u);
                 }
                 g_raw = __hip_atomic_load(&sp.gthr[hasq ? tid : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            // ---- stage.  Dense rows: the tile's docs of each row, 16 bytes per lane.  Postings: eight lanes per chunk.  A lane
-            //      issues all its loads (KD + KB) before it waits for the first; a lane without an item reads cell 0 and writes nothing.
+            // ---- stage: eight lanes per chunk.  A lane issues all its loads (KB) before it waits for the first; a lane without an
+            //      item reads past the end (0) and writes nothing.
             {
                 const u32 grp = tid >> 3, sub = tid & 7u;
-                float4* const s4 = (float4*)s_post;
-                // dense rows (KD pieces per lane cover ND * docs / 4 <= KD * NT pieces: the plan sees to it; a piece past the rows' end reads 0)
-                float4 dv[KD];
-#pragma unroll
-                for (int i = 0; i < KD; i++) {
-                    const bool in = (u32)i * NT + tid < n_d4 && tile_d0 + (dro[i] % (u32)sp.dense_stride) + 4ull <= sp.dense_stride;
-                    const sa_v4u x4 = __builtin_amdgcn_raw_buffer_load_b128(r_dense, in ? (dro[i] + (u32)tile_d0) << 2 : 0xFFFFFFF0u, 0, 0);
-                    dv[i] = make_float4(__uint_as_float(x4[0]), __uint_as_float(x4[1]), __uint_as_float(x4[2]), __uint_as_float(x4[3]));
-                }
                 u32 x0 = 0;
                 do {                                                    // (uniform: one round unless the tile has more than KB * 64 chunks)
                     u64 v[KB]; u32 dst[KB];
@@ -585,10 +652,6 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                         const bool ok = x < NC && sub < (d.dc >> 13);
                         dst[i] = ok ? (d.dc & 0x1FFFu) + sub : 0xFFFFFFFFu;
                         v[i] = cell_at(ok ? d.off + (sub << 3) : 0xFFFFFFF0u);
-                    }
-                    if (x0 == 0) {
-#pragma unroll
-                        for (int i = 0; i < KD; i++) { const u32 y = (u32)i * NT + tid; if (y < n_d4) s4[y] = dv[i]; }
                     }
                     SA_SPT(3);
 #pragma unroll
@@ -601,7 +664,6 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
             SA_SPT(5);
             // ---- the queries: bound; what every position can add at most in THIS tile (weight x bound of the term's factors here);
             //      essential positions; their postings are the candidates, reserved in the work list with one LDS atomic
-            const u32 pass_docs = (u32)(d_e - d_s), pass_o = (u32)(d_s - tile_d0);
             u32 cum[TMAX];                                          // candidates of the essential positions <= i (this thread's query)
             u32 ncand = 0, done = 0;
             if (hasq) {
@@ -625,12 +687,14 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                     s_psfx[tid * (u32)TMAX + (u32)i] = sm;
                     if (sm >= thr_f && ness == 0u) ness = (u32)i + 1u;
                 }
+                bool bad = false;
 #pragma unroll
                 for (int i = 0; i < TMAX; i++) {
                     const u32 nn = pk[i] & 0xFFFFu;
-                    if ((u32)i < ness) ncand += nn == SA_ST_DENSE ? pass_docs : nn;
+                    if ((u32)i < ness) { if (nn == SA_ST_PROBE) bad = true; else ncand += nn; }
                     cum[i] = ncand;
                 }
+                if (bad) *sp.flag = 1u;                             // (a probed term essential: the plan rules it out; the run would be redone)
                 s_thr[tid] = thr;
             }
             SA_SPT(6);
@@ -664,45 +728,52 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                     const u32 thr = s_thr[q];
                     const float thr_f = __uint_as_float(thr);
                     const u32 u_src = s_pu[qb + i_src];
-                    const u32 pk_src = s_off[u_src];
-                    u32 d4; float f_src;
-                    if ((pk_src & 0xFFFFu) == SA_ST_DENSE) {
-                        f_src = sf[(pk_src >> 16) * 2u + pass_o + j];
-                        d4 = (u32)(d_s + j) << 2;
-                    } else {
-                        const u64 v = s_post[(pk_src >> 16) + j];
-                        d4 = (u32)(v >> 32); f_src = __uint_as_float((u32)v);
-                    }
-                    const u32 o_doc = (d4 >> 2) - (u32)tile_d0;
+                    const u64 v = s_post[(s_off[u_src] >> 16) + j];
+                    const u32 d4 = (u32)(v >> 32);
                     const float w_src = s_pw[qb + i_src];
-                    float known = __fmul_rn(f_src, w_src);
+                    float known = __fmul_rn(__uint_as_float((u32)v), w_src);
                     const float ub_src = __fmul_rn(__uint_as_float(s_tmax[u_src]), w_src);
-                    bool alive = f_src != 0.f;                      // (a doc of the tile the dense row's term does not hold)
+                    bool alive = true;
                     float xs[TMAX];                                 // the terms' contributions, by position
+                    u32 prow[TMAX];                                 // probe row of a probed position, else 0xFFFFFFFF
 #pragma unroll
                     for (int i = 0; i < TMAX; i++) {
-                        xs[i] = 0.f;
+                        xs[i] = 0.f; prow[i] = 0xFFFFFFFFu;
                         if ((u32)i == i_src) xs[i] = known;
                         else if (alive) {
-                            // what the positions from i on can still add (the candidate's own term is already in `known`)
-                            const float rem = s_psfx[qb + (u32)i] - ((u32)i < i_src ? ub_src : 0.f);
-                            if (__fmul_rn(__fadd_rn(known, rem), SA_ST_MARGIN) < thr_f) alive = false;
-                            else {
-                                const u32 u = s_pu[qb + (u32)i];
-                                if (u != SA_ST_NONE) {
-                                    const u32 pk = s_off[u];
-                                    float f; bool found;
-                                    if ((pk & 0xFFFFu) == SA_ST_DENSE) { f = sf[(pk >> 16) * 2u + o_doc]; found = f != 0.f; }
-                                    else f = sa_st_lookup(s_post, pk, d4, found);
-                                    if (found) {
-                                        if ((u32)i < i_src) alive = false;   // the doc is the candidate of that (essential, higher) position
-                                        else { xs[i] = __fmul_rn(f, s_pw[qb + (u32)i]); known = __fadd_rn(known, xs[i]); }
+                            const u32 u = s_pu[qb + (u32)i];
+                            if (u != SA_ST_NONE) {
+                                const u32 pk = s_off[u];
+                                if ((pk & 0xFFFFu) == SA_ST_PROBE) prow[i] = pk >> 16;      // (probed positions come last: looked at if the doc gets that far)
+                                else {
+                                    // what the positions from i on can still add (the candidate's own term is already in `known`)
+                                    const float rem = s_psfx[qb + (u32)i] - ((u32)i < i_src ? ub_src : 0.f);
+                                    if (__fmul_rn(__fadd_rn(known, rem), SA_ST_MARGIN) < thr_f) alive = false;
+                                    else {
+                                        bool found;
+                                        const float f = sa_st_lookup(s_post, pk, d4, found);
+                                        if (found) {
+                                            if ((u32)i < i_src) alive = false;   // the doc is the candidate of that (essential, higher) position
+                                            else { xs[i] = __fmul_rn(f, s_pw[qb + (u32)i]); known = __fadd_rn(known, xs[i]); }
+                                        }
                                     }
                                 }
                             }
                         }
                     }
-                    if (alive && __fmul_rn(known, SA_ST_MARGIN) >= thr_f) {
+                    if (alive) {
+                        // the probed terms: what they can add at most first, then their factors from the probe rows
+                        float pend = 0.f;
+#pragma unroll
+                        for (int i = 0; i < TMAX; i++)
+                            if (prow[i] != 0xFFFFFFFFu) pend = __fadd_rn(pend, __fmul_rn(__uint_as_float(s_tmax[s_pu[qb + (u32)i]]), s_pw[qb + (u32)i]));
+                        if (__fmul_rn(__fadd_rn(known, pend), SA_ST_MARGIN) < thr_f) alive = false;
+                    }
+                    if (alive) {
+                        const u64 doc_l = (u64)(d4 >> 2);
+#pragma unroll
+                        for (int i = 0; i < TMAX; i++)
+                            if (prow[i] != 0xFFFFFFFFu) xs[i] = __fmul_rn(sp.probe[(u64)prow[i] * sp.probe_stride + doc_l], s_pw[qb + (u32)i]);
                         // the exact score: factor * weight per term (held in xs), summed in QUERY-TERM order (bm25.pyx:19-23, np.sum over the terms)
                         const u32 inv = sp.inv[q];
                         float S = 0.f;
@@ -716,7 +787,7 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                         }
                         const u32 sb = __float_as_uint(S);
                         if (sb >= thr) {
-                            const u64 doc = sp.doc_base + (u64)(d4 >> 2);
+                            const u64 doc = sp.doc_base + doc_l;
                             const u32 pos = atomicAdd(&sp.cand_cnt[q], 1u);
                             if (pos < sp.cand_cap) sp.cand[(u64)q * sp.cand_cap + pos] = ((u64)sb << 32) | (u64)(u32)(~(u32)doc);
                             atomicAdd(&sp.hist[(u64)q * SA_HBINS + sa_score_bin(sb)], 1u);
@@ -767,14 +838,13 @@ int sa_launch_stage(sa_batch* bt, const Bm25Params& p, hipStream_t st) {
     StageParams sp;
     memset(&sp, 0, sizeof(sp));
     sp.imp = p.imp; sp.cell_base = bt->st_cell_base;
+    sp.imp_bytes = bt->st_imp_bytes;
+    sp.cm_bytes = (u32)std::min<u64>(0xFFFFFFE0ull, (u64)bt->st_dir->n_rows * bt->st_dir->n_st * 4ull);
     sp.abs = bt->st_dir->d_abs; sp.cm = bt->st_dir->d_cm;
     sp.docs = bt->st_docs; sp.n_st = bt->st_dir->n_st;
     sp.n_docs = ix->n_docs; sp.doc_base = ix->doc_base;
-    sp.terms = (const StTerm*)(bt->d_st + L.terms); sp.U = bt->st_U; sp.ND = bt->st_ND;
-    sp.dense = bt->impacts->d_dense; sp.dense_stride = bt->impacts->dense_stride;
-    sp.imp_bytes = bt->st_imp_bytes;
-    sp.cm_bytes = (u32)std::min<u64>(0xFFFFFFF0ull, (u64)bt->st_dir->n_rows * bt->st_dir->n_st * 4ull);
-    sp.dense_bytes = bt->impacts->d_dense ? (u32)std::min<u64>(0xFFFFFFF0ull, (u64)bt->impacts->n_dense * bt->impacts->dense_stride * 4ull) : 16u;
+    sp.terms = (const StTerm*)(bt->d_st + L.terms); sp.U = bt->st_U; sp.NS = bt->st_NS;
+    sp.probe = bt->impacts->d_probe; sp.probe_stride = bt->impacts->probe_stride;
     sp.B = bt->B; sp.T = bt->T; sp.k = bt->k;
     sp.pu = (const unsigned short*)(bt->d_st + L.pu);
     sp.pw = (const float*)(bt->d_st + L.pw);
@@ -782,6 +852,7 @@ int sa_launch_stage(sa_batch* bt, const Bm25Params& p, hipStream_t st) {
     sp.seed = p.seed;
     sp.gthr = p.gthr; sp.hist = p.hist;
     sp.cand = p.cand; sp.cand_cap = p.cand_cap; sp.cand_cnt = p.cand_cnt;
+    sp.flag = bt->d_overflow;
     if (sp.n_st == 0) return SA_OK;
     const u32 wgs = (u32)std::min<long long>(8, std::max<long long>(1, sa_opt(bt->opts.stage_wgs, 2)));
     u32 grid = (u32)ix->n_cus * wgs / 8u * 8u;
