@@ -103,17 +103,18 @@ def main():
                                  "fine": {nm: round(v[i] / items, 1) for i, nm in ((9, "kernel_start_to_group_entry_loaded"), (10, "slice_bounds_loaded"), (11, "q0_postings_loaded_after_tables"))} if any(v[9:12]) else None,
                                  "note": "s_memtime ticks at 100 MHz x ... see DESIGN 3.1a; one launch; items that reach the overlay"}
                     if hasattr(api._cdll, "sa_debug_stage_probe_read") and batch.last_route() == "staged":   # (-DSA_PROBE: the staged-tile kernel's phases)
-                        buf = (ctypes.c_ulonglong * 16)()
+                        buf = (ctypes.c_ulonglong * 32)()
                         api._cdll.sa_debug_stage_probe_read(buf, 1)
                         batch.run(sync=True)
                         api._cdll.sa_debug_stage_probe_read(buf, 1)
                         v = list(buf)
-                        passes = max(v[12], 1)
+                        passes = max(v[24], 1)
                         names = ["slice_ends_and_scan", "offsets_and_chunk_list", "barrier_a", "next_tile_reads_and_stage_loads_issued", "stage_loads_landed_and_written", "barrier_b",
-                                 "query_phase", "reserve_and_expand", "barrier_c", "candidates", "barrier_d_and_refresh", "tile_top_and_tail"]
-                        probe = {"tile_passes": v[12], "workgroups": v[14], "candidates_per_pass": round(v[13] / passes, 1),
+                                 "query_phase_and_scan", "barrier_c", "stage_a_tail", "stage_b_rounds_tail", "pass_tail", "tile_top",
+                                 "a_search", "a_check", "a_compact", "a_barrier", "b_round_head", "b_lookups", "b_compact", "b_barrier", "before_flush", "flush_atomics_append", "flush_refresh_and_barriers", "flush_probes_and_score"]
+                        probe = {"tile_passes": v[24], "workgroups": v[26], "candidates_per_pass": round(v[25] / passes, 1), "finalists_per_pass": round(v[27] / passes, 1), "flushes_per_pass": round(v[28] / passes, 2),
                                  "cycles_per_pass": {nm: round(v[i] / passes, 1) for i, nm in enumerate(names)},
-                                 "cycles_per_pass_total": round(sum(v[:12]) / passes, 1),
+                                 "cycles_per_pass_total": round(sum(v[:24]) / passes, 1),
                                  "note": "s_memtime of wave 0 at the phase boundaries (shader cycles); one launch"}
                     r0 = ref.setdefault((qname, k), res)
                     same = bool(np.array_equal(r0[0], res[0]) and np.array_equal(r0[1], res[1]))

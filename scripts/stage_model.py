@@ -76,3 +76,54 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def finalists(docs=1_000_000, k=10):
+    """fraction of the candidates (postings of the essential terms) whose staged contributions + the probed terms' bounds reach the
+    starting bound: what stage B hands to stage C"""
+    N, V = docs, 100_000
+    lens, terms = synth.zipf_batch_tokens(0, N, V, 32, 1234, fast=True)
+    doc = np.repeat(np.arange(N, dtype=np.int64), lens)
+    key = terms.astype(np.int64) * N + doc
+    uk, tf = np.unique(key, return_counts=True)
+    pt, pd = uk // N, uk % N
+    off = np.searchsorted(pt, np.arange(V + 1))
+    dl = lens.astype(np.float32)
+    avgdl = np.float32(dl.mean())
+    norm = np.float32(1.2) * ((np.float32(1) - np.float32(0.75)) + np.float32(0.75) * (dl[pd] / avgdl))
+    fac = tf.astype(np.float32) / (tf.astype(np.float32) + norm)
+    df = np.diff(off)
+    idf = np.log(1 + (N - df + 0.5) / (df + 0.5)).astype(np.float32)
+    qs = synth.bm25_queries(256, V)
+    tot_c = tot_f = tot_surv = 0
+    for q in qs:
+        sl = [slice(off[t], off[t + 1]) for t in q]
+        w = idf[q]
+        kth = [np.partition(fac[s], -k)[-k] if df[t] >= k else 0.0 for s, t in zip(sl, q)]
+        seed = max(wi * f for wi, f in zip(w, kth))
+        ub = np.array([wi * fac[s].max() for wi, s in zip(w, sl)], dtype=np.float32)
+        order = np.argsort(-ub)
+        sfx = np.cumsum(ub[order][::-1])[::-1]
+        n_ess = 4
+        for i in range(4):
+            if sfx[i] * 1.00001 < seed:
+                n_ess = i
+                break
+        ess = order[:n_ess]
+        ne = order[n_ess:]
+        known = np.zeros(N, dtype=np.float32)
+        for i in ess:
+            known[pd[sl[i]]] += fac[sl[i]] * w[i]
+        pend = float(ub[ne].sum())
+        cand = known > 0
+        full = known.copy()
+        for i in ne:
+            full[pd[sl[i]]] += fac[sl[i]] * w[i]
+        tot_c += int(cand.sum())
+        tot_f += int((known[cand] + pend >= seed).sum())
+        tot_surv += int((full[cand] >= seed).sum())
+    print(f"candidates {tot_c:,}  finalists (known + pend >= seed) {tot_f:,} ({100.0 * tot_f / tot_c:.1f} %)  at or above the seed {tot_surv:,}")
+
+
+if __name__ == "__main__" and "--finalists" in sys.argv:
+    finalists()

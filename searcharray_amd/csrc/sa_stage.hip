@@ -49,6 +49,7 @@
 #define SA_ST_NT 512            // threads per workgroup
 #define SA_ST_UMAX 768          // distinct terms of a query set
 #define SA_ST_BMAX 256          // queries of a query set
+#define SA_ST_CCAP 768          // finalists that wait for stage C
 #define SA_ST_REF 64            // queries whose bound is re-derived at the end of a tile pass
 #define SA_ST_NONE 0xFFFFu      // "no term" in the queries' term tables
 #define SA_ST_PROBE 0xFFFFu     // s_off: the term is not staged; its factors are probed in its probe row (high half: the row)
@@ -56,7 +57,7 @@
 #define SA_ST_MARGIN 1.0000153f // 1 + 2^-16: covers the fp32 roundings of a sum of up to 8 non-negative terms taken in another order
 
 // 8-byte cells an LDS stage holds (TMAX = 4: the BASELINE shape; 8: wider query tables, smaller stage); two workgroups per CU
-template <int TMAX> struct SaStCap { static constexpr int v = TMAX <= 4 ? 6208 : 5056; };
+template <int TMAX> struct SaStCap { static constexpr int v = TMAX <= 4 ? 3584 : 1536; };
 
 struct alignas(16) StTerm {
     u64 cell0;                  // first cell of the term in the impact stream
@@ -75,7 +76,7 @@ struct StageParams {
     u32 docs, n_st;                       // docs per stage tile, tiles
     u64 n_docs, doc_base;
     const StTerm* terms; u32 U, NS;       // distinct terms; the first NS are staged, the others probed
-    const float* probe; u64 probe_stride; // probe rows
+    const float* probe; u64 probe_rows64; // probe rows (interleaved: sa_probe_cell), rows x 64
     u32 B, T, k;
     const unsigned short* pu;             // [B][T] distinct-term index of the query's term at POSITION i (staged terms by descending bound, then the probed ones), SA_ST_NONE: absent
     const float* pw;                      // [B][T] its weight
@@ -162,11 +163,15 @@ static std::shared_ptr<sa_stagedir> sa_stagedir_get(sa_index* ix, sa_impacts* im
 }
 
 // ---- probe rows ------------------------------------------------------------------------------------------------
+// Probe rows are interleaved in blocks of 64 documents: factor of (row, doc) at  (doc >> 6) * (rows * 64) + row * 64 + (doc & 63) --
+// the rows of one stretch of documents sit together (a workgroup that probes ~100 rows for the documents of its tiles touches a
+// few pages, not one per row: with row-major rows of 40 MB each the probes were page-table walks)
+__device__ __host__ __forceinline__ u64 sa_probe_cell(u32 row, u64 doc, u64 rows64) { return (doc >> 6) * rows64 + ((u64)row << 6) + (doc & 63ull); }
 __global__ void __launch_bounds__(256)
-sa_k_make_probe_row(const u64* __restrict__ imp, u64 first, u64 df, float* __restrict__ row) {
+sa_k_make_probe_row(const u64* __restrict__ imp, u64 first, u64 df, u32 row, u64 rows64, float* __restrict__ probe) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < df; i += (u64)gridDim.x * blockDim.x) {
         const u64 c = imp[first + i];
-        row[(u32)(c >> 32) >> 2] = __uint_as_float((u32)c);
+        probe[sa_probe_cell(row, (u64)((u32)(c >> 32) >> 2), rows64)] = __uint_as_float((u32)c);
     }
 }
 
@@ -202,7 +207,7 @@ static void sa_probe_rows_ensure(sa_index* ix, sa_impacts* im, const sa_options_
         const u64 df = cand[r].first;
         const u32 grid = df / 256 + 1 < 8192 ? (u32)(df / 256 + 1) : 8192u;
         hipLaunchKernelGGL(sa_k_make_probe_row, dim3(grid), dim3(256), 0, st, (const u64*)im->d_imp, sa_imp_base(ix->h_tf_off[t], t), df,
-                           im->d_probe + r * im->probe_stride);
+                           (u32)r, (u64)cand.size() * 64ull, im->d_probe);
         im->probe_slot[t] = (u32)r;
     }
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
@@ -315,6 +320,7 @@ int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* ro
     u32 NS = 0;
     u64 dfsum = 0;
     for (u32 r = 0; r < U; r++) { const DT& d = dist[order[r]]; idx[d.term] = r; if (d.staged) { NS++; dfsum += d.df; } }
+    if (U - NS > (u32)SA_ST_NT) return SA_OK;                // (one probed term per thread)
     // docs per stage tile: the largest of the sizes below whose expected postings fit the stage with room for the tiles above the
     // mean, and that leave a workgroup of a full device a dozen tiles or more
     const u32 tmax = T <= 4 ? 4u : 8u;
@@ -437,12 +443,12 @@ __device__ __forceinline__ void sa_block_excl_scan2(u32 a, u32 b, u32* red, u32 
 // -DSA_PROBE (scripts/build_probe.sh; never in the product build): cycles a workgroup spends per phase of a tile pass, summed
 // over the launch by wave 0 (s_memtime at the phase boundaries), read by sa_debug_stage_probe_read
 #ifdef SA_PROBE
-__device__ unsigned long long g_sa_stage_probe[16];
+__device__ unsigned long long g_sa_stage_probe[32];
 #define SA_SPT(i) do { if (tid == 0) { const u64 t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - plast; plast = t_; } } while (0)
 extern "C" int sa_debug_stage_probe_read(unsigned long long* out16, int clear) {
     if (hipDeviceSynchronize() != hipSuccess) return SA_ERR_HIP;
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sa_stage_probe), 16 * 8) != hipSuccess) return SA_ERR_HIP;
-    if (clear) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sa_stage_probe), z, 16 * 8) != hipSuccess) return SA_ERR_HIP; }
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sa_stage_probe), 32 * 8) != hipSuccess) return SA_ERR_HIP;
+    if (clear) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sa_stage_probe), z, 32 * 8) != hipSuccess) return SA_ERR_HIP; }
     return SA_OK;
 }
 #else
@@ -452,14 +458,15 @@ extern "C" int sa_debug_stage_probe_read(unsigned long long* out16, int clear) {
 typedef unsigned int sa_v2u __attribute__((vector_size(8)));
 struct alignas(8) StChunk { u32 dc, off; };    // a copy chunk: first stage cell | postings (1 .. 8) << 13; byte offset of its first posting from the stream base
 
-template <int TMAX>
+// KT: staged terms per thread (1: up to SA_ST_NT staged terms, the usual case; 2: up to SA_ST_UMAX)
+template <int TMAX, int KT>
 __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams sp) {
     constexpr int CAP = SaStCap<TMAX>::v;
-    constexpr int NT = SA_ST_NT, NW = NT / SA_WAVE, KT = (SA_ST_UMAX + NT - 1) / NT;
-    constexpr int NCH = CAP / 8 + SA_ST_UMAX;                    // 8-posting chunks a stage can hold at most
-    constexpr int NWL = 2 * NCH;                                 // work-list records that fit the chunk list's cells
+    constexpr int NT = SA_ST_NT, NW = NT / SA_WAVE;
+    constexpr int NCH = CAP / 8 + (KT == 1 ? SA_ST_NT : SA_ST_UMAX);   // 8-posting chunks a stage can hold at most (a partly filled one per staged term)
+    constexpr int NWL = 1024;                                    // candidates per round of stage A (its survivors fit s_b)
     constexpr int KB = 10;                                       // chunk loads a lane issues before it waits
-    static_assert(KT == 2, "two terms per thread");
+    static_assert(KT == 1 || KT == 2, "one or two staged terms per thread");
     static_assert(SA_ST_UMAX <= CAP, "a single document's postings must fit the stage");
     static_assert(CAP <= 8192 && SA_ST_UMAX <= 1024, "13-bit stage cells in a chunk descriptor");
     static_assert(SA_ST_BMAX <= 256 && TMAX <= 8, "8-bit query, 3-bit position in a work-list record");
@@ -471,8 +478,12 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
     __shared__ alignas(16) float s_pw[SA_ST_BMAX * TMAX];       //   its weight
     __shared__ alignas(16) float s_psfx[SA_ST_BMAX * TMAX];     //   what the positions >= i can add in THIS tile (with the margin)
     __shared__ u32 s_thr[SA_ST_BMAX];
+    __shared__ u32 s_b[NWL];                                    // records of the candidates that pass stage A
+    __shared__ u32 s_c[SA_ST_CCAP * (2 + TMAX)];                // finalists: query, doc key, contributions by position
+    __shared__ unsigned short s_cum[SA_ST_BMAX * TMAX];         // per query: candidates of the essential positions <= i
+    __shared__ u32 s_qoff[SA_ST_BMAX + 1];                      // per query: its first candidate
     __shared__ u32 s_ref[SA_ST_REF];
-    __shared__ u32 s_nref, s_wlcnt;
+    __shared__ u32 s_nref, s_nb, s_nc;
     __shared__ u32 s_red[4 * NW];
     const u32 tid = threadIdx.x, lane = tid & (SA_WAVE - 1), wave = tid / SA_WAVE;
     const u32 T = sp.T, B = sp.B, U = sp.U, NS = sp.NS;
@@ -482,11 +493,11 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
     const __amdgpu_buffer_rsrc_t r_cm = __builtin_amdgcn_make_buffer_rsrc((void*)sp.cm, 0, (int)sp.cm_bytes, 0x00020000);
     auto cell_at = [&](u32 boff) -> u64 { const sa_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r_imp, boff, 0, 0); return ((u64)v[1] << 32) | (u64)v[0]; };
     auto key_at = [&](u32 boff) -> u32 { return __builtin_amdgcn_raw_buffer_load_b32(r_imp, boff + 4u, 0, 0); };      // (the doc key of a cell: its high word)
-    u32* const s_wl = (u32*)s_cd;
 #ifdef SA_PROBE
-    u64 pacc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    u64 pacc[24];
+    for (int i = 0; i < 24; i++) pacc[i] = 0;
     u64 plast = __builtin_amdgcn_s_memtime();
-    u32 ptiles = 0, pcand = 0;
+    u32 ptiles = 0, pcand = 0, pfin = 0, pflush = 0;
 #endif
     // XCD-aware tile ranges: block b runs on XCD b % 8; an XCD walks a contiguous range of tiles and its workgroups
     // contiguous sub-ranges -- a term's slices of neighbouring tiles are neighbours in memory, so the cache line a slice
@@ -504,16 +515,16 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
         s_pu[i] = c < T ? sp.pu[q * T + c] : (unsigned short)SA_ST_NONE;
         s_pw[i] = c < T ? sp.pw[q * T + c] : 0.f;
     }
-    if (tid == 0) { s_nref = 0u; s_wlcnt = 0u; }
+    if (tid == 0) { s_nref = 0u; s_nb = 0u; s_nc = 0u; s_qoff[SA_ST_BMAX] = 0xFFFFFFFFu; }
     const bool hasq = tid < B;
     const u32 seed = (hasq && sp.seed) ? sp.seed[tid] : 0u;
     u32 g_raw = 0u;
     u32 parity = 0;
-    // This thread's two terms (u = tid, tid + NT).  lo: first posting not yet staged.  A term with a directory row: nx = its cm
+    // This thread's STAGED terms (u = tid, tid + NT).  lo: first posting not yet staged.  A term with a directory row: nx = its cm
     // word (postings | bound of the factors) of the NEXT tile to take, read one tile ahead.  A term without one is WALKED: nx, w1
     // = doc keys of the postings at lo and lo + 1 (read one tile ahead too; the sentinel behind a term's postings has the doc
-    // field all ones: a walk stops there); its bound is its largest factor in the shard.  A PROBED term (u >= NS) has a row:
-    // only its bound is taken.  A thread without a term walks a sentinel: nothing ever comes of it.
+    // field all ones: a walk stops there); its bound is its largest factor in the shard.  A thread without a term walks a
+    // sentinel: nothing ever comes of it.  The PROBED terms (u >= NS) have no owner: their bound is their largest factor in the shard.
     u32 src0[KT], lo[KT], nx[KT], w1[KT], cmi[KT];
     bool rowed[KT];
 #pragma unroll
@@ -522,14 +533,13 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
         const StTerm t0 = sp.terms[0];
         src0[kx] = NS ? (u32)(t0.cell0 - sp.cell_base) + t0.df : 0u;       // (term 0's sentinel)
         lo[kx] = 0; nx[kx] = 0xFFFFFFFFu; w1[kx] = 0xFFFFFFFFu; rowed[kx] = false; cmi[kx] = 0x3FFFFFFFu;
-        if (u < U) {
+        if (u < NS) {
             const StTerm t = sp.terms[u];
-            if (u < NS) src0[kx] = (u32)(t.cell0 - sp.cell_base);
+            src0[kx] = (u32)(t.cell0 - sp.cell_base);
             s_tmax[u] = t.maxf;                                 // (a walked term keeps this bound; a term with a row gets its tile's)
-            if (u >= NS) s_off[u] = (t.probe << 16) | SA_ST_PROBE;
             if (t.row != SA_ST_NOROW) {
                 rowed[kx] = true;
-                lo[kx] = u < NS ? sp.abs[(u64)t.row * (sp.n_st + 1u) + t_begin] : 0u;
+                lo[kx] = sp.abs[(u64)t.row * (sp.n_st + 1u) + t_begin];
                 cmi[kx] = t.row * sp.n_st + t_begin;
                 nx[kx] = __builtin_amdgcn_raw_buffer_load_b32(r_cm, cmi[kx] << 2, 0, 0);
             } else {
@@ -541,6 +551,80 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
             }
         }
     }
+    // a PROBED term (u >= NS; one per thread: the plan sees to it): only the bound of its factors in the tile is taken, from its cm word
+    u32 pcmi = 0x3FFFFFFFu, pnx = 0u;
+    if (NS + tid < U) {
+        const StTerm t = sp.terms[NS + tid];
+        s_off[NS + tid] = (t.probe << 16) | SA_ST_PROBE;
+        pcmi = t.row * sp.n_st + t_begin;
+        pnx = __builtin_amdgcn_raw_buffer_load_b32(r_cm, pcmi << 2, 0, 0);
+    }
+    // ---- stage C: the finalists waiting in s_c -- the probed terms' factors from their probe rows, the exact score, the query's
+    //      candidate list.  Block-uniform; called when the list is nearly full and at the end.
+    auto flush_finalists = [&]() {
+        SA_SPT(20);
+        const u32 nc = s_nc;
+        for (u32 z0 = 0; z0 < nc; z0 += NT) {                   // (uniform)
+            const u32 z = z0 + tid;
+            const bool havez = z < nc;
+            const u32* const c = s_c + (havez ? z : 0u) * (2u + (u32)TMAX);
+            const u32 fq = c[0], fd4 = c[1];
+            const u32 qb = fq * (u32)TMAX;
+            const u32 doc_l = fd4 >> 2;
+            float fx[TMAX], pw[TMAX], pv[TMAX];
+            bool isp[TMAX];
+            // (every load unconditional and issued before the first is looked at: a position that is not probed reads cell 0)
+#pragma unroll
+            for (int i = 0; i < TMAX; i++) {
+                fx[i] = __uint_as_float(c[2 + i]);
+                const u32 u = s_pu[qb + (u32)i];
+                const u32 pk = s_off[u != SA_ST_NONE ? u : 0u];
+                isp[i] = havez && u != SA_ST_NONE && (pk & 0xFFFFu) == SA_ST_PROBE;
+                pw[i] = s_pw[qb + (u32)i];
+                pv[i] = sp.probe[isp[i] ? sa_probe_cell(pk >> 16, (u64)doc_l, sp.probe_rows64) : 0ull];
+            }
+            const u32 inv = sp.inv[fq];
+#pragma unroll
+            for (int i = 0; i < TMAX; i++) fx[i] = isp[i] ? __fmul_rn(pv[i], pw[i]) : fx[i];
+            // the exact score: factor * weight per term, summed in QUERY-TERM order (bm25.pyx:19-23, np.sum over the terms)
+            float S = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < TMAX; sl++) {
+                const u32 pos = (u32)sl < T ? (inv >> (4u * (u32)sl)) & 15u : 15u;
+                float x = 0.f;
+#pragma unroll
+                for (int i = 0; i < TMAX; i++) x = pos == (u32)i ? fx[i] : x;
+                S = __fadd_rn(S, x);
+            }
+            const u32 sb = __float_as_uint(S);
+            SA_SPT(23);
+#ifdef SA_PROBE
+            if (tid == 0) { pfin += nc; pflush++; }
+#endif
+            if (havez && sb >= s_thr[fq]) {
+                const u64 doc = sp.doc_base + (u64)doc_l;
+                const u32 pos = atomicAdd(&sp.cand_cnt[fq], 1u);
+                if (pos < sp.cand_cap) sp.cand[(u64)fq * sp.cand_cap + pos] = ((u64)sb << 32) | (u64)(u32)(~(u32)doc);
+                atomicAdd(&sp.hist[(u64)fq * SA_HBINS + sa_score_bin(sb)], 1u);
+                if (((pos + 1u) & 31u) == 0u) { const u32 sl = atomicAdd(&s_nref, 1u); if (sl < (u32)SA_ST_REF) s_ref[sl] = fq; }
+            }
+        }
+        SA_SPT(21);
+        __syncthreads();
+        if (tid == 0) s_nc = 0u;
+        // bounds re-derived for the queries whose candidate list crossed a multiple of 32 entries
+        const u32 nref = s_nref < (u32)SA_ST_REF ? s_nref : (u32)SA_ST_REF;
+        if (nref) {                                             // (uniform)
+            for (u32 r = wave; r < nref; r += NW) {
+                const u32 q = s_ref[r];
+                sa_hist_refresh(sp.hist + (u64)q * SA_HBINS, &sp.gthr[q], sp.k, lane);
+            }
+            __syncthreads();
+            if (tid == 0) s_nref = 0u;
+        }
+        __syncthreads();
+        SA_SPT(22);
+    };
     __syncthreads();
 
     for (u32 tile = t_begin; tile < t_end; tile++) {
@@ -559,28 +643,37 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                     nw = 1;
                     if (w1[kx] < key) { nw = 2; while (key_at((src0[kx] + lo[kx] + nw) << 3) < key) nw++; }   // (three postings of a rare term in one tile: hardly ever)
                 }
-                n_t[kx] = rowed[kx] ? (tid + (u32)kx * NT < NS ? cmw & 0xFFFFu : 0u) : nw;
+                n_t[kx] = rowed[kx] ? cmw & 0xFFFFu : nw;
                 tm[kx] = cmw & 0xFFFF0000u;
             }
         }
+        const u32 ptm = pnx & 0xFFFF0000u;
         if (tile + 1u < t_end) {                                  // (uniform) the cm words the passes below read are the next tile's
 #pragma unroll
             for (int kx = 0; kx < KT; kx++) cmi[kx] += rowed[kx] ? 1u : 0u;
+            pcmi += NS + tid < U ? 1u : 0u;
         }
         // the queries' bounds (a bound only ever rises: a stale one is valid), read a tile ago
         const u32 g_now = g_raw > seed ? g_raw : seed;
         // A tile whose postings do not fit the stage is taken in doc sub-ranges: halve the range until it fits (a single
         // document holds at most U <= CAP postings), the slices' ends by a search of the posting lists.
         u64 d_s = tile_d0;
-        u32 used[KT] = {0u, 0u};                                // postings of the tile already staged by earlier passes
+        u32 used[KT];                                           // postings of the tile already staged by earlier passes
+#pragma unroll
+        for (int kx = 0; kx < KT; kx++) used[kx] = 0u;
         while (d_s < tile_d1) {                                 // (uniform)
             u64 d_e = tile_d1;
             u32 n[KT];
 #pragma unroll
             for (int kx = 0; kx < KT; kx++) n[kx] = n_t[kx] - used[kx];
             u32 excl, exch, P, NC;
-            sa_block_excl_scan2<NW>(n[0] + n[1], ((n[0] + 7u) >> 3) + ((n[1] + 7u) >> 3), s_red, parity, excl, exch, P, NC);
-            parity ^= 1u;
+            {
+                u32 mine = 0, mch = 0;
+#pragma unroll
+                for (int kx = 0; kx < KT; kx++) { mine += n[kx]; mch += (n[kx] + 7u) >> 3; }
+                sa_block_excl_scan2<NW>(mine, mch, s_red, parity, excl, exch, P, NC);
+                parity ^= 1u;
+            }
             // (the rare case apart from the common path: a loop with loads in it makes the compiler wait for every load in flight at its head)
             if (P > (u32)CAP && d_e - d_s > 1ull) {
                 do {
@@ -593,7 +686,10 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                         while (a < b) { const u32 mid = a + ((b - a) >> 1); if (key_at((first + mid) << 3) < key) a = mid + 1u; else b = mid; }
                         n[kx] = a;
                     }
-                    sa_block_excl_scan2<NW>(n[0] + n[1], ((n[0] + 7u) >> 3) + ((n[1] + 7u) >> 3), s_red, parity, excl, exch, P, NC);
+                    u32 mine = 0, mch = 0;
+#pragma unroll
+                    for (int kx = 0; kx < KT; kx++) { mine += n[kx]; mch += (n[kx] + 7u) >> 3; }
+                    sa_block_excl_scan2<NW>(mine, mch, s_red, parity, excl, exch, P, NC);
                     parity ^= 1u;
                 } while (P > (u32)CAP && d_e - d_s > 1ull);
             }
@@ -604,9 +700,9 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
 #pragma unroll
                 for (int kx = 0; kx < KT; kx++) {
                     const u32 u = tid + (u32)kx * NT;
-                    if (kx == 0 || u < U) {
+                    if (u < NS) {
                         if (rowed[kx]) s_tmax[u] = tm[kx];
-                        if (u < NS) {
+                        {
                             s_off[u] = (o << 16) | n[kx];
                             u32 boff = (src0[kx] + lo[kx]) << 3;
                             for (u32 left = n[kx]; left; ) {
@@ -619,6 +715,7 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                     }
                 }
             }
+            if (NS + tid < U) s_tmax[NS + tid] = ptm;
             SA_SPT(1);
             __syncthreads();
             SA_SPT(2);
@@ -636,6 +733,7 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                     nx[kx] = rowed[kx] ? c0 : k0;
                     w1[kx] = key_at(kb + 8u);
                 }
+                pnx = __builtin_amdgcn_raw_buffer_load_b32(r_cm, NS + tid < U ? pcmi << 2 : 0xFFFFFFF0u, 0, 0);
                 g_raw = __hip_atomic_load(&sp.gthr[hasq ? tid : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             // ---- stage: eight lanes per chunk.  A lane issues all its loads (KB) before it waits for the first; a lane without an
@@ -663,155 +761,171 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
             __syncthreads();
             SA_SPT(5);
             // ---- the queries: bound; what every position can add at most in THIS tile (weight x bound of the term's factors here);
-            //      essential positions; their postings are the candidates, reserved in the work list with one LDS atomic
-            u32 cum[TMAX];                                          // candidates of the essential positions <= i (this thread's query)
-            u32 ncand = 0, done = 0;
+            //      essential positions; their postings are the candidates.  (Branch-free, the LDS reads in three batches: a read
+            //      inside a branch is waited for on the spot.)
+            u32 ncand = 0;
             if (hasq) {
+                const u32 qb = tid * (u32)TMAX;
                 const u32 thr = g_now > 1u ? g_now : 1u;
                 const float thr_f = __uint_as_float(thr);
-                u32 pk[TMAX]; float ubv[TMAX];
+                u32 uu[TMAX], pk[TMAX]; float ubv[TMAX];
+                bool have[TMAX];
 #pragma unroll
-                for (int i = 0; i < TMAX; i++) {
-                    const u32 u = s_pu[tid * (u32)TMAX + (u32)i];
-                    const bool have = u != SA_ST_NONE;
-                    const u32 uu = have ? u : 0u;
-                    pk[i] = have ? s_off[uu] : 0u;
-                    ubv[i] = have ? __fmul_rn(__uint_as_float(s_tmax[uu]), s_pw[tid * (u32)TMAX + (u32)i]) : 0.f;
-                }
+                for (int i = 0; i < TMAX; i++) { const u32 u = s_pu[qb + (u32)i]; have[i] = u != SA_ST_NONE; uu[i] = have[i] ? u : 0u; }
+#pragma unroll
+                for (int i = 0; i < TMAX; i++) { pk[i] = s_off[uu[i]]; ubv[i] = __fmul_rn(__uint_as_float(s_tmax[uu[i]]), s_pw[qb + (u32)i]); }
                 float sfx = 0.f;
                 u32 ness = 0;
 #pragma unroll
                 for (int i = TMAX - 1; i >= 0; i--) {
-                    sfx = __fadd_rn(sfx, ubv[i]);
+                    sfx = __fadd_rn(sfx, have[i] ? ubv[i] : 0.f);
                     const float sm = __fmul_rn(sfx, SA_ST_MARGIN);
-                    s_psfx[tid * (u32)TMAX + (u32)i] = sm;
-                    if (sm >= thr_f && ness == 0u) ness = (u32)i + 1u;
+                    s_psfx[qb + (u32)i] = sm;
+                    ness = (sm >= thr_f && ness == 0u) ? (u32)i + 1u : ness;
                 }
                 bool bad = false;
+                unsigned short cumv[TMAX];
 #pragma unroll
                 for (int i = 0; i < TMAX; i++) {
                     const u32 nn = pk[i] & 0xFFFFu;
-                    if ((u32)i < ness) { if (nn == SA_ST_PROBE) bad = true; else ncand += nn; }
-                    cum[i] = ncand;
+                    const bool ess = have[i] && (u32)i < ness;
+                    bad = bad || (ess && nn == SA_ST_PROBE);
+                    ncand += ess && nn != SA_ST_PROBE ? nn : 0u;
+                    cumv[i] = (unsigned short)ncand;
                 }
+#pragma unroll
+                for (int i = 0; i < TMAX; i++) s_cum[qb + (u32)i] = cumv[i];
                 if (bad) *sp.flag = 1u;                             // (a probed term essential: the plan rules it out; the run would be redone)
                 s_thr[tid] = thr;
             }
+            // the queries' candidates, one after the other: query q's are [s_qoff[q], s_qoff[q + 1])
+            u32 C;
+            {
+                u32 e0, e1, t1;
+                sa_block_excl_scan2<NW>(ncand, 0u, s_red, parity, e0, e1, C, t1);
+                parity ^= 1u;
+                if (tid < (u32)SA_ST_BMAX) s_qoff[tid] = hasq ? e0 : 0xFFFFFFFFu;
+            }
             SA_SPT(6);
-            for (;;) {                                          // (uniform: rounds of at most NWL candidates)
-                // thread q writes the records of its next candidates: query | position << 8 | posting << 11
-                if (ncand > done) {
-                    const u32 want = ncand - done;
-                    const u32 o = atomicAdd(&s_wlcnt, want);
-                    const u32 take = o < (u32)NWL ? (want < (u32)NWL - o ? want : (u32)NWL - o) : 0u;
-                    for (u32 x = 0; x < take; x++) {
-                        const u32 r = done + x;
-                        u32 i = 0, base = 0;
-#pragma unroll
-                        for (int c = 0; c < TMAX - 1; c++) if (r >= cum[c]) { i = (u32)c + 1u; base = cum[c]; }
-                        s_wl[o + x] = tid | (i << 8) | ((r - base) << 11);
-                    }
-                    done += take;
-                }
-                SA_SPT(7);
-                __syncthreads();
-                SA_SPT(8);
-                const u32 reserved = s_wlcnt;
-                const u32 nchunk = reserved < (u32)NWL ? reserved : (u32)NWL;
+            __syncthreads();
+            SA_SPT(7);
 #ifdef SA_PROBE
-                pcand += nchunk;
+            pcand += C;
 #endif
-                for (u32 x = tid; x < nchunk; x += NT) {
-                    const u32 rec = s_wl[x];
-                    const u32 q = rec & 0xFFu, i_src = (rec >> 8) & 7u, j = rec >> 11;
-                    const u32 qb = q * (u32)TMAX;
-                    const u32 thr = s_thr[q];
-                    const float thr_f = __uint_as_float(thr);
-                    const u32 u_src = s_pu[qb + i_src];
-                    const u64 v = s_post[(s_off[u_src] >> 16) + j];
-                    const u32 d4 = (u32)(v >> 32);
-                    const float w_src = s_pw[qb + i_src];
-                    float known = __fmul_rn(__uint_as_float((u32)v), w_src);
-                    const float ub_src = __fmul_rn(__uint_as_float(s_tmax[u_src]), w_src);
-                    bool alive = true;
-                    float xs[TMAX];                                 // the terms' contributions, by position
-                    u32 prow[TMAX];                                 // probe row of a probed position, else 0xFFFFFFFF
+            const u64 ltmask = (1ull << lane) - 1ull;
+            for (u32 c0 = 0; c0 < C; c0 += (u32)NWL) {          // (uniform: rounds of at most NWL candidates)
+                const u32 cend = C - c0 < (u32)NWL ? C : c0 + (u32)NWL;
+                // ---- stage A, every candidate, one per lane: whose it is (a search of the queries' offsets), then its own
+                //      contribution + everything the query's other terms can add in this tile, against the bound.  The survivors'
+                //      records -- query | position << 8 | posting << 11 -- are compacted into s_b (one LDS atomic per wave).
+                for (u32 x0 = c0; x0 < cend; x0 += NT) {          // (uniform)
+                    const u32 x = x0 + tid;
+                    const bool valid = x < cend;
+                    const u32 xx = valid ? x : c0;
+                    u32 q = 0;
 #pragma unroll
-                    for (int i = 0; i < TMAX; i++) {
-                        xs[i] = 0.f; prow[i] = 0xFFFFFFFFu;
-                        if ((u32)i == i_src) xs[i] = known;
-                        else if (alive) {
-                            const u32 u = s_pu[qb + (u32)i];
-                            if (u != SA_ST_NONE) {
-                                const u32 pk = s_off[u];
-                                if ((pk & 0xFFFFu) == SA_ST_PROBE) prow[i] = pk >> 16;      // (probed positions come last: looked at if the doc gets that far)
-                                else {
-                                    // what the positions from i on can still add (the candidate's own term is already in `known`)
-                                    const float rem = s_psfx[qb + (u32)i] - ((u32)i < i_src ? ub_src : 0.f);
-                                    if (__fmul_rn(__fadd_rn(known, rem), SA_ST_MARGIN) < thr_f) alive = false;
+                    for (int step = SA_ST_BMAX / 2; step >= 1; step >>= 1) q += s_qoff[q + (u32)step] <= xx ? (u32)step : 0u;
+                    SA_SPT(12);
+                    const u32 qb = q * (u32)TMAX;
+                    const u32 r = xx - s_qoff[q];
+                    u32 i = 0, base = 0;
+#pragma unroll
+                    for (int c = 0; c < TMAX - 1; c++) { const u32 cc = s_cum[qb + (u32)c]; const bool ge = r >= cc; i = ge ? (u32)c + 1u : i; base = ge ? cc : base; }
+                    const u32 j = r - base;
+                    const u32 u_src = s_pu[qb + i];
+                    const float w_src = s_pw[qb + i];
+                    const float f_src = __uint_as_float((u32)s_post[(s_off[u_src] >> 16) + j]);
+                    const float rem = s_psfx[qb] - __fmul_rn(__uint_as_float(s_tmax[u_src]), w_src);
+                    const bool alive = valid && !(__fmul_rn(__fadd_rn(__fmul_rn(f_src, w_src), rem), SA_ST_MARGIN) < __uint_as_float(s_thr[q]));
+                    SA_SPT(13);
+                    const u64 m = (u64)__builtin_amdgcn_ballot_w64(alive);
+                    if (m) {                                        // (wave-uniform)
+                        u32 wb = 0;
+                        if (lane == (u32)__builtin_ctzll(m)) wb = atomicAdd(&s_nb, (u32)__popcll(m));
+                        wb = (u32)__builtin_amdgcn_readlane((int)wb, (int)__builtin_ctzll(m));
+                        if (alive) s_b[wb + (u32)__popcll(m & ltmask)] = q | (i << 8) | (j << 11);
+                    }
+                    SA_SPT(14);
+                }
+                SA_SPT(8);
+                __syncthreads();
+                SA_SPT(15);
+                const u32 nb = s_nb;
+                // ---- stage B, the survivors, one per lane: the document is looked up in the query's other STAGED terms, in
+                //      descending-bound order, as long as what is known plus what the remaining terms can add reaches the bound;
+                //      the documents that get through are the FINALISTS (s_c: query, doc, the contributions found).  They wait
+                //      there -- across rounds and tiles -- until the list is nearly full: stage C (flush_finalists).
+                for (u32 y0 = 0; y0 < nb; y0 += NT) {            // (uniform)
+                    if (s_nc + NT > (u32)SA_ST_CCAP) flush_finalists();     // (uniform: s_nc only changes between barriers)
+                    SA_SPT(16);
+                    const u32 y = y0 + tid;
+                    bool fin = false;
+                    u32 q = 0, d4 = 0;
+                    float xs[TMAX];                                 // the terms' contributions, by position
+#pragma unroll
+                    for (int i = 0; i < TMAX; i++) xs[i] = 0.f;
+                    if (y < nb) {
+                        const u32 rec = s_b[y];
+                        q = rec & 0xFFu;
+                        const u32 i_src = (rec >> 8) & 7u, j = rec >> 11;
+                        const u32 qb = q * (u32)TMAX;
+                        const float thr_f = __uint_as_float(s_thr[q]);
+                        const u32 u_src = s_pu[qb + i_src];
+                        const u64 v = s_post[(s_off[u_src] >> 16) + j];
+                        d4 = (u32)(v >> 32);
+                        const float w_src = s_pw[qb + i_src];
+                        float known = __fmul_rn(__uint_as_float((u32)v), w_src);
+                        const float ub_src = __fmul_rn(__uint_as_float(s_tmax[u_src]), w_src);
+                        bool alive = true;
+                        float pend = 0.f;                           // what the probed terms can add at most
+#pragma unroll
+                        for (int i = 0; i < TMAX; i++) {
+                            if ((u32)i == i_src) xs[i] = known;
+                            else if (alive) {
+                                const u32 u = s_pu[qb + (u32)i];
+                                if (u != SA_ST_NONE) {
+                                    const u32 pk = s_off[u];
+                                    if ((pk & 0xFFFFu) == SA_ST_PROBE) pend = __fadd_rn(pend, __fmul_rn(__uint_as_float(s_tmax[u]), s_pw[qb + (u32)i]));
                                     else {
-                                        bool found;
-                                        const float f = sa_st_lookup(s_post, pk, d4, found);
-                                        if (found) {
-                                            if ((u32)i < i_src) alive = false;   // the doc is the candidate of that (essential, higher) position
-                                            else { xs[i] = __fmul_rn(f, s_pw[qb + (u32)i]); known = __fadd_rn(known, xs[i]); }
+                                        // what the positions from i on can still add (the candidate's own term is already in `known`)
+                                        const float rem = s_psfx[qb + (u32)i] - ((u32)i < i_src ? ub_src : 0.f);
+                                        if (__fmul_rn(__fadd_rn(known, rem), SA_ST_MARGIN) < thr_f) alive = false;
+                                        else {
+                                            bool found;
+                                            const float f = sa_st_lookup(s_post, pk, d4, found);
+                                            if (found) {
+                                                if ((u32)i < i_src) alive = false;   // the doc is the candidate of that (essential, higher) position
+                                                else { xs[i] = __fmul_rn(f, s_pw[qb + (u32)i]); known = __fadd_rn(known, xs[i]); }
+                                            }
                                         }
                                     }
                                 }
                             }
                         }
+                        fin = alive && !(__fmul_rn(__fadd_rn(known, pend), SA_ST_MARGIN) < thr_f);
                     }
-                    if (alive) {
-                        // the probed terms: what they can add at most first, then their factors from the probe rows
-                        float pend = 0.f;
+                    SA_SPT(17);
+                    const u64 m = (u64)__builtin_amdgcn_ballot_w64(fin);
+                    if (m) {                                        // (wave-uniform)
+                        u32 wb = 0;
+                        if (lane == (u32)__builtin_ctzll(m)) wb = atomicAdd(&s_nc, (u32)__popcll(m));
+                        wb = (u32)__builtin_amdgcn_readlane((int)wb, (int)__builtin_ctzll(m));
+                        if (fin) {
+                            u32* const c = s_c + (wb + (u32)__popcll(m & ltmask)) * (2u + (u32)TMAX);
+                            c[0] = q; c[1] = d4;
 #pragma unroll
-                        for (int i = 0; i < TMAX; i++)
-                            if (prow[i] != 0xFFFFFFFFu) pend = __fadd_rn(pend, __fmul_rn(__uint_as_float(s_tmax[s_pu[qb + (u32)i]]), s_pw[qb + (u32)i]));
-                        if (__fmul_rn(__fadd_rn(known, pend), SA_ST_MARGIN) < thr_f) alive = false;
-                    }
-                    if (alive) {
-                        const u64 doc_l = (u64)(d4 >> 2);
-#pragma unroll
-                        for (int i = 0; i < TMAX; i++)
-                            if (prow[i] != 0xFFFFFFFFu) xs[i] = __fmul_rn(sp.probe[(u64)prow[i] * sp.probe_stride + doc_l], s_pw[qb + (u32)i]);
-                        // the exact score: factor * weight per term (held in xs), summed in QUERY-TERM order (bm25.pyx:19-23, np.sum over the terms)
-                        const u32 inv = sp.inv[q];
-                        float S = 0.f;
-#pragma unroll
-                        for (int s = 0; s < TMAX; s++) {
-                            const u32 pos = (u32)s < T ? (inv >> (4u * (u32)s)) & 15u : 15u;
-                            float x = 0.f;
-#pragma unroll
-                            for (int i = 0; i < TMAX; i++) x = pos == (u32)i ? xs[i] : x;
-                            S = __fadd_rn(S, x);
-                        }
-                        const u32 sb = __float_as_uint(S);
-                        if (sb >= thr) {
-                            const u64 doc = sp.doc_base + doc_l;
-                            const u32 pos = atomicAdd(&sp.cand_cnt[q], 1u);
-                            if (pos < sp.cand_cap) sp.cand[(u64)q * sp.cand_cap + pos] = ((u64)sb << 32) | (u64)(u32)(~(u32)doc);
-                            atomicAdd(&sp.hist[(u64)q * SA_HBINS + sa_score_bin(sb)], 1u);
-                            if (((pos + 1u) & 31u) == 0u) { const u32 sl = atomicAdd(&s_nref, 1u); if (sl < (u32)SA_ST_REF) s_ref[sl] = q; }
+                            for (int i = 0; i < TMAX; i++) c[2 + i] = __float_as_uint(xs[i]);
                         }
                     }
+                    SA_SPT(18);
+                    __syncthreads();
+                    SA_SPT(19);
                 }
-                SA_SPT(9);
-                __syncthreads();
-                if (tid == 0) s_wlcnt = 0u;
-                if (reserved <= (u32)NWL) break;                // (uniform: nobody was cut short)
+                if (tid == 0) s_nb = 0u;
                 __syncthreads();
             }
+            SA_SPT(9);
             SA_SPT(10);
-            // bounds re-derived for the queries whose candidate list crossed a multiple of 32 entries
-            const u32 nref = s_nref < (u32)SA_ST_REF ? s_nref : (u32)SA_ST_REF;
-            if (nref) {                                         // (uniform)
-                for (u32 r = wave; r < nref; r += NW) {
-                    const u32 q = s_ref[r];
-                    sa_hist_refresh(sp.hist + (u64)q * SA_HBINS, &sp.gthr[q], sp.k, lane);
-                }
-                __syncthreads();
-                if (tid == 0) s_nref = 0u;
-            }
 #pragma unroll
             for (int kx = 0; kx < KT; kx++) { lo[kx] += n[kx]; used[kx] += n[kx]; }
             d_s = d_e;
@@ -820,13 +934,16 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
 #endif
         }
     }
+    flush_finalists();
 #ifdef SA_PROBE
     SA_SPT(11);
     if (tid == 0) {
-        for (int i = 0; i < 12; i++) atomicAdd(&g_sa_stage_probe[i], pacc[i]);
-        atomicAdd(&g_sa_stage_probe[12], (unsigned long long)ptiles);
-        atomicAdd(&g_sa_stage_probe[13], (unsigned long long)pcand);
-        atomicAdd(&g_sa_stage_probe[14], 1ull);
+        for (int i = 0; i < 24; i++) atomicAdd(&g_sa_stage_probe[i], pacc[i]);
+        atomicAdd(&g_sa_stage_probe[24], (unsigned long long)ptiles);
+        atomicAdd(&g_sa_stage_probe[25], (unsigned long long)pcand);
+        atomicAdd(&g_sa_stage_probe[26], 1ull);
+        atomicAdd(&g_sa_stage_probe[27], (unsigned long long)pfin);
+        atomicAdd(&g_sa_stage_probe[28], (unsigned long long)pflush);
     }
 #endif
 }
@@ -844,7 +961,8 @@ int sa_launch_stage(sa_batch* bt, const Bm25Params& p, hipStream_t st) {
     sp.docs = bt->st_docs; sp.n_st = bt->st_dir->n_st;
     sp.n_docs = ix->n_docs; sp.doc_base = ix->doc_base;
     sp.terms = (const StTerm*)(bt->d_st + L.terms); sp.U = bt->st_U; sp.NS = bt->st_NS;
-    sp.probe = bt->impacts->d_probe; sp.probe_stride = bt->impacts->probe_stride;
+    sp.probe = bt->impacts->d_probe ? bt->impacts->d_probe : (const float*)p.imp;      // (no probe rows: nothing is probed; the kernel's unconditional loads read a cell nobody uses)
+    sp.probe_rows64 = (u64)bt->impacts->n_probe * 64ull;
     sp.B = bt->B; sp.T = bt->T; sp.k = bt->k;
     sp.pu = (const unsigned short*)(bt->d_st + L.pu);
     sp.pw = (const float*)(bt->d_st + L.pw);
@@ -860,7 +978,13 @@ int sa_launch_stage(sa_batch* bt, const Bm25Params& p, hipStream_t st) {
     sp.tpx = (sp.n_st + 7u) / 8u;
     const u32 wpx = grid / 8u;
     sp.tpw = (sp.tpx + wpx - 1u) / wpx;
-    if (bt->st_tmax == 4) hipLaunchKernelGGL(sa_k_bm25_stage<4>, dim3(grid), dim3(SA_ST_NT), 0, st, sp);
-    else hipLaunchKernelGGL(sa_k_bm25_stage<8>, dim3(grid), dim3(SA_ST_NT), 0, st, sp);
+    const bool one = bt->st_NS <= (u32)SA_ST_NT;
+    if (bt->st_tmax == 4) {
+        if (one) hipLaunchKernelGGL((sa_k_bm25_stage<4, 1>), dim3(grid), dim3(SA_ST_NT), 0, st, sp);
+        else hipLaunchKernelGGL((sa_k_bm25_stage<4, 2>), dim3(grid), dim3(SA_ST_NT), 0, st, sp);
+    } else {
+        if (one) hipLaunchKernelGGL((sa_k_bm25_stage<8, 1>), dim3(grid), dim3(SA_ST_NT), 0, st, sp);
+        else hipLaunchKernelGGL((sa_k_bm25_stage<8, 2>), dim3(grid), dim3(SA_ST_NT), 0, st, sp);
+    }
     return SA_OK;
 }
