@@ -42,6 +42,7 @@ sa_impacts::~sa_impacts() {
     if (d_topf) hipFree(d_topf);
     if (d_maxf) hipFree(d_maxf);
     if (d_probe) hipFree(d_probe);
+    if (d_pbits) hipFree(d_pbits);
 }
 
 // dense factor row of one term (sa_impacts::d_dense): row[doc] = factor bits of the term's posting of doc; the row is zeroed before

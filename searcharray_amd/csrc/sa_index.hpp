@@ -93,6 +93,9 @@ struct sa_impacts {
     // is not streamed at all: the few documents that survive the bound test on the query's other terms read its factor with
     // one 4-byte load from its row.  Built by the first batch that plans the route.
     float* d_probe = nullptr;
+    u32* d_pbits = nullptr;         // presence bitmaps of the same terms: [n_probe][pbits_words] (bit doc & 31 of word doc >> 5) -- what a tile of the
+                                    // staged-tile kernel stages of a probed term, so that only the documents that HOLD it wait for a probe
+    u64 pbits_words = 0;            // words per bitmap row (n_docs / 32 rounded up to 32 words)
     u64 probe_stride = 0;           // floats per row (n_docs rounded up to 64)
     std::vector<u32> probe_slot;    // [n_terms] row of a term, or 0xFFFFFFFF (host)
     u32 n_probe = 0;

@@ -49,7 +49,7 @@
 #define SA_ST_NT 512            // threads per workgroup
 #define SA_ST_UMAX 768          // distinct terms of a query set
 #define SA_ST_BMAX 256          // queries of a query set
-#define SA_ST_CCAP 768          // finalists that wait for stage C
+#define SA_ST_BW 32             // words of such a bitmap (tiles of at most 1024 docs)
 #define SA_ST_REF 64            // queries whose bound is re-derived at the end of a tile pass
 #define SA_ST_NONE 0xFFFFu      // "no term" in the queries' term tables
 #define SA_ST_PROBE 0xFFFFu     // s_off: the term is not staged; its factors are probed in its probe row (high half: the row)
@@ -57,7 +57,10 @@
 #define SA_ST_MARGIN 1.0000153f // 1 + 2^-16: covers the fp32 roundings of a sum of up to 8 non-negative terms taken in another order
 
 // 8-byte cells an LDS stage holds (TMAX = 4: the BASELINE shape; 8: wider query tables, smaller stage); two workgroups per CU
-template <int TMAX> struct SaStCap { static constexpr int v = TMAX <= 4 ? 3584 : 1536; };
+template <int TMAX> struct SaStCap { static constexpr int v = TMAX <= 4 ? 2304 : 1024; };
+// probed terms whose presence bitmap a tile stages; finalists that wait for stage C
+template <int TMAX> struct SaStNpb { static constexpr int v = TMAX <= 4 ? 128 : 64; };
+template <int TMAX> struct SaStCcap { static constexpr int v = TMAX <= 4 ? 384 : 192; };
 
 struct alignas(16) StTerm {
     u64 cell0;                  // first cell of the term in the impact stream
@@ -77,6 +80,8 @@ struct StageParams {
     u64 n_docs, doc_base;
     const StTerm* terms; u32 U, NS;       // distinct terms; the first NS are staged, the others probed
     const float* probe; u64 probe_rows64; // probe rows (interleaved: sa_probe_cell), rows x 64
+    const u32* pbits; u32 pbits_words, pbits_bytes;     // their presence bitmaps: words per row, bytes in all
+    u32 NPB;                              // probed terms whose bitmap the tiles stage (the first NPB of them)
     u32 B, T, k;
     const unsigned short* pu;             // [B][T] distinct-term index of the query's term at POSITION i (staged terms by descending bound, then the probed ones), SA_ST_NONE: absent
     const float* pw;                      // [B][T] its weight
@@ -168,10 +173,12 @@ static std::shared_ptr<sa_stagedir> sa_stagedir_get(sa_index* ix, sa_impacts* im
 // few pages, not one per row: with row-major rows of 40 MB each the probes were page-table walks)
 __device__ __host__ __forceinline__ u64 sa_probe_cell(u32 row, u64 doc, u64 rows64) { return (doc >> 6) * rows64 + ((u64)row << 6) + (doc & 63ull); }
 __global__ void __launch_bounds__(256)
-sa_k_make_probe_row(const u64* __restrict__ imp, u64 first, u64 df, u32 row, u64 rows64, float* __restrict__ probe) {
+sa_k_make_probe_row(const u64* __restrict__ imp, u64 first, u64 df, u32 row, u64 rows64, float* __restrict__ probe, u32* __restrict__ bits) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < df; i += (u64)gridDim.x * blockDim.x) {
         const u64 c = imp[first + i];
-        probe[sa_probe_cell(row, (u64)((u32)(c >> 32) >> 2), rows64)] = __uint_as_float((u32)c);
+        const u32 doc = (u32)(c >> 32) >> 2;
+        probe[sa_probe_cell(row, (u64)doc, rows64)] = __uint_as_float((u32)c);
+        atomicOr(&bits[doc >> 5], 1u << (doc & 31u));
     }
 }
 
@@ -196,10 +203,14 @@ static void sa_probe_rows_ensure(sa_index* ix, sa_impacts* im, const sa_options_
     if (cand.size() > max_rows) cand.resize(max_rows);
     if (cand.empty()) return;
     const size_t bytes = cand.size() * im->probe_stride * sizeof(float);
+    im->pbits_words = (((ix->n_docs + 31ull) >> 5) + 31ull) & ~31ull;
+    const size_t bbytes = cand.size() * im->pbits_words * sizeof(u32);
     hipStream_t st = ix->stream;
-    if (hipMalloc(&im->d_probe, bytes) != hipSuccess || hipMemsetAsync(im->d_probe, 0, bytes, st) != hipSuccess) {
+    if (hipMalloc(&im->d_probe, bytes) != hipSuccess || hipMemsetAsync(im->d_probe, 0, bytes, st) != hipSuccess ||
+        hipMalloc(&im->d_pbits, bbytes) != hipSuccess || hipMemsetAsync(im->d_pbits, 0, bbytes, st) != hipSuccess) {
         (void)hipGetLastError();
         if (im->d_probe) { (void)hipFree(im->d_probe); im->d_probe = nullptr; }
+        if (im->d_pbits) { (void)hipFree(im->d_pbits); im->d_pbits = nullptr; }
         return;
     }
     for (size_t r = 0; r < cand.size(); r++) {
@@ -207,12 +218,13 @@ static void sa_probe_rows_ensure(sa_index* ix, sa_impacts* im, const sa_options_
         const u64 df = cand[r].first;
         const u32 grid = df / 256 + 1 < 8192 ? (u32)(df / 256 + 1) : 8192u;
         hipLaunchKernelGGL(sa_k_make_probe_row, dim3(grid), dim3(256), 0, st, (const u64*)im->d_imp, sa_imp_base(ix->h_tf_off[t], t), df,
-                           (u32)r, (u64)cand.size() * 64ull, im->d_probe);
+                           (u32)r, (u64)cand.size() * 64ull, im->d_probe, im->d_pbits + r * im->pbits_words);
         im->probe_slot[t] = (u32)r;
     }
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(im->d_probe); im->d_probe = nullptr;
+        (void)hipFree(im->d_pbits); im->d_pbits = nullptr;
         im->probe_slot.assign(ix->n_terms, 0xFFFFFFFFu);
         return;
     }
@@ -327,9 +339,9 @@ int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* ro
     const double cap = tmax == 4 ? (double)SaStCap<4>::v : (double)SaStCap<8>::v;
     const double per_doc = (double)dfsum / (double)ix->n_docs;
     u32 docs = 0;
-    if (sa_opt_is_set(bt->opts.stage_docs)) docs = (u32)std::min<long long>(4096, std::max<long long>(64, bt->opts.stage_docs)) / 64u * 64u;
+    if (sa_opt_is_set(bt->opts.stage_docs)) docs = (u32)std::min<long long>(1024, std::max<long long>(64, bt->opts.stage_docs)) / 64u * 64u;
     else {
-        static const u32 sizes[] = {4096, 3072, 2048, 1536, 1024, 768, 512, 384, 256, 192, 128, 64};
+        static const u32 sizes[] = {1024, 768, 512, 384, 256, 128, 64};
         const u64 wgs = (u64)ix->n_cus * (u64)std::max<long long>(1, sa_opt(bt->opts.stage_wgs, 2));
         for (u32 s : sizes) {
             if (per_doc * s + 4.0 * sqrt(per_doc * s) > 0.97 * cap) continue;
@@ -456,6 +468,7 @@ extern "C" int sa_debug_stage_probe_read(unsigned long long* out16, int clear) {
 #endif
 
 typedef unsigned int sa_v2u __attribute__((vector_size(8)));
+typedef unsigned int sa_v4u __attribute__((vector_size(16)));
 struct alignas(8) StChunk { u32 dc, off; };    // a copy chunk: first stage cell | postings (1 .. 8) << 13; byte offset of its first posting from the stream base
 
 // KT: staged terms per thread (1: up to SA_ST_NT staged terms, the usual case; 2: up to SA_ST_UMAX)
@@ -463,9 +476,10 @@ template <int TMAX, int KT>
 __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams sp) {
     constexpr int CAP = SaStCap<TMAX>::v;
     constexpr int NT = SA_ST_NT, NW = NT / SA_WAVE;
+    constexpr int NPBMAX = SaStNpb<TMAX>::v, CCAP = SaStCcap<TMAX>::v;
     constexpr int NCH = CAP / 8 + (KT == 1 ? SA_ST_NT : SA_ST_UMAX);   // 8-posting chunks a stage can hold at most (a partly filled one per staged term)
     constexpr int NWL = 1024;                                    // candidates per round of stage A (its survivors fit s_b)
-    constexpr int KB = 10;                                       // chunk loads a lane issues before it waits
+    constexpr int KB = 8;                                        // chunk loads a lane issues before it waits
     static_assert(KT == 1 || KT == 2, "one or two staged terms per thread");
     static_assert(SA_ST_UMAX <= CAP, "a single document's postings must fit the stage");
     static_assert(CAP <= 8192 && SA_ST_UMAX <= 1024, "13-bit stage cells in a chunk descriptor");
@@ -479,9 +493,10 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
     __shared__ alignas(16) float s_psfx[SA_ST_BMAX * TMAX];     //   what the positions >= i can add in THIS tile (with the margin)
     __shared__ u32 s_thr[SA_ST_BMAX];
     __shared__ u32 s_b[NWL];                                    // records of the candidates that pass stage A
-    __shared__ u32 s_c[SA_ST_CCAP * (2 + TMAX)];                // finalists: query, doc key, contributions by position
+    __shared__ u32 s_c[CCAP * (2 + TMAX)];                // finalists: query, doc key, contributions by position
     __shared__ unsigned short s_cum[SA_ST_BMAX * TMAX];         // per query: candidates of the essential positions <= i
     __shared__ u32 s_qoff[SA_ST_BMAX + 1];                      // per query: its first candidate
+    __shared__ alignas(16) u32 s_bits[NPBMAX * SA_ST_BW];   // presence bitmaps of the probed terms, this tile's docs
     __shared__ u32 s_ref[SA_ST_REF];
     __shared__ u32 s_nref, s_nb, s_nc;
     __shared__ u32 s_red[4 * NW];
@@ -491,6 +506,7 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
     // address arithmetic, no address register pairs), and a lane without an item passes an offset past the end and reads 0.
     const __amdgpu_buffer_rsrc_t r_imp = __builtin_amdgcn_make_buffer_rsrc((void*)(sp.imp + sp.cell_base), 0, (int)sp.imp_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_cm = __builtin_amdgcn_make_buffer_rsrc((void*)sp.cm, 0, (int)sp.cm_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_bits = __builtin_amdgcn_make_buffer_rsrc((void*)(sp.pbits ? (const void*)sp.pbits : (const void*)sp.imp), 0, (int)sp.pbits_bytes, 0x00020000);
     auto cell_at = [&](u32 boff) -> u64 { const sa_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r_imp, boff, 0, 0); return ((u64)v[1] << 32) | (u64)v[0]; };
     auto key_at = [&](u32 boff) -> u32 { return __builtin_amdgcn_raw_buffer_load_b32(r_imp, boff + 4u, 0, 0); };      // (the doc key of a cell: its high word)
 #ifdef SA_PROBE
@@ -559,6 +575,22 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
         pcmi = t.row * sp.n_st + t_begin;
         pnx = __builtin_amdgcn_raw_buffer_load_b32(r_cm, pcmi << 2, 0, 0);
     }
+    // presence bitmaps of the first NPB probed terms: this thread's two 16-byte pieces of a tile's bitmaps (which term, which
+    // 128 docs of the tile: the same for every tile)
+    u32 bro[2];
+    const u32 p4n = sp.docs >> 7;
+    auto bdst_of = [&](u32 y) -> u32 { const u32 r = y / (p4n ? p4n : 1u); return r * (u32)(SA_ST_BW / 4) + (y - r * p4n); };   // (16-byte cell of piece y in s_bits)
+    {
+        const u32 n_bp = sp.NPB * p4n;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const u32 y = (u32)i * NT + tid;
+            const bool have = y < n_bp;
+            const u32 yy = have ? y : 0u;
+            const u32 r = yy / (p4n ? p4n : 1u), c = yy - r * p4n;
+            bro[i] = have ? (sp.terms[NS + r].probe * sp.pbits_words + 4u * c) << 2 : 0xFFFFFFF0u;
+        }
+    }
     // ---- stage C: the finalists waiting in s_c -- the probed terms' factors from their probe rows, the exact score, the query's
     //      candidate list.  Block-uniform; called when the list is nearly full and at the end.
     auto flush_finalists = [&]() {
@@ -568,7 +600,7 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
             const u32 z = z0 + tid;
             const bool havez = z < nc;
             const u32* const c = s_c + (havez ? z : 0u) * (2u + (u32)TMAX);
-            const u32 fq = c[0], fd4 = c[1];
+            const u32 fq = c[0] & 0xFFu, fmask = c[0] >> 8, fd4 = c[1];
             const u32 qb = fq * (u32)TMAX;
             const u32 doc_l = fd4 >> 2;
             float fx[TMAX], pw[TMAX], pv[TMAX];
@@ -579,7 +611,7 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                 fx[i] = __uint_as_float(c[2 + i]);
                 const u32 u = s_pu[qb + (u32)i];
                 const u32 pk = s_off[u != SA_ST_NONE ? u : 0u];
-                isp[i] = havez && u != SA_ST_NONE && (pk & 0xFFFFu) == SA_ST_PROBE;
+                isp[i] = havez && ((fmask >> i) & 1u) != 0u;
                 pw[i] = s_pw[qb + (u32)i];
                 pv[i] = sp.probe[isp[i] ? sa_probe_cell(pk >> 16, (u64)doc_l, sp.probe_rows64) : 0ull];
             }
@@ -736,33 +768,27 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                 pnx = __builtin_amdgcn_raw_buffer_load_b32(r_cm, NS + tid < U ? pcmi << 2 : 0xFFFFFFF0u, 0, 0);
                 g_raw = __hip_atomic_load(&sp.gthr[hasq ? tid : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            // ---- stage: eight lanes per chunk.  A lane issues all its loads (KB) before it waits for the first; a lane without an
-            //      item reads past the end (0) and writes nothing.
-            {
-                const u32 grp = tid >> 3, sub = tid & 7u;
-                u32 x0 = 0;
-                do {                                                    // (uniform: one round unless the tile has more than KB * 64 chunks)
-                    u64 v[KB]; u32 dst[KB];
+            // ---- stage: eight lanes per chunk (and 16 bytes per lane of the probed terms' presence bitmaps).  A lane issues all its
+            //      loads before it waits for the first; a lane without an item reads past the end (0) and writes nothing.  While the
+            //      loads are in flight the QUERY PHASE runs (it needs the slices' sizes and bounds, not the postings).
+            const u32 grp = tid >> 3, sub = tid & 7u;
+            sa_v4u bv[2];
+            u64 v[KB]; u32 dst[KB];
 #pragma unroll
-                    for (int i = 0; i < KB; i++) {
-                        const u32 x = x0 + (u32)i * (NT / 8) + grp;
-                        const StChunk d = s_cd[x < NC ? x : 0u];
-                        const bool ok = x < NC && sub < (d.dc >> 13);
-                        dst[i] = ok ? (d.dc & 0x1FFFu) + sub : 0xFFFFFFFFu;
-                        v[i] = cell_at(ok ? d.off + (sub << 3) : 0xFFFFFFF0u);
-                    }
-                    SA_SPT(3);
+            for (int i = 0; i < 2; i++)
+                bv[i] = __builtin_amdgcn_raw_buffer_load_b128(r_bits, bro[i] == 0xFFFFFFF0u ? 0xFFFFFFF0u : bro[i] + ((u32)(tile_d0 >> 5) << 2), 0, 0);
 #pragma unroll
-                    for (int i = 0; i < KB; i++) if (dst[i] != 0xFFFFFFFFu) s_post[dst[i]] = v[i];
-                    x0 += (u32)(KB * (NT / 8));
-                } while (x0 < NC);
+            for (int i = 0; i < KB; i++) {
+                const u32 x = (u32)i * (NT / 8) + grp;
+                const StChunk d = s_cd[x < NC ? x : 0u];
+                const bool ok = x < NC && sub < (d.dc >> 13);
+                dst[i] = ok ? (d.dc & 0x1FFFu) + sub : 0xFFFFFFFFu;
+                v[i] = cell_at(ok ? d.off + (sub << 3) : 0xFFFFFFF0u);
             }
-            SA_SPT(4);
-            __syncthreads();
-            SA_SPT(5);
+            SA_SPT(3);
             // ---- the queries: bound; what every position can add at most in THIS tile (weight x bound of the term's factors here);
-            //      essential positions; their postings are the candidates.  (Branch-free, the LDS reads in three batches: a read
-            //      inside a branch is waited for on the spot.)
+            //      essential positions; their postings are the candidates.  (Branch-free, the LDS reads in batches: a read inside a
+            //      branch is waited for on the spot.)
             u32 ncand = 0;
             if (hasq) {
                 const u32 qb = tid * (u32)TMAX;
@@ -806,6 +832,26 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                 parity ^= 1u;
                 if (tid < (u32)SA_ST_BMAX) s_qoff[tid] = hasq ? e0 : 0xFFFFFFFFu;
             }
+            SA_SPT(4);
+            // ---- the stage's loads land
+#pragma unroll
+            for (int i = 0; i < 2; i++) if (bro[i] != 0xFFFFFFF0u) ((sa_v4u*)s_bits)[bdst_of((u32)i * NT + tid)] = bv[i];
+#pragma unroll
+            for (int i = 0; i < KB; i++) if (dst[i] != 0xFFFFFFFFu) s_post[dst[i]] = v[i];
+            for (u32 x0 = (u32)(KB * (NT / 8)); x0 < NC; x0 += (u32)(KB * (NT / 8))) {       // (uniform: a tile with more than KB * 64 chunks, hardly ever)
+                u64 v2[KB]; u32 dst2[KB];
+#pragma unroll
+                for (int i = 0; i < KB; i++) {
+                    const u32 x = x0 + (u32)i * (NT / 8) + grp;
+                    const StChunk d = s_cd[x < NC ? x : 0u];
+                    const bool ok = x < NC && sub < (d.dc >> 13);
+                    dst2[i] = ok ? (d.dc & 0x1FFFu) + sub : 0xFFFFFFFFu;
+                    v2[i] = cell_at(ok ? d.off + (sub << 3) : 0xFFFFFFF0u);
+                }
+#pragma unroll
+                for (int i = 0; i < KB; i++) if (dst2[i] != 0xFFFFFFFFu) s_post[dst2[i]] = v2[i];
+            }
+            SA_SPT(5);
             SA_SPT(6);
             __syncthreads();
             SA_SPT(7);
@@ -832,11 +878,27 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
 #pragma unroll
                     for (int c = 0; c < TMAX - 1; c++) { const u32 cc = s_cum[qb + (u32)c]; const bool ge = r >= cc; i = ge ? (u32)c + 1u : i; base = ge ? cc : base; }
                     const u32 j = r - base;
-                    const u32 u_src = s_pu[qb + i];
-                    const float w_src = s_pw[qb + i];
-                    const float f_src = __uint_as_float((u32)s_post[(s_off[u_src] >> 16) + j]);
-                    const float rem = s_psfx[qb] - __fmul_rn(__uint_as_float(s_tmax[u_src]), w_src);
-                    const bool alive = valid && !(__fmul_rn(__fadd_rn(__fmul_rn(f_src, w_src), rem), SA_ST_MARGIN) < __uint_as_float(s_thr[q]));
+                    u32 up[TMAX]; float wp[TMAX];
+#pragma unroll
+                    for (int c = 0; c < TMAX; c++) { up[c] = s_pu[qb + (u32)c]; wp[c] = s_pw[qb + (u32)c]; }
+                    u32 u_src = 0; float w_src = 0.f;
+#pragma unroll
+                    for (int c = 0; c < TMAX; c++) if ((u32)c == i) { u_src = up[c]; w_src = wp[c]; }
+                    const u64 vsrc = s_post[(s_off[u_src] >> 16) + j];
+                    const u32 od = ((u32)(vsrc >> 32) >> 2) - (u32)tile_d0;
+                    // what the other terms can add: all of them in this tile, less the probed terms the doc does not hold (presence bitmaps)
+                    float rem = s_psfx[qb] - __fmul_rn(__uint_as_float(s_tmax[u_src]), w_src);
+                    u32 tmp[TMAX], bwp[TMAX];
+#pragma unroll
+                    for (int c = 0; c < TMAX; c++) {
+                        const bool pr = up[c] != SA_ST_NONE && up[c] >= NS && up[c] - NS < sp.NPB;
+                        const u32 slot = pr ? up[c] - NS : 0u;
+                        tmp[c] = s_tmax[pr ? up[c] : 0u];
+                        bwp[c] = pr ? s_bits[slot * (u32)SA_ST_BW + (od >> 5)] : 0xFFFFFFFFu;
+                    }
+#pragma unroll
+                    for (int c = 0; c < TMAX; c++) rem -= ((bwp[c] >> (od & 31u)) & 1u) ? 0.f : __fmul_rn(__uint_as_float(tmp[c]), wp[c]);
+                    const bool alive = valid && !(__fmul_rn(__fadd_rn(__fmul_rn(__uint_as_float((u32)vsrc), w_src), rem), SA_ST_MARGIN) < __uint_as_float(s_thr[q]));
                     SA_SPT(13);
                     const u64 m = (u64)__builtin_amdgcn_ballot_w64(alive);
                     if (m) {                                        // (wave-uniform)
@@ -855,55 +917,94 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                 //      descending-bound order, as long as what is known plus what the remaining terms can add reaches the bound;
                 //      the documents that get through are the FINALISTS (s_c: query, doc, the contributions found).  They wait
                 //      there -- across rounds and tiles -- until the list is nearly full: stage C (flush_finalists).
-                for (u32 y0 = 0; y0 < nb; y0 += NT) {            // (uniform)
-                    if (s_nc + NT > (u32)SA_ST_CCAP) flush_finalists();     // (uniform: s_nc only changes between barriers)
+                for (u32 y0 = 0; y0 < nb; ) {                    // (uniform)
+                    // (a round takes as many survivors as s_c has room for finalists: s_nc only changes between barriers)
+                    const u32 want = nb - y0 < (u32)NT ? nb - y0 : (u32)NT;
+                    if ((u32)CCAP - s_nc < want && s_nc) flush_finalists();
+                    const u32 room = (u32)CCAP - s_nc;
+                    const u32 cnt = want < room ? want : room;
                     SA_SPT(16);
                     const u32 y = y0 + tid;
-                    bool fin = false;
-                    u32 q = 0, d4 = 0;
-                    float xs[TMAX];                                 // the terms' contributions, by position
+                    // (branch-free, the searches of the query's staged terms IN LOCKSTEP: every LDS read of a step is issued before the
+                    //  first is looked at -- one term after the other, with an early exit between them, was a chain of ~35 dependent
+                    //  LDS round trips per survivor)
+                    const bool act = tid < cnt;
+                    const u32 rec = s_b[act ? y : 0u];
+                    const u32 q = rec & 0xFFu, i_src = (rec >> 8) & 7u, j = rec >> 11;
+                    const u32 qb = q * (u32)TMAX;
+                    u32 up[TMAX]; float wp[TMAX], sfxp[TMAX];
 #pragma unroll
-                    for (int i = 0; i < TMAX; i++) xs[i] = 0.f;
-                    if (y < nb) {
-                        const u32 rec = s_b[y];
-                        q = rec & 0xFFu;
-                        const u32 i_src = (rec >> 8) & 7u, j = rec >> 11;
-                        const u32 qb = q * (u32)TMAX;
-                        const float thr_f = __uint_as_float(s_thr[q]);
-                        const u32 u_src = s_pu[qb + i_src];
-                        const u64 v = s_post[(s_off[u_src] >> 16) + j];
-                        d4 = (u32)(v >> 32);
-                        const float w_src = s_pw[qb + i_src];
-                        float known = __fmul_rn(__uint_as_float((u32)v), w_src);
-                        const float ub_src = __fmul_rn(__uint_as_float(s_tmax[u_src]), w_src);
-                        bool alive = true;
-                        float pend = 0.f;                           // what the probed terms can add at most
+                    for (int i = 0; i < TMAX; i++) { up[i] = s_pu[qb + (u32)i]; wp[i] = s_pw[qb + (u32)i]; sfxp[i] = s_psfx[qb + (u32)i]; }
+                    const float thr_f = __uint_as_float(s_thr[q]);
+                    u32 pk[TMAX], tmx[TMAX];
+#pragma unroll
+                    for (int i = 0; i < TMAX; i++) { const u32 uu = up[i] != SA_ST_NONE ? up[i] : 0u; pk[i] = s_off[uu]; tmx[i] = s_tmax[uu]; }
+                    u32 pk_src = 0; float w_src = 0.f, ub_src = 0.f;
+#pragma unroll
+                    for (int i = 0; i < TMAX; i++) if ((u32)i == i_src) { pk_src = pk[i]; w_src = wp[i]; ub_src = __fmul_rn(__uint_as_float(tmx[i]), wp[i]); }
+                    const u64 vsrc = s_post[(pk_src >> 16) + j];
+                    const u32 d4 = (u32)(vsrc >> 32);
+                    const u32 od = (d4 >> 2) - (u32)tile_d0;
+                    const float known0 = __fmul_rn(__uint_as_float((u32)vsrc), w_src);
+                    // the staged terms other than the candidate's own: the last posting <= the doc, by halving
+                    bool stg[TMAX], prb[TMAX];
+                    u32 base[TMAX], len[TMAX];
+                    u32 anylen = 0;
+#pragma unroll
+                    for (int i = 0; i < TMAX; i++) {
+                        const bool have = up[i] != SA_ST_NONE && (u32)i != i_src;
+                        prb[i] = have && (pk[i] & 0xFFFFu) == SA_ST_PROBE;
+                        stg[i] = have && !prb[i] && (pk[i] & 0xFFFFu) != 0u;
+                        base[i] = stg[i] ? pk[i] >> 16 : 0u;
+                        len[i] = stg[i] ? pk[i] & 0xFFFFu : 0u;
+                        anylen |= act ? len[i] : 0u;
+                    }
+                    const u32* const key32 = (const u32*)s_post;
+                    while (__builtin_amdgcn_ballot_w64(anylen > 1u)) {   // (wave-uniform: as many steps as the longest slice needs)
+                        u32 kk[TMAX];
+#pragma unroll
+                        for (int i = 0; i < TMAX; i++) kk[i] = key32[2u * (base[i] + (len[i] >> 1)) + 1u];
+                        anylen = 0;
 #pragma unroll
                         for (int i = 0; i < TMAX; i++) {
-                            if ((u32)i == i_src) xs[i] = known;
-                            else if (alive) {
-                                const u32 u = s_pu[qb + (u32)i];
-                                if (u != SA_ST_NONE) {
-                                    const u32 pk = s_off[u];
-                                    if ((pk & 0xFFFFu) == SA_ST_PROBE) pend = __fadd_rn(pend, __fmul_rn(__uint_as_float(s_tmax[u]), s_pw[qb + (u32)i]));
-                                    else {
-                                        // what the positions from i on can still add (the candidate's own term is already in `known`)
-                                        const float rem = s_psfx[qb + (u32)i] - ((u32)i < i_src ? ub_src : 0.f);
-                                        if (__fmul_rn(__fadd_rn(known, rem), SA_ST_MARGIN) < thr_f) alive = false;
-                                        else {
-                                            bool found;
-                                            const float f = sa_st_lookup(s_post, pk, d4, found);
-                                            if (found) {
-                                                if ((u32)i < i_src) alive = false;   // the doc is the candidate of that (essential, higher) position
-                                                else { xs[i] = __fmul_rn(f, s_pw[qb + (u32)i]); known = __fadd_rn(known, xs[i]); }
-                                            }
-                                        }
-                                    }
-                                }
+                            const u32 half = len[i] >> 1;
+                            base[i] += kk[i] <= d4 ? half : 0u;
+                            len[i] -= half;
+                            anylen |= len[i];
+                        }
+                    }
+                    u64 cell[TMAX]; u32 bw[TMAX];
+#pragma unroll
+                    for (int i = 0; i < TMAX; i++) {
+                        cell[i] = s_post[base[i]];
+                        const u32 slot = prb[i] ? up[i] - NS : 0u;
+                        bw[i] = s_bits[(slot < sp.NPB ? slot : 0u) * (u32)SA_ST_BW + (od >> 5)];
+                    }
+                    // in the terms' order: the bound tests, the duplicates, what is known
+                    bool alive = true;
+                    float known = known0, pend = 0.f;               // (pend: what the probed terms the doc holds can add at most)
+                    u32 pmask = 0;                                  // (the probed positions whose term the doc holds)
+                    float xs[TMAX];                                 // the terms' contributions, by position
+#pragma unroll
+                    for (int i = 0; i < TMAX; i++) {
+                        xs[i] = (u32)i == i_src ? known0 : 0.f;
+                        const float ubi = __fmul_rn(__uint_as_float(tmx[i]), wp[i]);
+                        if (prb[i]) {
+                            // a probed term: does the doc hold it (the tile's presence bitmap)?  Then it may add up to its bound, and is probed
+                            const bool may = up[i] - NS >= sp.NPB || ((bw[i] >> (od & 31u)) & 1u) != 0u;
+                            if (alive && may) { pend = __fadd_rn(pend, ubi); pmask |= 1u << i; }
+                        } else if (up[i] != SA_ST_NONE && (u32)i != i_src) {
+                            // what the positions from i on can still add (the candidate's own term is already in `known`)
+                            const float rem = sfxp[i] - ((u32)i < i_src ? ub_src : 0.f);
+                            if (__fmul_rn(__fadd_rn(known, rem), SA_ST_MARGIN) < thr_f) alive = false;
+                            const bool found = stg[i] && (u32)(cell[i] >> 32) == d4;
+                            if (alive && found) {
+                                if ((u32)i < i_src) alive = false;       // the doc is the candidate of that (essential, higher) position
+                                else { xs[i] = __fmul_rn(__uint_as_float((u32)cell[i]), wp[i]); known = __fadd_rn(known, xs[i]); }
                             }
                         }
-                        fin = alive && !(__fmul_rn(__fadd_rn(known, pend), SA_ST_MARGIN) < thr_f);
                     }
+                    const bool fin = act && alive && !(__fmul_rn(__fadd_rn(known, pend), SA_ST_MARGIN) < thr_f);
                     SA_SPT(17);
                     const u64 m = (u64)__builtin_amdgcn_ballot_w64(fin);
                     if (m) {                                        // (wave-uniform)
@@ -912,7 +1013,7 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                         wb = (u32)__builtin_amdgcn_readlane((int)wb, (int)__builtin_ctzll(m));
                         if (fin) {
                             u32* const c = s_c + (wb + (u32)__popcll(m & ltmask)) * (2u + (u32)TMAX);
-                            c[0] = q; c[1] = d4;
+                            c[0] = q | (pmask << 8); c[1] = d4;
 #pragma unroll
                             for (int i = 0; i < TMAX; i++) c[2 + i] = __float_as_uint(xs[i]);
                         }
@@ -920,6 +1021,7 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                     SA_SPT(18);
                     __syncthreads();
                     SA_SPT(19);
+                    y0 += cnt;
                 }
                 if (tid == 0) s_nb = 0u;
                 __syncthreads();
@@ -963,6 +1065,9 @@ int sa_launch_stage(sa_batch* bt, const Bm25Params& p, hipStream_t st) {
     sp.terms = (const StTerm*)(bt->d_st + L.terms); sp.U = bt->st_U; sp.NS = bt->st_NS;
     sp.probe = bt->impacts->d_probe ? bt->impacts->d_probe : (const float*)p.imp;      // (no probe rows: nothing is probed; the kernel's unconditional loads read a cell nobody uses)
     sp.probe_rows64 = (u64)bt->impacts->n_probe * 64ull;
+    sp.pbits = bt->impacts->d_pbits; sp.pbits_words = (u32)bt->impacts->pbits_words;
+    sp.pbits_bytes = bt->impacts->d_pbits ? (u32)std::min<u64>(0xFFFFFFE0ull, (u64)bt->impacts->n_probe * bt->impacts->pbits_words * 4ull) : 16u;
+    sp.NPB = bt->impacts->d_pbits && bt->st_docs <= 1024u && bt->st_docs % 128u == 0u ? std::min<u32>(bt->st_U - bt->st_NS, bt->st_tmax == 4 ? (u32)SaStNpb<4>::v : (u32)SaStNpb<8>::v) : 0u;
     sp.B = bt->B; sp.T = bt->T; sp.k = bt->k;
     sp.pu = (const unsigned short*)(bt->d_st + L.pu);
     sp.pw = (const float*)(bt->d_st + L.pw);
