@@ -118,6 +118,7 @@ struct sa_batch {
     bool bounds_valid = false;      // d_bounds / d_qbase / d_qbase_imp hold the current query set's slice table (the staged route does not need it)
     u32 st_U = 0, st_NS = 0;        // distinct terms of the query set; the first st_NS are staged, the others probed in their probe rows
     u32 st_docs = 0;                // docs per stage tile
+    float st_cand_per_doc = 0.f;    // candidates (postings of essential terms) per document the plan expects, all queries together
     u32 st_imp_bytes = 0;           // bytes of the stream from st_cell_base to the end of the set's last term
     u64 st_cell_base = 0;           // smallest impact-stream cell of the set's terms (the kernel's 32-bit offsets count from it)
     u32 st_tmax = 4;                // kernel instantiation: 4 or 8 terms per query

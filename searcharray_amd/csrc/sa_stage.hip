@@ -47,7 +47,7 @@
 #include <unordered_map>
 
 #define SA_ST_NT 512            // threads per workgroup
-#define SA_ST_UMAX 768          // distinct terms of a query set
+#define SA_ST_UMAX 1024         // distinct terms of a query set
 #define SA_ST_BMAX 256          // queries of a query set
 #define SA_ST_BW 32             // words of such a bitmap (tiles of at most 1024 docs)
 #define SA_ST_REF 64            // queries whose bound is re-derived at the end of a tile pass
@@ -290,6 +290,7 @@ int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* ro
     for (int i = SA_TOPF_NR - 1; i >= 0; i--) if (sa_topf_ranks[i] >= bt->k) rank_idx = (u32)i;
     const float seed_scale = (float)sa_opt(bt->opts.seed_scale_pct, 100) / 100.f;
     std::vector<float> ubs((size_t)B * T, 0.f), seeds(B, 0.f);
+    double cand_df = 0.0;
     std::vector<unsigned char> probed((size_t)B * T, 0);
     for (u32 q = 0; q < B; q++) {
         float seed = 0.f;
@@ -302,6 +303,18 @@ int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* ro
             if (sd1 > seed) seed = sd1;
         }
         seeds[q] = seed;
+        {
+            // the candidates this query has to expect: the postings of the terms that its starting bound leaves essential
+            u32 os[8];
+            for (u32 s = 0; s < T; s++) os[s] = s;
+            std::stable_sort(os, os + T, [&](u32 a, u32 c) { return ubs[(size_t)q * T + a] < ubs[(size_t)q * T + c]; });
+            float sf = 0.f;
+            for (u32 j = 0; j < T; j++) {
+                const u32 t = row_terms[(size_t)q * T + os[j]];
+                sf += ubs[(size_t)q * T + os[j]];
+                if (t < ix->n_terms && !(seed > 0.f && sf * SA_ST_MARGIN < seed)) cand_df += (double)dist[idx[t]].df;
+            }
+        }
         if (!(seed > 0.f)) continue;
         // candidates for probing: smallest bound first
         u32 cs[8]; u32 nc = 0;
@@ -394,7 +407,23 @@ int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* ro
         u32 sb; memcpy(&sb, &seeds[q], 4);
         h_seed[q] = seeds[q] > 0.f ? sb : 0u;
     }
+    // Unless the caller forces the route (option stage = 1): only where it was measured ahead of the grouped overlay kernel
+    // (scripts/gpu_r6_stage4.sh, profiles/route_rule_r06.jsonl; 10 M docs, 256 queries): few candidates per document at small k --
+    // the BASELINE set up to k = 32 (1.8 .. 2.1 candidates per doc: 0.24 / 0.28 / 0.35 ms against 0.38 / 0.38 / 0.39), not at k = 100
+    // (2.3: 0.47 against 0.42) or k = 1000; not the pairwise-distinct set (3.7 per doc and 768 staged terms: 0.97 against 0.46) --
+    // or a handful of staged terms (the `hot` set, 8 staged terms: ahead up to k = 100)
+    const float cpd = (float)(cand_df / (double)ix->n_docs);
+    if (sa_opt(bt->opts.stage, -1) != 1) {
+        const bool few_cands = bt->k <= 32u && cpd <= 2.5f && NS <= (u32)SA_ST_NT;
+        const bool few_terms = bt->k <= 100u && NS <= 32u;
+        if (!few_cands && !few_terms) {
+            if (sa_opt(bt->opts.trace, 0)) fprintf(stderr, "sa_stage_plan: not taken (k = %u, %u staged terms, %.3f candidates per doc expected)\n", bt->k, NS, cpd);
+            return SA_OK;
+        }
+    }
     bt->st_U = U; bt->st_NS = NS; bt->st_docs = docs; bt->st_tmax = tmax;
+    bt->st_cand_per_doc = cpd;
+    if (sa_opt(bt->opts.trace, 0)) fprintf(stderr, "sa_stage_plan: %u terms (%u staged, %u probed), %u docs per tile, %.3f candidates per doc expected\n", U, NS, U - NS, docs, bt->st_cand_per_doc);
     bt->st_cell_base = cell_lo;
     bt->st_imp_bytes = (u32)((cell_hi - cell_lo) * 8ull);
     bt->st_dir = sd;
@@ -657,6 +686,19 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
         __syncthreads();
         SA_SPT(22);
     };
+    // whose candidate number x of a pass is: query | position << 8 | posting of the position's slice << 11 (a search of the queries'
+    // first candidates, then of the query's essential positions)
+    auto owner_of = [&](u32 xx) -> u32 {
+        u32 q = 0;
+#pragma unroll
+        for (int step = SA_ST_BMAX / 2; step >= 1; step >>= 1) q += s_qoff[q + (u32)step] <= xx ? (u32)step : 0u;
+        const u32 qb = q * (u32)TMAX;
+        const u32 r = xx - s_qoff[q];
+        u32 i = 0, base = 0;
+#pragma unroll
+        for (int c = 0; c < TMAX - 1; c++) { const u32 cc = s_cum[qb + (u32)c]; const bool ge = r >= cc; i = ge ? (u32)c + 1u : i; base = ge ? cc : base; }
+        return q | (i << 8) | ((r - base) << 11);
+    };
     __syncthreads();
 
     for (u32 tile = t_begin; tile < t_end; tile++) {
@@ -868,16 +910,10 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                     const u32 x = x0 + tid;
                     const bool valid = x < cend;
                     const u32 xx = valid ? x : c0;
-                    u32 q = 0;
-#pragma unroll
-                    for (int step = SA_ST_BMAX / 2; step >= 1; step >>= 1) q += s_qoff[q + (u32)step] <= xx ? (u32)step : 0u;
+                    const u32 orec = owner_of(xx);
                     SA_SPT(12);
+                    const u32 q = orec & 0xFFu, i = (orec >> 8) & 7u, j = orec >> 11;
                     const u32 qb = q * (u32)TMAX;
-                    const u32 r = xx - s_qoff[q];
-                    u32 i = 0, base = 0;
-#pragma unroll
-                    for (int c = 0; c < TMAX - 1; c++) { const u32 cc = s_cum[qb + (u32)c]; const bool ge = r >= cc; i = ge ? (u32)c + 1u : i; base = ge ? cc : base; }
-                    const u32 j = r - base;
                     u32 up[TMAX]; float wp[TMAX];
 #pragma unroll
                     for (int c = 0; c < TMAX; c++) { up[c] = s_pu[qb + (u32)c]; wp[c] = s_pw[qb + (u32)c]; }

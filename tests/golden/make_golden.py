@@ -8,7 +8,7 @@ Run in the build container only (the GPU box has no /root/reference):
 
 Nothing from the reference is copied into the repo: the fixtures hold seeded synthetic
 inputs (produced by searcharray_amd.synth) and the reference's OUTPUTS on them, plus the
-two of the reference's captured lhs/rhs/mask triples (data files, fixtures/*.npy) with
+reference's captured lhs/rhs/mask triples (data files, fixtures/*.npy) with
 the reference's outputs on them.
 """
 import os
@@ -35,10 +35,14 @@ HEADER_MASK = np.uint64(0xFFFFFFFFFFFC0000)
 LSB_MASK = np.uint64(0x3FFFF)
 
 
+SNP_TAGS = ("128", "24179", "27685", "44358")        # every COMPLETE captured triple under fixtures/ (lhs + rhs + mask)
+SNP_LHS_ONLY = ("185", "45907", "90596")              # captured without an rhs: the one-array primitives only
+
+
 def snp_fixture_goldens():
     """Reference set primitives on its own captured arrays (test/test_snp_ops.py:323-349)."""
     out = {}
-    for tag in ("128", "24179"):
+    for tag in SNP_TAGS:
         lhs = np.load(f"/root/reference/fixtures/lhs_{tag}.npy")
         rhs = np.load(f"/root/reference/fixtures/rhs_{tag}.npy")
         mask = np.load(f"/root/reference/fixtures/mask_{tag}.npy")
@@ -63,6 +67,16 @@ def snp_fixture_goldens():
         out[f"{tag}_bg_lhs_ids"], out[f"{tag}_bg_lhs_counts"], out[f"{tag}_bg_lhs_next"] = ids, cnt, ln
     np.savez_compressed(os.path.join(OUT, "snp_fixtures.npz"), **out)
     print("snp_fixtures.npz", len(out), "arrays")
+    out = {}
+    for tag in SNP_LHS_ONLY:
+        lhs = np.load(f"/root/reference/fixtures/lhs_{tag}.npy")
+        out[f"{tag}_lhs"] = lhs
+        out[f"{tag}_unique36"] = unique(lhs, 36)
+        out[f"{tag}_unique18"] = unique(lhs, 18)
+        k, c = popcount64_reduce(lhs, np.uint64(36), LSB_MASK)
+        out[f"{tag}_pcr_keys"], out[f"{tag}_pcr_counts"] = k, c
+    np.savez_compressed(os.path.join(OUT, "snp_fixtures_lhs.npz"), **out)
+    print("snp_fixtures_lhs.npz", len(out), "arrays")
 
 
 def sparse(a):
@@ -306,9 +320,10 @@ def memmap_goldens():
 
 
 if __name__ == "__main__":
-    only = os.environ.get("ONLY", "")          # "" = everything, or one of: core, edismax, memmap, similarity, encoder
-    if only in ("", "core"):
+    only = os.environ.get("ONLY", "")          # "" = everything, or one of: snp, core, edismax, memmap, similarity, encoder
+    if only in ("", "core", "snp"):
         snp_fixture_goldens()
+    if only in ("", "core"):
         slopq = [([3, 7], 1), ([3, 7], 2), ([0, 1], 2), ([5, 2, 9], 2), ([10, 4], 3), ([1, 0], 1),
                  ([20, 30], 5), ([2, 2], 2), ([8, 1, 3], 4), ([40, 6], 2)]
         corpus_goldens("zipf_small", 1500, 200, 40, 4321, 10, slopq)

@@ -308,6 +308,16 @@ inline int __builtin_amdgcn_readfirstlane(int v) {
     return (int)hipemu::wave_collective(hipemu::OP_FIRST, (uint64_t)(uint32_t)v, 0);
 }
 
+// v_mbcnt_lo / v_mbcnt_hi: base + set bits of the mask half below this lane
+inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned base) {
+    const int lane = __lane_id();
+    return base + (unsigned)__builtin_popcount(lane >= 32 ? mask : (mask & ((1u << lane) - 1u)));
+}
+inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned base) {
+    const int lane = __lane_id();
+    return base + (lane > 32 ? (unsigned)__builtin_popcount(mask & ((1u << (lane - 32)) - 1u)) : 0u);
+}
+
 // buffer resources (raw buffer loads: base + 32-bit byte offset, a read past the end returns 0)
 struct __amdgpu_buffer_rsrc_t { const char* base; unsigned bytes; };
 inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int num_bytes, int) {

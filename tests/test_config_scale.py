@@ -124,3 +124,30 @@ def test_config5_slop2_at_1m_docs(zipf1m):
         if nz.any():
             worst = max(worst, float(np.max(np.abs(s_dev[nz] - s_cpu[nz]) / np.abs(s_cpu[nz]))))
     assert worst <= 1e-5, worst
+
+
+def test_config5_slop2_equals_the_reference_golden(zipf1m):
+    """tests/golden/slop_1m.npz: the REFERENCE's own termfreqs(slop=2) and BM25 top-10 on this corpus (tests/golden/make_slop_1m.py,
+    oracle/_ref) for the 32 queries above and 44 of the bench's, the four heaviest included -- the device's counts bit for bit (sha1 of
+    the float32[1M] vector, plus the sparse pairs where the fixture holds them), its slop scores within 1e-5 relative"""
+    import hashlib
+    from tests.helpers import load_golden
+    dev, _, _, _ = zipf1m
+    g = load_golden("slop_1m")
+    assert [int(x) for x in g["meta"]] == [D, V]
+    for tag in "tb":
+        qs = [[int(x) for x in q] for q in g[f"{tag}_queries"]]
+        pb = dev.phrase_batch(qs, k=10, slop=2)
+        pb.run()
+        ps, _ = pb.fetch()
+        pb.close()
+        for i, ph in enumerate(qs):
+            got = dev.phrase_freqs_dense(ph, slop=2)
+            sha = np.frombuffer(hashlib.sha1(np.ascontiguousarray(got, dtype=np.float32).tobytes()).digest(), dtype=np.uint8)
+            assert np.array_equal(sha, g[f"{tag}{i}_sha1"]), f"slop-2 counts {ph} vs the reference"
+            if f"{tag}{i}_idx" in g.files:
+                nz = np.flatnonzero(got)
+                assert np.array_equal(nz, g[f"{tag}{i}_idx"]) and np.array_equal(got[nz], g[f"{tag}{i}_val"])
+            ws = g[f"{tag}{i}_top_scores"]
+            n = int((ws > 0).sum())
+            assert np.allclose(ps[i, :n], ws[:n], rtol=1e-5, atol=0) and not (ps[i, n:] > 0).any(), f"slop-2 top-10 {ph} vs the reference"

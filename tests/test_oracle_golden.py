@@ -138,7 +138,7 @@ def test_popcount_known_answers():
 
 
 # ---- reference outputs on its own captured arrays
-@pytest.mark.parametrize("tag", ["128", "24179"])
+@pytest.mark.parametrize("tag", ["128", "24179", "27685", "44358"])          # every complete triple the reference captured
 def test_snp_fixtures_match_reference(tag):
     g = load_golden("snp_fixtures")
     lhs, rhs, mask = g[f"{tag}_lhs"], g[f"{tag}_rhs"], np.uint64(g[f"{tag}_mask"])
@@ -162,6 +162,16 @@ def test_snp_fixtures_match_reference(tag):
     (ids, cnt), (ln, _) = O.bigram_freqs(lhs, rhs, O.CONT_LHS)
     assert np.array_equal(ids, g[f"{tag}_bg_lhs_ids"]) and np.array_equal(cnt, g[f"{tag}_bg_lhs_counts"])
     assert np.array_equal(ln, g[f"{tag}_bg_lhs_next"])
+
+
+@pytest.mark.parametrize("tag", ["185", "45907", "90596"])                       # captured without an rhs (fixtures/lhs_*.npy)
+def test_snp_lhs_only_fixtures_match_reference(tag):
+    g = load_golden("snp_fixtures_lhs")
+    lhs = g[f"{tag}_lhs"]
+    assert np.array_equal(O.unique(lhs, 36), g[f"{tag}_unique36"])
+    assert np.array_equal(O.unique(lhs, 18), g[f"{tag}_unique18"])
+    k, c = O.popcount64_reduce(lhs, 36, 0x3FFFF)
+    assert np.array_equal(k, g[f"{tag}_pcr_keys"]) and np.array_equal(c, g[f"{tag}_pcr_counts"])
 
 
 # ---- reference outputs on seeded synthetic corpora
@@ -286,3 +296,55 @@ def test_snp_fixture_goldens_equal_the_built_reference():
         assert np.array_equal(unique(lhs, 36), g[f"{tag}_unique36"]), tag
         keys, counts = popcount64_reduce(lhs, np.uint64(36), lsb_mask)
         assert np.array_equal(keys, g[f"{tag}_pcr_keys"]) and np.array_equal(counts, g[f"{tag}_pcr_counts"]), tag
+
+
+# ---- slop counts at BASELINE config 5's scale: tests/golden/slop_1m.npz = the reference's outputs on zipf-1M ----------------
+def _slop_1m_corpus():
+    from searcharray_amd import synth
+    lens, terms = synth.zipf_batch_tokens(0, 1_000_000, 100_000, fast=True)
+    words, counts = synth.encode_batch(lens, terms, 100_000)
+    words, term_off = synth.concat_term_major([(words, counts)], 100_000)
+    return words, term_off, lens.astype(np.float32)
+
+
+def slop_1m_digest(tf):
+    import hashlib
+    return np.frombuffer(hashlib.sha1(np.ascontiguousarray(tf, dtype=np.float32).tobytes()).digest(), dtype=np.uint8)
+
+
+def test_slop_1m_golden_oracle_port_and_built_reference():
+    """oracle/spans.c (the port the GPU tests and the bench compare with at 1M docs) equals the REFERENCE's slop-2 counts and BM25
+    top-10 on every query of the fixture -- the 32 of test_config_scale.py, 44 of the bench's 256, the four heaviest among them
+    (up to 1.6 M matches); and, where oracle/_ref is built, the reference recomputes the light ones (the heavy ones take it minutes:
+    tests/golden/make_slop_1m.py is the offline job)"""
+    g = load_golden("slop_1m")
+    words, term_off, doc_lens = _slop_1m_corpus()
+    orc = O.OracleIndex(words, np.arange(100_000), term_off, doc_lens, 1_000_000)
+    n = 0
+    for tag in "tb":
+        for i, q in enumerate(g[f"{tag}_queries"]):
+            ph = [int(x) for x in q]
+            tf = orc.phrase_freqs(ph, slop=2)
+            nz = np.flatnonzero(tf)
+            assert len(nz) == int(g[f"{tag}{i}_stat"][0]) and float(tf.sum()) == float(g[f"{tag}{i}_stat"][1]), (tag, i, ph)
+            assert np.array_equal(slop_1m_digest(tf), g[f"{tag}{i}_sha1"]), (tag, i, ph)
+            if f"{tag}{i}_idx" in g.files:
+                assert np.array_equal(nz, g[f"{tag}{i}_idx"]) and np.array_equal(tf[nz], g[f"{tag}{i}_val"])
+            ws, wd = O.topk(orc.score(ph, slop=2), 10)
+            m = int((g[f"{tag}{i}_top_scores"] > 0).sum())
+            assert int((ws > 0).sum()) == m
+            assert np.allclose(ws[:m], g[f"{tag}{i}_top_scores"][:m], rtol=1e-5, atol=0), (tag, i, ph)   # (north_star: slop scores within 1e-5)
+            n += 1
+    assert n >= 72
+    from oracle import ref_loader
+    if ref_loader.available():
+        sa = ref_loader.reference_array(words, term_off, doc_lens)
+        done = 0
+        for tag in "tb":
+            for i, q in enumerate(g[f"{tag}_queries"]):
+                if int(g[f"{tag}{i}_stat"][0]) > 200:
+                    continue
+                tf = np.asarray(sa.termfreqs([f"t{int(x)}" for x in q], slop=2), dtype=np.float32)
+                assert np.array_equal(slop_1m_digest(tf), g[f"{tag}{i}_sha1"]), (tag, i)
+                done += 1
+        assert done >= 40

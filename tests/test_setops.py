@@ -88,7 +88,7 @@ def test_reference_scenarios(api):
     assert len(ops.intersect(u64([]), u64([3]), api=api)[0]) == 0
 
 
-@pytest.mark.parametrize("tag", ["128", "24179"])
+@pytest.mark.parametrize("tag", ["128", "24179", "27685", "44358"])          # every complete triple the reference captured
 def test_reference_fixture_arrays(api, tag):
     g = load_golden("snp_fixtures")
     lhs, rhs, mask = g[f"{tag}_lhs"], g[f"{tag}_rhs"], np.uint64(g[f"{tag}_mask"])
@@ -103,6 +103,19 @@ def test_reference_fixture_arrays(api, tag):
     assert np.array_equal(al, g[f"{tag}_adj_l"]) and np.array_equal(ar, g[f"{tag}_adj_r"])
     assert np.array_equal(ops.merge(lhs, rhs, api=api), g[f"{tag}_merge"])
     assert np.array_equal(ops.merge(lhs, rhs, drop_duplicates=True, api=api), g[f"{tag}_merge_drop"])
+
+
+@pytest.mark.parametrize("tag", ["128", "24179", "27685", "44358", "185", "45907", "90596"])
+def test_reference_fixture_one_array_primitives(api, tag):
+    """unique / popcount64_reduce (reference roaringish/unique.pyx, popcount.pyx) on every captured lhs array, the three captured
+    without an rhs included; expected = the reference's outputs (tests/golden/make_golden.py)"""
+    g = load_golden("snp_fixtures" if tag in ("128", "24179", "27685", "44358") else "snp_fixtures_lhs")
+    lhs = g[f"{tag}_lhs"]
+    assert np.array_equal(ops.unique(lhs, 36, api=api), g[f"{tag}_unique36"])
+    k, c = ops.popcount64_reduce(lhs, 36, 0x3FFFF, api=api)
+    assert np.array_equal(k, g[f"{tag}_pcr_keys"]) and np.array_equal(c, g[f"{tag}_pcr_counts"])
+    if f"{tag}_unique18" in g.files:
+        assert np.array_equal(ops.unique(lhs, 18, api=api), g[f"{tag}_unique18"])
 
 
 def test_all_ones_header_quirk_of_the_drop_variants(api):

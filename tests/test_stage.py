@@ -21,8 +21,11 @@ def corpus():
     return words, rz.term_offsets(wt, VOCAB), lens, O.OracleIndex.from_triples(t, d, p, N_DOCS, doc_lens=lens)
 
 
-def check(api, corpus, queries, k, tile_docs=1024, doc_base=0, expect="staged", runs=2):
+def check(api, corpus, queries, k, tile_docs=1024, doc_base=0, expect="staged", runs=2, force=True):
+    """force: option stage = 1 (the kernel is under test, whatever the library's own rule would pick for the shape)"""
     words, off, lens, orc = corpus
+    if force:
+        set_opt("stage", 1)
     dev = DeviceIndex(words, off, lens, tile_docs=tile_docs, doc_base=doc_base, api=api)
     bt = dev.batch(np.asarray(queries), k=k)
     for _ in range(runs):
@@ -84,13 +87,27 @@ def test_stage_overflow_splits_the_tile(api, corpus):
     check(api, corpus, queries, 10)
 
 
-def test_explicit_sparse_option_keeps_the_older_routes(api, corpus):
+def test_route_rule_and_options(api, corpus):
+    """the library's own rule (csrc/sa_stage.hip, sa_stage_plan): the staged route where few candidates per document are expected at
+    small k; an explicit `sparse` option chooses between the two older routes; `stage` = 1 / 0 forces / forbids"""
     rng = np.random.default_rng(3)
     queries = band_queries(rng, 24, 4, heads=[0, 3])
+    check(api, corpus, queries, 5, expect="staged", force=False)
+    check(api, corpus, queries, 200, expect="exhaustive", force=False)
     set_opt("SA_SPARSE", "0")
-    check(api, corpus, queries, 10, expect="exhaustive")
+    check(api, corpus, queries, 10, expect="exhaustive", force=False)
     set_opt("stage", 1)
-    check(api, corpus, queries, 10, expect="staged")
+    check(api, corpus, queries, 10, expect="staged", force=False)
     unset_opt("SA_SPARSE")
     set_opt("stage", 0)
-    check(api, corpus, queries, 10, expect="exhaustive")
+    check(api, corpus, queries, 10, expect="exhaustive", force=False)
+
+
+def test_probed_terms_and_streaming_everything(api, corpus):
+    """stage_probe = 0: every term of the batch is staged (no probe rows); default: terms that cannot be essential are probed"""
+    rng = np.random.default_rng(11)
+    queries = band_queries(rng, 48, 4, heads=[0, 1, 2, 5])
+    a = check(api, corpus, queries, 10)
+    set_opt("stage_probe", 0)
+    b = check(api, corpus, queries, 10)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
