@@ -81,6 +81,8 @@ def parse_args():
     ap.add_argument("--corpus-cache", default="", help="directory to cache the encoded corpus shard (.npz)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs (traffic / L2 hit rate)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="a library option for every batch of the run (e.g. stage=0: the main region on round 5's routes); measurement only")
     ap.add_argument("--pruned", action="store_true",
                     help="time dynamic pruning in the main region (default: the exhaustive kernel, which scores every "
                          "posting like the reference; the other mode is always reported beside it)")
@@ -928,6 +930,8 @@ def main():
     exhaustive = not args.pruned
     from searcharray_amd import options as sa_options
     route = sa_options.Scope()                              # the scoring route of the legs below: an OPTION of the batches (thread-scoped here)
+    for kv in args.opt:
+        route.set(kv.split("=")[0], int(kv.split("=")[1]))
     if args.pruned:
         route.set(sparse=1)
     P = max(1, args.pipeline if B <= 1024 else min(args.pipeline, 4))
@@ -1038,8 +1042,15 @@ def main():
         r.index.synchronize()
         dt_dev = (time.perf_counter() - t0) / nd
         vec.close()
+        dfs = [int(r.df[t]) for t in terms]                 # (docs holding the term = postings of the impact stream)
+        alg = sum(8 * x for x in dfs) / len(dfs) + 4 * D       # every posting of the term once + the float32[n_docs] result
         dense_out = {"to_host_ms_per_call": round(dt_host * 1e3, 4), "to_host_GBps": round(4 * D / dt_host / 1e9, 1),
                      "device_resident_ms_per_call": round(dt_dev * 1e3, 4), "calls": nd,
+                     "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "sa_k_bm25_dense_direct (one launch per call)",
+                                  "algorithmic_bytes_per_call": int(alg), "achieved": round(alg / dt_dev / 1e9, 1),
+                                  "frac": round(alg / dt_dev / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                                  "note": f"bytes = 8 x df + 4 x n_docs, mean over the 4 terms of the calls (df {dfs}); time = wall clock of {nd} back-to-back "
+                                          "asynchronous calls / their number (launch gaps included), the result left in a device vector"},
                      "note": f"single-term BM25 over {D} docs: sa_index_bm25_dense with the float32[{D}] result copied into a page-locked "
                              "host buffer (the drop-in SearchArray.score: PCIe-bound) vs left in a device vector (SearchArray.score_device)"}
 

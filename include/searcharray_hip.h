@@ -88,6 +88,7 @@ typedef struct sa_options {
     int64_t stage_wgs;       /* staged-tile route: resident workgroups per CU (default 2) */
     int64_t stage_probe;     /* 0: the staged-tile route streams EVERY term of the batch; default: terms that cannot be essential are probed in dense rows */
     int64_t probe_div;       /* probe rows (dense factor rows the staged-tile route probes) for terms with df >= n_docs / this (default 128; 0: none) */
+    int64_t dense_direct;    /* 0: sa_index_bm25_dense scores the TF postings into scratch and copies (rounds 1-5); default: one launch over the impact stream, straight into the destination */
     int64_t batch_stream;    /* 0: batches share the index stream */
     int64_t res_xs;          /* 0: result copies on the batches' own streams */
     int64_t dense_div;       /* dense factor rows for terms with df >= n_docs / this (default 4) */

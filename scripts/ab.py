@@ -75,7 +75,9 @@ def main():
                         os.environ.pop(key, None)
                     os.environ["SA_SPARSE"] = "0"
                     os.environ.update(cfg)
-                    batch = QueryBatch(index, queries, k=k, idf=idf, opts=dict({"sparse": 0}, **cfg))
+                    # (configuration "default=1": no route option at all -- the library's own rule picks the route)
+                    bopts = {kk: vv for kk, vv in cfg.items() if kk != "default"} if "default" in cfg else dict({"sparse": 0}, **cfg)
+                    batch = QueryBatch(index, queries, k=k, idf=idf, opts=bopts)
                     for _ in range(3):
                         batch.run(sync=False)
                     index.synchronize()

@@ -13,6 +13,17 @@
 #define SA_SP_CHUNK_LEAD 256
 #define SA_SP_CHUNK 1024
 
+// working arrays of sa_stage_plan (sa_stage.hip), kept in the batch between query sets
+struct sa_stage_scratch {
+    std::vector<u32> tmap;                     // [n_terms] term -> distinct index while a plan runs, all ones otherwise
+    std::vector<unsigned short> di;            // [B][T] distinct index of a slot's term
+    std::vector<float> ubs, seeds;             // [B][T] bound of the slot's term x weight; [B] starting bounds
+    std::vector<unsigned char> probed, staged; // [B][T] the slot may be probed; [U] the term must be staged
+    std::vector<u64> dist_df;
+    std::vector<u32> dist_term, dist_probe, order, rank;
+    std::vector<std::pair<u64, u32>> keys;
+};
+
 struct sa_batch {
     sa_options_t opts;              // the batch's switches: the creating thread's defaults, else its index's; sa_batch_set_options
     sa_index* ix = nullptr;
@@ -123,6 +134,7 @@ struct sa_batch {
     u64 st_cell_base = 0;           // smallest impact-stream cell of the set's terms (the kernel's 32-bit offsets count from it)
     u32 st_tmax = 4;                // kernel instantiation: 4 or 8 terms per query
     std::shared_ptr<sa_stagedir> st_dir;
+    sa_stage_scratch st_work;       // the plan's working arrays (kept between plans: a plan allocates nothing)
     char* d_st = nullptr;           // the plan's region of the upload block (sa_stage_bind carves it)
     size_t st_bytes = 0;
     // phrase batches (sa_phrase_batch.hip): kind == 1

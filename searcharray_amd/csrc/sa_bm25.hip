@@ -1772,6 +1772,73 @@ static int sa_launch_bm25(sa_index* ix, const Bm25Params& p, hipStream_t st) {
     return p.pruned ? sa_launch_bm25_mode<1>(ix, p, st) : sa_launch_bm25_mode<0>(ix, p, st);
 }
 
+
+// ---- BASELINE config 2 as one launch (reference postings.py:652-680 score(), bm25.pyx:11-25; summed over the query terms as
+// test/test_msmarco.py:353-354 does): the dense float32[n_docs] BM25 vector of T terms, written ONCE -- straight into the caller's
+// device vector (times its boost) or into the scratch vector the host copy starts from.  A workgroup owns a tile of docs: zeroes
+// its accumulators in LDS, adds factor x idf for every posting of every term in the tile (term after term, so a doc's sum is formed
+// in query-term order exactly like the tile kernel's), stores the tile.  Bytes per call: 8 x (postings of the terms) + 4 x n_docs.
+// The terms and weights travel in the kernel arguments: no upload, no slice-table launch (a slice's ends come from the index's own
+// tile directory, or a search of the term's postings), no fill, no scale / copy pass.
+struct DenseQuery { u32 term[SA_MAX_QTERMS]; float w[SA_MAX_QTERMS]; };
+
+template <int TILE>
+__global__ void __launch_bounds__(256)
+sa_k_bm25_dense_direct(const u64* __restrict__ tfp, const u64* __restrict__ tf_off, const u32* __restrict__ dir_slot,
+                       const u32* __restrict__ tile_dir, const u64* __restrict__ imp, u32 n_terms, u32 n_tiles, u64 n_docs,
+                       const DenseQuery q, u32 T, float boost, int has_boost, float* __restrict__ out) {
+    __shared__ alignas(16) float acc[TILE];
+    __shared__ u64 s_first[SA_MAX_QTERMS];
+    __shared__ u32 s_cnt[SA_MAX_QTERMS];
+    const u32 tile = blockIdx.x, tid = threadIdx.x;
+    const u64 d0 = (u64)tile * TILE;
+    for (u32 i = tid; i < (u32)TILE / 4u; i += 256u) ((float4*)acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < T) {
+        const u32 term = q.term[tid];
+        u64 first = 0; u32 cnt = 0;
+        if (term < n_terms) {
+            const u64 base = tf_off[term];
+            const u32 df = (u32)(tf_off[term + 1] - base);
+            const u32 slot = dir_slot[term];
+            u32 lo, hi;
+            if (slot != 0xFFFFFFFFu) {
+                lo = tile_dir[(u64)slot * (n_tiles + 1) + tile];
+                hi = tile_dir[(u64)slot * (n_tiles + 1) + tile + 1u];
+            } else {
+                lo = sa_lower_bound(tfp + base, 0, df, d0 << SA_KEY_SHIFT, SA_KEY_MASK);
+                hi = sa_lower_bound(tfp + base, lo, df, (d0 + (u64)TILE) << SA_KEY_SHIFT, SA_KEY_MASK);
+            }
+            first = sa_imp_base(base, term) + lo;
+            cnt = hi - lo;
+        }
+        s_first[tid] = first; s_cnt[tid] = cnt;
+    }
+    __syncthreads();
+    for (u32 t = 0; t < T; t++) {                               // (uniform)
+        const u64 first = s_first[t];
+        const u32 cnt = s_cnt[t];
+        const float w = q.w[t];
+        for (u32 j = tid; j < cnt; j += 256u) {
+            const u64 cell = imp[first + j];
+            const u32 d = ((u32)(cell >> 32) >> 2) - (u32)d0;   // (a term holds a doc once: no two lanes meet on an accumulator)
+            acc[d] = __fadd_rn(acc[d], __fmul_rn(__uint_as_float((u32)cell), w));
+        }
+        if (T > 1u) __syncthreads();
+    }
+    __syncthreads();
+    const u64 left = n_docs - d0;
+    const u32 n = left < (u64)TILE ? (u32)left : (u32)TILE;
+    if (n == (u32)TILE && (n_docs & 3ull) == 0ull) {
+        for (u32 i = tid; i < (u32)TILE / 4u; i += 256u) {
+            float4 v = ((const float4*)acc)[i];
+            if (has_boost) { v.x = __fmul_rn(v.x, boost); v.y = __fmul_rn(v.y, boost); v.z = __fmul_rn(v.z, boost); v.w = __fmul_rn(v.w, boost); }
+            ((float4*)(out + d0))[i] = v;
+        }
+    } else {
+        for (u32 i = tid; i < n; i += 256u) out[d0 + i] = has_boost ? __fmul_rn(acc[i], boost) : acc[i];
+    }
+}
+
 extern "C" int sa_index_bm25_dense(sa_index_t* ix, const uint32_t* terms, const float* idf,
                                    int n_query_terms, float k1, float b, float* out) {
     SA_ARG(ix && out, "null argument");
@@ -1788,9 +1855,42 @@ extern "C" int sa_index_bm25_dense(sa_index_t* ix, const uint32_t* terms, const 
         sa_emit_zeros(ix, out);
         return SA_OK;
     }
-    // scratch: [out chunk accumulators N floats][terms][idf]
     const int T = n_query_terms;
     SA_ARG(T <= SA_MAX_QTERMS, "more than 32 query terms per call is not supported");
+    // One launch over the impact stream of (k1, b) -- the stream the index already holds for these parameters, or a new one when
+    // it holds none (built once: the batches of the same parameters share it); an index whose stream belongs to OTHER parameters
+    // keeps it and scores the TF postings as before.
+    if (sa_opt(ix->opts.dense_direct, 1) != 0 && (ix->tile_docs == 1024 || ix->tile_docs == 2048 || ix->tile_docs == 4096) && ix->n_tiles > 0) {
+        auto same = [](float x, float y) { return memcmp(&x, &y, sizeof(float)) == 0; };
+        std::shared_ptr<sa_impacts> im;
+        if (!ix->impacts || (same(ix->impacts->k1, k1) && same(ix->impacts->b, b) && same(ix->impacts->avgdl, ix->avg_doc_len)))
+            im = sa_impacts_get(ix, k1, b, ix->opts);
+        if (im && im->d_imp) {
+            DenseQuery dq;
+            memset(&dq, 0, sizeof(dq));
+            for (int i = 0; i < T; i++) { dq.term[i] = terms[i]; dq.w[i] = idf[i]; }
+            float* dst = nullptr; float boost = 1.f; int has_boost = 0;
+            const bool to_vec = sa_vec_target_take(ix, &dst, &boost, &has_boost);
+            if (!to_vec) {
+                void* scratch;
+                SA_TRY(sa_index_scratch(ix, N * sizeof(float) + 1024, &scratch));
+                dst = (float*)scratch;
+            }
+#define SA_LAUNCH_DENSE(TILE)                                                                                                      \
+    hipLaunchKernelGGL((sa_k_bm25_dense_direct<TILE>), dim3(ix->n_tiles), dim3(256), 0, st, (const u64*)ix->d_tfp, (const u64*)ix->d_tf_off, \
+                       (const u32*)ix->d_dir_slot, (const u32*)ix->d_tile_dir, (const u64*)im->d_imp, ix->n_terms, ix->n_tiles, N, dq, (u32)T,  \
+                       boost, has_boost, dst)
+            if (ix->tile_docs == 1024) SA_LAUNCH_DENSE(1024);
+            else if (ix->tile_docs == 2048) SA_LAUNCH_DENSE(2048);
+            else SA_LAUNCH_DENSE(4096);
+#undef SA_LAUNCH_DENSE
+            SA_HIP(hipGetLastError());
+            if (!to_vec) SA_TRY(sa_emit_dense(ix, dst, out));
+            SA_TRY(lane.finish());
+            return SA_OK;
+        }
+    }
+    // scratch: [out chunk accumulators N floats][terms][idf]
     void* scratch;
     const size_t nb = (size_t)T * (ix->n_tiles + 1);
     SA_TRY(sa_index_scratch(ix, N * sizeof(float) + (size_t)T * 16 + nb * 4 + SA_SAT_NTF * SA_SAT_WMAX * 4 + 1024, &scratch));

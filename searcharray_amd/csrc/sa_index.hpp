@@ -228,6 +228,7 @@ void sa_emit_zeros(sa_index* ix, float* out);
 // sa_vec.hip: divert the result into a device vector if this thread asked for it (sa_index_select_vec)
 bool sa_emit_to_vec(sa_index* ix, const float* d_vec);
 bool sa_vec_target_pending(const sa_index* ix, bool clear);
+bool sa_vec_target_take(const sa_index* ix, float** dst, float* boost, int* has_boost);
 // index construction pieces shared by sa_index_create (sa_index.hip) and sa_index_create_from_tokens (sa_build.hip)
 int sa_index_setup(sa_index* ix, const float* doc_lens);
 int sa_index_derive(sa_index* ix);

@@ -43,6 +43,7 @@
     X(stage_wgs)       /* staged-tile route: resident workgroups per CU (default 2) */                                              \
     X(stage_probe)     /* 0: the staged-tile route streams EVERY term of the batch; default: terms that cannot be essential are probed in dense rows */ \
     X(probe_div)       /* probe rows (dense factor rows the staged-tile route probes) for terms with df >= n_docs / this (default 128; 0: none) */ \
+    X(dense_direct)    /* 0: sa_index_bm25_dense scores the TF postings into scratch and copies (rounds 1-5); default: one launch over the impact stream, straight into the destination */ \
     X(batch_stream)    /* 0: batches share the index stream */                                                                     \
     X(res_xs)          /* 0: result copies on the batches' own streams */                                                          \
     /* ---- index creation (sa_index.hip, sa_bm25.hip) */                                                                          \

@@ -44,7 +44,6 @@
 #include <algorithm>
 #include <math.h>
 #include <new>
-#include <unordered_map>
 
 #define SA_ST_NT 512            // threads per workgroup
 #define SA_ST_UMAX 1024         // distinct terms of a query set
@@ -268,83 +267,109 @@ int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* ro
     unsigned short* h_pu = (unsigned short*)(base + L.pu);
     u32* h_seed = (u32*)(img + ((char*)bt->d_seed - bt->d_up));
 
-    // distinct terms
-    std::unordered_map<u32, u32> idx;
-    idx.reserve((size_t)B * T * 2);
+    // distinct terms: di[slot] = index of the slot's term among the set's distinct terms (SA_ST_NONE: unknown term).  The map from
+    // term ids is a table of the batch (n_terms cells, all ones between plans: the cells written are put back below) and every
+    // working array lives in the batch -- a plan allocates nothing and hashes nothing (it runs once per fresh query set, on the host
+    // thread that feeds the device)
     struct DT { u64 df; u32 term; u32 probe; bool staged; };
-    std::vector<DT> dist;
-    for (size_t i = 0; i < (size_t)B * T; i++) {
+    sa_stage_scratch& W = bt->st_work;
+    if (W.tmap.size() != ix->n_terms) W.tmap.assign(ix->n_terms, 0xFFFFFFFFu);
+    const size_t BT = (size_t)B * T;
+    W.di.resize(BT); W.ubs.resize(BT); W.probed.resize(BT); W.seeds.resize(B);
+    W.dist_df.clear(); W.dist_term.clear(); W.dist_probe.clear();
+    bool too_many = false;
+    // (the per-term host tables are indexed by term id -- random cells of arrays far bigger than the caches: ask for all of them
+    //  first, so that the misses overlap instead of being taken one after the other)
+    u32 rank_idx = SA_TOPF_NR - 1;
+    for (int i = SA_TOPF_NR - 1; i >= 0; i--) if (sa_topf_ranks[i] >= bt->k) rank_idx = (u32)i;
+    for (size_t i = 0; i < BT; i++) {
         const u32 t = row_terms[i];
         if (t >= ix->n_terms) continue;
-        auto it = idx.emplace(t, (u32)dist.size());
-        if (it.second) dist.push_back({ix->h_tf_off[t + 1] - ix->h_tf_off[t], t,
-                                       probing && im->d_probe && t < im->probe_slot.size() ? im->probe_slot[t] : 0xFFFFFFFFu, false});
+        __builtin_prefetch(&W.tmap[t]);
+        __builtin_prefetch(&ix->h_tf_off[t]);
+        __builtin_prefetch(&im->h_maxf[t]);
+        __builtin_prefetch(&im->h_topf[(size_t)t * SA_TOPF_NR + rank_idx]);
+        if (probing && t < im->probe_slot.size()) __builtin_prefetch(&im->probe_slot[t]);
     }
-    if (dist.empty() || dist.size() > SA_ST_UMAX) return SA_OK;
-    const u32 U = (u32)dist.size();
+    for (size_t i = 0; i < BT; i++) {
+        const u32 t = row_terms[i];
+        if (t >= ix->n_terms) { W.di[i] = SA_ST_NONE; continue; }
+        u32 u = W.tmap[t];
+        if (u == 0xFFFFFFFFu) {
+            u = (u32)W.dist_term.size();
+            if (u >= (u32)SA_ST_UMAX) { too_many = true; W.di[i] = SA_ST_NONE; continue; }
+            W.tmap[t] = u;
+            W.dist_term.push_back(t);
+            W.dist_df.push_back(ix->h_tf_off[t + 1] - ix->h_tf_off[t]);
+            W.dist_probe.push_back(probing && im->d_probe && t < im->probe_slot.size() ? im->probe_slot[t] : 0xFFFFFFFFu);
+        }
+        W.di[i] = u;
+    }
+    const u32 U = (u32)W.dist_term.size();
+    for (u32 u = 0; u < U; u++) W.tmap[W.dist_term[u]] = 0xFFFFFFFFu;          // (the table is all ones again)
+    if (U == 0 || too_many) return SA_OK;
+    W.staged.assign(U, 0);
+    // insertion sorts of at most 8 slots (stable; std::stable_sort allocates)
+    auto sort_slots = [](u32* a, u32 n, auto less) {
+        for (u32 i = 1; i < n; i++) { const u32 x = a[i]; u32 j = i; while (j > 0 && less(x, a[j - 1])) { a[j] = a[j - 1]; j--; } a[j] = x; }
+    };
     // per query: the starting bound; the terms it can PROBE -- those with a probe row whose bounds in the shard, taken
     // together from the smallest up, stay below the starting bound with the kernel's own arithmetic (so that the kernel,
     // whose tile bounds are never above these and whose bound G is never below the starting one, can never find them
     // essential); every other term must be STAGED, for every query
-    u32 rank_idx = SA_TOPF_NR - 1;
-    for (int i = SA_TOPF_NR - 1; i >= 0; i--) if (sa_topf_ranks[i] >= bt->k) rank_idx = (u32)i;
     const float seed_scale = (float)sa_opt(bt->opts.seed_scale_pct, 100) / 100.f;
-    std::vector<float> ubs((size_t)B * T, 0.f), seeds(B, 0.f);
+    float* const ubs = W.ubs.data();
+    float* const seeds = W.seeds.data();
+    unsigned char* const probed = W.probed.data();
+    const unsigned short* const di = W.di.data();
     double cand_df = 0.0;
-    std::vector<unsigned char> probed((size_t)B * T, 0);
     for (u32 q = 0; q < B; q++) {
+        const size_t qb = (size_t)q * T;
         float seed = 0.f;
         for (u32 s = 0; s < T; s++) {
-            const u32 t = row_terms[(size_t)q * T + s];
-            if (t >= ix->n_terms) continue;
-            const float w = row_idf[(size_t)q * T + s];
-            ubs[(size_t)q * T + s] = sa_st_round_up16(im->h_maxf[t]) * w;          // (what the kernel forms from a cm word, at most)
+            probed[qb + s] = 0; ubs[qb + s] = 0.f;
+            if (di[qb + s] == SA_ST_NONE) continue;
+            const u32 t = row_terms[qb + s];
+            const float w = row_idf[qb + s];
+            ubs[qb + s] = sa_st_round_up16(im->h_maxf[t]) * w;          // (what the kernel forms from a cm word, at most)
             const float sd1 = (im->h_topf[(size_t)t * SA_TOPF_NR + rank_idx] * w) * seed_scale;   // (the arithmetic of sa_k_make_bounds)
             if (sd1 > seed) seed = sd1;
         }
         seeds[q] = seed;
+        u32 os[8];
+        for (u32 s = 0; s < T; s++) os[s] = s;
+        sort_slots(os, T, [&](u32 a, u32 c) { return ubs[qb + a] < ubs[qb + c]; });
         {
             // the candidates this query has to expect: the postings of the terms that its starting bound leaves essential
-            u32 os[8];
-            for (u32 s = 0; s < T; s++) os[s] = s;
-            std::stable_sort(os, os + T, [&](u32 a, u32 c) { return ubs[(size_t)q * T + a] < ubs[(size_t)q * T + c]; });
             float sf = 0.f;
             for (u32 j = 0; j < T; j++) {
-                const u32 t = row_terms[(size_t)q * T + os[j]];
-                sf += ubs[(size_t)q * T + os[j]];
-                if (t < ix->n_terms && !(seed > 0.f && sf * SA_ST_MARGIN < seed)) cand_df += (double)dist[idx[t]].df;
+                sf += ubs[qb + os[j]];
+                if (di[qb + os[j]] != SA_ST_NONE && !(seed > 0.f && sf * SA_ST_MARGIN < seed)) cand_df += (double)W.dist_df[di[qb + os[j]]];
             }
         }
-        if (!(seed > 0.f)) continue;
-        // candidates for probing: smallest bound first
-        u32 cs[8]; u32 nc = 0;
-        for (u32 s = 0; s < T; s++) {
-            const u32 t = row_terms[(size_t)q * T + s];
-            if (t < ix->n_terms && dist[idx[t]].probe != 0xFFFFFFFFu) cs[nc++] = s;
+        if (seed > 0.f) {
+            // candidates for probing: smallest bound first (the slots with a probe row, in the order of `os`)
+            float sfx = 0.f;
+            for (u32 j = 0; j < T; j++) {
+                const u32 s = os[j];
+                if (di[qb + s] == SA_ST_NONE || W.dist_probe[di[qb + s]] == 0xFFFFFFFFu) continue;
+                sfx = sfx + ubs[qb + s];
+                if (!(sfx * SA_ST_MARGIN * 1.0001f < seed)) break;
+                probed[qb + s] = 1;
+            }
         }
-        std::stable_sort(cs, cs + nc, [&](u32 a, u32 c) { return ubs[(size_t)q * T + a] < ubs[(size_t)q * T + c]; });
-        float sfx = 0.f;
-        for (u32 j = 0; j < nc; j++) {
-            sfx = sfx + ubs[(size_t)q * T + cs[j]];
-            if (!(sfx * SA_ST_MARGIN * 1.0001f < seed)) break;
-            probed[(size_t)q * T + cs[j]] = 1;
-        }
+        for (u32 s = 0; s < T; s++) if (di[qb + s] != SA_ST_NONE && !probed[qb + s]) W.staged[di[qb + s]] = 1;
     }
-    for (u32 q = 0; q < B; q++)
-        for (u32 s = 0; s < T; s++) {
-            const u32 t = row_terms[(size_t)q * T + s];
-            if (t < ix->n_terms && !probed[(size_t)q * T + s]) dist[idx[t]].staged = true;
-        }
     // staged terms first, most frequent first; then the probed ones
-    std::vector<u32> order(U);
-    for (u32 u = 0; u < U; u++) order[u] = u;
-    std::sort(order.begin(), order.end(), [&](u32 a, u32 c) {
-        if (dist[a].staged != dist[c].staged) return dist[a].staged;
-        return dist[a].df > dist[c].df || (dist[a].df == dist[c].df && dist[a].term < dist[c].term);
-    });
+    // (one integer key per term: probed bit | df descending | term ascending -- df < 2^31: the shard holds at most 2^28 docs)
+    W.order.resize(U); W.rank.resize(U); W.keys.resize(U);
+    for (u32 u = 0; u < U; u++)
+        W.keys[u] = {((u64)(W.staged[u] ? 0u : 1u) << 63) | ((u64)(0x7FFFFFFFu - (u32)W.dist_df[u]) << 32) | (u64)W.dist_term[u], u};
+    std::sort(W.keys.begin(), W.keys.end());
+    for (u32 r = 0; r < U; r++) W.order[r] = W.keys[r].second;
     u32 NS = 0;
     u64 dfsum = 0;
-    for (u32 r = 0; r < U; r++) { const DT& d = dist[order[r]]; idx[d.term] = r; if (d.staged) { NS++; dfsum += d.df; } }
+    for (u32 r = 0; r < U; r++) { const u32 u = W.order[r]; W.rank[u] = r; if (W.staged[u]) { NS++; dfsum += W.dist_df[u]; } }
     if (U - NS > (u32)SA_ST_NT) return SA_OK;                // (one probed term per thread)
     // docs per stage tile: the largest of the sizes below whose expected postings fit the stage with room for the tiles above the
     // mean, and that leave a workgroup of a full device a dozen tiles or more
@@ -363,22 +388,23 @@ int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* ro
         }
         if (!docs) return SA_OK;                          // (more than ~70 staged postings per doc: not this route)
     }
-    std::shared_ptr<sa_stagedir> sd = sa_stagedir_get(ix, im, docs);
+    std::shared_ptr<sa_stagedir> sd = (bt->st_dir && bt->st_dir->docs == docs) ? bt->st_dir : sa_stagedir_get(ix, im, docs);
     if (!sd) return SA_OK;
     if ((u64)sd->n_rows * sd->n_st >= (1ull << 30)) return SA_OK;
     // the kernel addresses the stream with 32-bit byte offsets from the first staged term
     u64 cell_lo = ~0ull, cell_hi = 0;
     for (u32 r = 0; r < U; r++) {
-        const DT& d = dist[order[r]];
+        const u32 u = W.order[r];
+        const u32 term = W.dist_term[u];
         StTerm& x = h_terms[r];
-        x.cell0 = sa_imp_base(ix->h_tf_off[d.term], d.term);
-        x.df = (u32)d.df;
-        x.row = sd->row[d.term];
-        x.probe = d.staged ? 0xFFFFFFFFu : d.probe;
-        memcpy(&x.maxf, &im->h_maxf[d.term], 4);
+        x.cell0 = sa_imp_base(ix->h_tf_off[term], term);
+        x.df = (u32)W.dist_df[u];
+        x.row = sd->row[term];
+        x.probe = W.staged[u] ? 0xFFFFFFFFu : W.dist_probe[u];
+        memcpy(&x.maxf, &im->h_maxf[term], 4);
         x.pad0 = 0; x.pad1 = 0;
-        if (!d.staged && (x.row == SA_ST_NOROW || x.probe >= 65536u)) return SA_OK;       // (cannot happen: a probe row means df >= n_docs / 128)
-        if (d.staged) {
+        if (!W.staged[u] && (x.row == SA_ST_NOROW || x.probe >= 65536u)) return SA_OK;       // (cannot happen: a probe row means df >= n_docs / 128)
+        if (W.staged[u]) {
             cell_lo = std::min<u64>(cell_lo, x.cell0);
             cell_hi = std::max<u64>(cell_hi, x.cell0 + (u64)x.df + 4ull);
         }
@@ -387,20 +413,20 @@ int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* ro
     if (cell_hi - cell_lo >= (1ull << 29)) return SA_OK;              // (32-bit BYTE offsets in the kernel: shards of up to ~18 M docs of this corpus; bigger ones keep the older routes)
     // the queries: staged terms by descending bound, then the probed ones; weights; starting bounds
     for (u32 q = 0; q < B; q++) {
+        const size_t qb = (size_t)q * T;
         u32 ord[8];
         for (u32 s = 0; s < T; s++) ord[s] = s;
-        auto is_probed = [&](u32 s) { const u32 t = row_terms[(size_t)q * T + s]; return t < ix->n_terms && !dist[order[idx[t]]].staged; };
-        std::stable_sort(ord, ord + T, [&](u32 a, u32 c) {
+        auto is_probed = [&](u32 s) { return di[qb + s] != SA_ST_NONE && !W.staged[di[qb + s]]; };
+        sort_slots(ord, T, [&](u32 a, u32 c) {
             const bool pa = is_probed(a), pc = is_probed(c);
             if (pa != pc) return !pa;
-            return ubs[(size_t)q * T + a] > ubs[(size_t)q * T + c];
+            return ubs[qb + a] > ubs[qb + c];
         });
         u32 inv = 0;
         for (u32 i = 0; i < T; i++) {
             const u32 s = ord[i];
-            const u32 t = row_terms[(size_t)q * T + s];
-            h_pu[(size_t)q * T + i] = (unsigned short)(t < ix->n_terms ? idx[t] : SA_ST_NONE);
-            h_pw[(size_t)q * T + i] = row_idf[(size_t)q * T + s];
+            h_pu[qb + i] = (unsigned short)(di[qb + s] != SA_ST_NONE ? W.rank[di[qb + s]] : SA_ST_NONE);
+            h_pw[qb + i] = row_idf[qb + s];
             inv |= i << (4u * s);
         }
         h_inv[q] = inv;

@@ -241,6 +241,15 @@ bool sa_vec_target_pending(const sa_index* ix, bool clear) {
     return pending;
 }
 
+// the diversion pending for this thread's next dense call on `ix`, handed to a kernel that writes the vector itself
+// (sa_index_bm25_dense's one-launch route): destination, boost; the diversion is consumed
+bool sa_vec_target_take(const sa_index* ix, float** dst, float* boost, int* has_boost) {
+    if (tl_vec.ix != ix || !tl_vec.v || !tl_vec.v->n) return false;
+    *dst = (float*)tl_vec.v->d; *boost = tl_vec.boost; *has_boost = tl_vec.has_boost;
+    tl_vec.ix = nullptr; tl_vec.v = nullptr;
+    return true;
+}
+
 // called by sa_emit_dense / sa_emit_zeros (sa_index.hip): true if the result was diverted into a vector
 bool sa_emit_to_vec(sa_index* ix, const float* d_vec) {
     if (tl_vec.ix != ix) return false;

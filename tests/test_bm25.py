@@ -394,6 +394,45 @@ def test_dense_calls_with_a_row_selection(api):
     assert np.array_equal(dev.termfreqs_dense(3), full_tf)                                  # selection was cleared
 
 
+@pytest.mark.parametrize("tile_docs", [1024, 2048, 4096, 8192])
+def test_dense_bm25_one_launch_equals_the_tf_route_and_the_oracle(api, tile_docs):
+    """BASELINE config 2 itself (reference postings.py:652-680 + bm25.pyx:11-25, summed over the terms as test/test_msmarco.py:353-354):
+    sa_index_bm25_dense as ONE launch over the impact stream, written straight into the destination (host copy, row selection, a
+    device vector times a boost) == the rounds 1-5 route (TF postings -> scratch -> copy; option dense_direct = 0) == the oracle, bit
+    for bit; 1 .. 8 terms, a term twice, unknown terms, (k1, b) other than the stream's (the TF route serves those), a shard
+    whose last tile is partial; tile sizes the launch has no instance for (8192) take the TF route"""
+    from searcharray_amd.device_index import DeviceVec
+    from searcharray_amd._lib import p_u32, p_f32
+    t, d, p, lens = synth.corpus_triples(5003, 300, 12, seed=9)
+    words, wt = rz.encode_sorted(t, d, p)
+    off = rz.term_offsets(wt, 300)
+    orc = O.OracleIndex.from_triples(t, d, p, 5003, doc_lens=lens)
+    dev = DeviceIndex(words, off, lens, tile_docs=tile_docs, api=api)
+    old = DeviceIndex(words, off, lens, tile_docs=tile_docs, api=api, opts={"dense_direct": 0})
+    rng = np.random.default_rng(tile_docs)
+    queries = [[0], [299], [5, 5], [0, 1, 2], [7, 4000, 3], [4000], [250, 0, 17, 3, 120, 9, 1, 77]] + [list(rng.integers(0, 300, int(n))) for n in rng.integers(1, 9, 12)]
+    rows = np.asarray([5, 0, 5002, 700, 5, 3, 4095, 4096], dtype=np.uint64)
+    vec = DeviceVec(api, 5003, False)
+    for q in queries:
+        q = [int(x) for x in q]
+        known = [x for x in q if x < 300]
+        want = orc.score_terms_sum(known) if known else np.zeros(5003, dtype=np.float32)
+        got = dev.bm25_dense(q)
+        assert np.array_equal(got, want), q
+        assert np.array_equal(old.bm25_dense(q), want), q
+        assert np.array_equal(dev.bm25_dense(q, rows=rows), want[rows.astype(np.int64)]), q
+        tarr = np.asarray([x if x < 300 else 0xFFFFFFFF for x in q], dtype=np.uint32)
+        idf = dev.idfs(q)
+        for boost in (None, 2.5):
+            dev.into_vec(vec, boost, "sa_index_bm25_dense", p_u32(tarr), p_f32(idf), len(tarr), np.float32(1.2), np.float32(0.75))
+            assert np.array_equal(vec.fetch(), want if boost is None else want * np.float32(boost)), (q, boost)
+        if known:
+            assert np.array_equal(dev.bm25_dense(q, k1=0.9, b=0.4), orc.score_terms_sum(known, k1=0.9, b=0.4)), q
+    vec.close()
+    dev.close()
+    old.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # impact stream (sa_k_make_impacts): the per-posting factor evaluated once per (k1, b)
 # ---------------------------------------------------------------------------------------------
