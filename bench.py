@@ -14,9 +14,10 @@ libsearcharray_hip.so's own RCCL communicator (include/searcharray_hip.h Part 3)
 
 A "step" = one pass of the hot path over one batch of 256 queries THE DEVICE HAS NOT SEEN, ONE library call
 (sa_batch_step): the batch's idf weights are gathered from the index's per-term table (float64 numpy arithmetic of the
-reference, formed once like df itself), sa_batch_reset (grouping + pruning tables into a page-locked image, one async
-copy, the slice-table kernel), then sa_batch_run: scoring kernel(s) (postings
-stream -> LDS accumulators -> pruned per-tile selection) + per-shard merge (+ RCCL all-gather of the per-shard
+reference, formed once like df itself), sa_batch_reset (the query set's tables -- the staged-tile route's plan, or grouping /
+pruning tables -- into a page-locked image, one async copy), then sa_batch_run: the scoring kernel of the route the library
+picks for the batch's shape (staged tiles, exhaustive overlay or dynamic pruning -- all exact, identical results)
++ per-shard merge (+ RCCL all-gather of the per-shard
 top-k keys and a final merge when N > 1) + an async copy of the B x k results to the host, which the loop fetches
 two steps later.  Eight seeded query sets rotate through two batch objects, so nothing is replayed: what is timed is
 what a query stream gets (the reference's unit of work is score() on a fresh query, postings.py:652-680, timed as
@@ -30,12 +31,16 @@ The index is resident in HBM before the timed region.  Rank 0 prints one JSON li
 
 Legs (all on the same resident index; only the first is `value`):
   main (fresh)      8 rotating BASELINE-shaped query sets (256 x 4 terms, one rank from each of 1-10 / 11-100 /
-                    101-1000 / 1001-10000; set 0 is THE BASELINE set, seed 42), EXHAUSTIVE: every posting of every
-                    query term is scored, like the reference; reset + run + fetch per step
-  replay            set 0 resident, run only (what rounds 1-2 reported as `value`)
-  dynamic_pruning   set 0 through the library's default top-k path (MaxScore-style pruning), replayed
-  distinct_terms    256 x 4 pairwise-distinct terms (ranks 1..1024), exhaustive: no posting list is shared
-                    between queries, so cache reuse cannot flatter the bandwidth figure
+                    101-1000 / 1001-10000; set 0 is THE BASELINE set, seed 42) through the library's DEFAULT route for
+                    the batch's shape (round 6, k <= 32: the staged-tile route; `roofline.route` names it): the exact top-k of
+                    every query -- identical to scoring every posting of every query term like the reference does, which
+                    parity_check verifies against the reference itself; reset + run + fetch per step
+  replay            set 0 resident, run only (what rounds 1-2 reported as `value`); its HIP-event kernel time is the roofline's
+  exhaustive_overlay  set 0 with every posting scored (option sparse = 0: rounds 2-5's headline route), replayed
+  dynamic_pruning   set 0 through sa_sparse.hip (option sparse = 1), replayed
+  distinct_terms    256 x 4 pairwise-distinct terms (ranks 1..1024), default route (the exhaustive overlay): no posting list is
+                    shared between queries, so cache reuse cannot flatter the bandwidth figure
+  dense_score       BASELINE config 2's literal call: single-term BM25 -> float32[n_docs], to the host and left on the device
   phrase_batch      BASELINE config 3: 256 sampled 3-token phrases -> BM25 -> top-10 on a resident zipf-1M index
   slop_batch        BASELINE config 5 (synthetic stand-in): 256 two-token slop-2 phrases (half on ranks 1-50) -> top-10, same index
 Roofline blocks are per leg; see roofline_block().

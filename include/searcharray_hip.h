@@ -395,8 +395,9 @@ int sa_batch_stats(sa_batch_t* batch, int enable, uint64_t* sparse_candidates_ou
  * in groups, out[2] = of them in groups that share their first term (the others are loose groups), out[3] = queries
  * left to the per-query kernel.  Diagnostics for benchmarks and tests; no reference counterpart. */
 int sa_batch_group_info(sa_batch_t* batch, uint32_t out[4]);
-/* Which route the batch's last run took: *pruned_out = 1 dynamic pruning, 0 exhaustive scoring (the option `sparse`, or -- unset --
- * the library's rule: csrc/sa_bm25.hip, sa_batch_run_shard; measured by scripts/route_rule.py).  Diagnostics; no reference counterpart. */
+/* Which route the batch's last run took: *pruned_out = 2 the staged-tile route (csrc/sa_stage.hip), 1 dynamic pruning, 0 exhaustive scoring
+ * (the options `stage` / `sparse`, or -- unset -- the library's rule: csrc/sa_stage.hip sa_stage_plan, csrc/sa_bm25.hip sa_batch_run_shard;
+ * measured: profiles/route_rule_r06*.jsonl).  All three are exact.  Diagnostics; no reference counterpart. */
 int sa_batch_last_route(sa_batch_t* batch, int* pruned_out);
 /* Host time this batch's steps have cost, cumulative nanoseconds by part: out[0] = sa_batch_reset / _step up to the upload
  * (grouping + pruning tables: CPU work only), out[1] = its enqueues (the upload copy, the slice-table launch), out[2] =

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Copy the outputs of scripts/gpu_full_r5.sh (r04: gpu_full_r4.sh, r03: gpu_full_r3.sh) from gpurun_out/ (scratch) into profiles/ (tracked), named per round:
+"""Copy the outputs of scripts/gpu_full_r6.sh (r05: gpu_full_r5.sh, r04: gpu_full_r4.sh, r03: gpu_full_r3.sh) from gpurun_out/ (scratch) into profiles/ (tracked), named per round:
 bench JSON lines (which carry their own PMC traffic / L2 hit rates: bench.py profiles itself under rocprofv3),
 rocprofv3 kernel stats per leg, SQ counters of the scoring kernels, the HIP-API summary of the fresh-batch loop's
 steady state, PMC traffic of the phrase and slop kernels."""
@@ -102,7 +102,13 @@ def main():
                      ("dense_threads.jsonl", f"dense_threads_{RND}.jsonl"), ("issue_probe.jsonl", f"issue_probe_{RND}.jsonl"),
                      ("probe_sections.jsonl", f"group_kernel_cycle_sections_{RND}.jsonl"), ("probe_sections_fine.jsonl", f"group_kernel_cycle_sections_fine_{RND}.jsonl"),
                      ("occupancy.jsonl", f"group_kernel_occupancy_{RND}.jsonl"), ("item_ab.jsonl", f"group_item_passes_ab_{RND}.jsonl"), ("item_sweep.jsonl", f"group_item_passes_by_shard_size_{RND}.jsonl"), ("lds_fadd_probe.json", f"lds_fadd_probe_{RND}.jsonl"),
-                     ("slop_heavy.log", f"slop_heaviest_{RND}.jsonl"), ("slop_routes.log", f"slop_routes_{RND}.jsonl")]:
+                     ("slop_heavy.log", f"slop_heaviest_{RND}.jsonl"), ("slop_routes.log", f"slop_routes_{RND}.jsonl"),
+                     # round 6: the staged-tile route
+                     ("route_rule_no_impact.jsonl", f"route_rule_{RND}_no_impact_stream.jsonl"), ("stage_probe.jsonl", f"stage_kernel_cycle_sections_{RND}.jsonl"),
+                     ("stage_sweep.jsonl", f"stage_kernel_option_sweep_{RND}.jsonl"), ("dense_ab.jsonl", f"dense_call_one_launch_ab_{RND}.jsonl"),
+                     ("shard_routes.jsonl", f"shard_routes_{RND}.jsonl"), ("pipeline_sweep.jsonl", f"pipeline_sweep_{RND}.jsonl"),
+                     ("ab_sweep1.log", f"stage_kernel_streaming_loads_ab_{RND}.jsonl"), ("ab_x2b.log", f"stage_kernel_hoisted_search_ab_{RND}.jsonl"),
+                     ("ab_mix.log", f"stage_kernel_register_diet_ab_{RND}.jsonl")]:
         js = json_lines(os.path.join(OUT, src))
         if js:
             open(os.path.join(PROF, dst), "w").write("\n".join(json.dumps(j) for j in js) + "\n")
@@ -110,7 +116,7 @@ def main():
     for sub, dst in [("prof_main", f"{RND}_main_leg_kernel_stats.csv"), ("prof_distinct", f"{RND}_distinct_leg_kernel_stats.csv"),
                      ("prof_bench", f"{RND}_bench_kernel_stats.csv"), ("prof_phrase", f"{RND}_phrase_bench_kernel_stats.csv"),
                      ("prof_slop", f"{RND}_slop_bench_kernel_stats.csv"), ("prof_slopb", f"{RND}_phrase_slop_batch_legs_kernel_stats.csv"),
-                     ("prof_k1000", f"{RND}_main_leg_k1000_kernel_stats.csv"),
+                     ("prof_k1000", f"{RND}_main_leg_k1000_kernel_stats.csv"), ("prof_dense", f"{RND}_dense_call_ab_kernel_stats.csv"),
                      ("prof_rank", f"{RND}_rank_sized_shard_exchange_kernel_stats.csv"),
                      ("prof_slop2", f"{RND}_slop_heaviest_2term_kernel_stats.csv"),
                      ("prof_slop3", f"{RND}_slop_heaviest_3term_kernel_stats.csv")]:
@@ -127,7 +133,7 @@ def main():
     sq = os.path.join(OUT, "sq_summary.json")
     if os.path.exists(sq) and os.path.getsize(sq) > 10:
         out = {"command": "rocprofv3 --pmc <8 SQ counters> --kernel-trace -- python scripts/ab.py --ks 10 --steps 2 (two passes); 10M docs, "
-                          "256 x 4-term BASELINE queries, top-10, one resident batch (grouped exhaustive path); mean per dispatch; "
+                          "256 x 4-term BASELINE queries, top-10, one resident batch (the library's default route: r06 staged, r02-r05 grouped exhaustive); mean per dispatch; "
                           "SQ_WAVE_CYCLES / SQ_BUSY_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles",
                "kernels": json.load(open(sq))}
         json.dump(out, open(os.path.join(PROF, f"{RND}_scoring_kernels_sq_counters.json"), "w"), indent=1)

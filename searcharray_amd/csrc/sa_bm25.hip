@@ -2552,7 +2552,7 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
                                sa_opt(bt->opts.topk_hist, 1) != 0;
     // Unset, SA_SPARSE follows the measurements: pruning pays while the shard holds many docs per requested
     // result (10 M docs: 2.2x at k = 10, 1.9x at k = 100, but the exhaustive kernel is 1.2x faster at k = 1000;
-    // 1.25 M docs, k = 1000: exhaustive 1.8x faster) -- on from 32768 docs per result.  SA_SPARSE=1 / 0 force it.
+    // 1.25 M docs, k = 1000: exhaustive 1.8x faster) -- on from 32768 docs per result (8192 since round 6, below).  SA_SPARSE=1 / 0 force it.
     const int sparse_env = (int)sa_opt(bt->opts.sparse, -1);
     // Round 2: when most queries of the batch share their first terms, the grouped exhaustive kernel is as fast at
     // k = 10 and faster above (10 M docs, BASELINE batch: 369 K vs 341 K queries/s at k = 100, 236 K vs 114 K at
@@ -2573,7 +2573,10 @@ static int sa_batch_run_shard(sa_batch* bt, u64* shard_out, bool defer_check, bo
     // other tile sizes), where the per-query TF kernel is what it competes with.
     const bool impact_route = p.pruned && hist_possible && p.imp && !p.no_topk &&
                               (ix->tile_docs == 1024 || ix->tile_docs == 2048 || ix->tile_docs == 4096);
-    const bool sparse_wanted = sparse_env >= 0 ? sparse_env != 0 : (ix->n_docs >= (u64)bt->k * 32768ull && !impact_route);
+    // Round 6, the batches that remain (no impact stream), measured by shard size (profiles/route_rule_r06_no_impact_stream*.jsonl: 1.25 / 2.5 /
+    // 5 / 10 M docs x k = 10 / 100 / 1000 x two query sets): pruning beats the TF kernels 1.4 - 5.7 x from 10 000 docs per requested result
+    // on (1.0 - 1.9 x at 10 000 - 12 500), loses up to 1.4 x at 5 000 and below -- on from 8192 docs per result (rounds 3-5: 32768).
+    const bool sparse_wanted = sparse_env >= 0 ? sparse_env != 0 : (ix->n_docs >= (u64)bt->k * 8192ull && !impact_route);
     if (sparse_wanted && bt->sparse_lazy && bt->kind == 0 &&
         !(bt->stage_ok && sa_batch_stage_wanted(bt))) {
         // the tables were left out at reset (the run was expected to score every posting): derive them into the image of the

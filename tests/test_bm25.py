@@ -492,7 +492,7 @@ def test_impact_stream_exhaustive_scan(api, monkeypatch, integer_lens):
 
 def test_dynamic_pruning_default_policy(api, monkeypatch):
     """Option `sparse` unset (round 5's measured rule, scripts/route_rule.py; round 6: the staged-tile route where the older rule scored
-    exhaustively): a batch that can take the impact stream with histogram bounds takes the staged-tile route; one that cannot (impact = 0) is pruned while the shard holds at least 32768 docs
+    exhaustively): a batch that can take the impact stream with histogram bounds takes the staged-tile route; one that cannot (impact = 0) is pruned while the shard holds at least 8192 docs
     per requested result.  Either way the top-k equals the oracle, and last_route() says which it was."""
     unset_opt("SA_SPARSE")
     n_docs, vocab = 60000, 3000
@@ -501,7 +501,7 @@ def test_dynamic_pruning_default_policy(api, monkeypatch):
     dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
     orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
     queries = np.asarray([[0, 40, 700, 2500], [2900, 1, 3, 1500], [2999, 2998, 0, 1]])
-    for impact, k, pruned, route in ((1, 1, False, "staged"), (0, 1, True, "pruned"), (0, 5, False, "exhaustive")):   # 60000 / 32768 = 1.8 results
+    for impact, k, pruned, route in ((1, 1, False, "staged"), (0, 1, True, "pruned"), (0, 8, False, "exhaustive")):   # 60000 / 8192 = 7.3 results
         bt = dev.batch(queries, k=k, opts={"impact": impact})
         bt.stats(True)
         _check_batch(bt, orc, queries, k)
