@@ -652,6 +652,7 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
         SA_SPT(20);
         const u32 nc = s_nc;
         for (u32 z0 = 0; z0 < nc; z0 += NT) {                   // (uniform)
+            if (z0 + (tid & ~(u32)(SA_WAVE - 1)) >= nc) continue;   // (a wave without a finalist issues nothing: the VALU is the busiest unit, and the other workgroup of the CU wants it)
             const u32 z = z0 + tid;
             const bool havez = z < nc;
             const u32* const c = s_c + (havez ? z : 0u) * (2u + (u32)TMAX);
@@ -933,6 +934,7 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                 //      contribution + everything the query's other terms can add in this tile, against the bound.  The survivors'
                 //      records -- query | position << 8 | posting << 11 -- are compacted into s_b (one LDS atomic per wave).
                 for (u32 x0 = c0; x0 < cend; x0 += NT) {          // (uniform)
+                    if (x0 + (tid & ~(u32)(SA_WAVE - 1)) >= cend) continue;   // (a wave without a candidate issues nothing)
                     const u32 x = x0 + tid;
                     const bool valid = x < cend;
                     const u32 xx = valid ? x : c0;
@@ -987,6 +989,7 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                     const u32 cnt = want < room ? want : room;
                     SA_SPT(16);
                     const u32 y = y0 + tid;
+                    if ((tid & ~(u32)(SA_WAVE - 1)) < cnt) {       // (a wave without a survivor issues nothing)
                     // (branch-free, the searches of the query's staged terms IN LOCKSTEP: every LDS read of a step is issued before the
                     //  first is looked at -- one term after the other, with an early exit between them, was a chain of ~35 dependent
                     //  LDS round trips per survivor)
@@ -1079,6 +1082,7 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
 #pragma unroll
                             for (int i = 0; i < TMAX; i++) c[2 + i] = __float_as_uint(xs[i]);
                         }
+                    }
                     }
                     SA_SPT(18);
                     __syncthreads();
