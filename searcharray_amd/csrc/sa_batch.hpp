@@ -13,6 +13,18 @@
 #define SA_SP_CHUNK_LEAD 256
 #define SA_SP_CHUNK 1024
 
+// the plan of one slice of a query set (at most 256 device rows) on the staged-tile route: one launch (sa_stage.hip)
+struct sa_stagedir;
+struct sa_stage_slice {
+    u32 q0 = 0, nq = 0;             // device rows [q0, q0 + nq)
+    u32 U = 0, NS = 0;              // distinct terms of the slice; the first NS are staged, the others probed in their probe rows
+    u32 docs = 0, tmax = 4;         // docs per stage tile; kernel instantiation (4 or 8 terms per query)
+    u32 imp_bytes = 0;              // bytes of the stream from cell_base to the end of the slice's last staged term
+    u64 cell_base = 0;              // smallest impact-stream cell of the slice's staged terms (the kernel's 32-bit offsets count from it)
+    float cand_per_doc = 0.f;       // candidates per document the plan expects
+    std::shared_ptr<sa_stagedir> dir;
+};
+
 // working arrays of sa_stage_plan (sa_stage.hip), kept in the batch between query sets
 struct sa_stage_scratch {
     std::vector<u32> tmap;                     // [n_terms] term -> distinct index while a plan runs, all ones otherwise
@@ -134,6 +146,7 @@ struct sa_batch {
     u64 st_cell_base = 0;           // smallest impact-stream cell of the set's terms (the kernel's 32-bit offsets count from it)
     u32 st_tmax = 4;                // kernel instantiation: 4 or 8 terms per query
     std::shared_ptr<sa_stagedir> st_dir;
+    std::vector<sa_stage_slice> st_slices;   // the current set's plan, slice by slice (empty: none); the st_* fields above repeat slice 0
     sa_stage_scratch st_work;       // the plan's working arrays (kept between plans: a plan allocates nothing)
     char* d_st = nullptr;           // the plan's region of the upload block (sa_stage_bind carves it)
     size_t st_bytes = 0;

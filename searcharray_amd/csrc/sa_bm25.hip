@@ -2431,6 +2431,7 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
     // only runs if the run takes another route after all (sa_batch_ensure_bounds)
     bt->stage_ok = false;
     bt->st_dir.reset();
+    bt->st_slices.clear();
     if (bt->seed_on && sa_batch_stage_wanted(bt)) SA_TRY(sa_stage_plan(bt, img, h_terms, h_idf));
     const u64 t_host = sa_now_ns();
     SA_TRY(sa_batch_upload_commit(bt));

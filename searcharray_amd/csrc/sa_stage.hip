@@ -242,7 +242,10 @@ static StLayout sa_stage_layout(u32 B, u32 T) {
     L.total = off;
     return L;
 }
-size_t sa_stage_upload_bytes(u32 B, u32 T) { return sa_stage_layout(B, T).total; }
+// (a query set of more than SA_ST_BMAX queries is planned and run in SLICES of SA_ST_BMAX device rows: one region of the layout each)
+static u32 sa_stage_slices(u32 B) { return (B + (u32)SA_ST_BMAX - 1u) / (u32)SA_ST_BMAX; }
+static size_t sa_stage_slice_bytes(u32 B, u32 T) { return sa_stage_layout(B < (u32)SA_ST_BMAX ? B : (u32)SA_ST_BMAX, T).total; }
+size_t sa_stage_upload_bytes(u32 B, u32 T) { return (size_t)sa_stage_slices(B) * sa_stage_slice_bytes(B, T); }
 
 // the bound the kernel forms from a cm word: the largest factor's fp32 pattern with its low 16 bits rounded UP
 static float sa_st_round_up16(float f) { u32 b; memcpy(&b, &f, 4); b = ((b + 0xFFFFu) >> 16) << 16; float r; memcpy(&r, &b, 4); return r; }
@@ -250,22 +253,20 @@ static float sa_st_round_up16(float f) { u32 b; memcpy(&b, &f, 4); b = ((b + 0xF
 // Plan the query set (row_terms / row_idf: [B][T] in device-row order) into the upload image: distinct terms (staged ones first, most
 // frequent first, then the probed ones), per query the terms in the kernel's order with their weights, the starting bounds.
 // Leaves bt->stage_ok false when the set is not for this route (the caller then takes another one).
-int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* row_idf) {
-    bt->stage_ok = false;
+// one slice: device rows [q0, q0 + B) of the set (row_terms / row_idf point at row q0); `base`: the slice's region of the image, h_seed:
+// the starting bounds of its rows.  *ok = the slice has a plan (in `out`).
+static int sa_stage_plan_slice(sa_batch* bt, char* base, u32* h_seed, const u32* row_terms, const float* row_idf, u32 q0, u32 B,
+                               sa_stage_slice& out, bool* ok) {
+    *ok = false;
     sa_index* ix = bt->ix;
-    const u32 B = bt->B, T = bt->T;
+    const u32 T = bt->T;
     sa_impacts* im = bt->impacts.get();
-    if (!im || im->h_maxf.size() != ix->n_terms || im->h_topf.size() != (size_t)ix->n_terms * SA_TOPF_NR) return SA_OK;
-    if (B > SA_ST_BMAX || T > 8 || !bt->d_st || ix->n_docs == 0 || ix->n_docs > (1ull << 28)) return SA_OK;
     const bool probing = sa_opt(bt->opts.stage_probe, 1) != 0;
-    if (probing) sa_probe_rows_ensure(ix, im, bt->opts);
     const StLayout L = sa_stage_layout(B, T);
-    char* base = img + (bt->d_st - bt->d_up);
     StTerm* h_terms = (StTerm*)(base + L.terms);
     float* h_pw = (float*)(base + L.pw);
     u32* h_inv = (u32*)(base + L.inv);
     unsigned short* h_pu = (unsigned short*)(base + L.pu);
-    u32* h_seed = (u32*)(img + ((char*)bt->d_seed - bt->d_up));
 
     // distinct terms: di[slot] = index of the slot's term among the set's distinct terms (SA_ST_NONE: unknown term).  The map from
     // term ids is a table of the batch (n_terms cells, all ones between plans: the cells written are put back below) and every
@@ -447,12 +448,47 @@ int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* ro
             return SA_OK;
         }
     }
-    bt->st_U = U; bt->st_NS = NS; bt->st_docs = docs; bt->st_tmax = tmax;
-    bt->st_cand_per_doc = cpd;
-    if (sa_opt(bt->opts.trace, 0)) fprintf(stderr, "sa_stage_plan: %u terms (%u staged, %u probed), %u docs per tile, %.3f candidates per doc expected\n", U, NS, U - NS, docs, bt->st_cand_per_doc);
-    bt->st_cell_base = cell_lo;
-    bt->st_imp_bytes = (u32)((cell_hi - cell_lo) * 8ull);
-    bt->st_dir = sd;
+    out.q0 = q0; out.nq = B; out.U = U; out.NS = NS; out.docs = docs; out.tmax = tmax;
+    out.cand_per_doc = cpd;
+    if (sa_opt(bt->opts.trace, 0)) fprintf(stderr, "sa_stage_plan: rows %u..%u: %u terms (%u staged, %u probed), %u docs per tile, %.3f candidates per doc expected\n", q0, q0 + B, U, NS, U - NS, docs, cpd);
+    out.cell_base = cell_lo;
+    out.imp_bytes = (u32)((cell_hi - cell_lo) * 8ull);
+    out.dir = sd;
+    *ok = true;
+    return SA_OK;
+}
+
+int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* row_idf) {
+    bt->stage_ok = false;
+    bt->st_slices.clear();
+    sa_index* ix = bt->ix;
+    const u32 B = bt->B, T = bt->T;
+    sa_impacts* im = bt->impacts.get();
+    if (!im || im->h_maxf.size() != ix->n_terms || im->h_topf.size() != (size_t)ix->n_terms * SA_TOPF_NR) return SA_OK;
+    if (B == 0 || T > 8 || !bt->d_st || ix->n_docs == 0 || ix->n_docs > (1ull << 28)) return SA_OK;
+    // Sets of more than 256 queries run slice by slice, one launch after the other.  Measured against the overlay route, whose items
+    // grow with the set (profiles/wide_set_routes_r06.jsonl, BASELINE-shaped sets, k = 10): 1024 queries at 10 M docs 1.095 vs 1.166 ms,
+    // 2048 queries 2.195 vs 2.171 -- unless forced, up to 1024 queries
+    if (B > 4u * (u32)SA_ST_BMAX && sa_opt(bt->opts.stage, -1) != 1) return SA_OK;
+    if (sa_opt(bt->opts.stage_probe, 1) != 0) sa_probe_rows_ensure(ix, im, bt->opts);
+    const u32 S = sa_stage_slices(B);
+    const size_t SB = sa_stage_slice_bytes(B, T);
+    char* base = img + (bt->d_st - bt->d_up);
+    u32* h_seed = (u32*)(img + ((char*)bt->d_seed - bt->d_up));
+    bt->st_slices.resize(S);
+    for (u32 sl = 0; sl < S; sl++) {
+        const u32 q0 = sl * (u32)SA_ST_BMAX, nq = std::min<u32>((u32)SA_ST_BMAX, B - q0);
+        bool ok = false;
+        SA_TRY(sa_stage_plan_slice(bt, base + sl * SB, h_seed + q0, row_terms + (size_t)q0 * T, row_idf + (size_t)q0 * T, q0, nq, bt->st_slices[sl], &ok));
+        if (!ok) {                                              // (one slice the route does not take: the whole set runs another route)
+            bt->st_slices.clear();
+            for (u32 q = 0; q < B; q++) h_seed[q] = 0u;         // (the slice-table kernel forms the starting bounds of that route)
+            return SA_OK;
+        }
+    }
+    const sa_stage_slice& f = bt->st_slices[0];
+    bt->st_U = f.U; bt->st_NS = f.NS; bt->st_docs = f.docs; bt->st_tmax = f.tmax; bt->st_cand_per_doc = f.cand_per_doc;
+    bt->st_cell_base = f.cell_base; bt->st_imp_bytes = f.imp_bytes; bt->st_dir = f.dir;
     bt->stage_ok = true;
     return SA_OK;
 }
@@ -1118,44 +1154,51 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
 
 int sa_launch_stage(sa_batch* bt, const Bm25Params& p, hipStream_t st) {
     sa_index* ix = bt->ix;
-    if (!bt->stage_ok || !bt->st_dir || !bt->impacts || !p.hist || !p.gthr || !p.imp) { sa_set_error("staged route: no plan"); return SA_ERR_STATE; }
-    const StLayout L = sa_stage_layout(bt->B, bt->T);
-    StageParams sp;
-    memset(&sp, 0, sizeof(sp));
-    sp.imp = p.imp; sp.cell_base = bt->st_cell_base;
-    sp.imp_bytes = bt->st_imp_bytes;
-    sp.cm_bytes = (u32)std::min<u64>(0xFFFFFFE0ull, (u64)bt->st_dir->n_rows * bt->st_dir->n_st * 4ull);
-    sp.abs = bt->st_dir->d_abs; sp.cm = bt->st_dir->d_cm;
-    sp.docs = bt->st_docs; sp.n_st = bt->st_dir->n_st;
-    sp.n_docs = ix->n_docs; sp.doc_base = ix->doc_base;
-    sp.terms = (const StTerm*)(bt->d_st + L.terms); sp.U = bt->st_U; sp.NS = bt->st_NS;
-    sp.probe = bt->impacts->d_probe ? bt->impacts->d_probe : (const float*)p.imp;      // (no probe rows: nothing is probed; the kernel's unconditional loads read a cell nobody uses)
-    sp.probe_rows64 = (u64)bt->impacts->n_probe * 64ull;
-    sp.pbits = bt->impacts->d_pbits; sp.pbits_words = (u32)bt->impacts->pbits_words;
-    sp.pbits_bytes = bt->impacts->d_pbits ? (u32)std::min<u64>(0xFFFFFFE0ull, (u64)bt->impacts->n_probe * bt->impacts->pbits_words * 4ull) : 16u;
-    sp.NPB = bt->impacts->d_pbits && bt->st_docs <= 1024u && bt->st_docs % 128u == 0u ? std::min<u32>(bt->st_U - bt->st_NS, bt->st_tmax == 4 ? (u32)SaStNpb<4>::v : (u32)SaStNpb<8>::v) : 0u;
-    sp.B = bt->B; sp.T = bt->T; sp.k = bt->k;
-    sp.pu = (const unsigned short*)(bt->d_st + L.pu);
-    sp.pw = (const float*)(bt->d_st + L.pw);
-    sp.inv = (const u32*)(bt->d_st + L.inv);
-    sp.seed = p.seed;
-    sp.gthr = p.gthr; sp.hist = p.hist;
-    sp.cand = p.cand; sp.cand_cap = p.cand_cap; sp.cand_cnt = p.cand_cnt;
-    sp.flag = bt->d_overflow;
-    if (sp.n_st == 0) return SA_OK;
+    if (!bt->stage_ok || bt->st_slices.empty() || !bt->impacts || !p.hist || !p.gthr || !p.imp) { sa_set_error("staged route: no plan"); return SA_ERR_STATE; }
+    const size_t SB = sa_stage_slice_bytes(bt->B, bt->T);
     const u32 wgs = (u32)std::min<long long>(8, std::max<long long>(1, sa_opt(bt->opts.stage_wgs, 2)));
     u32 grid = (u32)ix->n_cus * wgs / 8u * 8u;
     if (grid < 8u) grid = 8u;
-    sp.tpx = (sp.n_st + 7u) / 8u;
-    const u32 wpx = grid / 8u;
-    sp.tpw = (sp.tpx + wpx - 1u) / wpx;
-    const bool one = bt->st_NS <= (u32)SA_ST_NT;
-    if (bt->st_tmax == 4) {
-        if (one) hipLaunchKernelGGL((sa_k_bm25_stage<4, 1>), dim3(grid), dim3(SA_ST_NT), 0, st, sp);
-        else hipLaunchKernelGGL((sa_k_bm25_stage<4, 2>), dim3(grid), dim3(SA_ST_NT), 0, st, sp);
-    } else {
-        if (one) hipLaunchKernelGGL((sa_k_bm25_stage<8, 1>), dim3(grid), dim3(SA_ST_NT), 0, st, sp);
-        else hipLaunchKernelGGL((sa_k_bm25_stage<8, 2>), dim3(grid), dim3(SA_ST_NT), 0, st, sp);
+    // one launch per slice of SA_ST_BMAX device rows, one after the other on the batch's stream: the slice's tables, and the rows'
+    // bounds / histograms / candidate lists (the kernel numbers its queries from 0)
+    for (size_t sl = 0; sl < bt->st_slices.size(); sl++) {
+        const sa_stage_slice& x = bt->st_slices[sl];
+        const StLayout L = sa_stage_layout(x.nq, bt->T);
+        const char* base = bt->d_st + sl * SB;
+        StageParams sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.imp = p.imp; sp.cell_base = x.cell_base;
+        sp.imp_bytes = x.imp_bytes;
+        sp.cm_bytes = (u32)std::min<u64>(0xFFFFFFE0ull, (u64)x.dir->n_rows * x.dir->n_st * 4ull);
+        sp.abs = x.dir->d_abs; sp.cm = x.dir->d_cm;
+        sp.docs = x.docs; sp.n_st = x.dir->n_st;
+        sp.n_docs = ix->n_docs; sp.doc_base = ix->doc_base;
+        sp.terms = (const StTerm*)(base + L.terms); sp.U = x.U; sp.NS = x.NS;
+        sp.probe = bt->impacts->d_probe ? bt->impacts->d_probe : (const float*)p.imp;      // (no probe rows: nothing is probed; the kernel's unconditional loads read a cell nobody uses)
+        sp.probe_rows64 = (u64)bt->impacts->n_probe * 64ull;
+        sp.pbits = bt->impacts->d_pbits; sp.pbits_words = (u32)bt->impacts->pbits_words;
+        sp.pbits_bytes = bt->impacts->d_pbits ? (u32)std::min<u64>(0xFFFFFFE0ull, (u64)bt->impacts->n_probe * bt->impacts->pbits_words * 4ull) : 16u;
+        sp.NPB = bt->impacts->d_pbits && x.docs <= 1024u && x.docs % 128u == 0u ? std::min<u32>(x.U - x.NS, x.tmax == 4 ? (u32)SaStNpb<4>::v : (u32)SaStNpb<8>::v) : 0u;
+        sp.B = x.nq; sp.T = bt->T; sp.k = bt->k;
+        sp.pu = (const unsigned short*)(base + L.pu);
+        sp.pw = (const float*)(base + L.pw);
+        sp.inv = (const u32*)(base + L.inv);
+        sp.seed = p.seed ? p.seed + x.q0 : nullptr;
+        sp.gthr = p.gthr + x.q0; sp.hist = p.hist + (size_t)x.q0 * SA_HBINS;
+        sp.cand = p.cand + (size_t)x.q0 * p.cand_cap; sp.cand_cap = p.cand_cap; sp.cand_cnt = p.cand_cnt + x.q0;
+        sp.flag = bt->d_overflow;
+        if (sp.n_st == 0) continue;
+        sp.tpx = (sp.n_st + 7u) / 8u;
+        const u32 wpx = grid / 8u;
+        sp.tpw = (sp.tpx + wpx - 1u) / wpx;
+        const bool one = x.NS <= (u32)SA_ST_NT;
+        if (x.tmax == 4) {
+            if (one) hipLaunchKernelGGL((sa_k_bm25_stage<4, 1>), dim3(grid), dim3(SA_ST_NT), 0, st, sp);
+            else hipLaunchKernelGGL((sa_k_bm25_stage<4, 2>), dim3(grid), dim3(SA_ST_NT), 0, st, sp);
+        } else {
+            if (one) hipLaunchKernelGGL((sa_k_bm25_stage<8, 1>), dim3(grid), dim3(SA_ST_NT), 0, st, sp);
+            else hipLaunchKernelGGL((sa_k_bm25_stage<8, 2>), dim3(grid), dim3(SA_ST_NT), 0, st, sp);
+        }
     }
     return SA_OK;
 }

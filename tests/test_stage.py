@@ -111,3 +111,13 @@ def test_probed_terms_and_streaming_everything(api, corpus):
     set_opt("stage_probe", 0)
     b = check(api, corpus, queries, 10)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_wide_query_sets_run_in_slices_of_256_rows(api, corpus):
+    """more than 256 queries per set: the plan and the launches go slice by slice (256 device rows each, the last one partial), every
+    query's top-k still equals the oracle's; a set with a slice the route does not take runs another route as a whole"""
+    rng = np.random.default_rng(77)
+    queries = band_queries(rng, 600, 4, heads=[0, 1, 2, 7, 350])
+    check(api, corpus, queries, 10)
+    check(api, corpus, queries[:257], 3, doc_base=1 << 20)
+    check(api, corpus, band_queries(rng, 513, 3, heads=[0, 5]), 10, force=False)      # (the library's own rule: few candidates, k <= 32)
