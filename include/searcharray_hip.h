@@ -516,6 +516,8 @@ int sa_sharded_phrase_batch_create(sa_sharded_t* sh, const uint32_t* terms, cons
                                    sa_sharded_batch_t** out);
 int sa_sharded_batch_reset(sa_sharded_batch_t* batch, const uint32_t* terms, const float* idf);
 int sa_sharded_batch_run(sa_sharded_batch_t* batch, int sync);
+/* replace the options of every shard's batch (as sa_batch_set_options does for one) */
+int sa_sharded_batch_set_options(sa_sharded_batch_t* batch, const sa_options_t* opts);
 int sa_sharded_batch_fetch(sa_sharded_batch_t* batch, float* scores_out, uint64_t* docs_out);
 int sa_sharded_batch_destroy(sa_sharded_batch_t* batch);
 

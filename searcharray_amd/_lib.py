@@ -131,6 +131,7 @@ PROTOTYPES = {
                                                c_int, c_float, c_float, POINTER(c_void_p)]),
     "sa_sharded_batch_reset": (c_int, [c_void_p, u32p, f32p]),
     "sa_sharded_batch_run": (c_int, [c_void_p, c_int]),
+    "sa_sharded_batch_set_options": (c_int, [c_void_p, c_void_p]),
     "sa_sharded_batch_fetch": (c_int, [c_void_p, f32p, u64p]),
     "sa_sharded_batch_destroy": (c_int, [c_void_p]),
     "sa_index_select_rows": (c_int, [c_void_p, u64p, c_uint64]),

@@ -3077,6 +3077,9 @@ extern "C" int sa_batch_get_options(sa_batch_t* bt, sa_options_t* out) {
 
 extern "C" int sa_batch_destroy(sa_batch_t* bt) {
     if (!bt) return SA_OK;
-    sa_batch_free(bt);
+    // (under the index lock: a dense call on another thread swaps ix->stream / scratch to its lane while it holds the lock --
+    //  sa_batch_free must synchronise the index's own stream, not a lane's)
+    if (bt->ix) { std::lock_guard<std::mutex> g(bt->ix->mu); sa_batch_free(bt); }
+    else sa_batch_free(bt);
     return SA_OK;
 }

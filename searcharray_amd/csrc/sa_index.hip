@@ -116,11 +116,20 @@ extern "C" int sa_options_set_thread_defaults(const sa_options_t* o) {
     if (o) t_sa_opts = *o;
     return SA_OK;
 }
-// what a handle created by this thread starts from: the thread's defaults, else `fallback` (a batch: its index's options), else the
-// process defaults
+// what a handle created by this thread starts from, per switch: the thread's default, else `fallback` (a batch: its index's
+// option), else the process default
+// (field by field: a thread default that sets ONE switch does not erase the index's other options or the SA_OPTS override)
 sa_options_t sa_options_for_new_handle(const sa_options_t* fallback) {
-    if (t_sa_opts_set) return t_sa_opts;
-    return fallback ? *fallback : sa_options_process_defaults();
+    sa_options_t o = sa_options_process_defaults();
+#define SA_X(f) if (fallback && sa_opt_is_set(fallback->f)) o.f = fallback->f;
+    SA_OPTION_LIST(SA_X)
+#undef SA_X
+    if (t_sa_opts_set) {
+#define SA_X(f) if (sa_opt_is_set(t_sa_opts.f)) o.f = t_sa_opts.f;
+        SA_OPTION_LIST(SA_X)
+#undef SA_X
+    }
+    return o;
 }
 bool sa_options_thread_defaults(sa_options_t* out) {
     if (t_sa_opts_set && out) *out = t_sa_opts;

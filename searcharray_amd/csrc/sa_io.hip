@@ -24,8 +24,11 @@
 
 namespace {
 
-// what the calling thread's options say (the file routines run before / without an index handle)
-static sa_options_t sa_io_opts() { return sa_options_for_new_handle(nullptr); }
+// the options of the handle a file routine works for (sa_index_save: the index's), over what the calling thread's defaults say (the
+// loading routines run before an index handle exists)
+static thread_local const sa_options_t* t_io_handle_opts = nullptr;
+static sa_options_t sa_io_opts() { return sa_options_for_new_handle(t_io_handle_opts); }
+struct SaIoHandleOpts { SaIoHandleOpts(const sa_options_t* o) { t_io_handle_opts = o; } ~SaIoHandleOpts() { t_io_handle_opts = nullptr; } };
 // bytes per staged piece (option io_piece_bytes: test hook, lets small files exercise the ring's wrap-around)
 static size_t sa_io_piece() {
     size_t v = 4u << 20;      // larger pieces only add page-locking time (~0.5 ms per MiB of ring), measured
@@ -362,6 +365,7 @@ extern "C" int sa_index_create_from_file(int device, uint64_t n_docs, uint64_t d
 extern "C" int sa_index_save(sa_index_t* ix, const char* path) {
     SA_ARG(ix && path, "null argument");
     std::lock_guard<std::mutex> g(ix->mu);
+    SaIoHandleOpts io_opts(&ix->opts);                         // (io_piece_bytes / io_threads of the INDEX apply to its save)
     SA_HIP(hipSetDevice(ix->device));
     const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
     if (fd < 0) { sa_set_error("cannot create %s: %s", path, strerror(errno)); return SA_ERR_IO; }

@@ -296,6 +296,12 @@ extern "C" int sa_sharded_batch_run(sa_sharded_batch_t* bt, int sync) {
     return bt->sh->all([&](int g) { return sa_batch_run(bt->parts[(size_t)g], sync); });
 }
 
+// replace the options of every shard's batch (the sharded counterpart of sa_batch_set_options)
+extern "C" int sa_sharded_batch_set_options(sa_sharded_batch_t* bt, const sa_options_t* o) {
+    SA_ARG(bt && bt->sh && o, "null argument");
+    return bt->sh->all([&](int g) { return bt->parts[(size_t)g] ? sa_batch_set_options(bt->parts[(size_t)g], o) : SA_OK; });
+}
+
 extern "C" int sa_sharded_batch_fetch(sa_sharded_batch_t* bt, float* scores_out, uint64_t* docs_out) {
     SA_ARG(bt && bt->sh && scores_out && docs_out, "null argument");
     // collective: after a candidate-list overflow all ranks redo the batch together (sa_batch_fetch)

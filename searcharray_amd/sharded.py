@@ -153,7 +153,7 @@ class ShardedIndex:
         with _options.creating(self.api, _options.Options(self._opts, opts)):
             self.api.call("sa_sharded_batch_create", self._h, _lib.p_u32(terms), _lib.p_f32(idf), q.shape[0], q.shape[1], int(k),
                           np.float32(k1), np.float32(b), _lib.ctypes.byref(h))
-        return ShardedBatch(self, h, q.shape[0], int(k), n_terms=q.shape[1])
+        return ShardedBatch(self, h, q.shape[0], int(k), n_terms=q.shape[1], opts=_options.Options(self._opts, opts))
 
     def phrase_batch(self, phrases, k: int = 10, k1: float = 1.2, b: float = 0.75, slop=0, opts=None) -> "ShardedBatch":
         ct = _lib.ctypes
@@ -176,7 +176,7 @@ class ShardedIndex:
             self.api.call("sa_sharded_phrase_batch_create", self._h, _lib.p_u32(_lib.as_u32(terms)),
                           n_terms.ctypes.data_as(ct.POINTER(ct.c_int32)), slops.ctypes.data_as(ct.POINTER(ct.c_int32)),
                           _lib.p_f32(_lib.as_f32(idf)), B, T, int(k), np.float32(k1), np.float32(b), ct.byref(h))
-        return ShardedBatch(self, h, B, int(k))
+        return ShardedBatch(self, h, B, int(k), opts=_options.Options(self._opts, opts))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -196,13 +196,16 @@ class ShardedIndex:
             pass
 
 
-class ShardedBatch:
+class ShardedBatch(_options.OptionsMixin):
     """One resident query batch per shard behind one handle (``sa_sharded_batch_*``); ``run`` = score every shard +
-    all-gather + merge, ``fetch`` = the merged top-k."""
+    all-gather + merge, ``fetch`` = the merged top-k.  Follows the thread's scoped options and ``set_options`` like a
+    ``QueryBatch`` does (``sa_sharded_batch_set_options`` fans out to the shards' batches)."""
+    _opt_setter = "sa_sharded_batch_set_options"
 
-    def __init__(self, index: ShardedIndex, handle, B: int, k: int, n_terms: Optional[int] = None):
+    def __init__(self, index: ShardedIndex, handle, B: int, k: int, n_terms: Optional[int] = None, opts=None):
         self.index, self.api, self._h = index, index.api, handle
         self.B, self.k, self.T = B, k, n_terms
+        self._init_opts(opts)
 
     def reset(self, queries: np.ndarray):
         q = np.asarray(queries, dtype=np.int64)
@@ -210,10 +213,10 @@ class ShardedBatch:
             raise ValueError("reset takes a BM25 batch and queries of its shape")
         idf = _lib.as_f32(self.index.idfs(q.reshape(-1)).reshape(q.shape))
         terms = _lib.as_u32(np.where((q >= 0) & (q < self.index.n_terms), q, NO_TERM).astype(np.uint32))
-        self.api.call("sa_sharded_batch_reset", self._h, _lib.p_u32(terms), _lib.p_f32(idf))
+        self._call("sa_sharded_batch_reset", self._h, _lib.p_u32(terms), _lib.p_f32(idf))
 
     def run(self, sync: bool = True):
-        self.api.call("sa_sharded_batch_run", self._h, 1 if sync else 0)
+        self._call("sa_sharded_batch_run", self._h, 1 if sync else 0)
 
     def synchronize(self):
         self.index.map(lambda g, s: s.synchronize())
@@ -221,7 +224,7 @@ class ShardedBatch:
     def fetch(self) -> Tuple[np.ndarray, np.ndarray]:
         scores = np.empty((self.B, self.k), dtype=np.float32)
         docs = np.empty((self.B, self.k), dtype=np.uint64)
-        self.api.call("sa_sharded_batch_fetch", self._h, _lib.p_f32(scores), _lib.p_u64(docs))
+        self._call("sa_sharded_batch_fetch", self._h, _lib.p_f32(scores), _lib.p_u64(docs))
         return scores, docs
 
     def close(self):

@@ -89,6 +89,38 @@ def test_sharded_topk_is_bit_identical_to_the_single_index_oracle(api, corpus, s
         ix.close()
 
 
+def test_sharded_batch_follows_options_set_after_its_creation(api, corpus):
+    """sa_sharded_batch_set_options fans out to the shards' batches: a switch set on an existing sharded batch -- set_options, or the
+    thread's scoped options -- applies to its next run (it used to be ignored silently).  cand_cap is read when a batch is
+    CREATED, so the observable switch here is the route: every route returns the same top-k, and the batch reports what it was given."""
+    words, off, lens, orc = corpus
+    ix = ShardedIndex(words, off, lens, devices=[0, 0], tile_docs=1024, api=api)
+    try:
+        bt = ix.batch(QUERIES, k=K)
+        want = None
+        for kw in ({}, {"stage": 0}, {"stage": 1}, {"stage": 0, "sparse": 1}, {"stage": None, "sparse": None}):
+            if kw:
+                bt.set_options(**kw)
+                for name, v in kw.items():
+                    assert bt.options().get(name) == v
+            bt.run()
+            got = bt.fetch()
+            if want is None:
+                want = got
+                for qi, q in enumerate(QUERIES):
+                    ws, wd = O.topk(orc.score_terms_sum([int(x) for x in q]), K)
+                    assert np.array_equal(got[0][qi], ws) and np.array_equal(got[1][qi][ws > 0], wd[ws > 0])
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), kw
+        set_opt("group", 0)                                      # (the thread's scope reaches the existing batch too)
+        bt.run()
+        got = bt.fetch()
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        assert bt.options().get("group") == 0
+        bt.close()
+    finally:
+        ix.close()
+
+
 def test_search_array_search_over_devices(default_api):
     from searcharray_amd import SearchArray
     docs = ["foo bar bar baz", "data2", "data3 bar", "bunny funny wunny"] * 25

@@ -121,3 +121,12 @@ def test_wide_query_sets_run_in_slices_of_256_rows(api, corpus):
     check(api, corpus, queries, 10)
     check(api, corpus, queries[:257], 3, doc_base=1 << 20)
     check(api, corpus, band_queries(rng, 513, 3, heads=[0, 5]), 10, force=False)      # (the library's own rule: few candidates, k <= 32)
+
+
+def test_candidate_list_overflow_is_redone(api, corpus):
+    """a candidate list of 64 keys per query (test hook cand_cap) runs over on the staged route like on the others: the cursor keeps
+    counting, the merge flags the query, the run is redone without bounds at fetch -- results still equal the oracle"""
+    set_opt("SA_CAND_CAP", "64")
+    rng = np.random.default_rng(9)
+    queries = band_queries(rng, 32, 4, heads=[0, 1])
+    check(api, corpus, queries, 50)
