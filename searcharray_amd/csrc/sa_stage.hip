@@ -434,17 +434,23 @@ static int sa_stage_plan_slice(sa_batch* bt, char* base, u32* h_seed, const u32*
         u32 sb; memcpy(&sb, &seeds[q], 4);
         h_seed[q] = seeds[q] > 0.f ? sb : 0u;
     }
-    // Unless the caller forces the route (option stage = 1): only where it was measured ahead of the grouped overlay kernel
-    // (scripts/gpu_r6_stage4.sh, profiles/route_rule_r06.jsonl; 10 M docs, 256 queries): few candidates per document at small k --
-    // the BASELINE set up to k = 32 (1.8 .. 2.1 candidates per doc: 0.24 / 0.28 / 0.35 ms against 0.38 / 0.38 / 0.39), not at k = 100
-    // (2.3: 0.47 against 0.42) or k = 1000; not the pairwise-distinct set (3.7 per doc and 768 staged terms: 0.97 against 0.46) --
-    // or a handful of staged terms (the `hot` set, 8 staged terms: ahead up to k = 100)
+    // Unless the caller forces the route (option stage = 1): only where it was measured ahead of the grouped overlay / per-query kernels
+    // (profiles/route_rule_r06.jsonl, small_set_routes_r06.jsonl; 10 M docs):
+    //  * few candidates per document at small k -- the BASELINE set of 256 queries up to k = 32 (1.8 .. 2.1 candidates per doc: 0.24 / 0.28 /
+    //    0.36 ms against 0.37 / 0.38 / 0.39), not at k = 100 (2.3: 0.47 against 0.42) or k = 1000, not the pairwise-distinct set (3.7 per doc
+    //    and 768 staged terms: 0.97 against 0.46);
+    //  * k up to 100 when the set is small -- 16 queries 0.29 against 0.60 ms, 64 queries 0.215 against 0.226 (0.6 candidates per doc);
+    //  * a handful of staged terms (the `hot` set, 8 staged terms: ahead up to k = 100);
+    //  * NOT a set of one to three queries: the route walks every tile of the shard whatever the number of queries (one query 0.150 ms
+    //    against 0.055 for the per-query kernel, four queries 0.165 against 0.150 at k = 10, 0.235 against 0.284 at k = 100).
     const float cpd = (float)(cand_df / (double)ix->n_docs);
     if (sa_opt(bt->opts.stage, -1) != 1) {
-        const bool few_cands = bt->k <= 32u && cpd <= 2.5f && NS <= (u32)SA_ST_NT;
-        const bool few_terms = bt->k <= 100u && NS <= 32u;
-        if (!few_cands && !few_terms) {
-            if (sa_opt(bt->opts.trace, 0)) fprintf(stderr, "sa_stage_plan: not taken (k = %u, %u staged terms, %.3f candidates per doc expected)\n", bt->k, NS, cpd);
+        const u32 Bset = bt->B;
+        const bool few_cands = bt->k <= 32u && cpd <= 2.5f && NS <= (u32)SA_ST_NT && Bset >= 8u;
+        const bool small_set = bt->k > 32u && bt->k <= 100u && cpd <= 0.6f && NS <= (u32)SA_ST_NT && Bset >= 4u;
+        const bool few_terms = bt->k <= 100u && NS <= 32u && Bset >= (bt->k <= 32u ? 8u : 4u);
+        if (!few_cands && !small_set && !few_terms) {
+            if (sa_opt(bt->opts.trace, 0)) fprintf(stderr, "sa_stage_plan: not taken (%u queries, k = %u, %u staged terms, %.3f candidates per doc expected)\n", Bset, bt->k, NS, cpd);
             return SA_OK;
         }
     }

@@ -500,7 +500,7 @@ def test_dynamic_pruning_default_policy(api, monkeypatch):
     words, wt = rz.encode_sorted(t, d, p)
     dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
     orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
-    queries = np.asarray([[0, 40, 700, 2500], [2900, 1, 3, 1500], [2999, 2998, 0, 1]])
+    queries = np.asarray([[0, 40, 700, 2500], [2900, 1, 3, 1500], [2999, 2998, 0, 1]] + [[i, 50 + i, 900 + i, 2000 + i] for i in range(6)])
     for impact, k, pruned, route in ((1, 1, False, "staged"), (0, 1, True, "pruned"), (0, 8, False, "exhaustive")):   # 60000 / 8192 = 7.3 results
         bt = dev.batch(queries, k=k, opts={"impact": impact})
         bt.stats(True)

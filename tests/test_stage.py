@@ -94,6 +94,7 @@ def test_route_rule_and_options(api, corpus):
     queries = band_queries(rng, 24, 4, heads=[0, 3])
     check(api, corpus, queries, 5, expect="staged", force=False)
     check(api, corpus, queries, 200, expect="exhaustive", force=False)
+    check(api, corpus, queries[:3], 5, expect="exhaustive", force=False)     # (one to three queries: the per-query kernel, the route walks every tile whatever the set)
     set_opt("SA_SPARSE", "0")
     check(api, corpus, queries, 10, expect="exhaustive", force=False)
     set_opt("stage", 1)
@@ -101,6 +102,7 @@ def test_route_rule_and_options(api, corpus):
     unset_opt("SA_SPARSE")
     set_opt("stage", 0)
     check(api, corpus, queries, 10, expect="exhaustive", force=False)
+    check(api, corpus, queries[:3], 5, expect="staged")                      # (a set of three, forced: stage = 1)
 
 
 def test_probed_terms_and_streaming_everything(api, corpus):
