@@ -86,6 +86,7 @@ typedef struct sa_options {
     int64_t stage;           /* staged-tile route (sa_stage.hip): 1 force where eligible, 0 off; unset: on where eligible and `sparse` is unset */
     int64_t stage_docs;      /* docs per stage tile (multiple of 64; default: what fits the LDS stage for the query set's terms) */
     int64_t stage_wgs;       /* staged-tile route: resident workgroups per CU (default 2) */
+    int64_t stage_cw;        /* staged-tile route: workgroups of an XCD that co-walk a range of tiles (default 32; 1: private ranges) */
     int64_t stage_probe;     /* 0: the staged-tile route streams EVERY term of the batch; default: terms that cannot be essential are probed in dense rows */
     int64_t probe_div;       /* probe rows (dense factor rows the staged-tile route probes) for terms with df >= n_docs / this (default 128; 0: none) */
     int64_t dense_direct;    /* 0: sa_index_bm25_dense scores the TF postings into scratch and copies (rounds 1-5); default: one launch over the impact stream, straight into the destination */

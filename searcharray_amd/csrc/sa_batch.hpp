@@ -22,6 +22,7 @@ struct sa_stage_slice {
     u32 imp_bytes = 0;              // bytes of the stream from cell_base to the end of the slice's last staged term
     u64 cell_base = 0;              // smallest impact-stream cell of the slice's staged terms (the kernel's 32-bit offsets count from it)
     float cand_per_doc = 0.f;       // candidates per document the plan expects
+    bool all_rowed = true;          // every staged term has a stage-directory row (the launch may let workgroups co-walk tile ranges)
     std::shared_ptr<sa_stagedir> dir;
 };
 

@@ -56,8 +56,8 @@ static const unsigned sa_topf_ranks[SA_TOPF_NR] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 
 struct sa_stagedir {
     int device = 0;
     u32 docs = 0, n_st = 0, n_rows = 0;
-    u32* d_abs = nullptr;           // [n_rows][n_st + 1]
-    u32* d_cm = nullptr;            // [n_rows][n_st]
+    u32* d_dir = nullptr;           // [n_rows][n_st + 1][2]: {abs, cm} of a (term, tile) side by side -- one 8-byte load gives the kernel the slice's
+                                    // start, size and bound (the entry behind a row's last tile: abs = df, cm = 0)
     std::vector<u32> row;           // [n_terms] row of a term, or 0xFFFFFFFF
     ~sa_stagedir();
 };
