@@ -30,7 +30,10 @@ A="--no-cpu-baseline --no-pmc --no-phrase-legs --docs 1250000 --steps 200 --pipe
 ( time timeout 900 python scripts/ab.py --corpus-cache $C --ks 10,100,1000 --qsets baseline,distinct --envs "impact=0,sparse=0;impact=0,sparse=1;impact=0,default=1" ) 2>> $O/route_rule.err | grep "^{" > $O/route_rule_no_impact.jsonl
 # the staged-tile kernel: phase cycles per tile pass (-DSA_PROBE), other tile sizes / workgroups per CU / everything streamed
 ( timeout 300 python scripts/ab.py --corpus-cache $C --ks 10 --qsets baseline,hot --libs build/libsearcharray_hip_probe.so --envs "stage=1" ) 2>&1 | grep "^{" > $O/stage_probe.jsonl
-( timeout 600 python scripts/ab.py --corpus-cache $C --ks 10 --qsets baseline --envs "stage=1;stage=1,stage_docs=768;stage=1,stage_docs=512;stage=1,stage_wgs=1;stage=1,stage_wgs=3;stage=1,stage_probe=0;stage=1,probe_div=32;stage=1,probe_div=512" ) 2>&1 | grep "^{" > $O/stage_sweep.jsonl
+( timeout 600 python scripts/ab.py --corpus-cache $C --ks 10 --qsets baseline --envs "stage=1;stage=1,stage_docs=768;stage=1,stage_docs=512;stage=1,stage_wgs=1;stage=1,stage_wgs=3;stage=1,stage_probe=0;stage=1,probe_div=32;stage=1,probe_div=512;stage=1,stage_cw=1;stage=1,stage_cw=4;stage=1,stage_cw=16;stage=1,stage_cw=64" ) 2>&1 | grep "^{" > $O/stage_sweep.jsonl
+bash scripts/gpu_r6_shards.sh > /dev/null 2>&1
+bash scripts/gpu_r6_pipe.sh > /dev/null 2>&1
+( timeout 600 python scripts/first_batch_ms.py $C ) > $O/first_batch_ms.jsonl 2>/dev/null
 ( time timeout 300 python scripts/dense_ab.py --corpus-cache $C ) > $O/dense_ab.jsonl 2> $O/dense_ab.err
 ( time timeout 300 python scripts/host_cost.py --docs 1250000 ) > $O/host_cost.log 2>&1
 ( time timeout 300 python scripts/host_cost.py --docs 1250000 --comm ) >> $O/host_cost.log 2>&1

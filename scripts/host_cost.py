@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--queries", type=int, default=256)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--comm", action="store_true")
+    ap.add_argument("--default-route", action="store_true")
     args = ap.parse_args()
     api = _lib.api()
     D, V, B = args.docs, args.vocab, args.queries
@@ -32,7 +33,8 @@ def main():
     df = index.docfreqs().astype(np.uint64)
     if args.comm:
         index.comm_init(0, 1, DeviceIndex.comm_unique_id(api))
-    os.environ["SA_SPARSE"] = "0"
+    if not args.default_route:
+        os.environ["SA_SPARSE"] = "0"                          # (rounds 3-5: the exhaustive overlay route; --default-route: the library's own choice)
     sets = [synth.bm25_queries(B, vocab=V, seed=1000 + i) for i in range(8)]
 
     def idf_of(q):

@@ -94,7 +94,7 @@ def test_sharded_batch_follows_options_set_after_its_creation(api, corpus):
     thread's scoped options -- applies to its next run (it used to be ignored silently).  cand_cap is read when a batch is
     CREATED, so the observable switch here is the route: every route returns the same top-k, and the batch reports what it was given."""
     words, off, lens, orc = corpus
-    ix = ShardedIndex(words, off, lens, devices=[0, 0], tile_docs=1024, api=api)
+    ix = ShardedIndex(words, off, lens, devices=list(range(n_devices(api, 2))), tile_docs=1024, api=api)
     try:
         bt = ix.batch(QUERIES, k=K)
         want = None
