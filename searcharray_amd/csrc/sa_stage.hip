@@ -479,10 +479,11 @@ int sa_stage_plan(sa_batch* bt, char* img, const u32* row_terms, const float* ro
     sa_impacts* im = bt->impacts.get();
     if (!im || im->h_maxf.size() != ix->n_terms || im->h_topf.size() != (size_t)ix->n_terms * SA_TOPF_NR) return SA_OK;
     if (B == 0 || T > 8 || !bt->d_st || ix->n_docs == 0 || ix->n_docs > (1ull << 28)) return SA_OK;
-    // Sets of more than 256 queries run slice by slice, one launch after the other.  Measured against the overlay route, whose items
-    // grow with the set (profiles/wide_set_routes_r06.jsonl, BASELINE-shaped sets, k = 10): 1024 queries at 10 M docs 1.095 vs 1.166 ms,
-    // 2048 queries 2.195 vs 2.171 -- unless forced, up to 1024 queries
-    if (B > 4u * (u32)SA_ST_BMAX && sa_opt(bt->opts.stage, -1) != 1) return SA_OK;
+    // Sets of more than 256 queries run slice by slice, one launch after the other, and every launch walks every tile of the shard.
+    // Measured against the overlay route, whose items grow with the set (profiles/wide_set_routes_r06*.jsonl, BASELINE-shaped sets,
+    // k = 10, staged / overlay): 10 M docs 512 .. 2048 queries 0.86 - 0.93; 5 M docs 0.94 / 1.05 / 1.13; 2.5 M 1.10 / 1.25 / 1.41;
+    // 1.25 M 1.31 / 1.48 / 1.80 -- unless forced, only on shards of 8 M docs and more, up to 2048 queries
+    if (B > (u32)SA_ST_BMAX && sa_opt(bt->opts.stage, -1) != 1 && (ix->n_docs < 8000000ull || B > 8u * (u32)SA_ST_BMAX)) return SA_OK;
     if (sa_opt(bt->opts.stage_probe, 1) != 0) sa_probe_rows_ensure(ix, im, bt->opts);
     const u32 S = sa_stage_slices(B);
     const size_t SB = sa_stage_slice_bytes(B, T);

@@ -122,7 +122,9 @@ def test_wide_query_sets_run_in_slices_of_256_rows(api, corpus):
     queries = band_queries(rng, 600, 4, heads=[0, 1, 2, 7, 350])
     check(api, corpus, queries, 10)
     check(api, corpus, queries[:257], 3, doc_base=1 << 20)
-    check(api, corpus, band_queries(rng, 513, 3, heads=[0, 5]), 10, force=False)      # (the library's own rule: few candidates, k <= 32)
+    check(api, corpus, band_queries(rng, 513, 3, heads=[0, 5]), 10)
+    unset_opt("stage")
+    check(api, corpus, queries, 10, expect="exhaustive", force=False)     # (the library's own rule takes slices only on shards of 8 M docs and more: measured)
 
 
 def test_candidate_list_overflow_is_redone(api, corpus):
