@@ -134,3 +134,22 @@ def test_candidate_list_overflow_is_redone(api, corpus):
     rng = np.random.default_rng(9)
     queries = band_queries(rng, 32, 4, heads=[0, 1])
     check(api, corpus, queries, 50)
+
+
+@pytest.mark.parametrize("cw", [1, 2, 4])
+def test_workgroups_co_walking_tile_ranges(api, corpus, cw):
+    """groups of `stage_cw` workgroups of an XCD share a tile range and take every cw-th tile of it (csrc/sa_stage.hip, StageParams::cw): a
+    term's first posting comes from the directory per tile instead of a running cursor.  stage_wgs = 8 gives the emulated 4-CU device 4
+    workgroups per XCD, 64-doc tiles give every workgroup several tiles; whatever the order the tiles are taken in, the top-k equals the
+    oracle's.  (A set with a term too rare for a directory row keeps private ranges: the walked cursor cannot skip tiles.)"""
+    set_opt("stage_wgs", 8)
+    set_opt("stage_cw", cw)
+    set_opt("stage_docs", 64)
+    rng = np.random.default_rng(40 + cw)
+    orc = corpus[3]
+    frequent = np.asarray([t for t in range(VOCAB) if orc.docfreq(t) >= 64])          # (every one of them has a directory row: df >= max(32, tiles / 8))
+    assert len(frequent) >= 40
+    queries = frequent[rng.integers(0, len(frequent), (40, 4))]
+    check(api, corpus, queries, 10)
+    check(api, corpus, queries[:24, :3], 3, doc_base=77)
+    check(api, corpus, band_queries(rng, 24, 3, heads=[0, 350]), 3)                  # (with rare terms: private ranges)
