@@ -74,10 +74,6 @@ def main():
     print(f"  seed / true k-th score: min {min(gaps):.3f} median {np.median(gaps):.3f} max {max(gaps):.3f}")
 
 
-if __name__ == "__main__":
-    main()
-
-
 def finalists(docs=1_000_000, k=10):
     """fraction of the candidates (postings of the essential terms) whose staged contributions + the probed terms' bounds reach the
     starting bound: what stage B hands to stage C"""
@@ -125,5 +121,9 @@ def finalists(docs=1_000_000, k=10):
     print(f"candidates {tot_c:,}  finalists (known + pend >= seed) {tot_f:,} ({100.0 * tot_f / tot_c:.1f} %)  at or above the seed {tot_surv:,}")
 
 
-if __name__ == "__main__" and "--finalists" in sys.argv:
-    finalists()
+if __name__ == "__main__":
+    if "--finalists" in sys.argv:
+        sys.argv.remove("--finalists")
+        finalists()
+    else:
+        main()

@@ -1222,6 +1222,7 @@ int sa_launch_stage(sa_batch* bt, const Bm25Params& p, hipStream_t st) {
         u32 cw = (u32)std::max<long long>(1, sa_opt(bt->opts.stage_cw, 32));
         while (cw > 1u && wpx % cw != 0u) cw >>= 1;              // (the largest power-of-two share of an XCD's workgroups at most the wish)
         sp.cw = (x.all_rowed && cw > 1u && sp.tpw >= 2u) ? cw : 1u;
+        if (sa_opt(bt->opts.trace, 0)) fprintf(stderr, "sa_launch_stage: rows %u..%u: %u workgroups, %u tiles of %u docs, %u per workgroup, co-walking groups of %u\n", x.q0, x.q0 + x.nq, grid, sp.n_st, sp.docs, sp.tpw, sp.cw);
         const bool one = x.NS <= (u32)SA_ST_NT;
         if (x.tmax == 4) {
             if (one) hipLaunchKernelGGL((sa_k_bm25_stage<4, 1>), dim3(grid), dim3(SA_ST_NT), 0, st, sp);
