@@ -1049,7 +1049,9 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_wave(const SpanMachinePa
 #define SA_SPAN_FD 512                   // documents of a block
 #define SA_SPAN_PC 8                     // positions of a document the gather keeps in LDS (= positions of a 64-lane chunk's lane)
 #define SA_SPAN_PMAXF 32                 // positions of a document a lane takes at all
+#ifndef SA_SPAN_FROWS
 #define SA_SPAN_FROWS 12                 // table rows of a lane of a 64-lane chunk, incl. the scratch row: 12 x 64 x 8 = 6 KiB per wave
+#endif
 
 struct SpanDocParams {
     SpanTerms st;                        // (dd[t] == null: a term without a directory row, its documents are found by search)
@@ -2352,9 +2354,11 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
         const u32 cnt = dfirst[c + 1] - dfirst[c];
         if (cnt == 0 || dblocks[c] == 0) continue;
         const SpanDocParams* jc = dd_dev + dfirst[c];
-        if (c == 0) hipLaunchKernelGGL(sa_k_span_doc_fused_multi<2>, dim3(dblocks[c]), dim3(SA_SPAN_FT), 0, st, jc, cnt);
-        else if (c == 1) hipLaunchKernelGGL(sa_k_span_doc_fused_multi<3>, dim3(dblocks[c]), dim3(SA_SPAN_FT), 0, st, jc, cnt);
-        else hipLaunchKernelGGL(sa_k_span_doc_fused_multi<4>, dim3(dblocks[c]), dim3(SA_SPAN_FT), 0, st, jc, cnt);
+        // (span_lds_pad: MEASUREMENT HOOK -- unused dynamic LDS per block lowers the resident blocks per CU: the occupancy experiment of DESIGN 3.4)
+        const u32 pad = (u32)std::min<long long>(120000, std::max<long long>(0, sa_opt(ix->opts.span_lds_pad, 0)));
+        if (c == 0) hipLaunchKernelGGL(sa_k_span_doc_fused_multi<2>, dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, cnt);
+        else if (c == 1) hipLaunchKernelGGL(sa_k_span_doc_fused_multi<3>, dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, cnt);
+        else hipLaunchKernelGGL(sa_k_span_doc_fused_multi<4>, dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, cnt);
     }
     SA_HIP(hipGetLastError());
     return SA_OK;
