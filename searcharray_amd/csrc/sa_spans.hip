@@ -1141,6 +1141,23 @@ __device__ __forceinline__ u32 sa_span_doc_npos_slow(const SpanTerms& st, const 
 
 // The document's words of every term (at most SA_SPAN_DW each within 30 blocks, else *many) and which of them are
 // candidates (bit q of keep[t]), from the document's own words in registers.
+// the first SA_SPAN_DW words of every term's words of the document (j0: where each term's begin) and the one behind them
+template <int TT>
+__device__ __forceinline__ void sa_span_doc_words_load(const SpanTerms& st, const u32 (&j0)[TT], u64 (&W)[TT][SA_SPAN_DW], u64 (&X)[TT]) {
+#pragma unroll
+    for (int t = 0; t < TT; t++) {
+#pragma unroll
+        for (int q = 0; q < SA_SPAN_DW; q++) {
+            const u32 idx = j0[t] + (u32)q;
+            W[t][q] = idx < st.len[t] ? st.words[t][idx] : ~0ull;
+        }
+        const u32 idx = j0[t] + (u32)SA_SPAN_DW;
+        X[t] = idx < st.len[t] ? st.words[t][idx] : ~0ull;
+    }
+}
+template <int TT>
+__device__ __forceinline__ bool sa_span_doc_words_eval(const u64 doc, u64 (&W)[TT][SA_SPAN_DW], const u64 (&X)[TT], u32 (&c)[TT], u32 (&keep)[TT],
+                                                       bool* many, u32* first_blk);
 template <int TT>
 __device__ __forceinline__ bool sa_span_doc_words(const SpanTerms& st, const u64 doc, u64 (&W)[TT][SA_SPAN_DW], u32 (&c)[TT],
                                                   u32 (&keep)[TT], bool* many, u32* first_blk = nullptr) {
@@ -1153,16 +1170,13 @@ __device__ __forceinline__ bool sa_span_doc_words(const SpanTerms& st, const u64
     *many = false;
     if (!all) return false;
     u64 X[TT];                                                   // the word behind the ones held
-#pragma unroll
-    for (int t = 0; t < TT; t++) {
-#pragma unroll
-        for (int q = 0; q < SA_SPAN_DW; q++) {
-            const u32 idx = j0[t] + (u32)q;
-            W[t][q] = idx < st.len[t] ? st.words[t][idx] : ~0ull;
-        }
-        const u32 idx = j0[t] + (u32)SA_SPAN_DW;
-        X[t] = idx < st.len[t] ? st.words[t][idx] : ~0ull;
-    }
+    sa_span_doc_words_load<TT>(st, j0, W, X);
+    return sa_span_doc_words_eval<TT>(doc, W, X, c, keep, many, first_blk);
+}
+// (c, keep zero and *many false on entry)
+template <int TT>
+__device__ __forceinline__ bool sa_span_doc_words_eval(const u64 doc, u64 (&W)[TT][SA_SPAN_DW], const u64 (&X)[TT], u32 (&c)[TT], u32 (&keep)[TT],
+                                                       bool* many, u32* first_blk) {
 #pragma unroll
     for (int t = 0; t < TT; t++) {
         bool run = true;
@@ -1572,8 +1586,26 @@ __device__ __forceinline__ void sa_span_doc_chunk(const SpanDocParams& p, u64* t
     }
 }
 
+// -DSA_PROBE (scripts/build_probe.sh; never in the product build): shader cycles a block's wave 0 spends per phase of the doc-parallel
+// body, summed over the launch (s_memtime at the phase boundaries), read by sa_debug_span_probe_read
+#ifdef SA_PROBE
+__device__ unsigned long long g_sa_span_probe[8];
+#define SA_SPP(i) do { if (threadIdx.x == 0) { const u64 t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_sa_span_probe[i], (unsigned long long)(t_ - sp_last)); sp_last = t_; } } while (0)
+extern "C" int sa_debug_span_probe_read(unsigned long long* out8, int clear) {
+    if (hipDeviceSynchronize() != hipSuccess) return SA_ERR_HIP;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_sa_span_probe), 8 * 8) != hipSuccess) return SA_ERR_HIP;
+    if (clear) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sa_span_probe), z, 8 * 8) != hipSuccess) return SA_ERR_HIP; }
+    return SA_OK;
+}
+#else
+#define SA_SPP(i) do { } while (0)
+#endif
+
 template <int TT>
 __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, const u32 block) {
+#ifdef SA_PROBE
+    u64 sp_last = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int NW = SA_SPAN_FT / 64, ROUNDS = SA_SPAN_FD / SA_SPAN_FT;
     constexpr int TABW = SA_SPAN_FROWS * 64;                     // a wave's tables, in 8-byte words
     __shared__ unsigned short s_plist[SA_SPAN_PC * SA_SPAN_FD];  // position-major: position q of local document d at [q * FD + d]
@@ -1599,56 +1631,125 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
     const bool ranked = p.rank.cand != nullptr;
     const bool staged = ranked || (p.touched != nullptr && p.anchor < 0);
     // ---- gather: bins and short position lists
-    {
+    // (the slot's document: the (lo + local)-th document, or the one the (lo + local)-th word of the rarest term's list opens -- a word
+    //  whose predecessor belongs to the same document opens none)
+    auto slot_doc = [&](const u32 local, bool* valid_out) -> u64 {
+        u64 doc = lo + local;
+        bool valid = doc < p.st.n_docs;
+        if (p.anchor >= 0) {
+            const u64* const aw = p.st.words[p.anchor];
+            valid = doc < p.st.len[p.anchor];
+            if (valid) {
+                const u64 i = doc;
+                doc = aw[i] >> SA_KEY_SHIFT;
+                valid = (i == 0 || (aw[i - 1] >> SA_KEY_SHIFT) != doc) && doc < p.st.n_docs;
+            }
+        } else if (valid && !p.touched && !ranked) {
+            p.counts[doc] = 0.f;
+        }
+        *valid_out = valid;
+        return doc;
+    };
+    // (what the gather keeps of a document whose words are held: its bin, and the short position list of a light one)
+    auto slot_bin = [&](const u32 local, const u64 doc, const bool have_words, u64 (&W)[TT][SA_SPAN_DW], const u32 (&keep)[TT], const bool many, const u32 first_blk) -> u32 {
+        u32 bin = 0;
+        if (have_words) {
+            u32 npos = 0;
+            if (many) {
+                npos = sa_span_doc_npos_slow<TT>(p.st, doc);
+            } else {
+#pragma unroll
+                for (int t = 0; t < TT; t++)
+#pragma unroll
+                    for (int q = 0; q < SA_SPAN_DW; q++)
+                        if ((keep[t] >> q) & 1u) npos += (u32)__popc((u32)(W[t][q] & SA_LSB_MASK));
+                if (npos != 0 && npos <= (u32)SA_SPAN_PC) {
+                    sa_span_doc_positions16<TT>(W, keep, first_blk, s_plist + local, SA_SPAN_FD, npos);
+                    s_pbase[local] = first_blk * (u32)SA_LSB_BITS;
+                }
+            }
+            bin = npos == 0 ? 0u : ((many || npos > PMAX) ? HEAVY : npos);
+        }
+        return bin;
+    };
+    if (TT == 2 && ROUNDS == 2 && p.st.dd[0] && p.st.dd[1] && p.st.len[0] && p.st.len[1]) {       // (uniform)
+        // Two terms with doc-directory rows (round 6): BOTH documents of a thread are in flight together and no load sits inside a
+        // branch (the compiler waits for every load in flight where a branch that contains one joins): the directory cells of both
+        // terms for both documents, then all their words -- two dependent round trips per block where the loop below takes six.
+        // A slot without a document reads cell 0 / a clamped word and discards it.  (The probe build's phase cycles put half of a
+        // block's time into this phase; registers are not what limits the four blocks per CU -- LDS is.)
+        u64 docs_[2]; bool valid_[2]; u32 j0_[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const u32 local = (u32)r * SA_SPAN_FT + threadIdx.x;
+            docs_[r] = slot_doc(local, &valid_[r]);
+            s_doc[local] = (u32)docs_[r];
+        }
+        u32 dcell[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int t = 0; t < 2; t++) dcell[r][t] = p.st.dd[t][valid_[r] ? docs_[r] : 0ull];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            j0_[r][0] = valid_[r] ? dcell[r][0] : SA_DD_ABSENT;
+            j0_[r][1] = j0_[r][0] != SA_DD_ABSENT ? dcell[r][1] : SA_DD_ABSENT;
+        }
+        u64 WW[2][2][SA_SPAN_DW], XX[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const u32 last = p.st.len[t] - 1u;
+#pragma unroll
+                for (int q = 0; q <= SA_SPAN_DW; q++) {
+                    const u32 idx = j0_[r][t] + (u32)q;                      // (ABSENT + q wraps or stays huge: clamped, discarded below)
+                    const bool in = j0_[r][t] != SA_DD_ABSENT && idx <= last;
+                    const u64 w = p.st.words[t][in ? idx : last];
+                    if (q < SA_SPAN_DW) WW[r][t][q < SA_SPAN_DW ? q : 0] = in ? w : ~0ull; else XX[r][t] = in ? w : ~0ull;
+                }
+            }
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const u32 local = (u32)r * SA_SPAN_FT + threadIdx.x;
+            u32 c[2] = {0, 0}, keep[2] = {0, 0};
+            bool many = false;
+            u32 first_blk = 0;
+            const bool all = j0_[r][1] != SA_DD_ABSENT;
+            u64 (&Wr)[TT][SA_SPAN_DW] = reinterpret_cast<u64 (&)[TT][SA_SPAN_DW]>(WW[r]);
+            const u64 (&Xr)[TT] = reinterpret_cast<const u64 (&)[TT]>(XX[r]);
+            u32 (&cr)[TT] = reinterpret_cast<u32 (&)[TT]>(c);
+            u32 (&kr)[TT] = reinterpret_cast<u32 (&)[TT]>(keep);
+            const bool have_words = all && sa_span_doc_words_eval<TT>(docs_[r], Wr, Xr, cr, kr, &many, &first_blk);
+            const u32 bin = slot_bin(local, docs_[r], have_words, Wr, kr, many, first_blk);
+            if (bin) atomicAdd(&s_h[bin], 1u);
+            if (staged && (bin == 0u || bin == HEAVY)) s_pbase[local] = 0u;      // (no machine in the chunks: nothing counted so far; a slot without a document never counts)
+            s_bin[local] = (unsigned char)bin;
+        }
+    } else {
         u64 W[TT][SA_SPAN_DW];
         u32 c[TT], keep[TT];
 #pragma unroll 1
         for (int r = 0; r < ROUNDS; r++) {
             const u32 local = (u32)r * SA_SPAN_FT + threadIdx.x;
-            // the slot's document: the (lo + local)-th document, or the one the (lo + local)-th word of the rarest
-            // term's list opens (a word whose predecessor belongs to the same document opens none)
-            u64 doc = lo + local;
-            bool valid = doc < p.st.n_docs;
-            if (p.anchor >= 0) {
-                const u64* const aw = p.st.words[p.anchor];
-                valid = doc < p.st.len[p.anchor];
-                if (valid) {
-                    const u64 i = doc;
-                    doc = aw[i] >> SA_KEY_SHIFT;
-                    valid = (i == 0 || (aw[i - 1] >> SA_KEY_SHIFT) != doc) && doc < p.st.n_docs;
-                }
-            } else if (valid && !p.touched && !ranked) {
-                p.counts[doc] = 0.f;
-            }
+            bool valid = false;
+            const u64 doc = slot_doc(local, &valid);
             s_doc[local] = (u32)doc;
             u32 bin = 0;
             if (valid) {
                 bool many = false;
                 u32 first_blk = 0;
-                if (sa_span_doc_words<TT>(p.st, doc, W, c, keep, &many, &first_blk)) {
-                    u32 npos = 0;
-                    if (many) {
-                        npos = sa_span_doc_npos_slow<TT>(p.st, doc);
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < TT; t++)
-#pragma unroll
-                            for (int q = 0; q < SA_SPAN_DW; q++)
-                                if ((keep[t] >> q) & 1u) npos += (u32)__popc((u32)(W[t][q] & SA_LSB_MASK));
-                        if (npos != 0 && npos <= (u32)SA_SPAN_PC) {
-                            sa_span_doc_positions16<TT>(W, keep, first_blk, s_plist + local, SA_SPAN_FD, npos);
-                            s_pbase[local] = first_blk * (u32)SA_LSB_BITS;
-                        }
-                    }
-                    bin = npos == 0 ? 0u : ((many || npos > PMAX) ? HEAVY : npos);
-                }
+                const bool have_words = sa_span_doc_words<TT>(p.st, doc, W, c, keep, &many, &first_blk);
+                bin = slot_bin(local, doc, have_words, W, keep, many, first_blk);
                 if (bin) atomicAdd(&s_h[bin], 1u);
             }
             if (staged && (bin == 0u || bin == HEAVY)) s_pbase[local] = 0u;      // (no machine in the chunks: nothing counted so far; a slot without a document never counts)
             s_bin[local] = (unsigned char)bin;
         }
     }
+    SA_SPP(0);                                                  // gather (this wave's share)
     __syncthreads();
+    SA_SPP(1);                                                  // ... and the wait for the block's other waves
     // ---- order: s_first[b] = documents with more than b positions (lane x of wave 0: bin PMAX - x)
     if (wave == 0) {
         const u32 b = lane <= PMAX ? PMAX - lane : 0u;
@@ -1670,6 +1771,7 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
         else if (bin) s_order[s_first[bin] + atomicAdd(&s_cur[bin], 1u)] = (unsigned short)local;
     }
     __syncthreads();
+    SA_SPP(2);                                                  // order
     // ---- machine: chunks of 8 documents while they have more than 16 positions, of 16 above 8, else 64; a wave takes the
     //      next chunk when it is done with its last (the first chunks are the long ones)
     {
@@ -1697,12 +1799,15 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
             __builtin_amdgcn_wave_barrier();
         }
     }
+    SA_SPP(3);                                                  // machines (this wave's chunks)
     __syncthreads();
+    SA_SPP(4);                                                  // ... and the wait for the block's other waves
     // ---- heavy documents and outgrown tables: a wave each, the block's tables now being free (HW full tables fit)
     const u32 nh = s_nheavy;
     if (wave < (u32)HW)
         for (u32 i = wave; i < nh; i += (u32)HW)
             sa_span_wave_doc<TT>(p, s_doc[s_heavy[i]], (SpanEnt*)s_tab + (size_t)wave * SA_NSPANS, lane, staged ? &s_pbase[s_heavy[i]] : nullptr);
+    SA_SPP(5);                                                  // heavy documents
     if (ranked) {
         // counts -> BM25 (the reference's operation order, similarity.py:24-38 / bm25.pyx:19-23, as sa_k_dense_topk_tiles forms it)
         // in place, then the pruned selection of the phrase batches over the block's documents (s_doc: their ids)
@@ -1741,6 +1846,10 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
             p.touched[(lo + SA_SPAN_FD - 1 < p.st.n_docs ? lo + SA_SPAN_FD - 1 : p.st.n_docs - 1) >> p.touch_shift] = 1;
         }
     }
+    SA_SPP(6);                                                  // scoring + ranking (or the staged counts' store)
+#ifdef SA_PROBE
+    if (threadIdx.x == 0) atomicAdd(&g_sa_span_probe[7], 1ull);    // blocks
+#endif
 }
 
 template <int TT>
