@@ -324,9 +324,12 @@ static int sa_stage_plan_slice(sa_batch* bt, char* base, u32* h_seed, const u32*
     unsigned char* const probed = W.probed.data();
     const unsigned short* const di = W.di.data();
     double cand_df = 0.0;
+    u32 dense_further = 0;                                      // queries with a dense term (df >= n_docs / 4) that is not their first
     for (u32 q = 0; q < B; q++) {
         const size_t qb = (size_t)q * T;
         float seed = 0.f;
+        for (u32 s = 1; s < T; s++)
+            if (di[qb + s] != SA_ST_NONE && W.dist_df[di[qb + s]] * 4ull >= ix->n_docs) { dense_further++; break; }
         for (u32 s = 0; s < T; s++) {
             probed[qb + s] = 0; ubs[qb + s] = 0.f;
             if (di[qb + s] == SA_ST_NONE) continue;
@@ -456,7 +459,12 @@ static int sa_stage_plan_slice(sa_batch* bt, char* base, u32* h_seed, const u32*
         const bool few_cands = bt->k <= 32u && cpd <= 2.5f && NS <= (u32)SA_ST_NT && Bset >= 8u;
         const bool small_set = bt->k > 32u && bt->k <= 100u && cpd <= 0.6f && NS <= (u32)SA_ST_NT && Bset >= 4u;
         const bool few_terms = bt->k <= 100u && NS <= 32u && Bset >= (bt->k <= 32u ? 8u : 4u);
-        if (!few_cands && !small_set && !few_terms) {
+        //  * queries with a SECOND dense term: the overlay route shares a query's first term only, a further dense term sends the
+        //    (tile, query) pair to the per-query kernel -- 256 queries of 6 / 8 terms with two terms of ranks 1-10 each: 4.7 / 5.0 ms there,
+        //    2.5 / 3.2 ms here (k = 10; 3.3 / 4.1 against 4.8 / 5.1 at k = 100) although 15 candidates per document are expected
+        //    (profiles/query_length_routes_r06.jsonl)
+        const bool dense_pairs = bt->k <= 100u && dense_further * 2u >= B && Bset >= 8u;
+        if (!few_cands && !small_set && !few_terms && !dense_pairs) {
             if (sa_opt(bt->opts.trace, 0)) fprintf(stderr, "sa_stage_plan: not taken (%u queries, k = %u, %u staged terms, %.3f candidates per doc expected)\n", Bset, bt->k, NS, cpd);
             return SA_OK;
         }
