@@ -71,6 +71,7 @@ typedef struct sa_options {
     int64_t loose_postings;  /* loose groups: expected postings of a query per tile at most (default 400) */
     int64_t xcd_range;       /* 0: tiles dealt round-robin to the XCDs instead of ranges */
     int64_t term_seed;       /* 0: no starting bounds from the terms' rank tables */
+    int64_t topf_slice;      /* TEST HOOK: postings per workgroup of a long list's rank-table histogram (default 65536; lists of 4 slices and more) */
     int64_t seed_scale_pct;  /* TEST HOOK: starting bounds scaled by this percentage (> 100 makes them too high: the redo path) */
     int64_t merge_small;     /* 0: the 1024-thread merge also for k <= 64 */
     int64_t impact;          /* 0: score the TF postings, no impact stream */
@@ -401,6 +402,9 @@ int sa_batch_group_info(sa_batch_t* batch, uint32_t out[4]);
  * (the options `stage` / `sparse`, or -- unset -- the library's rule: csrc/sa_stage.hip sa_stage_plan, csrc/sa_bm25.hip sa_batch_run_shard;
  * measured: profiles/route_rule_r06*.jsonl).  All three are exact.  Diagnostics; no reference counterpart. */
 int sa_batch_last_route(sa_batch_t* batch, int* pruned_out);
+/* Diagnostics: the rank table (22 lower bounds of a term's r-th largest BM25 factor, r = 1, 2, ... 1024) and the exact largest factor of
+ * `term` in this batch's impact stream -- what starting bounds are formed from.  No reference counterpart. */
+int sa_batch_debug_rank_table(sa_batch_t* batch, uint32_t term, float* ranks22_out, float* maxf_out);
 /* Host time this batch's steps have cost, cumulative nanoseconds by part: out[0] = sa_batch_reset / _step up to the upload
  * (grouping + pruning tables: CPU work only), out[1] = its enqueues (the upload copy, the slice-table launch), out[2] =
  * sa_batch_run's enqueues, out[3] = number of query sets filled.  Diagnostics (scripts/host_cost.py); no reference counterpart. */

@@ -118,6 +118,7 @@ PROTOTYPES = {
     "sa_batch_group_info": (c_int, [c_void_p, POINTER(c_uint32)]),
     "sa_batch_last_route": (c_int, [c_void_p, POINTER(c_int)]),
     "sa_batch_host_times": (c_int, [c_void_p, POINTER(c_uint64)]),
+    "sa_batch_debug_rank_table": (c_int, [c_void_p, ctypes.c_uint32, POINTER(ctypes.c_float), POINTER(ctypes.c_float)]),
     "sa_batch_seeds": (c_int, [c_void_p, POINTER(c_float)]),
     "sa_batch_stats": (c_int, [c_void_p, c_int, u64p, u64p]),
     "sa_batch_destroy": (c_int, [c_void_p]),

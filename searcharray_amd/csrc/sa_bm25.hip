@@ -61,10 +61,37 @@ sa_k_make_dense_row(const u64* __restrict__ imp, u64 first, u64 df, float* __res
 // that holds the r-th largest factor for each tabulated rank r; the bin's LOWER edge is what is stored.
 #define SA_TOPF_BINS 2048
 #define SA_TOPF_LO (123u << 9)
+#define SA_TOPF_SLICE 65536ull          // postings per workgroup of a LONG list's histogram (lists of 4 slices and more; option topf_slice: test hook)
 struct TopfRanks { u32 r[SA_TOPF_NR]; };
 __global__ void __launch_bounds__(256)
+sa_k_topf_hist_long(const u64* __restrict__ imp, const u64* __restrict__ tf_off, const u32* __restrict__ slice_term,
+                    const u32* __restrict__ slice_first, const u32* __restrict__ long_slot, u32* __restrict__ ghist, u32* __restrict__ gmax, const u64 slice) {
+    // one workgroup per SLICE (SA_TOPF_SLICE postings) of a LONG list: its histogram in LDS, added to the term's row of `ghist`
+    __shared__ u32 s_h[SA_TOPF_BINS];
+    const u32 tid = threadIdx.x, t = slice_term[blockIdx.x];
+    const u64 base = tf_off[t], df = tf_off[t + 1] - base;
+    const u64 i0 = (u64)slice_first[blockIdx.x] * slice, i1 = i0 + slice < df ? i0 + slice : df;
+    for (u32 i = tid; i < (u32)SA_TOPF_BINS; i += 256) s_h[i] = 0;
+    __syncthreads();
+    const u64* const cells = imp + sa_imp_base(base, t);
+    u32 mx = 0u;
+    for (u64 i = i0 + tid; i < i1; i += 256) {
+        const u32 fb = (u32)cells[i];
+        mx = fb > mx ? fb : mx;
+        const u32 e = fb >> 14;
+        const u32 b = e <= SA_TOPF_LO ? 0u : (e - SA_TOPF_LO > (u32)(SA_TOPF_BINS - 1) ? (u32)(SA_TOPF_BINS - 1) : e - SA_TOPF_LO);
+        atomicAdd(&s_h[b], 1u);
+    }
+    __syncthreads();
+    u32* const row = ghist + (u64)long_slot[t] * SA_TOPF_BINS;
+    for (u32 i = tid; i < (u32)SA_TOPF_BINS; i += 256) if (s_h[i]) atomicAdd(&row[i], s_h[i]);
+    if (mx) atomicMax(&gmax[long_slot[t]], mx);
+}
+
+// (long_slot: [n_terms] row of a LONG term in ghist / gmax -- its histogram is there already, sa_k_topf_hist_long -- else all ones; or null)
+__global__ void __launch_bounds__(256)
 sa_k_make_topf(const u64* __restrict__ imp, const u64* __restrict__ tf_off, u32 n_terms, const TopfRanks ranks, float* __restrict__ topf,
-               float* __restrict__ maxf) {
+               float* __restrict__ maxf, const u32* __restrict__ long_slot, const u32* __restrict__ ghist, const u32* __restrict__ gmax) {
     __shared__ u32 s_h[SA_TOPF_BINS];
     __shared__ u32 s_part[256];
     __shared__ u32 s_max;
@@ -77,12 +104,13 @@ sa_k_make_topf(const u64* __restrict__ imp, const u64* __restrict__ tf_off, u32 
             if (tid == 0 && maxf) maxf[t] = 0.f;
             continue;
         }
-        for (u32 i = tid; i < (u32)SA_TOPF_BINS; i += 256) s_h[i] = 0;
-        if (tid == 0) s_max = 0u;
+        const u32 ls = long_slot ? long_slot[t] : 0xFFFFFFFFu;     // (uniform)
+        for (u32 i = tid; i < (u32)SA_TOPF_BINS; i += 256) s_h[i] = ls != 0xFFFFFFFFu ? ghist[(u64)ls * SA_TOPF_BINS + i] : 0u;
+        if (tid == 0) s_max = ls != 0xFFFFFFFFu ? gmax[ls] : 0u;
         __syncthreads();
         const u64* const cells = imp + sa_imp_base(base, t);
         u32 mx = 0u;                                             // (factors are non-negative: their bit patterns order like the values)
-        for (u64 i = tid; i < df; i += 256) {
+        for (u64 i = tid; i < (ls != 0xFFFFFFFFu ? 0ull : df); i += 256) {
             const u32 fb = (u32)cells[i];
             mx = fb > mx ? fb : mx;
             const u32 e = fb >> 14;
@@ -234,10 +262,47 @@ static void sa_impacts_ensure_topf(sa_index* ix, sa_impacts* im) {
     TopfRanks rk;
     for (int i = 0; i < SA_TOPF_NR; i++) rk.r[i] = sa_topf_ranks[i];
     if (hipMalloc(&im->d_maxf, (size_t)ix->n_terms * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); im->d_maxf = nullptr; }
+    // Long lists (4 slices of 64 K postings and more) are histogrammed slice by slice first: with one workgroup per TERM the ten longest
+    // lists of a 10 M-doc shard were 16 ms of the table's build (round 5 review, item 8)
+    u32* d_long = nullptr;                                      // [n_terms] slot | [slices] term | [slices] slice | [n_long][BINS] hist | [n_long] max
+    const u32 *d_slot = nullptr, *d_ghist = nullptr, *d_gmax = nullptr;
+    {
+        std::vector<u32> slot(ix->n_terms, 0xFFFFFFFFu), sl_term, sl_first;
+        u32 n_long = 0;
+        const u64 slice = (u64)std::max<long long>(64, sa_opt(ix->opts.topf_slice, (long long)SA_TOPF_SLICE));
+        for (u32 t = 0; t < ix->n_terms; t++) {
+            const u64 df = ix->h_tf_off[t + 1] - ix->h_tf_off[t];
+            if (df < 4ull * slice) continue;
+            slot[t] = n_long++;
+            for (u64 sl = 0; sl * slice < df; sl++) { sl_term.push_back(t); sl_first.push_back((u32)sl); }
+        }
+        if (n_long) {
+            const size_t words = (size_t)ix->n_terms + 2 * sl_term.size() + (size_t)n_long * SA_TOPF_BINS + n_long;
+            if (hipMalloc(&d_long, words * sizeof(u32)) == hipSuccess) {
+                u32* const d_st = d_long + ix->n_terms;
+                u32* const d_sf = d_st + sl_term.size();
+                u32* const d_h = d_sf + sl_term.size();
+                bool ok = hipMemcpyAsync(d_long, slot.data(), slot.size() * sizeof(u32), hipMemcpyHostToDevice, ix->stream) == hipSuccess &&
+                          hipMemcpyAsync(d_st, sl_term.data(), sl_term.size() * sizeof(u32), hipMemcpyHostToDevice, ix->stream) == hipSuccess &&
+                          hipMemcpyAsync(d_sf, sl_first.data(), sl_first.size() * sizeof(u32), hipMemcpyHostToDevice, ix->stream) == hipSuccess &&
+                          hipMemsetAsync(d_h, 0, ((size_t)n_long * SA_TOPF_BINS + n_long) * sizeof(u32), ix->stream) == hipSuccess;
+                if (ok) {
+                    hipLaunchKernelGGL(sa_k_topf_hist_long, dim3((u32)sl_term.size()), dim3(256), 0, ix->stream, (const u64*)im->d_imp, (const u64*)ix->d_tf_off,
+                                       (const u32*)d_st, (const u32*)d_sf, (const u32*)d_long, d_h, d_h + (size_t)n_long * SA_TOPF_BINS, slice);
+                    // (the copies above read pageable host vectors that die with this scope)
+                    ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(ix->stream) == hipSuccess;
+                }
+                if (ok) { d_slot = d_long; d_ghist = d_h; d_gmax = d_h + (size_t)n_long * SA_TOPF_BINS; }
+                else { (void)hipGetLastError(); hipFree(d_long); d_long = nullptr; }
+            } else (void)hipGetLastError();
+        }
+    }
     const u32 grid = ix->n_terms < 16384u ? ix->n_terms : 16384u;
     hipLaunchKernelGGL(sa_k_make_topf, dim3(grid), dim3(256), 0, ix->stream, (const u64*)im->d_imp, (const u64*)ix->d_tf_off, ix->n_terms, rk,
-                       im->d_topf, im->d_maxf);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ix->stream) != hipSuccess) {
+                       im->d_topf, im->d_maxf, d_slot, d_ghist, d_gmax);
+    const bool topf_ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(ix->stream) == hipSuccess;
+    if (d_long) hipFree(d_long);
+    if (!topf_ok) {
         (void)hipGetLastError();
         hipFree(im->d_topf); im->d_topf = nullptr;
         if (im->d_maxf) { hipFree(im->d_maxf); im->d_maxf = nullptr; }
@@ -3072,6 +3137,21 @@ extern "C" int sa_batch_get_options(sa_batch_t* bt, sa_options_t* out) {
     SA_ARG(bt && bt->ix && out, "null argument");
     std::lock_guard<std::mutex> g(bt->ix->mu);
     *out = bt->opts;
+    return SA_OK;
+}
+
+// Diagnostics: the rank table of a term in this batch's impact stream (22 lower bounds of its r-th largest factor, sa_topf_ranks) and its
+// exact largest factor -- what the starting bounds are formed from.  Tests compare the tables of differently built streams.
+extern "C" int sa_batch_debug_rank_table(sa_batch_t* bt, uint32_t term, float* ranks22_out, float* maxf_out) {
+    SA_ARG(bt && bt->ix && ranks22_out && maxf_out, "null argument");
+    std::lock_guard<std::mutex> g(bt->ix->mu);
+    sa_impacts* im = bt->impacts.get();
+    if (!im || term >= bt->ix->n_terms || im->h_topf.size() != (size_t)bt->ix->n_terms * SA_TOPF_NR || im->h_maxf.size() != bt->ix->n_terms) {
+        sa_set_error("sa_batch_debug_rank_table: the batch has no rank tables (no impact stream, term_seed = 0, or an unknown term)");
+        return SA_ERR_STATE;
+    }
+    memcpy(ranks22_out, &im->h_topf[(size_t)term * SA_TOPF_NR], SA_TOPF_NR * sizeof(float));
+    *maxf_out = im->h_maxf[term];
     return SA_OK;
 }
 

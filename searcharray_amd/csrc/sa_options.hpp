@@ -26,6 +26,7 @@
     X(loose_postings)  /* loose groups: expected postings of a query per tile at most (default 400) */                             \
     X(xcd_range)       /* 0: tiles dealt round-robin to the XCDs instead of ranges */                                              \
     X(term_seed)       /* 0: no starting bounds from the terms' rank tables */                                                     \
+    X(topf_slice)      /* TEST HOOK: postings per workgroup of a long list's rank-table histogram (default 65536; lists of 4 slices and more) */ \
     X(seed_scale_pct)  /* TEST HOOK: starting bounds scaled by this percentage (> 100 makes them too high: the redo path) */       \
     X(merge_small)     /* 0: the 1024-thread merge also for k <= 64 */                                                             \
     X(impact)          /* 0: score the TF postings, no impact stream */                                                            \

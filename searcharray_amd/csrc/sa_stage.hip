@@ -171,13 +171,20 @@ static std::shared_ptr<sa_stagedir> sa_stagedir_get(sa_index* ix, sa_impacts* im
 // the rows of one stretch of documents sit together (a workgroup that probes ~100 rows for the documents of its tiles touches a
 // few pages, not one per row: with row-major rows of 40 MB each the probes were page-table walks)
 __device__ __host__ __forceinline__ u64 sa_probe_cell(u32 row, u64 doc, u64 rows64) { return (doc >> 6) * rows64 + ((u64)row << 6) + (doc & 63ull); }
+// all rows in ONE launch: blockIdx.y = the row, its list's first cell and length in `jobs` (round 6's first version launched a kernel per
+// row: 336 launches, 6.4 ms of the first batch at 10 M docs)
+struct ProbeRowJob { u64 first, df; };
 __global__ void __launch_bounds__(256)
-sa_k_make_probe_row(const u64* __restrict__ imp, u64 first, u64 df, u32 row, u64 rows64, float* __restrict__ probe, u32* __restrict__ bits) {
+sa_k_make_probe_rows(const u64* __restrict__ imp, const ProbeRowJob* __restrict__ jobs, u64 rows64, float* __restrict__ probe,
+                     u32* __restrict__ bits, u64 bits_words) {
+    const u32 row = blockIdx.y;
+    const u64 first = jobs[row].first, df = jobs[row].df;
+    u32* const rb = bits + (u64)row * bits_words;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < df; i += (u64)gridDim.x * blockDim.x) {
         const u64 c = imp[first + i];
         const u32 doc = (u32)(c >> 32) >> 2;
         probe[sa_probe_cell(row, (u64)doc, rows64)] = __uint_as_float((u32)c);
-        atomicOr(&bits[doc >> 5], 1u << (doc & 31u));
+        atomicOr(&rb[doc >> 5], 1u << (doc & 31u));
     }
 }
 
@@ -212,15 +219,24 @@ static void sa_probe_rows_ensure(sa_index* ix, sa_impacts* im, const sa_options_
         if (im->d_pbits) { (void)hipFree(im->d_pbits); im->d_pbits = nullptr; }
         return;
     }
+    std::vector<ProbeRowJob> jobs(cand.size());
     for (size_t r = 0; r < cand.size(); r++) {
         const u32 t = cand[r].second;
-        const u64 df = cand[r].first;
-        const u32 grid = df / 256 + 1 < 8192 ? (u32)(df / 256 + 1) : 8192u;
-        hipLaunchKernelGGL(sa_k_make_probe_row, dim3(grid), dim3(256), 0, st, (const u64*)im->d_imp, sa_imp_base(ix->h_tf_off[t], t), df,
-                           (u32)r, (u64)cand.size() * 64ull, im->d_probe, im->d_pbits + r * im->pbits_words);
+        jobs[r].first = sa_imp_base(ix->h_tf_off[t], t); jobs[r].df = cand[r].first;
         im->probe_slot[t] = (u32)r;
     }
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+    ProbeRowJob* d_jobs = nullptr;
+    bool jobs_ok = hipMalloc(&d_jobs, jobs.size() * sizeof(ProbeRowJob)) == hipSuccess &&
+                   hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(ProbeRowJob), hipMemcpyHostToDevice, st) == hipSuccess;
+    if (jobs_ok) {
+        const u64 longest = cand[0].first;                      // (most frequent first)
+        const u32 gx = (u32)std::min<u64>(512, longest / 4096 + 1);     // (a row's blocks stride over its list: 16 postings per thread and more)
+        hipLaunchKernelGGL(sa_k_make_probe_rows, dim3(gx, (u32)cand.size()), dim3(256), 0, st, (const u64*)im->d_imp, (const ProbeRowJob*)d_jobs,
+                           (u64)cand.size() * 64ull, im->d_probe, im->d_pbits, (u64)im->pbits_words);
+    }
+    const bool rows_ok = jobs_ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    if (d_jobs) (void)hipFree(d_jobs);
+    if (!rows_ok) {
         (void)hipGetLastError();
         (void)hipFree(im->d_probe); im->d_probe = nullptr;
         (void)hipFree(im->d_pbits); im->d_pbits = nullptr;

@@ -272,3 +272,41 @@ def test_starting_bounds_from_the_terms_rank_tables(api, corpus, monkeypatch, k,
     bt.close()
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     dev.close()
+
+
+def test_rank_tables_of_long_lists_built_by_slices(api):
+    """sa_k_topf_hist_long (round 6): the factor histogram of a LONG posting list is built slice by slice (one workgroup per 64 K postings)
+    and merged, instead of by one workgroup per term.  With slices of 64 / 100 postings (test hook topf_slice) every frequent term of a
+    small corpus takes that route: rank tables and exact maxima equal the one-workgroup-per-term build entry for entry, and the maxima
+    equal the oracle's largest factor of the term."""
+    import ctypes
+    n_docs, vocab = 6000, 300
+    t, d, p, lens = synth.corpus_triples(n_docs, vocab, 12, seed=21)
+    words, wt = rz.encode_sorted(t, d, p)
+    off = rz.term_offsets(wt, vocab)
+    orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
+    queries = np.asarray([[0, 1, 2, 3]] * 8)
+
+    def tables(opts):
+        dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api, opts=opts)
+        bt = dev.batch(queries, k=10)
+        out = []
+        for term in range(vocab):
+            r = (ctypes.c_float * 22)()
+            m = ctypes.c_float(0)
+            api.call("sa_batch_debug_rank_table", bt._h, ctypes.c_uint32(term), r, ctypes.byref(m))
+            out.append((np.asarray(list(r), dtype=np.float32), np.float32(m.value)))
+        bt.close()
+        dev.close()
+        return out
+    whole = tables({"topf_slice": 1 << 30})
+    for slice_ in (64, 100):
+        cut = tables({"topf_slice": slice_})
+        for term in range(vocab):
+            assert np.array_equal(whole[term][0], cut[term][0]) and whole[term][1] == cut[term][1], (slice_, term)
+    for term in (0, 1, 17, 150, 299):
+        tf = orc.termfreqs(term).astype(np.float32)
+        nz = tf > 0
+        if nz.any():
+            norm = np.float32(1.2) * ((np.float32(1) - np.float32(0.75)) + np.float32(0.75) * (lens[nz].astype(np.float32) / np.float32(np.mean(lens.astype(np.float32)))))
+            assert whole[term][1] == np.max(tf[nz] / (tf[nz] + norm)), term
