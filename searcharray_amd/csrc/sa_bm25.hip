@@ -2461,6 +2461,19 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
                     tt = tt_loose; tsh = tsh_loose;
                 }
             }
+            // Groups of ONE (round 6, option group_one; round 5 review item 4): a query left over whose first term has a dense factor row --
+            // too dense for a loose group, shared with nobody -- is an item of its own: its base comes from the row with 16-byte loads (no
+            // scatter of ~1900 postings per tile), its other terms are overlaid.  Without it such queries run the per-query kernel on the side stream.
+            if (sa_opt(bt->opts.group_one, 0) != 0 && bt->impacts && bt->impacts->d_dense && sa_opt(bt->opts.group_dense, 1) != 0) {
+                std::vector<u32> still;
+                for (u32 q : rest) {
+                    const u32 t0 = terms[(size_t)q * T];
+                    const u32 slot = (t0 < ix->n_terms && t0 < bt->impacts->dense_slot.size()) ? bt->impacts->dense_slot[t0] : 0xFFFFFFFFu;
+                    if (slot != 0xFFFFFFFFu) { h_grp.push_back((u32)order.size()); h_grp.push_back(1u); h_grp.push_back(slot); order.push_back(q); }
+                    else still.push_back(q);
+                }
+                rest = still;
+            }
             bt->n_grouped_rows = (u32)order.size();
             bt->n_groups = (u32)(h_grp.size() / 3);
             order.insert(order.end(), rest.begin(), rest.end());
