@@ -2463,13 +2463,16 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
             }
             // Groups of ONE (round 6, option group_one; round 5 review item 4): a query left over whose first term has a dense factor row --
             // too dense for a loose group, shared with nobody -- is an item of its own: its base comes from the row with 16-byte loads (no
-            // scatter of ~1900 postings per tile), its other terms are overlaid.  Without it such queries run the per-query kernel on the side stream.
-            if (sa_opt(bt->opts.group_one, 0) != 0 && bt->impacts && bt->impacts->d_dense && sa_opt(bt->opts.group_dense, 1) != 0) {
+            // scatter of ~1900 postings per tile), its other terms are overlaid.  Without it such queries run the per-query kernel on the side stream
+            // (256 pairwise-distinct queries at 10 M docs, 10 such queries: 0.465 -> 0.436 ms at k = 10, 0.859 -> 0.738 at k = 1000; never slower
+            //  on the BASELINE / hot sets or the 1.25 M-doc shard: profiles/group_of_one_dense_row_ab_r06.jsonl).
+            if (sa_opt(bt->opts.group_one, 1) != 0 && bt->impacts && bt->impacts->d_dense && sa_opt(bt->opts.group_dense, 1) != 0) {
                 std::vector<u32> still;
                 for (u32 q : rest) {
                     const u32 t0 = terms[(size_t)q * T];
                     const u32 slot = (t0 < ix->n_terms && t0 < bt->impacts->dense_slot.size()) ? bt->impacts->dense_slot[t0] : 0xFFFFFFFFu;
-                    if (slot != 0xFFFFFFFFu) { h_grp.push_back((u32)order.size()); h_grp.push_back(1u); h_grp.push_back(slot); order.push_back(q); }
+                    // (group_one = 2, experiment: every left-over query with a known first term, its base from the postings where no row exists)
+                    if (slot != 0xFFFFFFFFu || (sa_opt(bt->opts.group_one, 1) == 2 && t0 < ix->n_terms)) { h_grp.push_back((u32)order.size()); h_grp.push_back(1u); h_grp.push_back(slot); order.push_back(q); }
                     else still.push_back(q);
                 }
                 rest = still;

@@ -160,18 +160,28 @@ def test_loose_groups_equal_oracle_and_per_query_kernel(api, corpus, monkeypatch
         if i % 13 == 0:
             q[-1] = VOCAB + 5                                      # an unknown term
         queries.append(q)
-    queries.append([0] + [int(x) for x in rng.integers(150, VOCAB, T - 1)])      # a dense first term: per-query kernel
+    queries.append([0] + [int(x) for x in rng.integers(150, VOCAB, T - 1)])      # a dense first term: a group of ONE over its dense row (round 6)
     got = check(api, corpus, queries, k, tile_docs=1024)
     words, off, lens, _ = corpus
-    dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api)
-    bt = dev.batch(np.asarray(queries), k=k)
-    gi = bt.group_info()
-    bt.close()
-    dev.close()
-    # no first term is shared; loose groups exist (when the half tables take all T terms of 16 queries) and the
-    # query with the dense first term stays with the per-query kernel
-    assert gi["shared_first_term"] == 0 and gi["per_query_kernel"] >= 1
+
+    def info():
+        dev = DeviceIndex(words, off, lens, tile_docs=1024, api=api)
+        bt = dev.batch(np.asarray(queries), k=k)
+        gi = bt.group_info()
+        bt.close()
+        dev.close()
+        return gi
+    gi = info()
+    # no first term is shared; loose groups exist (when the half tables take all T terms of 16 queries)
+    assert gi["shared_first_term"] == 0
     assert gi["groups"] >= 2 and gi["grouped_queries"] >= 20
+    # ... and the query with the dense first term is a group of one -- with group_one = 0 it stays with the per-query kernel, same results
+    set_opt("group_one", 0)
+    gi0 = info()
+    assert gi0["per_query_kernel"] >= 1 and gi0["per_query_kernel"] == gi["per_query_kernel"] + 1 and gi0["groups"] == gi["groups"] - 1
+    ref1 = check(api, corpus, queries, k, tile_docs=1024)
+    assert np.array_equal(got[0], ref1[0]) and np.array_equal(got[1], ref1[1])
+    unset_opt("group_one")
     set_opt("SA_GROUP_LOOSE", "0")
     ref = check(api, corpus, queries, k, tile_docs=1024)
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
