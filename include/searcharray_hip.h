@@ -64,7 +64,7 @@ typedef struct sa_options {
     int64_t group_loose;     /* 0: no loose groups */
     int64_t group_side;      /* 0: ungrouped rows on the batch's own stream instead of the side stream */
     int64_t group_dense;     /* 0: the grouped kernel builds its base from postings even where a dense factor row exists */
-    int64_t group_one;       /* 0: a left-over query whose first term has a dense factor row runs the per-query kernel instead of becoming a group of one */
+    int64_t group_one;       /* left-over queries (too dense for a loose group, first term shared with nobody) as groups of one: 2 all (default), 1 only over a dense factor row, 0 none (per-query kernel) */
     int64_t group_min;       /* smallest group (default 2) */
     int64_t group_maxq;      /* queries per table pass of a grouped item (default and at most 16) */
     int64_t group_item;      /* queries per grouped item: passes of group_maxq queries over ONE base (at most 64; default 32 for big launches, else 16) */

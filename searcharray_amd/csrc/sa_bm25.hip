@@ -2461,18 +2461,20 @@ static int sa_batch_fill(sa_batch* bt, const uint32_t* terms, const float* idf) 
                     tt = tt_loose; tsh = tsh_loose;
                 }
             }
-            // Groups of ONE (round 6, option group_one; round 5 review item 4): a query left over whose first term has a dense factor row --
-            // too dense for a loose group, shared with nobody -- is an item of its own: its base comes from the row with 16-byte loads (no
-            // scatter of ~1900 postings per tile), its other terms are overlaid.  Without it such queries run the per-query kernel on the side stream
-            // (256 pairwise-distinct queries at 10 M docs, 10 such queries: 0.465 -> 0.436 ms at k = 10, 0.859 -> 0.738 at k = 1000; never slower
-            //  on the BASELINE / hot sets or the 1.25 M-doc shard: profiles/group_of_one_dense_row_ab_r06.jsonl).
-            if (sa_opt(bt->opts.group_one, 1) != 0 && bt->impacts && bt->impacts->d_dense && sa_opt(bt->opts.group_dense, 1) != 0) {
+            // Groups of ONE (round 6, option group_one; round 5 review item 4): a query left over -- too dense for a loose group, its first
+            // term shared with nobody -- is an item of its own: one WAVE per (tile, query) whose base comes from the first term's dense factor
+            // row with 16-byte loads where it has one (no scatter of ~1900 postings per tile), from its postings otherwise, the other terms
+            // overlaid.  Without it such queries run the per-query kernel (a workgroup per pair) on the side stream.  Measured
+            // (profiles/group_of_one_dense_row_ab_r06.jsonl; 256 pairwise-distinct queries, 13 of them left over, 10 with a dense row):
+            // 10 M docs k = 10 / 1000: none 0.465 / 0.859 ms, rows only (group_one = 1) 0.431 / 0.725, all (2, the default) 0.408 / 0.648;
+            // 1.25 M docs k = 10 / 100: 0.138 / 0.180 -> 0.106 / 0.132; never slower on the BASELINE / hot sets.
+            const long long g1 = sa_opt(bt->opts.group_one, 2);
+            if (g1 != 0 && bt->impacts && sa_opt(bt->opts.group_dense, 1) != 0) {
                 std::vector<u32> still;
                 for (u32 q : rest) {
                     const u32 t0 = terms[(size_t)q * T];
-                    const u32 slot = (t0 < ix->n_terms && t0 < bt->impacts->dense_slot.size()) ? bt->impacts->dense_slot[t0] : 0xFFFFFFFFu;
-                    // (group_one = 2, experiment: every left-over query with a known first term, its base from the postings where no row exists)
-                    if (slot != 0xFFFFFFFFu || (sa_opt(bt->opts.group_one, 1) == 2 && t0 < ix->n_terms)) { h_grp.push_back((u32)order.size()); h_grp.push_back(1u); h_grp.push_back(slot); order.push_back(q); }
+                    const u32 slot = (bt->impacts->d_dense && t0 < ix->n_terms && t0 < bt->impacts->dense_slot.size()) ? bt->impacts->dense_slot[t0] : 0xFFFFFFFFu;
+                    if (slot != 0xFFFFFFFFu || (g1 >= 2 && t0 < ix->n_terms)) { h_grp.push_back((u32)order.size()); h_grp.push_back(1u); h_grp.push_back(slot); order.push_back(q); }
                     else still.push_back(q);
                 }
                 rest = still;

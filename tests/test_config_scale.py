@@ -66,15 +66,22 @@ def test_config2_bm25_topk_at_1m_docs(zipf1m, k):
 @pytest.mark.parametrize("k", [10, 100])
 def test_config2_queries_without_shared_terms_at_1m_docs(zipf1m, k):
     """256 queries of pairwise-distinct terms (no posting list shared): the exhaustive path scores the sparse ones as
-    LOOSE groups and the ones with a dense term with the per-query kernel on the side stream -- equal to the
-    per-query kernel alone, to dynamic pruning, and (16 queries) to the oracle"""
+    LOOSE groups and the ones with a dense term as groups of ONE (round 6; option group_one = 0: the per-query kernel on the
+    side stream, as rounds 3-5 did) -- equal to each other, to the per-query kernel alone, to dynamic pruning, and (all queries)
+    to the oracle"""
     dev, orc, _, _ = zipf1m
     queries = synth.bm25_queries_distinct(256, vocab=V)
     bt = dev.batch(queries, k=k)
     gi = bt.group_info()
     bt.close()
-    assert gi["shared_first_term"] == 0 and gi["grouped_queries"] >= 128 and gi["per_query_kernel"] >= 1, gi
+    bt = dev.batch(queries, k=k, opts={"group_one": 0})
+    gi0 = bt.group_info()
+    bt.close()
+    assert gi["shared_first_term"] == 0 and gi["grouped_queries"] == 256 and gi["per_query_kernel"] == 0, gi
+    assert gi0["shared_first_term"] == 0 and gi0["grouped_queries"] >= 128 and gi0["per_query_kernel"] >= 1, gi0
     loose = run_batch(dev, queries, k, {"SA_SPARSE": "0", "SA_GROUP": "1"})
+    side = run_batch(dev, queries, k, {"SA_SPARSE": "0", "SA_GROUP": "1", "group_one": 0})
+    assert np.array_equal(loose[0], side[0]) and np.array_equal(loose[1], side[1]), "groups of one vs the per-query kernel on the side stream"
     per_query = run_batch(dev, queries, k, {"SA_SPARSE": "0", "SA_GROUP": "0"})
     pruned = run_batch(dev, queries, k, {"SA_SPARSE": "1"})
     for name, got in (("per-query", per_query), ("pruned", pruned)):

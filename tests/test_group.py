@@ -160,7 +160,7 @@ def test_loose_groups_equal_oracle_and_per_query_kernel(api, corpus, monkeypatch
         if i % 13 == 0:
             q[-1] = VOCAB + 5                                      # an unknown term
         queries.append(q)
-    queries.append([0] + [int(x) for x in rng.integers(150, VOCAB, T - 1)])      # a dense first term: a group of ONE over its dense row (round 6)
+    queries.append([0] + [int(x) for x in rng.integers(150, VOCAB, T - 1)])      # a dense first term: a group of ONE (round 6)
     got = check(api, corpus, queries, k, tile_docs=1024)
     words, off, lens, _ = corpus
 
@@ -178,7 +178,13 @@ def test_loose_groups_equal_oracle_and_per_query_kernel(api, corpus, monkeypatch
     # ... and the query with the dense first term is a group of one -- with group_one = 0 it stays with the per-query kernel, same results
     set_opt("group_one", 0)
     gi0 = info()
-    assert gi0["per_query_kernel"] >= 1 and gi0["per_query_kernel"] == gi["per_query_kernel"] + 1 and gi0["groups"] == gi["groups"] - 1
+    assert gi0["per_query_kernel"] >= 1 and gi["per_query_kernel"] == 0 and gi0["groups"] == gi["groups"] - gi0["per_query_kernel"]
+    set_opt("group_one", 1)                                    # (only the ones whose first term has a dense factor row)
+    gi1 = info()
+    assert 0 <= gi1["per_query_kernel"] < gi0["per_query_kernel"]
+    ref2 = check(api, corpus, queries, k, tile_docs=1024)
+    assert np.array_equal(got[0], ref2[0]) and np.array_equal(got[1], ref2[1])
+    set_opt("group_one", 0)
     ref1 = check(api, corpus, queries, k, tile_docs=1024)
     assert np.array_equal(got[0], ref1[0]) and np.array_equal(got[1], ref1[1])
     unset_opt("group_one")
