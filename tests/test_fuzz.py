@@ -42,6 +42,45 @@ def test_random_bm25_batches_pruned_and_exhaustive(api, seed, monkeypatch):
         dev.close()
 
 
+@pytest.mark.parametrize("seed", [31, 32, 33, 34])
+def test_random_bm25_batches_on_the_staged_route(api, seed):
+    """the staged-tile route (csrc/sa_stage.hip) forced on random corpora and query sets: any B (slices above 256), T = 1 .. 8, k = 1 .. 300,
+    stage tiles of 64 .. 1024 docs, 1 / 2 / 8 workgroups per CU with co-walking groups of 1 / 2 / 4, with and without probe rows, BM25
+    parameters at the edges of the range the bounds admit (b = 0, b = 1) -- top-k equal to the oracle's bit for bit, and the route
+    taken is the staged one whenever the set has a known term"""
+    rng = np.random.default_rng(seed)
+    for _ in range(5):
+        n_docs, vocab, mean = int(rng.integers(200, 9000)), int(rng.integers(5, 500)), int(rng.integers(2, 24))
+        t, d, p, lens = synth.corpus_triples(n_docs, vocab, mean, seed=int(rng.integers(1 << 30)))
+        words, wt = rz.encode_sorted(t, d, p)
+        doc_base = int(rng.choice([0, 12345]))
+        dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=int(rng.choice([1024, 2048, 4096])), doc_base=doc_base, api=api)
+        orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
+        T, B, k = int(rng.integers(1, 9)), int(rng.choice([1, 2, 7, 40, 257, 300])), int(rng.choice([1, 3, 10, 33, 100, 300]))
+        queries = rng.integers(0, vocab + 2, size=(B, T))                       # includes unknown ids
+        queries[rng.random((B, T)) < 0.4] = rng.integers(0, max(1, vocab // 8))  # frequent terms, shared between queries
+        k1, b = float(rng.choice([1.2, 0.4, 2.0])), float(rng.choice([0.75, 0.0, 1.0]))     # (k1 = 0 is 0 / 0 = NaN for every doc without the term in the reference's dense formula)
+        opts = {"stage": 1, "stage_docs": int(rng.choice([64, 128, 256, 512, 1024])), "stage_wgs": int(rng.choice([1, 2, 8])),
+                "stage_cw": int(rng.choice([1, 2, 4])), "stage_probe": int(rng.choice([0, 1])), "probe_div": int(rng.choice([4, 128]))}
+        bt = dev.batch(queries, k=k, k1=k1, b=b, opts=opts)
+        for _ in range(2):
+            bt.run()
+        scores, docs = bt.fetch()
+        any_known = bool((queries < vocab).any())
+        if any_known and k <= 1024:
+            assert bt.last_route() in ("staged", "exhaustive"), bt.last_route()     # (exhaustive: a plan the route declines -- e.g. more than 1024 distinct terms)
+        for qi, q in enumerate(queries):
+            known = [int(x) for x in q if x < vocab]
+            dense = orc.score_terms_sum(known, k1=k1, b=b) if known else np.zeros(n_docs, np.float32)
+            ws, wd = O.topk(dense, k)
+            n = int((ws > 0).sum())
+            assert np.array_equal(scores[qi, :n], ws[:n]), (seed, opts, qi)
+            assert np.array_equal(docs[qi, :n], wd[:n] + np.uint64(doc_base)), (seed, opts, qi)
+            assert (docs[qi, n:] == NO_DOC).all()
+        bt.close()
+        dev.close()
+
+
 @pytest.mark.parametrize("seed", [21, 22])
 def test_random_phrases_batches_and_slop(api, seed, monkeypatch):
     rng = np.random.default_rng(seed)
