@@ -42,6 +42,9 @@ def test_random_bm25_batches_pruned_and_exhaustive(api, seed, monkeypatch):
         dev.close()
 
 
+STAGE_FUZZ_DOCS = (200, 9000)            # (scripts/fuzz_stage.py --big widens it on the GPU: enough tiles for the co-walking groups of a full device)
+
+
 @pytest.mark.parametrize("seed", [31, 32, 33, 34])
 def test_random_bm25_batches_on_the_staged_route(api, seed):
     """the staged-tile route (csrc/sa_stage.hip) forced on random corpora and query sets: any B (slices above 256), T = 1 .. 8, k = 1 .. 300,
@@ -50,7 +53,7 @@ def test_random_bm25_batches_on_the_staged_route(api, seed):
     taken is the staged one whenever the set has a known term"""
     rng = np.random.default_rng(seed)
     for _ in range(5):
-        n_docs, vocab, mean = int(rng.integers(200, 9000)), int(rng.integers(5, 500)), int(rng.integers(2, 24))
+        n_docs, vocab, mean = int(rng.integers(*STAGE_FUZZ_DOCS)), int(rng.integers(5, 500)), int(rng.integers(2, 24))
         t, d, p, lens = synth.corpus_triples(n_docs, vocab, mean, seed=int(rng.integers(1 << 30)))
         words, wt = rz.encode_sorted(t, d, p)
         doc_base = int(rng.choice([0, 12345]))
