@@ -397,7 +397,7 @@ static int sa_stage_plan_slice(sa_batch* bt, char* base, u32* h_seed, const u32*
     for (u32 r = 0; r < U; r++) { const u32 u = W.order[r]; W.rank[u] = r; if (W.staged[u]) { NS++; dfsum += W.dist_df[u]; } }
     if (U - NS > (u32)SA_ST_NT) return SA_OK;                // (one probed term per thread)
     // docs per stage tile: the largest of the sizes below whose expected postings fit the stage with room for the tiles above the
-    // mean, and that leave a workgroup of a full device a dozen tiles or more
+    // mean, and that leave a workgroup of a full device nine tiles or more
     const u32 tmax = T <= 4 ? 4u : 8u;
     const double cap = tmax == 4 ? (double)SaStCap<4>::v : (double)SaStCap<8>::v;
     const double per_doc = (double)dfsum / (double)ix->n_docs;
@@ -409,7 +409,9 @@ static int sa_stage_plan_slice(sa_batch* bt, char* base, u32* h_seed, const u32*
         for (u32 s : sizes) {
             if (per_doc * s + 4.0 * sqrt(per_doc * s) > 0.97 * cap) continue;
             if (!docs) docs = s;                             // (the largest that fits, unless a smaller one spreads the shard better)
-            if (ix->n_docs / s >= 12ull * wgs || s <= 512u) { docs = s; break; }
+            // (measured on 1.25 / 2.5 / 5 M-doc shards, 1024 / 768 / 512 / 384 docs per tile: 0.098 / 0.089 / 0.077 / 0.090, 0.120 / 0.114 / 0.111 /
+            //  0.149, 0.161 / 0.169 / 0.186 / 0.278 ms -- the biggest tile from nine tiles per workgroup on, else 512)
+            if (ix->n_docs / s >= 9ull * wgs || s <= 512u) { docs = s; break; }
         }
         if (!docs) return SA_OK;                          // (more than ~70 staged postings per doc: not this route)
     }
