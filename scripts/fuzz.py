@@ -27,7 +27,9 @@ def main():
     else:
         from searcharray_amd import _lib
         api = _lib.api()
-    from tests import test_fuzz
+    from tests import test_fuzz, helpers
+    from searcharray_amd import options as _options
+    helpers._scope = _options.Scope()                     # (what tests/conftest.py's fixture gives a test: the scope set_opt writes into)
     fails = 0
     for seed in range(100, 100 + args.seeds):
         for fn in (test_fuzz.test_random_bm25_batches_pruned_and_exhaustive, test_fuzz.test_random_phrases_batches_and_slop):
