@@ -86,6 +86,9 @@ def parse_args():
     ap.add_argument("--corpus-cache", default="", help="directory to cache the encoded corpus shard (.npz)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs (traffic / L2 hit rate)")
+    ap.add_argument("--driver", choices=["ring", "queue"], default="ring",
+                    help="who feeds the fresh-batch stream: 'ring' = this process steps a ring of batch objects (sa_batch_step + sa_batch_fetch per step: "
+                         "rounds 3-6), 'queue' = the library's query-set queue (sa_queue_*: a worker thread of the library steps the ring)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="a library option for every batch of the run (e.g. stage=0: the main region on round 5's routes); measurement only")
     ap.add_argument("--pruned", action="store_true",
@@ -289,6 +292,43 @@ class Rank:
             batch.run(sync=False)
         self.barrier()
         return self.allmax(time.perf_counter() - t0)
+
+    def timed_fresh_queue(self, queue, sets, n_warm, n_steps, repeats=1):
+        """The same query stream through the library's QUEUE (sa_queue_*: a ring of `depth` batches fed by a worker thread of the library):
+        step i fetches ticket i - depth (its slot is the one ticket i takes) and submits set i mod len(sets); the worker runs sa_batch_step.
+        Same bracketing and the same EXACTLY n_steps per timed region as timed_fresh.  -> ([seconds per region], {set: (scores, docs)})"""
+        P = queue.depth
+        pending = []
+        results = {}
+        sets_u32 = [np.ascontiguousarray(q, dtype=np.uint32) for q in sets]
+
+        def drain_one():
+            tk, si = pending.pop(0)
+            results[si] = queue.fetch(tk)
+
+        def step(i):
+            if len(pending) == P:
+                drain_one()
+            si = i % len(sets)
+            pending.append((queue.submit(sets_u32[si]), si))
+
+        for i in range(n_warm):
+            step(i)
+        while pending:
+            drain_one()
+        self.barrier()
+        dts, i0 = [], n_warm
+        for _ in range(max(1, repeats)):
+            self.barrier()
+            t0 = time.perf_counter()
+            for i in range(n_steps):
+                step(i0 + i)
+            while pending:
+                drain_one()
+            self.barrier()
+            dts.append(self.allmax(time.perf_counter() - t0))
+            i0 += n_steps
+        return dts, results
 
     def timed_fresh(self, ring, sets, n_warm, n_steps, repeats=1):
         """The query stream: step i hands batch object i mod P the query set i mod len(sets) -- ONE library call per step
@@ -942,11 +982,16 @@ def main():
     P = max(1, args.pipeline if B <= 1024 else min(args.pipeline, 4))
     pair = [r.make_batch(sets[i % len(sets)], check=(i == 0)) for i in range(P)]
     R = max(1, args.repeats)
-    dts, fresh_results = r.timed_fresh(pair, sets, max(W, P), K, repeats=R)
+    if args.driver == "queue":
+        qq = r.index.queue(B, sets[0].shape[1], k=args.k, depth=P)
+        dts, fresh_results = r.timed_fresh_queue(qq, sets, max(W, P), K, repeats=R)
+        qq.close()
+    else:
+        dts, fresh_results = r.timed_fresh(pair, sets, max(W, P), K, repeats=R)
     dt = float(np.median(dts))
     # (HIP events around one batch's scoring kernels: with P batches in flight on P streams they overlap the other
     #  batches' kernels, so this is a batch's latency share, not the device time per step -- the replay leg's is)
-    kernel_ms_fresh = float(np.mean([b.profile()[0] for b in pair]))
+    kernel_ms_fresh = float(np.mean([b.profile()[0] for b in pair])) if args.driver == "ring" else float("nan")     # (the queue's batches are its own)
     scores, docs = fresh_results[0] if 0 in fresh_results else (None, None)
 
     # replay of the resident set 0 (rounds 1-2 reported this as `value`)
@@ -1126,7 +1171,7 @@ def main():
                                    f"one sa_batch_step (idf gathered from the index table, reset, run) + fetch per step, "
                                    f"top-{args.k}, the library's default route for the shape: {main_route}",
                        "docs": D, "queries_per_step": B, "terms_per_query": 4, "k": args.k, "query_sets": len(sets),
-                       "batches_in_flight": P,
+                       "batches_in_flight": P, "driver": args.driver,
                        "distinct_terms_in_batch": int(len(np.unique(queries))),
                        "tile_docs": int(r.info.tile_docs), "parallelism": f"doc-range shards x{world}",
                        "collective": r.collective, "collective_library": dict(zip(("nccl_version", "path"), comm_lib)),
@@ -1134,7 +1179,7 @@ def main():
                                                                "collectives = libsearcharray_hip.so's RCCL communicator"},
             "postings_scanned_GBps": round(post_total * K / dt / 1e9, 2),
             "collective_library": dict(zip(("nccl_version", "path"), comm_lib)),
-            "fresh_batch_latency_ms": round(kernel_ms_fresh, 4),
+            "fresh_batch_latency_ms": None if kernel_ms_fresh != kernel_ms_fresh else round(kernel_ms_fresh, 4),
             "replay": {"value": round(B * K / dt_r, 2), "unit": "queries/s", "ms_per_step": round(dt_r / K * 1e3, 4),
                        "kernel_ms": round(kernel_ms_r, 4), "fresh_over_replay": round(dt_r / dt, 4),
                        "fresh_equals_replay": fresh_equals_replay,

@@ -382,6 +382,20 @@ int sa_batch_merge_gathered(sa_batch_t* batch, const void* gathered_keys_device,
  * (sync = 0).  What the caller loop score() -> top-k is per query (postings.py:652-680), per batch. */
 int sa_index_set_idf_table(sa_index_t* ix, const float* idf_per_term, uint32_t n_terms);
 int sa_batch_step(sa_batch_t* batch, const uint32_t* terms);
+
+/* ---- Part 2c: a query-set QUEUE (csrc/sa_queue.hip).  A ring of `depth` batches of the same shape behind one handle, fed by a WORKER
+ * THREAD of the library: sa_queue_submit copies a set of B x T term ids (weights come from the index's idf table, sa_index_set_idf_table,
+ * as for sa_batch_step) and returns a ticket -- it blocks only while `depth` tickets are outstanding; the worker runs sa_batch_step for
+ * the tickets in order; sa_queue_fetch(ticket) waits for that set's device work without holding any lock the worker needs and returns
+ * its top-k (scores float32[B][k], doc ids uint64[B][k], as sa_batch_fetch).  Every ticket must be fetched; its slot is free again then.
+ * The counterpart of the reference's callers that drive score() from a thread pool (test/test_msmarco.py:483-507): the host cost of
+ * preparing a query set leaves the caller's thread.  sa_queue_batch exposes a slot's batch for diagnostics (sa_batch_last_route ...). */
+typedef struct sa_queue sa_queue_t;
+int sa_queue_create(sa_index_t* index, int n_queries, int n_query_terms, int k, float k1, float b, int depth, sa_queue_t** out);
+int sa_queue_submit(sa_queue_t* queue, const uint32_t* terms, uint64_t* ticket_out);
+int sa_queue_fetch(sa_queue_t* queue, uint64_t ticket, float* scores_out, uint64_t* docs_out);
+int sa_queue_batch(sa_queue_t* queue, int slot, sa_batch_t** out);
+int sa_queue_destroy(sa_queue_t* queue);
 /* Results to the host: scores f32[B][k], docs u64[B][k].  Every sa_batch_run ends with an asynchronous copy of its
  * B*k keys into a page-locked buffer of the batch; fetch waits for THAT copy only (not for the streams), so other
  * batches of the index keep running behind it. */

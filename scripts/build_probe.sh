@@ -6,7 +6,7 @@
 set -e
 cd "$(dirname "$0")/../searcharray_amd/csrc"
 mkdir -p ../../build/probe_obj
-for f in sa_index sa_build sa_bm25 sa_stage sa_sparse sa_ops sa_setops sa_phrase sa_phrase_batch sa_spans sa_vec sa_io sa_comm sa_sort sa_sharded; do
+for f in sa_index sa_build sa_bm25 sa_stage sa_queue sa_sparse sa_ops sa_setops sa_phrase sa_phrase_batch sa_spans sa_vec sa_io sa_comm sa_sort sa_sharded; do
   if [ $f = sa_bm25 ] || [ $f = sa_stage ] || [ $f = sa_spans ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DSA_PROBE ${SA_PROBE_EXTRA} -c $f.hip -o ../../build/probe_obj/$f.o
   else

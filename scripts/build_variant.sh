@@ -5,7 +5,7 @@ set -e
 NAME=$1; shift
 cd "$(dirname "$0")/../searcharray_amd/csrc"
 mkdir -p ../../build/var_$NAME
-for f in sa_index sa_build sa_bm25 sa_stage sa_sparse sa_ops sa_setops sa_phrase sa_phrase_batch sa_spans sa_vec sa_io sa_comm sa_sort sa_sharded; do
+for f in sa_index sa_build sa_bm25 sa_stage sa_queue sa_sparse sa_ops sa_setops sa_phrase sa_phrase_batch sa_spans sa_vec sa_io sa_comm sa_sort sa_sharded; do
   if [ $f = ${VARIANT_FILE:-sa_stage} ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off "$@" -c $f.hip -o ../../build/var_$NAME/$f.o
   else

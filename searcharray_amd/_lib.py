@@ -118,6 +118,11 @@ PROTOTYPES = {
     "sa_batch_group_info": (c_int, [c_void_p, POINTER(c_uint32)]),
     "sa_batch_last_route": (c_int, [c_void_p, POINTER(c_int)]),
     "sa_batch_host_times": (c_int, [c_void_p, POINTER(c_uint64)]),
+    "sa_queue_create": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_int, POINTER(c_void_p)]),
+    "sa_queue_submit": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint64)]),
+    "sa_queue_fetch": (c_int, [c_void_p, c_uint64, POINTER(c_float), POINTER(c_uint64)]),
+    "sa_queue_batch": (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
+    "sa_queue_destroy": (c_int, [c_void_p]),
     "sa_batch_debug_rank_table": (c_int, [c_void_p, ctypes.c_uint32, POINTER(ctypes.c_float), POINTER(ctypes.c_float)]),
     "sa_batch_seeds": (c_int, [c_void_p, POINTER(c_float)]),
     "sa_batch_stats": (c_int, [c_void_p, c_int, u64p, u64p]),

@@ -392,6 +392,11 @@ class DeviceIndex(_options.OptionsMixin):
               idf: Optional[np.ndarray] = None, opts=None) -> "QueryBatch":
         return QueryBatch(self, queries, k=k, k1=k1, b=b, idf=idf, opts=opts)
 
+    def queue(self, n_queries: int, n_terms: int, k: int = 10, k1: float = 1.2, b: float = 0.75, depth: int = 6, opts=None) -> "QueryQueue":
+        """a query-set queue (``sa_queue_*``): ``depth`` batches of ``n_queries`` x ``n_terms`` behind one handle, stepped by a worker
+        thread of the library; needs ``set_idf_table`` first"""
+        return QueryQueue(self, n_queries, n_terms, k=k, k1=k1, b=b, depth=depth, opts=opts)
+
     def phrase_batch(self, phrases: Sequence[Sequence[int]], k: int = 10, k1: float = 1.2, b: float = 0.75,
                      idf: Optional[np.ndarray] = None, slop=0, opts=None) -> "PhraseBatch":
         return PhraseBatch(self, phrases, k=k, k1=k1, b=b, idf=idf, slop=slop, opts=opts)
@@ -541,6 +546,65 @@ class QueryBatch(_options.OptionsMixin):
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self.api.sa_batch_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class QueryQueue:
+    """A stream of query SETS (each ``[B][T]`` term ids) through a ring of ``depth`` batches that a worker thread of the library feeds
+    (``sa_queue_*``, csrc/sa_queue.hip): ``submit`` copies a set and returns a ticket at once -- the idf gather, the set's tables, the
+    upload and the launches (``sa_batch_step``) happen on the worker --, ``fetch(ticket)`` waits for that set's results.  Tickets are
+    served in order and every ticket must be fetched (``submit`` blocks while ``depth`` are outstanding).  The caller idiom of the
+    reference's thread-pool drivers (test/test_msmarco.py:483-507) without the caller's thread paying for the preparation of a set.
+    The batches take the options in force when the queue is created."""
+
+    def __init__(self, index: DeviceIndex, n_queries: int, n_terms: int, k: int = 10, k1: float = 1.2, b: float = 0.75,
+                 depth: int = 6, opts=None):
+        self.index, self.api = index, index.api
+        self.B, self.T, self.k, self.depth = int(n_queries), int(n_terms), int(k), int(depth)
+        self._h = ctypes.c_void_p()
+        base = _options.Options(index._opts_base, opts)
+        with _options.creating(self.api, base):
+            self.api.call("sa_queue_create", index._h, self.B, self.T, self.k, np.float32(k1), np.float32(b), self.depth, ctypes.byref(self._h))
+        index._track(self)
+
+    def submit(self, queries: np.ndarray) -> int:
+        q = np.asarray(queries)
+        if q.shape != (self.B, self.T):
+            raise ValueError(f"submit takes [{self.B}][{self.T}] term ids")
+        if q.dtype != np.uint32 or not q.flags.c_contiguous:
+            q = as_u32(np.where((q >= 0) & (q < self.index.n_terms), q, NO_TERM).astype(np.uint32))
+        t = _lib.c_uint64(0)
+        self.api.call("sa_queue_submit", self._h, p_u32(q), ctypes.byref(t))
+        return t.value
+
+    def fetch(self, ticket: int) -> Tuple[np.ndarray, np.ndarray]:
+        scores = np.empty((self.B, self.k), dtype=np.float32)
+        docs = np.empty((self.B, self.k), dtype=np.uint64)
+        self.api.call("sa_queue_fetch", self._h, _lib.c_uint64(int(ticket)), p_f32(scores), p_u64(docs))
+        return scores, docs
+
+    def last_route(self, slot: int = 0) -> str:
+        """the route the last run of the batch in ``slot`` took (``QueryBatch.last_route``)"""
+        bh = ctypes.c_void_p()
+        self.api.call("sa_queue_batch", self._h, int(slot), ctypes.byref(bh))
+        r = ctypes.c_int(0)
+        self.api.call("sa_batch_last_route", bh, ctypes.byref(r))
+        return {0: "exhaustive", 1: "pruned", 2: "staged"}.get(r.value, str(r.value))
+
+    def batch_handle(self, slot: int):
+        bh = ctypes.c_void_p()
+        self.api.call("sa_queue_batch", self._h, int(slot), ctypes.byref(bh))
+        return bh
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.api.sa_queue_destroy(self._h)
             self._h = ctypes.c_void_p()
 
     def __del__(self):

@@ -214,3 +214,61 @@ def test_pruning_tables_on_demand(api, corpus, monkeypatch):
             assert bt.seeds().max() > 0
     bt.close()
     dev.close()
+
+
+def test_query_set_queue_with_a_worker_thread(api):
+    """sa_queue_* (csrc/sa_queue.hip): a stream of query sets through a ring of batches stepped by a worker thread of the library -- every
+    ticket's results equal a batch created for that set (and through it the oracle: tests above), in order, with more sets than the ring
+    is deep, with the caller fetching late (submit blocks until a slot is free) and from a second caller thread; a ticket cannot be
+    fetched twice; a failing step (no idf table) surfaces at fetch with the worker's error text."""
+    import threading
+    n_docs, vocab = 9000, 400
+    t, d, p, lens = synth.corpus_triples(n_docs, vocab, 14, seed=31)
+    words, wt = rz.encode_sorted(t, d, p)
+    dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+    rng = np.random.default_rng(77)
+    sets = [np.stack([rng.integers(0, 6, 24), rng.integers(3, vocab, 24), rng.integers(100, vocab + 2, 24)], axis=1) for _ in range(11)]
+    want = []
+    for s_ in sets:
+        bt = dev.batch(s_, k=7)
+        bt.run()
+        want.append(bt.fetch())
+        bt.close()
+    qq = dev.queue(24, 3, k=7, depth=3)
+    tk = qq.submit(sets[0])
+    with pytest.raises(Exception, match="set_idf_table"):
+        qq.fetch(tk)                                             # (sa_batch_step needs sa_index_set_idf_table)
+    df = dev.docfreqs().astype(np.float64)
+    dev.set_idf_table(np.log(1 + (n_docs - df + 0.5) / (df + 0.5)).astype(np.float32))
+    tickets = []
+    got = {}
+    for i, s_ in enumerate(sets):                                # 11 sets through a ring of 3: fetch when the ring is full
+        if len(tickets) == 3:
+            t0 = tickets.pop(0)
+            got[t0[1]] = qq.fetch(t0[0])
+        tickets.append((qq.submit(s_), i))
+    for tk, i in tickets:
+        got[i] = qq.fetch(tk)
+    for i in range(len(sets)):
+        assert np.array_equal(got[i][0], want[i][0]) and np.array_equal(got[i][1], want[i][1]), i
+    with pytest.raises(Exception, match="fetched already|never handed out"):
+        qq.fetch(tickets[-1][0])
+    # a producer thread submits, the main thread fetches
+    order = []
+
+    def produce():
+        for i in (4, 2, 9, 0, 7, 5):
+            order.append((qq.submit(sets[i]), i))
+    th = threading.Thread(target=produce)
+    th.start()
+    done = 0
+    while done < 6:
+        if len(order) > done:
+            tk, i = order[done]
+            r = qq.fetch(tk)
+            assert np.array_equal(r[0], want[i][0]) and np.array_equal(r[1], want[i][1]), i
+            done += 1
+    th.join()
+    assert qq.last_route(0) in ("staged", "exhaustive", "pruned")
+    qq.close()
+    dev.close()
