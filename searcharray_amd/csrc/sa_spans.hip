@@ -1044,11 +1044,17 @@ __global__ void __launch_bounds__(64) sa_k_span_machine_wave(const SpanMachinePa
 // other blocks' machines.  Span entries are 8 bytes here (position bits 32, first position 23, last - first 5, terms
 // 4): T + slop <= 15.
 #define SA_SPAN_DW 4                     // words of one term per document the gather holds in registers
-#define SA_SPAN_DB 64                    // bins: [npos] for 1 <= npos <= 32, [33] heavy
+#define SA_SPAN_DB 36                    // bins: [npos] for 1 <= npos <= 32, [33] heavy (the block is 8 bytes under 21 LDS granules of 1280 bytes with it: six blocks per CU)
 #define SA_SPAN_FT 256                   // threads of a block
 #define SA_SPAN_FD 512                   // documents of a block
 #define SA_SPAN_PC 8                     // positions of a document the gather keeps in LDS (= positions of a 64-lane chunk's lane)
 #define SA_SPAN_PMAXF 32                 // positions of a document a lane takes at all
+#ifndef SA_SPAN_NTAB
+#define SA_SPAN_NTAB 4                   // waves of a block that own span tables and run the lane machines (the block's other waves only gather and rank)
+#endif
+#ifndef SA_SPAN_NTAB_BATCH
+#define SA_SPAN_NTAB_BATCH 2             // the same for a batch launch that fills the device: 12 KiB of tables less per block, six resident blocks per CU instead of four
+#endif
 #ifndef SA_SPAN_FROWS
 #define SA_SPAN_FROWS 12                 // table rows of a lane of a 64-lane chunk, incl. the scratch row: 12 x 64 x 8 = 6 KiB per wave
 #endif
@@ -1540,8 +1546,7 @@ __device__ __forceinline__ bool sa_span_lane_machine(u64* ents, const Pos& pos, 
 // left them; fewer: behind the tables (PM x S words), from the gather's list if it holds them, else from the words again.
 template <int CE, int PM, int S, int TT>
 __device__ __forceinline__ void sa_span_doc_chunk(const SpanDocParams& p, u64* tab, const unsigned short* s_plist, u32* s_pbase,
-                                                  const unsigned char* s_bin, const unsigned short* s_order, unsigned short* s_heavy,
-                                                  u32* n_heavy, const u32* s_doc, const u32 lane, const u32 start, const u32 n,
+                                                  unsigned char* s_bin, const unsigned short* s_order, const u32* s_doc, const u32 lane, const u32 start, const u32 n,
                                                   const bool staged) {
     const bool have = lane < (u32)S && start + lane < n;
     const u32 local = have ? s_order[start + lane] : 0u;
@@ -1582,7 +1587,7 @@ __device__ __forceinline__ void sa_span_doc_chunk(const SpanDocParams& p, u64* t
         // staged: the document's slot of s_pbase -- its position base is not needed any more -- takes the count
         if (staged) s_pbase[local] = ok ? incr : 0u;
         else if (ok && incr) sa_span_doc_put(p, doc, incr);
-        if (!ok) s_heavy[atomicAdd(n_heavy, 1u)] = (unsigned short)local;      // its table outgrew the column: a wave of its own below
+        if (!ok) s_bin[local] = (unsigned char)(SA_SPAN_PMAXF + 1);            // its table outgrew the column: marked heavy -- a wave of its own below
     }
 }
 
@@ -1601,7 +1606,7 @@ extern "C" int sa_debug_span_probe_read(unsigned long long* out8, int clear) {
 #define SA_SPP(i) do { } while (0)
 #endif
 
-template <int TT>
+template <int TT, int NTAB_>
 __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, const u32 block) {
 #ifdef SA_PROBE
     u64 sp_last = __builtin_amdgcn_s_memtime();
@@ -1611,12 +1616,13 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
     __shared__ unsigned short s_plist[SA_SPAN_PC * SA_SPAN_FD];  // position-major: position q of local document d at [q * FD + d]
     __shared__ u32 s_pbase[SA_SPAN_FD];                          // 18 x the document's first block
     __shared__ u32 s_doc[SA_SPAN_FD];                            // the slot's document
-    __shared__ alignas(16) u64 s_tab[NW * TABW];
+    constexpr int NTAB = NTAB_ < NW ? NTAB_ : NW;                // waves with tables: they run the lane machines
+    __shared__ alignas(16) u64 s_tab[NTAB * TABW];
     __shared__ unsigned char s_bin[SA_SPAN_FD];
-    __shared__ unsigned short s_order[SA_SPAN_FD], s_heavy[SA_SPAN_FD];
+    __shared__ unsigned short s_order[SA_SPAN_FD];               // the machines' work order; afterwards the list of the heavy documents
     __shared__ u32 s_h[SA_SPAN_DB], s_first[SA_SPAN_DB], s_cur[SA_SPAN_DB];
     __shared__ u32 s_nheavy, s_next;
-    constexpr int HW = (int)(NW * TABW * 8 / (SA_NSPANS * sizeof(SpanEnt)));      // waves that find room for a full 512-span table afterwards
+    constexpr int HW = (int)(NTAB * TABW * 8 / (SA_NSPANS * sizeof(SpanEnt)));      // waves that find room for a full 512-span table afterwards
     static_assert(HW >= 1, "the block's tables must hold one full table");
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (threadIdx.x < SA_SPAN_DB) { s_h[threadIdx.x] = 0; s_cur[threadIdx.x] = 0; }
@@ -1767,8 +1773,7 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
     for (int r = 0; r < ROUNDS; r++) {
         const u32 local = (u32)r * SA_SPAN_FT + threadIdx.x;
         const u32 bin = s_bin[local];
-        if (bin == HEAVY) s_heavy[atomicAdd(&s_nheavy, 1u)] = (unsigned short)local;
-        else if (bin) s_order[s_first[bin] + atomicAdd(&s_cur[bin], 1u)] = (unsigned short)local;
+        if (bin && bin != HEAVY) s_order[s_first[bin] + atomicAdd(&s_cur[bin], 1u)] = (unsigned short)local;
     }
     __syncthreads();
     SA_SPP(2);                                                  // order
@@ -1784,18 +1789,18 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
         //  wave with 20 rows each there, a wave of their own for the rest)
         constexpr u32 AL = TT == 2 ? 64u : 32u;
         const u32 k_a = (n - start_a + AL - 1u) / AL;
-        u64* const tab = s_tab + (size_t)wave * TABW;
+        u64* const tab = s_tab + (size_t)(wave < (u32)NTAB ? wave : 0u) * TABW;
         constexpr int R = SA_SPAN_FROWS;
         // 8 lanes: 32 positions x 8 x 4 B = 1 KiB behind (TABW - 128) / 8 rows; 16 lanes: 16 x 16 x 4 B = 1 KiB behind (TABW - 128) / 16 rows
-        for (;;) {
+        for (; wave < (u32)NTAB; ) {
             u32 ck = 0;
             if (lane == 0) ck = atomicAdd(&s_next, 1u);
             ck = (u32)__builtin_amdgcn_readfirstlane((int)ck);
             if (ck >= k_c + k_b + k_a) break;
-            if (ck < k_c) sa_span_doc_chunk<(TABW - 128) / 8 - 1, 4 * SA_SPAN_PC, 8, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, s_doc, lane, 8u * ck, n, staged);
-            else if (ck < k_c + k_b) sa_span_doc_chunk<(TABW - 128) / 16 - 1, 2 * SA_SPAN_PC, 16, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, s_doc, lane, start_b + 16u * (ck - k_c), n, staged);
-            else if (TT == 2) sa_span_doc_chunk<R - 1, SA_SPAN_PC, 64, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, s_doc, lane, start_a + 64u * (ck - k_c - k_b), n, staged);
-            else sa_span_doc_chunk<(TABW - 128) / 32 - 1, SA_SPAN_PC, 32, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_heavy, &s_nheavy, s_doc, lane, start_a + 32u * (ck - k_c - k_b), n, staged);
+            if (ck < k_c) sa_span_doc_chunk<(TABW - 128) / 8 - 1, 4 * SA_SPAN_PC, 8, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_doc, lane, 8u * ck, n, staged);
+            else if (ck < k_c + k_b) sa_span_doc_chunk<(TABW - 128) / 16 - 1, 2 * SA_SPAN_PC, 16, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_doc, lane, start_b + 16u * (ck - k_c), n, staged);
+            else if (TT == 2) sa_span_doc_chunk<R - 1, SA_SPAN_PC, 64, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_doc, lane, start_a + 64u * (ck - k_c - k_b), n, staged);
+            else sa_span_doc_chunk<(TABW - 128) / 32 - 1, SA_SPAN_PC, 32, TT>(p, tab, s_plist, s_pbase, s_bin, s_order, s_doc, lane, start_a + 32u * (ck - k_c - k_b), n, staged);
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -1803,10 +1808,17 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
     __syncthreads();
     SA_SPP(4);                                                  // ... and the wait for the block's other waves
     // ---- heavy documents and outgrown tables: a wave each, the block's tables now being free (HW full tables fit)
+    // (their list: the documents the gather found heavy and the ones a lane machine marked -- into s_order, which the machines are done with)
+#pragma unroll 1
+    for (int r = 0; r < ROUNDS; r++) {
+        const u32 local = (u32)r * SA_SPAN_FT + threadIdx.x;
+        if (s_bin[local] == HEAVY) s_order[atomicAdd(&s_nheavy, 1u)] = (unsigned short)local;
+    }
+    __syncthreads();
     const u32 nh = s_nheavy;
     if (wave < (u32)HW)
         for (u32 i = wave; i < nh; i += (u32)HW)
-            sa_span_wave_doc<TT>(p, s_doc[s_heavy[i]], (SpanEnt*)s_tab + (size_t)wave * SA_NSPANS, lane, staged ? &s_pbase[s_heavy[i]] : nullptr);
+            sa_span_wave_doc<TT>(p, s_doc[s_order[i]], (SpanEnt*)s_tab + (size_t)wave * SA_NSPANS, lane, staged ? &s_pbase[s_order[i]] : nullptr);
     SA_SPP(5);                                                  // heavy documents
     if (ranked) {
         // counts -> BM25 (the reference's operation order, similarity.py:24-38 / bm25.pyx:19-23, as sa_k_dense_topk_tiles forms it)
@@ -1854,12 +1866,12 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
 
 template <int TT>
 __global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused(const SpanDocParams p) {
-    sa_span_doc_fused_body<TT>(p, blockIdx.x);
+    sa_span_doc_fused_body<TT, SA_SPAN_NTAB>(p, blockIdx.x);
 }
 
 // B phrases in ONE launch: the blocks of all phrases back to back, block b belongs to the phrase j with
 // jobs[j].block0 <= b < jobs[j].block0 + jobs[j].n_blocks (found by bisection: the jobs are sorted by block0)
-template <int TT>
+template <int TT, int NTAB>
 __global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused_multi(const SpanDocParams* __restrict__ jobs, u32 n_jobs) {
     u32 lo = 0, hi = n_jobs;
     while (hi - lo > 1u) {
@@ -1877,7 +1889,7 @@ __global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused_multi(const Sp
     const u32 bl = blockIdx.x - p.block0, per = (p.n_blocks + 7u) >> 3;
     const u32 wb = (bl & 7u) * per + (bl >> 3);
     if ((bl >> 3) >= per || wb >= p.n_blocks) return;
-    sa_span_doc_fused_body<TT>(p, wb);
+    sa_span_doc_fused_body<TT, NTAB>(p, wb);
 }
 
 static bool sa_opt_span_doc(const sa_index* ix) { return sa_opt(ix->opts.span_doc, 1) != 0; }
@@ -2465,9 +2477,23 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
         const SpanDocParams* jc = dd_dev + dfirst[c];
         // (span_lds_pad: MEASUREMENT HOOK -- unused dynamic LDS per block lowers the resident blocks per CU: the occupancy experiment of DESIGN 3.4)
         const u32 pad = (u32)std::min<long long>(120000, std::max<long long>(0, sa_opt(ix->opts.span_lds_pad, 0)));
-        if (c == 0) hipLaunchKernelGGL(sa_k_span_doc_fused_multi<2>, dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, cnt);
-        else if (c == 1) hipLaunchKernelGGL(sa_k_span_doc_fused_multi<3>, dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, cnt);
-        else hipLaunchKernelGGL(sa_k_span_doc_fused_multi<4>, dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, cnt);
+        // Waves of a block with span tables.  A launch that fills the device is bound by how many blocks a CU holds -- a block's gather
+        // waits for memory, its machines are short -- and the tables are most of a block's LDS: with two of the four waves running the
+        // machines a block takes 26 KB instead of 39 and a CU holds six instead of four (the bench's 256-phrase batch: 0.588 -> 0.48 ms).
+        // A launch of few blocks is bound by a block's own latency: all four waves run machines there (33 sampled phrases: -7 % with two).
+        const long long tw = sa_opt(ix->opts.span_tab_waves, dblocks[c] > 4u * (u32)ix->n_cus ? SA_SPAN_NTAB_BATCH : SA_SPAN_NTAB);
+        const bool few = tw < SA_SPAN_NTAB;
+        if (sa_opt(ix->opts.trace, 0)) fprintf(stderr, "sa_span_counts_batch: doc-parallel launch of %u phrases, %u blocks, %d table waves per block\n", cnt, dblocks[c], few ? SA_SPAN_NTAB_BATCH : SA_SPAN_NTAB);
+        if (c == 0) {
+            if (few) hipLaunchKernelGGL((sa_k_span_doc_fused_multi<2, SA_SPAN_NTAB_BATCH>), dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, cnt);
+            else hipLaunchKernelGGL((sa_k_span_doc_fused_multi<2, SA_SPAN_NTAB>), dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, cnt);
+        } else if (c == 1) {
+            if (few) hipLaunchKernelGGL((sa_k_span_doc_fused_multi<3, SA_SPAN_NTAB_BATCH>), dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, cnt);
+            else hipLaunchKernelGGL((sa_k_span_doc_fused_multi<3, SA_SPAN_NTAB>), dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, cnt);
+        } else {
+            if (few) hipLaunchKernelGGL((sa_k_span_doc_fused_multi<4, SA_SPAN_NTAB_BATCH>), dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, cnt);
+            else hipLaunchKernelGGL((sa_k_span_doc_fused_multi<4, SA_SPAN_NTAB>), dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, cnt);
+        }
     }
     SA_HIP(hipGetLastError());
     return SA_OK;

@@ -138,16 +138,23 @@ def test_config5_slop2_equals_the_reference_golden(zipf1m):
     oracle/_ref) for the 32 queries above and 44 of the bench's, the four heaviest included -- the device's counts bit for bit (sha1 of
     the float32[1M] vector, plus the sparse pairs where the fixture holds them), its slop scores within 1e-5 relative"""
     import hashlib
+    from searcharray_amd import options
     from tests.helpers import load_golden
     dev, _, _, _ = zipf1m
     g = load_golden("slop_1m")
     assert [int(x) for x in g["meta"]] == [D, V]
     for tag in "tb":
         qs = [[int(x) for x in q] for q in g[f"{tag}_queries"]]
-        pb = dev.phrase_batch(qs, k=10, slop=2)
-        pb.run()
-        ps, _ = pb.fetch()
-        pb.close()
+        # (both instances of the batch launch: four and two of a block's waves with span tables -- the size of the launch decides otherwise)
+        tops = []
+        for tw in (4, 2):
+            with options.scoped(span_tab_waves=tw):
+                pb = dev.phrase_batch(qs, k=10, slop=2)
+                pb.run()
+                tops.append(pb.fetch())
+                pb.close()
+        assert np.array_equal(tops[0][0], tops[1][0]) and np.array_equal(tops[0][1], tops[1][1]), "two vs four table waves per block"
+        ps = tops[1][0]
         for i, ph in enumerate(qs):
             got = dev.phrase_freqs_dense(ph, slop=2)
             sha = np.frombuffer(hashlib.sha1(np.ascontiguousarray(got, dtype=np.float32).tobytes()).digest(), dtype=np.uint8)

@@ -811,15 +811,29 @@ def test_slop_phrases_of_a_batch_share_their_launches(api, monkeypatch):
     unset_opt("SA_SPAN_MULTI")
     unset_opt("SA_SPAN_DOC_MULTI")
     pairs = [[int(a), int(b)] for a, b in rng.choice(min(vocab, 40), (24, 2)) if a != b] + [[0, 1], [1, 0], [2, 0]]
-    pb = dev.phrase_batch(pairs, k=k, slop=2)
-    for _ in range(2):
-        pb.run()
-    ps, pd_ = pb.fetch()
+    # ... with two or four of a block's waves holding span tables (SA_SPAN_TAB_WAVES; unset: by the size of the launch -- two when it
+    # fills the device: six resident blocks per CU instead of four), then the mixed batch again on the two-wave instances of 2 - 4 terms
+    for tw in (None, "2", "4"):
+        if tw is None:
+            unset_opt("SA_SPAN_TAB_WAVES")
+        else:
+            set_opt("SA_SPAN_TAB_WAVES", tw)
+        pb = dev.phrase_batch(pairs, k=k, slop=2)
+        for _ in range(2):
+            pb.run()
+        ps, pd_ = pb.fetch()
+        pb.close()
+        for i, ph in enumerate(pairs):
+            ws, wd = O.topk(orc.score(list(ph), slop=2), k)
+            n = int((ws > 0).sum())
+            assert np.array_equal(ps[i, :n], ws[:n]) and np.array_equal(pd_[i, :n], wd[:n]), f"phrase {ph} slop 2 (pairs only, table waves {tw})"
+    set_opt("SA_SPAN_TAB_WAVES", "2")
+    pb = dev.phrase_batch(phrases, k=k, slop=slops)
+    pb.run()
+    got = pb.fetch()
     pb.close()
-    for i, ph in enumerate(pairs):
-        ws, wd = O.topk(orc.score(list(ph), slop=2), k)
-        n = int((ws > 0).sum())
-        assert np.array_equal(ps[i, :n], ws[:n]) and np.array_equal(pd_[i, :n], wd[:n]), f"phrase {ph} slop 2 (pairs only)"
+    assert np.array_equal(got[0], results["11"][0]) and np.array_equal(got[1], results["11"][1]), "mixed batch, two table waves per block"
+    unset_opt("SA_SPAN_TAB_WAVES")
     dev.close()
 
 
