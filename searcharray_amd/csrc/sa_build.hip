@@ -154,12 +154,12 @@ extern "C" int sa_index_create_from_tokens(int device, uint64_t n_docs, uint64_t
         hipLaunchKernelGGL(sa_k_scan_chunks, dim3(1), dim3(1024), 0, st, d_chunks, nchunks, d_cnt);
         SA_HIP_F(hipMemcpyAsync(&W, d_cnt, sizeof(u32), hipMemcpyDeviceToHost, st));
         SA_HIP_F(hipStreamSynchronize(st));
-        SA_HIP_F(hipMalloc(&ix->d_words, ((size_t)W + 1) * sizeof(u64)));
+        SA_HIP_F(hipMalloc(&ix->d_words, ((size_t)W + SA_WORDS_PAD) * sizeof(u64)));
         SA_HIP_F(hipMalloc(&d_wterm, ((size_t)W + 1) * sizeof(u32)));
         h.words = ix->d_words; h.wterm = d_wterm;
         hipLaunchKernelGGL((sa_k_compact_emit<TokenWordHeads>), dim3(cgrid), dim3(SA_CT), 0, st, h, (const u32*)nullptr, n, d_chunks);
     } else {
-        SA_HIP_F(hipMalloc(&ix->d_words, sizeof(u64)));
+        SA_HIP_F(hipMalloc(&ix->d_words, SA_WORDS_PAD * sizeof(u64)));
         SA_HIP_F(hipMalloc(&d_wterm, sizeof(u32)));
     }
     ix->n_words = W;

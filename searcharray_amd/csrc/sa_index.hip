@@ -453,7 +453,7 @@ static int sa_index_build(sa_index* ix, const u64* words, const u64* term_off, c
     const u64 W = ix->n_words;
     SA_TRY(sa_index_setup(ix, doc_lens));
     hipStream_t st = ix->stream;
-    SA_HIP(hipMalloc(&ix->d_words, (W ? W : 1) * sizeof(u64)));
+    SA_HIP(hipMalloc(&ix->d_words, (W + SA_WORDS_PAD) * sizeof(u64)));
     SA_HIP(hipMalloc(&ix->d_term_off, ((size_t)V + 1) * sizeof(u64)));
     SA_HIP(hipMemcpyAsync(ix->d_words, words, W * sizeof(u64), hipMemcpyHostToDevice, st));
     SA_HIP(hipMemcpyAsync(ix->d_term_off, term_off, ((size_t)V + 1) * sizeof(u64), hipMemcpyHostToDevice, st));

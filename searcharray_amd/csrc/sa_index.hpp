@@ -31,6 +31,10 @@ struct sa_comm;   // RCCL communicator wrapper (sa_comm.hip)
 // 1.33 / 1.44 ms per 256-query launch at 10 M docs, k = 1000: 1.83 / 1.93 / 2.25 ms), on a par for dynamic pruning.
 #define SA_DEFAULT_TILE_DOCS 2048u
 #define SA_DD_ABSENT 0xFFFFFFFFu
+// words allocated behind the index's roaringish words (never written, never part of a list): kernels that fetch a document's words
+// with wide loads may read up to this many words past the end of a term's list -- of the last term's too
+#define SA_WORDS_PAD 8
+struct sa_w2 { u64 x, y; };                     // (two words fetched by one 16-byte load from an 8-byte-aligned address)
 #define SA_DD_NONE 0xFFFFFFFFu
 
 // Impact stream of one (k1, b, avgdl) instantiation of BM25 (sa_bm25.hip, sa_k_make_impacts): the TF

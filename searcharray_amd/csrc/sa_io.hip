@@ -349,7 +349,7 @@ extern "C" int sa_index_create_from_file(int device, uint64_t n_docs, uint64_t d
     ix->h_term_off = term_off;
     auto build = [&]() -> int {
         SA_TRY(sa_index_setup(ix, doc_lens));
-        SA_HIP(hipMalloc(&ix->d_words, (W ? W : 1) * sizeof(u64)));
+        SA_HIP(hipMalloc(&ix->d_words, (W + SA_WORDS_PAD) * sizeof(u64)));
         SA_HIP(hipMalloc(&ix->d_term_off, ((size_t)n_terms + 1) * sizeof(u64)));
         SA_HIP(hipMemcpyAsync(ix->d_term_off, ix->h_term_off.data(), ((size_t)n_terms + 1) * sizeof(u64),
                               hipMemcpyHostToDevice, ix->stream));

@@ -1691,28 +1691,43 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
             docs_[r] = slot_doc(local, &valid_[r]);
             s_doc[local] = (u32)docs_[r];
         }
+        // (the anchor term's cell is not read: a document that the (lo + local)-th word of the anchor's list opens has that word as its
+        //  first -- every lane reads cell 0 of that row instead, one line for the wave where the cells of 64 scattered documents are 64)
         u32 dcell[2][2];
 #pragma unroll
         for (int r = 0; r < 2; r++)
 #pragma unroll
-            for (int t = 0; t < 2; t++) dcell[r][t] = p.st.dd[t][valid_[r] ? docs_[r] : 0ull];
+            for (int t = 0; t < 2; t++) dcell[r][t] = p.st.dd[t][(valid_[r] && p.anchor != t) ? docs_[r] : 0ull];
 #pragma unroll
         for (int r = 0; r < 2; r++) {
+            const u32 own = (u32)(lo + (u32)r * SA_SPAN_FT + threadIdx.x);
+#pragma unroll
+            for (int t = 0; t < 2; t++) dcell[r][t] = p.anchor == t ? own : dcell[r][t];
             j0_[r][0] = valid_[r] ? dcell[r][0] : SA_DD_ABSENT;
             j0_[r][1] = j0_[r][0] != SA_DD_ABSENT ? dcell[r][1] : SA_DD_ABSENT;
         }
+        // The document's words, SA_SPAN_DW + 1 of them per term, as 16 + 16 + 8 bytes: a load instruction of 64 scattered lanes costs the
+        // L1 a tag lookup per lane whatever its width, and this phase is what a block waits for.  The loads run up to four words past
+        // the term's list -- into the next term's, or into the padding behind the index's words (SA_WORDS_PAD) -- and what lies past
+        // the list is discarded.
+        static_assert(SA_SPAN_DW == 4 && SA_WORDS_PAD >= SA_SPAN_DW, "five words per term and document: two 16-byte loads and one of 8");
         u64 WW[2][2][SA_SPAN_DW], XX[2][2];
 #pragma unroll
         for (int r = 0; r < 2; r++)
 #pragma unroll
             for (int t = 0; t < 2; t++) {
                 const u32 last = p.st.len[t] - 1u;
+                const bool there = j0_[r][t] != SA_DD_ABSENT;
+                const u64* const wp = p.st.words[t] + (there ? j0_[r][t] : 0u);
+                sa_w2 a, b;
+                __builtin_memcpy(&a, wp, 16);
+                __builtin_memcpy(&b, wp + 2, 16);
+                const u64 c = wp[4];
+                const u64 L[SA_SPAN_DW + 1] = {a.x, a.y, b.x, b.y, c};
 #pragma unroll
                 for (int q = 0; q <= SA_SPAN_DW; q++) {
-                    const u32 idx = j0_[r][t] + (u32)q;                      // (ABSENT + q wraps or stays huge: clamped, discarded below)
-                    const bool in = j0_[r][t] != SA_DD_ABSENT && idx <= last;
-                    const u64 w = p.st.words[t][in ? idx : last];
-                    if (q < SA_SPAN_DW) WW[r][t][q < SA_SPAN_DW ? q : 0] = in ? w : ~0ull; else XX[r][t] = in ? w : ~0ull;
+                    const bool in = there && j0_[r][t] + (u32)q <= last;      // (j0 <= last: no wrap)
+                    if (q < SA_SPAN_DW) WW[r][t][q < SA_SPAN_DW ? q : 0] = in ? L[q] : ~0ull; else XX[r][t] = in ? L[q] : ~0ull;
                 }
             }
 #pragma unroll
