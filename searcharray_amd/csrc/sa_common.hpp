@@ -59,6 +59,13 @@ static inline u32 sa_div_up(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 
 // ---- device helpers ----
 __device__ __forceinline__ int sa_lane() { return threadIdx.x & (SA_WAVE - 1); }
+// A pointer a kernel has READ from memory (a field of a job struct) is a flat pointer to the compiler: its loads are flat_load, which
+// count against the LDS counter as well as the vector-memory one -- every wait for an LDS read then waits for the loads in flight.
+// sa_glob says "this is global memory": the loads through the pointer it returns are global_load.
+#ifndef SA_AS_GLOBAL
+#define SA_AS_GLOBAL __attribute__((address_space(1)))
+#endif
+template <typename T> __device__ __forceinline__ T SA_AS_GLOBAL* sa_glob(T* p) { return (T SA_AS_GLOBAL*)p; }
 __device__ __forceinline__ int sa_wave_id() { return threadIdx.x / SA_WAVE; }
 
 __device__ __forceinline__ u32 sa_wave_sum(u32 v) {

@@ -1643,7 +1643,7 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
         u64 doc = lo + local;
         bool valid = doc < p.st.n_docs;
         if (p.anchor >= 0) {
-            const u64* const aw = p.st.words[p.anchor];
+            const auto aw = sa_glob(p.st.words[p.anchor]);
             valid = doc < p.st.len[p.anchor];
             if (valid) {
                 const u64 i = doc;
@@ -1697,7 +1697,7 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
 #pragma unroll
         for (int r = 0; r < 2; r++)
 #pragma unroll
-            for (int t = 0; t < 2; t++) dcell[r][t] = p.st.dd[t][(valid_[r] && p.anchor != t) ? docs_[r] : 0ull];
+            for (int t = 0; t < 2; t++) dcell[r][t] = sa_glob(p.st.dd[t])[(valid_[r] && p.anchor != t) ? docs_[r] : 0ull];
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             const u32 own = (u32)(lo + (u32)r * SA_SPAN_FT + threadIdx.x);
@@ -1718,10 +1718,10 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
             for (int t = 0; t < 2; t++) {
                 const u32 last = p.st.len[t] - 1u;
                 const bool there = j0_[r][t] != SA_DD_ABSENT;
-                const u64* const wp = p.st.words[t] + (there ? j0_[r][t] : 0u);
+                const auto wp = sa_glob(p.st.words[t]) + (there ? j0_[r][t] : 0u);
                 sa_w2 a, b;
-                __builtin_memcpy(&a, wp, 16);
-                __builtin_memcpy(&b, wp + 2, 16);
+                __builtin_memcpy(&a, (const void*)wp, 16);
+                __builtin_memcpy(&b, (const void*)(wp + 2), 16);
                 const u64 c = wp[4];
                 const u64 L[SA_SPAN_DW + 1] = {a.x, a.y, b.x, b.y, c};
 #pragma unroll
@@ -1842,7 +1842,7 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
         const float one_minus_b = 1.0f - p.rank.b;
         u32 slot_val = 0xFFFFFFFFu;
         if ((threadIdx.x & 63u) < 32u)
-            slot_val = __hip_atomic_load(&p.rank.slots[p.row * 32u + (threadIdx.x & 31u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            slot_val = __hip_atomic_load(&sa_glob(p.rank.slots)[p.row * 32u + (threadIdx.x & 31u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         float* const acc = (float*)s_pbase;
         for (int r = 0; r < ROUNDS; r++) {
             const u32 local = (u32)r * SA_SPAN_FT + threadIdx.x;
@@ -1850,7 +1850,7 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
             float sc = 0.f;
             if (c != 0u) {
                 const float t = (float)c;
-                const float norm = __fmul_rn(p.rank.k1, __fadd_rn(one_minus_b, __fmul_rn(p.rank.b, __fdiv_rn(p.rank.doc_lens[s_doc[local]], p.rank.avgdl))));
+                const float norm = __fmul_rn(p.rank.k1, __fadd_rn(one_minus_b, __fmul_rn(p.rank.b, __fdiv_rn(sa_glob(p.rank.doc_lens)[s_doc[local]], p.rank.avgdl))));
                 sc = __fmul_rn(__fdiv_rn(t, __fadd_rn(t, norm)), p.idf);
             }
             acc[local] = sc;                                             // (each thread rewrites its own two slots)

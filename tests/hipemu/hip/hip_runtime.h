@@ -27,6 +27,7 @@
 #include <vector>
 
 #define __global__
+#define SA_AS_GLOBAL                                 // (address spaces are the device compiler's business)
 #define __device__
 #define __host__
 #define __forceinline__ inline
