@@ -113,6 +113,7 @@ typedef struct sa_options {
     int64_t span_multi;      /* 0: no multi-phrase launch of the general route */
     int64_t span_sort;       /* 1 / 0: force / forbid sorting the docs by work */
     int64_t span_lds_pad;    /* MEASUREMENT HOOK: unused dynamic LDS per block of the doc-parallel batch launch (fewer resident blocks per CU) */
+    int64_t span_bundle;     /* doc-parallel batch launch: phrases whose blocks take turns in the launch (default 32; 1: a phrase's blocks back to back) */
     int64_t span_tab_waves;  /* doc-parallel batch launch: waves of a block that hold span tables, 2 / 4 (unset: 2 when the launch has more blocks than four per CU, else 4) */
     int64_t span_threads;    /* TEST HOOK: grid cap (forces the stride loop) */
     int64_t io_piece_bytes;  /* bytes per staged piece */

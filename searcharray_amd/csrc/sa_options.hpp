@@ -71,6 +71,7 @@
     X(span_multi)      /* 0: no multi-phrase launch of the general route */                                                        \
     X(span_sort)       /* 1 / 0: force / forbid sorting the docs by work */                                                        \
     X(span_lds_pad)    /* MEASUREMENT HOOK: unused dynamic LDS per block of the doc-parallel batch launch (fewer resident blocks per CU) */   \
+    X(span_bundle)     /* doc-parallel batch launch: phrases whose blocks take turns in the launch (default 32; 1: a phrase's blocks back to back) */   \
     X(span_tab_waves)  /* doc-parallel batch launch: waves of a block that hold span tables, 2 / 4 (unset: 2 when the launch has more blocks than four per CU, else 4) */   \
     X(span_threads)    /* TEST HOOK: grid cap (forces the stride loop) */                                                          \
     /* ---- index files (sa_io.hip) */                                                                                             \

@@ -1069,7 +1069,7 @@ struct SpanDocParams {
     // cleared; [doc >> touch_shift] of `touched` = 1 wherever a count is written (the ranking launch reads those tiles only)
     unsigned char* touched;
     u32 touch_shift;
-    u32 block0, n_blocks;                // the phrase's blocks in the shared launch: [block0, block0 + n_blocks)
+    u32 block0, n_blocks;                // the phrase's blocks (block0: where they would start in a phrase-after-phrase launch; the shared launch goes by SpanSlot)
     // ... or no result vector at all (rank.cand != null): the block turns its documents' counts into BM25 scores and ranks them
     // itself -- the batch's pruned top-k selection over the block's 512 documents -- so only candidates above the phrase's
     // bound leave the kernel
@@ -1086,9 +1086,9 @@ __device__ __forceinline__ void sa_span_doc_put(const SpanDocParams& p, u64 doc,
 // index of the document's first word in term t's list -- through the term's doc directory row, or, for a term without
 // one, by a search on the 28-bit key -- or SA_DD_ABSENT
 __device__ __forceinline__ u32 sa_span_first(const SpanTerms& st, const int t, const u64 doc) {
-    if (st.dd[t]) return st.dd[t][doc];
+    if (st.dd[t]) return sa_glob(st.dd[t])[doc];
     const u32 j = sa_lower_bound(st.words[t], 0, st.len[t], doc << SA_KEY_SHIFT, SA_KEY_MASK);
-    return (j < st.len[t] && (st.words[t][j] >> SA_KEY_SHIFT) == doc) ? j : SA_DD_ABSENT;
+    return (j < st.len[t] && (sa_glob(st.words[t])[j] >> SA_KEY_SHIFT) == doc) ? j : SA_DD_ABSENT;
 }
 
 // sa_header_triple_dd with the document's first word found as above (no word of these lists sits in a last block)
@@ -1155,10 +1155,10 @@ __device__ __forceinline__ void sa_span_doc_words_load(const SpanTerms& st, cons
 #pragma unroll
         for (int q = 0; q < SA_SPAN_DW; q++) {
             const u32 idx = j0[t] + (u32)q;
-            W[t][q] = idx < st.len[t] ? st.words[t][idx] : ~0ull;
+            W[t][q] = idx < st.len[t] ? sa_glob(st.words[t])[idx] : ~0ull;
         }
         const u32 idx = j0[t] + (u32)SA_SPAN_DW;
-        X[t] = idx < st.len[t] ? st.words[t][idx] : ~0ull;
+        X[t] = idx < st.len[t] ? sa_glob(st.words[t])[idx] : ~0ull;
     }
 }
 template <int TT>
@@ -1741,7 +1741,11 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
             const u64 (&Xr)[TT] = reinterpret_cast<const u64 (&)[TT]>(XX[r]);
             u32 (&cr)[TT] = reinterpret_cast<u32 (&)[TT]>(c);
             u32 (&kr)[TT] = reinterpret_cast<u32 (&)[TT]>(keep);
+#ifdef SA_EXP_NOEVAL
+            const bool have_words = all && (Wr[0][0] ^ Wr[1][0] ^ Xr[0] ^ Xr[1] ^ Wr[0][3] ^ Wr[1][3]) == 0x1234567ull;
+#else
             const bool have_words = all && sa_span_doc_words_eval<TT>(docs_[r], Wr, Xr, cr, kr, &many, &first_blk);
+#endif
             const u32 bin = slot_bin(local, docs_[r], have_words, Wr, kr, many, first_blk);
             if (bin) atomicAdd(&s_h[bin], 1u);
             if (staged && (bin == 0u || bin == HEAVY)) s_pbase[local] = 0u;      // (no machine in the chunks: nothing counted so far; a slot without a document never counts)
@@ -1770,6 +1774,9 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
     }
     SA_SPP(0);                                                  // gather (this wave's share)
     __syncthreads();
+#ifdef SA_EXP_GATHER_ONLY                                        // (SA_EXP_*: timing experiments of scripts/gpu_r6_slop_exp.sh -- a phase removed, results wrong; never in the product build)
+    return;
+#endif
     SA_SPP(1);                                                  // ... and the wait for the block's other waves
     // ---- order: s_first[b] = documents with more than b positions (lane x of wave 0: bin PMAX - x)
     if (wave == 0) {
@@ -1807,6 +1814,9 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
         u64* const tab = s_tab + (size_t)(wave < (u32)NTAB ? wave : 0u) * TABW;
         constexpr int R = SA_SPAN_FROWS;
         // 8 lanes: 32 positions x 8 x 4 B = 1 KiB behind (TABW - 128) / 8 rows; 16 lanes: 16 x 16 x 4 B = 1 KiB behind (TABW - 128) / 16 rows
+#ifdef SA_EXP_NOMACH
+        if (false)
+#endif
         for (; wave < (u32)NTAB; ) {
             u32 ck = 0;
             if (lane == 0) ck = atomicAdd(&s_next, 1u);
@@ -1835,6 +1845,9 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
         for (u32 i = wave; i < nh; i += (u32)HW)
             sa_span_wave_doc<TT>(p, s_doc[s_order[i]], (SpanEnt*)s_tab + (size_t)wave * SA_NSPANS, lane, staged ? &s_pbase[s_order[i]] : nullptr);
     SA_SPP(5);                                                  // heavy documents
+#ifdef SA_EXP_NORANK
+    if (ranked) return;
+#endif
     if (ranked) {
         // counts -> BM25 (the reference's operation order, similarity.py:24-38 / bm25.pyx:19-23, as sa_k_dense_topk_tiles forms it)
         // in place, then the pruned selection of the phrase batches over the block's documents (s_doc: their ids)
@@ -1884,26 +1897,25 @@ __global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused(const SpanDocP
     sa_span_doc_fused_body<TT, SA_SPAN_NTAB>(p, blockIdx.x);
 }
 
-// B phrases in ONE launch: the blocks of all phrases back to back, block b belongs to the phrase j with
-// jobs[j].block0 <= b < jobs[j].block0 + jobs[j].n_blocks (found by bisection: the jobs are sorted by block0)
+struct SpanSlot { u32 job, round; };   // eight blocks of a shared launch: job (index in the launch's job array), its round
+// B phrases in ONE launch.  Block b of the launch: XCD x = b % 8 (the hardware deals consecutive blocks round-robin to the XCDs),
+// slot s = b / 8; work[s] = {job, r} says whose block it is -- the r-th block of the x-th EIGHTH of that job's blocks (of its
+// documents: a job's blocks are in doc order).  So XCD x walks the x-th eighth of every job of the launch: the doc directory rows
+// and words of a frequent term that several phrases share stay in ONE L2 per doc range and are found there by the next phrase
+// (round 4 dealt a job's blocks round-robin: every XCD saw every eighth block of every phrase, no line was ever found again --
+// 3.08 x the algorithmic bytes at an L2 hit rate of 14 %).  The host writes the slots so that the jobs of a BUNDLE (neighbours
+// in the launch's order: phrases over the same frequent term) take turns, round after round: only a few blocks of a phrase are
+// resident at a time, and the ones that follow find the phrase's ranking bounds (SpanRankCtx::slots) already raised -- with a
+// phrase's blocks back to back all of them ranked against empty bounds, every wave of a heavy phrase took the exact top-k path.
 template <int TT, int NTAB>
-__global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused_multi(const SpanDocParams* __restrict__ jobs, u32 n_jobs) {
-    u32 lo = 0, hi = n_jobs;
-    while (hi - lo > 1u) {
-        const u32 mid = lo + ((hi - lo) >> 1);
-        if (jobs[mid].block0 <= blockIdx.x) lo = mid; else hi = mid;
-    }
+__global__ void __launch_bounds__(SA_SPAN_FT) sa_k_span_doc_fused_multi(const SpanDocParams* __restrict__ jobs, const SpanSlot* __restrict__ work) {
+    const SpanSlot w = work[blockIdx.x >> 3];
     // (a reference, not a copy: a private copy of the job lives in scratch -- its term arrays are indexed at run time -- and
     // every access of it is HBM traffic; through the pointer the fields are scalar loads at a wave-uniform address)
-    const SpanDocParams& p = jobs[lo];
-    // XCD x (= blockIdx % 8: every job's block0 is a multiple of 8) walks the x-th EIGHTH of the job's blocks -- of its documents:
-    // the blocks are in doc order -- and so does it for every job of the launch: the doc directory rows and words of a frequent
-    // term that several phrases of the batch share stay in ONE L2 per doc range and are found there by the next phrase (the
-    // host orders the jobs by their longest list).  Round 4 dealt a job's blocks round-robin: every XCD saw every eighth block
-    // of every phrase, no line was ever found again -- 3.08 x the algorithmic bytes at an L2 hit rate of 14 %.
-    const u32 bl = blockIdx.x - p.block0, per = (p.n_blocks + 7u) >> 3;
-    const u32 wb = (bl & 7u) * per + (bl >> 3);
-    if ((bl >> 3) >= per || wb >= p.n_blocks) return;
+    const SpanDocParams& p = jobs[w.job];
+    const u32 per = (p.n_blocks + 7u) >> 3;
+    const u32 wb = (blockIdx.x & 7u) * per + w.round;
+    if (wb >= p.n_blocks) return;
     sa_span_doc_fused_body<TT, NTAB>(p, wb);
 }
 
@@ -2343,7 +2355,11 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
     // (the ranking jobs -- counts, idf, batch row of every phrase taken -- ride behind the span jobs in the same upload)
     const size_t span_jobs_bytes = ((size_t)nj * sizeof(SpanJob) + 255) & ~(size_t)255;
     const size_t rank_jobs_bytes = ((size_t)nv * sizeof(sa_dense_rank_job) + 255) & ~(size_t)255;
-    const size_t jobs_bytes = span_jobs_bytes + rank_jobs_bytes + (((size_t)nd * sizeof(SpanDocParams) + 255) & ~(size_t)255);
+    // (... and behind the doc-parallel phrases' parameter blocks the slots of their launches: {job, round} per eight blocks)
+    const size_t doc_jobs_bytes = ((size_t)nd * sizeof(SpanDocParams) + 255) & ~(size_t)255;
+    size_t n_slots = 0;
+    for (int c = 0; c < 3; c++) for (const SpanDocParams& P : djobs[c]) n_slots += (P.n_blocks + 7u) >> 3;
+    const size_t jobs_bytes = span_jobs_bytes + rank_jobs_bytes + doc_jobs_bytes + ((n_slots * sizeof(SpanSlot) + 255) & ~(size_t)255);
     const size_t need = jobs_bytes + used + 4096;
     if (ix->span_batch_bytes < need) {
         SA_HIP(hipStreamSynchronize(st));
@@ -2415,9 +2431,14 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
     SpanDocParams* hd = (SpanDocParams*)((char*)ix->h_span_jobs + span_jobs_bytes + rank_jobs_bytes);
     const SpanDocParams* dd_dev = (const SpanDocParams*)((char*)ix->d_span_batch + span_jobs_bytes + rank_jobs_bytes);
     u32 dfirst[4] = {0, 0, 0, 0}, dblocks[3] = {0, 0, 0};
+    SpanSlot* const hw = (SpanSlot*)((char*)ix->h_span_jobs + span_jobs_bytes + rank_jobs_bytes + doc_jobs_bytes);
+    const SpanSlot* const dw_dev = (const SpanSlot*)((char*)ix->d_span_batch + span_jobs_bytes + rank_jobs_bytes + doc_jobs_bytes);
+    u32 wfirst[3] = {0, 0, 0};
+    // jobs of a bundle take turns in the launch's slots (option span_bundle; 1: a phrase's blocks back to back)
+    const u32 bundle = (u32)std::min<long long>(4096, std::max<long long>(1, sa_opt(ix->opts.span_bundle, 32)));
     {
         int q = nj;
-        u32 k = 0;
+        u32 k = 0, wk = 0;
         for (int c = 0; c < 3; c++) {
             dfirst[c] = k;
             u32 b0 = 0;
@@ -2434,6 +2455,15 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
                 const auto ka = longest(djobs[c][a]), kb = longest(djobs[c][b]);
                 return ka.first != kb.first ? ka.first > kb.first : ka.second < kb.second;
             });
+            wfirst[c] = wk;
+            for (size_t j0 = 0; j0 < ord.size(); j0 += bundle) {
+                const size_t j1 = std::min(ord.size(), j0 + (size_t)bundle);
+                u32 rounds = 0;
+                for (size_t jj = j0; jj < j1; jj++) rounds = std::max(rounds, (djobs[c][ord[jj]].n_blocks + 7u) >> 3);
+                for (u32 r = 0; r < rounds; r++)
+                    for (size_t jj = j0; jj < j1; jj++)
+                        if (r < ((djobs[c][ord[jj]].n_blocks + 7u) >> 3)) { hw[wk].job = (u32)(jj); hw[wk].round = r; wk++; }
+            }
             for (size_t jj = 0; jj < ord.size(); jj++, q++, k++) {
                 const size_t j = ord[jj];
                 SpanDocParams P = djobs[c][j];
@@ -2490,6 +2520,7 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
         const u32 cnt = dfirst[c + 1] - dfirst[c];
         if (cnt == 0 || dblocks[c] == 0) continue;
         const SpanDocParams* jc = dd_dev + dfirst[c];
+        const SpanSlot* const wc = dw_dev + wfirst[c];
         // (span_lds_pad: MEASUREMENT HOOK -- unused dynamic LDS per block lowers the resident blocks per CU: the occupancy experiment of DESIGN 3.4)
         const u32 pad = (u32)std::min<long long>(120000, std::max<long long>(0, sa_opt(ix->opts.span_lds_pad, 0)));
         // Waves of a block with span tables.  A launch that fills the device is bound by how many blocks a CU holds -- a block's gather
@@ -2500,14 +2531,14 @@ int sa_span_counts_batch(sa_index* ix, hipStream_t st, int n, const u32* const* 
         const bool few = tw < SA_SPAN_NTAB;
         if (sa_opt(ix->opts.trace, 0)) fprintf(stderr, "sa_span_counts_batch: doc-parallel launch of %u phrases, %u blocks, %d table waves per block\n", cnt, dblocks[c], few ? SA_SPAN_NTAB_BATCH : SA_SPAN_NTAB);
         if (c == 0) {
-            if (few) hipLaunchKernelGGL((sa_k_span_doc_fused_multi<2, SA_SPAN_NTAB_BATCH>), dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, cnt);
-            else hipLaunchKernelGGL((sa_k_span_doc_fused_multi<2, SA_SPAN_NTAB>), dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, cnt);
+            if (few) hipLaunchKernelGGL((sa_k_span_doc_fused_multi<2, SA_SPAN_NTAB_BATCH>), dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, wc);
+            else hipLaunchKernelGGL((sa_k_span_doc_fused_multi<2, SA_SPAN_NTAB>), dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, wc);
         } else if (c == 1) {
-            if (few) hipLaunchKernelGGL((sa_k_span_doc_fused_multi<3, SA_SPAN_NTAB_BATCH>), dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, cnt);
-            else hipLaunchKernelGGL((sa_k_span_doc_fused_multi<3, SA_SPAN_NTAB>), dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, cnt);
+            if (few) hipLaunchKernelGGL((sa_k_span_doc_fused_multi<3, SA_SPAN_NTAB_BATCH>), dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, wc);
+            else hipLaunchKernelGGL((sa_k_span_doc_fused_multi<3, SA_SPAN_NTAB>), dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, wc);
         } else {
-            if (few) hipLaunchKernelGGL((sa_k_span_doc_fused_multi<4, SA_SPAN_NTAB_BATCH>), dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, cnt);
-            else hipLaunchKernelGGL((sa_k_span_doc_fused_multi<4, SA_SPAN_NTAB>), dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, cnt);
+            if (few) hipLaunchKernelGGL((sa_k_span_doc_fused_multi<4, SA_SPAN_NTAB_BATCH>), dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, wc);
+            else hipLaunchKernelGGL((sa_k_span_doc_fused_multi<4, SA_SPAN_NTAB>), dim3(dblocks[c]), dim3(SA_SPAN_FT), pad, st, jc, wc);
         }
     }
     SA_HIP(hipGetLastError());
