@@ -49,6 +49,9 @@
 #define SA_ST_UMAX 1024         // distinct terms of a query set
 #define SA_ST_BMAX 256          // queries of a query set
 #define SA_ST_BW 32             // words of such a bitmap (tiles of at most 1024 docs)
+#ifndef SA_ST_REFRESH_MASK
+#define SA_ST_REFRESH_MASK 31    // a query's bound is re-derived from its histogram whenever its candidate list crosses a multiple of this + 1
+#endif
 #define SA_ST_REF 64            // queries whose bound is re-derived at the end of a tile pass
 #define SA_ST_NONE 0xFFFFu      // "no term" in the queries' term tables
 #define SA_ST_PROBE 0xFFFFu     // s_off: the term is not staged; its factors are probed in its probe row (high half: the row)
@@ -777,7 +780,7 @@ __global__ void __launch_bounds__(SA_ST_NT, 4) sa_k_bm25_stage(const StageParams
                 const u32 pos = atomicAdd(&sp.cand_cnt[fq], 1u);
                 if (pos < sp.cand_cap) sp.cand[(u64)fq * sp.cand_cap + pos] = ((u64)sb << 32) | (u64)(u32)(~(u32)doc);
                 atomicAdd(&sp.hist[(u64)fq * SA_HBINS + sa_score_bin(sb)], 1u);
-                if (((pos + 1u) & 31u) == 0u) { const u32 sl = atomicAdd(&s_nref, 1u); if (sl < (u32)SA_ST_REF) s_ref[sl] = fq; }
+                if (((pos + 1u) & (u32)SA_ST_REFRESH_MASK) == 0u) { const u32 sl = atomicAdd(&s_nref, 1u); if (sl < (u32)SA_ST_REF) s_ref[sl] = fq; }
             }
         }
         SA_SPT(21);
