@@ -32,13 +32,13 @@ def main():
     helpers._scope = _options.Scope()                     # (what tests/conftest.py's fixture gives a test: the scope set_opt writes into)
     fails = 0
     for seed in range(100, 100 + args.seeds):
-        for fn in (test_fuzz.test_random_bm25_batches_pruned_and_exhaustive, test_fuzz.test_random_phrases_batches_and_slop):
+        for fn in (test_fuzz.test_random_bm25_batches_pruned_and_exhaustive, test_fuzz.test_random_phrases_batches_and_slop, test_fuzz.test_random_slop_batches):
             try:
                 fn(api, seed, _Env())
             except AssertionError as e:
                 fails += 1
                 print("FAIL", fn.__name__, seed, str(e)[:200], flush=True)
-    print(f"fuzz done: {2 * args.seeds} runs, {fails} failures")
+    print(f"fuzz done: {3 * args.seeds} runs, {fails} failures")
 
 
 if __name__ == "__main__":

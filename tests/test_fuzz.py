@@ -111,3 +111,40 @@ def test_random_phrases_batches_and_slop(api, seed, monkeypatch):
                 slop = int(rng.integers(1, 4))
                 assert np.array_equal(dev.phrase_freqs_dense(ph, slop=slop), orc.phrase_freqs(ph, slop=slop))
         dev.close()
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_random_slop_batches(api, seed, monkeypatch):
+    """Batches of slop phrases of 2 - 4 terms (the doc-parallel batch launch, csrc/sa_spans.hip sa_k_span_doc_fused_multi: ranked inside
+    the kernel) with random launch shapes -- phrases per bundle, waves with span tables, one launch or one per phrase -- against the
+    oracle's score(): the slot list, both instances of the kernel, heavy documents, phrases without matches"""
+    from tests import emu
+    small = emu._api is api                                   # (the host stand-in runs a 256-thread block on fibers: smaller corpora, fewer phrases there)
+    rng = np.random.default_rng(seed)
+    for _ in range(1 if small else 3):
+        n_docs, vocab, mean = int(rng.integers(200, 1200 if small else 6000)), int(rng.integers(4, 40)), int(rng.integers(4, 20 if small else 50))
+        t, d, p, lens = synth.corpus_triples(n_docs, vocab, mean, seed=int(rng.integers(1 << 30)))
+        words, wt = rz.encode_sorted(t, d, p)
+        set_opt("SA_SPAN_BUNDLE", str(rng.choice([1, 2, 3, 32])))
+        tw = rng.choice([0, 2, 4])
+        if tw:
+            set_opt("SA_SPAN_TAB_WAVES", str(tw))
+        else:
+            unset_opt("SA_SPAN_TAB_WAVES")
+        set_opt("SA_SPAN_DOC_MULTI", str(rng.choice([1, 1, 1, 0])))
+        dev = DeviceIndex(words, rz.term_offsets(wt, vocab), lens, tile_docs=1024, api=api)
+        orc = O.OracleIndex.from_triples(t, d, p, n_docs, doc_lens=lens)
+        nb = int(rng.integers(1, 8 if small else 24))
+        phrases = [[int(x) for x in rng.choice(vocab, int(rng.integers(2, min(5, vocab))), replace=False)] for _ in range(nb)]
+        slops = [int(rng.integers(1, 4)) for _ in range(nb)]
+        k = int(rng.choice([1, 5, 40]))
+        bt = dev.phrase_batch(phrases, k=k, slop=slops)
+        for _ in range(2):
+            bt.run()
+        s, dd = bt.fetch()
+        bt.close()
+        for i, (ph, sl) in enumerate(zip(phrases, slops)):
+            ws, wd = O.topk(orc.score(list(ph), slop=sl), k)
+            n = int((ws > 0).sum())
+            assert np.array_equal(s[i, :n], ws[:n]) and np.array_equal(dd[i, :n], wd[:n]) and (dd[i, n:] == NO_DOC).all(), f"seed {seed}: {ph} slop {sl}"
+        dev.close()
