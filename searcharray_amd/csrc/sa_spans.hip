@@ -1678,6 +1678,7 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
         }
         return bin;
     };
+    bool compacted = false;                                     // (uniform: the ranked fast path moves its documents to the front of the slots)
     if (TT == 2 && ROUNDS == 2 && p.st.dd[0] && p.st.dd[1] && p.st.len[0] && p.st.len[1]) {       // (uniform)
         // Two terms with doc-directory rows (round 6): BOTH documents of a thread are in flight together and no load sits inside a
         // branch (the compiler waits for every load in flight where a branch that contains one joins): the directory cells of both
@@ -1705,6 +1706,46 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
             for (int t = 0; t < 2; t++) dcell[r][t] = p.anchor == t ? own : dcell[r][t];
             j0_[r][0] = valid_[r] ? dcell[r][0] : SA_DD_ABSENT;
             j0_[r][1] = j0_[r][0] != SA_DD_ABSENT ? dcell[r][1] : SA_DD_ABSENT;
+        }
+        compacted = ranked;
+        if (ranked) {                                               // (uniform)
+            // COMPACTION: only the documents that hold BOTH terms go on -- to the front of the block's slots, in slot order.  A slot
+            // that opens no document (anchor words of a document's second, third ... word) or whose document lacks the other term
+            // kept its lane idle through everything that follows (29 of 64 lanes active per VALU instruction, measured): after the
+            // compaction the waves behind the last document skip the candidate test and the position lists altogether.  (The
+            // slot <-> document mapping is free in the ranked batch: the block's results leave as (score, doc) candidates.  The
+            // unranked routes store whole lines of counts by slot = document and keep their slots.)
+            bool has[2];
+#pragma unroll
+            for (int r = 0; r < 2; r++) has[r] = j0_[r][1] != SA_DD_ABSENT;
+            const u64 b0 = __ballot(has[0]), b1 = __ballot(has[1]);
+            if (lane == 0) { s_first[wave] = (u32)__popcll(b0); s_first[(u32)NW + wave] = (u32)__popcll(b1); }
+            __syncthreads();
+            u32 base0 = 0, base1 = 0, n_all = 0;
+#pragma unroll
+            for (int i = 0; i < 2 * NW; i++) {
+                const u32 c = s_first[i];
+                base0 += (u32)i < wave ? c : 0u;
+                base1 += (u32)i < (u32)NW + wave ? c : 0u;
+                n_all += c;
+            }
+            const u64 ltm = (1ull << lane) - 1ull;
+            const u32 pos[2] = {base0 + (u32)__popcll(b0 & ltm), base1 + (u32)__popcll(b1 & ltm)};
+            u32* const tmp0 = (u32*)s_tab;                          // (the span tables are not in use before the machines)
+            u32* const tmp1 = tmp0 + SA_SPAN_FD;
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+                if (has[r]) { s_doc[pos[r]] = (u32)docs_[r]; tmp0[pos[r]] = j0_[r][0]; tmp1[pos[r]] = j0_[r][1]; }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const u32 local = (u32)r * SA_SPAN_FT + threadIdx.x;
+                const bool have = local < n_all;
+                if (!have) s_doc[local] = 0u;
+                docs_[r] = have ? (u64)s_doc[local] : 0ull;
+                j0_[r][0] = have ? tmp0[local] : SA_DD_ABSENT;
+                j0_[r][1] = have ? tmp1[local] : SA_DD_ABSENT;
+            }
         }
         // The document's words, SA_SPAN_DW + 1 of them per term, as 16 + 16 + 8 bytes: a load instruction of 64 scattered lanes costs the
         // L1 a tag lookup per lane whatever its width, and this phase is what a block waits for.  The loads run up to four words past
@@ -1870,7 +1911,7 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
         }
         __syncthreads();
         sa_tile_topk_pruned<SA_SPAN_FD, SA_SPAN_FT>(acc, slot_val, p.row, block, p.rank.doc_base, p.rank.k, p.rank.slots, p.rank.cand,
-                                                    p.rank.cand_cap, p.rank.cand_cnt, s_doc);
+                                                    p.rank.cand_cap, p.rank.cand_cnt, s_doc, compacted ? 8u : 0u);
     } else if (staged) {
         __syncthreads();
         bool any = false;

@@ -100,7 +100,7 @@ __device__ __forceinline__ void sa_block_bitonic_desc(u64* a, u32 n_pow2) {
 template <int TILE, int THREADS>
 __device__ __forceinline__ void sa_tile_topk_pruned(float* acc, u32 slot_val, u32 q, u32 tile, u64 doc0, u32 k,
                                                     u32* __restrict__ slots, u64* __restrict__ cand, u32 cand_cap,
-                                                    u32* __restrict__ cand_cnt, const u32* docs = nullptr) {
+                                                    u32* __restrict__ cand_cnt, const u32* docs = nullptr, const u32 wave_stride = 0u) {
     constexpr int NW = THREADS / SA_WAVE;
     constexpr int E = TILE / THREADS;
     const u32 tid = threadIdx.x;
@@ -116,7 +116,9 @@ __device__ __forceinline__ void sa_tile_topk_pruned(float* acc, u32 slot_val, u3
     const u32 thr = g > 1u ? g : 1u;
     if (wmax < thr) return;                                    // wave-uniform
 #define SA_ELEM(j) ((u32)(j) * THREADS + tid)
-    const u32 widx = tile * NW + wave;
+    // (the slot this (tile, wave) raises.  wave_stride: for tiles whose elements are COMPACTED to the front -- their first wave holds
+    //  most of them, the last ones often nothing -- the slots go by tile first, so that the first waves of consecutive tiles reach all 32)
+    const u32 widx = wave_stride ? tile + wave * wave_stride : tile * NW + wave;
     {
         // slot update: the rr-th largest lane maximum (lanes counted individually)
         const u32 my_slot = (u32)__shfl((int)slot_val, (int)(widx & 31u), SA_WAVE);
