@@ -135,6 +135,22 @@ __device__ __forceinline__ void sa_tile_topk_pruned(float* acc, u32 slot_val, u3
             if (lane == 0 && mr > my_slot) atomicMax(&slots[q * 32u + (widx & 31u)], mr);
         }
     }
+    if (wave_stride && k <= 32u) {
+        // A compacted tile's first wave also raises the slots of the tile's other waves -- mostly empty, they would leave their slots
+        // at 0 and the bound (the minimum over the slots) with them -- with its NEXT largest lane maxima: other lanes, other documents,
+        // so the slots stay backed by pairwise distinct documents (k <= 32: one document per slot).
+        u32 v = lmax;
+        { const u64 eq = __ballot(v == wmax); if (lane == (u32)__builtin_ctzll(eq)) v = 0u; }
+        for (u32 i = 1; i < (u32)NW; i++) {
+            const u32 m = sa_wave_max_u32(v);
+            if (m < thr) break;                                // (wave-uniform: every slot is at thr or above already)
+            const u32 si = (widx + i * wave_stride) & 31u;
+            const u32 cur = (u32)__shfl((int)slot_val, (int)si, SA_WAVE);
+            if (lane == 0 && m > cur) atomicMax(&slots[q * 32u + si], m);
+            const u64 eq = __ballot(v == m);
+            if (lane == (u32)__builtin_ctzll(eq)) v = 0u;
+        }
+    }
     u64* qcand = cand + (u64)q * cand_cap;
     const u64 lt = (1ull << lane) - 1ull;
     u32 c = 0;
