@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 6: the staged kernel's 1024-thread instance (one workgroup per CU, 2048-doc tiles: option stage_docs = 2048) against the default
-# (two 512-thread workgroups per CU, 1024-doc tiles), same box, same library
+# (two 512-thread workgroups per CU, 1024-doc tiles), same box, same library.  The instance was measured and NOT kept: this script
+# needs profiles/stage_kernel_1024_thread_instance_r06.patch applied to csrc/sa_stage.hip (without it stage_docs is clamped to 1024)
 set -x
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
