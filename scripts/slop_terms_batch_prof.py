@@ -14,6 +14,7 @@ import bench                                             # noqa: E402
 from searcharray_amd import _lib, options               # noqa: E402
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 api = _lib.api()
 side = bench.PhraseSide(api, 1_000_000, 100_000)
 rng = np.random.default_rng(9)
@@ -26,13 +27,13 @@ for i in range(256):
         if x not in ph:
             ph.append(x)
     phrases.append(ph)
-b = side.index.phrase_batch(phrases, k=10, slop=2)
+b = side.index.phrase_batch(phrases, k=K, slop=2)
 dt, kms = side.timed(b, 3, 20)
 got = b.fetch()
-out = {"terms": T, "ms_per_step": round(dt / 20 * 1e3, 4), "kernel_ms": round(kms, 4), "word_bytes": side.word_bytes(phrases)}
+out = {"terms": T, "k": K, "ms_per_step": round(dt / 20 * 1e3, 4), "kernel_ms": round(kms, 4), "word_bytes": side.word_bytes(phrases)}
 if os.environ.get("SA_CHECK", "1") != "0":
     with options.scoped(span_doc_multi=0):
-        b1 = side.index.phrase_batch(phrases[:48], k=10, slop=2)
+        b1 = side.index.phrase_batch(phrases[:48], k=K, slop=2)
         b1.run()
         want = b1.fetch()
         b1.close()

@@ -1707,8 +1707,8 @@ __device__ __forceinline__ void sa_span_doc_fused_body(const SpanDocParams& p, c
             j0_[r][0] = valid_[r] ? dcell[r][0] : SA_DD_ABSENT;
             j0_[r][1] = j0_[r][0] != SA_DD_ABSENT ? dcell[r][1] : SA_DD_ABSENT;
         }
-        compacted = ranked;
-        if (ranked) {                                               // (uniform)
+        compacted = ranked && p.rank.k <= 32u;                      // (k <= 32: a wave may raise several of the phrase's bound slots -- sa_tile_topk_pruned -- which a compacted block needs)
+        if (compacted) {                                            // (uniform)
             // COMPACTION: only the documents that hold BOTH terms go on -- to the front of the block's slots, in slot order.  A slot
             // that opens no document (anchor words of a document's second, third ... word) or whose document lacks the other term
             // kept its lane idle through everything that follows (29 of 64 lanes active per VALU instruction, measured): after the
